@@ -1,0 +1,192 @@
+"""Generate golden vectors by importing the REAL RigGS reference (CPU) — run in the
+build container only:   python tests/golden/make_golden.py
+
+Emits small .npz fixtures (inputs + expected outputs) next to this file.  The
+reference Python itself is never copied; fixtures are data.
+SURVEY.md §8-c G1..G4, G7..G9.
+"""
+import os
+import sys
+import math
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _ref_shim as S  # noqa: E402
+
+S.install()
+with S.quiet():
+    from skeleton_utils.skeleton_warp import SkeletonWarp  # noqa: E402
+    from skeleton_utils.network_utils import PoseMLP  # noqa: E402
+    from utils.time_utils import quaternion_to_matrix, matrix_to_quaternion  # noqa: E402
+    from utils.sh_utils import eval_sh  # noqa: E402
+    from utils.general_utils import build_scaling_rotation, strip_symmetric  # noqa: E402
+    from gaussian_renderer import render  # noqa: E402
+    from scene.gaussian_model import GaussianModel  # noqa: E402
+    from scene.cameras import Camera  # noqa: E402
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def random_tree(g, J, chain=False):
+    if chain:
+        parents = torch.arange(-1, J - 1)
+        joints = torch.stack([torch.zeros(J), -0.8 + 1.6 * torch.arange(J) / (J - 1), torch.zeros(J)], -1)
+        joints = joints + 0.01 * torch.randn(J, 3, generator=g)
+    else:
+        parents = torch.full((J,), -1, dtype=torch.long)
+        joints = torch.zeros(J, 3)
+        for i in range(1, J):
+            parents[i] = int(torch.randint(0, i, (1,), generator=g))
+            joints[i] = joints[parents[i]] + 0.25 * torch.randn(3, generator=g)
+        joints = joints / joints.norm(dim=1).max()
+    return joints, parents
+
+
+def make_warp(joints, parents, K):
+    with S.quiet():
+        sw = SkeletonWarp(is_blender=True, joints=joints, parent_indices=parents, K=K, is_scene_static=True,
+                          use_skinning_weight_mlp=False, use_template_offsets=False, hyper_dim=8)
+    return sw
+
+
+def fixture_deform(name, seed, J, N, K, chain=False, mask_random=False, degenerate=False):
+    g = torch.Generator().manual_seed(seed)
+    joints, parents = random_tree(g, J, chain)
+    if degenerate:
+        joints[J - 1] = joints[parents[J - 1]]  # zero-length bone
+    sw = make_warp(joints, parents, K)
+    rho = math.log(0.15) + 0.3 * torch.randn(J, generator=g)
+    sw._node_radius.data = rho.clone()
+    bone = torch.randint(1, J, (N,), generator=g)
+    t = torch.rand(N, 1, generator=g) * 1.4 - 0.2  # some beyond segment ends
+    a, b = joints[parents[bone]], joints[bone]
+    x = a + t * (b - a) + 0.06 * torch.randn(N, 3, generator=g)
+    x[0] = joints[1]  # a point exactly on a joint
+    q = torch.tensor([1.0, 0, 0, 0]) + 0.3 * torch.randn(J, 4, generator=g)  # NOT normalised
+    gt = 0.02 * torch.randn(3, generator=g)
+    mask = torch.sigmoid(torch.randn(N, 1, generator=g)) if mask_random else torch.ones(N, 1)
+    q.requires_grad_(True)
+    gt.requires_grad_(True)
+    mask.requires_grad_(True)
+    out = sw.deform_by_pose(x, {"local_rotation": q, "global_trans": gt}, mask)
+    # FK pieces (G1)
+    R = quaternion_to_matrix(q)
+    posed, G = sw.chain_product_transform(R, sw.nodes[:, :3])
+    node_rot = matrix_to_quaternion(G[:, :3, :3].detach())
+    # distances (G2)
+    w, d2, idx = sw.cal_nn_weight_skeleton(x=x, nodes=sw.nodes)
+    # backward (G4) with fixed cotangents
+    g_xyz = torch.randn(N, 3, generator=g)
+    g_rot = torch.randn(N, 4, generator=g)
+    g_nodes = torch.randn(J, 3, generator=g)
+    loss = (out["d_xyz"] * g_xyz).sum() + (out["d_rotation"] * g_rot).sum() + (out["d_nodes"] * g_nodes).sum()
+    loss.backward()
+    np.savez_compressed(
+        os.path.join(HERE, name + ".npz"),
+        joints=np_(joints), parents=np_(parents), node_radius_log=np_(rho), x=np_(x), local_rot=np_(q),
+        global_trans=np_(gt), motion_mask=np_(mask), K=np.int64(K),
+        R=np_(R), posed=np_(posed), transforms=np_(G), node_rot=np_(node_rot),
+        d2=np_(d2), nn_idx=np_(idx), nn_weight=np_(w),
+        d_xyz=np_(out["d_xyz"]), d_rotation=np_(out["d_rotation"]), d_scaling=np_(out["d_scaling"]),
+        d_nodes=np_(out["d_nodes"]),
+        g_xyz=np_(g_xyz), g_rot=np_(g_rot), g_nodes=np_(g_nodes),
+        grad_local_rot=np_(q.grad), grad_global_trans=np_(gt.grad), grad_node_radius=np_(sw._node_radius.grad),
+        grad_motion_mask=np_(mask.grad),
+    )
+    print("wrote", name, "J", J, "N", N, "K", K)
+
+
+def fixture_posemlp(name, seed, J):
+    torch.manual_seed(seed)
+    net = PoseMLP(1, J * 4, depth=8, hidden_dimensions=32, multires=8)  # small width fits a fixture
+    t = torch.tensor([0.37])
+    out = net(t)
+    sd = {k.replace(".", "__"): np_(v) for k, v in net.state_dict().items()}
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), t=np_(t), rotation=np_(out["rotation"]),
+                        translation=np_(out["translation"]), J=np.int64(J), **sd)
+    print("wrote", name)
+
+
+def fixture_glue(name, seed, N, isotropic, from_K):
+    """G7: render() glue — what render() hands to the rasterizer, and camera matrices."""
+    g = torch.Generator().manual_seed(seed)
+    gm = GaussianModel(3, fea_dim=8, with_motion_mask=False, use_isotropic_gs=isotropic)
+    P = torch.nn.Parameter
+    gm._xyz = P(torch.randn(N, 3, generator=g))
+    gm._features_dc = P(torch.randn(N, 1, 3, generator=g))
+    gm._features_rest = P(0.1 * torch.randn(N, 15, 3, generator=g))
+    gm._scaling = P(math.log(0.05) + 0.35 * torch.randn(N, 1 if isotropic else 3, generator=g))
+    gm._rotation = P(torch.randn(N, 4, generator=g))
+    gm._opacity = P(1.5 * torch.randn(N, 1, generator=g))
+    gm.active_sh_degree = 3
+    d_xyz = 0.05 * torch.randn(N, 3, generator=g)
+    d_rot = torch.tensor([1.0, 0, 0, 0]) + 0.1 * torch.randn(N, 4, generator=g)
+    d_scaling = torch.zeros(N, 3)
+    # camera: look-at origin from radius 4, elevation 20 deg, azimuth 45 deg
+    az, el, rad = math.radians(45.0), math.radians(20.0), 4.0
+    eye = np.array([rad * math.cos(el) * math.sin(az), -rad * math.sin(el), -rad * math.cos(el) * math.cos(az)])
+    fwd = -eye / np.linalg.norm(eye)
+    right = np.cross(np.array([0.0, -1.0, 0.0]), fwd)
+    right /= np.linalg.norm(right)
+    up = np.cross(fwd, right)
+    Rc2w = np.stack([right, up, fwd], axis=1)  # columns = camera axes in world
+    R = Rc2w  # reference stores R = c2w rotation (transposed inside getWorld2View2)
+    T = -Rc2w.T @ eye
+    H, W = 40, 56
+    fov = 0.6911112
+    K = None
+    if from_K:
+        fx = W / (2 * math.tan(fov / 2))
+        K = np.array([[fx, 0, W / 2 + 13.0 * W / 1024], [0, fx, H / 2 - 7.0 * H / 1024], [0, 0, 1]], dtype=np.float64)
+    cam = Camera(0, R, T, fov, fov * 0.8, torch.zeros(3, H, W), None, "c", 0, data_device="cpu", fid=0.37, K=K)
+
+    class Pipe:
+        convert_SHs_python = False
+        compute_cov3D_python = False
+        debug = False
+    bg = torch.zeros(3)
+    render(cam, gm, Pipe, bg, d_xyz, d_rot, d_scaling)
+    kw, st = S.CAPTURE["kwargs"], S.CAPTURE["settings"]
+    # G8: SH colour via the convert_SHs_python branch arithmetic (gaussian_renderer/__init__.py:107-112)
+    shs = kw["shs"]
+    means3D = kw["means3D"]
+    shs_view = shs.transpose(1, 2).view(-1, 3, 16)
+    dir_pp = means3D - cam.camera_center.repeat(N, 1)
+    dirn = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+    cols = {}
+    for deg in range(4):
+        cols["rgb_deg%d" % deg] = np_(torch.clamp_min(eval_sh(deg, shs_view, dirn) + 0.5, 0.0))
+    # G9: Sigma3D via build_scaling_rotation (utils/general_utils.py:137-170) on the
+    # rasterizer's own inputs (unit quaternion, activated scales)
+    L = build_scaling_rotation(1.0 * kw["scales"], kw["rotations"])
+    cov6 = strip_symmetric(L @ L.transpose(1, 2))
+    np.savez_compressed(
+        os.path.join(HERE, name + ".npz"),
+        xyz=np_(gm._xyz), features_dc=np_(gm._features_dc), features_rest=np_(gm._features_rest),
+        scaling=np_(gm._scaling), rotation=np_(gm._rotation), opacity=np_(gm._opacity),
+        d_xyz=np_(d_xyz), d_rotation=np_(d_rot), d_scaling=np_(d_scaling), isotropic=np.bool_(isotropic),
+        cam_R=R, cam_T=T, fovx=np.float64(fov), fovy=np.float64(fov * 0.8), H=np.int64(H), W=np.int64(W),
+        K=(K if K is not None else np.zeros((0,), np.float64)),
+        means3D=np_(kw["means3D"]), opacities=np_(kw["opacities"]), scales=np_(kw["scales"]),
+        rotations=np_(kw["rotations"]), shs=np_(kw["shs"]), means2D=np_(kw["means2D"]),
+        viewmatrix=np_(st.viewmatrix), projmatrix=np_(st.projmatrix), campos=np_(st.campos),
+        tanfovx=np.float64(st.tanfovx), tanfovy=np.float64(st.tanfovy), sh_degree=np.int64(st.sh_degree),
+        cov6=np_(cov6), **cols,
+    )
+    print("wrote", name)
+
+
+if __name__ == "__main__":
+    fixture_deform("deform_chain8_n257", 11, 8, 257, -1, chain=True)
+    fixture_deform("deform_tree24_n1024", 12, 24, 1024, -1, mask_random=True)
+    fixture_deform("deform_tree32_n512_k3", 13, 32, 512, 3)
+    fixture_deform("deform_tree64_n300", 14, 64, 300, -1)
+    fixture_deform("deform_tree6_degenerate", 15, 6, 129, -1, degenerate=True, mask_random=True)
+    fixture_posemlp("posemlp_w32_j24", 21, 24)
+    fixture_glue("glue_aniso_fov", 31, 96, False, False)
+    fixture_glue("glue_iso_K", 32, 96, True, True)
