@@ -1,0 +1,186 @@
+/*
+ * riggs_hip.h — C ABI of libriggs_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for RigGS's per-frame hot path.  Every entry point names the
+ * reference interface it replaces (paths relative to the RigGS tree).  Plain
+ * pointers and sizes only: all `const float*` / `float*` arguments are DEVICE
+ * pointers (HBM) unless stated, `stream` is a hipStream_t, nothing here owns
+ * memory — the caller (PyTorch's caching allocator, or any hipMalloc) does.
+ * Every function returns 0 on success, non-zero on error (see riggs_last_error()).
+ *
+ * Binding stubs for the reference side are shown in INTEGRATION.md.
+ */
+#ifndef RIGGS_HIP_H
+#define RIGGS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* riggs_stream; /* hipStream_t */
+
+int riggs_version(void);
+const char* riggs_last_error(void);
+
+/* =====================================================================
+ * Rasterizer.  Replaces the un-vendored CUDA extension
+ *   diff_gaussian_rasterization._C.rasterize_gaussians / rasterize_gaussians_backward
+ * reached from gaussian_renderer/__init__.py:14,57-72 (settings) and :133-141 (call).
+ * ===================================================================== */
+
+/* Mirror of GaussianRasterizationSettings (gaussian_renderer/__init__.py:57-70).
+ * bg / viewmatrix / projmatrix / campos are device tensors exactly as render() builds them
+ * (4x4 matrices in the transposed row-vector convention of scene/cameras.py:61-71). */
+typedef struct riggs_raster_cfg {
+  int32_t num_points;     /* N */
+  int32_t sh_degree;      /* active degree 0..3 */
+  int32_t sh_coeffs;      /* M = shs.shape[1] (16 for max degree 3); 0 with colors_precomp */
+  int32_t image_height;
+  int32_t image_width;
+  float tanfovx;
+  float tanfovy;
+  float scale_modifier;
+  const float* bg;         /* (3,) */
+  const float* viewmatrix; /* (4,4) */
+  const float* projmatrix; /* (4,4) */
+  const float* campos;     /* (3,) */
+  int32_t debug;           /* pipe.debug: synchronise + validate after each stage */
+  /* Fused "render glue" (gaussian_renderer/__init__.py:74-92, scene/gaussian_model.py:104-132):
+   * when glue != 0 the rasterizer takes RAW parameters and applies
+   *   means3D = xyz + d_xyz, opacity = sigmoid(_opacity), scales = exp(_scaling) + d_scaling,
+   *   rotations = normalize(_rotation + d_rotation)
+   * in-kernel, and the backward returns gradients w.r.t. the raw tensors. */
+  int32_t glue;
+  int32_t isotropic;       /* glue only: _scaling is (N,1) repeated (gaussian_model.py:105-108) */
+} riggs_raster_cfg;
+
+/* Opaque arenas (upstream: geomBuffer / binningBuffer / imgBuffer byte tensors). */
+size_t riggs_raster_geom_bytes(int32_t num_points);
+size_t riggs_raster_image_bytes(int32_t image_height, int32_t image_width);
+size_t riggs_raster_binning_bytes(int64_t instance_capacity, int32_t num_points, int32_t image_height,
+                                  int32_t image_width);
+
+/* Field offsets (bytes) inside the arenas, for tests / debugging tools. */
+enum {
+  RIGGS_GEOM_XYD = 0,      /* float4 (px, py, depth, 0) */
+  RIGGS_GEOM_CONIC_O,      /* float4 (A, B, C, opacity) */
+  RIGGS_GEOM_RGB,          /* float4 (r, g, b, 0) */
+  RIGGS_GEOM_COV3D,        /* float[6] */
+  RIGGS_GEOM_CLAMPED,      /* uint8 bitmask (bit ch) */
+  RIGGS_GEOM_TILES,        /* uint32 tiles_touched */
+  RIGGS_GEOM_RECT,         /* ushort4 (x0, y0, x1, y1) */
+  RIGGS_GEOM_DEPTH_ORDER,  /* uint32: Gaussian indices sorted by depth bits */
+  RIGGS_GEOM_OFFSETS,      /* uint32: inclusive scan of tiles_touched in depth order */
+  RIGGS_GEOM_NFIELDS_
+};
+enum {
+  RIGGS_IMG_FINAL_T = 0,   /* float  H*W */
+  RIGGS_IMG_N_CONTRIB,     /* uint32 H*W */
+  RIGGS_IMG_RANGES,        /* uint2  tiles */
+  RIGGS_IMG_NFIELDS_
+};
+enum {
+  RIGGS_BIN_POINT_LIST = 0, /* uint32 [capacity]: Gaussian index per sorted instance */
+  RIGGS_BIN_TILE_KEYS,      /* uint32 [capacity]: tile id per sorted instance */
+  RIGGS_BIN_NFIELDS_
+};
+int riggs_raster_geom_layout(int32_t num_points, size_t* offsets /*[RIGGS_GEOM_NFIELDS_]*/);
+int riggs_raster_image_layout(int32_t image_height, int32_t image_width, size_t* offsets /*[RIGGS_IMG_NFIELDS_]*/);
+int riggs_raster_binning_layout(int64_t instance_capacity, int32_t num_points, int32_t image_height,
+                                int32_t image_width, size_t* offsets /*[RIGGS_BIN_NFIELDS_]*/);
+
+/* Stage 1 (per Gaussian): projection, covariance, SH colour, tile rectangle; then the
+ * depth sort of the Gaussians and the scan of tiles_touched.  Writes the number of tile
+ * instances R into counters[0] (device).  Inputs follow GaussianRasterizer.forward
+ * (gaussian_renderer/__init__.py:133-141): exactly one of shs / colors_precomp and exactly
+ * one of (scales, rotations) / cov3D_precomp is non-NULL.
+ * With cfg->glue: means3D=_xyz, opacities=_opacity(logit), scales=_scaling(log), rotations=_rotation,
+ * and d_xyz (N,3) / d_rotation (N,4) / d_scaling (N,3) may be NULL (treated as 0, the Python-float case;
+ * scales = exp(_scaling) + d_scaling as at gaussian_renderer/__init__.py:89). */
+int riggs_raster_preprocess(const riggs_raster_cfg* cfg, const float* means3D, const float* shs,
+                            const float* colors_precomp, const float* opacities, const float* scales,
+                            const float* rotations, const float* cov3D_precomp, const float* d_xyz,
+                            const float* d_rotation, const float* d_scaling, void* geom, int32_t* radii,
+                            uint32_t* counters /* device [4]: R, overflow, rsv, rsv */, riggs_stream stream);
+
+/* Stage 2: instance emission (duplicateWithKeys), stable tile sort, tile ranges, and the
+ * per-tile alpha compositing.  `instance_capacity` bounds R: if R > capacity the launch is
+ * still memory-safe, counters[1] is set to 1 and the image is undefined (caller retries
+ * with a larger arena; riggs_amd.rasterizer does that). */
+int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom, void* binning, int64_t instance_capacity,
+                        void* image_state, float* out_color /*(3,H,W)*/, float* out_depth /*(1,H,W)*/,
+                        float* out_alpha /*(1,H,W)*/, uint32_t* counters, riggs_stream stream);
+
+/* Backward of both stages.  Gradient outputs are fully written (no pre-zeroing needed).
+ * dL_ddepth / dL_dalpha may be NULL (RigGS stage 2 uses only "render": train_rig.py:499).
+ * Outputs that do not apply (e.g. dL_dsh with colors_precomp) may be NULL.
+ * With cfg->glue the outputs are gradients w.r.t. the raw tensors: dL_dmeans3D = dL/d_xyz = dL/dd_xyz,
+ * dL_dopacities = dL/d_opacity(logit), dL_dscales = dL/d_scaling(log; (N,1) when isotropic),
+ * dL_drotations = dL/d_rotation = dL/dd_rotation. */
+int riggs_raster_backward(const riggs_raster_cfg* cfg, const float* means3D, const float* shs,
+                          const float* colors_precomp, const float* opacities, const float* scales,
+                          const float* rotations, const float* cov3D_precomp, const float* d_xyz,
+                          const float* d_rotation, const float* d_scaling, const int32_t* radii, const void* geom, const void* binning,
+                          int64_t instance_capacity, const void* image_state, const uint32_t* counters,
+                          const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
+                          void* workspace /* riggs_raster_backward_workspace_bytes(N) */, float* dL_dmeans3D,
+                          float* dL_dmeans2D /*(N,3)*/, float* dL_dsh, float* dL_dcolors_precomp,
+                          float* dL_dopacities, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
+                          float* dL_dd_scaling /* glue only, may be NULL */, riggs_stream stream);
+size_t riggs_raster_backward_workspace_bytes(int32_t num_points);
+
+/* =====================================================================
+ * Skeleton deformation.  Replaces the torch-op graph of
+ *   SkeletonWarp.deform_by_pose  skeleton_utils/skeleton_warp.py:130-172
+ * ===================================================================== */
+
+/* Forward kinematics + helpers on ONE workgroup:
+ *   quaternion_to_matrix      utils/time_utils.py:115-132
+ *   chain_product_transform   skeleton_utils/skeleton_warp.py:242-273
+ *   matrix_to_quaternion      utils/time_utils.py:146-205 (on the detached global rotations)
+ * local_rot (J,4) un-normalised wxyz; joints (J,3); parents (J,) int32 with parents[i] < i.
+ * Outputs: transforms (J,12) = rows of [R|t] 3x4, node_rot (J,4), d_nodes (J,3) = posed + global_trans. */
+int riggs_fk_forward(int32_t num_joints, const float* local_rot, const float* joints, const int32_t* parents,
+                     const float* global_trans, float* transforms, float* node_rot, float* d_nodes,
+                     riggs_stream stream);
+/* Reverse sweep: (dL/dtransforms (J,12), dL/dd_nodes (J,3) or NULL) -> dL/dlocal_rot (J,4);
+ * accumulates sum_j dL/dd_nodes into dL_dglobal_trans (3) (+=). */
+int riggs_fk_backward(int32_t num_joints, const float* local_rot, const float* joints, const int32_t* parents,
+                      const float* dL_dtransforms, const float* dL_dd_nodes, float* dL_dlocal_rot,
+                      float* dL_dglobal_trans, riggs_stream stream);
+
+/* Bone-distance skinning weights + linear blend skinning, fused:
+ *   cal_nn_weight_skeleton        skeleton_warp.py:41-76   (gs_kernel, K = -1 or top-K)
+ *   line_segment_distance         skeleton_warp.py:215-238 (squared)
+ *   LBS of means / quaternion     skeleton_warp.py:149-165
+ * x (N,3), motion_mask (N,) or NULL (= ones), node_radius_log (J,) = SkeletonWarp._node_radius.
+ * Outputs d_xyz (N,3), d_rotation (N,4); optional nn_weight (N,Kp) / nn_idx (N,Kp) int64 where
+ * Kp = J-1 (K<=0) or K — needed by render_rig.py:156-158, not by training (may be NULL). */
+int riggs_lbs_forward(int32_t num_points, int32_t num_joints, int32_t K, const float* x, const float* joints,
+                      const int32_t* parents, const float* node_radius_log, const float* transforms,
+                      const float* node_rot, const float* global_trans, const float* motion_mask, float* d_xyz,
+                      float* d_rotation, float* nn_weight, int64_t* nn_idx, riggs_stream stream);
+/* Backward: cotangents g_xyz (N,3), g_rot (N,4) -> dL/dtransforms (J,12), dL/dnode_radius_log (J),
+ * dL/dglobal_trans (3), optional dL/dmotion_mask (N).  Reduction over N is done in-kernel
+ * (wave -> workgroup -> one atomic per workgroup per output); outputs are zeroed first.
+ * No gradient to x or joints (both detached in the reference: skeleton_warp.py:16,44,131). */
+int riggs_lbs_backward(int32_t num_points, int32_t num_joints, int32_t K, const float* x, const float* joints,
+                       const int32_t* parents, const float* node_radius_log, const float* transforms,
+                       const float* node_rot, const float* global_trans, const float* motion_mask,
+                       const float* g_xyz, const float* g_rot, float* dL_dtransforms, float* dL_dnode_radius_log,
+                       float* dL_dglobal_trans, float* dL_dmotion_mask, riggs_stream stream);
+
+/* =====================================================================
+ * simple_knn._C.distCUDA2 (scene/gaussian_model.py:20,170): mean squared distance to the 3
+ * nearest neighbours.  points (P,3) -> out (P,).  workspace: riggs_knn_workspace_bytes(P).
+ * ===================================================================== */
+size_t riggs_knn_workspace_bytes(int32_t num_points);
+int riggs_dist2_knn3(int32_t num_points, const float* points, float* out, void* workspace, riggs_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RIGGS_HIP_H */

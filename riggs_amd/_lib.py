@@ -1,0 +1,109 @@
+"""ctypes binding of libriggs_hip.so (include/riggs_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or fails to load,
+every op raises.  PyTorch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "lib", "libriggs_hip.so")
+
+# enum mirrors (include/riggs_hip.h)
+GEOM_XYD, GEOM_CONIC_O, GEOM_RGB, GEOM_COV3D, GEOM_CLAMPED, GEOM_TILES, GEOM_RECT, GEOM_DEPTH_ORDER, GEOM_OFFSETS, \
+    GEOM_NFIELDS = range(10)
+IMG_FINAL_T, IMG_N_CONTRIB, IMG_RANGES, IMG_NFIELDS = range(4)
+BIN_POINT_LIST, BIN_TILE_KEYS, BIN_NFIELDS = range(3)
+
+
+class RasterCfg(C.Structure):
+    _fields_ = [
+        ("num_points", C.c_int32), ("sh_degree", C.c_int32), ("sh_coeffs", C.c_int32),
+        ("image_height", C.c_int32), ("image_width", C.c_int32),
+        ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
+        ("bg", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
+        ("debug", C.c_int32), ("glue", C.c_int32), ("isotropic", C.c_int32),
+    ]
+
+
+_lib = None
+
+_P = C.c_void_p
+_SIGS = {
+    "riggs_version": (C.c_int, []),
+    "riggs_last_error": (C.c_char_p, []),
+    "riggs_raster_geom_bytes": (C.c_size_t, [C.c_int32]),
+    "riggs_raster_image_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "riggs_raster_binning_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
+    "riggs_raster_backward_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "riggs_raster_geom_layout": (C.c_int, [C.c_int32, C.POINTER(C.c_size_t)]),
+    "riggs_raster_image_layout": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
+    "riggs_raster_binning_layout": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
+    "riggs_raster_preprocess": (C.c_int, [C.POINTER(RasterCfg)] + [_P] * 10 + [_P, _P, _P, _P]),
+    "riggs_raster_render": (C.c_int, [C.POINTER(RasterCfg), _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P]),
+    "riggs_raster_backward": (C.c_int, [C.POINTER(RasterCfg)] + [_P] * 10 + [_P, _P, _P, C.c_int64, _P, _P] + [_P] * 3
+                              + [_P] + [_P] * 9 + [_P]),
+    "riggs_fk_forward": (C.c_int, [C.c_int32] + [_P] * 8),
+    "riggs_fk_backward": (C.c_int, [C.c_int32] + [_P] * 8),
+    "riggs_lbs_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [_P] * 13),
+    "riggs_lbs_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [_P] * 15),
+    "riggs_knn_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "riggs_dist2_knn3": (C.c_int, [C.c_int32, _P, _P, _P, _P]),
+}
+
+
+class RiggsHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libriggs_hip.so; raise loudly when it is absent (no CPU/eager fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RiggsHipError(
+                "libriggs_hip.so not found at %s — build it with `python -m riggs_amd.build` "
+                "(or __graft_entry__.build()).  There is no fallback path." % SO_PATH)
+        L = C.CDLL(SO_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGS.keys())
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().riggs_last_error().decode(errors="replace")
+        raise RiggsHipError("%s failed (rc=%d): %s" % (what, rc, msg))
+
+
+def ptr(t):
+    """Device pointer of a tensor (or None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda_f32(name, t, shape=None):
+    import torch
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RiggsHipError("%s must be a CUDA(HIP) tensor — the product path is GPU-only" % name)
+    if t.dtype != torch.float32:
+        raise RiggsHipError("%s must be float32, got %s" % (name, t.dtype))
+    if shape is not None:
+        if len(shape) != t.dim() or any(s is not None and s != d for s, d in zip(shape, t.shape)):
+            raise RiggsHipError("%s has shape %s, expected %s" % (name, tuple(t.shape), shape))
+    return t.contiguous()

@@ -1,0 +1,265 @@
+// extern "C" boundary of libriggs_hip.so (see include/riggs_hip.h) — rasterizer part.
+#include <stdarg.h>
+
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "raster_internal.h"
+
+namespace riggs {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+static size_t sort_temp_bytes_u32(size_t n) {
+  size_t bytes = 0;
+  uint32_t* k = nullptr;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, k, k, n, 0, 32, (hipStream_t)0);
+  return bytes;
+}
+static size_t scan_temp_bytes_u32(size_t n) {
+  size_t bytes = 0;
+  uint32_t* k = nullptr;
+  (void)rocprim::inclusive_scan(nullptr, bytes, k, k, n, rocprim::plus<uint32_t>(), (hipStream_t)0);
+  return bytes;
+}
+
+GeomLayout geom_layout(int N) {
+  GeomLayout L;
+  size_t n = (size_t)(N > 0 ? N : 1), o = 0;
+  L.xyd = o; o = align_up(o + n * 16);
+  L.conic_o = o; o = align_up(o + n * 16);
+  L.rgb = o; o = align_up(o + n * 16);
+  L.cov3D = o; o = align_up(o + n * 24);
+  L.clamped = o; o = align_up(o + n);
+  L.tiles = o; o = align_up(o + n * 4);
+  L.rect = o; o = align_up(o + n * 8);
+  L.depth_key = o; o = align_up(o + n * 4);
+  L.depth_key_sorted = o; o = align_up(o + n * 4);
+  L.order_in = o; o = align_up(o + n * 4);
+  L.order = o; o = align_up(o + n * 4);
+  L.tt_sorted = o; o = align_up(o + n * 4);
+  L.offsets = o; o = align_up(o + n * 4);
+  size_t t1 = sort_temp_bytes_u32(n), t2 = scan_temp_bytes_u32(n);
+  L.temp_bytes = align_up(t1 > t2 ? t1 : t2);
+  L.temp = o; o += L.temp_bytes;
+  L.total = o;
+  return L;
+}
+
+ImageLayout image_layout(int H, int W) {
+  ImageLayout L;
+  size_t hw = (size_t)H * W, o = 0;
+  size_t T = (size_t)((W + RIGGS_TILE - 1) / RIGGS_TILE) * ((H + RIGGS_TILE - 1) / RIGGS_TILE);
+  L.final_T = o; o = align_up(o + hw * 4);
+  L.n_contrib = o; o = align_up(o + hw * 4);
+  L.ranges = o; o = align_up(o + (T + 1) * 8);
+  L.total = o;
+  return L;
+}
+
+BinLayout bin_layout(int64_t cap, int N, int H, int W) {
+  (void)N; (void)H; (void)W;
+  BinLayout L;
+  size_t n = (size_t)(cap > 0 ? cap : 1), o = 0;
+  L.vals_b = o; o = align_up(o + n * 4);   // sorted point list first (RIGGS_BIN_POINT_LIST)
+  L.keys_b = o; o = align_up(o + n * 4);
+  L.vals_a = o; o = align_up(o + n * 4);
+  L.keys_a = o; o = align_up(o + n * 4);
+  L.temp_bytes = align_up(sort_temp_bytes_u32(n));
+  L.temp = o; o += L.temp_bytes;
+  L.total = o;
+  return L;
+}
+
+}  // namespace riggs
+
+using namespace riggs;
+
+extern "C" {
+
+int riggs_version(void) { return 100; }
+const char* riggs_last_error(void) { return g_err; }
+
+size_t riggs_raster_geom_bytes(int32_t N) { return geom_layout(N).total; }
+size_t riggs_raster_image_bytes(int32_t H, int32_t W) { return image_layout(H, W).total; }
+size_t riggs_raster_binning_bytes(int64_t cap, int32_t N, int32_t H, int32_t W) { return bin_layout(cap, N, H, W).total; }
+size_t riggs_raster_backward_workspace_bytes(int32_t N) { return align_up((size_t)(N > 0 ? N : 1) * RIGGS_GACC * 4); }
+
+int riggs_raster_geom_layout(int32_t N, size_t* o) {
+  GeomLayout L = geom_layout(N);
+  o[RIGGS_GEOM_XYD] = L.xyd; o[RIGGS_GEOM_CONIC_O] = L.conic_o; o[RIGGS_GEOM_RGB] = L.rgb;
+  o[RIGGS_GEOM_COV3D] = L.cov3D; o[RIGGS_GEOM_CLAMPED] = L.clamped; o[RIGGS_GEOM_TILES] = L.tiles;
+  o[RIGGS_GEOM_RECT] = L.rect; o[RIGGS_GEOM_DEPTH_ORDER] = L.order; o[RIGGS_GEOM_OFFSETS] = L.offsets;
+  return 0;
+}
+int riggs_raster_image_layout(int32_t H, int32_t W, size_t* o) {
+  ImageLayout L = image_layout(H, W);
+  o[RIGGS_IMG_FINAL_T] = L.final_T; o[RIGGS_IMG_N_CONTRIB] = L.n_contrib; o[RIGGS_IMG_RANGES] = L.ranges;
+  return 0;
+}
+int riggs_raster_binning_layout(int64_t cap, int32_t N, int32_t H, int32_t W, size_t* o) {
+  BinLayout L = bin_layout(cap, N, H, W);
+  o[RIGGS_BIN_POINT_LIST] = L.vals_b; o[RIGGS_BIN_TILE_KEYS] = L.keys_b;
+  return 0;
+}
+
+static int fill_pre_args(PreArgs& a, const riggs_raster_cfg* c, const float* means3D, const float* shs,
+                         const float* colors_precomp, const float* opac, const float* scales, const float* rots,
+                         const float* cov3D_precomp, const float* d_xyz, const float* d_rot, const float* d_scaling,
+                         char* geom, int32_t* radii) {
+  RIGGS_REQUIRE(c != nullptr, "cfg is NULL");
+  RIGGS_REQUIRE(c->num_points >= 0 && c->image_height > 0 && c->image_width > 0, "bad sizes");
+  RIGGS_REQUIRE((shs != nullptr) != (colors_precomp != nullptr), "Please provide excatly one of either SHs or precomputed colors!");
+  RIGGS_REQUIRE(((scales != nullptr && rots != nullptr) != (cov3D_precomp != nullptr)) && ((scales != nullptr) == (rots != nullptr)),
+                "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+  RIGGS_REQUIRE(c->sh_degree >= 0 && c->sh_degree <= 3, "sh_degree must be 0..3");
+  RIGGS_REQUIRE(shs == nullptr || c->sh_coeffs >= (c->sh_degree + 1) * (c->sh_degree + 1), "sh_coeffs too small for sh_degree");
+  RIGGS_REQUIRE(!(c->glue && cov3D_precomp), "glue mode needs scales/rotations");
+  GeomLayout L = geom_layout(c->num_points);
+  a.N = c->num_points; a.deg = c->sh_degree; a.M = c->sh_coeffs; a.W = c->image_width; a.H = c->image_height;
+  a.glue = c->glue; a.isotropic = c->isotropic;
+  a.tanx = c->tanfovx; a.tany = c->tanfovy; a.mod = c->scale_modifier;
+  a.view = c->viewmatrix; a.proj = c->projmatrix; a.campos = c->campos;
+  a.means3D = means3D; a.shs = shs; a.colors_precomp = colors_precomp; a.opac = opac; a.scales = scales; a.rots = rots;
+  a.cov3D_precomp = cov3D_precomp; a.d_xyz = d_xyz; a.d_rot = d_rot; a.d_scaling = d_scaling;
+  a.radii = radii;
+  a.xyd = (float4*)(geom + L.xyd); a.conic_o = (float4*)(geom + L.conic_o); a.rgb = (float4*)(geom + L.rgb);
+  a.cov3D = (float*)(geom + L.cov3D); a.clamped = (uint8_t*)(geom + L.clamped); a.tiles = (uint32_t*)(geom + L.tiles);
+  a.rect = (ushort4*)(geom + L.rect); a.depth_key = (uint32_t*)(geom + L.depth_key);
+  a.order_in = (uint32_t*)(geom + L.order_in);
+  return 0;
+}
+
+int riggs_raster_preprocess(const riggs_raster_cfg* cfg, const float* means3D, const float* shs,
+                            const float* colors_precomp, const float* opacities, const float* scales,
+                            const float* rotations, const float* cov3D_precomp, const float* d_xyz,
+                            const float* d_rotation, const float* d_scaling, void* geom_, int32_t* radii,
+                            uint32_t* counters, riggs_stream stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  char* geom = (char*)geom_;
+  PreArgs a;
+  int rc = fill_pre_args(a, cfg, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, d_xyz,
+                         d_rotation, d_scaling, geom, radii);
+  if (rc) return rc;
+  const int N = cfg->num_points;
+  RIGGS_HIP_CHECK(hipMemsetAsync(counters, 0, 16, s));
+  if (N == 0) return 0;
+  GeomLayout L = geom_layout(N);
+  launch_preprocess_fwd(a, s);
+  if (debug_sync(cfg->debug, s, "preprocess_fwd")) return 1;
+  // depth sort of the Gaussians (stable: equal depths keep ascending index)
+  size_t tb = L.temp_bytes;
+  RIGGS_HIP_CHECK(rocprim::radix_sort_pairs(geom + L.temp, tb, (uint32_t*)(geom + L.depth_key),
+                                            (uint32_t*)(geom + L.depth_key_sorted), (uint32_t*)(geom + L.order_in),
+                                            (uint32_t*)(geom + L.order), (size_t)N, 0, 32, s));
+  launch_gather_tiles(N, (uint32_t*)(geom + L.order), (uint32_t*)(geom + L.tiles), (uint32_t*)(geom + L.tt_sorted), s);
+  tb = L.temp_bytes;
+  RIGGS_HIP_CHECK(rocprim::inclusive_scan(geom + L.temp, tb, (uint32_t*)(geom + L.tt_sorted),
+                                          (uint32_t*)(geom + L.offsets), (size_t)N, rocprim::plus<uint32_t>(), s));
+  // publish R for the host (counters[0]); emit_kernel rewrites it together with the overflow flag
+  RIGGS_HIP_CHECK(hipMemcpyAsync(counters, geom + L.offsets + (size_t)(N - 1) * 4, 4, hipMemcpyDeviceToDevice, s));
+  if (debug_sync(cfg->debug, s, "depth sort / scan")) return 1;
+  return 0;
+}
+
+int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* binning_, int64_t cap, void* image_,
+                        float* out_color, float* out_depth, float* out_alpha, uint32_t* counters,
+                        riggs_stream stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  RIGGS_REQUIRE(cfg != nullptr, "cfg is NULL");
+  const int N = cfg->num_points, H = cfg->image_height, W = cfg->image_width;
+  const int gx = (W + RIGGS_TILE - 1) / RIGGS_TILE, gy = (H + RIGGS_TILE - 1) / RIGGS_TILE, T = gx * gy;
+  RIGGS_REQUIRE(T < 65535 * 16, "image too large");
+  const char* geom = (const char*)geom_;
+  char* bin = (char*)binning_;
+  char* img = (char*)image_;
+  GeomLayout G = geom_layout(N);
+  ImageLayout I = image_layout(H, W);
+  BinLayout B = bin_layout(cap, N, H, W);
+  RIGGS_HIP_CHECK(hipMemsetAsync(img + I.ranges, 0, (size_t)(T + 1) * 8, s));
+  const uint32_t* point_list = (const uint32_t*)(bin + B.vals_b);
+  if (N > 0 && cap > 0) {
+    launch_emit(N, gx, T, cap, (const uint32_t*)(geom + G.order), (const uint32_t*)(geom + G.offsets),
+                (const uint32_t*)(geom + G.tiles), (const ushort4*)(geom + G.rect), (uint32_t*)(bin + B.keys_a),
+                (uint32_t*)(bin + B.vals_a), counters, s);
+    if (debug_sync(cfg->debug, s, "emit")) return 1;
+    int end_bit = 1;
+    while ((1u << end_bit) <= (uint32_t)T) end_bit++;  // sentinel key T must be representable
+    size_t tb = B.temp_bytes;
+    RIGGS_HIP_CHECK(rocprim::radix_sort_pairs(bin + B.temp, tb, (uint32_t*)(bin + B.keys_a), (uint32_t*)(bin + B.keys_b),
+                                              (uint32_t*)(bin + B.vals_a), (uint32_t*)(bin + B.vals_b), (size_t)cap, 0,
+                                              end_bit, s));
+    launch_ranges(cap, T, (const uint32_t*)(bin + B.keys_b), counters, (uint2*)(img + I.ranges), s);
+    if (debug_sync(cfg->debug, s, "tile sort / ranges")) return 1;
+  }
+  RenderArgs r;
+  r.W = W; r.H = H;
+  r.ranges = (const uint2*)(img + I.ranges);
+  r.point_list = point_list;
+  r.xyd = (const float4*)(geom + G.xyd); r.conic_o = (const float4*)(geom + G.conic_o); r.rgb = (const float4*)(geom + G.rgb);
+  r.bg = cfg->bg;
+  r.final_T = (float*)(img + I.final_T); r.n_contrib = (uint32_t*)(img + I.n_contrib);
+  r.out_color = out_color; r.out_depth = out_depth; r.out_alpha = out_alpha;
+  launch_render_fwd(r, s);
+  if (debug_sync(cfg->debug, s, "render_fwd")) return 1;
+  return 0;
+}
+
+int riggs_raster_backward(const riggs_raster_cfg* cfg, const float* means3D, const float* shs,
+                          const float* colors_precomp, const float* opacities, const float* scales,
+                          const float* rotations, const float* cov3D_precomp, const float* d_xyz,
+                          const float* d_rotation, const float* d_scaling, const int32_t* radii, const void* geom_,
+                          const void* binning_,
+                          int64_t cap, const void* image_, const uint32_t* counters, const float* dL_dcolor,
+                          const float* dL_ddepth, const float* dL_dalpha, void* workspace, float* dL_dmeans3D,
+                          float* dL_dmeans2D, float* dL_dsh, float* dL_dcolors_precomp, float* dL_dopacities,
+                          float* dL_dscales, float* dL_drotations, float* dL_dcov3D, float* dL_dd_scaling,
+                          riggs_stream stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  (void)counters;
+  PreBwdArgs b;
+  int rc = fill_pre_args(b.f, cfg, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, d_xyz,
+                         d_rotation, d_scaling, (char*)geom_, (int32_t*)radii);
+  if (rc) return rc;
+  RIGGS_REQUIRE(dL_dcolor && dL_dmeans3D && dL_dmeans2D && dL_dopacities && workspace, "missing gradient buffers");
+  RIGGS_REQUIRE(shs == nullptr || dL_dsh != nullptr, "dL_dsh required with shs");
+  RIGGS_REQUIRE(colors_precomp == nullptr || dL_dcolors_precomp != nullptr, "dL_dcolors_precomp required");
+  RIGGS_REQUIRE(cov3D_precomp == nullptr || dL_dcov3D != nullptr, "dL_dcov3D required");
+  RIGGS_REQUIRE(scales == nullptr || (dL_dscales != nullptr && dL_drotations != nullptr), "dL_dscales/dL_drotations required");
+  const int N = cfg->num_points, H = cfg->image_height, W = cfg->image_width;
+  if (N == 0) return 0;
+  const char* geom = (const char*)geom_;
+  const char* bin = (const char*)binning_;
+  const char* img = (const char*)image_;
+  GeomLayout G = geom_layout(N);
+  ImageLayout I = image_layout(H, W);
+  BinLayout B = bin_layout(cap, N, H, W);
+  RIGGS_HIP_CHECK(hipMemsetAsync(workspace, 0, (size_t)N * RIGGS_GACC * 4, s));
+  RenderBwdArgs r;
+  r.W = W; r.H = H;
+  r.ranges = (const uint2*)(img + I.ranges);
+  r.point_list = (const uint32_t*)(bin + B.vals_b);
+  r.xyd = (const float4*)(geom + G.xyd); r.conic_o = (const float4*)(geom + G.conic_o); r.rgb = (const float4*)(geom + G.rgb);
+  r.bg = cfg->bg;
+  r.final_T = (const float*)(img + I.final_T); r.n_contrib = (const uint32_t*)(img + I.n_contrib);
+  r.dL_dcolor = dL_dcolor; r.dL_ddepth = dL_ddepth; r.dL_dalpha = dL_dalpha;
+  r.gacc = (float*)workspace;
+  if (cap > 0) launch_render_bwd(r, s);
+  if (debug_sync(cfg->debug, s, "render_bwd")) return 1;
+  b.g_mean2D_conic = (const float*)workspace;
+  b.dL_dmeans3D = dL_dmeans3D; b.dL_dmeans2D = dL_dmeans2D; b.dL_dsh = dL_dsh; b.dL_dcolors = dL_dcolors_precomp;
+  b.dL_dopac = dL_dopacities; b.dL_dscales = dL_dscales; b.dL_drots = dL_drotations; b.dL_dcov3D = dL_dcov3D;
+  b.dL_dd_scaling = dL_dd_scaling;
+  launch_preprocess_bwd(b, s);
+  if (debug_sync(cfg->debug, s, "preprocess_bwd")) return 1;
+  return 0;
+}
+
+}  // extern "C"

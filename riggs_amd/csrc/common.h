@@ -1,0 +1,83 @@
+// Shared helpers for the gfx950 kernels of libriggs_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/riggs_hip.h"
+
+#define RIGGS_TILE 16
+#define RIGGS_TILE_PIX 256
+#define RIGGS_WAVE 64
+
+namespace riggs {
+
+void set_error(const char* fmt, ...);
+
+#define RIGGS_HIP_CHECK(expr)                                                                  \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) {                                                                    \
+      riggs::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return 1;                                                                                \
+    }                                                                                          \
+  } while (0)
+
+#define RIGGS_REQUIRE(cond, msg)                                   \
+  do {                                                             \
+    if (!(cond)) {                                                 \
+      riggs::set_error("%s (%s:%d)", msg, __FILE__, __LINE__);     \
+      return 2;                                                    \
+    }                                                              \
+  } while (0)
+
+inline int debug_sync(int debug, hipStream_t s, const char* what) {
+  if (!debug) return 0;
+  hipError_t e = hipStreamSynchronize(s);
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("debug: %s failed: %s", what, hipGetErrorString(e));
+    return 1;
+  }
+  return 0;
+}
+
+static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// ---- arena layouts ---------------------------------------------------------
+struct GeomLayout {
+  size_t xyd, conic_o, rgb, cov3D, clamped, tiles, rect, depth_key, depth_key_sorted, order_in, order, tt_sorted,
+      offsets, temp, temp_bytes, total;
+};
+GeomLayout geom_layout(int N);
+
+struct ImageLayout {
+  size_t final_T, n_contrib, ranges, total;
+};
+ImageLayout image_layout(int H, int W);
+
+struct BinLayout {
+  size_t keys_a, keys_b, vals_a, vals_b, temp, temp_bytes, total;
+};
+BinLayout bin_layout(int64_t cap, int N, int H, int W);
+
+// ---- wave64 reductions -----------------------------------------------------
+// Sum over the 64 lanes of a wave using DPP row operations + two cross-row steps.
+__device__ __forceinline__ float wave_sum(float v) {
+  // within rows of 16 lanes
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));  // row_shr:1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));  // row_shr:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));  // row_shr:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));  // row_shr:8
+  // lane 15 of each row now holds the row sum; combine rows
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, true));  // row_bcast:15
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, true));  // row_bcast:31
+  return v;  // valid in lane 63
+}
+__device__ __forceinline__ float wave_sum_bcast(float v) {
+  v = wave_sum(v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+}  // namespace riggs

@@ -1,0 +1,467 @@
+// Skeleton-driven deformation of the Gaussian cloud:
+//   fk_*   : forward kinematics over <= 64 joints on ONE wave64 (replaces ~3*J torch launches
+//            of SkeletonWarp.chain_product_transform, skeleton_warp.py:242-273)
+//   lbs_*  : bone-distance skinning weights + linear blend skinning fused per Gaussian, with the
+//            <= 63 bone records (segment, radius, 3x4 transform, quaternion) staged in LDS.
+// Backward reduces over the N Gaussians inside the kernel: wave64 DPP sums -> LDS -> one atomic
+// per workgroup per output.
+#include "common.h"
+
+namespace riggs {
+
+#define MAX_J 64
+#define LOG2E 1.4426950408889634f
+
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * LOG2E); }
+
+// quaternion_to_matrix with two_s = 2/|q|^2 (utils/time_utils.py:115-132)
+__device__ __forceinline__ void quat_to_R_unnorm(const float* q, float* R) {
+  const float r = q[0], i = q[1], j = q[2], k = q[3];
+  const float two_s = 2.0f / (r * r + i * i + j * j + k * k);
+  R[0] = 1.f - two_s * (j * j + k * k); R[1] = two_s * (i * j - k * r); R[2] = two_s * (i * k + j * r);
+  R[3] = two_s * (i * j + k * r); R[4] = 1.f - two_s * (i * i + k * k); R[5] = two_s * (j * k - i * r);
+  R[6] = two_s * (i * k - j * r); R[7] = two_s * (j * k + i * r); R[8] = 1.f - two_s * (i * i + j * j);
+}
+
+// matrix_to_quaternion (utils/time_utils.py:146-205): best-conditioned candidate, no sign fix
+__device__ __forceinline__ void R_to_quat(const float* m, float* q) {
+  const float m00 = m[0], m01 = m[1], m02 = m[2], m10 = m[4], m11 = m[5], m12 = m[6], m20 = m[8], m21 = m[9], m22 = m[10];
+  float a[4] = {1.0f + m00 + m11 + m22, 1.0f + m00 - m11 - m22, 1.0f - m00 + m11 - m22, 1.0f - m00 - m11 + m22};
+  float qa[4];
+  int pick = 0;
+#pragma unroll
+  for (int c = 0; c < 4; c++) qa[c] = a[c] > 0.f ? sqrtf(a[c]) : 0.f;
+#pragma unroll
+  for (int c = 1; c < 4; c++) if (qa[c] > qa[pick]) pick = c;
+  float cand[4];
+  if (pick == 0) { cand[0] = qa[0] * qa[0]; cand[1] = m21 - m12; cand[2] = m02 - m20; cand[3] = m10 - m01; }
+  else if (pick == 1) { cand[0] = m21 - m12; cand[1] = qa[1] * qa[1]; cand[2] = m10 + m01; cand[3] = m02 + m20; }
+  else if (pick == 2) { cand[0] = m02 - m20; cand[1] = m10 + m01; cand[2] = qa[2] * qa[2]; cand[3] = m12 + m21; }
+  else { cand[0] = m10 - m01; cand[1] = m20 + m02; cand[2] = m21 + m12; cand[3] = qa[3] * qa[3]; }
+  const float den = 2.0f * fmaxf(qa[pick], 0.1f);
+#pragma unroll
+  for (int c = 0; c < 4; c++) q[c] = cand[c] / den;
+}
+
+// Shared by fk forward and backward: local transforms T (J,12) and the global chain G (J,12) in LDS.
+// transforms are 3x4 row-major [R|t].
+__device__ void fk_chain_lds(int J, const float* __restrict__ local_rot, const float* __restrict__ joints,
+                             const int32_t* __restrict__ parents, float (*T)[12], float (*G)[12], int* par) {
+  const int j = threadIdx.x;
+  if (j < J) {
+    float q[4] = {local_rot[4 * j], local_rot[4 * j + 1], local_rot[4 * j + 2], local_rot[4 * j + 3]};
+    float R[9];
+    quat_to_R_unnorm(q, R);
+    const int vp = (j == 0) ? 0 : parents[j];  // skeleton_warp.py:246-247
+    par[j] = vp;
+    const float cx = joints[3 * vp], cy = joints[3 * vp + 1], cz = joints[3 * vp + 2];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      T[j][4 * r] = R[3 * r]; T[j][4 * r + 1] = R[3 * r + 1]; T[j][4 * r + 2] = R[3 * r + 2];
+      const float c = (r == 0) ? cx : (r == 1 ? cy : cz);
+      T[j][4 * r + 3] = c - (R[3 * r] * cx + R[3 * r + 1] * cy + R[3 * r + 2] * cz);  // rotate about the PARENT joint
+    }
+  }
+  __syncthreads();
+  if (j < 12) G[0][j] = T[0][j];
+  __syncthreads();
+  // G_i = G_parent(i) * T_i in index order (parents[i] < i); 12 lanes own the 12 entries
+  const int r = j >> 2, c = j & 3;
+  for (int i = 1; i < J; i++) {
+    if (j < 12) {
+      const float* Gp = G[par[i]];
+      float v = Gp[4 * r] * T[i][c] + Gp[4 * r + 1] * T[i][4 + c] + Gp[4 * r + 2] * T[i][8 + c];
+      if (c == 3) v += Gp[4 * r + 3];
+      G[i][j] = v;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(64) void fk_forward_kernel(int J, const float* __restrict__ local_rot,
+                                                        const float* __restrict__ joints,
+                                                        const int32_t* __restrict__ parents,
+                                                        const float* __restrict__ global_trans,
+                                                        float* __restrict__ transforms, float* __restrict__ node_rot,
+                                                        float* __restrict__ d_nodes) {
+  __shared__ float T[MAX_J][12];
+  __shared__ float G[MAX_J][12];
+  __shared__ int par[MAX_J];
+  fk_chain_lds(J, local_rot, joints, parents, T, G, par);
+  const int j = threadIdx.x;
+  if (j < J) {
+    const float x = joints[3 * j], y = joints[3 * j + 1], z = joints[3 * j + 2];
+#pragma unroll
+    for (int e = 0; e < 12; e++) transforms[12 * j + e] = G[j][e];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+      d_nodes[3 * j + r] = (G[j][4 * r] * x + G[j][4 * r + 1] * y + G[j][4 * r + 2] * z + G[j][4 * r + 3]) + global_trans[r];
+    float q[4];
+    R_to_quat(G[j], q);
+#pragma unroll
+    for (int e = 0; e < 4; e++) node_rot[4 * j + e] = q[e];
+  }
+}
+
+__global__ __launch_bounds__(64) void fk_backward_kernel(int J, const float* __restrict__ local_rot,
+                                                         const float* __restrict__ joints,
+                                                         const int32_t* __restrict__ parents,
+                                                         const float* __restrict__ dL_dG_in,
+                                                         const float* __restrict__ dL_dnodes,
+                                                         float* __restrict__ dL_dlocal_rot,
+                                                         float* __restrict__ dL_dglobal_trans) {
+  __shared__ float T[MAX_J][12];
+  __shared__ float G[MAX_J][12];
+  __shared__ float dG[MAX_J][12];
+  __shared__ float dT[MAX_J][12];
+  __shared__ int par[MAX_J];
+  fk_chain_lds(J, local_rot, joints, parents, T, G, par);
+  const int j = threadIdx.x;
+  if (j < J) {
+    const float x = joints[3 * j], y = joints[3 * j + 1], z = joints[3 * j + 2];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const float e = dL_dnodes ? dL_dnodes[3 * j + r] : 0.f;  // posed_j = G_j [joint_j; 1]
+      dG[j][4 * r] = dL_dG_in[12 * j + 4 * r] + e * x;
+      dG[j][4 * r + 1] = dL_dG_in[12 * j + 4 * r + 1] + e * y;
+      dG[j][4 * r + 2] = dL_dG_in[12 * j + 4 * r + 2] + e * z;
+      dG[j][4 * r + 3] = dL_dG_in[12 * j + 4 * r + 3] + e;
+    }
+  }
+  if (dL_dnodes && j < 3) {  // d_nodes = posed + global_trans
+    float s = 0.f;
+    for (int k = 0; k < J; k++) s += dL_dnodes[3 * k + j];
+    dL_dglobal_trans[j] += s;
+  }
+  __syncthreads();
+  const int r = j >> 2, c = j & 3;
+  for (int i = J - 1; i >= 1; i--) {
+    const int p = par[i];
+    float add = 0.f, dt = 0.f;
+    if (j < 12) {
+      // dT_i = Rp^T dG_i  (both the rotation block and the translation column)
+      dt = G[p][r] * dG[i][c] + G[p][4 + r] * dG[i][4 + c] + G[p][8 + r] * dG[i][8 + c];
+      // dG_p += [dR_G R_T^T + dt_G t_T^T | dt_G]
+      if (c < 3) add = dG[i][4 * r] * T[i][4 * c] + dG[i][4 * r + 1] * T[i][4 * c + 1] + dG[i][4 * r + 2] * T[i][4 * c + 2] +
+                       dG[i][4 * r + 3] * T[i][4 * c + 3];
+      else add = dG[i][4 * r + 3];
+    }
+    __syncthreads();
+    if (j < 12) { dT[i][j] = dt; dG[p][j] += add; }
+    __syncthreads();
+  }
+  if (j < 12) dT[0][j] = dG[0][j];
+  __syncthreads();
+  if (j < J) {
+    const int vp = par[j];
+    const float cx = joints[3 * vp], cy = joints[3 * vp + 1], cz = joints[3 * vp + 2];
+    const float cc[3] = {cx, cy, cz};
+    float dR[9];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 3; b++) dR[3 * a + b] = dT[j][4 * a + b] - dT[j][4 * a + 3] * cc[b];  // t = c - R c
+    const float qr = local_rot[4 * j], qi = local_rot[4 * j + 1], qj = local_rot[4 * j + 2], qk = local_rot[4 * j + 3];
+    const float n = qr * qr + qi * qi + qj * qj + qk * qk;
+    const float s = 2.0f / n;
+    // A = (R - I)/s
+    const float A[9] = {-(qj * qj + qk * qk), qi * qj - qk * qr, qi * qk + qj * qr,
+                        qi * qj + qk * qr, -(qi * qi + qk * qk), qj * qk - qi * qr,
+                        qi * qk - qj * qr, qj * qk + qi * qr, -(qi * qi + qj * qj)};
+    float dotA = 0.f;
+#pragma unroll
+    for (int e = 0; e < 9; e++) dotA += dR[e] * A[e];
+    const float gr = -qk * dR[1] + qj * dR[2] + qk * dR[3] - qi * dR[5] - qj * dR[6] + qi * dR[7];
+    const float gi = qj * dR[1] + qk * dR[2] + qj * dR[3] - 2.f * qi * dR[4] - qr * dR[5] + qk * dR[6] + qr * dR[7] - 2.f * qi * dR[8];
+    const float gj = -2.f * qj * dR[0] + qi * dR[1] + qr * dR[2] + qi * dR[3] + qk * dR[5] - qr * dR[6] + qk * dR[7] - 2.f * qj * dR[8];
+    const float gk = -2.f * qk * dR[0] - qr * dR[1] + qi * dR[2] + qr * dR[3] - 2.f * qk * dR[4] + qj * dR[5] + qi * dR[6] + qj * dR[7];
+    const float s2 = s * s;
+    dL_dlocal_rot[4 * j] = s * gr - s2 * qr * dotA;
+    dL_dlocal_rot[4 * j + 1] = s * gi - s2 * qi * dotA;
+    dL_dlocal_rot[4 * j + 2] = s * gj - s2 * qj * dotA;
+    dL_dlocal_rot[4 * j + 3] = s * gk - s2 * qk * dotA;
+  }
+}
+
+// ------------------------------------------------------------------------------------ LBS
+struct Bone {        // 24 floats, LDS resident
+  float a[3];        // parent joint (segment start)  skeleton_warp.py:208-209
+  float inv_len2;    // 1 / max(|b-a|^2, 1e-6)        :226
+  float ba[3];       // b - a
+  float inv2r2;      // 1 / (2 exp(rho)^2)            :65-66
+  float G[12];       // global transform of the CHILD joint
+  float q[4];        // node_rot of the child joint (detached)
+};
+
+struct LbsArgs {
+  int N, J, K;
+  const float *x, *joints, *node_radius_log, *transforms, *node_rot, *global_trans, *motion_mask;
+  const int32_t* parents;
+  float *d_xyz, *d_rot, *nn_weight;
+  int64_t* nn_idx;
+  // backward
+  const float *g_xyz, *g_rot;
+  float *dG, *drho, *dgt, *dmask;
+};
+
+__device__ __forceinline__ void stage_bones(const LbsArgs& a, Bone* bones) {
+  for (int k = threadIdx.x; k < a.J - 1; k += blockDim.x) {
+    const int child = k + 1, par = a.parents[child];
+    Bone b;
+    float l2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      b.a[c] = a.joints[3 * par + c];
+      b.ba[c] = a.joints[3 * child + c] - b.a[c];
+      l2 += b.ba[c] * b.ba[c];
+    }
+    b.inv_len2 = 1.0f / fmaxf(l2, 1e-6f);
+    const float rad = expf(a.node_radius_log[child]);
+    b.inv2r2 = 1.0f / (2.0f * rad * rad);
+#pragma unroll
+    for (int e = 0; e < 12; e++) b.G[e] = a.transforms[12 * child + e];
+#pragma unroll
+    for (int e = 0; e < 4; e++) b.q[e] = a.node_rot[4 * child + e];
+    bones[k] = b;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ float bone_d2(const Bone& b, float px, float py, float pz) {
+  const float ex = px - b.a[0], ey = py - b.a[1], ez = pz - b.a[2];
+  float t = (ex * b.ba[0] + ey * b.ba[1] + ez * b.ba[2]) * b.inv_len2;
+  t = fminf(fmaxf(t, 0.0f), 1.0f);
+  const float sx = t * b.ba[0] - ex, sy = t * b.ba[1] - ey, sz = t * b.ba[2] - ez;
+  return sx * sx + sy * sy + sz * sz;
+}
+
+// Top-K selection state: the K smallest (d2, idx) pairs in ascending order, by K selection
+// passes (K is tiny, 3 in the reference configs) — no per-thread arrays.
+__device__ __forceinline__ bool topk_selected(const Bone* bones, int B, int K, float px, float py, float pz, int k,
+                                              float d2k) {
+  // bone k is selected iff fewer than K bones are strictly "smaller" in (d2, idx) order
+  int smaller = 0;
+  for (int m = 0; m < B; m++) {
+    const float dm = bone_d2(bones[m], px, py, pz);
+    smaller += (dm < d2k || (dm == d2k && m < k)) ? 1 : 0;
+  }
+  return smaller < K;
+}
+
+__global__ __launch_bounds__(256) void lbs_forward_kernel(LbsArgs a) {
+  __shared__ Bone bones[MAX_J - 1];
+  stage_bones(a, bones);
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= a.N) return;
+  const int B = a.J - 1;
+  const float px = a.x[3 * n], py = a.x[3 * n + 1], pz = a.x[3 * n + 2];
+  float M[12], qa[4] = {0.f, 0.f, 0.f, 0.f}, sum = 0.f;
+#pragma unroll
+  for (int e = 0; e < 12; e++) M[e] = 0.f;
+  for (int k = 0; k < B; k++) {
+    const Bone& b = bones[k];
+    const float d2 = bone_d2(b, px, py, pz);
+    if (a.K > 0 && !topk_selected(bones, B, a.K, px, py, pz, k, d2)) continue;
+    const float v = fast_exp(-d2 * b.inv2r2) + 1e-7f;  // skeleton_warp.py:66,71
+    sum += v;
+#pragma unroll
+    for (int e = 0; e < 12; e++) M[e] += v * b.G[e];
+#pragma unroll
+    for (int e = 0; e < 4; e++) qa[e] += v * b.q[e];
+  }
+  const float inv = 1.0f / sum;
+  const float m = a.motion_mask ? a.motion_mask[n] : 1.0f;
+  const float gx = a.global_trans[0], gy = a.global_trans[1], gz = a.global_trans[2];
+  const float ax = (M[0] * px + M[1] * py + M[2] * pz + M[3]) * inv + gx;
+  const float ay = (M[4] * px + M[5] * py + M[6] * pz + M[7]) * inv + gy;
+  const float az = (M[8] * px + M[9] * py + M[10] * pz + M[11]) * inv + gz;
+  a.d_xyz[3 * n] = (ax - px) * m; a.d_xyz[3 * n + 1] = (ay - py) * m; a.d_xyz[3 * n + 2] = (az - pz) * m;
+  reinterpret_cast<float4*>(a.d_rot)[n] = make_float4(qa[0] * inv * m, qa[1] * inv * m, qa[2] * inv * m, qa[3] * inv * m);
+  if (a.nn_weight || a.nn_idx) {
+    if (a.K > 0) {
+      // ascending-d2 order like torch.topk(largest=False): K selection passes
+      float prev_d = -1.f; int prev_i = -1;
+      for (int s = 0; s < a.K; s++) {
+        float best = INFINITY; int bi = -1;
+        for (int k = 0; k < B; k++) {
+          const float d2 = bone_d2(bones[k], px, py, pz);
+          const bool after = (d2 > prev_d) || (d2 == prev_d && k > prev_i);
+          if (after && (d2 < best)) { best = d2; bi = k; }
+        }
+        prev_d = best; prev_i = bi;
+        if (a.nn_weight) a.nn_weight[(size_t)n * a.K + s] = (fast_exp(-best * bones[bi].inv2r2) + 1e-7f) * inv;
+        if (a.nn_idx) a.nn_idx[(size_t)n * a.K + s] = bi + 1;
+      }
+    } else {
+      for (int k = 0; k < B; k++) {
+        if (a.nn_weight) a.nn_weight[(size_t)n * B + k] = (fast_exp(-bone_d2(bones[k], px, py, pz) * bones[k].inv2r2) + 1e-7f) * inv;
+        if (a.nn_idx) a.nn_idx[(size_t)n * B + k] = k + 1;
+      }
+    }
+  }
+}
+
+// Backward.  Per bone 13 sums over the Gaussians: dG_k (12) = sum_n w_nk * (ghat_n (x) [x_n;1]) and
+// drho_k = sum_n dL/dv_nk * u_nk * d2_nk * exp(-2 rho_k).
+__global__ __launch_bounds__(256) void lbs_backward_kernel(LbsArgs a) {
+  __shared__ Bone bones[MAX_J - 1];
+  __shared__ float s_acc[MAX_J - 1][13];
+  __shared__ float s_gt[3];
+  stage_bones(a, bones);
+  const int B = a.J - 1;
+  for (int e = threadIdx.x; e < B * 13; e += 256) (&s_acc[0][0])[e] = 0.f;
+  if (threadIdx.x < 3) s_gt[threadIdx.x] = 0.f;
+  __syncthreads();
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const bool valid = n < a.N;
+  const int lane = threadIdx.x & 63;
+  float px = 0.f, py = 0.f, pz = 0.f, m = 0.f;
+  float g[3] = {0.f, 0.f, 0.f}, h[4] = {0.f, 0.f, 0.f, 0.f};
+  if (valid) {
+    px = a.x[3 * n]; py = a.x[3 * n + 1]; pz = a.x[3 * n + 2];
+    m = a.motion_mask ? a.motion_mask[n] : 1.0f;
+    g[0] = a.g_xyz[3 * n]; g[1] = a.g_xyz[3 * n + 1]; g[2] = a.g_xyz[3 * n + 2];
+    const float4 hh = reinterpret_cast<const float4*>(a.g_rot)[n];
+    h[0] = hh.x; h[1] = hh.y; h[2] = hh.z; h[3] = hh.w;
+  }
+  const float gh[3] = {g[0] * m, g[1] * m, g[2] * m};
+  const float hh4[4] = {h[0] * m, h[1] * m, h[2] * m, h[3] * m};
+  // pass 1: normaliser and blended outputs
+  float M[12], qa[4] = {0.f, 0.f, 0.f, 0.f}, sum = 0.f;
+#pragma unroll
+  for (int e = 0; e < 12; e++) M[e] = 0.f;
+  for (int k = 0; k < B; k++) {
+    const Bone& b = bones[k];
+    const float d2 = bone_d2(b, px, py, pz);
+    if (a.K > 0 && !topk_selected(bones, B, a.K, px, py, pz, k, d2)) continue;
+    const float v = fast_exp(-d2 * b.inv2r2) + 1e-7f;
+    sum += v;
+#pragma unroll
+    for (int e = 0; e < 12; e++) M[e] += v * b.G[e];
+#pragma unroll
+    for (int e = 0; e < 4; e++) qa[e] += v * b.q[e];
+  }
+  const float inv = valid ? 1.0f / sum : 0.f;
+  const float ax = (M[0] * px + M[1] * py + M[2] * pz + M[3]) * inv;
+  const float ay = (M[4] * px + M[5] * py + M[6] * pz + M[7]) * inv;
+  const float az = (M[8] * px + M[9] * py + M[10] * pz + M[11]) * inv;
+  const float qv[4] = {qa[0] * inv, qa[1] * inv, qa[2] * inv, qa[3] * inv};
+  // S = sum_j w_j dL/dw_j
+  const float S = gh[0] * ax + gh[1] * ay + gh[2] * az + hh4[0] * qv[0] + hh4[1] * qv[1] + hh4[2] * qv[2] + hh4[3] * qv[3];
+  if (valid && a.dmask) {
+    const float gxs = a.global_trans[0], gys = a.global_trans[1], gzs = a.global_trans[2];
+    a.dmask[n] = g[0] * (ax + gxs - px) + g[1] * (ay + gys - py) + g[2] * (az + gzs - pz) + h[0] * qv[0] + h[1] * qv[1] +
+                 h[2] * qv[2] + h[3] * qv[3];
+  }
+  // pass 2: per-bone contributions, reduced over the wave
+  const float P[12] = {gh[0] * px, gh[0] * py, gh[0] * pz, gh[0], gh[1] * px, gh[1] * py, gh[1] * pz, gh[1],
+                       gh[2] * px, gh[2] * py, gh[2] * pz, gh[2]};
+  for (int k = 0; k < B; k++) {
+    const Bone& b = bones[k];
+    const float d2 = bone_d2(b, px, py, pz);
+    float w = 0.f, r = 0.f;
+    const bool sel = valid && !(a.K > 0 && !topk_selected(bones, B, a.K, px, py, pz, k, d2));
+    if (sel) {
+      const float u = fast_exp(-d2 * b.inv2r2);
+      w = (u + 1e-7f) * inv;
+      const float Ax = b.G[0] * px + b.G[1] * py + b.G[2] * pz + b.G[3];
+      const float Ay = b.G[4] * px + b.G[5] * py + b.G[6] * pz + b.G[7];
+      const float Az = b.G[8] * px + b.G[9] * py + b.G[10] * pz + b.G[11];
+      const float dLdw = gh[0] * Ax + gh[1] * Ay + gh[2] * Az + hh4[0] * b.q[0] + hh4[1] * b.q[1] + hh4[2] * b.q[2] + hh4[3] * b.q[3];
+      const float dLdv = (dLdw - S) * inv;
+      r = dLdv * u * d2 * (2.0f * b.inv2r2);
+    }
+    float red[13];
+#pragma unroll
+    for (int e = 0; e < 12; e++) red[e] = wave_sum(w * P[e]);
+    red[12] = wave_sum(r);
+    if (lane == 63) {
+#pragma unroll
+      for (int e = 0; e < 13; e++) atomicAdd(&s_acc[k][e], red[e]);
+    }
+  }
+  const float t0 = wave_sum(gh[0]), t1 = wave_sum(gh[1]), t2 = wave_sum(gh[2]);
+  if (lane == 63) { atomicAdd(&s_gt[0], t0); atomicAdd(&s_gt[1], t1); atomicAdd(&s_gt[2], t2); }
+  __syncthreads();
+  for (int e = threadIdx.x; e < B * 13; e += 256) {
+    const int k = e / 13, c = e % 13;
+    const float v = s_acc[k][c];
+    if (c < 12) atomicAdd(&a.dG[12 * (k + 1) + c], v);
+    else atomicAdd(&a.drho[k + 1], v);
+  }
+  if (threadIdx.x < 3) atomicAdd(&a.dgt[threadIdx.x], s_gt[threadIdx.x]);
+}
+
+}  // namespace riggs
+
+using namespace riggs;
+
+extern "C" {
+
+int riggs_fk_forward(int32_t J, const float* local_rot, const float* joints, const int32_t* parents,
+                     const float* global_trans, float* transforms, float* node_rot, float* d_nodes,
+                     riggs_stream stream) {
+  RIGGS_REQUIRE(J >= 1 && J <= MAX_J, "num_joints must be in [1, 64]");
+  hipLaunchKernelGGL(fk_forward_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, J, local_rot, joints, parents,
+                     global_trans, transforms, node_rot, d_nodes);
+  RIGGS_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int riggs_fk_backward(int32_t J, const float* local_rot, const float* joints, const int32_t* parents,
+                      const float* dL_dtransforms, const float* dL_dd_nodes, float* dL_dlocal_rot,
+                      float* dL_dglobal_trans, riggs_stream stream) {
+  RIGGS_REQUIRE(J >= 1 && J <= MAX_J, "num_joints must be in [1, 64]");
+  hipLaunchKernelGGL(fk_backward_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, J, local_rot, joints, parents,
+                     dL_dtransforms, dL_dd_nodes, dL_dlocal_rot, dL_dglobal_trans);
+  RIGGS_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+static int fill_lbs(LbsArgs& a, int32_t N, int32_t J, int32_t K, const float* x, const float* joints,
+                    const int32_t* parents, const float* rho, const float* transforms, const float* node_rot,
+                    const float* gt, const float* mask) {
+  RIGGS_REQUIRE(J >= 2 && J <= MAX_J, "num_joints must be in [2, 64]");
+  RIGGS_REQUIRE(N >= 0, "num_points < 0");
+  RIGGS_REQUIRE(K < J, "K must be < num_joints");
+  memset(&a, 0, sizeof(a));
+  a.N = N; a.J = J; a.K = K; a.x = x; a.joints = joints; a.parents = parents; a.node_radius_log = rho;
+  a.transforms = transforms; a.node_rot = node_rot; a.global_trans = gt; a.motion_mask = mask;
+  return 0;
+}
+
+int riggs_lbs_forward(int32_t N, int32_t J, int32_t K, const float* x, const float* joints, const int32_t* parents,
+                      const float* node_radius_log, const float* transforms, const float* node_rot,
+                      const float* global_trans, const float* motion_mask, float* d_xyz, float* d_rotation,
+                      float* nn_weight, int64_t* nn_idx, riggs_stream stream) {
+  LbsArgs a;
+  int rc = fill_lbs(a, N, J, K, x, joints, parents, node_radius_log, transforms, node_rot, global_trans, motion_mask);
+  if (rc) return rc;
+  a.d_xyz = d_xyz; a.d_rot = d_rotation; a.nn_weight = nn_weight; a.nn_idx = nn_idx;
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(lbs_forward_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+  RIGGS_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int riggs_lbs_backward(int32_t N, int32_t J, int32_t K, const float* x, const float* joints, const int32_t* parents,
+                       const float* node_radius_log, const float* transforms, const float* node_rot,
+                       const float* global_trans, const float* motion_mask, const float* g_xyz, const float* g_rot,
+                       float* dL_dtransforms, float* dL_dnode_radius_log, float* dL_dglobal_trans,
+                       float* dL_dmotion_mask, riggs_stream stream) {
+  LbsArgs a;
+  int rc = fill_lbs(a, N, J, K, x, joints, parents, node_radius_log, transforms, node_rot, global_trans, motion_mask);
+  if (rc) return rc;
+  a.g_xyz = g_xyz; a.g_rot = g_rot; a.dG = dL_dtransforms; a.drho = dL_dnode_radius_log; a.dgt = dL_dglobal_trans;
+  a.dmask = dL_dmotion_mask;
+  hipStream_t s = (hipStream_t)stream;
+  RIGGS_HIP_CHECK(hipMemsetAsync(dL_dtransforms, 0, (size_t)J * 48, s));
+  RIGGS_HIP_CHECK(hipMemsetAsync(dL_dnode_radius_log, 0, (size_t)J * 4, s));
+  RIGGS_HIP_CHECK(hipMemsetAsync(dL_dglobal_trans, 0, 12, s));
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(lbs_backward_kernel, dim3((N + 255) / 256), dim3(256), 0, s, a);
+  RIGGS_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,347 @@
+// Per-Gaussian stage of the rasterizer (SURVEY.md §8 A7+A8, A11): projection, covariance,
+// SH colour, tile rectangle — forward and backward — with the optional fused "render glue".
+//
+// HBM-bound streaming kernels: one thread per Gaussian, 256-thread workgroups (4 waves),
+// every output written once as 16-byte records where the layout is ours (xyd / conic_o / rgb
+// float4 arrays) so that the compositing kernels gather whole 16-B words.
+//
+// This translation unit is compiled with FP contraction OFF (gauss_math.h) — geometry is
+// bit-identical to oracle/raster_ref.c.
+#include "gauss_math.h"
+#include "raster_internal.h"
+
+namespace riggs {
+
+__device__ __forceinline__ void load_inputs(const PreArgs& a, int i, GlueIn& g, bool need_sr) {
+  g.p[0] = a.means3D[3 * i]; g.p[1] = a.means3D[3 * i + 1]; g.p[2] = a.means3D[3 * i + 2];
+  if (a.glue) {
+    if (a.d_xyz) { g.p[0] = g.p[0] + a.d_xyz[3 * i]; g.p[1] = g.p[1] + a.d_xyz[3 * i + 1]; g.p[2] = g.p[2] + a.d_xyz[3 * i + 2]; }
+    g.o = sigmoidf_(a.opac[i]);
+    if (need_sr) {
+      if (a.isotropic) { float s = expf(a.scales[i]); g.es[0] = g.es[1] = g.es[2] = s; }
+      else { g.es[0] = expf(a.scales[3 * i]); g.es[1] = expf(a.scales[3 * i + 1]); g.es[2] = expf(a.scales[3 * i + 2]); }
+      g.s[0] = g.es[0]; g.s[1] = g.es[1]; g.s[2] = g.es[2];
+      if (a.d_scaling) { g.s[0] = g.s[0] + a.d_scaling[3 * i]; g.s[1] = g.s[1] + a.d_scaling[3 * i + 1]; g.s[2] = g.s[2] + a.d_scaling[3 * i + 2]; }
+      const float4 r = reinterpret_cast<const float4*>(a.rots)[i];
+      g.v[0] = r.x; g.v[1] = r.y; g.v[2] = r.z; g.v[3] = r.w;
+      if (a.d_rot) {
+        const float4 d = reinterpret_cast<const float4*>(a.d_rot)[i];
+        g.v[0] = g.v[0] + d.x; g.v[1] = g.v[1] + d.y; g.v[2] = g.v[2] + d.z; g.v[3] = g.v[3] + d.w;
+      }
+      // F.normalize(v, eps=1e-12): v / max(|v|, eps)   (scene/gaussian_model.py:116-118)
+      float n = sqrtf(g.v[0] * g.v[0] + g.v[1] * g.v[1] + g.v[2] * g.v[2] + g.v[3] * g.v[3]);
+      g.vnorm = fmaxf(n, 1e-12f);
+      g.q[0] = g.v[0] / g.vnorm; g.q[1] = g.v[1] / g.vnorm; g.q[2] = g.v[2] / g.vnorm; g.q[3] = g.v[3] / g.vnorm;
+    }
+  } else {
+    g.o = a.opac[i];
+    if (need_sr) {
+      g.s[0] = a.scales[3 * i]; g.s[1] = a.scales[3 * i + 1]; g.s[2] = a.scales[3 * i + 2];
+      const float4 r = reinterpret_cast<const float4*>(a.rots)[i];
+      g.q[0] = r.x; g.q[1] = r.y; g.q[2] = r.z; g.q[3] = r.w;
+      g.vnorm = 1.f;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.N) return;
+  const float* __restrict__ V = a.view;
+  const float* __restrict__ P = a.proj;
+  a.radii[i] = 0;
+  a.tiles[i] = 0;
+  a.depth_key[i] = 0xFFFFFFFFu;  // culled Gaussians sort last
+  a.order_in[i] = (uint32_t)i;
+  GlueIn g;
+  const bool need_sr = (a.cov3D_precomp == nullptr);
+  load_inputs(a, i, g, need_sr);
+  const float* p = g.p;
+  float vz = V[2] * p[0] + V[6] * p[1] + V[10] * p[2] + V[14];
+  if (vz <= RIGGS_NEAR_Z) return;
+  float hx = P[0] * p[0] + P[4] * p[1] + P[8] * p[2] + P[12];
+  float hy = P[1] * p[0] + P[5] * p[1] + P[9] * p[2] + P[13];
+  float hw = P[3] * p[0] + P[7] * p[1] + P[11] * p[2] + P[15];
+  float pw = 1.0f / (hw + 0.0000001f);
+  float ndcx = hx * pw, ndcy = hy * pw;
+  float c6[6];
+  if (a.cov3D_precomp) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) c6[k] = a.cov3D_precomp[6 * i + k];
+  } else {
+    cov3d_from_scale_rot(g.s, a.mod, g.q, c6);
+  }
+  float fx = a.W / (2.0f * a.tanx), fy = a.H / (2.0f * a.tany);
+  Cov2D cv;
+  cov2d_eval(p, c6, V, fx, fy, a.tanx, a.tany, cv);
+  float det = cv.a * cv.c - cv.b * cv.b;
+  if (det == 0.0f) return;
+  float det_inv = 1.0f / det;
+  float mid = 0.5f * (cv.a + cv.c);
+  float root = sqrtf(fmaxf(0.1f, mid * mid - det));
+  float lam1 = mid + root, lam2 = mid - root;
+  float rad = ceilf(3.0f * sqrtf(fmaxf(lam1, lam2)));
+  float px = ((ndcx + 1.0f) * a.W - 1.0f) * 0.5f;
+  float py = ((ndcy + 1.0f) * a.H - 1.0f) * 0.5f;
+  int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE, gy = (a.H + RIGGS_TILE - 1) / RIGGS_TILE;
+  int ir = (int)rad;
+  int x0 = (int)((px - ir) / (float)RIGGS_TILE), y0 = (int)((py - ir) / (float)RIGGS_TILE);
+  int x1 = (int)((px + ir + RIGGS_TILE - 1) / (float)RIGGS_TILE), y1 = (int)((py + ir + RIGGS_TILE - 1) / (float)RIGGS_TILE);
+  x0 = min(gx, max(0, x0)); x1 = min(gx, max(0, x1));
+  y0 = min(gy, max(0, y0)); y1 = min(gy, max(0, y1));
+  if ((x1 - x0) * (y1 - y0) == 0) return;
+
+  float rgbv[3];
+  uint8_t cl = 0;
+  if (a.colors_precomp) {
+    rgbv[0] = a.colors_precomp[3 * i]; rgbv[1] = a.colors_precomp[3 * i + 1]; rgbv[2] = a.colors_precomp[3 * i + 2];
+  } else {
+    float dx = p[0] - a.campos[0], dy = p[1] - a.campos[1], dz = p[2] - a.campos[2];
+    float len = sqrtf(dx * dx + dy * dy + dz * dz);
+    dx = dx / len; dy = dy / len; dz = dz / len;
+    float B[16];
+    sh_basis(a.deg, dx, dy, dz, B);
+    const int nb = (a.deg + 1) * (a.deg + 1);
+    const float* sh = a.shs + (size_t)i * a.M * 3;
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+    if (a.M == 16) {  // 192-byte record: twelve 16-B loads
+      const float4* sh4 = reinterpret_cast<const float4*>(sh);
+      float c[48];
+#pragma unroll
+      for (int k = 0; k < 12; k++) {
+        if (k * 4 < nb * 3) { float4 t = sh4[k]; c[4 * k] = t.x; c[4 * k + 1] = t.y; c[4 * k + 2] = t.z; c[4 * k + 3] = t.w; }
+        else { c[4 * k] = c[4 * k + 1] = c[4 * k + 2] = c[4 * k + 3] = 0.f; }
+      }
+#pragma unroll
+      for (int k = 0; k < 16; k++)
+        if (k < nb) { r0 += B[k] * c[3 * k]; r1 += B[k] * c[3 * k + 1]; r2 += B[k] * c[3 * k + 2]; }
+    } else {
+      for (int k = 0; k < nb; k++) { r0 += B[k] * sh[3 * k]; r1 += B[k] * sh[3 * k + 1]; r2 += B[k] * sh[3 * k + 2]; }
+    }
+    r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
+    cl = (uint8_t)((r0 < 0.f ? 1 : 0) | (r1 < 0.f ? 2 : 0) | (r2 < 0.f ? 4 : 0));
+    rgbv[0] = fmaxf(r0, 0.f); rgbv[1] = fmaxf(r1, 0.f); rgbv[2] = fmaxf(r2, 0.f);
+  }
+  a.radii[i] = ir;
+  a.xyd[i] = make_float4(px, py, vz, 0.f);
+  a.conic_o[i] = make_float4(cv.c * det_inv, -cv.b * det_inv, cv.a * det_inv, g.o);
+  a.rgb[i] = make_float4(rgbv[0], rgbv[1], rgbv[2], 0.f);
+#pragma unroll
+  for (int k = 0; k < 6; k++) a.cov3D[6 * i + k] = c6[k];
+  a.clamped[i] = cl;
+  a.tiles[i] = (uint32_t)((x1 - x0) * (y1 - y0));
+  a.rect[i] = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
+  a.depth_key[i] = __float_as_uint(vz);
+}
+
+// ---------------------------------------------------------------------------- backward
+__global__ __launch_bounds__(256) void preprocess_bwd_kernel(PreBwdArgs b) {
+  const PreArgs& a = b.f;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.N) return;
+  const float* __restrict__ V = a.view;
+  const float* __restrict__ P = a.proj;
+  const bool visible = a.radii[i] > 0;
+  const bool sh_mode = (a.colors_precomp == nullptr);
+  const bool need_sr = (a.cov3D_precomp == nullptr);
+  float gm[3] = {0.f, 0.f, 0.f};
+  float g2x = 0.f, g2y = 0.f, g_op = 0.f;
+  float gcol[3] = {0.f, 0.f, 0.f};
+  float gs[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f}, gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  GlueIn g;
+  g.vnorm = 1.f;
+  if (visible) {
+    load_inputs(a, i, g, need_sr);
+    const float* p = g.p;
+    const float* acc = b.g_mean2D_conic + (size_t)i * RIGGS_GACC;
+    g2x = acc[0]; g2y = acc[1];
+    const float gA = acc[2], gB = acc[3], gC = acc[4];
+    g_op = acc[5];
+    gcol[0] = acc[6]; gcol[1] = acc[7]; gcol[2] = acc[8];
+    const float gd = acc[9];
+    float c6[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) c6[k] = a.cov3D[6 * i + k];
+    float fx = a.W / (2.0f * a.tanx), fy = a.H / (2.0f * a.tany);
+    Cov2D cv;
+    cov2d_eval(p, c6, V, fx, fy, a.tanx, a.tany, cv);
+    const float ca = cv.a, cb = cv.b, cc = cv.c;
+    const float det = ca * cc - cb * cb;
+    const float d2inv = 1.0f / (det * det + 0.0000001f);
+    const float dL_da = d2inv * (-cc * cc * gA + cb * cc * gB - cb * cb * gC);
+    const float dL_db = d2inv * (2.f * cb * cc * gA - (det + 2.f * cb * cb) * gB + 2.f * ca * cb * gC);
+    const float dL_dc = d2inv * (-cb * cb * gA + ca * cb * gB - ca * ca * gC);
+    const float* M2 = cv.M2;
+    const float hb = 0.5f * dL_db;
+    float DM[6];
+#pragma unroll
+    for (int j = 0; j < 3; j++) { DM[j] = dL_da * M2[j] + hb * M2[3 + j]; DM[3 + j] = hb * M2[j] + dL_dc * M2[3 + j]; }
+    float GS[9];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) GS[3 * r + j] = M2[r] * DM[j] + M2[3 + r] * DM[3 + j];
+    const float S[9] = {c6[0], c6[1], c6[2], c6[1], c6[3], c6[4], c6[2], c6[4], c6[5]};
+    float dM2[6];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+        dM2[3 * r + j] = 2.f * (DM[3 * r] * S[j] + DM[3 * r + 1] * S[3 + j] + DM[3 * r + 2] * S[6 + j]);
+    const float dJ00 = dM2[0] * V[0] + dM2[1] * V[4] + dM2[2] * V[8];
+    const float dJ02 = dM2[0] * V[2] + dM2[1] * V[6] + dM2[2] * V[10];
+    const float dJ11 = dM2[3] * V[1] + dM2[4] * V[5] + dM2[5] * V[9];
+    const float dJ12 = dM2[3] * V[2] + dM2[4] * V[6] + dM2[5] * V[10];
+    const float tz = 1.f / cv.tz, tz2 = tz * tz, tz3 = tz2 * tz;
+    const float dtx = (cv.clamp_x ? 0.f : 1.f) * (-fx * tz2 * dJ02);
+    const float dty = (cv.clamp_y ? 0.f : 1.f) * (-fy * tz2 * dJ12);
+    const float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2.f * fx * cv.tx) * tz3 * dJ02 + (2.f * fy * cv.ty) * tz3 * dJ12;
+    gm[0] = V[0] * dtx + V[1] * dty + V[2] * dtz;
+    gm[1] = V[4] * dtx + V[5] * dty + V[6] * dtz;
+    gm[2] = V[8] * dtx + V[9] * dty + V[10] * dtz;
+    // 2-D mean (NDC-scaled) through the perspective divide
+    const float hx = P[0] * p[0] + P[4] * p[1] + P[8] * p[2] + P[12];
+    const float hy = P[1] * p[0] + P[5] * p[1] + P[9] * p[2] + P[13];
+    const float hw = P[3] * p[0] + P[7] * p[1] + P[11] * p[2] + P[15];
+    const float mw = 1.0f / (hw + 0.0000001f);
+    const float mul1 = hx * mw * mw, mul2 = hy * mw * mw;
+    gm[0] += (P[0] * mw - P[3] * mul1) * g2x + (P[1] * mw - P[3] * mul2) * g2y;
+    gm[1] += (P[4] * mw - P[7] * mul1) * g2x + (P[5] * mw - P[7] * mul2) * g2y;
+    gm[2] += (P[8] * mw - P[11] * mul1) * g2x + (P[9] * mw - P[11] * mul2) * g2y;
+    gm[0] += V[2] * gd; gm[1] += V[6] * gd; gm[2] += V[10] * gd;
+
+    if (sh_mode) {
+      float dx = p[0] - a.campos[0], dy = p[1] - a.campos[1], dz = p[2] - a.campos[2];
+      const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+      const float ux = dx / len, uy = dy / len, uz = dz / len;
+      float B[16];
+      sh_basis(a.deg, ux, uy, uz, B);
+      const int nb = (a.deg + 1) * (a.deg + 1);
+      const uint8_t cl = a.clamped[i];
+      const float gc0 = (cl & 1) ? 0.f : gcol[0], gc1 = (cl & 2) ? 0.f : gcol[1], gc2 = (cl & 4) ? 0.f : gcol[2];
+      const float* sh = a.shs + (size_t)i * a.M * 3;
+      float* gsh = b.dL_dsh + (size_t)i * a.M * 3;
+      float w[16];
+      if (a.M == 16) {
+        const float4* sh4 = reinterpret_cast<const float4*>(sh);
+        float4* gsh4 = reinterpret_cast<float4*>(gsh);
+        float c[48], o[48];
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+          if (k * 4 < nb * 3) { float4 t = sh4[k]; c[4 * k] = t.x; c[4 * k + 1] = t.y; c[4 * k + 2] = t.z; c[4 * k + 3] = t.w; }
+          else { c[4 * k] = c[4 * k + 1] = c[4 * k + 2] = c[4 * k + 3] = 0.f; }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          const float bk = (k < nb) ? B[k] : 0.f;
+          o[3 * k] = bk * gc0; o[3 * k + 1] = bk * gc1; o[3 * k + 2] = bk * gc2;
+          w[k] = c[3 * k] * gc0 + c[3 * k + 1] * gc1 + c[3 * k + 2] * gc2;
+        }
+#pragma unroll
+        for (int k = 0; k < 12; k++) gsh4[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+      } else {
+        for (int k = 0; k < a.M; k++) {
+          const float bk = (k < nb) ? B[k] : 0.f;
+          gsh[3 * k] = bk * gc0; gsh[3 * k + 1] = bk * gc1; gsh[3 * k + 2] = bk * gc2;
+          w[k] = (k < nb) ? (sh[3 * k] * gc0 + sh[3 * k + 1] * gc1 + sh[3 * k + 2] * gc2) : 0.f;
+        }
+      }
+      float gdir[3];
+      sh_dir_grad(a.deg, ux, uy, uz, w, gdir);
+      const float dot = ux * gdir[0] + uy * gdir[1] + uz * gdir[2];
+      gm[0] += (gdir[0] - ux * dot) / len; gm[1] += (gdir[1] - uy * dot) / len; gm[2] += (gdir[2] - uz * dot) / len;
+    }
+    if (!need_sr) {
+      gcov[0] = GS[0]; gcov[1] = 2.f * GS[1]; gcov[2] = 2.f * GS[2];
+      gcov[3] = GS[4]; gcov[4] = 2.f * GS[5]; gcov[5] = GS[8];
+    } else {
+      float Rm[9];
+      quat_to_R(g.q, Rm);
+      const float s3[3] = {a.mod * g.s[0], a.mod * g.s[1], a.mod * g.s[2]};
+      float Mm[9], dMm[9], dR[9];
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Mm[3 * r + j] = Rm[3 * r + j] * s3[j];
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+          dMm[3 * r + j] = 2.f * (GS[3 * r] * Mm[j] + GS[3 * r + 1] * Mm[3 + j] + GS[3 * r + 2] * Mm[6 + j]);
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const float ds = Rm[j] * dMm[j] + Rm[3 + j] * dMm[3 + j] + Rm[6 + j] * dMm[6 + j];
+        gs[j] = a.mod * ds;
+#pragma unroll
+        for (int r = 0; r < 3; r++) dR[3 * r + j] = s3[j] * dMm[3 * r + j];
+      }
+      const float r = g.q[0], x = g.q[1], y = g.q[2], z = g.q[3];
+      gq[0] = 2.f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
+      gq[1] = 2.f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.f * x * dR[8]);
+      gq[2] = 2.f * (-2.f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.f * y * dR[8]);
+      gq[3] = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+    }
+  } else if (sh_mode && b.dL_dsh) {
+    float* gsh = b.dL_dsh + (size_t)i * a.M * 3;
+    if (a.M == 16) {
+      float4* gsh4 = reinterpret_cast<float4*>(gsh);
+#pragma unroll
+      for (int k = 0; k < 12; k++) gsh4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      for (int k = 0; k < a.M * 3; k++) gsh[k] = 0.f;
+    }
+  }
+  // ---- outputs (with the chain rule of the render glue when fused) ----
+  b.dL_dmeans3D[3 * i] = gm[0]; b.dL_dmeans3D[3 * i + 1] = gm[1]; b.dL_dmeans3D[3 * i + 2] = gm[2];
+  b.dL_dmeans2D[3 * i] = g2x; b.dL_dmeans2D[3 * i + 1] = g2y; b.dL_dmeans2D[3 * i + 2] = 0.f;
+  if (b.dL_dcolors) {
+    const bool pc = !sh_mode;
+    b.dL_dcolors[3 * i] = pc ? gcol[0] : 0.f; b.dL_dcolors[3 * i + 1] = pc ? gcol[1] : 0.f; b.dL_dcolors[3 * i + 2] = pc ? gcol[2] : 0.f;
+  }
+  if (a.glue) {
+    // opacity = sigmoid(raw): d/draw = o (1 - o)
+    b.dL_dopac[i] = visible ? g_op * g.o * (1.f - g.o) : 0.f;
+    if (b.dL_dscales) {
+      // scales = exp(raw): d/draw = s ; isotropic: the three columns collapse onto column 0
+      if (a.isotropic) b.dL_dscales[i] = visible ? (gs[0] * g.es[0] + gs[1] * g.es[1] + gs[2] * g.es[2]) : 0.f;
+      else {
+        b.dL_dscales[3 * i] = visible ? gs[0] * g.es[0] : 0.f;
+        b.dL_dscales[3 * i + 1] = visible ? gs[1] * g.es[1] : 0.f;
+        b.dL_dscales[3 * i + 2] = visible ? gs[2] * g.es[2] : 0.f;
+      }
+      if (b.dL_dd_scaling) { b.dL_dd_scaling[3 * i] = gs[0]; b.dL_dd_scaling[3 * i + 1] = gs[1]; b.dL_dd_scaling[3 * i + 2] = gs[2]; }
+    }
+    if (b.dL_drots) {
+      // q = v / |v| : dL/dv = (gq - q (q . gq)) / |v|
+      float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (visible) {
+        const float dot = g.q[0] * gq[0] + g.q[1] * gq[1] + g.q[2] * gq[2] + g.q[3] * gq[3];
+        o4 = make_float4((gq[0] - g.q[0] * dot) / g.vnorm, (gq[1] - g.q[1] * dot) / g.vnorm,
+                         (gq[2] - g.q[2] * dot) / g.vnorm, (gq[3] - g.q[3] * dot) / g.vnorm);
+      }
+      reinterpret_cast<float4*>(b.dL_drots)[i] = o4;
+    }
+  } else {
+    b.dL_dopac[i] = g_op;
+    if (b.dL_dscales) { b.dL_dscales[3 * i] = gs[0]; b.dL_dscales[3 * i + 1] = gs[1]; b.dL_dscales[3 * i + 2] = gs[2]; }
+    if (b.dL_drots) reinterpret_cast<float4*>(b.dL_drots)[i] = make_float4(gq[0], gq[1], gq[2], gq[3]);
+  }
+  if (b.dL_dcov3D) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) b.dL_dcov3D[6 * i + k] = gcov[k];
+  }
+}
+
+// host-side launchers (called from capi.hip)
+int launch_preprocess_fwd(const PreArgs& a, hipStream_t s) {
+  if (a.N == 0) return 0;
+  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((a.N + 255) / 256), dim3(256), 0, s, a);
+  return 0;
+}
+int launch_preprocess_bwd(const PreBwdArgs& b, hipStream_t s) {
+  if (b.f.N == 0) return 0;
+  hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((b.f.N + 255) / 256), dim3(256), 0, s, b);
+  return 0;
+}
+
+}  // namespace riggs

@@ -1,0 +1,65 @@
+// Internal argument blocks and launchers shared by the rasterizer translation units.
+#pragma once
+#include "common.h"
+
+namespace riggs {
+
+struct PreArgs {
+  int N, deg, M, W, H, glue, isotropic;
+  float tanx, tany, mod;
+  const float *view, *proj, *campos;
+  const float *means3D, *shs, *colors_precomp, *opac, *scales, *rots, *cov3D_precomp, *d_xyz, *d_rot, *d_scaling;
+  int32_t* radii;
+  float4 *xyd, *conic_o, *rgb;
+  float* cov3D;
+  uint8_t* clamped;
+  uint32_t* tiles;
+  ushort4* rect;
+  uint32_t *depth_key, *order_in;
+};
+
+struct PreBwdArgs {
+  PreArgs f;                     // forward inputs (radii/xyd/... unused here except radii, cov3D, clamped)
+  const float* g_mean2D_conic;   // workspace: per Gaussian [mean2D.x, mean2D.y, gA, gB, gC, g_opacity, g_r, g_g, g_b, g_depth]
+  float *dL_dmeans3D, *dL_dmeans2D, *dL_dsh, *dL_dcolors, *dL_dopac, *dL_dscales, *dL_drots, *dL_dcov3D, *dL_dd_scaling;
+};
+#define RIGGS_GACC 12  // floats per Gaussian in the render-backward accumulator (padded to 48 B)
+
+
+int launch_preprocess_fwd(const PreArgs& a, hipStream_t s);
+int launch_preprocess_bwd(const PreBwdArgs& b, hipStream_t s);
+
+struct RenderArgs {
+  int W, H;
+  const uint2* ranges;
+  const uint32_t* point_list;
+  const float4 *xyd, *conic_o, *rgb;
+  const float* bg;
+  float* final_T;
+  uint32_t* n_contrib;
+  float *out_color, *out_depth, *out_alpha;
+};
+int launch_render_fwd(const RenderArgs& a, hipStream_t s);
+
+struct RenderBwdArgs {
+  int W, H;
+  const uint2* ranges;
+  const uint32_t* point_list;
+  const float4 *xyd, *conic_o, *rgb;
+  const float* bg;
+  const float* final_T;
+  const uint32_t* n_contrib;
+  const float *dL_dcolor, *dL_ddepth, *dL_dalpha;
+  float* gacc;  // (N, RIGGS_GACC) accumulators, zeroed by the caller
+};
+int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s);
+
+// binning
+int launch_gather_tiles(int N, const uint32_t* order, const uint32_t* tiles, uint32_t* tt_sorted, hipStream_t s);
+int launch_emit(int N, int grid_x, int n_tiles, int64_t cap, const uint32_t* order, const uint32_t* offsets,
+                const uint32_t* tiles, const ushort4* rect, uint32_t* keys, uint32_t* vals, uint32_t* counters,
+                hipStream_t s);
+int launch_ranges(int64_t n, int n_tiles, const uint32_t* keys_sorted, const uint32_t* counters, uint2* ranges,
+                  hipStream_t s);
+
+}  // namespace riggs

@@ -1,0 +1,278 @@
+// Tile binning and per-tile alpha compositing, forward and backward.
+//
+// Workgroup = one 16x16 tile = 256 threads = 4 wave64 (a wave owns 4 rows x 16 columns).
+// Instances of the tile are staged 256 at a time through LDS as three float4 records
+// (48 B / instance, gathered as whole 16-B words), then every pixel walks the batch with
+// wave-uniform LDS addresses (broadcast reads, no bank conflicts).
+#include "raster_internal.h"
+
+namespace riggs {
+
+#define ALPHA_MIN (1.0f / 255.0f)
+#define ALPHA_MAX 0.99f
+#define T_EPS 0.0001f
+#define LOG2E 1.4426950408889634f
+
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * LOG2E); }
+
+// ------------------------------------------------------------------ binning helpers
+__global__ __launch_bounds__(256) void gather_tiles_kernel(int N, const uint32_t* __restrict__ order,
+                                                           const uint32_t* __restrict__ tiles,
+                                                           uint32_t* __restrict__ tt_sorted) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s < N) tt_sorted[s] = tiles[order[s]];
+}
+
+// duplicateWithKeys in DEPTH order: sorted slot s owns instances [offsets[s-1], offsets[s]) and
+// writes (tile id, Gaussian index) row-major over its rectangle.  A later STABLE sort by tile id
+// then yields exactly the order of a 64-bit (tile | depth-bits) key sort with ties in ascending
+// Gaussian index.  Also pads [R, cap) with the sentinel tile id n_tiles.
+__global__ __launch_bounds__(256) void emit_kernel(int N, int grid_x, int n_tiles, int64_t cap,
+                                                   const uint32_t* __restrict__ order,
+                                                   const uint32_t* __restrict__ offsets,
+                                                   const uint32_t* __restrict__ tiles,
+                                                   const ushort4* __restrict__ rect, uint32_t* __restrict__ keys,
+                                                   uint32_t* __restrict__ vals, uint32_t* __restrict__ counters) {
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint32_t R = N > 0 ? offsets[N - 1] : 0u;
+  if (s == 0) { counters[0] = R; counters[1] = ((int64_t)R > cap) ? 1u : 0u; }
+  if (s < N) {
+    const uint32_t g = order[s];
+    const uint32_t n = tiles[g];
+    if (n != 0) {
+      int64_t off = (s == 0) ? 0 : offsets[s - 1];
+      const ushort4 rc = rect[g];
+      for (int y = rc.y; y < rc.w; y++)
+        for (int x = rc.x; x < rc.z; x++) {
+          if (off < cap) { keys[off] = (uint32_t)(y * grid_x + x); vals[off] = g; }
+          off++;
+        }
+    }
+  }
+  // pad region (grid covers max(N, cap) threads)
+  if (s >= (int64_t)R && s < cap) { keys[s] = (uint32_t)n_tiles; vals[s] = 0u; }
+}
+
+__global__ __launch_bounds__(256) void ranges_kernel(int64_t n, int n_tiles, const uint32_t* __restrict__ keys,
+                                                     const uint32_t* __restrict__ counters,
+                                                     uint2* __restrict__ ranges) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t R = min((int64_t)counters[0], n);
+  if (i >= R) return;
+  const uint32_t k = keys[i];
+  if (i == 0) ranges[k].x = 0;
+  else {
+    const uint32_t pk = keys[i - 1];
+    if (pk != k) { ranges[pk].y = (uint32_t)i; ranges[k].x = (uint32_t)i; }
+  }
+  if (i == R - 1) ranges[k].y = (uint32_t)R;
+}
+
+int launch_gather_tiles(int N, const uint32_t* order, const uint32_t* tiles, uint32_t* tt_sorted, hipStream_t s) {
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(gather_tiles_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, order, tiles, tt_sorted);
+  return 0;
+}
+int launch_emit(int N, int grid_x, int n_tiles, int64_t cap, const uint32_t* order, const uint32_t* offsets,
+                const uint32_t* tiles, const ushort4* rect, uint32_t* keys, uint32_t* vals, uint32_t* counters,
+                hipStream_t s) {
+  int64_t n = N > cap ? N : cap;
+  if (n < 1) n = 1;
+  hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, N, grid_x, n_tiles, cap, order,
+                     offsets, tiles, rect, keys, vals, counters);
+  return 0;
+}
+int launch_ranges(int64_t n, int n_tiles, const uint32_t* keys_sorted, const uint32_t* counters, uint2* ranges,
+                  hipStream_t s) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, n_tiles, keys_sorted,
+                     counters, ranges);
+  return 0;
+}
+
+// ------------------------------------------------------------------ render forward
+__global__ __launch_bounds__(256) void render_fwd_kernel(RenderArgs a) {
+  __shared__ float4 s_xyd[256];
+  __shared__ float4 s_con[256];
+  __shared__ float4 s_rgb[256];
+  const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE;
+  const int tile = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int pxi = (tile % gx) * RIGGS_TILE + (tid & 15);
+  const int pyi = (tile / gx) * RIGGS_TILE + (tid >> 4);
+  const bool inside = pxi < a.W && pyi < a.H;
+  const float pfx = (float)pxi, pfy = (float)pyi;
+  const uint2 range = a.ranges[tile];
+  const int total = (int)(range.y - range.x);
+  bool done = !inside;
+  float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f;
+  uint32_t contributor = 0, last = 0;
+  for (int base = 0; base < total; base += 256) {
+    if (__syncthreads_count(done) == 256) break;
+    const int nb = min(256, total - base);
+    if (tid < nb) {
+      const uint32_t id = a.point_list[range.x + base + tid];
+      s_xyd[tid] = a.xyd[id];
+      s_con[tid] = a.conic_o[id];
+      s_rgb[tid] = a.rgb[id];
+    }
+    __syncthreads();
+    for (int j = 0; !done && j < nb; j++) {
+      contributor++;
+      const float4 xy = s_xyd[j];
+      const float4 co = s_con[j];
+      const float dx = xy.x - pfx, dy = xy.y - pfy;
+      const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+      if (power > 0.0f) continue;
+      const float alpha = fminf(ALPHA_MAX, co.w * fast_exp(power));
+      if (alpha < ALPHA_MIN) continue;
+      const float test_T = T * (1.0f - alpha);
+      if (test_T < T_EPS) { done = true; continue; }
+      const float4 c = s_rgb[j];
+      const float w = alpha * T;
+      C0 += c.x * w; C1 += c.y * w; C2 += c.z * w;
+      D += xy.z * w; A += w;
+      T = test_T;
+      last = contributor;
+    }
+  }
+  if (inside) {
+    const size_t pid = (size_t)pyi * a.W + pxi, HW = (size_t)a.H * a.W;
+    a.final_T[pid] = T;
+    a.n_contrib[pid] = last;
+    a.out_color[pid] = C0 + T * a.bg[0];
+    a.out_color[HW + pid] = C1 + T * a.bg[1];
+    a.out_color[2 * HW + pid] = C2 + T * a.bg[2];
+    a.out_depth[pid] = D;
+    a.out_alpha[pid] = A;
+  }
+}
+
+int launch_render_fwd(const RenderArgs& a, hipStream_t s) {
+  const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE, gy = (a.H + RIGGS_TILE - 1) / RIGGS_TILE;
+  if (gx * gy == 0) return 0;
+  hipLaunchKernelGGL(render_fwd_kernel, dim3(gx * gy), dim3(256), 0, s, a);
+  return 0;
+}
+
+// ------------------------------------------------------------------ render backward
+// Back-to-front walk per pixel; per-instance gradient contributions are summed over the 64
+// pixels of a wave with DPP, the 4 waves meet in LDS, and ONE atomicAdd per value per
+// (tile, instance) goes to the per-Gaussian accumulator (48-B record).
+__global__ __launch_bounds__(256) void render_bwd_kernel(RenderBwdArgs a) {
+  __shared__ float4 s_xyd[256];
+  __shared__ float4 s_con[256];
+  __shared__ float4 s_rgb[256];
+  __shared__ uint32_t s_id[256];
+  __shared__ float s_part[4][10];
+  const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE;
+  const int tile = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int pxi = (tile % gx) * RIGGS_TILE + (tid & 15);
+  const int pyi = (tile / gx) * RIGGS_TILE + (tid >> 4);
+  const bool inside = pxi < a.W && pyi < a.H;
+  const float pfx = (float)pxi, pfy = (float)pyi;
+  const uint2 range = a.ranges[tile];
+  const int total = (int)(range.y - range.x);
+  const size_t pid = (size_t)pyi * a.W + pxi, HW = (size_t)a.H * a.W;
+  const float T_final = inside ? a.final_T[pid] : 0.f;
+  float T = T_final;
+  const int last = inside ? (int)a.n_contrib[pid] : 0;
+  float gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, gD = 0.f, gA = 0.f;
+  if (inside) {
+    gC0 = a.dL_dcolor[pid]; gC1 = a.dL_dcolor[HW + pid]; gC2 = a.dL_dcolor[2 * HW + pid];
+    if (a.dL_ddepth) gD = a.dL_ddepth[pid];
+    if (a.dL_dalpha) gA = a.dL_dalpha[pid];
+  }
+  const float bg_dot = a.bg[0] * gC0 + a.bg[1] * gC1 + a.bg[2] * gC2;
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accd = 0.f, acca = 0.f;
+  float lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, ld = 0.f, last_alpha = 0.f;
+  const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
+  // the block only needs instances [0, max_last) of the tile
+  int max_last = last;
+  for (int o = 32; o > 0; o >>= 1) max_last = max(max_last, __shfl_xor(max_last, o));
+  __shared__ int s_max[4];
+  if (lane == 0) s_max[wave] = max_last;
+  __syncthreads();
+  max_last = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+  max_last = min(max_last, total);
+
+  for (int hi = max_last; hi > 0; hi -= 256) {
+    const int lo = max(0, hi - 256);
+    const int nb = hi - lo;
+    __syncthreads();
+    if (tid < nb) {
+      // slot j holds instance position hi-1-j (back-to-front)
+      const uint32_t id = a.point_list[range.x + (hi - 1 - tid)];
+      s_id[tid] = id;
+      s_xyd[tid] = a.xyd[id];
+      s_con[tid] = a.conic_o[id];
+      s_rgb[tid] = a.rgb[id];
+    }
+    __syncthreads();
+    for (int j = 0; j < nb; j++) {
+      const int pos = hi - 1 - j;  // 0-based position in the tile list
+      float v_mx = 0.f, v_my = 0.f, v_ca = 0.f, v_cb = 0.f, v_cc = 0.f, v_op = 0.f, v_r = 0.f, v_g = 0.f, v_b = 0.f,
+            v_d = 0.f;
+      bool active = pos < last;
+      if (active) {
+        const float4 xy = s_xyd[j];
+        const float4 co = s_con[j];
+        const float dx = xy.x - pfx, dy = xy.y - pfy;
+        const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+        const float G = fast_exp(power);
+        const float alpha = fminf(ALPHA_MAX, co.w * G);
+        active = (power <= 0.0f) && (alpha >= ALPHA_MIN);
+        if (active) {
+          const float4 c = s_rgb[j];
+          T = T / (1.0f - alpha);
+          const float w = alpha * T;
+          acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0; lc0 = c.x;
+          acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1; lc1 = c.y;
+          acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2; lc2 = c.z;
+          accd = last_alpha * ld + (1.f - last_alpha) * accd; ld = xy.z;
+          acca = last_alpha + (1.f - last_alpha) * acca;
+          float dL_dalpha = (c.x - acc0) * gC0 + (c.y - acc1) * gC1 + (c.z - acc2) * gC2 + (xy.z - accd) * gD +
+                            (1.0f - acca) * gA;
+          dL_dalpha *= T;
+          last_alpha = alpha;
+          dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+          const float dL_dG = co.w * dL_dalpha;
+          const float gdx = G * dx, gdy = G * dy;
+          v_mx = dL_dG * (-gdx * co.x - gdy * co.y) * ddelx_dx;
+          v_my = dL_dG * (-gdy * co.z - gdx * co.y) * ddely_dy;
+          v_ca = -0.5f * gdx * dx * dL_dG;
+          v_cb = -gdx * dy * dL_dG;
+          v_cc = -0.5f * gdy * dy * dL_dG;
+          v_op = G * dL_dalpha;
+          v_r = w * gC0; v_g = w * gC1; v_b = w * gC2;
+          v_d = w * gD;
+        }
+      }
+      // wave-uniform skip when no pixel of the wave touched this instance
+      if (__builtin_amdgcn_ballot_w64(active) != 0) {
+        v_mx = wave_sum(v_mx); v_my = wave_sum(v_my); v_ca = wave_sum(v_ca); v_cb = wave_sum(v_cb);
+        v_cc = wave_sum(v_cc); v_op = wave_sum(v_op); v_r = wave_sum(v_r); v_g = wave_sum(v_g);
+        v_b = wave_sum(v_b); v_d = wave_sum(v_d);
+        if (lane == 63) {
+          float* g = a.gacc + (size_t)s_id[j] * RIGGS_GACC;
+          atomicAdd(g + 0, v_mx); atomicAdd(g + 1, v_my); atomicAdd(g + 2, v_ca); atomicAdd(g + 3, v_cb);
+          atomicAdd(g + 4, v_cc); atomicAdd(g + 5, v_op); atomicAdd(g + 6, v_r); atomicAdd(g + 7, v_g);
+          atomicAdd(g + 8, v_b);
+          if (a.dL_ddepth) atomicAdd(g + 9, v_d);
+        }
+      }
+    }
+  }
+  (void)s_part;
+}
+
+int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s) {
+  const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE, gy = (a.H + RIGGS_TILE - 1) / RIGGS_TILE;
+  if (gx * gy == 0) return 0;
+  hipLaunchKernelGGL(render_bwd_kernel, dim3(gx * gy), dim3(256), 0, s, a);
+  return 0;
+}
+
+}  // namespace riggs

@@ -1,0 +1,263 @@
+"""Host side of the HIP rasterizer: the `diff_gaussian_rasterization` Python surface.
+
+Mirrors what RigGS imports at /root/reference/gaussian_renderer/__init__.py:14 and calls
+at :57-72 (GaussianRasterizationSettings, by keyword) and :133-141
+(GaussianRasterizer.forward, by keyword) — same names, argument meaning, 4-tuple result
+``(color (3,H,W), radii (N,) int32, depth (1,H,W), alpha (1,H,W))`` and error behaviour.
+All compute is in libriggs_hip.so; torch provides memory, streams and autograd plumbing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+class RasterArena:
+    """Persistent instance arena: lets consecutive frames skip the device->host read of the
+    instance count R (upstream synchronises on it every call).  The arena is sized from the
+    previous frame (x1.25 head-room); the kernels are overflow-safe and the (rare) overflow is
+    detected when the count is finally read, then the frame is re-rendered with a larger arena.
+    """
+
+    def __init__(self, growth: float = 1.25, min_capacity: int = 1 << 16):
+        self.growth = growth
+        self.capacity = 0
+        self.min_capacity = min_capacity
+        self.binning: Optional[torch.Tensor] = None
+        self.last_R = -1
+
+    def ensure(self, cap: int, N: int, H: int, W: int, device):
+        cap = max(int(cap), self.min_capacity)
+        if self.binning is None or cap > self.capacity or self.binning.device != device:
+            nbytes = L.lib().riggs_raster_binning_bytes(cap, N, H, W)
+            self.binning = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self.capacity = cap
+        return self.binning
+
+
+def _cfg(settings: GaussianRasterizationSettings, N: int, M: int, glue: bool, isotropic: bool, keep: list):
+    dev = settings.viewmatrix.device
+    bg = L.require_cuda_f32("bg", settings.bg.to(dev).reshape(-1), (3,))
+    view = L.require_cuda_f32("viewmatrix", settings.viewmatrix, (4, 4))
+    proj = L.require_cuda_f32("projmatrix", settings.projmatrix, (4, 4))
+    campos = L.require_cuda_f32("campos", settings.campos.reshape(-1), (3,))
+    keep += [bg, view, proj, campos]
+    c = L.RasterCfg()
+    c.num_points = N
+    c.sh_degree = int(settings.sh_degree)
+    c.sh_coeffs = M
+    c.image_height = int(settings.image_height)
+    c.image_width = int(settings.image_width)
+    c.tanfovx = float(settings.tanfovx)
+    c.tanfovy = float(settings.tanfovy)
+    c.scale_modifier = float(settings.scale_modifier)
+    c.bg, c.viewmatrix, c.projmatrix, c.campos = bg.data_ptr(), view.data_ptr(), proj.data_ptr(), campos.data_ptr()
+    c.debug = 1 if settings.debug else 0
+    c.glue = 1 if glue else 0
+    c.isotropic = 1 if isotropic else 0
+    return c
+
+
+class _Saved:
+    pass
+
+
+def rasterize_forward(settings, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                      d_xyz=None, d_rotation=None, d_scaling=None, glue=False, isotropic=False,
+                      arena: Optional[RasterArena] = None):
+    """Runs both forward stages.  Returns (color, radii, depth, alpha, saved-state)."""
+    lib = L.lib()
+    N = means3D.shape[0]
+    dev = means3D.device
+    H, W = int(settings.image_height), int(settings.image_width)
+    M = 0 if shs is None else shs.shape[1]
+    keep = []
+    cfg = _cfg(settings, N, M, glue, isotropic, keep)
+    geom = torch.empty(lib.riggs_raster_geom_bytes(N), dtype=torch.uint8, device=dev)
+    img = torch.empty(lib.riggs_raster_image_bytes(H, W), dtype=torch.uint8, device=dev)
+    radii = torch.empty(N, dtype=torch.int32, device=dev)
+    counters = torch.empty(4, dtype=torch.int32, device=dev)
+    color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+    depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+    alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+    st = L.stream_ptr()
+    L.check(lib.riggs_raster_preprocess(C.byref(cfg), L.ptr(means3D), L.ptr(shs), L.ptr(colors_precomp),
+                                        L.ptr(opacities), L.ptr(scales), L.ptr(rotations), L.ptr(cov3D_precomp),
+                                        L.ptr(d_xyz), L.ptr(d_rotation), L.ptr(d_scaling), geom.data_ptr(), radii.data_ptr(),
+                                        counters.data_ptr(), st), "riggs_raster_preprocess")
+    s = _Saved()
+    if arena is None or arena.last_R < 0:
+        R = int(counters[0].item())  # device->host sync, as upstream does
+        cap = R
+        if arena is not None:
+            binning = arena.ensure(int(R * arena.growth) + 1, N, H, W, dev)
+            cap = arena.capacity
+            arena.last_R = R
+        else:
+            binning = torch.empty(lib.riggs_raster_binning_bytes(cap, N, H, W), dtype=torch.uint8, device=dev)
+        s.R = R
+    else:
+        binning = arena.ensure(int(arena.last_R * arena.growth) + 1, N, H, W, dev)
+        cap = arena.capacity
+        s.R = None  # unknown until counters are read
+    L.check(lib.riggs_raster_render(C.byref(cfg), geom.data_ptr(), binning.data_ptr(), cap, img.data_ptr(),
+                                    color.data_ptr(), depth.data_ptr(), alpha.data_ptr(), counters.data_ptr(), st),
+            "riggs_raster_render")
+    s.cfg, s.keep, s.geom, s.img, s.binning, s.cap, s.radii, s.counters = cfg, keep, geom, img, binning, cap, radii, counters
+    s.N, s.H, s.W, s.M = N, H, W, M
+    return color, radii, depth, alpha, s
+
+
+def arena_check(s: _Saved, arena: RasterArena) -> bool:
+    """Reads the instance count of a frame rendered through an arena.  Returns False when the
+    arena overflowed (the caller must re-render)."""
+    c = s.counters[:2].tolist()
+    s.R = int(c[0]) & 0xFFFFFFFF
+    arena.last_R = s.R
+    return c[1] == 0
+
+
+def rasterize_backward(s: _Saved, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                       d_xyz, d_rotation, grad_color, grad_depth, grad_alpha, d_scaling=None,
+                       want_d_scaling_grad=False):
+    lib = L.lib()
+    N, M, dev = s.N, s.M, means3D.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    cfg = s.cfg
+    g_means3D = torch.empty(N, 3, **f32)
+    g_means2D = torch.empty(N, 3, **f32)
+    g_sh = torch.empty(N, M, 3, **f32) if shs is not None else None
+    g_colors = torch.empty(N, 3, **f32) if colors_precomp is not None else None
+    g_opac = torch.empty(N, 1, **f32)
+    iso = bool(cfg.glue and cfg.isotropic)
+    g_scales = torch.empty(N, 1 if iso else 3, **f32) if scales is not None else None
+    g_rots = torch.empty(N, 4, **f32) if rotations is not None else None
+    g_cov = torch.empty(N, 6, **f32) if cov3D_precomp is not None else None
+    g_dscaling = torch.empty(N, 3, **f32) if (d_scaling is not None and want_d_scaling_grad) else None
+    ws = torch.empty(lib.riggs_raster_backward_workspace_bytes(N), dtype=torch.uint8, device=dev)
+    gc = L.require_cuda_f32("grad_color", grad_color, (3, s.H, s.W))
+    gd = L.require_cuda_f32("grad_depth", grad_depth) if grad_depth is not None else None
+    ga = L.require_cuda_f32("grad_alpha", grad_alpha) if grad_alpha is not None else None
+    L.check(lib.riggs_raster_backward(
+        C.byref(cfg), L.ptr(means3D), L.ptr(shs), L.ptr(colors_precomp), L.ptr(opacities), L.ptr(scales),
+        L.ptr(rotations), L.ptr(cov3D_precomp), L.ptr(d_xyz), L.ptr(d_rotation), L.ptr(d_scaling), s.radii.data_ptr(),
+        s.geom.data_ptr(), s.binning.data_ptr(), s.cap, s.img.data_ptr(), s.counters.data_ptr(), gc.data_ptr(),
+        L.ptr(gd), L.ptr(ga), ws.data_ptr(), g_means3D.data_ptr(), g_means2D.data_ptr(), L.ptr(g_sh),
+        L.ptr(g_colors), g_opac.data_ptr(), L.ptr(g_scales), L.ptr(g_rots), L.ptr(g_cov), L.ptr(g_dscaling),
+        L.stream_ptr()),
+        "riggs_raster_backward")
+    return g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rots, g_cov, g_dscaling
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings):
+        color, radii, depth, alpha, s = rasterize_forward(settings, means3D, sh, colors_precomp, opacities, scales,
+                                                          rotations, cov3Ds_precomp)
+        ctx.s = s
+        ctx.save_for_backward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
+        means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp = ctx.saved_tensors
+        g = rasterize_backward(ctx.s, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, None,
+                               None, grad_color, grad_depth, grad_alpha)
+        g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rots, g_cov, _ = g
+        return g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rots, g_cov, None
+
+
+def _prep(name, t, shape):
+    if t is None or (isinstance(t, torch.Tensor) and t.numel() == 0 and shape[0] != 0 and t.dim() == 1):
+        return None
+    return L.require_cuda_f32(name, t, shape)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """Frustum test of upstream's markVisible: view-space z > 0.2."""
+        with torch.no_grad():
+            V = self.raster_settings.viewmatrix
+            z = positions @ V[:3, 2] + V[3, 2]
+            return z > 0.2
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        N = means3D.shape[0]
+        means3D = L.require_cuda_f32("means3D", means3D, (N, 3))
+        if means2D is None:
+            means2D = torch.zeros_like(means3D)
+        opacities = L.require_cuda_f32("opacities", opacities.reshape(N, 1), (N, 1))
+        shs = L.require_cuda_f32("shs", shs, (N, None, 3)) if shs is not None else None
+        colors_precomp = L.require_cuda_f32("colors_precomp", colors_precomp, (N, 3)) if colors_precomp is not None else None
+        scales = L.require_cuda_f32("scales", scales, (N, 3)) if scales is not None else None
+        rotations = L.require_cuda_f32("rotations", rotations, (N, 4)) if rotations is not None else None
+        cov3D_precomp = L.require_cuda_f32("cov3D_precomp", cov3D_precomp, (N, 6)) if cov3D_precomp is not None else None
+        return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                         cov3D_precomp, self.raster_settings)
+
+
+# ---- debugging / test access to the opaque arenas --------------------------------------
+def saved_views(s: _Saved):
+    """Typed views into the geometry / image / binning arenas of a forward call (tests)."""
+    lib = L.lib()
+    go = (C.c_size_t * L.GEOM_NFIELDS)()
+    io = (C.c_size_t * L.IMG_NFIELDS)()
+    bo = (C.c_size_t * L.BIN_NFIELDS)()
+    lib.riggs_raster_geom_layout(s.N, go)
+    lib.riggs_raster_image_layout(s.H, s.W, io)
+    lib.riggs_raster_binning_layout(s.cap, s.N, s.H, s.W, bo)
+    N, H, W = s.N, s.H, s.W
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    if s.R is None:
+        s.R = int(s.counters[0].item())
+
+    def view(buf, off, nbytes, dtype, shape):
+        return buf[off:off + nbytes].view(dtype).reshape(shape)
+    return {
+        "xyd": view(s.geom, go[L.GEOM_XYD], N * 16, torch.float32, (N, 4)),
+        "conic_o": view(s.geom, go[L.GEOM_CONIC_O], N * 16, torch.float32, (N, 4)),
+        "rgb": view(s.geom, go[L.GEOM_RGB], N * 16, torch.float32, (N, 4)),
+        "cov3D": view(s.geom, go[L.GEOM_COV3D], N * 24, torch.float32, (N, 6)),
+        "clamped": view(s.geom, go[L.GEOM_CLAMPED], N, torch.uint8, (N,)),
+        "tiles_touched": view(s.geom, go[L.GEOM_TILES], N * 4, torch.int32, (N,)),
+        "rect": view(s.geom, go[L.GEOM_RECT], N * 8, torch.int16, (N, 4)),
+        "depth_order": view(s.geom, go[L.GEOM_DEPTH_ORDER], N * 4, torch.int32, (N,)),
+        "offsets": view(s.geom, go[L.GEOM_OFFSETS], N * 4, torch.int32, (N,)),
+        "final_T": view(s.img, io[L.IMG_FINAL_T], H * W * 4, torch.float32, (H, W)),
+        "n_contrib": view(s.img, io[L.IMG_N_CONTRIB], H * W * 4, torch.int32, (H, W)),
+        "ranges": view(s.img, io[L.IMG_RANGES], T * 8, torch.int32, (T, 2)),
+        "point_list": view(s.binning, bo[L.BIN_POINT_LIST], s.R * 4, torch.int32, (s.R,)),
+        "tile_keys": view(s.binning, bo[L.BIN_TILE_KEYS], s.R * 4, torch.int32, (s.R,)),
+        "R": s.R,
+    }

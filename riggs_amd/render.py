@@ -1,0 +1,163 @@
+"""Host-side mirror of ``render()`` (/root/reference/gaussian_renderer/__init__.py:37-151).
+
+Two paths, same signature and return dict:
+  * general path — the reference's own sequence of activations, then the drop-in
+    ``GaussianRasterizer`` (every optional branch of the reference works);
+  * fused path (``fused=True`` and the default branch: SH colours from the rasterizer,
+    scales/rotations, tensor or 0.0 residuals) — raw parameters go straight to the HIP
+    preprocess kernel which applies sigmoid / exp / normalize(_rotation + d_rotation) /
+    xyz + d_xyz in registers, and the backward kernel applies their chain rule, so none
+    of those (N,k) intermediates ever round-trips HBM.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _lib as L
+from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, RasterArena, rasterize_forward,
+                         rasterize_backward, arena_check)
+
+
+def quaternion_multiply(a, b):
+    aw, ax, ay, az = torch.unbind(a, -1)
+    bw, bx, by, bz = torch.unbind(b, -1)
+    o = torch.stack((aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                     aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw), -1)
+    return torch.where(o[..., 0:1] < 0, -o, o)
+
+
+class _FusedGlueRaster(torch.autograd.Function):
+    """render glue + rasterizer as ONE autograd node over the raw Gaussian parameters."""
+
+    @staticmethod
+    def forward(ctx, xyz, means2D, f_dc, f_rest, opacity, scaling, rotation, d_xyz, d_rot, d_scaling, settings,
+                isotropic, arena):
+        N = xyz.shape[0]
+        shs = torch.cat((f_dc, f_rest), dim=1).contiguous()  # (N,16,3): the rasterizer's SH record
+        xyz = L.require_cuda_f32("_xyz", xyz, (N, 3))
+        opacity = L.require_cuda_f32("_opacity", opacity, (N, 1))
+        scaling = L.require_cuda_f32("_scaling", scaling, (N, 1 if isotropic else 3))
+        rotation = L.require_cuda_f32("_rotation", rotation, (N, 4))
+        d_xyz = L.require_cuda_f32("d_xyz", d_xyz, (N, 3)) if d_xyz is not None else None
+        d_rot = L.require_cuda_f32("d_rotation", d_rot, (N, 4)) if d_rot is not None else None
+        d_scaling = L.require_cuda_f32("d_scaling", d_scaling, (N, 3)) if d_scaling is not None else None
+        out = rasterize_forward(settings, xyz, shs, None, opacity, scaling, rotation, None, d_xyz=d_xyz,
+                                d_rotation=d_rot, d_scaling=d_scaling, glue=True, isotropic=isotropic, arena=arena)
+        color, radii, depth, alpha, s = out
+        ctx.s, ctx.arena, ctx.settings, ctx.isotropic = s, arena, settings, isotropic
+        ctx.n_dc = f_dc.shape[1]
+        ctx.save_for_backward(xyz, shs, opacity, scaling, rotation, d_xyz, d_rot, d_scaling)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, g_color, _g_radii, g_depth, g_alpha):
+        xyz, shs, opacity, scaling, rotation, d_xyz, d_rot, d_scaling = ctx.saved_tensors
+        s = ctx.s
+        if s.R is None and ctx.arena is not None and not arena_check(s, ctx.arena):
+            raise L.RiggsHipError("instance arena overflowed (R=%d > capacity=%d): re-run the frame; the arena has "
+                                  "been regrown" % (s.R, s.cap))
+        need_ds = d_scaling is not None and ctx.needs_input_grad[9]
+        g = rasterize_backward(s, xyz, shs, None, opacity, scaling, rotation, None, d_xyz, d_rot, g_color, g_depth,
+                               g_alpha, d_scaling=d_scaling, want_d_scaling_grad=need_ds)
+        g_means3D, g_means2D, g_sh, _, g_opac, g_scales, g_rots, _, g_ds = g
+        n = ctx.n_dc
+        return (g_means3D, g_means2D, g_sh[:, :n], g_sh[:, n:], g_opac, g_scales, g_rots,
+                g_means3D if d_xyz is not None else None, g_rots if d_rot is not None else None, g_ds, None, None,
+                None)
+
+
+def _is_zero_scalar(v):
+    return (not isinstance(v, torch.Tensor)) and float(v) == 0.0
+
+
+def render(viewpoint_camera, pc, pipe, bg_color, d_xyz, d_rotation, d_scaling, d_opacity=None, d_color=None,
+           scaling_modifier=1.0, override_color=None, random_bg_color=False, render_motion=False, detach_xyz=False,
+           detach_scale=False, detach_rot=False, detach_opacity=False, d_rot_as_res=True, scale_const=None,
+           d_rotation_bias=None, force_visible=False, fused=True, arena: RasterArena = None):
+    """Same contract as the reference ``render`` (returns the same dict).  ``fused`` / ``arena`` are additions."""
+    xyz = pc.get_xyz
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
+    tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
+    bg = bg_color if not random_bg_color else torch.rand_like(bg_color)
+    settings = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=tanfovx, tanfovy=tanfovy, bg=bg, scale_modifier=scaling_modifier,
+        viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
+        sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center, prefiltered=False, debug=pipe.debug)
+
+    default_branch = (not pipe.compute_cov3D_python and not pipe.convert_SHs_python and not render_motion
+                      and override_color is None and scale_const is None and d_opacity is None
+                      and d_rotation_bias is None and (d_color is None or type(d_color) is float)
+                      and not (detach_xyz or detach_scale or detach_rot or detach_opacity))
+    if fused and default_branch:
+        dx = None if _is_zero_scalar(d_xyz) else d_xyz
+        dr = None if _is_zero_scalar(d_rotation) else d_rotation
+        ds = None if _is_zero_scalar(d_scaling) else d_scaling
+        iso = bool(getattr(pc, "use_isotropic_gs", False))
+        scaling = pc._scaling[..., :1] if iso else pc._scaling
+        color, radii, depth, alpha = _FusedGlueRaster.apply(
+            pc._xyz, screenspace_points, pc._features_dc, pc._features_rest, pc._opacity, scaling, pc._rotation,
+            dx, dr, ds, settings, iso, arena)
+        return {"render": color, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+                "radii": radii, "depth": depth, "alpha": alpha, "bg_color": bg}
+
+    # ---- general path: the reference's own op sequence (gaussian_renderer/__init__.py:74-141) ----
+    rasterizer = GaussianRasterizer(raster_settings=settings)
+    means3D = xyz + d_xyz
+    means2D = screenspace_points
+    if scale_const is not None:
+        opacity = torch.ones_like(pc.get_opacity)
+    else:
+        opacity = pc.get_opacity if d_opacity is None else pc.get_opacity + d_opacity
+    scales = rotations = cov3D_precomp = None
+    if pipe.compute_cov3D_python:
+        cov3D_precomp = pc.get_covariance(scaling_modifier, d_rotation=None if type(d_rotation) is float else d_rotation,
+                                          gs_rot_bias=d_rotation_bias)
+    else:
+        scales = pc.get_scaling + d_scaling
+        rotations = pc.get_rotation_bias(d_rotation)
+        if d_rotation_bias is not None:
+            rotations = quaternion_multiply(d_rotation_bias, rotations)
+    shs = colors_precomp = None
+    if render_motion:
+        colors_precomp = torch.zeros_like(xyz)
+        colors_precomp[..., :1] = pc.motion_mask
+        colors_precomp[..., -1:] = 1 - pc.motion_mask
+    elif override_color is None:
+        feats = pc.get_features
+        if d_color is not None and type(d_color) is not float:
+            feats = torch.cat([feats[:, :1] + d_color[:, None], feats[:, 1:]], dim=1)
+        if pipe.convert_SHs_python:
+            from .sh import eval_sh
+            shs_view = feats.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+            dir_pp = xyz - viewpoint_camera.camera_center.repeat(feats.shape[0], 1)
+            colors_precomp = torch.clamp_min(eval_sh(pc.active_sh_degree, shs_view, dir_pp / dir_pp.norm(dim=1, keepdim=True)) + 0.5, 0.0)
+        else:
+            shs = feats
+    else:
+        colors_precomp = override_color
+    if detach_xyz:
+        means3D = means3D.detach()
+    if detach_rot or detach_scale:
+        if cov3D_precomp is not None:
+            cov3D_precomp = cov3D_precomp.detach()
+        else:
+            rotations = rotations.detach() if detach_rot else rotations
+            scales = scales.detach() if detach_scale else scales
+    if detach_opacity:
+        opacity = opacity.detach()
+    if scale_const is not None:
+        scales = scale_const * torch.ones_like(scales)
+    rendered_image, radii, depth, alpha = rasterizer(means3D=means3D, means2D=means2D, shs=shs,
+                                                     colors_precomp=colors_precomp, opacities=opacity, scales=scales,
+                                                     rotations=rotations, cov3D_precomp=cov3D_precomp)
+    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+            "radii": radii, "depth": depth, "alpha": alpha, "bg_color": bg}

@@ -1,0 +1,288 @@
+"""Host-side mirror of RigGS's skeleton deformation interface, backed by libriggs_hip.so.
+
+Mirrors (same names, argument meaning, return dict) of
+  * ``SkeletonWarp``   /root/reference/skeleton_utils/skeleton_warp.py:10-300
+  * ``PoseMLP``        /root/reference/skeleton_utils/network_utils.py:115-150
+  * ``SkeletonModel``  /root/reference/scene/skeleton_model.py:9-85 (``step`` only)
+The per-Gaussian work (bone distances, skinning weights, LBS of means and quaternions,
+and the reductions of the backward) runs in HIP kernels; the one-row PoseMLP stays in torch
+(SURVEY.md §8 A1).  The optional per-Gaussian MLP heads (WeightMLP / DeformMLP,
+``use_skinning_weight_mlp`` / ``use_template_offsets``) are a later row of SURVEY.md §8-f and
+raise NotImplementedError here rather than silently computing something else.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib as L
+
+
+# --------------------------------------------------------------------------- PoseMLP (A1)
+def _embed(t: torch.Tensor, multires: int) -> torch.Tensor:
+    """get_embedder(multires, 1): [t, sin(2^k t), cos(2^k t)] (utils/time_utils.py:208-256)."""
+    out = [t]
+    for k in range(multires):
+        f = float(2.0 ** k)
+        out.append(torch.sin(t * f))
+        out.append(torch.cos(t * f))
+    return torch.cat(out, -1)
+
+
+class PoseMLP(nn.Module):
+    def __init__(self, input_ch, output_ch, depth=8, hidden_dimensions=256, multires=8):
+        super().__init__()
+        self.skips = [depth // 2]
+        self.multires = multires
+        if multires > 0:
+            input_ch = input_ch * (1 + 2 * multires)
+        self.net = nn.ModuleList(
+            [nn.Linear(input_ch, hidden_dimensions)]
+            + [nn.Linear(hidden_dimensions, hidden_dimensions) if i not in self.skips
+               else nn.Linear(hidden_dimensions + input_ch, hidden_dimensions) for i in range(depth - 1)])
+        self.rotation_predictor = nn.Linear(hidden_dimensions, output_ch)
+        self.translation_predictor = nn.Linear(hidden_dimensions, 3)
+
+    def forward(self, t):
+        t_emb = _embed(t, self.multires) if self.multires > 0 else t
+        h = t_emb + 0.0
+        for i, layer in enumerate(self.net):
+            h = F.relu(layer(h))
+            if i in self.skips:
+                h = torch.cat([t_emb, h], -1)
+        return {"rotation": self.rotation_predictor(h), "translation": self.translation_predictor(h)}
+
+
+# --------------------------------------------------------------------------- HIP ops
+def fk_forward(local_rot, joints, parents_i32, global_trans):
+    J = joints.shape[0]
+    f32 = dict(dtype=torch.float32, device=joints.device)
+    transforms = torch.empty(J, 12, **f32)
+    node_rot = torch.empty(J, 4, **f32)
+    d_nodes = torch.empty(J, 3, **f32)
+    L.check(L.lib().riggs_fk_forward(J, local_rot.data_ptr(), joints.data_ptr(), parents_i32.data_ptr(),
+                                     global_trans.data_ptr(), transforms.data_ptr(), node_rot.data_ptr(),
+                                     d_nodes.data_ptr(), L.stream_ptr()), "riggs_fk_forward")
+    return transforms, node_rot, d_nodes
+
+
+def lbs_forward(x, joints, parents_i32, rho, transforms, node_rot, global_trans, mask, K=-1, want_weights=False):
+    N, J = x.shape[0], joints.shape[0]
+    f32 = dict(dtype=torch.float32, device=x.device)
+    d_xyz = torch.empty(N, 3, **f32)
+    d_rot = torch.empty(N, 4, **f32)
+    Kp = K if K > 0 else J - 1
+    w = torch.empty(N, Kp, **f32) if want_weights else None
+    idx = torch.empty(N, Kp, dtype=torch.int64, device=x.device) if want_weights else None
+    L.check(L.lib().riggs_lbs_forward(N, J, K, x.data_ptr(), joints.data_ptr(), parents_i32.data_ptr(), rho.data_ptr(),
+                                      transforms.data_ptr(), node_rot.data_ptr(), global_trans.data_ptr(), L.ptr(mask),
+                                      d_xyz.data_ptr(), d_rot.data_ptr(), L.ptr(w), L.ptr(idx), L.stream_ptr()),
+            "riggs_lbs_forward")
+    return d_xyz, d_rot, w, idx
+
+
+class _DeformByPose(torch.autograd.Function):
+    """deform_by_pose as one autograd node: FK (1 workgroup) + fused skinning/LBS."""
+
+    @staticmethod
+    def forward(ctx, local_rot, global_trans, rho, mask, x, joints, parents_i32, K):
+        local_rot = L.require_cuda_f32("local_rotation", local_rot, (joints.shape[0], 4))
+        global_trans = L.require_cuda_f32("global_trans", global_trans.reshape(-1), (3,))
+        rho = L.require_cuda_f32("_node_radius", rho, (joints.shape[0],))
+        mflat = None if mask is None else L.require_cuda_f32("motion_mask", mask.reshape(-1), (x.shape[0],))
+        transforms, node_rot, d_nodes = fk_forward(local_rot, joints, parents_i32, global_trans)
+        d_xyz, d_rot, _, _ = lbs_forward(x, joints, parents_i32, rho, transforms, node_rot, global_trans, mflat, K)
+        ctx.save_for_backward(local_rot, global_trans, rho, mflat, x, joints, parents_i32, transforms, node_rot)
+        ctx.K = K
+        ctx.mask_shape = None if mask is None else mask.shape
+        ctx.mark_non_differentiable(node_rot)
+        return d_xyz, d_rot, d_nodes, transforms, node_rot
+
+    @staticmethod
+    def backward(ctx, g_xyz, g_rot, g_nodes, g_transforms, _g_node_rot):
+        local_rot, global_trans, rho, mflat, x, joints, parents_i32, transforms, node_rot = ctx.saved_tensors
+        N, J = x.shape[0], joints.shape[0]
+        f32 = dict(dtype=torch.float32, device=x.device)
+        g_xyz = torch.zeros(N, 3, **f32) if g_xyz is None else g_xyz.contiguous()
+        g_rot = torch.zeros(N, 4, **f32) if g_rot is None else g_rot.contiguous()
+        dG = torch.empty(J, 12, **f32)
+        drho = torch.empty(J, **f32)
+        dgt = torch.empty(3, **f32)
+        need_mask = mflat is not None and ctx.needs_input_grad[3]
+        dmask = torch.empty(N, **f32) if need_mask else None
+        lib = L.lib()
+        st = L.stream_ptr()
+        L.check(lib.riggs_lbs_backward(N, J, ctx.K, x.data_ptr(), joints.data_ptr(), parents_i32.data_ptr(),
+                                       rho.data_ptr(), transforms.data_ptr(), node_rot.data_ptr(),
+                                       global_trans.data_ptr(), L.ptr(mflat), g_xyz.data_ptr(), g_rot.data_ptr(),
+                                       dG.data_ptr(), drho.data_ptr(), dgt.data_ptr(), L.ptr(dmask), st),
+                "riggs_lbs_backward")
+        if g_transforms is not None:
+            dG = dG + g_transforms
+        dq = torch.empty(J, 4, **f32)
+        gn = None if g_nodes is None else g_nodes.contiguous()
+        L.check(lib.riggs_fk_backward(J, local_rot.data_ptr(), joints.data_ptr(), parents_i32.data_ptr(), dG.data_ptr(),
+                                      L.ptr(gn), dq.data_ptr(), dgt.data_ptr(), st), "riggs_fk_backward")
+        gmask = dmask.reshape(ctx.mask_shape) if need_mask else None
+        return dq, dgt, drho, gmask, None, None, None, None
+
+
+class _LazyDeformDict(dict):
+    """deform_by_pose's return dict; ``nn_idx`` / ``nn_weight`` (needed by render_rig.py:156-158,
+    not by training) are materialised by the HIP kernel on first access."""
+
+    _LAZY = ("nn_idx", "nn_weight")
+
+    def __init__(self, *a, producer=None, **k):
+        super().__init__(*a, **k)
+        self._producer = producer
+
+    def _fill(self):
+        if self._producer is not None:
+            w, idx = self._producer()
+            self._producer = None
+            dict.__setitem__(self, "nn_weight", w)
+            dict.__setitem__(self, "nn_idx", idx)
+
+    def __getitem__(self, key):
+        if key in self._LAZY and self._producer is not None:
+            self._fill()
+        return dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        if key in self._LAZY and self._producer is not None:
+            self._fill()
+        return dict.get(self, key, default)
+
+
+class SkeletonWarp(nn.Module):
+    """HIP-backed mirror of skeleton_utils/skeleton_warp.py:SkeletonWarp (LBS mode)."""
+
+    def __init__(self, is_blender=True, joints=None, parent_indices=None, init_pcl=None, K=3, hyper_dim=2,
+                 d_rot_as_res=True, use_skinning_weight_mlp=True, use_template_offsets=True, **kwargs):
+        super().__init__()
+        if joints is None or parent_indices is None:
+            raise ValueError("joints and parent_indices are required")
+        J = joints.shape[0]
+        if J > 64:
+            raise ValueError("at most 64 joints are supported by the LDS-staged kernels")
+        self.K = K
+        self.name = "node"
+        self.is_blender = is_blender
+        self.d_rot_as_res = d_rot_as_res
+        self.hyper_dim = hyper_dim
+        self.reg_loss = 0.0
+        nodes = torch.randn(J, 3 + hyper_dim)
+        nodes[:, :3] = joints.detach().float().cpu()
+        self.nodes = nn.Parameter(nodes, requires_grad=False)  # skeleton_warp.py:14-16
+        self._node_radius = nn.Parameter(torch.randn(J))        # utils/time_utils.py:807
+        self.register_buffer("parents", parent_indices.detach().long().cpu().clone())
+        self.use_skinning_weight_mlp = use_skinning_weight_mlp
+        self.use_template_offsets = use_template_offsets
+        self.control_nodes = nn.Parameter(torch.zeros(512, 3))  # checkpoint compatibility (:31)
+        self.template_offsets = None
+        self.pose_net = PoseMLP(1, J * 4)
+        self._parents_i32 = None
+
+    # -- reference surface ------------------------------------------------------------------
+    @property
+    def node_radius(self):
+        return torch.exp(self._node_radius)
+
+    @property
+    def node_num(self):
+        return self.nodes.shape[0]
+
+    def expand_time(self, t):
+        return t.unsqueeze(0).expand(self.nodes.shape[0], -1)  # utils/time_utils.py:929-932
+
+    def update_control_nodes(self, nodes):
+        self.control_nodes.data = nodes
+
+    def trainable_parameters(self):
+        return [{"params": [self._node_radius], "name": "nodes"},
+                {"params": list(self.pose_net.parameters()), "name": "pose"}]
+
+    def _check_variant(self):
+        if self.use_skinning_weight_mlp or self.use_template_offsets:
+            raise NotImplementedError(
+                "WeightMLP / DeformMLP heads (use_skinning_weight_mlp / use_template_offsets) are not part of the "
+                "HIP hot path yet (SURVEY.md §8-f rank 3); the trainer keeps both off for the first 15000 "
+                "iterations (train_rig.py:398-400) and the argparse defaults are False.")
+
+    def _parents_dev(self, device):
+        if self._parents_i32 is None or self._parents_i32.device != device:
+            p = self.parents.to(torch.int32).clone()
+            p[0] = 0
+            if bool((p[1:] >= torch.arange(1, p.shape[0], dtype=torch.int32)).any()):
+                raise ValueError("parents[i] < i is required (skeleton_warp.py:257-263)")
+            self._parents_i32 = p.to(device)
+        return self._parents_i32
+
+    def get_pose_info(self, t):
+        if t.dim() == 0:
+            t = self.expand_time(t)
+        m = self.pose_net(t[0])
+        bias = torch.tensor([1.0, 0, 0, 0], device=self.nodes.device)
+        return {"local_rotation": m["rotation"].reshape(-1, 4) + bias, "global_trans": m["translation"], "t": t[0]}
+
+    def forward(self, x, t, motion_mask, **kwargs):
+        return self.deform_by_pose(x, self.get_pose_info(t), motion_mask)
+
+    def deform_by_pose(self, x, node_attrs, motion_mask):
+        self._check_variant()
+        x = L.require_cuda_f32("x", x.detach(), (x.shape[0], 3))
+        local_rot, global_trans = node_attrs["local_rotation"], node_attrs["global_trans"]
+        joints = self.nodes[:, :3].detach().contiguous()
+        par = self._parents_dev(x.device)
+        mask = motion_mask
+        if mask is not None and not isinstance(mask, torch.Tensor):
+            mask = None if float(mask) == 1.0 else torch.full((x.shape[0], 1), float(mask), device=x.device)
+        d_xyz, d_rot, d_nodes, transforms, node_rot = _DeformByPose.apply(
+            local_rot, global_trans, self._node_radius, mask, x, joints, par, self.K)
+        rho = self._node_radius.detach()
+        gt = global_trans.detach().reshape(-1).contiguous()
+        mflat = None if mask is None else mask.detach().reshape(-1).contiguous()
+
+        def producer():
+            _, _, w, idx = lbs_forward(x, joints, par, rho.contiguous(), transforms.detach(), node_rot, gt, mflat,
+                                       self.K, want_weights=True)
+            return w, idx
+        return _LazyDeformDict(
+            {"d_xyz": d_xyz, "d_rotation": d_rot, "d_scaling": torch.zeros(x.shape[0], 3, device=x.device),
+             "d_nodes": d_nodes, "nn_idx": None, "nn_weight": None, "local_rotation": node_attrs["local_rotation"],
+             "global_trans": global_trans, "d_opacity": None, "d_color": None}, producer=producer)
+
+    def node_deformation(self, x, node_attrs):
+        x = x.detach()
+        joints = self.nodes[:, :3].detach().contiguous()
+        par = self._parents_dev(joints.device)
+        local_rot = L.require_cuda_f32("local_rotation", node_attrs["local_rotation"], (joints.shape[0], 4))
+        gt = L.require_cuda_f32("global_trans", node_attrs["global_trans"].reshape(-1), (3,))
+        _, _, d_nodes = fk_forward(local_rot.detach(), joints, par, gt.detach())
+        return {"d_xyz": d_nodes - x, "d_opacity": None, "d_color": None,
+                "local_rotation": node_attrs["local_rotation"]}
+
+
+class SkeletonModel:
+    """scene/skeleton_model.py: thin wrapper; only the hot-path surface is mirrored."""
+
+    def __init__(self, is_blender=False, d_rot_as_res=True, **kwargs):
+        self.deform = SkeletonWarp(is_blender=is_blender, d_rot_as_res=d_rot_as_res, **kwargs).cuda()
+        self.name = self.deform.name
+        self.optimizer = None
+        self.d_rot_as_res = d_rot_as_res
+
+    @property
+    def reg_loss(self):
+        return self.deform.reg_loss
+
+    def step(self, xyz, time_emb, **kwargs):
+        return self.deform(xyz, time_emb, **kwargs)
+
+    def train_setting(self, lr=5e-4):
+        groups = [{"params": g["params"], "lr": lr, "name": g["name"]} for g in self.deform.trainable_parameters()]
+        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)

@@ -1,0 +1,65 @@
+"""CPU: the C-ABI library loads and exports every symbol include/riggs_hip.h declares; host-side
+logic that needs no GPU."""
+import os
+import re
+
+import pytest
+import torch
+
+from riggs_amd import _lib
+
+
+def _header_functions():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = open(os.path.join(root, "include", "riggs_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(riggs_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    declared = _header_functions()
+    assert len(declared) >= 18
+    L = _lib.lib()  # loads without a GPU; argtypes set for every symbol
+    for name in declared:
+        assert hasattr(L, name), "symbol %s declared in include/riggs_hip.h but not exported" % name
+    assert sorted(_lib.exported_symbols()) == declared
+    assert L.riggs_version() >= 100
+
+
+def test_product_path_refuses_cpu_tensors():
+    from riggs_amd.rasterizer import GaussianRasterizer, GaussianRasterizationSettings
+    st = GaussianRasterizationSettings(16, 16, 0.5, 0.5, torch.zeros(3), 1.0, torch.eye(4), torch.eye(4), 3,
+                                       torch.zeros(3), False, False)
+    r = GaussianRasterizer(st)
+    with pytest.raises(_lib.RiggsHipError, match="CUDA"):
+        r(means3D=torch.zeros(4, 3), means2D=torch.zeros(4, 3), opacities=torch.zeros(4, 1), shs=torch.zeros(4, 16, 3),
+          scales=torch.ones(4, 3), rotations=torch.ones(4, 4))
+    with pytest.raises(Exception, match="SHs or precomputed colors"):
+        r(means3D=torch.zeros(4, 3), means2D=None, opacities=torch.zeros(4, 1), scales=torch.ones(4, 3),
+          rotations=torch.ones(4, 4))
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "SO_PATH", "/nonexistent/libriggs_hip.so")
+    with pytest.raises(_lib.RiggsHipError, match="no fallback"):
+        _lib.lib()
+
+
+def test_skeleton_host_logic_cpu():
+    from riggs_amd.skeleton import SkeletonWarp
+    joints = torch.randn(5, 3)
+    sw = SkeletonWarp(joints=joints, parent_indices=torch.tensor([-1, 0, 1, 1, 3]), K=-1, hyper_dim=8,
+                      use_skinning_weight_mlp=False, use_template_offsets=False)
+    assert sw.nodes.shape == (5, 11) and not sw.nodes.requires_grad
+    assert sw.expand_time(torch.tensor([0.5])).shape == (5, 1)
+    info = sw.get_pose_info(sw.expand_time(torch.tensor([0.5])))
+    assert info["local_rotation"].shape == (5, 4) and info["global_trans"].shape == (3,)
+    names = [g["name"] for g in sw.trainable_parameters()]
+    assert names == ["nodes", "pose"]
+    keys = set(sw.state_dict().keys())
+    assert {"nodes", "_node_radius", "control_nodes", "pose_net.rotation_predictor.weight"} <= keys
+    with pytest.raises(ValueError):
+        bad = SkeletonWarp(joints=joints, parent_indices=torch.tensor([-1, 2, 1, 1, 3]), K=-1,
+                           use_skinning_weight_mlp=False, use_template_offsets=False)
+        bad._parents_dev(torch.device("cpu"))

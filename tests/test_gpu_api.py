@@ -1,0 +1,112 @@
+"""-m gpu: the drop-in Python surface (render(), diff_gaussian_rasterization, simple_knn) end to end."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import deform_ref as O  # noqa: E402
+from oracle import raster_ref as RR  # noqa: E402
+from riggs_amd import synth  # noqa: E402
+from riggs_amd.gaussian_model import GaussianModel  # noqa: E402
+from riggs_amd.render import render  # noqa: E402
+from riggs_amd.skeleton import SkeletonWarp  # noqa: E402
+from tests import gpu_util as U  # noqa: E402
+
+
+class Pipe:
+    convert_SHs_python = False
+    compute_cov3D_python = False
+    debug = True
+
+
+def _oracle_pipeline(sc, cam, bg, gimg, isotropic=False):
+    """deform (torch CPU oracle) -> glue -> C rasterizer fwd+bwd -> autograd back to the raw parameters."""
+    leaf = lambda t: t.clone().requires_grad_(True)  # noqa: E731
+    P = {k: leaf(sc[k]) for k in ("xyz", "features_dc", "features_rest", "scaling", "rotation", "opacity",
+                                  "local_rotation", "global_trans", "node_radius")}
+    scaling = P["scaling"][:, :1] if isotropic else P["scaling"]
+    dv = O.deform_by_pose(P["xyz"].detach(), sc["joints"], sc["parents"], P["node_radius"], P["local_rotation"],
+                          P["global_trans"], sc["motion_mask"], -1)
+    d_rot = dv["d_rotation"] * (0.0 if isotropic else 1.0)
+    m3, op, scl, rot, shs = O.render_glue(P["xyz"], P["features_dc"], P["features_rest"], scaling, P["rotation"],
+                                          P["opacity"], dv["d_xyz"], d_rot, dv["d_scaling"], isotropic)
+    out, saved = RR.forward(m3.detach().numpy(), op.detach().numpy(), cam.world_view_transform.numpy(),
+                            cam.full_proj_transform.numpy(), cam.camera_center.numpy(), math.tan(cam.FoVx / 2),
+                            math.tan(cam.FoVy / 2), cam.image_height, cam.image_width, np.asarray(bg, np.float32),
+                            shs=shs.detach().numpy(), scales=scl.detach().numpy(), rotations=rot.detach().numpy())
+    g = RR.backward(saved, gimg.numpy(), None, None)
+    T = torch.from_numpy
+    torch.autograd.backward([m3, op, scl, rot, shs], [T(g["means3D"]), T(g["opacities"]), T(g["scales"]),
+                                                      T(g["rotations"]), T(g["shs"])])
+    return out, saved, P, g
+
+
+@pytest.mark.parametrize("fused,isotropic", [(True, False), (False, False), (True, True)])
+def test_render_end_to_end_matches_oracle_pipeline(fused, isotropic):
+    N, J, H, W = 6000, 24, 160, 160
+    sc = synth.make_scene(N, J, 77, scale=0.02)
+    if isotropic:
+        sc["scaling"] = sc["scaling"][:, :1].contiguous()
+    cam = synth.look_at_camera(H, W)
+    bg = [0.0, 0.0, 0.0]
+    g = torch.Generator().manual_seed(4)
+    gimg = torch.sign(torch.rand(3, H, W, generator=g) - 0.5) / (3 * H * W)
+    out_o, saved_o, Po, g_o = _oracle_pipeline(sc, cam, bg, gimg, isotropic)
+
+    gm = GaussianModel.from_tensors(sc["xyz"], sc["features_dc"], sc["features_rest"], sc["scaling"], sc["rotation"],
+                                    sc["opacity"], use_isotropic_gs=isotropic)
+    sw = SkeletonWarp(joints=sc["joints"], parent_indices=sc["parents"], K=-1, hyper_dim=8,
+                      use_skinning_weight_mlp=False, use_template_offsets=False).cuda()
+    sw._node_radius.data = sc["node_radius"].cuda()
+    q = sc["local_rotation"].cuda().requires_grad_(True)
+    gt = sc["global_trans"].cuda().requires_grad_(True)
+    dv = sw.deform_by_pose(gm.get_xyz.detach(), {"local_rotation": q, "global_trans": gt}, gm.motion_mask)
+    d_rot = dv["d_rotation"] * 0.0 if isotropic else dv["d_rotation"]  # train_rig.py:422-423
+    pkg = render(cam.to("cuda"), gm, Pipe, torch.tensor(bg, device="cuda"), dv["d_xyz"], d_rot, dv["d_scaling"],
+                 fused=fused)
+    assert set(pkg) == {"render", "viewspace_points", "visibility_filter", "radii", "depth", "alpha", "bg_color"}
+    # the deformed means differ from the oracle's by float rounding, so ordering is compared with tolerance here
+    U.assert_close(pkg["render"].detach().cpu().numpy(), out_o["color"], "render", U.REL_TOL, 1e-3)
+    assert (pkg["radii"].cpu().numpy() != saved_o.radii).mean() < 1e-3
+    assert torch.equal(pkg["visibility_filter"], pkg["radii"] > 0)
+    (pkg["render"] * gimg.cuda()).sum().backward()
+    vs = pkg["viewspace_points"].grad
+    U.assert_close(vs.cpu().numpy(), g_o["means2D"], "viewspace_points.grad", 2e-4, 1e-3)
+    for name, p in (("xyz", gm._xyz), ("features_dc", gm._features_dc), ("features_rest", gm._features_rest),
+                    ("opacity", gm._opacity), ("scaling", gm._scaling), ("rotation", gm._rotation)):
+        U.assert_close(p.grad.cpu().numpy(), Po[name].grad.numpy(), "dL/d_" + name, 2e-4, 1e-3)
+    U.assert_close(q.grad.cpu().numpy(), Po["local_rotation"].grad.numpy(), "dL/dlocal_rotation", 1e-3)
+    U.assert_close(gt.grad.cpu().numpy(), Po["global_trans"].grad.numpy(), "dL/dglobal_trans", 1e-3)
+    U.assert_close(sw._node_radius.grad.cpu().numpy(), Po["node_radius"].grad.numpy(), "dL/d_node_radius", 1e-3)
+
+
+def test_render_accepts_python_float_residuals_and_override_color():
+    sc = synth.make_scene(2000, 8, 3, scale=0.03)
+    cam = synth.look_at_camera(64, 64).to("cuda")
+    gm = GaussianModel.from_tensors(sc["xyz"], sc["features_dc"], sc["features_rest"], sc["scaling"], sc["rotation"],
+                                    sc["opacity"])
+    bg = torch.zeros(3, device="cuda")
+    a = render(cam, gm, Pipe, bg, 0.0, 0.0, 0.0, fused=True)       # train_gui.py:1032 passes floats
+    b = render(cam, gm, Pipe, bg, 0.0, 0.0, 0.0, fused=False)
+    U.assert_close(a["render"].detach().cpu().numpy(), b["render"].detach().cpu().numpy(), "fused vs general", 1e-5, 1e-4)
+    col = torch.rand(2000, 3, device="cuda")
+    c = render(cam, gm, Pipe, bg, 0.0, 0.0, 0.0, override_color=col)
+    assert c["render"].shape == (3, 64, 64) and torch.isfinite(c["render"]).all()
+
+
+def test_drop_in_module_surfaces():
+    import diff_gaussian_rasterization as dgr
+    from simple_knn._C import distCUDA2
+    assert dgr.GaussianRasterizationSettings._fields == (
+        "image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix", "projmatrix",
+        "sh_degree", "campos", "prefiltered", "debug")
+    assert issubclass(dgr.GaussianRasterizer, torch.nn.Module)
+    g = torch.Generator().manual_seed(0)
+    for P in (1, 3, 24, 5000):
+        pts = torch.randn(P, 3, generator=g)
+        ref = RR.dist2_knn3(pts.numpy())
+        got = distCUDA2(pts.cuda()).cpu().numpy()
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-9)

@@ -1,0 +1,111 @@
+"""-m gpu: HIP skeleton deformation vs (a) golden vectors captured from the REAL RigGS reference
+and (b) the pinned CPU oracle on larger seeded inputs.  Tolerance: 1e-4 relative (north_star)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import deform_ref as O  # noqa: E402
+from riggs_amd import synth  # noqa: E402
+from riggs_amd.skeleton import SkeletonWarp  # noqa: E402
+from tests import gpu_util as U  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DEFORM = sorted(glob.glob(os.path.join(GOLD, "deform_*.npz")))
+
+
+def T(a, dev="cuda"):
+    return torch.from_numpy(np.asarray(a)).to(dev)
+
+
+def make_warp(joints, parents, rho, K):
+    sw = SkeletonWarp(is_blender=True, joints=joints, parent_indices=parents, K=K, hyper_dim=8,
+                      use_skinning_weight_mlp=False, use_template_offsets=False).cuda()
+    sw._node_radius.data = rho.cuda()
+    return sw
+
+
+@pytest.mark.parametrize("path", DEFORM, ids=[os.path.basename(p)[:-4] for p in DEFORM])
+def test_deform_matches_reference_golden(path):
+    g = np.load(path)
+    K = int(g["K"])
+    sw = make_warp(T(g["joints"], "cpu"), T(g["parents"], "cpu"), T(g["node_radius_log"], "cpu"), K)
+    q = T(g["local_rot"]).clone().requires_grad_(True)
+    gt = T(g["global_trans"]).clone().requires_grad_(True)
+    mask = T(g["motion_mask"]).clone().requires_grad_(True)
+    out = sw.deform_by_pose(T(g["x"]), {"local_rotation": q, "global_trans": gt}, mask)
+    U.assert_close(out["d_xyz"].detach().cpu().numpy(), g["d_xyz"], "d_xyz")
+    U.assert_close(out["d_rotation"].detach().cpu().numpy(), g["d_rotation"], "d_rotation")
+    U.assert_close(out["d_nodes"].detach().cpu().numpy(), g["d_nodes"], "d_nodes", 1e-5)
+    assert float(out["d_scaling"].abs().max()) == 0.0
+    assert out["d_opacity"] is None and out["d_color"] is None
+    idx = out["nn_idx"].cpu().numpy()
+    if K > 0:  # ties in d2 are not ordered by torch.topk: compare as sets per row
+        assert np.array_equal(np.sort(idx, 1), np.sort(g["nn_idx"], 1))
+        order_h, order_r = np.argsort(idx, 1), np.argsort(g["nn_idx"], 1)
+        w_h = np.take_along_axis(out["nn_weight"].cpu().numpy(), order_h, 1)
+        w_r = np.take_along_axis(g["nn_weight"], order_r, 1)
+        U.assert_close(w_h, w_r, "nn_weight")
+    else:
+        assert np.array_equal(idx, g["nn_idx"])
+        U.assert_close(out["nn_weight"].cpu().numpy(), g["nn_weight"], "nn_weight")
+    loss = (out["d_xyz"] * T(g["g_xyz"])).sum() + (out["d_rotation"] * T(g["g_rot"])).sum() \
+        + (out["d_nodes"] * T(g["g_nodes"])).sum()
+    loss.backward()
+    U.assert_close(q.grad.cpu().numpy(), g["grad_local_rot"], "dL/dlocal_rotation")
+    U.assert_close(gt.grad.cpu().numpy(), g["grad_global_trans"], "dL/dglobal_trans")
+    U.assert_close(sw._node_radius.grad.cpu().numpy(), g["grad_node_radius"], "dL/d_node_radius")
+    U.assert_close(mask.grad.cpu().numpy(), g["grad_motion_mask"], "dL/dmotion_mask")
+
+
+@pytest.mark.parametrize("N,J,chain,seed", [(10_000, 8, True, 1235), (150_001, 24, False, 1236), (40_000, 64, False, 3)])
+def test_deform_matches_oracle_large(N, J, chain, seed):
+    sc = synth.make_scene(N, J, seed, chain=chain)
+    g = torch.Generator().manual_seed(seed)
+    gx, gr, gn = torch.randn(N, 3, generator=g), torch.randn(N, 4, generator=g), torch.randn(J, 3, generator=g)
+    # oracle (torch CPU autograd)
+    q = sc["local_rotation"].clone().requires_grad_(True)
+    gt = sc["global_trans"].clone().requires_grad_(True)
+    rho = sc["node_radius"].clone().requires_grad_(True)
+    o = O.deform_by_pose(sc["xyz"], sc["joints"], sc["parents"], rho, q, gt, sc["motion_mask"], -1)
+    ((o["d_xyz"] * gx).sum() + (o["d_rotation"] * gr).sum() + (o["d_nodes"] * gn).sum()).backward()
+    # HIP
+    sw = make_warp(sc["joints"], sc["parents"], sc["node_radius"], -1)
+    qh = sc["local_rotation"].cuda().requires_grad_(True)
+    gth = sc["global_trans"].cuda().requires_grad_(True)
+    h = sw.deform_by_pose(sc["xyz"].cuda(), {"local_rotation": qh, "global_trans": gth}, sc["motion_mask"].cuda())
+    ((h["d_xyz"] * gx.cuda()).sum() + (h["d_rotation"] * gr.cuda()).sum() + (h["d_nodes"] * gn.cuda()).sum()).backward()
+    U.assert_close(h["d_xyz"].detach().cpu().numpy(), o["d_xyz"].detach().numpy(), "d_xyz")
+    U.assert_close(h["d_rotation"].detach().cpu().numpy(), o["d_rotation"].detach().numpy(), "d_rotation")
+    U.assert_close(h["d_nodes"].detach().cpu().numpy(), o["d_nodes"].detach().numpy(), "d_nodes", 1e-5)
+    U.assert_close(qh.grad.cpu().numpy(), q.grad.numpy(), "dL/dlocal_rotation", 2e-4)
+    U.assert_close(gth.grad.cpu().numpy(), gt.grad.numpy(), "dL/dglobal_trans", 2e-4)
+    U.assert_close(sw._node_radius.grad.cpu().numpy(), rho.grad.numpy(), "dL/d_node_radius", 2e-4)
+
+
+def test_forward_through_pose_net_and_node_deformation():
+    sc = synth.make_scene(2048, 24, 5)
+    sw = make_warp(sc["joints"], sc["parents"], sc["node_radius"], -1)
+    t = sw.expand_time(torch.tensor([0.37], device="cuda"))
+    assert t.shape == (24, 1)
+    out = sw(sc["xyz"].cuda(), t, motion_mask=sc["motion_mask"].cuda())
+    pose = sw.get_pose_info(t)
+    ref = O.deform_by_pose(sc["xyz"], sc["joints"], sc["parents"], sc["node_radius"], pose["local_rotation"].detach().cpu(),
+                           pose["global_trans"].detach().cpu(), sc["motion_mask"], -1)
+    U.assert_close(out["d_xyz"].detach().cpu().numpy(), ref["d_xyz"].numpy(), "d_xyz via pose_net")
+    out["d_xyz"].sum().backward()
+    assert all(p.grad is not None for p in sw.pose_net.parameters())
+    nd = sw.node_deformation(sc["joints"].cuda(), pose)
+    U.assert_close(nd["d_xyz"].detach().cpu().numpy(), (ref["d_nodes"] - sc["joints"]).numpy(), "node_deformation", 1e-5)
+
+
+def test_variants_not_in_scope_fail_loudly():
+    sc = synth.make_scene(64, 8, 1)
+    sw = SkeletonWarp(joints=sc["joints"], parent_indices=sc["parents"], K=-1).cuda()  # reference defaults: both heads on
+    with pytest.raises(NotImplementedError):
+        sw.deform_by_pose(sc["xyz"].cuda(), {"local_rotation": sc["local_rotation"].cuda(),
+                                             "global_trans": sc["global_trans"].cuda()}, sc["motion_mask"].cuda())

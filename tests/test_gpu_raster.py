@@ -1,0 +1,211 @@
+"""-m gpu: HIP rasterizer (through the C ABI) vs the CPU oracle on identical seeded inputs.
+
+Bar (BASELINE.json north_star): bit-exact tile/depth ordering and indexing; rendered values and
+dL/dparam within 1e-4 relative.  Full-size configs are checked through size-independent properties.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import raster_ref as RR  # noqa: E402
+from riggs_amd import synth  # noqa: E402
+from riggs_amd.rasterizer import (GaussianRasterizer, rasterize_backward, rasterize_forward,  # noqa: E402
+                                  saved_views, RasterArena)
+from tests import gpu_util as U  # noqa: E402
+
+
+def _grads_close(hip, ref, what, frac=1e-4):
+    U.assert_close(hip.cpu().numpy().reshape(ref.shape), ref, what, U.REL_TOL, frac)
+
+
+CASES = [
+    # N, J, seed, H, W, scale, cam kwargs
+    (2000, 8, 1235, 128, 128, 0.03, dict()),                       # small chain-like scene
+    (10000, 8, 1235, 256, 256, 0.012, dict()),                     # BASELINE config C1 size
+    (5000, 24, 7, 200, 333, 0.02, dict(azimuth_deg=90.0)),         # ragged image (not multiples of 16)
+    (3000, 24, 9, 160, 160, 0.25, dict(radius=1.2)),               # camera inside the cloud: near culls, big splats
+]
+
+
+@pytest.mark.parametrize("N,J,seed,H,W,scale,camkw", CASES)
+def test_forward_backward_parity_vs_oracle(N, J, seed, H, W, scale, camkw):
+    sc, act, cam = U.activated_scene(N, J, seed, H, W, scale=scale, **camkw)
+    bg = [0.1, 0.3, 0.7]
+    out_o, so = U.oracle_forward(act, cam, bg)
+    color, radii, depth, alpha, s = U.hip_forward(act, cam, bg)
+    v = saved_views(s)
+    assert so.R > 0
+    U.compare_forward_state(so, v, out_o, color, depth, alpha, radii)
+    # backward with an L1-like image gradient plus depth/alpha cotangents
+    g = torch.Generator().manual_seed(seed)
+    gc = torch.sign(torch.rand(3, H, W, generator=g) - 0.5) / (3 * H * W)
+    gd = torch.randn(1, H, W, generator=g) / (H * W)
+    ga = torch.randn(1, H, W, generator=g) / (H * W)
+    go = RR.backward(so, gc.numpy(), gd.numpy()[0], ga.numpy()[0])
+    d = lambda t: t.cuda().contiguous()  # noqa: E731
+    gh = rasterize_backward(s, d(act["means3D"]), d(act["shs"]), None, d(act["opacities"]), d(act["scales"]),
+                            d(act["rotations"]), None, None, None, d(gc), d(gd), d(ga))
+    g_means3D, g_means2D, g_sh, _, g_opac, g_scales, g_rots, _, _ = gh
+    _grads_close(g_means2D, go["means2D"], "dL/dmeans2D")
+    _grads_close(g_means3D, go["means3D"], "dL/dmeans3D")
+    _grads_close(g_opac, go["opacities"], "dL/dopacity")
+    _grads_close(g_scales, go["scales"], "dL/dscales")
+    _grads_close(g_rots, go["rotations"], "dL/drotations")
+    _grads_close(g_sh, go["shs"], "dL/dsh")
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2])
+def test_lower_sh_degrees(deg):
+    sc, act, cam = U.activated_scene(3000, 8, 21, 96, 96, scale=0.03)
+    out_o, so = U.oracle_forward(act, cam, [0, 0, 0], sh_degree=deg)
+    color, radii, depth, alpha, s = U.hip_forward(act, cam, [0, 0, 0], sh_degree=deg)
+    U.compare_forward_state(so, saved_views(s), out_o, color, depth, alpha, radii)
+    gc = torch.ones(3, 96, 96) / (96 * 96)
+    go = RR.backward(so, gc.numpy(), None, None)
+    d = lambda t: t.cuda().contiguous()  # noqa: E731
+    gh = rasterize_backward(s, d(act["means3D"]), d(act["shs"]), None, d(act["opacities"]), d(act["scales"]),
+                            d(act["rotations"]), None, None, None, d(gc), None, None)
+    _grads_close(gh[2], go["shs"], "dL/dsh deg %d" % deg)
+    _grads_close(gh[0], go["means3D"], "dL/dmeans3D deg %d" % deg)
+
+
+def test_colors_precomp_and_cov3d_precomp():
+    sc, act, cam = U.activated_scene(3000, 8, 33, 112, 80, scale=0.03)
+    g = torch.Generator().manual_seed(1)
+    colors = torch.rand(3000, 3, generator=g)
+    cov6 = torch.from_numpy(U.oracle_forward(act, cam, [0, 0, 0])[1].cov3D.copy())
+    out_o, so = U.oracle_forward(act, cam, [1, 1, 1], colors=colors, cov6=cov6, mod=1.0)
+    color, radii, depth, alpha, s = U.hip_forward(act, cam, [1, 1, 1], colors=colors, cov6=cov6)
+    U.compare_forward_state(so, saved_views(s), out_o, color, depth, alpha, radii)
+    gc = torch.randn(3, 112, 80, generator=g) / (112 * 80)
+    go = RR.backward(so, gc.numpy(), None, None)
+    d = lambda t: t.cuda().contiguous()  # noqa: E731
+    gh = rasterize_backward(s, d(act["means3D"]), None, d(colors), d(act["opacities"]), None, None, d(cov6), None,
+                            None, d(gc), None, None)
+    _grads_close(gh[3], go["colors_precomp"], "dL/dcolors_precomp")
+    _grads_close(gh[7], go["cov3D_precomp"], "dL/dcov3D_precomp")
+    _grads_close(gh[0], go["means3D"], "dL/dmeans3D")
+
+
+def test_scale_modifier():
+    sc, act, cam = U.activated_scene(2000, 8, 5, 64, 64, scale=0.03)
+    out_o, so = U.oracle_forward(act, cam, [0, 0, 0], mod=0.5)
+    color, radii, depth, alpha, s = U.hip_forward(act, cam, [0, 0, 0], mod=0.5)
+    U.compare_forward_state(so, saved_views(s), out_o, color, depth, alpha, radii)
+
+
+def test_empty_and_all_culled_inputs():
+    cam = synth.look_at_camera(48, 48)
+    st = U.settings_for(cam, [0.2, 0.4, 0.6])
+    z = lambda *s: torch.zeros(*s, device="cuda")  # noqa: E731
+    color, radii, depth, alpha, s = rasterize_forward(st, z(0, 3), z(0, 16, 3), None, z(0, 1), z(0, 3), z(0, 4), None)
+    assert radii.numel() == 0 and torch.allclose(color[2], torch.full_like(color[2], 0.6)) and float(alpha.abs().max()) == 0
+    # everything behind the camera
+    sc, act, cam = U.activated_scene(500, 8, 3, 48, 48)
+    act["means3D"] = act["means3D"] + torch.tensor([0.0, 0.0, 0.0])
+    cam_far = synth.look_at_camera(48, 48, radius=4.0)
+    act["means3D"] = act["means3D"] * 0 + cam_far.camera_center + torch.tensor([0.0, 0.0, 0.0])
+    color, radii, depth, alpha, s = U.hip_forward(act, cam_far, [0.2, 0.4, 0.6])
+    assert int(radii.max()) == 0 and saved_views(s)["R"] == 0
+    assert torch.allclose(color[0], torch.full_like(color[0], 0.2))
+
+
+def test_rasterizer_module_errors_and_autograd_surface():
+    sc, act, cam = U.activated_scene(1500, 8, 11, 64, 64, scale=0.03)
+    st = U.settings_for(cam, [0, 0, 0])
+    r = GaussianRasterizer(raster_settings=st)
+    d = lambda t: t.cuda().contiguous().requires_grad_(True)  # noqa: E731
+    m3, op, sc_, ro, sh = d(act["means3D"]), d(act["opacities"]), d(act["scales"]), d(act["rotations"]), d(act["shs"])
+    m2 = torch.zeros_like(m3, requires_grad=True)
+    with pytest.raises(Exception, match="SHs or precomputed colors"):
+        r(means3D=m3, means2D=m2, opacities=op, shs=None, colors_precomp=None, scales=sc_, rotations=ro)
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        r(means3D=m3, means2D=m2, opacities=op, shs=sh, scales=sc_, rotations=None)
+    color, radii, depth, alpha = r(means3D=m3, means2D=m2, opacities=op, shs=sh, colors_precomp=None, scales=sc_,
+                                   rotations=ro, cov3D_precomp=None)
+    assert color.shape == (3, 64, 64) and depth.shape == (1, 64, 64) and alpha.shape == (1, 64, 64)
+    assert radii.dtype == torch.int32 and radii.shape == (1500,)
+    (color.sum() + 0.1 * depth.sum()).backward()
+    for t in (m3, m2, op, sc_, ro, sh):
+        assert t.grad is not None and torch.isfinite(t.grad).all()
+    assert float(m2.grad[:, 2].abs().max()) == 0.0 and float(m2.grad[:, :2].abs().max()) > 0
+    with pytest.raises(Exception):
+        r(means3D=act["means3D"], means2D=None, opacities=act["opacities"], shs=act["shs"], scales=act["scales"],
+          rotations=act["rotations"])  # CPU tensors: the product path is GPU-only and says so
+
+
+def test_arena_mode_matches_sync_mode_and_recovers_from_overflow():
+    sc, act, cam = U.activated_scene(4000, 8, 2, 128, 128, scale=0.03)
+    d = lambda t: t.cuda().contiguous()  # noqa: E731
+    st = U.settings_for(cam, [0, 0, 0])
+    args = (d(act["means3D"]), d(act["shs"]), None, d(act["opacities"]), d(act["scales"]), d(act["rotations"]), None)
+    ref = rasterize_forward(st, *args)
+    arena = RasterArena(min_capacity=16)
+    a1 = rasterize_forward(st, *args, arena=arena)   # first call synchronises and sizes the arena
+    a2 = rasterize_forward(st, *args, arena=arena)   # second call: no host sync, padded sort
+    assert torch.equal(ref[0], a1[0]) and torch.equal(ref[0], a2[0])
+    assert torch.equal(ref[1], a2[1])
+    from riggs_amd.rasterizer import arena_check
+    assert arena_check(a2[4], arena)
+    arena.capacity = 0
+    arena.binning = None
+    arena.last_R = 10  # force a too-small arena
+    arena.min_capacity = 16
+    a3 = rasterize_forward(st, *args, arena=arena)
+    assert not arena_check(a3[4], arena)  # overflow detected, arena.last_R now holds the true count
+    a4 = rasterize_forward(st, *args, arena=arena)
+    assert arena_check(a4[4], arena) and torch.equal(ref[0], a4[0])
+
+
+@pytest.mark.parametrize("N,J,H,W", [(150_000, 24, 800, 800), (300_000, 32, 800, 800)])
+def test_full_size_properties(N, J, H, W):
+    """BASELINE configs C2 / C3 at full size: size-independent properties instead of the oracle."""
+    sc, act, cam = U.activated_scene(N, J, 1234 + 2, H, W)
+    d = lambda t: t.cuda().contiguous()  # noqa: E731
+    bg0 = U.settings_for(cam, [0, 0, 0])
+    args = (d(act["means3D"]), d(act["shs"]), None, d(act["opacities"]), d(act["scales"]), d(act["rotations"]), None)
+    color, radii, depth, alpha, s = rasterize_forward(bg0, *args)
+    v = saved_views(s)
+    R = v["R"]
+    tiles = v["tiles_touched"].long()
+    assert int(tiles.sum()) == R and R > N  # checksum of checksums: scan total == emitted instances
+    # tile-major, then depth-ascending, ties by ascending Gaussian index (stable)
+    pl, tk = v["point_list"].long(), v["tile_keys"].long()
+    dbits = v["xyd"][:, 2].contiguous().view(torch.int32).long()[pl]
+    key = tk * (1 << 32) + dbits
+    assert bool((key[1:] >= key[:-1]).all()), "instances not sorted by (tile, depth bits)"
+    same = key[1:] == key[:-1]
+    assert bool((pl[1:][same] > pl[:-1][same]).all()), "equal keys must keep ascending Gaussian index"
+    rg = v["ranges"].long()
+    assert int(rg[0, 0]) == 0 or int(rg[:, 1].max()) == R
+    counts = torch.bincount(tk, minlength=rg.shape[0])
+    assert torch.equal(counts, rg[:, 1] - rg[:, 0])
+    # compositing identity: sum_i alpha_i T_i == 1 - T_final
+    fT = v["final_T"]
+    assert float((alpha[0] + fT - 1).abs().max()) < 2e-5
+    assert float(fT.min()) >= 0.9e-4 * 0 and float(fT.max()) <= 1.0
+    # linearity in the background: color(bg) == color(0) + T_final * bg
+    bg1 = U.settings_for(cam, [0.25, 0.5, 1.0])
+    color1 = rasterize_forward(bg1, *args)[0]
+    ref = color + fT[None] * torch.tensor([0.25, 0.5, 1.0], device="cuda")[:, None, None]
+    assert float((color1 - ref).abs().max()) < 1e-5
+    # determinism of the forward (bitwise)
+    assert torch.equal(color, rasterize_forward(bg0, *args)[0])
+    # backward is linear in the incoming gradient
+    g = torch.Generator().manual_seed(0)
+    gc = (torch.sign(torch.rand(3, H, W, generator=g) - 0.5) / (3 * H * W)).cuda()
+    g1 = rasterize_backward(s, *args, None, None, gc, None, None)
+    g2 = rasterize_backward(s, *args, None, None, 2 * gc, None, None)
+    for a, b, nm in zip(g1, g2, "means3D means2D sh colors opac scales rots cov".split()):
+        if a is None:
+            continue
+        scale = float(a.abs().max())
+        assert float((2 * a - b).abs().max()) <= 2e-4 * max(scale, 1e-20), nm
+        assert torch.isfinite(a).all()
+    # invisible Gaussians receive exactly zero gradient
+    inv = radii == 0
+    assert float(g1[0][inv].abs().max() if inv.any() else 0.0) == 0.0
