@@ -1,0 +1,240 @@
+#!/usr/bin/env python
+"""bench.py — one "step" = one pass of RigGS's per-frame hot path over one frame:
+   PoseMLP(t) -> skeleton deform (FK + skinning/LBS, HIP) -> render glue + rasterizer forward (HIP)
+   -> given dL/dimage -> rasterizer backward (HIP) -> deform backward (HIP) -> PoseMLP backward,
+producing gradients for every Gaussian and skeleton parameter.  No loss, optimizer,
+densification or logging.  N ranks = N independent frames per step (weak scaling) followed by one
+RCCL all-reduce of the flat gradient buffer of the replicated parameters.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
+timed live with HIP events on its launch stream) and `cpu_baseline` (the CPU oracle timed on the host cores).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOAD = dict(N=300_000, J=24, H=800, W=800, seed=1237)  # BASELINE.json metric: 300k Gaussians @800x800, 24 joints
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+class Pipe:
+    convert_SHs_python = False
+    compute_cov3D_python = False
+    debug = False
+
+
+def build_workload(rank: int, device: str):
+    from riggs_amd import synth
+    from riggs_amd.gaussian_model import GaussianModel
+    from riggs_amd.skeleton import SkeletonWarp
+    w = WORKLOAD
+    sc = synth.make_scene(w["N"], w["J"], w["seed"])
+    cam = synth.look_at_camera(w["H"], w["W"], azimuth_deg=45.0 * rank, fid=0.37 + 0.05 * rank).to(device)
+    gm = GaussianModel.from_tensors(sc["xyz"], sc["features_dc"], sc["features_rest"], sc["scaling"], sc["rotation"],
+                                    sc["opacity"], device=device)
+    torch.manual_seed(w["seed"])
+    sw = SkeletonWarp(joints=sc["joints"], parent_indices=sc["parents"], K=-1, hyper_dim=8,
+                      use_skinning_weight_mlp=False, use_template_offsets=False).to(device)
+    sw._node_radius.data = sc["node_radius"].to(device)
+    with torch.no_grad():  # small seeded pose so that the PoseMLP output is a plausible articulation
+        sw.pose_net.rotation_predictor.weight.mul_(0.1)
+        sw.pose_net.translation_predictor.weight.mul_(0.1)
+    return sc, cam, gm, sw
+
+
+def params_of(gm, sw):
+    return gm.parameters() + [sw._node_radius] + list(sw.pose_net.parameters())
+
+
+def make_step(cam, gm, sw, gimg, arena, world):
+    from riggs_amd.render import render
+    import torch.distributed as dist
+    bg = torch.zeros(3, device=gimg.device)
+    params = params_of(gm, sw)
+    t_in = sw.expand_time(cam.fid)
+
+    def step():
+        for p in params:
+            p.grad = None
+        dv = sw(gm.get_xyz.detach(), t_in, motion_mask=gm.motion_mask)  # skeleton.step() (train_rig.py:411)
+        pkg = render(cam, gm, Pipe, bg, dv["d_xyz"], dv["d_rotation"], dv["d_scaling"], fused=True, arena=arena)
+        pkg["render"].backward(gimg)
+        if world > 1:
+            flat = torch.cat([p.grad.reshape(-1) for p in params])
+            dist.all_reduce(flat)  # RCCL over xGMI: sum of the per-frame gradients
+            flat.div_(world)
+            o = 0
+            for p in params:
+                n = p.numel()
+                p.grad = flat[o:o + n].view_as(p)
+                o += n
+        return pkg
+    return step
+
+
+def cpu_baseline(sc, cam_cpu, gimg_cpu, budget_s=20.0):
+    """The CPU oracle (torch-CPU deform restatement + C/OpenMP rasterizer) on the SAME workload, all host cores."""
+    import numpy as np
+    from oracle import deform_ref as O
+    from oracle import raster_ref as RR
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    RR.set_threads(cores)
+    tanx, tany = math.tan(cam_cpu.FoVx / 2), math.tan(cam_cpu.FoVy / 2)
+
+    def one():
+        leaf = lambda t: t.clone().requires_grad_(True)  # noqa: E731
+        P = {k: leaf(sc[k]) for k in ("xyz", "features_dc", "features_rest", "scaling", "rotation", "opacity",
+                                      "local_rotation", "global_trans", "node_radius")}
+        dv = O.deform_by_pose(P["xyz"].detach(), sc["joints"], sc["parents"], P["node_radius"], P["local_rotation"],
+                              P["global_trans"], sc["motion_mask"], -1)
+        m3, op, scl, rot, shs = O.render_glue(P["xyz"], P["features_dc"], P["features_rest"], P["scaling"],
+                                              P["rotation"], P["opacity"], dv["d_xyz"], dv["d_rotation"], dv["d_scaling"])
+        out, saved = RR.forward(m3.detach().numpy(), op.detach().numpy(), cam_cpu.world_view_transform.numpy(),
+                                cam_cpu.full_proj_transform.numpy(), cam_cpu.camera_center.numpy(), tanx, tany,
+                                cam_cpu.image_height, cam_cpu.image_width, np.zeros(3, np.float32),
+                                shs=shs.detach().numpy(), scales=scl.detach().numpy(), rotations=rot.detach().numpy())
+        g = RR.backward(saved, gimg_cpu.numpy(), None, None)
+        T = torch.from_numpy
+        torch.autograd.backward([m3, op, scl, rot, shs], [T(g["means3D"]), T(g["opacities"]), T(g["scales"]),
+                                                          T(g["rotations"]), T(g["shs"])])
+        return saved.R
+    t0 = time.perf_counter()
+    one()  # warm-up (page-in, thread pools)
+    warm = time.perf_counter() - t0
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one()
+        n += 1
+        el = time.perf_counter() - t0
+        if el + warm > budget_s or n >= 5:
+            break
+    return {"value": n / el, "unit": "iters/s", "cores": cores, "kind": "port",
+            "sample": "%d full iterations of the same workload (300k Gaussians, 24 joints, 800x800): torch-CPU deform "
+                      "oracle + C/OpenMP rasterizer oracle fwd+bwd, %d threads" % (n, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-all", action="store_true", help="print a per-kernel event-timer table to stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+
+    from riggs_amd import _lib as L
+    from riggs_amd.rasterizer import RasterArena
+    lib = L.lib()
+    sc, cam, gm, sw = build_workload(rank, dev)
+    arena = RasterArena()
+    # dL/dimage of an L1 loss against a seeded target, computed ONCE from an untimed render
+    w = WORKLOAD
+    g = torch.Generator().manual_seed(w["seed"] + 100 + rank)
+    target = torch.rand(3, w["H"], w["W"], generator=g).to(dev)
+    gimg = torch.zeros(3, w["H"], w["W"], device=dev)
+    step = make_step(cam, gm, sw, gimg, arena, world)
+    pkg = step()
+    gimg.copy_(torch.sign(pkg["render"].detach() - target) / (3 * w["H"] * w["W"]))
+    torch.cuda.synchronize()
+    arena.resolve()
+    R = arena.last_R
+
+    names = [lib.riggs_prof_name(i).decode() for i in range(lib.riggs_prof_count())]
+    dom = names.index("render_bwd")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    lib.riggs_prof_reset()
+    lib.riggs_prof_enable(1 << dom)  # two HIP events per step around the dominant kernel only
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    lib.riggs_prof_enable(0)
+    import ctypes as C
+    tot, cnt = C.c_float(), C.c_int32()
+    L.check(lib.riggs_prof_read(dom, C.byref(tot), C.byref(cnt)), "riggs_prof_read")
+    dom_ms = tot.value / max(cnt.value, 1)
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    table = None
+    if args.profile_all or rank == 0:
+        lib.riggs_prof_reset()
+        lib.riggs_prof_enable(0xFFFFFFFF)
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+        lib.riggs_prof_enable(0)
+        table = {}
+        for i, nm in enumerate(names):
+            L.check(lib.riggs_prof_read(i, C.byref(tot), C.byref(cnt)), "riggs_prof_read")
+            if cnt.value:
+                table[nm] = round(tot.value / cnt.value, 4)
+        if args.profile_all:
+            sys.stderr.write("per-launch ms (HIP events, 10 steps): %s\n" % json.dumps(table))
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * args.steps / elapsed
+        HW = w["H"] * w["W"]
+        # algorithmic bytes of ONE render_bwd launch: per tile instance 4 (id) + 48 (three
+        # float4 records) read + 36 (nine accumulated floats) written; per pixel 4+4+12 read.
+        dom_bytes = R * 88 + HW * 20
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        out = {
+            "metric": "train iters/sec (deform+raster fwd+bwd), 300k Gaussians @800x800",
+            "value": round(value, 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "300k Gaussians / 24-joint skeleton / 800x800, LBS-only, SH degree 3, anisotropic, "
+                                   "one frame per GPU per step", "num_gaussians": w["N"], "num_joints": w["J"],
+                       "image": [w["H"], w["W"]], "tile_instances_R": R, "parallelism": "frames x%d" % world},
+            "roofline": {"kernel": "render_bwd", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "ms_per_launch": round(dom_ms, 4), "algorithmic_bytes_per_launch": dom_bytes,
+                         "pairs_per_s": round(256.0 * R / (dom_ms * 1e-3), 1) if dom_ms > 0 else None},
+            "kernels_ms": table,
+        }
+        if not args.no_cpu_baseline:
+            cam_cpu = cam.to("cpu")
+            out["cpu_baseline"] = cpu_baseline(sc, cam_cpu, gimg.cpu())
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

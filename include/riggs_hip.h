@@ -180,6 +180,18 @@ int riggs_lbs_backward(int32_t num_points, int32_t num_joints, int32_t K, const 
 size_t riggs_knn_workspace_bytes(int32_t num_points);
 int riggs_dist2_knn3(int32_t num_points, const float* points, float* out, void* workspace, riggs_stream stream);
 
+/* =====================================================================
+ * Kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
+ * `mask` has bit i set to time stage i; 0 disables (default: no events, no overhead).
+ * riggs_prof_read synchronises on the recorded events and returns the sum / count since the
+ * last riggs_prof_reset.  Stage ids: riggs_prof_name(i) for i in [0, riggs_prof_count()).
+ * ===================================================================== */
+int riggs_prof_count(void);
+const char* riggs_prof_name(int32_t id);
+int riggs_prof_enable(uint32_t mask);
+int riggs_prof_reset(void);
+int riggs_prof_read(int32_t id, float* total_ms, int32_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,6 +49,11 @@ _SIGS = {
     "riggs_fk_backward": (C.c_int, [C.c_int32] + [_P] * 8),
     "riggs_lbs_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [_P] * 13),
     "riggs_lbs_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [_P] * 15),
+    "riggs_prof_count": (C.c_int, []),
+    "riggs_prof_name": (C.c_char_p, [C.c_int32]),
+    "riggs_prof_enable": (C.c_int, [C.c_uint32]),
+    "riggs_prof_reset": (C.c_int, []),
+    "riggs_prof_read": (C.c_int, [C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "riggs_knn_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "riggs_dist2_knn3": (C.c_int, [C.c_int32, _P, _P, _P, _P]),
 }

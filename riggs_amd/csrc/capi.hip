@@ -2,6 +2,7 @@
 #include <stdarg.h>
 
 #include <cstring>
+#include <vector>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
@@ -15,6 +16,32 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+// ---- event-based kernel timing -------------------------------------------------------
+static const char* kProfNames[PROF_COUNT] = {
+    "preprocess_fwd", "depth_sort", "scan", "emit", "tile_sort", "ranges", "render_fwd", "render_bwd",
+    "preprocess_bwd", "fk_fwd", "lbs_fwd", "lbs_bwd", "fk_bwd", "knn"};
+struct ProfSlot {
+  std::vector<hipEvent_t> start, stop;
+  size_t used = 0;
+};
+static uint32_t g_prof_mask = 0;
+static ProfSlot g_prof[PROF_COUNT];
+void prof_begin(int id, hipStream_t s) {
+  if (!(g_prof_mask >> id & 1u)) return;
+  ProfSlot& p = g_prof[id];
+  if (p.used == p.start.size()) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    p.start.push_back(a); p.stop.push_back(b);
+  }
+  (void)hipEventRecord(p.start[p.used], s);
+}
+void prof_end(int id, hipStream_t s) {
+  if (!(g_prof_mask >> id & 1u)) return;
+  ProfSlot& p = g_prof[id];
+  if (p.used < p.start.size()) { (void)hipEventRecord(p.stop[p.used], s); p.used++; }
 }
 
 static size_t sort_temp_bytes_u32(size_t n) {
@@ -85,6 +112,28 @@ using namespace riggs;
 extern "C" {
 
 int riggs_version(void) { return 100; }
+
+int riggs_prof_count(void) { return PROF_COUNT; }
+const char* riggs_prof_name(int32_t id) { return (id >= 0 && id < PROF_COUNT) ? kProfNames[id] : ""; }
+int riggs_prof_enable(uint32_t mask) { g_prof_mask = mask; return 0; }
+int riggs_prof_reset(void) {
+  for (int i = 0; i < PROF_COUNT; i++) g_prof[i].used = 0;
+  return 0;
+}
+int riggs_prof_read(int32_t id, float* total_ms, int32_t* launches) {
+  RIGGS_REQUIRE(id >= 0 && id < PROF_COUNT, "bad stage id");
+  ProfSlot& p = g_prof[id];
+  float tot = 0.f;
+  for (size_t i = 0; i < p.used; i++) {
+    RIGGS_HIP_CHECK(hipEventSynchronize(p.stop[i]));
+    float ms = 0.f;
+    RIGGS_HIP_CHECK(hipEventElapsedTime(&ms, p.start[i], p.stop[i]));
+    tot += ms;
+  }
+  *total_ms = tot;
+  *launches = (int32_t)p.used;
+  return 0;
+}
 const char* riggs_last_error(void) { return g_err; }
 
 size_t riggs_raster_geom_bytes(int32_t N) { return geom_layout(N).total; }
@@ -116,9 +165,11 @@ static int fill_pre_args(PreArgs& a, const riggs_raster_cfg* c, const float* mea
                          char* geom, int32_t* radii) {
   RIGGS_REQUIRE(c != nullptr, "cfg is NULL");
   RIGGS_REQUIRE(c->num_points >= 0 && c->image_height > 0 && c->image_width > 0, "bad sizes");
-  RIGGS_REQUIRE((shs != nullptr) != (colors_precomp != nullptr), "Please provide excatly one of either SHs or precomputed colors!");
-  RIGGS_REQUIRE(((scales != nullptr && rots != nullptr) != (cov3D_precomp != nullptr)) && ((scales != nullptr) == (rots != nullptr)),
-                "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+  if (c->num_points > 0) {  // (empty tensors have NULL data pointers)
+    RIGGS_REQUIRE((shs != nullptr) != (colors_precomp != nullptr), "Please provide excatly one of either SHs or precomputed colors!");
+    RIGGS_REQUIRE(((scales != nullptr && rots != nullptr) != (cov3D_precomp != nullptr)) && ((scales != nullptr) == (rots != nullptr)),
+                  "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+  }
   RIGGS_REQUIRE(c->sh_degree >= 0 && c->sh_degree <= 3, "sh_degree must be 0..3");
   RIGGS_REQUIRE(shs == nullptr || c->sh_coeffs >= (c->sh_degree + 1) * (c->sh_degree + 1), "sh_coeffs too small for sh_degree");
   RIGGS_REQUIRE(!(c->glue && cov3D_precomp), "glue mode needs scales/rotations");
@@ -152,17 +203,23 @@ int riggs_raster_preprocess(const riggs_raster_cfg* cfg, const float* means3D, c
   RIGGS_HIP_CHECK(hipMemsetAsync(counters, 0, 16, s));
   if (N == 0) return 0;
   GeomLayout L = geom_layout(N);
-  launch_preprocess_fwd(a, s);
+  { ProfScope ps(PROF_PREPROCESS_FWD, s); launch_preprocess_fwd(a, s); }
   if (debug_sync(cfg->debug, s, "preprocess_fwd")) return 1;
   // depth sort of the Gaussians (stable: equal depths keep ascending index)
   size_t tb = L.temp_bytes;
-  RIGGS_HIP_CHECK(rocprim::radix_sort_pairs(geom + L.temp, tb, (uint32_t*)(geom + L.depth_key),
-                                            (uint32_t*)(geom + L.depth_key_sorted), (uint32_t*)(geom + L.order_in),
-                                            (uint32_t*)(geom + L.order), (size_t)N, 0, 32, s));
-  launch_gather_tiles(N, (uint32_t*)(geom + L.order), (uint32_t*)(geom + L.tiles), (uint32_t*)(geom + L.tt_sorted), s);
-  tb = L.temp_bytes;
-  RIGGS_HIP_CHECK(rocprim::inclusive_scan(geom + L.temp, tb, (uint32_t*)(geom + L.tt_sorted),
-                                          (uint32_t*)(geom + L.offsets), (size_t)N, rocprim::plus<uint32_t>(), s));
+  {
+    ProfScope ps(PROF_DEPTH_SORT, s);
+    RIGGS_HIP_CHECK(rocprim::radix_sort_pairs(geom + L.temp, tb, (uint32_t*)(geom + L.depth_key),
+                                              (uint32_t*)(geom + L.depth_key_sorted), (uint32_t*)(geom + L.order_in),
+                                              (uint32_t*)(geom + L.order), (size_t)N, 0, 32, s));
+  }
+  {
+    ProfScope ps(PROF_SCAN, s);
+    launch_gather_tiles(N, (uint32_t*)(geom + L.order), (uint32_t*)(geom + L.tiles), (uint32_t*)(geom + L.tt_sorted), s);
+    tb = L.temp_bytes;
+    RIGGS_HIP_CHECK(rocprim::inclusive_scan(geom + L.temp, tb, (uint32_t*)(geom + L.tt_sorted),
+                                            (uint32_t*)(geom + L.offsets), (size_t)N, rocprim::plus<uint32_t>(), s));
+  }
   // publish R for the host (counters[0]); emit_kernel rewrites it together with the overflow flag
   RIGGS_HIP_CHECK(hipMemcpyAsync(counters, geom + L.offsets + (size_t)(N - 1) * 4, 4, hipMemcpyDeviceToDevice, s));
   if (debug_sync(cfg->debug, s, "depth sort / scan")) return 1;
@@ -186,17 +243,26 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
   RIGGS_HIP_CHECK(hipMemsetAsync(img + I.ranges, 0, (size_t)(T + 1) * 8, s));
   const uint32_t* point_list = (const uint32_t*)(bin + B.vals_b);
   if (N > 0 && cap > 0) {
-    launch_emit(N, gx, T, cap, (const uint32_t*)(geom + G.order), (const uint32_t*)(geom + G.offsets),
-                (const uint32_t*)(geom + G.tiles), (const ushort4*)(geom + G.rect), (uint32_t*)(bin + B.keys_a),
-                (uint32_t*)(bin + B.vals_a), counters, s);
+    {
+      ProfScope ps(PROF_EMIT, s);
+      launch_emit(N, gx, T, cap, (const uint32_t*)(geom + G.order), (const uint32_t*)(geom + G.offsets),
+                  (const uint32_t*)(geom + G.tiles), (const ushort4*)(geom + G.rect), (uint32_t*)(bin + B.keys_a),
+                  (uint32_t*)(bin + B.vals_a), counters, s);
+    }
     if (debug_sync(cfg->debug, s, "emit")) return 1;
     int end_bit = 1;
     while ((1u << end_bit) <= (uint32_t)T) end_bit++;  // sentinel key T must be representable
     size_t tb = B.temp_bytes;
-    RIGGS_HIP_CHECK(rocprim::radix_sort_pairs(bin + B.temp, tb, (uint32_t*)(bin + B.keys_a), (uint32_t*)(bin + B.keys_b),
-                                              (uint32_t*)(bin + B.vals_a), (uint32_t*)(bin + B.vals_b), (size_t)cap, 0,
-                                              end_bit, s));
-    launch_ranges(cap, T, (const uint32_t*)(bin + B.keys_b), counters, (uint2*)(img + I.ranges), s);
+    {
+      ProfScope ps(PROF_TILE_SORT, s);
+      RIGGS_HIP_CHECK(rocprim::radix_sort_pairs(bin + B.temp, tb, (uint32_t*)(bin + B.keys_a), (uint32_t*)(bin + B.keys_b),
+                                                (uint32_t*)(bin + B.vals_a), (uint32_t*)(bin + B.vals_b), (size_t)cap, 0,
+                                                end_bit, s));
+    }
+    {
+      ProfScope ps(PROF_RANGES, s);
+      launch_ranges(cap, T, (const uint32_t*)(bin + B.keys_b), counters, (uint2*)(img + I.ranges), s);
+    }
     if (debug_sync(cfg->debug, s, "tile sort / ranges")) return 1;
   }
   RenderArgs r;
@@ -207,7 +273,7 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
   r.bg = cfg->bg;
   r.final_T = (float*)(img + I.final_T); r.n_contrib = (uint32_t*)(img + I.n_contrib);
   r.out_color = out_color; r.out_depth = out_depth; r.out_alpha = out_alpha;
-  launch_render_fwd(r, s);
+  { ProfScope ps(PROF_RENDER_FWD, s); launch_render_fwd(r, s); }
   if (debug_sync(cfg->debug, s, "render_fwd")) return 1;
   return 0;
 }
@@ -251,13 +317,13 @@ int riggs_raster_backward(const riggs_raster_cfg* cfg, const float* means3D, con
   r.final_T = (const float*)(img + I.final_T); r.n_contrib = (const uint32_t*)(img + I.n_contrib);
   r.dL_dcolor = dL_dcolor; r.dL_ddepth = dL_ddepth; r.dL_dalpha = dL_dalpha;
   r.gacc = (float*)workspace;
-  if (cap > 0) launch_render_bwd(r, s);
+  if (cap > 0) { ProfScope ps(PROF_RENDER_BWD, s); launch_render_bwd(r, s); }
   if (debug_sync(cfg->debug, s, "render_bwd")) return 1;
   b.g_mean2D_conic = (const float*)workspace;
   b.dL_dmeans3D = dL_dmeans3D; b.dL_dmeans2D = dL_dmeans2D; b.dL_dsh = dL_dsh; b.dL_dcolors = dL_dcolors_precomp;
   b.dL_dopac = dL_dopacities; b.dL_dscales = dL_dscales; b.dL_drots = dL_drotations; b.dL_dcov3D = dL_dcov3D;
   b.dL_dd_scaling = dL_dd_scaling;
-  launch_preprocess_bwd(b, s);
+  { ProfScope ps(PROF_PREPROCESS_BWD, s); launch_preprocess_bwd(b, s); }
   if (debug_sync(cfg->debug, s, "preprocess_bwd")) return 1;
   return 0;
 }

@@ -45,6 +45,19 @@ inline int debug_sync(int debug, hipStream_t s, const char* what) {
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
+// ---- in-library kernel timing (HIP events on the launch stream; see riggs_prof_* in the ABI) ----
+enum ProfId {
+  PROF_PREPROCESS_FWD = 0, PROF_DEPTH_SORT, PROF_SCAN, PROF_EMIT, PROF_TILE_SORT, PROF_RANGES, PROF_RENDER_FWD,
+  PROF_RENDER_BWD, PROF_PREPROCESS_BWD, PROF_FK_FWD, PROF_LBS_FWD, PROF_LBS_BWD, PROF_FK_BWD, PROF_KNN, PROF_COUNT
+};
+void prof_begin(int id, hipStream_t s);
+void prof_end(int id, hipStream_t s);
+struct ProfScope {
+  int id; hipStream_t s;
+  ProfScope(int id_, hipStream_t s_) : id(id_), s(s_) { prof_begin(id, s); }
+  ~ProfScope() { prof_end(id, s); }
+};
+
 // ---- arena layouts ---------------------------------------------------------
 struct GeomLayout {
   size_t xyd, conic_o, rgb, cov3D, clamped, tiles, rect, depth_key, depth_key_sorted, order_in, order, tt_sorted,

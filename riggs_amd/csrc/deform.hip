@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64) void fk_backward_kernel(int J, const float* __r
 // ------------------------------------------------------------------------------------ LBS
 struct Bone {        // 24 floats, LDS resident
   float a[3];        // parent joint (segment start)  skeleton_warp.py:208-209
-  float inv_len2;    // 1 / max(|b-a|^2, 1e-6)        :226
+  float len2c;       // max(|b-a|^2, 1e-6)            :226
   float ba[3];       // b - a
   float inv2r2;      // 1 / (2 exp(rho)^2)            :65-66
   float G[12];       // global transform of the CHILD joint
@@ -208,14 +208,13 @@ __device__ __forceinline__ void stage_bones(const LbsArgs& a, Bone* bones) {
   for (int k = threadIdx.x; k < a.J - 1; k += blockDim.x) {
     const int child = k + 1, par = a.parents[child];
     Bone b;
-    float l2 = 0.f;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       b.a[c] = a.joints[3 * par + c];
       b.ba[c] = a.joints[3 * child + c] - b.a[c];
-      l2 += b.ba[c] * b.ba[c];
     }
-    b.inv_len2 = 1.0f / fmaxf(l2, 1e-6f);
+    const float l2 = __fadd_rn(__fadd_rn(__fmul_rn(b.ba[0], b.ba[0]), __fmul_rn(b.ba[1], b.ba[1])), __fmul_rn(b.ba[2], b.ba[2]));
+    b.len2c = fmaxf(l2, 1e-6f);
     const float rad = expf(a.node_radius_log[child]);
     b.inv2r2 = 1.0f / (2.0f * rad * rad);
 #pragma unroll
@@ -227,12 +226,16 @@ __device__ __forceinline__ void stage_bones(const LbsArgs& a, Bone* bones) {
   __syncthreads();
 }
 
+// line_segment_distance (skeleton_warp.py:215-238), squared.  Written in the reference's own
+// operation order with FP contraction off: bones that share a joint give near-tied distances
+// and the top-K selection (K > 0) must break those ties the way the reference's arithmetic does.
 __device__ __forceinline__ float bone_d2(const Bone& b, float px, float py, float pz) {
+#pragma clang fp contract(off)
   const float ex = px - b.a[0], ey = py - b.a[1], ez = pz - b.a[2];
-  float t = (ex * b.ba[0] + ey * b.ba[1] + ez * b.ba[2]) * b.inv_len2;
+  float t = ((ex * b.ba[0] + ey * b.ba[1]) + ez * b.ba[2]) / b.len2c;
   t = fminf(fmaxf(t, 0.0f), 1.0f);
-  const float sx = t * b.ba[0] - ex, sy = t * b.ba[1] - ey, sz = t * b.ba[2] - ez;
-  return sx * sx + sy * sy + sz * sz;
+  const float sx = (b.a[0] + t * b.ba[0]) - px, sy = (b.a[1] + t * b.ba[1]) - py, sz = (b.a[2] + t * b.ba[2]) - pz;
+  return (sx * sx + sy * sy) + sz * sz;
 }
 
 // Top-K selection state: the K smallest (d2, idx) pairs in ascending order, by K selection
@@ -402,8 +405,11 @@ int riggs_fk_forward(int32_t J, const float* local_rot, const float* joints, con
                      const float* global_trans, float* transforms, float* node_rot, float* d_nodes,
                      riggs_stream stream) {
   RIGGS_REQUIRE(J >= 1 && J <= MAX_J, "num_joints must be in [1, 64]");
-  hipLaunchKernelGGL(fk_forward_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, J, local_rot, joints, parents,
-                     global_trans, transforms, node_rot, d_nodes);
+  {
+    ProfScope ps(PROF_FK_FWD, (hipStream_t)stream);
+    hipLaunchKernelGGL(fk_forward_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, J, local_rot, joints, parents,
+                       global_trans, transforms, node_rot, d_nodes);
+  }
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -412,8 +418,11 @@ int riggs_fk_backward(int32_t J, const float* local_rot, const float* joints, co
                       const float* dL_dtransforms, const float* dL_dd_nodes, float* dL_dlocal_rot,
                       float* dL_dglobal_trans, riggs_stream stream) {
   RIGGS_REQUIRE(J >= 1 && J <= MAX_J, "num_joints must be in [1, 64]");
-  hipLaunchKernelGGL(fk_backward_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, J, local_rot, joints, parents,
-                     dL_dtransforms, dL_dd_nodes, dL_dlocal_rot, dL_dglobal_trans);
+  {
+    ProfScope ps(PROF_FK_BWD, (hipStream_t)stream);
+    hipLaunchKernelGGL(fk_backward_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, J, local_rot, joints, parents,
+                       dL_dtransforms, dL_dd_nodes, dL_dlocal_rot, dL_dglobal_trans);
+  }
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -439,7 +448,10 @@ int riggs_lbs_forward(int32_t N, int32_t J, int32_t K, const float* x, const flo
   if (rc) return rc;
   a.d_xyz = d_xyz; a.d_rot = d_rotation; a.nn_weight = nn_weight; a.nn_idx = nn_idx;
   if (N == 0) return 0;
-  hipLaunchKernelGGL(lbs_forward_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+  {
+    ProfScope ps(PROF_LBS_FWD, (hipStream_t)stream);
+    hipLaunchKernelGGL(lbs_forward_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+  }
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -459,7 +471,10 @@ int riggs_lbs_backward(int32_t N, int32_t J, int32_t K, const float* x, const fl
   RIGGS_HIP_CHECK(hipMemsetAsync(dL_dnode_radius_log, 0, (size_t)J * 4, s));
   RIGGS_HIP_CHECK(hipMemsetAsync(dL_dglobal_trans, 0, 12, s));
   if (N == 0) return 0;
-  hipLaunchKernelGGL(lbs_backward_kernel, dim3((N + 255) / 256), dim3(256), 0, s, a);
+  {
+    ProfScope ps(PROF_LBS_BWD, s);
+    hipLaunchKernelGGL(lbs_backward_kernel, dim3((N + 255) / 256), dim3(256), 0, s, a);
+  }
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
 }

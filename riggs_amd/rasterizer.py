@@ -45,6 +45,32 @@ class RasterArena:
         self.min_capacity = min_capacity
         self.binning: Optional[torch.Tensor] = None
         self.last_R = -1
+        self._pending = None  # (event, pinned host counters, capacity used)
+
+    def _post(self, counters: torch.Tensor, cap: int):
+        """Queue an asynchronous read-back of (R, overflow) behind the frame just launched."""
+        host = torch.empty(4, dtype=torch.int32, pin_memory=True)
+        host.copy_(counters, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending = (ev, host, cap)
+
+    def resolve(self, block: bool = True) -> bool:
+        """Consume the pending read-back of the previous frame (normally long complete: no stall).
+        Raises when that frame overflowed the arena — its image and gradients are invalid."""
+        if self._pending is None:
+            return True
+        ev, host, cap = self._pending
+        if not block and not ev.query():
+            return False
+        ev.synchronize()
+        self._pending = None
+        R, overflow = int(host[0]) & 0xFFFFFFFF, int(host[1])
+        self.last_R = R
+        if overflow:
+            raise L.RiggsHipError("instance arena overflowed on the previous frame (R=%d > capacity=%d); that frame\'s "
+                                  "outputs are invalid.  The arena is regrown on the next call." % (R, cap))
+        return True
 
     def ensure(self, cap: int, N: int, H: int, W: int, device):
         cap = max(int(cap), self.min_capacity)
@@ -117,12 +143,15 @@ def rasterize_forward(settings, means3D, shs, colors_precomp, opacities, scales,
             binning = torch.empty(lib.riggs_raster_binning_bytes(cap, N, H, W), dtype=torch.uint8, device=dev)
         s.R = R
     else:
+        arena.resolve(block=True)
         binning = arena.ensure(int(arena.last_R * arena.growth) + 1, N, H, W, dev)
         cap = arena.capacity
         s.R = None  # unknown until counters are read
     L.check(lib.riggs_raster_render(C.byref(cfg), geom.data_ptr(), binning.data_ptr(), cap, img.data_ptr(),
                                     color.data_ptr(), depth.data_ptr(), alpha.data_ptr(), counters.data_ptr(), st),
             "riggs_raster_render")
+    if arena is not None and s.R is None:
+        arena._post(counters, cap)
     s.cfg, s.keep, s.geom, s.img, s.binning, s.cap, s.radii, s.counters = cfg, keep, geom, img, binning, cap, radii, counters
     s.N, s.H, s.W, s.M = N, H, W, M
     return color, radii, depth, alpha, s

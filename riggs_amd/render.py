@@ -56,9 +56,8 @@ class _FusedGlueRaster(torch.autograd.Function):
     def backward(ctx, g_color, _g_radii, g_depth, g_alpha):
         xyz, shs, opacity, scaling, rotation, d_xyz, d_rot, d_scaling = ctx.saved_tensors
         s = ctx.s
-        if s.R is None and ctx.arena is not None and not arena_check(s, ctx.arena):
-            raise L.RiggsHipError("instance arena overflowed (R=%d > capacity=%d): re-run the frame; the arena has "
-                                  "been regrown" % (s.R, s.cap))
+        if ctx.arena is not None:
+            ctx.arena.resolve(block=False)  # raises if the forward of this frame is known to have overflowed
         need_ds = d_scaling is not None and ctx.needs_input_grad[9]
         g = rasterize_backward(s, xyz, shs, None, opacity, scaling, rotation, None, d_xyz, d_rot, g_color, g_depth,
                                g_alpha, d_scaling=d_scaling, want_d_scaling_grad=need_ds)

@@ -215,7 +215,7 @@ class SkeletonWarp(nn.Module):
 
     def _parents_dev(self, device):
         if self._parents_i32 is None or self._parents_i32.device != device:
-            p = self.parents.to(torch.int32).clone()
+            p = self.parents.detach().cpu().to(torch.int32).clone()
             p[0] = 0
             if bool((p[1:] >= torch.arange(1, p.shape[0], dtype=torch.int32)).any()):
                 raise ValueError("parents[i] < i is required (skeleton_warp.py:257-263)")

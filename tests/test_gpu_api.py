@@ -77,6 +77,11 @@ def test_render_end_to_end_matches_oracle_pipeline(fused, isotropic):
     U.assert_close(vs.cpu().numpy(), g_o["means2D"], "viewspace_points.grad", 2e-4, 1e-3)
     for name, p in (("xyz", gm._xyz), ("features_dc", gm._features_dc), ("features_rest", gm._features_rest),
                     ("opacity", gm._opacity), ("scaling", gm._scaling), ("rotation", gm._rotation)):
+        if isotropic and name == "rotation":
+            # Sigma = s^2 R R^T = s^2 I: the rotation gradient is identically zero in exact arithmetic and pure
+            # rounding noise in both implementations — check it is negligible instead of comparing noise.
+            assert float(p.grad.abs().max()) < 1e-3 * float(gm._xyz.grad.abs().max())
+            continue
         U.assert_close(p.grad.cpu().numpy(), Po[name].grad.numpy(), "dL/d_" + name, 2e-4, 1e-3)
     U.assert_close(q.grad.cpu().numpy(), Po["local_rotation"].grad.numpy(), "dL/dlocal_rotation", 1e-3)
     U.assert_close(gt.grad.cpu().numpy(), Po["global_trans"].grad.numpy(), "dL/dglobal_trans", 1e-3)
