@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--profile-all", action="store_true", help="print a per-kernel event-timer table to stderr")
     args = ap.parse_args()
 
@@ -160,9 +161,30 @@ def main():
     torch.cuda.synchronize()
     arena.resolve()
     R = arena.last_R
+    del pkg
+    for p in params_of(gm, sw):
+        p.grad = None
+    if not args.no_graph:
+        # hipGraph replay of the frame (deform -> render -> backward); the gradient all-reduce stays eager
+        from riggs_amd.graph import GraphedFrame
+        import torch.distributed as dist
+        params = params_of(gm, sw)
+        gf = GraphedFrame(gm, sw, cam, torch.zeros(3, device=dev), params).capture()
+        gf.set_inputs(gimg=gimg)
+
+        def step():  # noqa: F811
+            out = gf.run()
+            if world > 1:
+                flat = torch.cat([p.grad.reshape(-1) for p in params])
+                dist.all_reduce(flat)
+                flat.div_(world)
+            return out
+        step()
+        torch.cuda.synchronize()
+        assert gf.check() == R, "graphed frame disagrees with the eager frame on the instance count"
 
     names = [lib.riggs_prof_name(i).decode() for i in range(lib.riggs_prof_count())]
-    dom = names.index("render_bwd")
+    eager_step = make_step(cam, gm, sw, gimg, arena, world)
 
     def barrier():
         if world > 1:
@@ -172,47 +194,59 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    lib.riggs_prof_reset()
-    lib.riggs_prof_enable(1 << dom)  # two HIP events per step around the dominant kernel only
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    lib.riggs_prof_enable(0)
-    import ctypes as C
-    tot, cnt = C.c_float(), C.c_int32()
-    L.check(lib.riggs_prof_read(dom, C.byref(tot), C.byref(cnt)), "riggs_prof_read")
-    dom_ms = tot.value / max(cnt.value, 1)
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    table = None
-    if args.profile_all or rank == 0:
+    # Roofline leg: every HIP kernel of the path timed live with HIP events recorded on its launch stream
+    # (riggs_prof_* in include/riggs_hip.h), over eagerly issued steps of the same workload.
+    import ctypes as C
+    table = {}
+    if rank == 0:
+        tot, cnt = C.c_float(), C.c_int32()
+        for _ in range(3):
+            eager_step()
+        torch.cuda.synchronize()
         lib.riggs_prof_reset()
         lib.riggs_prof_enable(0xFFFFFFFF)
-        for _ in range(10):
-            step()
+        for _ in range(min(args.steps, 20)):
+            eager_step()
         torch.cuda.synchronize()
         lib.riggs_prof_enable(0)
-        table = {}
         for i, nm in enumerate(names):
             L.check(lib.riggs_prof_read(i, C.byref(tot), C.byref(cnt)), "riggs_prof_read")
             if cnt.value:
                 table[nm] = round(tot.value / cnt.value, 4)
         if args.profile_all:
-            sys.stderr.write("per-launch ms (HIP events, 10 steps): %s\n" % json.dumps(table))
+            sys.stderr.write("per-launch ms (HIP events): %s\n" % json.dumps(table))
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * args.steps / elapsed
-        HW = w["H"] * w["W"]
-        # algorithmic bytes of ONE render_bwd launch: per tile instance 4 (id) + 48 (three
-        # float4 records) read + 36 (nine accumulated floats) written; per pixel 4+4+12 read.
-        dom_bytes = R * 88 + HW * 20
+        N, HW, Bn = w["N"], w["H"] * w["W"], w["J"] - 1
+        # ALGORITHMIC bytes per launch of each kernel (DESIGN.md "Kernels and rooflines")
+        alg_bytes = {
+            "preprocess_fwd": N * (12 + 12 + 16 + 12 + 16 + 12 + 4 + 192) + N * (48 + 24 + 1 + 4 + 8 + 4 + 4 + 4),
+            "render_fwd": R * (4 + 48) + HW * (12 + 4 + 4 + 4 + 4 + 16),
+            "render_bwd": R * (4 + 48 + 36) + HW * (12 + 4 + 4 + 16),
+            "preprocess_bwd": N * (276 + 24 + 1 + 4 + 48) + N * (12 + 12 + 192 + 4 + 12 + 16),
+            "lbs_fwd": N * (12 + 4 + 12 + 16),
+            "lbs_bwd": N * (12 + 4 + 12 + 16),
+            "tile_sort": R * 16 * 2,
+            "depth_sort": N * 16 * 4,
+        }
+        dom = max((k for k in table if k in alg_bytes), key=lambda k: table[k])
+        dom_ms, dom_bytes = table[dom], alg_bytes[dom]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        per_kernel = {k: {"ms": table[k], "GBps": round(alg_bytes[k] / (table[k] * 1e-3) / 1e9, 1),
+                          "frac_hbm": round(alg_bytes[k] / (table[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                      for k in table if k in alg_bytes and table[k] > 0}
         out = {
             "metric": "train iters/sec (deform+raster fwd+bwd), 300k Gaussians @800x800",
             "value": round(value, 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -220,12 +254,13 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "300k Gaussians / 24-joint skeleton / 800x800, LBS-only, SH degree 3, anisotropic, "
                                    "one frame per GPU per step", "num_gaussians": w["N"], "num_joints": w["J"],
-                       "image": [w["H"], w["W"]], "tile_instances_R": R, "parallelism": "frames x%d" % world},
-            "roofline": {"kernel": "render_bwd", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                       "image": [w["H"], w["W"]], "tile_instances_R": R, "parallelism": "frames x%d" % world,
+                       "launch": "eager" if args.no_graph else "hipGraph replay"},
+            "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "ms_per_launch": round(dom_ms, 4), "algorithmic_bytes_per_launch": dom_bytes,
-                         "pairs_per_s": round(256.0 * R / (dom_ms * 1e-3), 1) if dom_ms > 0 else None},
-            "kernels_ms": table,
+                         "ms_per_launch": dom_ms, "algorithmic_bytes_per_launch": dom_bytes,
+                         "pixel_gaussian_pairs_per_s": round(256.0 * R / (dom_ms * 1e-3), 1) if dom.startswith("render") else None},
+            "kernels": per_kernel, "kernels_ms": table,
         }
         if not args.no_cpu_baseline:
             cam_cpu = cam.to("cpu")

@@ -87,13 +87,17 @@ ImageLayout image_layout(int H, int W) {
   L.final_T = o; o = align_up(o + hw * 4);
   L.n_contrib = o; o = align_up(o + hw * 4);
   L.ranges = o; o = align_up(o + (T + 1) * 8);
+  L.final_acc = o; o = align_up(o + hw * 16);
+  L.tile_max = o; o = align_up(o + (T + 1) * 4);
+  L.slot_base = o; o = align_up(o + (T + 2) * 4);
   L.total = o;
   return L;
 }
 
 BinLayout bin_layout(int64_t cap, int N, int H, int W) {
-  (void)N; (void)H; (void)W;
+  (void)N;
   BinLayout L;
+  const size_t T = (size_t)((W + RIGGS_TILE - 1) / RIGGS_TILE) * ((H + RIGGS_TILE - 1) / RIGGS_TILE);
   size_t n = (size_t)(cap > 0 ? cap : 1), o = 0;
   L.vals_b = o; o = align_up(o + n * 4);   // sorted point list first (RIGGS_BIN_POINT_LIST)
   L.keys_b = o; o = align_up(o + n * 4);
@@ -101,6 +105,8 @@ BinLayout bin_layout(int64_t cap, int N, int H, int W) {
   L.keys_a = o; o = align_up(o + n * 4);
   L.temp_bytes = align_up(sort_temp_bytes_u32(n));
   L.temp = o; o += L.temp_bytes;
+  L.n_slots = (n >> 6) + T + 1;  // tile t, chunk c -> slot (range.x(t) >> 6) + t + c
+  L.ckpt = o; o += align_up(L.n_slots * RIGGS_CKPT_FLOATS * 4);
   L.total = o;
   return L;
 }
@@ -262,6 +268,7 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
     {
       ProfScope ps(PROF_RANGES, s);
       launch_ranges(cap, T, (const uint32_t*)(bin + B.keys_b), counters, (uint2*)(img + I.ranges), s);
+      launch_slot_base(cap, T, (const uint32_t*)(bin + B.keys_b), counters, (uint32_t*)(img + I.slot_base), s);
     }
     if (debug_sync(cfg->debug, s, "tile sort / ranges")) return 1;
   }
@@ -273,6 +280,9 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
   r.bg = cfg->bg;
   r.final_T = (float*)(img + I.final_T); r.n_contrib = (uint32_t*)(img + I.n_contrib);
   r.out_color = out_color; r.out_depth = out_depth; r.out_alpha = out_alpha;
+  r.final_acc = (float4*)(img + I.final_acc); r.tile_max = (uint32_t*)(img + I.tile_max);
+  r.slot_base = (const uint32_t*)(img + I.slot_base); r.ckpt = (float*)(bin + B.ckpt);
+  if (!(N > 0 && cap > 0)) RIGGS_HIP_CHECK(hipMemsetAsync(img + I.slot_base, 0, (size_t)(T + 2) * 4, s));
   { ProfScope ps(PROF_RENDER_FWD, s); launch_render_fwd(r, s); }
   if (debug_sync(cfg->debug, s, "render_fwd")) return 1;
   return 0;
@@ -317,6 +327,10 @@ int riggs_raster_backward(const riggs_raster_cfg* cfg, const float* means3D, con
   r.final_T = (const float*)(img + I.final_T); r.n_contrib = (const uint32_t*)(img + I.n_contrib);
   r.dL_dcolor = dL_dcolor; r.dL_ddepth = dL_ddepth; r.dL_dalpha = dL_dalpha;
   r.gacc = (float*)workspace;
+  r.final_acc = (const float4*)(img + I.final_acc); r.tile_max = (const uint32_t*)(img + I.tile_max);
+  r.slot_base = (const uint32_t*)(img + I.slot_base); r.ckpt = (const float*)(bin + B.ckpt);
+  r.n_tiles = ((W + RIGGS_TILE - 1) / RIGGS_TILE) * ((H + RIGGS_TILE - 1) / RIGGS_TILE);
+  r.n_slots = (int64_t)B.n_slots;
   if (cap > 0) { ProfScope ps(PROF_RENDER_BWD, s); launch_render_bwd(r, s); }
   if (debug_sync(cfg->debug, s, "render_bwd")) return 1;
   b.g_mean2D_conic = (const float*)workspace;

@@ -238,17 +238,22 @@ __device__ __forceinline__ float bone_d2(const Bone& b, float px, float py, floa
   return (sx * sx + sy * sy) + sz * sz;
 }
 
-// Top-K selection state: the K smallest (d2, idx) pairs in ascending order, by K selection
-// passes (K is tiny, 3 in the reference configs) — no per-thread arrays.
-__device__ __forceinline__ bool topk_selected(const Bone* bones, int B, int K, float px, float py, float pz, int k,
-                                              float d2k) {
-  // bone k is selected iff fewer than K bones are strictly "smaller" in (d2, idx) order
-  int smaller = 0;
-  for (int m = 0; m < B; m++) {
-    const float dm = bone_d2(bones[m], px, py, pz);
-    smaller += (dm < d2k || (dm == d2k && m < k)) ? 1 : 0;
+// Top-K selection (K > 0): bitmask of the K bones with the smallest (d2, index), found by K
+// selection passes over the <= 63 bones.  Already-picked bones are excluded through the mask, so
+// no floating-point value is ever compared for equality across call sites.
+__device__ __forceinline__ uint64_t topk_mask(const Bone* bones, int B, int K, float px, float py, float pz) {
+  uint64_t mask = 0;
+  for (int s = 0; s < K; s++) {
+    float best = INFINITY;
+    int bi = -1;
+    for (int k = 0; k < B; k++) {
+      if ((mask >> k) & 1ull) continue;
+      const float d2 = bone_d2(bones[k], px, py, pz);
+      if (d2 < best || bi < 0) { best = d2; bi = k; }
+    }
+    mask |= 1ull << bi;
   }
-  return smaller < K;
+  return mask;
 }
 
 __global__ __launch_bounds__(256) void lbs_forward_kernel(LbsArgs a) {
@@ -258,13 +263,14 @@ __global__ __launch_bounds__(256) void lbs_forward_kernel(LbsArgs a) {
   if (n >= a.N) return;
   const int B = a.J - 1;
   const float px = a.x[3 * n], py = a.x[3 * n + 1], pz = a.x[3 * n + 2];
+  const uint64_t selmask = a.K > 0 ? topk_mask(bones, B, a.K, px, py, pz) : ~0ull;
   float M[12], qa[4] = {0.f, 0.f, 0.f, 0.f}, sum = 0.f;
 #pragma unroll
   for (int e = 0; e < 12; e++) M[e] = 0.f;
   for (int k = 0; k < B; k++) {
     const Bone& b = bones[k];
+    if (!((selmask >> k) & 1ull)) continue;
     const float d2 = bone_d2(b, px, py, pz);
-    if (a.K > 0 && !topk_selected(bones, B, a.K, px, py, pz, k, d2)) continue;
     const float v = fast_exp(-d2 * b.inv2r2) + 1e-7f;  // skeleton_warp.py:66,71
     sum += v;
 #pragma unroll
@@ -282,16 +288,16 @@ __global__ __launch_bounds__(256) void lbs_forward_kernel(LbsArgs a) {
   reinterpret_cast<float4*>(a.d_rot)[n] = make_float4(qa[0] * inv * m, qa[1] * inv * m, qa[2] * inv * m, qa[3] * inv * m);
   if (a.nn_weight || a.nn_idx) {
     if (a.K > 0) {
-      // ascending-d2 order like torch.topk(largest=False): K selection passes
-      float prev_d = -1.f; int prev_i = -1;
+      // ascending-d2 order like torch.topk(largest=False): K selection passes inside the mask
+      uint64_t left = selmask;
       for (int s = 0; s < a.K; s++) {
         float best = INFINITY; int bi = -1;
         for (int k = 0; k < B; k++) {
+          if (!((left >> k) & 1ull)) continue;
           const float d2 = bone_d2(bones[k], px, py, pz);
-          const bool after = (d2 > prev_d) || (d2 == prev_d && k > prev_i);
-          if (after && (d2 < best)) { best = d2; bi = k; }
+          if (d2 < best || bi < 0) { best = d2; bi = k; }
         }
-        prev_d = best; prev_i = bi;
+        left &= ~(1ull << bi);
         if (a.nn_weight) a.nn_weight[(size_t)n * a.K + s] = (fast_exp(-best * bones[bi].inv2r2) + 1e-7f) * inv;
         if (a.nn_idx) a.nn_idx[(size_t)n * a.K + s] = bi + 1;
       }
@@ -330,13 +336,14 @@ __global__ __launch_bounds__(256) void lbs_backward_kernel(LbsArgs a) {
   const float gh[3] = {g[0] * m, g[1] * m, g[2] * m};
   const float hh4[4] = {h[0] * m, h[1] * m, h[2] * m, h[3] * m};
   // pass 1: normaliser and blended outputs
+  const uint64_t selmask = a.K > 0 ? topk_mask(bones, B, a.K, px, py, pz) : ~0ull;
   float M[12], qa[4] = {0.f, 0.f, 0.f, 0.f}, sum = 0.f;
 #pragma unroll
   for (int e = 0; e < 12; e++) M[e] = 0.f;
   for (int k = 0; k < B; k++) {
     const Bone& b = bones[k];
+    if (!((selmask >> k) & 1ull)) continue;
     const float d2 = bone_d2(b, px, py, pz);
-    if (a.K > 0 && !topk_selected(bones, B, a.K, px, py, pz, k, d2)) continue;
     const float v = fast_exp(-d2 * b.inv2r2) + 1e-7f;
     sum += v;
 #pragma unroll
@@ -363,7 +370,7 @@ __global__ __launch_bounds__(256) void lbs_backward_kernel(LbsArgs a) {
     const Bone& b = bones[k];
     const float d2 = bone_d2(b, px, py, pz);
     float w = 0.f, r = 0.f;
-    const bool sel = valid && !(a.K > 0 && !topk_selected(bones, B, a.K, px, py, pz, k, d2));
+    const bool sel = valid && ((selmask >> k) & 1ull);
     if (sel) {
       const float u = fast_exp(-d2 * b.inv2r2);
       w = (u + 1e-7f) * inv;

@@ -38,8 +38,15 @@ struct RenderArgs {
   float* final_T;
   uint32_t* n_contrib;
   float *out_color, *out_depth, *out_alpha;
+  // state for the chunk-parallel backward
+  float4* final_acc;          // per pixel (C0, C1, C2, D) accumulated WITHOUT background
+  uint32_t* tile_max;         // per tile: max n_contrib
+  const uint32_t* slot_base;  // per tile: first checkpoint slot ((range.x >> 6) + tile)
+  float* ckpt;                // [slot][5][256]: (T, C0, C1, C2, D) per pixel at every 64th instance
 };
 int launch_render_fwd(const RenderArgs& a, hipStream_t s);
+int launch_slot_base(int64_t n, int n_tiles, const uint32_t* keys_sorted, const uint32_t* counters,
+                     uint32_t* slot_base, hipStream_t s);
 
 struct RenderBwdArgs {
   int W, H;
@@ -51,6 +58,12 @@ struct RenderBwdArgs {
   const uint32_t* n_contrib;
   const float *dL_dcolor, *dL_ddepth, *dL_dalpha;
   float* gacc;  // (N, RIGGS_GACC) accumulators, zeroed by the caller
+  const float4* final_acc;
+  const uint32_t* tile_max;
+  const uint32_t* slot_base;
+  const float* ckpt;
+  int n_tiles;
+  int64_t n_slots;
 };
 int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s);
 

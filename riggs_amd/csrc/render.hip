@@ -4,6 +4,8 @@
 // Instances of the tile are staged 256 at a time through LDS as three float4 records
 // (48 B / instance, gathered as whole 16-B words), then every pixel walks the batch with
 // wave-uniform LDS addresses (broadcast reads, no bank conflicts).
+#include <stdlib.h>
+
 #include "raster_internal.h"
 
 namespace riggs {
@@ -91,10 +93,40 @@ int launch_ranges(int64_t n, int n_tiles, const uint32_t* keys_sorted, const uin
 }
 
 // ------------------------------------------------------------------ render forward
+// Checkpoint slots: tile t, chunk c (= 64 consecutive instances of the tile list) -> slot
+// slot_base[t] + c with slot_base[t] = (lower_bound(tile t) >> 6) + t  (monotone, <= R/64 + T).
+__global__ __launch_bounds__(256) void slot_base_kernel(int64_t n, int n_tiles, const uint32_t* __restrict__ keys,
+                                                        const uint32_t* __restrict__ counters,
+                                                        uint32_t* __restrict__ slot_base) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t > n_tiles) return;
+  const int64_t R = min((int64_t)counters[0], n);
+  int64_t lo = 0, hi = R;  // first index with key >= t
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (keys[mid] < (uint32_t)t) lo = mid + 1; else hi = mid;
+  }
+  slot_base[t] = (uint32_t)(lo >> 6) + (uint32_t)t;
+}
+int launch_slot_base(int64_t n, int n_tiles, const uint32_t* keys_sorted, const uint32_t* counters,
+                     uint32_t* slot_base, hipStream_t s) {
+  hipLaunchKernelGGL(slot_base_kernel, dim3((n_tiles + 1 + 255) / 256), dim3(256), 0, s, n, n_tiles, keys_sorted,
+                     counters, slot_base);
+  return 0;
+}
+
+// Per-pixel front-to-back compositing.  The only true dependency between consecutive instances
+// is the transmittance product, so the kernel evaluates the Gaussian falloff (LDS reads, conic
+// form, exp) of FOUR instances at once and then applies the four T updates with selects
+// (no exec-mask juggling): a deep tile is bound by the latency of one wave's instruction
+// stream, not by throughput, and this shortens that stream ~4x.  Every 64 instances the
+// running state (T, C, D) is checkpointed for the chunk-parallel backward.
+#define FWD_ILP 4
 __global__ __launch_bounds__(256) void render_fwd_kernel(RenderArgs a) {
-  __shared__ float4 s_xyd[256];
-  __shared__ float4 s_con[256];
-  __shared__ float4 s_rgb[256];
+  __shared__ float4 s_xyd[256 + FWD_ILP];
+  __shared__ float4 s_con[256 + FWD_ILP];
+  __shared__ float4 s_rgb[256 + FWD_ILP];
+  __shared__ uint32_t s_max[4];
   const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE;
   const int tile = blockIdx.x;
   const int tid = threadIdx.x;
@@ -104,42 +136,76 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(RenderArgs a) {
   const float pfx = (float)pxi, pfy = (float)pyi;
   const uint2 range = a.ranges[tile];
   const int total = (int)(range.y - range.x);
+  const uint32_t slot0 = a.slot_base[tile];
   bool done = !inside;
   float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f;
-  uint32_t contributor = 0, last = 0;
+  uint32_t last = 0;
+  if (tid < FWD_ILP) {  // permanent null records behind a full batch
+    s_xyd[256 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    s_con[256 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    s_rgb[256 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   for (int base = 0; base < total; base += 256) {
     if (__syncthreads_count(done) == 256) break;
     const int nb = min(256, total - base);
-    if (tid < nb) {
-      const uint32_t id = a.point_list[range.x + base + tid];
-      s_xyd[tid] = a.xyd[id];
-      s_con[tid] = a.conic_o[id];
-      s_rgb[tid] = a.rgb[id];
+    {
+      float4 xy = make_float4(0.f, 0.f, 0.f, 0.f), co = xy, cc = xy;  // opacity 0 => never contributes
+      if (tid < nb) {
+        const uint32_t id = a.point_list[range.x + base + tid];
+        xy = a.xyd[id]; co = a.conic_o[id]; cc = a.rgb[id];
+      }
+      s_xyd[tid] = xy; s_con[tid] = co; s_rgb[tid] = cc;
     }
     __syncthreads();
-    for (int j = 0; !done && j < nb; j++) {
-      contributor++;
-      const float4 xy = s_xyd[j];
-      const float4 co = s_con[j];
-      const float dx = xy.x - pfx, dy = xy.y - pfy;
-      const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-      if (power > 0.0f) continue;
-      const float alpha = fminf(ALPHA_MAX, co.w * fast_exp(power));
-      if (alpha < ALPHA_MIN) continue;
-      const float test_T = T * (1.0f - alpha);
-      if (test_T < T_EPS) { done = true; continue; }
-      const float4 c = s_rgb[j];
-      const float w = alpha * T;
-      C0 += c.x * w; C1 += c.y * w; C2 += c.z * w;
-      D += xy.z * w; A += w;
-      T = test_T;
-      last = contributor;
+    for (int j = 0; j < nb; j += FWD_ILP) {
+      if (__builtin_amdgcn_ballot_w64(!done) == 0) break;  // this wave's 64 pixels are finished
+      if (((base + j) & 63) == 0 && !done) {
+        float* ck = a.ckpt + ((size_t)(slot0 + ((base + j) >> 6)) * 5) * 256 + tid;
+        ck[0] = T; ck[256] = C0; ck[512] = C1; ck[768] = C2; ck[1024] = D;
+      }
+      float alpha[FWD_ILP], depth[FWD_ILP];
+      bool valid[FWD_ILP];
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < FWD_ILP; k++) {
+        const float4 xy = s_xyd[j + k];
+        const float4 co = s_con[j + k];
+        const float dx = xy.x - pfx, dy = xy.y - pfy;
+        const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+        alpha[k] = fminf(ALPHA_MAX, co.w * fast_exp(power));
+        valid[k] = (power <= 0.0f) && (alpha[k] >= ALPHA_MIN);
+        depth[k] = xy.z;
+        any = any || valid[k];
+      }
+      if (__builtin_amdgcn_ballot_w64(any && !done) == 0) continue;  // nothing lands on this wave's pixels
+#pragma unroll
+      for (int k = 0; k < FWD_ILP; k++) {
+        const float4 c = s_rgb[j + k];
+        const bool v = valid[k] && !done;
+        const float test_T = T * (1.0f - alpha[k]);
+        const bool stop = v && (test_T < T_EPS);
+        const bool use = v && !stop;
+        done = done || stop;
+        const float w = use ? alpha[k] * T : 0.f;
+        C0 += c.x * w; C1 += c.y * w; C2 += c.z * w;
+        D += depth[k] * w; A += w;
+        T = use ? test_T : T;
+        last = use ? (uint32_t)(base + j + k + 1) : last;
+      }
     }
   }
+  // per-tile max of n_contrib bounds the work of the backward
+  uint32_t m = inside ? last : 0u;
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+  __syncthreads();
+  if ((tid & 63) == 0) s_max[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) a.tile_max[tile] = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
   if (inside) {
     const size_t pid = (size_t)pyi * a.W + pxi, HW = (size_t)a.H * a.W;
     a.final_T[pid] = T;
     a.n_contrib[pid] = last;
+    a.final_acc[pid] = make_float4(C0, C1, C2, D);
     a.out_color[pid] = C0 + T * a.bg[0];
     a.out_color[HW + pid] = C1 + T * a.bg[1];
     a.out_color[2 * HW + pid] = C2 + T * a.bg[2];
@@ -159,7 +225,7 @@ int launch_render_fwd(const RenderArgs& a, hipStream_t s) {
 // Back-to-front walk per pixel; per-instance gradient contributions are summed over the 64
 // pixels of a wave with DPP, the 4 waves meet in LDS, and ONE atomicAdd per value per
 // (tile, instance) goes to the per-Gaussian accumulator (48-B record).
-__global__ __launch_bounds__(256) void render_bwd_kernel(RenderBwdArgs a) {
+__global__ __launch_bounds__(256) void render_bwd_v1_kernel(RenderBwdArgs a) {
   __shared__ float4 s_xyd[256];
   __shared__ float4 s_con[256];
   __shared__ float4 s_rgb[256];
@@ -268,10 +334,153 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderBwdArgs a) {
   (void)s_part;
 }
 
+// ---- wave64 scans (DPP).  Inclusive Hillis-Steele inside rows of 16, then row broadcasts.
+#define DPP_F(old, v, ctrl, rmask) \
+  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(old)), __builtin_bit_cast(int, (float)(v)), ctrl, rmask, 0xf, false))
+
+__device__ __forceinline__ float wave_excl_prod_scan(float v) {
+  v *= DPP_F(1.0f, v, 0x111, 0xf);  // row_shr:1
+  v *= DPP_F(1.0f, v, 0x112, 0xf);  // row_shr:2
+  v *= DPP_F(1.0f, v, 0x114, 0xf);  // row_shr:4
+  v *= DPP_F(1.0f, v, 0x118, 0xf);  // row_shr:8
+  v *= DPP_F(1.0f, v, 0x142, 0xa);  // row_bcast:15 -> rows 1,3
+  v *= DPP_F(1.0f, v, 0x143, 0xc);  // row_bcast:31 -> rows 2,3
+  return DPP_F(1.0f, v, 0x138, 0xf);  // wave_shr:1 : inclusive -> exclusive
+}
+__device__ __forceinline__ float wave_excl_sum_scan(float v) {
+  v += DPP_F(0.0f, v, 0x111, 0xf);
+  v += DPP_F(0.0f, v, 0x112, 0xf);
+  v += DPP_F(0.0f, v, 0x114, 0xf);
+  v += DPP_F(0.0f, v, 0x118, 0xf);
+  v += DPP_F(0.0f, v, 0x142, 0xa);
+  v += DPP_F(0.0f, v, 0x143, 0xc);
+  return DPP_F(0.0f, v, 0x138, 0xf);
+}
+
+// Chunk-parallel, instance-major backward.  One wave64 owns one chunk of 64 consecutive
+// instances of one tile: lane <-> instance, and the wave walks the tile's 256 pixels.  For a
+// pixel the 64 transmittances are an exclusive product scan over the lanes seeded with the
+// forward's checkpoint, and dL/dalpha needs one more scan (prefix of the projected colour
+//   k = gC.c + gD.z + gA), the suffix being  total - prefix.  Per-instance gradients
+// accumulate in registers over the 256 pixels — no cross-lane reduction, no atomic
+// contention (one atomic per value per (tile, instance) at the end).  Chunks are independent,
+// so a tile with thousands of contributing instances spreads over the whole chip instead of
+// serialising on four waves.
+__global__ __launch_bounds__(256) void render_bwd_kernel(RenderBwdArgs a) {
+  __shared__ float4 s_pa[4][256];  // (T_start, Pre_start, Qb, n_contrib as float bits)
+  __shared__ float4 s_pb[4][256];  // (gC0, gC1, gC2, gD)
+  __shared__ float s_pc[4][256];   // gA
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t slot = (int64_t)blockIdx.x * 4 + wave;
+  if (slot >= a.n_slots) return;
+  // slot -> tile: last t with slot_base[t] <= slot
+  int lo = 0, hi = a.n_tiles;  // slot_base has n_tiles + 1 entries
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int64_t)a.slot_base[mid] <= slot) lo = mid; else hi = mid - 1;
+  }
+  const int tile = lo;
+  if (tile >= a.n_tiles) return;
+  const int chunk = (int)(slot - a.slot_base[tile]);
+  const uint2 range = a.ranges[tile];
+  const int total = (int)(range.y - range.x);
+  const int limit = min(total, (int)a.tile_max[tile]);
+  const int pos0 = chunk * 64;
+  if (pos0 >= limit) return;
+  const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE;
+  const int tx0 = (tile % gx) * RIGGS_TILE, ty0 = (tile / gx) * RIGGS_TILE;
+  const size_t HW = (size_t)a.H * a.W;
+  const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
+  // ---- stage the 256 pixels' uniform data (4 pixels per lane)
+  const float* ck = a.ckpt + ((size_t)slot * 5) * 256;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int pix = lane + 64 * q;
+    const int pxi = tx0 + (pix & 15), pyi = ty0 + (pix >> 4);
+    float4 pa = make_float4(1.f, 0.f, 0.f, 0.f), pb = make_float4(0.f, 0.f, 0.f, 0.f);
+    float pc = 0.f;
+    if (pxi < a.W && pyi < a.H) {
+      const size_t pid = (size_t)pyi * a.W + pxi;
+      const uint32_t n = a.n_contrib[pid];
+      if ((int)n > pos0) {
+        const float Tn = a.final_T[pid];
+        const float4 acc = a.final_acc[pid];
+        const float g0 = a.dL_dcolor[pid], g1 = a.dL_dcolor[HW + pid], g2 = a.dL_dcolor[2 * HW + pid];
+        const float gD = a.dL_ddepth ? a.dL_ddepth[pid] : 0.f;
+        const float gA = a.dL_dalpha ? a.dL_dalpha[pid] : 0.f;
+        const float Ts = ck[pix], S0 = ck[256 + pix], S1 = ck[512 + pix], S2 = ck[768 + pix], Ds = ck[1024 + pix];
+        const float pre = g0 * S0 + g1 * S1 + g2 * S2 + gD * Ds + gA * (1.0f - Ts);
+        const float qb = (g0 * acc.x + g1 * acc.y + g2 * acc.z + gD * acc.w + gA * (1.0f - Tn)) +
+                         Tn * (bg0 * g0 + bg1 * g1 + bg2 * g2);
+        pa = make_float4(Ts, pre, qb, __uint_as_float(n));
+        pb = make_float4(g0, g1, g2, gD);
+        pc = gA;
+      }
+    }
+    s_pa[wave][pix] = pa; s_pb[wave][pix] = pb; s_pc[wave][pix] = pc;
+  }
+  // ---- this lane's instance
+  const int pos = pos0 + lane;
+  const bool active = pos < limit;
+  uint32_t id = 0;
+  float4 xy = make_float4(0.f, 0.f, 0.f, 0.f), co = xy, cc = xy;
+  if (active) {
+    id = a.point_list[range.x + pos];
+    xy = a.xyd[id]; co = a.conic_o[id]; cc = a.rgb[id];
+  }
+  const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
+  float a_mx = 0.f, a_my = 0.f, a_ca = 0.f, a_cb = 0.f, a_cc = 0.f, a_op = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f, a_d = 0.f;
+  // (the wave only reads its own LDS region: no workgroup barrier needed, LDS ops of one wave are ordered)
+  for (int pix = 0; pix < 256; pix++) {
+    const float4 pa = s_pa[wave][pix];
+    const int n = (int)__float_as_uint(pa.w);
+    if (n <= pos0) continue;  // wave-uniform: this chunk lies behind the pixel's last contributor
+    const float pfx = (float)(tx0 + (pix & 15)), pfy = (float)(ty0 + (pix >> 4));
+    const float dx = xy.x - pfx, dy = xy.y - pfy;
+    const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+    const float G = fast_exp(power);
+    float alpha = fminf(ALPHA_MAX, co.w * G);
+    const bool valid = active && (pos < n) && (power <= 0.0f) && (alpha >= ALPHA_MIN);
+    if (__builtin_amdgcn_ballot_w64(valid) == 0) continue;
+    alpha = valid ? alpha : 0.f;
+    const float om = 1.0f - alpha;
+    const float Tl = pa.x * wave_excl_prod_scan(om);
+    const float4 pb = s_pb[wave][pix];
+    const float gA = s_pc[wave][pix];
+    const float w = alpha * Tl;
+    const float k = pb.x * cc.x + pb.y * cc.y + pb.z * cc.z + pb.w * xy.z + gA;
+    const float wk = w * k;
+    const float pre = pa.y + wave_excl_sum_scan(wk);
+    // dL/dalpha = T k - (suffix + T_final * bg.g) / (1 - alpha),  suffix = total - prefix - own
+    const float dL_dalpha = Tl * k - (pa.z - pre - wk) * __builtin_amdgcn_rcpf(om);
+    const float dL_dG = co.w * dL_dalpha;
+    const float gdx = G * dx, gdy = G * dy;
+    if (valid) {
+      a_mx += dL_dG * (-gdx * co.x - gdy * co.y);
+      a_my += dL_dG * (-gdy * co.z - gdx * co.y);
+      a_ca += gdx * dx * dL_dG;
+      a_cb += gdx * dy * dL_dG;
+      a_cc += gdy * dy * dL_dG;
+      a_op += G * dL_dalpha;
+      a_r += w * pb.x; a_g += w * pb.y; a_b += w * pb.z;
+      a_d += w * pb.w;
+    }
+  }
+  if (active) {
+    float* g = a.gacc + (size_t)id * RIGGS_GACC;
+    atomicAdd(g + 0, a_mx * ddelx_dx); atomicAdd(g + 1, a_my * ddely_dy);
+    atomicAdd(g + 2, -0.5f * a_ca); atomicAdd(g + 3, -a_cb); atomicAdd(g + 4, -0.5f * a_cc);
+    atomicAdd(g + 5, a_op); atomicAdd(g + 6, a_r); atomicAdd(g + 7, a_g); atomicAdd(g + 8, a_b);
+    if (a.dL_ddepth) atomicAdd(g + 9, a_d);
+  }
+}
+
 int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s) {
   const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE, gy = (a.H + RIGGS_TILE - 1) / RIGGS_TILE;
   if (gx * gy == 0) return 0;
-  hipLaunchKernelGGL(render_bwd_kernel, dim3(gx * gy), dim3(256), 0, s, a);
+  static const bool v1 = getenv("RIGGS_RENDER_BWD_V1") != nullptr;  // A/B switch: pixel-major reference kernel
+  if (v1) hipLaunchKernelGGL(render_bwd_v1_kernel, dim3(gx * gy), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(render_bwd_kernel, dim3((unsigned)((a.n_slots + 3) / 4)), dim3(256), 0, s, a);
   return 0;
 }
 

@@ -1,0 +1,101 @@
+"""hipGraph capture of one hot-path frame (deform -> render -> backward).
+
+The per-frame step issues ~100+ small launches (PoseMLP layers, the sorts' passes, our kernels);
+replaying them from a captured hipGraph removes the host launch cost that otherwise bounds the
+iteration rate (the reference loop is host-bound the same way: train_rig.py:535-554 issues every
+kernel eagerly and synchronises on ``num_rendered``).  Frame-dependent inputs (camera matrices,
+time, dL/dimage) live in static device buffers that ``run()`` refreshes before each replay; the
+tile-instance arena has a fixed capacity inside the graph and the overflow flag is read back after
+the replay (``check()``), so a frame that outgrows it is detected, never silently wrong.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+from .rasterizer import RasterArena
+from .render import render
+from .synth import Camera
+
+
+class _Pipe:
+    convert_SHs_python = False
+    compute_cov3D_python = False
+    debug = False
+
+
+class GraphedFrame:
+    def __init__(self, gm, sw, cam: Camera, bg: torch.Tensor, params, headroom: float = 1.5, fused: bool = True):
+        self.gm, self.sw, self.params = gm, sw, list(params)
+        dev = bg.device
+        self.cam = Camera(cam.image_height, cam.image_width, cam.FoVx, cam.FoVy, cam.world_view_transform.clone(),
+                          cam.full_proj_transform.clone(), cam.camera_center.clone(), cam.fid.clone())
+        self.bg = bg.clone()
+        self.gimg = torch.zeros(3, cam.image_height, cam.image_width, device=dev)
+        self.arena = RasterArena(growth=headroom)
+        self.fused = fused
+        self.graph = None
+        self.out = None
+
+    def _frame(self):
+        for p in self.params:
+            p.grad = None
+        t_in = self.sw.expand_time(self.cam.fid)
+        dv = self.sw(self.gm.get_xyz.detach(), t_in, motion_mask=self.gm.motion_mask)
+        pkg = render(self.cam, self.gm, _Pipe, self.bg, dv["d_xyz"], dv["d_rotation"], dv["d_scaling"],
+                     fused=self.fused, arena=self.arena)
+        pkg["render"].backward(self.gimg)
+        # only detached outputs are kept: a live autograd graph would pin AccumulateGrad nodes to this stream
+        return {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in pkg.items() if k != "viewspace_points"} | {
+            "viewspace_points_grad": pkg["viewspace_points"].grad}
+
+    def set_inputs(self, cam: Camera = None, gimg: torch.Tensor = None):
+        if cam is not None:
+            if (cam.image_height, cam.image_width, cam.FoVx, cam.FoVy) != (
+                    self.cam.image_height, self.cam.image_width, self.cam.FoVx, self.cam.FoVy):
+                raise ValueError("image size / field of view are baked into the captured graph: capture a new one")
+            self.cam.world_view_transform.copy_(cam.world_view_transform, non_blocking=True)
+            self.cam.full_proj_transform.copy_(cam.full_proj_transform, non_blocking=True)
+            self.cam.camera_center.copy_(cam.camera_center, non_blocking=True)
+            self.cam.fid.copy_(cam.fid, non_blocking=True)
+        if gimg is not None:
+            self.gimg.copy_(gimg, non_blocking=True)
+
+    def capture(self, warmup: int = 2):
+        """Eager warm-up (sizes the arena, initialises rocPRIM/hipBLASLt workspaces) then capture."""
+        import gc
+        self.stream = s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self.out = self._frame()
+                torch.cuda.current_stream().synchronize()
+                self.arena.resolve()
+                self.out = None
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        for p in self.params:
+            p.grad = None
+        gc.collect()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=s):  # same stream as the warm-up: AccumulateGrad nodes match
+            self.out = self._frame()
+        return self
+
+    def run(self, cam: Camera = None, gimg: torch.Tensor = None):
+        """Replay one frame.  Outputs (``self.out`` dict, ``p.grad`` of every parameter) are static tensors that
+        the next replay overwrites."""
+        if self.graph is None:
+            self.capture()
+        self.set_inputs(cam, gimg)
+        self.graph.replay()
+        return self.out
+
+    def check(self):
+        """Blocking read-back of the instance counters of the last replay; raises on arena overflow."""
+        c = self.arena.static_counters[:2].tolist()
+        R, overflow = int(c[0]) & 0xFFFFFFFF, int(c[1])
+        if overflow:
+            raise L.RiggsHipError("instance arena overflowed inside the captured graph (R=%d > capacity=%d): "
+                                  "re-capture with more headroom" % (R, self.arena.capacity))
+        return R

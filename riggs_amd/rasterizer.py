@@ -46,9 +46,13 @@ class RasterArena:
         self.binning: Optional[torch.Tensor] = None
         self.last_R = -1
         self._pending = None  # (event, pinned host counters, capacity used)
+        self.static_counters = None
 
     def _post(self, counters: torch.Tensor, cap: int):
         """Queue an asynchronous read-back of (R, overflow) behind the frame just launched."""
+        self.static_counters = counters
+        if torch.cuda.is_current_stream_capturing():
+            return  # inside a hipGraph capture: GraphedFrame.check() reads the counters after the replay
         host = torch.empty(4, dtype=torch.int32, pin_memory=True)
         host.copy_(counters, non_blocking=True)
         ev = torch.cuda.Event()

@@ -185,6 +185,7 @@ class SkeletonWarp(nn.Module):
         self.control_nodes = nn.Parameter(torch.zeros(512, 3))  # checkpoint compatibility (:31)
         self.template_offsets = None
         self.pose_net = PoseMLP(1, J * 4)
+        self.register_buffer("_rot_bias", torch.tensor([1.0, 0.0, 0.0, 0.0]), persistent=False)  # skeleton_warp.py:118
         self._parents_i32 = None
 
     # -- reference surface ------------------------------------------------------------------
@@ -226,8 +227,7 @@ class SkeletonWarp(nn.Module):
         if t.dim() == 0:
             t = self.expand_time(t)
         m = self.pose_net(t[0])
-        bias = torch.tensor([1.0, 0, 0, 0], device=self.nodes.device)
-        return {"local_rotation": m["rotation"].reshape(-1, 4) + bias, "global_trans": m["translation"], "t": t[0]}
+        return {"local_rotation": m["rotation"].reshape(-1, 4) + self._rot_bias, "global_trans": m["translation"], "t": t[0]}
 
     def forward(self, x, t, motion_mask, **kwargs):
         return self.deform_by_pose(x, self.get_pose_info(t), motion_mask)
