@@ -174,6 +174,28 @@ int riggs_lbs_backward(int32_t num_points, int32_t num_joints, int32_t K, const 
                        float* dL_dglobal_trans, float* dL_dmotion_mask, riggs_stream stream);
 
 /* =====================================================================
+ * PoseMLP (time -> J quaternions + root translation), batch of ONE row:
+ *   PoseMLP.forward   skeleton_utils/network_utils.py:134-150  (8 x Linear(256) + ReLU, the
+ *   embedding re-concatenated IN FRONT of h after layer `skip`, two linear heads) with the
+ *   embedding of utils/time_utils.py:208-256 for input_dims = 1.
+ * weights[l] / biases[l] are HOST arrays of `depth` DEVICE pointers to torch's nn.Linear tensors
+ * (row-major (out, in)).  `acts` (riggs_pose_mlp_acts_floats floats) is written by forward and
+ * read by backward.  backward writes every parameter gradient into ONE flat buffer laid out as
+ *   [W_0, b_0, ..., W_{depth-1}, b_{depth-1}, W_rot, b_rot, W_tr, b_tr]   (no gradient to t).
+ * ===================================================================== */
+size_t riggs_pose_mlp_acts_floats(int32_t depth, int32_t width, int32_t multires);
+size_t riggs_pose_mlp_backward_workspace_floats(int32_t depth, int32_t width, int32_t multires);
+int riggs_pose_mlp_forward(int32_t depth, int32_t width, int32_t multires, int32_t skip, int32_t n_rot,
+                           const float* const* weights, const float* const* biases, const float* W_rot,
+                           const float* b_rot, const float* W_tr, const float* b_tr, const float* t, float* acts,
+                           float* rotation, float* translation, riggs_stream stream);
+int riggs_pose_mlp_backward(int32_t depth, int32_t width, int32_t multires, int32_t skip, int32_t n_rot,
+                            const float* const* weights, const float* const* biases, const float* W_rot,
+                            const float* b_rot, const float* W_tr, const float* b_tr, const float* acts,
+                            const float* g_rotation, const float* g_translation, float* workspace,
+                            float* flat_grads, riggs_stream stream);
+
+/* =====================================================================
  * simple_knn._C.distCUDA2 (scene/gaussian_model.py:20,170): mean squared distance to the 3
  * nearest neighbours.  points (P,3) -> out (P,).  workspace: riggs_knn_workspace_bytes(P).
  * ===================================================================== */

@@ -19,6 +19,7 @@ SOURCES = {
     "render.hip": ["-ffp-contract=fast"],
     "deform.hip": ["-ffp-contract=fast"],
     "knn.hip": ["-ffp-contract=fast"],
+    "pose_mlp.hip": ["-ffp-contract=fast"],
     "capi.hip": [],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fhip-fp32-correctly-rounded-divide-sqrt",

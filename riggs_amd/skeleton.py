@@ -46,7 +46,22 @@ class PoseMLP(nn.Module):
         self.rotation_predictor = nn.Linear(hidden_dimensions, output_ch)
         self.translation_predictor = nn.Linear(hidden_dimensions, 3)
 
+    def _fusable(self, t):
+        w = self.net[0].out_features
+        return (t.is_cuda and t.dtype == torch.float32 and t.numel() == 1 and self.multires > 0 and w <= 256
+                and self.net[0].in_features == 1 + 2 * self.multires and len(self.net) <= 12
+                and all(l.out_features == w for l in self.net))
+
     def forward(self, t):
+        if self._fusable(t):  # one row: three HIP launches instead of ~60 torch ops
+            params = []
+            for l in self.net:
+                params += [l.weight, l.bias]
+            params += [self.rotation_predictor.weight, self.rotation_predictor.bias,
+                       self.translation_predictor.weight, self.translation_predictor.bias]
+            rot, tr = _PoseMLPFn.apply(t.reshape(1), len(self.net), self.net[0].out_features, self.multires,
+                                       self.skips[0], *params)
+            return {"rotation": rot, "translation": tr}
         t_emb = _embed(t, self.multires) if self.multires > 0 else t
         h = t_emb + 0.0
         for i, layer in enumerate(self.net):
@@ -54,6 +69,61 @@ class PoseMLP(nn.Module):
             if i in self.skips:
                 h = torch.cat([t_emb, h], -1)
         return {"rotation": self.rotation_predictor(h), "translation": self.translation_predictor(h)}
+
+
+class _PoseMLPFn(torch.autograd.Function):
+    """PoseMLP forward/backward through riggs_pose_mlp_* (csrc/pose_mlp.hip)."""
+
+    @staticmethod
+    def _ptrs(params, depth):
+        import ctypes as C
+        Wp = (C.c_void_p * depth)(*[params[2 * l].data_ptr() for l in range(depth)])
+        bp = (C.c_void_p * depth)(*[params[2 * l + 1].data_ptr() for l in range(depth)])
+        return Wp, bp
+
+    @staticmethod
+    def forward(ctx, t, depth, width, multires, skip, *params):
+        params = [p.contiguous() for p in params]
+        lib = L.lib()
+        dev = t.device
+        n_rot = params[2 * depth].shape[0]
+        acts = torch.empty(lib.riggs_pose_mlp_acts_floats(depth, width, multires), dtype=torch.float32, device=dev)
+        rot = torch.empty(n_rot, dtype=torch.float32, device=dev)
+        tr = torch.empty(3, dtype=torch.float32, device=dev)
+        Wp, bp = _PoseMLPFn._ptrs(params, depth)
+        h = params[2 * depth:]
+        L.check(lib.riggs_pose_mlp_forward(depth, width, multires, skip, n_rot, Wp, bp, h[0].data_ptr(),
+                                           h[1].data_ptr(), h[2].data_ptr(), h[3].data_ptr(), t.data_ptr(),
+                                           acts.data_ptr(), rot.data_ptr(), tr.data_ptr(), L.stream_ptr()),
+                "riggs_pose_mlp_forward")
+        ctx.save_for_backward(acts, *params)
+        ctx.cfg = (depth, width, multires, skip, n_rot)
+        return rot, tr
+
+    @staticmethod
+    def backward(ctx, g_rot, g_tr):
+        acts, *params = ctx.saved_tensors
+        depth, width, multires, skip, n_rot = ctx.cfg
+        lib = L.lib()
+        dev = acts.device
+        g_rot = torch.zeros(n_rot, device=dev) if g_rot is None else g_rot.contiguous()
+        g_tr = torch.zeros(3, device=dev) if g_tr is None else g_tr.contiguous()
+        total = sum(p.numel() for p in params)
+        flat = torch.empty(total, dtype=torch.float32, device=dev)
+        dzs = torch.empty(lib.riggs_pose_mlp_backward_workspace_floats(depth, width, multires), dtype=torch.float32,
+                          device=dev)
+        Wp, bp = _PoseMLPFn._ptrs(params, depth)
+        h = params[2 * depth:]
+        L.check(lib.riggs_pose_mlp_backward(depth, width, multires, skip, n_rot, Wp, bp, h[0].data_ptr(),
+                                            h[1].data_ptr(), h[2].data_ptr(), h[3].data_ptr(), acts.data_ptr(),
+                                            g_rot.data_ptr(), g_tr.data_ptr(), dzs.data_ptr(), flat.data_ptr(),
+                                            L.stream_ptr()), "riggs_pose_mlp_backward")
+        grads, o = [], 0
+        for p in params:
+            n = p.numel()
+            grads.append(flat[o:o + n].view_as(p))
+            o += n
+        return (None, None, None, None, None, *grads)
 
 
 # --------------------------------------------------------------------------- HIP ops
