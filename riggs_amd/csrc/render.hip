@@ -214,10 +214,98 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(RenderArgs a) {
   }
 }
 
+// Variant that keeps the instance stream in SGPRs: a tile's instance records are wave-uniform, so
+// they are fetched with scalar loads (s_load_dwordx4 through the scalar cache) straight from the
+// per-Gaussian arrays — no LDS staging, no workgroup barriers, and the vector pipe only sees the
+// per-pixel arithmetic.  Each wave walks the list on its own and stops as soon as its 64 pixels
+// are finished.
+__global__ __launch_bounds__(256) void render_fwd_sgpr_kernel(RenderArgs a) {
+  __shared__ uint32_t s_max[4];
+  // constant address space (4): these arrays are read-only for the whole launch, which lets the
+  // compiler use the scalar unit for the wave-uniform loads.
+  typedef const uint32_t __attribute__((address_space(4))) c_u32;
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  typedef const f4v __attribute__((address_space(4))) c_f4;
+  c_u32* plist = (c_u32*)(uintptr_t)a.point_list;
+  c_f4* gxyd = (c_f4*)(uintptr_t)a.xyd;
+  c_f4* gcon = (c_f4*)(uintptr_t)a.conic_o;
+  c_f4* grgb = (c_f4*)(uintptr_t)a.rgb;
+  const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE;
+  const int tile = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int pxi = (tile % gx) * RIGGS_TILE + (tid & 15);
+  const int pyi = (tile / gx) * RIGGS_TILE + (tid >> 4);
+  const bool inside = pxi < a.W && pyi < a.H;
+  const float pfx = (float)pxi, pfy = (float)pyi;
+  const uint2 range = a.ranges[tile];
+  const int total = (int)(range.y - range.x);
+  const uint32_t slot0 = a.slot_base[tile];
+  bool done = !inside;
+  float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f;
+  uint32_t last = 0;
+  for (int j = 0; j < total; j += FWD_ILP) {
+    if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+    if ((j & 63) == 0 && !done) {
+      float* ck = a.ckpt + ((size_t)(slot0 + (j >> 6)) * 5) * 256 + tid;
+      ck[0] = T; ck[256] = C0; ck[512] = C1; ck[768] = C2; ck[1024] = D;
+    }
+    float alpha[FWD_ILP], depth[FWD_ILP];
+    f4v col[FWD_ILP];
+    bool valid[FWD_ILP];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < FWD_ILP; k++) {
+      const int jj = min(j + k, total - 1);
+      const uint32_t id = plist[range.x + jj];
+      const f4v xy = gxyd[id];
+      const f4v co = gcon[id];
+      col[k] = grgb[id];
+      const float dx = xy.x - pfx, dy = xy.y - pfy;
+      const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+      alpha[k] = fminf(ALPHA_MAX, co.w * fast_exp(power));
+      valid[k] = (j + k < total) && (power <= 0.0f) && (alpha[k] >= ALPHA_MIN);
+      depth[k] = xy.z;
+      any = any || valid[k];
+    }
+    if (__builtin_amdgcn_ballot_w64(any && !done) == 0) continue;
+#pragma unroll
+    for (int k = 0; k < FWD_ILP; k++) {
+      const bool v = valid[k] && !done;
+      const float test_T = T * (1.0f - alpha[k]);
+      const bool stop = v && (test_T < T_EPS);
+      const bool use = v && !stop;
+      done = done || stop;
+      const float w = use ? alpha[k] * T : 0.f;
+      C0 += col[k].x * w; C1 += col[k].y * w; C2 += col[k].z * w;
+      D += depth[k] * w; A += w;
+      T = use ? test_T : T;
+      last = use ? (uint32_t)(j + k + 1) : last;
+    }
+  }
+  uint32_t m = inside ? last : 0u;
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+  if ((tid & 63) == 0) s_max[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) a.tile_max[tile] = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+  if (inside) {
+    const size_t pid = (size_t)pyi * a.W + pxi, HW = (size_t)a.H * a.W;
+    a.final_T[pid] = T;
+    a.n_contrib[pid] = last;
+    a.final_acc[pid] = make_float4(C0, C1, C2, D);
+    a.out_color[pid] = C0 + T * a.bg[0];
+    a.out_color[HW + pid] = C1 + T * a.bg[1];
+    a.out_color[2 * HW + pid] = C2 + T * a.bg[2];
+    a.out_depth[pid] = D;
+    a.out_alpha[pid] = A;
+  }
+}
+
 int launch_render_fwd(const RenderArgs& a, hipStream_t s) {
   const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE, gy = (a.H + RIGGS_TILE - 1) / RIGGS_TILE;
   if (gx * gy == 0) return 0;
-  hipLaunchKernelGGL(render_fwd_kernel, dim3(gx * gy), dim3(256), 0, s, a);
+  static const int variant = getenv("RIGGS_RENDER_FWD") ? atoi(getenv("RIGGS_RENDER_FWD")) : 0;  // A/B switch
+  if (variant == 1) hipLaunchKernelGGL(render_fwd_sgpr_kernel, dim3(gx * gy), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(render_fwd_kernel, dim3(gx * gy), dim3(256), 0, s, a);
   return 0;
 }
 
