@@ -101,6 +101,8 @@ int riggs_raster_binning_layout(int64_t instance_capacity, int32_t num_points, i
  * and d_xyz (N,3) / d_rotation (N,4) / d_scaling (N,3) may be NULL (treated as 0, the Python-float case;
  * scales = exp(_scaling) + d_scaling as at gaussian_renderer/__init__.py:89). */
 int riggs_raster_preprocess(const riggs_raster_cfg* cfg, const float* means3D, const float* shs,
+                            const float* shs_rest /* NULL, or (N,M-1,3) with shs = (N,1,3): the reference's
+                            _features_dc / _features_rest pair read in place, no torch.cat */,
                             const float* colors_precomp, const float* opacities, const float* scales,
                             const float* rotations, const float* cov3D_precomp, const float* d_xyz,
                             const float* d_rotation, const float* d_scaling, void* geom, int32_t* radii,
@@ -121,7 +123,7 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom, void* bin
  * dL_dopacities = dL/d_opacity(logit), dL_dscales = dL/d_scaling(log; (N,1) when isotropic),
  * dL_drotations = dL/d_rotation = dL/dd_rotation. */
 int riggs_raster_backward(const riggs_raster_cfg* cfg, const float* means3D, const float* shs,
-                          const float* colors_precomp, const float* opacities, const float* scales,
+                          const float* shs_rest, const float* colors_precomp, const float* opacities, const float* scales,
                           const float* rotations, const float* cov3D_precomp, const float* d_xyz,
                           const float* d_rotation, const float* d_scaling, const int32_t* radii, const void* geom, const void* binning,
                           int64_t instance_capacity, const void* image_state, const uint32_t* counters,
@@ -129,7 +131,9 @@ int riggs_raster_backward(const riggs_raster_cfg* cfg, const float* means3D, con
                           void* workspace /* riggs_raster_backward_workspace_bytes(N) */, float* dL_dmeans3D,
                           float* dL_dmeans2D /*(N,3)*/, float* dL_dsh, float* dL_dcolors_precomp,
                           float* dL_dopacities, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
-                          float* dL_dd_scaling /* glue only, may be NULL */, riggs_stream stream);
+                          float* dL_dd_scaling /* glue only, may be NULL */,
+                          float* dL_dsh_rest /* with shs_rest: (N,M-1,3), dL_dsh is then (N,1,3) */,
+                          riggs_stream stream);
 size_t riggs_raster_backward_workspace_bytes(int32_t num_points);
 
 /* =====================================================================

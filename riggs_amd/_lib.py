@@ -41,10 +41,10 @@ _SIGS = {
     "riggs_raster_geom_layout": (C.c_int, [C.c_int32, C.POINTER(C.c_size_t)]),
     "riggs_raster_image_layout": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
     "riggs_raster_binning_layout": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
-    "riggs_raster_preprocess": (C.c_int, [C.POINTER(RasterCfg)] + [_P] * 10 + [_P, _P, _P, _P]),
+    "riggs_raster_preprocess": (C.c_int, [C.POINTER(RasterCfg)] + [_P] * 11 + [_P, _P, _P, _P]),
     "riggs_raster_render": (C.c_int, [C.POINTER(RasterCfg), _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P]),
-    "riggs_raster_backward": (C.c_int, [C.POINTER(RasterCfg)] + [_P] * 10 + [_P, _P, _P, C.c_int64, _P, _P] + [_P] * 3
-                              + [_P] + [_P] * 9 + [_P]),
+    "riggs_raster_backward": (C.c_int, [C.POINTER(RasterCfg)] + [_P] * 11 + [_P, _P, _P, C.c_int64, _P, _P] + [_P] * 3
+                              + [_P] + [_P] * 10 + [_P]),
     "riggs_fk_forward": (C.c_int, [C.c_int32] + [_P] * 8),
     "riggs_fk_backward": (C.c_int, [C.c_int32] + [_P] * 8),
     "riggs_lbs_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [_P] * 13),

@@ -166,7 +166,7 @@ int riggs_raster_binning_layout(int64_t cap, int32_t N, int32_t H, int32_t W, si
 }
 
 static int fill_pre_args(PreArgs& a, const riggs_raster_cfg* c, const float* means3D, const float* shs,
-                         const float* colors_precomp, const float* opac, const float* scales, const float* rots,
+                         const float* shs_rest, const float* colors_precomp, const float* opac, const float* scales, const float* rots,
                          const float* cov3D_precomp, const float* d_xyz, const float* d_rot, const float* d_scaling,
                          char* geom, int32_t* radii) {
   RIGGS_REQUIRE(c != nullptr, "cfg is NULL");
@@ -184,7 +184,7 @@ static int fill_pre_args(PreArgs& a, const riggs_raster_cfg* c, const float* mea
   a.glue = c->glue; a.isotropic = c->isotropic;
   a.tanx = c->tanfovx; a.tany = c->tanfovy; a.mod = c->scale_modifier;
   a.view = c->viewmatrix; a.proj = c->projmatrix; a.campos = c->campos;
-  a.means3D = means3D; a.shs = shs; a.colors_precomp = colors_precomp; a.opac = opac; a.scales = scales; a.rots = rots;
+  a.means3D = means3D; a.shs = shs; a.shs_rest = shs_rest; a.colors_precomp = colors_precomp; a.opac = opac; a.scales = scales; a.rots = rots;
   a.cov3D_precomp = cov3D_precomp; a.d_xyz = d_xyz; a.d_rot = d_rot; a.d_scaling = d_scaling;
   a.radii = radii;
   a.xyd = (float4*)(geom + L.xyd); a.conic_o = (float4*)(geom + L.conic_o); a.rgb = (float4*)(geom + L.rgb);
@@ -195,14 +195,14 @@ static int fill_pre_args(PreArgs& a, const riggs_raster_cfg* c, const float* mea
 }
 
 int riggs_raster_preprocess(const riggs_raster_cfg* cfg, const float* means3D, const float* shs,
-                            const float* colors_precomp, const float* opacities, const float* scales,
+                            const float* shs_rest, const float* colors_precomp, const float* opacities, const float* scales,
                             const float* rotations, const float* cov3D_precomp, const float* d_xyz,
                             const float* d_rotation, const float* d_scaling, void* geom_, int32_t* radii,
                             uint32_t* counters, riggs_stream stream_) {
   hipStream_t s = (hipStream_t)stream_;
   char* geom = (char*)geom_;
   PreArgs a;
-  int rc = fill_pre_args(a, cfg, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, d_xyz,
+  int rc = fill_pre_args(a, cfg, means3D, shs, shs_rest, colors_precomp, opacities, scales, rotations, cov3D_precomp, d_xyz,
                          d_rotation, d_scaling, geom, radii);
   if (rc) return rc;
   const int N = cfg->num_points;
@@ -289,7 +289,7 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
 }
 
 int riggs_raster_backward(const riggs_raster_cfg* cfg, const float* means3D, const float* shs,
-                          const float* colors_precomp, const float* opacities, const float* scales,
+                          const float* shs_rest, const float* colors_precomp, const float* opacities, const float* scales,
                           const float* rotations, const float* cov3D_precomp, const float* d_xyz,
                           const float* d_rotation, const float* d_scaling, const int32_t* radii, const void* geom_,
                           const void* binning_,
@@ -297,11 +297,11 @@ int riggs_raster_backward(const riggs_raster_cfg* cfg, const float* means3D, con
                           const float* dL_ddepth, const float* dL_dalpha, void* workspace, float* dL_dmeans3D,
                           float* dL_dmeans2D, float* dL_dsh, float* dL_dcolors_precomp, float* dL_dopacities,
                           float* dL_dscales, float* dL_drotations, float* dL_dcov3D, float* dL_dd_scaling,
-                          riggs_stream stream_) {
+                          float* dL_dsh_rest, riggs_stream stream_) {
   hipStream_t s = (hipStream_t)stream_;
   (void)counters;
   PreBwdArgs b;
-  int rc = fill_pre_args(b.f, cfg, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, d_xyz,
+  int rc = fill_pre_args(b.f, cfg, means3D, shs, shs_rest, colors_precomp, opacities, scales, rotations, cov3D_precomp, d_xyz,
                          d_rotation, d_scaling, (char*)geom_, (int32_t*)radii);
   if (rc) return rc;
   RIGGS_REQUIRE(dL_dcolor && dL_dmeans3D && dL_dmeans2D && dL_dopacities && workspace, "missing gradient buffers");
@@ -336,7 +336,8 @@ int riggs_raster_backward(const riggs_raster_cfg* cfg, const float* means3D, con
   b.g_mean2D_conic = (const float*)workspace;
   b.dL_dmeans3D = dL_dmeans3D; b.dL_dmeans2D = dL_dmeans2D; b.dL_dsh = dL_dsh; b.dL_dcolors = dL_dcolors_precomp;
   b.dL_dopac = dL_dopacities; b.dL_dscales = dL_dscales; b.dL_drots = dL_drotations; b.dL_dcov3D = dL_dcov3D;
-  b.dL_dd_scaling = dL_dd_scaling;
+  b.dL_dd_scaling = dL_dd_scaling; b.dL_dsh_rest = dL_dsh_rest;
+  RIGGS_REQUIRE(shs_rest == nullptr || dL_dsh_rest != nullptr, "dL_dsh_rest required with shs_rest");
   { ProfScope ps(PROF_PREPROCESS_BWD, s); launch_preprocess_bwd(b, s); }
   if (debug_sync(cfg->debug, s, "preprocess_bwd")) return 1;
   return 0;

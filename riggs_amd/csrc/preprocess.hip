@@ -44,8 +44,80 @@ __device__ __forceinline__ void load_inputs(const PreArgs& a, int i, GlueIn& g, 
   }
 }
 
+
+// ---- coalesced SH staging -----------------------------------------------------------------
+// A workgroup's 256 Gaussians own one contiguous run of coefficients in HBM ((N,16,3) records of
+// 192 B, or the reference's split parameters _features_dc (N,1,3) / _features_rest (N,15,3) of
+// 12 B + 180 B, scene/gaussian_model.py:177-195).  Per-thread record reads would touch every
+// 128-B line from 8+ different load instructions; instead the run is copied with full-line float4
+// accesses into LDS (row stride padded to an odd number of dwords -> conflict-free b32 reads) and
+// each thread then picks its own record.  The same path, reversed, writes dL/dsh.
+__device__ __forceinline__ int sh_lds_stride(int per) { return per | 1; }
+
+__device__ __forceinline__ void sh_stage_in(const float* __restrict__ src, int per, int count, float* lds) {
+  const int total = count * per;
+  const int stride = sh_lds_stride(per);
+  const bool aligned = ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+  const int q1024 = 1024 / per, r1024 = 1024 % per;
+  int e = threadIdx.x * 4;
+  int g = e / per, k = e % per;
+  for (; e < total; e += 1024) {
+    float v[4];
+    if (aligned && e + 3 < total) {
+      const float4 t = *reinterpret_cast<const float4*>(src + e);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; q++) v[q] = (e + q < total) ? src[e + q] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      int kk = k + q, gg = g;
+      if (kk >= per) { kk -= per; gg++; }
+      if (e + q < total) lds[gg * stride + kk] = v[q];
+    }
+    k += r1024; g += q1024;
+    if (k >= per) { k -= per; g++; }
+  }
+}
+
+__device__ __forceinline__ void sh_stage_out(float* __restrict__ dst, int per, int count, const float* lds) {
+  const int total = count * per;
+  const int stride = sh_lds_stride(per);
+  const bool aligned = ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+  const int q1024 = 1024 / per, r1024 = 1024 % per;
+  int e = threadIdx.x * 4;
+  int g = e / per, k = e % per;
+  for (; e < total; e += 1024) {
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      int kk = k + q, gg = g;
+      if (kk >= per) { kk -= per; gg++; }
+      v[q] = (e + q < total) ? lds[gg * stride + kk] : 0.f;
+    }
+    if (aligned && e + 3 < total) *reinterpret_cast<float4*>(dst + e) = make_float4(v[0], v[1], v[2], v[3]);
+    else {
+#pragma unroll
+      for (int q = 0; q < 4; q++) if (e + q < total) dst[e + q] = v[q];
+    }
+    k += r1024; g += q1024;
+    if (k >= per) { k -= per; g++; }
+  }
+}
+
 __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a) {
+  extern __shared__ float s_sh[];
   const int i = blockIdx.x * 256 + threadIdx.x;
+  // SH records of this workgroup -> LDS (uniform; before any per-Gaussian exit)
+  const bool sh_mode = (a.colors_precomp == nullptr);
+  const int sh_per = a.shs_rest ? (a.M - 1) * 3 : a.M * 3;  // floats per Gaussian in the staged array
+  if (sh_mode && sh_per > 0) {
+    const int first = blockIdx.x * 256, count = min(256, a.N - first);
+    const float* src = (a.shs_rest ? a.shs_rest : a.shs) + (size_t)first * sh_per;
+    sh_stage_in(src, sh_per, count, s_sh);
+    __syncthreads();
+  }
   if (i >= a.N) return;
   const float* __restrict__ V = a.view;
   const float* __restrict__ P = a.proj;
@@ -102,21 +174,15 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a) {
     float B[16];
     sh_basis(a.deg, dx, dy, dz, B);
     const int nb = (a.deg + 1) * (a.deg + 1);
-    const float* sh = a.shs + (size_t)i * a.M * 3;
+    const float* mine = s_sh + threadIdx.x * sh_lds_stride(sh_per);
+    const int koff = a.shs_rest ? 3 : 0;  // split layout: coefficient 0 comes from _features_dc
     float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-    if (a.M == 16) {  // 192-byte record: twelve 16-B loads
-      const float4* sh4 = reinterpret_cast<const float4*>(sh);
-      float c[48];
+    if (a.shs_rest) { r0 = B[0] * a.shs[3 * i]; r1 = B[0] * a.shs[3 * i + 1]; r2 = B[0] * a.shs[3 * i + 2]; }
 #pragma unroll
-      for (int k = 0; k < 12; k++) {
-        if (k * 4 < nb * 3) { float4 t = sh4[k]; c[4 * k] = t.x; c[4 * k + 1] = t.y; c[4 * k + 2] = t.z; c[4 * k + 3] = t.w; }
-        else { c[4 * k] = c[4 * k + 1] = c[4 * k + 2] = c[4 * k + 3] = 0.f; }
+    for (int k = 0; k < 16; k++) {
+      if (k < nb && 3 * k >= koff) {
+        r0 += B[k] * mine[3 * k - koff]; r1 += B[k] * mine[3 * k + 1 - koff]; r2 += B[k] * mine[3 * k + 2 - koff];
       }
-#pragma unroll
-      for (int k = 0; k < 16; k++)
-        if (k < nb) { r0 += B[k] * c[3 * k]; r1 += B[k] * c[3 * k + 1]; r2 += B[k] * c[3 * k + 2]; }
-    } else {
-      for (int k = 0; k < nb; k++) { r0 += B[k] * sh[3 * k]; r1 += B[k] * sh[3 * k + 1]; r2 += B[k] * sh[3 * k + 2]; }
     }
     r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
     cl = (uint8_t)((r0 < 0.f ? 1 : 0) | (r1 < 0.f ? 2 : 0) | (r2 < 0.f ? 4 : 0));
@@ -135,14 +201,24 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a) {
 }
 
 // ---------------------------------------------------------------------------- backward
-__global__ __launch_bounds__(256) void preprocess_bwd_kernel(PreBwdArgs b) {
+__global__ __launch_bounds__(256, 3) void preprocess_bwd_kernel(PreBwdArgs b) {
+  extern __shared__ float s_sh[];
   const PreArgs& a = b.f;
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.N) return;
+  const bool in_range = i < a.N;
   const float* __restrict__ V = a.view;
   const float* __restrict__ P = a.proj;
-  const bool visible = a.radii[i] > 0;
   const bool sh_mode = (a.colors_precomp == nullptr);
+  const int sh_per = a.shs_rest ? (a.M - 1) * 3 : a.M * 3;
+  const int sh_first = blockIdx.x * 256, sh_count = min(256, a.N - sh_first);
+  if (sh_mode && sh_per > 0) {
+    sh_stage_in((a.shs_rest ? a.shs_rest : a.shs) + (size_t)sh_first * sh_per, sh_per, sh_count, s_sh);
+    __syncthreads();
+  }
+  const bool visible = in_range && a.radii[i] > 0;
+  float Bk[16], gcs[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 16; k++) Bk[k] = 0.f;
   const bool need_sr = (a.cov3D_precomp == nullptr);
   float gm[3] = {0.f, 0.f, 0.f};
   float g2x = 0.f, g2y = 0.f, g_op = 0.f;
@@ -214,36 +290,21 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(PreBwdArgs b) {
       float dx = p[0] - a.campos[0], dy = p[1] - a.campos[1], dz = p[2] - a.campos[2];
       const float len = sqrtf(dx * dx + dy * dy + dz * dz);
       const float ux = dx / len, uy = dy / len, uz = dz / len;
-      float B[16];
-      sh_basis(a.deg, ux, uy, uz, B);
+      sh_basis(a.deg, ux, uy, uz, Bk);
       const int nb = (a.deg + 1) * (a.deg + 1);
+#pragma unroll
+      for (int k = 0; k < 16; k++) if (k >= nb) Bk[k] = 0.f;
       const uint8_t cl = a.clamped[i];
-      const float gc0 = (cl & 1) ? 0.f : gcol[0], gc1 = (cl & 2) ? 0.f : gcol[1], gc2 = (cl & 4) ? 0.f : gcol[2];
-      const float* sh = a.shs + (size_t)i * a.M * 3;
-      float* gsh = b.dL_dsh + (size_t)i * a.M * 3;
+      gcs[0] = (cl & 1) ? 0.f : gcol[0]; gcs[1] = (cl & 2) ? 0.f : gcol[1]; gcs[2] = (cl & 4) ? 0.f : gcol[2];
+      const float* mine = s_sh + threadIdx.x * sh_lds_stride(sh_per);
+      const int koff = a.shs_rest ? 3 : 0;
       float w[16];
-      if (a.M == 16) {
-        const float4* sh4 = reinterpret_cast<const float4*>(sh);
-        float4* gsh4 = reinterpret_cast<float4*>(gsh);
-        float c[48], o[48];
 #pragma unroll
-        for (int k = 0; k < 12; k++) {
-          if (k * 4 < nb * 3) { float4 t = sh4[k]; c[4 * k] = t.x; c[4 * k + 1] = t.y; c[4 * k + 2] = t.z; c[4 * k + 3] = t.w; }
-          else { c[4 * k] = c[4 * k + 1] = c[4 * k + 2] = c[4 * k + 3] = 0.f; }
-        }
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-          const float bk = (k < nb) ? B[k] : 0.f;
-          o[3 * k] = bk * gc0; o[3 * k + 1] = bk * gc1; o[3 * k + 2] = bk * gc2;
-          w[k] = c[3 * k] * gc0 + c[3 * k + 1] * gc1 + c[3 * k + 2] * gc2;
-        }
-#pragma unroll
-        for (int k = 0; k < 12; k++) gsh4[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
-      } else {
-        for (int k = 0; k < a.M; k++) {
-          const float bk = (k < nb) ? B[k] : 0.f;
-          gsh[3 * k] = bk * gc0; gsh[3 * k + 1] = bk * gc1; gsh[3 * k + 2] = bk * gc2;
-          w[k] = (k < nb) ? (sh[3 * k] * gc0 + sh[3 * k + 1] * gc1 + sh[3 * k + 2] * gc2) : 0.f;
+      for (int k = 0; k < 16; k++) {
+        w[k] = 0.f;
+        if (k < nb) {
+          if (3 * k >= koff) w[k] = mine[3 * k - koff] * gcs[0] + mine[3 * k + 1 - koff] * gcs[1] + mine[3 * k + 2 - koff] * gcs[2];
+          else w[k] = a.shs[3 * i] * gcs[0] + a.shs[3 * i + 1] * gcs[1] + a.shs[3 * i + 2] * gcs[2];
         }
       }
       float gdir[3];
@@ -281,16 +342,29 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(PreBwdArgs b) {
       gq[2] = 2.f * (-2.f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.f * y * dR[8]);
       gq[3] = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
     }
-  } else if (sh_mode && b.dL_dsh) {
-    float* gsh = b.dL_dsh + (size_t)i * a.M * 3;
-    if (a.M == 16) {
-      float4* gsh4 = reinterpret_cast<float4*>(gsh);
+  }
+  // ---- dL/dsh: per-thread records -> LDS -> full-line stores (zeros for invisible Gaussians)
+  if (sh_mode) {
+    const int koff = a.shs_rest ? 3 : 0;
+    if (sh_per > 0) {
+      __syncthreads();  // every thread is done reading the staged coefficients
+      float* mine = s_sh + threadIdx.x * sh_lds_stride(sh_per);
 #pragma unroll
-      for (int k = 0; k < 12; k++) gsh4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    } else {
-      for (int k = 0; k < a.M * 3; k++) gsh[k] = 0.f;
+      for (int k = 0; k < 16; k++) {
+        if (k < a.M && 3 * k >= koff) {
+          mine[3 * k - koff] = Bk[k] * gcs[0]; mine[3 * k + 1 - koff] = Bk[k] * gcs[1]; mine[3 * k + 2 - koff] = Bk[k] * gcs[2];
+        }
+      }
+      for (int k = 16; k < a.M; k++) { mine[3 * k - koff] = 0.f; mine[3 * k + 1 - koff] = 0.f; mine[3 * k + 2 - koff] = 0.f; }
+      __syncthreads();
+      float* dst = (a.shs_rest ? b.dL_dsh_rest : b.dL_dsh) + (size_t)sh_first * sh_per;
+      sh_stage_out(dst, sh_per, sh_count, s_sh);
+    }
+    if (a.shs_rest && in_range) {
+      b.dL_dsh[3 * i] = Bk[0] * gcs[0]; b.dL_dsh[3 * i + 1] = Bk[0] * gcs[1]; b.dL_dsh[3 * i + 2] = Bk[0] * gcs[2];
     }
   }
+  if (!in_range) return;
   // ---- outputs (with the chain rule of the render glue when fused) ----
   b.dL_dmeans3D[3 * i] = gm[0]; b.dL_dmeans3D[3 * i + 1] = gm[1]; b.dL_dmeans3D[3 * i + 2] = gm[2];
   b.dL_dmeans2D[3 * i] = g2x; b.dL_dmeans2D[3 * i + 1] = g2y; b.dL_dmeans2D[3 * i + 2] = 0.f;
@@ -335,12 +409,16 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(PreBwdArgs b) {
 // host-side launchers (called from capi.hip)
 int launch_preprocess_fwd(const PreArgs& a, hipStream_t s) {
   if (a.N == 0) return 0;
-  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((a.N + 255) / 256), dim3(256), 0, s, a);
+  const int per = a.shs_rest ? (a.M - 1) * 3 : a.M * 3;
+  const size_t lds = a.colors_precomp ? 0 : (size_t)256 * (per | 1) * sizeof(float);
+  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((a.N + 255) / 256), dim3(256), lds, s, a);
   return 0;
 }
 int launch_preprocess_bwd(const PreBwdArgs& b, hipStream_t s) {
   if (b.f.N == 0) return 0;
-  hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((b.f.N + 255) / 256), dim3(256), 0, s, b);
+  const int per = b.f.shs_rest ? (b.f.M - 1) * 3 : b.f.M * 3;
+  const size_t lds = b.f.colors_precomp ? 0 : (size_t)256 * (per | 1) * sizeof(float);
+  hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((b.f.N + 255) / 256), dim3(256), lds, s, b);
   return 0;
 }
 

@@ -8,7 +8,7 @@ struct PreArgs {
   int N, deg, M, W, H, glue, isotropic;
   float tanx, tany, mod;
   const float *view, *proj, *campos;
-  const float *means3D, *shs, *colors_precomp, *opac, *scales, *rots, *cov3D_precomp, *d_xyz, *d_rot, *d_scaling;
+  const float *means3D, *shs, *shs_rest, *colors_precomp, *opac, *scales, *rots, *cov3D_precomp, *d_xyz, *d_rot, *d_scaling;
   int32_t* radii;
   float4 *xyd, *conic_o, *rgb;
   float* cov3D;
@@ -21,7 +21,7 @@ struct PreArgs {
 struct PreBwdArgs {
   PreArgs f;                     // forward inputs (radii/xyd/... unused here except radii, cov3D, clamped)
   const float* g_mean2D_conic;   // workspace: per Gaussian [mean2D.x, mean2D.y, gA, gB, gC, g_opacity, g_r, g_g, g_b, g_depth]
-  float *dL_dmeans3D, *dL_dmeans2D, *dL_dsh, *dL_dcolors, *dL_dopac, *dL_dscales, *dL_drots, *dL_dcov3D, *dL_dd_scaling;
+  float *dL_dmeans3D, *dL_dmeans2D, *dL_dsh, *dL_dcolors, *dL_dopac, *dL_dscales, *dL_drots, *dL_dcov3D, *dL_dd_scaling, *dL_dsh_rest;
 };
 #define RIGGS_GACC 12  // floats per Gaussian in the render-backward accumulator (padded to 48 B)
 

@@ -114,13 +114,13 @@ class _Saved:
 
 def rasterize_forward(settings, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                       d_xyz=None, d_rotation=None, d_scaling=None, glue=False, isotropic=False,
-                      arena: Optional[RasterArena] = None):
+                      arena: Optional[RasterArena] = None, shs_rest=None):
     """Runs both forward stages.  Returns (color, radii, depth, alpha, saved-state)."""
     lib = L.lib()
     N = means3D.shape[0]
     dev = means3D.device
     H, W = int(settings.image_height), int(settings.image_width)
-    M = 0 if shs is None else shs.shape[1]
+    M = 0 if shs is None else shs.shape[1] + (0 if shs_rest is None else shs_rest.shape[1])
     keep = []
     cfg = _cfg(settings, N, M, glue, isotropic, keep)
     geom = torch.empty(lib.riggs_raster_geom_bytes(N), dtype=torch.uint8, device=dev)
@@ -131,7 +131,7 @@ def rasterize_forward(settings, means3D, shs, colors_precomp, opacities, scales,
     depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
     alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
     st = L.stream_ptr()
-    L.check(lib.riggs_raster_preprocess(C.byref(cfg), L.ptr(means3D), L.ptr(shs), L.ptr(colors_precomp),
+    L.check(lib.riggs_raster_preprocess(C.byref(cfg), L.ptr(means3D), L.ptr(shs), L.ptr(shs_rest), L.ptr(colors_precomp),
                                         L.ptr(opacities), L.ptr(scales), L.ptr(rotations), L.ptr(cov3D_precomp),
                                         L.ptr(d_xyz), L.ptr(d_rotation), L.ptr(d_scaling), geom.data_ptr(), radii.data_ptr(),
                                         counters.data_ptr(), st), "riggs_raster_preprocess")
@@ -172,14 +172,15 @@ def arena_check(s: _Saved, arena: RasterArena) -> bool:
 
 def rasterize_backward(s: _Saved, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                        d_xyz, d_rotation, grad_color, grad_depth, grad_alpha, d_scaling=None,
-                       want_d_scaling_grad=False):
+                       want_d_scaling_grad=False, shs_rest=None):
     lib = L.lib()
     N, M, dev = s.N, s.M, means3D.device
     f32 = dict(dtype=torch.float32, device=dev)
     cfg = s.cfg
     g_means3D = torch.empty(N, 3, **f32)
     g_means2D = torch.empty(N, 3, **f32)
-    g_sh = torch.empty(N, M, 3, **f32) if shs is not None else None
+    g_sh = torch.empty(N, shs.shape[1], 3, **f32) if shs is not None else None
+    g_sh_rest = torch.empty(N, shs_rest.shape[1], 3, **f32) if shs_rest is not None else None
     g_colors = torch.empty(N, 3, **f32) if colors_precomp is not None else None
     g_opac = torch.empty(N, 1, **f32)
     iso = bool(cfg.glue and cfg.isotropic)
@@ -192,13 +193,15 @@ def rasterize_backward(s: _Saved, means3D, shs, colors_precomp, opacities, scale
     gd = L.require_cuda_f32("grad_depth", grad_depth) if grad_depth is not None else None
     ga = L.require_cuda_f32("grad_alpha", grad_alpha) if grad_alpha is not None else None
     L.check(lib.riggs_raster_backward(
-        C.byref(cfg), L.ptr(means3D), L.ptr(shs), L.ptr(colors_precomp), L.ptr(opacities), L.ptr(scales),
+        C.byref(cfg), L.ptr(means3D), L.ptr(shs), L.ptr(shs_rest), L.ptr(colors_precomp), L.ptr(opacities), L.ptr(scales),
         L.ptr(rotations), L.ptr(cov3D_precomp), L.ptr(d_xyz), L.ptr(d_rotation), L.ptr(d_scaling), s.radii.data_ptr(),
         s.geom.data_ptr(), s.binning.data_ptr(), s.cap, s.img.data_ptr(), s.counters.data_ptr(), gc.data_ptr(),
         L.ptr(gd), L.ptr(ga), ws.data_ptr(), g_means3D.data_ptr(), g_means2D.data_ptr(), L.ptr(g_sh),
         L.ptr(g_colors), g_opac.data_ptr(), L.ptr(g_scales), L.ptr(g_rots), L.ptr(g_cov), L.ptr(g_dscaling),
-        L.stream_ptr()),
+        L.ptr(g_sh_rest), L.stream_ptr()),
         "riggs_raster_backward")
+    if shs_rest is not None:
+        g_sh = (g_sh, g_sh_rest)
     return g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rots, g_cov, g_dscaling
 
 

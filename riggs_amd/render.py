@@ -35,7 +35,8 @@ class _FusedGlueRaster(torch.autograd.Function):
     def forward(ctx, xyz, means2D, f_dc, f_rest, opacity, scaling, rotation, d_xyz, d_rot, d_scaling, settings,
                 isotropic, arena):
         N = xyz.shape[0]
-        shs = torch.cat((f_dc, f_rest), dim=1).contiguous()  # (N,16,3): the rasterizer's SH record
+        f_dc = L.require_cuda_f32("_features_dc", f_dc, (N, 1, 3))      # read in place: no torch.cat, the kernel
+        f_rest = L.require_cuda_f32("_features_rest", f_rest, (N, None, 3))  # stages both arrays through LDS
         xyz = L.require_cuda_f32("_xyz", xyz, (N, 3))
         opacity = L.require_cuda_f32("_opacity", opacity, (N, 1))
         scaling = L.require_cuda_f32("_scaling", scaling, (N, 1 if isotropic else 3))
@@ -43,27 +44,26 @@ class _FusedGlueRaster(torch.autograd.Function):
         d_xyz = L.require_cuda_f32("d_xyz", d_xyz, (N, 3)) if d_xyz is not None else None
         d_rot = L.require_cuda_f32("d_rotation", d_rot, (N, 4)) if d_rot is not None else None
         d_scaling = L.require_cuda_f32("d_scaling", d_scaling, (N, 3)) if d_scaling is not None else None
-        out = rasterize_forward(settings, xyz, shs, None, opacity, scaling, rotation, None, d_xyz=d_xyz,
-                                d_rotation=d_rot, d_scaling=d_scaling, glue=True, isotropic=isotropic, arena=arena)
+        out = rasterize_forward(settings, xyz, f_dc, None, opacity, scaling, rotation, None, d_xyz=d_xyz,
+                                d_rotation=d_rot, d_scaling=d_scaling, glue=True, isotropic=isotropic, arena=arena,
+                                shs_rest=f_rest)
         color, radii, depth, alpha, s = out
         ctx.s, ctx.arena, ctx.settings, ctx.isotropic = s, arena, settings, isotropic
-        ctx.n_dc = f_dc.shape[1]
-        ctx.save_for_backward(xyz, shs, opacity, scaling, rotation, d_xyz, d_rot, d_scaling)
+        ctx.save_for_backward(xyz, f_dc, f_rest, opacity, scaling, rotation, d_xyz, d_rot, d_scaling)
         ctx.mark_non_differentiable(radii)
         return color, radii, depth, alpha
 
     @staticmethod
     def backward(ctx, g_color, _g_radii, g_depth, g_alpha):
-        xyz, shs, opacity, scaling, rotation, d_xyz, d_rot, d_scaling = ctx.saved_tensors
+        xyz, f_dc, f_rest, opacity, scaling, rotation, d_xyz, d_rot, d_scaling = ctx.saved_tensors
         s = ctx.s
         if ctx.arena is not None:
             ctx.arena.resolve(block=False)  # raises if the forward of this frame is known to have overflowed
         need_ds = d_scaling is not None and ctx.needs_input_grad[9]
-        g = rasterize_backward(s, xyz, shs, None, opacity, scaling, rotation, None, d_xyz, d_rot, g_color, g_depth,
-                               g_alpha, d_scaling=d_scaling, want_d_scaling_grad=need_ds)
-        g_means3D, g_means2D, g_sh, _, g_opac, g_scales, g_rots, _, g_ds = g
-        n = ctx.n_dc
-        return (g_means3D, g_means2D, g_sh[:, :n], g_sh[:, n:], g_opac, g_scales, g_rots,
+        g = rasterize_backward(s, xyz, f_dc, None, opacity, scaling, rotation, None, d_xyz, d_rot, g_color, g_depth,
+                               g_alpha, d_scaling=d_scaling, want_d_scaling_grad=need_ds, shs_rest=f_rest)
+        g_means3D, g_means2D, (g_dc, g_rest), _, g_opac, g_scales, g_rots, _, g_ds = g
+        return (g_means3D, g_means2D, g_dc, g_rest, g_opac, g_scales, g_rots,
                 g_means3D if d_xyz is not None else None, g_rots if d_rot is not None else None, g_ds, None, None,
                 None)
 
