@@ -58,7 +58,9 @@ def make_step(cam, gm, sw, gimg, arena, world):
     from riggs_amd.render import render
     import torch.distributed as dist
     bg = torch.zeros(3, device=gimg.device)
+    from riggs_amd.dist import FlatGradAllReduce
     params = params_of(gm, sw)
+    allreduce = FlatGradAllReduce(params)
     t_in = sw.expand_time(cam.fid)
 
     def step():
@@ -68,14 +70,7 @@ def make_step(cam, gm, sw, gimg, arena, world):
         pkg = render(cam, gm, Pipe, bg, dv["d_xyz"], dv["d_rotation"], dv["d_scaling"], fused=True, arena=arena)
         pkg["render"].backward(gimg)
         if world > 1:
-            flat = torch.cat([p.grad.reshape(-1) for p in params])
-            dist.all_reduce(flat)  # RCCL over xGMI: sum of the per-frame gradients
-            flat.div_(world)
-            o = 0
-            for p in params:
-                n = p.numel()
-                p.grad = flat[o:o + n].view_as(p)
-                o += n
+            allreduce()  # RCCL over xGMI: one all-reduce of the flat gradient buffer, averaged
         return pkg
     return step
 
@@ -172,12 +167,13 @@ def main():
         gf = GraphedFrame(gm, sw, cam, torch.zeros(3, device=dev), params).capture()
         gf.set_inputs(gimg=gimg)
 
+        from riggs_amd.dist import FlatGradAllReduce
+        graph_allreduce = FlatGradAllReduce(params)
+
         def step():  # noqa: F811
             out = gf.run()
             if world > 1:
-                flat = torch.cat([p.grad.reshape(-1) for p in params])
-                dist.all_reduce(flat)
-                flat.div_(world)
+                graph_allreduce(sources=gf.grads)  # graph-owned gradient buffers -> flat -> RCCL -> p.grad views
             return out
         step()
         torch.cuda.synchronize()

@@ -80,6 +80,7 @@ class GraphedFrame:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=s):  # same stream as the warm-up: AccumulateGrad nodes match
             self.out = self._frame()
+        self.grads = [p.grad for p in self.params]  # static gradient buffers refilled by every replay
         return self
 
     def run(self, cam: Camera = None, gimg: torch.Tensor = None):
