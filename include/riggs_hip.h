@@ -169,13 +169,15 @@ int riggs_lbs_forward(int32_t num_points, int32_t num_joints, int32_t K, const f
                       float* d_rotation, float* nn_weight, int64_t* nn_idx, riggs_stream stream);
 /* Backward: cotangents g_xyz (N,3), g_rot (N,4) -> dL/dtransforms (J,12), dL/dnode_radius_log (J),
  * dL/dglobal_trans (3), optional dL/dmotion_mask (N).  Reduction over N is done in-kernel
- * (wave -> workgroup -> one atomic per workgroup per output); outputs are zeroed first.
+ * (registers -> workgroup partials -> a fixed-order second stage: run-to-run deterministic).
  * No gradient to x or joints (both detached in the reference: skeleton_warp.py:16,44,131). */
 int riggs_lbs_backward(int32_t num_points, int32_t num_joints, int32_t K, const float* x, const float* joints,
                        const int32_t* parents, const float* node_radius_log, const float* transforms,
                        const float* node_rot, const float* global_trans, const float* motion_mask,
                        const float* g_xyz, const float* g_rot, float* dL_dtransforms, float* dL_dnode_radius_log,
-                       float* dL_dglobal_trans, float* dL_dmotion_mask, riggs_stream stream);
+                       float* dL_dglobal_trans, float* dL_dmotion_mask,
+                       void* workspace /* riggs_lbs_backward_workspace_bytes(N, J) */, riggs_stream stream);
+size_t riggs_lbs_backward_workspace_bytes(int32_t num_points, int32_t num_joints);
 
 /* =====================================================================
  * PoseMLP (time -> J quaternions + root translation), batch of ONE row:

@@ -48,7 +48,8 @@ _SIGS = {
     "riggs_fk_forward": (C.c_int, [C.c_int32] + [_P] * 8),
     "riggs_fk_backward": (C.c_int, [C.c_int32] + [_P] * 8),
     "riggs_lbs_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [_P] * 13),
-    "riggs_lbs_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [_P] * 15),
+    "riggs_lbs_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [_P] * 16),
+    "riggs_lbs_backward_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "riggs_pose_mlp_acts_floats": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "riggs_pose_mlp_backward_workspace_floats": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "riggs_pose_mlp_forward": (C.c_int, [C.c_int32] * 5 + [_P] * 11),

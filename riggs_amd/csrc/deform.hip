@@ -5,6 +5,8 @@
 //            <= 63 bone records (segment, radius, 3x4 transform, quaternion) staged in LDS.
 // Backward reduces over the N Gaussians inside the kernel: wave64 DPP sums -> LDS -> one atomic
 // per workgroup per output.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace riggs {
@@ -202,6 +204,7 @@ struct LbsArgs {
   // backward
   const float *g_xyz, *g_rot;
   float *dG, *drho, *dgt, *dmask;
+  float* partial;  // [workgroups][(J-1)*13 + 3] per-workgroup sums (deterministic two-stage reduction)
 };
 
 __device__ __forceinline__ void stage_bones(const LbsArgs& a, Bone* bones) {
@@ -402,6 +405,149 @@ __global__ __launch_bounds__(256) void lbs_backward_kernel(LbsArgs a) {
   if (threadIdx.x < 3) atomicAdd(&a.dgt[threadIdx.x], s_gt[threadIdx.x]);
 }
 
+// ---- backward, K <= 0 (all bones): lane <-> (Gaussian slot, bone) ---------------------------------
+// A wave64 is 8 Gaussian slots x 8 bone lanes; bones are covered in blocks of 8.  Each lane owns one
+// bone per block, so the 13 per-bone sums over the Gaussians are plain register accumulations (no
+// cross-lane reduction per Gaussian); only the two per-Gaussian normalisers (sum_k v_k and
+// sum_k v_k dL/dw_k) are reduced over the 8 bone lanes (3 DPP steps).  The 8 slot rows are folded once
+// per wave at the end.  (The pixel-major variant above spent ~30 DPP ops per (Gaussian, bone).)
+#define LB_BONES 8                      // bone lanes per Gaussian slot
+#define LB_MAXBLK ((MAX_J - 1 + LB_BONES - 1) / LB_BONES)
+#define LB_GPB 256                      // Gaussians per workgroup (8 steps of 8 per wave)
+
+__device__ __forceinline__ float row8_sum(float v) {
+  // sum over the 8 lanes sharing (lane >> 3): xor 1, 2, 4 via DPP quad_perm / row_half_mirror patterns
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+  return v;
+}
+
+template <int NBLK>
+__global__ __launch_bounds__(256) void lbs_backward_bonelane_kernel(LbsArgs a) {
+  __shared__ Bone bones[MAX_J - 1 + LB_BONES];
+  __shared__ float s_acc[MAX_J - 1 + LB_BONES][13];
+  __shared__ float s_gt[3];
+  const int B = a.J - 1;
+  stage_bones(a, bones);
+  for (int k = B + threadIdx.x; k < NBLK * LB_BONES; k += 256) {  // padding bones: never selected
+    Bone z;
+    memset(&z, 0, sizeof(z));
+    z.len2c = 1.f;
+    bones[k] = z;
+  }
+  for (int e = threadIdx.x; e < NBLK * LB_BONES * 13; e += 256) (&s_acc[0][0])[e] = 0.f;
+  if (threadIdx.x < 3) s_gt[threadIdx.x] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = lane >> 3, bl = lane & 7;
+  const int wave_first = blockIdx.x * LB_GPB + wave * (LB_GPB / 4);
+  const int wave_end = min(a.N, wave_first + LB_GPB / 4);
+  float acc[NBLK][13];
+#pragma unroll
+  for (int bb = 0; bb < NBLK; bb++)
+#pragma unroll
+    for (int e = 0; e < 13; e++) acc[bb][e] = 0.f;
+  float gt0 = 0.f, gt1 = 0.f, gt2 = 0.f;
+  const float gx = a.global_trans[0], gy = a.global_trans[1], gz = a.global_trans[2];
+  for (int n0 = wave_first; n0 < wave_end; n0 += 8) {
+    const int n = n0 + slot;
+    const bool valid = n < wave_end;
+    float px = 0.f, py = 0.f, pz = 0.f, m = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) {
+      px = a.x[3 * n]; py = a.x[3 * n + 1]; pz = a.x[3 * n + 2];
+      m = a.motion_mask ? a.motion_mask[n] : 1.0f;
+      g0 = a.g_xyz[3 * n]; g1 = a.g_xyz[3 * n + 1]; g2 = a.g_xyz[3 * n + 2];
+      h = reinterpret_cast<const float4*>(a.g_rot)[n];
+    }
+    const float gh0 = g0 * m, gh1 = g1 * m, gh2 = g2 * m;
+    const float hh0 = h.x * m, hh1 = h.y * m, hh2 = h.z * m, hh3 = h.w * m;
+    // pass 1: this lane's bones
+    float v[NBLK], u[NBLK], d2[NBLK], dw[NBLK], du[NBLK];
+    float sum = 0.f, sv = 0.f, su = 0.f;
+#pragma unroll
+    for (int bb = 0; bb < NBLK; bb++) {
+      const int k = bb * LB_BONES + bl;
+      const Bone& b = bones[k];
+      d2[bb] = bone_d2(b, px, py, pz);
+      const bool on = valid && (k < B);
+      u[bb] = on ? fast_exp(-d2[bb] * b.inv2r2) : 0.f;
+      v[bb] = on ? u[bb] + 1e-7f : 0.f;
+      const float Ax = b.G[0] * px + b.G[1] * py + b.G[2] * pz + b.G[3];
+      const float Ay = b.G[4] * px + b.G[5] * py + b.G[6] * pz + b.G[7];
+      const float Az = b.G[8] * px + b.G[9] * py + b.G[10] * pz + b.G[11];
+      dw[bb] = gh0 * Ax + gh1 * Ay + gh2 * Az + hh0 * b.q[0] + hh1 * b.q[1] + hh2 * b.q[2] + hh3 * b.q[3];
+      du[bb] = g0 * Ax + g1 * Ay + g2 * Az + h.x * b.q[0] + h.y * b.q[1] + h.z * b.q[2] + h.w * b.q[3];  // un-masked (dmask)
+      sum += v[bb];
+      sv += v[bb] * dw[bb];
+      su += v[bb] * du[bb];
+    }
+    sum = row8_sum(sum);
+    sv = row8_sum(sv);
+    const float inv = valid ? 1.0f / sum : 0.f;
+    const float S = sv * inv;
+    if (a.dmask) {
+      su = row8_sum(su);
+      if (valid && bl == 0) a.dmask[n] = su * inv + g0 * (gx - px) + g1 * (gy - py) + g2 * (gz - pz);
+    }
+    // pass 2: accumulate this lane's bones
+    const float P[12] = {gh0 * px, gh0 * py, gh0 * pz, gh0, gh1 * px, gh1 * py, gh1 * pz, gh1,
+                         gh2 * px, gh2 * py, gh2 * pz, gh2};
+#pragma unroll
+    for (int bb = 0; bb < NBLK; bb++) {
+      const float w = v[bb] * inv;
+      const float dLdv = (dw[bb] - S) * inv;
+      const float r = dLdv * u[bb] * d2[bb] * (2.0f * bones[bb * LB_BONES + bl].inv2r2);
+#pragma unroll
+      for (int e = 0; e < 12; e++) acc[bb][e] += w * P[e];
+      acc[bb][12] += r;
+    }
+    if (bl == 0) { gt0 += gh0; gt1 += gh1; gt2 += gh2; }
+  }
+  // fold the 8 slot rows (lanes l, l^8, l^16, l^32) and push to the workgroup accumulators
+#pragma unroll
+  for (int bb = 0; bb < NBLK; bb++)
+#pragma unroll
+    for (int e = 0; e < 13; e++) {
+      float t = acc[bb][e];
+      t += __shfl_xor(t, 8); t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);
+      if (slot == 0) atomicAdd(&s_acc[bb * LB_BONES + bl][e], t);
+    }
+  gt0 = wave_sum(gt0); gt1 = wave_sum(gt1); gt2 = wave_sum(gt2);
+  if (lane == 63) { atomicAdd(&s_gt[0], gt0); atomicAdd(&s_gt[1], gt1); atomicAdd(&s_gt[2], gt2); }
+  __syncthreads();
+  // per-workgroup partial sums; lbs_backward_finish_kernel adds them up in a fixed order (deterministic)
+  float* part = a.partial + (size_t)blockIdx.x * (B * 13 + 3);
+  for (int e = threadIdx.x; e < B * 13; e += 256) part[e] = (&s_acc[0][0])[e];
+  if (threadIdx.x < 3) part[B * 13 + threadIdx.x] = s_gt[threadIdx.x];
+}
+
+// one workgroup per output value: sum over the workgroups' partials
+__global__ __launch_bounds__(256) void lbs_backward_finish_kernel(LbsArgs a, int n_parts) {
+  __shared__ float s_red[4];
+  const int B = a.J - 1, stride = B * 13 + 3, e = blockIdx.x;
+  float t = 0.f;
+  for (int p = threadIdx.x; p < n_parts; p += 256) t += a.partial[(size_t)p * stride + e];
+  t = wave_sum(t);
+  if ((threadIdx.x & 63) == 63) s_red[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float v = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    if (e < B * 13) {
+      const int k = e / 13, c = e % 13;
+      if (c < 12) a.dG[12 * (k + 1) + c] = v; else a.drho[k + 1] = v;
+    } else a.dgt[e - B * 13] = v;
+  }
+}
+
+template <int NBLK>
+static void launch_lbs_bwd_bonelane(const LbsArgs& a, hipStream_t s) {
+  const int blocks = (a.N + LB_GPB - 1) / LB_GPB;
+  hipLaunchKernelGGL(lbs_backward_bonelane_kernel<NBLK>, dim3(blocks), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(lbs_backward_finish_kernel, dim3((a.J - 1) * 13 + 3), dim3(256), 0, s, a, blocks);
+}
+
 }  // namespace riggs
 
 using namespace riggs;
@@ -463,16 +609,23 @@ int riggs_lbs_forward(int32_t N, int32_t J, int32_t K, const float* x, const flo
   return 0;
 }
 
+size_t riggs_lbs_backward_workspace_bytes(int32_t N, int32_t J) {
+  const size_t blocks = (size_t)(N > 0 ? (N + LB_GPB - 1) / LB_GPB : 1);
+  return align_up(blocks * ((size_t)(J - 1) * 13 + 3) * sizeof(float));
+}
+
 int riggs_lbs_backward(int32_t N, int32_t J, int32_t K, const float* x, const float* joints, const int32_t* parents,
                        const float* node_radius_log, const float* transforms, const float* node_rot,
                        const float* global_trans, const float* motion_mask, const float* g_xyz, const float* g_rot,
                        float* dL_dtransforms, float* dL_dnode_radius_log, float* dL_dglobal_trans,
-                       float* dL_dmotion_mask, riggs_stream stream) {
+                       float* dL_dmotion_mask, void* workspace, riggs_stream stream) {
   LbsArgs a;
   int rc = fill_lbs(a, N, J, K, x, joints, parents, node_radius_log, transforms, node_rot, global_trans, motion_mask);
   if (rc) return rc;
   a.g_xyz = g_xyz; a.g_rot = g_rot; a.dG = dL_dtransforms; a.drho = dL_dnode_radius_log; a.dgt = dL_dglobal_trans;
   a.dmask = dL_dmotion_mask;
+  a.partial = (float*)workspace;
+  RIGGS_REQUIRE(workspace != nullptr, "riggs_lbs_backward needs its workspace");
   hipStream_t s = (hipStream_t)stream;
   RIGGS_HIP_CHECK(hipMemsetAsync(dL_dtransforms, 0, (size_t)J * 48, s));
   RIGGS_HIP_CHECK(hipMemsetAsync(dL_dnode_radius_log, 0, (size_t)J * 4, s));
@@ -480,7 +633,19 @@ int riggs_lbs_backward(int32_t N, int32_t J, int32_t K, const float* x, const fl
   if (N == 0) return 0;
   {
     ProfScope ps(PROF_LBS_BWD, s);
-    hipLaunchKernelGGL(lbs_backward_kernel, dim3((N + 255) / 256), dim3(256), 0, s, a);
+    static const bool v1 = getenv("RIGGS_LBS_BWD_V1") != nullptr;  // A/B switch: thread-per-Gaussian kernel
+    const int nblk = (J - 1 + LB_BONES - 1) / LB_BONES;
+    if (K > 0 || v1) hipLaunchKernelGGL(lbs_backward_kernel, dim3((N + 255) / 256), dim3(256), 0, s, a);
+    else switch (nblk) {
+      case 1: launch_lbs_bwd_bonelane<1>(a, s); break;
+      case 2: launch_lbs_bwd_bonelane<2>(a, s); break;
+      case 3: launch_lbs_bwd_bonelane<3>(a, s); break;
+      case 4: launch_lbs_bwd_bonelane<4>(a, s); break;
+      case 5: launch_lbs_bwd_bonelane<5>(a, s); break;
+      case 6: launch_lbs_bwd_bonelane<6>(a, s); break;
+      case 7: launch_lbs_bwd_bonelane<7>(a, s); break;
+      default: launch_lbs_bwd_bonelane<8>(a, s); break;
+    }
   }
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;

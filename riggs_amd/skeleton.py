@@ -185,10 +185,11 @@ class _DeformByPose(torch.autograd.Function):
         dmask = torch.empty(N, **f32) if need_mask else None
         lib = L.lib()
         st = L.stream_ptr()
+        ws = torch.empty(lib.riggs_lbs_backward_workspace_bytes(N, J), dtype=torch.uint8, device=x.device)
         L.check(lib.riggs_lbs_backward(N, J, ctx.K, x.data_ptr(), joints.data_ptr(), parents_i32.data_ptr(),
                                        rho.data_ptr(), transforms.data_ptr(), node_rot.data_ptr(),
                                        global_trans.data_ptr(), L.ptr(mflat), g_xyz.data_ptr(), g_rot.data_ptr(),
-                                       dG.data_ptr(), drho.data_ptr(), dgt.data_ptr(), L.ptr(dmask), st),
+                                       dG.data_ptr(), drho.data_ptr(), dgt.data_ptr(), L.ptr(dmask), ws.data_ptr(), st),
                 "riggs_lbs_backward")
         if g_transforms is not None:
             dG = dG + g_transforms
