@@ -17,6 +17,7 @@ SO = os.path.join(LIBDIR, "libriggs_hip.so")
 SOURCES = {
     "preprocess.hip": ["-ffp-contract=off"],
     "render.hip": ["-ffp-contract=fast"],
+    "binning.hip": ["-ffp-contract=fast"],
     "deform.hip": ["-ffp-contract=fast"],
     "knn.hip": ["-ffp-contract=fast"],
     "pose_mlp.hip": ["-ffp-contract=fast"],

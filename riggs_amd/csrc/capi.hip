@@ -1,6 +1,7 @@
 // extern "C" boundary of libriggs_hip.so (see include/riggs_hip.h) — rasterizer part.
 #include <stdarg.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -42,6 +43,12 @@ void prof_end(int id, hipStream_t s) {
   if (!(g_prof_mask >> id & 1u)) return;
   ProfSlot& p = g_prof[id];
   if (p.used < p.start.size()) { (void)hipEventRecord(p.stop[p.used], s); p.used++; }
+}
+
+// A/B switch: RIGGS_BINNING=rocprim restores emit + rocPRIM radix sort + ranges
+static bool use_rocprim_binning() {
+  static const bool v = getenv("RIGGS_BINNING") != nullptr && strcmp(getenv("RIGGS_BINNING"), "rocprim") == 0;
+  return v;
 }
 
 static size_t sort_temp_bytes_u32(size_t n) {
@@ -95,7 +102,6 @@ ImageLayout image_layout(int H, int W) {
 }
 
 BinLayout bin_layout(int64_t cap, int N, int H, int W) {
-  (void)N;
   BinLayout L;
   const size_t T = (size_t)((W + RIGGS_TILE - 1) / RIGGS_TILE) * ((H + RIGGS_TILE - 1) / RIGGS_TILE);
   size_t n = (size_t)(cap > 0 ? cap : 1), o = 0;
@@ -107,6 +113,7 @@ BinLayout bin_layout(int64_t cap, int N, int H, int W) {
   L.temp = o; o += L.temp_bytes;
   L.n_slots = (n >> 6) + T + 1;  // tile t, chunk c -> slot (range.x(t) >> 6) + t + c
   L.ckpt = o; o += align_up(L.n_slots * RIGGS_CKPT_FLOATS * 4);
+  L.table = o; o += align_up(bin_table_bytes(N, (int)T));
   L.total = o;
   return L;
 }
@@ -191,6 +198,8 @@ static int fill_pre_args(PreArgs& a, const riggs_raster_cfg* c, const float* mea
   a.cov3D = (float*)(geom + L.cov3D); a.clamped = (uint8_t*)(geom + L.clamped); a.tiles = (uint32_t*)(geom + L.tiles);
   a.rect = (ushort4*)(geom + L.rect); a.depth_key = (uint32_t*)(geom + L.depth_key);
   a.order_in = (uint32_t*)(geom + L.order_in);
+  a.total_tiles = nullptr;
+  a.block_tiles = (uint32_t*)(geom + L.tt_sorted);
   return 0;
 }
 
@@ -209,6 +218,7 @@ int riggs_raster_preprocess(const riggs_raster_cfg* cfg, const float* means3D, c
   RIGGS_HIP_CHECK(hipMemsetAsync(counters, 0, 16, s));
   if (N == 0) return 0;
   GeomLayout L = geom_layout(N);
+  a.total_tiles = counters;
   { ProfScope ps(PROF_PREPROCESS_FWD, s); launch_preprocess_fwd(a, s); }
   if (debug_sync(cfg->debug, s, "preprocess_fwd")) return 1;
   // depth sort of the Gaussians (stable: equal depths keep ascending index)
@@ -219,15 +229,14 @@ int riggs_raster_preprocess(const riggs_raster_cfg* cfg, const float* means3D, c
                                               (uint32_t*)(geom + L.depth_key_sorted), (uint32_t*)(geom + L.order_in),
                                               (uint32_t*)(geom + L.order), (size_t)N, 0, 32, s));
   }
-  {
+  if (use_rocprim_binning()) {
     ProfScope ps(PROF_SCAN, s);
     launch_gather_tiles(N, (uint32_t*)(geom + L.order), (uint32_t*)(geom + L.tiles), (uint32_t*)(geom + L.tt_sorted), s);
     tb = L.temp_bytes;
     RIGGS_HIP_CHECK(rocprim::inclusive_scan(geom + L.temp, tb, (uint32_t*)(geom + L.tt_sorted),
                                             (uint32_t*)(geom + L.offsets), (size_t)N, rocprim::plus<uint32_t>(), s));
   }
-  // publish R for the host (counters[0]); emit_kernel rewrites it together with the overflow flag
-  RIGGS_HIP_CHECK(hipMemcpyAsync(counters, geom + L.offsets + (size_t)(N - 1) * 4, 4, hipMemcpyDeviceToDevice, s));
+  // R for the host is counters[0] (accumulated by preprocess_fwd; stage 2 rewrites it with the overflow flag)
   if (debug_sync(cfg->debug, s, "depth sort / scan")) return 1;
   return 0;
 }
@@ -248,7 +257,17 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
   BinLayout B = bin_layout(cap, N, H, W);
   RIGGS_HIP_CHECK(hipMemsetAsync(img + I.ranges, 0, (size_t)(T + 1) * 8, s));
   const uint32_t* point_list = (const uint32_t*)(bin + B.vals_b);
-  if (N > 0 && cap > 0) {
+  if (N > 0 && cap > 0 && !use_rocprim_binning()) {
+    // stable counting sort by tile (csrc/binning.hip)
+    ProfScope ps(PROF_TILE_SORT, s);
+    point_list = (const uint32_t*)(bin + B.vals_b);
+    int rcb = launch_binning(N, T, gx, cap, (const uint32_t*)(geom + G.order), (const uint32_t*)(geom + G.tiles),
+                             (const ushort4*)(geom + G.rect), bin + B.table, (uint32_t*)(bin + B.vals_b),
+                             (uint32_t*)(bin + B.keys_b), (uint2*)(img + I.ranges), (uint32_t*)(img + I.slot_base),
+                             counters, s);
+    if (rcb) return rcb;
+    if (debug_sync(cfg->debug, s, "binning (counting sort)")) return 1;
+  } else if (N > 0 && cap > 0) {
     {
       ProfScope ps(PROF_EMIT, s);
       launch_emit(N, gx, T, cap, (const uint32_t*)(geom + G.order), (const uint32_t*)(geom + G.offsets),

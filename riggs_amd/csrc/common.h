@@ -72,7 +72,7 @@ struct ImageLayout {
 ImageLayout image_layout(int H, int W);
 
 struct BinLayout {
-  size_t keys_a, keys_b, vals_a, vals_b, temp, temp_bytes, ckpt, n_slots, total;
+  size_t keys_a, keys_b, vals_a, vals_b, temp, temp_bytes, ckpt, n_slots, table, total;
 };
 #define RIGGS_CKPT_FLOATS (5 * 256)  // floats per checkpoint slot
 BinLayout bin_layout(int64_t cap, int N, int H, int W);

@@ -118,7 +118,9 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a) {
     sh_stage_in(src, sh_per, count, s_sh);
     __syncthreads();
   }
-  if (i >= a.N) return;
+  uint32_t my_tiles = 0u;
+  do {
+  if (i >= a.N) break;
   const float* __restrict__ V = a.view;
   const float* __restrict__ P = a.proj;
   a.radii[i] = 0;
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a) {
   load_inputs(a, i, g, need_sr);
   const float* p = g.p;
   float vz = V[2] * p[0] + V[6] * p[1] + V[10] * p[2] + V[14];
-  if (vz <= RIGGS_NEAR_Z) return;
+  if (vz <= RIGGS_NEAR_Z) break;
   float hx = P[0] * p[0] + P[4] * p[1] + P[8] * p[2] + P[12];
   float hy = P[1] * p[0] + P[5] * p[1] + P[9] * p[2] + P[13];
   float hw = P[3] * p[0] + P[7] * p[1] + P[11] * p[2] + P[15];
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a) {
   Cov2D cv;
   cov2d_eval(p, c6, V, fx, fy, a.tanx, a.tany, cv);
   float det = cv.a * cv.c - cv.b * cv.b;
-  if (det == 0.0f) return;
+  if (det == 0.0f) break;
   float det_inv = 1.0f / det;
   float mid = 0.5f * (cv.a + cv.c);
   float root = sqrtf(fmaxf(0.1f, mid * mid - det));
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a) {
   int x1 = (int)((px + ir + RIGGS_TILE - 1) / (float)RIGGS_TILE), y1 = (int)((py + ir + RIGGS_TILE - 1) / (float)RIGGS_TILE);
   x0 = min(gx, max(0, x0)); x1 = min(gx, max(0, x1));
   y0 = min(gy, max(0, y0)); y1 = min(gy, max(0, y1));
-  if ((x1 - x0) * (y1 - y0) == 0) return;
+  if ((x1 - x0) * (y1 - y0) == 0) break;
 
   float rgbv[3];
   uint8_t cl = 0;
@@ -198,6 +200,30 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a) {
   a.tiles[i] = (uint32_t)((x1 - x0) * (y1 - y0));
   a.rect[i] = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
   a.depth_key[i] = __float_as_uint(vz);
+  my_tiles = (uint32_t)((x1 - x0) * (y1 - y0));
+  } while (0);
+  // instance count R = sum of tiles_touched: wave reduction -> per-workgroup partial (summed by a tiny
+  // second kernel; thousands of same-address atomics would serialise in L2)
+  __shared__ uint32_t s_tiles[4];
+  for (int o = 32; o > 0; o >>= 1) my_tiles += (uint32_t)__shfl_xor((int)my_tiles, o);
+  if ((threadIdx.x & 63) == 0) s_tiles[threadIdx.x >> 6] = my_tiles;
+  __syncthreads();
+  if (threadIdx.x == 0) a.block_tiles[blockIdx.x] = s_tiles[0] + s_tiles[1] + s_tiles[2] + s_tiles[3];
+}
+
+__global__ __launch_bounds__(1024) void sum_block_tiles_kernel(int n, const uint32_t* __restrict__ part,
+                                                               uint32_t* __restrict__ total) {
+  __shared__ uint32_t s_w[16];
+  uint32_t v = 0;
+  for (int i = threadIdx.x; i < n; i += 1024) v += part[i];
+  for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (int w = 0; w < 16; w++) t += s_w[w];
+    total[0] = t;
+  }
 }
 
 // ---------------------------------------------------------------------------- backward
@@ -412,6 +438,7 @@ int launch_preprocess_fwd(const PreArgs& a, hipStream_t s) {
   const int per = a.shs_rest ? (a.M - 1) * 3 : a.M * 3;
   const size_t lds = a.colors_precomp ? 0 : (size_t)256 * (per | 1) * sizeof(float);
   hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((a.N + 255) / 256), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(sum_block_tiles_kernel, dim3(1), dim3(1024), 0, s, (a.N + 255) / 256, a.block_tiles, a.total_tiles);
   return 0;
 }
 int launch_preprocess_bwd(const PreBwdArgs& b, hipStream_t s) {

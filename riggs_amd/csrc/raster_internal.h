@@ -16,6 +16,8 @@ struct PreArgs {
   uint32_t* tiles;
   ushort4* rect;
   uint32_t *depth_key, *order_in;
+  uint32_t* total_tiles;  // counters[0] = R (sum of tiles_touched)
+  uint32_t* block_tiles;  // per-workgroup partial sums of tiles_touched
 };
 
 struct PreBwdArgs {
@@ -68,6 +70,10 @@ struct RenderBwdArgs {
 int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s);
 
 // binning
+size_t bin_table_bytes(int N, int T);
+int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order, const uint32_t* tiles,
+                   const ushort4* rect, void* table_mem, uint32_t* point_list, uint32_t* tile_keys, uint2* ranges,
+                   uint32_t* slot_base, uint32_t* counters, hipStream_t s);
 int launch_gather_tiles(int N, const uint32_t* order, const uint32_t* tiles, uint32_t* tt_sorted, hipStream_t s);
 int launch_emit(int N, int grid_x, int n_tiles, int64_t cap, const uint32_t* order, const uint32_t* offsets,
                 const uint32_t* tiles, const ushort4* rect, uint32_t* keys, uint32_t* vals, uint32_t* counters,
