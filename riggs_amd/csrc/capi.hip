@@ -93,8 +93,8 @@ ImageLayout image_layout(int H, int W) {
   size_t T = (size_t)((W + RIGGS_TILE - 1) / RIGGS_TILE) * ((H + RIGGS_TILE - 1) / RIGGS_TILE);
   L.final_T = o; o = align_up(o + hw * 4);
   L.n_contrib = o; o = align_up(o + hw * 4);
-  L.ranges = o; o = align_up(o + (T + 1) * 8);
   L.final_acc = o; o = align_up(o + hw * 16);
+  L.ranges = o; o = align_up(o + (T + 1) * 8);   // ranges and tile_max are adjacent: one memset clears both
   L.tile_max = o; o = align_up(o + (T + 1) * 4);
   L.slot_base = o; o = align_up(o + (T + 2) * 4);
   L.total = o;
@@ -215,10 +215,12 @@ int riggs_raster_preprocess(const riggs_raster_cfg* cfg, const float* means3D, c
                          d_rotation, d_scaling, geom, radii);
   if (rc) return rc;
   const int N = cfg->num_points;
+  // (kept although sum_block_tiles_kernel rewrites all four words: without this memset node a captured
+  // hipGraph of the frame faults on replay — ROCm 7.2, reproducible, root cause not understood)
   RIGGS_HIP_CHECK(hipMemsetAsync(counters, 0, 16, s));
   if (N == 0) return 0;
   GeomLayout L = geom_layout(N);
-  a.total_tiles = counters;
+  a.total_tiles = counters;  // sum_block_tiles_kernel writes counters[0] and clears counters[1..3]
   { ProfScope ps(PROF_PREPROCESS_FWD, s); launch_preprocess_fwd(a, s); }
   if (debug_sync(cfg->debug, s, "preprocess_fwd")) return 1;
   // depth sort of the Gaussians (stable: equal depths keep ascending index)
@@ -255,7 +257,7 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
   GeomLayout G = geom_layout(N);
   ImageLayout I = image_layout(H, W);
   BinLayout B = bin_layout(cap, N, H, W);
-  RIGGS_HIP_CHECK(hipMemsetAsync(img + I.ranges, 0, (size_t)(T + 1) * 8, s));
+  RIGGS_HIP_CHECK(hipMemsetAsync(img + I.ranges, 0, (I.tile_max - I.ranges) + (size_t)(T + 1) * 4, s));  // ranges + tile_max
   const uint32_t* point_list = (const uint32_t*)(bin + B.vals_b);
   if (N > 0 && cap > 0 && !use_rocprim_binning()) {
     // stable counting sort by tile (csrc/binning.hip)

@@ -539,6 +539,9 @@ __global__ __launch_bounds__(256) void lbs_backward_finish_kernel(LbsArgs a, int
       if (c < 12) a.dG[12 * (k + 1) + c] = v; else a.drho[k + 1] = v;
     } else a.dgt[e - B * 13] = v;
   }
+  // joint 0 carries no bone: its transform / radius receive no gradient from the skinning
+  if (e == 0 && threadIdx.x < 12) a.dG[threadIdx.x] = 0.f;
+  if (e == 0 && threadIdx.x == 12) a.drho[0] = 0.f;
 }
 
 template <int NBLK>
@@ -627,9 +630,12 @@ int riggs_lbs_backward(int32_t N, int32_t J, int32_t K, const float* x, const fl
   a.partial = (float*)workspace;
   RIGGS_REQUIRE(workspace != nullptr, "riggs_lbs_backward needs its workspace");
   hipStream_t s = (hipStream_t)stream;
-  RIGGS_HIP_CHECK(hipMemsetAsync(dL_dtransforms, 0, (size_t)J * 48, s));
-  RIGGS_HIP_CHECK(hipMemsetAsync(dL_dnode_radius_log, 0, (size_t)J * 4, s));
-  RIGGS_HIP_CHECK(hipMemsetAsync(dL_dglobal_trans, 0, 12, s));
+  static const bool lbs_v1 = getenv("RIGGS_LBS_BWD_V1") != nullptr;
+  if (N == 0 || K > 0 || lbs_v1) {  // the atomic (thread-per-Gaussian) path accumulates into zeroed outputs
+    RIGGS_HIP_CHECK(hipMemsetAsync(dL_dtransforms, 0, (size_t)J * 48, s));
+    RIGGS_HIP_CHECK(hipMemsetAsync(dL_dnode_radius_log, 0, (size_t)J * 4, s));
+    RIGGS_HIP_CHECK(hipMemsetAsync(dL_dglobal_trans, 0, 12, s));
+  }
   if (N == 0) return 0;
   {
     ProfScope ps(PROF_LBS_BWD, s);

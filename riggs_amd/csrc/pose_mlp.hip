@@ -98,45 +98,42 @@ __global__ __launch_bounds__(256) void pm_layer_kernel(PoseMlpDesc d, int l, flo
 // Each block owns 64 columns; its 4 waves split the rows (coalesced 256-B row segments), LDS combines.
 // For hidden layers v = dz_l = dh_l * relu'(h_l) is computed by every block (block 0 stores it for the
 // weight-gradient kernel).  dh buffers: dh[l] holds the gradient w.r.t. the INPUT of consumer l.
+#define PM_RG 8  // row groups of the transposed GEMV (grid.y)
 __global__ __launch_bounds__(256) void pm_backward_step_kernel(PoseMlpDesc d, int l, const float* __restrict__ acts,
                                                                const float* __restrict__ g_rot,
                                                                const float* __restrict__ g_tr,
                                                                const float* __restrict__ dh_out /* input-grad of consumer l+1 */,
-                                                               float* __restrict__ dh_in, float* __restrict__ dzs) {
-  __shared__ float s_v[PM_MAX_W];
+                                                               float* __restrict__ dh_in /* zeroed */, float* __restrict__ dzs) {
   __shared__ float s_part[4][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int emb = 1 + 2 * d.multires;
   const bool heads = (l == d.depth);
   const int n_rows = heads ? d.n_rot + 3 : d.width;
   const int in_dim = pm_in_dim(d, l, emb);
-  if (heads) {
-    for (int r = tid; r < n_rows; r += 256) s_v[r] = (r < d.n_rot) ? g_rot[r] : g_tr[r - d.n_rot];
-  } else {
-    // dh of h_l lives in the consumer (l+1)'s input gradient, behind the embedding when that input was [emb, h]
-    const int off = (l == d.skip) ? emb : 0;
-    for (int r = tid; r < n_rows; r += 256) {
-      const float h = acts[emb + (size_t)l * d.width + r];
-      const float dz = (h > 0.f) ? dh_out[off + r] : 0.f;
-      s_v[r] = dz;
-      if (blockIdx.x == 0) dzs[(size_t)l * d.width + r] = dz;
-    }
-  }
-  __syncthreads();
-  if (l == 0) return;  // the embedding has no trainable input
+  // dh of h_l lives in the consumer (l+1)'s input gradient, behind the embedding when that input was [emb, h]
+  const int off = (l == d.skip) ? emb : 0;
   const int c = blockIdx.x * 64 + lane;
+  const int rstep = 4 * PM_RG, r0 = blockIdx.y * 4 + wave;
   float acc = 0.f;
-  if (c < in_dim) {
-#pragma unroll 8
-    for (int r = wave; r < n_rows; r += 4) {
-      const float* row = heads ? ((r < d.n_rot) ? d.W_rot + (size_t)r * in_dim : d.W_tr + (size_t)(r - d.n_rot) * in_dim)
-                               : d.W[l] + (size_t)r * in_dim;
-      acc += row[c] * s_v[r];
+#pragma unroll 4
+  for (int r = r0; r < n_rows; r += rstep) {
+    float v;
+    const float* row;
+    if (heads) {
+      v = (r < d.n_rot) ? g_rot[r] : g_tr[r - d.n_rot];
+      row = (r < d.n_rot) ? d.W_rot + (size_t)r * in_dim : d.W_tr + (size_t)(r - d.n_rot) * in_dim;
+    } else {
+      const float h = acts[emb + (size_t)l * d.width + r];
+      v = (h > 0.f) ? dh_out[off + r] : 0.f;  // dz_l
+      row = d.W[l] + (size_t)r * in_dim;
+      if (blockIdx.x == 0 && lane == 0) dzs[(size_t)l * d.width + r] = v;
     }
+    if (l > 0 && c < in_dim) acc += row[c] * v;
   }
+  if (l == 0) return;  // the embedding has no trainable input
   s_part[wave][lane] = acc;
   __syncthreads();
-  if (wave == 0 && c < in_dim) dh_in[c] = s_part[0][lane] + s_part[1][lane] + s_part[2][lane] + s_part[3][lane];
+  if (wave == 0 && c < in_dim) atomicAdd(&dh_in[c], s_part[0][lane] + s_part[1][lane] + s_part[2][lane] + s_part[3][lane]);
 }
 
 // Weight / bias gradients: one block per (parameter matrix, row): dW[r][:] = v[r] * input[:], db[r] = v[r].
@@ -240,10 +237,11 @@ int riggs_pose_mlp_backward(int32_t depth, int32_t width, int32_t multires, int3
   g.row_start[depth + 1] = rows; rows += 3;
   g.row_start[depth + 2] = rows;
   ProfScope ps(PROF_POSE_BWD, s);
+  RIGGS_HIP_CHECK(hipMemsetAsync(dh, 0, (size_t)(depth + 1) * PM_MAX_IN * sizeof(float), s));
   for (int l = depth; l >= 0; l--) {
     const int in_l = (l == 0) ? emb : ((l - 1 == skip) ? width + emb : width);
     const float* dh_out = (l == depth) ? nullptr : dh + (size_t)(l + 1) * PM_MAX_IN;
-    hipLaunchKernelGGL(pm_backward_step_kernel, dim3(l == 0 ? 1 : (in_l + 63) / 64), dim3(256), 0, s, d, l, acts,
+    hipLaunchKernelGGL(pm_backward_step_kernel, dim3(l == 0 ? 1 : (in_l + 63) / 64, PM_RG), dim3(256), 0, s, d, l, acts,
                        g_rotation, g_translation, dh_out, dh + (size_t)l * PM_MAX_IN, dzs);
   }
   hipLaunchKernelGGL(pm_backward_weights_kernel, dim3(rows), dim3(64), 0, s, d, g, acts, dzs, g_rotation,

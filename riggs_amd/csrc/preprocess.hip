@@ -222,7 +222,7 @@ __global__ __launch_bounds__(1024) void sum_block_tiles_kernel(int n, const uint
   if (threadIdx.x == 0) {
     uint32_t t = 0;
     for (int w = 0; w < 16; w++) t += s_w[w];
-    total[0] = t;
+    total[0] = t; total[1] = 0u; total[2] = 0u; total[3] = 0u;
   }
 }
 

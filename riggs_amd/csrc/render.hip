@@ -447,7 +447,7 @@ int launch_render_fwd(const RenderArgs& a, hipStream_t s) {
   if (variant == 1) hipLaunchKernelGGL(render_fwd_sgpr_kernel, dim3(gx * gy), dim3(256), 0, s, a);
   else if (variant == 2) hipLaunchKernelGGL(render_fwd_kernel, dim3(gx * gy), dim3(256), 0, s, a);
   else {
-    if (hipMemsetAsync(a.tile_max, 0, (size_t)gx * gy * sizeof(uint32_t), s) != hipSuccess) return 1;
+    // tile_max was cleared together with ranges by riggs_raster_render
     hipLaunchKernelGGL(render_fwd_quad_kernel, dim3(gx * gy * 4), dim3(256), 0, s, a);
   }
   return 0;

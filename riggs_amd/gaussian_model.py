@@ -39,7 +39,10 @@ class GaussianModel:
     def motion_mask(self):  # gaussian_model.py:97-102
         if self.with_motion_mask:
             return torch.sigmoid(self.feature[..., -1:])
-        return torch.ones_like(self._xyz[..., :1])
+        m = getattr(self, "_ones_mask", None)
+        if m is None or m.shape[0] != self._xyz.shape[0] or m.device != self._xyz.device:
+            m = self._ones_mask = torch.ones_like(self._xyz[..., :1])  # constant when with_motion_mask is off
+        return m
 
     @property
     def get_scaling(self):  # :104-110

@@ -208,6 +208,7 @@ def rasterize_backward(s: _Saved, means3D, shs, colors_precomp, opacities, scale
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings):
+        ctx.set_materialize_grads(False)
         color, radii, depth, alpha, s = rasterize_forward(settings, means3D, sh, colors_precomp, opacities, scales,
                                                           rotations, cov3Ds_precomp)
         ctx.s = s

@@ -34,6 +34,7 @@ class _FusedGlueRaster(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, means2D, f_dc, f_rest, opacity, scaling, rotation, d_xyz, d_rot, d_scaling, settings,
                 isotropic, arena):
+        ctx.set_materialize_grads(False)
         N = xyz.shape[0]
         f_dc = L.require_cuda_f32("_features_dc", f_dc, (N, 1, 3))      # read in place: no torch.cat, the kernel
         f_rest = L.require_cuda_f32("_features_rest", f_rest, (N, None, 3))  # stages both arrays through LDS
@@ -97,6 +98,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, d_xyz, d_rotation, d_scaling, d
                       and d_rotation_bias is None and (d_color is None or type(d_color) is float)
                       and not (detach_xyz or detach_scale or detach_rot or detach_opacity))
     if fused and default_branch:
+        screenspace_points = torch.zeros_like(xyz, requires_grad=True)  # leaf: .grad is populated by autograd
         dx = None if _is_zero_scalar(d_xyz) else d_xyz
         dr = None if _is_zero_scalar(d_rotation) else d_rotation
         ds = None if _is_zero_scalar(d_scaling) else d_scaling

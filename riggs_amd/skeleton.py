@@ -83,6 +83,7 @@ class _PoseMLPFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, t, depth, width, multires, skip, *params):
+        ctx.set_materialize_grads(False)
         params = [p.contiguous() for p in params]
         lib = L.lib()
         dev = t.device
@@ -159,6 +160,7 @@ class _DeformByPose(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, local_rot, global_trans, rho, mask, x, joints, parents_i32, K):
+        ctx.set_materialize_grads(False)
         local_rot = L.require_cuda_f32("local_rotation", local_rot, (joints.shape[0], 4))
         global_trans = L.require_cuda_f32("global_trans", global_trans.reshape(-1), (3,))
         rho = L.require_cuda_f32("_node_radius", rho, (joints.shape[0],))
@@ -322,8 +324,11 @@ class SkeletonWarp(nn.Module):
             _, _, w, idx = lbs_forward(x, joints, par, rho.contiguous(), transforms.detach(), node_rot, gt, mflat,
                                        self.K, want_weights=True)
             return w, idx
+        zs = getattr(self, "_zero_scaling", None)
+        if zs is None or zs.shape[0] != x.shape[0] or zs.device != x.device:
+            zs = self._zero_scaling = torch.zeros(x.shape[0], 3, device=x.device)  # constant (skeleton_warp.py:165)
         return _LazyDeformDict(
-            {"d_xyz": d_xyz, "d_rotation": d_rot, "d_scaling": torch.zeros(x.shape[0], 3, device=x.device),
+            {"d_xyz": d_xyz, "d_rotation": d_rot, "d_scaling": zs,
              "d_nodes": d_nodes, "nn_idx": None, "nn_weight": None, "local_rotation": node_attrs["local_rotation"],
              "global_trans": global_trans, "d_opacity": None, "d_color": None}, producer=producer)
 
