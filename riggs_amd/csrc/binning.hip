@@ -19,7 +19,9 @@ namespace riggs {
 
 __device__ __forceinline__ int rect_tile(const ushort4 rc, int l, int grid_x) {
   const int w = rc.z - rc.x;
-  const int ry = l / w, rx = l - ry * w;
+  // l / w for small non-negative ints without the integer-division sequence (exact: |error| << 0.5/w)
+  const int ry = (int)(((float)l + 0.5f) * __builtin_amdgcn_rcpf((float)w));
+  const int rx = l - ry * w;
   return (rc.y + ry) * grid_x + rc.x + rx;
 }
 
@@ -46,22 +48,28 @@ __global__ __launch_bounds__(512) void bin_count_kernel(int N, int T, int grid_x
   for (int t = threadIdx.x; t < T; t += blockDim.x) row[t] = s_hist[t];
 }
 
-// per tile: exclusive scan over the chunks, in place; tile_count[t] = total
-__global__ __launch_bounds__(256) void bin_scan_kernel(int T, int n_chunks, uint32_t* __restrict__ table,
-                                                       uint32_t* __restrict__ tile_count) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= T) return;
+// per tile: exclusive scan over the chunks, in place; tile_count[t] = total.
+// Workgroup = 64 tiles x 16 chunk segments: every thread sums its segment (loads independent and
+// coalesced across the 64 tiles), LDS prefix over the 16 segments, then the exclusive prefixes are
+// written back — no serial walk over hundreds of chunks.
+#define SCAN_SEG 16
+__global__ __launch_bounds__(1024) void bin_scan_kernel(int T, int n_chunks, uint32_t* __restrict__ table,
+                                                        uint32_t* __restrict__ tile_count) {
+  __shared__ uint32_t s_seg[SCAN_SEG][64];
+  const int tl = threadIdx.x & 63, seg = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + tl;
+  const int per = (n_chunks + SCAN_SEG - 1) / SCAN_SEG;
+  const int b0 = seg * per, b1 = min(n_chunks, b0 + per);
+  uint32_t sum = 0;
+  if (t < T) for (int b = b0; b < b1; b++) sum += table[(size_t)b * T + t];
+  s_seg[seg][tl] = sum;
+  __syncthreads();
   uint32_t run = 0;
-  int b = 0;
-  for (; b + 8 <= n_chunks; b += 8) {
-    uint32_t c[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) c[k] = table[(size_t)(b + k) * T + t];
-#pragma unroll
-    for (int k = 0; k < 8; k++) { table[(size_t)(b + k) * T + t] = run; run += c[k]; }
+  for (int s2 = 0; s2 < seg; s2++) run += s_seg[s2][tl];
+  if (t < T) {
+    for (int b = b0; b < b1; b++) { const uint32_t c = table[(size_t)b * T + t]; table[(size_t)b * T + t] = run; run += c; }
+    if (seg == SCAN_SEG - 1) tile_count[t] = run;
   }
-  for (; b < n_chunks; b++) { const uint32_t c = table[(size_t)b * T + t]; table[(size_t)b * T + t] = run; run += c; }
-  tile_count[t] = run;
 }
 
 // exclusive scan over the tiles (one workgroup): ranges, checkpoint slot bases, R and the overflow flag
@@ -229,7 +237,7 @@ int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order,
   }
   hipLaunchKernelGGL(bin_count_kernel, dim3(p.n_chunks), dim3(p.threads), (size_t)T * 4, s, N, T, grid_x, p.g_per_block,
                      order, tiles, rect, table);
-  hipLaunchKernelGGL(bin_scan_kernel, dim3((T + 255) / 256), dim3(256), 0, s, T, p.n_chunks, table, tile_count);
+  hipLaunchKernelGGL(bin_scan_kernel, dim3((T + 63) / 64), dim3(1024), 0, s, T, p.n_chunks, table, tile_count);
   hipLaunchKernelGGL(bin_offsets_kernel, dim3(1), dim3(1024), 0, s, T, cap, tile_count, tile_start, ranges, slot_base,
                      counters);
   hipLaunchKernelGGL(bin_scatter_kernel, dim3(p.n_chunks), dim3(p.threads), p.lds_scatter, s, N, T, grid_x, cap,
