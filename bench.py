@@ -234,7 +234,8 @@ def main():
             "preprocess_bwd": N * (276 + 24 + 1 + 4 + 48) + N * (12 + 12 + 192 + 4 + 12 + 16),
             "lbs_fwd": N * (12 + 4 + 12 + 16),
             "lbs_bwd": N * (12 + 4 + 12 + 16),
-            "tile_sort": R * 16 * 2,
+            # counting-sort binning: 3 passes over (order, tiles, rect) + the chunk table twice + the instance list
+            "tile_sort": 2 * N * 16 + R * 8 + 2 * ((N + 1023) // 1024) * (((w["W"] + 15) // 16) * ((w["H"] + 15) // 16)) * 4,
             "depth_sort": N * 16 * 4,
         }
         dom = max((k for k in table if k in alg_bytes), key=lambda k: table[k])

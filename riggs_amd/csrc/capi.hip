@@ -97,6 +97,7 @@ ImageLayout image_layout(int H, int W) {
   L.ranges = o; o = align_up(o + (T + 1) * 8);   // ranges and tile_max are adjacent: one memset clears both
   L.tile_max = o; o = align_up(o + (T + 1) * 4);
   L.slot_base = o; o = align_up(o + (T + 2) * 4);
+  L.work_ctr = o; o = align_up(o + 16);  // backward work queue: {n_items, next}
   L.total = o;
   return L;
 }
@@ -114,6 +115,7 @@ BinLayout bin_layout(int64_t cap, int N, int H, int W) {
   L.n_slots = (n >> 6) + T + 1;  // tile t, chunk c -> slot (range.x(t) >> 6) + t + c
   L.ckpt = o; o += align_up(L.n_slots * RIGGS_CKPT_FLOATS * 4);
   L.table = o; o += align_up(bin_table_bytes(N, (int)T));
+  L.work = o; o += align_up(L.n_slots * 4);  // backward work list: (tile << 16 | chunk) per active chunk
   L.total = o;
   return L;
 }
@@ -352,6 +354,7 @@ int riggs_raster_backward(const riggs_raster_cfg* cfg, const float* means3D, con
   r.slot_base = (const uint32_t*)(img + I.slot_base); r.ckpt = (const float*)(bin + B.ckpt);
   r.n_tiles = ((W + RIGGS_TILE - 1) / RIGGS_TILE) * ((H + RIGGS_TILE - 1) / RIGGS_TILE);
   r.n_slots = (int64_t)B.n_slots;
+  r.work = (uint32_t*)(bin + B.work); r.work_ctr = (uint32_t*)(img + I.work_ctr);
   if (cap > 0) { ProfScope ps(PROF_RENDER_BWD, s); launch_render_bwd(r, s); }
   if (debug_sync(cfg->debug, s, "render_bwd")) return 1;
   b.g_mean2D_conic = (const float*)workspace;

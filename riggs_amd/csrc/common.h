@@ -67,12 +67,12 @@ struct GeomLayout {
 GeomLayout geom_layout(int N);
 
 struct ImageLayout {
-  size_t final_T, n_contrib, ranges, final_acc, tile_max, slot_base, total;
+  size_t final_T, n_contrib, ranges, final_acc, tile_max, slot_base, work_ctr, total;
 };
 ImageLayout image_layout(int H, int W);
 
 struct BinLayout {
-  size_t keys_a, keys_b, vals_a, vals_b, temp, temp_bytes, ckpt, n_slots, table, total;
+  size_t keys_a, keys_b, vals_a, vals_b, temp, temp_bytes, ckpt, n_slots, table, work, total;
 };
 #define RIGGS_CKPT_FLOATS (5 * 256)  // floats per checkpoint slot
 BinLayout bin_layout(int64_t cap, int N, int H, int W);

@@ -66,6 +66,8 @@ struct RenderBwdArgs {
   const float* ckpt;
   int n_tiles;
   int64_t n_slots;
+  uint32_t* work;      // [n_slots] active chunks, built on device from tile_max
+  uint32_t* work_ctr;  // {number of quarter-items, next item}
 };
 int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s);
 

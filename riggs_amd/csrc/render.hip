@@ -598,112 +598,161 @@ __device__ __forceinline__ float wave_excl_sum_scan(float v) {
 // contention (one atomic per value per (tile, instance) at the end).  Chunks are independent,
 // so a tile with thousands of contributing instances spreads over the whole chip instead of
 // serialising on four waves.
-__global__ __launch_bounds__(256) void render_bwd_kernel(RenderBwdArgs a) {
-  __shared__ float4 s_pa[4][256];  // (T_start, Pre_start, Qb, n_contrib as float bits)
-  __shared__ float4 s_pb[4][256];  // (gC0, gC1, gC2, gD)
-  __shared__ float s_pc[4][256];   // gA
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t slot = (int64_t)blockIdx.x * 4 + wave;
-  if (slot >= a.n_slots) return;
-  // slot -> tile: last t with slot_base[t] <= slot
-  int lo = 0, hi = a.n_tiles;  // slot_base has n_tiles + 1 entries
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if ((int64_t)a.slot_base[mid] <= slot) lo = mid; else hi = mid - 1;
+// Work list of the backward: one entry (tile << 16 | chunk) per chunk that holds a contributing instance
+// (chunk * 64 < min(list length, tile_max)).  One workgroup; tiles are scanned 1024 at a time.
+__global__ __launch_bounds__(1024) void render_bwd_worklist_kernel(RenderBwdArgs a) {
+  __shared__ uint32_t s_wave[16];
+  __shared__ uint32_t s_carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_carry = 0u;
+  __syncthreads();
+  for (int base = 0; base < a.n_tiles; base += 1024) {
+    const int t = base + tid;
+    uint32_t c = 0;
+    if (t < a.n_tiles) {
+      const uint2 rg = a.ranges[t];
+      const uint32_t limit = min(rg.y - rg.x, a.tile_max[t]);
+      c = (limit + 63u) >> 6;
+    }
+    uint32_t v = c;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t u = (uint32_t)__shfl_up((int)v, o);
+      if (lane >= o) v += u;
+    }
+    if (lane == 63) s_wave[wave] = v;
+    __syncthreads();
+    uint32_t off = s_carry;
+    for (int w = 0; w < wave; w++) off += s_wave[w];
+    const uint32_t start = off + v - c;
+    for (uint32_t k = 0; k < c; k++) a.work[start + k] = ((uint32_t)t << 16) | k;
+    __syncthreads();
+    if (tid == 1023) s_carry = off + v;
+    __syncthreads();
   }
-  const int tile = lo;
-  if (tile >= a.n_tiles) return;
-  const int chunk = (int)(slot - a.slot_base[tile]);
-  const uint2 range = a.ranges[tile];
-  const int total = (int)(range.y - range.x);
-  const int limit = min(total, (int)a.tile_max[tile]);
-  const int pos0 = chunk * 64;
-  if (pos0 >= limit) return;
+  if (tid == 0) { a.work_ctr[0] = s_carry * 4u; a.work_ctr[1] = 0u; }  // four pixel-quarters per chunk
+}
+
+// Persistent, dynamically scheduled: every wave pulls (chunk, pixel-quarter) items from one counter until
+// the list is empty, so deep tiles (dozens of fully active chunks) spread evenly over the chip.
+__global__ __launch_bounds__(256) void render_bwd_kernel(RenderBwdArgs a) {
+  __shared__ float4 s_pa[4][64];  // (T_start, Pre_start, Qb, n_contrib as float bits)
+  __shared__ float4 s_pb[4][64];  // (gC0, gC1, gC2, gD)
+  __shared__ float s_pc[4][64];   // gA
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t n_items = a.work_ctr[0];
   const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE;
-  const int tx0 = (tile % gx) * RIGGS_TILE, ty0 = (tile / gx) * RIGGS_TILE;
   const size_t HW = (size_t)a.H * a.W;
   const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
-  // ---- stage the 256 pixels' uniform data (4 pixels per lane)
-  const float* ck = a.ckpt + ((size_t)slot * 5) * 256;
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const int pix = lane + 64 * q;
-    const int pxi = tx0 + (pix & 15), pyi = ty0 + (pix >> 4);
-    float4 pa = make_float4(1.f, 0.f, 0.f, 0.f), pb = make_float4(0.f, 0.f, 0.f, 0.f);
-    float pc = 0.f;
-    if (pxi < a.W && pyi < a.H) {
-      const size_t pid = (size_t)pyi * a.W + pxi;
-      const uint32_t n = a.n_contrib[pid];
-      if ((int)n > pos0) {
-        const float Tn = a.final_T[pid];
-        const float4 acc = a.final_acc[pid];
-        const float g0 = a.dL_dcolor[pid], g1 = a.dL_dcolor[HW + pid], g2 = a.dL_dcolor[2 * HW + pid];
-        const float gD = a.dL_ddepth ? a.dL_ddepth[pid] : 0.f;
-        const float gA = a.dL_dalpha ? a.dL_dalpha[pid] : 0.f;
-        const float Ts = ck[pix], S0 = ck[256 + pix], S1 = ck[512 + pix], S2 = ck[768 + pix], Ds = ck[1024 + pix];
-        const float pre = g0 * S0 + g1 * S1 + g2 * S2 + gD * Ds + gA * (1.0f - Ts);
-        const float qb = (g0 * acc.x + g1 * acc.y + g2 * acc.z + gD * acc.w + gA * (1.0f - Tn)) +
-                         Tn * (bg0 * g0 + bg1 * g1 + bg2 * g2);
-        pa = make_float4(Ts, pre, qb, __uint_as_float(n));
-        pb = make_float4(g0, g1, g2, gD);
-        pc = gA;
+  const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
+  // static interleaving (a single dequeue word saturates at ~90 dequeues/us on this chip): workgroup b takes
+  // chunks b, b + #workgroups, ...; its four waves are the four pixel-quarters of the chunk and meet in
+  // LDS so that each (chunk, instance) still issues ONE set of atomics (float atomics are the scarce
+  // resource: ~30 ns each once millions are in flight)
+  __shared__ float s_red[3][64][10];
+  const uint32_t n_chunks = n_items >> 2;
+  for (uint32_t chunk_item = blockIdx.x; chunk_item < n_chunks; chunk_item += gridDim.x) {
+    const uint32_t wk_ = a.work[chunk_item];
+    const int quarter = wave;
+    const int tile = (int)(wk_ >> 16), chunk = (int)(wk_ & 0xFFFFu);
+    const int64_t slot = (int64_t)a.slot_base[tile] + chunk;
+    const uint2 range = a.ranges[tile];
+    const int total = (int)(range.y - range.x);
+    const int limit = min(total, (int)a.tile_max[tile]);
+    const int pos0 = chunk * 64;
+    const int tx0 = (tile % gx) * RIGGS_TILE, ty0 = (tile / gx) * RIGGS_TILE;
+    // ---- stage this quarter's 64 pixels (one per lane)
+    const float* ck = a.ckpt + ((size_t)slot * 5) * 256;
+    {
+      const int pix = quarter * 64 + lane;
+      const int pxi = tx0 + (pix & 15), pyi = ty0 + (pix >> 4);
+      float4 pa = make_float4(1.f, 0.f, 0.f, 0.f), pb = make_float4(0.f, 0.f, 0.f, 0.f);
+      float pc = 0.f;
+      if (pxi < a.W && pyi < a.H) {
+        const size_t pid = (size_t)pyi * a.W + pxi;
+        const uint32_t n = a.n_contrib[pid];
+        if ((int)n > pos0) {
+          const float Tn = a.final_T[pid];
+          const float4 acc = a.final_acc[pid];
+          const float g0 = a.dL_dcolor[pid], g1 = a.dL_dcolor[HW + pid], g2 = a.dL_dcolor[2 * HW + pid];
+          const float gD = a.dL_ddepth ? a.dL_ddepth[pid] : 0.f;
+          const float gA = a.dL_dalpha ? a.dL_dalpha[pid] : 0.f;
+          const float Ts = ck[pix], S0 = ck[256 + pix], S1 = ck[512 + pix], S2 = ck[768 + pix], Ds = ck[1024 + pix];
+          const float pre = g0 * S0 + g1 * S1 + g2 * S2 + gD * Ds + gA * (1.0f - Ts);
+          const float qb = (g0 * acc.x + g1 * acc.y + g2 * acc.z + gD * acc.w + gA * (1.0f - Tn)) +
+                           Tn * (bg0 * g0 + bg1 * g1 + bg2 * g2);
+          pa = make_float4(Ts, pre, qb, __uint_as_float(n));
+          pb = make_float4(g0, g1, g2, gD);
+          pc = gA;
+        }
+      }
+      s_pa[wave][lane] = pa; s_pb[wave][lane] = pb; s_pc[wave][lane] = pc;
+    }
+    // ---- this lane's instance
+    const int pos = pos0 + lane;
+    const bool active = pos < limit;
+    uint32_t id = 0;
+    float4 xy = make_float4(0.f, 0.f, 0.f, 0.f), co = xy, cc = xy;
+    if (active) {
+      id = a.point_list[range.x + pos];
+      xy = a.xyd[id]; co = a.conic_o[id]; cc = a.rgb[id];
+    }
+    float a_mx = 0.f, a_my = 0.f, a_ca = 0.f, a_cb = 0.f, a_cc = 0.f, a_op = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f, a_d = 0.f;
+    // (the wave only touches its own LDS region: LDS operations of one wave are ordered, no barrier needed)
+    for (int pl = 0; pl < 64; pl++) {
+      const float4 pa = s_pa[wave][pl];
+      const int n = (int)__float_as_uint(pa.w);
+      if (n <= pos0) continue;  // wave-uniform: this chunk lies behind the pixel's last contributor
+      const int pix = quarter * 64 + pl;
+      const float pfx = (float)(tx0 + (pix & 15)), pfy = (float)(ty0 + (pix >> 4));
+      const float dx = xy.x - pfx, dy = xy.y - pfy;
+      const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+      const float G = fast_exp(power);
+      float alpha = fminf(ALPHA_MAX, co.w * G);
+      const bool valid = active && (pos < n) && (power <= 0.0f) && (alpha >= ALPHA_MIN);
+      if (__builtin_amdgcn_ballot_w64(valid) == 0) continue;
+      alpha = valid ? alpha : 0.f;
+      const float om = 1.0f - alpha;
+      const float Tl = pa.x * wave_excl_prod_scan(om);
+      const float4 pb = s_pb[wave][pl];
+      const float gA = s_pc[wave][pl];
+      const float w = alpha * Tl;
+      const float k = pb.x * cc.x + pb.y * cc.y + pb.z * cc.z + pb.w * xy.z + gA;
+      const float wk = w * k;
+      const float pre = pa.y + wave_excl_sum_scan(wk);
+      // dL/dalpha = T k - (suffix + T_final * bg.g) / (1 - alpha),  suffix = total - prefix - own
+      const float dL_dalpha = Tl * k - (pa.z - pre - wk) * __builtin_amdgcn_rcpf(om);
+      const float dL_dG = co.w * dL_dalpha;
+      const float gdx = G * dx, gdy = G * dy;
+      if (valid) {
+        a_mx += dL_dG * (-gdx * co.x - gdy * co.y);
+        a_my += dL_dG * (-gdy * co.z - gdx * co.y);
+        a_ca += gdx * dx * dL_dG;
+        a_cb += gdx * dy * dL_dG;
+        a_cc += gdy * dy * dL_dG;
+        a_op += G * dL_dalpha;
+        a_r += w * pb.x; a_g += w * pb.y; a_b += w * pb.z;
+        a_d += w * pb.w;
       }
     }
-    s_pa[wave][pix] = pa; s_pb[wave][pix] = pb; s_pc[wave][pix] = pc;
-  }
-  // ---- this lane's instance
-  const int pos = pos0 + lane;
-  const bool active = pos < limit;
-  uint32_t id = 0;
-  float4 xy = make_float4(0.f, 0.f, 0.f, 0.f), co = xy, cc = xy;
-  if (active) {
-    id = a.point_list[range.x + pos];
-    xy = a.xyd[id]; co = a.conic_o[id]; cc = a.rgb[id];
-  }
-  const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
-  float a_mx = 0.f, a_my = 0.f, a_ca = 0.f, a_cb = 0.f, a_cc = 0.f, a_op = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f, a_d = 0.f;
-  // (the wave only reads its own LDS region: no workgroup barrier needed, LDS ops of one wave are ordered)
-  for (int pix = 0; pix < 256; pix++) {
-    const float4 pa = s_pa[wave][pix];
-    const int n = (int)__float_as_uint(pa.w);
-    if (n <= pos0) continue;  // wave-uniform: this chunk lies behind the pixel's last contributor
-    const float pfx = (float)(tx0 + (pix & 15)), pfy = (float)(ty0 + (pix >> 4));
-    const float dx = xy.x - pfx, dy = xy.y - pfy;
-    const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-    const float G = fast_exp(power);
-    float alpha = fminf(ALPHA_MAX, co.w * G);
-    const bool valid = active && (pos < n) && (power <= 0.0f) && (alpha >= ALPHA_MIN);
-    if (__builtin_amdgcn_ballot_w64(valid) == 0) continue;
-    alpha = valid ? alpha : 0.f;
-    const float om = 1.0f - alpha;
-    const float Tl = pa.x * wave_excl_prod_scan(om);
-    const float4 pb = s_pb[wave][pix];
-    const float gA = s_pc[wave][pix];
-    const float w = alpha * Tl;
-    const float k = pb.x * cc.x + pb.y * cc.y + pb.z * cc.z + pb.w * xy.z + gA;
-    const float wk = w * k;
-    const float pre = pa.y + wave_excl_sum_scan(wk);
-    // dL/dalpha = T k - (suffix + T_final * bg.g) / (1 - alpha),  suffix = total - prefix - own
-    const float dL_dalpha = Tl * k - (pa.z - pre - wk) * __builtin_amdgcn_rcpf(om);
-    const float dL_dG = co.w * dL_dalpha;
-    const float gdx = G * dx, gdy = G * dy;
-    if (valid) {
-      a_mx += dL_dG * (-gdx * co.x - gdy * co.y);
-      a_my += dL_dG * (-gdy * co.z - gdx * co.y);
-      a_ca += gdx * dx * dL_dG;
-      a_cb += gdx * dy * dL_dG;
-      a_cc += gdy * dy * dL_dG;
-      a_op += G * dL_dalpha;
-      a_r += w * pb.x; a_g += w * pb.y; a_b += w * pb.z;
-      a_d += w * pb.w;
+    // fold the four pixel-quarters
+    __syncthreads();
+    if (wave > 0) {
+      float* r = s_red[wave - 1][lane];
+      r[0] = a_mx; r[1] = a_my; r[2] = a_ca; r[3] = a_cb; r[4] = a_cc; r[5] = a_op; r[6] = a_r; r[7] = a_g; r[8] = a_b; r[9] = a_d;
     }
-  }
-  if (active) {
-    float* g = a.gacc + (size_t)id * RIGGS_GACC;
-    atomicAdd(g + 0, a_mx * ddelx_dx); atomicAdd(g + 1, a_my * ddely_dy);
-    atomicAdd(g + 2, -0.5f * a_ca); atomicAdd(g + 3, -a_cb); atomicAdd(g + 4, -0.5f * a_cc);
-    atomicAdd(g + 5, a_op); atomicAdd(g + 6, a_r); atomicAdd(g + 7, a_g); atomicAdd(g + 8, a_b);
-    if (a.dL_ddepth) atomicAdd(g + 9, a_d);
+    __syncthreads();
+    if (wave == 0 && active) {
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const float* r = s_red[q][lane];
+        a_mx += r[0]; a_my += r[1]; a_ca += r[2]; a_cb += r[3]; a_cc += r[4]; a_op += r[5]; a_r += r[6]; a_g += r[7]; a_b += r[8]; a_d += r[9];
+      }
+      float* g = a.gacc + (size_t)id * RIGGS_GACC;
+      atomicAdd(g + 0, a_mx * ddelx_dx); atomicAdd(g + 1, a_my * ddely_dy);
+      atomicAdd(g + 2, -0.5f * a_ca); atomicAdd(g + 3, -a_cb); atomicAdd(g + 4, -0.5f * a_cc);
+      atomicAdd(g + 5, a_op); atomicAdd(g + 6, a_r); atomicAdd(g + 7, a_g); atomicAdd(g + 8, a_b);
+      if (a.dL_ddepth) atomicAdd(g + 9, a_d);
+    }
   }
 }
 
@@ -712,7 +761,12 @@ int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s) {
   if (gx * gy == 0) return 0;
   static const bool v1 = getenv("RIGGS_RENDER_BWD_V1") != nullptr;  // A/B switch: pixel-major reference kernel
   if (v1) hipLaunchKernelGGL(render_bwd_v1_kernel, dim3(gx * gy), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(render_bwd_kernel, dim3((unsigned)((a.n_slots + 3) / 4)), dim3(256), 0, s, a);
+  else {
+    hipLaunchKernelGGL(render_bwd_worklist_kernel, dim3(1), dim3(1024), 0, s, a);
+    const int64_t max_blocks = 256 * 8;  // 8 workgroups of 4 waves per CU: every SIMD holds 8 pulling waves
+    const unsigned blocks = (unsigned)((a.n_slots < max_blocks) ? a.n_slots : max_blocks);
+    hipLaunchKernelGGL(render_bwd_kernel, dim3(blocks), dim3(256), 0, s, a);
+  }
   return 0;
 }
 
