@@ -83,6 +83,7 @@ GeomLayout geom_layout(int N) {
   size_t t1 = sort_temp_bytes_u32(n), t2 = scan_temp_bytes_u32(n);
   L.temp_bytes = align_up(t1 > t2 ? t1 : t2);
   L.temp = o; o += L.temp_bytes;
+  L.sort_table = o; o += align_up(depth_sort_table_bytes(N));
   L.total = o;
   return L;
 }
@@ -227,7 +228,11 @@ int riggs_raster_preprocess(const riggs_raster_cfg* cfg, const float* means3D, c
   if (debug_sync(cfg->debug, s, "preprocess_fwd")) return 1;
   // depth sort of the Gaussians (stable: equal depths keep ascending index)
   size_t tb = L.temp_bytes;
-  {
+  if (!use_rocprim_binning()) {
+    ProfScope ps(PROF_DEPTH_SORT, s);  // three counting-sort passes (csrc/binning.hip)
+    launch_depth_sort(N, (uint32_t*)(geom + L.depth_key), (uint32_t*)(geom + L.order_in),
+                      (uint32_t*)(geom + L.depth_key_sorted), (uint32_t*)(geom + L.order), geom + L.sort_table, s);
+  } else {
     ProfScope ps(PROF_DEPTH_SORT, s);
     RIGGS_HIP_CHECK(rocprim::radix_sort_pairs(geom + L.temp, tb, (uint32_t*)(geom + L.depth_key),
                                               (uint32_t*)(geom + L.depth_key_sorted), (uint32_t*)(geom + L.order_in),

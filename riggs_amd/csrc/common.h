@@ -62,7 +62,7 @@ struct ProfScope {
 // ---- arena layouts ---------------------------------------------------------
 struct GeomLayout {
   size_t xyd, conic_o, rgb, cov3D, clamped, tiles, rect, depth_key, depth_key_sorted, order_in, order, tt_sorted,
-      offsets, temp, temp_bytes, total;
+      offsets, temp, temp_bytes, sort_table, total;
 };
 GeomLayout geom_layout(int N);
 
