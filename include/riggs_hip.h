@@ -188,13 +188,16 @@ size_t riggs_lbs_backward_workspace_bytes(int32_t num_points, int32_t num_joints
  * (row-major (out, in)).  `acts` (riggs_pose_mlp_acts_floats floats) is written by forward and
  * read by backward.  backward writes every parameter gradient into ONE flat buffer laid out as
  *   [W_0, b_0, ..., W_{depth-1}, b_{depth-1}, W_rot, b_rot, W_tr, b_tr]   (no gradient to t).
+ * rot_bias4 (4 floats, may be NULL) is added to every predicted quaternion: the identity bias
+ * [1,0,0,0] of skeleton_warp.py:118 folded into the head instead of a separate elementwise op.
  * ===================================================================== */
 size_t riggs_pose_mlp_acts_floats(int32_t depth, int32_t width, int32_t multires);
 size_t riggs_pose_mlp_backward_workspace_floats(int32_t depth, int32_t width, int32_t multires);
 int riggs_pose_mlp_forward(int32_t depth, int32_t width, int32_t multires, int32_t skip, int32_t n_rot,
                            const float* const* weights, const float* const* biases, const float* W_rot,
-                           const float* b_rot, const float* W_tr, const float* b_tr, const float* t, float* acts,
-                           float* rotation, float* translation, riggs_stream stream);
+                           const float* b_rot, const float* W_tr, const float* b_tr, const float* t,
+                           const float* rot_bias4, float* acts, float* rotation, float* translation,
+                           riggs_stream stream);
 int riggs_pose_mlp_backward(int32_t depth, int32_t width, int32_t multires, int32_t skip, int32_t n_rot,
                             const float* const* weights, const float* const* biases, const float* W_rot,
                             const float* b_rot, const float* W_tr, const float* b_tr, const float* acts,

@@ -53,6 +53,7 @@ __global__ __launch_bounds__(512) void bin_count_kernel(int N, int T, int grid_x
 // coalesced across the 64 tiles), LDS prefix over the 16 segments, then the exclusive prefixes are
 // written back — no serial walk over hundreds of chunks.
 #define SCAN_SEG 16
+#define SCAN_KEEP 24
 __global__ __launch_bounds__(1024) void bin_scan_kernel(int T, int n_chunks, uint32_t* __restrict__ table,
                                                         uint32_t* __restrict__ tile_count) {
   __shared__ uint32_t s_seg[SCAN_SEG][64];
@@ -61,6 +62,27 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(int T, int n_chunks, uin
   const int per = (n_chunks + SCAN_SEG - 1) / SCAN_SEG;
   const int b0 = seg * per, b1 = min(n_chunks, b0 + per);
   uint32_t sum = 0;
+  if (per <= SCAN_KEEP) {
+    // the usual case: the whole segment stays in registers (one batch of independent loads, no re-read)
+    uint32_t v[SCAN_KEEP];
+#pragma unroll
+    for (int i = 0; i < SCAN_KEEP; i++) v[i] = (t < T && b0 + i < b1) ? table[(size_t)(b0 + i) * T + t] : 0u;
+#pragma unroll
+    for (int i = 0; i < SCAN_KEEP; i++) sum += v[i];
+    s_seg[seg][tl] = sum;
+    __syncthreads();
+    uint32_t run = 0;
+    for (int s2 = 0; s2 < seg; s2++) run += s_seg[s2][tl];
+    if (t < T) {
+#pragma unroll
+      for (int i = 0; i < SCAN_KEEP; i++) {
+        if (b0 + i < b1) table[(size_t)(b0 + i) * T + t] = run;
+        run += v[i];
+      }
+      if (seg == SCAN_SEG - 1) tile_count[t] = run;
+    }
+    return;
+  }
   if (t < T) for (int b = b0; b < b1; b++) sum += table[(size_t)b * T + t];
   s_seg[seg][tl] = sum;
   __syncthreads();
@@ -76,6 +98,7 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(int T, int n_chunks, uin
 __global__ __launch_bounds__(1024) void bin_offsets_kernel(int T, int64_t cap, const uint32_t* __restrict__ tile_count,
                                                            uint32_t* __restrict__ tile_start, uint2* __restrict__ ranges,
                                                            uint32_t* __restrict__ slot_base,
+                                                           uint32_t* __restrict__ tile_max,
                                                            uint32_t* __restrict__ counters) {
   __shared__ uint32_t s_wave[16];
   __shared__ uint32_t s_carry;
@@ -101,8 +124,9 @@ __global__ __launch_bounds__(1024) void bin_offsets_kernel(int T, int64_t cap, c
       tile_start[t] = start;
       // clamp to the arena: on overflow (flagged below) the frame is invalid but every access stays in bounds
       const uint32_t lo = (uint32_t)min((int64_t)start, cap), hi = (uint32_t)min((int64_t)start + c, cap);
-      // empty tiles keep (0, 0) like upstream's identifyTileRanges (ranges is zeroed before)
-      if (hi > lo) ranges[t] = make_uint2(lo, hi);
+      // empty tiles get (0, 0) like upstream's identifyTileRanges (whose ranges buffer is zeroed before)
+      ranges[t] = (hi > lo) ? make_uint2(lo, hi) : make_uint2(0u, 0u);
+      tile_max[t] = 0u;  // atomicMax target of the forward
       slot_base[t] = (lo >> 6) + (uint32_t)t;
     }
     __syncthreads();
@@ -112,6 +136,8 @@ __global__ __launch_bounds__(1024) void bin_offsets_kernel(int T, int64_t cap, c
   if (tid == 0) {
     const uint32_t R = s_carry;
     tile_start[T] = R;
+    ranges[T] = make_uint2(0u, 0u);
+    tile_max[T] = 0u;
     slot_base[T] = ((uint32_t)min((int64_t)R, cap) >> 6) + (uint32_t)T;
     counters[0] = R;
     counters[1] = ((int64_t)R > cap) ? 1u : 0u;
@@ -222,7 +248,7 @@ size_t bin_table_bytes(int N, int T) {
 
 int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order, const uint32_t* tiles,
                    const ushort4* rect, void* table_mem, uint32_t* point_list, uint32_t* tile_keys, uint2* ranges,
-                   uint32_t* slot_base, uint32_t* counters, hipStream_t s) {
+                   uint32_t* slot_base, uint32_t* tile_max, uint32_t* counters, hipStream_t s) {
   BinPlan p = bin_plan(N, T);
   char* mem = (char*)table_mem;
   uint32_t* table = (uint32_t*)mem;
@@ -239,7 +265,7 @@ int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order,
                      order, tiles, rect, table);
   hipLaunchKernelGGL(bin_scan_kernel, dim3((T + 63) / 64), dim3(1024), 0, s, T, p.n_chunks, table, tile_count);
   hipLaunchKernelGGL(bin_offsets_kernel, dim3(1), dim3(1024), 0, s, T, cap, tile_count, tile_start, ranges, slot_base,
-                     counters);
+                     tile_max, counters);
   hipLaunchKernelGGL(bin_scatter_kernel, dim3(p.n_chunks), dim3(p.threads), p.lds_scatter, s, N, T, grid_x, cap,
                      p.g_per_block, order, tiles, rect, table, tile_start, point_list, tile_keys);
   return 0;

@@ -264,7 +264,9 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
   GeomLayout G = geom_layout(N);
   ImageLayout I = image_layout(H, W);
   BinLayout B = bin_layout(cap, N, H, W);
-  RIGGS_HIP_CHECK(hipMemsetAsync(img + I.ranges, 0, (I.tile_max - I.ranges) + (size_t)(T + 1) * 4, s));  // ranges + tile_max
+  const bool counting = N > 0 && cap > 0 && !use_rocprim_binning();
+  if (!counting)  // (the counting sort's bin_offsets_kernel writes every entry of both itself)
+    RIGGS_HIP_CHECK(hipMemsetAsync(img + I.ranges, 0, (I.tile_max - I.ranges) + (size_t)(T + 1) * 4, s));  // ranges + tile_max
   const uint32_t* point_list = (const uint32_t*)(bin + B.vals_b);
   if (N > 0 && cap > 0 && !use_rocprim_binning()) {
     // stable counting sort by tile (csrc/binning.hip)
@@ -273,7 +275,7 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
     int rcb = launch_binning(N, T, gx, cap, (const uint32_t*)(geom + G.order), (const uint32_t*)(geom + G.tiles),
                              (const ushort4*)(geom + G.rect), bin + B.table, (uint32_t*)(bin + B.vals_b),
                              (uint32_t*)(bin + B.keys_b), (uint2*)(img + I.ranges), (uint32_t*)(img + I.slot_base),
-                             counters, s);
+                             (uint32_t*)(img + I.tile_max), counters, s);
     if (rcb) return rcb;
     if (debug_sync(cfg->debug, s, "binning (counting sort)")) return 1;
   } else if (N > 0 && cap > 0) {
@@ -345,8 +347,8 @@ int riggs_raster_backward(const riggs_raster_cfg* cfg, const float* means3D, con
   GeomLayout G = geom_layout(N);
   ImageLayout I = image_layout(H, W);
   BinLayout B = bin_layout(cap, N, H, W);
-  RIGGS_HIP_CHECK(hipMemsetAsync(workspace, 0, (size_t)N * RIGGS_GACC * 4, s));
   RenderBwdArgs r;
+  r.n_points = N;
   r.W = W; r.H = H;
   r.ranges = (const uint2*)(img + I.ranges);
   r.point_list = (const uint32_t*)(bin + B.vals_b);
@@ -361,6 +363,7 @@ int riggs_raster_backward(const riggs_raster_cfg* cfg, const float* means3D, con
   r.n_slots = (int64_t)B.n_slots;
   r.work = (uint32_t*)(bin + B.work); r.work_ctr = (uint32_t*)(img + I.work_ctr);
   if (cap > 0) { ProfScope ps(PROF_RENDER_BWD, s); launch_render_bwd(r, s); }
+  else RIGGS_HIP_CHECK(hipMemsetAsync(workspace, 0, (size_t)N * RIGGS_GACC * 4, s));
   if (debug_sync(cfg->debug, s, "render_bwd")) return 1;
   b.g_mean2D_conic = (const float*)workspace;
   b.dL_dmeans3D = dL_dmeans3D; b.dL_dmeans2D = dL_dmeans2D; b.dL_dsh = dL_dsh; b.dL_dcolors = dL_dcolors_precomp;

@@ -64,6 +64,7 @@ __global__ __launch_bounds__(64) void pm_embed_kernel(PoseMlpDesc d, const float
 
 // layer l (l == depth: the two heads): one wave64 per output row
 __global__ __launch_bounds__(256) void pm_layer_kernel(PoseMlpDesc d, int l, float* __restrict__ acts,
+                                                       const float* __restrict__ rot_bias4,
                                                        float* __restrict__ rotation, float* __restrict__ translation) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int emb = 1 + 2 * d.multires;
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void pm_layer_kernel(PoseMlpDesc d, int l, flo
   if (lane == 63) {
     const float v = acc + bias;
     if (!heads) acts[emb + (size_t)l * d.width + r] = fmaxf(v, 0.f);
-    else if (r < d.n_rot) rotation[r] = v;
+    else if (r < d.n_rot) rotation[r] = rot_bias4 ? v + rot_bias4[r & 3] : v;
     else translation[r - d.n_rot] = v;
   }
 }
@@ -187,8 +188,9 @@ size_t riggs_pose_mlp_acts_floats(int32_t depth, int32_t width, int32_t multires
 
 int riggs_pose_mlp_forward(int32_t depth, int32_t width, int32_t multires, int32_t skip, int32_t n_rot,
                            const float* const* weights, const float* const* biases, const float* W_rot,
-                           const float* b_rot, const float* W_tr, const float* b_tr, const float* t, float* acts,
-                           float* rotation, float* translation, riggs_stream stream) {
+                           const float* b_rot, const float* W_tr, const float* b_tr, const float* t,
+                           const float* rot_bias4, float* acts, float* rotation, float* translation,
+                           riggs_stream stream) {
   PoseMlpDesc d;
   int rc = pm_fill(d, depth, width, multires, skip, n_rot, weights, biases, W_rot, b_rot, W_tr, b_tr);
   if (rc) return rc;
@@ -197,7 +199,7 @@ int riggs_pose_mlp_forward(int32_t depth, int32_t width, int32_t multires, int32
   hipLaunchKernelGGL(pm_embed_kernel, dim3(1), dim3(64), 0, s, d, t, acts);
   for (int l = 0; l <= depth; l++) {
     const int n_out = (l == depth) ? n_rot + 3 : width;
-    hipLaunchKernelGGL(pm_layer_kernel, dim3((n_out + 3) / 4), dim3(256), 0, s, d, l, acts, rotation, translation);
+    hipLaunchKernelGGL(pm_layer_kernel, dim3((n_out + 3) / 4), dim3(256), 0, s, d, l, acts, rot_bias4, rotation, translation);
   }
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;

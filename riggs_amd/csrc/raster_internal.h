@@ -59,7 +59,8 @@ struct RenderBwdArgs {
   const float* final_T;
   const uint32_t* n_contrib;
   const float *dL_dcolor, *dL_ddepth, *dL_dalpha;
-  float* gacc;  // (N, RIGGS_GACC) accumulators, zeroed by the caller
+  float* gacc;  // (N, RIGGS_GACC) accumulators, zeroed by launch_render_bwd
+  int n_points;
   const float4* final_acc;
   const uint32_t* tile_max;
   const uint32_t* slot_base;
@@ -78,7 +79,7 @@ int launch_depth_sort(int N, uint32_t* keys_in, uint32_t* vals_in, uint32_t* key
 size_t bin_table_bytes(int N, int T);
 int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order, const uint32_t* tiles,
                    const ushort4* rect, void* table_mem, uint32_t* point_list, uint32_t* tile_keys, uint2* ranges,
-                   uint32_t* slot_base, uint32_t* counters, hipStream_t s);
+                   uint32_t* slot_base, uint32_t* tile_max, uint32_t* counters, hipStream_t s);
 int launch_gather_tiles(int N, const uint32_t* order, const uint32_t* tiles, uint32_t* tt_sorted, hipStream_t s);
 int launch_emit(int N, int grid_x, int n_tiles, int64_t cap, const uint32_t* order, const uint32_t* offsets,
                 const uint32_t* tiles, const ushort4* rect, uint32_t* keys, uint32_t* vals, uint32_t* counters,

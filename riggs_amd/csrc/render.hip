@@ -599,11 +599,19 @@ __device__ __forceinline__ float wave_excl_sum_scan(float v) {
 // so a tile with thousands of contributing instances spreads over the whole chip instead of
 // serialising on four waves.
 // Work list of the backward: one entry (tile << 16 | chunk) per chunk that holds a contributing instance
-// (chunk * 64 < min(list length, tile_max)).  One workgroup; tiles are scanned 1024 at a time.
+// (chunk * 64 < min(list length, tile_max)).  Workgroup 0 builds it (tiles are scanned 1024 at a time);
+// the other workgroups clear the per-Gaussian gradient accumulators meanwhile (this replaces a memset node).
 __global__ __launch_bounds__(1024) void render_bwd_worklist_kernel(RenderBwdArgs a) {
   __shared__ uint32_t s_wave[16];
   __shared__ uint32_t s_carry;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (blockIdx.x > 0) {
+    float4* z = reinterpret_cast<float4*>(a.gacc);  // N * RIGGS_GACC floats, RIGGS_GACC % 4 == 0, 256-byte aligned
+    const size_t n4 = (size_t)a.n_points * (RIGGS_GACC / 4);
+    for (size_t i = (size_t)(blockIdx.x - 1) * 1024 + tid; i < n4; i += (size_t)(gridDim.x - 1) * 1024)
+      z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
   if (tid == 0) s_carry = 0u;
   __syncthreads();
   for (int base = 0; base < a.n_tiles; base += 1024) {
@@ -760,9 +768,12 @@ int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s) {
   const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE, gy = (a.H + RIGGS_TILE - 1) / RIGGS_TILE;
   if (gx * gy == 0) return 0;
   static const bool v1 = getenv("RIGGS_RENDER_BWD_V1") != nullptr;  // A/B switch: pixel-major reference kernel
-  if (v1) hipLaunchKernelGGL(render_bwd_v1_kernel, dim3(gx * gy), dim3(256), 0, s, a);
+  if (v1) {
+    (void)hipMemsetAsync(a.gacc, 0, (size_t)a.n_points * RIGGS_GACC * 4, s);
+    hipLaunchKernelGGL(render_bwd_v1_kernel, dim3(gx * gy), dim3(256), 0, s, a);
+  }
   else {
-    hipLaunchKernelGGL(render_bwd_worklist_kernel, dim3(1), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(render_bwd_worklist_kernel, dim3(1 + 512), dim3(1024), 0, s, a);
     const int64_t max_blocks = 256 * 8;  // 8 workgroups of 4 waves per CU: every SIMD holds 8 pulling waves
     const unsigned blocks = (unsigned)((a.n_slots < max_blocks) ? a.n_slots : max_blocks);
     hipLaunchKernelGGL(render_bwd_kernel, dim3(blocks), dim3(256), 0, s, a);

@@ -14,7 +14,7 @@ import torch
 
 from . import _lib as L
 from .rasterizer import RasterArena
-from .render import render
+from .render import render, RenderPkg
 from .synth import Camera
 
 
@@ -46,8 +46,11 @@ class GraphedFrame:
                      fused=self.fused, arena=self.arena)
         pkg["render"].backward(self.gimg)
         # only detached outputs are kept: a live autograd graph would pin AccumulateGrad nodes to this stream
-        return {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in pkg.items() if k != "viewspace_points"} | {
-            "viewspace_points_grad": pkg["viewspace_points"].grad}
+        # (visibility_filter is left lazy: RenderPkg derives it from the static ``radii`` buffer on access)
+        out = {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in dict.items(pkg)
+               if k not in ("viewspace_points", "visibility_filter")}
+        out["viewspace_points_grad"] = pkg["viewspace_points"].grad
+        return RenderPkg(out, cache=False)
 
     def set_inputs(self, cam: Camera = None, gimg: torch.Tensor = None):
         if cam is not None:

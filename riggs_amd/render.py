@@ -28,6 +28,51 @@ def quaternion_multiply(a, b):
     return torch.where(o[..., 0:1] < 0, -o, o)
 
 
+class RenderPkg(dict):
+    """The dict ``render`` returns.  ``visibility_filter`` (= ``radii > 0``, gaussian_renderer/__init__.py:147) is
+    an elementwise launch that training does not need every frame: it is evaluated on first access.  With
+    ``cache=False`` (static buffers of a replayed hipGraph) it is re-evaluated on every access."""
+
+    def __init__(self, *a, cache=True, **k):
+        super().__init__(*a, **k)
+        self._cache = cache
+        dict.setdefault(self, "visibility_filter", None)
+
+    def _vis(self):
+        v = dict.__getitem__(self, "visibility_filter")
+        if v is None:
+            v = dict.__getitem__(self, "radii") > 0
+            if self._cache:
+                dict.__setitem__(self, "visibility_filter", v)
+        return v
+
+    def __getitem__(self, key):
+        return self._vis() if key == "visibility_filter" else dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        return self._vis() if key == "visibility_filter" else dict.get(self, key, default)
+
+    def items(self):
+        return [(k, self[k]) for k in dict.keys(self)]
+
+    def values(self):
+        return [self[k] for k in dict.keys(self)]
+
+
+_ZERO_POINTS = {}
+
+
+def _zero_points(xyz):
+    """A fresh autograd leaf of zeros shaped like ``xyz`` (the reference's ``screenspace_points``) that aliases
+    one cached zero buffer: nothing ever writes its values, so no fill kernel per frame."""
+    key = (xyz.device, xyz.shape[0])
+    z = _ZERO_POINTS.get(key)
+    if z is None:
+        _ZERO_POINTS.clear()
+        z = _ZERO_POINTS[key] = torch.zeros(xyz.shape[0], 3, dtype=torch.float32, device=xyz.device)
+    return z.detach().requires_grad_(True)
+
+
 class _FusedGlueRaster(torch.autograd.Function):
     """render glue + rasterizer as ONE autograd node over the raw Gaussian parameters."""
 
@@ -64,9 +109,12 @@ class _FusedGlueRaster(torch.autograd.Function):
         g = rasterize_backward(s, xyz, f_dc, None, opacity, scaling, rotation, None, d_xyz, d_rot, g_color, g_depth,
                                g_alpha, d_scaling=d_scaling, want_d_scaling_grad=need_ds, shs_rest=f_rest)
         g_means3D, g_means2D, (g_dc, g_rest), _, g_opac, g_scales, g_rots, _, g_ds = g
+        # dL/d(d_xyz) == dL/dxyz and dL/d(d_rotation) == dL/d_rotation: hand the residual branches an alias (a
+        # second tensor object on the same storage) so that AccumulateGrad can adopt the parameter gradients
+        # instead of cloning them because they are referenced twice
         return (g_means3D, g_means2D, g_dc, g_rest, g_opac, g_scales, g_rots,
-                g_means3D if d_xyz is not None else None, g_rots if d_rot is not None else None, g_ds, None, None,
-                None)
+                g_means3D.detach() if d_xyz is not None else None, g_rots.detach() if d_rot is not None else None,
+                g_ds, None, None, None)
 
 
 def _is_zero_scalar(v):
@@ -79,11 +127,6 @@ def render(viewpoint_camera, pc, pipe, bg_color, d_xyz, d_rotation, d_scaling, d
            d_rotation_bias=None, force_visible=False, fused=True, arena: RasterArena = None):
     """Same contract as the reference ``render`` (returns the same dict).  ``fused`` / ``arena`` are additions."""
     xyz = pc.get_xyz
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
     tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
     tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
     bg = bg_color if not random_bg_color else torch.rand_like(bg_color)
@@ -98,7 +141,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, d_xyz, d_rotation, d_scaling, d
                       and d_rotation_bias is None and (d_color is None or type(d_color) is float)
                       and not (detach_xyz or detach_scale or detach_rot or detach_opacity))
     if fused and default_branch:
-        screenspace_points = torch.zeros_like(xyz, requires_grad=True)  # leaf: .grad is populated by autograd
+        screenspace_points = _zero_points(xyz)  # leaf: .grad is populated by autograd
         dx = None if _is_zero_scalar(d_xyz) else d_xyz
         dr = None if _is_zero_scalar(d_rotation) else d_rotation
         ds = None if _is_zero_scalar(d_scaling) else d_scaling
@@ -107,10 +150,15 @@ def render(viewpoint_camera, pc, pipe, bg_color, d_xyz, d_rotation, d_scaling, d
         color, radii, depth, alpha = _FusedGlueRaster.apply(
             pc._xyz, screenspace_points, pc._features_dc, pc._features_rest, pc._opacity, scaling, pc._rotation,
             dx, dr, ds, settings, iso, arena)
-        return {"render": color, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
-                "radii": radii, "depth": depth, "alpha": alpha, "bg_color": bg}
+        return RenderPkg({"render": color, "viewspace_points": screenspace_points, "visibility_filter": None,
+                          "radii": radii, "depth": depth, "alpha": alpha, "bg_color": bg})
 
     # ---- general path: the reference's own op sequence (gaussian_renderer/__init__.py:74-141) ----
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
+    try:
+        screenspace_points.retain_grad()  # gaussian_renderer/__init__.py:48-52
+    except Exception:
+        pass
     rasterizer = GaussianRasterizer(raster_settings=settings)
     means3D = xyz + d_xyz
     means2D = screenspace_points

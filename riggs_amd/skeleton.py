@@ -52,7 +52,9 @@ class PoseMLP(nn.Module):
                 and self.net[0].in_features == 1 + 2 * self.multires and len(self.net) <= 12
                 and all(l.out_features == w for l in self.net))
 
-    def forward(self, t):
+    def forward(self, t, rot_bias=None):
+        """``rot_bias`` (4,) is added to every predicted quaternion (skeleton_warp.py:118 does it outside the
+        network; folding it into the head kernel saves one elementwise launch per frame)."""
         if self._fusable(t):  # one row: three HIP launches instead of ~60 torch ops
             params = []
             for l in self.net:
@@ -60,7 +62,7 @@ class PoseMLP(nn.Module):
             params += [self.rotation_predictor.weight, self.rotation_predictor.bias,
                        self.translation_predictor.weight, self.translation_predictor.bias]
             rot, tr = _PoseMLPFn.apply(t.reshape(1), len(self.net), self.net[0].out_features, self.multires,
-                                       self.skips[0], *params)
+                                       self.skips[0], rot_bias, *params)
             return {"rotation": rot, "translation": tr}
         t_emb = _embed(t, self.multires) if self.multires > 0 else t
         h = t_emb + 0.0
@@ -68,7 +70,10 @@ class PoseMLP(nn.Module):
             h = F.relu(layer(h))
             if i in self.skips:
                 h = torch.cat([t_emb, h], -1)
-        return {"rotation": self.rotation_predictor(h), "translation": self.translation_predictor(h)}
+        rot = self.rotation_predictor(h)
+        if rot_bias is not None:
+            rot = (rot.reshape(-1, 4) + rot_bias).reshape(rot.shape)
+        return {"rotation": rot, "translation": self.translation_predictor(h)}
 
 
 class _PoseMLPFn(torch.autograd.Function):
@@ -82,7 +87,7 @@ class _PoseMLPFn(torch.autograd.Function):
         return Wp, bp
 
     @staticmethod
-    def forward(ctx, t, depth, width, multires, skip, *params):
+    def forward(ctx, t, depth, width, multires, skip, rot_bias, *params):
         ctx.set_materialize_grads(False)
         params = [p.contiguous() for p in params]
         lib = L.lib()
@@ -95,7 +100,7 @@ class _PoseMLPFn(torch.autograd.Function):
         h = params[2 * depth:]
         L.check(lib.riggs_pose_mlp_forward(depth, width, multires, skip, n_rot, Wp, bp, h[0].data_ptr(),
                                            h[1].data_ptr(), h[2].data_ptr(), h[3].data_ptr(), t.data_ptr(),
-                                           acts.data_ptr(), rot.data_ptr(), tr.data_ptr(), L.stream_ptr()),
+                                           L.ptr(rot_bias), acts.data_ptr(), rot.data_ptr(), tr.data_ptr(), L.stream_ptr()),
                 "riggs_pose_mlp_forward")
         ctx.save_for_backward(acts, *params)
         ctx.cfg = (depth, width, multires, skip, n_rot)
@@ -124,7 +129,7 @@ class _PoseMLPFn(torch.autograd.Function):
             n = p.numel()
             grads.append(flat[o:o + n].view_as(p))
             o += n
-        return (None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, *grads)
 
 
 # --------------------------------------------------------------------------- HIP ops
@@ -260,6 +265,7 @@ class SkeletonWarp(nn.Module):
         self.pose_net = PoseMLP(1, J * 4)
         self.register_buffer("_rot_bias", torch.tensor([1.0, 0.0, 0.0, 0.0]), persistent=False)  # skeleton_warp.py:118
         self._parents_i32 = None
+        self._joints_key, self._joints_cache = None, None
 
     # -- reference surface ------------------------------------------------------------------
     @property
@@ -296,11 +302,20 @@ class SkeletonWarp(nn.Module):
             self._parents_i32 = p.to(device)
         return self._parents_i32
 
+    def _joints(self):
+        """Rest joint positions as a contiguous (J, 3) tensor; re-sliced only when ``nodes`` was modified
+        (``nodes`` is a frozen parameter in rig training: skeleton_warp.py:14-16), so no copy per frame."""
+        key = (self.nodes.data_ptr(), self.nodes._version)
+        if self._joints_key != key:
+            self._joints_cache = self.nodes[:, :3].detach().contiguous()
+            self._joints_key = key
+        return self._joints_cache
+
     def get_pose_info(self, t):
         if t.dim() == 0:
             t = self.expand_time(t)
-        m = self.pose_net(t[0])
-        return {"local_rotation": m["rotation"].reshape(-1, 4) + self._rot_bias, "global_trans": m["translation"], "t": t[0]}
+        m = self.pose_net(t[0], rot_bias=self._rot_bias)  # identity-quaternion bias of skeleton_warp.py:118
+        return {"local_rotation": m["rotation"].reshape(-1, 4), "global_trans": m["translation"], "t": t[0]}
 
     def forward(self, x, t, motion_mask, **kwargs):
         return self.deform_by_pose(x, self.get_pose_info(t), motion_mask)
@@ -309,7 +324,7 @@ class SkeletonWarp(nn.Module):
         self._check_variant()
         x = L.require_cuda_f32("x", x.detach(), (x.shape[0], 3))
         local_rot, global_trans = node_attrs["local_rotation"], node_attrs["global_trans"]
-        joints = self.nodes[:, :3].detach().contiguous()
+        joints = self._joints()
         par = self._parents_dev(x.device)
         mask = motion_mask
         if mask is not None and not isinstance(mask, torch.Tensor):
@@ -334,7 +349,7 @@ class SkeletonWarp(nn.Module):
 
     def node_deformation(self, x, node_attrs):
         x = x.detach()
-        joints = self.nodes[:, :3].detach().contiguous()
+        joints = self._joints()
         par = self._parents_dev(joints.device)
         local_rot = L.require_cuda_f32("local_rotation", node_attrs["local_rotation"], (joints.shape[0], 4))
         gt = L.require_cuda_f32("global_trans", node_attrs["global_trans"].reshape(-1), (3,))
