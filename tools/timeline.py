@@ -1,5 +1,6 @@
-"""Print the kernel timeline of the last full step found in a rocprofv3 rocpd database (kernel trace).
-usage: python tools/timeline.py <results.db> [anchor-kernel-substring]"""
+"""Print the kernel timeline of the fastest step (= a hipGraph replay) found in a rocprofv3 rocpd database.
+usage: python tools/timeline.py <results.db> [anchor-kernel-substring]
+  rocprofv3 --kernel-trace -d out -o kt -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline"""
 import sqlite3
 import sys
 
@@ -9,14 +10,14 @@ def main(db_path, anchor="pm_embed"):
     rows = db.execute("select name, start, end from kernels order by start").fetchall()
     idx = [i for i, r in enumerate(rows) if anchor in r[0]]
     if len(idx) < 3:
-        print("anchor not found"); return
-    a, b = idx[-3], idx[-2]
-    t0 = rows[a][1]
-    prev_end = t0
-    print("step period: %.1f us, %d kernels" % ((rows[b][1] - t0) / 1e3, b - a))
+        print("anchor not found")
+        return
+    period, k = min((rows[idx[j + 1]][1] - rows[idx[j]][1], j) for j in range(len(idx) - 1))
+    a, b = idx[k], idx[k + 1]
+    t0 = prev_end = rows[a][1]
+    print("step period: %.1f us, %d kernels" % (period / 1e3, b - a))
     for name, s, e in rows[a:b]:
-        short = name.split("(")[0][-60:]
-        print("%9.1f  dur %7.1f  gap %6.1f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3, short))
+        print("%8.1f  dur %6.1f  gap %5.1f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3, name.split("(")[0][-55:]))
         prev_end = max(prev_end, e)
 
 
