@@ -186,21 +186,29 @@ size_t riggs_lbs_backward_workspace_bytes(int32_t num_points, int32_t num_joints
  *   embedding of utils/time_utils.py:208-256 for input_dims = 1.
  * weights[l] / biases[l] are HOST arrays of `depth` DEVICE pointers to torch's nn.Linear tensors
  * (row-major (out, in)).  `acts` (riggs_pose_mlp_acts_floats floats) is written by forward and
- * read by backward.  backward writes every parameter gradient into ONE flat buffer laid out as
+ * read by backward (which also uses its tail — zeroed by forward — for its own hand-off state).  backward writes every parameter gradient into ONE flat buffer laid out as
  *   [W_0, b_0, ..., W_{depth-1}, b_{depth-1}, W_rot, b_rot, W_tr, b_tr]   (no gradient to t).
+ * sync_state (may be NULL): riggs_pose_mlp_sync_bytes bytes of device memory, ZEROED ONCE by the caller
+ * and then owned by this network (one launch in flight at a time): the forward runs as one launch whose
+ * workgroups hand the layer outputs to each other through it, and a generation counter inside makes
+ * every launch's tags unique.  With NULL a private copy inside `acts` is cleared by a memset node per call.
  * rot_bias4 (4 floats, may be NULL) is added to every predicted quaternion: the identity bias
  * [1,0,0,0] of skeleton_warp.py:118 folded into the head instead of a separate elementwise op.
  * ===================================================================== */
 size_t riggs_pose_mlp_acts_floats(int32_t depth, int32_t width, int32_t multires);
+size_t riggs_pose_mlp_sync_bytes(int32_t depth, int32_t width);
+/* debugging aid: 128 device u64 that workgroup 0 of the one-launch kernels stamps with the 100 MHz wall clock
+ * per stage (forward [0,64), backward [64,128)); NULL (the default) disables it. */
+int riggs_pose_mlp_set_trace(void* dev_u64x128);
 size_t riggs_pose_mlp_backward_workspace_floats(int32_t depth, int32_t width, int32_t multires);
 int riggs_pose_mlp_forward(int32_t depth, int32_t width, int32_t multires, int32_t skip, int32_t n_rot,
                            const float* const* weights, const float* const* biases, const float* W_rot,
                            const float* b_rot, const float* W_tr, const float* b_tr, const float* t,
-                           const float* rot_bias4, float* acts, float* rotation, float* translation,
-                           riggs_stream stream);
+                           const float* rot_bias4, void* sync_state, float* acts, float* rotation,
+                           float* translation, riggs_stream stream);
 int riggs_pose_mlp_backward(int32_t depth, int32_t width, int32_t multires, int32_t skip, int32_t n_rot,
                             const float* const* weights, const float* const* biases, const float* W_rot,
-                            const float* b_rot, const float* W_tr, const float* b_tr, const float* acts,
+                            const float* b_rot, const float* W_tr, const float* b_tr, float* acts,
                             const float* g_rotation, const float* g_translation, float* workspace,
                             float* flat_grads, riggs_stream stream);
 

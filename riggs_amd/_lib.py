@@ -52,7 +52,9 @@ _SIGS = {
     "riggs_lbs_backward_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "riggs_pose_mlp_acts_floats": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "riggs_pose_mlp_backward_workspace_floats": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
-    "riggs_pose_mlp_forward": (C.c_int, [C.c_int32] * 5 + [_P] * 12),
+    "riggs_pose_mlp_forward": (C.c_int, [C.c_int32] * 5 + [_P] * 13),
+    "riggs_pose_mlp_sync_bytes": (C.c_size_t, [C.c_int32] * 2),
+    "riggs_pose_mlp_set_trace": (C.c_int, [_P]),
     "riggs_pose_mlp_backward": (C.c_int, [C.c_int32] * 5 + [_P] * 12),
     "riggs_prof_count": (C.c_int, []),
     "riggs_prof_name": (C.c_char_p, [C.c_int32]),

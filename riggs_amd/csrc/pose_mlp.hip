@@ -178,6 +178,8 @@ __global__ __launch_bounds__(64) void pm_backward_weights_kernel(PoseMlpDesc d, 
 // word is set and the outputs are poisoned with NaN instead of hanging the queue.
 // =====================================================================================================
 #define PMF_WAVES 8
+// optional stage timestamps of workgroup 0 (riggs_pose_mlp_set_trace; 100 MHz wall clock)
+#define PM_TRACE(i) do { if (trace && blockIdx.x == 0 && threadIdx.x == 0) trace[i] = wall_clock64(); } while (0)
 #define PMF_SPIN_MAX (1u << 17)
 typedef __attribute__((address_space(1))) unsigned long long pm_gu64;
 
@@ -186,43 +188,104 @@ __device__ __forceinline__ void pm_store_granule(unsigned long long* g, uint32_t
                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// one wave re-reads its <= 4 granules per lane until every tag matches (wave-uniform exit)
+// one wave re-reads its <= 4 granules per lane until every tag matches (wave-uniform exit).  A granule
+// load is a round trip to the memory side (~1-2 us: the producers' write-through stores drop the line
+// from L2), so PMF_INFLIGHT sweeps are kept in flight and checked oldest first: the hand-off is seen one
+// load latency after it lands instead of up to two.
+#define PMF_INFLIGHT 4
+__device__ __forceinline__ void pm_sweep_issue(pm_gu64* g, int n, int lane, unsigned long long (&x)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int r = lane + 64 * k;
+    x[k] = (r < n) ? __hip_atomic_load(g + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+  }
+}
+__device__ __forceinline__ bool pm_sweep_check(const unsigned long long (&x)[4], int n, int lane, uint32_t tag,
+                                               float (&v)[4]) {
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    v[k] = __uint_as_float((uint32_t)x[k]);
+    if (lane + 64 * k < n) ok &= ((uint32_t)(x[k] >> 32) == tag);
+  }
+  return __all(ok);
+}
 __device__ __forceinline__ bool pm_sweep(const unsigned long long* gran, int n, uint32_t tag, float (&v)[4],
                                          uint32_t* err, int lane) {
   pm_gu64* g = (pm_gu64*)gran;
-  for (uint32_t spins = 0;; spins++) {
-    bool ok = true;
+  unsigned long long x[PMF_INFLIGHT][4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int r = lane + 64 * k;
-      if (r < n) {
-        const unsigned long long x = __hip_atomic_load(g + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        v[k] = __uint_as_float((uint32_t)x);
-        ok &= ((uint32_t)(x >> 32) == tag);
-      } else {
-        v[k] = 0.f;
-      }
+  for (int q = 0; q < PMF_INFLIGHT; q++) {
+    pm_sweep_issue(g, n, lane, x[q]);
+    __builtin_amdgcn_s_sleep(2);
+  }
+  for (uint32_t spins = 0;; spins++) {
+#pragma unroll
+    for (int q = 0; q < PMF_INFLIGHT; q++) {
+      if (pm_sweep_check(x[q], n, lane, tag, v)) return true;
+      pm_sweep_issue(g, n, lane, x[q]);
     }
-    if (__all(ok)) return true;
-    if (spins > PMF_SPIN_MAX) {
+    if (spins > PMF_SPIN_MAX / PMF_INFLIGHT) {
       if (lane == 0) atomicOr(err, 1u);
       return false;
     }
-    __builtin_amdgcn_s_sleep(1);
   }
 }
 
 __global__ __launch_bounds__(PMF_WAVES * 64) void pm_forward_fused_kernel(PoseMlpDesc d, const float* __restrict__ t,
                                                                           const float* __restrict__ rot_bias4,
                                                                           float* __restrict__ acts,
-                                                                          unsigned long long* gran, uint32_t* err,
+                                                                          unsigned long long* gran, uint32_t* gen,
+                                                                          uint32_t* bwd_state, int bwd_words,
                                                                           float* __restrict__ rotation,
-                                                                          float* __restrict__ translation) {
+                                                                          float* __restrict__ translation,
+                                                                          float* __restrict__ wt, int n_chain,
+                                                                          unsigned long long* trace) {
   __shared__ float s_in[PM_MAX_IN];
   __shared__ int s_failed;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if ((int)blockIdx.x >= n_chain) {
+    // ---- transposer workgroups (idle CUs, off the chain): WT_l[c][r] = M_l[r][off_l + c] for the backward,
+    // whose waves own COLUMNS: read in place a column costs 64 cache lines per load and ~12 us of per-CU
+    // miss latency at the head of that kernel; from WT it is one coalesced row like the forward's.
+    __shared__ float s_t[32][33];
+    const int emb_ = 1 + 2 * d.multires;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 16
+    const int tiles_per = (PM_MAX_W / 32) * (PM_MAX_W / 32);
+    for (int tile = blockIdx.x - n_chain; tile < d.depth * tiles_per; tile += gridDim.x - n_chain) {
+      const int l = 1 + tile / tiles_per, tt = tile % tiles_per;
+      const int r0 = (tt / (PM_MAX_W / 32)) * 32, c0 = (tt % (PM_MAX_W / 32)) * 32;
+      const bool heads = (l == d.depth);
+      const int in_dim = pm_in_dim(d, l, emb_);
+      const int off = (l - 1 == d.skip) ? emb_ : 0;
+      const int n_rows = heads ? d.n_rot + 3 : d.width;
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int r = r0 + ty + 16 * h, c = c0 + tx;
+        float v = 0.f;
+        if (r < n_rows && c < d.width) {
+          const float* rp = !heads ? d.W[l] + (size_t)r * in_dim
+                                   : (r < d.n_rot ? d.W_rot + (size_t)r * in_dim : d.W_tr + (size_t)(r - d.n_rot) * in_dim);
+          v = rp[off + c];
+        }
+        s_t[ty + 16 * h][tx] = v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+        wt[((size_t)(l - 1) * PM_MAX_W + c0 + ty + 16 * h) * PM_MAX_W + r0 + tx] = s_t[tx][ty + 16 * h];
+      __syncthreads();
+    }
+    return;
+  }
   const int row = blockIdx.x * PMF_WAVES + wave;
   const int emb = 1 + 2 * d.multires;
+  uint32_t* err = bwd_state;  // {err, gen, pad, pad, backward granules...}: cleared here for the backward launch
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < bwd_words; i += n_chain * blockDim.x) bwd_state[i] = 0u;
+  // `gen` (persistent across launches, bumped by workgroup 0 at the end) makes this launch's tags unique:
+  // granules left by the previous launch — or replay — never match, so no per-launch memset is needed
+  const uint32_t tag0 = __hip_atomic_load((__attribute__((address_space(1))) uint32_t*)gen, __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT) * 32u;
   // ---- every weight this wave will ever need, in flight at once
   float w[PM_MAX_LAYERS + 1][PM_CPL];
   float bias[PM_MAX_LAYERS + 1];
@@ -262,6 +325,7 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_forward_fused_kernel(PoseMl
     if (wave == 0 && blockIdx.x == 0) acts[lane] = embv;
   }
   if (threadIdx.x == 0) s_failed = 0;
+  PM_TRACE(0);
   __syncthreads();
 #pragma unroll
   for (int l = 0; l <= PM_MAX_LAYERS; l++) {
@@ -269,12 +333,13 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_forward_fused_kernel(PoseMl
       const bool heads = (l == d.depth);
       const int n_out = heads ? d.n_rot + 3 : d.width;
       const int in_dim = pm_in_dim(d, l, emb);
+      PM_TRACE(1 + 2 * l);
       if (l > 0) {
         if (wave == 0) {
           // input of layer l = h_{l-1} (behind the embedding when layer l-1 was the skip layer)
           float v[4];
           bool ok = (s_failed == 0);
-          if (ok) ok = pm_sweep(gran + (size_t)(l - 1) * d.width, d.width, (uint32_t)l, v, err, lane);
+          if (ok) ok = pm_sweep(gran + (size_t)(l - 1) * d.width, d.width, tag0 + (uint32_t)l, v, err, lane);
           if (!ok && lane == 0) s_failed = 1;
           const int off = (l - 1 == d.skip) ? emb : 0;
           if (off > 0 && lane < emb) s_in[lane] = embv;
@@ -293,12 +358,13 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_forward_fused_kernel(PoseMl
         if (i < in_dim) acc += w[l][k] * s_in[i];
       }
       acc = wave_sum(acc);
+      PM_TRACE(2 + 2 * l);
       if (lane == 63 && row < n_out) {
         float v = acc + bias[l];
         if (s_failed) v = __builtin_nanf("");
         if (!heads) {
           v = s_failed ? v : fmaxf(v, 0.f);
-          pm_store_granule(gran + (size_t)l * d.width + row, (uint32_t)(l + 1), v);
+          pm_store_granule(gran + (size_t)l * d.width + row, tag0 + (uint32_t)(l + 1), v);
           acts[emb + (size_t)l * d.width + row] = v;
         } else if (row < d.n_rot) {
           rotation[row] = rot_bias4 ? v + rot_bias4[row & 3] : v;
@@ -309,54 +375,69 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_forward_fused_kernel(PoseMl
       __syncthreads();  // s_in is rewritten by wave 0 for the next layer
     }
   }
+  // workgroup 0 has swept the last hidden layer, which every workgroup published after reading `gen`
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    __hip_atomic_store((__attribute__((address_space(1))) uint32_t*)gen, tag0 / 32u + 1u, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Backward chain in one launch.  Wave `col` owns hidden unit `col`: column (off_l + col) of every consumer
 // matrix l >= 1 (registers), and row `col` of every weight-gradient matrix.  Stage l (depth .. 0):
 //   v_l = dz_l (the heads: the incoming output gradients) -> LDS, from the granules of stage l + 1;
-//   D_l[col] = sum_r M_l[r][off_l + col] v_l[r]  -> granule (tag l), the gradient w.r.t. h_{l-1};
-//   dW_l[col][:] = v_l[col] * input_l[:], db_l[col] = v_l[col]  (plain stores, off the critical path).
+//   D_l[col] = sum_r M_l[r][off_l + col] v_l[r]  -> granule, the gradient w.r.t. h_{l-1};
+//   dW_l[col][:] = v_l[col] * input_l[:], db_l[col] = v_l[col]  (plain stores, off the critical path: the
+//   sweeping wave 0 postpones its own rows to the end, the others write while wave 0 polls).
+// The granules live behind the forward's in `acts` (zeroed by the forward's memset node, so the backward
+// needs none); tags carry a generation word that the last stage bumps, so a second backward over the same
+// activations (retain_graph) never matches the first one's granules.
 __global__ __launch_bounds__(PMF_WAVES * 64) void pm_backward_fused_kernel(PoseMlpDesc d, PoseMlpGradDesc g,
                                                                            const float* __restrict__ acts,
                                                                            const float* __restrict__ g_rot,
                                                                            const float* __restrict__ g_tr,
                                                                            unsigned long long* gran, uint32_t* err,
-                                                                           float* __restrict__ flat) {
+                                                                           uint32_t* gen, float* __restrict__ flat,
+                                                                           const float* __restrict__ wt,
+                                                                           unsigned long long* trace) {
   __shared__ float s_v[PM_MAX_W];
   __shared__ int s_failed;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = blockIdx.x * PMF_WAVES + wave;
   const int emb = 1 + 2 * d.multires;
   const int n_head = d.n_rot + 3;
+  const uint32_t tag0 = __hip_atomic_load((__attribute__((address_space(1))) uint32_t*)gen, __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT) * 32u;
+  // ---- this wave's column of every consumer matrix, from the transposed copy the forward launch left in
+  // `wt` (one coalesced 1 KB row per matrix), and the forward activations (8 KB) into LDS: no global load
+  // is left on the chain or in the weight-gradient rows
   float wc[PM_MAX_LAYERS + 1][4];
 #pragma unroll
   for (int l = 1; l <= PM_MAX_LAYERS; l++) {
 #pragma unroll
     for (int k = 0; k < 4; k++) wc[l][k] = 0.f;
     if (l <= d.depth && col < d.width) {
-      const bool heads = (l == d.depth);
-      const int in_dim = pm_in_dim(d, l, emb);
-      const int c = ((l - 1 == d.skip) ? emb : 0) + col;
-      const int n_rows = heads ? n_head : d.width;
+      const int n_rows = (l == d.depth) ? n_head : d.width;
+      const float* rp = wt + ((size_t)(l - 1) * PM_MAX_W + col) * PM_MAX_W;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const int r = lane + 64 * k;
-        if (r < n_rows) {
-          const float* rp = !heads ? d.W[l] + (size_t)r * in_dim
-                                   : (r < d.n_rot ? d.W_rot + (size_t)r * in_dim : d.W_tr + (size_t)(r - d.n_rot) * in_dim);
-          wc[l][k] = rp[c];
-        }
+        if (r < n_rows) wc[l][k] = rp[r];
       }
     }
   }
+  __shared__ float s_acts[PM_MAX_EMB + PM_MAX_LAYERS * PM_MAX_W];
+  __shared__ float s_late[PM_MAX_LAYERS + 1];
+  for (int i = threadIdx.x; i < emb + d.depth * d.width; i += blockDim.x) s_acts[i] = acts[i];
   if (threadIdx.x == 0) s_failed = 0;
+  PM_TRACE(0);
   __syncthreads();
+  PM_TRACE(1);
 #pragma unroll
   for (int l = PM_MAX_LAYERS; l >= 0; l--) {
     if (l <= d.depth) {
       const bool heads = (l == d.depth);
       const int n_rows = heads ? n_head : d.width;
       const int in_dim = pm_in_dim(d, l, emb);
+      PM_TRACE(2 + 2 * (d.depth - l));
       if (wave == 0) {
         if (heads) {
 #pragma unroll
@@ -369,11 +450,11 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_backward_fused_kernel(PoseM
 #pragma unroll
           for (int k = 0; k < 4; k++) {
             const int r = lane + 64 * k;
-            h[k] = (r < d.width) ? acts[emb + (size_t)l * d.width + r] : 0.f;
+            h[k] = (r < d.width) ? s_acts[emb + (size_t)l * d.width + r] : 0.f;
           }
           float v[4];
           bool ok = (s_failed == 0);
-          if (ok) ok = pm_sweep(gran + (size_t)l * d.width, d.width, (uint32_t)(l + 1), v, err, lane);
+          if (ok) ok = pm_sweep(gran + (size_t)l * d.width, d.width, tag0 + (uint32_t)(l + 1), v, err, lane);
           if (!ok && lane == 0) s_failed = 1;
 #pragma unroll
           for (int k = 0; k < 4; k++) {
@@ -383,29 +464,64 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_backward_fused_kernel(PoseM
         }
       }
       __syncthreads();
-      const bool failed = (s_failed != 0);
-      // (a) the chain: gradient w.r.t. h_{l-1}, published for stage l - 1   [granule slot l - 1, tag l]
+      PM_TRACE(3 + 2 * (d.depth - l));
+      float sv[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) sv[k] = s_v[lane + 64 * k];
+      float vr = (col < n_rows) ? s_v[col] : 0.f;
+      if (s_failed) vr = __builtin_nanf("");
+      __syncthreads();  // s_v may be rewritten by wave 0 from here on
+      // (a) the chain: gradient w.r.t. h_{l-1}, published for stage l - 1   [granule slot l - 1]
       if (l >= 1) {
         float acc = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           const int r = lane + 64 * k;
-          if (r < n_rows) acc += wc[l][k] * s_v[r];
+          if (r < n_rows) acc += wc[l][k] * sv[k];
         }
         acc = wave_sum(acc);
-        if (lane == 63 && col < d.width) pm_store_granule(gran + (size_t)(l - 1) * d.width + col, (uint32_t)l, acc);
+        if (lane == 63 && col < d.width) pm_store_granule(gran + (size_t)(l - 1) * d.width + col, tag0 + (uint32_t)l, acc);
       }
       // (b) weight / bias gradients of matrix l, row `col`
-      if (col < n_rows) {
+      if (wave == 0) {
+        if (lane == 0) s_late[l] = vr;  // written out after the chain, shared among the eight waves
+      } else if (col < n_rows) {
         int m = l, r = col;
         if (heads && col >= d.n_rot) { m = d.depth + 1; r = col - d.n_rot; }
-        const float vr = failed ? __builtin_nanf("") : s_v[col];
         float* out = flat + g.w_off[m] + (size_t)r * in_dim;
-        for (int c = lane; c < in_dim; c += 64) out[c] = vr * pm_input(d, acts, l, emb, c);
+        for (int c = lane; c < in_dim; c += 64) out[c] = vr * pm_input(d, s_acts, l, emb, c);
         if (lane == 0) flat[g.b_off[m] + r] = vr;
       }
-      __syncthreads();  // s_v is rewritten by wave 0 for the next stage
     }
+  }
+  PM_TRACE(4 + 2 * d.depth);
+  __syncthreads();
+  {
+    // wave 0's own rows (it was busy polling): matrix l goes to wave l % 8
+    const int col0 = blockIdx.x * PMF_WAVES;
+#pragma unroll
+    for (int l = PM_MAX_LAYERS; l >= 0; l--) {
+      if (l <= d.depth && (l % PMF_WAVES) == wave) {
+        const bool heads = (l == d.depth);
+        const int n_rows = heads ? n_head : d.width;
+        const int in_dim = pm_in_dim(d, l, emb);
+        if (col0 < n_rows) {
+          int m = l, r = col0;
+          if (heads && col0 >= d.n_rot) { m = d.depth + 1; r = col0 - d.n_rot; }
+          const float vr = s_late[l];
+          float* out = flat + g.w_off[m] + (size_t)r * in_dim;
+          for (int c = lane; c < in_dim; c += 64) out[c] = vr * pm_input(d, s_acts, l, emb, c);
+          if (lane == 0) flat[g.b_off[m] + r] = vr;
+        }
+      }
+    }
+  }
+  if (wave == 0) {
+    PM_TRACE(5 + 2 * d.depth);
+    // workgroup 0 has swept the last stage, i.e. every workgroup has read `gen`: bump it for a later backward
+    if (blockIdx.x == 0 && lane == 0)
+      __hip_atomic_store((__attribute__((address_space(1))) uint32_t*)gen, tag0 / 32u + 1u, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -428,36 +544,50 @@ static int pm_fill(PoseMlpDesc& d, int32_t depth, int32_t width, int32_t multire
   return 0;
 }
 
+static unsigned long long* g_pm_trace = nullptr;  // 128 u64: forward stamps [0,64), backward stamps [64,128)
+int riggs_pose_mlp_set_trace(void* dev_u64x128) { g_pm_trace = (unsigned long long*)dev_u64x128; return 0; }
+
 static bool pm_layered() {
   static const bool v = getenv("RIGGS_POSE_MLP_LAYERED") != nullptr;  // A/B switch: one launch per layer
   return v;
 }
-// activations, then (8-byte aligned) the hand-off granules of the one-launch kernel and its error word
+// acts: activations, then (256-byte aligned) the state of the one-launch kernels:
+//   [forward granules + gen (used when the caller passes no persistent sync_state) | err, gen, pad, pad | backward granules]
 static size_t pm_acts_core(int32_t depth, int32_t width, int32_t multires) {
-  return ((size_t)(1 + 2 * multires) + (size_t)depth * width + 1) & ~(size_t)1;
+  return ((size_t)(1 + 2 * multires) + (size_t)depth * width + 63) & ~(size_t)63;
 }
+static size_t pm_sync_floats(int32_t depth, int32_t width) {  // granules (2 floats each) + {gen, pad...}
+  return (2 * (size_t)depth * width + 4 + 63) & ~(size_t)63;
+}
+size_t riggs_pose_mlp_sync_bytes(int32_t depth, int32_t width) { return pm_sync_floats(depth, width) * sizeof(float); }
+// ... then the transposed consumer matrices (depth x 256 x 256) the forward launch prepares for the backward
 size_t riggs_pose_mlp_acts_floats(int32_t depth, int32_t width, int32_t multires) {
-  return pm_acts_core(depth, width, multires) + 2 * (size_t)depth * width + 4;
+  return pm_acts_core(depth, width, multires) + 2 * pm_sync_floats(depth, width) + (size_t)depth * PM_MAX_W * PM_MAX_W;
 }
 
 int riggs_pose_mlp_forward(int32_t depth, int32_t width, int32_t multires, int32_t skip, int32_t n_rot,
                            const float* const* weights, const float* const* biases, const float* W_rot,
                            const float* b_rot, const float* W_tr, const float* b_tr, const float* t,
-                           const float* rot_bias4, float* acts, float* rotation, float* translation,
-                           riggs_stream stream) {
+                           const float* rot_bias4, void* sync_state, float* acts, float* rotation,
+                           float* translation, riggs_stream stream) {
   PoseMlpDesc d;
   int rc = pm_fill(d, depth, width, multires, skip, n_rot, weights, biases, W_rot, b_rot, W_tr, b_tr);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(PROF_POSE_FWD, s);
-  if (!pm_layered()) {
-    float* gr = acts + pm_acts_core(depth, width, multires);
-    const size_t gbytes = (2 * (size_t)depth * width + 4) * sizeof(float);
-    RIGGS_HIP_CHECK(hipMemsetAsync(gr, 0, gbytes, s));  // tags 0 = "not written yet" (replayed with the graph)
-    const int rows = width > n_rot + 3 ? width : n_rot + 3;
-    hipLaunchKernelGGL(pm_forward_fused_kernel, dim3((rows + PMF_WAVES - 1) / PMF_WAVES), dim3(PMF_WAVES * 64), 0, s, d, t,
-                       rot_bias4, acts, (unsigned long long*)gr, (uint32_t*)(gr + 2 * (size_t)depth * width), rotation,
-                       translation);
+  if (!pm_layered() && n_rot + 3 <= width) {
+    const size_t sf = pm_sync_floats(depth, width);
+    float* own = acts + pm_acts_core(depth, width, multires);  // [own forward state | backward state]
+    float* fs = (float*)sync_state;
+    if (fs == nullptr) {
+      // no persistent state from the caller: clear a private one every launch (one aligned memset node)
+      fs = own;
+      RIGGS_HIP_CHECK(hipMemsetAsync(fs, 0, sf * sizeof(float), s));
+    }
+    const int n_chain = (width + PMF_WAVES - 1) / PMF_WAVES;  // + 64 transposer workgroups on otherwise idle CUs
+    hipLaunchKernelGGL(pm_forward_fused_kernel, dim3(n_chain + 64), dim3(PMF_WAVES * 64), 0, s, d, t, rot_bias4, acts,
+                       (unsigned long long*)fs, (uint32_t*)(fs + 2 * (size_t)depth * width), (uint32_t*)(own + sf), (int)sf,
+                       rotation, translation, own + 2 * sf, n_chain, g_pm_trace);
     RIGGS_HIP_CHECK(hipGetLastError());
     return 0;
   }
@@ -475,12 +605,12 @@ static size_t pm_bwd_core(int32_t depth, int32_t width) {
 }
 size_t riggs_pose_mlp_backward_workspace_floats(int32_t depth, int32_t width, int32_t multires) {
   (void)multires;
-  return pm_bwd_core(depth, width) + 2 * (size_t)depth * width + 4;
+  return pm_bwd_core(depth, width);  // used by the layered (one launch per layer) variant only
 }
 
 int riggs_pose_mlp_backward(int32_t depth, int32_t width, int32_t multires, int32_t skip, int32_t n_rot,
                             const float* const* weights, const float* const* biases, const float* W_rot,
-                            const float* b_rot, const float* W_tr, const float* b_tr, const float* acts,
+                            const float* b_rot, const float* W_tr, const float* b_tr, float* acts,
                             const float* g_rotation, const float* g_translation, float* workspace,
                             float* flat_grads, riggs_stream stream) {
   PoseMlpDesc d;
@@ -508,14 +638,13 @@ int riggs_pose_mlp_backward(int32_t depth, int32_t width, int32_t multires, int3
   g.row_start[depth + 1] = rows; rows += 3;
   g.row_start[depth + 2] = rows;
   ProfScope ps(PROF_POSE_BWD, s);
-  if (!pm_layered()) {
-    float* gr = workspace + pm_bwd_core(depth, width);
-    const size_t gbytes = (2 * (size_t)depth * width + 4) * sizeof(float);
-    RIGGS_HIP_CHECK(hipMemsetAsync(gr, 0, gbytes, s));
-    const int nr = width > n_rot + 3 ? width : n_rot + 3;
+  if (!pm_layered() && n_rot + 3 <= width) {
+    float* tail = acts + pm_acts_core(depth, width, multires) + pm_sync_floats(depth, width);
+    const int nr = width;
     hipLaunchKernelGGL(pm_backward_fused_kernel, dim3((nr + PMF_WAVES - 1) / PMF_WAVES), dim3(PMF_WAVES * 64), 0, s, d, g,
-                       acts, g_rotation, g_translation, (unsigned long long*)gr,
-                       (uint32_t*)(gr + 2 * (size_t)depth * width), flat_grads);
+                       acts, g_rotation, g_translation, (unsigned long long*)(tail + 4), (uint32_t*)tail,
+                       (uint32_t*)tail + 1, flat_grads, tail + pm_sync_floats(depth, width),
+                       g_pm_trace ? g_pm_trace + 64 : nullptr);
     RIGGS_HIP_CHECK(hipGetLastError());
     return 0;
   }

@@ -45,6 +45,10 @@ class PoseMLP(nn.Module):
                else nn.Linear(hidden_dimensions + input_ch, hidden_dimensions) for i in range(depth - 1)])
         self.rotation_predictor = nn.Linear(hidden_dimensions, output_ch)
         self.translation_predictor = nn.Linear(hidden_dimensions, 3)
+        # hand-off state of the one-launch HIP forward (include/riggs_hip.h: sync_state): zeroed once, here
+        # (never inside a hipGraph capture), then owned by the kernel; follows the module across .cuda()/.to()
+        self.register_buffer("_hip_sync", torch.zeros(2 * depth * hidden_dimensions + 64, dtype=torch.int32),
+                             persistent=False)
 
     def _fusable(self, t):
         w = self.net[0].out_features
@@ -61,8 +65,12 @@ class PoseMLP(nn.Module):
                 params += [l.weight, l.bias]
             params += [self.rotation_predictor.weight, self.rotation_predictor.bias,
                        self.translation_predictor.weight, self.translation_predictor.bias]
+            sync = self._hip_sync
+            if sync.device != t.device or sync.numel() * 4 < L.lib().riggs_pose_mlp_sync_bytes(len(self.net),
+                                                                                                   self.net[0].out_features):
+                sync = None  # the library then clears a private state per call
             rot, tr = _PoseMLPFn.apply(t.reshape(1), len(self.net), self.net[0].out_features, self.multires,
-                                       self.skips[0], rot_bias, *params)
+                                       self.skips[0], rot_bias, sync, *params)
             return {"rotation": rot, "translation": tr}
         t_emb = _embed(t, self.multires) if self.multires > 0 else t
         h = t_emb + 0.0
@@ -87,7 +95,7 @@ class _PoseMLPFn(torch.autograd.Function):
         return Wp, bp
 
     @staticmethod
-    def forward(ctx, t, depth, width, multires, skip, rot_bias, *params):
+    def forward(ctx, t, depth, width, multires, skip, rot_bias, sync, *params):
         ctx.set_materialize_grads(False)
         params = [p.contiguous() for p in params]
         lib = L.lib()
@@ -100,7 +108,7 @@ class _PoseMLPFn(torch.autograd.Function):
         h = params[2 * depth:]
         L.check(lib.riggs_pose_mlp_forward(depth, width, multires, skip, n_rot, Wp, bp, h[0].data_ptr(),
                                            h[1].data_ptr(), h[2].data_ptr(), h[3].data_ptr(), t.data_ptr(),
-                                           L.ptr(rot_bias), acts.data_ptr(), rot.data_ptr(), tr.data_ptr(), L.stream_ptr()),
+                                           L.ptr(rot_bias), L.ptr(sync), acts.data_ptr(), rot.data_ptr(), tr.data_ptr(), L.stream_ptr()),
                 "riggs_pose_mlp_forward")
         ctx.save_for_backward(acts, *params)
         ctx.cfg = (depth, width, multires, skip, n_rot)
@@ -129,7 +137,7 @@ class _PoseMLPFn(torch.autograd.Function):
             n = p.numel()
             grads.append(flat[o:o + n].view_as(p))
             o += n
-        return (None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, *grads)
 
 
 # --------------------------------------------------------------------------- HIP ops
