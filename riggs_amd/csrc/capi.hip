@@ -206,6 +206,11 @@ static int fill_pre_args(PreArgs& a, const riggs_raster_cfg* c, const float* mea
   return 0;
 }
 
+static bool render_cull() {
+  static const bool v = getenv("RIGGS_RENDER_NOCULL") == nullptr;  // A/B switch
+  return v;
+}
+
 int riggs_raster_preprocess(const riggs_raster_cfg* cfg, const float* means3D, const float* shs,
                             const float* shs_rest, const float* colors_precomp, const float* opacities, const float* scales,
                             const float* rotations, const float* cov3D_precomp, const float* d_xyz,
@@ -304,6 +309,7 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
   }
   RenderArgs r;
   r.W = W; r.H = H;
+  r.cull = render_cull() ? 1 : 0;
   r.ranges = (const uint2*)(img + I.ranges);
   r.point_list = point_list;
   r.xyd = (const float4*)(geom + G.xyd); r.conic_o = (const float4*)(geom + G.conic_o); r.rgb = (const float4*)(geom + G.rgb);
@@ -349,6 +355,7 @@ int riggs_raster_backward(const riggs_raster_cfg* cfg, const float* means3D, con
   BinLayout B = bin_layout(cap, N, H, W);
   RenderBwdArgs r;
   r.n_points = N;
+  r.cull = render_cull() ? 1 : 0;
   r.W = W; r.H = H;
   r.ranges = (const uint2*)(img + I.ranges);
   r.point_list = (const uint32_t*)(bin + B.vals_b);

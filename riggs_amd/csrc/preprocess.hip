@@ -190,10 +190,19 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a) {
     cl = (uint8_t)((r0 < 0.f ? 1 : 0) | (r1 < 0.f ? 2 : 0) | (r2 < 0.f ? 4 : 0));
     rgbv[0] = fmaxf(r0, 0.f); rgbv[1] = fmaxf(r1, 0.f); rgbv[2] = fmaxf(r2, 0.f);
   }
+  // axis-aligned half extents of the region where alpha = o * exp(power) can reach 1/255 (the compositing
+  // kernels cull instances against pixel blocks with it): q(d) <= tau = 2 ln(255 o), x-extent sqrt(tau * Sxx).
+  // Conservative: tau carries a +0.05 margin (2.5 % in alpha) — far above any rounding of cov / conic / exp.
+  float cull_hx = -1e30f, cull_hy = -1e30f;
+  {
+    const float tau = 2.0f * logf(255.0f * g.o) + 0.05f;
+    if (tau > 0.0f) { cull_hx = sqrtf(tau * cv.a) + 0.01f; cull_hy = sqrtf(tau * cv.c) + 0.01f; }
+    if (!(cull_hx == cull_hx) || !(cull_hy == cull_hy)) { cull_hx = 1e30f; cull_hy = 1e30f; }  // NaN: never cull
+  }
   a.radii[i] = ir;
-  a.xyd[i] = make_float4(px, py, vz, 0.f);
+  a.xyd[i] = make_float4(px, py, vz, cull_hx);
   a.conic_o[i] = make_float4(cv.c * det_inv, -cv.b * det_inv, cv.a * det_inv, g.o);
-  a.rgb[i] = make_float4(rgbv[0], rgbv[1], rgbv[2], 0.f);
+  a.rgb[i] = make_float4(rgbv[0], rgbv[1], rgbv[2], cull_hy);
 #pragma unroll
   for (int k = 0; k < 6; k++) a.cov3D[6 * i + k] = c6[k];
   a.clamped[i] = cl;

@@ -33,6 +33,7 @@ int launch_preprocess_bwd(const PreBwdArgs& b, hipStream_t s);
 
 struct RenderArgs {
   int W, H;
+  int cull;  // instance culling against pixel blocks (RIGGS_RENDER_NOCULL=1 turns it off)
   const uint2* ranges;
   const uint32_t* point_list;
   const float4 *xyd, *conic_o, *rgb;
@@ -51,6 +52,7 @@ int launch_slot_base(int64_t n, int n_tiles, const uint32_t* keys_sorted, const 
                      uint32_t* slot_base, hipStream_t s);
 
 struct RenderBwdArgs {
+  int cull;  // instance culling against pixel blocks (RIGGS_RENDER_NOCULL=1 turns it off)
   int W, H;
   const uint2* ranges;
   const uint32_t* point_list;

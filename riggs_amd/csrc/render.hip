@@ -234,15 +234,18 @@ __device__ __forceinline__ float quad_sum(float v) {
   return v;
 }
 
+// Most instances of a tile's list never reach a given 16 x 4 pixel block (the lists are built from the
+// 3-sigma tile rectangles; >90 % of the bench scene's pixels never saturate, so their waves walk the WHOLE
+// list of up to 47k instances): while a batch is staged, every instance is tested against the workgroup's
+// block with the axis-aligned extent of its alpha >= 1/255 ellipse (xyd.w / rgb.w, from the preprocess
+// kernel; conservative) and only the survivors are kept, compacted per 64-instance chunk so that the
+// checkpoints of the backward stay at multiples of 64 of the ORIGINAL list position.
 __global__ __launch_bounds__(256) void render_fwd_quad_kernel(RenderArgs a) {
-  __shared__ float4 s_xyd[256 + 8];
-  __shared__ float4 s_con[256 + 8];
-  __shared__ float4 s_rgb[256 + 8];
-  if (threadIdx.x < 8) {  // permanent null records behind a full batch
-    s_xyd[256 + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
-    s_con[256 + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
-    s_rgb[256 + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
+  __shared__ float4 s_xyd[256];
+  __shared__ float4 s_con[256];
+  __shared__ float4 s_rgb[256];
+  __shared__ unsigned short s_pos[256];  // position of the survivor inside its batch
+  __shared__ int s_cnt[4];               // survivors per chunk
   const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE;
   const int tile = blockIdx.x >> 2, sub = blockIdx.x & 3;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -256,6 +259,8 @@ __global__ __launch_bounds__(256) void render_fwd_quad_kernel(RenderArgs a) {
   const int total = (int)(range.y - range.x);
   const uint32_t slot0 = a.slot_base[tile];
   const int pix = prow * 16 + qx;                        // pixel index inside the tile (checkpoint layout)
+  const float bx0 = (float)((tile % gx) * RIGGS_TILE), bx1 = bx0 + (float)(RIGGS_TILE - 1);
+  const float by0 = (float)((tile / gx) * RIGGS_TILE + sub * 4), by1 = by0 + 3.0f;
   bool done = !inside;
   float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f, Tstop = -1.0f;
   uint32_t last = 0;
@@ -267,14 +272,25 @@ __global__ __launch_bounds__(256) void render_fwd_quad_kernel(RenderArgs a) {
   }
   for (int base = 0; base < total; base += 256) {
     if (__syncthreads_count(done) == 256) break;
-    s_xyd[tid] = n_xy; s_con[tid] = n_co; s_rgb[tid] = n_cc;   // threads beyond the batch hold null records
+    {
+      const bool keep = (base + tid < total) && (!a.cull || ((n_xy.x + n_xy.w >= bx0) && (n_xy.x - n_xy.w <= bx1) &&
+                                                            (n_xy.y + n_cc.w >= by0) && (n_xy.y - n_cc.w <= by1)));
+      const uint64_t mask = __builtin_amdgcn_ballot_w64(keep);
+      const int cnt = __builtin_popcountll(mask);
+      const int slot = wave * 64 + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+      if (keep) { s_xyd[slot] = n_xy; s_con[slot] = n_co; s_rgb[slot] = n_cc; s_pos[slot] = (unsigned short)tid; }
+      if (lane >= cnt && lane < ((cnt + 7) & ~7)) {  // null records up to the next multiple of 8
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_xyd[wave * 64 + lane] = z; s_con[wave * 64 + lane] = z; s_rgb[wave * 64 + lane] = z; s_pos[wave * 64 + lane] = 0;
+      }
+      if (lane == 0) s_cnt[wave] = cnt;
+    }
     __syncthreads();
     n_xy = make_float4(0.f, 0.f, 0.f, 0.f); n_co = n_xy; n_cc = n_xy;
     if (base + 256 + tid < total) {
       const uint32_t id = a.point_list[range.x + base + 256 + tid];
       n_xy = a.xyd[id]; n_co = a.conic_o[id]; n_cc = a.rgb[id];
     }
-    const int nb = min(256, total - base);
     // one quad step: four consecutive instances (one per lane of the quad) of this lane's pixel
     auto quad_step = [&](float alpha, bool valid_in, float depth, const float4 c, int pos1) {
       const bool valid = valid_in && !done;
@@ -303,16 +319,21 @@ __global__ __launch_bounds__(256) void render_fwd_quad_kernel(RenderArgs a) {
     };
     // two quad steps (8 instances) per iteration: the falloff of the second step overlaps the
     // dependent transmittance chain of the first
-    for (int g = 0; g < nb; g += 8) {
+    for (int k = 0; k < 4; k++) {
+      const int cbase = base + 64 * k;
+      if (cbase >= total) break;
       if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
-      if (((base + g) & 63) == 0) {
-        // checkpoint of the state BEFORE instance base+g: fold the quad's partial sums
+      {
+        // checkpoint of the state BEFORE instance cbase: fold the quad's partial sums
         const float k0 = quad_sum(C0), k1 = quad_sum(C1), k2 = quad_sum(C2), kd = quad_sum(D);
         if (!done && j == 0) {
-          float* ck = a.ckpt + ((size_t)(slot0 + ((base + g) >> 6)) * 5) * 256 + pix;
+          float* ck = a.ckpt + ((size_t)(slot0 + (cbase >> 6)) * 5) * 256 + pix;
           ck[0] = T; ck[256] = k0; ck[512] = k1; ck[768] = k2; ck[1024] = kd;
         }
       }
+      const int nk = s_cnt[k];
+    for (int g = 64 * k; g < 64 * k + nk; g += 8) {
+      if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
       const float4 xyA = s_xyd[g + j], coA = s_con[g + j];
       const float4 xyB = s_xyd[g + 4 + j], coB = s_con[g + 4 + j];
       const float dxA = xyA.x - pfx, dyA = xyA.y - pfy, dxB = xyB.x - pfx, dyB = xyB.y - pfy;
@@ -324,8 +345,9 @@ __global__ __launch_bounds__(256) void render_fwd_quad_kernel(RenderArgs a) {
       const bool vB = (pwB <= 0.0f) && (alB >= ALPHA_MIN);
       if (__builtin_amdgcn_ballot_w64((vA || vB) && !done) == 0) continue;
       const float4 cA = s_rgb[g + j], cB = s_rgb[g + 4 + j];
-      quad_step(alA, vA, xyA.z, cA, base + g + j + 1);
-      quad_step(alB, vB, xyB.z, cB, base + g + 4 + j + 1);
+      quad_step(alA, vA, xyA.z, cA, base + (int)s_pos[g + j] + 1);
+      quad_step(alB, vB, xyB.z, cB, base + (int)s_pos[g + 4 + j] + 1);
+    }
     }
   }
   // fold the quad

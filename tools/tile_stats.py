@@ -34,3 +34,9 @@ fT = v["final_T"].cpu().numpy()
 print("pixels with T<1e-3:", (fT < 1e-3).mean(), " mean final T", fT.mean())
 vis = (radii > 0).sum().item()
 print("visible", vis, "tiles/gaussian", v["R"] / vis, "mean radius", radii[radii > 0].float().mean().item())
+ne = tile_max[L > 0]
+print("tile_max percentiles (non-empty tiles): p10 %d p50 %d p90 %d p99 %d max %d" % tuple(np.percentile(ne, [10, 50, 90, 99, 100])))
+print("histogram of tile_max (bins of 256):", np.bincount((ne // 256).astype(np.int64)).tolist())
+rowmax = ncp.reshape(gy * 16, gx, 16).max(axis=2)  # per (pixel row, tile column): the chain one forward wave walks
+rm = rowmax[rowmax > 0]
+print("per-wave chain (row of 16 pixels) percentiles: p50 %d p90 %d p99 %d max %d  n %d" % (*np.percentile(rm, [50, 90, 99, 100]), rm.size))
