@@ -728,41 +728,50 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderBwdArgs a) {
     }
     float a_mx = 0.f, a_my = 0.f, a_ca = 0.f, a_cb = 0.f, a_cc = 0.f, a_op = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f, a_d = 0.f;
     // (the wave only touches its own LDS region: LDS operations of one wave are ordered, no barrier needed)
-    for (int pl = 0; pl < 64; pl++) {
-      const float4 pa = s_pa[wave][pl];
-      const int n = (int)__float_as_uint(pa.w);
-      if (n <= pos0) continue;  // wave-uniform: this chunk lies behind the pixel's last contributor
-      const int pix = quarter * 64 + pl;
+    // two pixels per iteration: their scans are independent chains that the scheduler interleaves (a lone
+    // chain leaves the SIMD idle through every DPP / transcendental latency)
+    for (int pl = 0; pl < 64; pl += 2) {
+      const float4 paA = s_pa[wave][pl], paB = s_pa[wave][pl + 1];
+      const int nA = (int)__float_as_uint(paA.w), nB = (int)__float_as_uint(paB.w);
+      if (nA <= pos0 && nB <= pos0) continue;  // wave-uniform: this chunk lies behind both pixels' last contributors
+      const int pix = quarter * 64 + pl;       // pl is even: both pixels are in the same row
       const float pfx = (float)(tx0 + (pix & 15)), pfy = (float)(ty0 + (pix >> 4));
-      const float dx = xy.x - pfx, dy = xy.y - pfy;
-      const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-      const float G = fast_exp(power);
-      float alpha = fminf(ALPHA_MAX, co.w * G);
-      const bool valid = active && (pos < n) && (power <= 0.0f) && (alpha >= ALPHA_MIN);
-      if (__builtin_amdgcn_ballot_w64(valid) == 0) continue;
-      alpha = valid ? alpha : 0.f;
-      const float om = 1.0f - alpha;
-      const float Tl = pa.x * wave_excl_prod_scan(om);
-      const float4 pb = s_pb[wave][pl];
-      const float gA = s_pc[wave][pl];
-      const float w = alpha * Tl;
-      const float k = pb.x * cc.x + pb.y * cc.y + pb.z * cc.z + pb.w * xy.z + gA;
-      const float wk = w * k;
-      const float pre = pa.y + wave_excl_sum_scan(wk);
+      const float dxA = xy.x - pfx, dxB = dxA - 1.0f, dy = xy.y - pfy;
+      const float cyy = co.z * dy * dy;
+      const float powA = -0.5f * (co.x * dxA * dxA + cyy) - co.y * dxA * dy;
+      const float powB = -0.5f * (co.x * dxB * dxB + cyy) - co.y * dxB * dy;
+      const float GA_ = fast_exp(powA), GB_ = fast_exp(powB);
+      float alA = fminf(ALPHA_MAX, co.w * GA_), alB = fminf(ALPHA_MAX, co.w * GB_);
+      const bool vA = active && (pos < nA) && (powA <= 0.0f) && (alA >= ALPHA_MIN);
+      const bool vB = active && (pos < nB) && (powB <= 0.0f) && (alB >= ALPHA_MIN);
+      if (__builtin_amdgcn_ballot_w64(vA || vB) == 0) continue;
+      alA = vA ? alA : 0.f; alB = vB ? alB : 0.f;
+      const float GA = vA ? GA_ : 0.f, GB = vB ? GB_ : 0.f;
+      const float omA = 1.0f - alA, omB = 1.0f - alB;
+      const float TlA = paA.x * wave_excl_prod_scan(omA);
+      const float TlB = paB.x * wave_excl_prod_scan(omB);
+      const float4 pbA = s_pb[wave][pl], pbB = s_pb[wave][pl + 1];
+      const float gAA = s_pc[wave][pl], gAB = s_pc[wave][pl + 1];
+      const float wA = alA * TlA, wB = alB * TlB;
+      const float kA = pbA.x * cc.x + pbA.y * cc.y + pbA.z * cc.z + pbA.w * xy.z + gAA;
+      const float kB = pbB.x * cc.x + pbB.y * cc.y + pbB.z * cc.z + pbB.w * xy.z + gAB;
+      const float wkA = wA * kA, wkB = wB * kB;
+      const float preA = paA.y + wave_excl_sum_scan(wkA);
+      const float preB = paB.y + wave_excl_sum_scan(wkB);
       // dL/dalpha = T k - (suffix + T_final * bg.g) / (1 - alpha),  suffix = total - prefix - own
-      const float dL_dalpha = Tl * k - (pa.z - pre - wk) * __builtin_amdgcn_rcpf(om);
-      const float dL_dG = co.w * dL_dalpha;
-      const float gdx = G * dx, gdy = G * dy;
-      if (valid) {
-        a_mx += dL_dG * (-gdx * co.x - gdy * co.y);
-        a_my += dL_dG * (-gdy * co.z - gdx * co.y);
-        a_ca += gdx * dx * dL_dG;
-        a_cb += gdx * dy * dL_dG;
-        a_cc += gdy * dy * dL_dG;
-        a_op += G * dL_dalpha;
-        a_r += w * pb.x; a_g += w * pb.y; a_b += w * pb.z;
-        a_d += w * pb.w;
-      }
+      float dLaA = TlA * kA - (paA.z - preA - wkA) * __builtin_amdgcn_rcpf(omA);
+      float dLaB = TlB * kB - (paB.z - preB - wkB) * __builtin_amdgcn_rcpf(omB);
+      dLaA = vA ? dLaA : 0.f; dLaB = vB ? dLaB : 0.f;
+      const float dGA = co.w * dLaA, dGB = co.w * dLaB;
+      const float gdxA = GA * dxA, gdxB = GB * dxB, gdyA = GA * dy, gdyB = GB * dy;
+      a_mx += dGA * (-gdxA * co.x - gdyA * co.y) + dGB * (-gdxB * co.x - gdyB * co.y);
+      a_my += dGA * (-gdyA * co.z - gdxA * co.y) + dGB * (-gdyB * co.z - gdxB * co.y);
+      a_ca += gdxA * dxA * dGA + gdxB * dxB * dGB;
+      a_cb += gdxA * dy * dGA + gdxB * dy * dGB;
+      a_cc += gdyA * dy * dGA + gdyB * dy * dGB;
+      a_op += GA * dLaA + GB * dLaB;
+      a_r += wA * pbA.x + wB * pbB.x; a_g += wA * pbA.y + wB * pbB.y; a_b += wA * pbA.z + wB * pbB.z;
+      a_d += wA * pbA.w + wB * pbB.w;
     }
     // fold the four pixel-quarters
     __syncthreads();
@@ -796,7 +805,8 @@ int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s) {
   }
   else {
     hipLaunchKernelGGL(render_bwd_worklist_kernel, dim3(1 + 512), dim3(1024), 0, s, a);
-    const int64_t max_blocks = 256 * 8;  // 8 workgroups of 4 waves per CU: every SIMD holds 8 pulling waves
+    static const int per_cu = getenv("RIGGS_BWD_WG_PER_CU") ? atoi(getenv("RIGGS_BWD_WG_PER_CU")) : 8;
+    const int64_t max_blocks = 256 * per_cu;  // 8 workgroups of 4 waves per CU: every SIMD holds 8 pulling waves
     const unsigned blocks = (unsigned)((a.n_slots < max_blocks) ? a.n_slots : max_blocks);
     hipLaunchKernelGGL(render_bwd_kernel, dim3(blocks), dim3(256), 0, s, a);
   }
