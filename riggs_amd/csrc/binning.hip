@@ -220,7 +220,7 @@ __global__ __launch_bounds__(512) void bin_scatter_kernel(int N, int T, int grid
         const unsigned short rel = cur[t];
         cur[t] = rel + 1;
         const int64_t pos = (int64_t)s_base[t] + rel;
-        if (pos < cap) { point_list[pos] = g; tile_keys[pos] = (uint32_t)t; }
+        if (pos < cap) { point_list[pos] = g; if (tile_keys) tile_keys[pos] = (uint32_t)t; }
       }
     }
   }

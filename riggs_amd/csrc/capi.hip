@@ -279,7 +279,9 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
     point_list = (const uint32_t*)(bin + B.vals_b);
     int rcb = launch_binning(N, T, gx, cap, (const uint32_t*)(geom + G.order), (const uint32_t*)(geom + G.tiles),
                              (const ushort4*)(geom + G.rect), bin + B.table, (uint32_t*)(bin + B.vals_b),
-                             (uint32_t*)(bin + B.keys_b), (uint2*)(img + I.ranges), (uint32_t*)(img + I.slot_base),
+                             // the per-instance tile id is only a debugging aid here (2M scattered 4-byte stores):
+                             // it is implied by `ranges`, so it is written with cfg.debug only
+                             cfg->debug ? (uint32_t*)(bin + B.keys_b) : nullptr, (uint2*)(img + I.ranges), (uint32_t*)(img + I.slot_base),
                              (uint32_t*)(img + I.tile_max), counters, s);
     if (rcb) return rcb;
     if (debug_sync(cfg->debug, s, "binning (counting sort)")) return 1;

@@ -281,7 +281,7 @@ def saved_views(s: _Saved):
 
     def view(buf, off, nbytes, dtype, shape):
         return buf[off:off + nbytes].view(dtype).reshape(shape)
-    return {
+    out = {
         "xyd": view(s.geom, go[L.GEOM_XYD], N * 16, torch.float32, (N, 4)),
         "conic_o": view(s.geom, go[L.GEOM_CONIC_O], N * 16, torch.float32, (N, 4)),
         "rgb": view(s.geom, go[L.GEOM_RGB], N * 16, torch.float32, (N, 4)),
@@ -298,3 +298,10 @@ def saved_views(s: _Saved):
         "tile_keys": view(s.binning, bo[L.BIN_TILE_KEYS], s.R * 4, torch.int32, (s.R,)),
         "R": s.R,
     }
+    if not s.cfg.debug:
+        # the counting-sort binning stores the per-instance tile id only with settings.debug; it is implied by
+        # the tile ranges (instance p belongs to the tile whose range holds p)
+        rg = out["ranges"].long()
+        lens = (rg[:, 1] - rg[:, 0]).clamp(min=0)
+        out["tile_keys"] = torch.repeat_interleave(torch.arange(T, device=rg.device), lens).to(torch.int32)[:s.R]
+    return out
