@@ -286,9 +286,21 @@ int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order,
 #define RS_BINS (1 << RS_BITS)
 #define RS_CHUNK 1024  // elements per workgroup (4 waves x 4 steps x 64 lanes)
 
+// (the last workgroup of the first pass also totals the per-workgroup tile counts of preprocess_fwd into
+// counters[0] = R for the host — that used to be a launch of its own)
 __global__ __launch_bounds__(256) void rs_count_kernel(int N, int shift, const uint32_t* __restrict__ keys,
-                                                       uint32_t* __restrict__ table) {
+                                                       uint32_t* __restrict__ table, const uint32_t* __restrict__ part,
+                                                       int n_part, uint32_t* __restrict__ total) {
   __shared__ uint32_t s_hist[RS_BINS];
+  if (part != nullptr && blockIdx.x == gridDim.x - 1) {
+    __shared__ uint32_t s_w[4];
+    uint32_t v = 0;
+    for (int i = threadIdx.x; i < n_part; i += 256) v += part[i];
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) { total[0] = s_w[0] + s_w[1] + s_w[2] + s_w[3]; total[1] = 0u; total[2] = 0u; total[3] = 0u; }
+  }
   for (int b = threadIdx.x; b < RS_BINS; b += 256) s_hist[b] = 0u;
   __syncthreads();
   const int first = blockIdx.x * RS_CHUNK;
@@ -380,14 +392,15 @@ size_t depth_sort_table_bytes(int N) {
 
 // three passes: the result ends in (keys_out, vals_out); (keys_in, vals_in) are used as scratch
 int launch_depth_sort(int N, uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, void* table_mem,
-                      hipStream_t s) {
+                      const uint32_t* block_tiles, uint32_t* counters, hipStream_t s) {
   const int chunks = (N + RS_CHUNK - 1) / RS_CHUNK;
   uint32_t* table = (uint32_t*)table_mem;
   uint32_t* bin_count = (uint32_t*)((char*)table_mem + align_up(((size_t)chunks + 1) * RS_BINS * 4));
   uint32_t *ka = keys_in, *va = vals_in, *kb = keys_out, *vb = vals_out;
   for (int pass = 0; pass < 3; pass++) {
     const int shift = pass * RS_BITS;
-    hipLaunchKernelGGL(rs_count_kernel, dim3(chunks), dim3(256), 0, s, N, shift, ka, table);
+    hipLaunchKernelGGL(rs_count_kernel, dim3(chunks), dim3(256), 0, s, N, shift, ka, table, pass == 0 ? block_tiles : nullptr,
+                       (N + 255) / 256, counters);
     hipLaunchKernelGGL(bin_scan_kernel, dim3((RS_BINS + 63) / 64), dim3(1024), 0, s, RS_BINS, chunks, table, bin_count);
     hipLaunchKernelGGL(rs_scatter_kernel, dim3(chunks), dim3(256), 0, s, N, shift, ka, va, table, bin_count, kb, vb);
     uint32_t* t = ka; ka = kb; kb = t;

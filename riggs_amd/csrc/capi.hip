@@ -228,7 +228,8 @@ int riggs_raster_preprocess(const riggs_raster_cfg* cfg, const float* means3D, c
   RIGGS_HIP_CHECK(hipMemsetAsync(counters, 0, 16, s));
   if (N == 0) return 0;
   GeomLayout L = geom_layout(N);
-  a.total_tiles = counters;  // sum_block_tiles_kernel writes counters[0] and clears counters[1..3]
+  // counters[0] = R (and [1..3] = 0): by the first kernel of the depth sort, or by sum_block_tiles_kernel (rocPRIM variant)
+  a.total_tiles = use_rocprim_binning() ? counters : nullptr;
   { ProfScope ps(PROF_PREPROCESS_FWD, s); launch_preprocess_fwd(a, s); }
   if (debug_sync(cfg->debug, s, "preprocess_fwd")) return 1;
   // depth sort of the Gaussians (stable: equal depths keep ascending index)
@@ -236,7 +237,8 @@ int riggs_raster_preprocess(const riggs_raster_cfg* cfg, const float* means3D, c
   if (!use_rocprim_binning()) {
     ProfScope ps(PROF_DEPTH_SORT, s);  // three counting-sort passes (csrc/binning.hip)
     launch_depth_sort(N, (uint32_t*)(geom + L.depth_key), (uint32_t*)(geom + L.order_in),
-                      (uint32_t*)(geom + L.depth_key_sorted), (uint32_t*)(geom + L.order), geom + L.sort_table, s);
+                      (uint32_t*)(geom + L.depth_key_sorted), (uint32_t*)(geom + L.order), geom + L.sort_table,
+                      a.block_tiles, counters, s);
   } else {
     ProfScope ps(PROF_DEPTH_SORT, s);
     RIGGS_HIP_CHECK(rocprim::radix_sort_pairs(geom + L.temp, tb, (uint32_t*)(geom + L.depth_key),

@@ -447,7 +447,8 @@ int launch_preprocess_fwd(const PreArgs& a, hipStream_t s) {
   const int per = a.shs_rest ? (a.M - 1) * 3 : a.M * 3;
   const size_t lds = a.colors_precomp ? 0 : (size_t)256 * (per | 1) * sizeof(float);
   hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((a.N + 255) / 256), dim3(256), lds, s, a);
-  hipLaunchKernelGGL(sum_block_tiles_kernel, dim3(1), dim3(1024), 0, s, (a.N + 255) / 256, a.block_tiles, a.total_tiles);
+  if (a.total_tiles)
+    hipLaunchKernelGGL(sum_block_tiles_kernel, dim3(1), dim3(1024), 0, s, (a.N + 255) / 256, a.block_tiles, a.total_tiles);
   return 0;
 }
 int launch_preprocess_bwd(const PreBwdArgs& b, hipStream_t s) {

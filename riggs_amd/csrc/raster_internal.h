@@ -77,7 +77,7 @@ int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s);
 // binning
 size_t depth_sort_table_bytes(int N);
 int launch_depth_sort(int N, uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, void* table_mem,
-                      hipStream_t s);
+                      const uint32_t* block_tiles, uint32_t* counters, hipStream_t s);
 size_t bin_table_bytes(int N, int T);
 int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order, const uint32_t* tiles,
                    const ushort4* rect, void* table_mem, uint32_t* point_list, uint32_t* tile_keys, uint2* ranges,
