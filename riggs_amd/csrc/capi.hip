@@ -314,6 +314,7 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
   RenderArgs r;
   r.W = W; r.H = H;
   r.cull = render_cull() ? 1 : 0;
+  { static const bool x = getenv("RIGGS_NO_XCD_MAP") == nullptr; r.xcd_map = x ? 1 : 0; }
   r.ranges = (const uint2*)(img + I.ranges);
   r.point_list = point_list;
   r.xyd = (const float4*)(geom + G.xyd); r.conic_o = (const float4*)(geom + G.conic_o); r.rgb = (const float4*)(geom + G.rgb);

@@ -240,14 +240,25 @@ __device__ __forceinline__ float quad_sum(float v) {
 // block with the axis-aligned extent of its alpha >= 1/255 ellipse (xyd.w / rgb.w, from the preprocess
 // kernel; conservative) and only the survivors are kept, compacted per 64-instance chunk so that the
 // checkpoints of the backward stay at multiples of 64 of the ORIGINAL list position.
+template <int FQ_BATCH>
 __global__ __launch_bounds__(256) void render_fwd_quad_kernel(RenderArgs a) {
-  __shared__ float4 s_xyd[256];
-  __shared__ float4 s_con[256];
-  __shared__ float4 s_rgb[256];
-  __shared__ unsigned short s_pos[256];  // position of the survivor inside its batch
-  __shared__ int s_cnt[4];               // survivors per chunk
+  // A round stages FQ_BATCH = 1024 instances (16 chunks; thread t holds instances t, t+256, ...): the walk of a
+  // 47k-entry list is a chain of rounds, each costing a global-load latency and a barrier whatever survives.
+  __shared__ float4 s_xyd[FQ_BATCH];
+  __shared__ float4 s_con[FQ_BATCH];
+  __shared__ float4 s_rgb[FQ_BATCH];
+  __shared__ unsigned short s_pos[FQ_BATCH];  // position of the survivor inside its batch
+  __shared__ int s_cnt[FQ_BATCH / 64];        // survivors per chunk
   const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE;
-  const int tile = blockIdx.x >> 2, sub = blockIdx.x & 3;
+  // XCD-aware mapping: workgroup b runs on XCD b % 8, so the four workgroups of a tile (which read the same
+  // list and the same records) are given ids 8 apart — same L2 — instead of four neighbouring ids
+  int tile, sub;
+  {
+    const int b = blockIdx.x, full = (int)(gridDim.x >> 5) << 5;
+    if (!a.xcd_map) { tile = b >> 2; sub = b & 3; }
+    else if (b < full) { tile = ((b >> 5) << 3) + (b & 7); sub = (b >> 3) & 3; }
+    else { tile = (full >> 2) + ((b - full) >> 2); sub = (b - full) & 3; }
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qx = lane >> 2, j = lane & 3;
   const int prow = sub * 4 + wave;                       // pixel row inside the tile
@@ -264,32 +275,42 @@ __global__ __launch_bounds__(256) void render_fwd_quad_kernel(RenderArgs a) {
   bool done = !inside;
   float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f, Tstop = -1.0f;
   uint32_t last = 0;
-  // prefetch registers for the next batch (one instance per thread)
-  float4 n_xy = make_float4(0.f, 0.f, 0.f, 0.f), n_co = n_xy, n_cc = n_xy;
-  if (tid < min(256, total)) {
-    const uint32_t id = a.point_list[range.x + tid];
-    n_xy = a.xyd[id]; n_co = a.conic_o[id]; n_cc = a.rgb[id];
+  // prefetch registers for the next round (FQ_BATCH / 256 instances per thread)
+  float4 n_xy[FQ_BATCH / 256], n_co[FQ_BATCH / 256], n_cc[FQ_BATCH / 256];
+#pragma unroll
+  for (int k = 0; k < FQ_BATCH / 256; k++) {
+    n_xy[k] = make_float4(0.f, 0.f, 0.f, 0.f); n_co[k] = n_xy[k]; n_cc[k] = n_xy[k];
+    if (k * 256 + tid < total) {
+      const uint32_t id = a.point_list[range.x + k * 256 + tid];
+      n_xy[k] = a.xyd[id]; n_co[k] = a.conic_o[id]; n_cc[k] = a.rgb[id];
+    }
   }
-  for (int base = 0; base < total; base += 256) {
+  for (int base = 0; base < total; base += FQ_BATCH) {
     if (__syncthreads_count(done) == 256) break;
-    {
-      const bool keep = (base + tid < total) && (!a.cull || ((n_xy.x + n_xy.w >= bx0) && (n_xy.x - n_xy.w <= bx1) &&
-                                                            (n_xy.y + n_cc.w >= by0) && (n_xy.y - n_cc.w <= by1)));
+#pragma unroll
+    for (int k = 0; k < FQ_BATCH / 256; k++) {
+      const int chunk = k * 4 + wave, inb = k * 256 + tid;  // this wave's 64 lanes = one chunk of the batch
+      const bool keep = (base + inb < total) &&
+                        (!a.cull || ((n_xy[k].x + n_xy[k].w >= bx0) && (n_xy[k].x - n_xy[k].w <= bx1) &&
+                                     (n_xy[k].y + n_cc[k].w >= by0) && (n_xy[k].y - n_cc[k].w <= by1)));
       const uint64_t mask = __builtin_amdgcn_ballot_w64(keep);
       const int cnt = __builtin_popcountll(mask);
-      const int slot = wave * 64 + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-      if (keep) { s_xyd[slot] = n_xy; s_con[slot] = n_co; s_rgb[slot] = n_cc; s_pos[slot] = (unsigned short)tid; }
+      const int slot = chunk * 64 + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+      if (keep) { s_xyd[slot] = n_xy[k]; s_con[slot] = n_co[k]; s_rgb[slot] = n_cc[k]; s_pos[slot] = (unsigned short)inb; }
       if (lane >= cnt && lane < ((cnt + 7) & ~7)) {  // null records up to the next multiple of 8
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        s_xyd[wave * 64 + lane] = z; s_con[wave * 64 + lane] = z; s_rgb[wave * 64 + lane] = z; s_pos[wave * 64 + lane] = 0;
+        s_xyd[chunk * 64 + lane] = z; s_con[chunk * 64 + lane] = z; s_rgb[chunk * 64 + lane] = z; s_pos[chunk * 64 + lane] = 0;
       }
-      if (lane == 0) s_cnt[wave] = cnt;
+      if (lane == 0) s_cnt[chunk] = cnt;
     }
     __syncthreads();
-    n_xy = make_float4(0.f, 0.f, 0.f, 0.f); n_co = n_xy; n_cc = n_xy;
-    if (base + 256 + tid < total) {
-      const uint32_t id = a.point_list[range.x + base + 256 + tid];
-      n_xy = a.xyd[id]; n_co = a.conic_o[id]; n_cc = a.rgb[id];
+#pragma unroll
+    for (int k = 0; k < FQ_BATCH / 256; k++) {
+      n_xy[k] = make_float4(0.f, 0.f, 0.f, 0.f); n_co[k] = n_xy[k]; n_cc[k] = n_xy[k];
+      if (base + FQ_BATCH + k * 256 + tid < total) {
+        const uint32_t id = a.point_list[range.x + base + FQ_BATCH + k * 256 + tid];
+        n_xy[k] = a.xyd[id]; n_co[k] = a.conic_o[id]; n_cc[k] = a.rgb[id];
+      }
     }
     // one quad step: four consecutive instances (one per lane of the quad) of this lane's pixel
     auto quad_step = [&](float alpha, bool valid_in, float depth, const float4 c, int pos1) {
@@ -319,7 +340,7 @@ __global__ __launch_bounds__(256) void render_fwd_quad_kernel(RenderArgs a) {
     };
     // two quad steps (8 instances) per iteration: the falloff of the second step overlaps the
     // dependent transmittance chain of the first
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < FQ_BATCH / 64; k++) {
       const int cbase = base + 64 * k;
       if (cbase >= total) break;
       if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
@@ -470,7 +491,10 @@ int launch_render_fwd(const RenderArgs& a, hipStream_t s) {
   else if (variant == 2) hipLaunchKernelGGL(render_fwd_kernel, dim3(gx * gy), dim3(256), 0, s, a);
   else {
     // tile_max was cleared together with ranges by riggs_raster_render
-    hipLaunchKernelGGL(render_fwd_quad_kernel, dim3(gx * gy * 4), dim3(256), 0, s, a);
+    static const int fq = getenv("RIGGS_FQ_BATCH") ? atoi(getenv("RIGGS_FQ_BATCH")) : 256;  // A/B switch (larger rounds lose)
+    if (fq == 512) hipLaunchKernelGGL(render_fwd_quad_kernel<512>, dim3(gx * gy * 4), dim3(256), 0, s, a);
+    else if (fq == 1024) hipLaunchKernelGGL(render_fwd_quad_kernel<1024>, dim3(gx * gy * 4), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(render_fwd_quad_kernel<256>, dim3(gx * gy * 4), dim3(256), 0, s, a);
   }
   return 0;
 }
