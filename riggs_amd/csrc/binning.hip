@@ -15,7 +15,7 @@
 
 namespace riggs {
 
-#define BIN_G_PER_WAVE 128  // Gaussians walked by one wave
+#define BIN_G_PER_WAVE 64  // Gaussians walked by one wave
 
 __device__ __forceinline__ int rect_tile(const ushort4 rc, int l, int grid_x) {
   const int w = rc.z - rc.x;
@@ -25,7 +25,7 @@ __device__ __forceinline__ int rect_tile(const ushort4 rc, int l, int grid_x) {
   return (rc.y + ry) * grid_x + rc.x + rx;
 }
 
-__global__ __launch_bounds__(512) void bin_count_kernel(int N, int T, int grid_x, int g_per_block,
+__global__ __launch_bounds__(1024) void bin_count_kernel(int N, int T, int grid_x, int g_per_block,
                                                         const uint32_t* __restrict__ order,
                                                         const uint32_t* __restrict__ tiles,
                                                         const ushort4* __restrict__ rect,
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(1024) void bin_offsets_kernel(int T, int64_t cap, c
 
 // Scatter.  LDS: s_base[T] (u32 absolute start of this block's segment in each tile) and
 // s_rel[W][T] (u16 offsets of each wave's sub-segment, then used as that wave's running cursor).
-__global__ __launch_bounds__(512) void bin_scatter_kernel(int N, int T, int grid_x, int64_t cap, int g_per_block,
+__global__ __launch_bounds__(1024) void bin_scatter_kernel(int N, int T, int grid_x, int64_t cap, int g_per_block,
                                                           const uint32_t* __restrict__ order,
                                                           const uint32_t* __restrict__ tiles,
                                                           const ushort4* __restrict__ rect,
@@ -231,8 +231,11 @@ struct BinPlan { int g_per_block, threads, n_chunks; size_t lds_scatter; };
 static BinPlan bin_plan(int N, int T) {
   // LDS of the scatter kernel: T*4 (bases) + W*Tpad*2 (wave cursors) <= ~150 KB
   const int Tpad = (T + 1) & ~1;
-  int W = 8;
-  while (W > 1 && (size_t)T * 4 + (size_t)W * Tpad * 2 > 150 * 1024) W >>= 1;
+  // 12 waves x 64 Gaussians: the ordered walk is a latency chain per wave, so short walks on many waves win;
+  // beyond 12 the LDS footprint leaves one workgroup per CU
+  static const int W0 = getenv("RIGGS_BIN_W") ? atoi(getenv("RIGGS_BIN_W")) : 12;
+  int W = W0;
+  while (W > 1 && (size_t)T * 4 + (size_t)W * Tpad * 2 > 150 * 1024) W = (W + 1) >> 1;
   BinPlan p;
   p.threads = W * 64;
   p.g_per_block = W * BIN_G_PER_WAVE;
