@@ -355,9 +355,10 @@ __global__ __launch_bounds__(256) void render_fwd_quad_kernel(RenderArgs a) {
       const int nk = s_cnt[k];
     for (int g = 64 * k; g < 64 * k + nk; g += 8) {
       if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
-      const float4 xyA = s_xyd[g + j], coA = s_con[g + j];
-      const float4 xyB = s_xyd[g + 4 + j], coB = s_con[g + 4 + j];
+      const float4 xyA = s_xyd[g + j];
+      const float4 xyB = s_xyd[g + 4 + j];
       const float dxA = xyA.x - pfx, dyA = xyA.y - pfy, dxB = xyB.x - pfx, dyB = xyB.y - pfy;
+      const float4 coA = s_con[g + j], coB = s_con[g + 4 + j];
       const float pwA = -0.5f * (coA.x * dxA * dxA + coA.z * dyA * dyA) - coA.y * dxA * dyA;
       const float pwB = -0.5f * (coB.x * dxB * dxB + coB.z * dyB * dyB) - coB.y * dxB * dyB;
       const float alA = fminf(ALPHA_MAX, coA.w * fast_exp(pwA));
@@ -761,6 +762,8 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderBwdArgs a) {
       const int pix = quarter * 64 + pl;       // pl is even: both pixels are in the same row
       const float pfx = (float)(tx0 + (pix & 15)), pfy = (float)(ty0 + (pix >> 4));
       const float dxA = xy.x - pfx, dxB = dxA - 1.0f, dy = xy.y - pfy;
+      // cheap conservative reject (alpha >= 1/255 extents, as in the forward's cull) before the exponentials
+      if (a.cull && __builtin_amdgcn_ballot_w64(active && fabsf(dy) <= cc.w && fminf(fabsf(dxA), fabsf(dxB)) <= xy.w) == 0) continue;
       const float cyy = co.z * dy * dy;
       const float powA = -0.5f * (co.x * dxA * dxA + cyy) - co.y * dxA * dy;
       const float powB = -0.5f * (co.x * dxB * dxB + cyy) - co.y * dxB * dy;
