@@ -244,6 +244,17 @@ def main():
         per_kernel = {k: {"ms": table[k], "GBps": round(alg_bytes[k] / (table[k] * 1e-3) / 1e9, 1),
                           "frac_hbm": round(alg_bytes[k] / (table[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                       for k in table if k in alg_bytes and table[k] > 0}
+        # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE in separate runs, tools/hbm_traffic.py; read side with the gfx950 x2 wide-stream correction)
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")))
+            key = {"render_fwd": "render_fwd_quad_kernel", "render_bwd": "render_bwd_kernel", "preprocess_fwd": "preprocess_fwd_kernel",
+                   "preprocess_bwd": "preprocess_bwd_kernel"}.get(dom)
+            if key in pm:
+                traffic = pm[key]["read_bytes_x2_corrected"] + pm[key]["write_bytes"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "train iters/sec (deform+raster fwd+bwd), 300k Gaussians @800x800",
             "value": round(value, 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -254,7 +265,7 @@ def main():
                        "image": [w["H"], w["W"]], "tile_instances_R": R, "parallelism": "frames x%d" % world,
                        "launch": "eager" if args.no_graph else "hipGraph replay"},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "ms_per_launch": dom_ms, "algorithmic_bytes_per_launch": dom_bytes,
                          "pixel_gaussian_pairs_per_s": round(256.0 * R / (dom_ms * 1e-3), 1) if dom.startswith("render") else None},
             "kernels": per_kernel, "kernels_ms": table,

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(1024) void bin_count_kernel(int N, int T, int grid_
 // coalesced across the 64 tiles), LDS prefix over the 16 segments, then the exclusive prefixes are
 // written back — no serial walk over hundreds of chunks.
 #define SCAN_SEG 16
-#define SCAN_KEEP 24
+#define SCAN_KEEP 32
 __global__ __launch_bounds__(1024) void bin_scan_kernel(int T, int n_chunks, uint32_t* __restrict__ table,
                                                         uint32_t* __restrict__ tile_count) {
   __shared__ uint32_t s_seg[SCAN_SEG][64];
