@@ -213,6 +213,27 @@ int riggs_pose_mlp_backward(int32_t depth, int32_t width, int32_t multires, int3
                             float* flat_grads, riggs_stream stream);
 
 /* =====================================================================
+ * Gaussian optimizer.
+ *   GaussianModel.training_setup  scene/gaussian_model.py:197-221 builds torch.optim.Adam(l, lr=0.0, eps=1e-15)
+ *   with ONE parameter tensor per group and per-group learning rates; train_rig.py:527 steps it.
+ * riggs_adam_step applies that update (plain Adam: no weight decay, no amsgrad; torch's single-tensor
+ * operation order) to up to 8 parameter tensors in ONE launch.  All pointer arrays are HOST arrays of
+ * DEVICE pointers (16-byte aligned tensors of numel[k] floats); lr[k] is the group's current learning
+ * rate, step[k] the step count AFTER this update (>= 1); exp_avg / exp_avg_sq are updated in place.
+ *   add_densification_stats       scene/gaussian_model.py:516-518
+ *   max_radii2D update            train_rig.py:333-335
+ * riggs_densify_stats: for every i with update_filter[i] (bytes, torch.bool layout):
+ *   xyz_gradient_accum[i] += ||viewspace_grad[i, :2]||, denom[i] += 1, and if max_radii2D and radii are
+ *   non-NULL max_radii2D[i] = max(max_radii2D[i], radii[i]).  viewspace_grad is (N,3).
+ * ===================================================================== */
+int riggs_adam_step(int32_t n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
+                    float* const* exp_avg_sq, const int64_t* numel, const double* lr, const int64_t* step, double beta1,
+                    double beta2, double eps, riggs_stream stream);
+int riggs_densify_stats(int32_t num_points, const float* viewspace_grad, const uint8_t* update_filter,
+                        const int32_t* radii, float* xyz_gradient_accum, float* denom, float* max_radii2D,
+                        riggs_stream stream);
+
+/* =====================================================================
  * simple_knn._C.distCUDA2 (scene/gaussian_model.py:20,170): mean squared distance to the 3
  * nearest neighbours.  points (P,3) -> out (P,).  workspace: riggs_knn_workspace_bytes(P).
  * ===================================================================== */

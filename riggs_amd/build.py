@@ -21,6 +21,7 @@ SOURCES = {
     "deform.hip": ["-ffp-contract=fast"],
     "knn.hip": ["-ffp-contract=fast"],
     "pose_mlp.hip": ["-ffp-contract=fast"],
+    "optim.hip": ["-ffp-contract=off"],
     "capi.hip": [],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fhip-fp32-correctly-rounded-divide-sqrt",

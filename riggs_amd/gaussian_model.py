@@ -1,7 +1,10 @@
 """Parameter store with the attribute names / layouts / getters of the reference's
 ``GaussianModel`` (/root/reference/scene/gaussian_model.py:37-132, :177-195) — only what the
-hot path reads.  Densification, optimizer surgery and PLY I/O are SURVEY.md §8-f items."""
+hot path reads, plus the optimizer set-up / step statistics of §8-f rank 1 (``training_setup``,
+``update_learning_rate``, ``add_densification_stats``).  Densification surgery and PLY I/O are later §8-f items."""
 from __future__ import annotations
+
+import math
 
 import torch
 import torch.nn as nn
@@ -73,3 +76,46 @@ class GaussianModel:
     def oneupSHdegree(self):
         if self.active_sh_degree < self.max_sh_degree:
             self.active_sh_degree += 1
+
+    # ---- optimizer (scene/gaussian_model.py:197-231, :516-518) --------------------------------------------------
+    def training_setup(self, training_args):
+        """Same groups, names and learning rates as the reference; the optimizer is ``riggs_amd.optim.FusedAdam``
+        (a torch.optim.Adam whose step is one HIP launch)."""
+        from .optim import FusedAdam
+        self.percent_dense = training_args.percent_dense
+        n, dev = self.get_xyz.shape[0], self.get_xyz.device
+        self.xyz_gradient_accum = torch.zeros((n, 1), device=dev)
+        self.denom = torch.zeros((n, 1), device=dev)
+        self.spatial_lr_scale = 5
+        groups = [
+            {"params": [self._xyz], "lr": training_args.position_lr_init * self.spatial_lr_scale, "name": "xyz"},
+            {"params": [self._features_dc], "lr": training_args.feature_lr, "name": "f_dc"},
+            {"params": [self._features_rest], "lr": training_args.feature_lr / 20.0, "name": "f_rest"},
+            {"params": [self._opacity], "lr": training_args.opacity_lr, "name": "opacity"},
+            {"params": [self._scaling], "lr": training_args.scaling_lr * self.spatial_lr_scale, "name": "scaling"},
+            {"params": [self._rotation], "lr": training_args.rotation_lr, "name": "rotation"},
+        ]
+        if self.fea_dim > 0:
+            groups.append({"params": [self.feature], "lr": training_args.feature_lr, "name": "feature"})
+        self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)
+        lr0 = training_args.position_lr_init * self.spatial_lr_scale
+        lr1 = training_args.position_lr_final * self.spatial_lr_scale
+        steps = training_args.position_lr_max_steps  # (position_lr_delay_mult is inert: lr_delay_steps stays 0)
+
+        def xyz_lr(step):  # get_expon_lr_func (utils/general_utils.py:49-87) with lr_delay_steps = 0
+            if step < 0 or (lr0 == 0.0 and lr1 == 0.0):
+                return 0.0
+            t = min(max(step / steps, 0.0), 1.0)
+            return math.exp(math.log(lr0) * (1 - t) + math.log(lr1) * t)
+        self.xyz_scheduler_args = xyz_lr
+        self.skeleton_gs_position_lr = getattr(training_args, "skeleton_gs_position_lr", lr0)
+
+    def update_learning_rate(self, iteration):  # :222-228
+        for group in self.optimizer.param_groups:
+            if group["name"] == "xyz":
+                group["lr"] = self.xyz_scheduler_args(iteration)
+
+    def add_densification_stats(self, viewspace_point_tensor, update_filter, radii=None):  # :516-518 (+ train_rig.py:333-335)
+        from .optim import densify_stats
+        densify_stats(viewspace_point_tensor.grad, update_filter, self.xyz_gradient_accum, self.denom, radii,
+                      self.max_radii2D if radii is not None else None)

@@ -181,6 +181,62 @@ def fixture_glue(name, seed, N, isotropic, from_K):
     print("wrote", name)
 
 
+def fixture_optim(name, seed, N):
+    """§8-f rank 1: the Gaussian optimizer exactly as the reference builds and steps it
+    (GaussianModel.training_setup scene/gaussian_model.py:197-221 -> torch.optim.Adam(l, lr=0.0, eps=1e-15);
+    optimizer.step / update_learning_rate / zero_grad train_rig.py:517-533) and add_densification_stats (:516-518)."""
+    from types import SimpleNamespace
+    g = torch.Generator().manual_seed(seed)
+    gm = GaussianModel(3, fea_dim=0, with_motion_mask=False)
+    P = torch.nn.Parameter
+    gm._xyz = P(torch.randn(N, 3, generator=g))
+    gm._features_dc = P(torch.randn(N, 1, 3, generator=g))
+    gm._features_rest = P(0.1 * torch.randn(N, 15, 3, generator=g))
+    gm._scaling = P(math.log(0.05) + 0.35 * torch.randn(N, 3, generator=g))
+    gm._rotation = P(torch.randn(N, 4, generator=g))
+    gm._opacity = P(1.5 * torch.randn(N, 1, generator=g))
+    args = SimpleNamespace(percent_dense=0.01, position_lr_init=0.00016, position_lr_final=0.0000016,
+                           position_lr_delay_mult=0.01, position_lr_max_steps=30000, feature_lr=0.0025, opacity_lr=0.05,
+                           scaling_lr=0.001, rotation_lr=0.001, skeleton_gs_position_lr=0.00001)
+    with S.quiet():
+        gm.training_setup(args)
+    names = [grp["name"] for grp in gm.optimizer.param_groups]
+    out = {"names": np.array(names), "N": N, "betas": np.array(gm.optimizer.param_groups[0]["betas"]),
+           "eps": gm.optimizer.param_groups[0]["eps"]}
+    for grp in gm.optimizer.param_groups:
+        out["p0_" + grp["name"]] = np_(grp["params"][0]).copy()
+    steps = 4
+    for it in range(steps):
+        for grp in gm.optimizer.param_groups:
+            p = grp["params"][0]
+            # sparse-ish gradients with a wide dynamic range, exact zeros for "invisible" Gaussians
+            gr = torch.randn(p.shape, generator=g) * torch.exp(3.0 * torch.randn(p.shape[0], *([1] * (p.dim() - 1)), generator=g))
+            gr = gr * (torch.rand(p.shape[0], *([1] * (p.dim() - 1)), generator=g) > 0.3)
+            p.grad = gr.clone()
+            out["g%d_%s" % (it, grp["name"])] = np_(gr)
+        out["lr%d" % it] = np.array([grp["lr"] for grp in gm.optimizer.param_groups], dtype=np.float64)
+        gm.optimizer.step()
+        gm.update_learning_rate(1000 * (it + 1))
+        gm.optimizer.zero_grad(set_to_none=True)
+        for grp in gm.optimizer.param_groups:
+            st = gm.optimizer.state[grp["params"][0]]
+            out["p%d_%s" % (it + 1, grp["name"])] = np_(grp["params"][0]).copy()
+            out["m%d_%s" % (it + 1, grp["name"])] = np_(st["exp_avg"]).copy()
+            out["v%d_%s" % (it + 1, grp["name"])] = np_(st["exp_avg_sq"]).copy()
+    out["steps"] = steps
+    # densification statistics, two frames
+    for it in range(2):
+        vt = SimpleNamespace(grad=torch.randn(N, 3, generator=g) * 1e-3)
+        filt = torch.rand(N, generator=g) > 0.4
+        gm.add_densification_stats(vt, filt)
+        out["ds_grad%d" % it] = np_(vt.grad)
+        out["ds_filter%d" % it] = np_(filt)
+        out["ds_accum%d" % it] = np_(gm.xyz_gradient_accum).copy()
+        out["ds_denom%d" % it] = np_(gm.denom).copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name)
+
+
 if __name__ == "__main__":
     fixture_deform("deform_chain8_n257", 11, 8, 257, -1, chain=True)
     fixture_deform("deform_tree24_n1024", 12, 24, 1024, -1, mask_random=True)
@@ -190,3 +246,4 @@ if __name__ == "__main__":
     fixture_posemlp("posemlp_w32_j24", 21, 24)
     fixture_glue("glue_aniso_fov", 31, 96, False, False)
     fixture_glue("glue_iso_K", 32, 96, True, True)
+    fixture_optim("optim_adam_n67", 41, 67)

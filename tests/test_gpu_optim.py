@@ -1,0 +1,133 @@
+"""§8-f rank 1 on the GPU: the one-launch Adam step and the densification statistics against the golden vectors of
+the reference's own optimizer, the CPU oracle, and torch.optim.Adam itself (the optimizer the reference constructs)."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "optim_adam_n67.npz"))
+NAMES = [str(n) for n in G["names"]]
+ARGS = SimpleNamespace(percent_dense=0.01, position_lr_init=0.00016, position_lr_final=0.0000016,
+                       position_lr_delay_mult=0.01, position_lr_max_steps=30000, feature_lr=0.0025, opacity_lr=0.05,
+                       scaling_lr=0.001, rotation_lr=0.001, skeleton_gs_position_lr=0.00001)
+
+
+def _close(got, want, what):
+    want = np.asarray(want)
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want, rtol=2e-6, atol=2e-7 * float(np.abs(want).max()), err_msg=what)
+
+
+def _model():
+    from riggs_amd.gaussian_model import GaussianModel
+    t = lambda n: torch.from_numpy(G["p0_" + n])  # noqa: E731
+    gm = GaussianModel.from_tensors(t("xyz"), t("f_dc"), t("f_rest"), t("scaling"), t("rotation"), t("opacity"))
+    gm.training_setup(ARGS)
+    return gm
+
+
+def test_training_setup_step_and_schedule_match_reference_golden():
+    gm = _model()
+    assert [g["name"] for g in gm.optimizer.param_groups] == NAMES
+    for it in range(int(G["steps"])):
+        np.testing.assert_allclose([g["lr"] for g in gm.optimizer.param_groups], G["lr%d" % it], rtol=1e-12)
+        for grp in gm.optimizer.param_groups:
+            grp["params"][0].grad = torch.from_numpy(G["g%d_%s" % (it, grp["name"])]).cuda()
+        gm.optimizer.step()
+        gm.update_learning_rate(1000 * (it + 1))
+        gm.optimizer.zero_grad(set_to_none=True)
+        for grp in gm.optimizer.param_groups:
+            n, st = grp["name"], gm.optimizer.state[grp["params"][0]]
+            _close(grp["params"][0], G["p%d_%s" % (it + 1, n)], "param " + n)
+            _close(st["exp_avg"], G["m%d_%s" % (it + 1, n)], "exp_avg " + n)
+            _close(st["exp_avg_sq"], G["v%d_%s" % (it + 1, n)], "exp_avg_sq " + n)
+            assert float(st["step"]) == it + 1
+
+
+def test_matches_torch_adam_ragged_sizes_many_groups_and_surgery():
+    from riggs_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(5)
+    shapes = [(1001, 3), (1001, 1, 3), (1001, 15, 3), (1001, 1), (1001, 3), (1001, 4), (7,), (1, 1), (513, 5), (2, 3)]  # 10 > 8
+    lrs = [8e-4, 2.5e-3, 1.25e-4, 5e-2, 5e-3, 1e-3, 1e-2, 1e-1, 3e-3, 1e-3]
+    mk = lambda: [torch.nn.Parameter(torch.randn(s, generator=torch.Generator().manual_seed(i)).cuda()) for i, s in enumerate(shapes)]  # noqa: E731
+    pa, pb = mk(), mk()
+    oa = FusedAdam([{"params": [p], "lr": lr, "name": str(i)} for i, (p, lr) in enumerate(zip(pa, lrs))], lr=0.0, eps=1e-15)
+    ob = torch.optim.Adam([{"params": [p], "lr": lr, "name": str(i)} for i, (p, lr) in enumerate(zip(pb, lrs))], lr=0.0, eps=1e-15)
+
+    def check():
+        for ga, gb in zip(oa.param_groups, ob.param_groups):
+            a, b = ga["params"][0], gb["params"][0]
+            tol = dict(rtol=3e-6, atol=3e-7 * float(b.detach().abs().max()))
+            torch.testing.assert_close(a, b, **tol)
+            torch.testing.assert_close(oa.state[a]["exp_avg"], ob.state[b]["exp_avg"], rtol=3e-6, atol=3e-7 * float(ob.state[b]["exp_avg"].abs().max()) + 1e-30)
+            torch.testing.assert_close(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"], rtol=3e-6, atol=1e-30)
+
+    def step(k):
+        for ga, gb in zip(oa.param_groups, ob.param_groups):
+            a, b = ga["params"][0], gb["params"][0]
+            gr = torch.randn(a.shape, generator=g).cuda() * (10.0 ** float(torch.randint(-6, 3, (1,), generator=g)))
+            if k % 2 and a.dim() > 1:
+                gr[::3] = 0  # invisible Gaussians: exact zeros
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step(), ob.step()
+        oa.zero_grad(set_to_none=True), ob.zero_grad(set_to_none=True)
+
+    for k in range(3):
+        step(k)
+        check()
+    # the reference's pruning surgery (scene/gaussian_model.py:356-371) applied to both optimizers, then more steps
+    for opt in (oa, ob):
+        for group in opt.param_groups[:6]:
+            old = group["params"][0]
+            mask = torch.arange(old.shape[0], device=old.device) % 5 != 0
+            st = opt.state.get(old)
+            st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"][mask], st["exp_avg_sq"][mask]
+            del opt.state[old]
+            group["params"][0] = torch.nn.Parameter(old[mask].requires_grad_(True))
+            opt.state[group["params"][0]] = st
+    for k in range(2):
+        step(k)
+        check()
+    sd = oa.state_dict()  # same layout as torch.optim.Adam's
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and sd["param_groups"][0]["eps"] == 1e-15
+
+
+def test_rejects_configurations_the_reference_does_not_use():
+    from riggs_amd.optim import FusedAdam
+    p = [torch.nn.Parameter(torch.zeros(4).cuda())]
+    with pytest.raises(NotImplementedError):
+        FusedAdam(p, weight_decay=0.1)
+    with pytest.raises(NotImplementedError):
+        FusedAdam(p, amsgrad=True)
+    o = FusedAdam([torch.nn.Parameter(torch.zeros(4))], lr=1e-3)
+    o.param_groups[0]["params"][0].grad = torch.ones(4)
+    with pytest.raises(RuntimeError):  # CPU tensors: the product path is GPU-only, no silent fallback
+        o.step()
+
+
+def test_densification_stats_match_reference_golden_and_oracle():
+    from oracle import optim_ref as O
+    gm = _model()
+    N = int(G["N"])
+    for it in range(2):
+        vt = SimpleNamespace(grad=torch.from_numpy(G["ds_grad%d" % it]).cuda())
+        gm.add_densification_stats(vt, torch.from_numpy(G["ds_filter%d" % it]).cuda())
+        np.testing.assert_allclose(gm.xyz_gradient_accum.cpu().numpy(), G["ds_accum%d" % it], rtol=1e-6)
+        np.testing.assert_array_equal(gm.denom.cpu().numpy(), G["ds_denom%d" % it])
+    # with the max_radii2D update of train_rig.py:333-335, against the oracle, ragged N
+    g = torch.Generator().manual_seed(9)
+    N = 100003
+    vg = (torch.randn(N, 3, generator=g) * 1e-3).cuda()
+    filt = (torch.rand(N, generator=g) > 0.5).cuda()
+    radii = torch.randint(0, 60, (N,), generator=g, dtype=torch.int32).cuda()
+    acc, den = torch.rand(N, 1, generator=g).cuda(), torch.randint(0, 9, (N, 1), generator=g).float().cuda()
+    mr = (torch.rand(N, generator=g) * 50).cuda()
+    want = O.densification_stats(vg.cpu().numpy(), filt.cpu().numpy(), acc.cpu().numpy(), den.cpu().numpy(), radii.cpu().numpy(), mr.cpu().numpy())
+    from riggs_amd.optim import densify_stats
+    densify_stats(vg, filt, acc, den, radii, mr)
+    np.testing.assert_allclose(acc.cpu().numpy(), want[0], rtol=1e-6)
+    np.testing.assert_array_equal(den.cpu().numpy(), want[1])
+    np.testing.assert_array_equal(mr.cpu().numpy(), want[2])
