@@ -221,6 +221,13 @@ def main():
             eager_step()
             if all(p.grad is not None for p in gm.parameters()):
                 gm.optimizer.step()
+        # ... and the fused image loss of §8-f rank 2 (L1 + SSIM forward, dL/dimage backward) on the rendered image
+        from riggs_amd.loss import l1_ssim
+        img_leaf = eager_step()["render"].detach().clone().requires_grad_(True)
+        for _ in range(min(args.steps, 20)):
+            l1v, sv = l1_ssim(img_leaf, gimg)
+            (0.8 * l1v + 0.2 * (1.0 - sv)).backward()
+            img_leaf.grad = None
         torch.cuda.synchronize()
         lib.riggs_prof_enable(0)
         for i, nm in enumerate(names):
@@ -246,8 +253,10 @@ def main():
             "tile_sort": 2 * N * 16 + R * 8 + 2 * ((N + 1023) // 1024) * (((w["W"] + 15) // 16) * ((w["H"] + 15) // 16)) * 4,
             "depth_sort": N * 16 * 4,
             "adam": N * 59 * 28,  # p, g, m, v read + p, m, v written, 59 floats per Gaussian
+            "loss_fwd": 3 * HW * 4 * (2 + 3),   # two images read, three derivative maps written
+            "loss_bwd": 3 * HW * 4 * (3 + 2 + 1),  # three maps + two images read, dL/dimage written
         }
-        dom = max((k for k in table if k in alg_bytes and k != "adam"), key=lambda k: table[k])  # (adam: not on the metric's path)
+        dom = max((k for k in table if k in alg_bytes and k not in ("adam", "loss_fwd", "loss_bwd")), key=lambda k: table[k])  # (adam: not on the metric's path)
         dom_ms, dom_bytes = table[dom], alg_bytes[dom]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         per_kernel = {k: {"ms": table[k], "GBps": round(alg_bytes[k] / (table[k] * 1e-3) / 1e9, 1),

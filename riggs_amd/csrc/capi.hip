@@ -22,7 +22,7 @@ void set_error(const char* fmt, ...) {
 // ---- event-based kernel timing -------------------------------------------------------
 static const char* kProfNames[PROF_COUNT] = {
     "preprocess_fwd", "depth_sort", "scan", "emit", "tile_sort", "ranges", "render_fwd", "render_bwd",
-    "preprocess_bwd", "fk_fwd", "lbs_fwd", "lbs_bwd", "fk_bwd", "knn", "pose_mlp_fwd", "pose_mlp_bwd", "adam"};
+    "preprocess_bwd", "fk_fwd", "lbs_fwd", "lbs_bwd", "fk_bwd", "knn", "pose_mlp_fwd", "pose_mlp_bwd", "adam", "loss_fwd", "loss_bwd"};
 struct ProfSlot {
   std::vector<hipEvent_t> start, stop;
   size_t used = 0;

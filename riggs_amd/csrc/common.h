@@ -49,7 +49,7 @@ static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a
 enum ProfId {
   PROF_PREPROCESS_FWD = 0, PROF_DEPTH_SORT, PROF_SCAN, PROF_EMIT, PROF_TILE_SORT, PROF_RANGES, PROF_RENDER_FWD,
   PROF_RENDER_BWD, PROF_PREPROCESS_BWD, PROF_FK_FWD, PROF_LBS_FWD, PROF_LBS_BWD, PROF_FK_BWD, PROF_KNN, PROF_POSE_FWD,
-  PROF_POSE_BWD, PROF_ADAM, PROF_COUNT
+  PROF_POSE_BWD, PROF_ADAM, PROF_LOSS_FWD, PROF_LOSS_BWD, PROF_COUNT
 };
 void prof_begin(int id, hipStream_t s);
 void prof_end(int id, hipStream_t s);

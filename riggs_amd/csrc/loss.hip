@@ -1,0 +1,208 @@
+// Image loss of the trainer: L1 and SSIM (11x11 Gaussian window, sigma 1.5, zero padding) of a
+// rendered image against the ground truth, and the gradient w.r.t. the rendered image that feeds the rasterizer backward.
+//   l1_loss / ssim / _ssim   /root/reference/utils/loss_utils.py:17-18, 33-77 ;  used at /root/reference/train_rig.py:508-509
+// The reference evaluates 5 grouped 11x11 conv2d (mu1, mu2, E[x^2], E[y^2], E[xy]) plus ~15 elementwise passes, and autograd
+// replays them backwards.  Here: ONE forward launch (tile of 16x16 pixels + 5-pixel halo staged in LDS, separable window,
+// the five moments kept in registers) that emits the two scalars' partial sums and three derivative maps
+//   d(ssim)/d(mu1), d(ssim)/d(E[x^2]), d(ssim)/d(E[xy])
+// and ONE backward launch that convolves the three maps with the (symmetric) window and combines them with the L1 sign:
+//   dL/dx = g_l1 * sign(x - y) / n  +  g_ssim / n * ( G*dmu + 2 x (G*de11) + y (G*de12) ).
+// HBM-bound by construction: forward reads 2 images and writes 3 maps, backward reads 3 maps + 2 images and writes 1.
+#include "common.h"
+
+namespace riggs {
+
+#define LS_T 16            // output tile edge
+#define LS_R 5             // window radius (11 taps)
+#define LS_S (LS_T + 2 * LS_R)  // staged edge: 26
+
+struct LossArgs {
+  int C, H, W;
+  const float *x, *y;      // rendered image, ground truth: (C, H, W)
+  float* maps;             // (3, C, H, W): dm/dmu1, dm/dE[x^2], dm/dE[xy]
+  float* partial;          // [blocks][2]: sum |x - y|, sum ssim_map
+  float* out2;             // [l1 mean, ssim mean]
+  const float *g_l1, *g_ssim;  // backward: upstream gradients of the two scalars (device scalars)
+  float* dx;               // (C, H, W)
+  float win[2 * LS_R + 1];
+};
+
+__device__ __forceinline__ float ld_pad(const float* __restrict__ p, int yy, int xx, int H, int W) {
+  return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? p[(size_t)yy * W + xx] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void l1_ssim_forward_kernel(LossArgs a) {
+  __shared__ float s_x[LS_S][LS_S + 1], s_y[LS_S][LS_S + 1];
+  __shared__ float s_h[5][LS_S][LS_T + 1];
+  __shared__ float s_red[2][4];
+  const int c = blockIdx.z, tx0 = blockIdx.x * LS_T, ty0 = blockIdx.y * LS_T;
+  const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
+  const float* X = a.x + (size_t)c * a.H * a.W;
+  const float* Y = a.y + (size_t)c * a.H * a.W;
+  for (int e = tid; e < LS_S * LS_S; e += 256) {
+    const int r = e / LS_S, q = e % LS_S;
+    s_x[r][q] = ld_pad(X, ty0 + r - LS_R, tx0 + q - LS_R, a.H, a.W);
+    s_y[r][q] = ld_pad(Y, ty0 + r - LS_R, tx0 + q - LS_R, a.H, a.W);
+  }
+  __syncthreads();
+  // horizontal pass: 26 rows x 16 columns x 5 moments
+  for (int e = tid; e < LS_S * LS_T; e += 256) {
+    const int r = e >> 4, q = e & 15;
+    float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+    for (int k = 0; k <= 2 * LS_R; k++) {
+      const float w = a.win[k], u = s_x[r][q + k], v = s_y[r][q + k];
+      m1 += w * u; m2 += w * v; e11 += w * (u * u); e22 += w * (v * v); e12 += w * (u * v);
+    }
+    s_h[0][r][q] = m1; s_h[1][r][q] = m2; s_h[2][r][q] = e11; s_h[3][r][q] = e22; s_h[4][r][q] = e12;
+  }
+  __syncthreads();
+  float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+  for (int k = 0; k <= 2 * LS_R; k++) {
+    const float w = a.win[k];
+    m1 += w * s_h[0][ly + k][lx]; m2 += w * s_h[1][ly + k][lx]; e11 += w * s_h[2][ly + k][lx];
+    e22 += w * s_h[3][ly + k][lx]; e12 += w * s_h[4][ly + k][lx];
+  }
+  const int px = tx0 + lx, py = ty0 + ly;
+  const bool in = px < a.W && py < a.H;
+  float ssim = 0.f, ad = 0.f;
+  if (in) {
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;  // loss_utils.py:67-68
+    const float mu1_sq = m1 * m1, mu2_sq = m2 * m2, mu12 = m1 * m2;
+    const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
+    const float A = 2.f * mu12 + C1, B = 2.f * s12 + C2, Cc = mu1_sq + mu2_sq + C1, D = s1 + s2 + C2;
+    const float inv = 1.0f / (Cc * D);
+    ssim = A * B * inv;
+    const size_t o = ((size_t)c * a.H + py) * a.W + px, plane = (size_t)a.C * a.H * a.W;
+    a.maps[o] = 2.f * m2 * (B - A) * inv - ssim * 2.f * m1 * (D - Cc) * inv;  // d/dmu1 (through sigma1^2, sigma12 too)
+    a.maps[plane + o] = -ssim / D;                                            // d/dE[x^2]
+    a.maps[2 * plane + o] = 2.f * A * inv;                                    // d/dE[xy]
+    ad = fabsf(s_x[ly + LS_R][lx + LS_R] - s_y[ly + LS_R][lx + LS_R]);
+  }
+  ad = wave_sum(ad); ssim = wave_sum(ssim);
+  if ((tid & 63) == 63) { s_red[0][tid >> 6] = ad; s_red[1][tid >> 6] = ssim; }
+  __syncthreads();
+  if (tid == 0) {
+    const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    a.partial[2 * b] = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
+    a.partial[2 * b + 1] = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
+  }
+}
+
+// fixed-order sum of the per-workgroup partials (deterministic), / n
+__global__ __launch_bounds__(1024) void l1_ssim_finish_kernel(int n_blocks, const float* __restrict__ partial, double inv_n,
+                                                              float* __restrict__ out2) {
+  __shared__ double s_w[2][16];
+  double s0 = 0.0, s1 = 0.0;
+  for (int i = threadIdx.x; i < n_blocks; i += 1024) { s0 += (double)partial[2 * i]; s1 += (double)partial[2 * i + 1]; }
+  for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+  if ((threadIdx.x & 63) == 0) { s_w[0][threadIdx.x >> 6] = s0; s_w[1][threadIdx.x >> 6] = s1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t0 = 0.0, t1 = 0.0;
+    for (int w = 0; w < 16; w++) { t0 += s_w[0][w]; t1 += s_w[1][w]; }
+    out2[0] = (float)(t0 * inv_n); out2[1] = (float)(t1 * inv_n);
+  }
+}
+
+__global__ __launch_bounds__(256) void l1_ssim_backward_kernel(LossArgs a) {
+  __shared__ float s_m[3][LS_S][LS_S + 1];
+  __shared__ float s_h[3][LS_S][LS_T + 1];
+  const int c = blockIdx.z, tx0 = blockIdx.x * LS_T, ty0 = blockIdx.y * LS_T;
+  const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
+  const size_t plane = (size_t)a.C * a.H * a.W, chan = (size_t)c * a.H * a.W;
+  for (int e = tid; e < LS_S * LS_S; e += 256) {
+    const int r = e / LS_S, q = e % LS_S;
+#pragma unroll
+    for (int k = 0; k < 3; k++) s_m[k][r][q] = ld_pad(a.maps + k * plane + chan, ty0 + r - LS_R, tx0 + q - LS_R, a.H, a.W);
+  }
+  __syncthreads();
+  for (int e = tid; e < LS_S * LS_T; e += 256) {
+    const int r = e >> 4, q = e & 15;
+    float h0 = 0.f, h1 = 0.f, h2 = 0.f;
+#pragma unroll
+    for (int k = 0; k <= 2 * LS_R; k++) {
+      const float w = a.win[k];
+      h0 += w * s_m[0][r][q + k]; h1 += w * s_m[1][r][q + k]; h2 += w * s_m[2][r][q + k];
+    }
+    s_h[0][r][q] = h0; s_h[1][r][q] = h1; s_h[2][r][q] = h2;
+  }
+  __syncthreads();
+  const int px = tx0 + lx, py = ty0 + ly;
+  if (px >= a.W || py >= a.H) return;
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+  for (int k = 0; k <= 2 * LS_R; k++) {
+    const float w = a.win[k];
+    c0 += w * s_h[0][ly + k][lx]; c1 += w * s_h[1][ly + k][lx]; c2 += w * s_h[2][ly + k][lx];
+  }
+  const size_t o = chan + (size_t)py * a.W + px;
+  const float x = a.x[o], y = a.y[o];
+  const float inv_n = 1.0f / (float)plane;
+  const float gl = a.g_l1 ? a.g_l1[0] : 0.f, gs = a.g_ssim ? a.g_ssim[0] : 0.f;
+  const float d = x - y;
+  const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);  // torch.abs backward: sign(0) = 0
+  a.dx[o] = gl * sgn * inv_n + gs * inv_n * (c0 + 2.f * x * c1 + y * c2);
+}
+
+static void fill_window(LossArgs& a) {
+  // gaussian(11, 1.5) of loss_utils.py:33-35: float32 tensor of the exps, divided by its float32 sum
+  float g[2 * LS_R + 1], s = 0.f;
+  for (int i = 0; i <= 2 * LS_R; i++) { g[i] = (float)exp(-(double)((i - LS_R) * (i - LS_R)) / (2.0 * 1.5 * 1.5)); s += g[i]; }
+  for (int i = 0; i <= 2 * LS_R; i++) a.win[i] = g[i] / s;
+}
+
+}  // namespace riggs
+
+using namespace riggs;
+
+extern "C" {
+
+static size_t ls_blocks(int C, int H, int W) { return (size_t)C * ((H + LS_T - 1) / LS_T) * ((W + LS_T - 1) / LS_T); }
+
+size_t riggs_l1_ssim_state_floats(int32_t C, int32_t H, int32_t W) {
+  return 3 * (size_t)C * H * W + 2 * ls_blocks(C, H, W);
+}
+
+int riggs_l1_ssim_forward(int32_t C, int32_t H, int32_t W, const float* image, const float* gt, float* state, float* out2,
+                          riggs_stream stream) {
+  RIGGS_REQUIRE(C >= 1 && H >= 1 && W >= 1 && C <= 65535, "bad image shape");
+  RIGGS_REQUIRE(image && gt && state && out2, "NULL buffer");
+  LossArgs a;
+  memset(&a, 0, sizeof(a));
+  a.C = C; a.H = H; a.W = W; a.x = image; a.y = gt;
+  a.maps = state; a.partial = state + 3 * (size_t)C * H * W; a.out2 = out2;
+  fill_window(a);
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((W + LS_T - 1) / LS_T, (H + LS_T - 1) / LS_T, C);
+  {
+    ProfScope ps(PROF_LOSS_FWD, s);
+    hipLaunchKernelGGL(l1_ssim_forward_kernel, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(l1_ssim_finish_kernel, dim3(1), dim3(1024), 0, s, (int)ls_blocks(C, H, W), a.partial,
+                       1.0 / ((double)C * H * W), out2);
+  }
+  RIGGS_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int riggs_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float* image, const float* gt, const float* state,
+                           const float* g_l1, const float* g_ssim, float* dL_dimage, riggs_stream stream) {
+  RIGGS_REQUIRE(C >= 1 && H >= 1 && W >= 1 && C <= 65535, "bad image shape");
+  RIGGS_REQUIRE(image && gt && state && dL_dimage, "NULL buffer");
+  LossArgs a;
+  memset(&a, 0, sizeof(a));
+  a.C = C; a.H = H; a.W = W; a.x = image; a.y = gt;
+  a.maps = const_cast<float*>(state); a.g_l1 = g_l1; a.g_ssim = g_ssim; a.dx = dL_dimage;
+  fill_window(a);
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((W + LS_T - 1) / LS_T, (H + LS_T - 1) / LS_T, C);
+  {
+    ProfScope ps(PROF_LOSS_BWD, s);
+    hipLaunchKernelGGL(l1_ssim_backward_kernel, grid, dim3(256), 0, s, a);
+  }
+  RIGGS_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

@@ -237,6 +237,30 @@ def fixture_optim(name, seed, N):
     print("wrote", name)
 
 
+def fixture_loss(name, seed, C, H, W):
+    """§8-f rank 2: the image loss exactly as the trainer evaluates it (train_rig.py:508-509) with the reference's own
+    l1_loss / ssim (utils/loss_utils.py) and autograd's gradient w.r.t. the rendered image."""
+    from utils.loss_utils import l1_loss, ssim
+    g = torch.Generator().manual_seed(seed)
+    gt = torch.rand(C, H, W, generator=g)
+    gt[:, : H // 3] = 0.0  # a flat black region (background): mu = sigma = 0 there
+    img = (gt + 0.15 * torch.randn(C, H, W, generator=g)).clamp(0, 1)
+    img[:, -3:, :] = gt[:, -3:, :]  # exact agreement on a strip: sign(0) = 0 in the L1 gradient
+    out = {"image": np_(img), "gt": np_(gt)}
+    x = img.clone().requires_grad_(True)
+    Ll1, s = l1_loss(x, gt), ssim(x, gt)
+    lam = 0.2
+    loss = (1.0 - lam) * Ll1 + lam * (1.0 - s)
+    loss.backward()
+    out.update(l1=float(Ll1.detach()), ssim=float(s.detach()), loss=float(loss.detach()), lambda_dssim=lam, grad_loss=np_(x.grad))
+    for key, fn in (("grad_l1", l1_loss), ("grad_ssim", ssim)):
+        x = img.clone().requires_grad_(True)
+        fn(x, gt).backward()
+        out[key] = np_(x.grad)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name)
+
+
 if __name__ == "__main__":
     fixture_deform("deform_chain8_n257", 11, 8, 257, -1, chain=True)
     fixture_deform("deform_tree24_n1024", 12, 24, 1024, -1, mask_random=True)
@@ -247,3 +271,4 @@ if __name__ == "__main__":
     fixture_glue("glue_aniso_fov", 31, 96, False, False)
     fixture_glue("glue_iso_K", 32, 96, True, True)
     fixture_optim("optim_adam_n67", 41, 67)
+    fixture_loss("loss_l1_ssim", 51, 3, 37, 45)
