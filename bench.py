@@ -54,13 +54,10 @@ def params_of(gm, sw):
     return gm.parameters() + [sw._node_radius] + list(sw.pose_net.parameters())
 
 
-def make_step(cam, gm, sw, gimg, arena, world):
+def make_step(cam, gm, sw, gimg, arena, world, allreduce):
     from riggs_amd.render import render
-    import torch.distributed as dist
     bg = torch.zeros(3, device=gimg.device)
-    from riggs_amd.dist import FlatGradAllReduce
     params = params_of(gm, sw)
-    allreduce = FlatGradAllReduce(params)
     t_in = sw.expand_time(cam.fid)
 
     def step():
@@ -150,7 +147,11 @@ def main():
     g = torch.Generator().manual_seed(w["seed"] + 100 + rank)
     target = torch.rand(3, w["H"], w["W"], generator=g).to(dev)
     gimg = torch.zeros(3, w["H"], w["W"], device=dev)
-    step = make_step(cam, gm, sw, gimg, arena, world)
+    # ONE flat gradient bucket: the HIP backward functions write every dL/dparam straight into it (riggs_amd/dist.py),
+    # so the data-parallel exchange is a single in-place RCCL all-reduce (AVG) with no pack / unpack / divide pass
+    from riggs_amd.dist import FlatGradAllReduce
+    bucket = FlatGradAllReduce(params_of(gm, sw))
+    step = make_step(cam, gm, sw, gimg, arena, world, bucket)
     pkg = step()
     gimg.copy_(torch.sign(pkg["render"].detach() - target) / (3 * w["H"] * w["W"]))
     torch.cuda.synchronize()
@@ -167,20 +168,17 @@ def main():
         gf = GraphedFrame(gm, sw, cam, torch.zeros(3, device=dev), params).capture()
         gf.set_inputs(gimg=gimg)
 
-        from riggs_amd.dist import FlatGradAllReduce
-        graph_allreduce = FlatGradAllReduce(params)
-
         def step():  # noqa: F811
             out = gf.run()
             if world > 1:
-                graph_allreduce(sources=gf.grads)  # graph-owned gradient buffers -> flat -> RCCL -> p.grad views
+                bucket(sources=gf.grads)  # the graph's gradient buffers ARE the bucket's slices: just the collective
             return out
         step()
         torch.cuda.synchronize()
         assert gf.check() == R, "graphed frame disagrees with the eager frame on the instance count"
 
     names = [lib.riggs_prof_name(i).decode() for i in range(lib.riggs_prof_count())]
-    eager_step = make_step(cam, gm, sw, gimg, arena, world)
+    eager_step = make_step(cam, gm, sw, gimg, arena, world, bucket)
 
     def barrier():
         if world > 1:

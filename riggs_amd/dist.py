@@ -12,35 +12,109 @@ import torch
 import torch.distributed as dist
 
 
-class FlatGradAllReduce:
-    """Packs ``p.grad`` of all parameters into one contiguous buffer, all-reduces it once, and hands
-    back views (so the optimizer sees averaged gradients without an unpack copy)."""
+# ---- zero-copy gradient bucket -------------------------------------------------------------------------
+# parameter data_ptr -> (flat buffer, offset, shape): the HIP backward functions (rasterizer, PoseMLP, deformation) write
+# a parameter's gradient straight into its slice of ONE flat buffer, so the all-reduce runs in place — no pack (71 MB
+# torch.cat at 300k Gaussians), no divide pass, no per-step Python loop re-pointing p.grad.
+_SLICES = {}
 
-    def __init__(self, params: Iterable[torch.Tensor], average: bool = True):
+
+def grad_out(param: torch.Tensor, shape=None) -> torch.Tensor:
+    """The tensor a backward should write ``dL/dparam`` into: the parameter's slice of a registered
+    ``FlatGradAllReduce`` bucket, else a fresh buffer.  Only valid when gradients are cleared (set to None) between
+    steps — accumulating into a live ``.grad`` that aliases the slice would double count."""
+    shape = tuple(param.shape if shape is None else shape)
+    ent = _SLICES.get(param.data_ptr())
+    if ent is not None:
+        flat, off, shp = ent
+        if shp == shape and flat.device == param.device:
+            n = 1
+            for d in shape:
+                n *= d
+            return flat[off:off + n].view(shape)
+    return torch.empty(shape, dtype=torch.float32, device=param.device)
+
+
+def grad_out_flat(params) -> torch.Tensor:
+    """One contiguous buffer for the gradients of ``params`` in order (the PoseMLP backward writes all of its
+    parameter gradients as one flat array): the bucket's own range when these parameters are registered back to
+    back, else a fresh buffer."""
+    total = sum(p.numel() for p in params)
+    ents = [_SLICES.get(p.data_ptr()) for p in params]
+    if total and all(e is not None for e in ents):
+        flat, off0 = ents[0][0], ents[0][1]
+        o = off0
+        ok = True
+        for p, (f, off, shp) in zip(params, ents):
+            ok = ok and f is flat and off == o and shp == tuple(p.shape)
+            o += p.numel()
+        if ok and flat.device == params[0].device:
+            return flat[off0:off0 + total]
+    return torch.empty(total, dtype=torch.float32, device=params[0].device)
+
+
+class FlatGradAllReduce:
+    """ONE flat fp32 buffer holding ``dL/dp`` of every parameter, all-reduced (averaged) in place once per step.
+
+    ``register=True`` (default on GPU) publishes the slices to the HIP backward functions (``grad_out``), which then
+    write gradients directly into the bucket: ``p.grad`` IS a view of the flat buffer and ``__call__`` is just the
+    collective.  Gradients that arrive in other tensors (CPU oracle pipeline, torch ops) are copied in first."""
+
+    def __init__(self, params: Iterable[torch.Tensor], average: bool = True, register: bool = None):
         self.params: List[torch.Tensor] = list(params)
         self.average = average
-        self.numel = sum(p.numel() for p in self.params)
-        self.flat = None
-
-    def __call__(self, sources=None):
-        """``sources``: gradient tensors to reduce (default: each parameter's ``.grad``) — e.g. the static
-        gradient buffers owned by a captured hipGraph."""
-        world = dist.get_world_size() if dist.is_initialized() else 1
-        p0 = self.params[0]
-        if self.flat is None or self.flat.device != p0.device:
-            self.flat = torch.empty(self.numel, dtype=torch.float32, device=p0.device)
-        src = [p.grad for p in self.params] if sources is None else sources
-        grads = [(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(src, self.params)]
-        torch.cat(grads, out=self.flat)
-        if world > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            if self.average:
-                self.flat.div_(world)
+        # every slice starts on a 16-byte boundary (the fused optimizer step reads gradients as float4)
+        self.offsets = []
         o = 0
         for p in self.params:
-            n = p.numel()
-            p.grad = self.flat[o:o + n].view_as(p)
-            o += n
+            self.offsets.append(o)
+            o += (p.numel() + 3) & ~3
+        self.numel = o
+        p0 = self.params[0]
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=p0.device)
+        self.views = [self.flat[o:o + p.numel()].view_as(p) for p, o in zip(self.params, self.offsets)]
+        self.registered = p0.is_cuda if register is None else register
+        if self.registered:
+            self.register()
+
+    def register(self):
+        for p, o in zip(self.params, self.offsets):
+            _SLICES[p.data_ptr()] = (self.flat, o, tuple(p.shape))
+        self.registered = True
+
+    def unregister(self):
+        for p in self.params:
+            ent = _SLICES.get(p.data_ptr())
+            if ent is not None and ent[0] is self.flat:
+                del _SLICES[p.data_ptr()]
+        self.registered = False
+
+    def __call__(self, sources=None):
+        """``sources``: gradient tensors to reduce (default: each parameter's ``.grad``).  Tensors that already are
+        the bucket's slices cost nothing; anything else is copied into place.  Afterwards ``p.grad`` views the
+        averaged flat buffer."""
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        if sources is None or sources is not getattr(self, "_in_place", None):
+            src = [p.grad for p in self.params] if sources is None else sources
+            in_place = True
+            for g, v, p in zip(src, self.views, self.params):
+                if g is None:
+                    v.zero_()
+                    in_place = False
+                elif g.data_ptr() != v.data_ptr():
+                    v.copy_(g.reshape(v.shape))
+                    in_place = False
+                if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                    p.grad = v
+            # a static list of gradient tensors (a captured hipGraph's) that already ARE the slices: skip this loop next time
+            self._in_place = sources if (in_place and sources is not None) else None
+        if world > 1:
+            if self.average and self.flat.is_cuda:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)  # RCCL averages in the collective: no divide pass
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+                if self.average:
+                    self.flat.div_(world)
         return self.flat
 
 

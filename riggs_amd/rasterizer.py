@@ -177,15 +177,17 @@ def rasterize_backward(s: _Saved, means3D, shs, colors_precomp, opacities, scale
     N, M, dev = s.N, s.M, means3D.device
     f32 = dict(dtype=torch.float32, device=dev)
     cfg = s.cfg
-    g_means3D = torch.empty(N, 3, **f32)
+    # (grad_out: the parameter's slice of a registered flat gradient bucket — riggs_amd/dist.py — else a fresh buffer)
+    from .dist import grad_out
+    g_means3D = grad_out(means3D, (N, 3))
     g_means2D = torch.empty(N, 3, **f32)
-    g_sh = torch.empty(N, shs.shape[1], 3, **f32) if shs is not None else None
-    g_sh_rest = torch.empty(N, shs_rest.shape[1], 3, **f32) if shs_rest is not None else None
+    g_sh = grad_out(shs, (N, shs.shape[1], 3)) if shs is not None else None
+    g_sh_rest = grad_out(shs_rest, (N, shs_rest.shape[1], 3)) if shs_rest is not None else None
     g_colors = torch.empty(N, 3, **f32) if colors_precomp is not None else None
-    g_opac = torch.empty(N, 1, **f32)
+    g_opac = grad_out(opacities, (N, 1))
     iso = bool(cfg.glue and cfg.isotropic)
-    g_scales = torch.empty(N, 1 if iso else 3, **f32) if scales is not None else None
-    g_rots = torch.empty(N, 4, **f32) if rotations is not None else None
+    g_scales = grad_out(scales, (N, 1 if iso else 3)) if scales is not None else None
+    g_rots = grad_out(rotations, (N, 4)) if rotations is not None else None
     g_cov = torch.empty(N, 6, **f32) if cov3D_precomp is not None else None
     g_dscaling = torch.empty(N, 3, **f32) if (d_scaling is not None and want_d_scaling_grad) else None
     ws = torch.empty(lib.riggs_raster_backward_workspace_bytes(N), dtype=torch.uint8, device=dev)

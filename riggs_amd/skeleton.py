@@ -122,8 +122,8 @@ class _PoseMLPFn(torch.autograd.Function):
         dev = acts.device
         g_rot = torch.zeros(n_rot, device=dev) if g_rot is None else g_rot.contiguous()
         g_tr = torch.zeros(3, device=dev) if g_tr is None else g_tr.contiguous()
-        total = sum(p.numel() for p in params)
-        flat = torch.empty(total, dtype=torch.float32, device=dev)
+        from .dist import grad_out_flat
+        flat = grad_out_flat(params)  # the flat gradient bucket's own range when one is registered
         dzs = torch.empty(lib.riggs_pose_mlp_backward_workspace_floats(depth, width, multires), dtype=torch.float32,
                           device=dev)
         Wp, bp = _PoseMLPFn._ptrs(params, depth)
@@ -194,7 +194,8 @@ class _DeformByPose(torch.autograd.Function):
         g_xyz = torch.zeros(N, 3, **f32) if g_xyz is None else g_xyz.contiguous()
         g_rot = torch.zeros(N, 4, **f32) if g_rot is None else g_rot.contiguous()
         dG = torch.empty(J, 12, **f32)
-        drho = torch.empty(J, **f32)
+        from .dist import grad_out
+        drho = grad_out(rho, (J,))
         dgt = torch.empty(3, **f32)
         need_mask = mflat is not None and ctx.needs_input_grad[3]
         dmask = torch.empty(N, **f32) if need_mask else None

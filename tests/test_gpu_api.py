@@ -115,3 +115,39 @@ def test_drop_in_module_surfaces():
         ref = RR.dist2_knn3(pts.numpy())
         got = distCUDA2(pts.cuda()).cpu().numpy()
         np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-9)
+
+
+def test_flat_gradient_bucket_receives_gradients_in_place():
+    """riggs_amd.dist: with a registered bucket every HIP backward writes dL/dparam into its slice of ONE flat buffer
+    (p.grad aliases it, the all-reduce needs no pack), and the values equal the unregistered run's."""
+    import bench
+    from riggs_amd.dist import FlatGradAllReduce
+    from riggs_amd.rasterizer import RasterArena
+    old = dict(bench.WORKLOAD)
+    bench.WORKLOAD.update(N=6001, J=8, H=96, W=112)
+    try:
+        sc, cam, gm, sw = bench.build_workload(0, "cuda:0")
+        params = bench.params_of(gm, sw)
+        gimg = torch.rand(3, 96, 112, generator=torch.Generator().manual_seed(1)).cuda()
+
+        def run(bucket):
+            step = bench.make_step(cam, gm, sw, gimg, RasterArena(), 1, bucket)
+            step()
+            torch.cuda.synchronize()
+            return [p.grad.clone() for p in params]
+        plain = FlatGradAllReduce(params, register=False)
+        ref = run(plain)
+        assert all(p.grad.data_ptr() != v.data_ptr() for p, v in zip(params, plain.views))
+        bucket = FlatGradAllReduce(params)
+        got = run(bucket)
+        lo, hi = bucket.flat.data_ptr(), bucket.flat.data_ptr() + bucket.flat.numel() * 4
+        assert all(lo <= p.grad.data_ptr() < hi and p.grad.data_ptr() == v.data_ptr() for p, v in zip(params, bucket.views))
+        assert all(v.data_ptr() % 16 == 0 for v in bucket.views)
+        for a, b in zip(got, ref):
+            torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-7 * float(b.abs().max()) + 1e-12)
+        bucket()  # world 1: no collective, gradients stay in place
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(params, bucket.views))
+        bucket.unregister()
+    finally:
+        bench.WORKLOAD.clear()
+        bench.WORKLOAD.update(old)
