@@ -636,6 +636,35 @@ __device__ __forceinline__ float wave_excl_sum_scan(float v) {
   return DPP_F(0.0f, v, 0x138, 0xf);
 }
 
+// Two independent wave64 exclusive scans at once, hand-scheduled.  The compiler expands every step of the generic
+// version above into v_mov (identity) + v_mov_dpp + v_op and pads the DPP read-after-write hazard (2 wait states)
+// with s_nop, one chain after the other: ~21 slots per product scan.  Here a step is ONE v_op_dpp in place — lanes
+// whose DPP source is invalid or masked off are simply not written (bound_ctrl:0), which IS the identity — and the
+// second chain fills the first one's hazard slots: 6 x (2 ops + s_nop 0) + 2 shifts for both scans.
+#define DUAL_SCAN_STEP(OP, CTRL) \
+  OP " %0, %0, %0 " CTRL "\n\t" OP " %1, %1, %1 " CTRL "\n\ts_nop 0\n\t"
+#define DUAL_SCAN_BODY(OP)                                                   \
+  "s_nop 1\n\t"                                                              \
+  DUAL_SCAN_STEP(OP, "row_shr:1 row_mask:0xf bank_mask:0xf")                 \
+  DUAL_SCAN_STEP(OP, "row_shr:2 row_mask:0xf bank_mask:0xf")                 \
+  DUAL_SCAN_STEP(OP, "row_shr:4 row_mask:0xf bank_mask:0xf")                 \
+  DUAL_SCAN_STEP(OP, "row_shr:8 row_mask:0xf bank_mask:0xf")                 \
+  DUAL_SCAN_STEP(OP, "row_bcast:15 row_mask:0xa bank_mask:0xf")              \
+  DUAL_SCAN_STEP(OP, "row_bcast:31 row_mask:0xc bank_mask:0xf")              \
+  "v_mov_b32_dpp %2, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"           \
+  "v_mov_b32_dpp %3, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"           \
+  "s_nop 0"
+__device__ __forceinline__ void dual_excl_prod_scan(float& a, float& b) {
+  float ea = 1.0f, eb = 1.0f;  // lane 0 has no source in the final shift: it keeps the identity
+  asm volatile(DUAL_SCAN_BODY("v_mul_f32_dpp") : "+v"(a), "+v"(b), "+v"(ea), "+v"(eb));
+  a = ea; b = eb;
+}
+__device__ __forceinline__ void dual_excl_sum_scan(float& a, float& b) {
+  float ea = 0.0f, eb = 0.0f;
+  asm volatile(DUAL_SCAN_BODY("v_add_f32_dpp") : "+v"(a), "+v"(b), "+v"(ea), "+v"(eb));
+  a = ea; b = eb;
+}
+
 // Chunk-parallel, instance-major backward.  One wave64 owns one chunk of 64 consecutive
 // instances of one tile: lane <-> instance, and the wave walks the tile's 256 pixels.  For a
 // pixel the 64 transmittances are an exclusive product scan over the lanes seeded with the
@@ -775,16 +804,18 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderBwdArgs a) {
       alA = vA ? alA : 0.f; alB = vB ? alB : 0.f;
       const float GA = vA ? GA_ : 0.f, GB = vB ? GB_ : 0.f;
       const float omA = 1.0f - alA, omB = 1.0f - alB;
-      const float TlA = paA.x * wave_excl_prod_scan(omA);
-      const float TlB = paB.x * wave_excl_prod_scan(omB);
+      float scA = omA, scB = omB;
+      dual_excl_prod_scan(scA, scB);
+      const float TlA = paA.x * scA, TlB = paB.x * scB;
       const float4 pbA = s_pb[wave][pl], pbB = s_pb[wave][pl + 1];
       const float gAA = s_pc[wave][pl], gAB = s_pc[wave][pl + 1];
       const float wA = alA * TlA, wB = alB * TlB;
       const float kA = pbA.x * cc.x + pbA.y * cc.y + pbA.z * cc.z + pbA.w * xy.z + gAA;
       const float kB = pbB.x * cc.x + pbB.y * cc.y + pbB.z * cc.z + pbB.w * xy.z + gAB;
       const float wkA = wA * kA, wkB = wB * kB;
-      const float preA = paA.y + wave_excl_sum_scan(wkA);
-      const float preB = paB.y + wave_excl_sum_scan(wkB);
+      float ssA = wkA, ssB = wkB;
+      dual_excl_sum_scan(ssA, ssB);
+      const float preA = paA.y + ssA, preB = paB.y + ssB;
       // dL/dalpha = T k - (suffix + T_final * bg.g) / (1 - alpha),  suffix = total - prefix - own
       float dLaA = TlA * kA - (paA.z - preA - wkA) * __builtin_amdgcn_rcpf(omA);
       float dLaB = TlB * kB - (paB.z - preB - wkB) * __builtin_amdgcn_rcpf(omB);
