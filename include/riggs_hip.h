@@ -165,8 +165,9 @@ int riggs_fk_backward(int32_t num_joints, const float* local_rot, const float* j
  * Kp = J-1 (K<=0) or K — needed by render_rig.py:156-158, not by training (may be NULL). */
 int riggs_lbs_forward(int32_t num_points, int32_t num_joints, int32_t K, const float* x, const float* joints,
                       const int32_t* parents, const float* node_radius_log, const float* transforms,
-                      const float* node_rot, const float* global_trans, const float* motion_mask, float* d_xyz,
-                      float* d_rotation, float* nn_weight, int64_t* nn_idx, riggs_stream stream);
+                      const float* node_rot, const float* global_trans, const float* motion_mask,
+                      const float* weight_mod /* NULL, or (N, J-1) = sigmoid(WeightMLP(x)): skeleton_warp.py:56-69; K = -1 only */,
+                      float* d_xyz, float* d_rotation, float* nn_weight, int64_t* nn_idx, riggs_stream stream);
 /* Backward: cotangents g_xyz (N,3), g_rot (N,4) -> dL/dtransforms (J,12), dL/dnode_radius_log (J),
  * dL/dglobal_trans (3), optional dL/dmotion_mask (N).  Reduction over N is done in-kernel
  * (registers -> workgroup partials -> a fixed-order second stage: run-to-run deterministic).
@@ -174,8 +175,9 @@ int riggs_lbs_forward(int32_t num_points, int32_t num_joints, int32_t K, const f
 int riggs_lbs_backward(int32_t num_points, int32_t num_joints, int32_t K, const float* x, const float* joints,
                        const int32_t* parents, const float* node_radius_log, const float* transforms,
                        const float* node_rot, const float* global_trans, const float* motion_mask,
-                       const float* g_xyz, const float* g_rot, float* dL_dtransforms, float* dL_dnode_radius_log,
-                       float* dL_dglobal_trans, float* dL_dmotion_mask,
+                       const float* weight_mod, const float* g_xyz, const float* g_rot, float* dL_dtransforms,
+                       float* dL_dnode_radius_log, float* dL_dglobal_trans, float* dL_dmotion_mask,
+                       float* dL_dweight_mod /* (N, J-1), required with weight_mod */,
                        void* workspace /* riggs_lbs_backward_workspace_bytes(N, J) */, riggs_stream stream);
 size_t riggs_lbs_backward_workspace_bytes(int32_t num_points, int32_t num_joints);
 

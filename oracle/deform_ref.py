@@ -133,10 +133,12 @@ def skin_weights(x, joints, parents, node_radius_log, K=-1, weight_offsets=None)
 # skeleton_warp.py:130-172 deform_by_pose (LBS-only mode)
 # --------------------------------------------------------------------------
 def deform_by_pose(x, joints, parents, node_radius_log, local_rot, global_trans, motion_mask, K=-1,
-                   template_offsets=None):
+                   template_offsets=None, weight_offsets=None):
+    """``weight_offsets`` (N, J-1) = sigmoid(WeightMLP(x)) (:56-69) and ``template_offsets`` (N, 3) = detail_net(x, pose)
+    (:152-158) are the outputs of the two optional per-Gaussian heads (evaluated by the caller)."""
     x = x.detach()  # :131
     R = quaternion_to_matrix(local_rot)  # :135
-    w, d2, idx = skin_weights(x, joints, parents, node_radius_log, K)  # :138
+    w, d2, idx = skin_weights(x, joints, parents, node_radius_log, K, weight_offsets)  # :138
     posed, G = fk_chain(R, joints[:, :3], parents)  # :140
     Grot = G[:, :3, :3]
     node_rot = matrix_to_quaternion(Grot.detach())  # :144

@@ -47,8 +47,8 @@ _SIGS = {
                               + [_P] + [_P] * 10 + [_P]),
     "riggs_fk_forward": (C.c_int, [C.c_int32] + [_P] * 8),
     "riggs_fk_backward": (C.c_int, [C.c_int32] + [_P] * 8),
-    "riggs_lbs_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [_P] * 13),
-    "riggs_lbs_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [_P] * 16),
+    "riggs_lbs_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [_P] * 14),
+    "riggs_lbs_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [_P] * 18),
     "riggs_lbs_backward_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "riggs_pose_mlp_acts_floats": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "riggs_pose_mlp_backward_workspace_floats": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),

@@ -198,6 +198,8 @@ struct Bone {        // 24 floats, LDS resident
 struct LbsArgs {
   int N, J, K;
   const float *x, *joints, *node_radius_log, *transforms, *node_rot, *global_trans, *motion_mask;
+  const float* weight_mod;  // (N, J-1) or NULL: sigmoid(WeightMLP(x)) multiplying the kernel weights (skeleton_warp.py:56-69)
+  float* dmod;              // backward: dL/dweight_mod (N, J-1) or NULL
   const int32_t* parents;
   float *d_xyz, *d_rot, *nn_weight;
   int64_t* nn_idx;
@@ -274,7 +276,9 @@ __global__ __launch_bounds__(256) void lbs_forward_kernel(LbsArgs a) {
     const Bone& b = bones[k];
     if (!((selmask >> k) & 1ull)) continue;
     const float d2 = bone_d2(b, px, py, pz);
-    const float v = fast_exp(-d2 * b.inv2r2) + 1e-7f;  // skeleton_warp.py:66,71
+    float u = fast_exp(-d2 * b.inv2r2);                // skeleton_warp.py:66
+    if (a.weight_mod) u *= a.weight_mod[(size_t)n * B + k];  // :68-69
+    const float v = u + 1e-7f;                          // :71
     sum += v;
 #pragma unroll
     for (int e = 0; e < 12; e++) M[e] += v * b.G[e];
@@ -306,7 +310,8 @@ __global__ __launch_bounds__(256) void lbs_forward_kernel(LbsArgs a) {
       }
     } else {
       for (int k = 0; k < B; k++) {
-        if (a.nn_weight) a.nn_weight[(size_t)n * B + k] = (fast_exp(-bone_d2(bones[k], px, py, pz) * bones[k].inv2r2) + 1e-7f) * inv;
+        if (a.nn_weight) a.nn_weight[(size_t)n * B + k] = (fast_exp(-bone_d2(bones[k], px, py, pz) * bones[k].inv2r2) *
+                                                              (a.weight_mod ? a.weight_mod[(size_t)n * B + k] : 1.0f) + 1e-7f) * inv;
         if (a.nn_idx) a.nn_idx[(size_t)n * B + k] = k + 1;
       }
     }
@@ -464,7 +469,7 @@ __global__ __launch_bounds__(256) void lbs_backward_bonelane_kernel(LbsArgs a) {
     const float gh0 = g0 * m, gh1 = g1 * m, gh2 = g2 * m;
     const float hh0 = h.x * m, hh1 = h.y * m, hh2 = h.z * m, hh3 = h.w * m;
     // pass 1: this lane's bones
-    float v[NBLK], u[NBLK], d2[NBLK], dw[NBLK], du[NBLK];
+    float v[NBLK], u[NBLK], d2[NBLK], dw[NBLK], du[NBLK], md[NBLK];
     float sum = 0.f, sv = 0.f, su = 0.f;
 #pragma unroll
     for (int bb = 0; bb < NBLK; bb++) {
@@ -473,7 +478,8 @@ __global__ __launch_bounds__(256) void lbs_backward_bonelane_kernel(LbsArgs a) {
       d2[bb] = bone_d2(b, px, py, pz);
       const bool on = valid && (k < B);
       u[bb] = on ? fast_exp(-d2[bb] * b.inv2r2) : 0.f;
-      v[bb] = on ? u[bb] + 1e-7f : 0.f;
+      md[bb] = (on && a.weight_mod) ? a.weight_mod[(size_t)n * B + k] : 1.0f;
+      v[bb] = on ? u[bb] * md[bb] + 1e-7f : 0.f;
       const float Ax = b.G[0] * px + b.G[1] * py + b.G[2] * pz + b.G[3];
       const float Ay = b.G[4] * px + b.G[5] * py + b.G[6] * pz + b.G[7];
       const float Az = b.G[8] * px + b.G[9] * py + b.G[10] * pz + b.G[11];
@@ -498,7 +504,8 @@ __global__ __launch_bounds__(256) void lbs_backward_bonelane_kernel(LbsArgs a) {
     for (int bb = 0; bb < NBLK; bb++) {
       const float w = v[bb] * inv;
       const float dLdv = (dw[bb] - S) * inv;
-      const float r = dLdv * u[bb] * d2[bb] * (2.0f * bones[bb * LB_BONES + bl].inv2r2);
+      const float r = dLdv * md[bb] * u[bb] * d2[bb] * (2.0f * bones[bb * LB_BONES + bl].inv2r2);
+      if (a.dmod && valid && bb * LB_BONES + bl < B) a.dmod[(size_t)n * B + bb * LB_BONES + bl] = dLdv * u[bb];  // v = u * mod + 1e-7
 #pragma unroll
       for (int e = 0; e < 12; e++) acc[bb][e] += w * P[e];
       acc[bb][12] += r;
@@ -597,12 +604,14 @@ static int fill_lbs(LbsArgs& a, int32_t N, int32_t J, int32_t K, const float* x,
 
 int riggs_lbs_forward(int32_t N, int32_t J, int32_t K, const float* x, const float* joints, const int32_t* parents,
                       const float* node_radius_log, const float* transforms, const float* node_rot,
-                      const float* global_trans, const float* motion_mask, float* d_xyz, float* d_rotation,
-                      float* nn_weight, int64_t* nn_idx, riggs_stream stream) {
+                      const float* global_trans, const float* motion_mask, const float* weight_mod, float* d_xyz,
+                      float* d_rotation, float* nn_weight, int64_t* nn_idx, riggs_stream stream) {
   LbsArgs a;
   int rc = fill_lbs(a, N, J, K, x, joints, parents, node_radius_log, transforms, node_rot, global_trans, motion_mask);
   if (rc) return rc;
   a.d_xyz = d_xyz; a.d_rot = d_rotation; a.nn_weight = nn_weight; a.nn_idx = nn_idx;
+  a.weight_mod = weight_mod;
+  RIGGS_REQUIRE(weight_mod == nullptr || K <= 0, "weight_mod is supported with K = -1 (all bones) only");
   if (N == 0) return 0;
   {
     ProfScope ps(PROF_LBS_FWD, (hipStream_t)stream);
@@ -619,19 +628,22 @@ size_t riggs_lbs_backward_workspace_bytes(int32_t N, int32_t J) {
 
 int riggs_lbs_backward(int32_t N, int32_t J, int32_t K, const float* x, const float* joints, const int32_t* parents,
                        const float* node_radius_log, const float* transforms, const float* node_rot,
-                       const float* global_trans, const float* motion_mask, const float* g_xyz, const float* g_rot,
-                       float* dL_dtransforms, float* dL_dnode_radius_log, float* dL_dglobal_trans,
-                       float* dL_dmotion_mask, void* workspace, riggs_stream stream) {
+                       const float* global_trans, const float* motion_mask, const float* weight_mod,
+                       const float* g_xyz, const float* g_rot, float* dL_dtransforms, float* dL_dnode_radius_log,
+                       float* dL_dglobal_trans, float* dL_dmotion_mask, float* dL_dweight_mod, void* workspace,
+                       riggs_stream stream) {
   LbsArgs a;
   int rc = fill_lbs(a, N, J, K, x, joints, parents, node_radius_log, transforms, node_rot, global_trans, motion_mask);
   if (rc) return rc;
   a.g_xyz = g_xyz; a.g_rot = g_rot; a.dG = dL_dtransforms; a.drho = dL_dnode_radius_log; a.dgt = dL_dglobal_trans;
   a.dmask = dL_dmotion_mask;
+  a.weight_mod = weight_mod; a.dmod = dL_dweight_mod;
+  RIGGS_REQUIRE(weight_mod == nullptr || (K <= 0 && dL_dweight_mod != nullptr), "weight_mod needs K = -1 and dL_dweight_mod");
   a.partial = (float*)workspace;
   RIGGS_REQUIRE(workspace != nullptr, "riggs_lbs_backward needs its workspace");
   hipStream_t s = (hipStream_t)stream;
   static const bool lbs_v1 = getenv("RIGGS_LBS_BWD_V1") != nullptr;
-  if (N == 0 || K > 0 || lbs_v1) {  // the atomic (thread-per-Gaussian) path accumulates into zeroed outputs
+  if (N == 0 || K > 0 || (lbs_v1 && !weight_mod)) {  // the atomic (thread-per-Gaussian) path accumulates into zeroed outputs
     RIGGS_HIP_CHECK(hipMemsetAsync(dL_dtransforms, 0, (size_t)J * 48, s));
     RIGGS_HIP_CHECK(hipMemsetAsync(dL_dnode_radius_log, 0, (size_t)J * 4, s));
     RIGGS_HIP_CHECK(hipMemsetAsync(dL_dglobal_trans, 0, 12, s));
@@ -641,7 +653,7 @@ int riggs_lbs_backward(int32_t N, int32_t J, int32_t K, const float* x, const fl
     ProfScope ps(PROF_LBS_BWD, s);
     static const bool v1 = getenv("RIGGS_LBS_BWD_V1") != nullptr;  // A/B switch: thread-per-Gaussian kernel
     const int nblk = (J - 1 + LB_BONES - 1) / LB_BONES;
-    if (K > 0 || v1) hipLaunchKernelGGL(lbs_backward_kernel, dim3((N + 255) / 256), dim3(256), 0, s, a);
+    if (K > 0 || (v1 && !weight_mod)) hipLaunchKernelGGL(lbs_backward_kernel, dim3((N + 255) / 256), dim3(256), 0, s, a);
     else switch (nblk) {
       case 1: launch_lbs_bwd_bonelane<1>(a, s); break;
       case 2: launch_lbs_bwd_bonelane<2>(a, s); break;

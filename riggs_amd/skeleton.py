@@ -5,10 +5,11 @@ Mirrors (same names, argument meaning, return dict) of
   * ``PoseMLP``        /root/reference/skeleton_utils/network_utils.py:115-150
   * ``SkeletonModel``  /root/reference/scene/skeleton_model.py:9-85 (``step`` only)
 The per-Gaussian work (bone distances, skinning weights, LBS of means and quaternions,
-and the reductions of the backward) runs in HIP kernels; the one-row PoseMLP stays in torch
-(SURVEY.md §8 A1).  The optional per-Gaussian MLP heads (WeightMLP / DeformMLP,
-``use_skinning_weight_mlp`` / ``use_template_offsets``) are a later row of SURVEY.md §8-f and
-raise NotImplementedError here rather than silently computing something else.
+and the reductions of the backward) and the one-row PoseMLP run in HIP kernels.  The optional
+per-Gaussian MLP heads of the stage-2 recipe (``WeightMLP`` / ``DeformMLP``, ``use_skinning_weight_mlp`` /
+``use_template_offsets``: network_utils.py:6-112) are batched MLPs whose GEMMs go to hipBLASLt through
+torch; the HIP skinning kernels consume the weight head's output (``weight_mod``) and return its gradient
+(the fused MFMA MLP is a later row).
 """
 from __future__ import annotations
 
@@ -84,6 +85,73 @@ class PoseMLP(nn.Module):
         return {"rotation": rot, "translation": self.translation_predictor(h)}
 
 
+class WeightMLP(nn.Module):
+    """Per-Gaussian skinning-weight modulation (skeleton_utils/network_utils.py:73-112): PE(x, 10 frequencies) -> 8 x
+    Linear(256) + ReLU with the embedding re-concatenated after layer 4 -> Linear(J-1) -> sigmoid.  A plain batched MLP:
+    its GEMMs go to hipBLASLt through torch (the fused MFMA version is a later row); what is HIP
+    here is the consumer — the skinning kernels take its output as ``weight_mod`` and return ``dL/dweight_mod``."""
+
+    def __init__(self, input_ch, output_ch, D=8, W=256, multires=10):
+        super().__init__()
+        self.D, self.W, self.output_ch, self.multires = D, W, output_ch, multires
+        self.skips = [D // 2]
+        self.input_ch = 3 * (1 + 2 * multires)
+        self.linear = nn.ModuleList(
+            [nn.Linear(self.input_ch, W)] + [nn.Linear(W, W) if i not in self.skips else nn.Linear(W + self.input_ch, W)
+                                             for i in range(D - 1)])
+        self.weight_predict = nn.Linear(W, output_ch)
+
+    def trainable_parameters(self):
+        return [{"params": list(self.parameters()), "name": "weight_mlp"}]
+
+    def forward(self, x, **kwargs):
+        x_emb = _embed(x, self.multires)
+        h = x_emb
+        for i, layer in enumerate(self.linear):
+            h = F.relu(layer(h))
+            if i in self.skips:
+                h = torch.cat([x_emb, h], -1)
+        return torch.sigmoid(self.weight_predict(h))
+
+
+class DeformMLP(nn.Module):
+    """Template offsets ``detail_net`` (skeleton_utils/network_utils.py:6-70): [PE(x, 4 frequencies), pose] -> 8 x
+    Linear(256) + ReLU (skip after layer 4) -> Linear(3), with the reference's initialisation.  Library GEMMs, as WeightMLP."""
+
+    def __init__(self, D=8, W=256, xyz_input_ch=3, time_input_ch=1, output_ch=3, t_multires=-1, multires=4):
+        super().__init__()
+        self.D, self.W, self.output_ch, self.t_multires, self.multires = D, W, output_ch, t_multires, multires
+        self.skips = [D // 2]
+        if t_multires > 0:
+            time_input_ch = time_input_ch * (1 + 2 * t_multires)
+        if multires > 0:
+            xyz_input_ch = xyz_input_ch * (1 + 2 * multires)
+        self.input_ch = xyz_input_ch + time_input_ch
+        self.linear = nn.ModuleList(
+            [nn.Linear(self.input_ch, W)] + [nn.Linear(W, W) if i not in self.skips else nn.Linear(W + self.input_ch, W)
+                                             for i in range(D - 1)])
+        self.gaussian_warp = nn.Linear(W, output_ch)
+        for layer in self.linear:
+            nn.init.kaiming_uniform_(layer.weight, mode="fan_in", nonlinearity="relu")
+            nn.init.zeros_(layer.bias)
+        nn.init.normal_(self.gaussian_warp.weight, mean=0, std=1e-5)
+        nn.init.zeros_(self.gaussian_warp.bias)
+
+    def trainable_parameters(self):
+        return [{"params": list(self.parameters()), "name": "offset_mlp"}]
+
+    def forward(self, x, t, **kwargs):
+        t_emb = _embed(t, self.t_multires) if self.t_multires > 0 else t
+        x_emb = _embed(x, self.multires) if self.multires > 0 else x
+        inp = torch.cat([x_emb, t_emb], dim=-1)
+        h = inp
+        for i, layer in enumerate(self.linear):
+            h = F.relu(layer(h))
+            if i in self.skips:
+                h = torch.cat([inp, h], -1)
+        return self.gaussian_warp(h)
+
+
 class _PoseMLPFn(torch.autograd.Function):
     """PoseMLP forward/backward through riggs_pose_mlp_* (csrc/pose_mlp.hip)."""
 
@@ -153,7 +221,8 @@ def fk_forward(local_rot, joints, parents_i32, global_trans):
     return transforms, node_rot, d_nodes
 
 
-def lbs_forward(x, joints, parents_i32, rho, transforms, node_rot, global_trans, mask, K=-1, want_weights=False):
+def lbs_forward(x, joints, parents_i32, rho, transforms, node_rot, global_trans, mask, K=-1, want_weights=False,
+                weight_mod=None):
     N, J = x.shape[0], joints.shape[0]
     f32 = dict(dtype=torch.float32, device=x.device)
     d_xyz = torch.empty(N, 3, **f32)
@@ -163,7 +232,8 @@ def lbs_forward(x, joints, parents_i32, rho, transforms, node_rot, global_trans,
     idx = torch.empty(N, Kp, dtype=torch.int64, device=x.device) if want_weights else None
     L.check(L.lib().riggs_lbs_forward(N, J, K, x.data_ptr(), joints.data_ptr(), parents_i32.data_ptr(), rho.data_ptr(),
                                       transforms.data_ptr(), node_rot.data_ptr(), global_trans.data_ptr(), L.ptr(mask),
-                                      d_xyz.data_ptr(), d_rot.data_ptr(), L.ptr(w), L.ptr(idx), L.stream_ptr()),
+                                      L.ptr(weight_mod), d_xyz.data_ptr(), d_rot.data_ptr(), L.ptr(w), L.ptr(idx),
+                                      L.stream_ptr()),
             "riggs_lbs_forward")
     return d_xyz, d_rot, w, idx
 
@@ -172,15 +242,18 @@ class _DeformByPose(torch.autograd.Function):
     """deform_by_pose as one autograd node: FK (1 workgroup) + fused skinning/LBS."""
 
     @staticmethod
-    def forward(ctx, local_rot, global_trans, rho, mask, x, joints, parents_i32, K):
+    def forward(ctx, local_rot, global_trans, rho, mask, x, joints, parents_i32, K, weight_mod=None):
         ctx.set_materialize_grads(False)
+        if weight_mod is not None:
+            weight_mod = L.require_cuda_f32("skinning weight offsets", weight_mod, (x.shape[0], joints.shape[0] - 1))
         local_rot = L.require_cuda_f32("local_rotation", local_rot, (joints.shape[0], 4))
         global_trans = L.require_cuda_f32("global_trans", global_trans.reshape(-1), (3,))
         rho = L.require_cuda_f32("_node_radius", rho, (joints.shape[0],))
         mflat = None if mask is None else L.require_cuda_f32("motion_mask", mask.reshape(-1), (x.shape[0],))
         transforms, node_rot, d_nodes = fk_forward(local_rot, joints, parents_i32, global_trans)
-        d_xyz, d_rot, _, _ = lbs_forward(x, joints, parents_i32, rho, transforms, node_rot, global_trans, mflat, K)
-        ctx.save_for_backward(local_rot, global_trans, rho, mflat, x, joints, parents_i32, transforms, node_rot)
+        d_xyz, d_rot, _, _ = lbs_forward(x, joints, parents_i32, rho, transforms, node_rot, global_trans, mflat, K,
+                                         weight_mod=weight_mod)
+        ctx.save_for_backward(local_rot, global_trans, rho, mflat, x, joints, parents_i32, transforms, node_rot, weight_mod)
         ctx.K = K
         ctx.mask_shape = None if mask is None else mask.shape
         ctx.mark_non_differentiable(node_rot)
@@ -188,7 +261,7 @@ class _DeformByPose(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_xyz, g_rot, g_nodes, g_transforms, _g_node_rot):
-        local_rot, global_trans, rho, mflat, x, joints, parents_i32, transforms, node_rot = ctx.saved_tensors
+        local_rot, global_trans, rho, mflat, x, joints, parents_i32, transforms, node_rot, weight_mod = ctx.saved_tensors
         N, J = x.shape[0], joints.shape[0]
         f32 = dict(dtype=torch.float32, device=x.device)
         g_xyz = torch.zeros(N, 3, **f32) if g_xyz is None else g_xyz.contiguous()
@@ -199,13 +272,15 @@ class _DeformByPose(torch.autograd.Function):
         dgt = torch.empty(3, **f32)
         need_mask = mflat is not None and ctx.needs_input_grad[3]
         dmask = torch.empty(N, **f32) if need_mask else None
+        dmod = torch.empty(N, J - 1, **f32) if weight_mod is not None else None
         lib = L.lib()
         st = L.stream_ptr()
         ws = torch.empty(lib.riggs_lbs_backward_workspace_bytes(N, J), dtype=torch.uint8, device=x.device)
         L.check(lib.riggs_lbs_backward(N, J, ctx.K, x.data_ptr(), joints.data_ptr(), parents_i32.data_ptr(),
                                        rho.data_ptr(), transforms.data_ptr(), node_rot.data_ptr(),
-                                       global_trans.data_ptr(), L.ptr(mflat), g_xyz.data_ptr(), g_rot.data_ptr(),
-                                       dG.data_ptr(), drho.data_ptr(), dgt.data_ptr(), L.ptr(dmask), ws.data_ptr(), st),
+                                       global_trans.data_ptr(), L.ptr(mflat), L.ptr(weight_mod), g_xyz.data_ptr(),
+                                       g_rot.data_ptr(), dG.data_ptr(), drho.data_ptr(), dgt.data_ptr(), L.ptr(dmask),
+                                       L.ptr(dmod), ws.data_ptr(), st),
                 "riggs_lbs_backward")
         if g_transforms is not None:
             dG = dG + g_transforms
@@ -214,7 +289,7 @@ class _DeformByPose(torch.autograd.Function):
         L.check(lib.riggs_fk_backward(J, local_rot.data_ptr(), joints.data_ptr(), parents_i32.data_ptr(), dG.data_ptr(),
                                       L.ptr(gn), dq.data_ptr(), dgt.data_ptr(), st), "riggs_fk_backward")
         gmask = dmask.reshape(ctx.mask_shape) if need_mask else None
-        return dq, dgt, drho, gmask, None, None, None, None
+        return dq, dgt, drho, gmask, None, None, None, None, dmod
 
 
 class _LazyDeformDict(dict):
@@ -269,7 +344,11 @@ class SkeletonWarp(nn.Module):
         self.register_buffer("parents", parent_indices.detach().long().cpu().clone())
         self.use_skinning_weight_mlp = use_skinning_weight_mlp
         self.use_template_offsets = use_template_offsets
+        self.skinning_weight_offsets = None
+        if use_skinning_weight_mlp:
+            self.skinning_weight_mlp = WeightMLP(input_ch=3, output_ch=J - 1)  # skeleton_warp.py:24-28
         self.control_nodes = nn.Parameter(torch.zeros(512, 3))  # checkpoint compatibility (:31)
+        self.detail_net = DeformMLP(xyz_input_ch=3, time_input_ch=J * 4, t_multires=-1)  # :32 (always constructed)
         self.template_offsets = None
         self.pose_net = PoseMLP(1, J * 4)
         self.register_buffer("_rot_bias", torch.tensor([1.0, 0.0, 0.0, 0.0]), persistent=False)  # skeleton_warp.py:118
@@ -292,15 +371,13 @@ class SkeletonWarp(nn.Module):
         self.control_nodes.data = nodes
 
     def trainable_parameters(self):
-        return [{"params": [self._node_radius], "name": "nodes"},
-                {"params": list(self.pose_net.parameters()), "name": "pose"}]
-
-    def _check_variant(self):
-        if self.use_skinning_weight_mlp or self.use_template_offsets:
-            raise NotImplementedError(
-                "WeightMLP / DeformMLP heads (use_skinning_weight_mlp / use_template_offsets) are not part of the "
-                "HIP hot path yet (SURVEY.md §8-f rank 3); the trainer keeps both off for the first 15000 "
-                "iterations (train_rig.py:398-400) and the argparse defaults are False.")
+        params = [{"params": [self._node_radius], "name": "nodes"},
+                  {"params": list(self.pose_net.parameters()), "name": "pose"}]
+        if self.use_skinning_weight_mlp:
+            params.append({"params": list(self.skinning_weight_mlp.parameters()), "name": "skinning_mlp"})
+        if self.use_template_offsets:
+            params.append({"params": list(self.detail_net.parameters()), "name": "detail_net"})
+        return params  # skeleton_warp.py:276-288
 
     def _parents_dev(self, device):
         if self._parents_i32 is None or self._parents_i32.device != device:
@@ -330,7 +407,6 @@ class SkeletonWarp(nn.Module):
         return self.deform_by_pose(x, self.get_pose_info(t), motion_mask)
 
     def deform_by_pose(self, x, node_attrs, motion_mask):
-        self._check_variant()
         x = L.require_cuda_f32("x", x.detach(), (x.shape[0], 3))
         local_rot, global_trans = node_attrs["local_rotation"], node_attrs["global_trans"]
         joints = self._joints()
@@ -338,15 +414,30 @@ class SkeletonWarp(nn.Module):
         mask = motion_mask
         if mask is not None and not isinstance(mask, torch.Tensor):
             mask = None if float(mask) == 1.0 else torch.full((x.shape[0], 1), float(mask), device=x.device)
+        weight_mod = None
+        if self.use_skinning_weight_mlp:  # skeleton_warp.py:56-61
+            if self.K > 0:
+                raise NotImplementedError("use_skinning_weight_mlp with K > 0: the reference gathers the MLP output with the "
+                                          "1-based bone indices (skeleton_warp.py:59), which runs off its (N, J-1) columns; "
+                                          "only K = -1 is well defined")
+            weight_mod = self.skinning_weight_mlp(x)
+            self.skinning_weight_offsets = weight_mod
         d_xyz, d_rot, d_nodes, transforms, node_rot = _DeformByPose.apply(
-            local_rot, global_trans, self._node_radius, mask, x, joints, par, self.K)
+            local_rot, global_trans, self._node_radius, mask, x, joints, par, self.K, weight_mod)
+        if self.use_template_offsets:  # skeleton_warp.py:152-158: offsets join the blended position before the mask
+            pose = local_rot.detach().reshape(-1)[None].expand(x.shape[0], -1)
+            self.template_offsets = self.detail_net(x, pose)
+            d_xyz = d_xyz + (self.template_offsets if mask is None else self.template_offsets * mask)
+        else:
+            self.template_offsets = None
+        wm = None if weight_mod is None else weight_mod.detach()
         rho = self._node_radius.detach()
         gt = global_trans.detach().reshape(-1).contiguous()
         mflat = None if mask is None else mask.detach().reshape(-1).contiguous()
 
         def producer():
             _, _, w, idx = lbs_forward(x, joints, par, rho.contiguous(), transforms.detach(), node_rot, gt, mflat,
-                                       self.K, want_weights=True)
+                                       self.K, want_weights=True, weight_mod=wm)
             return w, idx
         zs = getattr(self, "_zero_scaling", None)
         if zs is None or zs.shape[0] != x.shape[0] or zs.device != x.device:

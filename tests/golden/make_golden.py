@@ -261,6 +261,52 @@ def fixture_loss(name, seed, C, H, W):
     print("wrote", name)
 
 
+def seeded_heads(J, WeightCls, DeformCls, seed):
+    """The two per-Gaussian MLP heads with reproducible weights (the fixture stores checksums, not 4 MB of weights):
+    constructed standalone, in this order, right after torch.manual_seed(seed)."""
+    torch.manual_seed(seed)
+    wm = WeightCls(input_ch=3, output_ch=J - 1)
+    dn = DeformCls(xyz_input_ch=3, time_input_ch=J * 4, t_multires=-1)
+    with torch.no_grad():
+        dn.gaussian_warp.weight.mul_(2000.0)  # the reference initialises this head at std 1e-5: make the offsets visible
+        dn.gaussian_warp.bias.add_(0.01)
+    return wm, dn
+
+
+def fixture_deform_heads(name, seed, J, N):
+    """§8-f rank 3: deform_by_pose with BOTH per-Gaussian MLP heads on (use_skinning_weight_mlp, use_template_offsets:
+    skeleton_warp.py:24-32, 56-69, 152-158), K = -1, values and gradients incl. into the heads' parameters."""
+    from skeleton_utils.network_utils import DeformMLP, WeightMLP
+    g = torch.Generator().manual_seed(seed)
+    joints, parents = random_tree(g, J)
+    with S.quiet():
+        sw = SkeletonWarp(is_blender=True, joints=joints, parent_indices=parents, K=-1, is_scene_static=True,
+                          use_skinning_weight_mlp=True, use_template_offsets=True, hyper_dim=8)
+    sw.skinning_weight_mlp, sw.detail_net = seeded_heads(J, WeightMLP, DeformMLP, seed + 1000)
+    sw._node_radius.data = torch.log(0.15 + 0.2 * torch.rand(J, generator=g))
+    x = (joints[torch.randint(0, J, (N,), generator=g)] + 0.12 * torch.randn(N, 3, generator=g))
+    q = (torch.tensor([1.0, 0, 0, 0]) + 0.35 * torch.randn(J, 4, generator=g)).requires_grad_(True)
+    gt = (0.1 * torch.randn(3, generator=g)).requires_grad_(True)
+    mask = torch.rand(N, 1, generator=g)
+    out = sw.deform_by_pose(x, {"local_rotation": q, "global_trans": gt}, mask)
+    c_xyz, c_rot = torch.randn(N, 3, generator=g), torch.randn(N, 4, generator=g)
+    ((out["d_xyz"] * c_xyz).sum() + (out["d_rotation"] * c_rot).sum()).backward()
+    heads = {"wm": sw.skinning_weight_mlp, "dn": sw.detail_net}
+    picks = {"wm": ["linear.0.weight", "linear.5.bias", "weight_predict.weight"], "dn": ["linear.0.weight", "linear.5.bias", "gaussian_warp.weight"]}
+    res = dict(joints=np_(joints), parents=np_(parents), x=np_(x), node_radius=np_(sw._node_radius), local_rot=np_(q), global_trans=np_(gt),
+               mask=np_(mask), head_seed=seed + 1000, c_xyz=np_(c_xyz), c_rot=np_(c_rot), d_xyz=np_(out["d_xyz"]),
+               d_rotation=np_(out["d_rotation"]), nn_weight=np_(out["nn_weight"]), template_offsets=np_(sw.template_offsets),
+               skinning_weight_offsets=np_(sw.skinning_weight_offsets), g_local_rot=np_(q.grad), g_global_trans=np_(gt.grad),
+               g_node_radius=np_(sw._node_radius.grad))
+    for hk, mod in heads.items():
+        sd = dict(mod.named_parameters())
+        res["chk_" + hk] = np.array([float(p.detach().double().abs().sum()) for p in sd.values()])
+        for pn in picks[hk]:
+            res["g_%s_%s" % (hk, pn)] = np_(sd[pn].grad)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **res)
+    print("wrote", name)
+
+
 if __name__ == "__main__":
     fixture_deform("deform_chain8_n257", 11, 8, 257, -1, chain=True)
     fixture_deform("deform_tree24_n1024", 12, 24, 1024, -1, mask_random=True)
@@ -272,3 +318,4 @@ if __name__ == "__main__":
     fixture_glue("glue_iso_K", 32, 96, True, True)
     fixture_optim("optim_adam_n67", 41, 67)
     fixture_loss("loss_l1_ssim", 51, 3, 37, 45)
+    fixture_deform_heads("heads_tree12_n200", 61, 12, 200)

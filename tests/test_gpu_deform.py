@@ -120,12 +120,43 @@ def test_forward_through_pose_net_and_node_deformation():
     U.assert_close(nd["d_xyz"].detach().cpu().numpy(), (ref["d_nodes"] - sc["joints"]).numpy(), "node_deformation", 1e-5)
 
 
-def test_variants_not_in_scope_fail_loudly():
+def test_heads_with_topk_fail_loudly():
+    """use_skinning_weight_mlp with K > 0 is ill-defined in the reference (1-based gather off the (N, J-1) columns)."""
     sc = synth.make_scene(64, 8, 1)
-    sw = SkeletonWarp(joints=sc["joints"], parent_indices=sc["parents"], K=-1).cuda()  # reference defaults: both heads on
+    sw = SkeletonWarp(joints=sc["joints"], parent_indices=sc["parents"], K=3).cuda()  # reference defaults: both heads on
     with pytest.raises(NotImplementedError):
         sw.deform_by_pose(sc["xyz"].cuda(), {"local_rotation": sc["local_rotation"].cuda(),
                                              "global_trans": sc["global_trans"].cuda()}, sc["motion_mask"].cuda())
+
+
+def test_mlp_heads_match_reference_golden():
+    """both per-Gaussian heads on (the shipped stage-2 recipe) — the HIP skinning kernels take
+    sigmoid(WeightMLP(x)) as weight_mod and return dL/dweight_mod; values and every gradient (pose, radii, head
+    parameters) against the reference's own deform_by_pose."""
+    import os
+    from tests.test_oracle_heads import seeded_heads
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "heads_tree12_n200.npz"))
+    T = torch.from_numpy
+    J = G["joints"].shape[0]
+    sw = SkeletonWarp(joints=T(G["joints"]), parent_indices=T(G["parents"]), K=-1, hyper_dim=8)
+    sw.skinning_weight_mlp, sw.detail_net = seeded_heads(J, int(G["head_seed"]))
+    sw = sw.cuda()
+    sw._node_radius.data = T(G["node_radius"]).cuda()
+    assert {g["name"] for g in sw.trainable_parameters()} == {"nodes", "pose", "skinning_mlp", "detail_net"}
+    q = T(G["local_rot"]).cuda().requires_grad_(True)
+    gt = T(G["global_trans"]).cuda().requires_grad_(True)
+    out = sw.deform_by_pose(T(G["x"]).cuda(), {"local_rotation": q, "global_trans": gt}, T(G["mask"]).cuda())
+    U.assert_close(out["d_xyz"].detach().cpu().numpy(), G["d_xyz"], "d_xyz with heads", 1e-4)
+    U.assert_close(out["d_rotation"].detach().cpu().numpy(), G["d_rotation"], "d_rotation with heads", 1e-4)
+    U.assert_close(out["nn_weight"].cpu().numpy(), G["nn_weight"], "nn_weight with heads", 1e-4)
+    U.assert_close(sw.template_offsets.detach().cpu().numpy(), G["template_offsets"], "template offsets", 1e-4)
+    ((out["d_xyz"] * T(G["c_xyz"]).cuda()).sum() + (out["d_rotation"] * T(G["c_rot"]).cuda()).sum()).backward()
+    for got, key in ((q.grad, "g_local_rot"), (gt.grad, "g_global_trans"), (sw._node_radius.grad, "g_node_radius")):
+        U.assert_close(got.cpu().numpy(), G[key], key, 3e-4)
+    sd = {"wm": dict(sw.skinning_weight_mlp.named_parameters()), "dn": dict(sw.detail_net.named_parameters())}
+    for k in G.files:
+        if k.startswith("g_wm_") or k.startswith("g_dn_"):
+            U.assert_close(sd[k[2:4]][k[5:]].grad.cpu().numpy(), G[k], k, 2e-3)
 
 
 @pytest.mark.parametrize("width,J", [(256, 24), (32, 24), (64, 8)])
