@@ -119,3 +119,63 @@ class GaussianModel:
         from .optim import densify_stats
         densify_stats(viewspace_point_tensor.grad, update_filter, self.xyz_gradient_accum, self.denom, radii,
                       self.max_radii2D if radii is not None else None)
+
+    # ---- checkpoints (scene/gaussian_model.py:232-336) ------------------------------------------------------------
+    def construct_list_of_attributes(self):  # :232-251
+        names = ["x", "y", "z", "nx", "ny", "nz"]
+        names += ["f_dc_%d" % i for i in range(self._features_dc.shape[1] * self._features_dc.shape[2])]
+        names += ["f_rest_%d" % i for i in range(self._features_rest.shape[1] * self._features_rest.shape[2])]
+        names.append("opacity")
+        names += ["scale_%d" % i for i in range(self._scaling.shape[1])]
+        names += ["rot_%d" % i for i in range(self._rotation.shape[1])]
+        if self.fea_dim > 0:
+            names += ["fea_%d" % i for i in range(self.feature.shape[1])]
+        return names
+
+    def save_ply(self, path):  # :253-272 (same column order and (coefficient-major) SH flattening)
+        import os
+
+        import numpy as np
+
+        from .ply import write_vertex_ply
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        c = lambda t: t.detach().cpu().numpy()  # noqa: E731
+        xyz = c(self._xyz)
+        cols = [xyz, np.zeros_like(xyz), c(self._features_dc.detach().transpose(1, 2).flatten(start_dim=1).contiguous()),
+                c(self._features_rest.detach().transpose(1, 2).flatten(start_dim=1).contiguous()), c(self._opacity),
+                c(self._scaling), c(self._rotation)]
+        if self.fea_dim > 0:
+            cols.append(c(self.feature))
+        write_vertex_ply(path, self.construct_list_of_attributes(), np.concatenate(cols, axis=1))
+
+    def load_ply(self, path, og_number_points=-1, device="cuda"):  # :279-336
+        import numpy as np
+
+        from .ply import read_vertex_ply
+        self.og_number_points = og_number_points
+        names, v = read_vertex_ply(path)
+        col = lambda n: np.asarray(v[n], dtype=np.float32)  # noqa: E731
+        xyz = np.stack((col("x"), col("y"), col("z")), axis=1)
+        n = xyz.shape[0]
+        dc = np.stack((col("f_dc_0"), col("f_dc_1"), col("f_dc_2")), axis=1)[:, :, None]
+        rest_names = [k for k in names if k.startswith("f_rest_")]
+        assert len(rest_names) == 3 * (self.max_sh_degree + 1) ** 2 - 3
+        rest = np.stack([col(k) for k in rest_names], axis=1).reshape(n, 3, (self.max_sh_degree + 1) ** 2 - 1)
+        scales = np.stack([col(k) for k in names if k.startswith("scale_")], axis=1)
+        if self.use_isotropic_gs:
+            scales = scales[..., :1]
+        rots = np.stack([col(k) for k in names if k.startswith("rot")], axis=1)
+        feas = np.zeros((n, self.fea_dim), np.float32)
+        for i, k in enumerate([k for k in names if k.startswith("fea")]):
+            feas[:, i] = col(k)
+        P = lambda a: nn.Parameter(torch.tensor(a, dtype=torch.float, device=device).contiguous().requires_grad_(True))  # noqa: E731
+        self._xyz = P(xyz)
+        self._features_dc = nn.Parameter(torch.tensor(dc, dtype=torch.float, device=device).transpose(1, 2).contiguous().requires_grad_(True))
+        self._features_rest = nn.Parameter(torch.tensor(rest, dtype=torch.float, device=device).transpose(1, 2).contiguous().requires_grad_(True))
+        self._opacity = P(col("opacity")[:, None])
+        self._scaling = P(scales)
+        self._rotation = P(rots)
+        if self.fea_dim > 0:
+            self.feature = P(feas)
+        self.max_radii2D = torch.zeros(n, device=device)
+        self.active_sh_degree = self.max_sh_degree

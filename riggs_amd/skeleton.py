@@ -341,7 +341,7 @@ class SkeletonWarp(nn.Module):
         nodes[:, :3] = joints.detach().float().cpu()
         self.nodes = nn.Parameter(nodes, requires_grad=False)  # skeleton_warp.py:14-16
         self._node_radius = nn.Parameter(torch.randn(J))        # utils/time_utils.py:807
-        self.register_buffer("parents", parent_indices.detach().long().cpu().clone())
+        self.register_buffer("parents", parent_indices.detach().long().cpu().clone(), persistent=False)  # an attribute, not state, in the reference
         self.use_skinning_weight_mlp = use_skinning_weight_mlp
         self.use_template_offsets = use_template_offsets
         self.skinning_weight_offsets = None
@@ -351,6 +351,11 @@ class SkeletonWarp(nn.Module):
         self.detail_net = DeformMLP(xyz_input_ch=3, time_input_ch=J * 4, t_multires=-1)  # :32 (always constructed)
         self.template_offsets = None
         self.pose_net = PoseMLP(1, J * 4)
+        # checkpoint compatibility (skeleton.pth, scene/skeleton_model.py:43-72): the reference's state dict also holds the
+        # `inited` flag and the parameter of its (static) base network — utils/time_utils.py:288-300, :799-805
+        self.register_buffer("inited", torch.tensor(True))
+        self.network = nn.Module()
+        self.network.param = nn.Parameter(torch.zeros(1), requires_grad=False)
         self.register_buffer("_rot_bias", torch.tensor([1.0, 0.0, 0.0, 0.0]), persistent=False)  # skeleton_warp.py:118
         self._parents_i32 = None
         self._joints_key, self._joints_cache = None, None
@@ -369,6 +374,14 @@ class SkeletonWarp(nn.Module):
 
     def update_control_nodes(self, nodes):
         self.control_nodes.data = nodes
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        """Accepts the reference's ``skeleton.pth``: entries of its base deformation network other than the static
+        placeholder (a stage-1 leftover this path never evaluates) are dropped."""
+        mine = self.state_dict()
+        sd = {k: v for k, v in state_dict.items() if k in mine or not k.startswith("network.")}
+        sd.setdefault("network.param", mine["network.param"])  # absent when the file's base network was not the static one
+        return super().load_state_dict(sd, strict=strict, **kw)
 
     def trainable_parameters(self):
         params = [{"params": [self._node_radius], "name": "nodes"},
@@ -477,3 +490,24 @@ class SkeletonModel:
     def train_setting(self, lr=5e-4):
         groups = [{"params": g["params"], "lr": lr, "name": g["name"]} for g in self.deform.trainable_parameters()]
         self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+
+    # ---- checkpoints (scene/skeleton_model.py:43-72) --------------------------------------------------------------
+    def save_weights(self, model_path, iteration):
+        import os
+        out = os.path.join(model_path, "skeleton/iteration_{}".format(iteration))
+        os.makedirs(out, exist_ok=True)
+        torch.save(self.deform.state_dict(), os.path.join(out, "skeleton.pth"))
+
+    def load_weights(self, model_path, iteration=-1):
+        import os
+        root = os.path.join(model_path, "skeleton")
+        if iteration == -1:  # searchForMaxIteration (utils/system_utils.py)
+            its = [int(f.split("_")[-1]) for f in os.listdir(root)] if os.path.isdir(root) else []
+            if not its:
+                return False
+            iteration = max(its)
+        path = os.path.join(root, "iteration_{}/skeleton.pth".format(iteration))
+        if not os.path.exists(path):
+            return False
+        self.deform.load_state_dict(torch.load(path, map_location=self.deform.nodes.device))
+        return True
