@@ -428,7 +428,7 @@ __device__ __forceinline__ float row8_sum(float v) {
   return v;
 }
 
-template <int NBLK>
+template <int NBLK, bool MOD>
 __global__ __launch_bounds__(256) void lbs_backward_bonelane_kernel(LbsArgs a) {
   __shared__ Bone bones[MAX_J - 1 + LB_BONES];
   __shared__ float s_acc[MAX_J - 1 + LB_BONES][13];
@@ -478,8 +478,13 @@ __global__ __launch_bounds__(256) void lbs_backward_bonelane_kernel(LbsArgs a) {
       d2[bb] = bone_d2(b, px, py, pz);
       const bool on = valid && (k < B);
       u[bb] = on ? fast_exp(-d2[bb] * b.inv2r2) : 0.f;
-      md[bb] = (on && a.weight_mod) ? a.weight_mod[(size_t)n * B + k] : 1.0f;
-      v[bb] = on ? u[bb] * md[bb] + 1e-7f : 0.f;
+      if constexpr (MOD) {
+        md[bb] = on ? a.weight_mod[(size_t)n * B + k] : 1.0f;
+        v[bb] = on ? u[bb] * md[bb] + 1e-7f : 0.f;
+      } else {
+        md[bb] = 1.0f;
+        v[bb] = on ? u[bb] + 1e-7f : 0.f;
+      }
       const float Ax = b.G[0] * px + b.G[1] * py + b.G[2] * pz + b.G[3];
       const float Ay = b.G[4] * px + b.G[5] * py + b.G[6] * pz + b.G[7];
       const float Az = b.G[8] * px + b.G[9] * py + b.G[10] * pz + b.G[11];
@@ -504,8 +509,10 @@ __global__ __launch_bounds__(256) void lbs_backward_bonelane_kernel(LbsArgs a) {
     for (int bb = 0; bb < NBLK; bb++) {
       const float w = v[bb] * inv;
       const float dLdv = (dw[bb] - S) * inv;
-      const float r = dLdv * md[bb] * u[bb] * d2[bb] * (2.0f * bones[bb * LB_BONES + bl].inv2r2);
-      if (a.dmod && valid && bb * LB_BONES + bl < B) a.dmod[(size_t)n * B + bb * LB_BONES + bl] = dLdv * u[bb];  // v = u * mod + 1e-7
+      float r;
+      if constexpr (MOD) r = dLdv * md[bb] * u[bb] * d2[bb] * (2.0f * bones[bb * LB_BONES + bl].inv2r2);
+      else r = dLdv * u[bb] * d2[bb] * (2.0f * bones[bb * LB_BONES + bl].inv2r2);
+      if (MOD && valid && bb * LB_BONES + bl < B) a.dmod[(size_t)n * B + bb * LB_BONES + bl] = dLdv * u[bb];  // v = u * mod + 1e-7
 #pragma unroll
       for (int e = 0; e < 12; e++) acc[bb][e] += w * P[e];
       acc[bb][12] += r;
@@ -554,7 +561,9 @@ __global__ __launch_bounds__(256) void lbs_backward_finish_kernel(LbsArgs a, int
 template <int NBLK>
 static void launch_lbs_bwd_bonelane(const LbsArgs& a, hipStream_t s) {
   const int blocks = (a.N + LB_GPB - 1) / LB_GPB;
-  hipLaunchKernelGGL(lbs_backward_bonelane_kernel<NBLK>, dim3(blocks), dim3(256), 0, s, a);
+  // (the weight-modulated variant — WeightMLP head on — is a separate instantiation: the LBS-only kernel keeps its registers)
+  if (a.weight_mod) hipLaunchKernelGGL((lbs_backward_bonelane_kernel<NBLK, true>), dim3(blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((lbs_backward_bonelane_kernel<NBLK, false>), dim3(blocks), dim3(256), 0, s, a);
   hipLaunchKernelGGL(lbs_backward_finish_kernel, dim3((a.J - 1) * 13 + 3), dim3(256), 0, s, a, blocks);
 }
 

@@ -345,12 +345,14 @@ class SkeletonWarp(nn.Module):
         self.use_skinning_weight_mlp = use_skinning_weight_mlp
         self.use_template_offsets = use_template_offsets
         self.skinning_weight_offsets = None
-        if use_skinning_weight_mlp:
-            self.skinning_weight_mlp = WeightMLP(input_ch=3, output_ch=J - 1)  # skeleton_warp.py:24-28
         self.control_nodes = nn.Parameter(torch.zeros(512, 3))  # checkpoint compatibility (:31)
-        self.detail_net = DeformMLP(xyz_input_ch=3, time_input_ch=J * 4, t_multires=-1)  # :32 (always constructed)
         self.template_offsets = None
         self.pose_net = PoseMLP(1, J * 4)
+        # (the heads are constructed AFTER pose_net: they draw from the global RNG, and the pose network of a given seed
+        # — the benchmark's scene — must not depend on whether they exist)
+        if use_skinning_weight_mlp:
+            self.skinning_weight_mlp = WeightMLP(input_ch=3, output_ch=J - 1)  # skeleton_warp.py:24-28
+        self.detail_net = DeformMLP(xyz_input_ch=3, time_input_ch=J * 4, t_multires=-1)  # :32 (always constructed)
         # checkpoint compatibility (skeleton.pth, scene/skeleton_model.py:43-72): the reference's state dict also holds the
         # `inited` flag and the parameter of its (static) base network — utils/time_utils.py:288-300, :799-805
         self.register_buffer("inited", torch.tensor(True))
