@@ -231,6 +231,14 @@ int riggs_pose_mlp_backward(int32_t depth, int32_t width, int32_t multires, int3
 int riggs_adam_step(int32_t n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
                     float* const* exp_avg_sq, const int64_t* numel, const double* lr, const int64_t* step, double beta1,
                     double beta2, double eps, riggs_stream stream);
+/* The same update with the step counts (and optionally the learning rates) in DEVICE memory, the layout of
+ * torch.optim.Adam(capturable=True): step_dev[k] / lr_dev[k] are HOST arrays of DEVICE pointers to 0-dim float tensors;
+ * step_dev[k][0] holds the count AFTER this update (the caller increments it on the stream beforehand); lr_dev may be
+ * NULL or hold NULL entries (then lr[k], a host value baked into the launch, is used).  Safe to capture in a hipGraph. */
+int riggs_adam_step_capturable(int32_t n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
+                               float* const* exp_avg_sq, const int64_t* numel, const double* lr,
+                               const float* const* step_dev, const float* const* lr_dev, double beta1, double beta2,
+                               double eps, riggs_stream stream);
 int riggs_densify_stats(int32_t num_points, const float* viewspace_grad, const uint8_t* update_filter,
                         const int32_t* radii, float* xyz_gradient_accum, float* denom, float* max_radii2D,
                         riggs_stream stream);

@@ -24,6 +24,12 @@ struct AdamArgs {
   float neg_step_size[ADAM_MAX_GROUPS];    // -lr / (1 - beta1^t)
   float bc2_sqrt[ADAM_MAX_GROUPS];         // sqrt(1 - beta2^t)
   float w1, beta2, w2, eps;                // 1 - beta1, beta2, 1 - beta2, eps
+  // capturable mode (hipGraph replay): the step count and, optionally, the learning rate live in DEVICE memory, as
+  // torch.optim.Adam(capturable=True) keeps them; the coefficients above are then derived inside the kernel
+  const float* step_dev[ADAM_MAX_GROUPS];  // 0-dim float tensors holding the count AFTER this update, or NULL
+  const float* lr_dev[ADAM_MAX_GROUPS];    // 0-dim float tensors, or NULL (= lr_host)
+  double lr_host[ADAM_MAX_GROUPS];
+  double beta1_d, beta2_d;
 };
 
 __device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, float w1, float beta2, float w2, float eps,
@@ -36,6 +42,19 @@ __device__ __forceinline__ void adam_update(float& p, float g, float& m, float& 
 }
 
 __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a) {
+  __shared__ float s_ns[ADAM_MAX_GROUPS], s_bs[ADAM_MAX_GROUPS];
+  if (threadIdx.x < ADAM_MAX_GROUPS) {
+    const int k = threadIdx.x;
+    float ns = a.neg_step_size[k], bs = a.bc2_sqrt[k];
+    if (k < a.n_groups && a.step_dev[k]) {  // same double-precision bias corrections as the host path, from device state
+      const double t = (double)a.step_dev[k][0];
+      const double lr = a.lr_dev[k] ? (double)a.lr_dev[k][0] : a.lr_host[k];
+      ns = (float)(-(lr / (1.0 - pow(a.beta1_d, t))));
+      bs = (float)sqrt(1.0 - pow(a.beta2_d, t));
+    }
+    s_ns[k] = ns; s_bs[k] = bs;
+  }
+  __syncthreads();
   const int64_t total = a.vec_start[a.n_groups];
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     int gi = 0;
@@ -48,7 +67,7 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a) {
     const float* __restrict__ G = a.g[gi];
     float* __restrict__ M = a.m[gi];
     float* __restrict__ V = a.v[gi];
-    const float ns = a.neg_step_size[gi], bs = a.bc2_sqrt[gi];
+    const float ns = s_ns[gi], bs = s_bs[gi];
     if (e + 4 <= n) {
       float4 p = *reinterpret_cast<float4*>(P + e);
       const float4 g = *reinterpret_cast<const float4*>(G + e);
@@ -89,9 +108,10 @@ using namespace riggs;
 
 extern "C" {
 
-int riggs_adam_step(int32_t n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
-                    float* const* exp_avg_sq, const int64_t* numel, const double* lr, const int64_t* step, double beta1,
-                    double beta2, double eps, riggs_stream stream) {
+static int adam_launch(int32_t n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
+                       float* const* exp_avg_sq, const int64_t* numel, const double* lr, const int64_t* step,
+                       const float* const* step_dev, const float* const* lr_dev, double beta1, double beta2, double eps,
+                       riggs_stream stream) {
   RIGGS_REQUIRE(n_groups >= 0 && n_groups <= ADAM_MAX_GROUPS, "at most 8 parameter tensors per launch");
   AdamArgs a;
   memset(&a, 0, sizeof(a));
@@ -99,7 +119,7 @@ int riggs_adam_step(int32_t n_groups, float* const* params, const float* const* 
   int64_t vs = 0;
   for (int k = 0; k < n_groups; k++) {
     RIGGS_REQUIRE(params[k] && grads[k] && exp_avg[k] && exp_avg_sq[k], "NULL tensor in an Adam group");
-    RIGGS_REQUIRE(numel[k] >= 0 && step[k] >= 1, "numel >= 0 and step >= 1 (the count AFTER this update) are required");
+    RIGGS_REQUIRE(numel[k] >= 0 && (step_dev || step[k] >= 1), "numel >= 0 and step >= 1 (the count AFTER this update) are required");
     RIGGS_REQUIRE((((uintptr_t)params[k] | (uintptr_t)grads[k] | (uintptr_t)exp_avg[k] | (uintptr_t)exp_avg_sq[k]) & 15) == 0,
                   "Adam tensors must be 16-byte aligned");
     a.p[k] = params[k]; a.g[k] = grads[k]; a.m[k] = exp_avg[k]; a.v[k] = exp_avg_sq[k];
@@ -107,13 +127,21 @@ int riggs_adam_step(int32_t n_groups, float* const* params, const float* const* 
     a.vec_start[k] = vs;
     vs += (numel[k] + 3) / 4;
     // bias corrections in double, as torch does with Python floats (torch/optim/adam.py _single_tensor_adam)
-    const double bc1 = 1.0 - pow(beta1, (double)step[k]), bc2 = 1.0 - pow(beta2, (double)step[k]);
-    a.neg_step_size[k] = (float)(-(lr[k] / bc1));
-    a.bc2_sqrt[k] = (float)sqrt(bc2);
+    if (step_dev) {
+      RIGGS_REQUIRE(step_dev[k] != nullptr, "capturable mode needs a device step tensor per group");
+      a.step_dev[k] = step_dev[k];
+      a.lr_dev[k] = lr_dev ? lr_dev[k] : nullptr;
+      a.lr_host[k] = lr[k];
+    } else {
+      const double bc1 = 1.0 - pow(beta1, (double)step[k]), bc2 = 1.0 - pow(beta2, (double)step[k]);
+      a.neg_step_size[k] = (float)(-(lr[k] / bc1));
+      a.bc2_sqrt[k] = (float)sqrt(bc2);
+    }
   }
   a.vec_start[n_groups] = vs;
   for (int k = n_groups + 1; k <= ADAM_MAX_GROUPS; k++) a.vec_start[k] = vs;
   a.w1 = (float)(1.0 - beta1); a.beta2 = (float)beta2; a.w2 = (float)(1.0 - beta2); a.eps = (float)eps;
+  a.beta1_d = beta1; a.beta2_d = beta2;
   if (vs == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   {
@@ -124,6 +152,20 @@ int riggs_adam_step(int32_t n_groups, float* const* params, const float* const* 
   }
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
+}
+
+int riggs_adam_step(int32_t n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
+                    float* const* exp_avg_sq, const int64_t* numel, const double* lr, const int64_t* step, double beta1,
+                    double beta2, double eps, riggs_stream stream) {
+  return adam_launch(n_groups, params, grads, exp_avg, exp_avg_sq, numel, lr, step, nullptr, nullptr, beta1, beta2, eps, stream);
+}
+
+int riggs_adam_step_capturable(int32_t n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
+                               float* const* exp_avg_sq, const int64_t* numel, const double* lr,
+                               const float* const* step_dev, const float* const* lr_dev, double beta1, double beta2,
+                               double eps, riggs_stream stream) {
+  RIGGS_REQUIRE(step_dev != nullptr, "step_dev is NULL");
+  return adam_launch(n_groups, params, grads, exp_avg, exp_avg_sq, numel, lr, nullptr, step_dev, lr_dev, beta1, beta2, eps, stream);
 }
 
 int riggs_densify_stats(int32_t N, const float* viewspace_grad, const uint8_t* update_filter, const int32_t* radii,

@@ -20,12 +20,18 @@ _MAX = 8  # tensors per launch (ADAM_MAX_GROUPS in csrc/optim.hip)
 
 
 class FusedAdam(torch.optim.Adam):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, **kw):
+    """``capturable=True`` keeps every parameter's step count as a 0-dim DEVICE tensor (the layout of
+    ``torch.optim.Adam(capturable=True)``) and accepts 0-dim device tensors as a group's ``lr``: the bias corrections are
+    then evaluated inside the kernel, so a captured hipGraph of the step stays correct across replays (a learning-rate
+    schedule is applied with ``group["lr"].fill_(value)`` between replays)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, capturable=False, **kw):
         if weight_decay != 0 or amsgrad or kw.get("maximize", False):
             raise NotImplementedError("FusedAdam implements the reference's configuration: plain Adam "
                                       "(weight_decay=0, amsgrad=False, maximize=False)")
-        kw.pop("foreach", None), kw.pop("fused", None), kw.pop("capturable", None)
+        kw.pop("foreach", None), kw.pop("fused", None)
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, foreach=False)
+        self.hip_capturable = bool(capturable)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -34,10 +40,14 @@ class FusedAdam(torch.optim.Adam):
             with torch.enable_grad():
                 loss = closure()
         lib = L.lib()
+        cap = getattr(self, "hip_capturable", False)
         by_cfg = {}
         for group in self.param_groups:
             if group.get("weight_decay", 0) != 0 or group.get("amsgrad", False) or group.get("maximize", False):
                 raise NotImplementedError("FusedAdam: plain Adam only")
+            lr = group["lr"]
+            if isinstance(lr, torch.Tensor) and not cap:
+                lr = float(lr)
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -47,28 +57,42 @@ class FusedAdam(torch.optim.Adam):
                 if not p.is_contiguous():
                     raise L.RiggsHipError("FusedAdam needs contiguous parameters")
                 st = self.state[p]
-                if len(st) == 0:  # same lazy initialisation as torch.optim.Adam
-                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                if len(st) == 0:  # same lazy initialisation as torch.optim.Adam (device step tensor when capturable)
+                    st["step"] = torch.zeros((), dtype=torch.float32, device=p.device) if cap else torch.tensor(0.0, dtype=torch.float32)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
+                if cap and not st["step"].is_cuda:
+                    st["step"] = st["step"].to(p.device)
                 m, v = st["exp_avg"], st["exp_avg_sq"]
                 if not (m.is_contiguous() and v.is_contiguous()):
                     st["exp_avg"], st["exp_avg_sq"] = m, v = m.contiguous(), v.contiguous()
                 g = L.require_cuda_f32("gradient", p.grad, tuple(p.shape))
                 key = (group["betas"][0], group["betas"][1], group["eps"])
-                by_cfg.setdefault(key, []).append((p, g, m, v, float(group["lr"]), int(st["step"].item())))
+                by_cfg.setdefault(key, []).append((p, g, m, v, lr, st["step"]))
         st_ptr = L.stream_ptr()
+        if cap:
+            steps = [t[5] for items in by_cfg.values() for t in items]
+            if steps:
+                torch._foreach_add_(steps, 1.0)  # one multi-tensor launch; the kernels below read the new counts
         for (b1, b2, eps), items in by_cfg.items():
             for i in range(0, len(items), _MAX):
                 chunk = items[i:i + _MAX]
                 n = len(chunk)
                 arr = lambda k: (C.c_void_p * n)(*[t[k].data_ptr() for t in chunk])  # noqa: E731
                 numel = (C.c_int64 * n)(*[t[0].numel() for t in chunk])
-                lr = (C.c_double * n)(*[t[4] for t in chunk])
-                steps = (C.c_int64 * n)(*[t[5] for t in chunk])
-                L.check(lib.riggs_adam_step(n, arr(0), arr(1), arr(2), arr(3), numel, lr, steps, float(b1), float(b2),
-                                            float(eps), st_ptr), "riggs_adam_step")
+                if cap:
+                    lr_host = (C.c_double * n)(*[0.0 if isinstance(t[4], torch.Tensor) else float(t[4]) for t in chunk])
+                    lr_dev = (C.c_void_p * n)(*[L.require_cuda_f32("lr", t[4]).data_ptr() if isinstance(t[4], torch.Tensor) else None
+                                                for t in chunk])
+                    L.check(lib.riggs_adam_step_capturable(n, arr(0), arr(1), arr(2), arr(3), numel, lr_host, arr(5), lr_dev,
+                                                           float(b1), float(b2), float(eps), st_ptr), "riggs_adam_step_capturable")
+                else:
+                    for t in chunk:
+                        t[5].add_(1)
+                    lr = (C.c_double * n)(*[float(t[4]) for t in chunk])
+                    steps = (C.c_int64 * n)(*[int(t[5].item()) for t in chunk])
+                    L.check(lib.riggs_adam_step(n, arr(0), arr(1), arr(2), arr(3), numel, lr, steps, float(b1), float(b2),
+                                                float(eps), st_ptr), "riggs_adam_step")
         return loss
 
 

@@ -131,3 +131,58 @@ def test_densification_stats_match_reference_golden_and_oracle():
     np.testing.assert_allclose(acc.cpu().numpy(), want[0], rtol=1e-6)
     np.testing.assert_array_equal(den.cpu().numpy(), want[1])
     np.testing.assert_array_equal(mr.cpu().numpy(), want[2])
+
+
+def test_capturable_adam_replays_in_a_hipgraph_like_eager_torch_adam():
+    """capturable=True: step counts (and a scheduled lr) in device memory, so ONE captured step replays correctly."""
+    from riggs_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(11)
+    shapes = [(1001, 3), (1001, 15, 3), (513,)]
+    mk = lambda: [torch.nn.Parameter(torch.randn(s, generator=torch.Generator().manual_seed(i)).cuda()) for i, s in enumerate(shapes)]  # noqa: E731
+    pa, pb = mk(), mk()
+    lr_t = torch.tensor(8e-4, device="cuda")
+    oa = FusedAdam([{"params": [pa[0]], "lr": lr_t}, {"params": [pa[1]], "lr": 2e-3}, {"params": [pa[2]], "lr": 1e-2}],
+                   lr=0.0, eps=1e-15, capturable=True)
+    ob = torch.optim.Adam([{"params": [pb[0]], "lr": 8e-4}, {"params": [pb[1]], "lr": 2e-3}, {"params": [pb[2]], "lr": 1e-2}],
+                          lr=0.0, eps=1e-15)
+    grads = [torch.zeros_like(p) for p in pa]  # static gradient buffers, refilled before every replay
+    for p, gr in zip(pa, grads):
+        p.grad = gr
+
+    def fill(k):
+        out = []
+        for gr in grads:
+            v = torch.randn(gr.shape, generator=g).cuda() * (0.1 + k)
+            gr.copy_(v)
+            out.append(v)
+        return out
+    s = torch.cuda.Stream()
+    vals = fill(0)
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        oa.step()                                   # warm-up (allocates state), also step 1
+    torch.cuda.current_stream().wait_stream(s)
+    for p, v in zip(pb, vals):
+        p.grad = v.clone()
+    ob.step()
+    graph = torch.cuda.CUDAGraph()
+    vals = fill(1)
+    with torch.cuda.graph(graph, stream=s):
+        oa.step()                                   # captured (capture records, it does not execute) ...
+    graph.replay()                                  # ... step 2
+    for p, v in zip(pb, vals):
+        p.grad = v.clone()
+    ob.step()
+    for k in range(2, 5):                           # replays: steps 3..5, with a learning-rate schedule on group 0
+        lr = 8e-4 * (0.5 ** k)
+        lr_t.fill_(lr)
+        ob.param_groups[0]["lr"] = lr
+        vals = fill(k)
+        graph.replay()
+        for p, v in zip(pb, vals):
+            p.grad = v.clone()
+        ob.step()
+    torch.cuda.synchronize()
+    for a, b in zip(pa, pb):
+        torch.testing.assert_close(a.detach(), b.detach(), rtol=5e-6, atol=5e-7 * float(b.detach().abs().max()))
+        assert float(oa.state[a]["step"]) == 5.0 and oa.state[a]["step"].is_cuda
