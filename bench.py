@@ -50,6 +50,14 @@ def build_workload(rank: int, device: str):
     return sc, cam, gm, sw
 
 
+def _train_args():
+    """The reference's optimisation defaults (arguments/__init__.py OptimizationParams)."""
+    from types import SimpleNamespace
+    return SimpleNamespace(percent_dense=0.01, position_lr_init=0.00016, position_lr_final=0.0000016,
+                           position_lr_delay_mult=0.01, position_lr_max_steps=30000, feature_lr=0.0025,
+                           opacity_lr=0.05, scaling_lr=0.001, rotation_lr=0.001)
+
+
 def params_of(gm, sw):
     return gm.parameters() + [sw._node_radius] + list(sw.pose_net.parameters())
 
@@ -211,10 +219,7 @@ def main():
         lib.riggs_prof_enable(0xFFFFFFFF)
         # (the Gaussian optimizer step of SURVEY.md §8-f rank 1 is timed here as well — it is NOT part of the headline
         # metric, whose definition is deform + raster forward + backward)
-        from types import SimpleNamespace
-        gm.training_setup(SimpleNamespace(percent_dense=0.01, position_lr_init=0.00016, position_lr_final=0.0000016,
-                                          position_lr_delay_mult=0.01, position_lr_max_steps=30000, feature_lr=0.0025,
-                                          opacity_lr=0.05, scaling_lr=0.001, rotation_lr=0.001))
+        gm.training_setup(_train_args())
         for _ in range(min(args.steps, 20)):
             eager_step()
             if all(p.grad is not None for p in gm.parameters()):
@@ -286,6 +291,33 @@ def main():
                          "pixel_gaussian_pairs_per_s": round(256.0 * R / (dom_ms * 1e-3), 1) if dom.startswith("render") else None},
             "kernels": per_kernel, "kernels_ms": table,
         }
+        if world == 1 and not args.no_graph:
+            # Secondary number (NOT the metric): one WHOLE training iteration as a hipGraph — the metric's path plus the
+            # fused image loss, its backward, and the capturable FusedAdam steps of the Gaussians and the skeleton
+            # (SURVEY.md §8-f ranks 1-2 composed with the hot path; train_rig.py:535-554 minus logging / densification)
+            from riggs_amd.graph import GraphedTrainStep
+            from riggs_amd.optim import FusedAdam
+            for p in params_of(gm, sw):
+                p.grad = None
+            bucket.unregister()
+            gm.training_setup(_train_args(), capturable=True)
+            sk_opt = FusedAdam([{"params": g_["params"], "lr": 5e-4, "name": g_["name"]} for g_ in sw.trainable_parameters()],
+                               lr=0.0, eps=1e-15, capturable=True)
+            gts = GraphedTrainStep(gm, sw, cam, torch.zeros(3, device=dev), target, [gm.optimizer, sk_opt], lambda_dssim=0.2)
+            gts.capture()
+            for _ in range(5):
+                gts.run()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n_ts = max(10, min(args.steps, 100))
+            for _ in range(n_ts):
+                gts.run()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / n_ts
+            out["train_step"] = {"value": round(1.0 / dt, 2), "unit": "iters/s", "ms_per_step": round(dt * 1e3, 4),
+                                 "includes": "deform + raster fwd/bwd + fused L1/SSIM loss fwd/bwd + FusedAdam (Gaussians, "
+                                             "skeleton), one hipGraph; not the headline metric",
+                                 "final_loss": round(float(gts.out["loss"]), 6)}
         if not args.no_cpu_baseline:
             cam_cpu = cam.to("cpu")
             out["cpu_baseline"] = cpu_baseline(sc, cam_cpu, gimg.cpu())

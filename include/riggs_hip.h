@@ -246,15 +246,17 @@ int riggs_densify_stats(int32_t num_points, const float* viewspace_grad, const u
 /* =====================================================================
  * Image loss: utils/loss_utils.py:17-18 (l1_loss), :33-77 (ssim, 11x11 Gaussian window,
  * sigma 1.5, zero padding, C1 = 0.01^2, C2 = 0.03^2, mean over all elements), used at train_rig.py:508-509.
- * image / gt are (C, H, W) float32.  forward writes out2 = {mean |image - gt|, mean ssim_map} (device) and keeps
- * three derivative maps + per-workgroup partial sums in `state` (riggs_l1_ssim_state_floats floats); backward
- * takes the upstream gradients of the two scalars as DEVICE scalars (NULL = 0) and writes dL/dimage (C, H, W).
+ * image / gt are (C, H, W) float32.  forward writes out3 = {l1 = mean |image - gt|, ssim = mean ssim_map,
+ * (1 - lambda_dssim) l1 + lambda_dssim (1 - ssim)} (device; the third is the trainer's loss_img, train_rig.py:509) and
+ * keeps three derivative maps + per-workgroup partial sums in `state` (riggs_l1_ssim_state_floats floats); backward
+ * takes the upstream gradients of the three scalars as DEVICE scalars (NULL = 0) and writes dL/dimage (C, H, W).
  * ===================================================================== */
 size_t riggs_l1_ssim_state_floats(int32_t C, int32_t H, int32_t W);
-int riggs_l1_ssim_forward(int32_t C, int32_t H, int32_t W, const float* image, const float* gt, float* state, float* out2,
-                          riggs_stream stream);
+int riggs_l1_ssim_forward(int32_t C, int32_t H, int32_t W, const float* image, const float* gt, float lambda_dssim,
+                          float* state, float* out3, riggs_stream stream);
 int riggs_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float* image, const float* gt, const float* state,
-                           const float* g_l1, const float* g_ssim, float* dL_dimage, riggs_stream stream);
+                           float lambda_dssim, const float* g_l1, const float* g_ssim, const float* g_loss,
+                           float* dL_dimage, riggs_stream stream);
 
 /* =====================================================================
  * simple_knn._C.distCUDA2 (scene/gaussian_model.py:20,170): mean squared distance to the 3

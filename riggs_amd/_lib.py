@@ -60,8 +60,8 @@ _SIGS = {
     "riggs_adam_step_capturable": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, _P]),
     "riggs_densify_stats": (C.c_int, [C.c_int32] + [_P] * 7),
     "riggs_l1_ssim_state_floats": (C.c_size_t, [C.c_int32] * 3),
-    "riggs_l1_ssim_forward": (C.c_int, [C.c_int32] * 3 + [_P] * 5),
-    "riggs_l1_ssim_backward": (C.c_int, [C.c_int32] * 3 + [_P] * 7),
+    "riggs_l1_ssim_forward": (C.c_int, [C.c_int32] * 3 + [_P, _P, C.c_float, _P, _P, _P]),
+    "riggs_l1_ssim_backward": (C.c_int, [C.c_int32] * 3 + [_P, _P, _P, C.c_float, _P, _P, _P, _P, _P]),
     "riggs_prof_count": (C.c_int, []),
     "riggs_prof_name": (C.c_char_p, [C.c_int32]),
     "riggs_prof_enable": (C.c_int, [C.c_uint32]),

@@ -23,6 +23,8 @@ struct LossArgs {
   float* partial;          // [blocks][2]: sum |x - y|, sum ssim_map
   float* out2;             // [l1 mean, ssim mean]
   const float *g_l1, *g_ssim;  // backward: upstream gradients of the two scalars (device scalars)
+  const float* g_loss;         // ... and of the combined loss (1 - lambda) l1 + lambda (1 - ssim)
+  float lambda_dssim;
   float* dx;               // (C, H, W)
   float win[2 * LS_R + 1];
 };
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(256) void l1_ssim_forward_kernel(LossArgs a) {
 
 // fixed-order sum of the per-workgroup partials (deterministic), / n
 __global__ __launch_bounds__(1024) void l1_ssim_finish_kernel(int n_blocks, const float* __restrict__ partial, double inv_n,
-                                                              float* __restrict__ out2) {
+                                                              float lambda_dssim, float* __restrict__ out2) {
   __shared__ double s_w[2][16];
   double s0 = 0.0, s1 = 0.0;
   for (int i = threadIdx.x; i < n_blocks; i += 1024) { s0 += (double)partial[2 * i]; s1 += (double)partial[2 * i + 1]; }
@@ -129,7 +131,9 @@ __global__ __launch_bounds__(1024) void l1_ssim_finish_kernel(int n_blocks, cons
   if (threadIdx.x == 0) {
     double t0 = 0.0, t1 = 0.0;
     for (int w = 0; w < 16; w++) { t0 += s_w[0][w]; t1 += s_w[1][w]; }
-    out2[0] = (float)(t0 * inv_n); out2[1] = (float)(t1 * inv_n);
+    const float l1 = (float)(t0 * inv_n), ss = (float)(t1 * inv_n);
+    out2[0] = l1; out2[1] = ss;
+    out2[2] = (1.0f - lambda_dssim) * l1 + lambda_dssim * (1.0f - ss);  // train_rig.py:509
   }
 }
 
@@ -182,7 +186,9 @@ __global__ __launch_bounds__(256) void l1_ssim_backward_kernel(LossArgs a) {
   }
   const int px = tx0 + lx;
   const float inv_n = 1.0f / (float)plane;
-  const float gl = a.g_l1 ? a.g_l1[0] : 0.f, gs = a.g_ssim ? a.g_ssim[0] : 0.f;
+  const float gt_ = a.g_loss ? a.g_loss[0] : 0.f;
+  const float gl = (a.g_l1 ? a.g_l1[0] : 0.f) + (1.0f - a.lambda_dssim) * gt_;
+  const float gs = (a.g_ssim ? a.g_ssim[0] : 0.f) - a.lambda_dssim * gt_;
 #pragma unroll
   for (int o = 0; o < 4; o++) {
     const int py = ty0 + ly0 + o;
@@ -215,8 +221,8 @@ size_t riggs_l1_ssim_state_floats(int32_t C, int32_t H, int32_t W) {
   return 3 * (size_t)C * H * W + 2 * ls_blocks(C, H, W);
 }
 
-int riggs_l1_ssim_forward(int32_t C, int32_t H, int32_t W, const float* image, const float* gt, float* state, float* out2,
-                          riggs_stream stream) {
+int riggs_l1_ssim_forward(int32_t C, int32_t H, int32_t W, const float* image, const float* gt, float lambda_dssim,
+                          float* state, float* out2, riggs_stream stream) {
   RIGGS_REQUIRE(C >= 1 && H >= 1 && W >= 1 && C <= 65535, "bad image shape");
   RIGGS_REQUIRE(image && gt && state && out2, "NULL buffer");
   LossArgs a;
@@ -230,20 +236,22 @@ int riggs_l1_ssim_forward(int32_t C, int32_t H, int32_t W, const float* image, c
     ProfScope ps(PROF_LOSS_FWD, s);
     hipLaunchKernelGGL(l1_ssim_forward_kernel, grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL(l1_ssim_finish_kernel, dim3(1), dim3(1024), 0, s, (int)ls_blocks(C, H, W), a.partial,
-                       1.0 / ((double)C * H * W), out2);
+                       1.0 / ((double)C * H * W), lambda_dssim, out2);
   }
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
 int riggs_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float* image, const float* gt, const float* state,
-                           const float* g_l1, const float* g_ssim, float* dL_dimage, riggs_stream stream) {
+                           float lambda_dssim, const float* g_l1, const float* g_ssim, const float* g_loss,
+                           float* dL_dimage, riggs_stream stream) {
   RIGGS_REQUIRE(C >= 1 && H >= 1 && W >= 1 && C <= 65535, "bad image shape");
   RIGGS_REQUIRE(image && gt && state && dL_dimage, "NULL buffer");
   LossArgs a;
   memset(&a, 0, sizeof(a));
   a.C = C; a.H = H; a.W = W; a.x = image; a.y = gt;
-  a.maps = const_cast<float*>(state); a.g_l1 = g_l1; a.g_ssim = g_ssim; a.dx = dL_dimage;
+  a.maps = const_cast<float*>(state); a.g_l1 = g_l1; a.g_ssim = g_ssim; a.g_loss = g_loss; a.lambda_dssim = lambda_dssim;
+  a.dx = dL_dimage;
   fill_window(a);
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((W + LS_T - 1) / LS_T, (H + LS_T - 1) / LS_T, C);

@@ -78,7 +78,7 @@ class GaussianModel:
             self.active_sh_degree += 1
 
     # ---- optimizer (scene/gaussian_model.py:197-231, :516-518) --------------------------------------------------
-    def training_setup(self, training_args):
+    def training_setup(self, training_args, capturable=False):
         """Same groups, names and learning rates as the reference; the optimizer is ``riggs_amd.optim.FusedAdam``
         (a torch.optim.Adam whose step is one HIP launch)."""
         from .optim import FusedAdam
@@ -97,7 +97,9 @@ class GaussianModel:
         ]
         if self.fea_dim > 0:
             groups.append({"params": [self.feature], "lr": training_args.feature_lr, "name": "feature"})
-        self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)
+        if capturable:  # scheduled learning rate as a device scalar (see FusedAdam): update_learning_rate fills it
+            groups[0]["lr"] = torch.tensor(float(groups[0]["lr"]), dtype=torch.float32, device=dev)
+        self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15, capturable=capturable)
         lr0 = training_args.position_lr_init * self.spatial_lr_scale
         lr1 = training_args.position_lr_final * self.spatial_lr_scale
         steps = training_args.position_lr_max_steps  # (position_lr_delay_mult is inert: lr_delay_steps stays 0)
@@ -113,7 +115,11 @@ class GaussianModel:
     def update_learning_rate(self, iteration):  # :222-228
         for group in self.optimizer.param_groups:
             if group["name"] == "xyz":
-                group["lr"] = self.xyz_scheduler_args(iteration)
+                lr = self.xyz_scheduler_args(iteration)
+                if isinstance(group["lr"], torch.Tensor):
+                    group["lr"].fill_(lr)
+                else:
+                    group["lr"] = lr
 
     def add_densification_stats(self, viewspace_point_tensor, update_filter, radii=None):  # :516-518 (+ train_rig.py:333-335)
         from .optim import densify_stats

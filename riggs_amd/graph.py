@@ -103,3 +103,44 @@ class GraphedFrame:
             raise L.RiggsHipError("instance arena overflowed inside the captured graph (R=%d > capacity=%d): "
                                   "re-capture with more headroom" % (R, self.arena.capacity))
         return R
+
+
+class GraphedTrainStep(GraphedFrame):
+    """One WHOLE training iteration as a hipGraph (train_rig.py:535-554 minus logging / densification): deform -> render ->
+    image loss (fused L1 + SSIM, riggs_amd.loss) -> backward -> optimizer steps (riggs_amd.optim.FusedAdam with
+    ``capturable=True``: step counts and scheduled learning rates live on the device).  The ground-truth image, the camera
+    and the time are static device buffers refreshed by ``run()``; ``out["loss"]`` / ``out["l1"]`` are device scalars."""
+
+    def __init__(self, gm, sw, cam: Camera, bg: torch.Tensor, gt_image: torch.Tensor, optimizers, lambda_dssim: float = 0.2,
+                 headroom: float = 1.5):
+        params = gm.parameters() + [p for g in sw.trainable_parameters() for p in g["params"]]
+        super().__init__(gm, sw, cam, bg, params, headroom=headroom, fused=True)
+        for o in optimizers:
+            if not getattr(o, "hip_capturable", False):
+                raise ValueError("GraphedTrainStep needs FusedAdam(capturable=True) optimizers")
+        self.optimizers = list(optimizers)
+        self.gt = gt_image.clone()
+        self.lam = float(lambda_dssim)
+
+    def _frame(self):
+        from .loss import image_loss
+        for p in self.params:
+            p.grad = None
+        t_in = self.sw.expand_time(self.cam.fid)
+        dv = self.sw(self.gm.get_xyz.detach(), t_in, motion_mask=self.gm.motion_mask)
+        pkg = render(self.cam, self.gm, _Pipe, self.bg, dv["d_xyz"], dv["d_rotation"], dv["d_scaling"],
+                     fused=self.fused, arena=self.arena)
+        loss, l1 = image_loss(pkg["render"], self.gt, self.lam)
+        loss.backward()
+        for o in self.optimizers:
+            o.step()
+        out = {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in dict.items(pkg)
+               if k not in ("viewspace_points", "visibility_filter")}
+        out["viewspace_points_grad"] = pkg["viewspace_points"].grad
+        out["loss"], out["l1"] = loss.detach(), l1.detach()
+        return RenderPkg(out, cache=False)
+
+    def run(self, cam: Camera = None, gt_image: torch.Tensor = None):
+        if gt_image is not None:
+            self.gt.copy_(gt_image, non_blocking=True)
+        return super().run(cam, None)

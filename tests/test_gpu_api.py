@@ -144,10 +144,73 @@ def test_flat_gradient_bucket_receives_gradients_in_place():
         assert all(lo <= p.grad.data_ptr() < hi and p.grad.data_ptr() == v.data_ptr() for p, v in zip(params, bucket.views))
         assert all(v.data_ptr() % 16 == 0 for v in bucket.views)
         for a, b in zip(got, ref):
-            torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-7 * float(b.abs().max()) + 1e-12)
+            torch.testing.assert_close(a, b, rtol=1e-4, atol=2e-6 * float(b.abs().max()) + 1e-12)  # float atomics: order varies
         bucket()  # world 1: no collective, gradients stay in place
         assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(params, bucket.views))
         bucket.unregister()
+    finally:
+        bench.WORKLOAD.clear()
+        bench.WORKLOAD.update(old)
+
+
+def test_graphed_train_step_matches_eager_iterations():
+    """A whole training iteration (deform, render, fused loss, backward, capturable FusedAdam on Gaussians AND skeleton)
+    captured once and replayed, against the same iterations issued eagerly with torch.optim.Adam and the torch-op loss glue."""
+    import copy
+    from types import SimpleNamespace
+
+    import bench
+    from riggs_amd.graph import GraphedTrainStep
+    from riggs_amd.loss import l1_loss, ssim
+    from riggs_amd.optim import FusedAdam
+    from riggs_amd.rasterizer import RasterArena
+    from riggs_amd.render import render
+    old = dict(bench.WORKLOAD)
+    bench.WORKLOAD.update(N=5000, J=8, H=80, W=96)
+    args = SimpleNamespace(percent_dense=0.01, position_lr_init=0.00016, position_lr_final=0.0000016, position_lr_delay_mult=0.01,
+                           position_lr_max_steps=30000, feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.001, rotation_lr=0.001)
+    try:
+        sc, cam, gm, sw = bench.build_workload(0, "cuda:0")
+        gm2, sw2 = copy.deepcopy(gm), copy.deepcopy(sw)
+        gt = torch.rand(3, 80, 96, generator=torch.Generator().manual_seed(2)).cuda()
+        bg = torch.zeros(3, device="cuda")
+        # --- graph side
+        gm.training_setup(args, capturable=True)
+        sk_opt = FusedAdam([{"params": g["params"], "lr": 5e-4, "name": g["name"]} for g in sw.trainable_parameters()],
+                           lr=0.0, eps=1e-15, capturable=True)
+        gts = GraphedTrainStep(gm, sw, cam, bg, gt, [gm.optimizer, sk_opt], lambda_dssim=0.2)
+        gts.capture(warmup=1)          # one eager warm-up iteration (iteration 1)
+        losses = []
+        for it in range(2, 5):         # iterations 2..4 are replays; xyz learning rate rescheduled in between
+            gm.update_learning_rate(1000 * it)
+            out = gts.run()
+            losses.append(out["loss"].item())
+        gts.check()
+        # --- eager reference side: torch.optim.Adam, loss glue in torch ops
+        gm2.training_setup(args)
+        opt_g = torch.optim.Adam([{"params": g["params"], "lr": float(g["lr"]), "name": g["name"]} for g in gm2.optimizer.param_groups],
+                                 lr=0.0, eps=1e-15)
+        opt_s = torch.optim.Adam([{"params": g["params"], "lr": 5e-4} for g in sw2.trainable_parameters()], lr=0.0, eps=1e-15)
+        ref_losses = []
+        for it in range(1, 5):
+            if it >= 2:
+                for grp in opt_g.param_groups:
+                    if grp["name"] == "xyz":
+                        grp["lr"] = gm2.xyz_scheduler_args(1000 * it)
+            opt_g.zero_grad(set_to_none=True), opt_s.zero_grad(set_to_none=True)
+            dv = sw2(gm2.get_xyz.detach(), sw2.expand_time(cam.fid), motion_mask=gm2.motion_mask)
+            pkg = render(cam, gm2, bench.Pipe, bg, dv["d_xyz"], dv["d_rotation"], dv["d_scaling"], arena=RasterArena())
+            loss = 0.8 * l1_loss(pkg["render"], gt) + 0.2 * (1.0 - ssim(pkg["render"], gt))
+            loss.backward()
+            opt_g.step(), opt_s.step()
+            if it >= 2:
+                ref_losses.append(loss.item())
+        np.testing.assert_allclose(losses, ref_losses, rtol=2e-4)
+        assert losses[-1] < losses[0]  # it trains
+        for a, b in zip(gm.parameters(), gm2.parameters()):
+            torch.testing.assert_close(a.detach(), b.detach(), rtol=2e-3, atol=2e-4 * float(b.detach().abs().max()))
+        for a, b in zip(sw.pose_net.parameters(), sw2.pose_net.parameters()):
+            torch.testing.assert_close(a.detach(), b.detach(), rtol=2e-3, atol=2e-4 * float(b.detach().abs().max()) + 1e-7)
     finally:
         bench.WORKLOAD.clear()
         bench.WORKLOAD.update(old)
