@@ -219,7 +219,7 @@ int riggs_pose_mlp_backward(int32_t depth, int32_t width, int32_t multires, int3
  *   GaussianModel.training_setup  scene/gaussian_model.py:197-221 builds torch.optim.Adam(l, lr=0.0, eps=1e-15)
  *   with ONE parameter tensor per group and per-group learning rates; train_rig.py:527 steps it.
  * riggs_adam_step applies that update (plain Adam: no weight decay, no amsgrad; torch's single-tensor
- * operation order) to up to 8 parameter tensors in ONE launch.  All pointer arrays are HOST arrays of
+ * operation order) to up to 32 parameter tensors in ONE launch.  All pointer arrays are HOST arrays of
  * DEVICE pointers (16-byte aligned tensors of numel[k] floats); lr[k] is the group's current learning
  * rate, step[k] the step count AFTER this update (>= 1); exp_avg / exp_avg_sq are updated in place.
  *   add_densification_stats       scene/gaussian_model.py:516-518

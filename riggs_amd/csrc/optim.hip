@@ -11,7 +11,7 @@
 
 namespace riggs {
 
-#define ADAM_MAX_GROUPS 8
+#define ADAM_MAX_GROUPS 32  // 32 x 80 B of kernel arguments (the 35 tensors of the skeleton optimizer: two launches)
 
 struct AdamArgs {
   int n_groups;
@@ -112,7 +112,7 @@ static int adam_launch(int32_t n_groups, float* const* params, const float* cons
                        float* const* exp_avg_sq, const int64_t* numel, const double* lr, const int64_t* step,
                        const float* const* step_dev, const float* const* lr_dev, double beta1, double beta2, double eps,
                        riggs_stream stream) {
-  RIGGS_REQUIRE(n_groups >= 0 && n_groups <= ADAM_MAX_GROUPS, "at most 8 parameter tensors per launch");
+  RIGGS_REQUIRE(n_groups >= 0 && n_groups <= ADAM_MAX_GROUPS, "at most 32 parameter tensors per launch");
   AdamArgs a;
   memset(&a, 0, sizeof(a));
   a.n_groups = n_groups;

@@ -16,7 +16,7 @@ import torch
 
 from . import _lib as L
 
-_MAX = 8  # tensors per launch (ADAM_MAX_GROUPS in csrc/optim.hip)
+_MAX = 32  # tensors per launch (ADAM_MAX_GROUPS in csrc/optim.hip)
 
 
 class FusedAdam(torch.optim.Adam):

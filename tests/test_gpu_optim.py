@@ -50,8 +50,9 @@ def test_training_setup_step_and_schedule_match_reference_golden():
 def test_matches_torch_adam_ragged_sizes_many_groups_and_surgery():
     from riggs_amd.optim import FusedAdam
     g = torch.Generator().manual_seed(5)
-    shapes = [(1001, 3), (1001, 1, 3), (1001, 15, 3), (1001, 1), (1001, 3), (1001, 4), (7,), (1, 1), (513, 5), (2, 3)]  # 10 > 8
-    lrs = [8e-4, 2.5e-3, 1.25e-4, 5e-2, 5e-3, 1e-3, 1e-2, 1e-1, 3e-3, 1e-3]
+    shapes = [(1001, 3), (1001, 1, 3), (1001, 15, 3), (1001, 1), (1001, 3), (1001, 4), (7,), (1, 1), (513, 5), (2, 3)]
+    shapes += [(k + 3, 2) for k in range(27)]  # 37 tensors > 32 per launch: two launches
+    lrs = [8e-4, 2.5e-3, 1.25e-4, 5e-2, 5e-3, 1e-3, 1e-2, 1e-1, 3e-3, 1e-3] + [1e-3 * (1 + k % 5) for k in range(27)]
     mk = lambda: [torch.nn.Parameter(torch.randn(s, generator=torch.Generator().manual_seed(i)).cuda()) for i, s in enumerate(shapes)]  # noqa: E731
     pa, pb = mk(), mk()
     oa = FusedAdam([{"params": [p], "lr": lr, "name": str(i)} for i, (p, lr) in enumerate(zip(pa, lrs))], lr=0.0, eps=1e-15)
