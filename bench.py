@@ -23,6 +23,9 @@ sys.path.insert(0, ROOT)
 
 WORKLOAD = dict(N=300_000, J=24, H=800, W=800, seed=1237)  # BASELINE.json metric: 300k Gaussians @800x800, 24 joints
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+if os.environ.get("RIGGS_BENCH_TEST_WORKLOAD"):  # tests only (tests/test_gpu_api.py): a tiny scene, "N,J,H,W"
+    _n, _j, _h, _w = (int(v) for v in os.environ["RIGGS_BENCH_TEST_WORKLOAD"].split(","))
+    WORKLOAD.update(N=_n, J=_j, H=_h, W=_w)
 
 
 class Pipe:
@@ -138,12 +141,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = "cuda:%d" % local_rank
+    ndev = max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_rank % ndev)  # (% ndev: lets a 1-GPU box exercise the multi-rank control flow over gloo)
+    dev = "cuda:%d" % (local_rank % ndev)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        backend = os.environ.get("RIGGS_BENCH_BACKEND", "nccl")  # nccl = RCCL over xGMI; gloo only for control-flow tests
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from riggs_amd import _lib as L
     from riggs_amd.rasterizer import RasterArena
@@ -186,7 +194,7 @@ def main():
         assert gf.check() == R, "graphed frame disagrees with the eager frame on the instance count"
 
     names = [lib.riggs_prof_name(i).decode() for i in range(lib.riggs_prof_count())]
-    eager_step = make_step(cam, gm, sw, gimg, arena, world, bucket)
+    eager_step = make_step(cam, gm, sw, gimg, arena, 1, bucket)  # profiling leg: rank 0 alone, so NO collective inside
 
     def barrier():
         if world > 1:
@@ -318,7 +326,7 @@ def main():
                                  "includes": "deform + raster fwd/bwd + fused L1/SSIM loss fwd/bwd + FusedAdam (Gaussians, "
                                              "skeleton), one hipGraph; not the headline metric",
                                  "final_loss": round(float(gts.out["loss"]), 6)}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # (the CPU baseline is an N = 1 measurement)
             cam_cpu = cam.to("cpu")
             out["cpu_baseline"] = cpu_baseline(sc, cam_cpu, gimg.cpu())
         print(json.dumps(out), flush=True)

@@ -109,7 +109,7 @@ class FlatGradAllReduce:
             # a static list of gradient tensors (a captured hipGraph's) that already ARE the slices: skip this loop next time
             self._in_place = sources if (in_place and sources is not None) else None
         if world > 1:
-            if self.average and self.flat.is_cuda:
+            if self.average and self.flat.is_cuda and dist.get_backend() == "nccl":
                 dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)  # RCCL averages in the collective: no divide pass
             else:
                 dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)

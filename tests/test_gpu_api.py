@@ -214,3 +214,34 @@ def test_graphed_train_step_matches_eager_iterations():
     finally:
         bench.WORKLOAD.clear()
         bench.WORKLOAD.update(old)
+
+
+def test_bench_contract_single_and_two_ranks():
+    """bench.py end to end on a tiny scene: the N = 1 JSON line carries every field of the contract (roofline, cpu_baseline,
+    train_step), and the 2-rank launch (the driver's torch.distributed.run command line; gloo stands in for RCCL on a
+    1-GPU box) completes — no collective is ever issued by a subset of the ranks — and reports the whole-job aggregate."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RIGGS_BENCH_TEST_WORKLOAD="4000,8,96,112", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "5", "--warmup", "2"], cwd=root, env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["scaling"] == "weak" and d["dtype"] == "f32" and d["value"] > 0
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and d["roofline"]["peak"] == 8000.0
+    assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
+    assert d["train_step"]["value"] > 0
+    env["RIGGS_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d2 = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert d2["n_gpus"] == 2 and d2["config"]["parallelism"] == "frames x2" and "cpu_baseline" not in d2
+    assert abs(d2["value"] - 2 * 4 / (d2["ms_per_step"] * 4 / 1e3)) < 1e-3 * d2["value"]  # aggregate over both ranks
