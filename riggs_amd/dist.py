@@ -82,6 +82,12 @@ class FlatGradAllReduce:
             _SLICES[p.data_ptr()] = (self.flat, o, tuple(p.shape))
         self.registered = True
 
+    def __del__(self):
+        try:
+            self.unregister()
+        except Exception:
+            pass
+
     def unregister(self):
         for p in self.params:
             ent = _SLICES.get(p.data_ptr())
