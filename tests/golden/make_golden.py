@@ -307,6 +307,19 @@ def fixture_deform_heads(name, seed, J, N):
     print("wrote", name)
 
 
+def fixture_state_dict_layout():
+    """§8-f rank 4a: names and shapes of the reference SkeletonWarp's state dict (what skeleton.pth holds), J = 6,
+    hyper_dim = 8, with its static and its non-static base network."""
+    import json
+    joints, parents = torch.rand(6, 3), torch.tensor([-1, 0, 1, 1, 3, 0])
+    out = {}
+    for static in (True, False):
+        with S.quiet():
+            sw = SkeletonWarp(is_blender=True, joints=joints, parent_indices=parents, K=-1, is_scene_static=static, hyper_dim=8)
+        out["static" if static else "dynamic"] = {k: list(v.shape) for k, v in sw.state_dict().items()}
+    json.dump(out, open(os.path.join(HERE, "skeleton_state_dict_layout.json"), "w"), indent=0)
+
+
 if __name__ == "__main__":
     fixture_deform("deform_chain8_n257", 11, 8, 257, -1, chain=True)
     fixture_deform("deform_tree24_n1024", 12, 24, 1024, -1, mask_random=True)
@@ -319,16 +332,4 @@ if __name__ == "__main__":
     fixture_optim("optim_adam_n67", 41, 67)
     fixture_loss("loss_l1_ssim", 51, 3, 37, 45)
     fixture_deform_heads("heads_tree12_n200", 61, 12, 200)
-
-
-def fixture_state_dict_layout():
-    """§8-f rank 4a: names and shapes of the reference SkeletonWarp's state dict (what skeleton.pth holds), J = 6,
-    hyper_dim = 8, with its static and its non-static base network."""
-    import json
-    joints, parents = torch.rand(6, 3), torch.tensor([-1, 0, 1, 1, 3, 0])
-    out = {}
-    for static in (True, False):
-        with S.quiet():
-            sw = SkeletonWarp(is_blender=True, joints=joints, parent_indices=parents, K=-1, is_scene_static=static, hyper_dim=8)
-        out["static" if static else "dynamic"] = {k: list(v.shape) for k, v in sw.state_dict().items()}
-    json.dump(out, open(os.path.join(HERE, "skeleton_state_dict_layout.json"), "w"), indent=0)
+    fixture_state_dict_layout()
