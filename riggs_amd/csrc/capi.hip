@@ -206,6 +206,10 @@ static int fill_pre_args(PreArgs& a, const riggs_raster_cfg* c, const float* mea
   return 0;
 }
 
+static unsigned long long* g_raster_trace = nullptr;
+// debugging aid: device buffer of 6 u64 per forward WAVE (4 * tiles * 4 waves), see render_fwd_quad_kernel; NULL disables
+int riggs_raster_set_trace(void* dev_u64) { g_raster_trace = (unsigned long long*)dev_u64; return 0; }
+
 static bool render_cull() {
   static const bool v = getenv("RIGGS_RENDER_NOCULL") == nullptr;  // A/B switch
   return v;
@@ -314,6 +318,7 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
   RenderArgs r;
   r.W = W; r.H = H;
   r.cull = render_cull() ? 1 : 0;
+  r.trace = g_raster_trace;
   { static const bool x = getenv("RIGGS_NO_XCD_MAP") == nullptr; r.xcd_map = x ? 1 : 0; }
   r.ranges = (const uint2*)(img + I.ranges);
   r.point_list = point_list;

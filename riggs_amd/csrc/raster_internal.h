@@ -33,6 +33,7 @@ int launch_preprocess_bwd(const PreBwdArgs& b, hipStream_t s);
 
 struct RenderArgs {
   int W, H;
+  unsigned long long* trace;  // optional per-workgroup statistics of render_fwd (riggs_raster_set_trace), else NULL
   int xcd_map;  // workgroups of a tile on one XCD (RIGGS_NO_XCD_MAP=1 turns it off)
   int cull;  // instance culling against pixel blocks (RIGGS_RENDER_NOCULL=1 turns it off)
   const uint2* ranges;

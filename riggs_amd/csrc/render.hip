@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void render_fwd_sgpr_kernel(RenderArgs a) {
 int launch_render_fwd(const RenderArgs& a, hipStream_t s) {
   const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE, gy = (a.H + RIGGS_TILE - 1) / RIGGS_TILE;
   if (gx * gy == 0) return 0;
-  // A/B switch: 0 = quad-lane kernel (default), 1 = SGPR-stream variant, 2 = pixel-per-lane ILP kernel
+  // A/B switch: 0 = quad-lane kernel (default), 1 = SGPR-stream variant, 2 = pixel-per-lane ILP kernel (no cull)
   static const int variant = getenv("RIGGS_RENDER_FWD") ? atoi(getenv("RIGGS_RENDER_FWD")) : 0;
   if (variant == 1) hipLaunchKernelGGL(render_fwd_sgpr_kernel, dim3(gx * gy), dim3(256), 0, s, a);
   else if (variant == 2) hipLaunchKernelGGL(render_fwd_kernel, dim3(gx * gy), dim3(256), 0, s, a);
