@@ -275,6 +275,8 @@ __global__ __launch_bounds__(256) void render_fwd_quad_kernel(RenderArgs a) {
   bool done = !inside;
   float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f, Tstop = -1.0f;
   uint32_t last = 0;
+  const unsigned long long t_begin = a.trace ? wall_clock64() : 0ull;  // optional statistics (riggs_raster_set_trace)
+  uint32_t st_rounds = 0, st_surv = 0, st_iters = 0, st_full = 0;
   // prefetch registers for the next round (FQ_BATCH / 256 instances per thread)
   float4 n_xy[FQ_BATCH / 256], n_co[FQ_BATCH / 256], n_cc[FQ_BATCH / 256];
 #pragma unroll
@@ -302,7 +304,9 @@ __global__ __launch_bounds__(256) void render_fwd_quad_kernel(RenderArgs a) {
         s_xyd[chunk * 64 + lane] = z; s_con[chunk * 64 + lane] = z; s_rgb[chunk * 64 + lane] = z; s_pos[chunk * 64 + lane] = 0;
       }
       if (lane == 0) s_cnt[chunk] = cnt;
+      st_surv += (uint32_t)cnt;
     }
+    st_rounds++;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < FQ_BATCH / 256; k++) {
@@ -365,12 +369,18 @@ __global__ __launch_bounds__(256) void render_fwd_quad_kernel(RenderArgs a) {
       const float alB = fminf(ALPHA_MAX, coB.w * fast_exp(pwB));
       const bool vA = (pwA <= 0.0f) && (alA >= ALPHA_MIN);
       const bool vB = (pwB <= 0.0f) && (alB >= ALPHA_MIN);
+      st_iters++;
       if (__builtin_amdgcn_ballot_w64((vA || vB) && !done) == 0) continue;
+      st_full++;
       const float4 cA = s_rgb[g + j], cB = s_rgb[g + 4 + j];
       quad_step(alA, vA, xyA.z, cA, base + (int)s_pos[g + j] + 1);
       quad_step(alB, vB, xyB.z, cB, base + (int)s_pos[g + 4 + j] + 1);
     }
     }
+  }
+  if (a.trace && lane == 0) {  // per wave: {100 MHz ticks, rounds, survivors of this wave's chunk, iterations, iterations with a contribution, list length}
+    unsigned long long* tr = a.trace + ((size_t)blockIdx.x * 4 + wave) * 6;
+    tr[0] = wall_clock64() - t_begin; tr[1] = st_rounds; tr[2] = st_surv; tr[3] = st_iters; tr[4] = st_full; tr[5] = (unsigned long long)total;
   }
   // fold the quad
   const float k0 = quad_sum(C0), k1 = quad_sum(C1), k2 = quad_sum(C2), kd = quad_sum(D), ka = quad_sum(A);
