@@ -99,11 +99,16 @@ __global__ __launch_bounds__(1024) void bin_offsets_kernel(int T, int64_t cap, c
                                                            uint32_t* __restrict__ tile_start, uint2* __restrict__ ranges,
                                                            uint32_t* __restrict__ slot_base,
                                                            uint32_t* __restrict__ tile_max,
-                                                           uint32_t* __restrict__ counters) {
+                                                           uint32_t* __restrict__ counters,
+                                                           uint32_t* __restrict__ fwd_items,
+                                                           uint32_t* __restrict__ fwd_empty,
+                                                           uint32_t* __restrict__ fwd_ctr) {
   __shared__ uint32_t s_wave[16];
   __shared__ uint32_t s_carry;
+  __shared__ uint32_t s_hist[32], s_cur[32], s_nempty;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) s_carry = 0u;
+  if (tid == 0) { s_carry = 0u; s_nempty = 0u; }
+  if (tid < 32) s_hist[tid] = 0u;
   __syncthreads();
   for (int base = 0; base < T; base += 1024) {
     const int t = base + tid;
@@ -128,6 +133,9 @@ __global__ __launch_bounds__(1024) void bin_offsets_kernel(int T, int64_t cap, c
       ranges[t] = (hi > lo) ? make_uint2(lo, hi) : make_uint2(0u, 0u);
       tile_max[t] = 0u;  // atomicMax target of the forward
       slot_base[t] = (lo >> 6) + (uint32_t)t;
+      // forward work queue, step 1: histogram of floor(log2(list length)); the empty tiles go to their own list
+      if (hi > lo) atomicAdd(&s_hist[31 - __builtin_clz(hi - lo)], 1u);
+      else fwd_empty[atomicAdd(&s_nempty, 1u)] = (uint32_t)t;
     }
     __syncthreads();
     if (tid == 1023) s_carry = carry + wave_off + v;
@@ -141,6 +149,19 @@ __global__ __launch_bounds__(1024) void bin_offsets_kernel(int T, int64_t cap, c
     slot_base[T] = ((uint32_t)min((int64_t)R, cap) >> 6) + (uint32_t)T;
     counters[0] = R;
     counters[1] = ((int64_t)R > cap) ? 1u : 0u;
+    // step 2: the longest lists first (the forward deals the tiles to its workgroups in this order, so the long
+    // chains start at once and the short ones fill in around them)
+    uint32_t off = 0;
+    for (int b = 31; b >= 0; b--) { s_cur[b] = off; off += s_hist[b]; }
+    fwd_ctr[0] = off; fwd_ctr[1] = 0u; fwd_ctr[2] = s_nempty;
+  }
+  __syncthreads();
+  for (int t = tid; t < T; t += 1024) {  // (same thread that wrote ranges[t] above)
+    const uint2 r = ranges[t];
+    if (r.y > r.x) {
+      const uint32_t p = atomicAdd(&s_cur[31 - __builtin_clz(r.y - r.x)], 1u);
+      fwd_items[p] = (uint32_t)t;
+    }
   }
 }
 
@@ -251,7 +272,8 @@ size_t bin_table_bytes(int N, int T) {
 
 int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order, const uint32_t* tiles,
                    const ushort4* rect, void* table_mem, uint32_t* point_list, uint32_t* tile_keys, uint2* ranges,
-                   uint32_t* slot_base, uint32_t* tile_max, uint32_t* counters, hipStream_t s) {
+                   uint32_t* slot_base, uint32_t* tile_max, uint32_t* counters, uint32_t* fwd_items,
+                   uint32_t* fwd_empty, uint32_t* fwd_ctr, hipStream_t s) {
   BinPlan p = bin_plan(N, T);
   char* mem = (char*)table_mem;
   uint32_t* table = (uint32_t*)mem;
@@ -268,7 +290,7 @@ int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order,
                      order, tiles, rect, table);
   hipLaunchKernelGGL(bin_scan_kernel, dim3((T + 63) / 64), dim3(1024), 0, s, T, p.n_chunks, table, tile_count);
   hipLaunchKernelGGL(bin_offsets_kernel, dim3(1), dim3(1024), 0, s, T, cap, tile_count, tile_start, ranges, slot_base,
-                     tile_max, counters);
+                     tile_max, counters, fwd_items, fwd_empty, fwd_ctr);
   hipLaunchKernelGGL(bin_scatter_kernel, dim3(p.n_chunks), dim3(p.threads), p.lds_scatter, s, N, T, grid_x, cap,
                      p.g_per_block, order, tiles, rect, table, tile_start, point_list, tile_keys);
   return 0;

@@ -99,6 +99,11 @@ ImageLayout image_layout(int H, int W) {
   L.tile_max = o; o = align_up(o + (T + 1) * 4);
   L.slot_base = o; o = align_up(o + (T + 2) * 4);
   L.work_ctr = o; o = align_up(o + 16);  // backward work queue: {n_items, next}
+  // forward work list (written by bin_offsets_kernel): the non-empty tiles, longest lists first; the empty tiles;
+  // {n_nonempty, -, n_empty}
+  L.fwd_items = o; o = align_up(o + (T + 1) * 4);
+  L.fwd_empty = o; o = align_up(o + (T + 1) * 4);
+  L.fwd_ctr = o; o = align_up(o + 16);
   L.total = o;
   return L;
 }
@@ -288,7 +293,8 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
                              // the per-instance tile id is only a debugging aid here (2M scattered 4-byte stores):
                              // it is implied by `ranges`, so it is written with cfg.debug only
                              cfg->debug ? (uint32_t*)(bin + B.keys_b) : nullptr, (uint2*)(img + I.ranges), (uint32_t*)(img + I.slot_base),
-                             (uint32_t*)(img + I.tile_max), counters, s);
+                             (uint32_t*)(img + I.tile_max), counters, (uint32_t*)(img + I.fwd_items),
+                             (uint32_t*)(img + I.fwd_empty), (uint32_t*)(img + I.fwd_ctr), s);
     if (rcb) return rcb;
     if (debug_sync(cfg->debug, s, "binning (counting sort)")) return 1;
   } else if (N > 0 && cap > 0) {
@@ -319,7 +325,7 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
   r.W = W; r.H = H;
   r.cull = render_cull() ? 1 : 0;
   r.trace = g_raster_trace;
-  { static const bool x = getenv("RIGGS_NO_XCD_MAP") == nullptr; r.xcd_map = x ? 1 : 0; }
+  { static const bool x = getenv("RIGGS_NO_XCD_MAP") == nullptr; r.xcd_map = x ? 1 : 0; if (getenv("RIGGS_FWD_TOP")) r.xcd_map = atoi(getenv("RIGGS_FWD_TOP")); }
   r.ranges = (const uint2*)(img + I.ranges);
   r.point_list = point_list;
   r.xyd = (const float4*)(geom + G.xyd); r.conic_o = (const float4*)(geom + G.conic_o); r.rgb = (const float4*)(geom + G.rgb);
@@ -328,6 +334,9 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
   r.out_color = out_color; r.out_depth = out_depth; r.out_alpha = out_alpha;
   r.final_acc = (float4*)(img + I.final_acc); r.tile_max = (uint32_t*)(img + I.tile_max);
   r.slot_base = (const uint32_t*)(img + I.slot_base); r.ckpt = (float*)(bin + B.ckpt);
+  // longest-list-first work list of the forward (only the counting sort's bin_offsets_kernel builds it)
+  { static const bool q = getenv("RIGGS_FWD_STATIC") == nullptr; r.items = nullptr;
+    if (counting && q) { r.items = (const uint32_t*)(img + I.fwd_items); r.empties = (const uint32_t*)(img + I.fwd_empty); r.item_ctr = (uint32_t*)(img + I.fwd_ctr); } }
   if (!(N > 0 && cap > 0)) RIGGS_HIP_CHECK(hipMemsetAsync(img + I.slot_base, 0, (size_t)(T + 2) * 4, s));
   { ProfScope ps(PROF_RENDER_FWD, s); launch_render_fwd(r, s); }
   if (debug_sync(cfg->debug, s, "render_fwd")) return 1;

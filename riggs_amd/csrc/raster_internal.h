@@ -48,6 +48,11 @@ struct RenderArgs {
   uint32_t* tile_max;         // per tile: max n_contrib
   const uint32_t* slot_base;  // per tile: first checkpoint slot ((range.x >> 6) + tile)
   float* ckpt;                // [slot][5][256]: (T, C0, C1, C2, D) per pixel at every 64th instance
+  // work list (NULL: static blockIdx -> (tile, block) mapping): items = the non-empty tiles, longest lists
+  // first; empties = the tiles without instances; item_ctr = {n_nonempty, -, n_empty}
+  const uint32_t* items;
+  const uint32_t* empties;
+  uint32_t* item_ctr;
 };
 int launch_render_fwd(const RenderArgs& a, hipStream_t s);
 int launch_slot_base(int64_t n, int n_tiles, const uint32_t* keys_sorted, const uint32_t* counters,
@@ -83,7 +88,8 @@ int launch_depth_sort(int N, uint32_t* keys_in, uint32_t* vals_in, uint32_t* key
 size_t bin_table_bytes(int N, int T);
 int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order, const uint32_t* tiles,
                    const ushort4* rect, void* table_mem, uint32_t* point_list, uint32_t* tile_keys, uint2* ranges,
-                   uint32_t* slot_base, uint32_t* tile_max, uint32_t* counters, hipStream_t s);
+                   uint32_t* slot_base, uint32_t* tile_max, uint32_t* counters, uint32_t* fwd_items,
+                   uint32_t* fwd_empty, uint32_t* fwd_ctr, hipStream_t s);
 int launch_gather_tiles(int N, const uint32_t* order, const uint32_t* tiles, uint32_t* tt_sorted, hipStream_t s);
 int launch_emit(int N, int grid_x, int n_tiles, int64_t cap, const uint32_t* order, const uint32_t* offsets,
                 const uint32_t* tiles, const ushort4* rect, uint32_t* keys, uint32_t* vals, uint32_t* counters,

@@ -250,17 +250,47 @@ __global__ __launch_bounds__(256) void render_fwd_quad_kernel(RenderArgs a) {
   __shared__ unsigned short s_pos[FQ_BATCH];  // position of the survivor inside its batch
   __shared__ int s_cnt[FQ_BATCH / 64];        // survivors per chunk
   const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE;
-  // XCD-aware mapping: workgroup b runs on XCD b % 8, so the four workgroups of a tile (which read the same
-  // list and the same records) are given ids 8 apart — same L2 — instead of four neighbouring ids
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qx = lane >> 2, j = lane & 3;
+  if (a.items) {
+    // tiles without instances: background only, one pixel per thread
+    const int n_empty = (int)a.item_ctr[2];
+    for (int e = blockIdx.x; e < n_empty; e += gridDim.x) {
+      const int t = (int)a.empties[e];
+      const int px = (t % gx) * RIGGS_TILE + (tid & 15), py = (t / gx) * RIGGS_TILE + (tid >> 4);
+      if (px < a.W && py < a.H) {
+        const size_t pid = (size_t)py * a.W + px, HW = (size_t)a.H * a.W;
+        a.final_T[pid] = 1.0f; a.n_contrib[pid] = 0u; a.final_acc[pid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        a.out_color[pid] = a.bg[0]; a.out_color[HW + pid] = a.bg[1]; a.out_color[2 * HW + pid] = a.bg[2];
+        a.out_depth[pid] = 0.f; a.out_alpha[pid] = 0.f;
+      }
+    }
+  }
+  int n_items = a.items ? (int)a.item_ctr[0] * 4 : 0;  // four 16x4 pixel blocks per non-empty tile
+  const int dbg_tile = (a.xcd_map > 1) ? (a.xcd_map >> 4) : -1; const int dbg_flags = (a.xcd_map > 1) ? (a.xcd_map & 15) : 0;
+  for (int turn = 0;; turn++) {
   int tile, sub;
-  {
+  if (a.items) {
+    // work list: the non-empty tiles in the order bin_offsets_kernel wrote them (longest lists first), dealt
+    // round-robin to the resident workgroups (a shared dequeue word costs more than it balances: same-address
+    // atomics from 8 XCDs serialise at ~10-60 ns each).  The four blocks of a tile get workgroup ids 8 apart =
+    // the same XCD / L2.
+    const int i = (int)blockIdx.x + turn * (int)gridDim.x, full = (n_items >> 5) << 5;
+    if (i >= n_items) break;
+    int p;
+    if (i < full) { p = ((i >> 5) << 3) + (i & 7); sub = (i >> 3) & 3; }
+    else { p = (full >> 2) + ((i - full) >> 2); sub = (i - full) & 3; }
+    tile = (int)a.items[p];
+    if (dbg_tile >= 0 && tile != dbg_tile) continue;
+  } else {
+    if (turn > 0) break;
+    // XCD-aware mapping: workgroup b runs on XCD b % 8, so the four workgroups of a tile (which read the same
+    // list and the same records) are given ids 8 apart — same L2 — instead of four neighbouring ids
     const int b = blockIdx.x, full = (int)(gridDim.x >> 5) << 5;
     if (!a.xcd_map) { tile = b >> 2; sub = b & 3; }
     else if (b < full) { tile = ((b >> 5) << 3) + (b & 7); sub = (b >> 3) & 3; }
     else { tile = (full >> 2) + ((b - full) >> 2); sub = (b - full) & 3; }
   }
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int qx = lane >> 2, j = lane & 3;
   const int prow = sub * 4 + wave;                       // pixel row inside the tile
   const int pxi = (tile % gx) * RIGGS_TILE + qx;
   const int pyi = (tile / gx) * RIGGS_TILE + prow;
@@ -277,16 +307,35 @@ __global__ __launch_bounds__(256) void render_fwd_quad_kernel(RenderArgs a) {
   uint32_t last = 0;
   const unsigned long long t_begin = a.trace ? wall_clock64() : 0ull;  // optional statistics (riggs_raster_set_trace)
   uint32_t st_rounds = 0, st_surv = 0, st_iters = 0, st_full = 0;
-  // prefetch registers for the next round (FQ_BATCH / 256 instances per thread)
+  // prefetch registers for the next round (FQ_BATCH / 256 instances per thread), and the list entries of the round
+  // after it, so that the gathers of a round never wait for their own addresses: a tile whose pixels never saturate
+  // is a chain of rounds, and every global latency on that chain is kernel time (tools/fwd_placement.py)
   float4 n_xy[FQ_BATCH / 256], n_co[FQ_BATCH / 256], n_cc[FQ_BATCH / 256];
+  uint32_t n_id[FQ_BATCH / 256];
 #pragma unroll
   for (int k = 0; k < FQ_BATCH / 256; k++) {
     n_xy[k] = make_float4(0.f, 0.f, 0.f, 0.f); n_co[k] = n_xy[k]; n_cc[k] = n_xy[k];
+    n_id[k] = 0u;
+    if (FQ_BATCH + k * 256 + tid < total) n_id[k] = a.point_list[range.x + FQ_BATCH + k * 256 + tid];
     if (k * 256 + tid < total) {
       const uint32_t id = a.point_list[range.x + k * 256 + tid];
       n_xy[k] = a.xyd[id]; n_co[k] = a.conic_o[id]; n_cc[k] = a.rgb[id];
     }
   }
+  // checkpoints of a round are held in registers (lane j of a pixel's quad keeps the one of chunk j) and stored at
+  // the start of the NEXT round, ahead of that round's prefetch loads: vmcnt retires in order, so stores issued
+  // after the loads would make the wait for the loads also wait for the stores' acknowledgements
+  static_assert(FQ_BATCH == 256, "one held checkpoint per quad lane");
+  float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;
+  bool hv = false;
+  int hbase = 0;
+  auto flush_ckpt = [&]() {
+    if (hv) {
+      float* ck = a.ckpt + ((size_t)(slot0 + (hbase >> 6) + j) * 5) * 256 + pix;
+      ck[0] = h0; ck[256] = h1; ck[512] = h2; ck[768] = h3; ck[1024] = h4;
+    }
+    hv = false;
+  };
   for (int base = 0; base < total; base += FQ_BATCH) {
     if (__syncthreads_count(done) == 256) break;
 #pragma unroll
@@ -307,14 +356,17 @@ __global__ __launch_bounds__(256) void render_fwd_quad_kernel(RenderArgs a) {
       st_surv += (uint32_t)cnt;
     }
     st_rounds++;
+    flush_ckpt();
+    hbase = base;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < FQ_BATCH / 256; k++) {
       n_xy[k] = make_float4(0.f, 0.f, 0.f, 0.f); n_co[k] = n_xy[k]; n_cc[k] = n_xy[k];
       if (base + FQ_BATCH + k * 256 + tid < total) {
-        const uint32_t id = a.point_list[range.x + base + FQ_BATCH + k * 256 + tid];
+        const uint32_t id = n_id[k];
         n_xy[k] = a.xyd[id]; n_co[k] = a.conic_o[id]; n_cc[k] = a.rgb[id];
       }
+      if (base + 2 * FQ_BATCH + k * 256 + tid < total) n_id[k] = a.point_list[range.x + base + 2 * FQ_BATCH + k * 256 + tid];
     }
     // one quad step: four consecutive instances (one per lane of the quad) of this lane's pixel
     auto quad_step = [&](float alpha, bool valid_in, float depth, const float4 c, int pos1) {
@@ -351,10 +403,7 @@ __global__ __launch_bounds__(256) void render_fwd_quad_kernel(RenderArgs a) {
       {
         // checkpoint of the state BEFORE instance cbase: fold the quad's partial sums
         const float k0 = quad_sum(C0), k1 = quad_sum(C1), k2 = quad_sum(C2), kd = quad_sum(D);
-        if (!done && j == 0) {
-          float* ck = a.ckpt + ((size_t)(slot0 + (cbase >> 6)) * 5) * 256 + pix;
-          ck[0] = T; ck[256] = k0; ck[512] = k1; ck[768] = k2; ck[1024] = kd;
-        }
+        if (j == k) { h0 = T; h1 = k0; h2 = k1; h3 = k2; h4 = kd; hv = !done && !(dbg_flags & 2); }
       }
       const int nk = s_cnt[k];
     for (int g = 64 * k; g < 64 * k + nk; g += 8) {
@@ -379,9 +428,10 @@ __global__ __launch_bounds__(256) void render_fwd_quad_kernel(RenderArgs a) {
     }
   }
   if (a.trace && lane == 0) {  // per wave: {100 MHz ticks, rounds, survivors of this wave's chunk, iterations, iterations with a contribution, list length}
-    unsigned long long* tr = a.trace + ((size_t)blockIdx.x * 4 + wave) * 6;
-    tr[0] = wall_clock64() - t_begin; tr[1] = st_rounds; tr[2] = st_surv; tr[3] = st_iters; tr[4] = st_full; tr[5] = (unsigned long long)total;
+    unsigned long long* tr = a.trace + ((size_t)(tile * 4 + sub) * 4 + wave) * 6;
+    tr[0] = wall_clock64() - t_begin; tr[1] = st_rounds; tr[2] = (unsigned long long)st_surv | ((unsigned long long)(__builtin_amdgcn_s_getreg(63492) & 0xFFFFu) << 32) | ((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 0xFu) << 48) | ((unsigned long long)(t_begin & 0xFFFull) << 52); tr[3] = st_iters; tr[4] = st_full; tr[5] = (unsigned long long)total;
   }
+  flush_ckpt();
   // fold the quad
   const float k0 = quad_sum(C0), k1 = quad_sum(C1), k2 = quad_sum(C2), kd = quad_sum(D), ka = quad_sum(A);
   float ts = Tstop;
@@ -404,6 +454,8 @@ __global__ __launch_bounds__(256) void render_fwd_quad_kernel(RenderArgs a) {
     a.out_color[2 * HW + pid] = k2 + Tfin * a.bg[2];
     a.out_depth[pid] = kd;
     a.out_alpha[pid] = ka;
+  }
+  __syncthreads();  // the staging buffers are reused by the next item
   }
 }
 
@@ -502,10 +554,9 @@ int launch_render_fwd(const RenderArgs& a, hipStream_t s) {
   else if (variant == 2) hipLaunchKernelGGL(render_fwd_kernel, dim3(gx * gy), dim3(256), 0, s, a);
   else {
     // tile_max was cleared together with ranges by riggs_raster_render
-    static const int fq = getenv("RIGGS_FQ_BATCH") ? atoi(getenv("RIGGS_FQ_BATCH")) : 256;  // A/B switch (larger rounds lose)
-    if (fq == 512) hipLaunchKernelGGL(render_fwd_quad_kernel<512>, dim3(gx * gy * 4), dim3(256), 0, s, a);
-    else if (fq == 1024) hipLaunchKernelGGL(render_fwd_quad_kernel<1024>, dim3(gx * gy * 4), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(render_fwd_quad_kernel<256>, dim3(gx * gy * 4), dim3(256), 0, s, a);
+    static const int per_cu = getenv("RIGGS_FWD_WG_PER_CU") ? atoi(getenv("RIGGS_FWD_WG_PER_CU")) : 8;
+    const int nb = (a.items && per_cu > 0) ? min(gx * gy * 4, 256 * per_cu) : gx * gy * 4;  // work list: resident workgroups only
+    hipLaunchKernelGGL(render_fwd_quad_kernel<256>, dim3(nb), dim3(256), 0, s, a);
   }
   return 0;
 }
