@@ -325,7 +325,8 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
   r.W = W; r.H = H;
   r.cull = render_cull() ? 1 : 0;
   r.trace = g_raster_trace;
-  { static const bool x = getenv("RIGGS_NO_XCD_MAP") == nullptr; r.xcd_map = x ? 1 : 0; if (getenv("RIGGS_FWD_TOP")) r.xcd_map = atoi(getenv("RIGGS_FWD_TOP")); }
+  { static const bool x = getenv("RIGGS_NO_XCD_MAP") == nullptr; r.xcd_map = x ? 1 : 0; }
+  { static const int t = getenv("RIGGS_FWD_ONLY_TILE") ? atoi(getenv("RIGGS_FWD_ONLY_TILE")) : -1; r.only_tile = t; }
   r.ranges = (const uint2*)(img + I.ranges);
   r.point_list = point_list;
   r.xyd = (const float4*)(geom + G.xyd); r.conic_o = (const float4*)(geom + G.conic_o); r.rgb = (const float4*)(geom + G.rgb);

@@ -36,6 +36,7 @@ struct RenderArgs {
   unsigned long long* trace;  // optional per-workgroup statistics of render_fwd (riggs_raster_set_trace), else NULL
   int xcd_map;  // workgroups of a tile on one XCD (RIGGS_NO_XCD_MAP=1 turns it off)
   int cull;  // instance culling against pixel blocks (RIGGS_RENDER_NOCULL=1 turns it off)
+  int only_tile;  // diagnostics: composite this tile only (RIGGS_FWD_ONLY_TILE, tools/fwd_placement.py); -1 = all
   const uint2* ranges;
   const uint32_t* point_list;
   const float4 *xyd, *conic_o, *rgb;

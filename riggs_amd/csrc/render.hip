@@ -266,8 +266,7 @@ __global__ __launch_bounds__(256) void render_fwd_quad_kernel(RenderArgs a) {
       }
     }
   }
-  int n_items = a.items ? (int)a.item_ctr[0] * 4 : 0;  // four 16x4 pixel blocks per non-empty tile
-  const int dbg_tile = (a.xcd_map > 1) ? (a.xcd_map >> 4) : -1; const int dbg_flags = (a.xcd_map > 1) ? (a.xcd_map & 15) : 0;
+  const int n_items = a.items ? (int)a.item_ctr[0] * 4 : 0;  // four 16x4 pixel blocks per non-empty tile
   for (int turn = 0;; turn++) {
   int tile, sub;
   if (a.items) {
@@ -281,7 +280,7 @@ __global__ __launch_bounds__(256) void render_fwd_quad_kernel(RenderArgs a) {
     if (i < full) { p = ((i >> 5) << 3) + (i & 7); sub = (i >> 3) & 3; }
     else { p = (full >> 2) + ((i - full) >> 2); sub = (i - full) & 3; }
     tile = (int)a.items[p];
-    if (dbg_tile >= 0 && tile != dbg_tile) continue;
+    if (a.only_tile >= 0 && tile != a.only_tile) continue;  // diagnostics (tools/fwd_placement.py)
   } else {
     if (turn > 0) break;
     // XCD-aware mapping: workgroup b runs on XCD b % 8, so the four workgroups of a tile (which read the same
@@ -403,7 +402,7 @@ __global__ __launch_bounds__(256) void render_fwd_quad_kernel(RenderArgs a) {
       {
         // checkpoint of the state BEFORE instance cbase: fold the quad's partial sums
         const float k0 = quad_sum(C0), k1 = quad_sum(C1), k2 = quad_sum(C2), kd = quad_sum(D);
-        if (j == k) { h0 = T; h1 = k0; h2 = k1; h3 = k2; h4 = kd; hv = !done && !(dbg_flags & 2); }
+        if (j == k) { h0 = T; h1 = k0; h2 = k1; h3 = k2; h4 = kd; hv = !done; }
       }
       const int nk = s_cnt[k];
     for (int g = 64 * k; g < 64 * k + nk; g += 8) {
@@ -445,6 +444,234 @@ __global__ __launch_bounds__(256) void render_fwd_quad_kernel(RenderArgs a) {
   for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
   if (lane == 0 && m > 0) atomicMax(&a.tile_max[tile], m);  // tile_max is zeroed before the launch
   if (inside && j == 0) {
+    const size_t pid = (size_t)pyi * a.W + pxi, HW = (size_t)a.H * a.W;
+    a.final_T[pid] = Tfin;
+    a.n_contrib[pid] = lm;
+    a.final_acc[pid] = make_float4(k0, k1, k2, kd);
+    a.out_color[pid] = k0 + Tfin * a.bg[0];
+    a.out_color[HW + pid] = k1 + Tfin * a.bg[1];
+    a.out_color[2 * HW + pid] = k2 + Tfin * a.bg[2];
+    a.out_depth[pid] = kd;
+    a.out_alpha[pid] = ka;
+  }
+  __syncthreads();  // the staging buffers are reused by the next item
+  }
+}
+
+// ---- eight instance-lanes per pixel -------------------------------------------------------------------------------------
+// Same algorithm as the quad-lane kernel with the wave turned the other way: 8 pixels x 8 instance lanes, workgroup =
+// 4 waves = an 8 x 4 pixel block (eight per tile).  A wave needs ONE scan step per 8 instances instead of two quad steps
+// over 16 pixels: about the same number of wave instructions in total, spread over twice the waves.  That matters
+// because a wave alone on its SIMD is already issue-bound (one VALU instruction per 4 cycles), and the slowest 16 x 4
+// block of the quad-lane kernel (a tile whose pixels never saturate walks its whole list: 12 rounds, ~130 steps) takes
+// as long ALONE on the chip as the whole launch (tools/fwd_placement.py).  Halving the pixels per workgroup halves that
+// chain, and the smaller block culls more of the list.  A round stages 256 instances (4 chunks, one per wave); lane i < 4
+// of a pixel's eight holds the checkpoint of chunk i of the round.
+#define ODPP_F(old, v, ctrl, bank) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(old)), __builtin_bit_cast(int, (float)(v)), ctrl, 0xf, bank, false))
+#define ODPP_U(old, v, ctrl, bank) ((uint32_t)__builtin_amdgcn_update_dpp((int)(old), (int)(v), ctrl, 0xf, bank, false))
+#define DPP_ROW_SHL4 0x104
+#define DPP_ROW_SHR4 0x114
+#define DPP_HALF_MIRROR 0x141
+__device__ __forceinline__ float oct_sum(float v) {
+  v += QUAD_F(v, QP(1, 0, 3, 2));
+  v += QUAD_F(v, QP(2, 3, 0, 1));
+  v += ODPP_F(0.f, v, DPP_HALF_MIRROR, 0xf);
+  return v;
+}
+template <int B>
+__global__ __launch_bounds__(256) void render_fwd_oct_kernel(RenderArgs a) {
+  static_assert(B == 256 || B == 512, "one held checkpoint per lane of a pixel's eight");
+  constexpr int K = B / 256;  // instances per thread and round
+  __shared__ float4 s_xyd[B];
+  __shared__ float4 s_con[B];
+  __shared__ float4 s_rgb[B];
+  __shared__ unsigned short s_pos[B];  // position of the survivor inside its batch
+  __shared__ int s_cnt[B / 64];        // survivors per chunk
+  const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pl = lane >> 3, i = lane & 7;
+  if (a.items) {
+    // tiles without instances: background only, one pixel per thread
+    const int n_empty = (int)a.item_ctr[2];
+    for (int e = blockIdx.x; e < n_empty; e += gridDim.x) {
+      const int t = (int)a.empties[e];
+      const int px = (t % gx) * RIGGS_TILE + (tid & 15), py = (t / gx) * RIGGS_TILE + (tid >> 4);
+      if (px < a.W && py < a.H) {
+        const size_t pid = (size_t)py * a.W + px, HW = (size_t)a.H * a.W;
+        a.final_T[pid] = 1.0f; a.n_contrib[pid] = 0u; a.final_acc[pid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        a.out_color[pid] = a.bg[0]; a.out_color[HW + pid] = a.bg[1]; a.out_color[2 * HW + pid] = a.bg[2];
+        a.out_depth[pid] = 0.f; a.out_alpha[pid] = 0.f;
+      }
+    }
+  }
+  const int n_items = a.items ? (int)a.item_ctr[0] * 8 : 0;  // eight 8x4 pixel blocks per non-empty tile
+  for (int turn = 0;; turn++) {
+  int tile, sub;
+  if (a.items) {
+    // the eight blocks of a tile get workgroup ids 8 apart = the same XCD / L2
+    const int it = (int)blockIdx.x + turn * (int)gridDim.x, full = (n_items >> 6) << 6;
+    if (it >= n_items) break;
+    int p;
+    if (it < full) { p = ((it >> 6) << 3) + (it & 7); sub = (it >> 3) & 7; }
+    else { p = (full >> 3) + ((it - full) >> 3); sub = (it - full) & 7; }
+    tile = (int)a.items[p];
+    if (a.only_tile >= 0 && tile != a.only_tile) continue;  // diagnostics (tools/fwd_placement.py)
+  } else {
+    if (turn > 0) break;
+    const int b = blockIdx.x, full = (int)(gridDim.x >> 6) << 6;
+    if (!a.xcd_map) { tile = b >> 3; sub = b & 7; }
+    else if (b < full) { tile = ((b >> 6) << 3) + (b & 7); sub = (b >> 3) & 7; }
+    else { tile = (full >> 3) + ((b - full) >> 3); sub = (b - full) & 7; }
+  }
+  const int prow = (sub >> 1) * 4 + wave;                 // pixel row inside the tile
+  const int pcol = (sub & 1) * 8 + pl;                    // pixel column inside the tile
+  const int pxi = (tile % gx) * RIGGS_TILE + pcol;
+  const int pyi = (tile / gx) * RIGGS_TILE + prow;
+  const bool inside = pxi < a.W && pyi < a.H;
+  const float pfx = (float)pxi, pfy = (float)pyi;
+  const uint2 range = a.ranges[tile];
+  const int total = (int)(range.y - range.x);
+  const uint32_t slot0 = a.slot_base[tile];
+  const int pix = prow * 16 + pcol;                       // pixel index inside the tile (checkpoint layout)
+  const float bx0 = (float)((tile % gx) * RIGGS_TILE + (sub & 1) * 8), bx1 = bx0 + 7.0f;
+  const float by0 = (float)((tile / gx) * RIGGS_TILE + (sub >> 1) * 4), by1 = by0 + 3.0f;
+  bool done = !inside;
+  float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f, Tstop = -1.0f;
+  uint32_t last = 0;
+  const unsigned long long t_begin = a.trace ? wall_clock64() : 0ull;
+  uint32_t st_rounds = 0, st_surv = 0, st_iters = 0, st_full = 0;
+  // prefetch registers for the next round (one instance per thread) and the list entry of the round after it
+  float4 n_xy[K], n_co[K], n_cc[K];
+  uint32_t n_id[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    n_xy[k] = make_float4(0.f, 0.f, 0.f, 0.f); n_co[k] = n_xy[k]; n_cc[k] = n_xy[k];
+    n_id[k] = 0u;
+    if (B + k * 256 + tid < total) n_id[k] = a.point_list[range.x + B + k * 256 + tid];
+    if (k * 256 + tid < total) {
+      const uint32_t id = a.point_list[range.x + k * 256 + tid];
+      n_xy[k] = a.xyd[id]; n_co[k] = a.conic_o[id]; n_cc[k] = a.rgb[id];
+    }
+  }
+  // checkpoints are held one round (lane i keeps chunk i's) and stored ahead of the next round's loads
+  float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;
+  bool hv = false;
+  int hbase = 0;
+  auto flush_ckpt = [&]() {
+    if (hv) {
+      float* ck = a.ckpt + ((size_t)(slot0 + (hbase >> 6) + i) * 5) * 256 + pix;
+      ck[0] = h0; ck[256] = h1; ck[512] = h2; ck[768] = h3; ck[1024] = h4;
+    }
+    hv = false;
+  };
+  for (int base = 0; base < total; base += B) {
+    if (__syncthreads_count(done) == 256) break;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const int chunk = k * 4 + wave, inb = k * 256 + tid;  // this wave's 64 lanes = one chunk of the batch
+      const bool keep = (base + inb < total) &&
+                        (!a.cull || ((n_xy[k].x + n_xy[k].w >= bx0) && (n_xy[k].x - n_xy[k].w <= bx1) &&
+                                     (n_xy[k].y + n_cc[k].w >= by0) && (n_xy[k].y - n_cc[k].w <= by1)));
+      const uint64_t mask = __builtin_amdgcn_ballot_w64(keep);
+      const int cnt = __builtin_popcountll(mask);
+      const int slot = chunk * 64 + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+      if (keep) { s_xyd[slot] = n_xy[k]; s_con[slot] = n_co[k]; s_rgb[slot] = n_cc[k]; s_pos[slot] = (unsigned short)inb; }
+      if (lane >= cnt && lane < ((cnt + 7) & ~7)) {  // null records up to the next multiple of 8
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_xyd[chunk * 64 + lane] = z; s_con[chunk * 64 + lane] = z; s_rgb[chunk * 64 + lane] = z; s_pos[chunk * 64 + lane] = 0;
+      }
+      if (lane == 0) s_cnt[chunk] = cnt;
+      st_surv += (uint32_t)cnt;
+    }
+    st_rounds++;
+    flush_ckpt();
+    hbase = base;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      n_xy[k] = make_float4(0.f, 0.f, 0.f, 0.f); n_co[k] = n_xy[k]; n_cc[k] = n_xy[k];
+      if (base + B + k * 256 + tid < total) {
+        const uint32_t id = n_id[k];
+        n_xy[k] = a.xyd[id]; n_co[k] = a.conic_o[id]; n_cc[k] = a.rgb[id];
+      }
+      if (base + 2 * B + k * 256 + tid < total) n_id[k] = a.point_list[range.x + base + 2 * B + k * 256 + tid];
+    }
+    for (int k = 0; k < B / 64; k++) {
+      const int cbase = base + 64 * k;
+      if (cbase >= total) break;
+      if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+      {
+        // checkpoint of the state BEFORE instance cbase: fold the eight lanes' partial sums
+        const float k0 = oct_sum(C0), k1 = oct_sum(C1), k2 = oct_sum(C2), kd = oct_sum(D);
+        if (i == k) { h0 = T; h1 = k0; h2 = k1; h3 = k2; h4 = kd; hv = !done; }
+      }
+      const int nk = s_cnt[k];
+      for (int g = 64 * k; g < 64 * k + nk; g += 8) {
+        if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+        const float4 xy = s_xyd[g + i];
+        const float dx = xy.x - pfx, dy = xy.y - pfy;
+        const float4 co = s_con[g + i];
+        const float pw = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+        const float alpha = fminf(ALPHA_MAX, co.w * fast_exp(pw));
+        const bool valid = (pw <= 0.0f) && (alpha >= ALPHA_MIN) && !done;
+        st_iters++;
+        if (__builtin_amdgcn_ballot_w64(valid) == 0) continue;
+        st_full++;
+        const float4 c = s_rgb[g + i];
+        const int pos1 = base + (int)s_pos[g + i] + 1;
+        // one step: eight consecutive instances (one per lane) of this lane's pixel
+        const float om = valid ? 1.0f - alpha : 1.0f;
+        // exclusive product scan over the eight lanes: inside each quad as in the quad-lane kernel ...
+        float b1 = QUAD_F(om, QP(0, 0, 1, 2)); b1 = ((i & 3) >= 1) ? b1 : 1.0f;     // [1, o0, o1, o2]
+        float s1 = QUAD_F(b1, QP(0, 0, 1, 2)); s1 = ((i & 3) >= 1) ? s1 : 1.0f;     // [1, 1, o0, o1]
+        float s2 = QUAD_F(b1, QP(0, 0, 0, 1)); s2 = ((i & 3) >= 2) ? s2 : 1.0f;     // [1, 1, 1, o0]
+        float E = b1 * s1 * s2;                                                     // [1, o0, o0 o1, o0 o1 o2] per quad
+        // ... then the upper quad takes the lower quad's total (row_shr:4 written to banks 1 and 3 only)
+        const float Pq = QUAD_F(E * om, QP(3, 3, 3, 3));                            // product of the own quad
+        E *= ODPP_F(1.0f, Pq, DPP_ROW_SHR4, 0xA);
+        const float Tj = T * E;
+        const float test_T = Tj * om;
+        const bool sc = valid && (test_T < T_EPS);
+        const uint64_t bits = __builtin_amdgcn_ballot_w64(sc);
+        const uint32_t ob = (uint32_t)(bits >> (lane & 56)) & 0xFFu;
+        const bool first_stop_before = (ob & ((1u << i) - 1u)) != 0u;
+        const bool use = valid && !sc && !first_stop_before;
+        const float w = use ? alpha * Tj : 0.f;
+        C0 += c.x * w; C1 += c.y * w; C2 += c.z * w;
+        D += xy.z * w; A += w;
+        last = use ? (uint32_t)pos1 : last;
+        if (sc && !first_stop_before) Tstop = Tj;  // transmittance in front of the instance that ends the pixel
+        // product of all eight: the upper quad's running total, handed down to the lower quad (row_shl:4, banks 0 and 2)
+        const float X3 = QUAD_F(E * om, QP(3, 3, 3, 3));
+        const float prod8 = ODPP_F(X3, X3, DPP_ROW_SHL4, 0x5);
+        const bool nostop = (ob == 0u);
+        T = (nostop && !done) ? T * prod8 : T;
+        done = done || !nostop;
+      }
+    }
+  }
+  if (a.trace && lane == 0) {
+    unsigned long long* tr = a.trace + ((size_t)(tile * 8 + sub) * 4 + wave) * 6;
+    tr[0] = wall_clock64() - t_begin; tr[1] = st_rounds;
+    tr[2] = (unsigned long long)st_surv | ((unsigned long long)(__builtin_amdgcn_s_getreg(63492) & 0xFFFFu) << 32) | ((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 0xFu) << 48);
+    tr[3] = st_iters; tr[4] = st_full; tr[5] = (unsigned long long)total;
+  }
+  flush_ckpt();
+  // fold the eight lanes
+  const float k0 = oct_sum(C0), k1 = oct_sum(C1), k2 = oct_sum(C2), kd = oct_sum(D), ka = oct_sum(A);
+  float ts = Tstop;
+  ts = fmaxf(ts, QUAD_F(ts, QP(1, 0, 3, 2)));
+  ts = fmaxf(ts, QUAD_F(ts, QP(2, 3, 0, 1)));
+  ts = fmaxf(ts, ODPP_F(-1.0f, ts, DPP_HALF_MIRROR, 0xf));
+  uint32_t lm = last;
+  lm = max(lm, QUAD_U(lm, QP(1, 0, 3, 2)));
+  lm = max(lm, QUAD_U(lm, QP(2, 3, 0, 1)));
+  lm = max(lm, ODPP_U(0u, lm, DPP_HALF_MIRROR, 0xf));
+  const float Tfin = (ts >= 0.f) ? ts : T;
+  uint32_t m = inside ? lm : 0u;
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+  if (lane == 0 && m > 0) atomicMax(&a.tile_max[tile], m);  // tile_max is zeroed before the launch
+  if (inside && i == 0) {
     const size_t pid = (size_t)pyi * a.W + pxi, HW = (size_t)a.H * a.W;
     a.final_T[pid] = Tfin;
     a.n_contrib[pid] = lm;
@@ -548,15 +775,19 @@ __global__ __launch_bounds__(256) void render_fwd_sgpr_kernel(RenderArgs a) {
 int launch_render_fwd(const RenderArgs& a, hipStream_t s) {
   const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE, gy = (a.H + RIGGS_TILE - 1) / RIGGS_TILE;
   if (gx * gy == 0) return 0;
-  // A/B switch: 0 = quad-lane kernel (default), 1 = SGPR-stream variant, 2 = pixel-per-lane ILP kernel (no cull)
+  // A/B switch: 0 = eight-lane kernel (default), 1 = SGPR-stream variant, 2 = pixel-per-lane ILP kernel (no cull),
+  // 4 = quad-lane kernel (16 x 4 pixel blocks)
   static const int variant = getenv("RIGGS_RENDER_FWD") ? atoi(getenv("RIGGS_RENDER_FWD")) : 0;
+  // (tile_max was cleared together with ranges by riggs_raster_render)
   if (variant == 1) hipLaunchKernelGGL(render_fwd_sgpr_kernel, dim3(gx * gy), dim3(256), 0, s, a);
   else if (variant == 2) hipLaunchKernelGGL(render_fwd_kernel, dim3(gx * gy), dim3(256), 0, s, a);
+  else if (variant == 4) hipLaunchKernelGGL(render_fwd_quad_kernel<256>, dim3(gx * gy * 4), dim3(256), 0, s, a);
   else {
-    // tile_max was cleared together with ranges by riggs_raster_render
-    static const int per_cu = getenv("RIGGS_FWD_WG_PER_CU") ? atoi(getenv("RIGGS_FWD_WG_PER_CU")) : 8;
-    const int nb = (a.items && per_cu > 0) ? min(gx * gy * 4, 256 * per_cu) : gx * gy * 4;  // work list: resident workgroups only
-    hipLaunchKernelGGL(render_fwd_quad_kernel<256>, dim3(nb), dim3(256), 0, s, a);
+    // one workgroup per 8 x 4 block of every tile; with the work list the ones past the non-empty tiles only help
+    // with the background of the empty tiles and leave
+    static const int ob = getenv("RIGGS_FWD_OCT_BATCH") ? atoi(getenv("RIGGS_FWD_OCT_BATCH")) : 256;  // (512-instance rounds lose)
+    if (ob == 512) hipLaunchKernelGGL(render_fwd_oct_kernel<512>, dim3(gx * gy * 8), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(render_fwd_oct_kernel<256>, dim3(gx * gy * 8), dim3(256), 0, s, a);
   }
   return 0;
 }

@@ -17,7 +17,8 @@ def main():
     w = bench.WORKLOAD
     sc, cam, gm, sw = bench.build_workload(0, "cuda:0")
     T = ((w["W"] + 15) // 16) * ((w["H"] + 15) // 16)
-    trace = torch.zeros(T * 16 * 6, dtype=torch.int64, device="cuda")
+    BPT = 4 if os.environ.get("RIGGS_RENDER_FWD") == "4" else 8  # pixel blocks (workgroups) per tile; 4 waves each
+    trace = torch.zeros(T * BPT * 4 * 6, dtype=torch.int64, device="cuda")
     gimg = torch.rand(3, w["H"], w["W"], device="cuda") * 1e-6
     step = bench.make_step(cam, gm, sw, gimg, RasterArena(), 1, FlatGradAllReduce(bench.params_of(gm, sw), register=False))
     step()
@@ -32,12 +33,12 @@ def main():
     print("waves with work: %d; time us: max %.1f p99 %.1f p90 %.1f median %.1f" % (len(t), us.max(), *np.percentile(us, [99, 90, 50])))
     print("slowest waves: [us, rounds, survivors/4waves, iterations, full iterations, list length]")
     for i in order[:12]:
-        print("  %7.1f %5d %7d %6d %6d %7d" % (us[i], t[i, 1], t[i, 2], t[i, 3], t[i, 4], t[i, 5]))
+        print("  %7.1f %5d %7d %6d %6d %7d" % (us[i], t[i, 1], t[i, 2] & 0xFFFFFFFF, t[i, 3], t[i, 4], t[i, 5]))
     # simple linear model of a wave's time
     A = np.stack([np.ones(len(t)), t[:, 1], t[:, 3] - t[:, 4], t[:, 4]], 1).astype(np.float64)
     coef, *_ = np.linalg.lstsq(A, us, rcond=None)
     print("fit: us = %.2f + %.3f*rounds + %.3f*skipped_iterations + %.3f*full_iterations" % tuple(coef))
-    print("totals: rounds %d, iterations %d (full %d), survivors(sum over waves' own chunks) %d" % (t[:, 1].sum(), t[:, 3].sum(), t[:, 4].sum(), t[:, 2].sum()))
+    print("totals: rounds %d, iterations %d (full %d), survivors(sum over waves' own chunks) %d" % (t[:, 1].sum(), t[:, 3].sum(), t[:, 4].sum(), (t[:, 2] & 0xFFFFFFFF).sum()))
 
 
 if __name__ == "__main__":
