@@ -271,8 +271,10 @@ int riggs_dist2_knn3(int32_t num_points, const float* points, float* out, void* 
  * riggs_prof_read synchronises on the recorded events and returns the sum / count since the
  * last riggs_prof_reset.  Stage ids: riggs_prof_name(i) for i in [0, riggs_prof_count()).
  * ===================================================================== */
-/* debugging aid: per-wave statistics of the forward compositing kernel (6 u64 per wave, 16 waves per tile:
- * {100 MHz ticks, rounds, survivors, iterations, iterations with a contribution, list length}); NULL disables */
+/* debugging aid: per-wave statistics of the forward compositing kernel (6 u64 per wave, 8 pixel blocks x 4 waves
+ * per tile: {100 MHz ticks, rounds, survivors | hardware id << 32, steps, steps with a contribution, list length}),
+ * followed (at word n_tiles * 192) by 4 u64 per chunk of the compositing backward ({start, end, hardware id,
+ * workgroup << 32 | tile << 16 | chunk}); tools/fwd_trace.py, fwd_placement.py, bwd_trace.py.  NULL disables */
 int riggs_raster_set_trace(void* dev_u64);
 int riggs_prof_count(void);
 const char* riggs_prof_name(int32_t id);

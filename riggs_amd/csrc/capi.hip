@@ -121,7 +121,7 @@ BinLayout bin_layout(int64_t cap, int N, int H, int W) {
   L.n_slots = (n >> 6) + T + 1;  // tile t, chunk c -> slot (range.x(t) >> 6) + t + c
   L.ckpt = o; o += align_up(L.n_slots * RIGGS_CKPT_FLOATS * 4);
   L.table = o; o += align_up(bin_table_bytes(N, (int)T));
-  L.work = o; o += align_up(L.n_slots * 4);  // backward work list: (tile << 16 | chunk) per active chunk
+  L.work = o; o += align_up(L.n_slots * 16);  // backward work list: 16-byte entry per active chunk
   L.total = o;
   return L;
 }
@@ -375,6 +375,8 @@ int riggs_raster_backward(const riggs_raster_cfg* cfg, const float* means3D, con
   BinLayout B = bin_layout(cap, N, H, W);
   RenderBwdArgs r;
   r.n_points = N;
+  // (the backward's statistics follow the forward's: 8 blocks x 4 waves x 6 words per tile)
+  r.trace = g_raster_trace ? g_raster_trace + (size_t)(((W + RIGGS_TILE - 1) / RIGGS_TILE) * ((H + RIGGS_TILE - 1) / RIGGS_TILE)) * 8 * 4 * 6 : nullptr;
   r.cull = render_cull() ? 1 : 0;
   r.W = W; r.H = H;
   r.ranges = (const uint2*)(img + I.ranges);
@@ -388,7 +390,7 @@ int riggs_raster_backward(const riggs_raster_cfg* cfg, const float* means3D, con
   r.slot_base = (const uint32_t*)(img + I.slot_base); r.ckpt = (const float*)(bin + B.ckpt);
   r.n_tiles = ((W + RIGGS_TILE - 1) / RIGGS_TILE) * ((H + RIGGS_TILE - 1) / RIGGS_TILE);
   r.n_slots = (int64_t)B.n_slots;
-  r.work = (uint32_t*)(bin + B.work); r.work_ctr = (uint32_t*)(img + I.work_ctr);
+  r.work = (uint4*)(bin + B.work); r.work_ctr = (uint32_t*)(img + I.work_ctr);
   if (cap > 0) { ProfScope ps(PROF_RENDER_BWD, s); launch_render_bwd(r, s); }
   else RIGGS_HIP_CHECK(hipMemsetAsync(workspace, 0, (size_t)N * RIGGS_GACC * 4, s));
   if (debug_sync(cfg->debug, s, "render_bwd")) return 1;

@@ -60,6 +60,7 @@ int launch_slot_base(int64_t n, int n_tiles, const uint32_t* keys_sorted, const 
                      uint32_t* slot_base, hipStream_t s);
 
 struct RenderBwdArgs {
+  unsigned long long* trace;  // optional per-chunk statistics (riggs_raster_set_trace), else NULL
   int cull;  // instance culling against pixel blocks (RIGGS_RENDER_NOCULL=1 turns it off)
   int W, H;
   const uint2* ranges;
@@ -77,7 +78,7 @@ struct RenderBwdArgs {
   const float* ckpt;
   int n_tiles;
   int64_t n_slots;
-  uint32_t* work;      // [n_slots] active chunks, built on device from tile_max
+  uint4* work;  // per active chunk: (tile << 16 | chunk, checkpoint slot, start of the tile's list, instances to walk)
   uint32_t* work_ctr;  // {number of quarter-items, next item}
 };
 int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s);

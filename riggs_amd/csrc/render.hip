@@ -984,11 +984,12 @@ __global__ __launch_bounds__(1024) void render_bwd_worklist_kernel(RenderBwdArgs
   __syncthreads();
   for (int base = 0; base < a.n_tiles; base += 1024) {
     const int t = base + tid;
-    uint32_t c = 0;
+    uint32_t c = 0, limit = 0, sb = 0, rx = 0;
     if (t < a.n_tiles) {
       const uint2 rg = a.ranges[t];
-      const uint32_t limit = min(rg.y - rg.x, a.tile_max[t]);
+      limit = min(rg.y - rg.x, a.tile_max[t]);
       c = (limit + 63u) >> 6;
+      sb = a.slot_base[t]; rx = rg.x;
     }
     uint32_t v = c;
     for (int o = 1; o < 64; o <<= 1) {
@@ -999,8 +1000,9 @@ __global__ __launch_bounds__(1024) void render_bwd_worklist_kernel(RenderBwdArgs
     __syncthreads();
     uint32_t off = s_carry;
     for (int w = 0; w < wave; w++) off += s_wave[w];
-    const uint32_t start = off + v - c;
-    for (uint32_t k = 0; k < c; k++) a.work[start + k] = ((uint32_t)t << 16) | k;
+    // self-contained entries: (tile << 16 | chunk, checkpoint slot, start of the tile's list, instances to walk)
+    uint4* out = a.work + (off + v - c);
+    for (uint32_t k = 0; k < c; k++) out[k] = make_uint4(((uint32_t)t << 16) | k, sb + k, rx, limit);
     __syncthreads();
     if (tid == 1023) s_carry = off + v;
     __syncthreads();
@@ -1010,10 +1012,13 @@ __global__ __launch_bounds__(1024) void render_bwd_worklist_kernel(RenderBwdArgs
 
 // Persistent, dynamically scheduled: every wave pulls (chunk, pixel-quarter) items from one counter until
 // the list is empty, so deep tiles (dozens of fully active chunks) spread evenly over the chip.
-__global__ __launch_bounds__(256) void render_bwd_kernel(RenderBwdArgs a) {
-  __shared__ float4 s_pa[4][64];  // (T_start, Pre_start, Qb, n_contrib as float bits)
-  __shared__ float4 s_pb[4][64];  // (gC0, gC1, gC2, gD)
-  __shared__ float s_pc[4][64];   // gA
+template <int NW>  // waves per workgroup = parts the tile's 256 pixels are split into
+__global__ __launch_bounds__(64 * NW) void render_bwd_kernel(RenderBwdArgs a) {
+  constexpr int PPW = 256 / NW;    // pixels per wave
+  constexpr int RSTEP = NW;        // a wave's rows are part, part + NW, ...
+  __shared__ float4 s_pa[NW][PPW];  // (T_start, Pre_start, Qb, n_contrib as float bits)
+  __shared__ float4 s_pb[NW][PPW];  // (gC0, gC1, gC2, gD)
+  __shared__ float s_pc[NW][PPW];   // gA
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t n_items = a.work_ctr[0];
   const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE;
@@ -1024,63 +1029,102 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderBwdArgs a) {
   // chunks b, b + #workgroups, ...; its four waves are the four pixel-quarters of the chunk and meet in
   // LDS so that each (chunk, instance) still issues ONE set of atomics (float atomics are the scarce
   // resource: ~30 ns each once millions are in flight)
-  __shared__ float s_red[3][64][10];
+  __shared__ float s_red[NW - 1][64][11];  // ten partial sums and the 'has a contribution' flag
   const uint32_t n_chunks = n_items >> 2;
-  for (uint32_t chunk_item = blockIdx.x; chunk_item < n_chunks; chunk_item += gridDim.x) {
-    const uint32_t wk_ = a.work[chunk_item];
-    const int quarter = wave;
-    const int tile = (int)(wk_ >> 16), chunk = (int)(wk_ & 0xFFFFu);
-    const int64_t slot = (int64_t)a.slot_base[tile] + chunk;
-    const uint2 range = a.ranges[tile];
-    const int total = (int)(range.y - range.x);
-    const int limit = min(total, (int)a.tile_max[tile]);
+  const int quarter = wave;
+  // a wave's pixels are rows part, part + NW, ... of the tile: every wave then sees the same mix of instances and
+  // live pixels, and they meet at the barrier at about the same time
+  const int spix = ((lane >> 4) * RSTEP + quarter) * 16 + (lane & 15);  // this lane's pixel while staging (lane < PPW)
+  // A chunk costs about as much arithmetic as a few global round trips, and its inputs hang off a chain of them
+  // (work entry -> list entry / n_contrib -> records / per-pixel state), so the chain is software-pipelined across
+  // the workgroup's chunks: the work entry (self-contained: tile|chunk, checkpoint slot, list start, limit; read
+  // through the scalar cache) is fetched three chunks ahead, the list entry of this lane's instance and the
+  // n_contrib of this lane's pixel two ahead, and the records / per-pixel state of the NEXT chunk are requested
+  // right after this chunk's arithmetic and consumed after the fold of the partial sums — BEFORE this chunk's float
+  // atomics are issued: vmcnt retires in order, so loads queued behind the atomics would wait for every
+  // acknowledgement (microseconds once millions are in flight) with all the workgroup's waves at the barrier.
+  typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+  typedef const u4v __attribute__((address_space(4))) c_u4;
+  c_u4* work = (c_u4*)(uintptr_t)a.work;
+  const uint32_t stride = gridDim.x;
+  auto fetch_level2 = [&](const u4v wk, uint32_t& id_out, uint32_t& n_out) {
+    const int tile = (int)(wk.x >> 16), pos = (int)(wk.x & 0xFFFFu) * 64 + lane;
+    id_out = 0u; n_out = 0u;
+    if (pos < (int)wk.w) id_out = a.point_list[wk.z + pos];
+    const int pxi = (tile % gx) * RIGGS_TILE + (spix & 15), pyi = (tile / gx) * RIGGS_TILE + (spix >> 4);
+    if (lane < PPW && pxi < a.W && pyi < a.H) n_out = a.n_contrib[(size_t)pyi * a.W + pxi];
+  };
+  struct Level3 {  // what a lane loads for a chunk: its instance's records, its pixel's state
+    float4 xy, co, cc, acc;
+    float Tn, g0, g1, g2, gD, gA, Ts, S0, S1, S2, Ds;
+  };
+  auto issue_level3 = [&](const u4v wk, uint32_t id, uint32_t n, Level3& r) {
+    const int tile = (int)(wk.x >> 16), pos0 = (int)(wk.x & 0xFFFFu) * 64;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    r.xy = z; r.co = z; r.cc = z; r.acc = z;
+    r.Tn = 0.f; r.g0 = 0.f; r.g1 = 0.f; r.g2 = 0.f; r.gD = 0.f; r.gA = 0.f; r.Ts = 1.f; r.S0 = 0.f; r.S1 = 0.f; r.S2 = 0.f; r.Ds = 0.f;
+    if (pos0 + lane < (int)wk.w) { r.xy = a.xyd[id]; r.co = a.conic_o[id]; r.cc = a.rgb[id]; }
+    if ((int)n > pos0) {  // (n is 0 for the lanes without a pixel and for the pixels outside the image)
+      const int pxi = (tile % gx) * RIGGS_TILE + (spix & 15), pyi = (tile / gx) * RIGGS_TILE + (spix >> 4);
+      const size_t pid = (size_t)pyi * a.W + pxi;
+      const float* ck = a.ckpt + ((size_t)wk.y * 5) * 256;
+      r.Tn = a.final_T[pid];
+      r.acc = a.final_acc[pid];
+      r.g0 = a.dL_dcolor[pid]; r.g1 = a.dL_dcolor[HW + pid]; r.g2 = a.dL_dcolor[2 * HW + pid];
+      r.gD = a.dL_ddepth ? a.dL_ddepth[pid] : 0.f;
+      r.gA = a.dL_dalpha ? a.dL_dalpha[pid] : 0.f;
+      r.Ts = ck[spix]; r.S0 = ck[256 + spix]; r.S1 = ck[512 + spix]; r.S2 = ck[768 + spix]; r.Ds = ck[1024 + spix];
+    }
+  };
+  auto stage_pixels = [&](const u4v wk, uint32_t n, const Level3& r) {  // this wave's pixels (one per lane) -> LDS
+    const int pos0 = (int)(wk.x & 0xFFFFu) * 64;
+    float4 pa = make_float4(1.f, 0.f, 0.f, 0.f), pb = make_float4(0.f, 0.f, 0.f, 0.f);
+    float pc = 0.f;
+    if ((int)n > pos0) {
+      const float pre = r.g0 * r.S0 + r.g1 * r.S1 + r.g2 * r.S2 + r.gD * r.Ds + r.gA * (1.0f - r.Ts);
+      const float qb = (r.g0 * r.acc.x + r.g1 * r.acc.y + r.g2 * r.acc.z + r.gD * r.acc.w + r.gA * (1.0f - r.Tn)) +
+                       r.Tn * (bg0 * r.g0 + bg1 * r.g1 + bg2 * r.g2);
+      pa = make_float4(r.Ts, pre, qb, __uint_as_float(n));
+      pb = make_float4(r.g0, r.g1, r.g2, r.gD);
+      pc = r.gA;
+    }
+    if (lane < PPW) { s_pa[wave][lane] = pa; s_pb[wave][lane] = pb; s_pc[wave][lane] = pc; }
+  };
+  const u4v wk_zero = {0u, 0u, 0u, 0u};
+  u4v wk_a = wk_zero, wk_b = wk_zero, wk_c = wk_zero;  // this chunk, the next, the one after
+  uint32_t id_a = 0u, n_a = 0u, id_b = 0u, n_b = 0u;
+  float4 xy = make_float4(0.f, 0.f, 0.f, 0.f), co = xy, cc = xy;
+  if (blockIdx.x < n_chunks) {
+    wk_a = work[blockIdx.x];
+    fetch_level2(wk_a, id_a, n_a);
+    if (blockIdx.x + stride < n_chunks) { wk_b = work[blockIdx.x + stride]; fetch_level2(wk_b, id_b, n_b); }
+    if (blockIdx.x + 2 * stride < n_chunks) wk_c = work[blockIdx.x + 2 * stride];
+    Level3 r;
+    issue_level3(wk_a, id_a, n_a, r);
+    stage_pixels(wk_a, n_a, r);
+    xy = r.xy; co = r.co; cc = r.cc;
+  }
+  for (uint32_t chunk_item = blockIdx.x; chunk_item < n_chunks; chunk_item += stride) {
+    const u4v wk = wk_a;
+    const uint32_t id = id_a;
+    const unsigned long long t_begin = a.trace ? wall_clock64() : 0ull;
+    const int tile = (int)(wk.x >> 16), chunk = (int)(wk.x & 0xFFFFu);
+    const int limit = (int)wk.w;
     const int pos0 = chunk * 64;
     const int tx0 = (tile % gx) * RIGGS_TILE, ty0 = (tile / gx) * RIGGS_TILE;
-    // ---- stage this quarter's 64 pixels (one per lane)
-    const float* ck = a.ckpt + ((size_t)slot * 5) * 256;
-    {
-      const int pix = quarter * 64 + lane;
-      const int pxi = tx0 + (pix & 15), pyi = ty0 + (pix >> 4);
-      float4 pa = make_float4(1.f, 0.f, 0.f, 0.f), pb = make_float4(0.f, 0.f, 0.f, 0.f);
-      float pc = 0.f;
-      if (pxi < a.W && pyi < a.H) {
-        const size_t pid = (size_t)pyi * a.W + pxi;
-        const uint32_t n = a.n_contrib[pid];
-        if ((int)n > pos0) {
-          const float Tn = a.final_T[pid];
-          const float4 acc = a.final_acc[pid];
-          const float g0 = a.dL_dcolor[pid], g1 = a.dL_dcolor[HW + pid], g2 = a.dL_dcolor[2 * HW + pid];
-          const float gD = a.dL_ddepth ? a.dL_ddepth[pid] : 0.f;
-          const float gA = a.dL_dalpha ? a.dL_dalpha[pid] : 0.f;
-          const float Ts = ck[pix], S0 = ck[256 + pix], S1 = ck[512 + pix], S2 = ck[768 + pix], Ds = ck[1024 + pix];
-          const float pre = g0 * S0 + g1 * S1 + g2 * S2 + gD * Ds + gA * (1.0f - Ts);
-          const float qb = (g0 * acc.x + g1 * acc.y + g2 * acc.z + gD * acc.w + gA * (1.0f - Tn)) +
-                           Tn * (bg0 * g0 + bg1 * g1 + bg2 * g2);
-          pa = make_float4(Ts, pre, qb, __uint_as_float(n));
-          pb = make_float4(g0, g1, g2, gD);
-          pc = gA;
-        }
-      }
-      s_pa[wave][lane] = pa; s_pb[wave][lane] = pb; s_pc[wave][lane] = pc;
-    }
-    // ---- this lane's instance
     const int pos = pos0 + lane;
     const bool active = pos < limit;
-    uint32_t id = 0;
-    float4 xy = make_float4(0.f, 0.f, 0.f, 0.f), co = xy, cc = xy;
-    if (active) {
-      id = a.point_list[range.x + pos];
-      xy = a.xyd[id]; co = a.conic_o[id]; cc = a.rgb[id];
-    }
+    float m_x = 0.f, m_y = 0.f;
+    bool touched = false;  // this lane's instance contributes to at least one pixel of the tile
     float a_mx = 0.f, a_my = 0.f, a_ca = 0.f, a_cb = 0.f, a_cc = 0.f, a_op = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f, a_d = 0.f;
     // (the wave only touches its own LDS region: LDS operations of one wave are ordered, no barrier needed)
     // two pixels per iteration: their scans are independent chains that the scheduler interleaves (a lone
     // chain leaves the SIMD idle through every DPP / transcendental latency)
-    for (int pl = 0; pl < 64; pl += 2) {
+    for (int pl = 0; pl < PPW; pl += 2) {
       const float4 paA = s_pa[wave][pl], paB = s_pa[wave][pl + 1];
       const int nA = (int)__float_as_uint(paA.w), nB = (int)__float_as_uint(paB.w);
       if (nA <= pos0 && nB <= pos0) continue;  // wave-uniform: this chunk lies behind both pixels' last contributors
-      const int pix = quarter * 64 + pl;       // pl is even: both pixels are in the same row
+      const int pix = ((pl >> 4) * RSTEP + quarter) * 16 + (pl & 15);  // pl is even: both pixels are in the same row
       const float pfx = (float)(tx0 + (pix & 15)), pfy = (float)(ty0 + (pix >> 4));
       const float dxA = xy.x - pfx, dxB = dxA - 1.0f, dy = xy.y - pfy;
       // cheap conservative reject (alpha >= 1/255 extents, as in the forward's cull) before the exponentials
@@ -1093,6 +1137,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderBwdArgs a) {
       const bool vA = active && (pos < nA) && (powA <= 0.0f) && (alA >= ALPHA_MIN);
       const bool vB = active && (pos < nB) && (powB <= 0.0f) && (alB >= ALPHA_MIN);
       if (__builtin_amdgcn_ballot_w64(vA || vB) == 0) continue;
+      touched = touched || vA || vB;
       alA = vA ? alA : 0.f; alB = vB ? alB : 0.f;
       const float GA = vA ? GA_ : 0.f, GB = vB ? GB_ : 0.f;
       const float omA = 1.0f - alA, omB = 1.0f - alB;
@@ -1109,38 +1154,68 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(RenderBwdArgs a) {
       dual_excl_sum_scan(ssA, ssB);
       const float preA = paA.y + ssA, preB = paB.y + ssB;
       // dL/dalpha = T k - (suffix + T_final * bg.g) / (1 - alpha),  suffix = total - prefix - own
-      float dLaA = TlA * kA - (paA.z - preA - wkA) * __builtin_amdgcn_rcpf(omA);
-      float dLaB = TlB * kB - (paB.z - preB - wkB) * __builtin_amdgcn_rcpf(omB);
-      dLaA = vA ? dLaA : 0.f; dLaB = vB ? dLaB : 0.f;
-      const float dGA = co.w * dLaA, dGB = co.w * dLaB;
-      const float gdxA = GA * dxA, gdxB = GB * dxB, gdyA = GA * dy, gdyB = GB * dy;
-      a_mx += dGA * (-gdxA * co.x - gdyA * co.y) + dGB * (-gdxB * co.x - gdyB * co.y);
-      a_my += dGA * (-gdyA * co.z - gdxA * co.y) + dGB * (-gdyB * co.z - gdxB * co.y);
-      a_ca += gdxA * dxA * dGA + gdxB * dxB * dGB;
-      a_cb += gdxA * dy * dGA + gdxB * dy * dGB;
-      a_cc += gdyA * dy * dGA + gdyB * dy * dGB;
-      a_op += GA * dLaA + GB * dLaB;
+      // (no select on dLa: an invalid pair has G = 0 and every use below is multiplied by G)
+      const float dLaA = TlA * kA - (paA.z - preA - wkA) * __builtin_amdgcn_rcpf(omA);
+      const float dLaB = TlB * kB - (paB.z - preB - wkB) * __builtin_amdgcn_rcpf(omB);
+      // raw moments of q = dL/dalpha * G; opacity and the conic factors of dL/dmean2D are applied once per chunk
+      // (co is the lane's)
+      const float qA = dLaA * GA, qB = dLaB * GB;
+      const float qxA = qA * dxA, qxB = qB * dxB, qyA = qA * dy, qyB = qB * dy;
+      m_x += qxA + qxB; m_y += qyA + qyB;
+      a_ca += qxA * dxA + qxB * dxB;
+      a_cb += qxA * dy + qxB * dy;
+      a_cc += qyA * dy + qyB * dy;
+      a_op += qA + qB;
       a_r += wA * pbA.x + wB * pbB.x; a_g += wA * pbA.y + wB * pbB.y; a_b += wA * pbA.z + wB * pbB.z;
       a_d += wA * pbA.w + wB * pbB.w;
     }
-    // fold the four pixel-quarters
+    a_mx = -co.w * (co.x * m_x + co.y * m_y);
+    a_my = -co.w * (co.z * m_y + co.y * m_x);
+    a_ca *= co.w; a_cb *= co.w; a_cc *= co.w;
+    // ---- request the next chunk's records / pixel state, the list entry and n_contrib of the one after, and the
+    // work entry after that
+    const bool has_next = chunk_item + stride < n_chunks;
+    Level3 nr;
+    if (has_next) issue_level3(wk_b, id_b, n_b, nr);
+    uint32_t id_c = 0u, n_c = 0u;
+    if (chunk_item + 2 * stride < n_chunks) fetch_level2(wk_c, id_c, n_c);
+    u4v wk_d = wk_zero;
+    if (chunk_item + 3 * stride < n_chunks) wk_d = work[chunk_item + 3 * stride];
+    // ---- fold the pixel parts
     __syncthreads();
     if (wave > 0) {
       float* r = s_red[wave - 1][lane];
-      r[0] = a_mx; r[1] = a_my; r[2] = a_ca; r[3] = a_cb; r[4] = a_cc; r[5] = a_op; r[6] = a_r; r[7] = a_g; r[8] = a_b; r[9] = a_d;
+      r[0] = a_mx; r[1] = a_my; r[2] = a_ca; r[3] = a_cb; r[4] = a_cc; r[5] = a_op; r[6] = a_r; r[7] = a_g; r[8] = a_b; r[9] = a_d; r[10] = touched ? 1.f : 0.f;
     }
     __syncthreads();
     if (wave == 0 && active) {
 #pragma unroll
-      for (int q = 0; q < 3; q++) {
+      for (int q = 0; q < NW - 1; q++) {
         const float* r = s_red[q][lane];
         a_mx += r[0]; a_my += r[1]; a_ca += r[2]; a_cb += r[3]; a_cc += r[4]; a_op += r[5]; a_r += r[6]; a_g += r[7]; a_b += r[8]; a_d += r[9];
+        touched = touched || (r[10] != 0.f);
       }
+    }
+    // ---- the next chunk's pixels go to LDS (each wave only touches its own region, and is done with it)
+    if (has_next) { stage_pixels(wk_b, n_b, nr); xy = nr.xy; co = nr.co; cc = nr.cc; }
+    // ---- only now the atomics, and only for the instances that reach a pixel of this tile: the lists are built
+    // from 3-sigma rectangles, most of a tile's instances never get to alpha >= 1/255 inside it, and adding their
+    // exact zeros cost a quarter of the kernel (the memory-side atomic units were its one saturated resource)
+    if (wave == 0 && active && touched) {
       float* g = a.gacc + (size_t)id * RIGGS_GACC;
       atomicAdd(g + 0, a_mx * ddelx_dx); atomicAdd(g + 1, a_my * ddely_dy);
       atomicAdd(g + 2, -0.5f * a_ca); atomicAdd(g + 3, -a_cb); atomicAdd(g + 4, -0.5f * a_cc);
       atomicAdd(g + 5, a_op); atomicAdd(g + 6, a_r); atomicAdd(g + 7, a_g); atomicAdd(g + 8, a_b);
       if (a.dL_ddepth) atomicAdd(g + 9, a_d);
+    }
+    wk_a = wk_b; id_a = id_b; n_a = n_b;
+    wk_b = wk_c; id_b = id_c; n_b = n_c;
+    wk_c = wk_d;
+    if (a.trace && threadIdx.x == 0) {  // per chunk: {start, end (100 MHz ticks), hardware id, workgroup}
+      unsigned long long* tr = a.trace + (size_t)chunk_item * 4;
+      tr[0] = t_begin; tr[1] = wall_clock64();
+      tr[2] = (unsigned long long)(__builtin_amdgcn_s_getreg(63492) & 0xFFFFu) | ((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 0xFu) << 16);
+      tr[3] = ((unsigned long long)blockIdx.x << 32) | wk.x;
     }
   }
 }
@@ -1158,7 +1233,9 @@ int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s) {
     static const int per_cu = getenv("RIGGS_BWD_WG_PER_CU") ? atoi(getenv("RIGGS_BWD_WG_PER_CU")) : 8;
     const int64_t max_blocks = 256 * per_cu;  // 8 workgroups of 4 waves per CU: every SIMD holds 8 pulling waves
     const unsigned blocks = (unsigned)((a.n_slots < max_blocks) ? a.n_slots : max_blocks);
-    hipLaunchKernelGGL(render_bwd_kernel, dim3(blocks), dim3(256), 0, s, a);
+    static const int nw = getenv("RIGGS_BWD_WAVES") ? atoi(getenv("RIGGS_BWD_WAVES")) : 4;
+    if (nw == 8) hipLaunchKernelGGL(render_bwd_kernel<8>, dim3(blocks), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(render_bwd_kernel<4>, dim3(blocks), dim3(256), 0, s, a);
   }
   return 0;
 }
