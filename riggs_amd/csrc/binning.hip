@@ -110,6 +110,9 @@ __global__ __launch_bounds__(1024) void bin_offsets_kernel(int T, int64_t cap, c
   if (tid == 0) { s_carry = 0u; s_nempty = 0u; }
   if (tid < 32) s_hist[tid] = 0u;
   __syncthreads();
+  uint32_t my_len[8];  // list lengths of this thread's tiles (the first 8192 tiles; beyond that they are re-read)
+#pragma unroll
+  for (int k = 0; k < 8; k++) my_len[k] = 0u;
   for (int base = 0; base < T; base += 1024) {
     const int t = base + tid;
     const uint32_t c = (t < T) ? tile_count[t] : 0u;
@@ -136,6 +139,8 @@ __global__ __launch_bounds__(1024) void bin_offsets_kernel(int T, int64_t cap, c
       // forward work queue, step 1: histogram of floor(log2(list length)); the empty tiles go to their own list
       if (hi > lo) atomicAdd(&s_hist[31 - __builtin_clz(hi - lo)], 1u);
       else fwd_empty[atomicAdd(&s_nempty, 1u)] = (uint32_t)t;
+#pragma unroll
+      for (int k = 0; k < 8; k++) if (base == k * 1024) my_len[k] = hi - lo;
     }
     __syncthreads();
     if (tid == 1023) s_carry = carry + wave_off + v;
@@ -149,19 +154,29 @@ __global__ __launch_bounds__(1024) void bin_offsets_kernel(int T, int64_t cap, c
     slot_base[T] = ((uint32_t)min((int64_t)R, cap) >> 6) + (uint32_t)T;
     counters[0] = R;
     counters[1] = ((int64_t)R > cap) ? 1u : 0u;
-    // step 2: the longest lists first (the forward deals the tiles to its workgroups in this order, so the long
-    // chains start at once and the short ones fill in around them)
-    uint32_t off = 0;
-    for (int b = 31; b >= 0; b--) { s_cur[b] = off; off += s_hist[b]; }
-    fwd_ctr[0] = off; fwd_ctr[1] = 0u; fwd_ctr[2] = s_nempty;
+  }
+  // step 2: the longest lists first (the forward deals the tiles to its workgroups in this order, so the long
+  // chains start at once and the short ones fill in around them): exclusive scan of the histogram from the top
+  // bucket down, on the first 32 lanes
+  if (tid < 32) {
+    const uint32_t h = s_hist[31 - tid];
+    uint32_t v = h;
+    for (int o = 1; o < 32; o <<= 1) {
+      const uint32_t u = (uint32_t)__shfl_up((int)v, o);
+      if (tid >= o) v += u;
+    }
+    s_cur[31 - tid] = v - h;
+    if (tid == 31) { fwd_ctr[0] = v; fwd_ctr[1] = 0u; fwd_ctr[2] = s_nempty; }
   }
   __syncthreads();
-  for (int t = tid; t < T; t += 1024) {  // (same thread that wrote ranges[t] above)
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int t = k * 1024 + tid;
+    if (t < T && my_len[k] > 0u) fwd_items[atomicAdd(&s_cur[31 - __builtin_clz(my_len[k])], 1u)] = (uint32_t)t;
+  }
+  for (int t = 8192 + tid; t < T; t += 1024) {  // (same thread that wrote ranges[t] above)
     const uint2 r = ranges[t];
-    if (r.y > r.x) {
-      const uint32_t p = atomicAdd(&s_cur[31 - __builtin_clz(r.y - r.x)], 1u);
-      fwd_items[p] = (uint32_t)t;
-    }
+    if (r.y > r.x) fwd_items[atomicAdd(&s_cur[31 - __builtin_clz(r.y - r.x)], 1u)] = (uint32_t)t;
   }
 }
 
