@@ -455,9 +455,30 @@ __global__ __launch_bounds__(256) void lbs_backward_bonelane_kernel(LbsArgs a) {
     for (int e = 0; e < 13; e++) acc[bb][e] = 0.f;
   float gt0 = 0.f, gt1 = 0.f, gt2 = 0.f;
   const float gx = a.global_trans[0], gy = a.global_trans[1], gz = a.global_trans[2];
-  for (int n0 = wave_first; n0 < wave_end; n0 += 8) {
-    const int n = n0 + slot;
-    const bool valid = n < wave_end;
+  // Gaussians without an incoming gradient (behind saturated pixels, never at alpha >= 1/255, invisible: most of a
+  // deep scene) contribute exact zeros to every sum: the wave looks at its 64 Gaussians once, writes the zeros of
+  // the per-Gaussian outputs, and walks only the others, eight at a time.
+  __shared__ unsigned char s_list[4][64];
+  int n_work;
+  {
+    const int n = wave_first + lane;
+    bool touched = false;
+    if (n < wave_end) {
+      const float4 h4 = reinterpret_cast<const float4*>(a.g_rot)[n];
+      touched = (a.g_xyz[3 * n] != 0.f) || (a.g_xyz[3 * n + 1] != 0.f) || (a.g_xyz[3 * n + 2] != 0.f) ||
+                (h4.x != 0.f) || (h4.y != 0.f) || (h4.z != 0.f) || (h4.w != 0.f);
+      if (!touched) {
+        if (a.dmask) a.dmask[n] = 0.f;
+        if constexpr (MOD) for (int k = 0; k < B; k++) a.dmod[(size_t)n * B + k] = 0.f;
+      }
+    }
+    const uint64_t tm = __builtin_amdgcn_ballot_w64(touched);
+    n_work = __builtin_popcountll(tm);
+    if (touched) s_list[wave][__builtin_popcountll(tm & ((1ull << lane) - 1ull))] = (unsigned char)lane;
+  }
+  for (int w0 = 0; w0 < n_work; w0 += 8) {
+    const bool valid = w0 + slot < n_work;
+    const int n = valid ? wave_first + (int)s_list[wave][w0 + slot] : 0;  // (a wave's own LDS writes are ordered)
     float px = 0.f, py = 0.f, pz = 0.f, m = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
     float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
     if (valid) {

@@ -238,19 +238,60 @@ __global__ __launch_bounds__(1024) void sum_block_tiles_kernel(int n, const uint
 // ---------------------------------------------------------------------------- backward
 __global__ __launch_bounds__(256, 3) void preprocess_bwd_kernel(PreBwdArgs b) {
   extern __shared__ float s_sh[];
+  __shared__ unsigned char s_list[256];
+  __shared__ int s_wcount[4];
   const PreArgs& a = b.f;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const bool in_range = i < a.N;
   const float* __restrict__ V = a.view;
   const float* __restrict__ P = a.proj;
   const bool sh_mode = (a.colors_precomp == nullptr);
   const int sh_per = a.shs_rest ? (a.M - 1) * 3 : a.M * 3;
   const int sh_first = blockIdx.x * 256, sh_count = min(256, a.N - sh_first);
-  if (sh_mode && sh_per > 0) {
-    sh_stage_in((a.shs_rest ? a.shs_rest : a.shs) + (size_t)sh_first * sh_per, sh_per, sh_count, s_sh);
-    __syncthreads();
+  // ---- which Gaussians of this block received any gradient from the compositing backward?  A Gaussian whose
+  // accumulator record is all zeros (invisible, behind saturated pixels, or never at alpha >= 1/255 in a tile it
+  // overlaps: 93 % of the bench scene) has an exactly zero gradient: its thread writes the zeros right away, and
+  // the others are COMPACTED onto the first threads of the block, so that the long arithmetic below runs on full
+  // lanes of few waves instead of a few lanes of every wave, and nothing is read for the rest.
+  const int t0 = threadIdx.x, lane0 = t0 & 63, wave0 = t0 >> 6;
+  const int i0 = blockIdx.x * 256 + t0;
+  bool touched0 = false;
+  if (i0 < a.N && a.radii[i0] > 0) {
+    const float4* acc4 = reinterpret_cast<const float4*>(b.g_mean2D_conic + (size_t)i0 * RIGGS_GACC);
+    const float4 q0 = acc4[0], q1 = acc4[1], q2 = acc4[2];
+    touched0 = (q0.x != 0.f) || (q0.y != 0.f) || (q0.z != 0.f) || (q0.w != 0.f) || (q1.x != 0.f) || (q1.y != 0.f) ||
+               (q1.z != 0.f) || (q1.w != 0.f) || (q2.x != 0.f) || (q2.y != 0.f);
   }
-  const bool visible = in_range && a.radii[i] > 0;
+  const uint64_t tmask = __builtin_amdgcn_ballot_w64(touched0);
+  if (lane0 == 0) s_wcount[wave0] = __builtin_popcountll(tmask);
+  __syncthreads();
+  int tbase = 0;
+  for (int w = 0; w < wave0; w++) tbase += s_wcount[w];
+  const int n_work = s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
+  if (touched0) s_list[tbase + __builtin_popcountll(tmask & ((1ull << lane0) - 1ull))] = (unsigned char)t0;
+  if (i0 < a.N && !touched0) {
+    b.dL_dmeans3D[3 * i0] = 0.f; b.dL_dmeans3D[3 * i0 + 1] = 0.f; b.dL_dmeans3D[3 * i0 + 2] = 0.f;
+    b.dL_dmeans2D[3 * i0] = 0.f; b.dL_dmeans2D[3 * i0 + 1] = 0.f; b.dL_dmeans2D[3 * i0 + 2] = 0.f;
+    if (b.dL_dcolors) { b.dL_dcolors[3 * i0] = 0.f; b.dL_dcolors[3 * i0 + 1] = 0.f; b.dL_dcolors[3 * i0 + 2] = 0.f; }
+    b.dL_dopac[i0] = 0.f;
+    if (b.dL_dscales) {
+      if (a.glue && a.isotropic) b.dL_dscales[i0] = 0.f;
+      else { b.dL_dscales[3 * i0] = 0.f; b.dL_dscales[3 * i0 + 1] = 0.f; b.dL_dscales[3 * i0 + 2] = 0.f; }
+    }
+    if (a.glue && b.dL_dscales && b.dL_dd_scaling) { b.dL_dd_scaling[3 * i0] = 0.f; b.dL_dd_scaling[3 * i0 + 1] = 0.f; b.dL_dd_scaling[3 * i0 + 2] = 0.f; }
+    if (b.dL_drots) reinterpret_cast<float4*>(b.dL_drots)[i0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (b.dL_dcov3D) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) b.dL_dcov3D[6 * i0 + k] = 0.f;
+    }
+    if (sh_mode && a.shs_rest) { b.dL_dsh[3 * i0] = 0.f; b.dL_dsh[3 * i0 + 1] = 0.f; b.dL_dsh[3 * i0 + 2] = 0.f; }
+  }
+  // the block's coefficients are staged through LDS when most of it has work, else the few read their own rows
+  const bool staged = sh_mode && sh_per > 0 && n_work > 64;
+  if (staged) sh_stage_in((a.shs_rest ? a.shs_rest : a.shs) + (size_t)sh_first * sh_per, sh_per, sh_count, s_sh);
+  __syncthreads();  // s_list (and the staged coefficients)
+  const bool in_range = t0 < n_work;                       // from here on: "this thread has a Gaussian to work on"
+  const int slot = in_range ? (int)s_list[t0] : t0;        // its place in the block (LDS row of its coefficients)
+  const int i = blockIdx.x * 256 + slot;
+  const bool visible = in_range;
   float Bk[16], gcs[3] = {0.f, 0.f, 0.f};
 #pragma unroll
   for (int k = 0; k < 16; k++) Bk[k] = 0.f;
@@ -331,7 +372,8 @@ __global__ __launch_bounds__(256, 3) void preprocess_bwd_kernel(PreBwdArgs b) {
       for (int k = 0; k < 16; k++) if (k >= nb) Bk[k] = 0.f;
       const uint8_t cl = a.clamped[i];
       gcs[0] = (cl & 1) ? 0.f : gcol[0]; gcs[1] = (cl & 2) ? 0.f : gcol[1]; gcs[2] = (cl & 4) ? 0.f : gcol[2];
-      const float* mine = s_sh + threadIdx.x * sh_lds_stride(sh_per);
+      const float* mine = staged ? s_sh + slot * sh_lds_stride(sh_per)
+                                 : (a.shs_rest ? a.shs_rest : a.shs) + (size_t)i * sh_per;
       const int koff = a.shs_rest ? 3 : 0;
       float w[16];
 #pragma unroll
@@ -383,14 +425,20 @@ __global__ __launch_bounds__(256, 3) void preprocess_bwd_kernel(PreBwdArgs b) {
     const int koff = a.shs_rest ? 3 : 0;
     if (sh_per > 0) {
       __syncthreads();  // every thread is done reading the staged coefficients
-      float* mine = s_sh + threadIdx.x * sh_lds_stride(sh_per);
+      {  // zero rows for the Gaussians without work
+        float* row = s_sh + t0 * sh_lds_stride(sh_per);
+        for (int k = 0; k < sh_per; k++) row[k] = 0.f;
+      }
+      __syncthreads();
+      if (in_range) {
+        float* mine = s_sh + slot * sh_lds_stride(sh_per);
 #pragma unroll
-      for (int k = 0; k < 16; k++) {
-        if (k < a.M && 3 * k >= koff) {
-          mine[3 * k - koff] = Bk[k] * gcs[0]; mine[3 * k + 1 - koff] = Bk[k] * gcs[1]; mine[3 * k + 2 - koff] = Bk[k] * gcs[2];
+        for (int k = 0; k < 16; k++) {
+          if (k < a.M && 3 * k >= koff) {
+            mine[3 * k - koff] = Bk[k] * gcs[0]; mine[3 * k + 1 - koff] = Bk[k] * gcs[1]; mine[3 * k + 2 - koff] = Bk[k] * gcs[2];
+          }
         }
       }
-      for (int k = 16; k < a.M; k++) { mine[3 * k - koff] = 0.f; mine[3 * k + 1 - koff] = 0.f; mine[3 * k + 2 - koff] = 0.f; }
       __syncthreads();
       float* dst = (a.shs_rest ? b.dL_dsh_rest : b.dL_dsh) + (size_t)sh_first * sh_per;
       sh_stage_out(dst, sh_per, sh_count, s_sh);
