@@ -45,6 +45,53 @@ __device__ __forceinline__ void load_inputs(const PreArgs& a, int i, GlueIn& g, 
 }
 
 
+// The same in two steps for the backward: every global load of a Gaussian's parameters first (no arithmetic, so that
+// they are all in flight together), the arithmetic after — bit-identical to load_inputs.
+struct RawIn {
+  float p[3], dx[3], o, sc[3], dsc[3];
+  float4 r, dr;
+};
+__device__ __forceinline__ void load_raw(const PreArgs& a, int i, RawIn& w, bool need_sr) {
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  w.p[0] = a.means3D[3 * i]; w.p[1] = a.means3D[3 * i + 1]; w.p[2] = a.means3D[3 * i + 2];
+  w.dx[0] = w.dx[1] = w.dx[2] = 0.f; w.sc[0] = w.sc[1] = w.sc[2] = 0.f; w.dsc[0] = w.dsc[1] = w.dsc[2] = 0.f;
+  w.r = z; w.dr = z;
+  w.o = a.opac[i];
+  if (a.glue && a.d_xyz) { w.dx[0] = a.d_xyz[3 * i]; w.dx[1] = a.d_xyz[3 * i + 1]; w.dx[2] = a.d_xyz[3 * i + 2]; }
+  if (need_sr) {
+    if (a.glue && a.isotropic) w.sc[0] = a.scales[i];
+    else { w.sc[0] = a.scales[3 * i]; w.sc[1] = a.scales[3 * i + 1]; w.sc[2] = a.scales[3 * i + 2]; }
+    if (a.glue && a.d_scaling) { w.dsc[0] = a.d_scaling[3 * i]; w.dsc[1] = a.d_scaling[3 * i + 1]; w.dsc[2] = a.d_scaling[3 * i + 2]; }
+    w.r = reinterpret_cast<const float4*>(a.rots)[i];
+    if (a.glue && a.d_rot) w.dr = reinterpret_cast<const float4*>(a.d_rot)[i];
+  }
+}
+__device__ __forceinline__ void finish_inputs(const PreArgs& a, const RawIn& w, GlueIn& g, bool need_sr) {
+  g.p[0] = w.p[0]; g.p[1] = w.p[1]; g.p[2] = w.p[2];
+  if (a.glue) {
+    if (a.d_xyz) { g.p[0] = g.p[0] + w.dx[0]; g.p[1] = g.p[1] + w.dx[1]; g.p[2] = g.p[2] + w.dx[2]; }
+    g.o = sigmoidf_(w.o);
+    if (need_sr) {
+      if (a.isotropic) { float s = expf(w.sc[0]); g.es[0] = g.es[1] = g.es[2] = s; }
+      else { g.es[0] = expf(w.sc[0]); g.es[1] = expf(w.sc[1]); g.es[2] = expf(w.sc[2]); }
+      g.s[0] = g.es[0]; g.s[1] = g.es[1]; g.s[2] = g.es[2];
+      if (a.d_scaling) { g.s[0] = g.s[0] + w.dsc[0]; g.s[1] = g.s[1] + w.dsc[1]; g.s[2] = g.s[2] + w.dsc[2]; }
+      g.v[0] = w.r.x; g.v[1] = w.r.y; g.v[2] = w.r.z; g.v[3] = w.r.w;
+      if (a.d_rot) { g.v[0] = g.v[0] + w.dr.x; g.v[1] = g.v[1] + w.dr.y; g.v[2] = g.v[2] + w.dr.z; g.v[3] = g.v[3] + w.dr.w; }
+      float n = sqrtf(g.v[0] * g.v[0] + g.v[1] * g.v[1] + g.v[2] * g.v[2] + g.v[3] * g.v[3]);
+      g.vnorm = fmaxf(n, 1e-12f);
+      g.q[0] = g.v[0] / g.vnorm; g.q[1] = g.v[1] / g.vnorm; g.q[2] = g.v[2] / g.vnorm; g.q[3] = g.v[3] / g.vnorm;
+    }
+  } else {
+    g.o = w.o;
+    if (need_sr) {
+      g.s[0] = w.sc[0]; g.s[1] = w.sc[1]; g.s[2] = w.sc[2];
+      g.q[0] = w.r.x; g.q[1] = w.r.y; g.q[2] = w.r.z; g.q[3] = w.r.w;
+      g.vnorm = 1.f;
+    }
+  }
+}
+
 // ---- coalesced SH staging -----------------------------------------------------------------
 // A workgroup's 256 Gaussians own one contiguous run of coefficients in HBM ((N,16,3) records of
 // 192 B, or the reference's split parameters _features_dc (N,1,3) / _features_rest (N,15,3) of
@@ -302,18 +349,45 @@ __global__ __launch_bounds__(256, 3) void preprocess_bwd_kernel(PreBwdArgs b) {
   float gs[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f}, gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   GlueIn g;
   g.vnorm = 1.f;
+  // ---- every global load of this Gaussian up front, nothing used yet: left to itself the compiler sinks each load
+  // next to its use and the arithmetic below becomes a chain of ~45 exposed round trips (25 us for a wave that has
+  // the SIMD to itself, and few waves have work here)
+  RawIn raw;
+  float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
+  float c6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  uint8_t cl = 0;
+  float shv[48];  // coefficient k, channel c at [3 k + c] whatever the parameter layout
+#pragma unroll
+  for (int e = 0; e < 48; e++) shv[e] = 0.f;
   if (visible) {
-    load_inputs(a, i, g, need_sr);
-    const float* p = g.p;
-    const float* acc = b.g_mean2D_conic + (size_t)i * RIGGS_GACC;
-    g2x = acc[0]; g2y = acc[1];
-    const float gA = acc[2], gB = acc[3], gC = acc[4];
-    g_op = acc[5];
-    gcol[0] = acc[6]; gcol[1] = acc[7]; gcol[2] = acc[8];
-    const float gd = acc[9];
-    float c6[6];
+    load_raw(a, i, raw, need_sr);
+    const float4* acc4 = reinterpret_cast<const float4*>(b.g_mean2D_conic + (size_t)i * RIGGS_GACC);
+    q0 = acc4[0]; q1 = acc4[1]; q2 = acc4[2];
 #pragma unroll
     for (int k = 0; k < 6; k++) c6[k] = a.cov3D[6 * i + k];
+    if (sh_mode) {
+      cl = a.clamped[i];
+      const float* mine = staged ? s_sh + slot * sh_lds_stride(sh_per)
+                                 : (a.shs_rest ? a.shs_rest : a.shs) + (size_t)i * sh_per;
+      if (a.shs_rest) {
+        shv[0] = a.shs[3 * i]; shv[1] = a.shs[3 * i + 1]; shv[2] = a.shs[3 * i + 2];
+#pragma unroll
+        for (int e = 0; e < 45; e++) if (e < sh_per) shv[3 + e] = mine[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 48; e++) if (e < sh_per) shv[e] = mine[e];
+      }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if (visible) {
+    finish_inputs(a, raw, g, need_sr);
+    const float* p = g.p;
+    g2x = q0.x; g2y = q0.y;
+    const float gA = q0.z, gB = q0.w, gC = q1.x;
+    g_op = q1.y;
+    gcol[0] = q1.z; gcol[1] = q1.w; gcol[2] = q2.x;
+    const float gd = q2.y;
     float fx = a.W / (2.0f * a.tanx), fy = a.H / (2.0f * a.tany);
     Cov2D cv;
     cov2d_eval(p, c6, V, fx, fy, a.tanx, a.tany, cv);
@@ -370,19 +444,12 @@ __global__ __launch_bounds__(256, 3) void preprocess_bwd_kernel(PreBwdArgs b) {
       const int nb = (a.deg + 1) * (a.deg + 1);
 #pragma unroll
       for (int k = 0; k < 16; k++) if (k >= nb) Bk[k] = 0.f;
-      const uint8_t cl = a.clamped[i];
       gcs[0] = (cl & 1) ? 0.f : gcol[0]; gcs[1] = (cl & 2) ? 0.f : gcol[1]; gcs[2] = (cl & 4) ? 0.f : gcol[2];
-      const float* mine = staged ? s_sh + slot * sh_lds_stride(sh_per)
-                                 : (a.shs_rest ? a.shs_rest : a.shs) + (size_t)i * sh_per;
-      const int koff = a.shs_rest ? 3 : 0;
       float w[16];
 #pragma unroll
       for (int k = 0; k < 16; k++) {
         w[k] = 0.f;
-        if (k < nb) {
-          if (3 * k >= koff) w[k] = mine[3 * k - koff] * gcs[0] + mine[3 * k + 1 - koff] * gcs[1] + mine[3 * k + 2 - koff] * gcs[2];
-          else w[k] = a.shs[3 * i] * gcs[0] + a.shs[3 * i + 1] * gcs[1] + a.shs[3 * i + 2] * gcs[2];
-        }
+        if (k < nb) w[k] = shv[3 * k] * gcs[0] + shv[3 * k + 1] * gcs[1] + shv[3 * k + 2] * gcs[2];
       }
       float gdir[3];
       sh_dir_grad(a.deg, ux, uy, uz, w, gdir);
