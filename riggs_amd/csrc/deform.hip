@@ -418,7 +418,9 @@ __global__ __launch_bounds__(256) void lbs_backward_kernel(LbsArgs a) {
 // per wave at the end.  (The pixel-major variant above spent ~30 DPP ops per (Gaussian, bone).)
 #define LB_BONES 8                      // bone lanes per Gaussian slot
 #define LB_MAXBLK ((MAX_J - 1 + LB_BONES - 1) / LB_BONES)
-#define LB_GPB 256                      // Gaussians per workgroup (8 steps of 8 per wave)
+#ifndef LB_GPB
+#define LB_GPB 1024                     // Gaussians per workgroup: every wave looks at LB_GPB / 4, 64 at a time
+#endif
 
 __device__ __forceinline__ float row8_sum(float v) {
   // sum over the 8 lanes sharing (lane >> 3): xor 1, 2, 4 via DPP quad_perm / row_half_mirror patterns
@@ -459,11 +461,13 @@ __global__ __launch_bounds__(256) void lbs_backward_bonelane_kernel(LbsArgs a) {
   // deep scene) contribute exact zeros to every sum: the wave looks at its 64 Gaussians once, writes the zeros of
   // the per-Gaussian outputs, and walks only the others, eight at a time.
   __shared__ unsigned char s_list[4][64];
+  for (int sub_first = wave_first; sub_first < wave_end; sub_first += 64) {
+  const int sub_end = min(wave_end, sub_first + 64);
   int n_work;
   {
-    const int n = wave_first + lane;
+    const int n = sub_first + lane;
     bool touched = false;
-    if (n < wave_end) {
+    if (n < sub_end) {
       const float4 h4 = reinterpret_cast<const float4*>(a.g_rot)[n];
       touched = (a.g_xyz[3 * n] != 0.f) || (a.g_xyz[3 * n + 1] != 0.f) || (a.g_xyz[3 * n + 2] != 0.f) ||
                 (h4.x != 0.f) || (h4.y != 0.f) || (h4.z != 0.f) || (h4.w != 0.f);
@@ -478,7 +482,7 @@ __global__ __launch_bounds__(256) void lbs_backward_bonelane_kernel(LbsArgs a) {
   }
   for (int w0 = 0; w0 < n_work; w0 += 8) {
     const bool valid = w0 + slot < n_work;
-    const int n = valid ? wave_first + (int)s_list[wave][w0 + slot] : 0;  // (a wave's own LDS writes are ordered)
+    const int n = valid ? sub_first + (int)s_list[wave][w0 + slot] : 0;  // (a wave's own LDS writes are ordered)
     float px = 0.f, py = 0.f, pz = 0.f, m = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
     float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
     if (valid) {
@@ -539,6 +543,7 @@ __global__ __launch_bounds__(256) void lbs_backward_bonelane_kernel(LbsArgs a) {
       acc[bb][12] += r;
     }
     if (bl == 0) { gt0 += gh0; gt1 += gh1; gt2 += gh2; }
+  }
   }
   // fold the 8 slot rows (lanes l, l^8, l^16, l^32) and push to the workgroup accumulators
 #pragma unroll
