@@ -40,3 +40,8 @@ print("histogram of tile_max (bins of 256):", np.bincount((ne // 256).astype(np.
 rowmax = ncp.reshape(gy * 16, gx, 16).max(axis=2)  # per (pixel row, tile column): the chain one forward wave walks
 rm = rowmax[rowmax > 0]
 print("per-wave chain (row of 16 pixels) percentiles: p50 %d p90 %d p99 %d max %d  n %d" % (*np.percentile(rm, [50, 90, 99, 100]), rm.size))
+tt = v["tiles_touched"].cpu().numpy().astype(np.int64)
+tt = tt[tt > 0]
+print("tiles per visible Gaussian: mean %.1f; <=4: %.2f  <=8: %.2f  <=12: %.2f  <=16: %.2f  <=32: %.2f  max %d" % (
+    tt.mean(), (tt <= 4).mean(), (tt <= 8).mean(), (tt <= 12).mean(), (tt <= 16).mean(), (tt <= 32).mean(), tt.max()))
+print("share of the instances in Gaussians with <=8 tiles: %.2f, <=16: %.2f" % (tt[tt <= 8].sum() / tt.sum(), tt[tt <= 16].sum() / tt.sum()))
