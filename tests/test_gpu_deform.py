@@ -104,6 +104,36 @@ def test_deform_matches_oracle_large(N, J, chain, seed):
     U.assert_close(sw._node_radius.grad.cpu().numpy(), rho.grad.numpy(), "dL/d_node_radius", 2e-4)
 
 
+@pytest.mark.parametrize("keep", [0.0, 0.05, 0.5])
+def test_deform_backward_with_sparse_incoming_gradient(keep):
+    """The LBS backward walks only the Gaussians whose incoming gradient is non-zero (most of a deep scene gets none
+    from the rasterizer): values, per-Gaussian outputs and parameter gradients against the CPU oracle for cotangents
+    that are zero for most (or all) Gaussians, in odd-sized blocks."""
+    N, J, seed = 70_001, 24, 21
+    sc = synth.make_scene(N, J, seed)
+    g = torch.Generator().manual_seed(seed)
+    m = (torch.rand(N, 1, generator=g) < keep).float()
+    gx, gr = torch.randn(N, 3, generator=g) * m, torch.randn(N, 4, generator=g) * m
+    q = sc["local_rotation"].clone().requires_grad_(True)
+    gt = sc["global_trans"].clone().requires_grad_(True)
+    rho = sc["node_radius"].clone().requires_grad_(True)
+    mk = sc["motion_mask"].clone().requires_grad_(True)
+    o = O.deform_by_pose(sc["xyz"], sc["joints"], sc["parents"], rho, q, gt, mk, -1)
+    ((o["d_xyz"] * gx).sum() + (o["d_rotation"] * gr).sum()).backward()
+    sw = make_warp(sc["joints"], sc["parents"], sc["node_radius"], -1)
+    qh = sc["local_rotation"].cuda().requires_grad_(True)
+    gth = sc["global_trans"].cuda().requires_grad_(True)
+    mkh = sc["motion_mask"].cuda().requires_grad_(True)
+    h = sw.deform_by_pose(sc["xyz"].cuda(), {"local_rotation": qh, "global_trans": gth}, mkh)
+    ((h["d_xyz"] * gx.cuda()).sum() + (h["d_rotation"] * gr.cuda()).sum()).backward()
+    U.assert_close(qh.grad.cpu().numpy(), q.grad.numpy(), "dL/dlocal_rotation", 2e-4)
+    U.assert_close(gth.grad.cpu().numpy(), gt.grad.numpy(), "dL/dglobal_trans", 2e-4)
+    U.assert_close(sw._node_radius.grad.cpu().numpy(), rho.grad.numpy(), "dL/d_node_radius", 2e-4)
+    U.assert_close(mkh.grad.cpu().numpy().reshape(-1), mk.grad.numpy().reshape(-1), "dL/dmotion_mask", 2e-4)
+    if keep == 0.0:
+        assert float(qh.grad.abs().max()) == 0.0 and float(mkh.grad.abs().max()) == 0.0
+
+
 def test_forward_through_pose_net_and_node_deformation():
     sc = synth.make_scene(2048, 24, 5)
     sw = make_warp(sc["joints"], sc["parents"], sc["node_radius"], -1)

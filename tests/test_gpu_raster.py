@@ -28,6 +28,7 @@ CASES = [
     (10000, 8, 1235, 256, 256, 0.012, dict()),                     # BASELINE config C1 size
     (5000, 24, 7, 200, 333, 0.02, dict(azimuth_deg=90.0)),         # ragged image (not multiples of 16)
     (3000, 24, 9, 160, 160, 0.25, dict(radius=1.2)),               # camera inside the cloud: near culls, big splats
+    (30000, 24, 11, 96, 96, 0.05, dict()),                         # deep occlusion: pixels saturate, most Gaussians get no gradient
 ]
 
 
@@ -56,6 +57,9 @@ def test_forward_backward_parity_vs_oracle(N, J, seed, H, W, scale, camkw):
     _grads_close(g_scales, go["scales"], "dL/dscales")
     _grads_close(g_rots, go["rotations"], "dL/drotations")
     _grads_close(g_sh, go["shs"], "dL/dsh")
+    if N >= 30000:  # the case is there for the sparse-gradient paths: make sure it exercises them
+        untouched = float((g_opac.reshape(-1) == 0).float().mean())
+        assert 0.5 < untouched < 1.0, untouched
 
 
 @pytest.mark.parametrize("deg", [0, 1, 2])
