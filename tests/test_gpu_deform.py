@@ -189,6 +189,48 @@ def test_mlp_heads_match_reference_golden():
             U.assert_close(sd[k[2:4]][k[5:]].grad.cpu().numpy(), G[k], k, 2e-3)
 
 
+def test_mlp_heads_with_sparse_incoming_gradient_match_oracle():
+    """Heads on (weight_mod through the HIP skinning kernels) and a cotangent that is zero for most Gaussians: the
+    kernels skip those Gaussians and must still deliver exact zeros in dL/dweight_mod for them — every gradient,
+    incl. the WeightMLP parameters', against the CPU oracle (which is pinned to the reference by the fixture)."""
+    import os
+    from tests.test_oracle_heads import seeded_heads
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "heads_tree12_n200.npz"))
+    T = torch.from_numpy
+    J = G["joints"].shape[0]
+    g = torch.Generator().manual_seed(5)
+    N = 5_003
+    x = torch.randn(N, 3, generator=g) * 0.4
+    keepm = (torch.rand(N, 1, generator=g) < 0.1).float()
+    cx, cr = torch.randn(N, 3, generator=g) * keepm, torch.randn(N, 4, generator=g) * keepm
+    mask = torch.rand(N, 1, generator=g)
+    # oracle
+    wm, dn = seeded_heads(J, int(G["head_seed"]))
+    q = T(G["local_rot"]).clone().requires_grad_(True)
+    gt = T(G["global_trans"]).clone().requires_grad_(True)
+    rho = T(G["node_radius"]).clone().requires_grad_(True)
+    pose = q.detach().reshape(-1)[None].expand(N, -1)
+    o = O.deform_by_pose(x, T(G["joints"]), T(G["parents"]), rho, q, gt, mask, -1,
+                         template_offsets=dn(x, pose), weight_offsets=wm(x))
+    ((o["d_xyz"] * cx).sum() + (o["d_rotation"] * cr).sum()).backward()
+    # HIP
+    sw = SkeletonWarp(joints=T(G["joints"]), parent_indices=T(G["parents"]), K=-1, hyper_dim=8)
+    sw.skinning_weight_mlp, sw.detail_net = seeded_heads(J, int(G["head_seed"]))
+    sw = sw.cuda()
+    sw._node_radius.data = T(G["node_radius"]).cuda()
+    qh = T(G["local_rot"]).cuda().requires_grad_(True)
+    gth = T(G["global_trans"]).cuda().requires_grad_(True)
+    h = sw.deform_by_pose(x.cuda(), {"local_rotation": qh, "global_trans": gth}, mask.cuda())
+    U.assert_close(h["d_xyz"].detach().cpu().numpy(), o["d_xyz"].detach().numpy(), "d_xyz with heads", 1e-4)
+    ((h["d_xyz"] * cx.cuda()).sum() + (h["d_rotation"] * cr.cuda()).sum()).backward()
+    U.assert_close(qh.grad.cpu().numpy(), q.grad.numpy(), "dL/dlocal_rotation", 3e-4)
+    U.assert_close(gth.grad.cpu().numpy(), gt.grad.numpy(), "dL/dglobal_trans", 3e-4)
+    U.assert_close(sw._node_radius.grad.cpu().numpy(), rho.grad.numpy(), "dL/d_node_radius", 3e-4)
+    ref = dict(wm.named_parameters())
+    for name, p in sw.skinning_weight_mlp.named_parameters():
+        U.assert_close(p.grad.cpu().numpy(), ref[name].grad.numpy(), "WeightMLP " + name, 2e-3)
+
+
 @pytest.mark.parametrize("width,J", [(256, 24), (32, 24), (64, 8)])
 def test_fused_pose_mlp_matches_torch_and_reference_fixture(width, J):
     """riggs_pose_mlp_* (3 HIP launches) vs the torch-op PoseMLP (CPU) — outputs and every parameter gradient;
