@@ -478,7 +478,7 @@ __device__ __forceinline__ float oct_sum(float v) {
   v += ODPP_F(0.f, v, DPP_HALF_MIRROR, 0xf);
   return v;
 }
-template <int B>
+template <int B, bool TRACE>
 __global__ __launch_bounds__(256) void render_fwd_oct_kernel(RenderArgs a) {
   static_assert(B == 256 || B == 512, "one held checkpoint per lane of a pixel's eight");
   constexpr int K = B / 256;  // instances per thread and round
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256) void render_fwd_oct_kernel(RenderArgs a) {
   bool done = !inside;
   float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f, Tstop = -1.0f;
   uint32_t last = 0;
-  const unsigned long long t_begin = a.trace ? wall_clock64() : 0ull;
+  const unsigned long long t_begin = (TRACE && a.trace) ? wall_clock64() : 0ull;
   uint32_t st_rounds = 0, st_surv = 0, st_iters = 0, st_full = 0;
   // prefetch registers for the next round (one instance per thread) and the list entry of the round after it
   float4 n_xy[K], n_co[K], n_cc[K];
@@ -581,9 +581,9 @@ __global__ __launch_bounds__(256) void render_fwd_oct_kernel(RenderArgs a) {
         s_xyd[chunk * 64 + lane] = z; s_con[chunk * 64 + lane] = z; s_rgb[chunk * 64 + lane] = z; s_pos[chunk * 64 + lane] = 0;
       }
       if (lane == 0) s_cnt[chunk] = cnt;
-      st_surv += (uint32_t)cnt;
+      if constexpr (TRACE) st_surv += (uint32_t)cnt;
     }
-    st_rounds++;
+    if constexpr (TRACE) st_rounds++;
     flush_ckpt();
     hbase = base;
     __syncthreads();
@@ -607,16 +607,17 @@ __global__ __launch_bounds__(256) void render_fwd_oct_kernel(RenderArgs a) {
       }
       const int nk = s_cnt[k];
       for (int g = 64 * k; g < 64 * k + nk; g += 8) {
-        if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+        // (no 'all pixels finished' test here: it costs eight instructions per step of every wave to save a few steps
+        // once per wave; the chunk loop above has it)
         const float4 xy = s_xyd[g + i];
         const float dx = xy.x - pfx, dy = xy.y - pfy;
         const float4 co = s_con[g + i];
         const float pw = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
         const float alpha = fminf(ALPHA_MAX, co.w * fast_exp(pw));
         const bool valid = (pw <= 0.0f) && (alpha >= ALPHA_MIN) && !done;
-        st_iters++;
+        if constexpr (TRACE) st_iters++;
         if (__builtin_amdgcn_ballot_w64(valid) == 0) continue;
-        st_full++;
+        if constexpr (TRACE) st_full++;
         const float4 c = s_rgb[g + i];
         const int pos1 = base + (int)s_pos[g + i] + 1;
         // one step: eight consecutive instances (one per lane) of this lane's pixel
@@ -650,7 +651,7 @@ __global__ __launch_bounds__(256) void render_fwd_oct_kernel(RenderArgs a) {
       }
     }
   }
-  if (a.trace && lane == 0) {
+  if (TRACE && a.trace && lane == 0) {
     unsigned long long* tr = a.trace + ((size_t)(tile * 8 + sub) * 4 + wave) * 6;
     tr[0] = wall_clock64() - t_begin; tr[1] = st_rounds;
     tr[2] = (unsigned long long)st_surv | ((unsigned long long)(__builtin_amdgcn_s_getreg(63492) & 0xFFFFu) << 32) | ((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 0xFu) << 48);
@@ -786,8 +787,9 @@ int launch_render_fwd(const RenderArgs& a, hipStream_t s) {
     // one workgroup per 8 x 4 block of every tile; with the work list the ones past the non-empty tiles only help
     // with the background of the empty tiles and leave
     static const int ob = getenv("RIGGS_FWD_OCT_BATCH") ? atoi(getenv("RIGGS_FWD_OCT_BATCH")) : 256;  // (512-instance rounds lose)
-    if (ob == 512) hipLaunchKernelGGL(render_fwd_oct_kernel<512>, dim3(gx * gy * 8), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(render_fwd_oct_kernel<256>, dim3(gx * gy * 8), dim3(256), 0, s, a);
+    if (ob == 512) hipLaunchKernelGGL((render_fwd_oct_kernel<512, true>), dim3(gx * gy * 8), dim3(256), 0, s, a);
+    else if (a.trace) hipLaunchKernelGGL((render_fwd_oct_kernel<256, true>), dim3(gx * gy * 8), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((render_fwd_oct_kernel<256, false>), dim3(gx * gy * 8), dim3(256), 0, s, a);
   }
   return 0;
 }
