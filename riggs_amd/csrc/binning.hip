@@ -5,10 +5,12 @@
 // by tile id.  With T <= a few thousand tiles that is a counting sort:
 //   bin_count   : per chunk of depth-ordered Gaussians, a tile histogram in LDS        -> table[chunk][tile]
 //   bin_scan    : per tile, exclusive scan over the chunks (table rewritten in place)   -> tile_count[tile]
-//   bin_offsets : exclusive scan over the tiles -> ranges[tile], slot_base[tile], R, overflow flag
+//   bin_offsets : exclusive scan over the tiles -> ranges[tile], slot_base[tile], R, overflow flag, and the forward's
+//                 work list (non-empty tiles, longest lists first)
 //   bin_scatter : per chunk: LDS cursors = tile start + chunk offset + offset of the preceding waves,
-//                 then every wave walks ITS Gaussians in depth order (one Gaussian per step, lanes = the
-//                 tiles of its rectangle) and writes point_list[cursor++] — order-preserving by construction.
+//                 then every wave walks ITS Gaussians in depth order (four per step, lanes = (slot, tile of the
+//                 slot's rectangle), ranks from rectangle tests) and writes point_list — order-preserving by
+//                 construction.
 // HBM traffic: N*(4+8+4) read per pass, R*4(+4) written once, 2*chunks*T*4 for the table — against
 // ~R*32 B for two radix passes over (key, value) pairs plus the emit pass.
 #include "raster_internal.h"

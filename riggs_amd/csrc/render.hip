@@ -215,7 +215,8 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(RenderArgs a) {
 }
 
 // ---- quad-lane forward ------------------------------------------------------------------------------
-// Default forward.  The per-pixel chain of a deep tile is what bounds this kernel (thousands of
+// Quad-lane forward (RIGGS_RENDER_FWD=4; the default is the eight-lane kernel below, which grew out of this one).
+// The per-pixel chain of a deep tile is what bounds this kernel (thousands of
 // contributing instances walked by ONE wave), so the wave is laid out as 16 pixels x 4 instance lanes:
 // the four lanes of a DPP quad evaluate four CONSECUTIVE instances of the same pixel at once, their
 // transmittances come from a 3-step exclusive product scan inside the quad, the T < 1e-4 stop is
@@ -1012,8 +1013,8 @@ __global__ __launch_bounds__(1024) void render_bwd_worklist_kernel(RenderBwdArgs
   if (tid == 0) { a.work_ctr[0] = s_carry * 4u; a.work_ctr[1] = 0u; }  // four pixel-quarters per chunk
 }
 
-// Persistent, dynamically scheduled: every wave pulls (chunk, pixel-quarter) items from one counter until
-// the list is empty, so deep tiles (dozens of fully active chunks) spread evenly over the chip.
+// Persistent workgroups over the device-built list of (tile, 64-instance chunk) items, dealt round-robin: deep tiles
+// (dozens of fully active chunks) spread over the chip.
 template <int NW>  // waves per workgroup = parts the tile's 256 pixels are split into
 __global__ __launch_bounds__(64 * NW) void render_bwd_kernel(RenderBwdArgs a) {
   constexpr int PPW = 256 / NW;    // pixels per wave
