@@ -29,6 +29,7 @@ CASES = [
     (5000, 24, 7, 200, 333, 0.02, dict(azimuth_deg=90.0)),         # ragged image (not multiples of 16)
     (3000, 24, 9, 160, 160, 0.25, dict(radius=1.2)),               # camera inside the cloud: near culls, big splats
     (30000, 24, 11, 96, 96, 0.05, dict()),                         # deep occlusion: pixels saturate, most Gaussians get no gradient
+    (4000, 8, 13, 1168, 2064, 0.02, dict()),                       # 9 417 tiles (> 8 192: the per-thread tile arrays of bin_offsets overflow to their fallback)
 ]
 
 
