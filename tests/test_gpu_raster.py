@@ -27,7 +27,8 @@ CASES = [
     (2000, 8, 1235, 128, 128, 0.03, dict()),                       # small chain-like scene
     (10000, 8, 1235, 256, 256, 0.012, dict()),                     # BASELINE config C1 size
     (5000, 24, 7, 200, 333, 0.02, dict(azimuth_deg=90.0)),         # ragged image (not multiples of 16)
-    (3000, 24, 9, 160, 160, 0.25, dict(radius=1.2)),               # camera inside the cloud: near culls, big splats
+    (3001, 24, 9, 160, 160, 0.25, dict(radius=1.2)),               # camera inside the cloud: near culls, big splats; odd N
+    (3000, 8, 17, 160, 160, 0.1, dict()),                          # rectangles of <= 16 and > 16 tiles side by side
     (30000, 24, 11, 96, 96, 0.05, dict()),                         # deep occlusion: pixels saturate, most Gaussians get no gradient
     (4000, 8, 13, 1168, 2064, 0.02, dict()),                       # 9 417 tiles (> 8 192: the per-thread tile arrays of bin_offsets overflow to their fallback)
 ]
@@ -58,6 +59,9 @@ def test_forward_backward_parity_vs_oracle(N, J, seed, H, W, scale, camkw):
     _grads_close(g_scales, go["scales"], "dL/dscales")
     _grads_close(g_rots, go["rotations"], "dL/drotations")
     _grads_close(g_sh, go["shs"], "dL/dsh")
+    if scale == 0.1:  # the case is there for the binning walk: lane groups that mix rectangles of <= 16 and > 16 tiles
+        tt = v["tiles_touched"].cpu().numpy()
+        assert (tt > 16).sum() > 100 and ((tt > 0) & (tt <= 16)).sum() > 100
     if N >= 30000:  # the case is there for the sparse-gradient paths: make sure it exercises them
         untouched = float((g_opac.reshape(-1) == 0).float().mean())
         assert 0.5 < untouched < 1.0, untouched
