@@ -276,6 +276,22 @@ int riggs_dist2_knn3(int32_t num_points, const float* points, float* out, void* 
  * followed (at word n_tiles * 192) by 4 u64 per chunk of the compositing backward ({start, end, hardware id,
  * workgroup << 32 | tile << 16 | chunk}); tools/fwd_trace.py, fwd_placement.py, bwd_trace.py.  NULL disables */
 int riggs_raster_set_trace(void* dev_u64);
+/* =====================================================================
+ * Per-Gaussian MLP heads on the matrix cores: WeightMLP / DeformMLP of
+ * skeleton_utils/network_utils.py:6-112 as one fused launch per direction — bf16 operands, fp32 accumulation
+ * (v_mfma_f32_32x32x16_bf16).  x_emb (N, in_ch <= 128) fp32 -> depth x [Linear(256) + ReLU], the embedding
+ * re-concatenated IN FRONT of the hidden vector after layer `skip` (network_utils.py:58-61, 103-106) -> Linear(out_ch <= 32).
+ * weights_bf16[l]: (256, K_l) row-major bf16 with K_0 = in_pad, K_{skip+1} = in_pad + 256, else 256, where
+ * in_pad = in_ch rounded up to 32 and the padding columns are zero; w_out_bf16: (32, 256), rows >= out_ch zero.
+ * acts_bf16 (depth, N, 256) receives the post-ReLU activations for the backward (NULL for inference).
+ * Opt-in on the host side (riggs_amd.mlp): the reference computes these MLPs in fp32.
+ * ===================================================================== */
+int riggs_mlp_forward(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip,
+                      const void* const* weights_bf16, const float* const* biases, const void* w_out_bf16,
+                      const float* b_out, const float* x_emb, void* acts_bf16, float* out, riggs_stream stream);
+/* self-test of the MFMA fragment layouts mlp.hip assumes: writes D = A B for A = [I_16; 0] and an asymmetric B */
+int riggs_mlp_layout_probe(float* out32x32, riggs_stream stream);
+
 int riggs_prof_count(void);
 const char* riggs_prof_name(int32_t id);
 int riggs_prof_enable(uint32_t mask);

@@ -23,6 +23,7 @@ SOURCES = {
     "pose_mlp.hip": ["-ffp-contract=fast"],
     "optim.hip": ["-ffp-contract=off"],
     "loss.hip": ["-ffp-contract=fast"],
+    "mlp.hip": ["-ffp-contract=fast"],
     "capi.hip": [],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fhip-fp32-correctly-rounded-divide-sqrt",

@@ -1,0 +1,204 @@
+// Per-Gaussian MLP heads (second half): WeightMLP / DeformMLP
+// (skeleton_utils/network_utils.py:6-112) as ONE fused launch per direction on the CDNA4 matrix cores.
+//
+//   x_emb (N, in_ch) fp32 -> D x [Linear(256) + ReLU], the embedding re-concatenated in front of the hidden vector
+//   after layer `skip` -> Linear(out_ch)
+//
+// bf16 operands, fp32 accumulation (v_mfma_f32_32x32x16_bf16): the reference computes in fp32, so this path is
+// opt-in and its parity bar is the bf16 one ("parity tolerance must be renegotiated for bf16").
+//
+// Forward: a workgroup owns 64 rows (Gaussians).  The hidden vector of those rows lives in LDS as bf16
+// [64][256 (+pad)], the embedding as bf16 [64][in_pad (+pad)]; a layer is  H <- relu(H W^T + b)  with the weights
+// streamed from L2 (128 KB per layer, shared by all workgroups).  Wave w computes output columns [64 w, 64 w + 64)
+// of all 64 rows: 2 x 2 tiles of 32 x 32, K in steps of 16; A fragments (8 consecutive k of one row) are 16-byte LDS
+// reads, B fragments (8 consecutive k of one output column = 16 contiguous bytes of a weight row) are 16-byte global
+// loads.  The post-ReLU activations go back to LDS (in place, behind a barrier) and — for the backward — to HBM as
+// bf16 with full-line stores.
+//
+// Backward (data gradient): the same tiling with the transposed weights,  dH_{l-1} = (dH_l * relu'(H_l)) W_l ;
+// every layer's masked gradient is stored as bf16 for the weight gradients, which are plain (256 x N)·(N x K) GEMMs
+// left to the library (hipBLASLt through torch, bf16 in / fp32 out).  The inputs of both heads are detached in the
+// reference (positions and pose), so no gradient flows past the first layer.
+#include "common.h"
+
+namespace riggs {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MLP_W 256          // hidden width (the reference's W)
+#define MLP_ROWS 64        // rows per workgroup
+#define MLP_HS (MLP_W + 8) // LDS row stride of the hidden vector in bf16 (16-byte pad: conflict-free 16-byte column reads)
+#define MLP_MAX_IN 128     // padded embedding width supported
+#define MLP_XS (MLP_MAX_IN + 8)
+
+__device__ __forceinline__ unsigned short f2bf(float f) {  // round to nearest even
+  uint32_t u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((uint32_t)h << 16); }
+
+struct MlpDesc {
+  int N, in_ch, in_pad, out_ch, depth, skip;
+  const unsigned short* Wp[10];   // packed bf16 weights, layer l: [256][K_l], K_0 = in_pad, K_{skip+1} = in_pad + 256, else 256
+  const float* bias[10];          // [256]
+  const unsigned short* Wout;     // [32][256] (rows >= out_ch are zero)
+  const float* bout;              // [out_ch]
+};
+
+__device__ __forceinline__ int mlp_k(const MlpDesc& d, int l) { return l == 0 ? d.in_pad : (l == d.skip + 1 ? d.in_pad + MLP_W : MLP_W); }
+
+// acc[rt][ct] += A(rows 32 rt .. +31, k) * B(k, cols col0 + 32 ct .. +31) over k in [0, K): A from LDS (row stride
+// `as` bf16), B[k][n] = Wrow[n][k] with row stride `ws` bf16 in global memory
+template <int RT, int CT>
+__device__ __forceinline__ void mlp_gemm_part(f32x16 (&acc)[RT][CT], const unsigned short* A, int as, const unsigned short* Wg,
+                                              int ws, int K, int lane) {
+  const int r = lane & 31, kq = (lane >> 5) * 8;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    bf16x8 a[RT], b[CT];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) a[rt] = *reinterpret_cast<const bf16x8*>(A + (size_t)(32 * rt + r) * as + k0 + kq);
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) b[ct] = *reinterpret_cast<const bf16x8*>(Wg + (size_t)(32 * ct + r) * ws + k0 + kq);
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+      for (int ct = 0; ct < CT; ct++) acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rt], b[ct], acc[rt][ct], 0, 0, 0);
+  }
+}
+
+// C/D layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+__device__ __forceinline__ int mlp_c_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+__global__ __launch_bounds__(256) void mlp_forward_kernel(MlpDesc d, const float* __restrict__ x_emb,
+                                                          unsigned short* __restrict__ acts /* [depth][N][256] or NULL */,
+                                                          float* __restrict__ out /* [N][out_ch] */) {
+  __shared__ unsigned short s_h[MLP_ROWS * MLP_HS];
+  __shared__ unsigned short s_x[MLP_ROWS * MLP_XS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = blockIdx.x * MLP_ROWS;
+  // embedding -> bf16 LDS (zero padded to in_pad, rows past N are zero)
+  for (int e = tid; e < MLP_ROWS * d.in_pad; e += 256) {
+    const int r = e / d.in_pad, c = e - r * d.in_pad;
+    float v = 0.f;
+    if (row0 + r < d.N && c < d.in_ch) v = x_emb[(size_t)(row0 + r) * d.in_ch + c];
+    s_x[r * MLP_XS + c] = f2bf(v);
+  }
+  __syncthreads();
+  const int col0 = wave * 64;
+  for (int l = 0; l < d.depth; l++) {
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+      for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[rt][ct][e] = 0.f;
+    const int K = mlp_k(d, l);
+    const unsigned short* Wl = d.Wp[l] + (size_t)col0 * K;
+    if (l == 0) mlp_gemm_part<2, 2>(acc, s_x, MLP_XS, Wl, K, d.in_pad, lane);
+    else if (l == d.skip + 1) {
+      mlp_gemm_part<2, 2>(acc, s_x, MLP_XS, Wl, K, d.in_pad, lane);
+      mlp_gemm_part<2, 2>(acc, s_h, MLP_HS, Wl + d.in_pad, K, MLP_W, lane);
+    } else mlp_gemm_part<2, 2>(acc, s_h, MLP_HS, Wl, K, MLP_W, lane);
+    __syncthreads();  // every wave is done reading the previous hidden vector
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++) {
+      const int col = col0 + 32 * ct + (lane & 31);
+      const float b = d.bias[l][col];
+#pragma unroll
+      for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          const int row = 32 * rt + mlp_c_row(e, lane);
+          s_h[row * MLP_HS + col] = f2bf(fmaxf(acc[rt][ct][e] + b, 0.f));
+        }
+    }
+    __syncthreads();
+    if (acts) {  // full-line stores of the layer's activations (backward: ReLU mask and weight-gradient operand)
+      unsigned short* dst = acts + ((size_t)l * d.N + row0) * MLP_W;
+      for (int e = tid; e < MLP_ROWS * (MLP_W / 8); e += 256) {
+        const int r = e / (MLP_W / 8), c8 = e - r * (MLP_W / 8);
+        if (row0 + r < d.N)
+          *reinterpret_cast<bf16x8*>(dst + (size_t)r * MLP_W + 8 * c8) = *reinterpret_cast<const bf16x8*>(s_h + r * MLP_HS + 8 * c8);
+      }
+    }
+  }
+  // output head: 64 rows x 32 (padded) columns, K = 256: waves 0 and 1 take a 32-row tile each
+  if (wave < 2) {
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[0][0][e] = 0.f;
+    mlp_gemm_part<1, 1>(acc, s_h + (size_t)(32 * wave) * MLP_HS, MLP_HS, d.Wout, MLP_W, MLP_W, lane);
+    const int col = lane & 31;
+    if (col < d.out_ch) {
+      const float b = d.bout[col];
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int row = row0 + 32 * wave + mlp_c_row(e, lane);
+        if (row < d.N) out[(size_t)row * d.out_ch + col] = acc[0][0][e] + b;
+      }
+    }
+  }
+}
+
+// Self-test of the fragment layouts this file assumes (A = identity against an ASYMMETRIC B): D must equal B.
+__global__ __launch_bounds__(64) void mlp_layout_probe_kernel(float* __restrict__ out /* [32][32] */) {
+  __shared__ unsigned short s_a[32 * 24], s_b[32 * 24];  // A[i][k] (i < 32, k < 16), Bt[n][k] = B[k][n]
+  const int lane = threadIdx.x;
+  for (int e = lane; e < 32 * 16; e += 64) {
+    const int i = e / 16, k = e % 16;
+    s_a[i * 24 + k] = f2bf(i == k ? 1.f : 0.f);               // A = [I_16; 0]
+    s_b[i * 24 + k] = f2bf(k < 8 ? (float)(32 * k + i) : -(float)(32 * (k - 8) + i + 1));  // B[k][n], n = i: distinct, exact in bf16
+  }
+  __syncthreads();
+  f32x16 acc[1][1];
+  for (int e = 0; e < 16; e++) acc[0][0][e] = 0.f;
+  const int r = lane & 31, kq = (lane >> 5) * 8;
+  const bf16x8 a = *reinterpret_cast<const bf16x8*>(s_a + r * 24 + kq);
+  const bf16x8 b = *reinterpret_cast<const bf16x8*>(s_b + r * 24 + kq);
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[0][0], 0, 0, 0);
+  for (int e = 0; e < 16; e++) out[mlp_c_row(e, lane) * 32 + (lane & 31)] = acc[0][0][e];
+}
+
+}  // namespace riggs
+
+using namespace riggs;
+
+extern "C" {
+
+int riggs_mlp_layout_probe(float* out32x32, riggs_stream stream) {
+  hipLaunchKernelGGL(mlp_layout_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out32x32);
+  RIGGS_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+static int mlp_fill(MlpDesc& d, int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip, const void* const* Wp,
+                    const float* const* bias, const void* Wout, const float* bout) {
+  RIGGS_REQUIRE(N >= 0 && depth >= 1 && depth <= 10, "MLP depth out of range");
+  RIGGS_REQUIRE(in_ch >= 1 && in_ch <= MLP_MAX_IN, "MLP input width must be <= 128");
+  RIGGS_REQUIRE(out_ch >= 1 && out_ch <= 32, "MLP output width must be <= 32");
+  RIGGS_REQUIRE(skip >= 0 && skip < depth - 1, "MLP skip layer out of range");
+  d.N = N; d.in_ch = in_ch; d.in_pad = (in_ch + 31) & ~31; d.out_ch = out_ch; d.depth = depth; d.skip = skip;
+  for (int l = 0; l < depth; l++) { d.Wp[l] = (const unsigned short*)Wp[l]; d.bias[l] = bias[l]; RIGGS_REQUIRE(Wp[l] && bias[l], "MLP layer pointers"); }
+  d.Wout = (const unsigned short*)Wout; d.bout = bout;
+  RIGGS_REQUIRE(Wout && bout, "MLP head pointers");
+  return 0;
+}
+
+int riggs_mlp_forward(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip, const void* const* weights_bf16,
+                      const float* const* biases, const void* w_out_bf16, const float* b_out, const float* x_emb,
+                      void* acts_bf16, float* out, riggs_stream stream) {
+  MlpDesc d;
+  int rc = mlp_fill(d, N, in_ch, out_ch, depth, skip, weights_bf16, biases, w_out_bf16, b_out);
+  if (rc) return rc;
+  if (N == 0) return 0;
+  RIGGS_REQUIRE(x_emb && out, "MLP input / output pointers");
+  hipLaunchKernelGGL(mlp_forward_kernel, dim3((N + MLP_ROWS - 1) / MLP_ROWS), dim3(256), 0, (hipStream_t)stream, d, x_emb,
+                     (unsigned short*)acts_bf16, out);
+  RIGGS_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"
