@@ -289,6 +289,13 @@ int riggs_raster_set_trace(void* dev_u64);
 int riggs_mlp_forward(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip,
                       const void* const* weights_bf16, const float* const* biases, const void* w_out_bf16,
                       const float* b_out, const float* x_emb, void* acts_bf16, float* out, riggs_stream stream);
+/* Data-gradient pass of the same MLP: g_out (N, out_ch) = dL/d(output) -> dpre_bf16 (depth, N, 256) = dL/d(pre-activation)
+ * of every hidden layer, the operand of the weight gradients  dW_l = dpre_l^T · input_l ,  db_l = sum_n dpre_l  (plain
+ * GEMMs / reductions, left to the library).  weights_t_bf16[l] (l >= 1): (256, 256) = W_l[:, hidden part]^T;
+ * w_out_t_bf16: (256, 32) = W_out^T with zero columns >= out_ch.  No gradient w.r.t. x_emb (detached in the reference). */
+int riggs_mlp_backward(int32_t N, int32_t out_ch, int32_t depth, int32_t skip, const void* const* weights_t_bf16,
+                       const void* w_out_t_bf16, const float* g_out, const void* acts_bf16, void* dpre_bf16,
+                       riggs_stream stream);
 /* self-test of the MFMA fragment layouts mlp.hip assumes: writes D = A B for A = [I_16; 0] and an asymmetric B */
 int riggs_mlp_layout_probe(float* out32x32, riggs_stream stream);
 

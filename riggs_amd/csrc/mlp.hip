@@ -143,6 +143,74 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpDesc d, const float
   }
 }
 
+// Data-gradient pass.  d_post of the last hidden layer comes from the head (g_out W_out, K = 32 padded); then for
+// l = depth-1 .. 0:  d_pre_l = d_post_l * [act_l > 0]  (cooperative 16-byte pass: LDS gradient x global activation ->
+// LDS, and -> HBM as bf16 for the weight gradients), and for l >= 1  d_post_{l-1} = d_pre_l W_l[:, hidden part]
+// with the transposed bf16 copy of the weights as the B operand (row = input feature k, 8 consecutive output neurons
+// n contiguous).  No gradient leaves the first layer: both heads' inputs are detached in the reference.
+struct MlpBwdDesc {
+  int N, out_ch, depth, skip;
+  const unsigned short* Wt[10];   // l >= 1: [256 (k)][256 (n)] bf16 = W_l[:, hidden part]^T
+  const unsigned short* Wout_t;   // [256 (k)][32 (c)] bf16, columns >= out_ch zero
+};
+
+__global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdDesc d, const float* __restrict__ g_out,
+                                                           const unsigned short* __restrict__ acts,
+                                                           unsigned short* __restrict__ dpre /* [depth][N][256] */) {
+  __shared__ unsigned short s_d[MLP_ROWS * MLP_HS];
+  __shared__ unsigned short s_g[MLP_ROWS * 40];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = blockIdx.x * MLP_ROWS;
+  for (int e = tid; e < MLP_ROWS * 32; e += 256) {
+    const int r = e >> 5, c = e & 31;
+    float v = 0.f;
+    if (row0 + r < d.N && c < d.out_ch) v = g_out[(size_t)(row0 + r) * d.out_ch + c];
+    s_g[r * 40 + c] = f2bf(v);
+  }
+  __syncthreads();
+  const int col0 = wave * 64;
+  for (int l = d.depth - 1; l >= 0; l--) {
+    // ---- d_post_l for this wave's 64 columns
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+      for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[rt][ct][e] = 0.f;
+    if (l == d.depth - 1) mlp_gemm_part<2, 2>(acc, s_g, 40, d.Wout_t + (size_t)col0 * 32, 32, 32, lane);
+    else mlp_gemm_part<2, 2>(acc, s_d, MLP_HS, d.Wt[l + 1] + (size_t)col0 * MLP_W, MLP_W, MLP_W, lane);
+    __syncthreads();  // every wave is done reading d_pre_{l+1}
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++) {
+      const int col = col0 + 32 * ct + (lane & 31);
+#pragma unroll
+      for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) s_d[(32 * rt + mlp_c_row(e, lane)) * MLP_HS + col] = f2bf(acc[rt][ct][e]);
+    }
+    __syncthreads();
+    // ---- ReLU mask, in place, and out to HBM
+    const unsigned short* al = acts + ((size_t)l * d.N + row0) * MLP_W;
+    unsigned short* dl = dpre + ((size_t)l * d.N + row0) * MLP_W;
+    for (int e = tid; e < MLP_ROWS * (MLP_W / 8); e += 256) {
+      const int r = e / (MLP_W / 8), c8 = e - r * (MLP_W / 8);
+      bf16x8 g = *reinterpret_cast<const bf16x8*>(s_d + r * MLP_HS + 8 * c8);
+      if (row0 + r < d.N) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(al + (size_t)r * MLP_W + 8 * c8);
+#pragma unroll
+        for (int q = 0; q < 8; q++) g[q] = ((unsigned short)a[q] & 0x7FFFu) != 0 && ((unsigned short)a[q] & 0x8000u) == 0 ? g[q] : (short)0;
+        *reinterpret_cast<bf16x8*>(dl + (size_t)r * MLP_W + 8 * c8) = g;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; q++) g[q] = 0;
+      }
+      *reinterpret_cast<bf16x8*>(s_d + r * MLP_HS + 8 * c8) = g;
+    }
+    __syncthreads();
+  }
+}
+
 // Self-test of the fragment layouts this file assumes (A = identity against an ASYMMETRIC B): D must equal B.
 __global__ __launch_bounds__(64) void mlp_layout_probe_kernel(float* __restrict__ out /* [32][32] */) {
   __shared__ unsigned short s_a[32 * 24], s_b[32 * 24];  // A[i][k] (i < 32, k < 16), Bt[n][k] = B[k][n]
@@ -197,6 +265,23 @@ int riggs_mlp_forward(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, i
   RIGGS_REQUIRE(x_emb && out, "MLP input / output pointers");
   hipLaunchKernelGGL(mlp_forward_kernel, dim3((N + MLP_ROWS - 1) / MLP_ROWS), dim3(256), 0, (hipStream_t)stream, d, x_emb,
                      (unsigned short*)acts_bf16, out);
+  RIGGS_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int riggs_mlp_backward(int32_t N, int32_t out_ch, int32_t depth, int32_t skip, const void* const* weights_t_bf16,
+                       const void* w_out_t_bf16, const float* g_out, const void* acts_bf16, void* dpre_bf16,
+                       riggs_stream stream) {
+  RIGGS_REQUIRE(N >= 0 && depth >= 1 && depth <= 10, "MLP depth out of range");
+  RIGGS_REQUIRE(out_ch >= 1 && out_ch <= 32, "MLP output width must be <= 32");
+  if (N == 0) return 0;
+  MlpBwdDesc d;
+  d.N = N; d.out_ch = out_ch; d.depth = depth; d.skip = skip;
+  for (int l = 0; l < depth; l++) { d.Wt[l] = (const unsigned short*)weights_t_bf16[l]; RIGGS_REQUIRE(l == 0 || d.Wt[l], "MLP transposed weights"); }
+  d.Wout_t = (const unsigned short*)w_out_t_bf16;
+  RIGGS_REQUIRE(d.Wout_t && g_out && acts_bf16 && dpre_bf16, "MLP backward pointers");
+  hipLaunchKernelGGL(mlp_backward_kernel, dim3((N + MLP_ROWS - 1) / MLP_ROWS), dim3(256), 0, (hipStream_t)stream, d, g_out,
+                     (const unsigned short*)acts_bf16, (unsigned short*)dpre_bf16);
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -69,3 +69,87 @@ def forward(p: Packed, x_emb: torch.Tensor, want_acts: bool):
                                       p.b_out.data_ptr(), x_emb.data_ptr(), L.ptr(acts), out.data_ptr(), L.stream_ptr()),
             "riggs_mlp_forward")
     return out, acts
+
+
+def backward_data(p: Packed, g_out: torch.Tensor, acts: torch.Tensor) -> torch.Tensor:
+    """dL/d(pre-activation) of every hidden layer as bf16 (depth, N, 256)."""
+    N = g_out.shape[0]
+    g_out = L.require_cuda_f32("g_out", g_out, (N, p.out_ch))
+    dpre = torch.empty(p.depth, N, 256, dtype=torch.bfloat16, device=g_out.device)
+    if not hasattr(p, "_wtp"):
+        p.w_out_t_bf16 = torch.nn.functional.pad(p.w_out_t, (0, 32 - p.out_ch)).to(torch.bfloat16).contiguous()  # (256, 32)
+        p._wtp = (C.c_void_p * p.depth)(*[(t.data_ptr() if t is not None else None) for t in p.wt])
+    L.check(L.lib().riggs_mlp_backward(N, p.out_ch, p.depth, p.skip, p._wtp, p.w_out_t_bf16.data_ptr(), g_out.data_ptr(),
+                                       acts.data_ptr(), dpre.data_ptr(), L.stream_ptr()), "riggs_mlp_backward")
+    return dpre
+
+
+def _wgrad(d: torch.Tensor, a: torch.Tensor, splits: int = 128) -> torch.Tensor:
+    """d^T · a for d (N, M), a (N, K) in bf16 with fp32 output.  The reduction runs over N = 3e5 rows: one GEMM with
+    K_gemm = N leaves the library without parallelism (0.63 ms at 256 x 256 outputs); a batched GEMM over `splits` row
+    blocks plus a sum is 8x faster (0.08 ms)."""
+    N = d.shape[0]
+    n = N // splits
+    if n < 64:
+        return torch.mm(d.t(), a, out_dtype=torch.float32)
+    main = n * splits
+    out = torch.bmm(d[:main].view(splits, n, -1).transpose(1, 2), a[:main].view(splits, n, -1), out_dtype=torch.float32).sum(0)
+    if main < N:
+        out = out + torch.mm(d[main:].t(), a[main:], out_dtype=torch.float32)
+    return out
+
+
+class _FusedMLP(torch.autograd.Function):
+    """out = MLP(x_emb) with the fused kernels; gradients for the (fp32 master) parameters only."""
+
+    @staticmethod
+    def forward(ctx, x_emb, head, *params):
+        p = head._packed()
+        out, acts = forward(p, x_emb, True)
+        ctx.head, ctx.p = head, p
+        ctx.save_for_backward(x_emb, acts)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x_emb, acts = ctx.saved_tensors
+        p = ctx.p
+        g_out = g_out.contiguous()
+        dpre = backward_data(p, g_out, acts)
+        xb = torch.nn.functional.pad(x_emb, (0, p.in_pad - p.in_ch)).to(torch.bfloat16)  # (N, in_pad): aligned rows
+        grads = []
+        for l in range(p.depth):
+            if l == 0:
+                gw = _wgrad(dpre[l], xb)[:, :p.in_ch]
+            elif l == p.skip + 1:
+                gw = torch.cat([_wgrad(dpre[l], xb)[:, :p.in_ch], _wgrad(dpre[l], acts[l - 1])], 1)
+            else:
+                gw = _wgrad(dpre[l], acts[l - 1])
+            grads += [gw, dpre[l].sum(0, dtype=torch.float32)]
+        gob = torch.nn.functional.pad(g_out, (0, 32 - p.out_ch)).to(torch.bfloat16)
+        grads += [_wgrad(gob, acts[p.depth - 1])[:p.out_ch], g_out.sum(0)]
+        return (None, None) + tuple(grads)
+
+
+class FusedHead:
+    """Runs ``net`` (a WeightMLP or DeformMLP host mirror) through the fused kernels.  ``net`` keeps owning the fp32
+    parameters; the bf16 copies are rebuilt when a parameter's version counter changes (optimizer step, load)."""
+
+    def __init__(self, linears, head_linear, in_ch: int, skip: int):
+        self.linears, self.head_linear, self.in_ch, self.skip = list(linears), head_linear, in_ch, skip
+        self._pk, self._ver = None, None
+
+    def params(self):
+        ps = []
+        for lin in self.linears:
+            ps += [lin.weight, lin.bias]
+        return ps + [self.head_linear.weight, self.head_linear.bias]
+
+    def _packed(self) -> Packed:
+        ver = tuple(q._version for q in self.params()) + tuple(q.data_ptr() for q in self.params())
+        if self._pk is None or ver != self._ver:
+            self._pk, self._ver = Packed(self.linears, self.head_linear, self.in_ch, self.skip), ver
+        return self._pk
+
+    def __call__(self, x_emb: torch.Tensor) -> torch.Tensor:
+        return _FusedMLP.apply(x_emb.contiguous(), self, *self.params())

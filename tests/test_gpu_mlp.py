@@ -1,0 +1,110 @@
+"""-m gpu: the fused bf16-MFMA MLP heads (csrc/mlp.hip) against the fp32 host mirrors.
+
+The reference computes WeightMLP / DeformMLP in fp32 (skeleton_utils/network_utils.py:6-112); the fused path rounds the
+operands to bf16 (fp32 accumulation), so its bar is the bf16 one: outputs within a few 1e-3 .. 3e-2 relative, and —
+the sharper test of the kernels themselves — agreement at the 0.5 % level with a torch emulation that applies the SAME
+bf16 roundings (identical ReLU masks up to a handful of elements in millions)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from riggs_amd import mlp as M  # noqa: E402
+from riggs_amd.skeleton import DeformMLP, WeightMLP, _embed  # noqa: E402
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-20))
+
+
+def _mrel(a, b):
+    return float((a - b).abs().mean() / b.abs().mean().clamp_min(1e-20))
+
+
+def test_mfma_fragment_layout_selftest():
+    assert torch.equal(M.layout_probe().cpu(), M.expected_probe())
+
+
+def _nets(N):
+    torch.manual_seed(3)
+    x = torch.randn(N, 3, device="cuda") * 0.5
+    wm = WeightMLP(3, 23).cuda()
+    dn = DeformMLP(xyz_input_ch=3, time_input_ch=96).cuda()
+    with torch.no_grad():
+        dn.gaussian_warp.weight.mul_(2000.0)
+    pose = torch.randn(96, device="cuda")[None].expand(N, -1)
+    return [("WeightMLP", wm, wm.weight_predict, _embed(x, wm.multires).contiguous()),
+            ("DeformMLP", dn, dn.gaussian_warp, torch.cat([_embed(x, dn.multires), pose], -1).contiguous())]
+
+
+def _hidden(net, xe, rnd=lambda t: t):
+    hs, h = [], rnd(xe)
+    x0 = h
+    for i, layer in enumerate(net.linear):
+        h = rnd(torch.relu(torch.nn.functional.linear(h, rnd(layer.weight), layer.bias)))
+        hs.append(h)
+        if i in net.skips:
+            h = torch.cat([x0, h], -1)
+    return h, hs
+
+
+@pytest.mark.parametrize("N", [1, 63, 20_011])
+def test_forward_and_gradients_vs_fp32_mirror_and_bf16_emulation(N):
+    for name, net, head, xe in _nets(N):
+        g = torch.randn(N, head.weight.shape[0], device="cuda")
+        # fp32 mirror
+        out32 = head(_hidden(net, xe)[0])
+        (out32 * g).sum().backward()
+        g32 = {n: q.grad.clone() for n, q in net.named_parameters()}
+        for q in net.parameters():
+            q.grad = None
+        # fused
+        fh = M.FusedHead(net.linear, head, xe.shape[1], net.skips[0])
+        out = fh(xe)
+        (out * g).sum().backward()
+        assert _rel(out, out32) < (6e-3 if name == "WeightMLP" else 4e-2), (name, _rel(out, out32))
+        if N > 1000:  # gradient statistics need rows; ReLU-mask flips under bf16 make this a 3-12 % comparison
+            for n, q in net.named_parameters():
+                assert _mrel(q.grad, g32[n]) < 0.2, (name, n, _mrel(q.grad, g32[n]))
+        # bf16 emulation: same roundings in torch
+        class RoundBF(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, t):
+                return t.to(torch.bfloat16).float()
+
+            @staticmethod
+            def backward(ctx, gg):
+                return gg
+        h, hs = _hidden(net, xe, RoundBF.apply)
+        for t in hs:
+            t.retain_grad()
+        out_e = torch.nn.functional.linear(h, RoundBF.apply(head.weight), head.bias)
+        (out_e * g.to(torch.bfloat16).float()).sum().backward()
+        assert _rel(out, out_e) < 1.5e-2, (name, _rel(out, out_e))  # accumulation order differs from the library GEMM
+        p = fh._packed()
+        o2, acts = M.forward(p, xe, True)
+        dpre = M.backward_data(p, g, acts)
+        flips = sum(int(((acts[l].float() > 0) != (hs[l] > 0)).sum()) for l in range(p.depth))
+        assert flips <= max(4, int(2e-5 * acts.numel())), flips
+        if N > 1000:
+            for l in range(p.depth):
+                dref = hs[l].grad * (hs[l] > 0)
+                assert _mrel(dpre[l].float(), dref) < 2e-2, (name, l, _mrel(dpre[l].float(), dref))
+        for q in net.parameters():
+            q.grad = None
+
+
+def test_skeleton_warp_with_fused_heads_tracks_the_fp32_heads():
+    from riggs_amd import synth
+    from riggs_amd.skeleton import SkeletonWarp
+    sc = synth.make_scene(5_003, 24, 9)
+    sw = SkeletonWarp(joints=sc["joints"], parent_indices=sc["parents"], K=-1, hyper_dim=8).cuda()
+    x = sc["xyz"].cuda()
+    q = torch.nn.functional.normalize(torch.randn(24, 4, device="cuda"), dim=-1)
+    gt = torch.zeros(3, device="cuda")
+    outs = {}
+    for fused in (False, True):
+        sw.use_fused_heads(fused)
+        o = sw.deform_by_pose(x, {"local_rotation": q.clone().requires_grad_(True), "global_trans": gt.clone().requires_grad_(True)}, None)
+        outs[fused] = (o["d_xyz"].detach(), o["d_rotation"].detach())
+    assert _rel(outs[True][0], outs[False][0]) < 2e-2 and _rel(outs[True][1], outs[False][1]) < 2e-2

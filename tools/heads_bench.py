@@ -28,21 +28,27 @@ def main():
             p.grad = None
         out = sw.deform_by_pose(x, {"local_rotation": q, "global_trans": gt}, None)
         torch.autograd.backward((out["d_xyz"], out["d_rotation"]), (gx, gr))
-    for _ in range(3):
-        it()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    n = 10
-    for _ in range(n):
-        it()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / n
+    res = {}
+    for fused in (False, True):
+        sw.use_fused_heads(fused)
+        for _ in range(3):
+            it()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 10
+        for _ in range(n):
+            it()
+        torch.cuda.synchronize()
+        res[fused] = (time.perf_counter() - t0) / n
+    dt = res[False]
     mlp_flops = 0
     for name in ("skinning_weight_mlp", "detail_net"):
         m = getattr(sw, name)
         mlp_flops += sum(2 * p.numel() for n_, p in m.named_parameters() if p.dim() == 2)
     print("deform_by_pose fwd+bwd with WeightMLP + DeformMLP heads, N=%d: %.2f ms per iteration (%.1f TFLOP/s on the MLPs' "
           "3 x %.2f MFLOP per Gaussian)" % (x.shape[0], dt * 1e3, 3 * mlp_flops * x.shape[0] / dt / 1e12, mlp_flops / 1e6))
+    dt = res[True]
+    print("same with the fused bf16-MFMA heads (riggs_amd.mlp): %.2f ms per iteration (%.1f TFLOP/s)" % (dt * 1e3, 3 * mlp_flops * x.shape[0] / dt / 1e12))
 
 
 if __name__ == "__main__":
