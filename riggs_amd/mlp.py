@@ -99,6 +99,19 @@ def _wgrad(d: torch.Tensor, a: torch.Tensor, splits: int = 128) -> torch.Tensor:
     return out
 
 
+_ONES = {}
+
+
+def _colsum(d: torch.Tensor) -> torch.Tensor:
+    """Column sums of a tall bf16 matrix in fp32, as a (split-K) GEMM with a block of ones: torch's column reduction of a
+    (3e5, 256) bf16 tensor takes 0.09 ms and of a (3e5, 23) fp32 one 0.6 ms; this is ~0.03 ms."""
+    key = (d.device, d.shape[0])
+    ones = _ONES.get(key)
+    if ones is None:
+        ones = _ONES[key] = torch.ones(d.shape[0], 8, dtype=torch.bfloat16, device=d.device)
+    return _wgrad(d, ones)[:, 0].contiguous()
+
+
 class _FusedMLP(torch.autograd.Function):
     """out = MLP(x_emb) with the fused kernels; gradients for the (fp32 master) parameters only."""
 
@@ -125,9 +138,9 @@ class _FusedMLP(torch.autograd.Function):
                 gw = torch.cat([_wgrad(dpre[l], xb)[:, :p.in_ch], _wgrad(dpre[l], acts[l - 1])], 1)
             else:
                 gw = _wgrad(dpre[l], acts[l - 1])
-            grads += [gw, dpre[l].sum(0, dtype=torch.float32)]
+            grads += [gw, _colsum(dpre[l])]
         gob = torch.nn.functional.pad(g_out, (0, 32 - p.out_ch)).to(torch.bfloat16)
-        grads += [_wgrad(gob, acts[p.depth - 1])[:p.out_ch], g_out.sum(0)]
+        grads += [_wgrad(gob, acts[p.depth - 1])[:p.out_ch], _colsum(gob)[:p.out_ch]]
         return (None, None) + tuple(grads)
 
 
