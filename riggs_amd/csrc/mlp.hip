@@ -71,7 +71,7 @@ __device__ __forceinline__ void mlp_gemm_part(f32x16 (&acc)[RT][CT], const unsig
 // C/D layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 __device__ __forceinline__ int mlp_c_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
-__global__ __launch_bounds__(256) void mlp_forward_kernel(MlpDesc d, const float* __restrict__ x_emb,
+__global__ __launch_bounds__(256, 3) void mlp_forward_kernel(MlpDesc d, const float* __restrict__ x_emb,
                                                           unsigned short* __restrict__ acts /* [depth][N][256] or NULL */,
                                                           float* __restrict__ out /* [N][out_ch] */) {
   __shared__ unsigned short s_h[MLP_ROWS * MLP_HS];
@@ -154,7 +154,7 @@ struct MlpBwdDesc {
   const unsigned short* Wout_t;   // [256 (k)][32 (c)] bf16, columns >= out_ch zero
 };
 
-__global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdDesc d, const float* __restrict__ g_out,
+__global__ __launch_bounds__(256, 3) void mlp_backward_kernel(MlpBwdDesc d, const float* __restrict__ g_out,
                                                            const unsigned short* __restrict__ acts,
                                                            unsigned short* __restrict__ dpre /* [depth][N][256] */) {
   __shared__ unsigned short s_d[MLP_ROWS * MLP_HS];
