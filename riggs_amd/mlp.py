@@ -159,6 +159,10 @@ class FusedHead:
         return ps + [self.head_linear.weight, self.head_linear.bias]
 
     def _packed(self) -> Packed:
+        if torch.cuda.is_current_stream_capturing():
+            # inside a hipGraph capture the conversion must be PART of the graph: a replay sees new fp32 masters
+            # (the captured optimizer step) without this Python running again
+            return Packed(self.linears, self.head_linear, self.in_ch, self.skip)
         ver = tuple(q._version for q in self.params()) + tuple(q.data_ptr() for q in self.params())
         if self._pk is None or ver != self._ver:
             self._pk, self._ver = Packed(self.linears, self.head_linear, self.in_ch, self.skip), ver

@@ -93,6 +93,10 @@ class FusedAdam(torch.optim.Adam):
                     steps = (C.c_int64 * n)(*[int(t[5].item()) for t in chunk])
                     L.check(lib.riggs_adam_step(n, arr(0), arr(1), arr(2), arr(3), numel, lr, steps, float(b1), float(b2),
                                                 float(eps), st_ptr), "riggs_adam_step")
+                # the kernels write through raw pointers: tell autograd (and anything that caches derived copies of the
+                # parameters by version, e.g. the bf16 weights of riggs_amd.mlp) that the tensors changed
+                for t in chunk:
+                    torch.autograd.graph.increment_version(t[0])
         return loss
 
 

@@ -108,3 +108,18 @@ def test_skeleton_warp_with_fused_heads_tracks_the_fp32_heads():
         o = sw.deform_by_pose(x, {"local_rotation": q.clone().requires_grad_(True), "global_trans": gt.clone().requires_grad_(True)}, None)
         outs[fused] = (o["d_xyz"].detach(), o["d_rotation"].detach())
     assert _rel(outs[True][0], outs[False][0]) < 2e-2 and _rel(outs[True][1], outs[False][1]) < 2e-2
+
+
+def test_fused_head_follows_the_fused_optimizer():
+    """FusedAdam updates parameters through raw pointers; the bf16 copies of the fused head must follow."""
+    from riggs_amd.optim import FusedAdam
+    name, net, head, xe = _nets(4_096)[0]
+    fh = M.FusedHead(net.linear, head, xe.shape[1], net.skips[0])
+    opt = FusedAdam(list(net.parameters()), lr=1e-2, eps=1e-15)
+    out0 = fh(xe)
+    (out0 ** 2).sum().backward()
+    opt.step()
+    out1 = fh(xe).detach()
+    ref1 = head(_hidden(net, xe)[0]).detach()
+    assert _rel(out1, out0.detach()) > 1e-2          # the step changed the function
+    assert _rel(out1, ref1) < 6e-3                   # and the fused head sees the new weights
