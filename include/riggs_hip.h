@@ -279,7 +279,7 @@ int riggs_raster_set_trace(void* dev_u64);
 /* =====================================================================
  * Per-Gaussian MLP heads on the matrix cores: WeightMLP / DeformMLP of
  * skeleton_utils/network_utils.py:6-112 as one fused launch per direction — bf16 operands, fp32 accumulation
- * (v_mfma_f32_32x32x16_bf16).  x_emb (N, in_ch <= 128) fp32 -> depth x [Linear(256) + ReLU], the embedding
+ * (v_mfma_f32_32x32x16_bf16).  x_emb_bf16 (N rounded up to 128, in_pad) bf16, zero padded -> depth x [Linear(256) + ReLU], the embedding
  * re-concatenated IN FRONT of the hidden vector after layer `skip` (network_utils.py:58-61, 103-106) -> Linear(out_ch <= 32).
  * weights_bf16[l]: (256, K_l) row-major bf16 with K_0 = in_pad, K_{skip+1} = in_pad + 256, else 256, where
  * in_pad = in_ch rounded up to 32 and the padding columns are zero; w_out_bf16: (32, 256), rows >= out_ch zero.
@@ -288,7 +288,7 @@ int riggs_raster_set_trace(void* dev_u64);
  * ===================================================================== */
 int riggs_mlp_forward(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip,
                       const void* const* weights_bf16, const float* const* biases, const void* w_out_bf16,
-                      const float* b_out, const float* x_emb, void* acts_bf16, float* out, riggs_stream stream);
+                      const float* b_out, const void* x_emb_bf16, void* acts_bf16, float* out, riggs_stream stream);
 /* Data-gradient pass of the same MLP: g_out (N, out_ch) = dL/d(output) -> dpre_bf16 (depth, N, 256) = dL/d(pre-activation)
  * of every hidden layer, the operand of the weight gradients  dW_l = dpre_l^T · input_l ,  db_l = sum_n dpre_l  (plain
  * GEMMs / reductions, left to the library).  weights_t_bf16[l] (l >= 1): (256, 256) = W_l[:, hidden part]^T;

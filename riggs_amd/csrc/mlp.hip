@@ -27,10 +27,8 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define MLP_W 256          // hidden width (the reference's W)
-#define MLP_ROWS 64        // rows per workgroup
 #define MLP_HS (MLP_W + 8) // LDS row stride of the hidden vector in bf16 (16-byte pad: conflict-free 16-byte column reads)
 #define MLP_MAX_IN 128     // padded embedding width supported
-#define MLP_XS (MLP_MAX_IN + 8)
 
 __device__ __forceinline__ unsigned short f2bf(float f) {  // round to nearest even
   uint32_t u = __float_as_uint(f);
@@ -71,44 +69,40 @@ __device__ __forceinline__ void mlp_gemm_part(f32x16 (&acc)[RT][CT], const unsig
 // C/D layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 __device__ __forceinline__ int mlp_c_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
-__global__ __launch_bounds__(256, 3) void mlp_forward_kernel(MlpDesc d, const float* __restrict__ x_emb,
-                                                          unsigned short* __restrict__ acts /* [depth][N][256] or NULL */,
-                                                          float* __restrict__ out /* [N][out_ch] */) {
-  __shared__ unsigned short s_h[MLP_ROWS * MLP_HS];
-  __shared__ unsigned short s_x[MLP_ROWS * MLP_XS];
+template <int RT>  // 32-row tiles per workgroup (rows per workgroup = 32 RT); every wave owns 64 output columns of all of them
+__global__ __launch_bounds__(256, RT == 2 ? 3 : 2) void mlp_forward_kernel(MlpDesc d, const unsigned short* __restrict__ xb,
+                                                                            unsigned short* __restrict__ acts /* [depth][N][256] or NULL */,
+                                                                            float* __restrict__ out /* [N][out_ch] */) {
+  constexpr int ROWS = 32 * RT;
+  __shared__ unsigned short s_h[ROWS * MLP_HS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int row0 = blockIdx.x * MLP_ROWS;
-  // embedding -> bf16 LDS (zero padded to in_pad, rows past N are zero)
-  for (int e = tid; e < MLP_ROWS * d.in_pad; e += 256) {
-    const int r = e / d.in_pad, c = e - r * d.in_pad;
-    float v = 0.f;
-    if (row0 + r < d.N && c < d.in_ch) v = x_emb[(size_t)(row0 + r) * d.in_ch + c];
-    s_x[r * MLP_XS + c] = f2bf(v);
-  }
-  __syncthreads();
+  const int row0 = blockIdx.x * ROWS;
+  // the embedding is read from its bf16 copy in HBM ((rows rounded up to 128) x in_pad, zero padded): it is an A operand
+  // of two layers only, and keeping it out of LDS lets two 128-row workgroups share a CU
+  const unsigned short* xrow = xb + (size_t)row0 * d.in_pad;
   const int col0 = wave * 64;
   for (int l = 0; l < d.depth; l++) {
-    f32x16 acc[2][2];
+    f32x16 acc[RT][2];
 #pragma unroll
-    for (int rt = 0; rt < 2; rt++)
+    for (int rt = 0; rt < RT; rt++)
 #pragma unroll
       for (int ct = 0; ct < 2; ct++)
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[rt][ct][e] = 0.f;
     const int K = mlp_k(d, l);
     const unsigned short* Wl = d.Wp[l] + (size_t)col0 * K;
-    if (l == 0) mlp_gemm_part<2, 2>(acc, s_x, MLP_XS, Wl, K, d.in_pad, lane);
+    if (l == 0) mlp_gemm_part<RT, 2>(acc, xrow, d.in_pad, Wl, K, d.in_pad, lane);
     else if (l == d.skip + 1) {
-      mlp_gemm_part<2, 2>(acc, s_x, MLP_XS, Wl, K, d.in_pad, lane);
-      mlp_gemm_part<2, 2>(acc, s_h, MLP_HS, Wl + d.in_pad, K, MLP_W, lane);
-    } else mlp_gemm_part<2, 2>(acc, s_h, MLP_HS, Wl, K, MLP_W, lane);
+      mlp_gemm_part<RT, 2>(acc, xrow, d.in_pad, Wl, K, d.in_pad, lane);
+      mlp_gemm_part<RT, 2>(acc, s_h, MLP_HS, Wl + d.in_pad, K, MLP_W, lane);
+    } else mlp_gemm_part<RT, 2>(acc, s_h, MLP_HS, Wl, K, MLP_W, lane);
     __syncthreads();  // every wave is done reading the previous hidden vector
 #pragma unroll
     for (int ct = 0; ct < 2; ct++) {
       const int col = col0 + 32 * ct + (lane & 31);
       const float b = d.bias[l][col];
 #pragma unroll
-      for (int rt = 0; rt < 2; rt++)
+      for (int rt = 0; rt < RT; rt++)
 #pragma unroll
         for (int e = 0; e < 16; e++) {
           const int row = 32 * rt + mlp_c_row(e, lane);
@@ -118,15 +112,15 @@ __global__ __launch_bounds__(256, 3) void mlp_forward_kernel(MlpDesc d, const fl
     __syncthreads();
     if (acts) {  // full-line stores of the layer's activations (backward: ReLU mask and weight-gradient operand)
       unsigned short* dst = acts + ((size_t)l * d.N + row0) * MLP_W;
-      for (int e = tid; e < MLP_ROWS * (MLP_W / 8); e += 256) {
+      for (int e = tid; e < ROWS * (MLP_W / 8); e += 256) {
         const int r = e / (MLP_W / 8), c8 = e - r * (MLP_W / 8);
         if (row0 + r < d.N)
           *reinterpret_cast<bf16x8*>(dst + (size_t)r * MLP_W + 8 * c8) = *reinterpret_cast<const bf16x8*>(s_h + r * MLP_HS + 8 * c8);
       }
     }
   }
-  // output head: 64 rows x 32 (padded) columns, K = 256: waves 0 and 1 take a 32-row tile each
-  if (wave < 2) {
+  // output head: 32 RT rows x 32 (padded) columns, K = 256: wave w < RT takes the 32-row tile w
+  if (wave < RT) {
     f32x16 acc[1][1];
 #pragma unroll
     for (int e = 0; e < 16; e++) acc[0][0][e] = 0.f;
@@ -154,14 +148,16 @@ struct MlpBwdDesc {
   const unsigned short* Wout_t;   // [256 (k)][32 (c)] bf16, columns >= out_ch zero
 };
 
-__global__ __launch_bounds__(256, 3) void mlp_backward_kernel(MlpBwdDesc d, const float* __restrict__ g_out,
+template <int RT>
+__global__ __launch_bounds__(256, RT == 2 ? 3 : 2) void mlp_backward_kernel(MlpBwdDesc d, const float* __restrict__ g_out,
                                                            const unsigned short* __restrict__ acts,
                                                            unsigned short* __restrict__ dpre /* [depth][N][256] */) {
-  __shared__ unsigned short s_d[MLP_ROWS * MLP_HS];
-  __shared__ unsigned short s_g[MLP_ROWS * 40];
+  constexpr int ROWS = 32 * RT;
+  __shared__ unsigned short s_d[ROWS * MLP_HS];
+  __shared__ unsigned short s_g[ROWS * 40];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int row0 = blockIdx.x * MLP_ROWS;
-  for (int e = tid; e < MLP_ROWS * 32; e += 256) {
+  const int row0 = blockIdx.x * ROWS;
+  for (int e = tid; e < ROWS * 32; e += 256) {
     const int r = e >> 5, c = e & 31;
     float v = 0.f;
     if (row0 + r < d.N && c < d.out_ch) v = g_out[(size_t)(row0 + r) * d.out_ch + c];
@@ -171,21 +167,21 @@ __global__ __launch_bounds__(256, 3) void mlp_backward_kernel(MlpBwdDesc d, cons
   const int col0 = wave * 64;
   for (int l = d.depth - 1; l >= 0; l--) {
     // ---- d_post_l for this wave's 64 columns
-    f32x16 acc[2][2];
+    f32x16 acc[RT][2];
 #pragma unroll
-    for (int rt = 0; rt < 2; rt++)
+    for (int rt = 0; rt < RT; rt++)
 #pragma unroll
       for (int ct = 0; ct < 2; ct++)
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[rt][ct][e] = 0.f;
-    if (l == d.depth - 1) mlp_gemm_part<2, 2>(acc, s_g, 40, d.Wout_t + (size_t)col0 * 32, 32, 32, lane);
-    else mlp_gemm_part<2, 2>(acc, s_d, MLP_HS, d.Wt[l + 1] + (size_t)col0 * MLP_W, MLP_W, MLP_W, lane);
+    if (l == d.depth - 1) mlp_gemm_part<RT, 2>(acc, s_g, 40, d.Wout_t + (size_t)col0 * 32, 32, 32, lane);
+    else mlp_gemm_part<RT, 2>(acc, s_d, MLP_HS, d.Wt[l + 1] + (size_t)col0 * MLP_W, MLP_W, MLP_W, lane);
     __syncthreads();  // every wave is done reading d_pre_{l+1}
 #pragma unroll
     for (int ct = 0; ct < 2; ct++) {
       const int col = col0 + 32 * ct + (lane & 31);
 #pragma unroll
-      for (int rt = 0; rt < 2; rt++)
+      for (int rt = 0; rt < RT; rt++)
 #pragma unroll
         for (int e = 0; e < 16; e++) s_d[(32 * rt + mlp_c_row(e, lane)) * MLP_HS + col] = f2bf(acc[rt][ct][e]);
     }
@@ -193,7 +189,7 @@ __global__ __launch_bounds__(256, 3) void mlp_backward_kernel(MlpBwdDesc d, cons
     // ---- ReLU mask, in place, and out to HBM
     const unsigned short* al = acts + ((size_t)l * d.N + row0) * MLP_W;
     unsigned short* dl = dpre + ((size_t)l * d.N + row0) * MLP_W;
-    for (int e = tid; e < MLP_ROWS * (MLP_W / 8); e += 256) {
+    for (int e = tid; e < ROWS * (MLP_W / 8); e += 256) {
       const int r = e / (MLP_W / 8), c8 = e - r * (MLP_W / 8);
       bf16x8 g = *reinterpret_cast<const bf16x8*>(s_d + r * MLP_HS + 8 * c8);
       if (row0 + r < d.N) {
@@ -242,6 +238,12 @@ int riggs_mlp_layout_probe(float* out32x32, riggs_stream stream) {
   return 0;
 }
 
+// A/B switch: RIGGS_MLP_ROWS=64 selects the 64-row workgroups (2 x 2 tiles per wave); default 128 rows (4 x 2)
+static int mlp_rt() {
+  static const int v = (getenv("RIGGS_MLP_ROWS") != nullptr && atoi(getenv("RIGGS_MLP_ROWS")) == 64) ? 2 : 4;
+  return v;
+}
+
 static int mlp_fill(MlpDesc& d, int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip, const void* const* Wp,
                     const float* const* bias, const void* Wout, const float* bout) {
   RIGGS_REQUIRE(N >= 0 && depth >= 1 && depth <= 10, "MLP depth out of range");
@@ -256,15 +258,19 @@ static int mlp_fill(MlpDesc& d, int32_t N, int32_t in_ch, int32_t out_ch, int32_
 }
 
 int riggs_mlp_forward(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip, const void* const* weights_bf16,
-                      const float* const* biases, const void* w_out_bf16, const float* b_out, const float* x_emb,
+                      const float* const* biases, const void* w_out_bf16, const float* b_out, const void* x_emb_bf16,
                       void* acts_bf16, float* out, riggs_stream stream) {
   MlpDesc d;
   int rc = mlp_fill(d, N, in_ch, out_ch, depth, skip, weights_bf16, biases, w_out_bf16, b_out);
   if (rc) return rc;
   if (N == 0) return 0;
-  RIGGS_REQUIRE(x_emb && out, "MLP input / output pointers");
-  hipLaunchKernelGGL(mlp_forward_kernel, dim3((N + MLP_ROWS - 1) / MLP_ROWS), dim3(256), 0, (hipStream_t)stream, d, x_emb,
-                     (unsigned short*)acts_bf16, out);
+  RIGGS_REQUIRE(x_emb_bf16 && out, "MLP input / output pointers");
+  if (mlp_rt() == 2)
+    hipLaunchKernelGGL(mlp_forward_kernel<2>, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, d,
+                       (const unsigned short*)x_emb_bf16, (unsigned short*)acts_bf16, out);
+  else
+    hipLaunchKernelGGL(mlp_forward_kernel<4>, dim3((N + 127) / 128), dim3(256), 0, (hipStream_t)stream, d,
+                       (const unsigned short*)x_emb_bf16, (unsigned short*)acts_bf16, out);
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -280,8 +286,12 @@ int riggs_mlp_backward(int32_t N, int32_t out_ch, int32_t depth, int32_t skip, c
   for (int l = 0; l < depth; l++) { d.Wt[l] = (const unsigned short*)weights_t_bf16[l]; RIGGS_REQUIRE(l == 0 || d.Wt[l], "MLP transposed weights"); }
   d.Wout_t = (const unsigned short*)w_out_t_bf16;
   RIGGS_REQUIRE(d.Wout_t && g_out && acts_bf16 && dpre_bf16, "MLP backward pointers");
-  hipLaunchKernelGGL(mlp_backward_kernel, dim3((N + MLP_ROWS - 1) / MLP_ROWS), dim3(256), 0, (hipStream_t)stream, d, g_out,
-                     (const unsigned short*)acts_bf16, (unsigned short*)dpre_bf16);
+  if (mlp_rt() == 2)
+    hipLaunchKernelGGL(mlp_backward_kernel<2>, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, d, g_out,
+                       (const unsigned short*)acts_bf16, (unsigned short*)dpre_bf16);
+  else
+    hipLaunchKernelGGL(mlp_backward_kernel<4>, dim3((N + 127) / 128), dim3(256), 0, (hipStream_t)stream, d, g_out,
+                       (const unsigned short*)acts_bf16, (unsigned short*)dpre_bf16);
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -60,13 +60,24 @@ class Packed:
         self._bp = (C.c_void_p * self.depth)(*[t.data_ptr() for t in self.b])
 
 
-def forward(p: Packed, x_emb: torch.Tensor, want_acts: bool):
+def embed_bf16(p: Packed, x_emb: torch.Tensor) -> torch.Tensor:
+    """(N, in_ch) fp32 -> (N rounded up to 128, in_pad) bf16, zero padded: the kernels' A operand of the first and the
+    skip layer, and the right-hand side of their weight gradients."""
     N = x_emb.shape[0]
     x_emb = L.require_cuda_f32("x_emb", x_emb, (N, p.in_ch))
+    xb = torch.zeros((N + 127) // 128 * 128, p.in_pad, dtype=torch.bfloat16, device=x_emb.device)
+    xb[:N, :p.in_ch] = x_emb
+    return xb
+
+
+def forward(p: Packed, x_emb: torch.Tensor, want_acts: bool, xb: torch.Tensor = None):
+    N = x_emb.shape[0]
+    if xb is None:
+        xb = embed_bf16(p, x_emb)
     out = torch.empty(N, p.out_ch, device=x_emb.device)
     acts = torch.empty(p.depth, N, 256, dtype=torch.bfloat16, device=x_emb.device) if want_acts else None
     L.check(L.lib().riggs_mlp_forward(N, p.in_ch, p.out_ch, p.depth, p.skip, p._wp, p._bp, p.w_out.data_ptr(),
-                                      p.b_out.data_ptr(), x_emb.data_ptr(), L.ptr(acts), out.data_ptr(), L.stream_ptr()),
+                                      p.b_out.data_ptr(), xb.data_ptr(), L.ptr(acts), out.data_ptr(), L.stream_ptr()),
             "riggs_mlp_forward")
     return out, acts
 
@@ -118,18 +129,19 @@ class _FusedMLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_emb, head, *params):
         p = head._packed()
-        out, acts = forward(p, x_emb, True)
-        ctx.head, ctx.p = head, p
-        ctx.save_for_backward(x_emb, acts)
+        xb = embed_bf16(p, x_emb)
+        out, acts = forward(p, x_emb, True, xb)
+        ctx.head, ctx.p, ctx.n = head, p, x_emb.shape[0]
+        ctx.save_for_backward(xb, acts)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        x_emb, acts = ctx.saved_tensors
+        xb, acts = ctx.saved_tensors
         p = ctx.p
         g_out = g_out.contiguous()
         dpre = backward_data(p, g_out, acts)
-        xb = torch.nn.functional.pad(x_emb, (0, p.in_pad - p.in_ch)).to(torch.bfloat16)  # (N, in_pad): aligned rows
+        xb = xb[:ctx.n]
         grads = []
         for l in range(p.depth):
             if l == 0:
