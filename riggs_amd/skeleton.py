@@ -9,7 +9,7 @@ and the reductions of the backward) and the one-row PoseMLP run in HIP kernels. 
 per-Gaussian MLP heads of the stage-2 recipe (``WeightMLP`` / ``DeformMLP``, ``use_skinning_weight_mlp`` /
 ``use_template_offsets``: network_utils.py:6-112) are batched MLPs whose GEMMs go to hipBLASLt through
 torch; the HIP skinning kernels consume the weight head's output (``weight_mod``) and return its gradient
-(the fused MFMA MLP is a later row).
+(``use_fused_heads(True)`` switches them to the fused bf16-MFMA kernels of riggs_amd.mlp).
 """
 from __future__ import annotations
 
@@ -88,7 +88,8 @@ class PoseMLP(nn.Module):
 class WeightMLP(nn.Module):
     """Per-Gaussian skinning-weight modulation (skeleton_utils/network_utils.py:73-112): PE(x, 10 frequencies) -> 8 x
     Linear(256) + ReLU with the embedding re-concatenated after layer 4 -> Linear(J-1) -> sigmoid.  A plain batched MLP:
-    its GEMMs go to hipBLASLt through torch (the fused MFMA version is a later row); what is HIP
+    its GEMMs go to hipBLASLt through torch by default (the reference's fp32 arithmetic; the fused bf16-MFMA version is
+    riggs_amd.mlp, opt-in through ``SkeletonWarp.use_fused_heads``); what is HIP
     here is the consumer — the skinning kernels take its output as ``weight_mod`` and return ``dL/dweight_mod``."""
 
     def __init__(self, input_ch, output_ch, D=8, W=256, multires=10):
