@@ -83,6 +83,36 @@ def make_step(cam, gm, sw, gimg, arena, world, allreduce):
     return step
 
 
+def heads_timing(sc, gm, iters=5):
+    from riggs_amd.skeleton import SkeletonWarp
+    J = sc["joints"].shape[0]
+    sw = SkeletonWarp(joints=sc["joints"], parent_indices=sc["parents"], K=-1, hyper_dim=8).to(gm.get_xyz.device)
+    x = gm.get_xyz.detach()
+    q = torch.nn.functional.normalize(torch.randn(J, 4, device=x.device), dim=-1).requires_grad_(True)
+    gt = torch.zeros(3, device=x.device, requires_grad=True)
+    gx, gr = torch.randn_like(x), torch.randn(x.shape[0], 4, device=x.device)
+    params = [p for g in sw.trainable_parameters() for p in g["params"]]
+    res = {}
+    for fused in (False, True):
+        sw.use_fused_heads(fused)
+
+        def it():
+            for p in params + [q, gt]:
+                p.grad = None
+            o = sw.deform_by_pose(x, {"local_rotation": q, "global_trans": gt}, None)
+            torch.autograd.backward((o["d_xyz"], o["d_rotation"]), (gx, gr))
+        for _ in range(2):
+            it()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            it()
+        torch.cuda.synchronize()
+        res[fused] = (time.perf_counter() - t0) / iters
+    return {"what": "deform_by_pose forward+backward with WeightMLP and DeformMLP on, %d Gaussians; not the headline metric" % x.shape[0],
+            "ms_fp32_gemms": round(res[False] * 1e3, 3), "ms_fused_bf16_mfma": round(res[True] * 1e3, 3)}
+
+
 def cpu_baseline(sc, cam_cpu, gimg_cpu, budget_s=20.0):
     """The CPU oracle (torch-CPU deform restatement + C/OpenMP rasterizer) on the SAME workload, all host cores."""
     import numpy as np
@@ -326,6 +356,10 @@ def main():
                                  "includes": "deform + raster fwd/bwd + fused L1/SSIM loss fwd/bwd + FusedAdam (Gaussians, "
                                              "skeleton), one hipGraph; not the headline metric",
                                  "final_loss": round(float(gts.out["loss"]), 6)}
+        if world == 1 and not args.no_graph:
+            # Secondary number (NOT the metric): the deformation with both per-Gaussian MLP heads on (the stage-2 recipe,
+            # SURVEY.md §8-f rank 3), forward + backward, fp32 library GEMMs vs the fused bf16-MFMA kernels
+            out["mlp_heads"] = heads_timing(sc, gm)
         if not args.no_cpu_baseline and world == 1:  # (the CPU baseline is an N = 1 measurement)
             cam_cpu = cam.to("cpu")
             out["cpu_baseline"] = cpu_baseline(sc, cam_cpu, gimg.cpu())
