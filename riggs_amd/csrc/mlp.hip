@@ -53,16 +53,27 @@ template <int RT, int CT>
 __device__ __forceinline__ void mlp_gemm_part(f32x16 (&acc)[RT][CT], const unsigned short* A, int as, const unsigned short* Wg,
                                               int ws, int K, int lane) {
   const int r = lane & 31, kq = (lane >> 5) * 8;
+  // software-pipelined by one K-step: the fragments of step k + 1 are requested before the MFMAs of step k are issued
+  // (two waves per SIMD cannot hide an L2 round trip per step on their own)
+  bf16x8 a[RT], b[CT], an[RT], bn[CT];
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++) a[rt] = *reinterpret_cast<const bf16x8*>(A + (size_t)(32 * rt + r) * as + kq);
+#pragma unroll
+  for (int ct = 0; ct < CT; ct++) b[ct] = *reinterpret_cast<const bf16x8*>(Wg + (size_t)(32 * ct + r) * ws + kq);
   for (int k0 = 0; k0 < K; k0 += 16) {
-    bf16x8 a[RT], b[CT];
+    const int kn = (k0 + 16 < K) ? k0 + 16 : k0;  // (the last trip re-reads its own step: harmless, keeps the loop branch-free)
 #pragma unroll
-    for (int rt = 0; rt < RT; rt++) a[rt] = *reinterpret_cast<const bf16x8*>(A + (size_t)(32 * rt + r) * as + k0 + kq);
+    for (int ct = 0; ct < CT; ct++) bn[ct] = *reinterpret_cast<const bf16x8*>(Wg + (size_t)(32 * ct + r) * ws + kn + kq);
 #pragma unroll
-    for (int ct = 0; ct < CT; ct++) b[ct] = *reinterpret_cast<const bf16x8*>(Wg + (size_t)(32 * ct + r) * ws + k0 + kq);
+    for (int rt = 0; rt < RT; rt++) an[rt] = *reinterpret_cast<const bf16x8*>(A + (size_t)(32 * rt + r) * as + kn + kq);
 #pragma unroll
     for (int rt = 0; rt < RT; rt++)
 #pragma unroll
       for (int ct = 0; ct < CT; ct++) acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rt], b[ct], acc[rt][ct], 0, 0, 0);
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) a[rt] = an[rt];
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) b[ct] = bn[ct];
   }
 }
 
