@@ -295,7 +295,10 @@ int riggs_mlp_forward(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, i
  * w_out_t_bf16: (256, 32) = W_out^T with zero columns >= out_ch.  No gradient w.r.t. x_emb (detached in the reference). */
 int riggs_mlp_backward(int32_t N, int32_t out_ch, int32_t depth, int32_t skip, const void* const* weights_t_bf16,
                        const void* w_out_t_bf16, const float* g_out, const void* acts_bf16, void* dpre_bf16,
-                       riggs_stream stream);
+                       float* db_partial, riggs_stream stream);
+/* db_partial: (ceil(N / riggs_mlp_rows_per_workgroup()), depth, 256) fp32 — per-workgroup column sums of dpre; the bias
+ * gradients are their sum over the first axis */
+int32_t riggs_mlp_rows_per_workgroup(void);
 /* self-test of the MFMA fragment layouts mlp.hip assumes: writes D = A B for A = [I_16; 0] and an asymmetric B */
 int riggs_mlp_layout_probe(float* out32x32, riggs_stream stream);
 

@@ -162,7 +162,8 @@ struct MlpBwdDesc {
 template <int RT>
 __global__ __launch_bounds__(256, RT == 2 ? 3 : 2) void mlp_backward_kernel(MlpBwdDesc d, const float* __restrict__ g_out,
                                                            const unsigned short* __restrict__ acts,
-                                                           unsigned short* __restrict__ dpre /* [depth][N][256] */) {
+                                                           unsigned short* __restrict__ dpre /* [depth][N][256] */,
+                                                           float* __restrict__ db_part /* [workgroups][depth][256] */) {
   constexpr int ROWS = 32 * RT;
   __shared__ unsigned short s_d[ROWS * MLP_HS];
   __shared__ unsigned short s_g[ROWS * 40];
@@ -215,6 +216,14 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 2) void mlp_backward_kernel(MlpB
       *reinterpret_cast<bf16x8*>(s_d + r * MLP_HS + 8 * c8) = g;
     }
     __syncthreads();
+    // bias gradient of the layer: this workgroup's column sums (thread = column; summed over the workgroups in a fixed
+    // order by the caller — deterministic, and cheaper than a column reduction of the (N, 256) tensor)
+    {
+      float sum = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < ROWS; r++) sum += bf2f(s_d[r * MLP_HS + tid]);
+      db_part[((size_t)blockIdx.x * d.depth + l) * MLP_W + tid] = sum;
+    }
   }
 }
 
@@ -288,7 +297,7 @@ int riggs_mlp_forward(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, i
 
 int riggs_mlp_backward(int32_t N, int32_t out_ch, int32_t depth, int32_t skip, const void* const* weights_t_bf16,
                        const void* w_out_t_bf16, const float* g_out, const void* acts_bf16, void* dpre_bf16,
-                       riggs_stream stream) {
+                       float* db_partial, riggs_stream stream) {
   RIGGS_REQUIRE(N >= 0 && depth >= 1 && depth <= 10, "MLP depth out of range");
   RIGGS_REQUIRE(out_ch >= 1 && out_ch <= 32, "MLP output width must be <= 32");
   if (N == 0) return 0;
@@ -296,15 +305,18 @@ int riggs_mlp_backward(int32_t N, int32_t out_ch, int32_t depth, int32_t skip, c
   d.N = N; d.out_ch = out_ch; d.depth = depth; d.skip = skip;
   for (int l = 0; l < depth; l++) { d.Wt[l] = (const unsigned short*)weights_t_bf16[l]; RIGGS_REQUIRE(l == 0 || d.Wt[l], "MLP transposed weights"); }
   d.Wout_t = (const unsigned short*)w_out_t_bf16;
-  RIGGS_REQUIRE(d.Wout_t && g_out && acts_bf16 && dpre_bf16, "MLP backward pointers");
+  RIGGS_REQUIRE(d.Wout_t && g_out && acts_bf16 && dpre_bf16 && db_partial, "MLP backward pointers");
   if (mlp_rt() == 2)
     hipLaunchKernelGGL(mlp_backward_kernel<2>, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, d, g_out,
-                       (const unsigned short*)acts_bf16, (unsigned short*)dpre_bf16);
+                       (const unsigned short*)acts_bf16, (unsigned short*)dpre_bf16, db_partial);
   else
     hipLaunchKernelGGL(mlp_backward_kernel<4>, dim3((N + 127) / 128), dim3(256), 0, (hipStream_t)stream, d, g_out,
-                       (const unsigned short*)acts_bf16, (unsigned short*)dpre_bf16);
+                       (const unsigned short*)acts_bf16, (unsigned short*)dpre_bf16, db_partial);
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
 }
+
+/* rows per workgroup of the MLP kernels = rows that one slice of riggs_mlp_backward's db_partial covers */
+int32_t riggs_mlp_rows_per_workgroup(void) { return 32 * mlp_rt(); }
 
 }  // extern "C"

@@ -83,16 +83,18 @@ def forward(p: Packed, x_emb: torch.Tensor, want_acts: bool, xb: torch.Tensor = 
 
 
 def backward_data(p: Packed, g_out: torch.Tensor, acts: torch.Tensor) -> torch.Tensor:
-    """dL/d(pre-activation) of every hidden layer as bf16 (depth, N, 256)."""
+    """dL/d(pre-activation) of every hidden layer as bf16 (depth, N, 256), and the bias gradients (depth, 256)."""
     N = g_out.shape[0]
     g_out = L.require_cuda_f32("g_out", g_out, (N, p.out_ch))
     dpre = torch.empty(p.depth, N, 256, dtype=torch.bfloat16, device=g_out.device)
     if not hasattr(p, "_wtp"):
         p.w_out_t_bf16 = torch.nn.functional.pad(p.w_out_t, (0, 32 - p.out_ch)).to(torch.bfloat16).contiguous()  # (256, 32)
         p._wtp = (C.c_void_p * p.depth)(*[(t.data_ptr() if t is not None else None) for t in p.wt])
+    rows = L.lib().riggs_mlp_rows_per_workgroup()
+    db_part = torch.empty((N + rows - 1) // rows, p.depth, 256, device=g_out.device)
     L.check(L.lib().riggs_mlp_backward(N, p.out_ch, p.depth, p.skip, p._wtp, p.w_out_t_bf16.data_ptr(), g_out.data_ptr(),
-                                       acts.data_ptr(), dpre.data_ptr(), L.stream_ptr()), "riggs_mlp_backward")
-    return dpre
+                                       acts.data_ptr(), dpre.data_ptr(), db_part.data_ptr(), L.stream_ptr()), "riggs_mlp_backward")
+    return dpre, db_part.sum(0)
 
 
 def _wgrad(d: torch.Tensor, a: torch.Tensor, splits: int = 128) -> torch.Tensor:
@@ -140,7 +142,7 @@ class _FusedMLP(torch.autograd.Function):
         xb, acts = ctx.saved_tensors
         p = ctx.p
         g_out = g_out.contiguous()
-        dpre = backward_data(p, g_out, acts)
+        dpre, db = backward_data(p, g_out, acts)
         xb = xb[:ctx.n]
         grads = []
         for l in range(p.depth):
@@ -150,7 +152,7 @@ class _FusedMLP(torch.autograd.Function):
                 gw = torch.cat([_wgrad(dpre[l], xb)[:, :p.in_ch], _wgrad(dpre[l], acts[l - 1])], 1)
             else:
                 gw = _wgrad(dpre[l], acts[l - 1])
-            grads += [gw, _colsum(dpre[l])]
+            grads += [gw, db[l]]
         gob = torch.nn.functional.pad(g_out, (0, 32 - p.out_ch)).to(torch.bfloat16)
         grads += [_wgrad(gob, acts[p.depth - 1])[:p.out_ch], _colsum(gob)[:p.out_ch]]
         return (None, None) + tuple(grads)
