@@ -299,6 +299,11 @@ int riggs_mlp_backward(int32_t N, int32_t out_ch, int32_t depth, int32_t skip, c
 /* db_partial: (ceil(N / riggs_mlp_rows_per_workgroup()), depth, 256) fp32 — per-workgroup column sums of dpre; the bias
  * gradients are their sum over the first axis */
 int32_t riggs_mlp_rows_per_workgroup(void);
+/* The kernels' input operand from positions: row n = [x_n, sin(2^k x_n), cos(2^k x_n) for k < multires, tail (n_tail floats,
+ * the same for every row: DeformMLP's pose), 0 ...] as bf16, (N rounded up to 128) x (width rounded up to 32)
+ * (utils/time_utils.py:208-256 get_embedder + the concatenation of network_utils.py:40-46). */
+int riggs_mlp_embed(int32_t N, int32_t multires, int32_t n_tail, const float* x, const float* tail, void* out_bf16,
+                    riggs_stream stream);
 /* self-test of the MFMA fragment layouts mlp.hip assumes: writes D = A B for A = [I_16; 0] and an asymmetric B */
 int riggs_mlp_layout_probe(float* out32x32, riggs_stream stream);
 

@@ -227,6 +227,35 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 2) void mlp_backward_kernel(MlpB
   }
 }
 
+// Positional encoding straight into the kernels' operand: row n = [x_n, sin(2^k x_n), cos(2^k x_n) (k < multires), tail, 0 ...]
+// as bf16, (rows rounded up to 128) x in_pad — get_embedder of utils/time_utils.py:208-256 followed by the concatenation
+// with a per-call constant vector (DeformMLP's pose), instead of ~45 elementwise launches and a 75 MB fp32 intermediate.
+__global__ __launch_bounds__(256) void mlp_embed_kernel(int N, int n_rows, int multires, int n_tail, int in_pad,
+                                                        const float* __restrict__ x, const float* __restrict__ tail,
+                                                        unsigned short* __restrict__ out) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= n_rows) return;
+  unsigned short* row = out + (size_t)n * in_pad;
+  const int pe = 3 * (1 + 2 * multires);
+  if (n < N) {
+    const float v[3] = {x[3 * n], x[3 * n + 1], x[3 * n + 2]};
+    row[0] = f2bf(v[0]); row[1] = f2bf(v[1]); row[2] = f2bf(v[2]);
+    float f = 1.0f;
+    for (int k = 0; k < multires; k++) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        row[3 + 6 * k + c] = f2bf(sinf(v[c] * f));
+        row[6 + 6 * k + c] = f2bf(cosf(v[c] * f));
+      }
+      f *= 2.0f;
+    }
+    for (int j = 0; j < n_tail; j++) row[pe + j] = f2bf(tail[j]);
+    for (int j = pe + n_tail; j < in_pad; j++) row[j] = 0;
+  } else {
+    for (int j = 0; j < in_pad; j++) row[j] = 0;
+  }
+}
+
 // Self-test of the fragment layouts this file assumes (A = identity against an ASYMMETRIC B): D must equal B.
 __global__ __launch_bounds__(64) void mlp_layout_probe_kernel(float* __restrict__ out /* [32][32] */) {
   __shared__ unsigned short s_a[32 * 24], s_b[32 * 24];  // A[i][k] (i < 32, k < 16), Bt[n][k] = B[k][n]
@@ -312,6 +341,20 @@ int riggs_mlp_backward(int32_t N, int32_t out_ch, int32_t depth, int32_t skip, c
   else
     hipLaunchKernelGGL(mlp_backward_kernel<4>, dim3((N + 127) / 128), dim3(256), 0, (hipStream_t)stream, d, g_out,
                        (const unsigned short*)acts_bf16, (unsigned short*)dpre_bf16, db_partial);
+  RIGGS_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int riggs_mlp_embed(int32_t N, int32_t multires, int32_t n_tail, const float* x, const float* tail, void* out_bf16,
+                    riggs_stream stream) {
+  RIGGS_REQUIRE(N >= 0 && multires >= 0 && n_tail >= 0, "MLP embedding arguments");
+  const int in_ch = 3 * (1 + 2 * multires) + n_tail, in_pad = (in_ch + 31) & ~31;
+  RIGGS_REQUIRE(in_ch <= MLP_MAX_IN, "MLP input width must be <= 128");
+  const int n_rows = (N + 127) / 128 * 128;
+  if (n_rows == 0) return 0;
+  RIGGS_REQUIRE(x && out_bf16 && (n_tail == 0 || tail), "MLP embedding pointers");
+  hipLaunchKernelGGL(mlp_embed_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, n_rows, multires, n_tail,
+                     in_pad, x, tail, (unsigned short*)out_bf16);
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -70,6 +70,20 @@ def embed_bf16(p: Packed, x_emb: torch.Tensor) -> torch.Tensor:
     return xb
 
 
+def embed_positions_bf16(x: torch.Tensor, multires: int, tail: torch.Tensor = None) -> torch.Tensor:
+    """[x, sin(2^k x), cos(2^k x) ..., tail] per row as the kernels' padded bf16 operand, in one launch (``tail``: a vector
+    appended to every row — DeformMLP's pose)."""
+    N = x.shape[0]
+    x = L.require_cuda_f32("x", x, (N, 3))
+    n_tail = 0 if tail is None else tail.numel()
+    in_pad = (3 * (1 + 2 * multires) + n_tail + 31) & ~31
+    if tail is not None:
+        tail = L.require_cuda_f32("tail", tail.reshape(-1))
+    xb = torch.empty((N + 127) // 128 * 128, in_pad, dtype=torch.bfloat16, device=x.device)
+    L.check(L.lib().riggs_mlp_embed(N, multires, n_tail, x.data_ptr(), L.ptr(tail), xb.data_ptr(), L.stream_ptr()), "riggs_mlp_embed")
+    return xb
+
+
 def forward(p: Packed, x_emb: torch.Tensor, want_acts: bool, xb: torch.Tensor = None):
     N = x_emb.shape[0]
     if xb is None:
@@ -131,9 +145,10 @@ class _FusedMLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_emb, head, *params):
         p = head._packed()
-        xb = embed_bf16(p, x_emb)
-        out, acts = forward(p, x_emb, True, xb)
-        ctx.head, ctx.p, ctx.n = head, p, x_emb.shape[0]
+        n_rows = head._n_rows if x_emb.dtype == torch.bfloat16 else x_emb.shape[0]
+        xb = x_emb if x_emb.dtype == torch.bfloat16 else embed_bf16(p, x_emb)
+        out, acts = forward(p, xb[:n_rows], True, xb)
+        ctx.head, ctx.p, ctx.n = head, p, n_rows
         ctx.save_for_backward(xb, acts)
         return out
 
@@ -182,5 +197,7 @@ class FusedHead:
             self._pk, self._ver = Packed(self.linears, self.head_linear, self.in_ch, self.skip), ver
         return self._pk
 
-    def __call__(self, x_emb: torch.Tensor) -> torch.Tensor:
+    def __call__(self, x_emb: torch.Tensor, n_rows: int = None) -> torch.Tensor:
+        """``x_emb``: (N, in_ch) fp32, or the padded bf16 operand of ``embed_positions_bf16`` together with ``n_rows`` = N."""
+        self._n_rows = n_rows
         return _FusedMLP.apply(x_emb.contiguous(), self, *self.params())

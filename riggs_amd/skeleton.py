@@ -437,7 +437,8 @@ class SkeletonWarp(nn.Module):
         net = self.skinning_weight_mlp
         if getattr(self, "_fh_w", None) is None:
             self._fh_w = FusedHead(net.linear, net.weight_predict, net.input_ch, net.skips[0])
-        return torch.sigmoid(self._fh_w(_embed(x, net.multires)))
+        from .mlp import embed_positions_bf16
+        return torch.sigmoid(self._fh_w(embed_positions_bf16(x, net.multires), n_rows=x.shape[0]))
 
     def _head_detail(self, x, pose):
         if not getattr(self, "_fused_heads", False):
@@ -446,6 +447,9 @@ class SkeletonWarp(nn.Module):
         net = self.detail_net
         if getattr(self, "_fh_d", None) is None:
             self._fh_d = FusedHead(net.linear, net.gaussian_warp, net.input_ch, net.skips[0])
+        if net.t_multires <= 0 and net.multires > 0:  # the reference's configuration: PE(x) and the raw pose vector
+            from .mlp import embed_positions_bf16
+            return self._fh_d(embed_positions_bf16(x, net.multires, pose[0]), n_rows=x.shape[0])
         t_emb = _embed(pose, net.t_multires) if net.t_multires > 0 else pose
         x_emb = _embed(x, net.multires) if net.multires > 0 else x
         return self._fh_d(torch.cat([x_emb, t_emb], dim=-1))

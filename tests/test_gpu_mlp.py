@@ -123,3 +123,16 @@ def test_fused_head_follows_the_fused_optimizer():
     ref1 = head(_hidden(net, xe)[0]).detach()
     assert _rel(out1, out0.detach()) > 1e-2          # the step changed the function
     assert _rel(out1, ref1) < 6e-3                   # and the fused head sees the new weights
+
+
+def test_embedding_kernel_matches_the_reference_embedder():
+    torch.manual_seed(1)
+    N = 1_001
+    x = torch.randn(N, 3, device="cuda")
+    pose = torch.randn(96, device="cuda")
+    for multires, tail in ((10, None), (4, pose)):
+        xb = M.embed_positions_bf16(x, multires, tail)
+        ref = _embed(x, multires) if tail is None else torch.cat([_embed(x, multires), tail[None].expand(N, -1)], -1)
+        assert xb.shape == ((N + 127) // 128 * 128, (ref.shape[1] + 31) // 32 * 32)
+        assert float((xb[:N, :ref.shape[1]].float() - ref).abs().max()) < 8e-3 * float(ref.abs().max())  # bf16 rounding
+        assert float(xb[N:].float().abs().max()) == 0.0 and float(xb[:, ref.shape[1]:].float().abs().max()) == 0.0
