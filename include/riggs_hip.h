@@ -283,18 +283,21 @@ int riggs_raster_set_trace(void* dev_u64);
  * re-concatenated IN FRONT of the hidden vector after layer `skip` (network_utils.py:58-61, 103-106) -> Linear(out_ch <= 32).
  * weights_bf16[l]: (256, K_l) row-major bf16 with K_0 = in_pad, K_{skip+1} = in_pad + 256, else 256, where
  * in_pad = in_ch rounded up to 32 and the padding columns are zero; w_out_bf16: (32, 256), rows >= out_ch zero.
- * acts_bf16 (depth, N, 256) receives the post-ReLU activations for the backward (NULL for inference).
+ * acts_bf16 (depth, N, 256) receives the post-ReLU activations (operand of the weight gradients) and relu_masks
+ * (depth, ceil(N / riggs_mlp_rows_per_workgroup()), 256) x 16 bytes their signs in the kernels' accumulator layout, for
+ * riggs_mlp_backward (both NULL for inference).
  * Opt-in on the host side (riggs_amd.mlp): the reference computes these MLPs in fp32.
  * ===================================================================== */
 int riggs_mlp_forward(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip,
                       const void* const* weights_bf16, const float* const* biases, const void* w_out_bf16,
-                      const float* b_out, const void* x_emb_bf16, void* acts_bf16, float* out, riggs_stream stream);
+                      const float* b_out, const void* x_emb_bf16, void* acts_bf16, void* relu_masks, float* out,
+                      riggs_stream stream);
 /* Data-gradient pass of the same MLP: g_out (N, out_ch) = dL/d(output) -> dpre_bf16 (depth, N, 256) = dL/d(pre-activation)
  * of every hidden layer, the operand of the weight gradients  dW_l = dpre_l^T · input_l ,  db_l = sum_n dpre_l  (plain
  * GEMMs / reductions, left to the library).  weights_t_bf16[l] (l >= 1): (256, 256) = W_l[:, hidden part]^T;
  * w_out_t_bf16: (256, 32) = W_out^T with zero columns >= out_ch.  No gradient w.r.t. x_emb (detached in the reference). */
 int riggs_mlp_backward(int32_t N, int32_t out_ch, int32_t depth, int32_t skip, const void* const* weights_t_bf16,
-                       const void* w_out_t_bf16, const float* g_out, const void* acts_bf16, void* dpre_bf16,
+                       const void* w_out_t_bf16, const float* g_out, const void* relu_masks, void* dpre_bf16,
                        float* db_partial, riggs_stream stream);
 /* db_partial: (ceil(N / riggs_mlp_rows_per_workgroup()), depth, 256) fp32 — per-workgroup column sums of dpre; the bias
  * gradients are their sum over the first axis */

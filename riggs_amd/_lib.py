@@ -63,7 +63,7 @@ _SIGS = {
     "riggs_l1_ssim_forward": (C.c_int, [C.c_int32] * 3 + [_P, _P, C.c_float, _P, _P, _P]),
     "riggs_l1_ssim_backward": (C.c_int, [C.c_int32] * 3 + [_P, _P, _P, C.c_float, _P, _P, _P, _P, _P]),
     "riggs_raster_set_trace": (C.c_int, [_P]),
-    "riggs_mlp_forward": (C.c_int, [C.c_int32] * 5 + [_P] * 8),
+    "riggs_mlp_forward": (C.c_int, [C.c_int32] * 5 + [_P] * 9),
     "riggs_mlp_backward": (C.c_int, [C.c_int32] * 4 + [_P] * 7),
     "riggs_mlp_rows_per_workgroup": (C.c_int32, []),
     "riggs_mlp_embed": (C.c_int, [C.c_int32] * 3 + [_P] * 4),

@@ -83,6 +83,7 @@ __device__ __forceinline__ int mlp_c_row(int reg, int lane) { return (reg & 3) +
 template <int RT>  // 32-row tiles per workgroup (rows per workgroup = 32 RT); every wave owns 64 output columns of all of them
 __global__ __launch_bounds__(256, RT == 2 ? 3 : 2) void mlp_forward_kernel(MlpDesc d, const unsigned short* __restrict__ xb,
                                                                             unsigned short* __restrict__ acts /* [depth][N][256] or NULL */,
+                                                                            uint4* __restrict__ masks /* [depth][workgroups][256] or NULL */,
                                                                             float* __restrict__ out /* [N][out_ch] */) {
   constexpr int ROWS = 32 * RT;
   __shared__ unsigned short s_h[ROWS * MLP_HS];
@@ -108,6 +109,7 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 2) void mlp_forward_kernel(MlpDe
       mlp_gemm_part<RT, 2>(acc, s_h, MLP_HS, Wl + d.in_pad, K, MLP_W, lane);
     } else mlp_gemm_part<RT, 2>(acc, s_h, MLP_HS, Wl, K, MLP_W, lane);
     __syncthreads();  // every wave is done reading the previous hidden vector
+    uint32_t mbits[4] = {0u, 0u, 0u, 0u};  // ReLU mask of this lane's accumulator elements: bit (rt * 2 + ct) * 16 + e
 #pragma unroll
     for (int ct = 0; ct < 2; ct++) {
       const int col = col0 + 32 * ct + (lane & 31);
@@ -117,11 +119,17 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 2) void mlp_forward_kernel(MlpDe
 #pragma unroll
         for (int e = 0; e < 16; e++) {
           const int row = 32 * rt + mlp_c_row(e, lane);
-          s_h[row * MLP_HS + col] = f2bf(fmaxf(acc[rt][ct][e] + b, 0.f));
+          const float v = acc[rt][ct][e] + b;
+          const unsigned short hv = f2bf(fmaxf(v, 0.f));
+          s_h[row * MLP_HS + col] = hv;
+          if ((hv & 0x7FFFu) != 0u) mbits[(rt * 2 + ct) >> 1] |= 1u << ((((rt * 2 + ct) & 1) << 4) + e);
         }
     }
+    // (the data-gradient kernel uses the same tiling, so the mask travels in the accumulator layout: 16 bytes per lane
+    // and layer instead of re-reading the layer's activations)
+    if (masks) masks[((size_t)l * gridDim.x + blockIdx.x) * 256 + tid] = make_uint4(mbits[0], mbits[1], mbits[2], mbits[3]);
     __syncthreads();
-    if (acts) {  // full-line stores of the layer's activations (backward: ReLU mask and weight-gradient operand)
+    if (acts) {  // full-line stores of the layer's activations (operand of the weight gradients)
       unsigned short* dst = acts + ((size_t)l * d.N + row0) * MLP_W;
       for (int e = tid; e < ROWS * (MLP_W / 8); e += 256) {
         const int r = e / (MLP_W / 8), c8 = e - r * (MLP_W / 8);
@@ -161,7 +169,7 @@ struct MlpBwdDesc {
 
 template <int RT>
 __global__ __launch_bounds__(256, RT == 2 ? 3 : 2) void mlp_backward_kernel(MlpBwdDesc d, const float* __restrict__ g_out,
-                                                           const unsigned short* __restrict__ acts,
+                                                           const uint4* __restrict__ masks /* [depth][workgroups][256], from the forward */,
                                                            unsigned short* __restrict__ dpre /* [depth][N][256] */,
                                                            float* __restrict__ db_part /* [workgroups][depth][256] */) {
   constexpr int ROWS = 32 * RT;
@@ -189,33 +197,28 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 2) void mlp_backward_kernel(MlpB
     if (l == d.depth - 1) mlp_gemm_part<RT, 2>(acc, s_g, 40, d.Wout_t + (size_t)col0 * 32, 32, 32, lane);
     else mlp_gemm_part<RT, 2>(acc, s_d, MLP_HS, d.Wt[l + 1] + (size_t)col0 * MLP_W, MLP_W, MLP_W, lane);
     __syncthreads();  // every wave is done reading d_pre_{l+1}
+    // ---- d_pre_l = d_post_l where the forward's activation was positive (mask bits in this lane's accumulator layout)
+    const uint4 mk = masks[((size_t)l * gridDim.x + blockIdx.x) * 256 + tid];
+    const uint32_t mbits[4] = {mk.x, mk.y, mk.z, mk.w};
 #pragma unroll
     for (int ct = 0; ct < 2; ct++) {
       const int col = col0 + 32 * ct + (lane & 31);
 #pragma unroll
-      for (int rt = 0; rt < RT; rt++)
+      for (int rt = 0; rt < RT; rt++) {
+        const uint32_t m16 = mbits[(rt * 2 + ct) >> 1] >> (((rt * 2 + ct) & 1) << 4);
 #pragma unroll
-        for (int e = 0; e < 16; e++) s_d[(32 * rt + mlp_c_row(e, lane)) * MLP_HS + col] = f2bf(acc[rt][ct][e]);
+        for (int e = 0; e < 16; e++)
+          s_d[(32 * rt + mlp_c_row(e, lane)) * MLP_HS + col] = ((m16 >> e) & 1u) ? f2bf(acc[rt][ct][e]) : (unsigned short)0;
+      }
     }
     __syncthreads();
-    // ---- ReLU mask, in place, and out to HBM
-    const unsigned short* al = acts + ((size_t)l * d.N + row0) * MLP_W;
+    // ---- out to HBM (operand of the weight gradients), full lines
     unsigned short* dl = dpre + ((size_t)l * d.N + row0) * MLP_W;
     for (int e = tid; e < ROWS * (MLP_W / 8); e += 256) {
       const int r = e / (MLP_W / 8), c8 = e - r * (MLP_W / 8);
-      bf16x8 g = *reinterpret_cast<const bf16x8*>(s_d + r * MLP_HS + 8 * c8);
-      if (row0 + r < d.N) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(al + (size_t)r * MLP_W + 8 * c8);
-#pragma unroll
-        for (int q = 0; q < 8; q++) g[q] = ((unsigned short)a[q] & 0x7FFFu) != 0 && ((unsigned short)a[q] & 0x8000u) == 0 ? g[q] : (short)0;
-        *reinterpret_cast<bf16x8*>(dl + (size_t)r * MLP_W + 8 * c8) = g;
-      } else {
-#pragma unroll
-        for (int q = 0; q < 8; q++) g[q] = 0;
-      }
-      *reinterpret_cast<bf16x8*>(s_d + r * MLP_HS + 8 * c8) = g;
+      if (row0 + r < d.N)
+        *reinterpret_cast<bf16x8*>(dl + (size_t)r * MLP_W + 8 * c8) = *reinterpret_cast<const bf16x8*>(s_d + r * MLP_HS + 8 * c8);
     }
-    __syncthreads();
     // bias gradient of the layer: this workgroup's column sums (thread = column; summed over the workgroups in a fixed
     // order by the caller — deterministic, and cheaper than a column reduction of the (N, 256) tensor)
     {
@@ -308,7 +311,7 @@ static int mlp_fill(MlpDesc& d, int32_t N, int32_t in_ch, int32_t out_ch, int32_
 
 int riggs_mlp_forward(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip, const void* const* weights_bf16,
                       const float* const* biases, const void* w_out_bf16, const float* b_out, const void* x_emb_bf16,
-                      void* acts_bf16, float* out, riggs_stream stream) {
+                      void* acts_bf16, void* relu_masks, float* out, riggs_stream stream) {
   MlpDesc d;
   int rc = mlp_fill(d, N, in_ch, out_ch, depth, skip, weights_bf16, biases, w_out_bf16, b_out);
   if (rc) return rc;
@@ -316,16 +319,16 @@ int riggs_mlp_forward(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, i
   RIGGS_REQUIRE(x_emb_bf16 && out, "MLP input / output pointers");
   if (mlp_rt() == 2)
     hipLaunchKernelGGL(mlp_forward_kernel<2>, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, d,
-                       (const unsigned short*)x_emb_bf16, (unsigned short*)acts_bf16, out);
+                       (const unsigned short*)x_emb_bf16, (unsigned short*)acts_bf16, (uint4*)relu_masks, out);
   else
     hipLaunchKernelGGL(mlp_forward_kernel<4>, dim3((N + 127) / 128), dim3(256), 0, (hipStream_t)stream, d,
-                       (const unsigned short*)x_emb_bf16, (unsigned short*)acts_bf16, out);
+                       (const unsigned short*)x_emb_bf16, (unsigned short*)acts_bf16, (uint4*)relu_masks, out);
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
 int riggs_mlp_backward(int32_t N, int32_t out_ch, int32_t depth, int32_t skip, const void* const* weights_t_bf16,
-                       const void* w_out_t_bf16, const float* g_out, const void* acts_bf16, void* dpre_bf16,
+                       const void* w_out_t_bf16, const float* g_out, const void* relu_masks, void* dpre_bf16,
                        float* db_partial, riggs_stream stream) {
   RIGGS_REQUIRE(N >= 0 && depth >= 1 && depth <= 10, "MLP depth out of range");
   RIGGS_REQUIRE(out_ch >= 1 && out_ch <= 32, "MLP output width must be <= 32");
@@ -334,13 +337,13 @@ int riggs_mlp_backward(int32_t N, int32_t out_ch, int32_t depth, int32_t skip, c
   d.N = N; d.out_ch = out_ch; d.depth = depth; d.skip = skip;
   for (int l = 0; l < depth; l++) { d.Wt[l] = (const unsigned short*)weights_t_bf16[l]; RIGGS_REQUIRE(l == 0 || d.Wt[l], "MLP transposed weights"); }
   d.Wout_t = (const unsigned short*)w_out_t_bf16;
-  RIGGS_REQUIRE(d.Wout_t && g_out && acts_bf16 && dpre_bf16 && db_partial, "MLP backward pointers");
+  RIGGS_REQUIRE(d.Wout_t && g_out && relu_masks && dpre_bf16 && db_partial, "MLP backward pointers");
   if (mlp_rt() == 2)
     hipLaunchKernelGGL(mlp_backward_kernel<2>, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, d, g_out,
-                       (const unsigned short*)acts_bf16, (unsigned short*)dpre_bf16, db_partial);
+                       (const uint4*)relu_masks, (unsigned short*)dpre_bf16, db_partial);
   else
     hipLaunchKernelGGL(mlp_backward_kernel<4>, dim3((N + 127) / 128), dim3(256), 0, (hipStream_t)stream, d, g_out,
-                       (const unsigned short*)acts_bf16, (unsigned short*)dpre_bf16, db_partial);
+                       (const uint4*)relu_masks, (unsigned short*)dpre_bf16, db_partial);
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
 }

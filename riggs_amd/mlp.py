@@ -89,14 +89,18 @@ def forward(p: Packed, x_emb: torch.Tensor, want_acts: bool, xb: torch.Tensor = 
     if xb is None:
         xb = embed_bf16(p, x_emb)
     out = torch.empty(N, p.out_ch, device=x_emb.device)
-    acts = torch.empty(p.depth, N, 256, dtype=torch.bfloat16, device=x_emb.device) if want_acts else None
+    acts = masks = None
+    if want_acts:
+        rows = L.lib().riggs_mlp_rows_per_workgroup()
+        acts = torch.empty(p.depth, N, 256, dtype=torch.bfloat16, device=x_emb.device)
+        masks = torch.empty(p.depth, (N + rows - 1) // rows, 256, 4, dtype=torch.int32, device=x_emb.device)
     L.check(L.lib().riggs_mlp_forward(N, p.in_ch, p.out_ch, p.depth, p.skip, p._wp, p._bp, p.w_out.data_ptr(),
-                                      p.b_out.data_ptr(), xb.data_ptr(), L.ptr(acts), out.data_ptr(), L.stream_ptr()),
-            "riggs_mlp_forward")
-    return out, acts
+                                      p.b_out.data_ptr(), xb.data_ptr(), L.ptr(acts), L.ptr(masks), out.data_ptr(),
+                                      L.stream_ptr()), "riggs_mlp_forward")
+    return out, (acts, masks) if want_acts else None
 
 
-def backward_data(p: Packed, g_out: torch.Tensor, acts: torch.Tensor) -> torch.Tensor:
+def backward_data(p: Packed, g_out: torch.Tensor, masks: torch.Tensor) -> torch.Tensor:
     """dL/d(pre-activation) of every hidden layer as bf16 (depth, N, 256), and the bias gradients (depth, 256)."""
     N = g_out.shape[0]
     g_out = L.require_cuda_f32("g_out", g_out, (N, p.out_ch))
@@ -107,7 +111,7 @@ def backward_data(p: Packed, g_out: torch.Tensor, acts: torch.Tensor) -> torch.T
     rows = L.lib().riggs_mlp_rows_per_workgroup()
     db_part = torch.empty((N + rows - 1) // rows, p.depth, 256, device=g_out.device)
     L.check(L.lib().riggs_mlp_backward(N, p.out_ch, p.depth, p.skip, p._wtp, p.w_out_t_bf16.data_ptr(), g_out.data_ptr(),
-                                       acts.data_ptr(), dpre.data_ptr(), db_part.data_ptr(), L.stream_ptr()), "riggs_mlp_backward")
+                                       masks.data_ptr(), dpre.data_ptr(), db_part.data_ptr(), L.stream_ptr()), "riggs_mlp_backward")
     return dpre, db_part.sum(0)
 
 
@@ -147,17 +151,17 @@ class _FusedMLP(torch.autograd.Function):
         p = head._packed()
         n_rows = head._n_rows if x_emb.dtype == torch.bfloat16 else x_emb.shape[0]
         xb = x_emb if x_emb.dtype == torch.bfloat16 else embed_bf16(p, x_emb)
-        out, acts = forward(p, xb[:n_rows], True, xb)
+        out, (acts, masks) = forward(p, xb[:n_rows], True, xb)
         ctx.head, ctx.p, ctx.n = head, p, n_rows
-        ctx.save_for_backward(xb, acts)
+        ctx.save_for_backward(xb, acts, masks)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        xb, acts = ctx.saved_tensors
+        xb, acts, masks = ctx.saved_tensors
         p = ctx.p
         g_out = g_out.contiguous()
-        dpre, db = backward_data(p, g_out, acts)
+        dpre, db = backward_data(p, g_out, masks)
         xb = xb[:ctx.n]
         grads = []
         for l in range(p.depth):

@@ -82,8 +82,8 @@ def test_forward_and_gradients_vs_fp32_mirror_and_bf16_emulation(N):
         (out_e * g.to(torch.bfloat16).float()).sum().backward()
         assert _rel(out, out_e) < 1.5e-2, (name, _rel(out, out_e))  # accumulation order differs from the library GEMM
         p = fh._packed()
-        o2, acts = M.forward(p, xe, True)
-        dpre, _db = M.backward_data(p, g, acts)
+        o2, (acts, masks) = M.forward(p, xe, True)
+        dpre, _db = M.backward_data(p, g, masks)
         flips = sum(int(((acts[l].float() > 0) != (hs[l] > 0)).sum()) for l in range(p.depth))
         assert flips <= max(4, int(2e-5 * acts.numel())), flips
         if N > 1000:
