@@ -302,6 +302,11 @@ int riggs_mlp_backward(int32_t N, int32_t out_ch, int32_t depth, int32_t skip, c
 /* db_partial: (ceil(N / riggs_mlp_rows_per_workgroup()), depth, 256) fp32 — per-workgroup column sums of dpre; the bias
  * gradients are their sum over the first axis */
 int32_t riggs_mlp_rows_per_workgroup(void);
+/* fp32 master weights ((256, K_true) row-major per layer, (out_ch, 256) for the head) -> every bf16 operand the two kernels
+ * read (layouts above), in one launch. */
+int riggs_mlp_pack(int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip, const float* const* weights, const float* w_out,
+                   void* const* weights_bf16, void* const* weights_t_bf16, void* w_out_bf16, void* w_out_t_bf16,
+                   riggs_stream stream);
 /* The kernels' input operand from positions: row n = [x_n, sin(2^k x_n), cos(2^k x_n) for k < multires, tail (n_tail floats,
  * the same for every row: DeformMLP's pose), 0 ...] as bf16, (N rounded up to 128) x (width rounded up to 32)
  * (utils/time_utils.py:208-256 get_embedder + the concatenation of network_utils.py:40-46). */

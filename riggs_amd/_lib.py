@@ -67,6 +67,7 @@ _SIGS = {
     "riggs_mlp_backward": (C.c_int, [C.c_int32] * 4 + [_P] * 7),
     "riggs_mlp_rows_per_workgroup": (C.c_int32, []),
     "riggs_mlp_embed": (C.c_int, [C.c_int32] * 3 + [_P] * 4),
+    "riggs_mlp_pack": (C.c_int, [C.c_int32] * 4 + [_P] * 7),
     "riggs_mlp_layout_probe": (C.c_int, [_P, _P]),
     "riggs_prof_count": (C.c_int, []),
     "riggs_prof_name": (C.c_char_p, [C.c_int32]),

@@ -259,6 +259,50 @@ __global__ __launch_bounds__(256) void mlp_embed_kernel(int N, int n_rows, int m
   }
 }
 
+// fp32 master weights -> the bf16 operand layouts of both kernels, in ONE launch (the masters change every optimizer step,
+// and ~60 small conversion / padding / transposition launches per MLP were a tenth of a heads-on training iteration)
+struct MlpPackDesc {
+  int in_ch, in_pad, out_ch, depth, skip;
+  const float* W[10];            // (256, K_true): K_true = in_ch, in_ch + 256 (layer skip + 1) or 256
+  const float* Wout;             // (out_ch, 256)
+  unsigned short* Wp[10];        // (256, K_pad)
+  unsigned short* Wt[10];        // l >= 1: (256 k, 256 n) = hidden part transposed
+  unsigned short* Wout_p;        // (32, 256)
+  unsigned short* Wout_t;        // (256, 32)
+};
+__global__ __launch_bounds__(256) void mlp_pack_kernel(MlpPackDesc d) {
+  const int l = blockIdx.y;  // depth = the head
+  const int tid = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+  if (l == d.depth) {
+    for (int e = tid; e < 32 * MLP_W; e += stride) {
+      const int c = e / MLP_W, k = e - c * MLP_W;
+      d.Wout_p[e] = f2bf(c < d.out_ch ? d.Wout[(size_t)c * MLP_W + k] : 0.f);
+    }
+    for (int e = tid; e < MLP_W * 32; e += stride) {
+      const int k = e >> 5, c = e & 31;
+      d.Wout_t[e] = f2bf(c < d.out_ch ? d.Wout[(size_t)c * MLP_W + k] : 0.f);
+    }
+    return;
+  }
+  const bool first = (l == 0), sk = (l == d.skip + 1);
+  const int k_true = first ? d.in_ch : (sk ? d.in_ch + MLP_W : MLP_W);
+  const int k_pad = first ? d.in_pad : (sk ? d.in_pad + MLP_W : MLP_W);
+  const int hoff_true = sk ? d.in_ch : 0, hoff_pad = sk ? d.in_pad : 0;  // where the hidden part starts
+  const float* W = d.W[l];
+  for (int e = tid; e < MLP_W * k_pad; e += stride) {
+    const int n = e / k_pad, k = e - n * k_pad;
+    float v = 0.f;
+    if (first || (sk && k < hoff_pad)) { if (k < d.in_ch) v = W[(size_t)n * k_true + k]; }
+    else v = W[(size_t)n * k_true + hoff_true + (k - hoff_pad)];
+    d.Wp[l][e] = f2bf(v);
+  }
+  if (!first)
+    for (int e = tid; e < MLP_W * MLP_W; e += stride) {
+      const int k = e >> 8, n = e & 255;
+      d.Wt[l][e] = f2bf(W[(size_t)n * k_true + hoff_true + k]);
+    }
+}
+
 // Self-test of the fragment layouts this file assumes (A = identity against an ASYMMETRIC B): D must equal B.
 __global__ __launch_bounds__(64) void mlp_layout_probe_kernel(float* __restrict__ out /* [32][32] */) {
   __shared__ unsigned short s_a[32 * 24], s_b[32 * 24];  // A[i][k] (i < 32, k < 16), Bt[n][k] = B[k][n]
@@ -358,6 +402,24 @@ int riggs_mlp_embed(int32_t N, int32_t multires, int32_t n_tail, const float* x,
   RIGGS_REQUIRE(x && out_bf16 && (n_tail == 0 || tail), "MLP embedding pointers");
   hipLaunchKernelGGL(mlp_embed_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, n_rows, multires, n_tail,
                      in_pad, x, tail, (unsigned short*)out_bf16);
+  RIGGS_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int riggs_mlp_pack(int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip, const float* const* weights, const float* w_out,
+                   void* const* weights_bf16, void* const* weights_t_bf16, void* w_out_bf16, void* w_out_t_bf16,
+                   riggs_stream stream) {
+  RIGGS_REQUIRE(depth >= 1 && depth <= 10 && in_ch >= 1 && in_ch <= MLP_MAX_IN && out_ch >= 1 && out_ch <= 32 && skip >= 0 &&
+                skip < depth - 1, "MLP shape out of range");
+  MlpPackDesc d;
+  d.in_ch = in_ch; d.in_pad = (in_ch + 31) & ~31; d.out_ch = out_ch; d.depth = depth; d.skip = skip;
+  for (int l = 0; l < depth; l++) {
+    d.W[l] = weights[l]; d.Wp[l] = (unsigned short*)weights_bf16[l]; d.Wt[l] = (unsigned short*)weights_t_bf16[l];
+    RIGGS_REQUIRE(d.W[l] && d.Wp[l] && (l == 0 || d.Wt[l]), "MLP pack pointers");
+  }
+  d.Wout = w_out; d.Wout_p = (unsigned short*)w_out_bf16; d.Wout_t = (unsigned short*)w_out_t_bf16;
+  RIGGS_REQUIRE(d.Wout && d.Wout_p && d.Wout_t, "MLP pack head pointers");
+  hipLaunchKernelGGL(mlp_pack_kernel, dim3(32, depth + 1), dim3(256), 0, (hipStream_t)stream, d);
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
 }

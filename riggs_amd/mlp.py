@@ -32,31 +32,32 @@ def expected_probe() -> torch.Tensor:
 
 
 class Packed:
-    """bf16 copies of the weights in the kernels' layouts (rebuilt whenever the fp32 masters change)."""
+    """bf16 copies of the weights in the kernels' layouts.  The buffers are allocated once; ``repack()`` refills them from
+    the fp32 masters with one launch (``riggs_mlp_pack``) whenever those changed."""
 
     def __init__(self, linears, head, in_ch: int, skip: int):
         dev = head.weight.device
-        self.in_ch, self.in_pad, self.skip, self.depth = in_ch, (in_ch + 31) & ~31, skip, len(linears)
+        self.linears, self.head = list(linears), head
+        self.in_ch, self.in_pad, self.skip, self.depth = in_ch, (in_ch + 31) & ~31, skip, len(self.linears)
         self.out_ch = head.weight.shape[0]
-        pad = self.in_pad - in_ch
-        self.w, self.wt, self.b = [], [], []
-        for l, lin in enumerate(linears):
-            w = lin.weight.detach()
-            if l == 0:
-                w = torch.nn.functional.pad(w, (0, pad))
-            elif l == skip + 1:
-                w = torch.cat([torch.nn.functional.pad(w[:, :in_ch], (0, pad)), w[:, in_ch:]], 1)
-            self.w.append(w.to(torch.bfloat16).contiguous())
-            # transposed copy of the part that multiplies the hidden vector: (K_h = 256 rows of k, 256 columns of n)
-            wh = lin.weight.detach()[:, in_ch:] if l == skip + 1 else lin.weight.detach()
-            self.wt.append(wh.t().to(torch.bfloat16).contiguous() if l > 0 else None)
-            self.b.append(lin.bias.detach().float().contiguous())
-        wo = torch.zeros(32, 256, device=dev)
-        wo[: self.out_ch] = head.weight.detach()
-        self.w_out = wo.to(torch.bfloat16).contiguous()
-        self.w_out_t = head.weight.detach().t().contiguous()  # (256, out_ch) fp32, for the head's data gradient
-        self.b_out = head.bias.detach().float().contiguous()
+        bf = dict(dtype=torch.bfloat16, device=dev)
+        kpad = [self.in_pad if l == 0 else (self.in_pad + 256 if l == skip + 1 else 256) for l in range(self.depth)]
+        self.w = [torch.empty(256, k, **bf) for k in kpad]
+        self.wt = [None] + [torch.empty(256, 256, **bf) for _ in range(1, self.depth)]
+        self.w_out = torch.empty(32, 256, **bf)
+        self.w_out_t_bf16 = torch.empty(256, 32, **bf)
         self._wp = (C.c_void_p * self.depth)(*[t.data_ptr() for t in self.w])
+        self._wtp = (C.c_void_p * self.depth)(*[(t.data_ptr() if t is not None else None) for t in self.wt])
+        self.repack()
+
+    def repack(self):
+        ws = [L.require_cuda_f32("weight", lin.weight.detach()) for lin in self.linears]
+        wo = L.require_cuda_f32("head weight", self.head.weight.detach())
+        src = (C.c_void_p * self.depth)(*[t.data_ptr() for t in ws])
+        L.check(L.lib().riggs_mlp_pack(self.in_ch, self.out_ch, self.depth, self.skip, src, wo.data_ptr(), self._wp, self._wtp,
+                                       self.w_out.data_ptr(), self.w_out_t_bf16.data_ptr(), L.stream_ptr()), "riggs_mlp_pack")
+        self.b = [L.require_cuda_f32("bias", lin.bias.detach()) for lin in self.linears]  # (views of the masters)
+        self.b_out = L.require_cuda_f32("head bias", self.head.bias.detach())
         self._bp = (C.c_void_p * self.depth)(*[t.data_ptr() for t in self.b])
 
 
@@ -105,9 +106,6 @@ def backward_data(p: Packed, g_out: torch.Tensor, masks: torch.Tensor) -> torch.
     N = g_out.shape[0]
     g_out = L.require_cuda_f32("g_out", g_out, (N, p.out_ch))
     dpre = torch.empty(p.depth, N, 256, dtype=torch.bfloat16, device=g_out.device)
-    if not hasattr(p, "_wtp"):
-        p.w_out_t_bf16 = torch.nn.functional.pad(p.w_out_t, (0, 32 - p.out_ch)).to(torch.bfloat16).contiguous()  # (256, 32)
-        p._wtp = (C.c_void_p * p.depth)(*[(t.data_ptr() if t is not None else None) for t in p.wt])
     rows = L.lib().riggs_mlp_rows_per_workgroup()
     db_part = torch.empty((N + rows - 1) // rows, p.depth, 256, device=g_out.device)
     L.check(L.lib().riggs_mlp_backward(N, p.out_ch, p.depth, p.skip, p._wtp, p.w_out_t_bf16.data_ptr(), g_out.data_ptr(),
@@ -183,7 +181,7 @@ class FusedHead:
 
     def __init__(self, linears, head_linear, in_ch: int, skip: int):
         self.linears, self.head_linear, self.in_ch, self.skip = list(linears), head_linear, in_ch, skip
-        self._pk, self._ver = None, None
+        self._pk, self._ver, self._ptrs = None, None, None
 
     def params(self):
         ps = []
@@ -192,13 +190,21 @@ class FusedHead:
         return ps + [self.head_linear.weight, self.head_linear.bias]
 
     def _packed(self) -> Packed:
+        ptrs = tuple(q.data_ptr() for q in self.params())
+        ver = tuple(q._version for q in self.params())
+        if self._pk is None or ptrs != self._ptrs:
+            self._pk, self._ptrs, self._ver = Packed(self.linears, self.head_linear, self.in_ch, self.skip), ptrs, ver
+            fresh = True
+        else:
+            fresh = False
         if torch.cuda.is_current_stream_capturing():
             # inside a hipGraph capture the conversion must be PART of the graph: a replay sees new fp32 masters
             # (the captured optimizer step) without this Python running again
-            return Packed(self.linears, self.head_linear, self.in_ch, self.skip)
-        ver = tuple(q._version for q in self.params()) + tuple(q.data_ptr() for q in self.params())
-        if self._pk is None or ver != self._ver:
-            self._pk, self._ver = Packed(self.linears, self.head_linear, self.in_ch, self.skip), ver
+            self._pk.repack()
+            self._ver = None
+        elif not fresh and ver != self._ver:
+            self._pk.repack()
+            self._ver = ver
         return self._pk
 
     def __call__(self, x_emb: torch.Tensor, n_rows: int = None) -> torch.Tensor:
