@@ -236,27 +236,31 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 2) void mlp_backward_kernel(MlpB
 __global__ __launch_bounds__(256) void mlp_embed_kernel(int N, int n_rows, int multires, int n_tail, int in_pad,
                                                         const float* __restrict__ x, const float* __restrict__ tail,
                                                         unsigned short* __restrict__ out) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= n_rows) return;
-  unsigned short* row = out + (size_t)n * in_pad;
+  // thread = 8 consecutive columns of one row: 16-byte stores, consecutive threads -> consecutive addresses
+  const int segs = in_pad >> 3;
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (size_t)n_rows * segs) return;
+  const int n = (int)(t / segs), c0 = (int)(t - (size_t)n * segs) * 8;
   const int pe = 3 * (1 + 2 * multires);
-  if (n < N) {
-    const float v[3] = {x[3 * n], x[3 * n + 1], x[3 * n + 2]};
-    row[0] = f2bf(v[0]); row[1] = f2bf(v[1]); row[2] = f2bf(v[2]);
-    float f = 1.0f;
-    for (int k = 0; k < multires; k++) {
+  bf16x8 v;
 #pragma unroll
-      for (int c = 0; c < 3; c++) {
-        row[3 + 6 * k + c] = f2bf(sinf(v[c] * f));
-        row[6 + 6 * k + c] = f2bf(cosf(v[c] * f));
-      }
-      f *= 2.0f;
+  for (int q = 0; q < 8; q++) v[q] = 0;
+  if (n < N) {
+    const float xv[3] = {x[3 * n], x[3 * n + 1], x[3 * n + 2]};
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int c = c0 + q;
+      float f = 0.f;
+      if (c < 3) f = xv[c];
+      else if (c < pe) {
+        const int k = (c - 3) / 6, w = (c - 3) - 6 * k;
+        const float a = xv[w % 3] * (float)(1 << k);
+        f = (w < 3) ? sinf(a) : cosf(a);
+      } else if (c < pe + n_tail) f = tail[c - pe];
+      v[q] = (short)f2bf(f);
     }
-    for (int j = 0; j < n_tail; j++) row[pe + j] = f2bf(tail[j]);
-    for (int j = pe + n_tail; j < in_pad; j++) row[j] = 0;
-  } else {
-    for (int j = 0; j < in_pad; j++) row[j] = 0;
   }
+  *reinterpret_cast<bf16x8*>(out + (size_t)n * in_pad + c0) = v;
 }
 
 // fp32 master weights -> the bf16 operand layouts of both kernels, in ONE launch (the masters change every optimizer step,
@@ -400,7 +404,8 @@ int riggs_mlp_embed(int32_t N, int32_t multires, int32_t n_tail, const float* x,
   const int n_rows = (N + 127) / 128 * 128;
   if (n_rows == 0) return 0;
   RIGGS_REQUIRE(x && out_bf16 && (n_tail == 0 || tail), "MLP embedding pointers");
-  hipLaunchKernelGGL(mlp_embed_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, n_rows, multires, n_tail,
+  const size_t n_thr = (size_t)n_rows * (in_pad >> 3);
+  hipLaunchKernelGGL(mlp_embed_kernel, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N, n_rows, multires, n_tail,
                      in_pad, x, tail, (unsigned short*)out_bf16);
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
