@@ -136,3 +136,12 @@ def test_embedding_kernel_matches_the_reference_embedder():
         assert xb.shape == ((N + 127) // 128 * 128, (ref.shape[1] + 31) // 32 * 32)
         assert float((xb[:N, :ref.shape[1]].float() - ref).abs().max()) < 8e-3 * float(ref.abs().max())  # bf16 rounding
         assert float(xb[N:].float().abs().max()) == 0.0 and float(xb[:, ref.shape[1]:].float().abs().max()) == 0.0
+
+
+def test_empty_input():
+    name, net, head, xe = _nets(8)[0]
+    fh = M.FusedHead(net.linear, head, xe.shape[1], net.skips[0])
+    out = fh(xe[:0].contiguous())
+    assert out.shape == (0, head.weight.shape[0])
+    out.sum().backward()
+    assert all(q.grad is not None and float(q.grad.abs().max()) == 0.0 for q in net.parameters())
