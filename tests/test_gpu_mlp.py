@@ -145,3 +145,36 @@ def test_empty_input():
     assert out.shape == (0, head.weight.shape[0])
     out.sum().backward()
     assert all(q.grad is not None and float(q.grad.abs().max()) == 0.0 for q in net.parameters())
+
+
+def test_fused_heads_inside_a_captured_training_iteration():
+    """The bf16 copies of the head weights are rebuilt INSIDE the hipGraph (the captured optimizer step changes the fp32
+    masters without any Python running): every replay must see the weights of the step before it."""
+    import bench
+    from riggs_amd import synth
+    from riggs_amd.gaussian_model import GaussianModel
+    from riggs_amd.graph import GraphedTrainStep
+    from riggs_amd.optim import FusedAdam
+    from riggs_amd.skeleton import SkeletonWarp
+    sc = synth.make_scene(4_000, 8, 4)
+    cam = synth.look_at_camera(64, 80, fid=0.3).to("cuda")
+    gm = GaussianModel.from_tensors(sc["xyz"], sc["features_dc"], sc["features_rest"], sc["scaling"], sc["rotation"],
+                                    sc["opacity"], device="cuda")
+    torch.manual_seed(0)
+    sw = SkeletonWarp(joints=sc["joints"], parent_indices=sc["parents"], K=-1, hyper_dim=8).cuda().use_fused_heads(True)
+    gm.training_setup(bench._train_args(), capturable=True)
+    opt = FusedAdam([{"params": g["params"], "lr": 5e-4, "name": g["name"]} for g in sw.trainable_parameters()],
+                    lr=0.0, eps=1e-15, capturable=True)
+    target = torch.rand(3, 64, 80, device="cuda")
+    gts = GraphedTrainStep(gm, sw, cam, torch.zeros(3, device="cuda"), target, [gm.optimizer, opt], lambda_dssim=0.2)
+    gts.capture(warmup=1)
+    w0 = sw.skinning_weight_mlp.linear[2].weight.detach().clone()
+    losses = []
+    for _ in range(3):
+        gts.run()
+        losses.append(float(gts.out["loss"]))
+    w1 = sw.skinning_weight_mlp.linear[2].weight.detach().clone()
+    assert all(v == v and v < 10 for v in losses)
+    assert float((w1 - w0).abs().max()) > 1e-4                       # the captured optimizer moved the masters
+    pk = sw._fh_w._pk                                                 # the bf16 copy the LAST replay used = masters before its own step
+    assert float((pk.w[2][:, :256].float() - w1).abs().max()) < 2e-3   # within one Adam step (5e-4) + bf16 rounding of the masters
