@@ -128,6 +128,24 @@ def _wgrad(d: torch.Tensor, a: torch.Tensor, splits: int = 128) -> torch.Tensor:
     return out
 
 
+def _wgrad_multi(d: torch.Tensor, a: torch.Tensor, splits: int = 128) -> torch.Tensor:
+    """``_wgrad`` for a stack of layers: d (L, N, M), a (L, N, K) -> (L, M, K), one batched GEMM over L x splits blocks.
+
+    The (layer, split) axes only merge into one batch axis without a copy when the split count divides N, so the
+    divisor of N nearest ``splits`` is used; without one in [splits/2, 2*splits] the layers go one at a time."""
+    Lr, N = d.shape[0], d.shape[1]
+    best = 0
+    for c in range(splits // 2, 2 * splits + 1):
+        if N % c == 0 and abs(c - splits) < abs(best - splits):
+            best = c
+    if best == 0 or N // best < 64:
+        return torch.stack([_wgrad(d[i], a[i], splits) for i in range(Lr)])
+    n = N // best
+    dm = d.view(Lr * best, n, d.shape[2])
+    am = a.view(Lr * best, n, a.shape[2])
+    return torch.bmm(dm.transpose(1, 2), am, out_dtype=torch.float32).view(Lr, best, d.shape[2], a.shape[2]).sum(1)
+
+
 _ONES = {}
 
 
@@ -161,15 +179,20 @@ class _FusedMLP(torch.autograd.Function):
         g_out = g_out.contiguous()
         dpre, db = backward_data(p, g_out, masks)
         xb = xb[:ctx.n]
+        # hidden-to-hidden layers share shapes: one batched split-K GEMM per run of consecutive layers (1 .. skip and
+        # skip + 2 .. depth - 1) instead of one per layer
+        gws = [None] * p.depth
+        for lo, hi in ((1, p.skip + 1), (p.skip + 2, p.depth)):
+            if hi > lo:
+                g_run = _wgrad_multi(dpre[lo:hi], acts[lo - 1:hi - 1])
+                for l in range(lo, hi):
+                    gws[l] = g_run[l - lo]
+        gws[0] = _wgrad(dpre[0], xb)[:, :p.in_ch]
+        ls = p.skip + 1
+        gws[ls] = torch.cat([_wgrad(dpre[ls], xb)[:, :p.in_ch], _wgrad(dpre[ls], acts[ls - 1])], 1)
         grads = []
         for l in range(p.depth):
-            if l == 0:
-                gw = _wgrad(dpre[l], xb)[:, :p.in_ch]
-            elif l == p.skip + 1:
-                gw = torch.cat([_wgrad(dpre[l], xb)[:, :p.in_ch], _wgrad(dpre[l], acts[l - 1])], 1)
-            else:
-                gw = _wgrad(dpre[l], acts[l - 1])
-            grads += [gw, db[l]]
+            grads += [gws[l], db[l]]
         gob = torch.nn.functional.pad(g_out, (0, 32 - p.out_ch)).to(torch.bfloat16)
         grads += [_wgrad(gob, acts[p.depth - 1])[:p.out_ch], _colsum(gob)[:p.out_ch]]
         return (None, None) + tuple(grads)
