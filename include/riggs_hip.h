@@ -259,6 +259,30 @@ int riggs_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float* image, 
                            float* dL_dimage, riggs_stream stream);
 
 /* =====================================================================
+ * Skeleton projection loss: TrainRig.cal_skeleton_loss, train_rig.py:309-314, =
+ * sampling_skeleton_points (:264-276) -> project_nodes_to_2d_elements (utils/other_utils.py:101-127) ->
+ * pytorch3d.loss.chamfer_distance(x, y, norm=1) (third-party; restated from its published definition).
+ * S line parameters t (the host evaluates the reference's int(max_len / (sum_len / 512)) and linspace) on each of the
+ * J-1 bones of the posed joints d_nodes (J, 3); world_view_transform is the camera's (4, 4) matrix as the reference
+ * stores it (row-vector convention, DEVICE pointer); fx, fy, cx, cy as other_utils.py:107-117 computes them; thinned is
+ * the frame's (M, 2) silhouette-skeleton pixels as (row, col).  forward writes loss2 = {loss, weight * loss} (device;
+ * `weight` is the trainer's robust per-frame weight of train_rig.py:465-467 as a DEVICE scalar, NULL = 1) and keeps the
+ * nearest-neighbour keys in `state` (riggs_skeleton_projection_state_floats floats, 8-byte aligned); backward takes the
+ * upstream gradients of the two scalars as DEVICE scalars (NULL = 0) and writes dL/d(d_nodes) (J, 3).  Deterministic
+ * (the only atomics are 64-bit max and LDS integer adds).
+ * ===================================================================== */
+size_t riggs_skeleton_projection_state_floats(int32_t J, int32_t S, int32_t M);
+int riggs_skeleton_projection_forward(int32_t J, int32_t S, int32_t M, const int32_t* parents, const float* d_nodes,
+                                      const float* t, const float* world_view_transform, float fx, float fy, float cx,
+                                      float cy, const float* thinned, const float* weight, float* state, float* loss2,
+                                      riggs_stream stream);
+int riggs_skeleton_projection_backward(int32_t J, int32_t S, int32_t M, const int32_t* parents, const float* d_nodes,
+                                       const float* t, const float* world_view_transform, float fx, float fy, float cx,
+                                       float cy, const float* thinned, const float* weight, float* state,
+                                       const float* g_loss, const float* g_weighted, float* grad_nodes,
+                                       riggs_stream stream);
+
+/* =====================================================================
  * simple_knn._C.distCUDA2 (scene/gaussian_model.py:20,170): mean squared distance to the 3
  * nearest neighbours.  points (P,3) -> out (P,).  workspace: riggs_knn_workspace_bytes(P).
  * ===================================================================== */

@@ -66,3 +66,92 @@ def grad(x, y, g_l1, g_ssim):
     de12 = 2 * A * inv
     n = x.size
     return g_l1 * np.sign(x - y) / n + g_ssim / n * (_conv(dmu, w2) + 2 * x * _conv(de11, w2) + y * _conv(de12, w2))
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Skeleton projection loss (second half): TrainRig.cal_skeleton_loss, train_rig.py:309-314.
+#
+# * ``sampling_steps`` / ``sampling_skeleton_points`` — train_rig.py:264-276: with d_k the (detached) bone lengths,
+#   S = int(max d / (sum d / 512)) equally spaced parameters t in [0, 1] (torch.linspace, float32) on EVERY bone;
+#   point (s, k) = t_s * child_k + (1 - t_s) * parent_k, flattened s-major.
+# * ``project_nodes`` — utils/other_utils.py:101-127: row-vector world->view transform, pinhole with
+#   fx = W / (2 tan(FoVx/2)), fy likewise, principal point K[0,2], K[1,2] or the image centre; elements are (y, x).
+# * ``chamfer_l1`` — pytorch3d.loss.chamfer_distance(x, y, norm=1) with its defaults.  pytorch3d is a pip dependency of
+#   the reference (not vendored, not installed here): PARITY UNPINNED for this factor — restated from its published
+#   definition: per point the L1 distance to the nearest point of the other set (ties: lowest index), mean per set, the
+#   two directions added.  d|a - b|/da = sign(a - b) with sign(0) = 0.
+# Pinned (everything but the chamfer factor) by tests/golden/skelproj_*.npz: the reference's own sampling, projection and
+# composition with autograd's gradient (tests/golden/make_golden.py:fixture_skeleton_projection).
+# ------------------------------------------------------------------------------------------------------------------------
+def sampling_steps(nodes, parents, num_sample=512):
+    """The linspace parameters (float32, as torch computes them: from both ends towards the middle)."""
+    nodes = np.asarray(nodes, np.float32)
+    par = np.asarray(parents)[1:].astype(np.int64)
+    d = np.linalg.norm((nodes[1:] - nodes[par]).astype(np.float32), axis=-1).astype(np.float32)
+    each = np.float32(d.sum(dtype=np.float32) / np.float32(num_sample))
+    S = int(np.float32(d.max()) / each)
+    if S <= 0:
+        return np.zeros(0, np.float32)
+    if S == 1:
+        return np.zeros(1, np.float32)
+    step = np.float32(1.0) / np.float32(S - 1)
+    i = np.arange(S)
+    lo = (np.float32(0.0) + step * i.astype(np.float32)).astype(np.float32)
+    hi = (np.float32(1.0) - step * (S - 1 - i).astype(np.float32)).astype(np.float32)
+    return np.where(i < S // 2, lo, hi).astype(np.float32)
+
+
+def sampling_skeleton_points(nodes, parents, t):
+    nodes = np.asarray(nodes, np.float64)
+    par = np.asarray(parents)[1:].astype(np.int64)
+    t = np.asarray(t, np.float64)[:, None, None]
+    return (t * nodes[1:][None] + (1.0 - t) * nodes[par][None]).reshape(-1, 3)
+
+
+def intrinsics(FoVx, FoVy, H, W, K=None):
+    fx = W / (2.0 * math.tan(FoVx * 0.5))
+    fy = H / (2.0 * math.tan(FoVy * 0.5))
+    if K is not None and np.size(K):
+        return fx, fy, float(K[0][2]), float(K[1][2])
+    return fx, fy, W / 2.0, H / 2.0
+
+
+def project_nodes(points, world_view_transform, fx, fy, cx, cy):
+    V = np.asarray(world_view_transform, np.float64)
+    tr = np.asarray(points, np.float64) @ V[:3, :3] + V[3, :3]
+    return np.stack([fy * tr[:, 1] / tr[:, 2] + cy, fx * tr[:, 0] / tr[:, 2] + cx], -1)
+
+
+def chamfer_l1(x, y):
+    """-> (loss, nearest index in y per x, nearest index in x per y)."""
+    d = np.abs(np.asarray(x, np.float64)[:, None, :] - np.asarray(y, np.float64)[None, :, :]).sum(-1)
+    ix, iy = d.argmin(1), d.argmin(0)
+    return d.min(1).mean() + d.min(0).mean(), ix, iy
+
+
+def skeleton_projection_loss(nodes, parents, world_view_transform, fx, fy, cx, cy, thinned, t=None):
+    """-> (loss, d loss / d nodes)."""
+    nodes = np.asarray(nodes, np.float64)
+    par = np.asarray(parents)[1:].astype(np.int64)
+    if t is None:
+        t = sampling_steps(nodes, parents)
+    t = np.asarray(t, np.float64)
+    pts = sampling_skeleton_points(nodes, parents, t)
+    V = np.asarray(world_view_transform, np.float64)
+    tr = pts @ V[:3, :3] + V[3, :3]
+    proj = np.stack([fy * tr[:, 1] / tr[:, 2] + cy, fx * tr[:, 0] / tr[:, 2] + cx], -1)
+    thinned = np.asarray(thinned, np.float64)
+    loss, ix, iy = chamfer_l1(proj, thinned)
+    P, M = proj.shape[0], thinned.shape[0]
+    gp = np.sign(proj - thinned[ix]) / P
+    np.add.at(gp, iy, np.sign(proj[iy] - thinned) / M)
+    # back through the pinhole: element 0 is y, element 1 is x
+    gtr = np.zeros_like(tr)
+    gtr[:, 1] = gp[:, 0] * fy / tr[:, 2]
+    gtr[:, 0] = gp[:, 1] * fx / tr[:, 2]
+    gtr[:, 2] = -(gp[:, 0] * fy * tr[:, 1] + gp[:, 1] * fx * tr[:, 0]) / tr[:, 2] ** 2
+    gpts = (gtr @ V[:3, :3].T).reshape(t.shape[0], -1, 3)
+    g = np.zeros_like(nodes)
+    np.add.at(g, np.arange(1, nodes.shape[0]), (t[:, None, None] * gpts).sum(0))
+    np.add.at(g, par, ((1.0 - t)[:, None, None] * gpts).sum(0))
+    return loss, g

@@ -62,6 +62,9 @@ _SIGS = {
     "riggs_l1_ssim_state_floats": (C.c_size_t, [C.c_int32] * 3),
     "riggs_l1_ssim_forward": (C.c_int, [C.c_int32] * 3 + [_P, _P, C.c_float, _P, _P, _P]),
     "riggs_l1_ssim_backward": (C.c_int, [C.c_int32] * 3 + [_P, _P, _P, C.c_float, _P, _P, _P, _P, _P]),
+    "riggs_skeleton_projection_state_floats": (C.c_size_t, [C.c_int32] * 3),
+    "riggs_skeleton_projection_forward": (C.c_int, [C.c_int32] * 3 + [_P] * 4 + [C.c_float] * 4 + [_P] * 5),
+    "riggs_skeleton_projection_backward": (C.c_int, [C.c_int32] * 3 + [_P] * 4 + [C.c_float] * 4 + [_P] * 7),
     "riggs_raster_set_trace": (C.c_int, [_P]),
     "riggs_mlp_forward": (C.c_int, [C.c_int32] * 5 + [_P] * 9),
     "riggs_mlp_backward": (C.c_int, [C.c_int32] * 4 + [_P] * 7),

@@ -23,6 +23,7 @@ SOURCES = {
     "pose_mlp.hip": ["-ffp-contract=fast"],
     "optim.hip": ["-ffp-contract=off"],
     "loss.hip": ["-ffp-contract=fast"],
+    "skel_loss.hip": ["-ffp-contract=off"],
     "mlp.hip": ["-ffp-contract=fast"],
     "capi.hip": [],
 }

@@ -109,10 +109,16 @@ class GraphedTrainStep(GraphedFrame):
     """One WHOLE training iteration as a hipGraph (train_rig.py:535-554 minus logging / densification): deform -> render ->
     image loss (fused L1 + SSIM, riggs_amd.loss) -> backward -> optimizer steps (riggs_amd.optim.FusedAdam with
     ``capturable=True``: step counts and scheduled learning rates live on the device).  The ground-truth image, the camera
-    and the time are static device buffers refreshed by ``run()``; ``out["loss"]`` / ``out["l1"]`` are device scalars."""
+    and the time are static device buffers refreshed by ``run()``; ``out["loss"]`` / ``out["l1"]`` are device scalars.
+
+    With ``thinned`` (the frame's (M, 2) silhouette-skeleton pixels) the skeleton projection loss of train_rig.py:459-470 is
+    part of the iteration: the gradient is that of ``loss_img + projection_weight * cal_skeleton_loss(d_nodes, camera)``
+    (``out["loss"]`` stays the image term, ``out["projection_loss"]`` the unweighted projection term); the weight is a
+    device scalar the host refreshes between replays (riggs_amd.loss.ProjectionLossWeights).  M and the
+    sampling density are baked into the graph: frames with another pixel count need their own capture."""
 
     def __init__(self, gm, sw, cam: Camera, bg: torch.Tensor, gt_image: torch.Tensor, optimizers, lambda_dssim: float = 0.2,
-                 headroom: float = 1.5):
+                 headroom: float = 1.5, thinned: torch.Tensor = None, projection_weight: float = 1e-3, K=None):
         params = gm.parameters() + [p for g in sw.trainable_parameters() for p in g["params"]]
         super().__init__(gm, sw, cam, bg, params, headroom=headroom, fused=True)
         for o in optimizers:
@@ -121,9 +127,20 @@ class GraphedTrainStep(GraphedFrame):
         self.optimizers = list(optimizers)
         self.gt = gt_image.clone()
         self.lam = float(lambda_dssim)
+        self.thinned = None
+        if thinned is not None:
+            from .loss import sampling_steps
+            self.thinned = thinned.to(device=bg.device, dtype=torch.float32).clone()
+            self.proj_weight = torch.full((), float(projection_weight), device=bg.device)
+            self.cam.K = K
+            with torch.no_grad():
+                d_nodes = sw(gm.get_xyz.detach()[:1], sw.expand_time(self.cam.fid), motion_mask=None)["d_nodes"]
+            self.proj_steps = sampling_steps(d_nodes, sw.parents)
+            self.proj_parents = sw.parents.to(device=bg.device, dtype=torch.int32).clone()
+            self.one = torch.ones((), device=bg.device)
 
     def _frame(self):
-        from .loss import image_loss
+        from .loss import image_loss, cal_skeleton_loss
         for p in self.params:
             p.grad = None
         t_in = self.sw.expand_time(self.cam.fid)
@@ -131,16 +148,32 @@ class GraphedTrainStep(GraphedFrame):
         pkg = render(self.cam, self.gm, _Pipe, self.bg, dv["d_xyz"], dv["d_rotation"], dv["d_scaling"],
                      fused=self.fused, arena=self.arena)
         loss, l1 = image_loss(pkg["render"], self.gt, self.lam)
-        loss.backward()
+        proj = None
+        if self.thinned is None:
+            loss.backward()
+        else:
+            # two roots, one backward pass: no launches for "loss + weight * projection" and its autograd mirror
+            self.cam.thinned = self.thinned
+            proj, wproj = cal_skeleton_loss(dv["d_nodes"], self.proj_parents, self.cam, t=self.proj_steps, weight=self.proj_weight)
+            torch.autograd.backward([loss, wproj], [self.one, self.one])
         for o in self.optimizers:
             o.step()
         out = {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in dict.items(pkg)
                if k not in ("viewspace_points", "visibility_filter")}
         out["viewspace_points_grad"] = pkg["viewspace_points"].grad
         out["loss"], out["l1"] = loss.detach(), l1.detach()
+        if proj is not None:
+            out["projection_loss"] = proj.detach()
         return RenderPkg(out, cache=False)
 
-    def run(self, cam: Camera = None, gt_image: torch.Tensor = None):
+    def run(self, cam: Camera = None, gt_image: torch.Tensor = None, thinned: torch.Tensor = None,
+            projection_weight=None):
         if gt_image is not None:
             self.gt.copy_(gt_image, non_blocking=True)
+        if thinned is not None:
+            if self.thinned is None or thinned.shape != self.thinned.shape:
+                raise ValueError("the number of thinned pixels is baked into the captured graph: capture a new one")
+            self.thinned.copy_(thinned, non_blocking=True)
+        if projection_weight is not None:
+            self.proj_weight.fill_(float(projection_weight))
         return super().run(cam, None)

@@ -261,6 +261,87 @@ def fixture_loss(name, seed, C, H, W):
     print("wrote", name)
 
 
+def chamfer_l1_published(x, y, norm=1):
+    """Stand-in for pytorch3d.loss.chamfer_distance (pytorch3d is not vendored in the reference tree and not installed):
+    the PUBLISHED algorithm for the call the trainer makes (train_rig.py:313: norm=1, defaults otherwise) — for every
+    point the L1 distance to its nearest neighbour in the other set, averaged per set, the two directions added; batch of
+    one.  The chamfer part of the fixture is therefore a restatement ("parity unpinned" for that factor); the bone
+    sampling, the projection and the composition around it are the reference's own code."""
+    assert norm == 1 and x.shape[0] == 1 and y.shape[0] == 1
+    d = (x[0][:, None, :] - y[0][None, :, :]).abs().sum(-1)
+    return d.min(1).values.mean() + d.min(0).values.mean(), None
+
+
+def fixture_skeleton_projection(name, seed, J, M, from_K, chain=False):
+    """§8-f rank 2 (second half): TrainRig.cal_skeleton_loss (train_rig.py:309-314) = sampling_skeleton_points (:264-276)
+    -> project_nodes_to_2d_elements (utils/other_utils.py:101-127) -> chamfer distance to the camera's thinned silhouette
+    pixels, with autograd's gradient w.r.t. the posed joints."""
+    import types
+    class _Inert:  # absorbs the import-time side effects of modules the trainer pulls in (LPIPS nets, GUI)
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, *a, **k):
+            return _Inert()
+
+        def __getattr__(self, n):
+            return _Inert()
+
+    lp = types.ModuleType("lpips")
+    lp.LPIPS = _Inert
+    sys.modules.setdefault("lpips", lp)
+    for missing in ("piq", "pytorch_msssim", "dearpygui", "dearpygui.dearpygui"):
+        if missing not in sys.modules:
+            m = types.ModuleType(missing)
+            m.__path__ = []
+            m.__getattr__ = lambda n: _Inert
+            sys.modules[missing] = m
+    with S.quiet():
+        import train_rig
+        from utils.other_utils import project_nodes_to_2d_elements
+    train_rig.chamfer_distance = chamfer_l1_published
+    g = torch.Generator().manual_seed(seed)
+    joints, parents = random_tree(g, J, chain=chain)
+    nodes = (joints + 0.02 * torch.randn(J, 3, generator=g)).requires_grad_(True)
+    az, el, rad = math.radians(30.0), math.radians(15.0), 3.5
+    eye = np.array([rad * math.cos(el) * math.sin(az), -rad * math.sin(el), -rad * math.cos(el) * math.cos(az)])
+    fwd = -eye / np.linalg.norm(eye)
+    right = np.cross(np.array([0.0, -1.0, 0.0]), fwd)
+    right /= np.linalg.norm(right)
+    up = np.cross(fwd, right)
+    Rc2w = np.stack([right, up, fwd], axis=1)
+    T = -Rc2w.T @ eye
+    H, W = 120, 160
+    fovx = 0.6911112
+    K = None
+    if from_K:
+        fx = W / (2 * math.tan(fovx / 2))
+        K = np.array([[fx, 0, W / 2 + 5.5], [0, fx, H / 2 - 3.25], [0, 0, 1]], dtype=np.float64)
+    cam = Camera(0, Rc2w, T, fovx, fovx * 0.8, torch.zeros(3, H, W), None, "c", 0, data_device="cpu", fid=0.5, K=K)
+    # thinned silhouette pixels (row, col): near the projected skeleton, jittered, some far outliers, one exact repeat
+    with torch.no_grad():
+        proj0 = project_nodes_to_2d_elements(cam, nodes.detach())
+    pick = torch.randint(0, J, (M,), generator=g)
+    thinned = (proj0[pick] + 6.0 * torch.randn(M, 2, generator=g)).round()
+    thinned[: M // 10] = torch.stack([torch.randint(0, H, (M // 10,), generator=g),
+                                      torch.randint(0, W, (M // 10,), generator=g)], -1).float()
+    thinned[-1] = thinned[0]
+    cam.thinned = thinned
+    fake = types.SimpleNamespace(
+        sampling_skeleton_points=lambda j, p: train_rig.TrainRig.sampling_skeleton_points(None, j, p),
+        skeleton=types.SimpleNamespace(deform=types.SimpleNamespace(parents=parents)))
+    pts = train_rig.TrainRig.sampling_skeleton_points(None, nodes, parents)
+    proj = project_nodes_to_2d_elements(cam, pts)
+    loss = train_rig.TrainRig.cal_skeleton_loss(fake, nodes, cam)
+    loss.backward()
+    out = dict(d_nodes=np_(nodes), parents=parents.numpy().astype(np.int32), world_view_transform=np_(cam.world_view_transform),
+               FoVx=cam.FoVx, FoVy=cam.FoVy, image_height=H, image_width=W, K=(np.zeros((0, 0)) if K is None else np.asarray(K)),
+               thinned=np_(thinned), sampling_points=np_(pts), projected=np_(proj), loss=float(loss.detach()),
+               grad_nodes=np_(nodes.grad), steps=pts.shape[0] // (J - 1))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, "steps", out["steps"], "points", pts.shape[0], "loss", out["loss"])
+
+
 def seeded_heads(J, WeightCls, DeformCls, seed):
     """The two per-Gaussian MLP heads with reproducible weights (the fixture stores checksums, not 4 MB of weights):
     constructed standalone, in this order, right after torch.manual_seed(seed)."""
@@ -332,4 +413,6 @@ if __name__ == "__main__":
     fixture_optim("optim_adam_n67", 41, 67)
     fixture_loss("loss_l1_ssim", 51, 3, 37, 45)
     fixture_deform_heads("heads_tree12_n200", 61, 12, 200)
+    fixture_skeleton_projection("skelproj_tree24_m700", 71, 24, 700, False)
+    fixture_skeleton_projection("skelproj_chain8_m90_K", 72, 8, 90, True, chain=True)
     fixture_state_dict_layout()

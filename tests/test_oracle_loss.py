@@ -22,3 +22,45 @@ def test_gradients_match_reference_autograd():
         assert np.abs(g - G[key]).max() <= 2e-5 * np.abs(G[key]).max(), key
     # exact zero of the L1 gradient where image == gt (torch.abs backward), flat black region handled
     assert (G["grad_l1"][:, -3:, :] == 0).all() and (O.grad(G["image"], G["gt"], 1.0, 0.0)[:, -3:, :] == 0).all()
+
+
+# ---- skeleton projection loss: the reference's own sampling / projection / composition (chamfer factor restated) ----------
+SKEL = ["skelproj_tree24_m700", "skelproj_chain8_m90_K"]
+
+
+def _skel(name):
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    intr = O.intrinsics(float(z["FoVx"]), float(z["FoVy"]), int(z["image_height"]), int(z["image_width"]), z["K"])
+    return z, intr
+
+
+def test_skeleton_sampling_and_projection_match_reference():
+    for name in SKEL:
+        z, intr = _skel(name)
+        t = O.sampling_steps(z["d_nodes"], z["parents"])
+        assert len(t) == int(z["steps"])
+        pts = O.sampling_skeleton_points(z["d_nodes"], z["parents"], t)
+        assert np.abs(pts - z["sampling_points"]).max() < 2e-7
+        proj = O.project_nodes(z["sampling_points"], z["world_view_transform"], *intr)
+        assert np.abs(proj - z["projected"]).max() < 5e-5  # float32 pixels of O(100) in the fixture
+
+
+def test_skeleton_projection_loss_and_gradient_match_reference_autograd():
+    for name in SKEL:
+        z, intr = _skel(name)
+        loss, g = O.skeleton_projection_loss(z["d_nodes"], z["parents"], z["world_view_transform"], *intr, z["thinned"])
+        assert abs(loss - float(z["loss"])) < 1e-5 * float(z["loss"])
+        assert np.abs(g - z["grad_nodes"]).max() <= 1e-5 * np.abs(z["grad_nodes"]).max()
+
+
+def test_skeleton_projection_gradient_is_the_derivative_of_the_loss():
+    z, intr = _skel(SKEL[1])
+    t = O.sampling_steps(z["d_nodes"], z["parents"])
+    nodes = z["d_nodes"].astype(np.float64)
+    _, g = O.skeleton_projection_loss(nodes, z["parents"], z["world_view_transform"], *intr, z["thinned"], t=t)
+    rng = np.random.default_rng(0)
+    d = rng.standard_normal(nodes.shape)
+    h = 1e-7  # small enough that no nearest neighbour changes (piecewise-linear loss)
+    lp, _ = O.skeleton_projection_loss(nodes + h * d, z["parents"], z["world_view_transform"], *intr, z["thinned"], t=t)
+    lm, _ = O.skeleton_projection_loss(nodes - h * d, z["parents"], z["world_view_transform"], *intr, z["thinned"], t=t)
+    assert abs((lp - lm) / (2 * h) - (g * d).sum()) < 1e-3 * abs((g * d).sum())
