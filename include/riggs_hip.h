@@ -283,6 +283,38 @@ int riggs_skeleton_projection_backward(int32_t J, int32_t S, int32_t M, const in
                                        riggs_stream stream);
 
 /* =====================================================================
+ * Stage-1 control-node deformation, per-Gaussian part: ControlNodeWarp.cal_nn_weight
+ * (utils/time_utils.py:934-964) + the blend of ControlNodeWarp.forward (:1138-1191) for skinning = False,
+ * node_trans_bias = None, pred_opacity = pred_color = False.  pytorch3d.ops.knn_points (third-party) is restated as
+ * "K smallest squared distances, ascending, ties to the lowest index".
+ * x (N, 3); feature (N, feat_stride), its first `hyper` columns are the hyper coordinates (NULL and hyper = 0: xyz only);
+ * motion_mask (N) or NULL (= 1); nodes (M, node_stride) = xyz then hyper coordinates; node_radius_log = _node_radius,
+ * node_weight_logit = _node_weight (NULL: with_node_weight = False); node_trans / node_rot / node_scale / local_rot are the
+ * node network's d_xyz (M, 3), d_rotation (M, 4), d_scaling (M, 3), local_rotation (M, 4; raw, (1,0,0,0) is added inside).
+ * flags: 1 = local_frame, 2 = d_rot_as_res.  K <= 8, hyper <= 11, M (3 + hyper rounded up to 4) floats <= 128 KB.
+ * forward writes d_xyz, d_rotation, d_scaling and cal_nn_weight's nn_idx (int32), nn_weight, nn_dist (N, K).
+ * backward takes upstream gradients (each may be NULL = 0) and writes the gradients of feature (N, feat_stride; columns
+ * beyond `hyper` zero), motion_mask, the node attributes, _node_radius, _node_weight and the nodes' hyper coordinates
+ * (M, hyper); xyz of Gaussians and nodes are detached in the reference (:944, :947-949, :1152).  workspace:
+ * riggs_cnode_backward_workspace_floats floats.
+ * ===================================================================== */
+int riggs_cnode_backward_blocks(int32_t N);
+size_t riggs_cnode_backward_workspace_floats(int32_t N, int32_t M, int32_t hyper);
+int riggs_cnode_forward(int32_t N, int32_t M, int32_t K, int32_t hyper, int32_t feat_stride, int32_t node_stride, int32_t flags,
+                        const float* x, const float* feature, const float* motion_mask, const float* nodes,
+                        const float* node_radius_log, const float* node_weight_logit, const float* node_trans,
+                        const float* node_rot, const float* node_scale, const float* local_rot, float* d_xyz, float* d_rot,
+                        float* d_scale, int32_t* nn_idx, float* nn_weight, float* nn_dist, riggs_stream stream);
+int riggs_cnode_backward(int32_t N, int32_t M, int32_t K, int32_t hyper, int32_t feat_stride, int32_t node_stride, int32_t flags,
+                         const float* x, const float* feature, const float* motion_mask, const float* nodes,
+                         const float* node_radius_log, const float* node_weight_logit, const float* node_trans,
+                         const float* node_rot, const float* node_scale, const float* local_rot, const int32_t* nn_idx,
+                         const float* nn_dist, const float* g_xyz, const float* g_rot, const float* g_scale,
+                         float* g_feature, float* g_motion_mask, float* g_node_trans, float* g_node_rot, float* g_node_scale,
+                         float* g_local_rot, float* g_node_radius_log, float* g_node_weight_logit, float* g_nodes_hyper,
+                         float* workspace, riggs_stream stream);
+
+/* =====================================================================
  * simple_knn._C.distCUDA2 (scene/gaussian_model.py:20,170): mean squared distance to the 3
  * nearest neighbours.  points (P,3) -> out (P,).  workspace: riggs_knn_workspace_bytes(P).
  * ===================================================================== */

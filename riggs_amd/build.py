@@ -24,6 +24,7 @@ SOURCES = {
     "optim.hip": ["-ffp-contract=off"],
     "loss.hip": ["-ffp-contract=fast"],
     "skel_loss.hip": ["-ffp-contract=off"],
+    "cnode.hip": ["-ffp-contract=off"],
     "mlp.hip": ["-ffp-contract=fast"],
     "capi.hip": [],
 }

@@ -342,6 +342,68 @@ def fixture_skeleton_projection(name, seed, J, M, from_K, chain=False):
     print("wrote", name, "steps", out["steps"], "points", pts.shape[0], "loss", out["loss"])
 
 
+def knn_points_published(p1, p2, lengths1=None, lengths2=None, K=1, **kw):
+    """Stand-in for pytorch3d.ops.knn_points (not vendored, not installed): the published contract — for every point of p1 the
+    K nearest points of p2 by SQUARED Euclidean distance, ascending; returns (dists, idx, None).  "Parity unpinned" for this
+    factor; everything around it in the fixture is the reference's own code."""
+    d = ((p1[0][:, None, :] - p2[0][None, :, :]) ** 2).sum(-1)
+    dist, idx = d.topk(K, dim=1, largest=False, sorted=True)
+    return dist[None], idx[None], None
+
+
+def fixture_control_nodes(name, seed, N, M, K, hyper, local_frame, d_rot_as_res, with_node_weight, mask_random=False):
+    """§8-f rank 4 (second half): ControlNodeWarp.forward (utils/time_utils.py:1133-1236) = cal_nn_weight (:934-964) + the
+    per-Gaussian blend of the node deformations, with autograd's gradients w.r.t. every differentiable input.  The node
+    network is bypassed through the reference's own ``animation_d_values`` hook (:1141-1144): the fixture supplies the node
+    attributes a network would predict."""
+    import pytorch3d.ops as p3o
+    import pytorch3d as p3
+    p3o.knn_points = knn_points_published
+    p3.ops = p3o
+    with S.quiet():
+        from utils.time_utils import ControlNodeWarp
+        cn = ControlNodeWarp(is_blender=True, node_num=M, K=K, with_node_weight=with_node_weight, local_frame=local_frame,
+                             d_rot_as_res=d_rot_as_res, hyper_dim=hyper, is_scene_static=True)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, 3, generator=g) * 0.5
+    pick = torch.randint(0, N, (M,), generator=g)
+    nodes = torch.cat([x[pick] + 0.05 * torch.randn(M, 3, generator=g), 1e-2 + 0.02 * torch.randn(M, hyper, generator=g)], -1)
+    cn.nodes = torch.nn.Parameter(nodes)
+    cn._node_radius = torch.nn.Parameter(math.log(0.15) + 0.3 * torch.randn(M, generator=g))
+    if with_node_weight:
+        cn._node_weight = torch.nn.Parameter(0.5 * torch.randn(M, 1, generator=g))
+    feature = (0.02 * torch.randn(N, hyper + 1, generator=g)).requires_grad_(True) if hyper > 0 else None
+    mask = torch.rand(N, 1, generator=g) if mask_random else torch.ones(N, 1)
+    mask = mask.requires_grad_(True)
+    attrs = {"d_xyz": 0.1 * torch.randn(M, 3, generator=g), "d_rotation": 0.2 * torch.randn(M, 4, generator=g),
+             "d_scaling": 0.05 * torch.randn(M, 3, generator=g), "local_rotation": 0.3 * torch.randn(M, 4, generator=g)}
+    attrs = {k: v.requires_grad_(True) for k, v in attrs.items()}
+    cn.train()
+    out = cn(x, torch.tensor(0.3), feature, mask, animation_d_values=attrs)
+    go = {k: torch.randn(out[k].shape, generator=g) for k in ("d_xyz", "d_rotation", "d_scaling", "d_nodes")}
+    sum((out[k] * go[k]).sum() for k in go).backward()
+    nn_weight, nn_dist, nn_idx = cn.cal_nn_weight(x=x, feature=feature)
+    z = dict(x=np_(x), nodes=np_(nodes), _node_radius=np_(cn._node_radius), feature=(np_(feature) if feature is not None else np.zeros((0, 0), np.float32)),
+             motion_mask=np_(mask), K=K, hyper_dim=hyper, local_frame=local_frame, d_rot_as_res=d_rot_as_res,
+             with_node_weight=with_node_weight, nn_idx=nn_idx.numpy().astype(np.int32), nn_weight=np_(nn_weight), nn_dist=np_(nn_dist))
+    if with_node_weight:
+        z["_node_weight"] = np_(cn._node_weight)
+        z["grad__node_weight"] = np_(cn._node_weight.grad)
+    for k, v in attrs.items():
+        z["attr_" + k] = np_(v)
+        z["grad_attr_" + k] = np_(v.grad) if v.grad is not None else np.zeros(v.shape, np.float32)
+    for k in go:
+        z["out_" + k] = np_(out[k])
+        z["gout_" + k] = np_(go[k])
+    z["grad_nodes"] = np_(cn.nodes.grad)
+    z["grad__node_radius"] = np_(cn._node_radius.grad)
+    z["grad_motion_mask"] = np_(mask.grad)
+    if feature is not None:
+        z["grad_feature"] = np_(feature.grad)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **z)
+    print("wrote", name, {k: float(np.abs(v).max()) for k, v in z.items() if k.startswith("grad_")})
+
+
 def seeded_heads(J, WeightCls, DeformCls, seed):
     """The two per-Gaussian MLP heads with reproducible weights (the fixture stores checksums, not 4 MB of weights):
     constructed standalone, in this order, right after torch.manual_seed(seed)."""
@@ -414,5 +476,8 @@ if __name__ == "__main__":
     fixture_loss("loss_l1_ssim", 51, 3, 37, 45)
     fixture_deform_heads("heads_tree12_n200", 61, 12, 200)
     fixture_skeleton_projection("skelproj_tree24_m700", 71, 24, 700, False)
+    fixture_control_nodes("cnodes_local_res_h8", 81, 400, 64, 3, 8, True, True, True, mask_random=True)
+    fixture_control_nodes("cnodes_global_abs_h0", 82, 257, 40, 4, 0, False, False, False)
+    fixture_control_nodes("cnodes_default_h8", 83, 300, 128, 3, 8, False, True, True)
     fixture_skeleton_projection("skelproj_chain8_m90_K", 72, 8, 90, True, chain=True)
     fixture_state_dict_layout()

@@ -1,0 +1,131 @@
+"""§8-f rank 4 (second half) on the GPU: the stage-1 control-node deformation against the reference's goldens and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ["cnodes_local_res_h8", "cnodes_global_abs_h0", "cnodes_default_h8"]
+ATTRS = ("d_xyz", "d_rotation", "d_scaling", "local_rotation")
+OUTS = ("d_xyz", "d_rotation", "d_scaling", "d_nodes")
+
+
+def _module(z):
+    from riggs_amd.control_nodes import ControlNodeWarp
+    cn = ControlNodeWarp(node_num=z["nodes"].shape[0], K=int(z["K"]), with_node_weight=bool(z["with_node_weight"]),
+                         local_frame=bool(z["local_frame"]), d_rot_as_res=bool(z["d_rot_as_res"]), hyper_dim=int(z["hyper_dim"])).cuda()
+    cn.nodes.data = torch.from_numpy(z["nodes"]).cuda()
+    cn._node_radius.data = torch.from_numpy(z["_node_radius"]).cuda()
+    if bool(z["with_node_weight"]):
+        cn._node_weight.data = torch.from_numpy(z["_node_weight"]).cuda()
+    return cn
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_module_matches_reference_golden(name):
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    cn = _module(z)
+    x = torch.from_numpy(z["x"]).cuda()
+    feature = torch.from_numpy(z["feature"]).cuda().requires_grad_(True) if z["feature"].size else None
+    mask = torch.from_numpy(z["motion_mask"]).cuda().requires_grad_(True)
+    attrs = {k: torch.from_numpy(z["attr_" + k]).cuda().requires_grad_(True) for k in ATTRS}
+    out = cn(x, torch.tensor(0.3, device="cuda"), feature, mask, animation_d_values=attrs)
+    assert torch.equal(out["nn_idx"].cpu(), torch.from_numpy(z["nn_idx"]))          # index work: exact
+    assert np.abs(out["nn_weight"].cpu().numpy() - z["nn_weight"]).max() < 2e-6
+    for k in OUTS:
+        assert np.abs(out[k].detach().cpu().numpy() - z["out_" + k]).max() <= 1e-5 * max(1.0, np.abs(z["out_" + k]).max()), k
+    sum((out[k] * torch.from_numpy(z["gout_" + k]).cuda()).sum() for k in OUTS).backward()
+    got = {"attr_" + k: v.grad for k, v in attrs.items()}
+    got.update(nodes=cn.nodes.grad, _node_radius=cn._node_radius.grad, motion_mask=mask.grad)
+    if feature is not None:
+        got["feature"] = feature.grad
+    if bool(z["with_node_weight"]):
+        got["_node_weight"] = cn._node_weight.grad
+    for k, g in got.items():
+        ref = z["grad_" + k]
+        if g is None:
+            assert np.abs(ref).max() == 0, k
+            continue
+        err = np.abs(g.cpu().numpy().reshape(ref.shape) - ref).max()
+        assert err <= 1e-4 * max(np.abs(ref).max(), 1.0), (k, err)
+
+
+@pytest.mark.parametrize("N,M,K,hyper,local,res,nw,use_mask", [
+    (20_000, 512, 3, 8, True, True, True, True),      # the shipped shape of stage 1
+    (5_000, 1024, 3, 8, False, True, True, False),    # arguments/__init__.py defaults (node_num 1024, local_frame False)
+    (3_001, 40, 8, 0, True, False, False, True),      # K = 8, xyz only, absolute rotation
+    (257, 5, 5, 2, False, False, True, False),        # K = M
+    (1, 64, 3, 11, True, True, False, True),          # one Gaussian, widest hyper
+])
+def test_against_oracle(N, M, K, hyper, local, res, nw, use_mask):
+    from oracle import cnode_ref as O
+    from riggs_amd.control_nodes import control_node_blend
+    g = torch.Generator().manual_seed(N + M)
+    x = torch.randn(N, 3, generator=g) * 0.5
+    nodes = torch.cat([x[torch.randint(0, N, (M,), generator=g)] + 0.05 * torch.randn(M, 3, generator=g),
+                       1e-2 + 0.02 * torch.randn(M, hyper, generator=g)], -1)
+    feature = 0.02 * torch.randn(N, hyper + 1, generator=g) if hyper else None
+    mask = torch.rand(N, 1, generator=g) if use_mask else None
+    radius = np.log(0.15) + 0.3 * torch.randn(M, generator=g)
+    weight = 0.5 * torch.randn(M, 1, generator=g) if nw else None
+    attrs = {"d_xyz": 0.1 * torch.randn(M, 3, generator=g), "d_rotation": 0.2 * torch.randn(M, 4, generator=g),
+             "d_scaling": 0.05 * torch.randn(M, 3, generator=g), "local_rotation": 0.3 * torch.randn(M, 4, generator=g)}
+    gout = {k: torch.randn(N, w, generator=g) for k, w in (("d_xyz", 3), ("d_rotation", 4), ("d_scaling", 3))}
+    cu = lambda t: None if t is None else t.cuda().requires_grad_(True)  # noqa: E731
+    c_feat, c_mask, c_nodes, c_rad, c_w = cu(feature), cu(mask), cu(nodes), cu(radius), cu(weight)
+    c_attrs = {k: cu(v) for k, v in attrs.items()}
+    out = control_node_blend(x.cuda(), c_feat, c_mask, c_nodes, c_rad, c_w, c_attrs, K=K, hyper_dim=hyper, local_frame=local,
+                             d_rot_as_res=res)
+    sum((out[k] * gout[k].cuda()).sum() for k in gout).backward()
+    npy = lambda t: None if t is None else t.numpy()  # noqa: E731
+    cfg = dict(K=K, hyper_dim=hyper, local_frame=local, d_rot_as_res=res)
+    m_np = npy(mask) if mask is not None else np.ones((N, 1), np.float32)
+    a_np = {k: v.numpy() for k, v in attrs.items()}
+    ref = O.forward(x.numpy(), npy(feature), m_np, nodes.numpy(), radius.numpy(), npy(weight), a_np, **cfg)
+    idx = out["nn_idx"].cpu().numpy()
+    same = (idx == ref["nn_idx"]).all(1)
+    assert same.mean() > 0.999  # float32 vs float64 near-ties of the K-th neighbour may swap; everything else: exact
+    for k in gout:
+        err = np.abs(out[k].detach().cpu().numpy() - ref[k])[same].max()
+        assert err <= 1e-5 * max(1.0, np.abs(ref[k]).max()), (k, err)
+    if not same.all():
+        return  # gradients are sums over Gaussians: only comparable when every neighbour list agrees
+    go = {k: v.numpy() for k, v in gout.items()}
+    go["d_nodes"] = np.zeros((M, 3), np.float32)
+    gref = O.backward(x.numpy(), npy(feature), m_np, nodes.numpy(), radius.numpy(), npy(weight), a_np, gout=go, **cfg)
+    got = dict(c_attrs)
+    got.update(nodes=c_nodes, _node_radius=c_rad)
+    if weight is not None:
+        got["_node_weight"] = c_w
+    if feature is not None:
+        got["feature"] = c_feat
+    if mask is not None:
+        got["motion_mask"] = c_mask
+    for k, t in got.items():
+        if k == "local_rotation" and not local:
+            assert t.grad is None or float(t.grad.abs().max()) == 0
+            continue
+        r = gref[k]
+        err = np.abs(t.grad.cpu().numpy().reshape(r.shape) - r).max()
+        assert err <= 2e-4 * max(np.abs(r).max(), 1.0), (k, err, np.abs(r).max())
+
+
+def test_no_feature_means_xyz_only_and_unsupported_options_raise():
+    from riggs_amd import _lib as L
+    from riggs_amd.control_nodes import ControlNodeWarp, control_node_blend
+    cn = ControlNodeWarp(node_num=32, K=3, hyper_dim=4).cuda()
+    x = torch.randn(100, 3, device="cuda")
+    out = cn(x, torch.tensor(0.1, device="cuda"), None, 1.0)
+    d = ((x[:, None] - cn.nodes[None, :, :3]) ** 2).sum(-1)
+    assert torch.equal(out["nn_idx"].long(), d.topk(3, dim=1, largest=False).indices)
+    assert float(out["d_xyz"].detach().abs().max()) == 0 and out["d_nodes"].shape == (32, 3)   # static network: zero deformation
+    with pytest.raises(NotImplementedError):
+        ControlNodeWarp(skinning=True)
+    with pytest.raises(NotImplementedError):
+        cn(x, torch.tensor(0.1, device="cuda"), None, 1.0, node_trans_bias=torch.zeros(32, 3, device="cuda"))
+    with pytest.raises(L.RiggsHipError):
+        control_node_blend(x.cpu(), None, None, cn.nodes, cn._node_radius, None, cn.node_deform(torch.zeros(32, 1, device="cuda")))
+    with pytest.raises(L.RiggsHipError):  # K > 8
+        control_node_blend(x, None, None, cn.nodes, cn._node_radius, None, cn.node_deform(torch.zeros(32, 1, device="cuda")), K=9)
