@@ -129,3 +129,82 @@ def test_no_feature_means_xyz_only_and_unsupported_options_raise():
         control_node_blend(x.cpu(), None, None, cn.nodes, cn._node_radius, None, cn.node_deform(torch.zeros(32, 1, device="cuda")))
     with pytest.raises(L.RiggsHipError):  # K > 8
         control_node_blend(x, None, None, cn.nodes, cn._node_radius, None, cn.node_deform(torch.zeros(32, 1, device="cuda")), K=9)
+
+
+class _NodeNet(torch.nn.Module):
+    """A small stand-in for the reference's DeformNetwork (nodes, t -> per-node attributes); stage-1's node network is a
+    torch module supplied by the caller."""
+
+    def __init__(self):
+        super().__init__()
+        self.body = torch.nn.Sequential(torch.nn.Linear(4, 32), torch.nn.ReLU(), torch.nn.Linear(32, 14))
+
+    def forward(self, x, t, **kw):
+        o = self.body(torch.cat([x, t], -1)) * torch.tensor([.05] * 3 + [.1] * 4 + [.02] * 3 + [.2] * 4, device=x.device)
+        return {"d_xyz": o[:, :3], "d_rotation": o[:, 3:7], "d_scaling": o[:, 7:10], "local_rotation": o[:, 10:14],
+                "hidden": None, "d_opacity": None, "d_color": None}
+
+
+def _torch_blend(cn, x, feature, mask, attrs):
+    """ControlNodeWarp.forward's arithmetic in torch ops (time_utils.py:934-964, 1138-1191), differentiable by autograd."""
+    h = cn.hyper_dim
+    xa = torch.cat([x, feature[:, :h]], -1)
+    na = torch.cat([cn.nodes[:, :3].detach(), cn.nodes[:, 3:]], -1)
+    d, idx = ((xa[:, None] - na[None]) ** 2).sum(-1).topk(cn.K, dim=1, largest=False)
+    w = torch.exp(-d / (2 * cn.node_radius[idx] ** 2)) * cn.node_weight[idx][..., 0] + 1e-7
+    w = w / w.sum(-1, keepdim=True)
+    q = attrs["local_rotation"] + torch.tensor([1.0, 0, 0, 0], device=x.device)
+    r, i, j, k = torch.unbind(q, -1)
+    s = 2.0 / (q * q).sum(-1)
+    R = torch.stack((1 - s * (j * j + k * k), s * (i * j - k * r), s * (i * k + j * r), s * (i * j + k * r),
+                     1 - s * (i * i + k * k), s * (j * k - i * r), s * (i * k - j * r), s * (j * k + i * r),
+                     1 - s * (i * i + j * j)), -1).reshape(-1, 3, 3)
+    nn_ = cn.nodes[idx, :3].detach()
+    Ax = torch.einsum("nkab,nkb->nka", R[idx], x[:, None] - nn_) + nn_ + attrs["d_xyz"][idx]
+    return {"d_xyz": ((Ax * w[..., None]).sum(1) - x) * mask, "d_rotation": (attrs["d_rotation"][idx] * w[..., None]).sum(1) * mask,
+            "d_scaling": (attrs["d_scaling"][idx] * w[..., None]).sum(1) * mask}
+
+
+def test_stage1_iteration_through_the_rasterizer_matches_torch_blend():
+    """deform (control nodes) -> render -> image loss -> backward: the gradients that reach the node network, the nodes, the
+    radii / weights and the Gaussians' hyper feature agree with the same chain whose blend is written in torch ops."""
+    from riggs_amd import synth
+    from riggs_amd.control_nodes import ControlNodeWarp
+    from riggs_amd.gaussian_model import GaussianModel
+    from riggs_amd.graph import _Pipe
+    from riggs_amd.loss import image_loss
+    from riggs_amd.render import render
+    N, M, H = 6_000, 96, 8
+    sc = synth.make_scene(N, 8, 7)
+    cam = synth.look_at_camera(96, 96, fid=0.4).to("cuda")
+    gm = GaussianModel.from_tensors(sc["xyz"], sc["features_dc"], sc["features_rest"], sc["scaling"], sc["rotation"],
+                                    sc["opacity"], device="cuda")
+    gm.fea_dim, gm.with_motion_mask = H + 1, True
+    torch.manual_seed(5)
+    gm.feature = torch.nn.Parameter(torch.cat([0.02 * torch.randn(N, H), 2.0 + torch.randn(N, 1)], -1).cuda())
+    cn = ControlNodeWarp(node_num=M, K=3, local_frame=True, d_rot_as_res=True, hyper_dim=H, network=_NodeNet()).cuda()
+    with torch.no_grad():
+        cn.nodes.copy_(torch.cat([gm.get_xyz[torch.randperm(N)[:M].cuda()], 1e-2 + 0.02 * torch.randn(M, H, device="cuda")], -1))
+        cn._node_radius.fill_(float(np.log(0.2)))
+        cn._node_weight.copy_(0.3 * torch.randn(M, 1))
+    target = torch.rand(3, 96, 96, device="cuda")
+    bg = torch.zeros(3, device="cuda")
+    leaves = {"net": list(cn.network.parameters())[0], "nodes": cn.nodes, "radius": cn._node_radius, "weight": cn._node_weight,
+              "feature": gm.feature, "xyz": gm._xyz}
+    res = {}
+    for which in ("hip", "torch"):
+        for t in list(leaves.values()) + list(cn.network.parameters()):
+            t.grad = None
+        tt = torch.tensor(0.4, device="cuda")
+        if which == "hip":
+            dv = cn(gm.get_xyz.detach(), tt, gm.feature, gm.motion_mask)
+        else:
+            dv = _torch_blend(cn, gm.get_xyz.detach(), gm.feature, gm.motion_mask, cn.node_deform(cn.expand_time(tt)))
+        pkg = render(cam, gm, _Pipe, bg, dv["d_xyz"], dv["d_rotation"], dv["d_scaling"], d_rot_as_res=True)
+        loss, _ = image_loss(pkg["render"], target, 0.2)
+        loss.backward()
+        res[which] = (loss.item(), {k: v.grad.clone() for k, v in leaves.items()})
+    assert abs(res["hip"][0] - res["torch"][0]) <= 1e-5 * res["torch"][0]
+    for k, g in res["torch"][1].items():
+        err = (res["hip"][1][k] - g).abs().max().item()
+        assert g.abs().max().item() > 0 and err <= 2e-3 * g.abs().max().item(), (k, err, g.abs().max().item())
