@@ -298,7 +298,7 @@ int riggs_skeleton_projection_backward(int32_t J, int32_t S, int32_t M, const in
  * (M, hyper); xyz of Gaussians and nodes are detached in the reference (:944, :947-949, :1152).  workspace:
  * riggs_cnode_backward_workspace_floats floats.
  * ===================================================================== */
-int riggs_cnode_backward_blocks(int32_t N);
+int riggs_cnode_backward_blocks(int32_t N, int32_t M, int32_t hyper);
 size_t riggs_cnode_backward_workspace_floats(int32_t N, int32_t M, int32_t hyper);
 int riggs_cnode_forward(int32_t N, int32_t M, int32_t K, int32_t hyper, int32_t feat_stride, int32_t node_stride, int32_t flags,
                         const float* x, const float* feature, const float* motion_mask, const float* nodes,

@@ -156,11 +156,12 @@ __global__ void __launch_bounds__(256) cnode_forward_kernel(CNodeArgs a) {
 // accumulator columns of a node: [0:3] translation, [3:7] rotation, [7:10] scale, [10:19] dL/dR (row-major), [19] radius,
 // [20] node weight (before the sigmoid's derivative), [21:21+hyper] hyper coordinates
 #define CN_ACC_FIXED 21
-#define CN_BWD_THREADS 512
+#define CN_BWD_THREADS 1024
 
+template <int K>
 __global__ void __launch_bounds__(CN_BWD_THREADS) cnode_backward_kernel(CNodeArgs a) {
   extern __shared__ float s_acc[];  // (M, nacc)
-  const int K = a.K, nacc = a.nacc;
+  const int nacc = a.nacc;
   for (int e = threadIdx.x; e < a.M * nacc; e += CN_BWD_THREADS) s_acc[e] = 0.f;
   __syncthreads();
   const bool local = a.flags & CN_LOCAL_FRAME;
@@ -173,12 +174,12 @@ __global__ void __launch_bounds__(CN_BWD_THREADS) cnode_backward_kernel(CNodeArg
     if (a.g_scale) { s[0] = a.g_scale[3 * (size_t)i]; s[1] = a.g_scale[3 * (size_t)i + 1]; s[2] = a.g_scale[3 * (size_t)i + 2]; }
     const float x0 = a.x[3 * (size_t)i], x1 = a.x[3 * (size_t)i + 1], x2 = a.x[3 * (size_t)i + 2];
     // pass 1: weights and dL/dw
-    float w[CN_KMAX], u[CN_KMAX], e_[CN_KMAX], r2_[CN_KMAX], dw[CN_KMAX];
+    float w[K], u[K], e_[K], r2_[K], dw[K];
     float vsum = 0.f;
     float ts[3] = {0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f}, ss[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < CN_KMAX; ++k) {
-      if (k < K) {
+    for (int k = 0; k < K; ++k) {
+      {
         const int n = a.nn_idx[(size_t)i * K + k];
         float nw;
         cn_kernel_weight(a, n, a.nn_dist[(size_t)i * K + k], e_[k], nw, r2_[k]);
@@ -188,8 +189,8 @@ __global__ void __launch_bounds__(CN_BWD_THREADS) cnode_backward_kernel(CNodeArg
     }
     float wdw = 0.f;
 #pragma unroll
-    for (int k = 0; k < CN_KMAX; ++k) {
-      if (k < K) {
+    for (int k = 0; k < K; ++k) {
+      {
         const int n = a.nn_idx[(size_t)i * K + k];
         w[k] = (u[k] + 1e-7f) / vsum;
         float y0 = a.trans[3 * n], y1 = a.trans[3 * n + 1], y2 = a.trans[3 * n + 2];
@@ -234,8 +235,8 @@ __global__ void __launch_bounds__(CN_BWD_THREADS) cnode_backward_kernel(CNodeArg
 #pragma unroll
     for (int d = 0; d < 13; ++d) gf[d] = 0.f;
 #pragma unroll
-    for (int k = 0; k < CN_KMAX; ++k) {
-      if (k < K) {
+    for (int k = 0; k < K; ++k) {
+      {
         const int n = a.nn_idx[(size_t)i * K + k];
         const float dist = a.nn_dist[(size_t)i * K + k];
         const float dv = (dw[k] - wdw) / vsum;
@@ -279,8 +280,22 @@ __global__ void __launch_bounds__(256) cnode_finish_kernel(CNodeArgs a, CNodeGra
   const int nl = threadIdx.x >> 5, c = threadIdx.x & 31;
   const int n = blockIdx.x * 8 + nl;
   float v = 0.f;
-  if (n < a.M && c < a.nacc)
-    for (int b = 0; b < blocks; ++b) v += a.partial[((size_t)b * a.M + n) * a.nacc + c];
+  if (n < a.M && c < a.nacc) {
+    // four interleaved accumulators, eight loads in flight: a fixed order, but not one load latency per term
+    float v4[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* src = a.partial + (size_t)n * a.nacc + c;
+    const size_t step = (size_t)a.M * a.nacc;
+    int b = 0;
+    for (; b + 8 <= blocks; b += 8) {
+      float t[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t[q] = src[(size_t)(b + q) * step];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v4[q & 3] += t[q];
+    }
+    for (; b < blocks; ++b) v4[b & 3] += src[(size_t)b * step];
+    v = (v4[0] + v4[1]) + (v4[2] + v4[3]);
+  }
   s_v[nl][c] = v;
   __syncthreads();
   if (n >= a.M) return;
@@ -343,13 +358,15 @@ using namespace riggs;
 
 extern "C" {
 
-int riggs_cnode_backward_blocks(int32_t N) {
+// workgroups of the persistent backward grid: one per CU, two where two gradient tables fit a CU's LDS
+int riggs_cnode_backward_blocks(int32_t N, int32_t M, int32_t hyper) {
   const int want = (N + CN_BWD_THREADS - 1) / CN_BWD_THREADS;
-  return want < 1 ? 1 : (want > 256 ? 256 : want);
+  const int cap = (size_t)M * (CN_ACC_FIXED + hyper) * sizeof(float) <= 78 * 1024 ? 512 : 256;
+  return want < 1 ? 1 : (want > cap ? cap : want);
 }
 
 size_t riggs_cnode_backward_workspace_floats(int32_t N, int32_t M, int32_t hyper) {
-  return (size_t)riggs_cnode_backward_blocks(N) * M * (CN_ACC_FIXED + hyper);
+  return (size_t)riggs_cnode_backward_blocks(N, M, hyper) * M * (CN_ACC_FIXED + hyper);
 }
 
 int riggs_cnode_forward(int32_t N, int32_t M, int32_t K, int32_t hyper, int32_t feat_stride, int32_t node_stride, int32_t flags,
@@ -419,11 +436,22 @@ int riggs_cnode_backward(int32_t N, int32_t M, int32_t K, int32_t hyper, int32_t
   hipStream_t s = (hipStream_t)stream;
   static bool attr_set = false;
   if (!attr_set) {
-    RIGGS_HIP_CHECK(hipFuncSetAttribute((const void*)cnode_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define CN_BATTR(KK) RIGGS_HIP_CHECK(hipFuncSetAttribute((const void*)cnode_backward_kernel<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CN_BATTR(1) CN_BATTR(2) CN_BATTR(3) CN_BATTR(4) CN_BATTR(5) CN_BATTR(6) CN_BATTR(7) CN_BATTR(8)
     attr_set = true;
   }
-  const int blocks = riggs_cnode_backward_blocks(N);
-  hipLaunchKernelGGL(cnode_backward_kernel, dim3(blocks), dim3(CN_BWD_THREADS), lds, s, a);
+  const int blocks = riggs_cnode_backward_blocks(N, M, hyper);
+  const dim3 grid(blocks), block(CN_BWD_THREADS);
+  switch (K) {
+    case 1: hipLaunchKernelGGL(cnode_backward_kernel<1>, grid, block, lds, s, a); break;
+    case 2: hipLaunchKernelGGL(cnode_backward_kernel<2>, grid, block, lds, s, a); break;
+    case 3: hipLaunchKernelGGL(cnode_backward_kernel<3>, grid, block, lds, s, a); break;
+    case 4: hipLaunchKernelGGL(cnode_backward_kernel<4>, grid, block, lds, s, a); break;
+    case 5: hipLaunchKernelGGL(cnode_backward_kernel<5>, grid, block, lds, s, a); break;
+    case 6: hipLaunchKernelGGL(cnode_backward_kernel<6>, grid, block, lds, s, a); break;
+    case 7: hipLaunchKernelGGL(cnode_backward_kernel<7>, grid, block, lds, s, a); break;
+    default: hipLaunchKernelGGL(cnode_backward_kernel<8>, grid, block, lds, s, a); break;
+  }
   CNodeGrads o = {g_node_trans, g_node_rot, g_node_scale, g_local_rot, g_node_radius_log,
                   node_weight_logit ? g_node_weight_logit : nullptr, g_nodes_hyper};
   hipLaunchKernelGGL(cnode_finish_kernel, dim3((M + 7) / 8), dim3(256), 0, s, a, o, blocks);
