@@ -113,6 +113,58 @@ def heads_timing(sc, gm, iters=5):
             "ms_fp32_gemms": round(res[False] * 1e3, 3), "ms_fused_bf16_mfma": round(res[True] * 1e3, 3)}
 
 
+def next_rows_timing(sc, gm, cam, iters=20):
+    """Secondary numbers (NOT the metric) for two more SURVEY.md §8-f rows: the stage-1 control-node deformation (rank 4) and
+    the skeleton projection loss (rank 2), forward + backward each, eager launches timed with events."""
+    from riggs_amd.control_nodes import control_node_blend
+    from riggs_amd.loss import cal_skeleton_loss, sampling_steps
+    dev = gm.get_xyz.device
+    x = gm.get_xyz.detach()
+    N, M, H, K = x.shape[0], 512, 8, 3
+    g = torch.Generator().manual_seed(3)
+    P = lambda t: t.to(dev).requires_grad_(True)  # noqa: E731
+    nodes = P(torch.cat([x[torch.randint(0, N, (M,), generator=g).to(dev)].cpu(), 1e-2 + 0.02 * torch.randn(M, H, generator=g)], -1))
+    feature, mask = P(0.02 * torch.randn(N, H + 1, generator=g)), P(torch.rand(N, 1, generator=g))
+    radius, weight = P(-1.9 + 0.3 * torch.randn(M, generator=g)), P(0.5 * torch.randn(M, 1, generator=g))
+    attrs = {"d_xyz": P(0.1 * torch.randn(M, 3, generator=g)), "d_rotation": P(0.2 * torch.randn(M, 4, generator=g)),
+             "d_scaling": P(0.05 * torch.randn(M, 3, generator=g)), "local_rotation": P(0.3 * torch.randn(M, 4, generator=g))}
+    go = [torch.randn(N, w, device=dev) for w in (3, 4, 3)]
+    leaves = [nodes, feature, mask, radius, weight] + list(attrs.values())
+
+    def stage1():
+        for t in leaves:
+            t.grad = None
+        o = control_node_blend(x, feature, mask, nodes, radius, weight, attrs, K=K, hyper_dim=H, local_frame=True, d_rot_as_res=True)
+        torch.autograd.backward([o["d_xyz"], o["d_rotation"], o["d_scaling"]], go)
+
+    cam.thinned = torch.stack([torch.randint(150, 650, (1500,), generator=g), torch.randint(150, 650, (1500,), generator=g)], -1).float().to(dev)
+    joints = P(sc["joints"].clone())
+    parents = sc["parents"].to(dev)
+    steps = sampling_steps(joints, parents)
+
+    def projection():
+        joints.grad = None
+        cal_skeleton_loss(joints, parents, cam, t=steps).backward()
+
+    res = {}
+    for name, fn in (("stage1", stage1), ("projection", projection)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        res[name] = a.elapsed_time(b) / iters
+    return {"what": "forward+backward, eager launches; not the headline metric",
+            "stage1_control_node_deform_ms": round(res["stage1"], 4),
+            "stage1_config": {"gaussians": N, "nodes": M, "K": K, "hyper_dim": H, "local_frame": True},
+            "skeleton_projection_loss_ms": round(res["projection"], 4),
+            "projection_config": {"joints": int(joints.shape[0]), "sample_points": int(steps.shape[0]) * (int(joints.shape[0]) - 1), "pixels": 1500}}
+
+
 def cpu_baseline(sc, cam_cpu, gimg_cpu, budget_s=20.0):
     """The CPU oracle (torch-CPU deform restatement + C/OpenMP rasterizer) on the SAME workload, all host cores."""
     import numpy as np
@@ -360,6 +412,7 @@ def main():
             # Secondary number (NOT the metric): the deformation with both per-Gaussian MLP heads on (the stage-2 recipe,
             # SURVEY.md §8-f rank 3), forward + backward, fp32 library GEMMs vs the fused bf16-MFMA kernels
             out["mlp_heads"] = heads_timing(sc, gm)
+            out["next_rows"] = next_rows_timing(sc, gm, cam)
         if not args.no_cpu_baseline and world == 1:  # (the CPU baseline is an N = 1 measurement)
             cam_cpu = cam.to("cpu")
             out["cpu_baseline"] = cpu_baseline(sc, cam_cpu, gimg.cpu())
