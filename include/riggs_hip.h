@@ -269,17 +269,18 @@ int riggs_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float* image, 
  * `weight` is the trainer's robust per-frame weight of train_rig.py:465-467 as a DEVICE scalar, NULL = 1) and keeps the
  * nearest-neighbour keys in `state` (riggs_skeleton_projection_state_floats floats, 8-byte aligned); backward takes the
  * upstream gradients of the two scalars as DEVICE scalars (NULL = 0) and writes dL/d(d_nodes) (J, 3).  Deterministic
- * (the only atomics are 64-bit max and LDS integer adds).
+ * (the only atomics are 64-bit max and LDS integer adds).  pixel_count: optional DEVICE int32 (1 <= count <= M): the number
+ * of valid rows of `thinned`, M then being the buffer's capacity — one captured graph serves frames of any pixel count.
  * ===================================================================== */
 size_t riggs_skeleton_projection_state_floats(int32_t J, int32_t S, int32_t M);
 int riggs_skeleton_projection_forward(int32_t J, int32_t S, int32_t M, const int32_t* parents, const float* d_nodes,
                                       const float* t, const float* world_view_transform, float fx, float fy, float cx,
-                                      float cy, const float* thinned, const float* weight, float* state, float* loss2,
-                                      riggs_stream stream);
+                                      float cy, const float* thinned, const int32_t* pixel_count, const float* weight, float* state,
+                                      float* loss2, riggs_stream stream);
 int riggs_skeleton_projection_backward(int32_t J, int32_t S, int32_t M, const int32_t* parents, const float* d_nodes,
                                        const float* t, const float* world_view_transform, float fx, float fy, float cx,
-                                       float cy, const float* thinned, const float* weight, float* state,
-                                       const float* g_loss, const float* g_weighted, float* grad_nodes,
+                                       float cy, const float* thinned, const int32_t* pixel_count, const float* weight,
+                                       float* state, const float* g_loss, const float* g_weighted, float* grad_nodes,
                                        riggs_stream stream);
 
 /* =====================================================================

@@ -67,8 +67,8 @@ _SIGS = {
     "riggs_cnode_forward": (C.c_int, [C.c_int32] * 7 + [_P] * 17),
     "riggs_cnode_backward": (C.c_int, [C.c_int32] * 7 + [_P] * 26),
     "riggs_skeleton_projection_state_floats": (C.c_size_t, [C.c_int32] * 3),
-    "riggs_skeleton_projection_forward": (C.c_int, [C.c_int32] * 3 + [_P] * 4 + [C.c_float] * 4 + [_P] * 5),
-    "riggs_skeleton_projection_backward": (C.c_int, [C.c_int32] * 3 + [_P] * 4 + [C.c_float] * 4 + [_P] * 7),
+    "riggs_skeleton_projection_forward": (C.c_int, [C.c_int32] * 3 + [_P] * 4 + [C.c_float] * 4 + [_P] * 6),
+    "riggs_skeleton_projection_backward": (C.c_int, [C.c_int32] * 3 + [_P] * 4 + [C.c_float] * 4 + [_P] * 8),
     "riggs_raster_set_trace": (C.c_int, [_P]),
     "riggs_mlp_forward": (C.c_int, [C.c_int32] * 5 + [_P] * 9),
     "riggs_mlp_backward": (C.c_int, [C.c_int32] * 4 + [_P] * 7),

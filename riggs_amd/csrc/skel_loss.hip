@@ -22,11 +22,14 @@ struct SkelProjArgs {
   const float* view;    // (4, 4) world_view_transform as the reference stores it (row-vector convention)
   float fx, fy, cx, cy;
   const float* thinned; // (M, 2) (row, col)
+  const int* m_dev;     // optional device-side pixel count (<= M = the buffer's capacity): one captured graph, any frame
   // state, zeroed by one memset node at the head of the forward:
   unsigned long long* near_x;  // (P) ~(distance bits << 32 | index of the nearest pixel): atomicMax = nearest, lowest index
   unsigned long long* near_y;  // (M) the same for every pixel over the sample points
   float* bone_grad;            // (J-1, 6) child part, parent part
 };
+
+__device__ __forceinline__ int skel_pixels(const SkelProjArgs& a) { return a.m_dev ? min(max(a.m_dev[0], 1), a.M) : a.M; }
 
 // point p = s (J-1) + (k-1) lies on bone k (child k, parent parents[k]) at parameter t[s]
 __device__ __forceinline__ void skel_point(const SkelProjArgs& a, int p, float& tx, float& ty, float& tz, float& tt, int& k) {
@@ -67,9 +70,11 @@ __global__ void __launch_bounds__(SKEL_Q) skel_nearest_kernel(SkelProjArgs a, in
     const int r = blockIdx.x - n_xblocks, n_slices = (a.P + SKEL_C - 1) / SKEL_C;
     qb = r / n_slices; cs = r - qb * n_slices;
   }
-  const int nq = xdir ? a.P : a.M, nc = xdir ? a.M : a.P;
+  const int M = skel_pixels(a);
+  const int nq = xdir ? a.P : M, nc = xdir ? M : a.P;
   const int i = qb * SKEL_Q + threadIdx.x;
   const int base = cs * SKEL_C, n = min(SKEL_C, nc - base);
+  if (n <= 0 || qb * SKEL_Q >= nq) return;  // beyond the frame's pixel count (the grid is sized for the capacity)
   const float2* pix = reinterpret_cast<const float2*>(a.thinned);
   for (int j = threadIdx.x; j < n; j += SKEL_Q) s_c[j] = xdir ? pix[base + j] : skel_project(a, base + j);
   float2 me = make_float2(0.f, 0.f);
@@ -96,7 +101,8 @@ __global__ void __launch_bounds__(1024) skel_finish_kernel(SkelProjArgs a, const
   __shared__ float s_a[1024], s_b[1024];
   float sx = 0.f, sy = 0.f;
   for (int i = threadIdx.x; i < a.P; i += 1024) sx += __uint_as_float((unsigned)(~a.near_x[i] >> 32));
-  for (int m = threadIdx.x; m < a.M; m += 1024) sy += __uint_as_float((unsigned)(~a.near_y[m] >> 32));
+  const int M = skel_pixels(a);
+  for (int m = threadIdx.x; m < M; m += 1024) sy += __uint_as_float((unsigned)(~a.near_y[m] >> 32));
   s_a[threadIdx.x] = sx;
   s_b[threadIdx.x] = sy;
   __syncthreads();
@@ -108,7 +114,7 @@ __global__ void __launch_bounds__(1024) skel_finish_kernel(SkelProjArgs a, const
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    const float l = s_a[0] / (float)a.P + s_b[0] / (float)a.M;
+    const float l = s_a[0] / (float)a.P + s_b[0] / (float)M;
     loss[0] = l;
     loss[1] = weight ? weight[0] * l : l;  // the trainer's weighted term (train_rig.py:467-470)
   }
@@ -128,7 +134,8 @@ __global__ void __launch_bounds__(256) skel_bone_grad_kernel(SkelProjArgs a, con
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int s = threadIdx.x; s < a.S; s += 256) { s_pull[s][0] = 0; s_pull[s][1] = 0; }
   __syncthreads();
-  for (int m = threadIdx.x; m < a.M; m += 256) {
+  const int M = skel_pixels(a);
+  for (int m = threadIdx.x; m < M; m += 256) {
     const int p = (int)(unsigned)(~a.near_y[m]);
     const int s = p / nb;
     if (p - s * nb != kb) continue;
@@ -139,7 +146,7 @@ __global__ void __launch_bounds__(256) skel_bone_grad_kernel(SkelProjArgs a, con
   }
   __syncthreads();
   const float g = (g_loss ? g_loss[0] : 0.f) + (g_weighted ? g_weighted[0] * (weight ? weight[0] : 1.f) : 0.f);
-  const float wx = g / (float)a.P, wy = g / (float)a.M;
+  const float wx = g / (float)a.P, wy = g / (float)M;
   float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int s = threadIdx.x; s < a.S; s += 256) {
     const int p = s * nb + kb;
@@ -183,7 +190,8 @@ __global__ void skel_joint_gather_kernel(SkelProjArgs a, float* grad_nodes) {
 }
 
 static int skel_fill(SkelProjArgs& a, int J, int S, int M, const int32_t* parents, const float* d_nodes, const float* t,
-                     const float* view, float fx, float fy, float cx, float cy, const float* thinned, float* state) {
+                     const float* view, float fx, float fy, float cx, float cy, const float* thinned, const int32_t* pixel_count,
+                     float* state) {
   RIGGS_REQUIRE(J >= 2 && J <= 4096, "need 2..4096 joints");
   RIGGS_REQUIRE(S >= 1 && M >= 1, "empty point set: the reference's mean over it is undefined");
   RIGGS_REQUIRE(S <= SKEL_MAX_S, "more than 2048 samples per bone");
@@ -192,7 +200,7 @@ static int skel_fill(SkelProjArgs& a, int J, int S, int M, const int32_t* parent
   memset(&a, 0, sizeof(a));
   a.J = J; a.S = S; a.M = M; a.P = S * (J - 1);
   a.parents = parents; a.nodes = d_nodes; a.t = t; a.view = view;
-  a.fx = fx; a.fy = fy; a.cx = cx; a.cy = cy; a.thinned = thinned;
+  a.fx = fx; a.fy = fy; a.cx = cx; a.cy = cy; a.thinned = thinned; a.m_dev = pixel_count;
   RIGGS_REQUIRE(((uintptr_t)state & 7) == 0, "state must be 8-byte aligned");
   float* f = state;
   a.near_x = (unsigned long long*)f;  f += 2 * (size_t)a.P;
@@ -214,10 +222,10 @@ size_t riggs_skeleton_projection_state_floats(int32_t J, int32_t S, int32_t M) {
 
 int riggs_skeleton_projection_forward(int32_t J, int32_t S, int32_t M, const int32_t* parents, const float* d_nodes,
                                       const float* t, const float* world_view_transform, float fx, float fy, float cx,
-                                      float cy, const float* thinned, const float* weight, float* state, float* loss2,
-                                      riggs_stream stream) {
+                                      float cy, const float* thinned, const int32_t* pixel_count, const float* weight, float* state,
+                                      float* loss2, riggs_stream stream) {
   SkelProjArgs a;
-  if (int rc = skel_fill(a, J, S, M, parents, d_nodes, t, world_view_transform, fx, fy, cx, cy, thinned, state)) return rc;
+  if (int rc = skel_fill(a, J, S, M, parents, d_nodes, t, world_view_transform, fx, fy, cx, cy, thinned, pixel_count, state)) return rc;
   RIGGS_REQUIRE(loss2, "NULL buffer");
   hipStream_t s = (hipStream_t)stream;
   // zero = "no neighbour yet" for the complemented keys
@@ -232,11 +240,11 @@ int riggs_skeleton_projection_forward(int32_t J, int32_t S, int32_t M, const int
 
 int riggs_skeleton_projection_backward(int32_t J, int32_t S, int32_t M, const int32_t* parents, const float* d_nodes,
                                        const float* t, const float* world_view_transform, float fx, float fy, float cx,
-                                       float cy, const float* thinned, const float* weight, float* state,
-                                       const float* g_loss, const float* g_weighted, float* grad_nodes,
+                                       float cy, const float* thinned, const int32_t* pixel_count, const float* weight,
+                                       float* state, const float* g_loss, const float* g_weighted, float* grad_nodes,
                                        riggs_stream stream) {
   SkelProjArgs a;
-  if (int rc = skel_fill(a, J, S, M, parents, d_nodes, t, world_view_transform, fx, fy, cx, cy, thinned, state)) return rc;
+  if (int rc = skel_fill(a, J, S, M, parents, d_nodes, t, world_view_transform, fx, fy, cx, cy, thinned, pixel_count, state)) return rc;
   RIGGS_REQUIRE((g_loss || g_weighted) && grad_nodes, "NULL buffer");
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(skel_bone_grad_kernel, dim3(J - 1), dim3(256), 0, s, a, g_loss, g_weighted, weight);

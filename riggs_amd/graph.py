@@ -114,11 +114,12 @@ class GraphedTrainStep(GraphedFrame):
     With ``thinned`` (the frame's (M, 2) silhouette-skeleton pixels) the skeleton projection loss of train_rig.py:459-470 is
     part of the iteration: the gradient is that of ``loss_img + projection_weight * cal_skeleton_loss(d_nodes, camera)``
     (``out["loss"]`` stays the image term, ``out["projection_loss"]`` the unweighted projection term); the weight is a
-    device scalar the host refreshes between replays (riggs_amd.loss.ProjectionLossWeights).  M and the
-    sampling density are baked into the graph: frames with another pixel count need their own capture."""
+    device scalar the host refreshes between replays (riggs_amd.loss.ProjectionLossWeights).  The pixel buffer has a fixed
+    capacity (``max_pixels``) and a device-side count, so one graph serves frames of any pixel count up to it."""
 
     def __init__(self, gm, sw, cam: Camera, bg: torch.Tensor, gt_image: torch.Tensor, optimizers, lambda_dssim: float = 0.2,
-                 headroom: float = 1.5, thinned: torch.Tensor = None, projection_weight: float = 1e-3, K=None):
+                 headroom: float = 1.5, thinned: torch.Tensor = None, projection_weight: float = 1e-3, K=None,
+                 max_pixels: int = None):
         params = gm.parameters() + [p for g in sw.trainable_parameters() for p in g["params"]]
         super().__init__(gm, sw, cam, bg, params, headroom=headroom, fused=True)
         for o in optimizers:
@@ -130,7 +131,10 @@ class GraphedTrainStep(GraphedFrame):
         self.thinned = None
         if thinned is not None:
             from .loss import sampling_steps
-            self.thinned = thinned.to(device=bg.device, dtype=torch.float32).clone()
+            m = thinned.shape[0]
+            self.thinned = torch.zeros(max(int(max_pixels or m), m), 2, device=bg.device)  # fixed capacity, device-side count
+            self.thinned[:m] = thinned
+            self.pixel_count = torch.tensor([m], dtype=torch.int32, device=bg.device)
             self.proj_weight = torch.full((), float(projection_weight), device=bg.device)
             self.cam.K = K
             with torch.no_grad():
@@ -154,7 +158,8 @@ class GraphedTrainStep(GraphedFrame):
         else:
             # two roots, one backward pass: no launches for "loss + weight * projection" and its autograd mirror
             self.cam.thinned = self.thinned
-            proj, wproj = cal_skeleton_loss(dv["d_nodes"], self.proj_parents, self.cam, t=self.proj_steps, weight=self.proj_weight)
+            proj, wproj = cal_skeleton_loss(dv["d_nodes"], self.proj_parents, self.cam, t=self.proj_steps, weight=self.proj_weight,
+                                            pixel_count=self.pixel_count)
             torch.autograd.backward([loss, wproj], [self.one, self.one])
         for o in self.optimizers:
             o.step()
@@ -171,9 +176,11 @@ class GraphedTrainStep(GraphedFrame):
         if gt_image is not None:
             self.gt.copy_(gt_image, non_blocking=True)
         if thinned is not None:
-            if self.thinned is None or thinned.shape != self.thinned.shape:
-                raise ValueError("the number of thinned pixels is baked into the captured graph: capture a new one")
-            self.thinned.copy_(thinned, non_blocking=True)
+            m = thinned.shape[0]
+            if self.thinned is None or not 1 <= m <= self.thinned.shape[0]:
+                raise ValueError("the captured graph holds 1..max_pixels thinned pixels: capture a new one with more room")
+            self.thinned[:m].copy_(thinned, non_blocking=True)
+            self.pixel_count.fill_(m)
         if projection_weight is not None:
             self.proj_weight.fill_(float(projection_weight))
         return super().run(cam, None)

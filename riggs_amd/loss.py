@@ -87,37 +87,37 @@ def ssim(img1, img2, window_size=11, size_average=True):
 # ---- skeleton projection loss (train_rig.py:309-314) ---------------------------------------------------------------------
 class _SkeletonProjection(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, d_nodes, parents, t, view, thinned, weight, fx, fy, cx, cy):
+    def forward(ctx, d_nodes, parents, t, view, thinned, weight, count, fx, fy, cx, cy):
         J, S, M = d_nodes.shape[0], t.shape[0], thinned.shape[0]
         lib = L.lib()
         n_state = lib.riggs_skeleton_projection_state_floats(J, S, M)
         state = torch.empty(max(int(n_state), 2) // 2 + 1, dtype=torch.float64, device=d_nodes.device)  # 8-byte aligned
         loss2 = torch.empty(2, dtype=torch.float32, device=d_nodes.device)
         L.check(lib.riggs_skeleton_projection_forward(J, S, M, parents.data_ptr(), d_nodes.data_ptr(), t.data_ptr(),
-                                                      view.data_ptr(), fx, fy, cx, cy, thinned.data_ptr(), L.ptr(weight),
-                                                      state.data_ptr(), loss2.data_ptr(), L.stream_ptr()),
+                                                      view.data_ptr(), fx, fy, cx, cy, thinned.data_ptr(), L.ptr(count),
+                                                      L.ptr(weight), state.data_ptr(), loss2.data_ptr(), L.stream_ptr()),
                 "riggs_skeleton_projection_forward")
-        ctx.save_for_backward(d_nodes, parents, t, view, thinned, state, weight)
+        ctx.save_for_backward(d_nodes, parents, t, view, thinned, state, weight, count)
         ctx.intr = (fx, fy, cx, cy)
         ctx.set_materialize_grads(False)
         return loss2[0], loss2[1]
 
     @staticmethod
     def backward(ctx, g_loss, g_weighted):
-        d_nodes, parents, t, view, thinned, state, weight = ctx.saved_tensors
+        d_nodes, parents, t, view, thinned, state, weight, count = ctx.saved_tensors
         J, S, M = d_nodes.shape[0], t.shape[0], thinned.shape[0]
         if g_loss is None and g_weighted is None:
-            return (None,) * 10
+            return (None,) * 11
         f = lambda g: None if g is None else g.to(torch.float32).contiguous()  # noqa: E731
         g_loss, g_weighted = f(g_loss), f(g_weighted)
         grad = torch.empty_like(d_nodes)
         fx, fy, cx, cy = ctx.intr
         L.check(L.lib().riggs_skeleton_projection_backward(J, S, M, parents.data_ptr(), d_nodes.data_ptr(), t.data_ptr(),
-                                                           view.data_ptr(), fx, fy, cx, cy, thinned.data_ptr(), L.ptr(weight),
-                                                           state.data_ptr(), L.ptr(g_loss), L.ptr(g_weighted),
+                                                           view.data_ptr(), fx, fy, cx, cy, thinned.data_ptr(), L.ptr(count),
+                                                           L.ptr(weight), state.data_ptr(), L.ptr(g_loss), L.ptr(g_weighted),
                                                            grad.data_ptr(), L.stream_ptr()),
                 "riggs_skeleton_projection_backward")
-        return (grad,) + (None,) * 9
+        return (grad,) + (None,) * 10
 
 
 def sampling_steps(joints, parents, num_sample=512):
@@ -143,13 +143,15 @@ def camera_intrinsics(viewpoint_cam):
     return float(fx), float(fy), W / 2, H / 2
 
 
-def cal_skeleton_loss(d_nodes, parents, viewpoint_cam, t=None, num_sample=512, weight=None):
+def cal_skeleton_loss(d_nodes, parents, viewpoint_cam, t=None, num_sample=512, weight=None, pixel_count=None):
     """``TrainRig.cal_skeleton_loss(d_nodes, viewpoint_cam)`` (/root/reference/train_rig.py:309-314) with the skeleton's
     ``parents`` passed explicitly: points sampled on the posed bones, projected with the camera (elements are (row, col)) and
     compared with ``viewpoint_cam.thinned`` by the two-sided L1 chamfer distance; differentiable w.r.t. ``d_nodes``.
 
     With ``weight`` (a device scalar: the trainer's robust per-frame weight, train_rig.py:465-467) the pair
-    ``(loss, weight * loss)`` is returned, the product formed inside the kernels instead of two more launches."""
+    ``(loss, weight * loss)`` is returned, the product formed inside the kernels instead of two more launches.
+    ``pixel_count`` (a device int32 scalar, 1 <= count <= len(thinned)) marks the valid rows of ``thinned``, which is then a
+    buffer of fixed capacity: a captured graph serves frames of any pixel count."""
     d_nodes = L.require_cuda_f32("d_nodes", d_nodes).contiguous()
     if d_nodes.dim() != 2 or d_nodes.shape[1] != 3 or d_nodes.shape[0] < 2:
         raise L.RiggsHipError("d_nodes must be (J >= 2, 3)")
@@ -166,7 +168,11 @@ def cal_skeleton_loss(d_nodes, parents, viewpoint_cam, t=None, num_sample=512, w
     fx, fy, cx, cy = camera_intrinsics(viewpoint_cam)
     if weight is not None:
         weight = L.require_cuda_f32("weight", weight).reshape(1)
-    loss, weighted = _SkeletonProjection.apply(d_nodes, par, t, view, thinned, weight, fx, fy, cx, cy)
+    if pixel_count is not None:
+        if not pixel_count.is_cuda or pixel_count.dtype != torch.int32:
+            raise L.RiggsHipError("pixel_count must be a CUDA(HIP) int32 scalar tensor")
+        pixel_count = pixel_count.reshape(1)
+    loss, weighted = _SkeletonProjection.apply(d_nodes, par, t, view, thinned, weight, pixel_count, fx, fy, cx, cy)
     return loss if weight is None else (loss, weighted)
 
 

@@ -234,15 +234,19 @@ def test_projection_loss_inside_a_captured_training_iteration():
                     lr=0.0, eps=1e-15, capturable=True)
     thinned = torch.stack([torch.randint(10, 54, (150,)), torch.randint(10, 70, (150,))], -1).float().cuda()
     gts = GraphedTrainStep(gm, sw, cam, torch.zeros(3, device="cuda"), torch.rand(3, 64, 80, device="cuda"), [gm.optimizer, opt],
-                           thinned=thinned, projection_weight=1e-3)
+                           thinned=thinned, projection_weight=1e-3, max_pixels=400)
     gts.capture(warmup=1)
     gts.run()
-    for new_pixels in (None, torch.stack([torch.randint(0, 64, (150,)), torch.randint(0, 80, (150,))], -1).float().cuda()):
+    rnd = lambda m: torch.stack([torch.randint(0, 64, (m,)), torch.randint(0, 80, (m,))], -1).float().cuda()  # noqa: E731
+    for new_pixels in (None, rnd(150), rnd(400), rnd(1), rnd(333)):  # one graph, frames of any pixel count up to the capacity
         with torch.no_grad():  # the loss the NEXT replay will see: parameters as they are now
             cam.thinned = thinned if new_pixels is None else new_pixels
+            cam.K = None
             d_nodes = sw(gm.get_xyz.detach()[:1], sw.expand_time(cam.fid), motion_mask=None)["d_nodes"]
             want = cal_skeleton_loss(d_nodes, sw.parents, cam, t=gts.proj_steps).item()
         out = gts.run(thinned=new_pixels)
         assert out["projection_loss"].item() == pytest.approx(want, rel=1e-6)
+        if new_pixels is not None:
+            thinned = new_pixels
     with pytest.raises(ValueError):
-        gts.run(thinned=thinned[:10])
+        gts.run(thinned=rnd(401))
