@@ -297,10 +297,10 @@ int riggs_skeleton_projection_backward(int32_t J, int32_t S, int32_t M, const in
  * backward takes upstream gradients (each may be NULL = 0) and writes the gradients of feature (N, feat_stride; columns
  * beyond `hyper` zero), motion_mask, the node attributes, _node_radius, _node_weight and the nodes' hyper coordinates
  * (M, hyper); xyz of Gaussians and nodes are detached in the reference (:944, :947-949, :1152).  workspace:
- * riggs_cnode_backward_workspace_floats floats.
+ * riggs_cnode_backward_workspace_floats floats, 16-byte aligned.
  * ===================================================================== */
 int riggs_cnode_backward_blocks(int32_t N, int32_t M, int32_t hyper);
-size_t riggs_cnode_backward_workspace_floats(int32_t N, int32_t M, int32_t hyper);
+size_t riggs_cnode_backward_workspace_floats(int32_t N, int32_t M, int32_t K, int32_t hyper);
 int riggs_cnode_forward(int32_t N, int32_t M, int32_t K, int32_t hyper, int32_t feat_stride, int32_t node_stride, int32_t flags,
                         const float* x, const float* feature, const float* motion_mask, const float* nodes,
                         const float* node_radius_log, const float* node_weight_logit, const float* node_trans,

@@ -63,7 +63,7 @@ _SIGS = {
     "riggs_l1_ssim_forward": (C.c_int, [C.c_int32] * 3 + [_P, _P, C.c_float, _P, _P, _P]),
     "riggs_l1_ssim_backward": (C.c_int, [C.c_int32] * 3 + [_P, _P, _P, C.c_float, _P, _P, _P, _P, _P]),
     "riggs_cnode_backward_blocks": (C.c_int, [C.c_int32] * 3),
-    "riggs_cnode_backward_workspace_floats": (C.c_size_t, [C.c_int32] * 3),
+    "riggs_cnode_backward_workspace_floats": (C.c_size_t, [C.c_int32] * 4),
     "riggs_cnode_forward": (C.c_int, [C.c_int32] * 7 + [_P] * 17),
     "riggs_cnode_backward": (C.c_int, [C.c_int32] * 7 + [_P] * 26),
     "riggs_skeleton_projection_state_floats": (C.c_size_t, [C.c_int32] * 3),

@@ -56,7 +56,7 @@ class _ControlNodeBlend(torch.autograd.Function):
         g_radius = torch.empty_like(radius_log)
         g_weight = torch.empty_like(weight_logit) if weight_logit is not None else None
         g_hyper = torch.empty(M, hyper, **f32) if hyper > 0 else None
-        ws = torch.empty(max(int(lib.riggs_cnode_backward_workspace_floats(N, M, hyper)), 1), **f32)
+        ws = torch.empty(max(int(lib.riggs_cnode_backward_workspace_floats(N, M, K, hyper)), 1), **f32)
         fs = feature.shape[1] if feature is not None else 0
         L.check(lib.riggs_cnode_backward(N, M, K, hyper, fs, nodes.shape[1], flags, x.data_ptr(), L.ptr(feature), L.ptr(mask),
                                          nodes.data_ptr(), radius_log.data_ptr(), L.ptr(weight_logit), trans.data_ptr(),

@@ -6,11 +6,13 @@
 //                                  the lowest index"
 // The reference runs a KNN extension call, ~10 gathers of (N, K, ·) tensors, an einsum and a dozen elementwise passes, and
 // autograd replays them.  Here: ONE forward launch — the M control nodes (3 + hyper_dim coordinates) sit in LDS, a thread scans
-// them for its Gaussian with a register-resident sorted K-list, then blends its K nodes' attributes — and a backward of two:
-// a persistent grid that accumulates the per-node gradients (translation, rotation, scale, dL/dR of the local frame, radius,
-// node weight, hyper coordinates: 21 + hyper_dim floats per node) in LDS and writes one partial table per workgroup, and a
-// per-node finish that sums the partials in a fixed order and applies the node-level chain rules (quaternion -> matrix,
-// exp, sigmoid).  Forward is VALU-bound by the scan (N M (3 + hyper) FMAs); the tables it reads are L2-resident.
+// them for its Gaussian with a register-resident sorted K-list, then blends its K nodes' attributes — and a backward built on
+// per-node inverse lists: a counting sort of the N K neighbour entries by node, a per-Gaussian pass that writes each entry's
+// 21 + hyper_dim contributions (translation, rotation, scale, dL/dR of the local frame, radius, node weight, hyper coordinates)
+// as a 128-byte row at the entry's sorted position, and one workgroup per node that sums its contiguous rows and applies the
+// node-level chain rules (quaternion -> matrix, exp, sigmoid).  The first backward (LDS float atomics + per-workgroup partial
+// tables) is kept behind RIGGS_CNODE_BWD=atomics: the LDS executes float atomics lane by lane.  Forward is issue-bound by the
+// scan (N M (3 + hyper) FMAs); the tables it reads are L2-resident.
 #include "common.h"
 
 namespace riggs {
@@ -39,6 +41,12 @@ struct CNodeArgs {
   float* g_mask;      // (N) or NULL
   float* partial;     // (blocks, M, nacc)
   int nacc;
+  // inverse-list backward
+  float4* rows;       // (N K, 8) float4: the 21 + hyper contributions of every neighbour entry, grouped by node
+  int* sorted;        // (N K) position of every entry in the node-grouped order
+  int* hist;          // (list blocks, M) entry counts -> exclusive offsets inside the node's segment
+  int* node_off;      // (M + 1)
+  int list_blocks;
 };
 
 __device__ __forceinline__ void cn_quat_to_mat(const float q[4], float R[9]) {
@@ -158,12 +166,17 @@ __global__ void __launch_bounds__(256) cnode_forward_kernel(CNodeArgs a) {
 #define CN_ACC_FIXED 21
 #define CN_BWD_THREADS 1024
 
-template <int K>
+// LISTS = false: per-node gradients through LDS float atomics + one partial table per workgroup (the first version; the LDS
+// executes float atomics lane by lane).  LISTS = true: only the per-Gaussian outputs and four scalars per neighbour entry are
+// written; the per-node sums are made by cnode_node_reduce_kernel over inverse lists.
+template <int K, bool LISTS>
 __global__ void __launch_bounds__(CN_BWD_THREADS) cnode_backward_kernel(CNodeArgs a) {
   extern __shared__ float s_acc[];  // (M, nacc)
   const int nacc = a.nacc;
-  for (int e = threadIdx.x; e < a.M * nacc; e += CN_BWD_THREADS) s_acc[e] = 0.f;
-  __syncthreads();
+  if (!LISTS) {
+    for (int e = threadIdx.x; e < a.M * nacc; e += CN_BWD_THREADS) s_acc[e] = 0.f;
+    __syncthreads();
+  }
   const bool local = a.flags & CN_LOCAL_FRAME;
   const float bias = (a.flags & CN_ROT_AS_RES) ? 0.f : 1.f;
   for (int i = blockIdx.x * CN_BWD_THREADS + threadIdx.x; i < a.N; i += gridDim.x * CN_BWD_THREADS) {
@@ -174,7 +187,7 @@ __global__ void __launch_bounds__(CN_BWD_THREADS) cnode_backward_kernel(CNodeArg
     if (a.g_scale) { s[0] = a.g_scale[3 * (size_t)i]; s[1] = a.g_scale[3 * (size_t)i + 1]; s[2] = a.g_scale[3 * (size_t)i + 2]; }
     const float x0 = a.x[3 * (size_t)i], x1 = a.x[3 * (size_t)i + 1], x2 = a.x[3 * (size_t)i + 2];
     // pass 1: weights and dL/dw
-    float w[K], u[K], e_[K], r2_[K], dw[K];
+    float w[K], u[K], e_[K], r2_[K], dw[K], rel[K][3];
     float vsum = 0.f;
     float ts[3] = {0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f}, ss[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -200,15 +213,18 @@ __global__ void __launch_bounds__(CN_BWD_THREADS) cnode_backward_kernel(CNodeArg
           cn_quat_to_mat(q, R);
           const float n0 = a.nodes[(size_t)n * a.node_stride], n1 = a.nodes[(size_t)n * a.node_stride + 1], n2 = a.nodes[(size_t)n * a.node_stride + 2];
           const float r0 = x0 - n0, r1 = x1 - n1, r2 = x2 - n2;
+          rel[k][0] = r0; rel[k][1] = r1; rel[k][2] = r2;
           y0 += R[0] * r0 + R[1] * r1 + R[2] * r2 + n0;
           y1 += R[3] * r0 + R[4] * r1 + R[5] * r2 + n1;
           y2 += R[6] * r0 + R[7] * r1 + R[8] * r2 + n2;
           // dL/dR += w (g m) (x - n)^T
+          if (!LISTS) {
           float* acc = s_acc + (size_t)n * nacc + 10;
           const float wg0 = w[k] * g[0] * m, wg1 = w[k] * g[1] * m, wg2 = w[k] * g[2] * m;
           atomicAdd(acc + 0, wg0 * r0); atomicAdd(acc + 1, wg0 * r1); atomicAdd(acc + 2, wg0 * r2);
           atomicAdd(acc + 3, wg1 * r0); atomicAdd(acc + 4, wg1 * r1); atomicAdd(acc + 5, wg1 * r2);
           atomicAdd(acc + 6, wg2 * r0); atomicAdd(acc + 7, wg2 * r1); atomicAdd(acc + 8, wg2 * r2);
+          }
         }
         const float ro0 = a.rot[4 * n] + bias, ro1 = a.rot[4 * n + 1], ro2 = a.rot[4 * n + 2], ro3 = a.rot[4 * n + 3];
         const float c0 = a.scale[3 * n], c1 = a.scale[3 * n + 1], c2 = a.scale[3 * n + 2];
@@ -217,11 +233,13 @@ __global__ void __launch_bounds__(CN_BWD_THREADS) cnode_backward_kernel(CNodeArg
         ts[0] += w[k] * y0; ts[1] += w[k] * y1; ts[2] += w[k] * y2;
         rs[0] += w[k] * ro0; rs[1] += w[k] * ro1; rs[2] += w[k] * ro2; rs[3] += w[k] * ro3;
         ss[0] += w[k] * c0; ss[1] += w[k] * c1; ss[2] += w[k] * c2;
+        if (!LISTS) {
         float* acc = s_acc + (size_t)n * nacc;
         const float wm = w[k] * m;
         atomicAdd(acc + 0, wm * g[0]); atomicAdd(acc + 1, wm * g[1]); atomicAdd(acc + 2, wm * g[2]);
         atomicAdd(acc + 3, wm * h[0]); atomicAdd(acc + 4, wm * h[1]); atomicAdd(acc + 5, wm * h[2]); atomicAdd(acc + 6, wm * h[3]);
         atomicAdd(acc + 7, wm * s[0]); atomicAdd(acc + 8, wm * s[1]); atomicAdd(acc + 9, wm * s[2]);
+        }
       }
     }
     if (a.g_mask) {
@@ -241,19 +259,40 @@ __global__ void __launch_bounds__(CN_BWD_THREADS) cnode_backward_kernel(CNodeArg
         const float dist = a.nn_dist[(size_t)i * K + k];
         const float dv = (dw[k] - wdw) / vsum;
         float* acc = s_acc + (size_t)n * nacc;
-        atomicAdd(acc + 19, dv * u[k] * dist / r2_[k]);
-        if (a.weight_logit) atomicAdd(acc + 20, dv * e_[k]);
+        const float dd = dv * u[k] * (-1.0f / (2.0f * r2_[k]));
+        float row[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) row[c] = 0.f;
+        if (!LISTS) atomicAdd(acc + 19, dv * u[k] * dist / r2_[k]);
+        if (!LISTS && a.weight_logit) atomicAdd(acc + 20, dv * e_[k]);
         if (a.hyper > 0) {
-          const float dd = dv * u[k] * (-1.0f / (2.0f * r2_[k]));
 #pragma unroll
           for (int d = 0; d < 13; ++d) {
             if (d < a.hyper) {
               const float diff = a.feature[(size_t)i * a.feat_stride + d] - a.nodes[(size_t)n * a.node_stride + 3 + d];
               const float v = dd * 2.0f * diff;
               gf[d] += v;
-              atomicAdd(acc + CN_ACC_FIXED + d, -v);
+              if (!LISTS) atomicAdd(acc + CN_ACC_FIXED + d, -v);
+              if (LISTS) row[CN_ACC_FIXED + d] = -v;
             }
           }
+        }
+        if (LISTS) {
+          const float c1 = w[k] * m;
+          row[0] = c1 * g[0]; row[1] = c1 * g[1]; row[2] = c1 * g[2];
+          row[3] = c1 * h[0]; row[4] = c1 * h[1]; row[5] = c1 * h[2]; row[6] = c1 * h[3];
+          row[7] = c1 * s[0]; row[8] = c1 * s[1]; row[9] = c1 * s[2];
+          if (local) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+              row[10 + 3 * r] = c1 * g[r] * rel[k][0]; row[11 + 3 * r] = c1 * g[r] * rel[k][1]; row[12 + 3 * r] = c1 * g[r] * rel[k][2];
+            }
+          }
+          row[19] = dv * u[k] * dist / r2_[k];
+          row[20] = dv * e_[k];
+          float4* dst = a.rows + 8 * (size_t)a.sorted[(size_t)i * K + k];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) dst[q] = make_float4(row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]);
         }
       }
     }
@@ -263,43 +302,68 @@ __global__ void __launch_bounds__(CN_BWD_THREADS) cnode_backward_kernel(CNodeArg
       for (int d = 0; d < 13; ++d) if (d < a.hyper) a.g_feature[(size_t)i * a.feat_stride + d] = gf[d];
     }
   }
-  __syncthreads();
-  float* out = a.partial + (size_t)blockIdx.x * a.M * nacc;
-  for (int e = threadIdx.x; e < a.M * nacc; e += CN_BWD_THREADS) out[e] = s_acc[e];
+  if (!LISTS) {
+    __syncthreads();
+    float* out = a.partial + (size_t)blockIdx.x * a.M * nacc;
+    for (int e = threadIdx.x; e < a.M * nacc; e += CN_BWD_THREADS) out[e] = s_acc[e];
+  }
 }
+
+// ---- inverse lists: a counting sort of the N K neighbour entries by node (M <= 2730 bins live in LDS) ---------------------
+#define CN_LIST_CHUNK 4096  // entries per workgroup of the histogram / scatter passes
+
+__global__ void __launch_bounds__(256) cnode_list_hist_kernel(CNodeArgs a) {
+  extern __shared__ int s_bins[];
+  for (int n = threadIdx.x; n < a.M; n += 256) s_bins[n] = 0;
+  __syncthreads();
+  const int total = a.N * a.K, base = blockIdx.x * CN_LIST_CHUNK;
+  for (int e = base + threadIdx.x; e < min(base + CN_LIST_CHUNK, total); e += 256) atomicAdd(&s_bins[a.nn_idx[e]], 1);
+  __syncthreads();
+  for (int n = threadIdx.x; n < a.M; n += 256) a.hist[(size_t)blockIdx.x * a.M + n] = s_bins[n];
+}
+
+// one workgroup: per node an exclusive scan over the list blocks (eight loads in flight), then over the nodes
+__global__ void __launch_bounds__(1024) cnode_list_scan_kernel(CNodeArgs a) {
+  __shared__ int s_tot[4096];
+  for (int n = threadIdx.x; n < a.M; n += 1024) {
+    int run = 0, b = 0;
+    int* col = a.hist + n;
+    for (; b + 8 <= a.list_blocks; b += 8) {
+      int t[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t[q] = col[(size_t)(b + q) * a.M];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { col[(size_t)(b + q) * a.M] = run; run += t[q]; }
+    }
+    for (; b < a.list_blocks; ++b) { const int t = col[(size_t)b * a.M]; col[(size_t)b * a.M] = run; run += t; }
+    s_tot[n] = run;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int n = 0; n < a.M; ++n) { a.node_off[n] = run; run += s_tot[n]; }
+    a.node_off[a.M] = run;
+  }
+}
+
+__global__ void __launch_bounds__(256) cnode_list_scatter_kernel(CNodeArgs a) {
+  extern __shared__ int s_bins[];
+  for (int n = threadIdx.x; n < a.M; n += 256) s_bins[n] = a.node_off[n] + a.hist[(size_t)blockIdx.x * a.M + n];
+  __syncthreads();
+  const int total = a.N * a.K, base = blockIdx.x * CN_LIST_CHUNK;
+  for (int e = base + threadIdx.x; e < min(base + CN_LIST_CHUNK, total); e += 256) {
+    a.sorted[e] = atomicAdd(&s_bins[a.nn_idx[e]], 1);
+  }
+}
+
 
 struct CNodeGrads {
   float* g_trans; float* g_rot; float* g_scale; float* g_local_rot; float* g_radius_log; float* g_weight_logit;
   float* g_nodes_hyper;  // (M, hyper)
 };
 
-// 8 nodes per workgroup, 32 lanes per node: lane c sums column c of the workgroups' partial tables in a fixed order, then the
-// node-level chain rules.
-__global__ void __launch_bounds__(256) cnode_finish_kernel(CNodeArgs a, CNodeGrads o, int blocks) {
-  __shared__ float s_v[8][32];
-  const int nl = threadIdx.x >> 5, c = threadIdx.x & 31;
-  const int n = blockIdx.x * 8 + nl;
-  float v = 0.f;
-  if (n < a.M && c < a.nacc) {
-    // four interleaved accumulators, eight loads in flight: a fixed order, but not one load latency per term
-    float v4[4] = {0.f, 0.f, 0.f, 0.f};
-    const float* src = a.partial + (size_t)n * a.nacc + c;
-    const size_t step = (size_t)a.M * a.nacc;
-    int b = 0;
-    for (; b + 8 <= blocks; b += 8) {
-      float t[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) t[q] = src[(size_t)(b + q) * step];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) v4[q & 3] += t[q];
-    }
-    for (; b < blocks; ++b) v4[b & 3] += src[(size_t)b * step];
-    v = (v4[0] + v4[1]) + (v4[2] + v4[3]);
-  }
-  s_v[nl][c] = v;
-  __syncthreads();
-  if (n >= a.M) return;
-  const float* S = s_v[nl];
+// node-level chain rules on the summed accumulator row S of node n; lane c of 32 writes its share
+__device__ __forceinline__ void cn_node_chain(const CNodeArgs& a, const CNodeGrads& o, int n, const float* S, int c) {
   if (c < 3) { o.g_trans[3 * n + c] = S[c]; o.g_scale[3 * n + c] = S[7 + c]; }
   if (c < 4) o.g_rot[4 * n + c] = S[3 + c];
   if (c == 4) o.g_radius_log[n] = S[19];
@@ -329,6 +393,67 @@ __global__ void __launch_bounds__(256) cnode_finish_kernel(CNodeArgs a, CNodeGra
     }
     o.g_local_rot[4 * n] = dq[0]; o.g_local_rot[4 * n + 1] = dq[1]; o.g_local_rot[4 * n + 2] = dq[2]; o.g_local_rot[4 * n + 3] = dq[3];
   }
+}
+
+// One workgroup per node: its entries' rows are contiguous (the per-Gaussian pass wrote them in node-grouped order), 32 row
+// lanes x 32 columns sum them with four loads in flight each — no atomics, no gathers; then the node-level chain rules.
+#define CN_NODE_THREADS 1024
+__global__ void __launch_bounds__(CN_NODE_THREADS) cnode_node_reduce_kernel(CNodeArgs a, CNodeGrads o) {
+  __shared__ float s_w[32][33];
+  __shared__ float s_row[32];
+  const int n = blockIdx.x, c = threadIdx.x & 31, r = threadIdx.x >> 5;
+  const int lo = a.node_off[n], hi = a.node_off[n + 1];
+  const float* base = reinterpret_cast<const float*>(a.rows) + c;
+  float v4[4] = {0.f, 0.f, 0.f, 0.f};
+  int p = lo + r;
+  for (; p + 96 < hi; p += 128) {
+    float t[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] = base[32 * (size_t)(p + 32 * q)];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v4[q] += t[q];
+  }
+  for (; p < hi; p += 32) v4[0] += base[32 * (size_t)p];
+  s_w[r][c] = (v4[0] + v4[1]) + (v4[2] + v4[3]);
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 32; ++w) v += s_w[w][threadIdx.x];
+    s_row[threadIdx.x] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) cn_node_chain(a, o, n, s_row, threadIdx.x);
+}
+
+// 8 nodes per workgroup, 32 lanes per node: lane c sums column c of the workgroups' partial tables in a fixed order, then the
+// node-level chain rules.
+__global__ void __launch_bounds__(256) cnode_finish_kernel(CNodeArgs a, CNodeGrads o, int blocks) {
+  __shared__ float s_v[8][32];
+  const int nl = threadIdx.x >> 5, c = threadIdx.x & 31;
+  const int n = blockIdx.x * 8 + nl;
+  float v = 0.f;
+  if (n < a.M && c < a.nacc) {
+    // four interleaved accumulators, eight loads in flight: a fixed order, but not one load latency per term
+    float v4[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* src = a.partial + (size_t)n * a.nacc + c;
+    const size_t step = (size_t)a.M * a.nacc;
+    int b = 0;
+    for (; b + 8 <= blocks; b += 8) {
+      float t[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t[q] = src[(size_t)(b + q) * step];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v4[q & 3] += t[q];
+    }
+    for (; b < blocks; ++b) v4[b & 3] += src[(size_t)b * step];
+    v = (v4[0] + v4[1]) + (v4[2] + v4[3]);
+  }
+  s_v[nl][c] = v;
+  __syncthreads();
+  if (n >= a.M) return;
+  const float* S = s_v[nl];
+  cn_node_chain(a, o, n, S, c);
 }
 
 static int cn_check(int N, int M, int K, int hyper, int feat_stride, int node_stride, const void* feature) {
@@ -365,8 +490,22 @@ int riggs_cnode_backward_blocks(int32_t N, int32_t M, int32_t hyper) {
   return want < 1 ? 1 : (want > cap ? cap : want);
 }
 
-size_t riggs_cnode_backward_workspace_floats(int32_t N, int32_t M, int32_t hyper) {
-  return (size_t)riggs_cnode_backward_blocks(N, M, hyper) * M * (CN_ACC_FIXED + hyper);
+static int cn_list_blocks(int N, int K) {
+  const long long total = (long long)N * K;
+  const int b = (int)((total + CN_LIST_CHUNK - 1) / CN_LIST_CHUNK);
+  return b < 1 ? 1 : b;
+}
+
+static bool cn_use_lists() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("RIGGS_CNODE_BWD"); v = (e && !strcmp(e, "atomics")) ? 0 : 1; }
+  return v == 1;
+}
+
+size_t riggs_cnode_backward_workspace_floats(int32_t N, int32_t M, int32_t K, int32_t hyper) {
+  const size_t atomics = (size_t)riggs_cnode_backward_blocks(N, M, hyper) * M * (CN_ACC_FIXED + hyper);
+  const size_t lists = 33 * (size_t)N * K + (size_t)cn_list_blocks(N, K) * M + (size_t)M + 1 + 8;
+  return atomics > lists ? atomics : lists;
 }
 
 int riggs_cnode_forward(int32_t N, int32_t M, int32_t K, int32_t hyper, int32_t feat_stride, int32_t node_stride, int32_t flags,
@@ -430,31 +569,53 @@ int riggs_cnode_backward(int32_t N, int32_t M, int32_t K, int32_t hyper, int32_t
   a.nn_idx = const_cast<int32_t*>(nn_idx); a.nn_dist = const_cast<float*>(nn_dist);
   a.g_xyz = g_xyz; a.g_rot = g_rot; a.g_scale = g_scale; a.g_feature = g_feature; a.g_mask = g_motion_mask;
   a.partial = workspace; a.nacc = CN_ACC_FIXED + hyper;
-  const size_t lds = (size_t)M * a.nacc * sizeof(float);
-  RIGGS_REQUIRE(lds <= 160 * 1024 - 1024, "per-node gradient table does not fit LDS (M (21 + hyper_dim) floats <= 159 KB)");
   RIGGS_REQUIRE(a.nacc <= 32, "accumulator row too wide");
   hipStream_t s = (hipStream_t)stream;
-  static bool attr_set = false;
-  if (!attr_set) {
-#define CN_BATTR(KK) RIGGS_HIP_CHECK(hipFuncSetAttribute((const void*)cnode_backward_kernel<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    CN_BATTR(1) CN_BATTR(2) CN_BATTR(3) CN_BATTR(4) CN_BATTR(5) CN_BATTR(6) CN_BATTR(7) CN_BATTR(8)
-    attr_set = true;
-  }
-  const int blocks = riggs_cnode_backward_blocks(N, M, hyper);
-  const dim3 grid(blocks), block(CN_BWD_THREADS);
-  switch (K) {
-    case 1: hipLaunchKernelGGL(cnode_backward_kernel<1>, grid, block, lds, s, a); break;
-    case 2: hipLaunchKernelGGL(cnode_backward_kernel<2>, grid, block, lds, s, a); break;
-    case 3: hipLaunchKernelGGL(cnode_backward_kernel<3>, grid, block, lds, s, a); break;
-    case 4: hipLaunchKernelGGL(cnode_backward_kernel<4>, grid, block, lds, s, a); break;
-    case 5: hipLaunchKernelGGL(cnode_backward_kernel<5>, grid, block, lds, s, a); break;
-    case 6: hipLaunchKernelGGL(cnode_backward_kernel<6>, grid, block, lds, s, a); break;
-    case 7: hipLaunchKernelGGL(cnode_backward_kernel<7>, grid, block, lds, s, a); break;
-    default: hipLaunchKernelGGL(cnode_backward_kernel<8>, grid, block, lds, s, a); break;
-  }
   CNodeGrads o = {g_node_trans, g_node_rot, g_node_scale, g_local_rot, g_node_radius_log,
                   node_weight_logit ? g_node_weight_logit : nullptr, g_nodes_hyper};
-  hipLaunchKernelGGL(cnode_finish_kernel, dim3((M + 7) / 8), dim3(256), 0, s, a, o, blocks);
+#define CN_BLAUNCH(LISTS, grid, block, lds)                                                                          \
+  switch (K) {                                                                                                       \
+    case 1: hipLaunchKernelGGL((cnode_backward_kernel<1, LISTS>), grid, block, lds, s, a); break;                     \
+    case 2: hipLaunchKernelGGL((cnode_backward_kernel<2, LISTS>), grid, block, lds, s, a); break;                     \
+    case 3: hipLaunchKernelGGL((cnode_backward_kernel<3, LISTS>), grid, block, lds, s, a); break;                     \
+    case 4: hipLaunchKernelGGL((cnode_backward_kernel<4, LISTS>), grid, block, lds, s, a); break;                     \
+    case 5: hipLaunchKernelGGL((cnode_backward_kernel<5, LISTS>), grid, block, lds, s, a); break;                     \
+    case 6: hipLaunchKernelGGL((cnode_backward_kernel<6, LISTS>), grid, block, lds, s, a); break;                     \
+    case 7: hipLaunchKernelGGL((cnode_backward_kernel<7, LISTS>), grid, block, lds, s, a); break;                     \
+    default: hipLaunchKernelGGL((cnode_backward_kernel<8, LISTS>), grid, block, lds, s, a); break;                    \
+  }
+  if (cn_use_lists()) {
+    // (i) counting sort of the N K neighbour entries by node -> every entry's position; (ii) per-Gaussian pass: outputs of the
+    // Gaussians + each entry's 21 + hyper contributions as a 128-byte row at its position; (iii) one workgroup per node sums its
+    // (contiguous) rows
+    RIGGS_REQUIRE(M <= 4096, "more than 4096 control nodes");
+    RIGGS_REQUIRE(((uintptr_t)workspace & 15) == 0, "workspace must be 16-byte aligned");
+    a.list_blocks = cn_list_blocks(N, K);
+    a.rows = (float4*)workspace;
+    a.sorted = (int*)(workspace + 32 * (size_t)N * K);
+    a.hist = a.sorted + (size_t)N * K;
+    a.node_off = a.hist + (size_t)a.list_blocks * M;
+    hipLaunchKernelGGL(cnode_list_hist_kernel, dim3(a.list_blocks), dim3(256), (size_t)M * sizeof(int), s, a);
+    hipLaunchKernelGGL(cnode_list_scan_kernel, dim3(1), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(cnode_list_scatter_kernel, dim3(a.list_blocks), dim3(256), (size_t)M * sizeof(int), s, a);
+    const int gb = (N + CN_BWD_THREADS - 1) / CN_BWD_THREADS;
+    const dim3 grid(gb < 1 ? 1 : gb), block(CN_BWD_THREADS);
+    CN_BLAUNCH(true, grid, block, 0)
+    hipLaunchKernelGGL(cnode_node_reduce_kernel, dim3(M), dim3(CN_NODE_THREADS), 0, s, a, o);
+  } else {
+    const size_t lds = (size_t)M * a.nacc * sizeof(float);
+    RIGGS_REQUIRE(lds <= 160 * 1024 - 1024, "per-node gradient table does not fit LDS (M (21 + hyper_dim) floats <= 159 KB)");
+    static bool attr_set = false;
+    if (!attr_set) {
+#define CN_BATTR(KK) RIGGS_HIP_CHECK(hipFuncSetAttribute((const void*)cnode_backward_kernel<KK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      CN_BATTR(1) CN_BATTR(2) CN_BATTR(3) CN_BATTR(4) CN_BATTR(5) CN_BATTR(6) CN_BATTR(7) CN_BATTR(8)
+      attr_set = true;
+    }
+    const int blocks = riggs_cnode_backward_blocks(N, M, hyper);
+    const dim3 grid(blocks), block(CN_BWD_THREADS);
+    CN_BLAUNCH(false, grid, block, lds)
+    hipLaunchKernelGGL(cnode_finish_kernel, dim3((M + 7) / 8), dim3(256), 0, s, a, o, blocks);
+  }
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
 }
