@@ -5,7 +5,7 @@ import sqlite3
 import sys
 
 
-def main(db_path, anchor="pm_embed"):
+def main(db_path, anchor="pm_forward_fused"):
     db = sqlite3.connect(db_path)
     rows = db.execute("select name, start, end from kernels order by start").fetchall()
     idx = [i for i, r in enumerate(rows) if anchor in r[0]]
