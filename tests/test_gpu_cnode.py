@@ -208,3 +208,17 @@ def test_stage1_iteration_through_the_rasterizer_matches_torch_blend():
     for k, g in res["torch"][1].items():
         err = (res["hip"][1][k] - g).abs().max().item()
         assert g.abs().max().item() > 0 and err <= 2e-3 * g.abs().max().item(), (k, err, g.abs().max().item())
+
+
+def test_atomics_backward_variant_passes_the_same_goldens():
+    """RIGGS_CNODE_BWD=atomics (the first backward: LDS float atomics + partial tables) is read once per process: run the golden
+    and oracle cases in a child process with the switch set."""
+    import subprocess
+    import sys
+    if os.environ.get("RIGGS_CNODE_BWD") == "atomics":
+        pytest.skip("already inside the child")
+    env = dict(os.environ, RIGGS_CNODE_BWD="atomics")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_cnode.py", "-m", "gpu", "-q", "-x", "-k", "golden or oracle"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
