@@ -63,3 +63,22 @@ def test_skeleton_host_logic_cpu():
         bad = SkeletonWarp(joints=joints, parent_indices=torch.tensor([-1, 2, 1, 1, 3]), K=-1,
                            use_skinning_weight_mlp=False, use_template_offsets=False)
         bad._parents_dev(torch.device("cpu"))
+
+
+def test_argument_validation_of_the_next_row_entries_needs_no_gpu():
+    """Bad sizes / NULL buffers are rejected with a message before any HIP call (no compute, no GPU)."""
+    L = _lib.lib()
+    N = None
+    # control nodes: K > 8, hyper > 11, K > M
+    for (n, m, k, hyper) in ((10, 32, 9, 0), (10, 32, 3, 12), (10, 2, 3, 0)):
+        rc = L.riggs_cnode_forward(n, m, k, hyper, hyper, 3 + hyper, 0, *([N] * 17))
+        assert rc != 0 and L.riggs_last_error()
+    assert L.riggs_cnode_forward(10, 32, 3, 0, 0, 3, 1, *([N] * 17)) != 0            # local_frame without local_rotation
+    assert b"local_rotation" in L.riggs_last_error()
+    assert L.riggs_cnode_backward_workspace_floats(1000, 64, 3, 8) >= 33 * 3000
+    assert 1 <= L.riggs_cnode_backward_blocks(10, 64, 8) <= L.riggs_cnode_backward_blocks(10 ** 6, 64, 8) <= 512
+    # skeleton projection loss: one joint, empty sample / pixel sets, too many samples per bone
+    for (j, s, m) in ((1, 4, 4), (5, 0, 4), (5, 4, 0), (5, 4096, 4)):
+        rc = L.riggs_skeleton_projection_forward(j, s, m, N, N, N, N, 1.0, 1.0, 0.0, 0.0, N, N, N, N, N, N)
+        assert rc != 0 and L.riggs_last_error()
+    assert L.riggs_skeleton_projection_state_floats(24, 41, 1500) == 2 * 41 * 23 + 2 * 1500 + 6 * 23
