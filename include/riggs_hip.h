@@ -73,7 +73,6 @@ enum {
   RIGGS_GEOM_TILES,        /* uint32 tiles_touched */
   RIGGS_GEOM_RECT,         /* ushort4 (x0, y0, x1, y1) */
   RIGGS_GEOM_DEPTH_ORDER,  /* uint32: Gaussian indices sorted by depth bits */
-  RIGGS_GEOM_OFFSETS,      /* uint32: inclusive scan of tiles_touched in depth order */
   RIGGS_GEOM_NFIELDS_
 };
 enum {
@@ -84,7 +83,7 @@ enum {
 };
 enum {
   RIGGS_BIN_POINT_LIST = 0, /* uint32 [capacity]: Gaussian index per sorted instance */
-  RIGGS_BIN_TILE_KEYS,      /* uint32 [capacity]: tile id per sorted instance */
+  RIGGS_BIN_TILE_KEYS,      /* uint32 [capacity]: tile id per sorted instance (written with cfg.debug only) */
   RIGGS_BIN_NFIELDS_
 };
 int riggs_raster_geom_layout(int32_t num_points, size_t* offsets /*[RIGGS_GEOM_NFIELDS_]*/);

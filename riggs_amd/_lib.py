@@ -12,8 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libriggs_hip.so")
 
 # enum mirrors (include/riggs_hip.h)
-GEOM_XYD, GEOM_CONIC_O, GEOM_RGB, GEOM_COV3D, GEOM_CLAMPED, GEOM_TILES, GEOM_RECT, GEOM_DEPTH_ORDER, GEOM_OFFSETS, \
-    GEOM_NFIELDS = range(10)
+GEOM_XYD, GEOM_CONIC_O, GEOM_RGB, GEOM_COV3D, GEOM_CLAMPED, GEOM_TILES, GEOM_RECT, GEOM_DEPTH_ORDER, \
+    GEOM_NFIELDS = range(9)
 IMG_FINAL_T, IMG_N_CONTRIB, IMG_RANGES, IMG_NFIELDS = range(4)
 BIN_POINT_LIST, BIN_TILE_KEYS, BIN_NFIELDS = range(3)
 

@@ -313,8 +313,7 @@ static BinPlan bin_plan(int N, int T) {
   const int Tpad = (T + 1) & ~1;
   // 12 waves x 64 Gaussians: the ordered walk is a latency chain per wave, so short walks on many waves win;
   // beyond 12 the LDS footprint leaves one workgroup per CU
-  static const int W0 = getenv("RIGGS_BIN_W") ? atoi(getenv("RIGGS_BIN_W")) : 12;
-  int W = W0;
+  int W = 12;
   while (W > 1 && (size_t)T * 4 + (size_t)W * Tpad * 2 > 150 * 1024) W = (W + 1) >> 1;
   BinPlan p;
   p.threads = W * 64;

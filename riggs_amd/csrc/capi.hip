@@ -4,8 +4,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
 
 #include "raster_internal.h"
 
@@ -21,7 +19,7 @@ void set_error(const char* fmt, ...) {
 
 // ---- event-based kernel timing -------------------------------------------------------
 static const char* kProfNames[PROF_COUNT] = {
-    "preprocess_fwd", "depth_sort", "scan", "emit", "tile_sort", "ranges", "render_fwd", "render_bwd",
+    "preprocess_fwd", "depth_sort", "tile_sort", "render_fwd", "render_bwd",
     "preprocess_bwd", "fk_fwd", "lbs_fwd", "lbs_bwd", "fk_bwd", "knn", "pose_mlp_fwd", "pose_mlp_bwd", "adam", "loss_fwd", "loss_bwd"};
 struct ProfSlot {
   std::vector<hipEvent_t> start, stop;
@@ -45,25 +43,6 @@ void prof_end(int id, hipStream_t s) {
   if (p.used < p.start.size()) { (void)hipEventRecord(p.stop[p.used], s); p.used++; }
 }
 
-// A/B switch: RIGGS_BINNING=rocprim restores emit + rocPRIM radix sort + ranges
-static bool use_rocprim_binning() {
-  static const bool v = getenv("RIGGS_BINNING") != nullptr && strcmp(getenv("RIGGS_BINNING"), "rocprim") == 0;
-  return v;
-}
-
-static size_t sort_temp_bytes_u32(size_t n) {
-  size_t bytes = 0;
-  uint32_t* k = nullptr;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, k, k, n, 0, 32, (hipStream_t)0);
-  return bytes;
-}
-static size_t scan_temp_bytes_u32(size_t n) {
-  size_t bytes = 0;
-  uint32_t* k = nullptr;
-  (void)rocprim::inclusive_scan(nullptr, bytes, k, k, n, rocprim::plus<uint32_t>(), (hipStream_t)0);
-  return bytes;
-}
-
 GeomLayout geom_layout(int N) {
   GeomLayout L;
   size_t n = (size_t)(N > 0 ? N : 1), o = 0;
@@ -78,11 +57,7 @@ GeomLayout geom_layout(int N) {
   L.depth_key_sorted = o; o = align_up(o + n * 4);
   L.order_in = o; o = align_up(o + n * 4);
   L.order = o; o = align_up(o + n * 4);
-  L.tt_sorted = o; o = align_up(o + n * 4);
-  L.offsets = o; o = align_up(o + n * 4);
-  size_t t1 = sort_temp_bytes_u32(n), t2 = scan_temp_bytes_u32(n);
-  L.temp_bytes = align_up(t1 > t2 ? t1 : t2);
-  L.temp = o; o += L.temp_bytes;
+  L.block_tiles = o; o = align_up(o + ((n + 255) / 256) * 4);  // per-workgroup sums of tiles_touched (preprocess_fwd)
   L.sort_table = o; o += align_up(depth_sort_table_bytes(N));
   L.total = o;
   return L;
@@ -112,12 +87,8 @@ BinLayout bin_layout(int64_t cap, int N, int H, int W) {
   BinLayout L;
   const size_t T = (size_t)((W + RIGGS_TILE - 1) / RIGGS_TILE) * ((H + RIGGS_TILE - 1) / RIGGS_TILE);
   size_t n = (size_t)(cap > 0 ? cap : 1), o = 0;
-  L.vals_b = o; o = align_up(o + n * 4);   // sorted point list first (RIGGS_BIN_POINT_LIST)
-  L.keys_b = o; o = align_up(o + n * 4);
-  L.vals_a = o; o = align_up(o + n * 4);
-  L.keys_a = o; o = align_up(o + n * 4);
-  L.temp_bytes = align_up(sort_temp_bytes_u32(n));
-  L.temp = o; o += L.temp_bytes;
+  L.point_list = o; o = align_up(o + n * 4);  // sorted point list first (RIGGS_BIN_POINT_LIST)
+  L.tile_keys = o; o = align_up(o + n * 4);   // per-instance tile id (written with cfg.debug only)
   L.n_slots = (n >> 6) + T + 1;  // tile t, chunk c -> slot (range.x(t) >> 6) + t + c
   L.ckpt = o; o += align_up(L.n_slots * RIGGS_CKPT_FLOATS * 4);
   L.table = o; o += align_up(bin_table_bytes(N, (int)T));
@@ -166,7 +137,7 @@ int riggs_raster_geom_layout(int32_t N, size_t* o) {
   GeomLayout L = geom_layout(N);
   o[RIGGS_GEOM_XYD] = L.xyd; o[RIGGS_GEOM_CONIC_O] = L.conic_o; o[RIGGS_GEOM_RGB] = L.rgb;
   o[RIGGS_GEOM_COV3D] = L.cov3D; o[RIGGS_GEOM_CLAMPED] = L.clamped; o[RIGGS_GEOM_TILES] = L.tiles;
-  o[RIGGS_GEOM_RECT] = L.rect; o[RIGGS_GEOM_DEPTH_ORDER] = L.order; o[RIGGS_GEOM_OFFSETS] = L.offsets;
+  o[RIGGS_GEOM_RECT] = L.rect; o[RIGGS_GEOM_DEPTH_ORDER] = L.order;
   return 0;
 }
 int riggs_raster_image_layout(int32_t H, int32_t W, size_t* o) {
@@ -176,7 +147,7 @@ int riggs_raster_image_layout(int32_t H, int32_t W, size_t* o) {
 }
 int riggs_raster_binning_layout(int64_t cap, int32_t N, int32_t H, int32_t W, size_t* o) {
   BinLayout L = bin_layout(cap, N, H, W);
-  o[RIGGS_BIN_POINT_LIST] = L.vals_b; o[RIGGS_BIN_TILE_KEYS] = L.keys_b;
+  o[RIGGS_BIN_POINT_LIST] = L.point_list; o[RIGGS_BIN_TILE_KEYS] = L.tile_keys;
   return 0;
 }
 
@@ -206,19 +177,13 @@ static int fill_pre_args(PreArgs& a, const riggs_raster_cfg* c, const float* mea
   a.cov3D = (float*)(geom + L.cov3D); a.clamped = (uint8_t*)(geom + L.clamped); a.tiles = (uint32_t*)(geom + L.tiles);
   a.rect = (ushort4*)(geom + L.rect); a.depth_key = (uint32_t*)(geom + L.depth_key);
   a.order_in = (uint32_t*)(geom + L.order_in);
-  a.total_tiles = nullptr;
-  a.block_tiles = (uint32_t*)(geom + L.tt_sorted);
+  a.block_tiles = (uint32_t*)(geom + L.block_tiles);
   return 0;
 }
 
 static unsigned long long* g_raster_trace = nullptr;
-// debugging aid: device buffer of 6 u64 per forward WAVE (4 * tiles * 4 waves), see render_fwd_quad_kernel; NULL disables
+// debugging aid: device buffer of 6 u64 per forward WAVE (8 blocks * tiles * 4 waves), see render_fwd_oct_kernel; NULL disables
 int riggs_raster_set_trace(void* dev_u64) { g_raster_trace = (unsigned long long*)dev_u64; return 0; }
-
-static bool render_cull() {
-  static const bool v = getenv("RIGGS_RENDER_NOCULL") == nullptr;  // A/B switch
-  return v;
-}
 
 int riggs_raster_preprocess(const riggs_raster_cfg* cfg, const float* means3D, const float* shs,
                             const float* shs_rest, const float* colors_precomp, const float* opacities, const float* scales,
@@ -232,37 +197,22 @@ int riggs_raster_preprocess(const riggs_raster_cfg* cfg, const float* means3D, c
                          d_rotation, d_scaling, geom, radii);
   if (rc) return rc;
   const int N = cfg->num_points;
-  // (kept although sum_block_tiles_kernel rewrites all four words: without this memset node a captured
+  // (kept although the first kernel of the depth sort rewrites all four words: without this memset node a captured
   // hipGraph of the frame faults on replay — ROCm 7.2, reproducible, root cause not understood)
   RIGGS_HIP_CHECK(hipMemsetAsync(counters, 0, 16, s));
   if (N == 0) return 0;
   GeomLayout L = geom_layout(N);
-  // counters[0] = R (and [1..3] = 0): by the first kernel of the depth sort, or by sum_block_tiles_kernel (rocPRIM variant)
-  a.total_tiles = use_rocprim_binning() ? counters : nullptr;
+  // counters[0] = R (and [1..3] = 0) is written by the first kernel of the depth sort
   { ProfScope ps(PROF_PREPROCESS_FWD, s); launch_preprocess_fwd(a, s); }
   if (debug_sync(cfg->debug, s, "preprocess_fwd")) return 1;
-  // depth sort of the Gaussians (stable: equal depths keep ascending index)
-  size_t tb = L.temp_bytes;
-  if (!use_rocprim_binning()) {
-    ProfScope ps(PROF_DEPTH_SORT, s);  // three counting-sort passes (csrc/binning.hip)
+  // depth sort of the Gaussians (stable: equal depths keep ascending index): three counting-sort passes (csrc/binning.hip)
+  {
+    ProfScope ps(PROF_DEPTH_SORT, s);
     launch_depth_sort(N, (uint32_t*)(geom + L.depth_key), (uint32_t*)(geom + L.order_in),
                       (uint32_t*)(geom + L.depth_key_sorted), (uint32_t*)(geom + L.order), geom + L.sort_table,
                       a.block_tiles, counters, s);
-  } else {
-    ProfScope ps(PROF_DEPTH_SORT, s);
-    RIGGS_HIP_CHECK(rocprim::radix_sort_pairs(geom + L.temp, tb, (uint32_t*)(geom + L.depth_key),
-                                              (uint32_t*)(geom + L.depth_key_sorted), (uint32_t*)(geom + L.order_in),
-                                              (uint32_t*)(geom + L.order), (size_t)N, 0, 32, s));
   }
-  if (use_rocprim_binning()) {
-    ProfScope ps(PROF_SCAN, s);
-    launch_gather_tiles(N, (uint32_t*)(geom + L.order), (uint32_t*)(geom + L.tiles), (uint32_t*)(geom + L.tt_sorted), s);
-    tb = L.temp_bytes;
-    RIGGS_HIP_CHECK(rocprim::inclusive_scan(geom + L.temp, tb, (uint32_t*)(geom + L.tt_sorted),
-                                            (uint32_t*)(geom + L.offsets), (size_t)N, rocprim::plus<uint32_t>(), s));
-  }
-  // R for the host is counters[0] (accumulated by preprocess_fwd; stage 2 rewrites it with the overflow flag)
-  if (debug_sync(cfg->debug, s, "depth sort / scan")) return 1;
+  if (debug_sync(cfg->debug, s, "depth sort")) return 1;
   return 0;
 }
 
@@ -273,60 +223,32 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
   RIGGS_REQUIRE(cfg != nullptr, "cfg is NULL");
   const int N = cfg->num_points, H = cfg->image_height, W = cfg->image_width;
   const int gx = (W + RIGGS_TILE - 1) / RIGGS_TILE, gy = (H + RIGGS_TILE - 1) / RIGGS_TILE, T = gx * gy;
-  RIGGS_REQUIRE(T < 65535 * 16, "image too large");
   const char* geom = (const char*)geom_;
   char* bin = (char*)binning_;
   char* img = (char*)image_;
   GeomLayout G = geom_layout(N);
   ImageLayout I = image_layout(H, W);
   BinLayout B = bin_layout(cap, N, H, W);
-  const bool counting = N > 0 && cap > 0 && !use_rocprim_binning();
-  if (!counting)  // (the counting sort's bin_offsets_kernel writes every entry of both itself)
-    RIGGS_HIP_CHECK(hipMemsetAsync(img + I.ranges, 0, (I.tile_max - I.ranges) + (size_t)(T + 1) * 4, s));  // ranges + tile_max
-  const uint32_t* point_list = (const uint32_t*)(bin + B.vals_b);
-  if (N > 0 && cap > 0 && !use_rocprim_binning()) {
+  const bool binned = N > 0 && cap > 0;
+  if (!binned)  // (bin_offsets_kernel writes every entry of ranges / tile_max / slot_base itself)
+    RIGGS_HIP_CHECK(hipMemsetAsync(img + I.ranges, 0, (I.slot_base - I.ranges) + (size_t)(T + 2) * 4, s));
+  const uint32_t* point_list = (const uint32_t*)(bin + B.point_list);
+  if (binned) {
     // stable counting sort by tile (csrc/binning.hip)
     ProfScope ps(PROF_TILE_SORT, s);
-    point_list = (const uint32_t*)(bin + B.vals_b);
     int rcb = launch_binning(N, T, gx, cap, (const uint32_t*)(geom + G.order), (const uint32_t*)(geom + G.tiles),
-                             (const ushort4*)(geom + G.rect), bin + B.table, (uint32_t*)(bin + B.vals_b),
+                             (const ushort4*)(geom + G.rect), bin + B.table, (uint32_t*)(bin + B.point_list),
                              // the per-instance tile id is only a debugging aid here (2M scattered 4-byte stores):
                              // it is implied by `ranges`, so it is written with cfg.debug only
-                             cfg->debug ? (uint32_t*)(bin + B.keys_b) : nullptr, (uint2*)(img + I.ranges), (uint32_t*)(img + I.slot_base),
+                             cfg->debug ? (uint32_t*)(bin + B.tile_keys) : nullptr, (uint2*)(img + I.ranges), (uint32_t*)(img + I.slot_base),
                              (uint32_t*)(img + I.tile_max), counters, (uint32_t*)(img + I.fwd_items),
                              (uint32_t*)(img + I.fwd_empty), (uint32_t*)(img + I.fwd_ctr), s);
     if (rcb) return rcb;
     if (debug_sync(cfg->debug, s, "binning (counting sort)")) return 1;
-  } else if (N > 0 && cap > 0) {
-    {
-      ProfScope ps(PROF_EMIT, s);
-      launch_emit(N, gx, T, cap, (const uint32_t*)(geom + G.order), (const uint32_t*)(geom + G.offsets),
-                  (const uint32_t*)(geom + G.tiles), (const ushort4*)(geom + G.rect), (uint32_t*)(bin + B.keys_a),
-                  (uint32_t*)(bin + B.vals_a), counters, s);
-    }
-    if (debug_sync(cfg->debug, s, "emit")) return 1;
-    int end_bit = 1;
-    while ((1u << end_bit) <= (uint32_t)T) end_bit++;  // sentinel key T must be representable
-    size_t tb = B.temp_bytes;
-    {
-      ProfScope ps(PROF_TILE_SORT, s);
-      RIGGS_HIP_CHECK(rocprim::radix_sort_pairs(bin + B.temp, tb, (uint32_t*)(bin + B.keys_a), (uint32_t*)(bin + B.keys_b),
-                                                (uint32_t*)(bin + B.vals_a), (uint32_t*)(bin + B.vals_b), (size_t)cap, 0,
-                                                end_bit, s));
-    }
-    {
-      ProfScope ps(PROF_RANGES, s);
-      launch_ranges(cap, T, (const uint32_t*)(bin + B.keys_b), counters, (uint2*)(img + I.ranges), s);
-      launch_slot_base(cap, T, (const uint32_t*)(bin + B.keys_b), counters, (uint32_t*)(img + I.slot_base), s);
-    }
-    if (debug_sync(cfg->debug, s, "tile sort / ranges")) return 1;
   }
   RenderArgs r;
   r.W = W; r.H = H;
-  r.cull = render_cull() ? 1 : 0;
   r.trace = g_raster_trace;
-  { static const bool x = getenv("RIGGS_NO_XCD_MAP") == nullptr; r.xcd_map = x ? 1 : 0; }
-  { static const int t = getenv("RIGGS_FWD_ONLY_TILE") ? atoi(getenv("RIGGS_FWD_ONLY_TILE")) : -1; r.only_tile = t; }
   r.ranges = (const uint2*)(img + I.ranges);
   r.point_list = point_list;
   r.xyd = (const float4*)(geom + G.xyd); r.conic_o = (const float4*)(geom + G.conic_o); r.rgb = (const float4*)(geom + G.rgb);
@@ -335,10 +257,9 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
   r.out_color = out_color; r.out_depth = out_depth; r.out_alpha = out_alpha;
   r.final_acc = (float4*)(img + I.final_acc); r.tile_max = (uint32_t*)(img + I.tile_max);
   r.slot_base = (const uint32_t*)(img + I.slot_base); r.ckpt = (float*)(bin + B.ckpt);
-  // longest-list-first work list of the forward (only the counting sort's bin_offsets_kernel builds it)
-  { static const bool q = getenv("RIGGS_FWD_STATIC") == nullptr; r.items = nullptr;
-    if (counting && q) { r.items = (const uint32_t*)(img + I.fwd_items); r.empties = (const uint32_t*)(img + I.fwd_empty); r.item_ctr = (uint32_t*)(img + I.fwd_ctr); } }
-  if (!(N > 0 && cap > 0)) RIGGS_HIP_CHECK(hipMemsetAsync(img + I.slot_base, 0, (size_t)(T + 2) * 4, s));
+  // longest-list-first work list of the forward (bin_offsets_kernel builds it; NULL: every tile is empty)
+  r.items = nullptr; r.empties = nullptr; r.item_ctr = nullptr;
+  if (binned) { r.items = (const uint32_t*)(img + I.fwd_items); r.empties = (const uint32_t*)(img + I.fwd_empty); r.item_ctr = (uint32_t*)(img + I.fwd_ctr); }
   { ProfScope ps(PROF_RENDER_FWD, s); launch_render_fwd(r, s); }
   if (debug_sync(cfg->debug, s, "render_fwd")) return 1;
   return 0;
@@ -377,10 +298,9 @@ int riggs_raster_backward(const riggs_raster_cfg* cfg, const float* means3D, con
   r.n_points = N;
   // (the backward's statistics follow the forward's: 8 blocks x 4 waves x 6 words per tile)
   r.trace = g_raster_trace ? g_raster_trace + (size_t)(((W + RIGGS_TILE - 1) / RIGGS_TILE) * ((H + RIGGS_TILE - 1) / RIGGS_TILE)) * 8 * 4 * 6 : nullptr;
-  r.cull = render_cull() ? 1 : 0;
   r.W = W; r.H = H;
   r.ranges = (const uint2*)(img + I.ranges);
-  r.point_list = (const uint32_t*)(bin + B.vals_b);
+  r.point_list = (const uint32_t*)(bin + B.point_list);
   r.xyd = (const float4*)(geom + G.xyd); r.conic_o = (const float4*)(geom + G.conic_o); r.rgb = (const float4*)(geom + G.rgb);
   r.bg = cfg->bg;
   r.final_T = (const float*)(img + I.final_T); r.n_contrib = (const uint32_t*)(img + I.n_contrib);

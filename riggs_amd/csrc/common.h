@@ -47,7 +47,7 @@ static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a
 
 // ---- in-library kernel timing (HIP events on the launch stream; see riggs_prof_* in the ABI) ----
 enum ProfId {
-  PROF_PREPROCESS_FWD = 0, PROF_DEPTH_SORT, PROF_SCAN, PROF_EMIT, PROF_TILE_SORT, PROF_RANGES, PROF_RENDER_FWD,
+  PROF_PREPROCESS_FWD = 0, PROF_DEPTH_SORT, PROF_TILE_SORT, PROF_RENDER_FWD,
   PROF_RENDER_BWD, PROF_PREPROCESS_BWD, PROF_FK_FWD, PROF_LBS_FWD, PROF_LBS_BWD, PROF_FK_BWD, PROF_KNN, PROF_POSE_FWD,
   PROF_POSE_BWD, PROF_ADAM, PROF_LOSS_FWD, PROF_LOSS_BWD, PROF_COUNT
 };
@@ -61,8 +61,8 @@ struct ProfScope {
 
 // ---- arena layouts ---------------------------------------------------------
 struct GeomLayout {
-  size_t xyd, conic_o, rgb, cov3D, clamped, tiles, rect, depth_key, depth_key_sorted, order_in, order, tt_sorted,
-      offsets, temp, temp_bytes, sort_table, total;
+  size_t xyd, conic_o, rgb, cov3D, clamped, tiles, rect, depth_key, depth_key_sorted, order_in, order, block_tiles,
+      sort_table, total;
 };
 GeomLayout geom_layout(int N);
 
@@ -72,7 +72,7 @@ struct ImageLayout {
 ImageLayout image_layout(int H, int W);
 
 struct BinLayout {
-  size_t keys_a, keys_b, vals_a, vals_b, temp, temp_bytes, ckpt, n_slots, table, work, total;
+  size_t point_list, tile_keys, ckpt, n_slots, table, work, total;
 };
 #define RIGGS_CKPT_FLOATS (5 * 256)  // floats per checkpoint slot
 BinLayout bin_layout(int64_t cap, int N, int H, int W);

@@ -5,8 +5,6 @@
 //            <= 63 bone records (segment, radius, 3x4 transform, quaternion) staged in LDS.
 // Backward reduces over the N Gaussians inside the kernel: wave64 DPP sums -> LDS -> one atomic
 // per workgroup per output.
-#include <stdlib.h>
-
 #include "common.h"
 
 namespace riggs {
@@ -320,6 +318,8 @@ __global__ __launch_bounds__(256) void lbs_forward_kernel(LbsArgs a) {
 
 // Backward.  Per bone 13 sums over the Gaussians: dG_k (12) = sum_n w_nk * (ghat_n (x) [x_n;1]) and
 // drho_k = sum_n dL/dv_nk * u_nk * d2_nk * exp(-2 rho_k).
+// This thread-per-Gaussian kernel serves the top-K configuration (K > 0, skeleton_warp.py:46-49: every Gaussian has its
+// own bone subset); the all-bones default (K = -1) runs the bone-lane kernel below.
 __global__ __launch_bounds__(256) void lbs_backward_kernel(LbsArgs a) {
   __shared__ Bone bones[MAX_J - 1];
   __shared__ float s_acc[MAX_J - 1][13];
@@ -677,8 +677,7 @@ int riggs_lbs_backward(int32_t N, int32_t J, int32_t K, const float* x, const fl
   a.partial = (float*)workspace;
   RIGGS_REQUIRE(workspace != nullptr, "riggs_lbs_backward needs its workspace");
   hipStream_t s = (hipStream_t)stream;
-  static const bool lbs_v1 = getenv("RIGGS_LBS_BWD_V1") != nullptr;
-  if (N == 0 || K > 0 || (lbs_v1 && !weight_mod)) {  // the atomic (thread-per-Gaussian) path accumulates into zeroed outputs
+  if (N == 0 || K > 0) {  // the top-K (thread-per-Gaussian) path accumulates into zeroed outputs
     RIGGS_HIP_CHECK(hipMemsetAsync(dL_dtransforms, 0, (size_t)J * 48, s));
     RIGGS_HIP_CHECK(hipMemsetAsync(dL_dnode_radius_log, 0, (size_t)J * 4, s));
     RIGGS_HIP_CHECK(hipMemsetAsync(dL_dglobal_trans, 0, 12, s));
@@ -686,9 +685,8 @@ int riggs_lbs_backward(int32_t N, int32_t J, int32_t K, const float* x, const fl
   if (N == 0) return 0;
   {
     ProfScope ps(PROF_LBS_BWD, s);
-    static const bool v1 = getenv("RIGGS_LBS_BWD_V1") != nullptr;  // A/B switch: thread-per-Gaussian kernel
     const int nblk = (J - 1 + LB_BONES - 1) / LB_BONES;
-    if (K > 0 || (v1 && !weight_mod)) hipLaunchKernelGGL(lbs_backward_kernel, dim3((N + 255) / 256), dim3(256), 0, s, a);
+    if (K > 0) hipLaunchKernelGGL(lbs_backward_kernel, dim3((N + 255) / 256), dim3(256), 0, s, a);
     else switch (nblk) {
       case 1: launch_lbs_bwd_bonelane<1>(a, s); break;
       case 2: launch_lbs_bwd_bonelane<2>(a, s); break;

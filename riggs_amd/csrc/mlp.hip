@@ -338,11 +338,9 @@ int riggs_mlp_layout_probe(float* out32x32, riggs_stream stream) {
   return 0;
 }
 
-// A/B switch: RIGGS_MLP_ROWS=64 selects the 64-row workgroups (2 x 2 tiles per wave); default 128 rows (4 x 2)
-static int mlp_rt() {
-  static const int v = (getenv("RIGGS_MLP_ROWS") != nullptr && atoi(getenv("RIGGS_MLP_ROWS")) == 64) ? 2 : 4;
-  return v;
-}
+// 128-row workgroups: 4 x 2 tiles of 32 x 32 per wave (64-row workgroups with 2 x 2 tiles cost 0.84 / 1.01 ms against
+// 0.66 / 0.63 ms: twice the weight loads per MFMA)
+#define MLP_RT 4
 
 static int mlp_fill(MlpDesc& d, int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip, const void* const* Wp,
                     const float* const* bias, const void* Wout, const float* bout) {
@@ -365,12 +363,8 @@ int riggs_mlp_forward(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, i
   if (rc) return rc;
   if (N == 0) return 0;
   RIGGS_REQUIRE(x_emb_bf16 && out, "MLP input / output pointers");
-  if (mlp_rt() == 2)
-    hipLaunchKernelGGL(mlp_forward_kernel<2>, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, d,
-                       (const unsigned short*)x_emb_bf16, (unsigned short*)acts_bf16, (uint4*)relu_masks, out);
-  else
-    hipLaunchKernelGGL(mlp_forward_kernel<4>, dim3((N + 127) / 128), dim3(256), 0, (hipStream_t)stream, d,
-                       (const unsigned short*)x_emb_bf16, (unsigned short*)acts_bf16, (uint4*)relu_masks, out);
+  hipLaunchKernelGGL(mlp_forward_kernel<MLP_RT>, dim3((N + 127) / 128), dim3(256), 0, (hipStream_t)stream, d,
+                     (const unsigned short*)x_emb_bf16, (unsigned short*)acts_bf16, (uint4*)relu_masks, out);
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -386,12 +380,8 @@ int riggs_mlp_backward(int32_t N, int32_t out_ch, int32_t depth, int32_t skip, c
   for (int l = 0; l < depth; l++) { d.Wt[l] = (const unsigned short*)weights_t_bf16[l]; RIGGS_REQUIRE(l == 0 || d.Wt[l], "MLP transposed weights"); }
   d.Wout_t = (const unsigned short*)w_out_t_bf16;
   RIGGS_REQUIRE(d.Wout_t && g_out && relu_masks && dpre_bf16 && db_partial, "MLP backward pointers");
-  if (mlp_rt() == 2)
-    hipLaunchKernelGGL(mlp_backward_kernel<2>, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, d, g_out,
-                       (const uint4*)relu_masks, (unsigned short*)dpre_bf16, db_partial);
-  else
-    hipLaunchKernelGGL(mlp_backward_kernel<4>, dim3((N + 127) / 128), dim3(256), 0, (hipStream_t)stream, d, g_out,
-                       (const uint4*)relu_masks, (unsigned short*)dpre_bf16, db_partial);
+  hipLaunchKernelGGL(mlp_backward_kernel<MLP_RT>, dim3((N + 127) / 128), dim3(256), 0, (hipStream_t)stream, d, g_out,
+                     (const uint4*)relu_masks, (unsigned short*)dpre_bf16, db_partial);
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -430,6 +420,6 @@ int riggs_mlp_pack(int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip, c
 }
 
 /* rows per workgroup of the MLP kernels = rows that one slice of riggs_mlp_backward's db_partial covers */
-int32_t riggs_mlp_rows_per_workgroup(void) { return 32 * mlp_rt(); }
+int32_t riggs_mlp_rows_per_workgroup(void) { return 32 * MLP_RT; }
 
 }  // extern "C"

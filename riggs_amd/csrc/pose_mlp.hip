@@ -547,10 +547,8 @@ static int pm_fill(PoseMlpDesc& d, int32_t depth, int32_t width, int32_t multire
 static unsigned long long* g_pm_trace = nullptr;  // 128 u64: forward stamps [0,64), backward stamps [64,128)
 int riggs_pose_mlp_set_trace(void* dev_u64x128) { g_pm_trace = (unsigned long long*)dev_u64x128; return 0; }
 
-static bool pm_layered() {
-  static const bool v = getenv("RIGGS_POSE_MLP_LAYERED") != nullptr;  // A/B switch: one launch per layer
-  return v;
-}
+// The one-launch kernels need the rotation + translation head to fit one layer's width (n_rot + 3 <= width: up to 63
+// joints at width 256); wider heads (64 joints) and narrow test networks run one launch per layer.
 // acts: activations, then (256-byte aligned) the state of the one-launch kernels:
 //   [forward granules + gen (used when the caller passes no persistent sync_state) | err, gen, pad, pad | backward granules]
 static size_t pm_acts_core(int32_t depth, int32_t width, int32_t multires) {
@@ -575,7 +573,7 @@ int riggs_pose_mlp_forward(int32_t depth, int32_t width, int32_t multires, int32
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(PROF_POSE_FWD, s);
-  if (!pm_layered() && n_rot + 3 <= width) {
+  if (n_rot + 3 <= width) {
     const size_t sf = pm_sync_floats(depth, width);
     float* own = acts + pm_acts_core(depth, width, multires);  // [own forward state | backward state]
     float* fs = (float*)sync_state;
@@ -638,7 +636,7 @@ int riggs_pose_mlp_backward(int32_t depth, int32_t width, int32_t multires, int3
   g.row_start[depth + 1] = rows; rows += 3;
   g.row_start[depth + 2] = rows;
   ProfScope ps(PROF_POSE_BWD, s);
-  if (!pm_layered() && n_rot + 3 <= width) {
+  if (n_rot + 3 <= width) {
     float* tail = acts + pm_acts_core(depth, width, multires) + pm_sync_floats(depth, width);
     const int nr = width;
     hipLaunchKernelGGL(pm_backward_fused_kernel, dim3((nr + PMF_WAVES - 1) / PMF_WAVES), dim3(PMF_WAVES * 64), 0, s, d, g,

@@ -258,28 +258,13 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a) {
   a.depth_key[i] = __float_as_uint(vz);
   my_tiles = (uint32_t)((x1 - x0) * (y1 - y0));
   } while (0);
-  // instance count R = sum of tiles_touched: wave reduction -> per-workgroup partial (summed by a tiny
-  // second kernel; thousands of same-address atomics would serialise in L2)
+  // instance count R = sum of tiles_touched: wave reduction -> per-workgroup partial (summed by the first kernel of
+  // the depth sort; thousands of same-address atomics would serialise in L2)
   __shared__ uint32_t s_tiles[4];
   for (int o = 32; o > 0; o >>= 1) my_tiles += (uint32_t)__shfl_xor((int)my_tiles, o);
   if ((threadIdx.x & 63) == 0) s_tiles[threadIdx.x >> 6] = my_tiles;
   __syncthreads();
   if (threadIdx.x == 0) a.block_tiles[blockIdx.x] = s_tiles[0] + s_tiles[1] + s_tiles[2] + s_tiles[3];
-}
-
-__global__ __launch_bounds__(1024) void sum_block_tiles_kernel(int n, const uint32_t* __restrict__ part,
-                                                               uint32_t* __restrict__ total) {
-  __shared__ uint32_t s_w[16];
-  uint32_t v = 0;
-  for (int i = threadIdx.x; i < n; i += 1024) v += part[i];
-  for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
-  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t t = 0;
-    for (int w = 0; w < 16; w++) t += s_w[w];
-    total[0] = t; total[1] = 0u; total[2] = 0u; total[3] = 0u;
-  }
 }
 
 // ---------------------------------------------------------------------------- backward
@@ -562,8 +547,6 @@ int launch_preprocess_fwd(const PreArgs& a, hipStream_t s) {
   const int per = a.shs_rest ? (a.M - 1) * 3 : a.M * 3;
   const size_t lds = a.colors_precomp ? 0 : (size_t)256 * (per | 1) * sizeof(float);
   hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((a.N + 255) / 256), dim3(256), lds, s, a);
-  if (a.total_tiles)
-    hipLaunchKernelGGL(sum_block_tiles_kernel, dim3(1), dim3(1024), 0, s, (a.N + 255) / 256, a.block_tiles, a.total_tiles);
   return 0;
 }
 int launch_preprocess_bwd(const PreBwdArgs& b, hipStream_t s) {

@@ -16,7 +16,6 @@ struct PreArgs {
   uint32_t* tiles;
   ushort4* rect;
   uint32_t *depth_key, *order_in;
-  uint32_t* total_tiles;  // counters[0] = R (sum of tiles_touched)
   uint32_t* block_tiles;  // per-workgroup partial sums of tiles_touched
 };
 
@@ -34,9 +33,6 @@ int launch_preprocess_bwd(const PreBwdArgs& b, hipStream_t s);
 struct RenderArgs {
   int W, H;
   unsigned long long* trace;  // optional per-workgroup statistics of render_fwd (riggs_raster_set_trace), else NULL
-  int xcd_map;  // workgroups of a tile on one XCD (RIGGS_NO_XCD_MAP=1 turns it off)
-  int cull;  // instance culling against pixel blocks (RIGGS_RENDER_NOCULL=1 turns it off)
-  int only_tile;  // diagnostics: composite this tile only (RIGGS_FWD_ONLY_TILE, tools/fwd_placement.py); -1 = all
   const uint2* ranges;
   const uint32_t* point_list;
   const float4 *xyd, *conic_o, *rgb;
@@ -49,19 +45,16 @@ struct RenderArgs {
   uint32_t* tile_max;         // per tile: max n_contrib
   const uint32_t* slot_base;  // per tile: first checkpoint slot ((range.x >> 6) + tile)
   float* ckpt;                // [slot][5][256]: (T, C0, C1, C2, D) per pixel at every 64th instance
-  // work list (NULL: static blockIdx -> (tile, block) mapping): items = the non-empty tiles, longest lists
+  // work list (NULL: nothing was binned, every tile is empty): items = the non-empty tiles, longest lists
   // first; empties = the tiles without instances; item_ctr = {n_nonempty, -, n_empty}
   const uint32_t* items;
   const uint32_t* empties;
   uint32_t* item_ctr;
 };
 int launch_render_fwd(const RenderArgs& a, hipStream_t s);
-int launch_slot_base(int64_t n, int n_tiles, const uint32_t* keys_sorted, const uint32_t* counters,
-                     uint32_t* slot_base, hipStream_t s);
 
 struct RenderBwdArgs {
   unsigned long long* trace;  // optional per-chunk statistics (riggs_raster_set_trace), else NULL
-  int cull;  // instance culling against pixel blocks (RIGGS_RENDER_NOCULL=1 turns it off)
   int W, H;
   const uint2* ranges;
   const uint32_t* point_list;
@@ -78,7 +71,7 @@ struct RenderBwdArgs {
   const float* ckpt;
   int n_tiles;
   int64_t n_slots;
-  uint4* work;  // per active chunk: (tile << 16 | chunk, checkpoint slot, start of the tile's list, instances to walk)
+  uint4* work;  // per active chunk: (tile, chunk, start of the tile's list, instances to walk)
   uint32_t* work_ctr;  // {number of quarter-items, next item}
 };
 int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s);
@@ -92,11 +85,5 @@ int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order,
                    const ushort4* rect, void* table_mem, uint32_t* point_list, uint32_t* tile_keys, uint2* ranges,
                    uint32_t* slot_base, uint32_t* tile_max, uint32_t* counters, uint32_t* fwd_items,
                    uint32_t* fwd_empty, uint32_t* fwd_ctr, hipStream_t s);
-int launch_gather_tiles(int N, const uint32_t* order, const uint32_t* tiles, uint32_t* tt_sorted, hipStream_t s);
-int launch_emit(int N, int grid_x, int n_tiles, int64_t cap, const uint32_t* order, const uint32_t* offsets,
-                const uint32_t* tiles, const ushort4* rect, uint32_t* keys, uint32_t* vals, uint32_t* counters,
-                hipStream_t s);
-int launch_ranges(int64_t n, int n_tiles, const uint32_t* keys_sorted, const uint32_t* counters, uint2* ranges,
-                  hipStream_t s);
 
 }  // namespace riggs

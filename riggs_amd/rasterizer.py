@@ -292,7 +292,6 @@ def saved_views(s: _Saved):
         "tiles_touched": view(s.geom, go[L.GEOM_TILES], N * 4, torch.int32, (N,)),
         "rect": view(s.geom, go[L.GEOM_RECT], N * 8, torch.int16, (N, 4)),
         "depth_order": view(s.geom, go[L.GEOM_DEPTH_ORDER], N * 4, torch.int32, (N,)),
-        "offsets": view(s.geom, go[L.GEOM_OFFSETS], N * 4, torch.int32, (N,)),
         "final_T": view(s.img, io[L.IMG_FINAL_T], H * W * 4, torch.float32, (H, W)),
         "n_contrib": view(s.img, io[L.IMG_N_CONTRIB], H * W * 4, torch.int32, (H, W)),
         "ranges": view(s.img, io[L.IMG_RANGES], T * 8, torch.int32, (T, 2)),

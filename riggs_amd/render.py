@@ -153,60 +153,60 @@ def render(viewpoint_camera, pc, pipe, bg_color, d_xyz, d_rotation, d_scaling, d
         return RenderPkg({"render": color, "viewspace_points": screenspace_points, "visibility_filter": None,
                           "radii": radii, "depth": depth, "alpha": alpha, "bg_color": bg})
 
-    # ---- general path: the reference's own op sequence (gaussian_renderer/__init__.py:74-141) ----
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
-    try:
-        screenspace_points.retain_grad()  # gaussian_renderer/__init__.py:48-52
-    except Exception:
-        pass
-    rasterizer = GaussianRasterizer(raster_settings=settings)
-    means3D = xyz + d_xyz
-    means2D = screenspace_points
-    if scale_const is not None:
-        opacity = torch.ones_like(pc.get_opacity)
-    else:
-        opacity = pc.get_opacity if d_opacity is None else pc.get_opacity + d_opacity
-    scales = rotations = cov3D_precomp = None
+    # ---- general path: every optional branch of the reference's render(), resolved by three small helpers and
+    # handed to the drop-in GaussianRasterizer (the activations are torch ops here; the rasterizer is HIP)
+    screenspace_points = torch.zeros_like(xyz, requires_grad=True) + 0  # non-leaf, as the reference builds it
+    screenspace_points.retain_grad()
+    cut = lambda t, flag: t.detach() if (flag and t is not None) else t  # noqa: E731
+    means3D = cut(xyz + d_xyz, detach_xyz)
+    opacity = _general_opacity(pc, d_opacity, scale_const is not None)
+    shape = _general_shape(pc, pipe, scaling_modifier, d_rotation, d_scaling, d_rotation_bias, scale_const)
+    shape = {k: cut(v, (detach_rot or detach_scale) if k == "cov3D_precomp" else
+                    (detach_rot if k == "rotations" else detach_scale)) for k, v in shape.items()}
+    colour = _general_colour(pc, pipe, viewpoint_camera, xyz, d_color, override_color, render_motion)
+    image, radii, depth, alpha = GaussianRasterizer(raster_settings=settings)(
+        means3D=means3D, means2D=screenspace_points, opacities=cut(opacity, detach_opacity), **shape, **colour)
+    return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
+            "depth": depth, "alpha": alpha, "bg_color": bg}
+
+
+def _general_opacity(pc, d_opacity, constant_scale):
+    """gaussian_renderer/__init__.py:76-82: opaque splats when a constant scale is forced, else sigmoid(_opacity) (+ residual)."""
+    base = pc.get_opacity
+    if constant_scale:
+        return torch.ones_like(base)
+    return base if d_opacity is None else base + d_opacity
+
+
+def _general_shape(pc, pipe, scaling_modifier, d_rotation, d_scaling, d_rotation_bias, scale_const):
+    """Either the python 3-D covariance (:86-87) or the (scales, rotations) pair (:89-92, :129-130)."""
     if pipe.compute_cov3D_python:
-        cov3D_precomp = pc.get_covariance(scaling_modifier, d_rotation=None if type(d_rotation) is float else d_rotation,
-                                          gs_rot_bias=d_rotation_bias)
-    else:
-        scales = pc.get_scaling + d_scaling
-        rotations = pc.get_rotation_bias(d_rotation)
-        if d_rotation_bias is not None:
-            rotations = quaternion_multiply(d_rotation_bias, rotations)
-    shs = colors_precomp = None
-    if render_motion:
-        colors_precomp = torch.zeros_like(xyz)
-        colors_precomp[..., :1] = pc.motion_mask
-        colors_precomp[..., -1:] = 1 - pc.motion_mask
-    elif override_color is None:
-        feats = pc.get_features
-        if d_color is not None and type(d_color) is not float:
-            feats = torch.cat([feats[:, :1] + d_color[:, None], feats[:, 1:]], dim=1)
-        if pipe.convert_SHs_python:
-            from .sh import eval_sh
-            shs_view = feats.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
-            dir_pp = xyz - viewpoint_camera.camera_center.repeat(feats.shape[0], 1)
-            colors_precomp = torch.clamp_min(eval_sh(pc.active_sh_degree, shs_view, dir_pp / dir_pp.norm(dim=1, keepdim=True)) + 0.5, 0.0)
-        else:
-            shs = feats
-    else:
-        colors_precomp = override_color
-    if detach_xyz:
-        means3D = means3D.detach()
-    if detach_rot or detach_scale:
-        if cov3D_precomp is not None:
-            cov3D_precomp = cov3D_precomp.detach()
-        else:
-            rotations = rotations.detach() if detach_rot else rotations
-            scales = scales.detach() if detach_scale else scales
-    if detach_opacity:
-        opacity = opacity.detach()
+        dr = d_rotation if isinstance(d_rotation, torch.Tensor) else None
+        return {"scales": None, "rotations": None,
+                "cov3D_precomp": pc.get_covariance(scaling_modifier, d_rotation=dr, gs_rot_bias=d_rotation_bias)}
+    rotations = pc.get_rotation_bias(d_rotation)
+    if d_rotation_bias is not None:
+        rotations = quaternion_multiply(d_rotation_bias, rotations)
+    scales = pc.get_scaling + d_scaling
     if scale_const is not None:
-        scales = scale_const * torch.ones_like(scales)
-    rendered_image, radii, depth, alpha = rasterizer(means3D=means3D, means2D=means2D, shs=shs,
-                                                     colors_precomp=colors_precomp, opacities=opacity, scales=scales,
-                                                     rotations=rotations, cov3D_precomp=cov3D_precomp)
-    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
-            "radii": radii, "depth": depth, "alpha": alpha, "bg_color": bg}
+        scales = torch.full_like(scales, float(scale_const))
+    return {"scales": scales, "rotations": rotations, "cov3D_precomp": None}
+
+
+def _general_colour(pc, pipe, cam, xyz, d_color, override_color, render_motion):
+    """Where the splat colour comes from (:94-116): the motion-mask visualisation, a caller-supplied colour, SH evaluated
+    in python, or the SH coefficients themselves (evaluated by the rasterizer)."""
+    if render_motion:
+        mm = pc.motion_mask
+        return {"shs": None, "colors_precomp": torch.cat([mm, torch.zeros_like(mm), 1 - mm], dim=-1)}
+    if override_color is not None:
+        return {"shs": None, "colors_precomp": override_color}
+    feats = pc.get_features
+    if isinstance(d_color, torch.Tensor):
+        feats = torch.cat([feats[:, :1] + d_color[:, None], feats[:, 1:]], dim=1)
+    if not pipe.convert_SHs_python:
+        return {"shs": feats, "colors_precomp": None}
+    from .sh import eval_sh
+    view_dir = torch.nn.functional.normalize(xyz - cam.camera_center[None], dim=1, eps=0.0)
+    rgb = eval_sh(pc.active_sh_degree, feats.transpose(1, 2).reshape(-1, 3, (pc.max_sh_degree + 1) ** 2), view_dir)
+    return {"shs": None, "colors_precomp": torch.clamp_min(rgb + 0.5, 0.0)}

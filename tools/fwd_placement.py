@@ -1,6 +1,5 @@
 """Where do the forward compositing kernel's workgroups run, and which pixel blocks are its critical path?
-usage: python tools/fwd_placement.py            (RIGGS_RENDER_FWD=4 selects the quad-lane kernel: 4 blocks per tile)
-       RIGGS_FWD_ONLY_TILE=<tile> python tools/fwd_placement.py      -> that tile alone on the chip"""
+usage: python tools/fwd_placement.py"""
 import os
 import sys
 
@@ -13,7 +12,7 @@ from riggs_amd import _lib as L  # noqa: E402
 from riggs_amd.dist import FlatGradAllReduce  # noqa: E402
 from riggs_amd.rasterizer import RasterArena  # noqa: E402
 
-BPT = 4 if os.environ.get("RIGGS_RENDER_FWD") == "4" else 8  # pixel blocks (workgroups) per tile; 4 waves each
+BPT = 8  # pixel blocks (workgroups) per tile; 4 waves each
 w = bench.WORKLOAD
 sc, cam, gm, sw = bench.build_workload(0, "cuda:0")
 T = ((w["W"] + 15) // 16) * ((w["H"] + 15) // 16)

@@ -17,7 +17,7 @@ def main():
     w = bench.WORKLOAD
     sc, cam, gm, sw = bench.build_workload(0, "cuda:0")
     T = ((w["W"] + 15) // 16) * ((w["H"] + 15) // 16)
-    BPT = 4 if os.environ.get("RIGGS_RENDER_FWD") == "4" else 8  # pixel blocks (workgroups) per tile; 4 waves each
+    BPT = 8  # pixel blocks (workgroups) per tile; 4 waves each
     trace = torch.zeros(T * BPT * 4 * 6, dtype=torch.int64, device="cuda")
     gimg = torch.rand(3, w["H"], w["W"], device="cuda") * 1e-6
     step = bench.make_step(cam, gm, sw, gimg, RasterArena(), 1, FlatGradAllReduce(bench.params_of(gm, sw), register=False))
