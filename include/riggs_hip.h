@@ -107,8 +107,10 @@ int riggs_raster_preprocess(const riggs_raster_cfg* cfg, const float* means3D, c
                             const float* d_rotation, const float* d_scaling, void* geom, int32_t* radii,
                             uint32_t* counters /* device [4]: R, overflow, rsv, rsv */, riggs_stream stream);
 
-/* Stage 2: instance emission (duplicateWithKeys), stable tile sort, tile ranges, and the
- * per-tile alpha compositing.  `instance_capacity` bounds R: if R > capacity the launch is
+/* Stage 2: stable counting sort of the (depth-ordered) Gaussians' tile instances by tile — the order of upstream's
+ * duplicateWithKeys + 64-bit key sort + identifyTileRanges — and the per-tile alpha compositing.
+ * Limits: at most 25 600 tiles (e.g. 2560 x 2560 px; the per-workgroup tile table of the binning lives in LDS) —
+ * larger images are rejected with an error, never mis-rendered.  `instance_capacity` bounds R: if R > capacity the launch is
  * still memory-safe, counters[1] is set to 1 and the image is undefined (caller retries
  * with a larger arena; riggs_amd.rasterizer does that). */
 int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom, void* binning, int64_t instance_capacity,
@@ -116,6 +118,9 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom, void* bin
                         float* out_alpha /*(1,H,W)*/, uint32_t* counters, riggs_stream stream);
 
 /* Backward of both stages.  Gradient outputs are fully written (no pre-zeroing needed).
+ * `counters` is the forward's: when its overflow flag (counters[1]) is set the frame composited truncated
+ * lists, and the backward writes exact ZERO gradients (device-side guard: an optimizer step queued behind it —
+ * e.g. inside a captured hipGraph — sees zeros, never garbage); NULL skips the guard.
  * dL_ddepth / dL_dalpha may be NULL (RigGS stage 2 uses only "render": train_rig.py:499).
  * Outputs that do not apply (e.g. dL_dsh with colors_precomp) may be NULL.
  * With cfg->glue the outputs are gradients w.r.t. the raw tensors: dL_dmeans3D = dL/d_xyz = dL/dd_xyz,
@@ -198,6 +203,12 @@ size_t riggs_lbs_backward_workspace_bytes(int32_t num_points, int32_t num_joints
  * ===================================================================== */
 size_t riggs_pose_mlp_acts_floats(int32_t depth, int32_t width, int32_t multires);
 size_t riggs_pose_mlp_sync_bytes(int32_t depth, int32_t width);
+/* Index (32-bit words) of the STICKY status word inside sync_state.  The one-launch kernels pass data between
+ * workgroups by bounded spinning, which needs all of a launch's workgroups co-resident (<= 96 workgroups of 512
+ * threads: true on an otherwise idle MI355X; NOT guaranteed when another process or a concurrent stream holds
+ * CUs for long).  A spin that times out poisons that launch's outputs with NaN and sets bit 0 of this word; no
+ * kernel ever clears it.  The host reads it after a step (PoseMLP.check_status / GraphedFrame.check) and raises. */
+size_t riggs_pose_mlp_status_word(int32_t depth, int32_t width);
 /* debugging aid: 128 device u64 that workgroup 0 of the one-launch kernels stamps with the 100 MHz wall clock
  * per stage (forward [0,64), backward [64,128)); NULL (the default) disables it. */
 int riggs_pose_mlp_set_trace(void* dev_u64x128);
@@ -211,7 +222,7 @@ int riggs_pose_mlp_backward(int32_t depth, int32_t width, int32_t multires, int3
                             const float* const* weights, const float* const* biases, const float* W_rot,
                             const float* b_rot, const float* W_tr, const float* b_tr, float* acts,
                             const float* g_rotation, const float* g_translation, float* workspace,
-                            float* flat_grads, riggs_stream stream);
+                            float* flat_grads, void* sync_state /* the forward's, or NULL */, riggs_stream stream);
 
 /* =====================================================================
  * Gaussian optimizer.

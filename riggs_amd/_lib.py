@@ -55,7 +55,8 @@ _SIGS = {
     "riggs_pose_mlp_forward": (C.c_int, [C.c_int32] * 5 + [_P] * 13),
     "riggs_pose_mlp_sync_bytes": (C.c_size_t, [C.c_int32] * 2),
     "riggs_pose_mlp_set_trace": (C.c_int, [_P]),
-    "riggs_pose_mlp_backward": (C.c_int, [C.c_int32] * 5 + [_P] * 12),
+    "riggs_pose_mlp_backward": (C.c_int, [C.c_int32] * 5 + [_P] * 13),
+    "riggs_pose_mlp_status_word": (C.c_size_t, [C.c_int32] * 2),
     "riggs_adam_step": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, _P]),
     "riggs_adam_step_capturable": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, _P]),
     "riggs_densify_stats": (C.c_int, [C.c_int32] + [_P] * 7),

@@ -337,7 +337,10 @@ int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order,
   uint32_t* table = (uint32_t*)mem;
   uint32_t* tile_count = (uint32_t*)(mem + align_up(((size_t)p.n_chunks + 1) * T * 4));
   uint32_t* tile_start = (uint32_t*)((char*)tile_count + align_up((size_t)(T + 1) * 4));
-  if ((size_t)T * 4 > 150 * 1024) { set_error("too many tiles for the LDS histogram (%d)", T); return 2; }
+  if (p.lds_scatter > 150 * 1024) {  // (bin_plan is down to one wave per workgroup: T * 6 bytes of LDS)
+    set_error("image too large: %d tiles, the tile binning holds its per-workgroup tile table in LDS and takes at most 25600 (e.g. 2560 x 2560 px)", T);
+    return 2;
+  }
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bin_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -276,8 +276,8 @@ int riggs_raster_backward(const riggs_raster_cfg* cfg, const float* means3D, con
                           float* dL_dscales, float* dL_drotations, float* dL_dcov3D, float* dL_dd_scaling,
                           float* dL_dsh_rest, riggs_stream stream_) {
   hipStream_t s = (hipStream_t)stream_;
-  (void)counters;
   PreBwdArgs b;
+  b.counters = counters;
   int rc = fill_pre_args(b.f, cfg, means3D, shs, shs_rest, colors_precomp, opacities, scales, rotations, cov3D_precomp, d_xyz,
                          d_rotation, d_scaling, (char*)geom_, (int32_t*)radii);
   if (rc) return rc;

@@ -211,7 +211,7 @@ __device__ __forceinline__ bool pm_sweep_check(const unsigned long long (&x)[4],
   return __all(ok);
 }
 __device__ __forceinline__ bool pm_sweep(const unsigned long long* gran, int n, uint32_t tag, float (&v)[4],
-                                         uint32_t* err, int lane) {
+                                         uint32_t* err, uint32_t* sticky, int lane) {
   pm_gu64* g = (pm_gu64*)gran;
   unsigned long long x[PMF_INFLIGHT][4];
 #pragma unroll
@@ -226,7 +226,9 @@ __device__ __forceinline__ bool pm_sweep(const unsigned long long* gran, int n, 
       pm_sweep_issue(g, n, lane, x[q]);
     }
     if (spins > PMF_SPIN_MAX / PMF_INFLIGHT) {
-      if (lane == 0) atomicOr(err, 1u);
+      // per-call word (poisons this launch's outputs) and, when the caller keeps a persistent sync_state, its
+      // STICKY status word: never cleared by a kernel, read by the host (riggs_pose_mlp_status_word)
+      if (lane == 0) { atomicOr(err, 1u); if (sticky) atomicOr(sticky, 1u); }
       return false;
     }
   }
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_forward_fused_kernel(PoseMl
                                                                           const float* __restrict__ rot_bias4,
                                                                           float* __restrict__ acts,
                                                                           unsigned long long* gran, uint32_t* gen,
-                                                                          uint32_t* bwd_state, int bwd_words,
+                                                                          uint32_t* sticky, uint32_t* bwd_state, int bwd_words,
                                                                           float* __restrict__ rotation,
                                                                           float* __restrict__ translation,
                                                                           float* __restrict__ wt, int n_chain,
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_forward_fused_kernel(PoseMl
           // input of layer l = h_{l-1} (behind the embedding when layer l-1 was the skip layer)
           float v[4];
           bool ok = (s_failed == 0);
-          if (ok) ok = pm_sweep(gran + (size_t)(l - 1) * d.width, d.width, tag0 + (uint32_t)l, v, err, lane);
+          if (ok) ok = pm_sweep(gran + (size_t)(l - 1) * d.width, d.width, tag0 + (uint32_t)l, v, err, sticky, lane);
           if (!ok && lane == 0) s_failed = 1;
           const int off = (l - 1 == d.skip) ? emb : 0;
           if (off > 0 && lane < emb) s_in[lane] = embv;
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_backward_fused_kernel(PoseM
                                                                            const float* __restrict__ g_rot,
                                                                            const float* __restrict__ g_tr,
                                                                            unsigned long long* gran, uint32_t* err,
-                                                                           uint32_t* gen, float* __restrict__ flat,
+                                                                           uint32_t* sticky, uint32_t* gen, float* __restrict__ flat,
                                                                            const float* __restrict__ wt,
                                                                            unsigned long long* trace) {
   __shared__ float s_v[PM_MAX_W];
@@ -454,7 +456,7 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_backward_fused_kernel(PoseM
           }
           float v[4];
           bool ok = (s_failed == 0);
-          if (ok) ok = pm_sweep(gran + (size_t)l * d.width, d.width, tag0 + (uint32_t)(l + 1), v, err, lane);
+          if (ok) ok = pm_sweep(gran + (size_t)l * d.width, d.width, tag0 + (uint32_t)(l + 1), v, err, sticky, lane);
           if (!ok && lane == 0) s_failed = 1;
 #pragma unroll
           for (int k = 0; k < 4; k++) {
@@ -558,6 +560,9 @@ static size_t pm_sync_floats(int32_t depth, int32_t width) {  // granules (2 flo
   return (2 * (size_t)depth * width + 4 + 63) & ~(size_t)63;
 }
 size_t riggs_pose_mlp_sync_bytes(int32_t depth, int32_t width) { return pm_sync_floats(depth, width) * sizeof(float); }
+// index (in 32-bit words) of the sticky status word inside sync_state: bit 0 = a hand-off spin of the one-launch
+// kernels timed out (their outputs were poisoned with NaN)
+size_t riggs_pose_mlp_status_word(int32_t depth, int32_t width) { return 2 * (size_t)depth * width + 1; }
 // ... then the transposed consumer matrices (depth x 256 x 256) the forward launch prepares for the backward
 size_t riggs_pose_mlp_acts_floats(int32_t depth, int32_t width, int32_t multires) {
   return pm_acts_core(depth, width, multires) + 2 * pm_sync_floats(depth, width) + (size_t)depth * PM_MAX_W * PM_MAX_W;
@@ -584,7 +589,8 @@ int riggs_pose_mlp_forward(int32_t depth, int32_t width, int32_t multires, int32
     }
     const int n_chain = (width + PMF_WAVES - 1) / PMF_WAVES;  // + 64 transposer workgroups on otherwise idle CUs
     hipLaunchKernelGGL(pm_forward_fused_kernel, dim3(n_chain + 64), dim3(PMF_WAVES * 64), 0, s, d, t, rot_bias4, acts,
-                       (unsigned long long*)fs, (uint32_t*)(fs + 2 * (size_t)depth * width), (uint32_t*)(own + sf), (int)sf,
+                       (unsigned long long*)fs, (uint32_t*)(fs + 2 * (size_t)depth * width),
+                       sync_state ? (uint32_t*)(fs + 2 * (size_t)depth * width) + 1 : nullptr, (uint32_t*)(own + sf), (int)sf,
                        rotation, translation, own + 2 * sf, n_chain, g_pm_trace);
     RIGGS_HIP_CHECK(hipGetLastError());
     return 0;
@@ -610,7 +616,7 @@ int riggs_pose_mlp_backward(int32_t depth, int32_t width, int32_t multires, int3
                             const float* const* weights, const float* const* biases, const float* W_rot,
                             const float* b_rot, const float* W_tr, const float* b_tr, float* acts,
                             const float* g_rotation, const float* g_translation, float* workspace,
-                            float* flat_grads, riggs_stream stream) {
+                            float* flat_grads, void* sync_state, riggs_stream stream) {
   PoseMlpDesc d;
   int rc = pm_fill(d, depth, width, multires, skip, n_rot, weights, biases, W_rot, b_rot, W_tr, b_tr);
   if (rc) return rc;
@@ -641,6 +647,7 @@ int riggs_pose_mlp_backward(int32_t depth, int32_t width, int32_t multires, int3
     const int nr = width;
     hipLaunchKernelGGL(pm_backward_fused_kernel, dim3((nr + PMF_WAVES - 1) / PMF_WAVES), dim3(PMF_WAVES * 64), 0, s, d, g,
                        acts, g_rotation, g_translation, (unsigned long long*)(tail + 4), (uint32_t*)tail,
+                       sync_state ? (uint32_t*)sync_state + 2 * (size_t)depth * width + 1 : nullptr,
                        (uint32_t*)tail + 1, flat_grads, tail + pm_sync_floats(depth, width),
                        g_pm_trace ? g_pm_trace + 64 : nullptr);
     RIGGS_HIP_CHECK(hipGetLastError());

@@ -286,7 +286,10 @@ __global__ __launch_bounds__(256, 3) void preprocess_bwd_kernel(PreBwdArgs b) {
   const int t0 = threadIdx.x, lane0 = t0 & 63, wave0 = t0 >> 6;
   const int i0 = blockIdx.x * 256 + t0;
   bool touched0 = false;
-  if (i0 < a.N && a.radii[i0] > 0) {
+  // (a frame whose instance arena overflowed composited truncated lists: its gradients are undefined, so every
+  // Gaussian is treated as untouched and the optimizer sees zeros until the host notices the flag and re-renders)
+  const bool overflowed = b.counters != nullptr && b.counters[1] != 0u;
+  if (i0 < a.N && !overflowed && a.radii[i0] > 0) {
     const float4* acc4 = reinterpret_cast<const float4*>(b.g_mean2D_conic + (size_t)i0 * RIGGS_GACC);
     const float4 q0 = acc4[0], q1 = acc4[1], q2 = acc4[2];
     touched0 = (q0.x != 0.f) || (q0.y != 0.f) || (q0.z != 0.f) || (q0.w != 0.f) || (q1.x != 0.f) || (q1.y != 0.f) ||

@@ -21,6 +21,7 @@ struct PreArgs {
 
 struct PreBwdArgs {
   PreArgs f;                     // forward inputs (radii/xyd/... unused here except radii, cov3D, clamped)
+  const uint32_t* counters;      // the forward's {R, overflow flag}: an overflowed frame back-propagates exact zeros
   const float* g_mean2D_conic;   // workspace: per Gaussian [mean2D.x, mean2D.y, gA, gB, gC, g_opacity, g_r, g_g, g_b, g_depth]
   float *dL_dmeans3D, *dL_dmeans2D, *dL_dsh, *dL_dcolors, *dL_dopac, *dL_dscales, *dL_drots, *dL_dcov3D, *dL_dd_scaling, *dL_dsh_rest;
 };

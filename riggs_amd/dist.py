@@ -16,22 +16,41 @@ import torch.distributed as dist
 # parameter data_ptr -> (flat buffer, offset, shape): the HIP backward functions (rasterizer, PoseMLP, deformation) write
 # a parameter's gradient straight into its slice of ONE flat buffer, so the all-reduce runs in place — no pack (71 MB
 # torch.cat at 300k Gaussians), no divide pass, no per-step Python loop re-pointing p.grad.
-_SLICES = {}
+_SLICES = {}  # parameter data_ptr -> (flat buffer, offset, shape, weakref to the parameter)
+
+
+def _entry(param: torch.Tensor):
+    """The live registry entry of ``param`` or None.  An entry dies with its parameter: densification / pruning replace
+    the parameter tensors, and a NEW tensor that the allocator happens to place at the old address must not be routed
+    into the old bucket."""
+    ent = _SLICES.get(param.data_ptr())
+    if ent is None:
+        return None
+    owner = ent[3]()
+    if owner is None:
+        del _SLICES[param.data_ptr()]
+        return None
+    return ent
 
 
 def grad_out(param: torch.Tensor, shape=None) -> torch.Tensor:
     """The tensor a backward should write ``dL/dparam`` into: the parameter's slice of a registered
-    ``FlatGradAllReduce`` bucket, else a fresh buffer.  Only valid when gradients are cleared (set to None) between
-    steps — accumulating into a live ``.grad`` that aliases the slice would double count."""
+    ``FlatGradAllReduce`` bucket, else a fresh buffer.  A slice is handed out only while the parameter's ``.grad``
+    does not already alias it: a second backward through the same parameter in one step (gradient accumulation, two
+    renders per iteration, ``zero_grad(set_to_none=False)``) gets a fresh buffer, which autograd then ADDS to the
+    live ``.grad`` — writing into the aliased slice would overwrite the first gradient and double the second."""
     shape = tuple(param.shape if shape is None else shape)
-    ent = _SLICES.get(param.data_ptr())
+    ent = _entry(param)
     if ent is not None:
-        flat, off, shp = ent
+        flat, off, shp, ref = ent
         if shp == shape and flat.device == param.device:
             n = 1
             for d in shape:
                 n *= d
-            return flat[off:off + n].view(shape)
+            view = flat[off:off + n].view(shape)
+            live = ref().grad
+            if live is None or live.data_ptr() != view.data_ptr():
+                return view
     return torch.empty(shape, dtype=torch.float32, device=param.device)
 
 
@@ -40,13 +59,15 @@ def grad_out_flat(params) -> torch.Tensor:
     parameter gradients as one flat array): the bucket's own range when these parameters are registered back to
     back, else a fresh buffer."""
     total = sum(p.numel() for p in params)
-    ents = [_SLICES.get(p.data_ptr()) for p in params]
+    ents = [_entry(p) for p in params]
     if total and all(e is not None for e in ents):
         flat, off0 = ents[0][0], ents[0][1]
         o = off0
         ok = True
-        for p, (f, off, shp) in zip(params, ents):
+        for p, (f, off, shp, ref) in zip(params, ents):
+            live = ref().grad
             ok = ok and f is flat and off == o and shp == tuple(p.shape)
+            ok = ok and (live is None or live.data_ptr() != flat[off:off + 1].data_ptr())  # (see grad_out)
             o += p.numel()
         if ok and flat.device == params[0].device:
             return flat[off0:off0 + total]
@@ -78,8 +99,9 @@ class FlatGradAllReduce:
             self.register()
 
     def register(self):
+        import weakref
         for p, o in zip(self.params, self.offsets):
-            _SLICES[p.data_ptr()] = (self.flat, o, tuple(p.shape))
+            _SLICES[p.data_ptr()] = (self.flat, o, tuple(p.shape), weakref.ref(p))
         self.registered = True
 
     def __del__(self):

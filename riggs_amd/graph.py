@@ -96,7 +96,11 @@ class GraphedFrame:
         return self.out
 
     def check(self):
-        """Blocking read-back of the instance counters of the last replay; raises on arena overflow."""
+        """Blocking read-back of the instance counters of the last replay; raises on arena overflow and on a timed-out
+        workgroup hand-off of the one-launch PoseMLP kernels (their status word is sticky across replays)."""
+        pose_net = getattr(self.sw, "pose_net", None)
+        if pose_net is not None and hasattr(pose_net, "check_status"):
+            pose_net.check_status()
         c = self.arena.static_counters[:2].tolist()
         R, overflow = int(c[0]) & 0xFFFFFFFF, int(c[1])
         if overflow:

@@ -191,6 +191,8 @@ def rasterize_backward(s: _Saved, means3D, shs, colors_precomp, opacities, scale
     g_cov = torch.empty(N, 6, **f32) if cov3D_precomp is not None else None
     g_dscaling = torch.empty(N, 3, **f32) if (d_scaling is not None and want_d_scaling_grad) else None
     ws = torch.empty(lib.riggs_raster_backward_workspace_bytes(N), dtype=torch.uint8, device=dev)
+    if grad_color is None:  # a loss on depth / alpha only (set_materialize_grads(False) hands None for the unused output)
+        grad_color = torch.zeros(3, s.H, s.W, **f32)
     gc = L.require_cuda_f32("grad_color", grad_color, (3, s.H, s.W))
     gd = L.require_cuda_f32("grad_depth", grad_depth) if grad_depth is not None else None
     ga = L.require_cuda_f32("grad_alpha", grad_alpha) if grad_alpha is not None else None

@@ -51,6 +51,20 @@ class PoseMLP(nn.Module):
         self.register_buffer("_hip_sync", torch.zeros(2 * depth * hidden_dimensions + 64, dtype=torch.int32),
                              persistent=False)
 
+    def check_status(self):
+        """Blocking read of the sticky status word of the one-launch HIP kernels (include/riggs_hip.h:
+        riggs_pose_mlp_status_word).  Raises — and clears the word — when a hand-off spin timed out since the last
+        check: that launch's pose was poisoned with NaN (the kernels need their <= 96 workgroups co-resident; a GPU
+        shared with long-running kernels of another stream or process can break that)."""
+        sync = self._hip_sync
+        if not sync.is_cuda:
+            return
+        w = int(L.lib().riggs_pose_mlp_status_word(len(self.net), self.net[0].out_features))
+        if w < sync.numel() and int(sync[w].item()) != 0:
+            sync[w] = 0
+            raise L.RiggsHipError("PoseMLP: a workgroup hand-off of the one-launch kernel timed out (GPU shared with "
+                                  "another long-running kernel?); the pose of that step was NaN — discard the step")
+
     def _fusable(self, t):
         w = self.net[0].out_features
         return (t.is_cuda and t.dtype == torch.float32 and t.numel() == 1 and self.multires > 0 and w <= 256
@@ -181,6 +195,7 @@ class _PoseMLPFn(torch.autograd.Function):
                 "riggs_pose_mlp_forward")
         ctx.save_for_backward(acts, *params)
         ctx.cfg = (depth, width, multires, skip, n_rot)
+        ctx.sync = sync
         return rot, tr
 
     @staticmethod
@@ -200,7 +215,7 @@ class _PoseMLPFn(torch.autograd.Function):
         L.check(lib.riggs_pose_mlp_backward(depth, width, multires, skip, n_rot, Wp, bp, h[0].data_ptr(),
                                             h[1].data_ptr(), h[2].data_ptr(), h[3].data_ptr(), acts.data_ptr(),
                                             g_rot.data_ptr(), g_tr.data_ptr(), dzs.data_ptr(), flat.data_ptr(),
-                                            L.stream_ptr()), "riggs_pose_mlp_backward")
+                                            L.ptr(ctx.sync), L.stream_ptr()), "riggs_pose_mlp_backward")
         grads, o = [], 0
         for p in params:
             n = p.numel()

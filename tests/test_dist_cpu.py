@@ -83,3 +83,38 @@ def test_frame_assignment_is_one_frame_per_rank():
     frames = list(range(8))
     assert [frame_for_rank(frames, 0, r, 8) for r in range(8)] == frames
     assert frame_for_rank(frames, 1, 3, 4) == 7
+
+
+def test_bucket_slices_are_not_handed_out_twice_and_die_with_their_parameter():
+    """riggs_amd.dist.grad_out: a parameter whose .grad already aliases its slice gets a fresh buffer for the next
+    backward (autograd then accumulates: no lost / doubled gradient), and an entry does not outlive its parameter."""
+    import gc
+    from riggs_amd import dist as D
+    ps = [torch.nn.Parameter(torch.randn(8, 3)), torch.nn.Parameter(torch.randn(12))]
+    bucket = FlatGradAllReduce(ps, register=True)
+    try:
+        first = D.grad_out(ps[0])
+        assert first.data_ptr() == bucket.views[0].data_ptr()
+        first.fill_(1.0)
+        ps[0].grad = first                      # what AccumulateGrad does with the first backward's output
+        second = D.grad_out(ps[0])              # second backward of the same step
+        assert second.data_ptr() != first.data_ptr()
+        second.fill_(2.0)
+        ps[0].grad += second
+        assert float(ps[0].grad.sum()) == 3.0 * 24 and float(bucket.views[0].sum()) == 3.0 * 24
+        ps[0].grad = None
+        assert D.grad_out(ps[0]).data_ptr() == first.data_ptr()
+        flat = D.grad_out_flat(ps)
+        assert flat.data_ptr() == bucket.flat.data_ptr() and flat.numel() == 36
+        ps[1].grad = bucket.views[1]
+        assert D.grad_out_flat(ps).data_ptr() != bucket.flat.data_ptr()
+        # an entry whose parameter died is dropped instead of capturing the next tensor at that address
+        key = ps[1].data_ptr()
+        bucket.params, bucket.views = bucket.params[:1], bucket.views[:1]
+        del ps[1]
+        gc.collect()
+        probe = torch.empty(12)
+        probe.data_ptr = lambda: key  # a new tensor the allocator placed at the dead parameter's address
+        assert D._entry(probe) is None and key not in D._SLICES
+    finally:
+        bucket.unregister()

@@ -1,0 +1,150 @@
+"""-m gpu: BASELINE.json configs C4 and C5.
+
+C4 = ZJU-MoCap-like: ~500k Gaussians, 24 joints, 1024x1024, the camera built from an intrinsic matrix K with an
+off-centre principal point (+13, -7) px — the reference's ``getProjectionMatrix_from_K`` path
+(/root/reference/utils/graphics_utils.py:79-100, scene/cameras.py:61-72).
+C5 = 2M Gaussians, 64 joints, 1920x1080.
+At sizes the CPU oracle finishes in seconds the HIP path is compared with it; at full size through properties.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import deform_ref as O  # noqa: E402
+from oracle import raster_ref as RR  # noqa: E402
+from riggs_amd import synth  # noqa: E402
+from riggs_amd.gaussian_model import GaussianModel  # noqa: E402
+from riggs_amd.rasterizer import rasterize_backward, rasterize_forward, saved_views  # noqa: E402
+from riggs_amd.render import render  # noqa: E402
+from riggs_amd.skeleton import SkeletonWarp  # noqa: E402
+from tests import gpu_util as U  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def zju_K(H, W, fovx=0.6911112, dx=13.0, dy=-7.0):
+    """Intrinsics with the principal point moved off the image centre."""
+    fx = W / (2.0 * math.tan(fovx / 2))
+    fy = H / (2.0 * math.tan(fovx / 2))
+    return np.array([[fx, 0.0, W / 2.0 + dx], [0.0, fy, H / 2.0 + dy], [0.0, 0.0, 1.0]])
+
+
+def test_c4_from_K_camera_parity_vs_oracle():
+    """1024x1024, projection from K with a (+13, -7) px principal point, 20k Gaussians: HIP vs the CPU oracle."""
+    N, J, H, W = 20_000, 24, 1024, 1024
+    sc, act, cam = U.activated_scene(N, J, 1238, H, W, scale=0.02, K=zju_K(H, W))
+    cam_sym = synth.look_at_camera(H, W)
+    assert not torch.allclose(cam.full_proj_transform, cam_sym.full_proj_transform, atol=1e-3)  # really off-centre
+    bg = [0.2, 0.1, 0.0]
+    out_o, so = U.oracle_forward(act, cam, bg)
+    color, radii, depth, alpha, s = U.hip_forward(act, cam, bg)
+    U.compare_forward_state(so, saved_views(s), out_o, color, depth, alpha, radii)
+    # ... and it moves the picture by (13, -7) px: the pixel centres differ from the symmetric projection's by that much
+    so_sym = U.oracle_forward(act, cam_sym, bg)[1]
+    both = (so.radii > 0) & (so_sym.radii > 0)
+    shift = (so.xy[both] - so_sym.xy[both]).mean(0)
+    assert abs(shift[0] - 13.0) < 0.05 and abs(shift[1] + 7.0) < 0.05, shift
+    g = torch.Generator().manual_seed(5)
+    gc = torch.sign(torch.rand(3, H, W, generator=g) - 0.5) / (3 * H * W)
+    go = RR.backward(so, gc.numpy(), None, None)
+    d = lambda t: t.cuda().contiguous()  # noqa: E731
+    gh = rasterize_backward(s, d(act["means3D"]), d(act["shs"]), None, d(act["opacities"]), d(act["scales"]),
+                            d(act["rotations"]), None, None, None, d(gc), None, None)
+    for got, name in ((gh[0], "means3D"), (gh[1], "means2D"), (gh[2], "shs"), (gh[4], "opacities"), (gh[5], "scales"),
+                      (gh[6], "rotations")):
+        U.assert_close(got.cpu().numpy().reshape(go[name].shape), go[name], "C4 dL/d" + name, U.REL_TOL, 1e-4)
+
+
+def test_c4_full_size_properties():
+    """~500k Gaussians, 24 joints, 1024x1024, from-K camera: size-independent properties."""
+    N, J, H, W = 500_000, 24, 1024, 1024
+    sc, act, cam = U.activated_scene(N, J, 1238, H, W, K=zju_K(H, W))
+    R, vis = U.check_full_size_properties(act, cam)
+    assert R > 2_000_000 and vis > 0.9 * N
+
+
+def test_c4_reference_glue_fixture_through_the_hip_glue_path():
+    """tests/golden/glue_iso_K.npz — captured from the reference's own render() glue + Camera (isotropic Gaussians,
+    projection from K): the RAW parameters go through the fused HIP glue (cfg.glue, isotropic) and must give the
+    image / radii / gradients of the oracle rasterizer fed with the reference's captured kwargs."""
+    g = np.load(os.path.join(GOLD, "glue_iso_K.npz"))
+    T = lambda k: torch.from_numpy(np.ascontiguousarray(g[k])).float()  # noqa: E731
+    H, W, N = int(g["H"]), int(g["W"]), g["xyz"].shape[0]
+    assert bool(g["isotropic"])
+    bg = np.array([0.0, 0.3, 0.1], np.float32)
+    out_o, so = RR.forward(g["means3D"], g["opacities"], g["viewmatrix"], g["projmatrix"], g["campos"], float(g["tanfovx"]),
+                           float(g["tanfovy"]), H, W, bg, shs=g["shs"], scales=g["scales"], rotations=g["rotations"],
+                           sh_degree=int(g["sh_degree"]))
+    assert so.R > 0
+    st = U.GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=float(g["tanfovx"]), tanfovy=float(g["tanfovy"]),
+        bg=torch.from_numpy(bg).cuda(), scale_modifier=1.0, viewmatrix=T("viewmatrix").cuda(), projmatrix=T("projmatrix").cuda(),
+        sh_degree=int(g["sh_degree"]), campos=T("campos").cuda(), prefiltered=False, debug=True)
+    d = lambda k: T(k).cuda().contiguous()  # noqa: E731
+    raw = dict(xyz=d("xyz"), dc=d("features_dc"), rest=d("features_rest"), op=d("opacity"), sc=d("scaling"), rot=d("rotation"),
+               dx=d("d_xyz"), dr=d("d_rotation"), ds=d("d_scaling"))
+    color, radii, depth, alpha, s = rasterize_forward(st, raw["xyz"], raw["dc"], None, raw["op"], raw["sc"], raw["rot"], None,
+                                                      d_xyz=raw["dx"], d_rotation=raw["dr"], d_scaling=raw["ds"], glue=True,
+                                                      isotropic=True, shs_rest=raw["rest"])
+    assert np.array_equal(radii.cpu().numpy(), so.radii)
+    U.assert_close(color.cpu().numpy(), out_o["color"], "glue_iso_K color", U.REL_TOL, 1e-4)
+    U.assert_close(alpha.cpu().numpy()[0], out_o["alpha"], "glue_iso_K alpha", U.REL_TOL, 1e-4)
+    # gradients w.r.t. the RAW parameters: oracle rasterizer backward chained through the oracle glue with autograd
+    gen = torch.Generator().manual_seed(3)
+    gc = torch.randn(3, H, W, generator=gen) / (H * W)
+    go = RR.backward(so, gc.numpy(), None, None)
+    P = {k: T(k).clone().requires_grad_(True) for k in ("xyz", "features_dc", "features_rest", "scaling", "rotation", "opacity")}
+    m3, op, scl, rot, shs = O.render_glue(P["xyz"], P["features_dc"], P["features_rest"], P["scaling"], P["rotation"],
+                                          P["opacity"], T("d_xyz"), T("d_rotation"), T("d_scaling"), True)
+    np.testing.assert_allclose(m3.detach().numpy(), g["means3D"], rtol=1e-6, atol=1e-7)  # oracle glue == reference capture
+    F = torch.from_numpy
+    torch.autograd.backward([m3, op, scl, rot, shs], [F(go["means3D"]), F(go["opacities"]), F(go["scales"]), F(go["rotations"]),
+                                                      F(go["shs"])])
+    gh = rasterize_backward(s, raw["xyz"], raw["dc"], None, raw["op"], raw["sc"], raw["rot"], None, raw["dx"], raw["dr"], gc.cuda(),
+                            None, None, d_scaling=raw["ds"], shs_rest=raw["rest"])
+    g_xyz, _, (g_dc, g_rest), _, g_op, g_sc, g_rot, _, _ = gh
+    for got, name in ((g_xyz, "xyz"), (g_dc, "features_dc"), (g_rest, "features_rest"), (g_op, "opacity"), (g_sc, "scaling")):
+        U.assert_close(got.cpu().numpy().reshape(P[name].grad.shape), P[name].grad.numpy(), "glue_iso_K dL/d_" + name, 2e-4, 1e-3)
+    # isotropic: Sigma = s^2 I, the rotation gradient is rounding noise in both implementations
+    assert float(g_rot.abs().max()) < 1e-3 * float(g_xyz.abs().max())
+
+
+def test_c5_full_size_properties_and_memory():
+    """2M Gaussians, 64 joints, 1920x1080: rasterizer properties at full size, then one whole frame (PoseMLP -> FK -> LBS over
+    63 bones -> fused glue + rasterizer -> backward) with its peak memory and finite, non-trivial gradients."""
+    N, J, H, W = 2_000_000, 64, 1080, 1920
+    fovx = 0.6911112
+    fovy = 2.0 * math.atan(math.tan(fovx / 2) * H / W)  # 16:9
+    sc, act, cam = U.activated_scene(N, J, 1239, H, W, fovx=fovx, fovy=fovy)
+    torch.cuda.reset_peak_memory_stats()
+    R, vis = U.check_full_size_properties(act, cam)
+    assert R > 10_000_000 and vis > 0.9 * N
+    del act
+    torch.cuda.empty_cache()
+    gm = GaussianModel.from_tensors(sc["xyz"], sc["features_dc"], sc["features_rest"], sc["scaling"], sc["rotation"], sc["opacity"])
+    torch.manual_seed(0)
+    sw = SkeletonWarp(joints=sc["joints"], parent_indices=sc["parents"], K=-1, hyper_dim=8, use_skinning_weight_mlp=False,
+                      use_template_offsets=False).cuda()
+    sw._node_radius.data = sc["node_radius"].cuda()
+
+    class Pipe:
+        convert_SHs_python = compute_cov3D_python = debug = False
+    camg = cam.to("cuda")
+    dv = sw(gm.get_xyz.detach(), sw.expand_time(camg.fid), motion_mask=gm.motion_mask)
+    pkg = render(camg, gm, Pipe, torch.zeros(3, device="cuda"), dv["d_xyz"], dv["d_rotation"], dv["d_scaling"])
+    g = torch.Generator().manual_seed(1)
+    gimg = (torch.sign(torch.rand(3, H, W, generator=g) - 0.5) / (3 * H * W)).cuda()
+    pkg["render"].backward(gimg)
+    torch.cuda.synchronize()
+    for p in gm.parameters() + [sw._node_radius] + list(sw.pose_net.parameters()):
+        assert p.grad is not None and torch.isfinite(p.grad).all()
+    assert float(gm._xyz.grad.abs().max()) > 0 and float(sw._node_radius.grad.abs().max()) > 0
+    # 64 joints do not fit the one-launch PoseMLP (4 * 64 + 3 > 256 outputs): the layered kernels ran; LBS walked 63 bones
+    assert dv["d_nodes"].shape == (64, 3)
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    assert peak < 16.0, "C5 peak memory %.1f GiB" % peak

@@ -258,3 +258,23 @@ def test_fused_pose_mlp_matches_torch_and_reference_fixture(width, J):
         U.assert_close(out["rotation"].detach().cpu().numpy(), g["rotation"], "rotation vs reference", 1e-5)
     for (n, p), q in zip(net.named_parameters(), net_g.parameters()):
         U.assert_close(q.grad.cpu().numpy(), p.grad.numpy(), "grad " + n, 1e-4)
+
+
+def test_pose_mlp_status_word_is_clean_after_normal_steps_and_raises_when_set():
+    """The one-launch PoseMLP kernels hand data between workgroups by bounded spinning; a time-out poisons the pose with
+    NaN and sets a STICKY status word that PoseMLP.check_status() / GraphedFrame.check() turn into an exception."""
+    from riggs_amd import _lib as L
+    sc = synth.make_scene(64, 24, 5)
+    sw = SkeletonWarp(joints=sc["joints"], parent_indices=sc["parents"], K=-1, hyper_dim=8, use_skinning_weight_mlp=False,
+                      use_template_offsets=False).cuda()
+    x = sc["xyz"].cuda()
+    for _ in range(3):
+        out = sw(x, sw.expand_time(torch.tensor([0.4], device="cuda")), motion_mask=None)
+        (out["d_xyz"].sum() + out["d_rotation"].sum()).backward()
+    assert torch.isfinite(out["d_xyz"]).all()
+    sw.pose_net.check_status()  # clean
+    w = int(L.lib().riggs_pose_mlp_status_word(len(sw.pose_net.net), sw.pose_net.net[0].out_features))
+    sw.pose_net._hip_sync[w] = 1  # what a timed-out spin leaves behind
+    with pytest.raises(L.RiggsHipError, match="timed out"):
+        sw.pose_net.check_status()
+    sw.pose_net.check_status()  # cleared by the raise

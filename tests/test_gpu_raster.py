@@ -174,47 +174,65 @@ def test_arena_mode_matches_sync_mode_and_recovers_from_overflow():
 def test_full_size_properties(N, J, H, W):
     """BASELINE configs C2 / C3 at full size: size-independent properties instead of the oracle."""
     sc, act, cam = U.activated_scene(N, J, 1234 + 2, H, W)
+    U.check_full_size_properties(act, cam)
+
+
+def test_largest_tile_grid_and_rejection_beyond_it():
+    """The binning keeps a per-workgroup tile table in LDS: 25 600 tiles (2560 x 2560 px) is the largest grid.  At that
+    size a handful of Gaussians must still match the oracle bit for bit in ordering (tile ids far above 16 bits' worth
+    of chunks / the old packed work entries), and one tile row more is rejected with an error, not mis-rendered."""
+    from riggs_amd._lib import RiggsHipError
+    H = W = 2560
+    sc, act, cam = U.activated_scene(300, 8, 41, H, W, scale=0.05)
+    out_o, so = U.oracle_forward(act, cam, [0.0, 0.1, 0.2])
+    color, radii, depth, alpha, s = U.hip_forward(act, cam, [0.0, 0.1, 0.2])
+    U.compare_forward_state(so, saved_views(s), out_o, color, depth, alpha, radii)
+    assert int(saved_views(s)["tile_keys"].max()) > 16_000  # instances land on tiles all over the grid
+    gc = torch.ones(3, H, W) / (3 * H * W)
+    go = RR.backward(so, gc.numpy(), None, None)
     d = lambda t: t.cuda().contiguous()  # noqa: E731
-    bg0 = U.settings_for(cam, [0, 0, 0])
+    gh = rasterize_backward(s, d(act["means3D"]), d(act["shs"]), None, d(act["opacities"]), d(act["scales"]),
+                            d(act["rotations"]), None, None, None, d(gc), None, None)
+    _grads_close(gh[0], go["means3D"], "dL/dmeans3D (25600 tiles)")
+    _grads_close(gh[4], go["opacities"], "dL/dopacity (25600 tiles)")
+    sc2, act2, cam2 = U.activated_scene(300, 8, 41, H + 16, W, scale=0.05)
+    with pytest.raises(RiggsHipError, match="image too large"):
+        U.hip_forward(act2, cam2, [0, 0, 0])
+
+
+def test_loss_on_depth_or_alpha_only_backpropagates():
+    """set_materialize_grads(False): a loss that ignores the colour image hands grad_color = None to the backward."""
+    sc, act, cam = U.activated_scene(1500, 8, 11, 64, 64, scale=0.03)
+    r = GaussianRasterizer(raster_settings=U.settings_for(cam, [0, 0, 0]))
+    d = lambda t: t.cuda().contiguous().requires_grad_(True)  # noqa: E731
+    m3, op, sc_, ro, sh = d(act["means3D"]), d(act["opacities"]), d(act["scales"]), d(act["rotations"]), d(act["shs"])
+    color, radii, depth, alpha = r(means3D=m3, means2D=torch.zeros_like(m3, requires_grad=True), opacities=op, shs=sh,
+                                   scales=sc_, rotations=ro)
+    (0.3 * depth.sum() + alpha.sum()).backward()
+    out_o, so = U.oracle_forward(act, cam, [0, 0, 0])
+    go = RR.backward(so, np.zeros((3, 64, 64), np.float32), np.full((64, 64), 0.3, np.float32), np.ones((64, 64), np.float32))
+    _grads_close(m3.grad, go["means3D"], "depth/alpha-only dL/dmeans3D")
+    _grads_close(op.grad, go["opacities"], "depth/alpha-only dL/dopacity")
+    assert float(sh.grad.abs().max()) == 0.0
+
+
+def test_overflowed_frame_backpropagates_exact_zeros():
+    """Device-side guard: when the instance arena overflowed, the frame's gradients are exact zeros — an
+    optimizer step queued behind the backward (captured graph) never consumes gradients of a truncated image."""
+    sc, act, cam = U.activated_scene(4000, 8, 2, 128, 128, scale=0.03)
+    d = lambda t: t.cuda().contiguous()  # noqa: E731
+    st = U.settings_for(cam, [0, 0, 0])
     args = (d(act["means3D"]), d(act["shs"]), None, d(act["opacities"]), d(act["scales"]), d(act["rotations"]), None)
-    color, radii, depth, alpha, s = rasterize_forward(bg0, *args)
-    v = saved_views(s)
-    R = v["R"]
-    tiles = v["tiles_touched"].long()
-    assert int(tiles.sum()) == R and R > N  # checksum of checksums: scan total == emitted instances
-    # tile-major, then depth-ascending, ties by ascending Gaussian index (stable)
-    pl, tk = v["point_list"].long(), v["tile_keys"].long()
-    dbits = v["xyd"][:, 2].contiguous().view(torch.int32).long()[pl]
-    key = tk * (1 << 32) + dbits
-    assert bool((key[1:] >= key[:-1]).all()), "instances not sorted by (tile, depth bits)"
-    same = key[1:] == key[:-1]
-    assert bool((pl[1:][same] > pl[:-1][same]).all()), "equal keys must keep ascending Gaussian index"
-    rg = v["ranges"].long()
-    assert int(rg[0, 0]) == 0 or int(rg[:, 1].max()) == R
-    counts = torch.bincount(tk, minlength=rg.shape[0])
-    assert torch.equal(counts, rg[:, 1] - rg[:, 0])
-    # compositing identity: sum_i alpha_i T_i == 1 - T_final
-    fT = v["final_T"]
-    assert float((alpha[0] + fT - 1).abs().max()) < 2e-5
-    assert float(fT.min()) >= 0.9e-4 * 0 and float(fT.max()) <= 1.0
-    # linearity in the background: color(bg) == color(0) + T_final * bg
-    bg1 = U.settings_for(cam, [0.25, 0.5, 1.0])
-    color1 = rasterize_forward(bg1, *args)[0]
-    ref = color + fT[None] * torch.tensor([0.25, 0.5, 1.0], device="cuda")[:, None, None]
-    assert float((color1 - ref).abs().max()) < 1e-5
-    # determinism of the forward (bitwise)
-    assert torch.equal(color, rasterize_forward(bg0, *args)[0])
-    # backward is linear in the incoming gradient
-    g = torch.Generator().manual_seed(0)
-    gc = (torch.sign(torch.rand(3, H, W, generator=g) - 0.5) / (3 * H * W)).cuda()
-    g1 = rasterize_backward(s, *args, None, None, gc, None, None)
-    g2 = rasterize_backward(s, *args, None, None, 2 * gc, None, None)
-    for a, b, nm in zip(g1, g2, "means3D means2D sh colors opac scales rots cov".split()):
-        if a is None:
-            continue
-        scale = float(a.abs().max())
-        assert float((2 * a - b).abs().max()) <= 2e-4 * max(scale, 1e-20), nm
-        assert torch.isfinite(a).all()
-    # invisible Gaussians receive exactly zero gradient
-    inv = radii == 0
-    assert float(g1[0][inv].abs().max() if inv.any() else 0.0) == 0.0
+    arena = RasterArena(min_capacity=16)
+    rasterize_forward(st, *args, arena=arena)
+    arena.capacity, arena.binning, arena.last_R, arena.min_capacity = 0, None, 10, 16  # next frame: far too small an arena
+    out = rasterize_forward(st, *args, arena=arena)
+    gc = torch.ones(3, 128, 128, device="cuda")
+    g = rasterize_backward(out[4], *args, None, None, gc, None, None)
+    assert int(out[4].counters[1]) == 1
+    for t in g:
+        if t is not None:
+            assert float(t.abs().max()) == 0.0
+    from riggs_amd._lib import RiggsHipError
+    with pytest.raises(RiggsHipError, match="overflowed"):
+        arena.resolve()
