@@ -123,3 +123,22 @@ def make_scene(N: int, J: int, seed: int, chain: bool = False, scale: float = 0.
         "local_rotation": local_rot, "global_trans": global_trans,
         "motion_mask": torch.ones(N, 1),
     }
+
+
+def make_surface_scene(N: int, J: int, seed: int, shell: float = 0.09, scale: float = 0.006):
+    """A dense-gradient variant of ``make_scene``: the Gaussians form a thin, mostly opaque SKIN around the bones (distance
+    ``shell`` from the bone axis, opacity logit ~ N(2.5, 0.5)) instead of a deep semi-transparent cloud — a surface-like
+    capture, where pixels saturate after a few layers and most FRONT-facing Gaussians receive a gradient.  Same
+    skeleton, pose and parameter distributions otherwise."""
+    sc = make_scene(N, J, seed, scale=scale)
+    g = torch.Generator().manual_seed(seed + 77)
+    joints, parents = sc["joints"], sc["parents"]
+    bone = torch.randint(1, J, (N,), generator=g)
+    t = torch.rand(N, 1, generator=g)
+    a, b = joints[parents[bone]], joints[bone]
+    axis = torch.nn.functional.normalize(b - a, dim=1)
+    r = torch.randn(N, 3, generator=g)
+    r = torch.nn.functional.normalize(r - (r * axis).sum(1, keepdim=True) * axis, dim=1)  # unit normal to the bone
+    sc["xyz"] = (a + t * (b - a) + shell * (1.0 + 0.03 * torch.randn(N, 1, generator=g)) * r).contiguous()
+    sc["opacity"] = 2.5 + 0.5 * torch.randn(N, 1, generator=g)
+    return sc
