@@ -132,7 +132,9 @@ int riggs_raster_backward(const riggs_raster_cfg* cfg, const float* means3D, con
                           const float* d_rotation, const float* d_scaling, const int32_t* radii, const void* geom, const void* binning,
                           int64_t instance_capacity, const void* image_state, const uint32_t* counters,
                           const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                          void* workspace /* riggs_raster_backward_workspace_bytes(N) */, float* dL_dmeans3D,
+                          void* workspace /* riggs_raster_backward_workspace_bytes(N); must be ALL ZERO on entry and is
+                          all zero again on return (self-cleaning accumulators): zero it once after allocating and keep it */,
+                          float* dL_dmeans3D,
                           float* dL_dmeans2D /*(N,3)*/, float* dL_dsh, float* dL_dcolors_precomp,
                           float* dL_dopacities, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
                           float* dL_dd_scaling /* glue only, may be NULL */,

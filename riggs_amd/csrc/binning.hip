@@ -137,6 +137,7 @@ __global__ __launch_bounds__(1024) void bin_offsets_kernel(int T, int64_t cap, c
       // empty tiles get (0, 0) like upstream's identifyTileRanges (whose ranges buffer is zeroed before)
       ranges[t] = (hi > lo) ? make_uint2(lo, hi) : make_uint2(0u, 0u);
       tile_max[t] = 0u;  // atomicMax target of the forward
+      tile_max[T + 1 + t] = 0u;  // ... and the arrival ticket of the tile's forward blocks
       slot_base[t] = (lo >> 6) + (uint32_t)t;
       // forward work queue, step 1: histogram of floor(log2(list length)); the empty tiles go to their own list
       if (hi > lo) atomicAdd(&s_hist[31 - __builtin_clz(hi - lo)], 1u);
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(1024) void bin_offsets_kernel(int T, int64_t cap, c
       if (tid >= o) v += u;
     }
     s_cur[31 - tid] = v - h;
-    if (tid == 31) { fwd_ctr[0] = v; fwd_ctr[1] = 0u; fwd_ctr[2] = s_nempty; }
+    if (tid == 31) { fwd_ctr[0] = v; fwd_ctr[1] = 0u; fwd_ctr[2] = s_nempty; fwd_ctr[4] = 0u; }  // ([4]: backward work-list size)
   }
   __syncthreads();
 #pragma unroll

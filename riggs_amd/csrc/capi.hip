@@ -70,15 +70,14 @@ ImageLayout image_layout(int H, int W) {
   L.final_T = o; o = align_up(o + hw * 4);
   L.n_contrib = o; o = align_up(o + hw * 4);
   L.final_acc = o; o = align_up(o + hw * 16);
-  L.ranges = o; o = align_up(o + (T + 1) * 8);   // ranges and tile_max are adjacent: one memset clears both
-  L.tile_max = o; o = align_up(o + (T + 1) * 4);
+  L.ranges = o; o = align_up(o + (T + 1) * 8);   // ranges, tile_max (+ tile tickets) and slot_base are adjacent: one memset clears them
+  L.tile_max = o; o = align_up(o + 2 * (T + 1) * 4);  // [tile_max (T + 1) | arrival tickets of the tile's forward blocks (T + 1)]
   L.slot_base = o; o = align_up(o + (T + 2) * 4);
-  L.work_ctr = o; o = align_up(o + 16);  // backward work queue: {n_items, next}
   // forward work list (written by bin_offsets_kernel): the non-empty tiles, longest lists first; the empty tiles;
   // {n_nonempty, -, n_empty}
   L.fwd_items = o; o = align_up(o + (T + 1) * 4);
   L.fwd_empty = o; o = align_up(o + (T + 1) * 4);
-  L.fwd_ctr = o; o = align_up(o + 16);
+  L.fwd_ctr = o; o = align_up(o + 32);  // + [4] = size of the backward's work list (in quarter-chunks), appended to by the forward
   L.total = o;
   return L;
 }
@@ -230,8 +229,10 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
   ImageLayout I = image_layout(H, W);
   BinLayout B = bin_layout(cap, N, H, W);
   const bool binned = N > 0 && cap > 0;
-  if (!binned)  // (bin_offsets_kernel writes every entry of ranges / tile_max / slot_base itself)
+  if (!binned) {  // (bin_offsets_kernel writes every entry of ranges / tile_max / slot_base / the counters itself)
     RIGGS_HIP_CHECK(hipMemsetAsync(img + I.ranges, 0, (I.slot_base - I.ranges) + (size_t)(T + 2) * 4, s));
+    RIGGS_HIP_CHECK(hipMemsetAsync(img + I.fwd_ctr, 0, 32, s));
+  }
   const uint32_t* point_list = (const uint32_t*)(bin + B.point_list);
   if (binned) {
     // stable counting sort by tile (csrc/binning.hip)
@@ -256,6 +257,8 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
   r.final_T = (float*)(img + I.final_T); r.n_contrib = (uint32_t*)(img + I.n_contrib);
   r.out_color = out_color; r.out_depth = out_depth; r.out_alpha = out_alpha;
   r.final_acc = (float4*)(img + I.final_acc); r.tile_max = (uint32_t*)(img + I.tile_max);
+  r.tile_ticket = r.tile_max + (T + 1);
+  r.work = (uint4*)(bin + B.work); r.work_ctr = (uint32_t*)(img + I.fwd_ctr) + 4;
   r.slot_base = (const uint32_t*)(img + I.slot_base); r.ckpt = (float*)(bin + B.ckpt);
   // longest-list-first work list of the forward (bin_offsets_kernel builds it; NULL: every tile is empty)
   r.items = nullptr; r.empties = nullptr; r.item_ctr = nullptr;
@@ -310,11 +313,11 @@ int riggs_raster_backward(const riggs_raster_cfg* cfg, const float* means3D, con
   r.slot_base = (const uint32_t*)(img + I.slot_base); r.ckpt = (const float*)(bin + B.ckpt);
   r.n_tiles = ((W + RIGGS_TILE - 1) / RIGGS_TILE) * ((H + RIGGS_TILE - 1) / RIGGS_TILE);
   r.n_slots = (int64_t)B.n_slots;
-  r.work = (uint4*)(bin + B.work); r.work_ctr = (uint32_t*)(img + I.work_ctr);
+  r.work = (const uint4*)(bin + B.work); r.work_ctr = (const uint32_t*)(img + I.fwd_ctr) + 4;
+  // (cap == 0: nothing was composited and the accumulators — zero on entry by contract — stay zero)
   if (cap > 0) { ProfScope ps(PROF_RENDER_BWD, s); launch_render_bwd(r, s); }
-  else RIGGS_HIP_CHECK(hipMemsetAsync(workspace, 0, (size_t)N * RIGGS_GACC * 4, s));
   if (debug_sync(cfg->debug, s, "render_bwd")) return 1;
-  b.g_mean2D_conic = (const float*)workspace;
+  b.gacc = (float*)workspace;
   b.dL_dmeans3D = dL_dmeans3D; b.dL_dmeans2D = dL_dmeans2D; b.dL_dsh = dL_dsh; b.dL_dcolors = dL_dcolors_precomp;
   b.dL_dopac = dL_dopacities; b.dL_dscales = dL_dscales; b.dL_drots = dL_drotations; b.dL_dcov3D = dL_dcov3D;
   b.dL_dd_scaling = dL_dd_scaling; b.dL_dsh_rest = dL_dsh_rest;

@@ -67,7 +67,7 @@ struct GeomLayout {
 GeomLayout geom_layout(int N);
 
 struct ImageLayout {
-  size_t final_T, n_contrib, ranges, final_acc, tile_max, slot_base, work_ctr, fwd_items, fwd_empty, fwd_ctr, total;
+  size_t final_T, n_contrib, ranges, final_acc, tile_max, slot_base, fwd_items, fwd_empty, fwd_ctr, total;
 };
 ImageLayout image_layout(int H, int W);
 

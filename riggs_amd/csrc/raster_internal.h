@@ -22,7 +22,8 @@ struct PreArgs {
 struct PreBwdArgs {
   PreArgs f;                     // forward inputs (radii/xyd/... unused here except radii, cov3D, clamped)
   const uint32_t* counters;      // the forward's {R, overflow flag}: an overflowed frame back-propagates exact zeros
-  const float* g_mean2D_conic;   // workspace: per Gaussian [mean2D.x, mean2D.y, gA, gB, gC, g_opacity, g_r, g_g, g_b, g_depth]
+  float* gacc;                   // workspace: per Gaussian [mean2D.x, mean2D.y, gA, gB, gC, g_opacity, g_r, g_g, g_b, g_depth, -, -];
+                                 // zero on entry of the compositing backward, zero again when preprocess_bwd returns
   float *dL_dmeans3D, *dL_dmeans2D, *dL_dsh, *dL_dcolors, *dL_dopac, *dL_dscales, *dL_drots, *dL_dcov3D, *dL_dd_scaling, *dL_dsh_rest;
 };
 #define RIGGS_GACC 12  // floats per Gaussian in the render-backward accumulator (padded to 48 B)
@@ -44,6 +45,9 @@ struct RenderArgs {
   // state for the chunk-parallel backward
   float4* final_acc;          // per pixel (C0, C1, C2, D) accumulated WITHOUT background
   uint32_t* tile_max;         // per tile: max n_contrib
+  uint32_t* tile_ticket;      // per tile: forward blocks that have finished it (the last one appends the tile's backward work)
+  uint4* work;                // backward work list: (tile, chunk, start of the tile's list, instances to walk) per active chunk
+  uint32_t* work_ctr;         // its size in quarter-chunks (zeroed by bin_offsets_kernel)
   const uint32_t* slot_base;  // per tile: first checkpoint slot ((range.x >> 6) + tile)
   float* ckpt;                // [slot][5][256]: (T, C0, C1, C2, D) per pixel at every 64th instance
   // work list (NULL: nothing was binned, every tile is empty): items = the non-empty tiles, longest lists
@@ -64,7 +68,7 @@ struct RenderBwdArgs {
   const float* final_T;
   const uint32_t* n_contrib;
   const float *dL_dcolor, *dL_ddepth, *dL_dalpha;
-  float* gacc;  // (N, RIGGS_GACC) accumulators, zeroed by launch_render_bwd
+  float* gacc;  // (N, RIGGS_GACC) accumulators: all zero on entry (see PreBwdArgs::gacc)
   int n_points;
   const float4* final_acc;
   const uint32_t* tile_max;
@@ -72,8 +76,8 @@ struct RenderBwdArgs {
   const float* ckpt;
   int n_tiles;
   int64_t n_slots;
-  uint4* work;  // per active chunk: (tile, chunk, start of the tile's list, instances to walk)
-  uint32_t* work_ctr;  // {number of quarter-items, next item}
+  const uint4* work;  // per active chunk: (tile, chunk, start of the tile's list, instances to walk); built by the forward
+  const uint32_t* work_ctr;  // number of quarter-items
 };
 int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s);
 

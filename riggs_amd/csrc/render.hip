@@ -50,7 +50,7 @@ __device__ __forceinline__ float oct_sum(float v) {
   return v;
 }
 template <bool TRACE>
-__global__ __launch_bounds__(256) void render_fwd_oct_kernel(RenderArgs a) {
+__global__ __launch_bounds__(256, 6) void render_fwd_oct_kernel(RenderArgs a) {
   constexpr int B = 256;      // instances per round
   constexpr int K = B / 256;  // instances per thread and round
   __shared__ float4 s_xyd[B];
@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void render_fwd_oct_kernel(RenderArgs a) {
   __shared__ float4 s_rgb[B];
   __shared__ unsigned short s_pos[B];  // position of the survivor inside its batch
   __shared__ int s_cnt[B / 64];        // survivors per chunk
+  __shared__ uint32_t s_wmax[4];
   const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int pl = lane >> 3, i = lane & 7;
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(256) void render_fwd_oct_kernel(RenderArgs a) {
   const float Tfin = (ts >= 0.f) ? ts : T;
   uint32_t m = inside ? lm : 0u;
   for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
-  if (lane == 0 && m > 0) atomicMax(&a.tile_max[tile], m);  // tile_max is zeroed before the launch
+  if (lane == 0) s_wmax[wave] = m;
   if (inside && i == 0) {
     const size_t pid = (size_t)pyi * a.W + pxi, HW = (size_t)a.H * a.W;
     a.final_T[pid] = Tfin;
@@ -251,7 +252,34 @@ __global__ __launch_bounds__(256) void render_fwd_oct_kernel(RenderArgs a) {
     a.out_depth[pid] = kd;
     a.out_alpha[pid] = ka;
   }
-  __syncthreads();  // the staging buffers are reused by the next item
+  __syncthreads();  // the staging buffers are reused by the next item (and s_wmax is complete)
+  // ---- work list of the backward.  A tile's instances past its last contributor (tile_max = max n_contrib over its 256
+  // pixels) need no backward, so the list holds one entry per 64-instance chunk below it.  Every block of the tile folds
+  // its maximum into tile_max and takes a ticket; the block that draws the last ticket knows the final value and appends
+  // the tile's entries (tile, chunk, start of the tile's list, instances to walk) — a separate list-building launch used to
+  // cost 10 us.  Both words are only ever touched with agent-scope atomics, and a block takes its ticket after its
+  // maximum has RETURNED (the returning atomic has been performed), so the last ticket holder reads the final maximum.
+  // Only wave 0 stays for this (two dependent atomic round trips to the memory side, ~4 us): the other three waves
+  // leave — or move on to the next item, where the round barrier waits for wave 0 — so their SIMD slots are free.
+  if (wave == 0) {
+    uint32_t n_c = 0u, base = 0u, limit = 0u;
+    if (lane == 0) {
+      const uint32_t mb = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+      const uint32_t before = __hip_atomic_fetch_max(&a.tile_max[tile], mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const uint32_t ticket = __hip_atomic_fetch_add(&a.tile_ticket[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (ticket == 7u) {  // eight 8 x 4 blocks per tile
+        limit = max(max(before, mb), __hip_atomic_load(&a.tile_max[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        limit = min((uint32_t)total, limit);
+        n_c = (limit + 63u) >> 6;
+        if (n_c) base = __hip_atomic_fetch_add(a.work_ctr, 4u * n_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 2;  // (quarter-chunks)
+      }
+    }
+    n_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_c);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    limit = (uint32_t)__builtin_amdgcn_readfirstlane((int)limit);
+    for (uint32_t k = lane; k < n_c; k += 64) a.work[base + k] = make_uint4((uint32_t)tile, k, range.x, limit);
+  }
   }
 }
 
@@ -259,7 +287,7 @@ int launch_render_fwd(const RenderArgs& a, hipStream_t s) {
   const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE, gy = (a.H + RIGGS_TILE - 1) / RIGGS_TILE;
   if (gx * gy == 0) return 0;
   // one workgroup per 8 x 4 block of every tile; the ones past the non-empty tiles of the work list only help with the
-  // background of the empty tiles and leave (tile_max was cleared by bin_offsets_kernel)
+  // background of the empty tiles and leave (tile_max, the tile tickets and the work-list size were cleared by bin_offsets_kernel)
   if (a.trace) hipLaunchKernelGGL(render_fwd_oct_kernel<true>, dim3(gx * gy * 8), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(render_fwd_oct_kernel<false>, dim3(gx * gy * 8), dim3(256), 0, s, a);
   return 0;
@@ -304,60 +332,22 @@ __device__ __forceinline__ void dual_excl_sum_scan(float& a, float& b) {
 // contention (one atomic per value per (tile, instance) at the end).  Chunks are independent,
 // so a tile with thousands of contributing instances spreads over the whole chip instead of
 // serialising on four waves.
-// Work list of the backward: one 16-byte entry (tile, chunk, start of the tile's list, instances to walk) per chunk that holds a contributing instance
-// (chunk * 64 < min(list length, tile_max)).  Workgroup 0 builds it (tiles are scanned 1024 at a time);
-// the other workgroups clear the per-Gaussian gradient accumulators meanwhile (this replaces a memset node).
-__global__ __launch_bounds__(1024) void render_bwd_worklist_kernel(RenderBwdArgs a) {
-  __shared__ uint32_t s_wave[16];
-  __shared__ uint32_t s_carry;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (blockIdx.x > 0) {
-    float4* z = reinterpret_cast<float4*>(a.gacc);  // N * RIGGS_GACC floats, RIGGS_GACC % 4 == 0, 256-byte aligned
-    const size_t n4 = (size_t)a.n_points * (RIGGS_GACC / 4);
-    for (size_t i = (size_t)(blockIdx.x - 1) * 1024 + tid; i < n4; i += (size_t)(gridDim.x - 1) * 1024)
-      z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    return;
-  }
-  if (tid == 0) s_carry = 0u;
-  __syncthreads();
-  for (int base = 0; base < a.n_tiles; base += 1024) {
-    const int t = base + tid;
-    uint32_t c = 0, limit = 0, rx = 0;
-    if (t < a.n_tiles) {
-      const uint2 rg = a.ranges[t];
-      limit = min(rg.y - rg.x, a.tile_max[t]);
-      c = (limit + 63u) >> 6;
-      rx = rg.x;
-    }
-    uint32_t v = c;
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t u = (uint32_t)__shfl_up((int)v, o);
-      if (lane >= o) v += u;
-    }
-    if (lane == 63) s_wave[wave] = v;
-    __syncthreads();
-    uint32_t off = s_carry;
-    for (int w = 0; w < wave; w++) off += s_wave[w];
-    // self-contained entries: (tile, chunk, start of the tile's list, instances to walk); the checkpoint slot of a
-    // chunk is (list start >> 6) + tile + chunk (= slot_base[tile] + chunk, see bin_offsets_kernel)
-    uint4* out = a.work + (off + v - c);
-    for (uint32_t k = 0; k < c; k++) out[k] = make_uint4((uint32_t)t, k, rx, limit);
-    __syncthreads();
-    if (tid == 1023) s_carry = off + v;
-    __syncthreads();
-  }
-  if (tid == 0) { a.work_ctr[0] = s_carry * 4u; a.work_ctr[1] = 0u; }  // four pixel-quarters per chunk
-}
-
 // Persistent workgroups over the device-built list of (tile, 64-instance chunk) items, dealt round-robin: deep tiles
 // (dozens of fully active chunks) spread over the chip.
-template <int NW>  // waves per workgroup = parts the tile's 256 pixels are split into
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2v splat2(float v) { return f2v{v, v}; }
+
+template <int NW>  // NW waves per workgroup = parts the tile's 256 pixels are split into
 __global__ __launch_bounds__(64 * NW) void render_bwd_kernel(RenderBwdArgs a) {
   constexpr int PPW = 256 / NW;    // pixels per wave
   constexpr int RSTEP = NW;        // a wave's rows are part, part + NW, ...
-  __shared__ float4 s_pa[NW][PPW];  // (T_start, Pre_start, Qb, n_contrib as float bits)
-  __shared__ float4 s_pb[NW][PPW];  // (gC0, gC1, gC2, gD)
-  __shared__ float s_pc[NW][PPW];   // gA
+  // per-pixel state of the chunk, interleaved per PAIR of neighbouring pixels (A, B): one LDS read delivers the two
+  // operands of a packed fp32 instruction in adjacent registers
+  __shared__ float4 s_q0[NW][PPW / 2];  // (T_A, T_B, Pre_A, Pre_B)
+  __shared__ float4 s_q1[NW][PPW / 2];  // (Qb_A, Qb_B, n_A, n_B as float bits)
+  __shared__ float4 s_q2[NW][PPW / 2];  // (gC0_A, gC0_B, gC1_A, gC1_B)
+  __shared__ float4 s_q3[NW][PPW / 2];  // (gC2_A, gC2_B, gD_A, gD_B)
+  __shared__ float2 s_q4[NW][PPW / 2];  // (gA_A, gA_B)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t n_items = a.work_ctr[0];
   const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE;
@@ -427,7 +417,16 @@ __global__ __launch_bounds__(64 * NW) void render_bwd_kernel(RenderBwdArgs a) {
       pb = make_float4(r.g0, r.g1, r.g2, r.gD);
       pc = r.gA;
     }
-    if (lane < PPW) { s_pa[wave][lane] = pa; s_pb[wave][lane] = pb; s_pc[wave][lane] = pc; }
+    {
+      if (lane < PPW) {
+        const int pp = lane >> 1, h = lane & 1;
+        float* q0 = reinterpret_cast<float*>(&s_q0[wave][pp]) + h; q0[0] = pa.x; q0[2] = pa.y;
+        float* q1 = reinterpret_cast<float*>(&s_q1[wave][pp]) + h; q1[0] = pa.z; q1[2] = pa.w;
+        float* q2 = reinterpret_cast<float*>(&s_q2[wave][pp]) + h; q2[0] = pb.x; q2[2] = pb.y;
+        float* q3 = reinterpret_cast<float*>(&s_q3[wave][pp]) + h; q3[0] = pb.z; q3[2] = pb.w;
+        reinterpret_cast<float*>(&s_q4[wave][pp])[h] = pc;
+      }
+    }
   };
   const u4v wk_zero = {0u, 0u, 0u, 0u};
   u4v wk_a = wk_zero, wk_b = wk_zero, wk_c = wk_zero;  // this chunk, the next, the one after
@@ -459,54 +458,61 @@ __global__ __launch_bounds__(64 * NW) void render_bwd_kernel(RenderBwdArgs a) {
     // (the wave only touches its own LDS region: LDS operations of one wave are ordered, no barrier needed)
     // two pixels per iteration: their scans are independent chains that the scheduler interleaves (a lone
     // chain leaves the SIMD idle through every DPP / transcendental latency)
-    for (int pl = 0; pl < PPW; pl += 2) {
-      const float4 paA = s_pa[wave][pl], paB = s_pa[wave][pl + 1];
-      const int nA = (int)__float_as_uint(paA.w), nB = (int)__float_as_uint(paB.w);
-      if (nA <= pos0 && nB <= pos0) continue;  // wave-uniform: this chunk lies behind both pixels' last contributors
-      const int pix = ((pl >> 4) * RSTEP + quarter) * 16 + (pl & 15);  // pl is even: both pixels are in the same row
-      const float pfx = (float)(tx0 + (pix & 15)), pfy = (float)(ty0 + (pix >> 4));
-      const float dxA = xy.x - pfx, dxB = dxA - 1.0f, dy = xy.y - pfy;
-      // cheap conservative reject (alpha >= 1/255 extents, as in the forward's cull) before the exponentials
-      if (__builtin_amdgcn_ballot_w64(active && fabsf(dy) <= cc.w && fminf(fabsf(dxA), fabsf(dxB)) <= xy.w) == 0) continue;
-      const float cyy = co.z * dy * dy;
-      const float powA = -0.5f * (co.x * dxA * dxA + cyy) - co.y * dxA * dy;
-      const float powB = -0.5f * (co.x * dxB * dxB + cyy) - co.y * dxB * dy;
-      const float GA_ = fast_exp(powA), GB_ = fast_exp(powB);
-      float alA = fminf(ALPHA_MAX, co.w * GA_), alB = fminf(ALPHA_MAX, co.w * GB_);
-      const bool vA = active && (pos < nA) && (powA <= 0.0f) && (alA >= ALPHA_MIN);
-      const bool vB = active && (pos < nB) && (powB <= 0.0f) && (alB >= ALPHA_MIN);
-      if (__builtin_amdgcn_ballot_w64(vA || vB) == 0) continue;
-      touched = touched || vA || vB;
-      alA = vA ? alA : 0.f; alB = vB ? alB : 0.f;
-      const float GA = vA ? GA_ : 0.f, GB = vB ? GB_ : 0.f;
-      const float omA = 1.0f - alA, omB = 1.0f - alB;
-      float scA = omA, scB = omB;
-      dual_excl_prod_scan(scA, scB);
-      const float TlA = paA.x * scA, TlB = paB.x * scB;
-      const float4 pbA = s_pb[wave][pl], pbB = s_pb[wave][pl + 1];
-      const float gAA = s_pc[wave][pl], gAB = s_pc[wave][pl + 1];
-      const float wA = alA * TlA, wB = alB * TlB;
-      const float kA = pbA.x * cc.x + pbA.y * cc.y + pbA.z * cc.z + pbA.w * xy.z + gAA;
-      const float kB = pbB.x * cc.x + pbB.y * cc.y + pbB.z * cc.z + pbB.w * xy.z + gAB;
-      const float wkA = wA * kA, wkB = wB * kB;
-      float ssA = wkA, ssB = wkB;
-      dual_excl_sum_scan(ssA, ssB);
-      const float preA = paA.y + ssA, preB = paB.y + ssB;
-      // dL/dalpha = T k - (suffix + T_final * bg.g) / (1 - alpha),  suffix = total - prefix - own
-      // (no select on dLa: an invalid pair has G = 0 and every use below is multiplied by G)
-      const float dLaA = TlA * kA - (paA.z - preA - wkA) * __builtin_amdgcn_rcpf(omA);
-      const float dLaB = TlB * kB - (paB.z - preB - wkB) * __builtin_amdgcn_rcpf(omB);
-      // raw moments of q = dL/dalpha * G; opacity and the conic factors of dL/dmean2D are applied once per chunk
-      // (co is the lane's)
-      const float qA = dLaA * GA, qB = dLaB * GB;
-      const float qxA = qA * dxA, qxB = qB * dxB, qyA = qA * dy, qyB = qB * dy;
-      m_x += qxA + qxB; m_y += qyA + qyB;
-      a_ca += qxA * dxA + qxB * dxB;
-      a_cb += qxA * dy + qxB * dy;
-      a_cc += qyA * dy + qyB * dy;
-      a_op += qA + qB;
-      a_r += wA * pbA.x + wB * pbB.x; a_g += wA * pbA.y + wB * pbB.y; a_b += wA * pbA.z + wB * pbB.z;
-      a_d += wA * pbA.w + wB * pbB.w;
+    {
+      // packed fp32 (v_pk_mul / v_pk_fma / v_pk_add_f32: two fp32 operations per lane and instruction) across the
+      // pixel pair: the per-instance operands are splat, the per-pixel ones arrive as (A, B) pairs from LDS, and the
+      // ten accumulators are pairs that are folded once per chunk
+      f2v m_x2 = splat2(0.f), m_y2 = m_x2, ca2 = m_x2, cb2 = m_x2, cc2 = m_x2, op2 = m_x2, r2 = m_x2, g2 = m_x2, b2 = m_x2, d2 = m_x2;
+      for (int pl = 0; pl < PPW; pl += 2) {
+        const float4 q1 = s_q1[wave][pl >> 1];
+        const int nA = (int)__float_as_uint(q1.z), nB = (int)__float_as_uint(q1.w);
+        if (nA <= pos0 && nB <= pos0) continue;  // wave-uniform: this chunk lies behind both pixels' last contributors
+        const int pix = ((pl >> 4) * RSTEP + quarter) * 16 + (pl & 15);  // pl is even: both pixels are in the same row
+        const float pfx = (float)(tx0 + (pix & 15)), pfy = (float)(ty0 + (pix >> 4));
+        const float dxA = xy.x - pfx, dy = xy.y - pfy;
+        const f2v dx = {dxA, dxA - 1.0f};
+        // cheap conservative reject (alpha >= 1/255 extents, as in the forward's cull) before the exponentials
+        if (__builtin_amdgcn_ballot_w64(active && fabsf(dy) <= cc.w && fminf(fabsf(dx.x), fabsf(dx.y)) <= xy.w) == 0) continue;
+        const float cyy = co.z * dy * dy, cody = co.y * dy;
+        const f2v pw = -0.5f * (splat2(co.x) * dx * dx + splat2(cyy)) - splat2(cody) * dx;
+        const f2v pl2 = pw * splat2(LOG2E);
+        const f2v Gr = {__builtin_amdgcn_exp2f(pl2.x), __builtin_amdgcn_exp2f(pl2.y)};
+        const f2v ar = splat2(co.w) * Gr;
+        const float alA_ = fminf(ALPHA_MAX, ar.x), alB_ = fminf(ALPHA_MAX, ar.y);
+        const bool vA = active && (pos < nA) && (pw.x <= 0.0f) && (alA_ >= ALPHA_MIN);
+        const bool vB = active && (pos < nB) && (pw.y <= 0.0f) && (alB_ >= ALPHA_MIN);
+        if (__builtin_amdgcn_ballot_w64(vA || vB) == 0) continue;
+        touched = touched || vA || vB;
+        const f2v al = {vA ? alA_ : 0.f, vB ? alB_ : 0.f};
+        const f2v G = {vA ? Gr.x : 0.f, vB ? Gr.y : 0.f};
+        const f2v om = splat2(1.0f) - al;
+        float scA = om.x, scB = om.y;
+        dual_excl_prod_scan(scA, scB);
+        const float4 q0 = s_q0[wave][pl >> 1], q2 = s_q2[wave][pl >> 1], q3 = s_q3[wave][pl >> 1];
+        const float2 q4 = s_q4[wave][pl >> 1];
+        const f2v Tl = f2v{q0.x, q0.y} * f2v{scA, scB};
+        const f2v w = al * Tl;
+        const f2v gc0 = {q2.x, q2.y}, gc1 = {q2.z, q2.w}, gc2 = {q3.x, q3.y}, gd = {q3.z, q3.w};
+        const f2v k = gc0 * splat2(cc.x) + gc1 * splat2(cc.y) + gc2 * splat2(cc.z) + gd * splat2(xy.z) + f2v{q4.x, q4.y};
+        const f2v wk2 = w * k;
+        float ssA = wk2.x, ssB = wk2.y;
+        dual_excl_sum_scan(ssA, ssB);
+        const f2v pre = f2v{q0.z, q0.w} + f2v{ssA, ssB};
+        // dL/dalpha = T k - (suffix + T_final * bg.g) / (1 - alpha),  suffix = total - prefix - own
+        // (no select on dLa: an invalid pair has G = 0 and every use below is multiplied by G)
+        const f2v rom = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+        const f2v dLa = Tl * k - (f2v{q1.x, q1.y} - pre - wk2) * rom;
+        // raw moments of q = dL/dalpha * G; opacity and the conic factors of dL/dmean2D are applied once per chunk
+        const f2v q = dLa * G;
+        const f2v qx = q * dx, qy = q * splat2(dy);
+        m_x2 += qx; m_y2 += qy;
+        ca2 += qx * dx; cb2 += qx * splat2(dy); cc2 += qy * splat2(dy);
+        op2 += q;
+        r2 += w * gc0; g2 += w * gc1; b2 += w * gc2; d2 += w * gd;
+      }
+      m_x = m_x2.x + m_x2.y; m_y = m_y2.x + m_y2.y;
+      a_ca = ca2.x + ca2.y; a_cb = cb2.x + cb2.y; a_cc = cc2.x + cc2.y; a_op = op2.x + op2.y;
+      a_r = r2.x + r2.y; a_g = g2.x + g2.y; a_b = b2.x + b2.y; a_d = d2.x + d2.y;
     }
     a_mx = -co.w * (co.x * m_x + co.y * m_y);
     a_my = -co.w * (co.z * m_y + co.y * m_x);
@@ -562,7 +568,6 @@ __global__ __launch_bounds__(64 * NW) void render_bwd_kernel(RenderBwdArgs a) {
 int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s) {
   const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE, gy = (a.H + RIGGS_TILE - 1) / RIGGS_TILE;
   if (gx * gy == 0) return 0;
-  hipLaunchKernelGGL(render_bwd_worklist_kernel, dim3(1 + 512), dim3(1024), 0, s, a);
   // 8 workgroups of 4 waves per CU: every SIMD holds 8 pulling waves (grid sizes from 3 to 128 per CU: within 2 %)
   const int64_t max_blocks = 256 * 8;
   const unsigned blocks = (unsigned)((a.n_slots < max_blocks) ? a.n_slots : max_blocks);

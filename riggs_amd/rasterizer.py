@@ -190,23 +190,41 @@ def rasterize_backward(s: _Saved, means3D, shs, colors_precomp, opacities, scale
     g_rots = grad_out(rotations, (N, 4)) if rotations is not None else None
     g_cov = torch.empty(N, 6, **f32) if cov3D_precomp is not None else None
     g_dscaling = torch.empty(N, 3, **f32) if (d_scaling is not None and want_d_scaling_grad) else None
-    ws = torch.empty(lib.riggs_raster_backward_workspace_bytes(N), dtype=torch.uint8, device=dev)
+    ws = _backward_workspace(lib.riggs_raster_backward_workspace_bytes(N), dev)
     if grad_color is None:  # a loss on depth / alpha only (set_materialize_grads(False) hands None for the unused output)
         grad_color = torch.zeros(3, s.H, s.W, **f32)
     gc = L.require_cuda_f32("grad_color", grad_color, (3, s.H, s.W))
     gd = L.require_cuda_f32("grad_depth", grad_depth) if grad_depth is not None else None
     ga = L.require_cuda_f32("grad_alpha", grad_alpha) if grad_alpha is not None else None
-    L.check(lib.riggs_raster_backward(
-        C.byref(cfg), L.ptr(means3D), L.ptr(shs), L.ptr(shs_rest), L.ptr(colors_precomp), L.ptr(opacities), L.ptr(scales),
-        L.ptr(rotations), L.ptr(cov3D_precomp), L.ptr(d_xyz), L.ptr(d_rotation), L.ptr(d_scaling), s.radii.data_ptr(),
-        s.geom.data_ptr(), s.binning.data_ptr(), s.cap, s.img.data_ptr(), s.counters.data_ptr(), gc.data_ptr(),
-        L.ptr(gd), L.ptr(ga), ws.data_ptr(), g_means3D.data_ptr(), g_means2D.data_ptr(), L.ptr(g_sh),
-        L.ptr(g_colors), g_opac.data_ptr(), L.ptr(g_scales), L.ptr(g_rots), L.ptr(g_cov), L.ptr(g_dscaling),
-        L.ptr(g_sh_rest), L.stream_ptr()),
-        "riggs_raster_backward")
+    try:
+        L.check(lib.riggs_raster_backward(
+            C.byref(cfg), L.ptr(means3D), L.ptr(shs), L.ptr(shs_rest), L.ptr(colors_precomp), L.ptr(opacities), L.ptr(scales),
+            L.ptr(rotations), L.ptr(cov3D_precomp), L.ptr(d_xyz), L.ptr(d_rotation), L.ptr(d_scaling), s.radii.data_ptr(),
+            s.geom.data_ptr(), s.binning.data_ptr(), s.cap, s.img.data_ptr(), s.counters.data_ptr(), gc.data_ptr(),
+            L.ptr(gd), L.ptr(ga), ws.data_ptr(), g_means3D.data_ptr(), g_means2D.data_ptr(), L.ptr(g_sh),
+            L.ptr(g_colors), g_opac.data_ptr(), L.ptr(g_scales), L.ptr(g_rots), L.ptr(g_cov), L.ptr(g_dscaling),
+            L.ptr(g_sh_rest), L.stream_ptr()),
+            "riggs_raster_backward")
+    except Exception:
+        _WORKSPACES.clear()  # a failed call may leave the accumulators dirty: the next one starts from fresh zeros
+        raise
     if shs_rest is not None:
         g_sh = (g_sh, g_sh_rest)
     return g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rots, g_cov, g_dscaling
+
+
+_WORKSPACES = {}
+
+
+def _backward_workspace(nbytes: int, dev) -> torch.Tensor:
+    """The per-Gaussian gradient accumulators of the compositing backward (include/riggs_hip.h: `workspace`): zeroed ONCE
+    here, then self-cleaning — the kernels leave them all zero — so a frame pays no fill pass.  One buffer per (device,
+    stream): a backward call uses it from its first to its last kernel on one stream."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), L.stream_ptr())
+    ws = _WORKSPACES.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _WORKSPACES[key] = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    return ws
 
 
 class _RasterizeGaussians(torch.autograd.Function):

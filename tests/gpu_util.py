@@ -78,14 +78,15 @@ STATS = []  # (what, elements, frac beyond the max-norm bound, max error / max|b
 
 def assert_close(a, b, what, rel=REL_TOL, allow_frac=0.0, allow_frac_elem=None):
     """Two bars: every element within rel * max|b| (up to `allow_frac` outliers), and all but `allow_frac_elem` of the
-    elements within the per-element bound of frac_bad_elem (default: 10x the max-norm allowance, at least 2e-3 — float
-    atomics reorder the sums of the compositing backward, and elements that are the difference of large cancelling
-    terms carry that noise at their neighbours' magnitude)."""
+    elements within the per-element bound of frac_bad_elem (default: 10x the max-norm allowance, at least 2e-3 and at
+    least 8 elements — float atomics reorder the sums of the compositing backward, and elements that are the difference
+    of large cancelling terms carry that noise at their neighbours' magnitude; measured: <= 8e-4 on every tensor of the
+    suite, gpurun_out/parity_stats.json)."""
     fb, mx = frac_bad(a, b, rel)
     fe = frac_bad_elem(a, b, rel)
     STATS.append((what, int(np.asarray(b).size), fb, mx, fe))
     assert fb <= allow_frac, "%s: %.3g of elements beyond %.1e rel (max rel err %.3g)" % (what, fb, rel, mx)
-    lim = max(2e-3, 10.0 * allow_frac) if allow_frac_elem is None else allow_frac_elem
+    lim = max(2e-3, 10.0 * allow_frac, 8.0 / max(1, int(np.asarray(b).size))) if allow_frac_elem is None else allow_frac_elem
     assert fe <= lim, "%s: %.3g of elements beyond the per-element bound %.1e |b| + %.0e max|b|" % (what, fe, rel, ELEM_ABS)
 
 
