@@ -5,12 +5,12 @@
 // by tile id.  With T <= a few thousand tiles that is a counting sort:
 //   bin_count   : per chunk of depth-ordered Gaussians, a tile histogram in LDS        -> table[chunk][tile]
 //   bin_scan    : per tile, exclusive scan over the chunks (table rewritten in place)   -> tile_count[tile]
-//   bin_offsets : exclusive scan over the tiles -> ranges[tile], slot_base[tile], R, overflow flag, and the forward's
-//                 work list (non-empty tiles, longest lists first)
-//   bin_scatter : per chunk: LDS cursors = tile start + chunk offset + offset of the preceding waves,
+//   bin_scatter : per chunk: LDS cursors = tile start (own exclusive scan over the tile counts) + chunk offset + offset of
+//                 the preceding waves,
 //                 then every wave walks ITS Gaussians in depth order (four per step, lanes = (slot, tile of the
 //                 slot's rectangle), ranks from rectangle tests) and writes point_list — order-preserving by
-//                 construction.
+//                 construction.  One extra workgroup of the same launch does the once-per-frame part (bin_offsets_body):
+//                 ranges[tile], slot_base[tile], R, overflow flag, the forward's work list (non-empty tiles, longest first).
 // HBM traffic: N*(4+8+4) read per pass, R*4(+4) written once, 2*chunks*T*4 for the table — against
 // ~R*32 B for two radix passes over (key, value) pairs plus the emit pass.
 #include "raster_internal.h"
@@ -96,26 +96,24 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(int T, int n_chunks, uin
   }
 }
 
-// exclusive scan over the tiles (one workgroup): ranges, checkpoint slot bases, R and the overflow flag
-__global__ __launch_bounds__(1024) void bin_offsets_kernel(int T, int64_t cap, const uint32_t* __restrict__ tile_count,
-                                                           uint32_t* __restrict__ tile_start, uint2* __restrict__ ranges,
-                                                           uint32_t* __restrict__ slot_base,
-                                                           uint32_t* __restrict__ tile_max,
-                                                           uint32_t* __restrict__ counters,
-                                                           uint32_t* __restrict__ fwd_items,
-                                                           uint32_t* __restrict__ fwd_empty,
-                                                           uint32_t* __restrict__ fwd_ctr) {
+// exclusive scan over the tiles (one workgroup — the extra, last one of bin_scatter_kernel's grid): ranges, checkpoint slot
+// bases, cleared per-tile words, R and the overflow flag, and the forward's work list
+__device__ void bin_offsets_body(int T, int64_t cap, const uint32_t* __restrict__ tile_count, uint2* __restrict__ ranges,
+                                 uint32_t* __restrict__ slot_base, uint32_t* __restrict__ tile_max,
+                                 uint32_t* __restrict__ counters, uint32_t* __restrict__ fwd_items,
+                                 uint32_t* __restrict__ fwd_empty, uint32_t* __restrict__ fwd_ctr) {
   __shared__ uint32_t s_wave[16];
   __shared__ uint32_t s_carry;
   __shared__ uint32_t s_hist[32], s_cur[32], s_nempty;
+  const int nthr = (int)blockDim.x;  // <= 1024
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) { s_carry = 0u; s_nempty = 0u; }
   if (tid < 32) s_hist[tid] = 0u;
   __syncthreads();
-  uint32_t my_len[8];  // list lengths of this thread's tiles (the first 8192 tiles; beyond that they are re-read)
+  uint32_t my_len[8];  // list lengths of this thread's tiles (the first 8 passes; beyond that they are re-read)
 #pragma unroll
   for (int k = 0; k < 8; k++) my_len[k] = 0u;
-  for (int base = 0; base < T; base += 1024) {
+  for (int base = 0, pass = 0; base < T; base += nthr, pass++) {
     const int t = base + tid;
     const uint32_t c = (t < T) ? tile_count[t] : 0u;
     // inclusive scan inside the wave
@@ -131,7 +129,6 @@ __global__ __launch_bounds__(1024) void bin_offsets_kernel(int T, int64_t cap, c
     const uint32_t carry = s_carry;
     const uint32_t start = carry + wave_off + v - c;
     if (t < T) {
-      tile_start[t] = start;
       // clamp to the arena: on overflow (flagged below) the frame is invalid but every access stays in bounds
       const uint32_t lo = (uint32_t)min((int64_t)start, cap), hi = (uint32_t)min((int64_t)start + c, cap);
       // empty tiles get (0, 0) like upstream's identifyTileRanges (whose ranges buffer is zeroed before)
@@ -143,15 +140,14 @@ __global__ __launch_bounds__(1024) void bin_offsets_kernel(int T, int64_t cap, c
       if (hi > lo) atomicAdd(&s_hist[31 - __builtin_clz(hi - lo)], 1u);
       else fwd_empty[atomicAdd(&s_nempty, 1u)] = (uint32_t)t;
 #pragma unroll
-      for (int k = 0; k < 8; k++) if (base == k * 1024) my_len[k] = hi - lo;
+      for (int k = 0; k < 8; k++) if (pass == k) my_len[k] = hi - lo;
     }
     __syncthreads();
-    if (tid == 1023) s_carry = carry + wave_off + v;
+    if (tid == nthr - 1) s_carry = carry + wave_off + v;
     __syncthreads();
   }
   if (tid == 0) {
     const uint32_t R = s_carry;
-    tile_start[T] = R;
     ranges[T] = make_uint2(0u, 0u);
     tile_max[T] = 0u;
     slot_base[T] = ((uint32_t)min((int64_t)R, cap) >> 6) + (uint32_t)T;
@@ -174,10 +170,10 @@ __global__ __launch_bounds__(1024) void bin_offsets_kernel(int T, int64_t cap, c
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < 8; k++) {
-    const int t = k * 1024 + tid;
+    const int t = k * nthr + tid;
     if (t < T && my_len[k] > 0u) fwd_items[atomicAdd(&s_cur[31 - __builtin_clz(my_len[k])], 1u)] = (uint32_t)t;
   }
-  for (int t = 8192 + tid; t < T; t += 1024) {  // (same thread that wrote ranges[t] above)
+  for (int t = 8 * nthr + tid; t < T; t += nthr) {  // (same thread that wrote ranges[t] above)
     const uint2 r = ranges[t];
     if (r.y > r.x) fwd_items[atomicAdd(&s_cur[31 - __builtin_clz(r.y - r.x)], 1u)] = (uint32_t)t;
   }
@@ -190,10 +186,17 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(int N, int T, int gri
                                                           const uint32_t* __restrict__ tiles,
                                                           const ushort4* __restrict__ rect,
                                                           const uint32_t* __restrict__ table,
-                                                          const uint32_t* __restrict__ tile_start,
+                                                          const uint32_t* __restrict__ tile_count,
                                                           uint32_t* __restrict__ point_list,
-                                                          uint32_t* __restrict__ tile_keys) {
+                                                          uint32_t* __restrict__ tile_keys, uint2* __restrict__ ranges,
+                                                          uint32_t* __restrict__ slot_base, uint32_t* __restrict__ tile_max,
+                                                          uint32_t* __restrict__ counters, uint32_t* __restrict__ fwd_items,
+                                                          uint32_t* __restrict__ fwd_empty, uint32_t* __restrict__ fwd_ctr) {
   extern __shared__ uint32_t s_mem[];
+  if (blockIdx.x == gridDim.x - 1) {  // the extra workgroup: what used to be a single-workgroup launch of its own
+    bin_offsets_body(T, cap, tile_count, ranges, slot_base, tile_max, counters, fwd_items, fwd_empty, fwd_ctr);
+    return;
+  }
   const int W = blockDim.x >> 6;
   uint32_t* s_base = s_mem;                                            // [T]
   const int Tpad = (T + 1) & ~1;
@@ -226,10 +229,34 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(int N, int T, int gri
     }
   }
   __syncthreads();
-  // (ii) counts -> offsets of the waves inside the block's segment; absolute base of the segment
+  // (ii) counts -> offsets of the waves inside the block's segment; absolute base of the segment = start of the tile's
+  // list (every workgroup scans the tile counts itself: T words from L2, instead of a launch that does it once) + the
+  // instances of the earlier chunks
   const uint32_t* row = table + (size_t)blockIdx.x * T;
+  {
+    __shared__ uint32_t s_wsum[16];
+    __shared__ uint32_t s_run;
+    if (tid == 0) s_run = 0u;
+    __syncthreads();
+    for (int base = 0; base < T; base += blockDim.x) {
+      const int t = base + tid;
+      const uint32_t c = (t < T) ? tile_count[t] : 0u;
+      uint32_t v = c;
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u = (uint32_t)__shfl_up((int)v, o);
+        if (lane >= o) v += u;
+      }
+      if (lane == 63) s_wsum[wave] = v;
+      __syncthreads();
+      uint32_t off = s_run;
+      for (int w = 0; w < wave; w++) off += s_wsum[w];
+      if (t < T) s_base[t] = off + v - c + row[t];
+      __syncthreads();
+      if (tid == (int)blockDim.x - 1) s_run = off + v;
+      __syncthreads();
+    }
+  }
   for (int t = tid; t < T; t += blockDim.x) {
-    s_base[t] = tile_start[t] + row[t];
     uint32_t run = 0;
     for (int w = 0; w < W; w++) {
       const unsigned short c = s_rel[(size_t)w * Tpad + t];
@@ -326,7 +353,7 @@ static BinPlan bin_plan(int N, int T) {
 
 size_t bin_table_bytes(int N, int T) {
   BinPlan p = bin_plan(N > 0 ? N : 1, T);
-  return align_up(((size_t)p.n_chunks + 1) * T * 4) + align_up((size_t)(T + 1) * 4) * 2;
+  return align_up(((size_t)p.n_chunks + 1) * T * 4) + align_up((size_t)(T + 1) * 4);
 }
 
 int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order, const uint32_t* tiles,
@@ -337,24 +364,24 @@ int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order,
   char* mem = (char*)table_mem;
   uint32_t* table = (uint32_t*)mem;
   uint32_t* tile_count = (uint32_t*)(mem + align_up(((size_t)p.n_chunks + 1) * T * 4));
-  uint32_t* tile_start = (uint32_t*)((char*)tile_count + align_up((size_t)(T + 1) * 4));
   if (p.lds_scatter > 150 * 1024) {  // (bin_plan is down to one wave per workgroup: T * 6 bytes of LDS)
     set_error("image too large: %d tiles, the tile binning holds its per-workgroup tile table in LDS and takes at most 25600 (e.g. 2560 x 2560 px)", T);
     return 2;
   }
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bin_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // (dynamic + static LDS <= 160 KB: the kernel also has ~1 KB of static scratch for its scans)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bin_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bin_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   hipLaunchKernelGGL(bin_count_kernel, dim3(p.n_chunks), dim3(p.threads), (size_t)T * 4, s, N, T, grid_x, p.g_per_block,
                      order, tiles, rect, table);
   hipLaunchKernelGGL(bin_scan_kernel, dim3((T + 63) / 64), dim3(1024), 0, s, T, p.n_chunks, table, tile_count);
-  hipLaunchKernelGGL(bin_offsets_kernel, dim3(1), dim3(1024), 0, s, T, cap, tile_count, tile_start, ranges, slot_base,
-                     tile_max, counters, fwd_items, fwd_empty, fwd_ctr);
-  hipLaunchKernelGGL(bin_scatter_kernel, dim3(p.n_chunks), dim3(p.threads), p.lds_scatter, s, N, T, grid_x, cap,
-                     p.g_per_block, order, tiles, rect, table, tile_start, point_list, tile_keys);
+  // (+ 1: the extra workgroup that writes the ranges, the counters and the forward's work list)
+  hipLaunchKernelGGL(bin_scatter_kernel, dim3(p.n_chunks + 1), dim3(p.threads), p.lds_scatter, s, N, T, grid_x, cap,
+                     p.g_per_block, order, tiles, rect, table, tile_count, point_list, tile_keys, ranges, slot_base, tile_max,
+                     counters, fwd_items, fwd_empty, fwd_ctr);
   return 0;
 }
 

@@ -12,41 +12,8 @@
 
 namespace riggs {
 
-__device__ __forceinline__ void load_inputs(const PreArgs& a, int i, GlueIn& g, bool need_sr) {
-  g.p[0] = a.means3D[3 * i]; g.p[1] = a.means3D[3 * i + 1]; g.p[2] = a.means3D[3 * i + 2];
-  if (a.glue) {
-    if (a.d_xyz) { g.p[0] = g.p[0] + a.d_xyz[3 * i]; g.p[1] = g.p[1] + a.d_xyz[3 * i + 1]; g.p[2] = g.p[2] + a.d_xyz[3 * i + 2]; }
-    g.o = sigmoidf_(a.opac[i]);
-    if (need_sr) {
-      if (a.isotropic) { float s = expf(a.scales[i]); g.es[0] = g.es[1] = g.es[2] = s; }
-      else { g.es[0] = expf(a.scales[3 * i]); g.es[1] = expf(a.scales[3 * i + 1]); g.es[2] = expf(a.scales[3 * i + 2]); }
-      g.s[0] = g.es[0]; g.s[1] = g.es[1]; g.s[2] = g.es[2];
-      if (a.d_scaling) { g.s[0] = g.s[0] + a.d_scaling[3 * i]; g.s[1] = g.s[1] + a.d_scaling[3 * i + 1]; g.s[2] = g.s[2] + a.d_scaling[3 * i + 2]; }
-      const float4 r = reinterpret_cast<const float4*>(a.rots)[i];
-      g.v[0] = r.x; g.v[1] = r.y; g.v[2] = r.z; g.v[3] = r.w;
-      if (a.d_rot) {
-        const float4 d = reinterpret_cast<const float4*>(a.d_rot)[i];
-        g.v[0] = g.v[0] + d.x; g.v[1] = g.v[1] + d.y; g.v[2] = g.v[2] + d.z; g.v[3] = g.v[3] + d.w;
-      }
-      // F.normalize(v, eps=1e-12): v / max(|v|, eps)   (scene/gaussian_model.py:116-118)
-      float n = sqrtf(g.v[0] * g.v[0] + g.v[1] * g.v[1] + g.v[2] * g.v[2] + g.v[3] * g.v[3]);
-      g.vnorm = fmaxf(n, 1e-12f);
-      g.q[0] = g.v[0] / g.vnorm; g.q[1] = g.v[1] / g.vnorm; g.q[2] = g.v[2] / g.vnorm; g.q[3] = g.v[3] / g.vnorm;
-    }
-  } else {
-    g.o = a.opac[i];
-    if (need_sr) {
-      g.s[0] = a.scales[3 * i]; g.s[1] = a.scales[3 * i + 1]; g.s[2] = a.scales[3 * i + 2];
-      const float4 r = reinterpret_cast<const float4*>(a.rots)[i];
-      g.q[0] = r.x; g.q[1] = r.y; g.q[2] = r.z; g.q[3] = r.w;
-      g.vnorm = 1.f;
-    }
-  }
-}
-
-
-// The same in two steps for the backward: every global load of a Gaussian's parameters first (no arithmetic, so that
-// they are all in flight together), the arithmetic after — bit-identical to load_inputs.
+// A Gaussian's inputs in two steps: every global load first (no arithmetic, so that they are all in flight together), the
+// arithmetic after.
 struct RawIn {
   float p[3], dx[3], o, sc[3], dsc[3];
   float4 r, dr;
@@ -128,6 +95,46 @@ __device__ __forceinline__ void sh_stage_in(const float* __restrict__ src, int p
   }
 }
 
+// The same copy in two steps — every global load of the thread first (up to SH_IT independent 16-byte loads in flight),
+// the LDS writes after — so that a workgroup's staging costs ONE memory round trip instead of one per 4 KB slice: written
+// as a single loop the compiler waits for each load before its LDS write.  (Reading each Gaussian's 180-byte row straight
+// into registers with dword-aligned 16-byte loads, which would free the LDS and let every workgroup be resident at once,
+// is 2x SLOWER: 64 lanes x 64 different cache lines per load instruction.)
+#define SH_IT 12  // 256 Gaussians x <= 48 floats / (256 threads x 4 floats)
+__device__ __forceinline__ void sh_stage_load(const float* __restrict__ src, int total, float4 (&v)[SH_IT]) {
+#pragma unroll
+  for (int it = 0; it < SH_IT; it++) {
+    const int e = threadIdx.x * 4 + it * 1024;
+    v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e + 3 < total) v[it] = *reinterpret_cast<const float4*>(src + e);
+  }
+}
+__device__ __forceinline__ void sh_stage_store(const float* __restrict__ src, int per, int total, const float4 (&v)[SH_IT], float* lds) {
+  const int stride = sh_lds_stride(per);
+  const int q1024 = 1024 / per, r1024 = 1024 % per;
+  int e = threadIdx.x * 4;
+  int g = e / per, k = e % per;
+#pragma unroll
+  for (int it = 0; it < SH_IT; it++, e += 1024) {
+    if (e + 3 < total) {
+      const float w[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        int kk = k + q, gg = g;
+        if (kk >= per) { kk -= per; gg++; }
+        lds[gg * stride + kk] = w[q];
+      }
+    }
+    k += r1024; g += q1024;
+    if (k >= per) { k -= per; g++; }
+  }
+  // ragged end of the last workgroup (total not a multiple of 4): at most three elements
+  if (threadIdx.x < (total & 3)) {
+    const int t = (total & ~3) + threadIdx.x;
+    lds[(t / per) * stride + (t % per)] = src[t];
+  }
+}
+
 __device__ __forceinline__ void sh_stage_out(float* __restrict__ dst, int per, int count, const float* lds) {
   const int total = count * per;
   const int stride = sh_lds_stride(per);
@@ -159,10 +166,28 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a) {
   // SH records of this workgroup -> LDS (uniform; before any per-Gaussian exit)
   const bool sh_mode = (a.colors_precomp == nullptr);
   const int sh_per = a.shs_rest ? (a.M - 1) * 3 : a.M * 3;  // floats per Gaussian in the staged array
+  // every global load of the thread is issued before anything waits: its slices of the workgroup's SH run and its own
+  // Gaussian's parameters (the compiler otherwise serialises them: one round trip per load)
+  const bool need_sr = (a.cov3D_precomp == nullptr);
+  const int sh_first = blockIdx.x * 256, sh_total = min(256, a.N - sh_first) * sh_per;
+  const float* sh_src = sh_mode ? (a.shs_rest ? a.shs_rest : a.shs) + (size_t)sh_first * sh_per : nullptr;
+  const bool sh_fast = sh_mode && sh_per > 0 && sh_per <= 48 && ((reinterpret_cast<uintptr_t>(sh_src) & 15) == 0);
+  float4 shq[SH_IT];
+  RawIn raw;
+  if (sh_fast) sh_stage_load(sh_src, sh_total, shq);
+  if (i < a.N) load_raw(a, i, raw, need_sr);
+  float c6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (i < a.N && a.cov3D_precomp) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) c6[k] = a.cov3D_precomp[6 * i + k];
+  }
+  float cpre[3] = {0.f, 0.f, 0.f}, dc0[3] = {0.f, 0.f, 0.f};
+  if (i < a.N && a.colors_precomp) { cpre[0] = a.colors_precomp[3 * i]; cpre[1] = a.colors_precomp[3 * i + 1]; cpre[2] = a.colors_precomp[3 * i + 2]; }
+  if (i < a.N && sh_mode && a.shs_rest) { dc0[0] = a.shs[3 * i]; dc0[1] = a.shs[3 * i + 1]; dc0[2] = a.shs[3 * i + 2]; }
+  __builtin_amdgcn_sched_barrier(0);
   if (sh_mode && sh_per > 0) {
-    const int first = blockIdx.x * 256, count = min(256, a.N - first);
-    const float* src = (a.shs_rest ? a.shs_rest : a.shs) + (size_t)first * sh_per;
-    sh_stage_in(src, sh_per, count, s_sh);
+    if (sh_fast) sh_stage_store(sh_src, sh_per, sh_total, shq, s_sh);
+    else sh_stage_in(sh_src, sh_per, min(256, a.N - sh_first), s_sh);
     __syncthreads();
   }
   uint32_t my_tiles = 0u;
@@ -175,8 +200,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a) {
   a.depth_key[i] = 0xFFFFFFFFu;  // culled Gaussians sort last
   a.order_in[i] = (uint32_t)i;
   GlueIn g;
-  const bool need_sr = (a.cov3D_precomp == nullptr);
-  load_inputs(a, i, g, need_sr);
+  finish_inputs(a, raw, g, need_sr);
   const float* p = g.p;
   float vz = V[2] * p[0] + V[6] * p[1] + V[10] * p[2] + V[14];
   if (vz <= RIGGS_NEAR_Z) break;
@@ -185,13 +209,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a) {
   float hw = P[3] * p[0] + P[7] * p[1] + P[11] * p[2] + P[15];
   float pw = 1.0f / (hw + 0.0000001f);
   float ndcx = hx * pw, ndcy = hy * pw;
-  float c6[6];
-  if (a.cov3D_precomp) {
-#pragma unroll
-    for (int k = 0; k < 6; k++) c6[k] = a.cov3D_precomp[6 * i + k];
-  } else {
-    cov3d_from_scale_rot(g.s, a.mod, g.q, c6);
-  }
+  if (!a.cov3D_precomp) cov3d_from_scale_rot(g.s, a.mod, g.q, c6);
   float fx = a.W / (2.0f * a.tanx), fy = a.H / (2.0f * a.tany);
   Cov2D cv;
   cov2d_eval(p, c6, V, fx, fy, a.tanx, a.tany, cv);
@@ -215,7 +233,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a) {
   float rgbv[3];
   uint8_t cl = 0;
   if (a.colors_precomp) {
-    rgbv[0] = a.colors_precomp[3 * i]; rgbv[1] = a.colors_precomp[3 * i + 1]; rgbv[2] = a.colors_precomp[3 * i + 2];
+    rgbv[0] = cpre[0]; rgbv[1] = cpre[1]; rgbv[2] = cpre[2];
   } else {
     float dx = p[0] - a.campos[0], dy = p[1] - a.campos[1], dz = p[2] - a.campos[2];
     float len = sqrtf(dx * dx + dy * dy + dz * dz);
@@ -226,7 +244,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a) {
     const float* mine = s_sh + threadIdx.x * sh_lds_stride(sh_per);
     const int koff = a.shs_rest ? 3 : 0;  // split layout: coefficient 0 comes from _features_dc
     float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-    if (a.shs_rest) { r0 = B[0] * a.shs[3 * i]; r1 = B[0] * a.shs[3 * i + 1]; r2 = B[0] * a.shs[3 * i + 2]; }
+    if (a.shs_rest) { r0 = B[0] * dc0[0]; r1 = B[0] * dc0[1]; r2 = B[0] * dc0[2]; }
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       if (k < nb && 3 * k >= koff) {
