@@ -165,7 +165,7 @@ __device__ void bin_offsets_body(int T, int64_t cap, const uint32_t* __restrict_
       if (tid >= o) v += u;
     }
     s_cur[31 - tid] = v - h;
-    if (tid == 31) { fwd_ctr[0] = v; fwd_ctr[1] = 0u; fwd_ctr[2] = s_nempty; fwd_ctr[4] = 0u; }  // ([4]: backward work-list size)
+    if (tid == 31) { fwd_ctr[0] = v; fwd_ctr[1] = 0u; fwd_ctr[2] = s_nempty; fwd_ctr[64] = 0u; }  // ([64]: backward work-list size, on its own cache line)
   }
   __syncthreads();
 #pragma unroll

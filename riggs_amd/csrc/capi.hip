@@ -77,7 +77,9 @@ ImageLayout image_layout(int H, int W) {
   // {n_nonempty, -, n_empty}
   L.fwd_items = o; o = align_up(o + (T + 1) * 4);
   L.fwd_empty = o; o = align_up(o + (T + 1) * 4);
-  L.fwd_ctr = o; o = align_up(o + 32);  // + [4] = size of the backward's work list (in quarter-chunks), appended to by the forward
+  // {n_nonempty, -, n_empty} read by every forward workgroup; [64] = size of the backward's work list (in quarter-chunks),
+  // appended to by the forward with atomics — on a cache line of its own (see render_fwd_oct_kernel)
+  L.fwd_ctr = o; o = align_up(o + 512);
   L.total = o;
   return L;
 }
@@ -231,7 +233,7 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
   const bool binned = N > 0 && cap > 0;
   if (!binned) {  // (bin_offsets_kernel writes every entry of ranges / tile_max / slot_base / the counters itself)
     RIGGS_HIP_CHECK(hipMemsetAsync(img + I.ranges, 0, (I.slot_base - I.ranges) + (size_t)(T + 2) * 4, s));
-    RIGGS_HIP_CHECK(hipMemsetAsync(img + I.fwd_ctr, 0, 32, s));
+    RIGGS_HIP_CHECK(hipMemsetAsync(img + I.fwd_ctr, 0, 512, s));
   }
   const uint32_t* point_list = (const uint32_t*)(bin + B.point_list);
   if (binned) {
@@ -258,7 +260,7 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
   r.out_color = out_color; r.out_depth = out_depth; r.out_alpha = out_alpha;
   r.final_acc = (float4*)(img + I.final_acc); r.tile_max = (uint32_t*)(img + I.tile_max);
   r.tile_ticket = r.tile_max + (T + 1);
-  r.work = (uint4*)(bin + B.work); r.work_ctr = (uint32_t*)(img + I.fwd_ctr) + 4;
+  r.work = (uint4*)(bin + B.work); r.work_ctr = (uint32_t*)(img + I.fwd_ctr) + 64;
   r.slot_base = (const uint32_t*)(img + I.slot_base); r.ckpt = (float*)(bin + B.ckpt);
   // longest-list-first work list of the forward (bin_offsets_kernel builds it; NULL: every tile is empty)
   r.items = nullptr; r.empties = nullptr; r.item_ctr = nullptr;
@@ -313,7 +315,7 @@ int riggs_raster_backward(const riggs_raster_cfg* cfg, const float* means3D, con
   r.slot_base = (const uint32_t*)(img + I.slot_base); r.ckpt = (const float*)(bin + B.ckpt);
   r.n_tiles = ((W + RIGGS_TILE - 1) / RIGGS_TILE) * ((H + RIGGS_TILE - 1) / RIGGS_TILE);
   r.n_slots = (int64_t)B.n_slots;
-  r.work = (const uint4*)(bin + B.work); r.work_ctr = (const uint32_t*)(img + I.fwd_ctr) + 4;
+  r.work = (const uint4*)(bin + B.work); r.work_ctr = (const uint32_t*)(img + I.fwd_ctr) + 64;
   // (cap == 0: nothing was composited and the accumulators — zero on entry by contract — stay zero)
   if (cap > 0) { ProfScope ps(PROF_RENDER_BWD, s); launch_render_bwd(r, s); }
   if (debug_sync(cfg->debug, s, "render_bwd")) return 1;

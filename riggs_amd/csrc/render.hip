@@ -259,6 +259,9 @@ __global__ __launch_bounds__(256, 6) void render_fwd_oct_kernel(RenderArgs a) {
   // the tile's entries (tile, chunk, start of the tile's list, instances to walk) — a separate list-building launch used to
   // cost 10 us.  Both words are only ever touched with agent-scope atomics, and a block takes its ticket after its
   // maximum has RETURNED (the returning atomic has been performed), so the last ticket holder reads the final maximum.
+  // The list's size word (work_ctr) lives on a cache line of ITS OWN: sharing one with item_ctr — which every one of the
+  // launch's 20 000 workgroups reads when it starts — cost 17 us (each of the ~470 atomics throws the line out of the L2s,
+  // and the late-dispatched workgroups queue behind it at the memory side).
   // Only wave 0 stays for this (two dependent atomic round trips to the memory side, ~4 us): the other three waves
   // leave — or move on to the next item, where the round barrier waits for wave 0 — so their SIMD slots are free.
   if (wave == 0) {
@@ -288,6 +291,7 @@ int launch_render_fwd(const RenderArgs& a, hipStream_t s) {
   if (gx * gy == 0) return 0;
   // one workgroup per 8 x 4 block of every tile; the ones past the non-empty tiles of the work list only help with the
   // background of the empty tiles and leave (tile_max, the tile tickets and the work-list size were cleared by bin_offsets_kernel)
+  // (a grid capped at 2048 .. 8192 persistent workgroups instead: within 1 %)
   if (a.trace) hipLaunchKernelGGL(render_fwd_oct_kernel<true>, dim3(gx * gy * 8), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(render_fwd_oct_kernel<false>, dim3(gx * gy * 8), dim3(256), 0, s, a);
   return 0;
