@@ -56,8 +56,8 @@ __global__ __launch_bounds__(1024) void bin_count_kernel(int N, int T, int grid_
 // written back — no serial walk over hundreds of chunks.
 #define SCAN_SEG 16
 #define SCAN_KEEP 32
-__global__ __launch_bounds__(1024) void bin_scan_kernel(int T, int n_chunks, uint32_t* __restrict__ table,
-                                                        uint32_t* __restrict__ tile_count) {
+__device__ __forceinline__ void bin_scan_body(int T, int n_chunks, uint32_t* __restrict__ table,
+                                              uint32_t* __restrict__ tile_count) {
   __shared__ uint32_t s_seg[SCAN_SEG][64];
   const int tl = threadIdx.x & 63, seg = threadIdx.x >> 6;
   const int t = blockIdx.x * 64 + tl;
@@ -94,6 +94,10 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(int T, int n_chunks, uin
     for (int b = b0; b < b1; b++) { const uint32_t c = table[(size_t)b * T + t]; table[(size_t)b * T + t] = run; run += c; }
     if (seg == SCAN_SEG - 1) tile_count[t] = run;
   }
+}
+__global__ __launch_bounds__(1024) void bin_scan_kernel(int T, int n_chunks, uint32_t* __restrict__ table,
+                                                        uint32_t* __restrict__ tile_count) {
+  bin_scan_body(T, n_chunks, table, tile_count);
 }
 
 // exclusive scan over the tiles (one workgroup — the extra, last one of bin_scatter_kernel's grid): ranges, checkpoint slot
@@ -387,83 +391,138 @@ int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order,
 
 
 // =====================================================================================================
-// Depth sort of the Gaussians: stable LSD radix sort of (u32 depth bits, u32 index) pairs in three
-// 11/11/10-bit passes, each pass a counting sort built like the tile binning above:
-//   rs_count   : per chunk of 1024 elements, a 2048-bin histogram in LDS            -> table[chunk][bin]
-//   bin_scan   : per bin, exclusive scan over the chunks (same kernel as the binning) -> bin_count[bin]
+// Depth sort of the Gaussians: stable LSD radix sort of (u32 depth bits, u32 index) pairs on 12-bit digits —
+// bits [0, 12), [12, 24) and, ONLY IF NEEDED, [24, 32) — each pass a counting sort built like the tile binning above:
+//   rs_count   : per chunk of 2048 elements, a 4096-bin histogram in LDS             -> table[chunk][bin]
+//   bin_scan   : per bin, exclusive scan over the chunks (same kernel as the binning)  -> bin_count[bin]
 //   rs_scatter : per chunk: scan of bin_count in LDS, per-wave offsets, then each wave ranks its elements
-//                64 at a time in input order (equal digits matched with 11 ballots) and scatters.
+//                64 at a time in input order (equal digits matched with 12 ballots) and scatters.
+// The top byte of a positive float is its sign and the upper seven exponent bits: it is the same for every depth of a
+// scene that lies inside one of the ranges [2, 8), [0.5, 2), [8, 32), ... (a D-NeRF / ZJU camera looks at its subject
+// from 2 - 6 units).  preprocess_fwd records the top bytes it saw; the first kernel folds them into counters[2] =
+// "third pass needed", and the three kernels of the third pass leave at once when it is not: two passes (six short
+// launches + three empty ones) instead of three 11-bit passes.  The result always ends in (keys_out, vals_out): the
+// first two passes go through a scratch pair or through the output pair depending on the flag.
 // rocPRIM picks a block sort + ~9 merge passes (18 launches, 0.12 ms) at N = 3e5 and Onesweep's chained
-// look-back costs the same at this size; nine short, chain-free launches take about half the time.
+// look-back costs the same at this size.
 // =====================================================================================================
-#define RS_BITS 11
+#define RS_BITS 12
 #define RS_BINS (1 << RS_BITS)
-#define RS_CHUNK 1024  // elements per workgroup (4 waves x 4 steps x 64 lanes)
+#define RS_CHUNK 2048   // elements per workgroup
+#define RS_SC_WAVES 8   // waves of a scatter workgroup (4 steps of 64 elements each)
+
+// routing of a pass: (source, destination) by the "third pass needed" flag (counters[2])
+struct RsBufs {
+  const uint32_t *k_in, *v_in;        // the caller's input (never written): pass 0 reads it (v_in may be NULL: value = index)
+  uint32_t *k_tmp, *v_tmp;            // scratch pair
+  uint32_t *k_out, *v_out;            // the result
+};
+__device__ __forceinline__ void rs_route(const RsBufs& b, int pass, bool three, const uint32_t*& ks, const uint32_t*& vs,
+                                         uint32_t*& kd, uint32_t*& vd) {
+  // two passes:   in -> tmp -> out            three passes:   in -> out -> tmp -> out
+  if (pass == 0) { ks = b.k_in; vs = b.v_in; kd = three ? b.k_out : b.k_tmp; vd = three ? b.v_out : b.v_tmp; }
+  else if (pass == 1) { ks = three ? b.k_out : b.k_tmp; vs = three ? b.v_out : b.v_tmp; kd = three ? b.k_tmp : b.k_out; vd = three ? b.v_tmp : b.v_out; }
+  else { ks = b.k_tmp; vs = b.v_tmp; kd = b.k_out; vd = b.v_out; }
+}
 
 // (the last workgroup of the first pass also totals the per-workgroup tile counts of preprocess_fwd into
-// counters[0] = R for the host — that used to be a launch of its own)
-__global__ __launch_bounds__(256) void rs_count_kernel(int N, int shift, const uint32_t* __restrict__ keys,
-                                                       uint32_t* __restrict__ table, const uint32_t* __restrict__ part,
-                                                       int n_part, uint32_t* __restrict__ total) {
+// counters[0] = R for the host, and every workgroup of it derives the flag from the recorded top bytes — the last one
+// publishes it in counters[2] for the later launches)
+__global__ __launch_bounds__(256) void rs_count_kernel(int N, int pass, RsBufs bufs, uint32_t* __restrict__ table,
+                                                       const uint32_t* __restrict__ part, int n_part,
+                                                       uint32_t* __restrict__ counters) {
   __shared__ uint32_t s_hist[RS_BINS];
-  if (part != nullptr && blockIdx.x == gridDim.x - 1) {
-    __shared__ uint32_t s_w[4];
-    uint32_t v = 0;
-    for (int i = threadIdx.x; i < n_part; i += 256) v += part[i];
-    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+  __shared__ uint32_t s_w[4], s_lo[4], s_hi[4];
+  bool three;
+  if (pass == 0) {
+    // part[0 .. n_part): tile counts; part[n_part .. 2 n_part): (min top byte << 8) | max top byte of the visible keys
+    uint32_t v = 0, lo = 0xFFu, hi = 0u;
+    for (int i = threadIdx.x; i < n_part; i += 256) {
+      v += part[i];
+      const uint32_t tb = part[n_part + i];
+      lo = min(lo, tb >> 8); hi = max(hi, tb & 0xFFu);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      v += (uint32_t)__shfl_xor((int)v, o);
+      lo = min(lo, (uint32_t)__shfl_xor((int)lo, o)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, o));
+    }
+    if ((threadIdx.x & 63) == 0) { s_w[threadIdx.x >> 6] = v; s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
     __syncthreads();
-    if (threadIdx.x == 0) { total[0] = s_w[0] + s_w[1] + s_w[2] + s_w[3]; total[1] = 0u; total[2] = 0u; total[3] = 0u; }
+    lo = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3])); hi = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
+    three = hi > lo;  // (no visible key at all: lo = 255 > hi = 0: two passes)
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+      counters[0] = s_w[0] + s_w[1] + s_w[2] + s_w[3]; counters[1] = 0u; counters[2] = three ? 1u : 0u; counters[3] = 0u;
+    }
+  } else {
+    three = counters[2] != 0u;
+    if (pass == 2 && !three) return;
   }
+  const uint32_t *ks, *vs; uint32_t *kd, *vd;
+  rs_route(bufs, pass, three, ks, vs, kd, vd);
+  const int shift = pass * RS_BITS;
   for (int b = threadIdx.x; b < RS_BINS; b += 256) s_hist[b] = 0u;
   __syncthreads();
   const int first = blockIdx.x * RS_CHUNK;
 #pragma unroll
   for (int k = 0; k < RS_CHUNK / 256; k++) {
     const int i = first + k * 256 + threadIdx.x;
-    if (i < N) atomicAdd(&s_hist[(keys[i] >> shift) & (RS_BINS - 1)], 1u);
+    if (i < N) atomicAdd(&s_hist[(ks[i] >> shift) & (RS_BINS - 1)], 1u);
   }
   __syncthreads();
   uint32_t* row = table + (size_t)blockIdx.x * RS_BINS;
   for (int b = threadIdx.x; b < RS_BINS; b += 256) row[b] = s_hist[b];
 }
 
-__global__ __launch_bounds__(256) void rs_scatter_kernel(int N, int shift, const uint32_t* __restrict__ keys,
-                                                         const uint32_t* __restrict__ vals,
-                                                         const uint32_t* __restrict__ table /* exclusive over chunks */,
-                                                         const uint32_t* __restrict__ bin_count,
-                                                         uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
-  __shared__ uint32_t s_start[RS_BINS];           // global start of this chunk's segment in each bin
-  __shared__ unsigned short s_wave[4][RS_BINS];   // per-wave counts -> per-wave running offsets
-  __shared__ uint32_t s_part[4];
+// (the third pass's scan when that pass is skipped: bin_scan_kernel itself is shared with the tile binning, so a thin
+// wrapper checks the flag)
+__global__ __launch_bounds__(1024) void rs_scan_kernel(int n_chunks, uint32_t* __restrict__ table, uint32_t* __restrict__ bin_count,
+                                                       const uint32_t* __restrict__ counters, int pass) {
+  if (pass == 2 && counters[2] == 0u) return;
+  bin_scan_body(RS_BINS, n_chunks, table, bin_count);
+}
+
+__global__ __launch_bounds__(RS_SC_WAVES * 64) void rs_scatter_kernel(int N, int pass, RsBufs bufs,
+                                                                      const uint32_t* __restrict__ table /* exclusive over chunks */,
+                                                                      const uint32_t* __restrict__ bin_count,
+                                                                      const uint32_t* __restrict__ counters) {
+  __shared__ uint32_t s_start[RS_BINS];                      // global start of this chunk's segment in each bin
+  __shared__ unsigned short s_wave[RS_SC_WAVES][RS_BINS];    // per-wave counts -> per-wave running offsets
+  __shared__ uint32_t s_part[RS_SC_WAVES];
+  const bool three = counters[2] != 0u;
+  if (pass == 2 && !three) return;
+  const uint32_t *ks, *vs; uint32_t *kd, *vd;
+  rs_route(bufs, pass, three, ks, vs, kd, vd);
+  const int shift = pass * RS_BITS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // exclusive scan of bin_count (2048 values, 8 per thread)
-  uint32_t c[8], tsum = 0;
+  constexpr int NT = RS_SC_WAVES * 64, PER = RS_BINS / NT;   // bins per thread in the scan
+  // exclusive scan of bin_count
+  uint32_t c[PER], tsum = 0;
 #pragma unroll
-  for (int k = 0; k < 8; k++) { c[k] = bin_count[tid * 8 + k]; tsum += c[k]; }
+  for (int k = 0; k < PER; k++) { c[k] = bin_count[tid * PER + k]; tsum += c[k]; }
   uint32_t v = tsum;
   for (int o = 1; o < 64; o <<= 1) {
     const uint32_t u = (uint32_t)__shfl_up((int)v, o);
     if (lane >= o) v += u;
   }
   if (lane == 63) s_part[wave] = v;
-  for (int e = tid; e < 4 * RS_BINS / 2; e += 256) reinterpret_cast<uint32_t*>(&s_wave[0][0])[e] = 0u;
+  for (int e = tid; e < RS_SC_WAVES * RS_BINS / 2; e += NT) reinterpret_cast<uint32_t*>(&s_wave[0][0])[e] = 0u;
   __syncthreads();
   uint32_t run = v - tsum;
   for (int w = 0; w < wave; w++) run += s_part[w];
   const uint32_t* row = table + (size_t)blockIdx.x * RS_BINS;
 #pragma unroll
-  for (int k = 0; k < 8; k++) { s_start[tid * 8 + k] = run + row[tid * 8 + k]; run += c[k]; }
+  for (int k = 0; k < PER; k++) { s_start[tid * PER + k] = run + row[tid * PER + k]; run += c[k]; }
   // this wave's elements: 4 steps of 64 consecutive elements
-  const int wfirst = blockIdx.x * RS_CHUNK + wave * 256;
-  uint32_t key[4], val[4];
-  int dig[4];
+  constexpr int STEPS = RS_CHUNK / NT;
+  const int wfirst = blockIdx.x * RS_CHUNK + wave * (64 * STEPS);
+  uint32_t key[STEPS], val[STEPS];
+  int dig[STEPS];
 #pragma unroll
-  for (int st = 0; st < 4; st++) {
+  for (int st = 0; st < STEPS; st++) {
     const int i = wfirst + st * 64 + lane;
     key[st] = 0u; val[st] = 0u; dig[st] = -1;
     if (i < N) {
-      key[st] = keys[i]; val[st] = vals[i];
+      key[st] = ks[i]; val[st] = vs ? vs[i] : (uint32_t)i;
       dig[st] = (int)((key[st] >> shift) & (RS_BINS - 1));
       // 16-bit counters packed in pairs (a wave adds at most 256 per bin)
       atomicAdd(reinterpret_cast<uint32_t*>(&s_wave[wave][0]) + (dig[st] >> 1), 1u << (16 * (dig[st] & 1)));
@@ -471,17 +530,17 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(int N, int shift, const
   }
   __syncthreads();
   // counts -> offsets of the waves inside the chunk's segment
-  for (int b = tid; b < RS_BINS; b += 256) {
+  for (int b = tid; b < RS_BINS; b += NT) {
     unsigned short r = 0;
 #pragma unroll
-    for (int w = 0; w < 4; w++) { const unsigned short cw = s_wave[w][b]; s_wave[w][b] = r; r += cw; }
+    for (int w = 0; w < RS_SC_WAVES; w++) { const unsigned short cw = s_wave[w][b]; s_wave[w][b] = r; r += cw; }
   }
   __syncthreads();
   unsigned short* cur = s_wave[wave];
 #pragma unroll
-  for (int st = 0; st < 4; st++) {
+  for (int st = 0; st < STEPS; st++) {
     const bool on = dig[st] >= 0;
-    // lanes with the same digit (match-any over 11 bits)
+    // lanes with the same digit (match-any over the digit's bits)
     uint64_t same = __builtin_amdgcn_ballot_w64(on);
 #pragma unroll
     for (int b = 0; b < RS_BITS; b++) {
@@ -493,35 +552,35 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(int N, int shift, const
       const uint32_t rank = (uint32_t)__builtin_popcountll(below);
       const unsigned short base = cur[dig[st]];
       const uint32_t pos = s_start[dig[st]] + base + rank;
-      keys_out[pos] = key[st]; vals_out[pos] = val[st];
+      kd[pos] = key[st]; vd[pos] = val[st];
       if ((same >> lane) >> 1 == 0ull) cur[dig[st]] = base + (unsigned short)__builtin_popcountll(same);  // highest lane of the group
     }
   }
 }
 
 size_t depth_sort_table_bytes(int N) {
-  const size_t chunks = (size_t)(N > 0 ? (N + RS_CHUNK - 1) / RS_CHUNK : 1);
-  return align_up((chunks + 1) * RS_BINS * 4) + align_up(RS_BINS * 4);
+  const size_t n = (size_t)(N > 0 ? N : 1), chunks = (n + RS_CHUNK - 1) / RS_CHUNK;
+  return align_up((chunks + 1) * RS_BINS * 4) + align_up(RS_BINS * 4) + 2 * align_up(n * 4);  // table, bin counts, scratch pair
 }
 
-// three passes: the result ends in (keys_out, vals_out); (keys_in, vals_in) are used as scratch
-int launch_depth_sort(int N, uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, void* table_mem,
-                      const uint32_t* block_tiles, uint32_t* counters, hipStream_t s) {
+// the result ends in (keys_out, vals_out); keys_in is left intact; values are the element indices
+int launch_depth_sort(int N, const uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_out, void* table_mem,
+                      const uint32_t* block_info, uint32_t* counters, hipStream_t s) {
   const int chunks = (N + RS_CHUNK - 1) / RS_CHUNK;
-  uint32_t* table = (uint32_t*)table_mem;
-  uint32_t* bin_count = (uint32_t*)((char*)table_mem + align_up(((size_t)chunks + 1) * RS_BINS * 4));
-  uint32_t *ka = keys_in, *va = vals_in, *kb = keys_out, *vb = vals_out;
+  char* mem = (char*)table_mem;
+  uint32_t* table = (uint32_t*)mem;
+  uint32_t* bin_count = (uint32_t*)(mem + align_up(((size_t)chunks + 1) * RS_BINS * 4));
+  RsBufs b;
+  b.k_in = keys_in; b.v_in = nullptr;
+  b.k_tmp = (uint32_t*)((char*)bin_count + align_up(RS_BINS * 4));
+  b.v_tmp = (uint32_t*)((char*)b.k_tmp + align_up((size_t)(N > 0 ? N : 1) * 4));
+  b.k_out = keys_out; b.v_out = vals_out;
   for (int pass = 0; pass < 3; pass++) {
-    const int shift = pass * RS_BITS;
-    hipLaunchKernelGGL(rs_count_kernel, dim3(chunks), dim3(256), 0, s, N, shift, ka, table, pass == 0 ? block_tiles : nullptr,
-                       (N + 255) / 256, counters);
-    hipLaunchKernelGGL(bin_scan_kernel, dim3((RS_BINS + 63) / 64), dim3(1024), 0, s, RS_BINS, chunks, table, bin_count);
-    hipLaunchKernelGGL(rs_scatter_kernel, dim3(chunks), dim3(256), 0, s, N, shift, ka, va, table, bin_count, kb, vb);
-    uint32_t* t = ka; ka = kb; kb = t;
-    t = va; va = vb; vb = t;
+    hipLaunchKernelGGL(rs_count_kernel, dim3(chunks), dim3(256), 0, s, N, pass, b, table, block_info, (N + 255) / 256, counters);
+    hipLaunchKernelGGL(rs_scan_kernel, dim3((RS_BINS + 63) / 64), dim3(1024), 0, s, chunks, table, bin_count, counters, pass);
+    hipLaunchKernelGGL(rs_scatter_kernel, dim3(chunks), dim3(RS_SC_WAVES * 64), 0, s, N, pass, b, table, bin_count, counters);
   }
-  return 0;  // after three passes the result sits in (keys_out, vals_out)
+  return 0;
 }
-
 
 }  // namespace riggs

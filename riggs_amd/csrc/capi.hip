@@ -55,9 +55,8 @@ GeomLayout geom_layout(int N) {
   L.rect = o; o = align_up(o + n * 8);
   L.depth_key = o; o = align_up(o + n * 4);
   L.depth_key_sorted = o; o = align_up(o + n * 4);
-  L.order_in = o; o = align_up(o + n * 4);
   L.order = o; o = align_up(o + n * 4);
-  L.block_tiles = o; o = align_up(o + ((n + 255) / 256) * 4);  // per-workgroup sums of tiles_touched (preprocess_fwd)
+  L.block_tiles = o; o = align_up(o + 2 * ((n + 255) / 256) * 4);  // per workgroup of preprocess_fwd: tile sums | depth top bytes
   L.sort_table = o; o += align_up(depth_sort_table_bytes(N));
   L.total = o;
   return L;
@@ -177,7 +176,6 @@ static int fill_pre_args(PreArgs& a, const riggs_raster_cfg* c, const float* mea
   a.xyd = (float4*)(geom + L.xyd); a.conic_o = (float4*)(geom + L.conic_o); a.rgb = (float4*)(geom + L.rgb);
   a.cov3D = (float*)(geom + L.cov3D); a.clamped = (uint8_t*)(geom + L.clamped); a.tiles = (uint32_t*)(geom + L.tiles);
   a.rect = (ushort4*)(geom + L.rect); a.depth_key = (uint32_t*)(geom + L.depth_key);
-  a.order_in = (uint32_t*)(geom + L.order_in);
   a.block_tiles = (uint32_t*)(geom + L.block_tiles);
   return 0;
 }
@@ -206,12 +204,11 @@ int riggs_raster_preprocess(const riggs_raster_cfg* cfg, const float* means3D, c
   // counters[0] = R (and [1..3] = 0) is written by the first kernel of the depth sort
   { ProfScope ps(PROF_PREPROCESS_FWD, s); launch_preprocess_fwd(a, s); }
   if (debug_sync(cfg->debug, s, "preprocess_fwd")) return 1;
-  // depth sort of the Gaussians (stable: equal depths keep ascending index): three counting-sort passes (csrc/binning.hip)
+  // depth sort of the Gaussians (stable: equal depths keep ascending index): two or three counting-sort passes (csrc/binning.hip)
   {
     ProfScope ps(PROF_DEPTH_SORT, s);
-    launch_depth_sort(N, (uint32_t*)(geom + L.depth_key), (uint32_t*)(geom + L.order_in),
-                      (uint32_t*)(geom + L.depth_key_sorted), (uint32_t*)(geom + L.order), geom + L.sort_table,
-                      a.block_tiles, counters, s);
+    launch_depth_sort(N, (const uint32_t*)(geom + L.depth_key), (uint32_t*)(geom + L.depth_key_sorted),
+                      (uint32_t*)(geom + L.order), geom + L.sort_table, a.block_tiles, counters, s);
   }
   if (debug_sync(cfg->debug, s, "depth sort")) return 1;
   return 0;

@@ -61,7 +61,7 @@ struct ProfScope {
 
 // ---- arena layouts ---------------------------------------------------------
 struct GeomLayout {
-  size_t xyd, conic_o, rgb, cov3D, clamped, tiles, rect, depth_key, depth_key_sorted, order_in, order, block_tiles,
+  size_t xyd, conic_o, rgb, cov3D, clamped, tiles, rect, depth_key, depth_key_sorted, order, block_tiles,
       sort_table, total;
 };
 GeomLayout geom_layout(int N);

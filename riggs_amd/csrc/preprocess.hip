@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a) {
     else sh_stage_in(sh_src, sh_per, min(256, a.N - sh_first), s_sh);
     __syncthreads();
   }
-  uint32_t my_tiles = 0u;
+  uint32_t my_tiles = 0u, my_top = 0xFFFFFFFFu;  // (top byte of the depth key of a visible Gaussian, else none)
   do {
   if (i >= a.N) break;
   const float* __restrict__ V = a.view;
@@ -198,7 +198,6 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a) {
   a.radii[i] = 0;
   a.tiles[i] = 0;
   a.depth_key[i] = 0xFFFFFFFFu;  // culled Gaussians sort last
-  a.order_in[i] = (uint32_t)i;
   GlueIn g;
   finish_inputs(a, raw, g, need_sr);
   const float* p = g.p;
@@ -274,15 +273,24 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a) {
   a.tiles[i] = (uint32_t)((x1 - x0) * (y1 - y0));
   a.rect[i] = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
   a.depth_key[i] = __float_as_uint(vz);
+  my_top = __float_as_uint(vz) >> 24;
   my_tiles = (uint32_t)((x1 - x0) * (y1 - y0));
   } while (0);
   // instance count R = sum of tiles_touched: wave reduction -> per-workgroup partial (summed by the first kernel of
   // the depth sort; thousands of same-address atomics would serialise in L2)
-  __shared__ uint32_t s_tiles[4];
-  for (int o = 32; o > 0; o >>= 1) my_tiles += (uint32_t)__shfl_xor((int)my_tiles, o);
-  if ((threadIdx.x & 63) == 0) s_tiles[threadIdx.x >> 6] = my_tiles;
+  // ... and the range of the top bytes of the visible depth keys (the depth sort skips its third pass when they all agree)
+  __shared__ uint32_t s_tiles[4], s_lo[4], s_hi[4];
+  uint32_t lo = (my_top == 0xFFFFFFFFu) ? 0xFFu : my_top, hi = (my_top == 0xFFFFFFFFu) ? 0u : my_top;
+  for (int o = 32; o > 0; o >>= 1) {
+    my_tiles += (uint32_t)__shfl_xor((int)my_tiles, o);
+    lo = min(lo, (uint32_t)__shfl_xor((int)lo, o)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, o));
+  }
+  if ((threadIdx.x & 63) == 0) { s_tiles[threadIdx.x >> 6] = my_tiles; s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
   __syncthreads();
-  if (threadIdx.x == 0) a.block_tiles[blockIdx.x] = s_tiles[0] + s_tiles[1] + s_tiles[2] + s_tiles[3];
+  if (threadIdx.x == 0) {
+    a.block_tiles[blockIdx.x] = s_tiles[0] + s_tiles[1] + s_tiles[2] + s_tiles[3];
+    a.block_tiles[gridDim.x + blockIdx.x] = (min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3])) << 8) | max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
+  }
 }
 
 // ---------------------------------------------------------------------------- backward

@@ -15,8 +15,8 @@ struct PreArgs {
   uint8_t* clamped;
   uint32_t* tiles;
   ushort4* rect;
-  uint32_t *depth_key, *order_in;
-  uint32_t* block_tiles;  // per-workgroup partial sums of tiles_touched
+  uint32_t* depth_key;
+  uint32_t* block_tiles;  // per workgroup: [0, n): sums of tiles_touched; [n, 2n): (min << 8) | max of the visible keys' top bytes
 };
 
 struct PreBwdArgs {
@@ -83,8 +83,8 @@ int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s);
 
 // binning
 size_t depth_sort_table_bytes(int N);
-int launch_depth_sort(int N, uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, void* table_mem,
-                      const uint32_t* block_tiles, uint32_t* counters, hipStream_t s);
+int launch_depth_sort(int N, const uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_out, void* table_mem,
+                      const uint32_t* block_info, uint32_t* counters, hipStream_t s);
 size_t bin_table_bytes(int N, int T);
 int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order, const uint32_t* tiles,
                    const ushort4* rect, void* table_mem, uint32_t* point_list, uint32_t* tile_keys, uint2* ranges,

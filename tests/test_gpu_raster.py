@@ -236,3 +236,16 @@ def test_overflowed_frame_backpropagates_exact_zeros():
     from riggs_amd._lib import RiggsHipError
     with pytest.raises(RiggsHipError, match="overflowed"):
         arena.resolve()
+
+
+def test_depth_sort_takes_two_passes_when_the_depths_share_their_top_byte_and_three_otherwise():
+    """The depth sort skips its third 12-bit pass when every visible depth key has the same top byte (all depths inside
+    [2, 8), [0.5, 2), ...): counters[2] records which path ran.  Both orders are checked bit for bit against the oracle."""
+    for radius, want in ((4.0, 0), (1.6, 1)):   # z in [3, 5] -> two passes; z in (0.2, 2.6] straddles 0.5 and 2 -> three
+        sc, act, cam = U.activated_scene(6000, 24, 19, 144, 176, scale=0.03, radius=radius)
+        out_o, so = U.oracle_forward(act, cam, [0, 0, 0])
+        color, radii, depth, alpha, s = U.hip_forward(act, cam, [0, 0, 0])
+        assert int(s.counters[2]) == want, (radius, int(s.counters[2]))
+        z = so.depths[so.radii > 0]
+        assert (z.view(np.uint32) >> 24).min() != (z.view(np.uint32) >> 24).max() if want else True
+        U.compare_forward_state(so, saved_views(s), out_o, color, depth, alpha, radii)
