@@ -259,3 +259,25 @@ def test_bench_contract_single_and_two_ranks():
     d2 = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert d2["n_gpus"] == 2 and d2["config"]["parallelism"] == "frames x2" and "cpu_baseline" not in d2
     assert abs(d2["value"] - 2 * 4 / (d2["ms_per_step"] * 4 / 1e3)) < 1e-3 * d2["value"]  # aggregate over both ranks
+
+
+def test_dist_knn3_at_initialisation_size():
+    """simple_knn.distCUDA2 at the size the reference calls it with (scene/gaussian_model.py:170: up to ~150k initial points):
+    exact 3-NN means against a k-d tree (scipy), and the launch is timed (exact brute force: O(P^2), tens of ms)."""
+    import time
+    from scipy.spatial import cKDTree
+    from simple_knn._C import distCUDA2
+    g = torch.Generator().manual_seed(7)
+    pts = torch.randn(150_000, 3, generator=g) * torch.tensor([1.0, 0.6, 0.3])
+    d, _ = cKDTree(pts.double().numpy()).query(pts.double().numpy(), k=4)
+    ref = (d[:, 1:] ** 2).mean(1)
+    x = pts.cuda()
+    distCUDA2(x[:1000])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    got = distCUDA2(x)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=2e-4, atol=1e-10)
+    assert dt < 1.0, "distCUDA2(150k) took %.3f s" % dt
+    print("distCUDA2(150k points): %.1f ms" % (dt * 1e3))
