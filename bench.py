@@ -395,8 +395,12 @@ def main():
     gimg = torch.zeros(3, w["H"], w["W"], device=dev)
     # ONE flat gradient bucket: the HIP backward functions write every dL/dparam straight into it (riggs_amd/dist.py),
     # so the data-parallel exchange is a single in-place RCCL all-reduce (AVG) with no pack / unpack / divide pass
-    from riggs_amd.dist import FlatGradAllReduce
-    bucket = FlatGradAllReduce(params_of(gm, sw))
+    # (world > 1: the bucket is ordered for the two-phase overlapped exchange — SH / opacity / scale first, they are final
+    # when the rasterizer's backward has run; xyz / rotation / skeleton after the deformation backward that still reads them)
+    from riggs_amd.dist import FlatGradAllReduce, OverlappedExchange, exchange_order
+    ordered, n_first = exchange_order(gm, sw)
+    bucket = FlatGradAllReduce(ordered if world > 1 else params_of(gm, sw))
+    exchange = OverlappedExchange(bucket, bucket.offsets[n_first]) if world > 1 else None
     step = make_step(cam, gm, sw, gimg, arena, world, bucket)
     pkg = step()
     gimg.copy_(torch.sign(pkg["render"].detach() - target) / (3 * w["H"] * w["W"]))
@@ -411,13 +415,22 @@ def main():
         from riggs_amd.graph import GraphedFrame
         import torch.distributed as dist
         params = params_of(gm, sw)
-        gf = GraphedFrame(gm, sw, cam, torch.zeros(3, device=dev), params).capture()
+        gf = GraphedFrame(gm, sw, cam, torch.zeros(3, device=dev), params, split_backward=world > 1).capture()
         gf.set_inputs(gimg=gimg)
+        if world > 1:
+            assert all(g.data_ptr() == v.data_ptr() for g, v in zip([p.grad for p in bucket.params], bucket.views)), \
+                "the captured gradient buffers must be the bucket's slices"
 
         def step():  # noqa: F811
-            out = gf.run()
-            if world > 1:
-                bucket(sources=gf.grads)  # the graph's gradient buffers ARE the bucket's slices: just the collective
+            if world == 1:
+                return gf.run()
+            # frame-parallel step: the graph's gradient buffers ARE the bucket's slices, so the exchange is two in-place
+            # collectives — the first (86 % of the bytes) on the links while the deformation backward still computes
+            out = gf.run_a()
+            exchange.launch(1)
+            gf.run_b()
+            exchange.launch(2)
+            exchange.wait()
             return out
         step()
         torch.cuda.synchronize()
@@ -564,7 +577,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "300k Gaussians / 24-joint skeleton / 800x800, LBS-only, SH degree 3, anisotropic, "
                                    "one frame per GPU per step", "num_gaussians": w["N"], "num_joints": w["J"],
-                       "image": [w["H"], w["W"]], "tile_instances_R": R, "parallelism": "frames x%d" % world,
+                       "image": [w["H"], w["W"]], "tile_instances_R": R, "parallelism": "frames x%d" % world, "exchange": None if world == 1 else "two-phase in-place all-reduce (AVG) of one flat bucket, phase 1 overlapped with the deformation backward",
                        "launch": "eager" if args.no_graph else "hipGraph replay"},
             # The dominant kernel is a compositing kernel: SURVEY.md §8-d bounds those by vector issue, not by HBM.  `achieved /
             # peak / frac` stay the HBM numbers from ALGORITHMIC bytes (the contract's definition); `bound` says what actually

@@ -149,3 +149,222 @@ class FlatGradAllReduce:
 def frame_for_rank(frames: list, step: int, rank: int, world: int):
     """Frame k of a step's batch of `world` frames goes to rank k (one frame per GPU per step)."""
     return frames[(step * world + rank) % len(frames)]
+
+
+# ---- overlapped exchange ------------------------------------------------------------------------------------------
+class OverlappedExchange:
+    """The data-parallel exchange of a 0.4 ms step, as two phases of the flat bucket issued on a communication stream:
+
+    * phase 1 — ``bucket.flat[:split]``: the gradients that are FINAL when the rasterizer's per-Gaussian backward has run
+      (SH, opacity, scale: 86 % of the bytes).  Its all-reduce is issued right there and runs on the xGMI links while the
+      compute stream still does the deformation backward (skinning, FK, PoseMLP: ~60 us of the step);
+    * phase 2 — the rest: ``_xyz`` / ``_rotation`` gradients — which the deformation backward still READS as dL/dd_xyz and
+      dL/dd_rotation (they alias the parameter gradients), so they must not be averaged in place under it — and the
+      skeleton's own parameters, issued after the deformation backward.
+
+    ``chunk_bytes`` splits a phase into several collectives (RCCL pipelines inside one call; smaller calls let the first
+    bytes leave earlier).  The reference has no distributed path (utils/general_utils.py:207 pins cuda:0): this is new."""
+
+    def __init__(self, bucket: FlatGradAllReduce, split: int, chunk_bytes: int = 0):
+        self.bucket, self.split = bucket, int(split)
+        self.chunk = int(chunk_bytes) // 4
+        self.cuda = bucket.flat.is_cuda
+        self.comm = torch.cuda.Stream(device=bucket.flat.device) if self.cuda else None
+        self.pending = []
+
+    def _reduce(self, t):
+        if not (dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        pieces = [t] if self.chunk <= 0 else [t[o:o + self.chunk] for o in range(0, t.numel(), self.chunk)]
+        for piece in pieces:
+            if self.bucket.average and self.cuda and dist.get_backend() == "nccl":
+                self.pending.append((dist.all_reduce(piece, op=dist.ReduceOp.AVG, async_op=True), None))
+            else:
+                self.pending.append((dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True), piece if self.bucket.average else None))
+
+    def launch(self, phase: int):
+        """Issue phase 1 (``flat[:split]``) or phase 2 (``flat[split:]``) behind everything the compute stream has queued."""
+        t = self.bucket.flat[:self.split] if phase == 1 else self.bucket.flat[self.split:]
+        if self.cuda:
+            self.comm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm):
+                self._reduce(t)
+        else:
+            self._reduce(t)
+
+    def wait(self):
+        """Make the compute stream (and, on CPU, the caller) wait for every collective issued so far."""
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        ctx = torch.cuda.stream(self.comm) if self.cuda else None
+        if ctx is not None:
+            ctx.__enter__()
+        try:
+            for work, needs_div in self.pending:
+                work.wait()
+                if needs_div is not None:
+                    needs_div.div_(world)
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
+        self.pending = []
+        if self.cuda:
+            torch.cuda.current_stream().wait_stream(self.comm)
+
+
+def exchange_order(gm, sw):
+    """Parameters in the order the overlapped exchange wants them in ONE flat bucket, and the number of leading tensors whose
+    gradients are final after the rasterizer's backward (phase 1): SH, opacity and scale first; then ``_xyz`` / ``_rotation``
+    (read by the deformation backward) and the skeleton's parameters."""
+    first = [gm._features_dc, gm._features_rest, gm._opacity, gm._scaling]
+    rest = [gm._xyz, gm._rotation, sw._node_radius] + list(sw.pose_net.parameters())
+    return first + rest, len(first)
+
+
+# ---- sharded optimizer step (ZeRO-1 over the frame-parallel replicas) -----------------------------------------------
+class ShardedAdam:
+    """reduce-scatter -> Adam on the rank's 1/W slice of the flat parameter space -> all-gather: the same
+    bytes on the links as the all-reduce (its two halves), the optimizer's HBM traffic (28 B per element: the largest consumer
+    after the frame itself) divided by the world size, and the Adam moments held once per node instead of once per GPU.
+
+    Parameters become views of ONE flat buffer (so the all-gather lands in place) and their gradients live in the matching
+    ``FlatGradAllReduce`` bucket.  ``groups`` = [{"params": [...], "lr": float}, ...] as for torch.optim.Adam (plain Adam,
+    eps inside the square root's sum as torch: the update of riggs_adam_step / torch.optim.Adam).  After densification /
+    pruning (new parameter tensors) build a new instance: the moments are per flat element."""
+
+    def __init__(self, groups, betas=(0.9, 0.999), eps=1e-15, average=True):
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.b1, self.b2, self.eps = float(betas[0]), float(betas[1]), float(eps)
+        self.params = [p for g in groups for p in g["params"]]
+        self.lrs = [g["lr"] for g in groups for _ in g["params"]]
+        self.bucket = FlatGradAllReduce(self.params, average=average, register=False)
+        n = self.bucket.numel
+        self.shard = (n + 4 * self.world - 1) // (4 * self.world) * 4     # 16-byte aligned, equal on every rank
+        dev = self.params[0].device
+        self.flat_p = torch.zeros(self.shard * self.world, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(self.shard * self.world, dtype=torch.float32, device=dev)
+        self.flat_g[:n] = self.bucket.flat
+        # the bucket's gradient buffer and the parameters move into the padded flat buffers (views keep their offsets)
+        self.bucket.flat = self.flat_g[:n]
+        self.bucket.views = [self.bucket.flat[o:o + p.numel()].view_as(p) for p, o in zip(self.params, self.bucket.offsets)]
+        with torch.no_grad():
+            for p, o in zip(self.params, self.bucket.offsets):
+                self.flat_p[o:o + p.numel()] = p.detach().reshape(-1)
+                p.data = self.flat_p[o:o + p.numel()].view_as(p)
+        if dev.type == "cuda":
+            self.bucket.register()  # (keyed by the parameters' NEW data pointers: the HIP backwards write into the bucket)
+        lo = self.rank * self.shard
+        self.lo, self.hi = lo, lo + self.shard
+        self.m = torch.zeros(self.shard, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(self.shard, dtype=torch.float32, device=dev)
+        self.steps = 0
+        # (tensor, slice of it that falls into this rank's shard): the segments one optimizer launch covers
+        self.segments = []
+        for p, o, lr_i in zip(self.params, self.bucket.offsets, range(len(self.params))):
+            a, b = max(o, self.lo), min(o + p.numel(), self.hi)
+            if a < b:
+                self.segments.append((a, b, lr_i))
+
+    def step(self):
+        """Gradients (already in the bucket) -> averaged shard -> Adam on the shard -> every replica's parameters."""
+        g_shard = self.flat_g[self.lo:self.hi]
+        if self.world > 1:
+            if self.flat_g.is_cuda and dist.get_backend() == "nccl":
+                out = torch.empty_like(g_shard)
+                dist.reduce_scatter_tensor(out, self.flat_g, op=dist.ReduceOp.AVG if self.bucket.average else dist.ReduceOp.SUM)
+                g_shard = out
+            else:  # gloo has no reduce-scatter: all-reduce and look at the own slice (CPU tests)
+                dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
+                if self.bucket.average:
+                    self.flat_g.div_(self.world)
+                g_shard = self.flat_g[self.lo:self.hi]
+        self.steps += 1
+        p_shard = self.flat_p[self.lo:self.hi]
+        if p_shard.is_cuda:
+            self._hip_step(p_shard, g_shard)
+        else:
+            bc1, bc2 = 1.0 - self.b1 ** self.steps, 1.0 - self.b2 ** self.steps
+            with torch.no_grad():
+                self.m.mul_(self.b1).add_(g_shard, alpha=1.0 - self.b1)
+                self.v.mul_(self.b2).addcmul_(g_shard, g_shard, value=1.0 - self.b2)
+                for a, b, i in self.segments:
+                    sl = slice(a - self.lo, b - self.lo)
+                    denom = (self.v[sl].sqrt() / (bc2 ** 0.5)).add_(self.eps)
+                    p_shard[sl].addcdiv_(self.m[sl], denom, value=-float(self.lrs[i]) / bc1)
+        if self.world > 1:
+            if self.flat_p.is_cuda and dist.get_backend() == "nccl":
+                dist.all_gather_into_tensor(self.flat_p, p_shard)
+            else:
+                self._gather_gloo(p_shard)
+        for p in self.params:
+            torch.autograd.graph.increment_version(p)
+
+    def _gather_gloo(self, p_shard):
+        parts = [torch.empty_like(p_shard) for _ in range(self.world)]
+        dist.all_gather(parts, p_shard.clone())
+        self.flat_p.copy_(torch.cat(parts))
+
+    def _hip_step(self, p_shard, g_shard):
+        import ctypes as C
+        from . import _lib as L
+        lib = L.lib()
+        segs = self.segments
+        for c0 in range(0, len(segs), 32):
+            chunk = segs[c0:c0 + 32]
+            n = len(chunk)
+            off = lambda t, a: t.data_ptr() + 4 * (a - self.lo)  # noqa: E731
+            P = (C.c_void_p * n)(*[off(p_shard, a) for a, _, _ in chunk])
+            G = (C.c_void_p * n)(*[off(g_shard, a) for a, _, _ in chunk])
+            M = (C.c_void_p * n)(*[off(self.m, a) for a, _, _ in chunk])
+            V = (C.c_void_p * n)(*[off(self.v, a) for a, _, _ in chunk])
+            numel = (C.c_int64 * n)(*[b - a for a, b, _ in chunk])
+            lr = (C.c_double * n)(*[float(self.lrs[i]) for _, _, i in chunk])
+            steps = (C.c_int64 * n)(*[self.steps] * n)
+            L.check(lib.riggs_adam_step(n, P, G, M, V, numel, lr, steps, self.b1, self.b2, self.eps, L.stream_ptr()),
+                    "riggs_adam_step")
+
+
+# ---- compacted exchange of the rows that have a gradient --------------------------------------------------------
+def sparse_rows_all_reduce(grads, capacity: int, average: bool = True):
+    """All-reduce of per-Gaussian gradient tensors ``grads`` = [(N, ...), ...] that exchanges only the Gaussians with a non-zero
+    gradient on some rank: in the bench scene 93 % of the rows are zero on every rank (SURVEY.md §8-d scene: deep, mostly
+    occluded), and different views touch different Gaussians.  Every rank compacts its non-zero rows (fixed ``capacity``: no
+    host synchronisation), all-gathers (index, row) pairs and adds them up locally: (W - 1) x capacity x (row bytes + 4) received
+    per rank instead of 2 (W - 1) / W x N x row bytes for the ring all-reduce — less traffic while capacity < ~2 N / W.
+    Returns the number of rows the fullest rank needed (a device scalar: when it exceeds ``capacity`` rows were dropped and the
+    caller must redo the exchange densely; checked like the rasterizer's arena overflow, after the fact)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    N = grads[0].shape[0]
+    flat = [g.reshape(N, -1) for g in grads]
+    nz = torch.zeros(N, dtype=torch.bool, device=flat[0].device)
+    for f in flat:
+        nz |= (f != 0).any(1)
+    need = nz.sum()
+    idx = torch.nonzero_static(nz, size=capacity, fill_value=N).reshape(-1)          # (capacity,), N = "no row"
+    safe = idx.clamp(max=N - 1)
+    valid = (idx < N).to(flat[0].dtype)[:, None]
+    payload = torch.cat([f.index_select(0, safe) for f in flat], dim=1) * valid       # (capacity, sum of widths)
+    if world > 1:
+        all_idx = torch.empty(world * capacity, dtype=idx.dtype, device=idx.device)
+        all_pay = torch.empty(world * capacity, payload.shape[1], dtype=payload.dtype, device=payload.device)
+        if idx.is_cuda and dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(all_idx, idx)
+            dist.all_gather_into_tensor(all_pay, payload)
+        else:
+            li, lp = [torch.empty_like(idx) for _ in range(world)], [torch.empty_like(payload) for _ in range(world)]
+            dist.all_gather(li, idx)
+            dist.all_gather(lp, payload)
+            all_idx, all_pay = torch.cat(li), torch.cat(lp)
+        dist.all_reduce(need, op=dist.ReduceOp.MAX)
+    else:
+        all_idx, all_pay = idx, payload
+    acc = torch.zeros(N + 1, all_pay.shape[1], dtype=all_pay.dtype, device=all_pay.device)
+    acc.index_add_(0, all_idx, all_pay)
+    if average:
+        acc /= world
+    o = 0
+    for g, f in zip(grads, flat):
+        w = f.shape[1]
+        g.copy_(acc[:N, o:o + w].reshape(g.shape))
+        o += w
+    return need

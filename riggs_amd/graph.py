@@ -25,7 +25,12 @@ class _Pipe:
 
 
 class GraphedFrame:
-    def __init__(self, gm, sw, cam: Camera, bg: torch.Tensor, params, headroom: float = 1.5, fused: bool = True):
+    def __init__(self, gm, sw, cam: Camera, bg: torch.Tensor, params, headroom: float = 1.5, fused: bool = True,
+                 split_backward: bool = False):
+        """``split_backward``: capture the frame as TWO graphs — (a) forward + rasterizer backward, (b) deformation backward
+        (skinning, FK, PoseMLP) — so that a data-parallel caller can put the all-reduce of the gradients that are final after
+        (a) on the links while (b) still runs (riggs_amd.dist.OverlappedExchange): ``run_a()``, ``run_b()``."""
+        self.split = bool(split_backward)
         self.gm, self.sw, self.params = gm, sw, list(params)
         dev = bg.device
         self.cam = Camera(cam.image_height, cam.image_width, cam.FoVx, cam.FoVy, cam.world_view_transform.clone(),
@@ -52,6 +57,26 @@ class GraphedFrame:
         out["viewspace_points_grad"] = pkg["viewspace_points"].grad
         return RenderPkg(out, cache=False)
 
+    def _frame_a(self):
+        for p in self.params:
+            p.grad = None
+        t_in = self.sw.expand_time(self.cam.fid)
+        dv = self.sw(self.gm.get_xyz.detach(), t_in, motion_mask=self.gm.motion_mask)
+        # the residuals enter the render as leaves: the backward of (a) stops at them, (b) continues from their gradients
+        self._dx = dv["d_xyz"].detach().requires_grad_(True)
+        self._dr = dv["d_rotation"].detach().requires_grad_(True)
+        pkg = render(self.cam, self.gm, _Pipe, self.bg, self._dx, self._dr, dv["d_scaling"], fused=self.fused, arena=self.arena)
+        pkg["render"].backward(self.gimg)
+        self._dv = dv
+        out = {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in dict.items(pkg)
+               if k not in ("viewspace_points", "visibility_filter")}
+        out["viewspace_points_grad"] = pkg["viewspace_points"].grad
+        return RenderPkg(out, cache=False)
+
+    def _frame_b(self):
+        torch.autograd.backward([self._dv["d_xyz"], self._dv["d_rotation"]], [self._dx.grad, self._dr.grad])
+        self._dv = None
+
     def set_inputs(self, cam: Camera = None, gimg: torch.Tensor = None):
         if cam is not None:
             if (cam.image_height, cam.image_width, cam.FoVx, cam.FoVy) != (
@@ -71,7 +96,11 @@ class GraphedFrame:
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(warmup):
-                self.out = self._frame()
+                if self.split:
+                    self.out = self._frame_a()
+                    self._frame_b()
+                else:
+                    self.out = self._frame()
                 torch.cuda.current_stream().synchronize()
                 self.arena.resolve()
                 self.out = None
@@ -81,10 +110,30 @@ class GraphedFrame:
             p.grad = None
         gc.collect()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=s):  # same stream as the warm-up: AccumulateGrad nodes match
-            self.out = self._frame()
+        if self.split:
+            self.graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=s):
+                self.out = self._frame_a()
+            with torch.cuda.graph(self.graph_b, stream=s, pool=self.graph.pool()):
+                self._frame_b()
+        else:
+            with torch.cuda.graph(self.graph, stream=s):  # same stream as the warm-up: AccumulateGrad nodes match
+                self.out = self._frame()
         self.grads = [p.grad for p in self.params]  # static gradient buffers refilled by every replay
         return self
+
+    def run_a(self, cam: Camera = None, gimg: torch.Tensor = None):
+        """split_backward: forward + rasterizer backward (every Gaussian gradient is final afterwards; ``_xyz`` / ``_rotation``
+        gradients are still read by ``run_b``)."""
+        if self.graph is None:
+            self.capture()
+        self.set_inputs(cam, gimg)
+        self.graph.replay()
+        return self.out
+
+    def run_b(self):
+        """split_backward: the deformation backward (skeleton gradients)."""
+        self.graph_b.replay()
 
     def run(self, cam: Camera = None, gimg: torch.Tensor = None):
         """Replay one frame.  Outputs (``self.out`` dict, ``p.grad`` of every parameter) are static tensors that
@@ -93,6 +142,8 @@ class GraphedFrame:
             self.capture()
         self.set_inputs(cam, gimg)
         self.graph.replay()
+        if self.split:
+            self.graph_b.replay()
         return self.out
 
     def check(self):

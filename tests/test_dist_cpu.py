@@ -118,3 +118,125 @@ def test_bucket_slices_are_not_handed_out_twice_and_die_with_their_parameter():
         assert D._entry(probe) is None and key not in D._SLICES
     finally:
         bucket.unregister()
+
+
+# ---- the overlapped / sharded / compacted exchange paths (world size 2 over gloo) ------------------------------------
+def _spawn(target, world=2, timeout=240):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_entry_point, args=(target, r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=timeout) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return got
+
+
+def _entry_point(target, rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    q.put((rank, target(rank, world)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _toy_params(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(37, 1, 3), (37, 15, 3), (37, 1), (37, 3), (37, 3), (37, 4), (6,), (9, 17), (9,)]
+    return [torch.nn.Parameter(torch.randn(*s, generator=g)) for s in shapes]
+
+
+def _rank_grads(params, rank):
+    g = torch.Generator().manual_seed(100 + rank)
+    return [torch.randn(p.shape, generator=g) for p in params]
+
+
+def _w_overlapped(rank, world):
+    from riggs_amd.dist import OverlappedExchange
+    params = _toy_params()
+    bucket = FlatGradAllReduce(params, register=False)
+    for v, gr in zip(bucket.views, _rank_grads(params, rank)):
+        v.copy_(gr)
+    split = bucket.offsets[4]  # the first four tensors form phase 1
+    ex = OverlappedExchange(bucket, split, chunk_bytes=256)  # several collectives per phase
+    ex.launch(1)
+    assert len(ex.pending) > 1
+    ex.launch(2)
+    ex.wait()
+    return [v.clone().numpy() for v in bucket.views]
+
+
+def test_overlapped_two_phase_exchange_equals_the_mean():
+    got = _spawn(_w_overlapped)
+    params = _toy_params()
+    mean = [sum(gs) / 2 for gs in zip(_rank_grads(params, 0), _rank_grads(params, 1))]
+    for r in range(2):
+        for a, b in zip(got[r], mean):
+            np.testing.assert_allclose(a, b.numpy(), rtol=1e-6, atol=1e-7)
+
+
+def _w_sharded(rank, world):
+    from riggs_amd.dist import ShardedAdam
+    params = _toy_params()
+    groups = [{"params": params[:2], "lr": 2.5e-3}, {"params": params[2:6], "lr": 1e-2}, {"params": params[6:], "lr": 5e-4}]
+    opt = ShardedAdam(groups, eps=1e-15)
+    assert opt.shard % 4 == 0 and opt.shard * world >= opt.bucket.numel
+    for step in range(3):
+        for v, gr in zip(opt.bucket.views, _rank_grads(params, rank + 10 * step)):
+            v.copy_(gr)
+        opt.step()
+    assert all(p.data_ptr() >= opt.flat_p.data_ptr() for p in params)  # parameters are views of the gathered flat buffer
+    return [p.detach().clone().numpy() for p in params], (opt.m.numel(), opt.bucket.numel)
+
+
+def test_sharded_adam_equals_adam_on_the_averaged_gradients():
+    got = _spawn(_w_sharded)
+    params = _toy_params()
+    ref = torch.optim.Adam([{"params": params[:2], "lr": 2.5e-3}, {"params": params[2:6], "lr": 1e-2},
+                            {"params": params[6:], "lr": 5e-4}], lr=0.0, eps=1e-15)
+    for step in range(3):
+        for p, g0, g1 in zip(params, _rank_grads(params, 10 * step), _rank_grads(params, 1 + 10 * step)):
+            p.grad = (g0 + g1) / 2
+        ref.step()
+    for r in range(2):
+        vals, (m_numel, n) = got[r]
+        assert m_numel < 0.51 * n + 8  # each rank holds half of the moments
+        for a, p in zip(vals, params):
+            np.testing.assert_allclose(a, p.detach().numpy(), rtol=2e-5, atol=2e-7)
+    for a, b in zip(got[0][0], got[1][0]):
+        assert np.array_equal(a, b)  # replicas stay bit-identical
+
+
+def _w_sparse(rank, world):
+    from riggs_amd.dist import sparse_rows_all_reduce
+    N = 200
+    g = torch.Generator().manual_seed(7 + rank)
+    rows = torch.randperm(N, generator=g)[:25]          # different Gaussians are touched on different ranks
+    grads = [torch.zeros(N, 3), torch.zeros(N, 15, 3), torch.zeros(N, 1)]
+    for t in grads:
+        t[rows] = torch.randn(25, *t.shape[1:], generator=g)
+    dense = [t.clone() for t in grads]
+    need = sparse_rows_all_reduce(grads, capacity=40)
+    for t in dense:
+        dist.all_reduce(t)
+        t /= world
+    small = [t.clone() for t in dense]  # (values irrelevant) a capacity that is too small is reported, not silently wrong
+    over = sparse_rows_all_reduce([torch.ones(N, 2) * (rank + 1)], capacity=16)
+    return [a.numpy() for a in grads], [b.numpy() for b in dense], int(need), int(over), len(small)
+
+
+def test_compacted_row_exchange_equals_the_dense_all_reduce_and_reports_overflow():
+    got = _spawn(_w_sparse)
+    for r in range(2):
+        sparse, dense, need, over, _ = got[r]
+        assert need == 25 and over == 200   # rows the fullest rank needed; 200 > capacity 16: the caller must go dense
+        for a, b in zip(sparse, dense):
+            np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-7)
