@@ -55,6 +55,11 @@ typedef struct riggs_raster_cfg {
    * in-kernel, and the backward returns gradients w.r.t. the raw tensors. */
   int32_t glue;
   int32_t isotropic;       /* glue only: _scaling is (N,1) repeated (gaussian_model.py:105-108) */
+  /* Ordered-reduction mode of the compositing backward ("deterministic-reduction mode for grads"): instead of
+   * float atomics into the per-Gaussian accumulators, every (tile instance) writes its partial gradient row and a second
+   * kernel sums each Gaussian's rows in ascending tile order: gradients are bitwise reproducible run to run.  Needs the
+   * larger workspace of riggs_raster_backward_workspace_bytes_ordered; slower (tests / debugging). */
+  int32_t deterministic;
 } riggs_raster_cfg;
 
 /* Opaque arenas (upstream: geomBuffer / binningBuffer / imgBuffer byte tensors). */
@@ -141,6 +146,9 @@ int riggs_raster_backward(const riggs_raster_cfg* cfg, const float* means3D, con
                           float* dL_dsh_rest /* with shs_rest: (N,M-1,3), dL_dsh is then (N,1,3) */,
                           riggs_stream stream);
 size_t riggs_raster_backward_workspace_bytes(int32_t num_points);
+/* cfg->deterministic: [accumulators | one row of 10 floats per tile instance | the instances of every Gaussian in tile order |
+ * their offsets]; need not be zeroed */
+size_t riggs_raster_backward_workspace_bytes_ordered(int32_t num_points, int64_t instance_capacity);
 
 /* =====================================================================
  * Skeleton deformation.  Replaces the torch-op graph of

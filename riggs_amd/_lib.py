@@ -24,7 +24,7 @@ class RasterCfg(C.Structure):
         ("image_height", C.c_int32), ("image_width", C.c_int32),
         ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
         ("bg", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
-        ("debug", C.c_int32), ("glue", C.c_int32), ("isotropic", C.c_int32),
+        ("debug", C.c_int32), ("glue", C.c_int32), ("isotropic", C.c_int32), ("deterministic", C.c_int32),
     ]
 
 
@@ -38,6 +38,7 @@ _SIGS = {
     "riggs_raster_image_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "riggs_raster_binning_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "riggs_raster_backward_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "riggs_raster_backward_workspace_bytes_ordered": (C.c_size_t, [C.c_int32, C.c_int64]),
     "riggs_raster_geom_layout": (C.c_int, [C.c_int32, C.POINTER(C.c_size_t)]),
     "riggs_raster_image_layout": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
     "riggs_raster_binning_layout": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),

@@ -132,6 +132,10 @@ size_t riggs_raster_geom_bytes(int32_t N) { return geom_layout(N).total; }
 size_t riggs_raster_image_bytes(int32_t H, int32_t W) { return image_layout(H, W).total; }
 size_t riggs_raster_binning_bytes(int64_t cap, int32_t N, int32_t H, int32_t W) { return bin_layout(cap, N, H, W).total; }
 size_t riggs_raster_backward_workspace_bytes(int32_t N) { return align_up((size_t)(N > 0 ? N : 1) * RIGGS_GACC * 4); }
+size_t riggs_raster_backward_workspace_bytes_ordered(int32_t N, int64_t cap) {
+  const size_t c = (size_t)(cap > 0 ? cap : 1), n = (size_t)(N > 0 ? N : 1);
+  return riggs_raster_backward_workspace_bytes(N) + align_up(c * 40) + align_up(c * 4) + align_up((n + 1) * 4);
+}
 
 int riggs_raster_geom_layout(int32_t N, size_t* o) {
   GeomLayout L = geom_layout(N);
@@ -313,8 +317,21 @@ int riggs_raster_backward(const riggs_raster_cfg* cfg, const float* means3D, con
   r.n_tiles = ((W + RIGGS_TILE - 1) / RIGGS_TILE) * ((H + RIGGS_TILE - 1) / RIGGS_TILE);
   r.n_slots = (int64_t)B.n_slots;
   r.work = (const uint4*)(bin + B.work); r.work_ctr = (const uint32_t*)(img + I.fwd_ctr) + 64;
-  // (cap == 0: nothing was composited and the accumulators — zero on entry by contract — stay zero)
-  if (cap > 0) { ProfScope ps(PROF_RENDER_BWD, s); launch_render_bwd(r, s); }
+  r.det_rows = nullptr;
+  if (cfg->deterministic && cap > 0) {
+    // ordered-reduction mode: rows instead of atomics, then a fixed-order sum per Gaussian that overwrites the accumulators
+    char* ws = (char*)workspace + riggs_raster_backward_workspace_bytes(N);
+    r.det_rows = (float*)ws;
+    uint32_t* inv = (uint32_t*)(ws + align_up((size_t)cap * 40));
+    uint32_t* off = (uint32_t*)((char*)inv + align_up((size_t)cap * 4));
+    RIGGS_HIP_CHECK(hipMemsetAsync(r.det_rows, 0, (size_t)cap * 40, s));
+    { ProfScope ps(PROF_RENDER_BWD, s); launch_render_bwd(r, s); }
+    const int gx = (W + RIGGS_TILE - 1) / RIGGS_TILE;
+    launch_ordered_gather(N, r.n_tiles, gx, cap, r.ranges, r.point_list, (const uint32_t*)(geom + G.tiles),
+                          (const ushort4*)(geom + G.rect), r.det_rows, inv, off, r.gacc, dL_ddepth != nullptr, s);
+  } else if (cap > 0) {  // (cap == 0: nothing was composited and the accumulators — zero on entry by contract — stay zero)
+    ProfScope ps(PROF_RENDER_BWD, s); launch_render_bwd(r, s);
+  }
   if (debug_sync(cfg->debug, s, "render_bwd")) return 1;
   b.gacc = (float*)workspace;
   b.dL_dmeans3D = dL_dmeans3D; b.dL_dmeans2D = dL_dmeans2D; b.dL_dsh = dL_dsh; b.dL_dcolors = dL_dcolors_precomp;

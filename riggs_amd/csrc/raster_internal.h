@@ -69,6 +69,7 @@ struct RenderBwdArgs {
   const uint32_t* n_contrib;
   const float *dL_dcolor, *dL_ddepth, *dL_dalpha;
   float* gacc;  // (N, RIGGS_GACC) accumulators: all zero on entry (see PreBwdArgs::gacc)
+  float* det_rows;  // ordered-reduction mode: one row of 10 floats per tile instance instead of the atomics (else NULL)
   int n_points;
   const float4* final_acc;
   const uint32_t* tile_max;
@@ -80,6 +81,10 @@ struct RenderBwdArgs {
   const uint32_t* work_ctr;  // number of quarter-items
 };
 int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s);
+// ordered-reduction mode: sum every Gaussian's instance rows in ascending tile order into the accumulators
+int launch_ordered_gather(int N, int n_tiles, int grid_x, int64_t cap, const uint2* ranges, const uint32_t* point_list,
+                          const uint32_t* tiles, const ushort4* rect, const float* det_rows, uint32_t* inv, uint32_t* off,
+                          float* gacc, int want_depth, hipStream_t s);
 
 // binning
 size_t depth_sort_table_bytes(int N);

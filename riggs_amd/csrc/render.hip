@@ -550,7 +550,14 @@ __global__ __launch_bounds__(64 * NW) void render_bwd_kernel(RenderBwdArgs a) {
     // ---- only now the atomics, and only for the instances that reach a pixel of this tile: the lists are built
     // from 3-sigma rectangles, most of a tile's instances never get to alpha >= 1/255 inside it, and adding their
     // exact zeros cost a quarter of the kernel (the memory-side atomic units were its one saturated resource)
-    if (wave == 0 && active && touched) {
+    if (a.det_rows) {
+      // ordered-reduction mode: the row of this tile instance, summed per Gaussian by launch_ordered_gather
+      if (wave == 0 && active && touched) {
+        float* r = a.det_rows + ((size_t)wk.z + (size_t)pos) * 10;
+        r[0] = a_mx * ddelx_dx; r[1] = a_my * ddely_dy; r[2] = -0.5f * a_ca; r[3] = -a_cb; r[4] = -0.5f * a_cc;
+        r[5] = a_op; r[6] = a_r; r[7] = a_g; r[8] = a_b; r[9] = a_d;
+      }
+    } else if (wave == 0 && active && touched) {
       float* g = a.gacc + (size_t)id * RIGGS_GACC;
       atomicAdd(g + 0, a_mx * ddelx_dx); atomicAdd(g + 1, a_my * ddely_dy);
       atomicAdd(g + 2, -0.5f * a_ca); atomicAdd(g + 3, -a_cb); atomicAdd(g + 4, -0.5f * a_cc);
@@ -567,6 +574,77 @@ __global__ __launch_bounds__(64 * NW) void render_bwd_kernel(RenderBwdArgs a) {
       tr[3] = ((unsigned long long)blockIdx.x << 32) | (unsigned long long)((wk.x << 16) | (wk.y & 0xFFFFu));
     }
   }
+}
+
+// ---- ordered-reduction mode (cfg.deterministic) ----------------------------------------------------------------------
+// exclusive scan of tiles_touched (one workgroup; a test / debugging mode: not tuned)
+__global__ __launch_bounds__(1024) void ordered_offsets_kernel(int N, const uint32_t* __restrict__ tiles, uint32_t* __restrict__ off) {
+  __shared__ uint32_t s_w[16];
+  __shared__ uint32_t s_carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_carry = 0u;
+  __syncthreads();
+  for (int base = 0; base < N; base += 1024) {
+    const int i = base + tid;
+    const uint32_t c = (i < N) ? tiles[i] : 0u;
+    uint32_t v = c;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t u = (uint32_t)__shfl_up((int)v, o);
+      if (lane >= o) v += u;
+    }
+    if (lane == 63) s_w[wave] = v;
+    __syncthreads();
+    uint32_t run = s_carry;
+    for (int w = 0; w < wave; w++) run += s_w[w];
+    if (i < N) off[i] = run + v - c;
+    __syncthreads();
+    if (tid == 1023) s_carry = run + v;
+    __syncthreads();
+  }
+  if (tid == 0) off[N] = s_carry;
+}
+// inv[off[g] + k] = list position of the k-th tile (row-major inside g's rectangle = ascending tile id) of Gaussian g
+__global__ __launch_bounds__(256) void ordered_fill_kernel(int grid_x, int64_t cap, const uint2* __restrict__ ranges,
+                                                          const uint32_t* __restrict__ point_list,
+                                                          const ushort4* __restrict__ rect, const uint32_t* __restrict__ off,
+                                                          uint32_t* __restrict__ inv) {
+  const int t = blockIdx.x, tx = t % grid_x, ty = t / grid_x;
+  const uint2 rg = ranges[t];
+  for (uint32_t p = rg.x + threadIdx.x; p < rg.y && (int64_t)p < cap; p += 256) {
+    const uint32_t g = point_list[p];
+    const ushort4 rc = rect[g];
+    const int k = (ty - (int)rc.y) * ((int)rc.z - (int)rc.x) + (tx - (int)rc.x);
+    inv[off[g] + (uint32_t)k] = p;
+  }
+}
+__global__ __launch_bounds__(256) void ordered_gather_kernel(int N, int64_t cap, const uint32_t* __restrict__ tiles,
+                                                            const uint32_t* __restrict__ off, const uint32_t* __restrict__ inv,
+                                                            const float* __restrict__ rows, float* __restrict__ gacc,
+                                                            int want_depth) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= N) return;
+  float acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const uint32_t n = tiles[g], o = off[g];
+  for (uint32_t k = 0; k < n; k++) {
+    if ((int64_t)(o + k) >= cap) break;  // (an overflowed arena: the frame is flagged invalid anyway)
+    const float* r = rows + (size_t)inv[o + k] * 10;
+#pragma unroll
+    for (int c = 0; c < 10; c++) acc[c] += r[c];
+  }
+  float* out = gacc + (size_t)g * RIGGS_GACC;
+#pragma unroll
+  for (int c = 0; c < 9; c++) out[c] = acc[c];
+  out[9] = want_depth ? acc[9] : 0.f;
+  out[10] = 0.f; out[11] = 0.f;
+}
+int launch_ordered_gather(int N, int n_tiles, int grid_x, int64_t cap, const uint2* ranges, const uint32_t* point_list,
+                          const uint32_t* tiles, const ushort4* rect, const float* det_rows, uint32_t* inv, uint32_t* off,
+                          float* gacc, int want_depth, hipStream_t s) {
+  hipLaunchKernelGGL(ordered_offsets_kernel, dim3(1), dim3(1024), 0, s, N, tiles, off);
+  hipLaunchKernelGGL(ordered_fill_kernel, dim3(n_tiles), dim3(256), 0, s, grid_x, cap, ranges, point_list, rect, off, inv);
+  hipLaunchKernelGGL(ordered_gather_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, cap, tiles, off, inv, det_rows, gacc,
+                     want_depth);
+  return 0;
 }
 
 int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s) {

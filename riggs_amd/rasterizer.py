@@ -105,7 +105,19 @@ def _cfg(settings: GaussianRasterizationSettings, N: int, M: int, glue: bool, is
     c.debug = 1 if settings.debug else 0
     c.glue = 1 if glue else 0
     c.isotropic = 1 if isotropic else 0
+    c.deterministic = 1 if ORDERED_BACKWARD else 0
     return c
+
+
+ORDERED_BACKWARD = False
+
+
+def set_ordered_backward(on: bool = True):
+    """Ordered-reduction mode of the compositing backward (riggs_raster_cfg.deterministic): per-instance gradient rows summed
+    per Gaussian in ascending tile order instead of float atomics — bitwise reproducible gradients, for tests and debugging
+    (SURVEY.md §5).  Applies to rasterizations started after the call."""
+    global ORDERED_BACKWARD
+    ORDERED_BACKWARD = bool(on)
 
 
 class _Saved:
@@ -190,7 +202,10 @@ def rasterize_backward(s: _Saved, means3D, shs, colors_precomp, opacities, scale
     g_rots = grad_out(rotations, (N, 4)) if rotations is not None else None
     g_cov = torch.empty(N, 6, **f32) if cov3D_precomp is not None else None
     g_dscaling = torch.empty(N, 3, **f32) if (d_scaling is not None and want_d_scaling_grad) else None
-    ws = _backward_workspace(lib.riggs_raster_backward_workspace_bytes(N), dev)
+    if cfg.deterministic:  # (its accumulators are overwritten by the ordered sum: nothing to keep zeroed)
+        ws = torch.zeros(lib.riggs_raster_backward_workspace_bytes_ordered(N, s.cap), dtype=torch.uint8, device=dev)
+    else:
+        ws = _backward_workspace(lib.riggs_raster_backward_workspace_bytes(N), dev)
     if grad_color is None:  # a loss on depth / alpha only (set_materialize_grads(False) hands None for the unused output)
         grad_color = torch.zeros(3, s.H, s.W, **f32)
     gc = L.require_cuda_f32("grad_color", grad_color, (3, s.H, s.W))

@@ -249,3 +249,40 @@ def test_depth_sort_takes_two_passes_when_the_depths_share_their_top_byte_and_th
         z = so.depths[so.radii > 0]
         assert (z.view(np.uint32) >> 24).min() != (z.view(np.uint32) >> 24).max() if want else True
         U.compare_forward_state(so, saved_views(s), out_o, color, depth, alpha, radii)
+
+
+def test_ordered_reduction_mode_gives_bitwise_reproducible_gradients():
+    """riggs_raster_cfg.deterministic: every tile instance writes its gradient row, a second kernel sums each
+    Gaussian's rows in ascending tile order — no float atomics, so two runs agree BIT FOR BIT (the default path only to
+    rounding), and the result equals the atomics path / the oracle within the usual tolerance."""
+    from riggs_amd import rasterizer as RZ
+    sc, act, cam = U.activated_scene(20000, 24, 11, 160, 176, scale=0.05)   # deep: hundreds of instances per Gaussian sum
+    bg = [0.1, 0.2, 0.3]
+    g = torch.Generator().manual_seed(4)
+    gc = (torch.sign(torch.rand(3, 160, 176, generator=g) - 0.5) / (3 * 160 * 176)).cuda()
+    gd = (torch.randn(1, 160, 176, generator=g) / (160 * 176)).cuda()
+    d = lambda t: t.cuda().contiguous()  # noqa: E731
+    args = (d(act["means3D"]), d(act["shs"]), None, d(act["opacities"]), d(act["scales"]), d(act["rotations"]), None)
+
+    def grads():
+        out = rasterize_forward(U.settings_for(cam, bg), *args)
+        return rasterize_backward(out[4], *args, None, None, gc, gd, None)
+    plain = [grads(), grads()]
+    RZ.set_ordered_backward(True)
+    try:
+        ordered = [grads(), grads()]
+    finally:
+        RZ.set_ordered_backward(False)
+    names = "means3D means2D sh colors opac scales rots cov dscaling".split()
+    differs = 0
+    for nm, a, b, p, q in zip(names, ordered[0], ordered[1], plain[0], plain[1]):
+        if a is None:
+            continue
+        assert torch.equal(a, b), "ordered mode not reproducible: " + nm
+        differs += int(not torch.equal(p, q))
+        U.assert_close(a.cpu().numpy(), p.cpu().numpy(), "ordered vs atomics dL/d" + nm, 2e-5, 1e-4)
+    assert differs > 0, "the atomics path happened to be reproducible here: the scene does not exercise the point of the mode"
+    out_o, so = U.oracle_forward(act, cam, bg)
+    go = RR.backward(so, gc.cpu().numpy(), gd.cpu().numpy()[0], None)
+    _grads_close(ordered[0][0], go["means3D"], "ordered dL/dmeans3D vs oracle")
+    _grads_close(ordered[0][4], go["opacities"], "ordered dL/dopacity vs oracle")
