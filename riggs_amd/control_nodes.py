@@ -3,8 +3,11 @@
 translations / local-frame rotations / rotation and scale residuals — ONE HIP launch forward, two backward (csrc/cnode.hip)
 instead of a KNN extension call, ~10 (N, K, ·) gathers, an einsum and autograd's replay of them.
 
-Covered: the configurations the trainer ships (``skinning=False``, ``pred_opacity = pred_color = False``,
-``node_trans_bias=None``; ``local_frame``, ``d_rot_as_res``, ``with_node_weight``, ``hyper_dim`` free).  The node network
+Covered: the configuration the trainer ships (KNN weights; ``local_frame``, ``d_rot_as_res``, ``with_node_weight``, ``hyper_dim``
+free) through the HIP kernels; ``pred_opacity`` / ``pred_color`` (two more blends with the same weights, torch ops on the
+kernel's neighbour lists) and ``skinning=True`` (softmax of a per-Gaussian (N, M) feature instead of KNN weights: a dense
+(N, M) x (M, 14) product, left to the GEMM library) as the reference defines them; ``node_trans_bias`` (the GUI's editing
+path) raises.  The node network
 (``self.network``: nodes, t -> per-node attributes; 512-1024 rows, time_utils.py:990-1002) stays a torch module supplied by the
 caller — it is a few hundred rows through an MLP, not a per-Gaussian cost.  No CPU / eager fallback.
 """
@@ -107,6 +110,40 @@ def control_node_blend(x, feature, motion_mask, nodes, _node_radius, _node_weigh
             "nn_idx": nn_idx, "nn_weight": nn_weight, "nn_dist": nn_dist}
 
 
+def knn_weights_torch(x, feature, nodes, _node_radius, _node_weight, nn_idx, hyper_dim):
+    """``cal_nn_weight`` (time_utils.py:934-964) as differentiable torch ops on GIVEN neighbour lists (the HIP kernel's): used
+    where autograd has to see the weights themselves (the opacity / colour blends)."""
+    idx = nn_idx.long()
+    q, nd = x.detach(), nodes[..., :3].detach()
+    if hyper_dim > 0 and feature is not None:
+        q = torch.cat([q, feature[..., :hyper_dim]], dim=-1)
+        nd = torch.cat([nd, nodes[..., 3:3 + hyper_dim]], dim=-1)
+    d2 = ((q[:, None] - nd[idx]) ** 2).sum(-1)
+    w = torch.exp(-d2 / (2 * torch.exp(_node_radius)[idx] ** 2))
+    if _node_weight is not None:
+        w = w * torch.sigmoid(_node_weight)[idx][..., 0]
+    w = w + 1e-7
+    return w / w.sum(dim=-1, keepdim=True)
+
+
+def skinning_blend(feature, motion_mask, node_attrs, d_rot_as_res=True, pred_opacity=False, pred_color=False):
+    """``ControlNodeWarp.forward`` with ``skinning=True`` (time_utils.py:934-938, 1160-1191, 1214-1225; ``local_frame`` off — the
+    reference's einsum does not take the skinning weights): weights = softmax over ALL nodes of the per-Gaussian feature, every
+    blend a dense (N, M) x (M, c) product."""
+    w = torch.softmax(feature, dim=-1)
+    rot_bias = torch.tensor([1.0, 0.0, 0.0, 0.0], device=feature.device)
+    mm = motion_mask
+    out = {"d_xyz": (w @ node_attrs["d_xyz"]) * mm, "d_scaling": (w @ node_attrs["d_scaling"]) * mm}
+    if d_rot_as_res:
+        out["d_rotation"] = (w @ node_attrs["d_rotation"]) * mm
+    else:
+        out["d_rotation"] = ((w @ (node_attrs["d_rotation"] + rot_bias)) - rot_bias) * mm + rot_bias
+    out["d_opacity"] = (w @ node_attrs["d_opacity"]) * mm if pred_opacity else None
+    out["d_color"] = (w @ node_attrs["d_color"]) * mm if pred_color else None
+    out["nn_weight"], out["nn_idx"], out["nn_dist"] = w, torch.arange(w.shape[1], device=w.device), None
+    return out
+
+
 class StaticNodeNetwork(nn.Module):
     """``StaticNetwork(return_tensors=True)`` (time_utils.py:288-301): zero attributes for every node."""
 
@@ -124,14 +161,18 @@ class ControlNodeWarp(nn.Module):
     def __init__(self, node_num=512, K=3, with_node_weight=True, local_frame=False, d_rot_as_res=True, hyper_dim=2, network=None,
                  pred_opacity=False, pred_color=False, skinning=False, **kwargs):
         super().__init__()
-        if pred_opacity or pred_color or skinning:
-            raise NotImplementedError("pred_opacity / pred_color / skinning are not part of the shipped stage-1 recipe")
+        if skinning and local_frame:
+            raise NotImplementedError("skinning with local_frame: the reference's own forward fails there (its einsum expects per-"
+                                      "Gaussian neighbour lists, time_utils.py:1152)")
+        self.skinning, self.pred_opacity, self.pred_color = bool(skinning), bool(pred_opacity), bool(pred_color)
+        hyper_dim = 0 if skinning else hyper_dim  # "skinning should not be with hyper" (time_utils.py:782)
         self.K, self.with_node_weight, self.local_frame, self.d_rot_as_res, self.hyper_dim = K, with_node_weight, local_frame, d_rot_as_res, hyper_dim
         self.network = network if network is not None else StaticNodeNetwork()
         self.nodes = nn.Parameter(torch.randn(node_num, 3 + hyper_dim))
-        self._node_radius = nn.Parameter(torch.randn(node_num))
-        if with_node_weight:
-            self._node_weight = nn.Parameter(torch.zeros(node_num, 1))
+        if not skinning:  # (time_utils.py:807-810)
+            self._node_radius = nn.Parameter(torch.randn(node_num))
+            if with_node_weight:
+                self._node_weight = nn.Parameter(torch.zeros(node_num, 1))
         self.reg_loss = 0.
 
     @property
@@ -147,6 +188,8 @@ class ControlNodeWarp(nn.Module):
         return self.nodes.shape[0]
 
     def trainable_parameters(self):
+        if self.skinning:  # (time_utils.py:825-827)
+            return [{"params": list(self.network.parameters()), "name": "deform"}, {"params": [self.nodes], "name": "nodes"}]
         node_params = [self.nodes, self._node_radius] + ([self._node_weight] if self.with_node_weight else [])
         return [{"params": list(self.network.parameters()), "name": "deform"}, {"params": node_params, "name": "nodes"}]
 
@@ -164,8 +207,18 @@ class ControlNodeWarp(nn.Module):
         node_attrs = dict(self.node_deform(t=t))
         if animation_d_values is not None:
             node_attrs.update(animation_d_values)
-        out = control_node_blend(x, feature, motion_mask, self.nodes, self._node_radius,
-                                 self._node_weight if self.with_node_weight else None, node_attrs, K=self.K,
-                                 hyper_dim=self.hyper_dim, local_frame=self.local_frame, d_rot_as_res=self.d_rot_as_res)
+        if self.skinning:
+            out = skinning_blend(feature, motion_mask, node_attrs, self.d_rot_as_res, self.pred_opacity, self.pred_color)
+        else:
+            nw = self._node_weight if self.with_node_weight else None
+            out = control_node_blend(x, feature, motion_mask, self.nodes, self._node_radius, nw, node_attrs, K=self.K,
+                                     hyper_dim=self.hyper_dim, local_frame=self.local_frame, d_rot_as_res=self.d_rot_as_res)
+            if self.pred_opacity or self.pred_color:  # (time_utils.py:1214-1225) the same weights, seen by autograd
+                w = knn_weights_torch(x, feature, self.nodes, self._node_radius, nw, out["nn_idx"], self.hyper_dim)
+                idx = out["nn_idx"].long()
+                if self.pred_opacity:
+                    out["d_opacity"] = (node_attrs["d_opacity"][idx] * w[..., None]).sum(dim=1) * motion_mask
+                if self.pred_color:
+                    out["d_color"] = (node_attrs["d_color"][idx] * w[..., None]).sum(dim=1) * motion_mask
         out["d_nodes"] = self.nodes[..., :3] + node_attrs["d_xyz"]
         return out

@@ -404,6 +404,54 @@ def fixture_control_nodes(name, seed, N, M, K, hyper, local_frame, d_rot_as_res,
     print("wrote", name, {k: float(np.abs(v).max()) for k, v in z.items() if k.startswith("grad_")})
 
 
+def fixture_control_nodes_blends(name, seed, N, M, skinning, d_rot_as_res):
+    """ControlNodeWarp.forward in the modes the shipped stage-1 recipe leaves off: ``skinning=True`` (softmax of a per-Gaussian
+    (N, M) feature instead of KNN weights, utils/time_utils.py:934-938) and ``pred_opacity`` / ``pred_color`` (:1214-1225), with
+    autograd's gradients."""
+    import pytorch3d.ops as p3o
+    import pytorch3d as p3
+    p3o.knn_points = knn_points_published
+    p3.ops = p3o
+    with S.quiet():
+        from utils.time_utils import ControlNodeWarp
+        cn = ControlNodeWarp(is_blender=True, node_num=M, K=3, with_node_weight=True, local_frame=False, d_rot_as_res=d_rot_as_res,
+                             hyper_dim=0 if skinning else 2, is_scene_static=True, skinning=skinning, pred_opacity=True,
+                             pred_color=True)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, 3, generator=g) * 0.5
+    hyper = 0 if skinning else 2
+    nodes = torch.cat([x[torch.randint(0, N, (M,), generator=g)] + 0.05 * torch.randn(M, 3, generator=g),
+                       1e-2 + 0.02 * torch.randn(M, hyper, generator=g)], -1)
+    cn.nodes = torch.nn.Parameter(nodes)
+    if not skinning:
+        cn._node_radius = torch.nn.Parameter(math.log(0.15) + 0.3 * torch.randn(M, generator=g))
+        cn._node_weight = torch.nn.Parameter(0.5 * torch.randn(M, 1, generator=g))
+    feature = (torch.randn(N, M, generator=g) if skinning else 0.02 * torch.randn(N, hyper + 1, generator=g)).requires_grad_(True)
+    mask = torch.rand(N, 1, generator=g).requires_grad_(True)
+    attrs = {"d_xyz": 0.1 * torch.randn(M, 3, generator=g), "d_rotation": 0.2 * torch.randn(M, 4, generator=g),
+             "d_scaling": 0.05 * torch.randn(M, 3, generator=g), "local_rotation": 0.3 * torch.randn(M, 4, generator=g),
+             "d_opacity": 0.3 * torch.randn(M, 1, generator=g), "d_color": 0.2 * torch.randn(M, 3, generator=g)}
+    attrs = {k: v.requires_grad_(True) for k, v in attrs.items()}
+    cn.train()
+    out = cn(x, torch.tensor(0.3), feature, mask, animation_d_values=attrs)
+    keys = ("d_xyz", "d_rotation", "d_scaling", "d_opacity", "d_color")
+    go = {k: torch.randn(out[k].shape, generator=g) for k in keys}
+    sum((out[k] * go[k]).sum() for k in go).backward()
+    z = dict(x=np_(x), nodes=np_(nodes), feature=np_(feature), motion_mask=np_(mask), skinning=skinning, d_rot_as_res=d_rot_as_res,
+             grad_feature=np_(feature.grad), grad_motion_mask=np_(mask.grad))
+    if not skinning:
+        z.update(_node_radius=np_(cn._node_radius), _node_weight=np_(cn._node_weight), grad__node_radius=np_(cn._node_radius.grad),
+                 grad__node_weight=np_(cn._node_weight.grad), grad_nodes=np_(cn.nodes.grad))
+    for k, v in attrs.items():
+        z["attr_" + k] = np_(v)
+        z["grad_attr_" + k] = np_(v.grad) if v.grad is not None else np.zeros(v.shape, np.float32)
+    for k in keys:
+        z["out_" + k] = np_(out[k])
+        z["gout_" + k] = np_(go[k])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **z)
+    print("wrote", name, {k: float(np.abs(v).max()) for k, v in z.items() if k.startswith("grad_")})
+
+
 def seeded_heads(J, WeightCls, DeformCls, seed):
     """The two per-Gaussian MLP heads with reproducible weights (the fixture stores checksums, not 4 MB of weights):
     constructed standalone, in this order, right after torch.manual_seed(seed)."""
@@ -479,5 +527,8 @@ if __name__ == "__main__":
     fixture_control_nodes("cnodes_local_res_h8", 81, 400, 64, 3, 8, True, True, True, mask_random=True)
     fixture_control_nodes("cnodes_global_abs_h0", 82, 257, 40, 4, 0, False, False, False)
     fixture_control_nodes("cnodes_default_h8", 83, 300, 128, 3, 8, False, True, True)
+    fixture_control_nodes_blends("cnodes_skinning_m48", 84, 220, 48, True, True)
+    fixture_control_nodes_blends("cnodes_skinning_abs_m32", 85, 150, 32, True, False)
+    fixture_control_nodes_blends("cnodes_knn_pred_opacity_color", 86, 260, 64, False, True)
     fixture_skeleton_projection("skelproj_chain8_m90_K", 72, 8, 90, True, chain=True)
     fixture_state_dict_layout()

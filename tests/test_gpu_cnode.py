@@ -122,7 +122,7 @@ def test_no_feature_means_xyz_only_and_unsupported_options_raise():
     assert torch.equal(out["nn_idx"].long(), d.topk(3, dim=1, largest=False).indices)
     assert float(out["d_xyz"].detach().abs().max()) == 0 and out["d_nodes"].shape == (32, 3)   # static network: zero deformation
     with pytest.raises(NotImplementedError):
-        ControlNodeWarp(skinning=True)
+        ControlNodeWarp(skinning=True, local_frame=True)  # (the reference's own forward fails in this combination)
     with pytest.raises(NotImplementedError):
         cn(x, torch.tensor(0.1, device="cuda"), None, 1.0, node_trans_bias=torch.zeros(32, 3, device="cuda"))
     with pytest.raises(L.RiggsHipError):
@@ -222,3 +222,29 @@ def test_atomics_backward_variant_passes_the_same_goldens():
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_cnode.py", "-m", "gpu", "-q", "-x", "-k", "golden or oracle"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_pred_opacity_and_color_match_reference_golden():
+    """KNN weights (HIP kernel) + the opacity / colour blends of time_utils.py:1214-1225, whose gradients reach the node radii,
+    node weights, hyper coordinates and the Gaussians' feature through the weights themselves."""
+    from riggs_amd.control_nodes import ControlNodeWarp
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cnodes_knn_pred_opacity_color.npz"))
+    T = lambda k, rg=False: torch.from_numpy(g[k].copy()).cuda().requires_grad_(rg)  # noqa: E731
+    M = g["nodes"].shape[0]
+    cn = ControlNodeWarp(node_num=M, K=3, hyper_dim=2, pred_opacity=True, pred_color=True).cuda()
+    cn.nodes.data, cn._node_radius.data, cn._node_weight.data = T("nodes"), T("_node_radius"), T("_node_weight")
+    feature, mask = T("feature", True), T("motion_mask", True)
+    attrs = {k: T("attr_" + k, True) for k in ("d_xyz", "d_rotation", "d_scaling", "local_rotation", "d_opacity", "d_color")}
+    out = cn(T("x"), torch.tensor(0.3).cuda(), feature, mask, animation_d_values=attrs)
+    keys = ("d_xyz", "d_rotation", "d_scaling", "d_opacity", "d_color")
+    for k in keys:
+        np.testing.assert_allclose(out[k].detach().cpu().numpy(), g["out_" + k], rtol=2e-5, atol=2e-6)
+    sum((out[k] * T("gout_" + k)).sum() for k in keys).backward()
+    rel = lambda a, b: float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))  # noqa: E731
+    assert rel(feature.grad.cpu().numpy(), g["grad_feature"]) < 2e-4
+    assert rel(mask.grad.cpu().numpy(), g["grad_motion_mask"]) < 2e-4
+    assert rel(cn._node_radius.grad.cpu().numpy(), g["grad__node_radius"]) < 2e-4
+    assert rel(cn._node_weight.grad.cpu().numpy(), g["grad__node_weight"]) < 2e-4
+    assert rel(cn.nodes.grad.cpu().numpy(), g["grad_nodes"]) < 2e-4
+    for k in ("d_xyz", "d_rotation", "d_scaling", "d_opacity", "d_color"):
+        assert rel(attrs[k].grad.cpu().numpy(), g["grad_attr_" + k]) < 2e-4, k
