@@ -156,7 +156,7 @@ __device__ void bin_offsets_body(int T, int64_t cap, const uint32_t* __restrict_
     tile_max[T] = 0u;
     slot_base[T] = ((uint32_t)min((int64_t)R, cap) >> 6) + (uint32_t)T;
     counters[0] = R;
-    counters[1] = ((int64_t)R > cap) ? 1u : 0u;
+    counters[1] = (counters[1] & 2u) | (((int64_t)R > cap) ? 1u : 0u);  // (bit 1: the depth sort's third pass failed to synchronise)
   }
   // step 2: the longest lists first (the forward deals the tiles to its workgroups in this order, so the long
   // chains start at once and the short ones fill in around them): exclusive scan of the histogram from the top
@@ -400,8 +400,8 @@ int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order,
 // The top byte of a positive float is its sign and the upper seven exponent bits: it is the same for every depth of a
 // scene that lies inside one of the ranges [2, 8), [0.5, 2), [8, 32), ... (a D-NeRF / ZJU camera looks at its subject
 // from 2 - 6 units).  preprocess_fwd records the top bytes it saw; the first kernel folds them into counters[2] =
-// "third pass needed", and the three kernels of the third pass leave at once when it is not: two passes (six short
-// launches + three empty ones) instead of three 11-bit passes.  The result always ends in (keys_out, vals_out): the
+// "third pass needed", and the third pass — ONE launch with an in-launch barrier — leaves at once when it is not: two
+// passes (six short launches + one empty one) instead of three 11-bit passes (nine).  The result always ends in (keys_out, vals_out): the
 // first two passes go through a scratch pair or through the output pair depending on the flag.
 // rocPRIM picks a block sort + ~9 merge passes (18 launches, 0.12 ms) at N = 3e5 and Onesweep's chained
 // look-back costs the same at this size.
@@ -455,7 +455,6 @@ __global__ __launch_bounds__(256) void rs_count_kernel(int N, int pass, RsBufs b
     }
   } else {
     three = counters[2] != 0u;
-    if (pass == 2 && !three) return;
   }
   const uint32_t *ks, *vs; uint32_t *kd, *vd;
   rs_route(bufs, pass, three, ks, vs, kd, vd);
@@ -477,7 +476,7 @@ __global__ __launch_bounds__(256) void rs_count_kernel(int N, int pass, RsBufs b
 // wrapper checks the flag)
 __global__ __launch_bounds__(1024) void rs_scan_kernel(int n_chunks, uint32_t* __restrict__ table, uint32_t* __restrict__ bin_count,
                                                        const uint32_t* __restrict__ counters, int pass) {
-  if (pass == 2 && counters[2] == 0u) return;
+  (void)counters; (void)pass;
   bin_scan_body(RS_BINS, n_chunks, table, bin_count);
 }
 
@@ -489,7 +488,6 @@ __global__ __launch_bounds__(RS_SC_WAVES * 64) void rs_scatter_kernel(int N, int
   __shared__ unsigned short s_wave[RS_SC_WAVES][RS_BINS];    // per-wave counts -> per-wave running offsets
   __shared__ uint32_t s_part[RS_SC_WAVES];
   const bool three = counters[2] != 0u;
-  if (pass == 2 && !three) return;
   const uint32_t *ks, *vs; uint32_t *kd, *vd;
   rs_route(bufs, pass, three, ks, vs, kd, vd);
   const int shift = pass * RS_BITS;
@@ -558,6 +556,130 @@ __global__ __launch_bounds__(RS_SC_WAVES * 64) void rs_scatter_kernel(int N, int
   }
 }
 
+// The THIRD pass (top byte: 256 bins) as ONE launch: it runs only when the depths straddle a power-of-four boundary, and three
+// launches that leave at once cost 13.7 us of every frame against 4.5 us for one.  Its workgroups (one per chunk, all
+// resident: <= 147 at 300k keys) histogram their chunk, publish the 256 counts with write-through stores, meet at an in-launch
+// barrier (one arrival counter, bounded spin: the guide's recipe; counters[3], cleared by the first kernel of the sort) and then
+// each reads the whole 150 KB table — every other chunk's counts — to place its own elements.
+#define RS3_BINS 256
+#define RS3_MAX_WG 512  // workgroups of the third pass (<= 2 per CU: all resident whatever N is; each loops over its chunks)
+typedef __attribute__((address_space(1))) uint32_t rs_gu32;
+__global__ __launch_bounds__(RS_SC_WAVES * 64) void rs_third_pass_kernel(int N, int n_chunks, RsBufs bufs,
+                                                                         uint32_t* __restrict__ table3,
+                                                                         uint32_t* __restrict__ counters) {
+  if (counters[2] == 0u) return;  // two passes sufficed (the usual case)
+  __shared__ uint32_t s_hist[RS3_BINS];
+  __shared__ uint32_t s_start[RS3_BINS];
+  __shared__ unsigned short s_wave[RS_SC_WAVES][RS3_BINS];
+  __shared__ int s_fail;
+  const uint32_t *ks = bufs.k_tmp, *vs = bufs.v_tmp;
+  uint32_t *kd = bufs.k_out, *vd = bufs.v_out;
+  constexpr int NT = RS_SC_WAVES * 64, STEPS = RS_CHUNK / NT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int G = (int)gridDim.x;
+  // ---- phase A: the counts of this workgroup's chunks, published with write-through stores
+  for (int chunk = blockIdx.x; chunk < n_chunks; chunk += G) {
+    if (tid < RS3_BINS) s_hist[tid] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < STEPS; st++) {
+      const int i = chunk * RS_CHUNK + wave * (64 * STEPS) + st * 64 + lane;
+      if (i < N) atomicAdd(&s_hist[ks[i] >> 24], 1u);
+    }
+    __syncthreads();
+    if (tid < RS3_BINS)
+      __hip_atomic_store((rs_gu32*)(table3 + (size_t)chunk * RS3_BINS + tid), s_hist[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (tid == 0) s_fail = 0;
+  __syncthreads();
+  // ---- the in-launch barrier
+  if (tid == 0) {
+    __hip_atomic_fetch_add((rs_gu32*)(counters + 3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t spins = 0;
+    while (__hip_atomic_load((rs_gu32*)(counters + 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)G) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1u << 22)) { s_fail = 1; break; }  // (a workgroup that never became resident; not on an idle chip)
+    }
+  }
+  __syncthreads();
+  if (s_fail) {  // flag the frame (bit 1 of counters[1]) instead of hanging: its ordering is undefined
+    if (tid == 0) atomicOr(counters + 1, 2u);
+    return;
+  }
+  // ---- phase B: per chunk, the start of every bin (total over all chunks, part of the earlier ones), then rank and scatter
+  for (int chunk = blockIdx.x; chunk < n_chunks; chunk += G) {
+    for (int e = tid; e < RS_SC_WAVES * RS3_BINS / 2; e += NT) reinterpret_cast<uint32_t*>(&s_wave[0][0])[e] = 0u;
+    if (tid < RS3_BINS) {
+      uint32_t total = 0, before = 0;
+      for (int c = 0; c < n_chunks; c += 4) {
+        uint32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          v[u] = (c + u < n_chunks) ? __hip_atomic_load((rs_gu32*)(table3 + (size_t)(c + u) * RS3_BINS + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; u++) { total += v[u]; if (c + u < chunk) before += v[u]; }
+      }
+      s_hist[tid] = total;
+      s_start[tid] = before;
+    }
+    __syncthreads();
+    uint32_t key[STEPS], val[STEPS];
+    int dig[STEPS];
+#pragma unroll
+    for (int st = 0; st < STEPS; st++) {
+      const int i = chunk * RS_CHUNK + wave * (64 * STEPS) + st * 64 + lane;
+      key[st] = 0u; val[st] = 0u; dig[st] = -1;
+      if (i < N) {
+        key[st] = ks[i]; val[st] = vs[i];
+        dig[st] = (int)(key[st] >> 24);
+        atomicAdd(reinterpret_cast<uint32_t*>(&s_wave[wave][0]) + (dig[st] >> 1), 1u << (16 * (dig[st] & 1)));
+      }
+    }
+    if (wave == 0) {  // exclusive scan of the 256 totals (4 per lane) -> start of every bin
+      uint32_t c4[4], t = 0;
+#pragma unroll
+      for (int u = 0; u < 4; u++) { c4[u] = s_hist[lane * 4 + u]; t += c4[u]; }
+      uint32_t v = t;
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u2 = (uint32_t)__shfl_up((int)v, o);
+        if (lane >= o) v += u2;
+      }
+      uint32_t run = v - t;
+#pragma unroll
+      for (int u = 0; u < 4; u++) { s_start[lane * 4 + u] += run; run += c4[u]; }
+    }
+    __syncthreads();
+    for (int b = tid; b < RS3_BINS; b += NT) {  // counts -> offsets of the waves inside the chunk's segment
+      unsigned short r = 0;
+#pragma unroll
+      for (int w = 0; w < RS_SC_WAVES; w++) { const unsigned short cw = s_wave[w][b]; s_wave[w][b] = r; r += cw; }
+    }
+    __syncthreads();
+    unsigned short* cur = s_wave[wave];
+#pragma unroll
+    for (int st = 0; st < STEPS; st++) {
+      const bool on = dig[st] >= 0;
+      uint64_t same = __builtin_amdgcn_ballot_w64(on);
+#pragma unroll
+      for (int b = 0; b < 8; b++) {
+        const uint64_t vote = __builtin_amdgcn_ballot_w64(on && ((dig[st] >> b) & 1));
+        same &= ((dig[st] >> b) & 1) ? vote : ~vote;
+      }
+      if (on) {
+        const uint64_t below = same & ((1ull << lane) - 1ull);
+        const uint32_t rank = (uint32_t)__builtin_popcountll(below);
+        const unsigned short base = cur[dig[st]];
+        const uint32_t pos = s_start[dig[st]] + base + rank;
+        kd[pos] = key[st]; vd[pos] = val[st];
+        if ((same >> lane) >> 1 == 0ull) cur[dig[st]] = base + (unsigned short)__builtin_popcountll(same);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 size_t depth_sort_table_bytes(int N) {
   const size_t n = (size_t)(N > 0 ? N : 1), chunks = (n + RS_CHUNK - 1) / RS_CHUNK;
   return align_up((chunks + 1) * RS_BINS * 4) + align_up(RS_BINS * 4) + 2 * align_up(n * 4);  // table, bin counts, scratch pair
@@ -575,11 +697,14 @@ int launch_depth_sort(int N, const uint32_t* keys_in, uint32_t* keys_out, uint32
   b.k_tmp = (uint32_t*)((char*)bin_count + align_up(RS_BINS * 4));
   b.v_tmp = (uint32_t*)((char*)b.k_tmp + align_up((size_t)(N > 0 ? N : 1) * 4));
   b.k_out = keys_out; b.v_out = vals_out;
-  for (int pass = 0; pass < 3; pass++) {
+  for (int pass = 0; pass < 2; pass++) {
     hipLaunchKernelGGL(rs_count_kernel, dim3(chunks), dim3(256), 0, s, N, pass, b, table, block_info, (N + 255) / 256, counters);
     hipLaunchKernelGGL(rs_scan_kernel, dim3((RS_BINS + 63) / 64), dim3(1024), 0, s, chunks, table, bin_count, counters, pass);
     hipLaunchKernelGGL(rs_scatter_kernel, dim3(chunks), dim3(RS_SC_WAVES * 64), 0, s, N, pass, b, table, bin_count, counters);
   }
+  // (the table of the 12-bit passes is free again: chunks x 256 counts fit into it)
+  hipLaunchKernelGGL(rs_third_pass_kernel, dim3(chunks < RS3_MAX_WG ? chunks : RS3_MAX_WG), dim3(RS_SC_WAVES * 64), 0, s, N, chunks,
+                     b, table, counters);
   return 0;
 }
 

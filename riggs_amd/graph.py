@@ -154,6 +154,8 @@ class GraphedFrame:
             pose_net.check_status()
         c = self.arena.static_counters[:2].tolist()
         R, overflow = int(c[0]) & 0xFFFFFFFF, int(c[1])
+        if overflow & 2:
+            raise L.RiggsHipError("the depth sort's third pass could not synchronise its workgroups inside the captured graph")
         if overflow:
             raise L.RiggsHipError("instance arena overflowed inside the captured graph (R=%d > capacity=%d): "
                                   "re-capture with more headroom" % (R, self.arena.capacity))

@@ -71,6 +71,9 @@ class RasterArena:
         self._pending = None
         R, overflow = int(host[0]) & 0xFFFFFFFF, int(host[1])
         self.last_R = R
+        if overflow & 2:
+            raise L.RiggsHipError("the depth sort's third pass could not synchronise its workgroups on the previous frame (GPU shared "
+                                  "with another long-running kernel?); that frame's outputs are invalid")
         if overflow:
             raise L.RiggsHipError("instance arena overflowed on the previous frame (R=%d > capacity=%d); that frame\'s "
                                   "outputs are invalid.  The arena is regrown on the next call." % (R, cap))
