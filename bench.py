@@ -362,6 +362,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--profile-all", action="store_true", help="print a per-kernel event-timer table to stderr")
+    ap.add_argument("--exchange", choices=("rows", "dense"), default="rows",
+                    help="N > 1: gradient-row exchange (packed rows of the Gaussians with a gradient) or the dense two-phase all-reduce")
     ap.add_argument("--metric-only", action="store_true", help="skip the secondary timings (train step, heads, next rows, dense scene)")
     args = ap.parse_args()
 
@@ -397,10 +399,18 @@ def main():
     # so the data-parallel exchange is a single in-place RCCL all-reduce (AVG) with no pack / unpack / divide pass
     # (world > 1: the bucket is ordered for the two-phase overlapped exchange — SH / opacity / scale first, they are final
     # when the rasterizer's backward has run; xyz / rotation / skeleton after the deformation backward that still reads them)
-    from riggs_amd.dist import FlatGradAllReduce, OverlappedExchange, exchange_order
+    from riggs_amd.dist import FlatGradAllReduce, OverlappedExchange, SparseRowExchange, exchange_order, row_exchange_order
     ordered, n_first = exchange_order(gm, sw)
+    assert [id(p) for p in ordered] == [id(p) for p in row_exchange_order(gm, sw)[0]]  # one bucket order serves both exchanges
+    n_rows = row_exchange_order(gm, sw)[1]
     bucket = FlatGradAllReduce(ordered if world > 1 else params_of(gm, sw))
     exchange = OverlappedExchange(bucket, bucket.offsets[n_first]) if world > 1 else None
+    # the gradient-row exchange (default): only the Gaussians that received a gradient travel (csrc/exchange.hip); the dense
+    # two-phase all-reduce is used when asked for, or when so many rows are touched that it moves fewer bytes per link
+    rows = None
+    if world > 1 and args.exchange == "rows":
+        rows = SparseRowExchange([v.view(w["N"], -1) for v in bucket.views[:n_rows]], rest=bucket.flat[bucket.offsets[n_rows]:],
+                                 capacity=max(1024, w["N"] // 8))
     step = make_step(cam, gm, sw, gimg, arena, world, bucket)
     pkg = step()
     gimg.copy_(torch.sign(pkg["render"].detach() - target) / (3 * w["H"] * w["W"]))
@@ -427,6 +437,15 @@ def main():
             # frame-parallel step: the graph's gradient buffers ARE the bucket's slices, so the exchange is two in-place
             # collectives — the first (86 % of the bytes) on the links while the deformation backward still computes
             out = gf.run_a()
+            if rows is not None:
+                # packed rows of the touched Gaussians -> all-gather (on the links while the deformation backward runs) ->
+                # small dense all-reduce of the skeleton's gradients -> ordered unpack
+                rows.pack()
+                rows.launch()
+                gf.run_b()
+                rows.launch_rest()
+                rows.wait()
+                return out
             exchange.launch(1)
             gf.run_b()
             exchange.launch(2)
@@ -435,6 +454,16 @@ def main():
         step()
         torch.cuda.synchronize()
         assert gf.check() == R, "graphed frame disagrees with the eager frame on the instance count"
+        if rows is not None:
+            # size the segments from what the fullest rank needed (every rank reads the same headers: same decision everywhere)
+            rows.check()
+            rows.resize(int(rows.need * 1.1) + 256)
+            if not rows.wins:
+                rows = None
+            else:
+                step()
+                torch.cuda.synchronize()
+                assert rows.check(), "gradient-row segments overflowed right after sizing"
 
     names = [lib.riggs_prof_name(i).decode() for i in range(lib.riggs_prof_count())]
     eager_step = make_step(cam, gm, sw, gimg, arena, 1, bucket)  # profiling leg: rank 0 alone, so NO collective inside
@@ -452,6 +481,24 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    if world > 1 and rows is not None and not args.no_graph:
+        assert rows.check(), "a gradient-row segment overflowed inside the timed region (that step was not exchanged)"
+        # outside the timed region: one more step whose exchanged gradients are compared with a plain all-reduce of the same
+        # local gradients (the row exchange must be the mean, on every rank)
+        gf.run_a()
+        gf.run_b()
+        local = [g.clone() for g in rows.rows]
+        rows.pack()
+        rows.launch()
+        rows.launch_rest()
+        rows.wait()
+        for g in local:
+            dist.all_reduce(g)
+            g /= world
+        torch.cuda.synchronize()
+        for got, want in zip(rows.rows, local):
+            tol = 1e-5 * float(want.abs().max()) + 1e-30
+            assert float((got - want).abs().max()) <= tol, "gradient-row exchange differs from the dense all-reduce"
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -506,6 +553,13 @@ def main():
         if args.profile_all:
             sys.stderr.write("per-launch ms (HIP events): %s\n" % json.dumps(table))
 
+    exchange_label = "two-phase in-place all-reduce (AVG) of one flat bucket, phase 1 overlapped with the deformation backward"
+    if rows is not None and not args.no_graph:
+        exchange_label = ("packed rows of the Gaussians with a gradient (%d of %d rows needed by the fullest rank, capacity %d, %.1f MB per "
+                          "segment) all-gathered during the deformation backward + dense all-reduce of the skeleton's %d floats; ordered "
+                          "unpack" % (rows.need, w["N"], rows.capacity, rows.segment.numel() * 4 / 1e6, rows.rest.numel()))
+    elif args.no_graph:
+        exchange_label = "one in-place all-reduce (AVG) of the flat bucket"
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * args.steps / elapsed
@@ -577,7 +631,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "300k Gaussians / 24-joint skeleton / 800x800, LBS-only, SH degree 3, anisotropic, "
                                    "one frame per GPU per step", "num_gaussians": w["N"], "num_joints": w["J"],
-                       "image": [w["H"], w["W"]], "tile_instances_R": R, "parallelism": "frames x%d" % world, "exchange": None if world == 1 else "two-phase in-place all-reduce (AVG) of one flat bucket, phase 1 overlapped with the deformation backward",
+                       "image": [w["H"], w["W"]], "tile_instances_R": R, "parallelism": "frames x%d" % world, "exchange": None if world == 1 else exchange_label,
                        "launch": "eager" if args.no_graph else "hipGraph replay"},
             # The dominant kernel is a compositing kernel: SURVEY.md §8-d bounds those by vector issue, not by HBM.  `achieved /
             # peak / frac` stay the HBM numbers from ALGORITHMIC bytes (the contract's definition); `bound` says what actually

@@ -137,8 +137,10 @@ int riggs_raster_backward(const riggs_raster_cfg* cfg, const float* means3D, con
                           const float* d_rotation, const float* d_scaling, const int32_t* radii, const void* geom, const void* binning,
                           int64_t instance_capacity, const void* image_state, const uint32_t* counters,
                           const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                          void* workspace /* riggs_raster_backward_workspace_bytes(N); must be ALL ZERO on entry and is
-                          all zero again on return (self-cleaning accumulators): zero it once after allocating and keep it */,
+                          void* workspace /* riggs_raster_backward_workspace_bytes(N); must be ALL ZERO on first use; the
+                          accumulators in it are all zero again on return (self-cleaning): zero it once after allocating and
+                          keep it — for THIS num_points: behind the accumulators the call leaves one bit per Gaussian "received a gradient"
+                          (riggs_grad_rows_*), at an offset that depends on num_points; re-zero the buffer before another size uses it */,
                           float* dL_dmeans3D,
                           float* dL_dmeans2D /*(N,3)*/, float* dL_dsh, float* dL_dcolors_precomp,
                           float* dL_dopacities, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
@@ -262,6 +264,30 @@ int riggs_adam_step_capturable(int32_t n_groups, float* const* params, const flo
 int riggs_densify_stats(int32_t num_points, const float* viewspace_grad, const uint8_t* update_filter,
                         const int32_t* radii, float* xyz_gradient_accum, float* denom, float* max_radii2D,
                         riggs_stream stream);
+
+/* =====================================================================
+ * Gradient-row exchange of the frame-sharded step (the reference is single-GPU:
+ * utils/general_utils.py:207 pins cuda:0, so this has no reference counterpart — it is what the data-parallel
+ * caller of riggs_raster_backward binds instead of an all-reduce over all N rows).
+ * riggs_raster_backward leaves in its workspace which Gaussians received a gradient this frame (the others' gradients
+ * are exactly zero in every tensor).  riggs_grad_rows_pack copies those rows — (Gaussian index, row of every tensor in
+ * `grads`, times `scale`) — in ascending Gaussian order into `segment`:
+ *   32-bit words [0] rows stored = min(needed, capacity), [1] rows needed, [2] N, [3] row_floats,
+ *   [4 .. 4 + ceil(N/256)] first row of every block of 256 Gaussians, then (16-byte aligned) `capacity` rows of
+ *   row_floats = riggs_grad_rows_row_floats(...) floats (index bits first, zero padded to a multiple of 4).
+ * The caller all-gathers the segments of all ranks (equal riggs_grad_rows_segment_bytes) and calls
+ * riggs_grad_rows_unpack: per Gaussian the rows are combined IN RANK ORDER — first occurrence overwrites, later ones are
+ * added; rows in no segment are left as they are (zero on every rank) — without atomics, so every rank obtains the same
+ * bits.  `grads` are HOST arrays of DEVICE pointers to (N, widths[k]) row-major float tensors (<= 8).  status[0] =
+ * max over segments of the rows needed, status[1] = 1 when a segment overflowed `capacity` or does not match (N,
+ * row_floats): then NOTHING is unpacked (the gradients keep their local values) and the caller exchanges densely.
+ * `backward_workspace` is the workspace the last riggs_raster_backward of these N Gaussians used, on the same stream. */
+int32_t riggs_grad_rows_row_floats(int32_t n_tensors, const int32_t* widths);
+size_t riggs_grad_rows_segment_bytes(int32_t num_points, int32_t row_floats, int32_t capacity);
+int riggs_grad_rows_pack(int32_t num_points, const void* backward_workspace, int32_t n_tensors, const float* const* grads,
+                         const int32_t* widths, float scale, int32_t capacity, void* segment, riggs_stream stream);
+int riggs_grad_rows_unpack(int32_t num_points, int32_t world, int32_t capacity, const void* segments, int32_t n_tensors,
+                           float* const* grads, const int32_t* widths, uint32_t* status, riggs_stream stream);
 
 /* =====================================================================
  * Image loss: utils/loss_utils.py:17-18 (l1_loss), :33-77 (ssim, 11x11 Gaussian window,

@@ -58,6 +58,10 @@ _SIGS = {
     "riggs_pose_mlp_set_trace": (C.c_int, [_P]),
     "riggs_pose_mlp_backward": (C.c_int, [C.c_int32] * 5 + [_P] * 13),
     "riggs_pose_mlp_status_word": (C.c_size_t, [C.c_int32] * 2),
+    "riggs_grad_rows_row_floats": (C.c_int32, [C.c_int32, _P]),
+    "riggs_grad_rows_segment_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "riggs_grad_rows_pack": (C.c_int, [C.c_int32, _P, C.c_int32, _P, _P, C.c_float, C.c_int32, _P, _P]),
+    "riggs_grad_rows_unpack": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P, _P]),
     "riggs_adam_step": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, _P]),
     "riggs_adam_step_capturable": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, _P]),
     "riggs_densify_stats": (C.c_int, [C.c_int32] + [_P] * 7),

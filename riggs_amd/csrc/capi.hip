@@ -131,7 +131,7 @@ const char* riggs_last_error(void) { return g_err; }
 size_t riggs_raster_geom_bytes(int32_t N) { return geom_layout(N).total; }
 size_t riggs_raster_image_bytes(int32_t H, int32_t W) { return image_layout(H, W).total; }
 size_t riggs_raster_binning_bytes(int64_t cap, int32_t N, int32_t H, int32_t W) { return bin_layout(cap, N, H, W).total; }
-size_t riggs_raster_backward_workspace_bytes(int32_t N) { return align_up((size_t)(N > 0 ? N : 1) * RIGGS_GACC * 4); }
+size_t riggs_raster_backward_workspace_bytes(int32_t N) { return ws_blocks_offset(N) + align_up((size_t)((N > 0 ? N : 1) + 255) / 256 * 4); }
 size_t riggs_raster_backward_workspace_bytes_ordered(int32_t N, int64_t cap) {
   const size_t c = (size_t)(cap > 0 ? cap : 1), n = (size_t)(N > 0 ? N : 1);
   return riggs_raster_backward_workspace_bytes(N) + align_up(c * 40) + align_up(c * 4) + align_up((n + 1) * 4);
@@ -334,6 +334,8 @@ int riggs_raster_backward(const riggs_raster_cfg* cfg, const float* means3D, con
   }
   if (debug_sync(cfg->debug, s, "render_bwd")) return 1;
   b.gacc = (float*)workspace;
+  b.touched_bits = (unsigned long long*)((char*)workspace + ws_bits_offset(N));
+  b.block_touched = (uint32_t*)((char*)workspace + ws_blocks_offset(N));
   b.dL_dmeans3D = dL_dmeans3D; b.dL_dmeans2D = dL_dmeans2D; b.dL_dsh = dL_dsh; b.dL_dcolors = dL_dcolors_precomp;
   b.dL_dopac = dL_dopacities; b.dL_dscales = dL_dscales; b.dL_drots = dL_drotations; b.dL_dcov3D = dL_dcov3D;
   b.dL_dd_scaling = dL_dd_scaling; b.dL_dsh_rest = dL_dsh_rest;

@@ -332,6 +332,8 @@ __global__ __launch_bounds__(256, 3) void preprocess_bwd_kernel(PreBwdArgs b) {
   int tbase = 0;
   for (int w = 0; w < wave0; w++) tbase += s_wcount[w];
   const int n_work = s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
+  if (lane0 == 0 && blockIdx.x * 256 + wave0 * 64 < a.N) b.touched_bits[blockIdx.x * 4 + wave0] = tmask;
+  if (t0 == 0) b.block_touched[blockIdx.x] = (uint32_t)n_work;
   if (touched0) s_list[tbase + __builtin_popcountll(tmask & ((1ull << lane0) - 1ull))] = (unsigned char)t0;
   if (i0 < a.N && !touched0) {
     b.dL_dmeans3D[3 * i0] = 0.f; b.dL_dmeans3D[3 * i0 + 1] = 0.f; b.dL_dmeans3D[3 * i0 + 2] = 0.f;

@@ -25,8 +25,15 @@ struct PreBwdArgs {
   float* gacc;                   // workspace: per Gaussian [mean2D.x, mean2D.y, gA, gB, gC, g_opacity, g_r, g_g, g_b, g_depth, -, -];
                                  // zero on entry of the compositing backward, zero again when preprocess_bwd returns
   float *dL_dmeans3D, *dL_dmeans2D, *dL_dsh, *dL_dcolors, *dL_dopac, *dL_dscales, *dL_drots, *dL_dcov3D, *dL_dd_scaling, *dL_dsh_rest;
+  // workspace, behind the accumulators: which Gaussians received a gradient this frame (one bit each, a 64-bit word per
+  // wave) and how many per block of 256 — rewritten by every launch; read by the gradient-row exchange (exchange.hip)
+  unsigned long long* touched_bits;
+  uint32_t* block_touched;
 };
 #define RIGGS_GACC 12  // floats per Gaussian in the render-backward accumulator (padded to 48 B)
+// backward workspace: [accumulators N x 48 B | touched bits, one 64-bit word per 64 Gaussians | touched count per 256]
+static inline size_t ws_bits_offset(int32_t N) { return align_up((size_t)(N > 0 ? N : 1) * RIGGS_GACC * 4); }
+static inline size_t ws_blocks_offset(int32_t N) { return ws_bits_offset(N) + align_up((size_t)((N > 0 ? N : 1) + 63) / 64 * 8); }
 
 
 int launch_preprocess_fwd(const PreArgs& a, hipStream_t s);

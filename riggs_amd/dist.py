@@ -220,6 +220,14 @@ def exchange_order(gm, sw):
     return first + rest, len(first)
 
 
+def row_exchange_order(gm, sw):
+    """Parameters in the order the gradient-row exchange wants them in ONE flat bucket — the six per-Gaussian tensors
+    (their gradients come from the rasterizer's backward alone: ``SparseRowExchange.rows``), then the skeleton's (dense,
+    0.6 M floats: ``rest``) — and the number of per-Gaussian tensors."""
+    rows = [gm._features_dc, gm._features_rest, gm._opacity, gm._scaling, gm._xyz, gm._rotation]
+    return rows + [sw._node_radius] + list(sw.pose_net.parameters()), len(rows)
+
+
 # ---- sharded optimizer step (ZeRO-1 over the frame-parallel replicas) -----------------------------------------------
 class ShardedAdam:
     """reduce-scatter -> Adam on the rank's 1/W slice of the flat parameter space -> all-gather: the same
@@ -368,3 +376,155 @@ def sparse_rows_all_reduce(grads, capacity: int, average: bool = True):
         g.copy_(acc[:N, o:o + w].reshape(g.shape))
         o += w
     return need
+
+
+# ---- gradient-row exchange (csrc/exchange.hip) --------------------------------------------------------------------------
+def segment_words(N: int, row_floats: int, capacity: int) -> int:
+    """32-bit words of one rank's segment (include/riggs_hip.h: riggs_grad_rows_segment_bytes / 4)."""
+    rows_off = (4 + (N + 255) // 256 + 1 + 3) // 4 * 4
+    return ((rows_off + capacity * row_floats) * 4 + 255) // 256 * 256 // 4
+
+
+def _hip_pack(ex):
+    import ctypes as C
+    from . import _lib as L
+    from .rasterizer import last_backward_workspace
+    ws, n = last_backward_workspace()
+    if n != ex.N or ws.device != ex.segment.device:
+        raise RuntimeError("the last rasterizer backward was not over these %d Gaussians" % ex.N)
+    L.check(L.lib().riggs_grad_rows_pack(ex.N, ws.data_ptr(), len(ex.rows), ex._ptrs, ex._widths, C.c_float(1.0 / ex.world if ex.average else 1.0),
+                                         ex.capacity, ex.segment.data_ptr(), L.stream_ptr()), "riggs_grad_rows_pack")
+
+
+def _hip_unpack(ex):
+    from . import _lib as L
+    L.check(L.lib().riggs_grad_rows_unpack(ex.N, ex.world, ex.capacity, ex.gathered.data_ptr(), len(ex.rows), ex._ptrs, ex._widths,
+                                           ex.status.data_ptr(), L.stream_ptr()), "riggs_grad_rows_unpack")
+
+
+class SparseRowExchange:
+    """The data-parallel exchange of a frame whose per-Gaussian gradients are sparse BY ROW (93 % of the rows are exactly
+    zero in the SURVEY.md §8-d scene): pack the touched rows (csrc/exchange.hip, riggs_grad_rows_pack — the list comes from
+    the rasterizer's backward, nothing is scanned), all-gather the packed segments, combine them in rank order on every
+    rank (riggs_grad_rows_unpack: no atomics, bit-identical replicas).  Per link and direction a rank sends capacity x 240
+    bytes once to every peer — CONSTANT in the world size on the xGMI mesh — where the ring all-reduce of the dense bucket
+    moves 2 N x 236 / W bytes: the rows win while capacity < 2 N / W (DESIGN.md §5 has the budget).
+
+    ``rows`` — the gradient tensors (N, ...) of the per-Gaussian parameters, fixed storage (bucket views / the captured
+    graph's gradient buffers); every one of them must get its gradient ONLY from the rasterizer's backward (a regulariser
+    that touches other rows needs the dense path).  ``rest`` — a flat tensor with the remaining (dense, small) gradients,
+    all-reduced as it is.  ``pack()`` right after the rasterizer's backward on the compute stream, ``launch()`` puts the
+    all-gather on the communication stream, ``launch_rest()`` the small all-reduce (after the deformation backward),
+    ``wait()`` joins and unpacks.  ``check()`` (a device->host read: once per step at most, or every k steps) returns
+    False when a segment overflowed ``capacity``: that step's unpack was skipped on EVERY rank (gradients still local),
+    call ``dense_fallback()`` for it and ``resize()``.  The reference has no distributed path."""
+
+    def __init__(self, rows, rest=None, capacity=None, average=True, pack=None, unpack=None, world=None):
+        self.world = int(world) if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        self.rows = [g for g in rows]
+        self.N = int(self.rows[0].shape[0])
+        if any(g.shape[0] != self.N or not g.is_contiguous() or g.dtype != torch.float32 for g in self.rows):
+            raise ValueError("rows: contiguous float32 tensors with one row per Gaussian")
+        if not 1 <= len(self.rows) <= 8:
+            raise ValueError("1..8 row tensors")
+        self.widths = [g.numel() // self.N for g in self.rows]
+        self.row_floats = (1 + sum(self.widths) + 3) // 4 * 4
+        self.rest, self.average = rest, bool(average)
+        self.cuda = self.rows[0].is_cuda
+        if not self.cuda and (pack is None or unpack is None):
+            raise RuntimeError("SparseRowExchange packs / unpacks with HIP kernels: CUDA tensors required")
+        self._pack, self._unpack = pack or _hip_pack, unpack or _hip_unpack
+        import ctypes as C
+        self._ptrs = (C.c_void_p * len(self.rows))(*[g.data_ptr() for g in self.rows])
+        self._widths = (C.c_int32 * len(self.rows))(*self.widths)
+        dev = self.rows[0].device
+        self.comm = torch.cuda.Stream(device=dev) if self.cuda else None
+        self.status = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.pending = []
+        self.need = 0
+        # the small dense all-reduce gets its OWN communicator: collectives of one process group run one after the other
+        # on that group's internal stream, and this one must not queue behind the all-gather of the rows
+        self.rest_group = None
+        if rest is not None and self.world > 1 and dist.is_initialized() and world is None:
+            self.rest_group = dist.new_group()
+        self.resize(int(capacity) if capacity is not None else max(1024, self.N // 8))
+
+    def resize(self, capacity: int):
+        self.capacity = int(min(max(capacity, 1), self.N))
+        words = segment_words(self.N, self.row_floats, self.capacity)
+        dev = self.rows[0].device
+        self.segment = torch.zeros(words, dtype=torch.int32, device=dev)
+        self.gathered = torch.zeros(self.world * words, dtype=torch.int32, device=dev)
+
+    @property
+    def wins(self) -> bool:
+        """Rows beat the dense ring all-reduce on the links while capacity < 2 N / W (always at W = 2)."""
+        return self.capacity * self.world < 2 * self.N
+
+    def pack(self):
+        self._pack(self)
+
+    def _on_comm(self, fn):
+        if self.cuda:
+            self.comm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm):
+                fn()
+        else:
+            fn()
+
+    def launch(self):
+        def go():
+            if self.world == 1:
+                self.gathered.copy_(self.segment)
+            elif self.cuda and dist.get_backend() == "nccl":
+                self.pending.append((dist.all_gather_into_tensor(self.gathered, self.segment, async_op=True), None))
+            elif self.cuda:  # gloo (the CPU-backend control-flow tests): its all_gather has no device implementation
+                host = self.segment.cpu()
+                parts = [torch.empty_like(host) for _ in range(self.world)]
+                dist.all_gather(parts, host)
+                self.gathered.copy_(torch.cat(parts))
+            else:
+                parts = list(self.gathered.view(self.world, -1).unbind(0))
+                self.pending.append((dist.all_gather(parts, self.segment, async_op=True), None))
+        self._on_comm(go)
+
+    def _reduce_dense(self, t, group=None):
+        if self.world == 1:
+            return
+        if self.average and self.cuda and dist.get_backend() == "nccl":
+            self.pending.append((dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group, async_op=True), None))
+        else:
+            self.pending.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True), t if self.average else None))
+
+    def launch_rest(self):
+        if self.rest is not None:
+            self._on_comm(lambda: self._reduce_dense(self.rest, self.rest_group))
+
+    def _join(self):
+        def go():
+            for work, needs_div in self.pending:
+                work.wait()
+                if needs_div is not None:
+                    needs_div.div_(self.world)
+            self.pending = []
+        if self.cuda:
+            with torch.cuda.stream(self.comm):
+                go()
+            torch.cuda.current_stream().wait_stream(self.comm)
+        else:
+            go()
+
+    def wait(self):
+        self._join()
+        self._unpack(self)
+
+    def check(self) -> bool:
+        need, bad = (int(v) for v in self.status.tolist())
+        self.need = need
+        return not bad
+
+    def dense_fallback(self):
+        """The step whose ``check()`` failed: its unpack was skipped everywhere, so the rows are averaged densely."""
+        for g in self.rows:
+            self._reduce_dense(g)
+        self._join()

@@ -41,6 +41,9 @@ class GraphedFrame:
         self.fused = fused
         self.graph = None
         self.out = None
+        # optional callable issued right behind the rasterizer's backward of a split frame, INSIDE graph (a): e.g. the pack
+        # of riggs_amd.dist.SparseRowExchange (it then bakes that object's segment buffer into the graph)
+        self.after_raster_backward = None
 
     def _frame(self):
         for p in self.params:
@@ -67,6 +70,8 @@ class GraphedFrame:
         self._dr = dv["d_rotation"].detach().requires_grad_(True)
         pkg = render(self.cam, self.gm, _Pipe, self.bg, self._dx, self._dr, dv["d_scaling"], fused=self.fused, arena=self.arena)
         pkg["render"].backward(self.gimg)
+        if self.after_raster_backward is not None:
+            self.after_raster_backward()
         self._dv = dv
         out = {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in dict.items(pkg)
                if k not in ("viewspace_points", "visibility_filter")}
@@ -120,6 +125,8 @@ class GraphedFrame:
             with torch.cuda.graph(self.graph, stream=s):  # same stream as the warm-up: AccumulateGrad nodes match
                 self.out = self._frame()
         self.grads = [p.grad for p in self.params]  # static gradient buffers refilled by every replay
+        from .rasterizer import last_backward_workspace
+        self.backward_workspace = last_backward_workspace()[0]  # baked into the graph: must live as long as it does
         return self
 
     def run_a(self, cam: Camera = None, gimg: torch.Tensor = None):

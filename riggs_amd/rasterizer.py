@@ -208,7 +208,7 @@ def rasterize_backward(s: _Saved, means3D, shs, colors_precomp, opacities, scale
     if cfg.deterministic:  # (its accumulators are overwritten by the ordered sum: nothing to keep zeroed)
         ws = torch.zeros(lib.riggs_raster_backward_workspace_bytes_ordered(N, s.cap), dtype=torch.uint8, device=dev)
     else:
-        ws = _backward_workspace(lib.riggs_raster_backward_workspace_bytes(N), dev)
+        ws = _backward_workspace(lib.riggs_raster_backward_workspace_bytes(N), dev, N)
     if grad_color is None:  # a loss on depth / alpha only (set_materialize_grads(False) hands None for the unused output)
         grad_color = torch.zeros(3, s.H, s.W, **f32)
     gc = L.require_cuda_f32("grad_color", grad_color, (3, s.H, s.W))
@@ -226,21 +226,34 @@ def rasterize_backward(s: _Saved, means3D, shs, colors_precomp, opacities, scale
     except Exception:
         _WORKSPACES.clear()  # a failed call may leave the accumulators dirty: the next one starts from fresh zeros
         raise
+    _LAST_WORKSPACE[:] = [ws, N]
     if shs_rest is not None:
         g_sh = (g_sh, g_sh_rest)
     return g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rots, g_cov, g_dscaling
 
 
 _WORKSPACES = {}
+_LAST_WORKSPACE = [None, 0]
 
 
-def _backward_workspace(nbytes: int, dev) -> torch.Tensor:
+def last_backward_workspace():
+    """(workspace, N) of the most recent ``rasterize_backward``: behind its accumulators the call leaves which Gaussians
+    received a gradient (include/riggs_hip.h: riggs_grad_rows_pack reads it; riggs_amd.dist.SparseRowExchange)."""
+    if _LAST_WORKSPACE[0] is None:
+        raise RuntimeError("no rasterizer backward has run yet")
+    return _LAST_WORKSPACE[0], _LAST_WORKSPACE[1]
+
+
+def _backward_workspace(nbytes: int, dev, N: int) -> torch.Tensor:
     """The per-Gaussian gradient accumulators of the compositing backward (include/riggs_hip.h: `workspace`): zeroed ONCE
     here, then self-cleaning — the kernels leave them all zero — so a frame pays no fill pass.  One buffer per (device,
-    stream): a backward call uses it from its first to its last kernel on one stream."""
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), L.stream_ptr())
+    stream, N): a backward call uses it from its first to its last kernel on one stream, and the row list behind the
+    accumulators sits at an offset that depends on N (a buffer shared between sizes would find it inside its accumulators)."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), L.stream_ptr(), N)
     ws = _WORKSPACES.get(key)
     if ws is None or ws.numel() < nbytes:
+        if len(_WORKSPACES) >= 8:  # (a training run has one or two sizes alive; densification retires the old ones)
+            _WORKSPACES.pop(next(iter(_WORKSPACES)))
         ws = _WORKSPACES[key] = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
     return ws
 

@@ -240,3 +240,76 @@ def test_compacted_row_exchange_equals_the_dense_all_reduce_and_reports_overflow
         assert need == 25 and over == 200   # rows the fullest rank needed; 200 > capacity 16: the caller must go dense
         for a, b in zip(sparse, dense):
             np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-7)
+
+
+# ---- the gradient-row exchange: protocol over gloo with the numpy restatement of the segment format standing in for
+# the HIP pack / unpack kernels (tests/rows_ref.py; the kernels themselves are checked against it in test_gpu_api.py) ----
+def _w_rows(rank, world):
+    import rows_ref
+    from riggs_amd.dist import SparseRowExchange
+    N = 700                                                 # three blocks of 256, the last one ragged
+    g = torch.Generator().manual_seed(31 + rank)
+    touched = torch.zeros(N, dtype=torch.bool)
+    touched[torch.randperm(N, generator=g)[:60]] = True    # different Gaussians on different ranks, some shared
+    touched[5] = True
+    grads = [torch.zeros(N, 3), torch.zeros(N, 45), torch.zeros(N, 1), torch.zeros(N, 4)]
+    for t in grads:
+        t[touched] = torch.randn(int(touched.sum()), t.shape[1], generator=g)
+    rest = torch.randn(50, generator=g)
+    dense = [t.clone() for t in grads] + [rest.clone()]
+    for t in dense:
+        dist.all_reduce(t)
+        t /= world
+
+    def pack(ex):
+        seg = rows_ref.pack([t.numpy() for t in ex.rows], touched.numpy(), 1.0 / ex.world, ex.capacity, ex.row_floats)
+        ex.segment.copy_(torch.from_numpy(seg))
+
+    def unpack(ex):
+        need, bad = rows_ref.unpack([t.numpy() for t in ex.rows], ex.gathered.view(ex.world, -1).numpy(), ex.capacity, ex.row_floats)
+        ex.status[0], ex.status[1] = need, int(bad)
+
+    out = {}
+    for name, cap in (("fits", 80), ("overflows", 40)):
+        mine = [t.clone() for t in grads]
+        r = rest.clone()
+        ex = SparseRowExchange(mine, rest=r, capacity=cap, pack=pack, unpack=unpack)
+        ex.pack()
+        ex.launch()
+        ex.launch_rest()
+        ex.wait()
+        ok = ex.check()
+        untouched = all(torch.equal(a, b) for a, b in zip(mine, grads))
+        if not ok:
+            ex.dense_fallback()
+        out[name] = (ok, ex.need, untouched, [t.numpy() for t in mine] + [r.numpy()], ex.wins)
+    return out, [t.numpy() for t in dense]
+
+
+def test_gradient_row_exchange_equals_the_dense_mean_and_falls_back_on_overflow():
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    got = _spawn(_w_rows)
+    for r in range(2):
+        out, dense = got[r]
+        ok, need, untouched, vals, wins = out["fits"]
+        assert ok and need == 61 and not untouched and wins
+        for a, b in zip(vals, dense):
+            np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-7)
+        ok, need, untouched, vals, _ = out["overflows"]
+        assert not ok and need == 61 and untouched          # nothing was unpacked: the rows still hold the local gradients
+        for a, b in zip(vals, dense):                       # ... and the dense fallback of that step gives the mean
+            np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-7)
+    for a, b in zip(got[0][0]["fits"][3], got[1][0]["fits"][3]):
+        assert np.array_equal(a, b)                         # replicas are bit-identical after the ordered unpack
+
+
+def test_segment_size_matches_the_library():
+    from riggs_amd import _lib as L
+    from riggs_amd.dist import segment_words
+    import ctypes as C
+    lib = L.lib()
+    w = (C.c_int32 * 6)(3, 45, 1, 3, 3, 4)
+    assert lib.riggs_grad_rows_row_floats(6, w) == 60
+    for N, cap in ((1, 0), (700, 80), (300_000, 30_000), (2_000_000, 1)):
+        assert lib.riggs_grad_rows_segment_bytes(N, 60, cap) == 4 * segment_words(N, 60, cap)

@@ -259,6 +259,14 @@ def test_bench_contract_single_and_two_ranks():
     d2 = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert d2["n_gpus"] == 2 and d2["config"]["parallelism"] == "frames x2" and "cpu_baseline" not in d2
     assert abs(d2["value"] - 2 * 4 / (d2["ms_per_step"] * 4 / 1e3)) < 1e-3 * d2["value"]  # aggregate over both ranks
+    # the default exchange is the packed-row one (bench.py itself compares it with a plain all-reduce after the timed region)
+    assert d2["config"]["exchange"].startswith("packed rows")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29534", "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--exchange", "dense"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d3 = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert d3["n_gpus"] == 2 and d3["config"]["exchange"].startswith("two-phase")
 
 
 def test_dist_knn3_at_initialisation_size():
