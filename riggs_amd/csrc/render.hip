@@ -341,7 +341,10 @@ __device__ __forceinline__ void dual_excl_sum_scan(float& a, float& b) {
 typedef float f2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2v splat2(float v) { return f2v{v, v}; }
 
-template <int NW>  // NW waves per workgroup = parts the tile's 256 pixels are split into
+// NW waves per workgroup = parts the tile's 256 pixels are split into; ORDERED = rows instead of atomics (cfg.deterministic);
+// TRACE = per-chunk statistics (both compiled out of the default instantiation: the ordered branch alone cost 4 VGPRs = one
+// wave per SIMD = 7 us)
+template <int NW, bool ORDERED, bool TRACE>
 __global__ __launch_bounds__(64 * NW) void render_bwd_kernel(RenderBwdArgs a) {
   constexpr int PPW = 256 / NW;    // pixels per wave
   constexpr int RSTEP = NW;        // a wave's rows are part, part + NW, ...
@@ -449,7 +452,7 @@ __global__ __launch_bounds__(64 * NW) void render_bwd_kernel(RenderBwdArgs a) {
   for (uint32_t chunk_item = blockIdx.x; chunk_item < n_chunks; chunk_item += stride) {
     const u4v wk = wk_a;
     const uint32_t id = id_a;
-    const unsigned long long t_begin = a.trace ? wall_clock64() : 0ull;
+    const unsigned long long t_begin = (TRACE && a.trace) ? wall_clock64() : 0ull;
     const int tile = (int)wk.x, chunk = (int)wk.y;
     const int limit = (int)wk.w;
     const int pos0 = chunk * 64;
@@ -550,7 +553,7 @@ __global__ __launch_bounds__(64 * NW) void render_bwd_kernel(RenderBwdArgs a) {
     // ---- only now the atomics, and only for the instances that reach a pixel of this tile: the lists are built
     // from 3-sigma rectangles, most of a tile's instances never get to alpha >= 1/255 inside it, and adding their
     // exact zeros cost a quarter of the kernel (the memory-side atomic units were its one saturated resource)
-    if (a.det_rows) {
+    if constexpr (ORDERED) {
       // ordered-reduction mode: the row of this tile instance, summed per Gaussian by launch_ordered_gather
       if (wave == 0 && active && touched) {
         float* r = a.det_rows + ((size_t)wk.z + (size_t)pos) * 10;
@@ -567,7 +570,7 @@ __global__ __launch_bounds__(64 * NW) void render_bwd_kernel(RenderBwdArgs a) {
     wk_a = wk_b; id_a = id_b; n_a = n_b;
     wk_b = wk_c; id_b = id_c; n_b = n_c;
     wk_c = wk_d;
-    if (a.trace && threadIdx.x == 0) {  // per chunk: {start, end (100 MHz ticks), hardware id, workgroup}
+    if (TRACE && a.trace && threadIdx.x == 0) {  // per chunk: {start, end (100 MHz ticks), hardware id, workgroup}
       unsigned long long* tr = a.trace + (size_t)chunk_item * 4;
       tr[0] = t_begin; tr[1] = wall_clock64();
       tr[2] = (unsigned long long)(__builtin_amdgcn_s_getreg(63492) & 0xFFFFu) | ((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 0xFu) << 16);
@@ -653,7 +656,9 @@ int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s) {
   // 8 workgroups of 4 waves per CU: every SIMD holds 8 pulling waves (grid sizes from 3 to 128 per CU: within 2 %)
   const int64_t max_blocks = 256 * 8;
   const unsigned blocks = (unsigned)((a.n_slots < max_blocks) ? a.n_slots : max_blocks);
-  hipLaunchKernelGGL(render_bwd_kernel<4>, dim3(blocks), dim3(256), 0, s, a);
+  if (a.trace) hipLaunchKernelGGL((render_bwd_kernel<4, false, true>), dim3(blocks), dim3(256), 0, s, a);
+  else if (a.det_rows) hipLaunchKernelGGL((render_bwd_kernel<4, true, false>), dim3(blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((render_bwd_kernel<4, false, false>), dim3(blocks), dim3(256), 0, s, a);
   return 0;
 }
 
