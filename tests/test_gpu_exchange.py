@@ -133,3 +133,49 @@ def test_exchange_rejects_cpu_tensors_and_foreign_workspaces(frames):
     ex = SparseRowExchange([torch.zeros(N + 5, 3, device="cuda")], capacity=4, world=2)
     with pytest.raises(RuntimeError):
         ex.pack()                                                # the last backward was over N Gaussians, not N + 5
+
+
+def test_row_exchange_around_a_split_captured_frame_is_the_identity_at_world_one():
+    """The whole host path on one GPU: a frame captured as two graphs with the pack INSIDE graph (a)
+    (GraphedFrame.after_raster_backward), gather (a copy at world 1), small all-reduce (nothing at world 1), ordered unpack —
+    the gradients come back bit for bit (scale 1, every row occurs once), replay after replay, and rows without a gradient
+    stay exactly zero."""
+    import bench
+    from riggs_amd.dist import FlatGradAllReduce, SparseRowExchange, row_exchange_order
+    from riggs_amd.graph import GraphedFrame
+    old = dict(bench.WORKLOAD)
+    bench.WORKLOAD.update(N=N, J=J, H=H, W=W)
+    try:
+        sc, cam, gm, sw = bench.build_workload(0, "cuda:0")
+    finally:
+        bench.WORKLOAD.clear()
+        bench.WORKLOAD.update(old)
+    ordered, n_rows = row_exchange_order(gm, sw)
+    bucket = FlatGradAllReduce(ordered)
+    try:
+        rows = SparseRowExchange([v.view(N, -1) for v in bucket.views[:n_rows]], rest=bucket.flat[bucket.offsets[n_rows]:], capacity=N)
+        gf = GraphedFrame(gm, sw, cam, torch.zeros(3, device="cuda"), bench.params_of(gm, sw), split_backward=True)
+        gf.after_raster_backward = rows.pack
+        gf.capture()
+        gf.set_inputs(gimg=torch.rand(3, H, W, generator=torch.Generator().manual_seed(3)).cuda())
+        for cam_az in (45.0, 160.0):
+            gf.run_a(cam=synth.look_at_camera(H, W, azimuth_deg=cam_az).to("cuda:0"))
+            rows.launch()
+            gf.run_b()
+            torch.cuda.synchronize()
+            before = [g.clone() for g in rows.rows]
+            rest_before = rows.rest.clone()
+            rows.launch_rest()
+            rows.wait()
+            torch.cuda.synchronize()
+            assert rows.check() and 0 < rows.need < N
+            for a, b in zip(rows.rows, before):
+                assert torch.equal(a, b)
+            assert torch.equal(rows.rest, rest_before)
+            touched = torch.zeros(N, dtype=torch.bool, device="cuda")
+            for g in before:
+                touched |= (g != 0).any(1)
+            assert int(touched.sum()) <= rows.need <= int(touched.sum()) + 0.02 * N
+            assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views))
+    finally:
+        bucket.unregister()
