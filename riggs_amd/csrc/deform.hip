@@ -191,6 +191,8 @@ struct Bone {        // 24 floats, LDS resident
   float inv2r2;      // 1 / (2 exp(rho)^2)            :65-66
   float G[12];       // global transform of the CHILD joint
   float q[4];        // node_rot of the child joint (detached)
+  float rl2;         // 1 / len2c (the all-bones path: no top-K ties to reproduce, so no IEEE division per bone and Gaussian)
+  float pad_[3];     // (records stay multiples of 16 bytes: whole-record ds_read_b128)
 };
 
 struct LbsArgs {
@@ -218,6 +220,8 @@ __device__ __forceinline__ void stage_bones(const LbsArgs& a, Bone* bones) {
     }
     const float l2 = __fadd_rn(__fadd_rn(__fmul_rn(b.ba[0], b.ba[0]), __fmul_rn(b.ba[1], b.ba[1])), __fmul_rn(b.ba[2], b.ba[2]));
     b.len2c = fmaxf(l2, 1e-6f);
+    b.rl2 = 1.0f / b.len2c;
+    b.pad_[0] = 0.f; b.pad_[1] = 0.f; b.pad_[2] = 0.f;
     const float rad = expf(a.node_radius_log[child]);
     b.inv2r2 = 1.0f / (2.0f * rad * rad);
 #pragma unroll
@@ -241,6 +245,16 @@ __device__ __forceinline__ float bone_d2(const Bone& b, float px, float py, floa
   return (sx * sx + sy * sy) + sz * sz;
 }
 
+// The same distance for the all-bones configuration (K = -1): nothing is selected by comparing distances there, so the
+// division becomes a multiplication by the staged reciprocal and contraction is allowed (an IEEE division is ~10 of this
+// function's ~30 instructions, and it runs once per bone and Gaussian).
+__device__ __forceinline__ float bone_d2_fast(const Bone& b, float px, float py, float pz) {
+  const float ex = px - b.a[0], ey = py - b.a[1], ez = pz - b.a[2];
+  const float t = __builtin_amdgcn_fmed3f((ex * b.ba[0] + ey * b.ba[1] + ez * b.ba[2]) * b.rl2, 0.0f, 1.0f);
+  const float sx = t * b.ba[0] - ex, sy = t * b.ba[1] - ey, sz = t * b.ba[2] - ez;
+  return sx * sx + sy * sy + sz * sz;
+}
+
 // Top-K selection (K > 0): bitmask of the K bones with the smallest (d2, index), found by K
 // selection passes over the <= 63 bones.  Already-picked bones are excluded through the mask, so
 // no floating-point value is ever compared for equality across call sites.
@@ -259,6 +273,7 @@ __device__ __forceinline__ uint64_t topk_mask(const Bone* bones, int B, int K, f
   return mask;
 }
 
+template <bool TOPK>
 __global__ __launch_bounds__(256) void lbs_forward_kernel(LbsArgs a) {
   __shared__ Bone bones[MAX_J - 1];
   stage_bones(a, bones);
@@ -266,14 +281,14 @@ __global__ __launch_bounds__(256) void lbs_forward_kernel(LbsArgs a) {
   if (n >= a.N) return;
   const int B = a.J - 1;
   const float px = a.x[3 * n], py = a.x[3 * n + 1], pz = a.x[3 * n + 2];
-  const uint64_t selmask = a.K > 0 ? topk_mask(bones, B, a.K, px, py, pz) : ~0ull;
+  const uint64_t selmask = TOPK ? topk_mask(bones, B, a.K, px, py, pz) : ~0ull;
   float M[12], qa[4] = {0.f, 0.f, 0.f, 0.f}, sum = 0.f;
 #pragma unroll
   for (int e = 0; e < 12; e++) M[e] = 0.f;
   for (int k = 0; k < B; k++) {
     const Bone& b = bones[k];
-    if (!((selmask >> k) & 1ull)) continue;
-    const float d2 = bone_d2(b, px, py, pz);
+    if (TOPK && !((selmask >> k) & 1ull)) continue;
+    const float d2 = TOPK ? bone_d2(b, px, py, pz) : bone_d2_fast(b, px, py, pz);
     float u = fast_exp(-d2 * b.inv2r2);                // skeleton_warp.py:66
     if (a.weight_mod) u *= a.weight_mod[(size_t)n * B + k];  // :68-69
     const float v = u + 1e-7f;                          // :71
@@ -292,7 +307,7 @@ __global__ __launch_bounds__(256) void lbs_forward_kernel(LbsArgs a) {
   a.d_xyz[3 * n] = (ax - px) * m; a.d_xyz[3 * n + 1] = (ay - py) * m; a.d_xyz[3 * n + 2] = (az - pz) * m;
   reinterpret_cast<float4*>(a.d_rot)[n] = make_float4(qa[0] * inv * m, qa[1] * inv * m, qa[2] * inv * m, qa[3] * inv * m);
   if (a.nn_weight || a.nn_idx) {
-    if (a.K > 0) {
+    if (TOPK) {
       // ascending-d2 order like torch.topk(largest=False): K selection passes inside the mask
       uint64_t left = selmask;
       for (int s = 0; s < a.K; s++) {
@@ -308,7 +323,7 @@ __global__ __launch_bounds__(256) void lbs_forward_kernel(LbsArgs a) {
       }
     } else {
       for (int k = 0; k < B; k++) {
-        if (a.nn_weight) a.nn_weight[(size_t)n * B + k] = (fast_exp(-bone_d2(bones[k], px, py, pz) * bones[k].inv2r2) *
+        if (a.nn_weight) a.nn_weight[(size_t)n * B + k] = (fast_exp(-bone_d2_fast(bones[k], px, py, pz) * bones[k].inv2r2) *
                                                               (a.weight_mod ? a.weight_mod[(size_t)n * B + k] : 1.0f) + 1e-7f) * inv;
         if (a.nn_idx) a.nn_idx[(size_t)n * B + k] = k + 1;
       }
@@ -500,7 +515,7 @@ __global__ __launch_bounds__(256) void lbs_backward_bonelane_kernel(LbsArgs a) {
     for (int bb = 0; bb < NBLK; bb++) {
       const int k = bb * LB_BONES + bl;
       const Bone& b = bones[k];
-      d2[bb] = bone_d2(b, px, py, pz);
+      d2[bb] = bone_d2_fast(b, px, py, pz);
       const bool on = valid && (k < B);
       u[bb] = on ? fast_exp(-d2[bb] * b.inv2r2) : 0.f;
       if constexpr (MOD) {
@@ -650,7 +665,8 @@ int riggs_lbs_forward(int32_t N, int32_t J, int32_t K, const float* x, const flo
   if (N == 0) return 0;
   {
     ProfScope ps(PROF_LBS_FWD, (hipStream_t)stream);
-    hipLaunchKernelGGL(lbs_forward_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    if (a.K > 0) hipLaunchKernelGGL(lbs_forward_kernel<true>, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(lbs_forward_kernel<false>, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
   }
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
