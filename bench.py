@@ -451,6 +451,8 @@ def main():
             exchange.launch(2)
             exchange.wait()
             return out
+        if rows is not None:
+            rows.workspace = gf.backward_workspace  # (the eager profiling steps below use another one)
         step()
         torch.cuda.synchronize()
         assert gf.check() == R, "graphed frame disagrees with the eager frame on the instance count"

@@ -389,7 +389,7 @@ def _hip_pack(ex):
     import ctypes as C
     from . import _lib as L
     from .rasterizer import last_backward_workspace
-    ws, n = last_backward_workspace()
+    ws, n = (ex.workspace, ex.N) if ex.workspace is not None else last_backward_workspace()
     if n != ex.N or ws.device != ex.segment.device:
         raise RuntimeError("the last rasterizer backward was not over these %d Gaussians" % ex.N)
     L.check(L.lib().riggs_grad_rows_pack(ex.N, ws.data_ptr(), len(ex.rows), ex._ptrs, ex._widths, C.c_float(1.0 / ex.world if ex.average else 1.0),
@@ -442,6 +442,9 @@ class SparseRowExchange:
         self.status = torch.zeros(2, dtype=torch.int32, device=dev)
         self.pending = []
         self.need = 0
+        # the backward workspace to pack from: None = the one the most recent rasterizer backward used; a caller that runs
+        # other backward passes in between (another stream, an eager profiling step) pins it (GraphedFrame.backward_workspace)
+        self.workspace = None
         # the small dense all-reduce gets its OWN communicator: collectives of one process group run one after the other
         # on that group's internal stream, and this one must not queue behind the all-gather of the rows
         self.rest_group = None
