@@ -381,8 +381,11 @@ int riggs_dist2_knn3(int32_t num_points, const float* points, float* out, void* 
 int riggs_raster_set_trace(void* dev_u64);
 /* =====================================================================
  * Per-Gaussian MLP heads on the matrix cores: WeightMLP / DeformMLP of
- * skeleton_utils/network_utils.py:6-112 as one fused launch per direction — bf16 operands, fp32 accumulation
- * (v_mfma_f32_32x32x16_bf16).  x_emb_bf16 (N rounded up to 128, in_pad) bf16, zero padded -> depth x [Linear(256) + ReLU], the embedding
+ * skeleton_utils/network_utils.py:6-112 as one fused launch per direction — 16-bit operands, fp32 accumulation
+ * (v_mfma_f32_32x32x16_bf16 / _f16).  Every "bf16" buffer below holds the format the `fp16` argument selects, the same in
+ * all five calls: 0 = bfloat16 (fp32's range, 8 significand bits), 1 = IEEE half (11 significand bits: parameter gradients
+ * within 1-2 % of the fp32 arithmetic instead of 3-11 %, same rate; its range is the caller's business — see g_scale).
+ * x_emb_bf16 (N rounded up to 128, in_pad) bf16, zero padded -> depth x [Linear(256) + ReLU], the embedding
  * re-concatenated IN FRONT of the hidden vector after layer `skip` (network_utils.py:58-61, 103-106) -> Linear(out_ch <= 32).
  * weights_bf16[l]: (256, K_l) row-major bf16 with K_0 = in_pad, K_{skip+1} = in_pad + 256, else 256, where
  * in_pad = in_ch rounded up to 32 and the padding columns are zero; w_out_bf16: (32, 256), rows >= out_ch zero.
@@ -394,14 +397,17 @@ int riggs_raster_set_trace(void* dev_u64);
 int riggs_mlp_forward(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip,
                       const void* const* weights_bf16, const float* const* biases, const void* w_out_bf16,
                       const float* b_out, const void* x_emb_bf16, void* acts_bf16, void* relu_masks, float* out,
-                      riggs_stream stream);
+                      int32_t fp16, riggs_stream stream);
 /* Data-gradient pass of the same MLP: g_out (N, out_ch) = dL/d(output) -> dpre_bf16 (depth, N, 256) = dL/d(pre-activation)
  * of every hidden layer, the operand of the weight gradients  dW_l = dpre_l^T · input_l ,  db_l = sum_n dpre_l  (plain
  * GEMMs / reductions, left to the library).  weights_t_bf16[l] (l >= 1): (256, 256) = W_l[:, hidden part]^T;
- * w_out_t_bf16: (256, 32) = W_out^T with zero columns >= out_ch.  No gradient w.r.t. x_emb (detached in the reference). */
+ * w_out_t_bf16: (256, 32) = W_out^T with zero columns >= out_ch.  No gradient w.r.t. x_emb (detached in the reference).
+ * g_scale (device scalar, may be NULL = 1): g_out is multiplied by it on load, so dpre and db_partial come out scaled by it —
+ * with fp16 the caller passes a power of two that lifts max|g_out| to ~2^10 (loss-scaled gradients: a per-pixel-averaged
+ * loss leaves |g_out| ~ 1e-7, below half precision's normal range) and divides the parameter gradients by it. */
 int riggs_mlp_backward(int32_t N, int32_t out_ch, int32_t depth, int32_t skip, const void* const* weights_t_bf16,
-                       const void* w_out_t_bf16, const float* g_out, const void* relu_masks, void* dpre_bf16,
-                       float* db_partial, riggs_stream stream);
+                       const void* w_out_t_bf16, const float* g_out, const float* g_scale, const void* relu_masks,
+                       void* dpre_bf16, float* db_partial, int32_t fp16, riggs_stream stream);
 /* db_partial: (ceil(N / riggs_mlp_rows_per_workgroup()), depth, 256) fp32 — per-workgroup column sums of dpre; the bias
  * gradients are their sum over the first axis */
 int32_t riggs_mlp_rows_per_workgroup(void);
@@ -409,12 +415,12 @@ int32_t riggs_mlp_rows_per_workgroup(void);
  * read (layouts above), in one launch. */
 int riggs_mlp_pack(int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip, const float* const* weights, const float* w_out,
                    void* const* weights_bf16, void* const* weights_t_bf16, void* w_out_bf16, void* w_out_t_bf16,
-                   riggs_stream stream);
+                   int32_t fp16, riggs_stream stream);
 /* The kernels' input operand from positions: row n = [x_n, sin(2^k x_n), cos(2^k x_n) for k < multires, tail (n_tail floats,
  * the same for every row: DeformMLP's pose), 0 ...] as bf16, (N rounded up to 128) x (width rounded up to 32)
  * (utils/time_utils.py:208-256 get_embedder + the concatenation of network_utils.py:40-46). */
 int riggs_mlp_embed(int32_t N, int32_t multires, int32_t n_tail, const float* x, const float* tail, void* out_bf16,
-                    riggs_stream stream);
+                    int32_t fp16, riggs_stream stream);
 /* self-test of the MFMA fragment layouts mlp.hip assumes: writes D = A B for A = [I_16; 0] and an asymmetric B */
 int riggs_mlp_layout_probe(float* out32x32, riggs_stream stream);
 

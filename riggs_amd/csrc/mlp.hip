@@ -36,6 +36,23 @@ __device__ __forceinline__ unsigned short f2bf(float f) {  // round to nearest e
   return (unsigned short)(u >> 16);
 }
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((uint32_t)h << 16); }
+// The 16-bit operand format is a template parameter of every kernel: bf16 (fp32's range, 8 significand bits) or fp16
+// (11 significand bits: an eighth of bf16's rounding error per operand — parameter gradients within 1-2 % of the fp32
+// mirror instead of 3-11 % — at the same MFMA rate; its narrow range is handled by the caller: the incoming gradient is
+// scaled by a power of two on the device (riggs_mlp_backward: g_scale) and the parameter gradients scaled back).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <bool H16> __device__ __forceinline__ unsigned short f2h(float f) {
+  if constexpr (H16) return __builtin_bit_cast(unsigned short, (_Float16)f);  // v_cvt_f16_f32: round to nearest even
+  else return f2bf(f);
+}
+template <bool H16> __device__ __forceinline__ float h2f(unsigned short h) {
+  if constexpr (H16) return (float)__builtin_bit_cast(_Float16, h);
+  else return bf2f(h);
+}
+template <bool H16> __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (H16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 
 struct MlpDesc {
   int N, in_ch, in_pad, out_ch, depth, skip;
@@ -49,7 +66,7 @@ __device__ __forceinline__ int mlp_k(const MlpDesc& d, int l) { return l == 0 ? 
 
 // acc[rt][ct] += A(rows 32 rt .. +31, k) * B(k, cols col0 + 32 ct .. +31) over k in [0, K): A from LDS (row stride
 // `as` bf16), B[k][n] = Wrow[n][k] with row stride `ws` bf16 in global memory
-template <int RT, int CT>
+template <int RT, int CT, bool H16>
 __device__ __forceinline__ void mlp_gemm_part(f32x16 (&acc)[RT][CT], const unsigned short* A, int as, const unsigned short* Wg,
                                               int ws, int K, int lane) {
   const int r = lane & 31, kq = (lane >> 5) * 8;
@@ -69,7 +86,7 @@ __device__ __forceinline__ void mlp_gemm_part(f32x16 (&acc)[RT][CT], const unsig
 #pragma unroll
     for (int rt = 0; rt < RT; rt++)
 #pragma unroll
-      for (int ct = 0; ct < CT; ct++) acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rt], b[ct], acc[rt][ct], 0, 0, 0);
+      for (int ct = 0; ct < CT; ct++) acc[rt][ct] = mfma16<H16>(a[rt], b[ct], acc[rt][ct]);
 #pragma unroll
     for (int rt = 0; rt < RT; rt++) a[rt] = an[rt];
 #pragma unroll
@@ -80,7 +97,7 @@ __device__ __forceinline__ void mlp_gemm_part(f32x16 (&acc)[RT][CT], const unsig
 // C/D layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 __device__ __forceinline__ int mlp_c_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
-template <int RT>  // 32-row tiles per workgroup (rows per workgroup = 32 RT); every wave owns 64 output columns of all of them
+template <int RT, bool H16>  // 32-row tiles per workgroup (rows per workgroup = 32 RT); every wave owns 64 output columns of all of them
 __global__ __launch_bounds__(256, RT == 2 ? 3 : 2) void mlp_forward_kernel(MlpDesc d, const unsigned short* __restrict__ xb,
                                                                             unsigned short* __restrict__ acts /* [depth][N][256] or NULL */,
                                                                             uint4* __restrict__ masks /* [depth][workgroups][256] or NULL */,
@@ -103,11 +120,11 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 2) void mlp_forward_kernel(MlpDe
         for (int e = 0; e < 16; e++) acc[rt][ct][e] = 0.f;
     const int K = mlp_k(d, l);
     const unsigned short* Wl = d.Wp[l] + (size_t)col0 * K;
-    if (l == 0) mlp_gemm_part<RT, 2>(acc, xrow, d.in_pad, Wl, K, d.in_pad, lane);
+    if (l == 0) mlp_gemm_part<RT, 2, H16>(acc, xrow, d.in_pad, Wl, K, d.in_pad, lane);
     else if (l == d.skip + 1) {
-      mlp_gemm_part<RT, 2>(acc, xrow, d.in_pad, Wl, K, d.in_pad, lane);
-      mlp_gemm_part<RT, 2>(acc, s_h, MLP_HS, Wl + d.in_pad, K, MLP_W, lane);
-    } else mlp_gemm_part<RT, 2>(acc, s_h, MLP_HS, Wl, K, MLP_W, lane);
+      mlp_gemm_part<RT, 2, H16>(acc, xrow, d.in_pad, Wl, K, d.in_pad, lane);
+      mlp_gemm_part<RT, 2, H16>(acc, s_h, MLP_HS, Wl + d.in_pad, K, MLP_W, lane);
+    } else mlp_gemm_part<RT, 2, H16>(acc, s_h, MLP_HS, Wl, K, MLP_W, lane);
     __syncthreads();  // every wave is done reading the previous hidden vector
     uint32_t mbits[4] = {0u, 0u, 0u, 0u};  // ReLU mask of this lane's accumulator elements: bit (rt * 2 + ct) * 16 + e
 #pragma unroll
@@ -120,7 +137,7 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 2) void mlp_forward_kernel(MlpDe
         for (int e = 0; e < 16; e++) {
           const int row = 32 * rt + mlp_c_row(e, lane);
           const float v = acc[rt][ct][e] + b;
-          const unsigned short hv = f2bf(fmaxf(v, 0.f));
+          const unsigned short hv = f2h<H16>(fmaxf(v, 0.f));
           s_h[row * MLP_HS + col] = hv;
           if ((hv & 0x7FFFu) != 0u) mbits[(rt * 2 + ct) >> 1] |= 1u << ((((rt * 2 + ct) & 1) << 4) + e);
         }
@@ -143,7 +160,7 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 2) void mlp_forward_kernel(MlpDe
     f32x16 acc[1][1];
 #pragma unroll
     for (int e = 0; e < 16; e++) acc[0][0][e] = 0.f;
-    mlp_gemm_part<1, 1>(acc, s_h + (size_t)(32 * wave) * MLP_HS, MLP_HS, d.Wout, MLP_W, MLP_W, lane);
+    mlp_gemm_part<1, 1, H16>(acc, s_h + (size_t)(32 * wave) * MLP_HS, MLP_HS, d.Wout, MLP_W, MLP_W, lane);
     const int col = lane & 31;
     if (col < d.out_ch) {
       const float b = d.bout[col];
@@ -167,8 +184,9 @@ struct MlpBwdDesc {
   const unsigned short* Wout_t;   // [256 (k)][32 (c)] bf16, columns >= out_ch zero
 };
 
-template <int RT>
+template <int RT, bool H16>
 __global__ __launch_bounds__(256, RT == 2 ? 3 : 2) void mlp_backward_kernel(MlpBwdDesc d, const float* __restrict__ g_out,
+                                                           const float* __restrict__ g_scale /* device scalar or NULL */,
                                                            const uint4* __restrict__ masks /* [depth][workgroups][256], from the forward */,
                                                            unsigned short* __restrict__ dpre /* [depth][N][256] */,
                                                            float* __restrict__ db_part /* [workgroups][depth][256] */) {
@@ -177,11 +195,12 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 2) void mlp_backward_kernel(MlpB
   __shared__ unsigned short s_g[ROWS * 40];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = blockIdx.x * ROWS;
+  const float gs = g_scale ? g_scale[0] : 1.0f;
   for (int e = tid; e < ROWS * 32; e += 256) {
     const int r = e >> 5, c = e & 31;
     float v = 0.f;
-    if (row0 + r < d.N && c < d.out_ch) v = g_out[(size_t)(row0 + r) * d.out_ch + c];
-    s_g[r * 40 + c] = f2bf(v);
+    if (row0 + r < d.N && c < d.out_ch) v = g_out[(size_t)(row0 + r) * d.out_ch + c] * gs;
+    s_g[r * 40 + c] = f2h<H16>(v);
   }
   __syncthreads();
   const int col0 = wave * 64;
@@ -194,8 +213,8 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 2) void mlp_backward_kernel(MlpB
       for (int ct = 0; ct < 2; ct++)
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[rt][ct][e] = 0.f;
-    if (l == d.depth - 1) mlp_gemm_part<RT, 2>(acc, s_g, 40, d.Wout_t + (size_t)col0 * 32, 32, 32, lane);
-    else mlp_gemm_part<RT, 2>(acc, s_d, MLP_HS, d.Wt[l + 1] + (size_t)col0 * MLP_W, MLP_W, MLP_W, lane);
+    if (l == d.depth - 1) mlp_gemm_part<RT, 2, H16>(acc, s_g, 40, d.Wout_t + (size_t)col0 * 32, 32, 32, lane);
+    else mlp_gemm_part<RT, 2, H16>(acc, s_d, MLP_HS, d.Wt[l + 1] + (size_t)col0 * MLP_W, MLP_W, MLP_W, lane);
     __syncthreads();  // every wave is done reading d_pre_{l+1}
     // ---- d_pre_l = d_post_l where the forward's activation was positive (mask bits in this lane's accumulator layout)
     const uint4 mk = masks[((size_t)l * gridDim.x + blockIdx.x) * 256 + tid];
@@ -208,7 +227,7 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 2) void mlp_backward_kernel(MlpB
         const uint32_t m16 = mbits[(rt * 2 + ct) >> 1] >> (((rt * 2 + ct) & 1) << 4);
 #pragma unroll
         for (int e = 0; e < 16; e++)
-          s_d[(32 * rt + mlp_c_row(e, lane)) * MLP_HS + col] = ((m16 >> e) & 1u) ? f2bf(acc[rt][ct][e]) : (unsigned short)0;
+          s_d[(32 * rt + mlp_c_row(e, lane)) * MLP_HS + col] = ((m16 >> e) & 1u) ? f2h<H16>(acc[rt][ct][e]) : (unsigned short)0;
       }
     }
     __syncthreads();
@@ -224,7 +243,7 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 2) void mlp_backward_kernel(MlpB
     {
       float sum = 0.f;
 #pragma unroll 8
-      for (int r = 0; r < ROWS; r++) sum += bf2f(s_d[r * MLP_HS + tid]);
+      for (int r = 0; r < ROWS; r++) sum += h2f<H16>(s_d[r * MLP_HS + tid]);
       db_part[((size_t)blockIdx.x * d.depth + l) * MLP_W + tid] = sum;
     }
   }
@@ -233,6 +252,7 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 2) void mlp_backward_kernel(MlpB
 // Positional encoding straight into the kernels' operand: row n = [x_n, sin(2^k x_n), cos(2^k x_n) (k < multires), tail, 0 ...]
 // as bf16, (rows rounded up to 128) x in_pad — get_embedder of utils/time_utils.py:208-256 followed by the concatenation
 // with a per-call constant vector (DeformMLP's pose), instead of ~45 elementwise launches and a 75 MB fp32 intermediate.
+template <bool H16>
 __global__ __launch_bounds__(256) void mlp_embed_kernel(int N, int n_rows, int multires, int n_tail, int in_pad,
                                                         const float* __restrict__ x, const float* __restrict__ tail,
                                                         unsigned short* __restrict__ out) {
@@ -257,7 +277,7 @@ __global__ __launch_bounds__(256) void mlp_embed_kernel(int N, int n_rows, int m
         const float a = xv[w % 3] * (float)(1 << k);
         f = (w < 3) ? sinf(a) : cosf(a);
       } else if (c < pe + n_tail) f = tail[c - pe];
-      v[q] = (short)f2bf(f);
+      v[q] = (short)f2h<H16>(f);
     }
   }
   *reinterpret_cast<bf16x8*>(out + (size_t)n * in_pad + c0) = v;
@@ -274,17 +294,18 @@ struct MlpPackDesc {
   unsigned short* Wout_p;        // (32, 256)
   unsigned short* Wout_t;        // (256, 32)
 };
+template <bool H16>
 __global__ __launch_bounds__(256) void mlp_pack_kernel(MlpPackDesc d) {
   const int l = blockIdx.y;  // depth = the head
   const int tid = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
   if (l == d.depth) {
     for (int e = tid; e < 32 * MLP_W; e += stride) {
       const int c = e / MLP_W, k = e - c * MLP_W;
-      d.Wout_p[e] = f2bf(c < d.out_ch ? d.Wout[(size_t)c * MLP_W + k] : 0.f);
+      d.Wout_p[e] = f2h<H16>(c < d.out_ch ? d.Wout[(size_t)c * MLP_W + k] : 0.f);
     }
     for (int e = tid; e < MLP_W * 32; e += stride) {
       const int k = e >> 5, c = e & 31;
-      d.Wout_t[e] = f2bf(c < d.out_ch ? d.Wout[(size_t)c * MLP_W + k] : 0.f);
+      d.Wout_t[e] = f2h<H16>(c < d.out_ch ? d.Wout[(size_t)c * MLP_W + k] : 0.f);
     }
     return;
   }
@@ -298,12 +319,12 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(MlpPackDesc d) {
     float v = 0.f;
     if (first || (sk && k < hoff_pad)) { if (k < d.in_ch) v = W[(size_t)n * k_true + k]; }
     else v = W[(size_t)n * k_true + hoff_true + (k - hoff_pad)];
-    d.Wp[l][e] = f2bf(v);
+    d.Wp[l][e] = f2h<H16>(v);
   }
   if (!first)
     for (int e = tid; e < MLP_W * MLP_W; e += stride) {
       const int k = e >> 8, n = e & 255;
-      d.Wt[l][e] = f2bf(W[(size_t)n * k_true + hoff_true + k]);
+      d.Wt[l][e] = f2h<H16>(W[(size_t)n * k_true + hoff_true + k]);
     }
 }
 
@@ -357,21 +378,23 @@ static int mlp_fill(MlpDesc& d, int32_t N, int32_t in_ch, int32_t out_ch, int32_
 
 int riggs_mlp_forward(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip, const void* const* weights_bf16,
                       const float* const* biases, const void* w_out_bf16, const float* b_out, const void* x_emb_bf16,
-                      void* acts_bf16, void* relu_masks, float* out, riggs_stream stream) {
+                      void* acts_bf16, void* relu_masks, float* out, int32_t fp16, riggs_stream stream) {
   MlpDesc d;
   int rc = mlp_fill(d, N, in_ch, out_ch, depth, skip, weights_bf16, biases, w_out_bf16, b_out);
   if (rc) return rc;
   if (N == 0) return 0;
   RIGGS_REQUIRE(x_emb_bf16 && out, "MLP input / output pointers");
-  hipLaunchKernelGGL(mlp_forward_kernel<MLP_RT>, dim3((N + 127) / 128), dim3(256), 0, (hipStream_t)stream, d,
-                     (const unsigned short*)x_emb_bf16, (unsigned short*)acts_bf16, (uint4*)relu_masks, out);
+  if (fp16) hipLaunchKernelGGL((mlp_forward_kernel<MLP_RT, true>), dim3((N + 127) / 128), dim3(256), 0, (hipStream_t)stream, d,
+                               (const unsigned short*)x_emb_bf16, (unsigned short*)acts_bf16, (uint4*)relu_masks, out);
+  else hipLaunchKernelGGL((mlp_forward_kernel<MLP_RT, false>), dim3((N + 127) / 128), dim3(256), 0, (hipStream_t)stream, d,
+                          (const unsigned short*)x_emb_bf16, (unsigned short*)acts_bf16, (uint4*)relu_masks, out);
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
 int riggs_mlp_backward(int32_t N, int32_t out_ch, int32_t depth, int32_t skip, const void* const* weights_t_bf16,
-                       const void* w_out_t_bf16, const float* g_out, const void* relu_masks, void* dpre_bf16,
-                       float* db_partial, riggs_stream stream) {
+                       const void* w_out_t_bf16, const float* g_out, const float* g_scale, const void* relu_masks, void* dpre_bf16,
+                       float* db_partial, int32_t fp16, riggs_stream stream) {
   RIGGS_REQUIRE(N >= 0 && depth >= 1 && depth <= 10, "MLP depth out of range");
   RIGGS_REQUIRE(out_ch >= 1 && out_ch <= 32, "MLP output width must be <= 32");
   if (N == 0) return 0;
@@ -380,14 +403,16 @@ int riggs_mlp_backward(int32_t N, int32_t out_ch, int32_t depth, int32_t skip, c
   for (int l = 0; l < depth; l++) { d.Wt[l] = (const unsigned short*)weights_t_bf16[l]; RIGGS_REQUIRE(l == 0 || d.Wt[l], "MLP transposed weights"); }
   d.Wout_t = (const unsigned short*)w_out_t_bf16;
   RIGGS_REQUIRE(d.Wout_t && g_out && relu_masks && dpre_bf16 && db_partial, "MLP backward pointers");
-  hipLaunchKernelGGL(mlp_backward_kernel<MLP_RT>, dim3((N + 127) / 128), dim3(256), 0, (hipStream_t)stream, d, g_out,
-                     (const uint4*)relu_masks, (unsigned short*)dpre_bf16, db_partial);
+  if (fp16) hipLaunchKernelGGL((mlp_backward_kernel<MLP_RT, true>), dim3((N + 127) / 128), dim3(256), 0, (hipStream_t)stream, d, g_out,
+                               g_scale, (const uint4*)relu_masks, (unsigned short*)dpre_bf16, db_partial);
+  else hipLaunchKernelGGL((mlp_backward_kernel<MLP_RT, false>), dim3((N + 127) / 128), dim3(256), 0, (hipStream_t)stream, d, g_out,
+                          g_scale, (const uint4*)relu_masks, (unsigned short*)dpre_bf16, db_partial);
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
 int riggs_mlp_embed(int32_t N, int32_t multires, int32_t n_tail, const float* x, const float* tail, void* out_bf16,
-                    riggs_stream stream) {
+                    int32_t fp16, riggs_stream stream) {
   RIGGS_REQUIRE(N >= 0 && multires >= 0 && n_tail >= 0, "MLP embedding arguments");
   const int in_ch = 3 * (1 + 2 * multires) + n_tail, in_pad = (in_ch + 31) & ~31;
   RIGGS_REQUIRE(in_ch <= MLP_MAX_IN, "MLP input width must be <= 128");
@@ -395,15 +420,17 @@ int riggs_mlp_embed(int32_t N, int32_t multires, int32_t n_tail, const float* x,
   if (n_rows == 0) return 0;
   RIGGS_REQUIRE(x && out_bf16 && (n_tail == 0 || tail), "MLP embedding pointers");
   const size_t n_thr = (size_t)n_rows * (in_pad >> 3);
-  hipLaunchKernelGGL(mlp_embed_kernel, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N, n_rows, multires, n_tail,
-                     in_pad, x, tail, (unsigned short*)out_bf16);
+  if (fp16) hipLaunchKernelGGL(mlp_embed_kernel<true>, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N, n_rows,
+                               multires, n_tail, in_pad, x, tail, (unsigned short*)out_bf16);
+  else hipLaunchKernelGGL(mlp_embed_kernel<false>, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N, n_rows,
+                          multires, n_tail, in_pad, x, tail, (unsigned short*)out_bf16);
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
 int riggs_mlp_pack(int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip, const float* const* weights, const float* w_out,
                    void* const* weights_bf16, void* const* weights_t_bf16, void* w_out_bf16, void* w_out_t_bf16,
-                   riggs_stream stream) {
+                   int32_t fp16, riggs_stream stream) {
   RIGGS_REQUIRE(depth >= 1 && depth <= 10 && in_ch >= 1 && in_ch <= MLP_MAX_IN && out_ch >= 1 && out_ch <= 32 && skip >= 0 &&
                 skip < depth - 1, "MLP shape out of range");
   MlpPackDesc d;
@@ -414,7 +441,8 @@ int riggs_mlp_pack(int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip, c
   }
   d.Wout = w_out; d.Wout_p = (unsigned short*)w_out_bf16; d.Wout_t = (unsigned short*)w_out_t_bf16;
   RIGGS_REQUIRE(d.Wout && d.Wout_p && d.Wout_t, "MLP pack head pointers");
-  hipLaunchKernelGGL(mlp_pack_kernel, dim3(32, depth + 1), dim3(256), 0, (hipStream_t)stream, d);
+  if (fp16) hipLaunchKernelGGL(mlp_pack_kernel<true>, dim3(32, depth + 1), dim3(256), 0, (hipStream_t)stream, d);
+  else hipLaunchKernelGGL(mlp_pack_kernel<false>, dim3(32, depth + 1), dim3(256), 0, (hipStream_t)stream, d);
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -1,10 +1,13 @@
 """Fused per-Gaussian MLP heads on the CDNA4 matrix cores (csrc/mlp.hip).
 
 ``FusedHead`` wraps a WeightMLP / DeformMLP host mirror (riggs_amd.skeleton): same parameters (fp32 masters, the ones
-the optimizer and the checkpoints see), but forward and backward run as ONE HIP launch each with bf16 operands and
-fp32 accumulation; the weight gradients are (256 x N)·(N x K) GEMMs handed to hipBLASLt (bf16 in, fp32 out).
-The reference computes these MLPs in fp32 (skeleton_utils/network_utils.py:6-112), so this path is OPT-IN
-(``SkeletonWarp.use_fused_heads(True)``) and is tested against the fp32 mirrors at bf16 tolerance.
+the optimizer and the checkpoints see), but forward and backward run as ONE HIP launch each with 16-bit operands and
+fp32 accumulation; the weight gradients are (256 x N)·(N x K) GEMMs handed to hipBLASLt (16-bit in, fp32 out: they
+already run at the HBM roof).  The operand format is a choice: ``"fp16"`` (default: 11 significand bits —
+parameter gradients within ~2 % of the fp32 mirror; the incoming gradient is scaled by a power of two on the device so
+that half precision's narrow range is never the limit, and the parameter gradients are scaled back) or ``"bf16"``
+(8 bits, fp32's range, 3-11 % on the gradients).  The reference computes these MLPs in fp32
+(skeleton_utils/network_utils.py:6-112), so the path is OPT-IN (``SkeletonWarp.use_fused_heads(True)``).
 """
 from __future__ import annotations
 
@@ -15,6 +18,14 @@ import torch
 from . import _lib as L
 
 ROWS = 64
+FORMATS = {"fp16": torch.float16, "bf16": torch.bfloat16}
+DEFAULT_FORMAT = "fp16"
+
+
+def _fmt_dtype(fmt):
+    if fmt not in FORMATS:
+        raise ValueError("operand format must be 'fp16' or 'bf16'")
+    return FORMATS[fmt]
 
 
 def layout_probe() -> torch.Tensor:
@@ -35,12 +46,14 @@ class Packed:
     """bf16 copies of the weights in the kernels' layouts.  The buffers are allocated once; ``repack()`` refills them from
     the fp32 masters with one launch (``riggs_mlp_pack``) whenever those changed."""
 
-    def __init__(self, linears, head, in_ch: int, skip: int):
+    def __init__(self, linears, head, in_ch: int, skip: int, fmt: str = None):
         dev = head.weight.device
+        self.fmt = fmt or DEFAULT_FORMAT
+        self.dtype, self.fp16 = _fmt_dtype(self.fmt), int(self.fmt == "fp16")
         self.linears, self.head = list(linears), head
         self.in_ch, self.in_pad, self.skip, self.depth = in_ch, (in_ch + 31) & ~31, skip, len(self.linears)
         self.out_ch = head.weight.shape[0]
-        bf = dict(dtype=torch.bfloat16, device=dev)
+        bf = dict(dtype=self.dtype, device=dev)
         kpad = [self.in_pad if l == 0 else (self.in_pad + 256 if l == skip + 1 else 256) for l in range(self.depth)]
         self.w = [torch.empty(256, k, **bf) for k in kpad]
         self.wt = [None] + [torch.empty(256, 256, **bf) for _ in range(1, self.depth)]
@@ -55,7 +68,7 @@ class Packed:
         wo = L.require_cuda_f32("head weight", self.head.weight.detach())
         src = (C.c_void_p * self.depth)(*[t.data_ptr() for t in ws])
         L.check(L.lib().riggs_mlp_pack(self.in_ch, self.out_ch, self.depth, self.skip, src, wo.data_ptr(), self._wp, self._wtp,
-                                       self.w_out.data_ptr(), self.w_out_t_bf16.data_ptr(), L.stream_ptr()), "riggs_mlp_pack")
+                                       self.w_out.data_ptr(), self.w_out_t_bf16.data_ptr(), self.fp16, L.stream_ptr()), "riggs_mlp_pack")
         self.b = [L.require_cuda_f32("bias", lin.bias.detach()) for lin in self.linears]  # (views of the masters)
         self.b_out = L.require_cuda_f32("head bias", self.head.bias.detach())
         self._bp = (C.c_void_p * self.depth)(*[t.data_ptr() for t in self.b])
@@ -66,22 +79,24 @@ def embed_bf16(p: Packed, x_emb: torch.Tensor) -> torch.Tensor:
     skip layer, and the right-hand side of their weight gradients."""
     N = x_emb.shape[0]
     x_emb = L.require_cuda_f32("x_emb", x_emb, (N, p.in_ch))
-    xb = torch.zeros((N + 127) // 128 * 128, p.in_pad, dtype=torch.bfloat16, device=x_emb.device)
+    xb = torch.zeros((N + 127) // 128 * 128, p.in_pad, dtype=p.dtype, device=x_emb.device)
     xb[:N, :p.in_ch] = x_emb
     return xb
 
 
-def embed_positions_bf16(x: torch.Tensor, multires: int, tail: torch.Tensor = None) -> torch.Tensor:
-    """[x, sin(2^k x), cos(2^k x) ..., tail] per row as the kernels' padded bf16 operand, in one launch (``tail``: a vector
-    appended to every row — DeformMLP's pose)."""
+def embed_positions_bf16(x: torch.Tensor, multires: int, tail: torch.Tensor = None, fmt: str = None) -> torch.Tensor:
+    """[x, sin(2^k x), cos(2^k x) ..., tail] per row as the kernels' padded 16-bit operand (``fmt``), in one launch (``tail``:
+    a vector appended to every row — DeformMLP's pose)."""
+    dtype = _fmt_dtype(fmt or DEFAULT_FORMAT)
     N = x.shape[0]
     x = L.require_cuda_f32("x", x, (N, 3))
     n_tail = 0 if tail is None else tail.numel()
     in_pad = (3 * (1 + 2 * multires) + n_tail + 31) & ~31
     if tail is not None:
         tail = L.require_cuda_f32("tail", tail.reshape(-1))
-    xb = torch.empty((N + 127) // 128 * 128, in_pad, dtype=torch.bfloat16, device=x.device)
-    L.check(L.lib().riggs_mlp_embed(N, multires, n_tail, x.data_ptr(), L.ptr(tail), xb.data_ptr(), L.stream_ptr()), "riggs_mlp_embed")
+    xb = torch.empty((N + 127) // 128 * 128, in_pad, dtype=dtype, device=x.device)
+    L.check(L.lib().riggs_mlp_embed(N, multires, n_tail, x.data_ptr(), L.ptr(tail), xb.data_ptr(), int(dtype == torch.float16),
+                                    L.stream_ptr()), "riggs_mlp_embed")
     return xb
 
 
@@ -93,23 +108,34 @@ def forward(p: Packed, x_emb: torch.Tensor, want_acts: bool, xb: torch.Tensor = 
     acts = masks = None
     if want_acts:
         rows = L.lib().riggs_mlp_rows_per_workgroup()
-        acts = torch.empty(p.depth, N, 256, dtype=torch.bfloat16, device=x_emb.device)
+        acts = torch.empty(p.depth, N, 256, dtype=p.dtype, device=x_emb.device)
         masks = torch.empty(p.depth, (N + rows - 1) // rows, 256, 4, dtype=torch.int32, device=x_emb.device)
     L.check(L.lib().riggs_mlp_forward(N, p.in_ch, p.out_ch, p.depth, p.skip, p._wp, p._bp, p.w_out.data_ptr(),
-                                      p.b_out.data_ptr(), xb.data_ptr(), L.ptr(acts), L.ptr(masks), out.data_ptr(),
+                                      p.b_out.data_ptr(), xb.data_ptr(), L.ptr(acts), L.ptr(masks), out.data_ptr(), p.fp16,
                                       L.stream_ptr()), "riggs_mlp_forward")
     return out, (acts, masks) if want_acts else None
 
 
-def backward_data(p: Packed, g_out: torch.Tensor, masks: torch.Tensor) -> torch.Tensor:
-    """dL/d(pre-activation) of every hidden layer as bf16 (depth, N, 256), and the bias gradients (depth, 256)."""
+def grad_scale(g_out: torch.Tensor) -> torch.Tensor:
+    """The power of two (a device scalar: no host synchronisation) that lifts max|g_out| to ~2^10: with fp16 operands the
+    gradients of a per-pixel-averaged loss (1e-6 .. 1e-9) would otherwise sit in half precision's subnormals."""
+    if g_out.numel() == 0:
+        return torch.ones(1, device=g_out.device)
+    amax = g_out.abs().amax().clamp_min(1e-30)
+    return torch.exp2(torch.floor(torch.log2(1024.0 / amax))).reshape(1)
+
+
+def backward_data(p: Packed, g_out: torch.Tensor, masks: torch.Tensor, scale: torch.Tensor = None) -> torch.Tensor:
+    """dL/d(pre-activation) of every hidden layer in the 16-bit format (depth, N, 256), and the bias gradients (depth, 256)
+    — both times ``scale`` when given (``grad_scale``)."""
     N = g_out.shape[0]
     g_out = L.require_cuda_f32("g_out", g_out, (N, p.out_ch))
-    dpre = torch.empty(p.depth, N, 256, dtype=torch.bfloat16, device=g_out.device)
+    dpre = torch.empty(p.depth, N, 256, dtype=p.dtype, device=g_out.device)
     rows = L.lib().riggs_mlp_rows_per_workgroup()
     db_part = torch.empty((N + rows - 1) // rows, p.depth, 256, device=g_out.device)
     L.check(L.lib().riggs_mlp_backward(N, p.out_ch, p.depth, p.skip, p._wtp, p.w_out_t_bf16.data_ptr(), g_out.data_ptr(),
-                                       masks.data_ptr(), dpre.data_ptr(), db_part.data_ptr(), L.stream_ptr()), "riggs_mlp_backward")
+                                       L.ptr(scale), masks.data_ptr(), dpre.data_ptr(), db_part.data_ptr(), p.fp16,
+                                       L.stream_ptr()), "riggs_mlp_backward")
     return dpre, db_part.sum(0)
 
 
@@ -152,10 +178,10 @@ _ONES = {}
 def _colsum(d: torch.Tensor) -> torch.Tensor:
     """Column sums of a tall bf16 matrix in fp32, as a (split-K) GEMM with a block of ones: torch's column reduction of a
     (3e5, 256) bf16 tensor takes 0.09 ms and of a (3e5, 23) fp32 one 0.6 ms; this is ~0.03 ms."""
-    key = (d.device, d.shape[0])
+    key = (d.device, d.shape[0], d.dtype)
     ones = _ONES.get(key)
     if ones is None:
-        ones = _ONES[key] = torch.ones(d.shape[0], 8, dtype=torch.bfloat16, device=d.device)
+        ones = _ONES[key] = torch.ones(d.shape[0], 8, dtype=d.dtype, device=d.device)
     return _wgrad(d, ones)[:, 0].contiguous()
 
 
@@ -165,8 +191,8 @@ class _FusedMLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_emb, head, *params):
         p = head._packed()
-        n_rows = head._n_rows if x_emb.dtype == torch.bfloat16 else x_emb.shape[0]
-        xb = x_emb if x_emb.dtype == torch.bfloat16 else embed_bf16(p, x_emb)
+        n_rows = head._n_rows if x_emb.dtype == p.dtype else x_emb.shape[0]
+        xb = x_emb if x_emb.dtype == p.dtype else embed_bf16(p, x_emb)
         out, (acts, masks) = forward(p, xb[:n_rows], True, xb)
         ctx.head, ctx.p, ctx.n = head, p, n_rows
         ctx.save_for_backward(xb, acts, masks)
@@ -177,7 +203,8 @@ class _FusedMLP(torch.autograd.Function):
         xb, acts, masks = ctx.saved_tensors
         p = ctx.p
         g_out = g_out.contiguous()
-        dpre, db = backward_data(p, g_out, masks)
+        scale = grad_scale(g_out) if p.fp16 else None
+        dpre, db = backward_data(p, g_out, masks, scale)
         xb = xb[:ctx.n]
         # hidden-to-hidden layers share shapes: one batched split-K GEMM per run of consecutive layers (1 .. skip and
         # skip + 2 .. depth - 1) instead of one per layer
@@ -193,8 +220,11 @@ class _FusedMLP(torch.autograd.Function):
         grads = []
         for l in range(p.depth):
             grads += [gws[l], db[l]]
-        gob = torch.nn.functional.pad(g_out, (0, 32 - p.out_ch)).to(torch.bfloat16)
+        gob = torch.nn.functional.pad(g_out if scale is None else g_out * scale, (0, 32 - p.out_ch)).to(p.dtype)
         grads += [_wgrad(gob, acts[p.depth - 1])[:p.out_ch], _colsum(gob)[:p.out_ch]]
+        if scale is not None:  # every product above carries the factor once: take it out again (a power of two: exact)
+            grads = [g.contiguous() for g in grads]
+            torch._foreach_mul_(grads, torch.reciprocal(scale).reshape(()))
         return (None, None) + tuple(grads)
 
 
@@ -202,7 +232,8 @@ class FusedHead:
     """Runs ``net`` (a WeightMLP or DeformMLP host mirror) through the fused kernels.  ``net`` keeps owning the fp32
     parameters; the bf16 copies are rebuilt when a parameter's version counter changes (optimizer step, load)."""
 
-    def __init__(self, linears, head_linear, in_ch: int, skip: int):
+    def __init__(self, linears, head_linear, in_ch: int, skip: int, fmt: str = None):
+        self.fmt = fmt or DEFAULT_FORMAT
         self.linears, self.head_linear, self.in_ch, self.skip = list(linears), head_linear, in_ch, skip
         self._pk, self._ver, self._ptrs = None, None, None
 
@@ -216,7 +247,7 @@ class FusedHead:
         ptrs = tuple(q.data_ptr() for q in self.params())
         ver = tuple(q._version for q in self.params())
         if self._pk is None or ptrs != self._ptrs:
-            self._pk, self._ptrs, self._ver = Packed(self.linears, self.head_linear, self.in_ch, self.skip), ptrs, ver
+            self._pk, self._ptrs, self._ver = Packed(self.linears, self.head_linear, self.in_ch, self.skip, self.fmt), ptrs, ver
             fresh = True
         else:
             fresh = False

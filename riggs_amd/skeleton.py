@@ -438,10 +438,13 @@ class SkeletonWarp(nn.Module):
         return self.deform_by_pose(x, self.get_pose_info(t), motion_mask)
 
     # ---- the per-Gaussian MLP heads: fp32 GEMMs through torch (the reference's arithmetic, default), or — opt-in —
-    # the fused bf16-MFMA kernels of riggs_amd.mlp (3.3x faster forward + backward at 300k
-    # Gaussians; outputs within 4e-3 / 3e-2 relative of the fp32 path)
-    def use_fused_heads(self, on: bool = True):
+    # the fused MFMA kernels of riggs_amd.mlp (~7x faster forward + backward at 300k Gaussians;
+    # ``fmt``: "fp16" (default; gradients within ~2 % of the fp32 path) or "bf16")
+    def use_fused_heads(self, on: bool = True, fmt: str = None):
+        from .mlp import DEFAULT_FORMAT, _fmt_dtype
         self._fused_heads = bool(on)
+        self._fused_fmt = fmt or DEFAULT_FORMAT
+        _fmt_dtype(self._fused_fmt)
         self._fh_w = self._fh_d = None
         return self
 
@@ -451,9 +454,9 @@ class SkeletonWarp(nn.Module):
         from .mlp import FusedHead
         net = self.skinning_weight_mlp
         if getattr(self, "_fh_w", None) is None:
-            self._fh_w = FusedHead(net.linear, net.weight_predict, net.input_ch, net.skips[0])
+            self._fh_w = FusedHead(net.linear, net.weight_predict, net.input_ch, net.skips[0], self._fused_fmt)
         from .mlp import embed_positions_bf16
-        return torch.sigmoid(self._fh_w(embed_positions_bf16(x, net.multires), n_rows=x.shape[0]))
+        return torch.sigmoid(self._fh_w(embed_positions_bf16(x, net.multires, fmt=self._fused_fmt), n_rows=x.shape[0]))
 
     def _head_detail(self, x, pose):
         if not getattr(self, "_fused_heads", False):
@@ -461,10 +464,10 @@ class SkeletonWarp(nn.Module):
         from .mlp import FusedHead
         net = self.detail_net
         if getattr(self, "_fh_d", None) is None:
-            self._fh_d = FusedHead(net.linear, net.gaussian_warp, net.input_ch, net.skips[0])
+            self._fh_d = FusedHead(net.linear, net.gaussian_warp, net.input_ch, net.skips[0], self._fused_fmt)
         if net.t_multires <= 0 and net.multires > 0:  # the reference's configuration: PE(x) and the raw pose vector
             from .mlp import embed_positions_bf16
-            return self._fh_d(embed_positions_bf16(x, net.multires, pose[0]), n_rows=x.shape[0])
+            return self._fh_d(embed_positions_bf16(x, net.multires, pose[0], fmt=self._fused_fmt), n_rows=x.shape[0])
         t_emb = _embed(pose, net.t_multires) if net.t_multires > 0 else pose
         x_emb = _embed(x, net.multires) if net.multires > 0 else x
         return self._fh_d(torch.cat([x_emb, t_emb], dim=-1))

@@ -48,7 +48,7 @@ def main():
     print("deform_by_pose fwd+bwd with WeightMLP + DeformMLP heads, N=%d: %.2f ms per iteration (%.1f TFLOP/s on the MLPs' "
           "3 x %.2f MFLOP per Gaussian)" % (x.shape[0], dt * 1e3, 3 * mlp_flops * x.shape[0] / dt / 1e12, mlp_flops / 1e6))
     dt = res[True]
-    print("same with the fused bf16-MFMA heads (riggs_amd.mlp): %.2f ms per iteration (%.1f TFLOP/s)" % (dt * 1e3, 3 * mlp_flops * x.shape[0] / dt / 1e12))
+    print("same with the fused MFMA heads, fp16 operands (riggs_amd.mlp): %.2f ms per iteration (%.1f TFLOP/s)" % (dt * 1e3, 3 * mlp_flops * x.shape[0] / dt / 1e12))
 
 
 if __name__ == "__main__":
