@@ -110,7 +110,7 @@ def heads_timing(sc, gm, iters=5):
         torch.cuda.synchronize()
         res[fused] = (time.perf_counter() - t0) / iters
     return {"what": "deform_by_pose forward+backward with WeightMLP and DeformMLP on, %d Gaussians; not the headline metric" % x.shape[0],
-            "ms_fp32_gemms": round(res[False] * 1e3, 3), "ms_fused_bf16_mfma": round(res[True] * 1e3, 3)}
+            "ms_fp32_gemms": round(res[False] * 1e3, 3), "ms_fused_mfma": round(res[True] * 1e3, 3), "fused_operand_format": "fp16 (fp32 accumulation, device-side gradient scaling)"}
 
 
 def next_rows_timing(sc, gm, cam, iters=20):
@@ -677,7 +677,7 @@ def main():
                                  "final_loss": round(float(gts.out["loss"]), 6)}
         if world == 1 and not args.no_graph and not args.metric_only:
             # Secondary number (NOT the metric): the deformation with both per-Gaussian MLP heads on (the stage-2 recipe,
-            # SURVEY.md §8-f rank 3), forward + backward, fp32 library GEMMs vs the fused bf16-MFMA kernels
+            # SURVEY.md §8-f rank 3), forward + backward, fp32 library GEMMs vs the fused MFMA kernels (fp16 operands)
             out["mlp_heads"] = heads_timing(sc, gm)
             out["next_rows"] = next_rows_timing(sc, gm, cam)
             out["dense_gradient_scene"] = dense_scene_timing(dev)
