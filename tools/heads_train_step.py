@@ -50,7 +50,7 @@ def main():
         # (the losses of the first replays are comparable between the two paths; later the iteration — Adam at the reference's
         # learning rates against a random target image — is chaotic: float-atomics noise decides which way it goes)
         print("heads %s: %.2f ms per training iteration (%.1f it/s), loss of replays 1-3 %s, WeightMLP layer-3 weights moved by %.2e"
-              % ("fused bf16 MFMA" if fused else "fp32 GEMMs", dt * 1e3, 1.0 / dt, " ".join("%.4f" % v for v in early), moved))
+              % ("fused MFMA (fp16 operands)" if fused else "fp32 GEMMs", dt * 1e3, 1.0 / dt, " ".join("%.4f" % v for v in early), moved))
 
 
 if __name__ == "__main__":
