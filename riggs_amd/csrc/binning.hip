@@ -13,11 +13,11 @@
 //                 ranges[tile], slot_base[tile], R, overflow flag, the forward's work list (non-empty tiles, longest first).
 // HBM traffic: N*(4+8+4) read per pass, R*4(+4) written once, 2*chunks*T*4 for the table — against
 // ~R*32 B for two radix passes over (key, value) pairs plus the emit pass.
+#include <stdlib.h>
 #include "raster_internal.h"
 
 namespace riggs {
 
-#define BIN_G_PER_WAVE 64  // Gaussians walked by one wave
 
 __device__ __forceinline__ int rect_tile(const ushort4 rc, int l, int grid_x) {
   const int w = rc.z - rc.x;
@@ -185,7 +185,7 @@ __device__ void bin_offsets_body(int T, int64_t cap, const uint32_t* __restrict_
 
 // Scatter.  LDS: s_base[T] (u32 absolute start of this block's segment in each tile) and
 // s_rel[W][T] (u16 offsets of each wave's sub-segment, then used as that wave's running cursor).
-__global__ __launch_bounds__(1024) void bin_scatter_kernel(int N, int T, int grid_x, int64_t cap, int g_per_block,
+__global__ __launch_bounds__(1024) void bin_scatter_kernel(int N, int T, int grid_x, int64_t cap, int g_per_block, int g_per_wave,
                                                           const uint32_t* __restrict__ order,
                                                           const uint32_t* __restrict__ tiles,
                                                           const ushort4* __restrict__ rect,
@@ -209,24 +209,32 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(int N, int T, int gri
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int e = tid; e < W * (Tpad >> 1); e += blockDim.x) s_rel32[e] = 0u;
   __syncthreads();
-  const int first = blockIdx.x * g_per_block + wave * BIN_G_PER_WAVE;
-  const int end = min(N, min(first + BIN_G_PER_WAVE, (blockIdx.x + 1) * g_per_block));
-  // (i) per-wave tile histogram (16-bit counters packed in pairs; a wave adds at most 128 per tile)
-  uint32_t my_g[BIN_G_PER_WAVE / 64], my_n[BIN_G_PER_WAVE / 64];
-  ushort4 my_rc[BIN_G_PER_WAVE / 64];
-#pragma unroll
-  for (int k = 0; k < BIN_G_PER_WAVE / 64; k++) {
-    const int s = first + k * 64 + lane;
-    my_g[k] = 0u; my_n[k] = 0u; my_rc[k] = make_ushort4(0, 0, 0, 0);
+  // a wave walks g_per_wave Gaussians in batches of 64 (one batch in the headline configuration; more when N is large,
+  // so that the O(T) set-up of a workgroup — cursor tables, tile bases, its row of the chunk table — is paid per thousands
+  // of Gaussians and the chunk table stays small: bin_plan)
+  const int first = blockIdx.x * g_per_block + wave * g_per_wave;
+  const int end = min(N, min(first + g_per_wave, (blockIdx.x + 1) * g_per_block));
+  auto load_batch = [&](int s0, uint32_t& g, uint32_t& n, ushort4& rc) {
+    const int s = s0 + lane;
+    g = 0u; n = 0u; rc = make_ushort4(0, 0, 0, 0);
     if (s < end) {
-      my_g[k] = order[s];
-      my_n[k] = tiles[my_g[k]];
-      if (my_n[k]) my_rc[k] = rect[my_g[k]];
+      g = order[s];
+      n = tiles[g];
+      if (n) rc = rect[g];
     }
-    if (my_n[k]) {
+  };
+  // (i) per-wave tile histogram (16-bit counters packed in pairs; a wave adds at most g_per_wave <= 1024 per tile)
+  uint32_t nx_g = 0u, nx_n = 0u;          // the first batch stays in registers for the walk below
+  ushort4 nx_rc = make_ushort4(0, 0, 0, 0);
+  for (int s0 = first; s0 < end; s0 += 64) {
+    uint32_t g, n;
+    ushort4 rc;
+    load_batch(s0, g, n, rc);
+    if (s0 == first) { nx_g = g; nx_n = n; nx_rc = rc; }
+    if (n) {
       uint32_t* hist = s_rel32 + (size_t)wave * (Tpad >> 1);
-      for (int y = my_rc[k].y; y < my_rc[k].w; y++)
-        for (int x = my_rc[k].x; x < my_rc[k].z; x++) {
+      for (int y = rc.y; y < rc.w; y++)
+        for (int x = rc.x; x < rc.z; x++) {
           const int t = y * grid_x + x;
           atomicAdd(&hist[t >> 1], 1u << (16 * (t & 1)));
         }
@@ -278,11 +286,13 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(int N, int T, int gri
   // 64-bit mask arithmetic: the CU's one scalar unit was what bounded the walk (7.8 M scalar instructions).
   unsigned short* cur = s_rel + (size_t)wave * Tpad;
   const int slot4 = lane >> 4, l16 = lane & 15;
-#pragma unroll
-  for (int k = 0; k < BIN_G_PER_WAVE / 64; k++) {
-    const uint64_t live = __builtin_amdgcn_ballot_w64(my_n[k] != 0u);
-    const uint64_t large = __builtin_amdgcn_ballot_w64(my_n[k] > 16u);
-    const int pk_xy = (int)my_rc[k].x | ((int)my_rc[k].y << 16), pk_zw = (int)my_rc[k].z | ((int)my_rc[k].w << 16);
+  for (int s0 = first; s0 < end; s0 += 64) {
+    const uint32_t cur_g = nx_g, cur_n = nx_n;
+    const ushort4 cur_rc = nx_rc;
+    if (s0 + 64 < end) load_batch(s0 + 64, nx_g, nx_n, nx_rc);  // (the next batch's loads fly during this one's walk)
+    const uint64_t live = __builtin_amdgcn_ballot_w64(cur_n != 0u);
+    const uint64_t large = __builtin_amdgcn_ballot_w64(cur_n > 16u);
+    const int pk_xy = (int)cur_rc.x | ((int)cur_rc.y << 16), pk_zw = (int)cur_rc.z | ((int)cur_rc.w << 16);
 #pragma unroll
     for (int q = 0; q < 16; q++) {
       if (((live >> (4 * q)) & 0xFull) == 0ull) continue;
@@ -291,9 +301,9 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(int N, int T, int gri
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const int src = 4 * q + j;
-          const int n = __builtin_amdgcn_readlane((int)my_n[k], src);
+          const int n = __builtin_amdgcn_readlane((int)cur_n, src);
           if (n == 0) continue;
-          const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)my_g[k], src);
+          const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)cur_g, src);
           const int r0 = __builtin_amdgcn_readlane(pk_xy, src), r1 = __builtin_amdgcn_readlane(pk_zw, src);
           ushort4 rc;
           rc.x = (unsigned short)(r0 & 0xFFFF); rc.y = (unsigned short)((uint32_t)r0 >> 16);
@@ -315,7 +325,7 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(int N, int T, int gri
       const int a3 = __builtin_amdgcn_readlane(pk_xy, 4 * q + 3), b3 = __builtin_amdgcn_readlane(pk_zw, 4 * q + 3);
       const int axy = (slot4 == 0) ? a0 : (slot4 == 1) ? a1 : (slot4 == 2) ? a2 : a3;
       const int bzw = (slot4 == 0) ? b0 : (slot4 == 1) ? b1 : (slot4 == 2) ? b2 : b3;
-      const uint32_t g = (uint32_t)__shfl((int)my_g[k], 4 * q + slot4);
+      const uint32_t g = (uint32_t)__shfl((int)cur_g, 4 * q + slot4);
       const int rx0 = axy & 0xFFFF, ry0 = (int)((uint32_t)axy >> 16), rx1 = bzw & 0xFFFF, ry1 = (int)((uint32_t)bzw >> 16);
       const int w = rx1 - rx0;
       const int ry = (int)(((float)l16 + 0.5f) * __builtin_amdgcn_rcpf((float)w));  // (as rect_tile)
@@ -338,7 +348,7 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(int N, int T, int gri
   }
 }
 
-struct BinPlan { int g_per_block, threads, n_chunks; size_t lds_scatter; };
+struct BinPlan { int g_per_block, g_per_wave, threads, n_chunks; size_t lds_scatter; };
 
 static BinPlan bin_plan(int N, int T) {
   // LDS of the scatter kernel: T*4 (bases) + W*Tpad*2 (wave cursors) <= ~150 KB
@@ -349,7 +359,14 @@ static BinPlan bin_plan(int N, int T) {
   while (W > 1 && (size_t)T * 4 + (size_t)W * Tpad * 2 > 150 * 1024) W = (W + 1) >> 1;
   BinPlan p;
   p.threads = W * 64;
-  p.g_per_block = W * BIN_G_PER_WAVE;
+  // batches of 64 Gaussians per wave: as many as keep the launch at <= ~640 chunks (one in the headline configuration:
+  // 391 chunks).  A chunk costs every kernel O(T) (table row, cursor tables) and its runs in a tile's list are short — a
+  // partial line per (chunk, tile) — which at 2 M Gaussians / 8160 tiles was a 170 MB table and 1.3 ms of binning with
+  // 384-Gaussian chunks; measured optimum: C3 1 batch, C4 (500 k) 2-4, C5 (2 M) 8
+  int batches = (int)(((int64_t)N + (int64_t)W * 64 * 640 - 1) / ((int64_t)W * 64 * 640));
+  batches = batches < 1 ? 1 : (batches > 16 ? 16 : batches);
+  p.g_per_wave = 64 * batches;
+  p.g_per_block = W * p.g_per_wave;
   p.n_chunks = (N + p.g_per_block - 1) / p.g_per_block;
   p.lds_scatter = (size_t)T * 4 + (size_t)W * Tpad * 2;
   return p;
@@ -384,7 +401,7 @@ int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order,
   hipLaunchKernelGGL(bin_scan_kernel, dim3((T + 63) / 64), dim3(1024), 0, s, T, p.n_chunks, table, tile_count);
   // (+ 1: the extra workgroup that writes the ranges, the counters and the forward's work list)
   hipLaunchKernelGGL(bin_scatter_kernel, dim3(p.n_chunks + 1), dim3(p.threads), p.lds_scatter, s, N, T, grid_x, cap,
-                     p.g_per_block, order, tiles, rect, table, tile_count, point_list, tile_keys, ranges, slot_base, tile_max,
+                     p.g_per_block, p.g_per_wave, order, tiles, rect, table, tile_count, point_list, tile_keys, ranges, slot_base, tile_max,
                      counters, fwd_items, fwd_empty, fwd_ctr);
   return 0;
 }
