@@ -425,7 +425,10 @@ def main():
         from riggs_amd.graph import GraphedFrame
         import torch.distributed as dist
         params = params_of(gm, sw)
-        gf = GraphedFrame(gm, sw, cam, torch.zeros(3, device=dev), params, split_backward=world > 1).capture()
+        # (a split frame skips the zero fill of untouched gradient rows only with the row exchange, which records the rows
+        # it writes; the dense all-reduce rewrites every row)
+        gf = GraphedFrame(gm, sw, cam, torch.zeros(3, device=dev), params, split_backward=world > 1,
+                          sparse_grad_rows=(world == 1 or rows is not None)).capture()
         gf.set_inputs(gimg=gimg)
         if world > 1:
             assert all(g.data_ptr() == v.data_ptr() for g, v in zip([p.grad for p in bucket.params], bucket.views)), \
@@ -453,6 +456,7 @@ def main():
             return out
         if rows is not None:
             rows.workspace = gf.backward_workspace  # (the eager profiling steps below use another one)
+            rows.record_rows = True
         step()
         torch.cuda.synchronize()
         assert gf.check() == R, "graphed frame disagrees with the eager frame on the instance count"
@@ -462,6 +466,8 @@ def main():
             rows.resize(int(rows.need * 1.1) + 256)
             if not rows.wins:
                 rows = None
+                gf = GraphedFrame(gm, sw, cam, torch.zeros(3, device=dev), params, split_backward=True, sparse_grad_rows=False).capture()
+                gf.set_inputs(gimg=gimg)
             else:
                 step()
                 torch.cuda.synchronize()

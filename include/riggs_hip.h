@@ -60,6 +60,14 @@ typedef struct riggs_raster_cfg {
    * kernel sums each Gaussian's rows in ascending tile order: gradients are bitwise reproducible run to run.  Needs the
    * larger workspace of riggs_raster_backward_workspace_bytes_ordered; slower (tests / debugging). */
   int32_t deterministic;
+  /* riggs_raster_backward only.  1 = the caller guarantees that the gradient output buffers are the SAME buffers the previous
+   * riggs_raster_backward with this workspace wrote and that nobody has written them since (or that buffers and workspace
+   * were zero-filled together): rows that receive no gradient now and received none then are not rewritten — they still
+   * hold their zeros.  The zero fill of those rows (86-93 % of them per frame) is two thirds of the per-Gaussian backward's
+   * HBM traffic.  A captured frame with static gradient buffers qualifies (riggs_amd.graph.GraphedFrame); an eager
+   * autograd backward, whose outputs are fresh allocations, does not.  riggs_grad_rows_unpack keeps the guarantee intact
+   * when it is given the workspace (it records the rows it writes). */
+  int32_t sparse_zero;
 } riggs_raster_cfg;
 
 /* Opaque arenas (upstream: geomBuffer / binningBuffer / imgBuffer byte tensors). */
@@ -286,8 +294,11 @@ int32_t riggs_grad_rows_row_floats(int32_t n_tensors, const int32_t* widths);
 size_t riggs_grad_rows_segment_bytes(int32_t num_points, int32_t row_floats, int32_t capacity);
 int riggs_grad_rows_pack(int32_t num_points, const void* backward_workspace, int32_t n_tensors, const float* const* grads,
                          const int32_t* widths, float scale, int32_t capacity, void* segment, riggs_stream stream);
+/* backward_workspace (may be NULL): when given, the rows written are recorded in it as "rows that hold a gradient", which
+ * keeps cfg.sparse_zero of the next riggs_raster_backward valid (rows other ranks touched are zeroed there when due). */
 int riggs_grad_rows_unpack(int32_t num_points, int32_t world, int32_t capacity, const void* segments, int32_t n_tensors,
-                           float* const* grads, const int32_t* widths, uint32_t* status, riggs_stream stream);
+                           float* const* grads, const int32_t* widths, uint32_t* status, void* backward_workspace,
+                           riggs_stream stream);
 
 /* =====================================================================
  * Image loss: utils/loss_utils.py:17-18 (l1_loss), :33-77 (ssim, 11x11 Gaussian window,

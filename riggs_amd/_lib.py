@@ -25,6 +25,7 @@ class RasterCfg(C.Structure):
         ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
         ("bg", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
         ("debug", C.c_int32), ("glue", C.c_int32), ("isotropic", C.c_int32), ("deterministic", C.c_int32),
+        ("sparse_zero", C.c_int32),
     ]
 
 
@@ -61,7 +62,7 @@ _SIGS = {
     "riggs_grad_rows_row_floats": (C.c_int32, [C.c_int32, _P]),
     "riggs_grad_rows_segment_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "riggs_grad_rows_pack": (C.c_int, [C.c_int32, _P, C.c_int32, _P, _P, C.c_float, C.c_int32, _P, _P]),
-    "riggs_grad_rows_unpack": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P, _P]),
+    "riggs_grad_rows_unpack": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, _P]),
     "riggs_adam_step": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, _P]),
     "riggs_adam_step_capturable": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, _P]),
     "riggs_densify_stats": (C.c_int, [C.c_int32] + [_P] * 7),

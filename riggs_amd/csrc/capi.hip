@@ -336,6 +336,7 @@ int riggs_raster_backward(const riggs_raster_cfg* cfg, const float* means3D, con
   b.gacc = (float*)workspace;
   b.touched_bits = (unsigned long long*)((char*)workspace + ws_bits_offset(N));
   b.block_touched = (uint32_t*)((char*)workspace + ws_blocks_offset(N));
+  b.sparse_zero = cfg->sparse_zero ? 1 : 0;
   b.dL_dmeans3D = dL_dmeans3D; b.dL_dmeans2D = dL_dmeans2D; b.dL_dsh = dL_dsh; b.dL_dcolors = dL_dcolors_precomp;
   b.dL_dopac = dL_dopacities; b.dL_dscales = dL_dscales; b.dL_drots = dL_drotations; b.dL_dcov3D = dL_dcov3D;
   b.dL_dd_scaling = dL_dd_scaling; b.dL_dsh_rest = dL_dsh_rest;

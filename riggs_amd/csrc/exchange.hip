@@ -133,7 +133,8 @@ __device__ inline float4 unpack_load4(const RowTensors& T, int g, int c0) {
 
 __global__ __launch_bounds__(256) void rows_unpack_kernel(int N, int world, int capacity, size_t seg_words,
                                                           const uint32_t* __restrict__ all, RowTensors T,
-                                                          uint32_t* __restrict__ status) {
+                                                          uint32_t* __restrict__ status,
+                                                          unsigned long long* __restrict__ touched_bits) {
   extern __shared__ float s_acc[];                     // [RIGGS_UNPACK_SLOTS][row_words]
   __shared__ unsigned short s_slot[256];               // Gaussian (local) -> slot, 0xFFFF = none yet
   __shared__ unsigned short s_local[256];              // slot -> Gaussian (local)
@@ -213,6 +214,12 @@ __global__ __launch_bounds__(256) void rows_unpack_kernel(int N, int world, int 
     }
     __syncthreads();
   }
+  // the rows this workgroup has written become the workspace's "rows that hold a gradient" (a superset of this rank's
+  // own): the next riggs_raster_backward with cfg.sparse_zero zeroes the ones it does not touch itself
+  if (touched_bits) {
+    const unsigned long long wrote = __builtin_amdgcn_ballot_w64(s_slot[t] != 0xFFFFu);
+    if ((t & 63) == 0 && b * 256 + (t >> 6) * 64 < N) touched_bits[b * 4 + (t >> 6)] = wrote;
+  }
   // store: one slot per group and step; lane k scatters floats 4k .. 4k+3 to their tensors
   const int n_slots = min((int)s_count, RIGGS_UNPACK_SLOTS);
   for (int slot = group; slot < n_slots; slot += 16) {
@@ -266,7 +273,8 @@ int riggs_grad_rows_pack(int32_t N, const void* backward_workspace, int32_t n_te
 }
 
 int riggs_grad_rows_unpack(int32_t N, int32_t world, int32_t capacity, const void* segments, int32_t n_tensors,
-                           float* const* grads, const int32_t* widths, uint32_t* status, riggs_stream stream_) {
+                           float* const* grads, const int32_t* widths, uint32_t* status, void* backward_workspace,
+                           riggs_stream stream_) {
   hipStream_t s = (hipStream_t)stream_;
   RIGGS_REQUIRE(N > 0 && world >= 1 && segments && status && capacity >= 0, "riggs_grad_rows_unpack: bad arguments");
   RowTensors T;
@@ -276,8 +284,9 @@ int riggs_grad_rows_unpack(int32_t N, int32_t world, int32_t capacity, const voi
   RIGGS_REQUIRE(world <= RIGGS_UNPACK_MAX_WORLD, "riggs_grad_rows_unpack: at most 64 segments");
   const size_t lds = (size_t)RIGGS_UNPACK_SLOTS * T.row_words * sizeof(float);
   RIGGS_REQUIRE(lds <= 60 * 1024, "riggs_grad_rows_unpack: rows wider than 160 floats");
+  unsigned long long* bits = backward_workspace ? (unsigned long long*)((char*)backward_workspace + ws_bits_offset(N)) : nullptr;
   hipLaunchKernelGGL(rows_unpack_kernel, dim3((N + 255) / 256), dim3(256), lds, s, N, world, capacity, seg_words,
-                     (const uint32_t*)segments, T, status);
+                     (const uint32_t*)segments, T, status, bits);
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
 }

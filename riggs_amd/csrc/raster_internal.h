@@ -29,6 +29,7 @@ struct PreBwdArgs {
   // wave) and how many per block of 256 — rewritten by every launch; read by the gradient-row exchange (exchange.hip)
   unsigned long long* touched_bits;
   uint32_t* block_touched;
+  int sparse_zero;               // cfg.sparse_zero: rows without a gradient now AND in the previous call are not rewritten
 };
 #define RIGGS_GACC 12  // floats per Gaussian in the render-backward accumulator (padded to 48 B)
 // backward workspace: [accumulators N x 48 B | touched bits, one 64-bit word per 64 Gaussians | touched count per 256]

@@ -54,6 +54,13 @@ def grad_out(param: torch.Tensor, shape=None) -> torch.Tensor:
     return torch.empty(shape, dtype=torch.float32, device=param.device)
 
 
+def in_bucket(param: torch.Tensor, tensor: torch.Tensor) -> bool:
+    """Is ``tensor`` the slice of a registered bucket that belongs to ``param`` (i.e. memory that lives outside any
+    hipGraph pool and that nothing else is ever placed in)?"""
+    ent = _entry(param)
+    return ent is not None and tensor is not None and tensor.data_ptr() == ent[0].data_ptr() + 4 * ent[1]
+
+
 def grad_out_flat(params) -> torch.Tensor:
     """One contiguous buffer for the gradients of ``params`` in order (the PoseMLP backward writes all of its
     parameter gradients as one flat array): the bucket's own range when these parameters are registered back to
@@ -398,8 +405,9 @@ def _hip_pack(ex):
 
 def _hip_unpack(ex):
     from . import _lib as L
+    ws = ex.workspace.data_ptr() if (ex.workspace is not None and ex.record_rows) else None
     L.check(L.lib().riggs_grad_rows_unpack(ex.N, ex.world, ex.capacity, ex.gathered.data_ptr(), len(ex.rows), ex._ptrs, ex._widths,
-                                           ex.status.data_ptr(), L.stream_ptr()), "riggs_grad_rows_unpack")
+                                           ex.status.data_ptr(), ws, L.stream_ptr()), "riggs_grad_rows_unpack")
 
 
 class SparseRowExchange:
@@ -445,6 +453,9 @@ class SparseRowExchange:
         # the backward workspace to pack from: None = the one the most recent rasterizer backward used; a caller that runs
         # other backward passes in between (another stream, an eager profiling step) pins it (GraphedFrame.backward_workspace)
         self.workspace = None
+        # with a pinned workspace: record the rows the unpack writes in it, so that a captured frame whose backward skips
+        # the zero fill of untouched rows (GraphedFrame(sparse_grad_rows=True)) zeroes the rows other ranks touched
+        self.record_rows = False
         # the small dense all-reduce gets its OWN communicator: collectives of one process group run one after the other
         # on that group's internal stream, and this one must not queue behind the all-gather of the rows
         self.rest_group = None

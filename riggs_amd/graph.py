@@ -26,11 +26,16 @@ class _Pipe:
 
 class GraphedFrame:
     def __init__(self, gm, sw, cam: Camera, bg: torch.Tensor, params, headroom: float = 1.5, fused: bool = True,
-                 split_backward: bool = False):
+                 split_backward: bool = False, sparse_grad_rows: bool = None):
         """``split_backward``: capture the frame as TWO graphs — (a) forward + rasterizer backward, (b) deformation backward
         (skinning, FK, PoseMLP) — so that a data-parallel caller can put the all-reduce of the gradients that are final after
         (a) on the links while (b) still runs (riggs_amd.dist.OverlappedExchange): ``run_a()``, ``run_b()``."""
         self.split = bool(split_backward)
+        # ``sparse_grad_rows``: the per-Gaussian backward rewrites only the rows that have a gradient now or had one in the
+        # previous replay (riggs_raster_cfg.sparse_zero) — valid while nobody else writes the captured gradient buffers
+        # between replays: an optimizer only reads them; riggs_amd.dist.SparseRowExchange records what it writes
+        # (``record_rows``); a dense in-place all-reduce does NOT qualify, hence off by default for a split frame.
+        self.sparse_rows = (not self.split) if sparse_grad_rows is None else bool(sparse_grad_rows)
         self.gm, self.sw, self.params = gm, sw, list(params)
         dev = bg.device
         self.cam = Camera(cam.image_height, cam.image_width, cam.FoVx, cam.FoVy, cam.world_view_transform.clone(),
@@ -97,37 +102,79 @@ class GraphedFrame:
     def capture(self, warmup: int = 2):
         """Eager warm-up (sizes the arena, initialises rocPRIM/hipBLASLt workspaces) then capture."""
         import gc
-        self.stream = s = torch.cuda.Stream()
+        from . import rasterizer as R
+        from .dist import FlatGradAllReduce, _entry
+        if self.sparse_rows and getattr(self, "_own_bucket", None) is None:
+            # sparse gradient rows need the Gaussians' gradient buffers to be persistent memory of their own: the slices of
+            # a registered bucket (the caller's — e.g. the data-parallel one — or one made here)
+            gp = list(self.gm.parameters())
+            have = [_entry(p) is not None for p in gp]
+            if not any(have):
+                self._own_bucket = FlatGradAllReduce(gp, register=True)
+            elif not all(have):
+                self.sparse_rows = False
+        if not hasattr(self, "stream"):
+            self.stream = torch.cuda.Stream()  # (one stream per frame: a re-capture finds its persistent buffers again)
+        s = self.stream
         s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(warmup):
-                if self.split:
-                    self.out = self._frame_a()
-                    self._frame_b()
-                else:
-                    self.out = self._frame()
-                torch.cuda.current_stream().synchronize()
-                self.arena.resolve()
-                self.out = None
+        R.SPARSE_GRAD_ROWS = self.sparse_rows  # (eager frames never skip rows; they create the persistent screen-space buffer)
+        try:
+            with torch.cuda.stream(s):
+                for _ in range(warmup):
+                    if self.split:
+                        self.out = self._frame_a()
+                        self._frame_b()
+                    else:
+                        self.out = self._frame()
+                    torch.cuda.current_stream().synchronize()
+                    self.arena.resolve()
+                    self.out = None
+        finally:
+            R.SPARSE_GRAD_ROWS = False
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         for p in self.params:
             p.grad = None
         gc.collect()
         self.graph = torch.cuda.CUDAGraph()
-        if self.split:
-            self.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, stream=s):
-                self.out = self._frame_a()
-            with torch.cuda.graph(self.graph_b, stream=s, pool=self.graph.pool()):
-                self._frame_b()
-        else:
-            with torch.cuda.graph(self.graph, stream=s):  # same stream as the warm-up: AccumulateGrad nodes match
-                self.out = self._frame()
+        R.SPARSE_GRAD_ROWS = self.sparse_rows
+        try:
+            if self.split:
+                self.graph_b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph, stream=s):
+                    self.out = self._frame_a()
+                with torch.cuda.graph(self.graph_b, stream=s, pool=self.graph.pool()):
+                    self._frame_b()
+            else:
+                with torch.cuda.graph(self.graph, stream=s):  # same stream as the warm-up: AccumulateGrad nodes match
+                    self.out = self._frame()
+        finally:
+            R.SPARSE_GRAD_ROWS = False
         self.grads = [p.grad for p in self.params]  # static gradient buffers refilled by every replay
-        from .rasterizer import last_backward_workspace
-        self.backward_workspace = last_backward_workspace()[0]  # baked into the graph: must live as long as it does
+        self.backward_workspace = R.last_backward_workspace()[0]  # baked into the graph: must live as long as it does
+        self.sparse_outputs = []
+        wanted = list(R._LAST_SPARSE_OUTPUTS)
+        if wanted:
+            # the kernels leave untouched rows alone: every buffer they write must be one that LIVES between replays — a
+            # parameter's .grad or the kept screen-space gradient — not an intermediate the graph's pool may reuse
+            alive = {g.data_ptr(): g for g in self.grads if g is not None}
+            vg = dict.get(self.out, "viewspace_points_grad")
+            if vg is not None:
+                alive[vg.data_ptr()] = vg
+            if not all(ptr in alive for ptr in wanted):
+                # (autograd kept a copy instead of the kernel's buffer for some gradient: capture again, writing every row)
+                self.sparse_rows = False
+                return self.capture(warmup=0)
+            self.sparse_outputs = [alive[ptr] for ptr in wanted]
+            self.reset_sparse_rows()
         return self
+
+    def reset_sparse_rows(self):
+        """Zero the captured gradient buffers and the workspace's row list together: the state ``sparse_grad_rows`` starts
+        from, and what to call after anything else has written into those buffers (e.g. a dense all-reduce)."""
+        for t in self.sparse_outputs:
+            t.zero_()
+        self.backward_workspace.zero_()
 
     def run_a(self, cam: Camera = None, gimg: torch.Tensor = None):
         """split_backward: forward + rasterizer backward (every Gaussian gradient is final afterwards; ``_xyz`` / ``_rotation``

@@ -205,6 +205,33 @@ def rasterize_backward(s: _Saved, means3D, shs, colors_precomp, opacities, scale
     g_rots = grad_out(rotations, (N, 4)) if rotations is not None else None
     g_cov = torch.empty(N, 6, **f32) if cov3D_precomp is not None else None
     g_dscaling = torch.empty(N, 3, **f32) if (d_scaling is not None and want_d_scaling_grad) else None
+    # sparse zero-fill (riggs_raster_cfg.sparse_zero): only inside a hipGraph capture whose owner asked for it
+    # (GraphedFrame(sparse_grad_rows=True): static gradient buffers, zero-filled together with the workspace after the
+    # capture), with the fused glue (the outputs ARE the parameters' gradient buffers, not autograd intermediates whose
+    # memory the graph's pool may hand to a later allocation) and without the optional outputs
+    sparse = bool(SPARSE_GRAD_ROWS and cfg.glue and not cfg.deterministic and g_colors is None and g_cov is None
+                  and g_dscaling is None and torch.cuda.is_current_stream_capturing())
+    if sparse:
+        # ... and every output must be PERSISTENT memory that nothing else is ever placed in: a tensor allocated inside the
+        # capture shares its block of the graph's pool with earlier intermediates of the same replay (measured: dL/d_xyz
+        # landed on the block the forward's d_xyz had just left — the rows not rewritten then hold d_xyz).  Bucket slices
+        # (riggs_amd.dist) qualify; the screen-space gradient gets a buffer of its own below.
+        from .dist import in_bucket
+        pairs = [(means3D, g_means3D), (shs, g_sh), (shs_rest, g_sh_rest), (opacities, g_opac), (scales, g_scales), (rotations, g_rots)]
+        sparse = all(in_bucket(p, g) for p, g in pairs if g is not None)
+    if SPARSE_GRAD_ROWS and cfg.glue:
+        # (the buffer is created by the owner's EAGER warm-up frames on this stream — outside any graph pool — and handed
+        # out as a fresh view per call, so that autograd adopts it as viewspace_points.grad instead of cloning it)
+        key = (dev.index if dev.index is not None else torch.cuda.current_device(), L.stream_ptr(), N)
+        if key not in _MEANS2D and not torch.cuda.is_current_stream_capturing():
+            if len(_MEANS2D) >= 8:
+                _MEANS2D.pop(next(iter(_MEANS2D)))
+            _MEANS2D[key] = torch.zeros(N, 3, **f32)
+        if sparse and key in _MEANS2D:
+            g_means2D = _MEANS2D[key].view(N, 3)
+        else:
+            sparse = False
+    cfg.sparse_zero = 1 if sparse else 0
     if cfg.deterministic:  # (its accumulators are overwritten by the ordered sum: nothing to keep zeroed)
         ws = torch.zeros(lib.riggs_raster_backward_workspace_bytes_ordered(N, s.cap), dtype=torch.uint8, device=dev)
     else:
@@ -227,6 +254,9 @@ def rasterize_backward(s: _Saved, means3D, shs, colors_precomp, opacities, scale
         _WORKSPACES.clear()  # a failed call may leave the accumulators dirty: the next one starts from fresh zeros
         raise
     _LAST_WORKSPACE[:] = [ws, N]
+    # (addresses, not tensors: an extra reference would make autograd's AccumulateGrad clone the gradient instead of
+    # adopting the kernel's buffer as the parameter's .grad)
+    _LAST_SPARSE_OUTPUTS[:] = [t.data_ptr() for t in (g_means3D, g_means2D, g_sh, g_sh_rest, g_opac, g_scales, g_rots) if t is not None] if sparse else []
     if shs_rest is not None:
         g_sh = (g_sh, g_sh_rest)
     return g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rots, g_cov, g_dscaling
@@ -234,6 +264,9 @@ def rasterize_backward(s: _Saved, means3D, shs, colors_precomp, opacities, scale
 
 _WORKSPACES = {}
 _LAST_WORKSPACE = [None, 0]
+_MEANS2D = {}              # (device, stream, N) -> persistent screen-space gradient buffer of the sparse mode
+_LAST_SPARSE_OUTPUTS = []  # addresses of the gradient buffers of the most recent backward that ran with cfg.sparse_zero
+SPARSE_GRAD_ROWS = False   # set by GraphedFrame around its capture only
 
 
 def last_backward_workspace():

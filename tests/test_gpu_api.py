@@ -289,3 +289,44 @@ def test_dist_knn3_at_initialisation_size():
     np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=2e-4, atol=1e-10)
     assert dt < 1.0, "distCUDA2(150k) took %.3f s" % dt
     print("distCUDA2(150k points): %.1f ms" % (dt * 1e3))
+
+
+def test_captured_frame_skips_the_zero_fill_of_untouched_rows_without_leaving_stale_gradients():
+    """riggs_raster_cfg.sparse_zero through GraphedFrame: replay after replay with changing cameras (so that rows gain and
+    lose their gradient), every parameter gradient and the screen-space gradient equal those of a frame that rewrites every
+    row — in particular a row that had a gradient in the previous replay and has none now is exactly zero."""
+    import bench
+    from riggs_amd import synth
+    from riggs_amd.graph import GraphedFrame
+    old = dict(bench.WORKLOAD)
+    bench.WORKLOAD.update(N=6001, J=8, H=96, W=112)
+    try:
+        sc, cam, gm, sw = bench.build_workload(0, "cuda:0")
+    finally:
+        bench.WORKLOAD.clear()
+        bench.WORKLOAD.update(old)
+    params = bench.params_of(gm, sw)
+    gimg = torch.rand(3, 96, 112, generator=torch.Generator().manual_seed(5)).cuda()
+    sparse = GraphedFrame(gm, sw, cam, torch.zeros(3, device="cuda"), params).capture()
+    full = GraphedFrame(gm, sw, cam, torch.zeros(3, device="cuda"), params, sparse_grad_rows=False).capture()
+    assert sparse.sparse_rows and len(sparse.sparse_outputs) >= 6 and not full.sparse_outputs
+    sparse.set_inputs(gimg=gimg)
+    full.set_inputs(gimg=gimg)
+    lost_rows = 0
+    prev_nz = None
+    for az, el in ((45.0, 20.0), (170.0, -35.0), (290.0, 60.0), (45.0, 20.0), (100.0, 0.0)):
+        c = synth.look_at_camera(96, 112, azimuth_deg=az, elevation_deg=el, radius=3.0).to("cuda:0")
+        a = sparse.run(cam=c)
+        b = full.run(cam=c)
+        torch.cuda.synchronize()
+        pairs = list(zip(sparse.grads, full.grads)) + [(a["viewspace_points_grad"], b["viewspace_points_grad"])]
+        for ga, gb in pairs:
+            assert int(((ga != 0) & (gb == 0)).sum()) == 0                      # nothing stale
+            torch.testing.assert_close(ga, gb, rtol=1e-4, atol=2e-6 * float(gb.abs().max()) + 1e-12)  # (float atomics: order varies)
+        nz = (full.grads[0].reshape(6001, -1) != 0).any(1)
+        if prev_nz is not None:
+            lost_rows += int((prev_nz & ~nz).sum())
+        prev_nz = nz
+    assert lost_rows > 100                                                     # the sequence did exercise "had a gradient, has none now"
+    sparse.reset_sparse_rows()
+    assert all(float(t.abs().max()) == 0.0 for t in sparse.sparse_outputs)
