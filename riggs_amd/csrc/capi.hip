@@ -72,7 +72,7 @@ ImageLayout image_layout(int H, int W) {
   L.ranges = o; o = align_up(o + (T + 1) * 8);   // ranges, tile_max (+ tile tickets) and slot_base are adjacent: one memset clears them
   L.tile_max = o; o = align_up(o + 2 * (T + 1) * 4);  // [tile_max (T + 1) | arrival tickets of the tile's forward blocks (T + 1)]
   L.slot_base = o; o = align_up(o + (T + 2) * 4);
-  // forward work list (written by bin_offsets_kernel): the non-empty tiles, longest lists first; the empty tiles;
+  // forward work list (written by the extra workgroup of bin_scatter_kernel): the non-empty tiles, longest lists first; the empty tiles;
   // {n_nonempty, -, n_empty}
   L.fwd_items = o; o = align_up(o + (T + 1) * 4);
   L.fwd_empty = o; o = align_up(o + (T + 1) * 4);
@@ -232,7 +232,7 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
   ImageLayout I = image_layout(H, W);
   BinLayout B = bin_layout(cap, N, H, W);
   const bool binned = N > 0 && cap > 0;
-  if (!binned) {  // (bin_offsets_kernel writes every entry of ranges / tile_max / slot_base / the counters itself)
+  if (!binned) {  // (the extra workgroup of bin_scatter_kernel writes every entry of ranges / tile_max / slot_base / the counters itself)
     RIGGS_HIP_CHECK(hipMemsetAsync(img + I.ranges, 0, (I.slot_base - I.ranges) + (size_t)(T + 2) * 4, s));
     RIGGS_HIP_CHECK(hipMemsetAsync(img + I.fwd_ctr, 0, 512, s));
   }
@@ -263,7 +263,7 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
   r.tile_ticket = r.tile_max + (T + 1);
   r.work = (uint4*)(bin + B.work); r.work_ctr = (uint32_t*)(img + I.fwd_ctr) + 64;
   r.slot_base = (const uint32_t*)(img + I.slot_base); r.ckpt = (float*)(bin + B.ckpt);
-  // longest-list-first work list of the forward (bin_offsets_kernel builds it; NULL: every tile is empty)
+  // longest-list-first work list of the forward (the extra workgroup of bin_scatter_kernel builds it; NULL: every tile is empty)
   r.items = nullptr; r.empties = nullptr; r.item_ctr = nullptr;
   if (binned) { r.items = (const uint32_t*)(img + I.fwd_items); r.empties = (const uint32_t*)(img + I.fwd_empty); r.item_ctr = (uint32_t*)(img + I.fwd_ctr); }
   { ProfScope ps(PROF_RENDER_FWD, s); launch_render_fwd(r, s); }

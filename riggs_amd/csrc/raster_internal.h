@@ -55,7 +55,7 @@ struct RenderArgs {
   uint32_t* tile_max;         // per tile: max n_contrib
   uint32_t* tile_ticket;      // per tile: forward blocks that have finished it (the last one appends the tile's backward work)
   uint4* work;                // backward work list: (tile, chunk, start of the tile's list, instances to walk) per active chunk
-  uint32_t* work_ctr;         // its size in quarter-chunks (zeroed by bin_offsets_kernel)
+  uint32_t* work_ctr;         // its size in quarter-chunks (zeroed by the extra workgroup of bin_scatter_kernel)
   const uint32_t* slot_base;  // per tile: first checkpoint slot ((range.x >> 6) + tile)
   float* ckpt;                // [slot][5][256]: (T, C0, C1, C2, D) per pixel at every 64th instance
   // work list (NULL: nothing was binned, every tile is empty): items = the non-empty tiles, longest lists

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256, 6) void render_fwd_oct_kernel(RenderArgs a) {
       }
     }
   }
-  // work list: the non-empty tiles in the order bin_offsets_kernel wrote them (longest lists first), dealt round-robin
+  // work list: the non-empty tiles in the order the extra workgroup of bin_scatter_kernel wrote them (longest lists first), dealt round-robin
   // to the resident workgroups (a shared dequeue word costs more than it balances: same-address atomics from 8 XCDs
   // serialise at ~10-60 ns each)
   const int n_items = a.items ? (int)a.item_ctr[0] * 8 : 0;  // eight 8x4 pixel blocks per non-empty tile
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, 6) void render_fwd_oct_kernel(RenderArgs a) {
         const int pos1 = base + (int)s_pos[g + i] + 1;
         // one step: eight consecutive instances (one per lane) of this lane's pixel
         const float om = valid ? 1.0f - alpha : 1.0f;
-        // exclusive product scan over the eight lanes: inside each quad as in the quad-lane kernel ...
+        // exclusive product scan over the eight lanes: inside each quad first ...
         float b1 = QUAD_F(om, QP(0, 0, 1, 2)); b1 = ((i & 3) >= 1) ? b1 : 1.0f;     // [1, o0, o1, o2]
         float s1 = QUAD_F(b1, QP(0, 0, 1, 2)); s1 = ((i & 3) >= 1) ? s1 : 1.0f;     // [1, 1, o0, o1]
         float s2 = QUAD_F(b1, QP(0, 0, 0, 1)); s2 = ((i & 3) >= 2) ? s2 : 1.0f;     // [1, 1, 1, o0]
@@ -290,7 +290,7 @@ int launch_render_fwd(const RenderArgs& a, hipStream_t s) {
   const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE, gy = (a.H + RIGGS_TILE - 1) / RIGGS_TILE;
   if (gx * gy == 0) return 0;
   // one workgroup per 8 x 4 block of every tile; the ones past the non-empty tiles of the work list only help with the
-  // background of the empty tiles and leave (tile_max, the tile tickets and the work-list size were cleared by bin_offsets_kernel)
+  // background of the empty tiles and leave (tile_max, the tile tickets and the work-list size were cleared by the extra workgroup of bin_scatter_kernel)
   // (a grid capped at 2048 .. 8192 persistent workgroups instead: within 1 %)
   if (a.trace) hipLaunchKernelGGL(render_fwd_oct_kernel<true>, dim3(gx * gy * 8), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(render_fwd_oct_kernel<false>, dim3(gx * gy * 8), dim3(256), 0, s, a);

@@ -100,7 +100,7 @@ class GraphedFrame:
             self.gimg.copy_(gimg, non_blocking=True)
 
     def capture(self, warmup: int = 2):
-        """Eager warm-up (sizes the arena, initialises rocPRIM/hipBLASLt workspaces) then capture."""
+        """Eager warm-up (sizes the arena, initialises library workspaces, creates the persistent buffers) then capture."""
         import gc
         from . import rasterizer as R
         from .dist import FlatGradAllReduce, _entry
