@@ -156,6 +156,10 @@ int riggs_raster_backward(const riggs_raster_cfg* cfg, const float* means3D, con
                           float* dL_dsh_rest /* with shs_rest: (N,M-1,3), dL_dsh is then (N,1,3) */,
                           riggs_stream stream);
 size_t riggs_raster_backward_workspace_bytes(int32_t num_points);
+/* where the workspace keeps its row list (one bit per Gaussian: "holds a gradient"): a caller that has written the gradient
+ * buffers itself (e.g. a dense all-reduce in place) fills these bytes with 0xFF before the next backward with
+ * cfg.sparse_zero, which then rewrites every row */
+int riggs_raster_backward_workspace_rows(int32_t num_points, size_t* offset, size_t* bytes);
 /* cfg->deterministic: [accumulators | one row of 10 floats per tile instance | the instances of every Gaussian in tile order |
  * their offsets]; need not be zeroed */
 size_t riggs_raster_backward_workspace_bytes_ordered(int32_t num_points, int64_t instance_capacity);

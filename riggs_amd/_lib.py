@@ -40,6 +40,7 @@ _SIGS = {
     "riggs_raster_binning_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "riggs_raster_backward_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "riggs_raster_backward_workspace_bytes_ordered": (C.c_size_t, [C.c_int32, C.c_int64]),
+    "riggs_raster_backward_workspace_rows": (C.c_int, [C.c_int32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "riggs_raster_geom_layout": (C.c_int, [C.c_int32, C.POINTER(C.c_size_t)]),
     "riggs_raster_image_layout": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
     "riggs_raster_binning_layout": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),

@@ -132,6 +132,11 @@ size_t riggs_raster_geom_bytes(int32_t N) { return geom_layout(N).total; }
 size_t riggs_raster_image_bytes(int32_t H, int32_t W) { return image_layout(H, W).total; }
 size_t riggs_raster_binning_bytes(int64_t cap, int32_t N, int32_t H, int32_t W) { return bin_layout(cap, N, H, W).total; }
 size_t riggs_raster_backward_workspace_bytes(int32_t N) { return ws_blocks_offset(N) + align_up((size_t)((N > 0 ? N : 1) + 255) / 256 * 4); }
+int riggs_raster_backward_workspace_rows(int32_t N, size_t* offset, size_t* bytes) {
+  *offset = ws_bits_offset(N);
+  *bytes = (size_t)((N > 0 ? N : 1) + 63) / 64 * 8;
+  return 0;
+}
 size_t riggs_raster_backward_workspace_bytes_ordered(int32_t N, int64_t cap) {
   const size_t c = (size_t)(cap > 0 ? cap : 1), n = (size_t)(N > 0 ? N : 1);
   return riggs_raster_backward_workspace_bytes(N) + align_up(c * 40) + align_up(c * 4) + align_up((n + 1) * 4);

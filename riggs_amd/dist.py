@@ -542,3 +542,6 @@ class SparseRowExchange:
         for g in self.rows:
             self._reduce_dense(g)
         self._join()
+        if self.record_rows and self.workspace is not None:  # every row may now hold something: the next sparse backward rewrites all
+            from .rasterizer import mark_all_rows
+            mark_all_rows(self.workspace, self.N)

@@ -169,6 +169,13 @@ class GraphedFrame:
             self.reset_sparse_rows()
         return self
 
+    def mark_all_rows(self):
+        """After another writer of the captured gradient buffers (a dense all-reduce in place ...): the next replay rewrites
+        every row; the values now in the buffers are kept."""
+        if self.sparse_outputs:
+            from .rasterizer import mark_all_rows
+            mark_all_rows(self.backward_workspace, int(self.gm.get_xyz.shape[0]))
+
     def reset_sparse_rows(self):
         """Zero the captured gradient buffers and the workspace's row list together: the state ``sparse_grad_rows`` starts
         from, and what to call after anything else has written into those buffers (e.g. a dense all-reduce)."""

@@ -269,6 +269,15 @@ _LAST_SPARSE_OUTPUTS = []  # addresses of the gradient buffers of the most recen
 SPARSE_GRAD_ROWS = False   # set by GraphedFrame around its capture only
 
 
+def mark_all_rows(workspace: torch.Tensor, N: int):
+    """Tell the next sparse backward that every gradient row may hold something (after a writer that does not keep the row
+    list, e.g. a dense all-reduce in place): it then rewrites all of them."""
+    import ctypes as C
+    off, nbytes = C.c_size_t(), C.c_size_t()
+    L.check(L.lib().riggs_raster_backward_workspace_rows(N, C.byref(off), C.byref(nbytes)), "riggs_raster_backward_workspace_rows")
+    workspace[off.value:off.value + nbytes.value].fill_(0xFF)
+
+
 def last_backward_workspace():
     """(workspace, N) of the most recent ``rasterize_backward``: behind its accumulators the call leaves which Gaussians
     received a gradient (include/riggs_hip.h: riggs_grad_rows_pack reads it; riggs_amd.dist.SparseRowExchange)."""

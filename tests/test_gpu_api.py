@@ -328,5 +328,15 @@ def test_captured_frame_skips_the_zero_fill_of_untouched_rows_without_leaving_st
             lost_rows += int((prev_nz & ~nz).sum())
         prev_nz = nz
     assert lost_rows > 100                                                     # the sequence did exercise "had a gradient, has none now"
+    # another writer (say a dense all-reduce in place) fills every row: after mark_all_rows() the next replay rewrites them all
+    for t in sparse.sparse_outputs:
+        t.fill_(7.0)
+    sparse.mark_all_rows()
+    a = sparse.run()
+    b = full.run()
+    torch.cuda.synchronize()
+    for ga, gb in list(zip(sparse.grads, full.grads)) + [(a["viewspace_points_grad"], b["viewspace_points_grad"])]:
+        assert int(((ga != 0) & (gb == 0)).sum()) == 0
+        torch.testing.assert_close(ga, gb, rtol=1e-4, atol=2e-6 * float(gb.abs().max()) + 1e-12)
     sparse.reset_sparse_rows()
     assert all(float(t.abs().max()) == 0.0 for t in sparse.sparse_outputs)
