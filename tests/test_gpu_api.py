@@ -305,11 +305,13 @@ def test_captured_frame_skips_the_zero_fill_of_untouched_rows_without_leaving_st
     finally:
         bench.WORKLOAD.clear()
         bench.WORKLOAD.update(old)
-    params = bench.params_of(gm, sw)
+    import copy
+    gm2, sw2 = copy.deepcopy(gm), copy.deepcopy(sw)  # (its own parameters: the two frames must not share gradient buffers)
     gimg = torch.rand(3, 96, 112, generator=torch.Generator().manual_seed(5)).cuda()
-    sparse = GraphedFrame(gm, sw, cam, torch.zeros(3, device="cuda"), params).capture()
-    full = GraphedFrame(gm, sw, cam, torch.zeros(3, device="cuda"), params, sparse_grad_rows=False).capture()
+    sparse = GraphedFrame(gm, sw, cam, torch.zeros(3, device="cuda"), bench.params_of(gm, sw)).capture()
+    full = GraphedFrame(gm2, sw2, cam, torch.zeros(3, device="cuda"), bench.params_of(gm2, sw2), sparse_grad_rows=False).capture()
     assert sparse.sparse_rows and len(sparse.sparse_outputs) >= 6 and not full.sparse_outputs
+    assert not {t.data_ptr() for t in sparse.grads} & {t.data_ptr() for t in full.grads}
     sparse.set_inputs(gimg=gimg)
     full.set_inputs(gimg=gimg)
     lost_rows = 0
