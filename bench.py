@@ -666,7 +666,9 @@ def main():
             gm.training_setup(_train_args(), capturable=True)
             sk_opt = FusedAdam([{"params": g_["params"], "lr": 5e-4, "name": g_["name"]} for g_ in sw.trainable_parameters()],
                                lr=0.0, eps=1e-15, capturable=True)
-            gts = GraphedTrainStep(gm, sw, cam, torch.zeros(3, device=dev), target, [gm.optimizer, sk_opt], lambda_dssim=0.2)
+            # (the headline frame `gf` shares these gradient buffers but is not replayed any more: this frame is their only writer)
+            gts = GraphedTrainStep(gm, sw, cam, torch.zeros(3, device=dev), target, [gm.optimizer, sk_opt], lambda_dssim=0.2,
+                                   sparse_grad_rows=True)
             gts.capture()
             for _ in range(5):
                 gts.run()

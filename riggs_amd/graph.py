@@ -26,16 +26,18 @@ class _Pipe:
 
 class GraphedFrame:
     def __init__(self, gm, sw, cam: Camera, bg: torch.Tensor, params, headroom: float = 1.5, fused: bool = True,
-                 split_backward: bool = False, sparse_grad_rows: bool = None):
+                 split_backward: bool = False, sparse_grad_rows: bool = False):
         """``split_backward``: capture the frame as TWO graphs — (a) forward + rasterizer backward, (b) deformation backward
         (skinning, FK, PoseMLP) — so that a data-parallel caller can put the all-reduce of the gradients that are final after
         (a) on the links while (b) still runs (riggs_amd.dist.OverlappedExchange): ``run_a()``, ``run_b()``."""
         self.split = bool(split_backward)
-        # ``sparse_grad_rows``: the per-Gaussian backward rewrites only the rows that have a gradient now or had one in the
-        # previous replay (riggs_raster_cfg.sparse_zero) — valid while nobody else writes the captured gradient buffers
-        # between replays: an optimizer only reads them; riggs_amd.dist.SparseRowExchange records what it writes
-        # (``record_rows``); a dense in-place all-reduce does NOT qualify, hence off by default for a split frame.
-        self.sparse_rows = (not self.split) if sparse_grad_rows is None else bool(sparse_grad_rows)
+        # ``sparse_grad_rows`` (opt-in): the per-Gaussian backward rewrites only the rows that have a gradient now or had one
+        # in the previous replay (riggs_raster_cfg.sparse_zero).  The caller promises that THIS frame is the only writer of
+        # the Gaussians' gradient buffers between its replays: an optimizer only reads them and
+        # riggs_amd.dist.SparseRowExchange records what it writes (``record_rows``), but a dense in-place all-reduce, an eager
+        # backward or ANOTHER captured frame over the same parameters (it is handed the same bucket slices) does write them —
+        # call ``mark_all_rows()`` after such a writer, or leave this off.
+        self.sparse_rows = bool(sparse_grad_rows)
         self.gm, self.sw, self.params = gm, sw, list(params)
         dev = bg.device
         self.cam = Camera(cam.image_height, cam.image_width, cam.FoVx, cam.FoVy, cam.world_view_transform.clone(),
@@ -237,9 +239,9 @@ class GraphedTrainStep(GraphedFrame):
 
     def __init__(self, gm, sw, cam: Camera, bg: torch.Tensor, gt_image: torch.Tensor, optimizers, lambda_dssim: float = 0.2,
                  headroom: float = 1.5, thinned: torch.Tensor = None, projection_weight: float = 1e-3, K=None,
-                 max_pixels: int = None):
+                 max_pixels: int = None, sparse_grad_rows: bool = False):
         params = gm.parameters() + [p for g in sw.trainable_parameters() for p in g["params"]]
-        super().__init__(gm, sw, cam, bg, params, headroom=headroom, fused=True)
+        super().__init__(gm, sw, cam, bg, params, headroom=headroom, fused=True, sparse_grad_rows=sparse_grad_rows)
         for o in optimizers:
             if not getattr(o, "hip_capturable", False):
                 raise ValueError("GraphedTrainStep needs FusedAdam(capturable=True) optimizers")

@@ -153,7 +153,8 @@ def test_flat_gradient_bucket_receives_gradients_in_place():
         bench.WORKLOAD.update(old)
 
 
-def test_graphed_train_step_matches_eager_iterations():
+@pytest.mark.parametrize("sparse_rows", [False, True])
+def test_graphed_train_step_matches_eager_iterations(sparse_rows):
     """A whole training iteration (deform, render, fused loss, backward, capturable FusedAdam on Gaussians AND skeleton)
     captured once and replayed, against the same iterations issued eagerly with torch.optim.Adam and the torch-op loss glue."""
     import copy
@@ -178,8 +179,9 @@ def test_graphed_train_step_matches_eager_iterations():
         gm.training_setup(args, capturable=True)
         sk_opt = FusedAdam([{"params": g["params"], "lr": 5e-4, "name": g["name"]} for g in sw.trainable_parameters()],
                            lr=0.0, eps=1e-15, capturable=True)
-        gts = GraphedTrainStep(gm, sw, cam, bg, gt, [gm.optimizer, sk_opt], lambda_dssim=0.2)
+        gts = GraphedTrainStep(gm, sw, cam, bg, gt, [gm.optimizer, sk_opt], lambda_dssim=0.2, sparse_grad_rows=sparse_rows)
         gts.capture(warmup=1)          # one eager warm-up iteration (iteration 1)
+        assert bool(gts.sparse_outputs) == sparse_rows
         losses = []
         for it in range(2, 5):         # iterations 2..4 are replays; xyz learning rate rescheduled in between
             gm.update_learning_rate(1000 * it)
@@ -308,7 +310,7 @@ def test_captured_frame_skips_the_zero_fill_of_untouched_rows_without_leaving_st
     import copy
     gm2, sw2 = copy.deepcopy(gm), copy.deepcopy(sw)  # (its own parameters: the two frames must not share gradient buffers)
     gimg = torch.rand(3, 96, 112, generator=torch.Generator().manual_seed(5)).cuda()
-    sparse = GraphedFrame(gm, sw, cam, torch.zeros(3, device="cuda"), bench.params_of(gm, sw)).capture()
+    sparse = GraphedFrame(gm, sw, cam, torch.zeros(3, device="cuda"), bench.params_of(gm, sw), sparse_grad_rows=True).capture()
     full = GraphedFrame(gm2, sw2, cam, torch.zeros(3, device="cuda"), bench.params_of(gm2, sw2), sparse_grad_rows=False).capture()
     assert sparse.sparse_rows and len(sparse.sparse_outputs) >= 6 and not full.sparse_outputs
     assert not {t.data_ptr() for t in sparse.grads} & {t.data_ptr() for t in full.grads}
