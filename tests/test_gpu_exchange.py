@@ -179,3 +179,27 @@ def test_row_exchange_around_a_split_captured_frame_is_the_identity_at_world_one
             assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views))
     finally:
         bucket.unregister()
+
+
+def test_sharded_adam_hip_step_equals_torch_adam_on_one_rank():
+    """riggs_amd.dist.ShardedAdam on the GPU (its shard update runs through riggs_adam_step on slices of the flat buffers;
+    world size 1: the collectives drop out) against torch.optim.Adam over three steps, with per-group learning rates and
+    tensor sizes that are not multiples of four."""
+    from riggs_amd.dist import ShardedAdam
+    g = torch.Generator().manual_seed(4)
+    shapes = [(1001, 1, 3), (1001, 15, 3), (1001, 1), (1001, 3), (1001, 4), (7,), (9, 17)]
+    mine = [torch.nn.Parameter(torch.randn(*s, generator=g).cuda()) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    lrs = [2.5e-3, 1.25e-4, 5e-2, 1e-3, 1e-3, 5e-4, 5e-4]
+    opt = ShardedAdam([{"params": [p], "lr": lr} for p, lr in zip(mine, lrs)], eps=1e-15)
+    topt = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(ref, lrs)], lr=0.0, eps=1e-15)
+    assert all(p.data_ptr() >= opt.flat_p.data_ptr() for p in mine)
+    for step in range(3):
+        grads = [torch.randn(*s, generator=g).cuda() for s in shapes]
+        for v, gr, r in zip(opt.bucket.views, grads, ref):
+            v.copy_(gr)
+            r.grad = gr.clone()
+        opt.step()
+        topt.step()
+    for a, b in zip(mine, ref):
+        torch.testing.assert_close(a.detach(), b.detach(), rtol=3e-6, atol=3e-7)
