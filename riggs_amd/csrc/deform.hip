@@ -475,37 +475,64 @@ __global__ __launch_bounds__(256) void lbs_backward_bonelane_kernel(LbsArgs a) {
   // Gaussians without an incoming gradient (behind saturated pixels, never at alpha >= 1/255, invisible: most of a
   // deep scene) contribute exact zeros to every sum: the wave looks at its 64 Gaussians once, writes the zeros of
   // the per-Gaussian outputs, and walks only the others, eight at a time.
-  __shared__ unsigned char s_list[4][64];
-  for (int sub_first = wave_first; sub_first < wave_end; sub_first += 64) {
-  const int sub_end = min(wave_end, sub_first + 64);
-  int n_work;
+  // The wave's Gaussians are looked at in ONE batch — the loads of all its 64-Gaussian groups are in flight together —
+  // and the ones with a gradient are listed across the groups: walking group by group paid two dependent round trips
+  // (test, then the listed Gaussians' operands) per group, which was most of this kernel's time in a sparse frame.
+  constexpr int GROUPS = LB_GPB / 4 / 64;
+  __shared__ unsigned short s_list[4][LB_GPB / 4];
+  int n_work = 0;
   {
-    const int n = sub_first + lane;
-    bool touched = false;
-    if (n < sub_end) {
-      const float4 h4 = reinterpret_cast<const float4*>(a.g_rot)[n];
-      touched = (a.g_xyz[3 * n] != 0.f) || (a.g_xyz[3 * n + 1] != 0.f) || (a.g_xyz[3 * n + 2] != 0.f) ||
-                (h4.x != 0.f) || (h4.y != 0.f) || (h4.z != 0.f) || (h4.w != 0.f);
-      if (!touched) {
+    float4 hq[GROUPS];
+    float gq[GROUPS][3];
+#pragma unroll
+    for (int g4 = 0; g4 < GROUPS; g4++) {
+      const int n = wave_first + 64 * g4 + lane;
+      hq[g4] = make_float4(0.f, 0.f, 0.f, 0.f); gq[g4][0] = 0.f; gq[g4][1] = 0.f; gq[g4][2] = 0.f;
+      if (n < wave_end) {
+        hq[g4] = reinterpret_cast<const float4*>(a.g_rot)[n];
+        gq[g4][0] = a.g_xyz[3 * n]; gq[g4][1] = a.g_xyz[3 * n + 1]; gq[g4][2] = a.g_xyz[3 * n + 2];
+      }
+    }
+#pragma unroll
+    for (int g4 = 0; g4 < GROUPS; g4++) {
+      const int n = wave_first + 64 * g4 + lane;
+      const bool touched = (gq[g4][0] != 0.f) || (gq[g4][1] != 0.f) || (gq[g4][2] != 0.f) ||
+                           (hq[g4].x != 0.f) || (hq[g4].y != 0.f) || (hq[g4].z != 0.f) || (hq[g4].w != 0.f);
+      if (n < wave_end && !touched) {
         if (a.dmask) a.dmask[n] = 0.f;
         if constexpr (MOD) for (int k = 0; k < B; k++) a.dmod[(size_t)n * B + k] = 0.f;
       }
+      const uint64_t tm = __builtin_amdgcn_ballot_w64(touched);
+      if (touched) s_list[wave][n_work + __builtin_popcountll(tm & ((1ull << lane) - 1ull))] = (unsigned short)(64 * g4 + lane);
+      n_work += __builtin_popcountll(tm);
     }
-    const uint64_t tm = __builtin_amdgcn_ballot_w64(touched);
-    n_work = __builtin_popcountll(tm);
-    if (touched) s_list[wave][__builtin_popcountll(tm & ((1ull << lane) - 1ull))] = (unsigned char)lane;
   }
-  for (int w0 = 0; w0 < n_work; w0 += 8) {
-    const bool valid = w0 + slot < n_work;
-    const int n = valid ? sub_first + (int)s_list[wave][w0 + slot] : 0;  // (a wave's own LDS writes are ordered)
-    float px = 0.f, py = 0.f, pz = 0.f, m = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
-    float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid) {
-      px = a.x[3 * n]; py = a.x[3 * n + 1]; pz = a.x[3 * n + 2];
-      m = a.motion_mask ? a.motion_mask[n] : 1.0f;
-      g0 = a.g_xyz[3 * n]; g1 = a.g_xyz[3 * n + 1]; g2 = a.g_xyz[3 * n + 2];
-      h = reinterpret_cast<const float4*>(a.g_rot)[n];
+  {
+  const int sub_first = wave_first;
+  // operands of a step's eight Gaussians, requested one step ahead of their use
+  struct StepOps { int n; bool valid; float px, py, pz, m, g0, g1, g2; float4 h; };
+  auto fetch = [&](int w0) {
+    StepOps o;
+    o.valid = w0 + slot < n_work;
+    o.n = o.valid ? sub_first + (int)s_list[wave][w0 + slot] : 0;  // (a wave's own LDS writes are ordered)
+    o.px = 0.f; o.py = 0.f; o.pz = 0.f; o.m = 0.f; o.g0 = 0.f; o.g1 = 0.f; o.g2 = 0.f;
+    o.h = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (o.valid) {
+      o.px = a.x[3 * o.n]; o.py = a.x[3 * o.n + 1]; o.pz = a.x[3 * o.n + 2];
+      o.m = a.motion_mask ? a.motion_mask[o.n] : 1.0f;
+      o.g0 = a.g_xyz[3 * o.n]; o.g1 = a.g_xyz[3 * o.n + 1]; o.g2 = a.g_xyz[3 * o.n + 2];
+      o.h = reinterpret_cast<const float4*>(a.g_rot)[o.n];
     }
+    return o;
+  };
+  StepOps nxt = fetch(0);
+  for (int w0 = 0; w0 < n_work; w0 += 8) {
+    const StepOps cu = nxt;
+    if (w0 + 8 < n_work) nxt = fetch(w0 + 8);
+    const bool valid = cu.valid;
+    const int n = cu.n;
+    const float px = cu.px, py = cu.py, pz = cu.pz, m = cu.m, g0 = cu.g0, g1 = cu.g1, g2 = cu.g2;
+    const float4 h = cu.h;
     const float gh0 = g0 * m, gh1 = g1 * m, gh2 = g2 * m;
     const float hh0 = h.x * m, hh1 = h.y * m, hh2 = h.z * m, hh3 = h.w * m;
     // pass 1: this lane's bones
