@@ -21,7 +21,7 @@ def main():
         sc, cam, gm, sw = bench.build_workload(0, "cuda:0")
         params = bench.params_of(gm, sw)
         gimg = torch.rand(3, cfg["H"], cfg["W"], device="cuda") * 1e-6
-        gf = GraphedFrame(gm, sw, cam, torch.zeros(3, device="cuda"), params).capture()
+        gf = GraphedFrame(gm, sw, cam, torch.zeros(3, device="cuda"), params, sparse_grad_rows=True).capture()  # (as bench.py)
         gf.set_inputs(gimg=gimg)
         for _ in range(5):
             gf.run()
