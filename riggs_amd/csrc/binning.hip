@@ -510,6 +510,22 @@ __global__ __launch_bounds__(RS_SC_WAVES * 64) void rs_scatter_kernel(int N, int
   const int shift = pass * RS_BITS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int NT = RS_SC_WAVES * 64, PER = RS_BINS / NT;   // bins per thread in the scan
+  // every global load of the workgroup up front — its elements, its row of the chunk table, the bin totals — so that the
+  // scan and the two barriers below run under ONE round trip instead of in front of two more (the compiler keeps loads
+  // behind a barrier where it finds them)
+  constexpr int STEPS = RS_CHUNK / NT;
+  const int wfirst = blockIdx.x * RS_CHUNK + wave * (64 * STEPS);
+  uint32_t key[STEPS], val[STEPS];
+#pragma unroll
+  for (int st = 0; st < STEPS; st++) {
+    const int i = wfirst + st * 64 + lane;
+    key[st] = 0u; val[st] = 0u;
+    if (i < N) { key[st] = ks[i]; val[st] = vs ? vs[i] : (uint32_t)i; }
+  }
+  const uint32_t* row = table + (size_t)blockIdx.x * RS_BINS;
+  uint32_t rw[PER];
+#pragma unroll
+  for (int k = 0; k < PER; k++) rw[k] = row[tid * PER + k];
   // exclusive scan of bin_count
   uint32_t c[PER], tsum = 0;
 #pragma unroll
@@ -524,20 +540,15 @@ __global__ __launch_bounds__(RS_SC_WAVES * 64) void rs_scatter_kernel(int N, int
   __syncthreads();
   uint32_t run = v - tsum;
   for (int w = 0; w < wave; w++) run += s_part[w];
-  const uint32_t* row = table + (size_t)blockIdx.x * RS_BINS;
 #pragma unroll
-  for (int k = 0; k < PER; k++) { s_start[tid * PER + k] = run + row[tid * PER + k]; run += c[k]; }
+  for (int k = 0; k < PER; k++) { s_start[tid * PER + k] = run + rw[k]; run += c[k]; }
   // this wave's elements: 4 steps of 64 consecutive elements
-  constexpr int STEPS = RS_CHUNK / NT;
-  const int wfirst = blockIdx.x * RS_CHUNK + wave * (64 * STEPS);
-  uint32_t key[STEPS], val[STEPS];
   int dig[STEPS];
 #pragma unroll
   for (int st = 0; st < STEPS; st++) {
     const int i = wfirst + st * 64 + lane;
-    key[st] = 0u; val[st] = 0u; dig[st] = -1;
+    dig[st] = -1;
     if (i < N) {
-      key[st] = ks[i]; val[st] = vs ? vs[i] : (uint32_t)i;
       dig[st] = (int)((key[st] >> shift) & (RS_BINS - 1));
       // 16-bit counters packed in pairs (a wave adds at most 256 per bin)
       atomicAdd(reinterpret_cast<uint32_t*>(&s_wave[wave][0]) + (dig[st] >> 1), 1u << (16 * (dig[st] & 1)));
