@@ -640,7 +640,10 @@ def main():
             "config": {"workload": "300k Gaussians / 24-joint skeleton / 800x800, LBS-only, SH degree 3, anisotropic, "
                                    "one frame per GPU per step", "num_gaussians": w["N"], "num_joints": w["J"],
                        "image": [w["H"], w["W"]], "tile_instances_R": R, "parallelism": "frames x%d" % world, "exchange": None if world == 1 else exchange_label,
-                       "launch": "eager" if args.no_graph else "hipGraph replay"},
+                       "launch": "eager" if args.no_graph else "hipGraph replay",
+                       "gradient_rows": "every row written" if (args.no_graph or not gf.sparse_outputs) else
+                       "rows without a gradient now and in the previous replay are not rewritten (they hold their zeros); the timed "
+                       "frame's gradients are compared with the oracle below"},
             # The dominant kernel is a compositing kernel: SURVEY.md §8-d bounds those by vector issue, not by HBM.  `achieved /
             # peak / frac` stay the HBM numbers from ALGORITHMIC bytes (the contract's definition); `bound` says what actually
             # limits the kernel, `frac_hbm_counter_bytes` prices the bytes the PMC counters saw, `valu` the issue time.
