@@ -489,6 +489,10 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    if not args.no_graph:
+        # (outside the timed region) the device-side status words of the replays just timed: PoseMLP hand-off time-outs, the
+        # sort's in-launch barrier, an instance arena that overflowed — any of them raises here instead of being a silent number
+        assert gf.check() == R, "the timed frames disagree with the first frame on the instance count"
     if world > 1 and rows is not None and not args.no_graph:
         assert rows.check(), "a gradient-row segment overflowed inside the timed region (that step was not exchanged)"
         # outside the timed region: one more step whose exchanged gradients are compared with a plain all-reduce of the same
