@@ -68,14 +68,12 @@ def test_c4_full_size_properties():
     assert R > 2_000_000 and vis > 0.9 * N
 
 
-def test_c4_full_size_pipeline_parity_vs_oracle():
-    """C4 at FULL size — 500k Gaussians, 24 joints, 1024x1024, projection from K with the off-centre principal point —
-    through the whole hot path (skeleton deformation -> fused glue -> rasterizer forward + backward) against the CPU oracle
-    run on the same inputs (a few seconds on the host): image and every parameter gradient within the bar bench.py applies
-    at the headline size (per tensor <= 2e-3 of the elements beyond 1e-4 of max|oracle|)."""
+def _pipeline_parity_vs_oracle(N, J, H, W, cam_cpu, tag):
+    """The whole hot path (skeleton deformation -> fused glue -> rasterizer forward + backward) on the HIP side against the
+    CPU oracle run on the same inputs: image and every parameter gradient within the bar bench.py applies at the headline size
+    (per tensor <= 2e-3 of the elements beyond 1e-4 of max|oracle|).  Returns R."""
     import bench
     from riggs_amd.rasterizer import RasterArena
-    N, J, H, W = 500_000, 24, 1024, 1024
     old = dict(bench.WORKLOAD)
     bench.WORKLOAD.update(N=N, J=J, H=H, W=W)
     try:
@@ -83,7 +81,6 @@ def test_c4_full_size_pipeline_parity_vs_oracle():
     finally:
         bench.WORKLOAD.clear()
         bench.WORKLOAD.update(old)
-    cam_cpu = synth.look_at_camera(H, W, K=zju_K(H, W), fid=0.37)
     cam = cam_cpu.to("cuda:0")
     gimg = torch.sign(torch.rand(3, H, W, generator=torch.Generator().manual_seed(9)) - 0.5) / (3 * H * W)
     step = bench.make_step(cam, gm, sw, gimg.cuda(), RasterArena(), 1, None)
@@ -97,7 +94,6 @@ def test_c4_full_size_pipeline_parity_vs_oracle():
     pose = (na["local_rotation"].detach().cpu(), na["global_trans"].detach().cpu())
     bench._set_threads(16)
     ora_image, ora_grads, R = bench._oracle_iteration(sc, cam_cpu, gimg, pose)
-    assert R > 2_000_000
     worst = 0.0
     pairs = [("image", pkg["render"].detach().cpu().numpy(), ora_image)] + [("dL/d_" + k, hip_grads[k], ora_grads[k]) for k in hip_grads]
     assert len(pairs) == 9
@@ -107,15 +103,30 @@ def test_c4_full_size_pipeline_parity_vs_oracle():
         err = np.abs(a - b)
         assert scale > 0
         if b.size < 1000:
-            # dL/d node_radius: 24 sums over 500k Gaussians each, of terms that cancel (random-sign cotangent): the float32
-            # summation order alone moves them by ~1e-4 of the largest; the per-Gaussian tensors below are the sharp check
-            assert err.max() <= 5e-4 * scale, (name, err.max() / scale)
+            # dL/d node_radius: J sums over all the Gaussians, of terms that cancel (random-sign cotangent): the float32
+            # summation order alone moves them by ~1e-4 of the largest; the per-Gaussian tensors are the sharp check
+            assert err.max() <= 5e-4 * scale, (tag, name, err.max() / scale)
             continue
         frac = float((err > 1e-4 * scale).mean())
         worst = max(worst, frac)
-        assert frac <= 2e-3, (name, frac, err.max() / scale)
-        U.STATS.append(("C4 full size " + name, int(b.size), frac, float(err.max() / scale), float((err > 1e-4 * np.abs(b) + 1e-6 * scale).mean())))
+        assert frac <= 2e-3, (tag, name, frac, err.max() / scale)
+        U.STATS.append((tag + " full size " + name, int(b.size), frac, float(err.max() / scale), float((err > 1e-4 * np.abs(b) + 1e-6 * scale).mean())))
     assert worst <= 2e-3
+    return R
+
+
+def test_c4_full_size_pipeline_parity_vs_oracle():
+    """C4 at FULL size — 500k Gaussians, 24 joints, 1024x1024, projection from K with the off-centre principal point —
+    against the CPU oracle (a few seconds on the host)."""
+    H = W = 1024
+    assert _pipeline_parity_vs_oracle(500_000, 24, H, W, synth.look_at_camera(H, W, K=zju_K(H, W), fid=0.37), "C4") > 2_000_000
+
+
+def test_c5_full_size_pipeline_parity_vs_oracle():
+    """C5 at FULL size — 2M Gaussians, 64 joints (the layered PoseMLP kernels: 259 head rows), 1920x1080, R = 38.8 M tile
+    instances, the binning walking nine batches per wave — against the CPU oracle (~half a minute on the host)."""
+    H, W = 1080, 1920
+    assert _pipeline_parity_vs_oracle(2_000_000, 64, H, W, synth.look_at_camera(H, W, fid=0.37), "C5") > 30_000_000
 
 
 def test_c4_reference_glue_fixture_through_the_hip_glue_path():
