@@ -1,4 +1,4 @@
-"""-m gpu: BASELINE.json configs C4 and C5.
+"""-m gpu: BASELINE.json configs C2 .. C5 at full size.
 
 C4 = ZJU-MoCap-like: ~500k Gaussians, 24 joints, 1024x1024, the camera built from an intrinsic matrix K with an
 off-centre principal point (+13, -7) px — the reference's ``getProjectionMatrix_from_K`` path
@@ -120,6 +120,12 @@ def test_c4_full_size_pipeline_parity_vs_oracle():
     against the CPU oracle (a few seconds on the host)."""
     H = W = 1024
     assert _pipeline_parity_vs_oracle(500_000, 24, H, W, synth.look_at_camera(H, W, K=zju_K(H, W), fid=0.37), "C4") > 2_000_000
+
+
+@pytest.mark.parametrize("N,J,tag", [(150_000, 24, "C2"), (300_000, 32, "C3")])
+def test_c2_c3_full_size_pipeline_parity_vs_oracle(N, J, tag):
+    """C2 (D-NeRF-like: 150k Gaussians, 24 joints) and C3 (300k, 32 joints) at 800x800, full size, against the CPU oracle."""
+    assert _pipeline_parity_vs_oracle(N, J, 800, 800, synth.look_at_camera(800, 800, fid=0.37), tag) > 500_000
 
 
 def test_c5_full_size_pipeline_parity_vs_oracle():
