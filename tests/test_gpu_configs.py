@@ -68,7 +68,7 @@ def test_c4_full_size_properties():
     assert R > 2_000_000 and vis > 0.9 * N
 
 
-def _pipeline_parity_vs_oracle(N, J, H, W, cam_cpu, tag):
+def _pipeline_parity_vs_oracle(N, J, H, W, cam_cpu, tag, surface=False):
     """The whole hot path (skeleton deformation -> fused glue -> rasterizer forward + backward) on the HIP side against the
     CPU oracle run on the same inputs: image and every parameter gradient within the bar bench.py applies at the headline size
     (per tensor <= 2e-3 of the elements beyond 1e-4 of max|oracle|).  Returns R."""
@@ -78,6 +78,10 @@ def _pipeline_parity_vs_oracle(N, J, H, W, cam_cpu, tag):
     bench.WORKLOAD.update(N=N, J=J, H=H, W=W)
     try:
         sc, _, gm, sw = bench.build_workload(0, "cuda:0")
+        if surface:  # the dense-gradient scene of bench.py: a thin, mostly opaque skin around the same skeleton
+            sc = synth.make_surface_scene(N, J, bench.WORKLOAD["seed"])
+            gm = GaussianModel.from_tensors(sc["xyz"], sc["features_dc"], sc["features_rest"], sc["scaling"], sc["rotation"],
+                                            sc["opacity"], device="cuda:0")
     finally:
         bench.WORKLOAD.clear()
         bench.WORKLOAD.update(old)
@@ -103,9 +107,13 @@ def _pipeline_parity_vs_oracle(N, J, H, W, cam_cpu, tag):
         err = np.abs(a - b)
         assert scale > 0
         if b.size < 1000:
-            # dL/d node_radius: J sums over all the Gaussians, of terms that cancel (random-sign cotangent): the float32
-            # summation order alone moves them by ~1e-4 of the largest; the per-Gaussian tensors are the sharp check
-            assert err.max() <= 5e-4 * scale, (tag, name, err.max() / scale)
+            # dL/d node_radius: J sums over all the Gaussians of terms that cancel (random-sign cotangent).  The sums inherit
+            # the per-Gaussian outliers counted below — the few Gaussians whose alpha >= 1/255, 0.99-cap or T < 1e-4 decision
+            # flips between the two sides' roundings of the deformed means (SURVEY.md §7 "hard parts") — undiluted: ~1e-4 of
+            # the largest entry in the translucent scenes, 3e-3 in the opaque-skin scene, where every flip is a large term
+            # (the float32 oracle's own deformation backward is within 3e-6 of a float64 run on identical upstream
+            # gradients, so this is not summation order).  The per-Gaussian tensors are the sharp check.
+            assert err.max() <= (1e-2 if surface else 5e-4) * scale, (tag, name, err.max() / scale)
             continue
         frac = float((err > 1e-4 * scale).mean())
         worst = max(worst, frac)
@@ -126,6 +134,12 @@ def test_c4_full_size_pipeline_parity_vs_oracle():
 def test_c2_c3_full_size_pipeline_parity_vs_oracle(N, J, tag):
     """C2 (D-NeRF-like: 150k Gaussians, 24 joints) and C3 (300k, 32 joints) at 800x800, full size, against the CPU oracle."""
     assert _pipeline_parity_vs_oracle(N, J, 800, 800, synth.look_at_camera(800, 800, fid=0.37), tag) > 500_000
+
+
+def test_dense_gradient_scene_full_size_pipeline_parity_vs_oracle():
+    """The dense-gradient scene bench.py reports (thin opaque skin: pixels saturate after a few layers, the T < 1e-4 stop and
+    the 0.99 cap carry most pixels) at the headline size, against the CPU oracle."""
+    assert _pipeline_parity_vs_oracle(300_000, 24, 800, 800, synth.look_at_camera(800, 800, fid=0.37), "dense scene", surface=True) > 500_000
 
 
 def test_c5_full_size_pipeline_parity_vs_oracle():
