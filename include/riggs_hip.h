@@ -58,7 +58,10 @@ typedef struct riggs_raster_cfg {
   /* Ordered-reduction mode of the compositing backward ("deterministic-reduction mode for grads"): instead of
    * float atomics into the per-Gaussian accumulators, every (tile instance) writes its partial gradient row and a second
    * kernel sums each Gaussian's rows in ascending tile order: gradients are bitwise reproducible run to run.  Needs the
-   * larger workspace of riggs_raster_backward_workspace_bytes_ordered; slower (tests / debugging). */
+   * larger workspace of riggs_raster_backward_workspace_bytes_ordered; slower (tests / debugging).
+   * riggs_raster_render: the segments of a long tile's list (> 1024 instances) are all composited from T = 1 and combined in
+   * a fixed association; without the flag a segment whose predecessors have already finished continues from their result,
+   * which rounds differently (1e-7 relative) and depends on timing: the image is bitwise reproducible only with the flag. */
   int32_t deterministic;
   /* riggs_raster_backward only.  1 = the caller guarantees that the gradient output buffers are the SAME buffers the previous
    * riggs_raster_backward with this workspace wrote and that nobody has written them since (or that buffers and workspace
@@ -389,11 +392,15 @@ int riggs_dist2_knn3(int32_t num_points, const float* points, float* out, void* 
  * riggs_prof_read synchronises on the recorded events and returns the sum / count since the
  * last riggs_prof_reset.  Stage ids: riggs_prof_name(i) for i in [0, riggs_prof_count()).
  * ===================================================================== */
-/* debugging aid: per-wave statistics of the forward compositing kernel (6 u64 per wave, 8 pixel blocks x 4 waves
- * per tile: {100 MHz ticks, rounds, survivors | hardware id << 32, steps, steps with a contribution, list length}),
- * followed (at word n_tiles * 192) by 4 u64 per chunk of the compositing backward ({start, end, hardware id,
- * workgroup << 32 | tile << 16 | chunk}); tools/fwd_trace.py, fwd_placement.py, bwd_trace.py.  NULL disables */
+/* debugging aid: per-wave statistics of the forward compositing kernel (8 u64 per wave, 4 waves per work item — a work
+ * item is one 8x4 pixel block of one segment of one tile, in launch order: {100 MHz ticks of the compositing loop, rounds,
+ * survivors | hardware id << 32, steps, steps with a contribution, segment length | tile << 32 | segment << 48, start tick,
+ * ticks in the segment chain | segments combined << 32 | chunks re-walked << 44 | chunks scanned back << 54}), followed (at word
+ * n_items * 32; n_items = riggs_raster_set_trace_items, default 8 per tile) by 4 u64 per chunk of the compositing backward
+ * ({start, end, hardware id, workgroup << 32 | tile << 16 | chunk}); tools/fwd_trace.py, fwd_placement.py, bwd_trace.py.
+ * NULL disables */
 int riggs_raster_set_trace(void* dev_u64);
+int riggs_raster_set_trace_items(uint64_t n_items);
 /* =====================================================================
  * Per-Gaussian MLP heads on the matrix cores: WeightMLP / DeformMLP of
  * skeleton_utils/network_utils.py:6-112 as one fused launch per direction — 16-bit operands, fp32 accumulation

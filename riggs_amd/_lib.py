@@ -78,6 +78,7 @@ _SIGS = {
     "riggs_skeleton_projection_forward": (C.c_int, [C.c_int32] * 3 + [_P] * 4 + [C.c_float] * 4 + [_P] * 6),
     "riggs_skeleton_projection_backward": (C.c_int, [C.c_int32] * 3 + [_P] * 4 + [C.c_float] * 4 + [_P] * 8),
     "riggs_raster_set_trace": (C.c_int, [_P]),
+    "riggs_raster_set_trace_items": (C.c_int, [C.c_uint64]),
     "riggs_mlp_forward": (C.c_int, [C.c_int32] * 5 + [_P] * 8 + [C.c_int32, _P]),
     "riggs_mlp_backward": (C.c_int, [C.c_int32] * 4 + [_P] * 7 + [C.c_int32, _P]),
     "riggs_mlp_rows_per_workgroup": (C.c_int32, []),

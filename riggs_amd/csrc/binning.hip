@@ -101,18 +101,38 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(int T, int n_chunks, uin
 }
 
 // exclusive scan over the tiles (one workgroup — the extra, last one of bin_scatter_kernel's grid): ranges, checkpoint slot
-// bases, cleared per-tile words, R and the overflow flag, and the forward's work list
-__device__ void bin_offsets_body(int T, int64_t cap, const uint32_t* __restrict__ tile_count, uint2* __restrict__ ranges,
-                                 uint32_t* __restrict__ slot_base, uint32_t* __restrict__ tile_max,
-                                 uint32_t* __restrict__ counters, uint32_t* __restrict__ fwd_items,
-                                 uint32_t* __restrict__ fwd_empty, uint32_t* __restrict__ fwd_ctr) {
+// bases, cleared per-tile words, R and the overflow flag, and the forward's work list.
+// The work list has one entry per (non-empty tile, segment of RIGGS_SEG instances): tile | segment << 16.  All FIRST
+// segments come first (longest lists first, as before: the workgroups that walk the lists), then the helpers of the later
+// segments, deepest level first: the hardware starts workgroups in this order, so a helper starts when the walkers leave
+// it room — by then a tile whose pixels saturate has usually told its helpers (dead_from) that they have nothing to do, and
+// the far segments, the ones a helper can finish before the walker arrives, are taken first (render.hip).
+#define SEG_LMAX 2048  // segment levels with a cursor of their own (deeper ones share the last)
+__device__ void bin_offsets_body(int T, int64_t cap, const uint32_t* __restrict__ tile_count, const BinOut o,
+                                 uint32_t* __restrict__ s_lvl /* LDS, 2 * SEG_LMAX words */) {
+  uint2* __restrict__ ranges = o.ranges;
+  uint32_t* __restrict__ slot_base = o.slot_base;
+  uint32_t* __restrict__ tile_max = o.tile_max;
+  uint32_t* __restrict__ counters = o.counters;
+  uint32_t* __restrict__ fwd_items = o.fwd_items;
+  uint32_t* __restrict__ fwd_empty = o.fwd_empty;
+  uint32_t* __restrict__ fwd_ctr = o.fwd_ctr;
   __shared__ uint32_t s_wave[16];
   __shared__ uint32_t s_carry;
-  __shared__ uint32_t s_hist[32], s_cur[32], s_nempty;
+  __shared__ uint32_t s_hist[32], s_cur[32], s_nempty, s_n0;
   const int nthr = (int)blockDim.x;  // <= 1024
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) { s_carry = 0u; s_nempty = 0u; }
   if (tid < 32) s_hist[tid] = 0u;
+  for (int k = tid; k < 2 * SEG_LMAX; k += nthr) s_lvl[k] = 0u;
+  {
+    // the hand-shake words of the segmented tiles and the per-block "dead from" words start every frame at zero
+    uint4* f4 = reinterpret_cast<uint4*>(o.seg_flags);
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (size_t e = tid; e < (size_t)o.n_seg_slots * 2; e += nthr) f4[e] = z;
+    uint4* d4 = reinterpret_cast<uint4*>(o.dead_from);
+    for (size_t e = tid; e < (size_t)T * 2; e += nthr) d4[e] = z;
+  }
   __syncthreads();
   uint32_t my_len[8];  // list lengths of this thread's tiles (the first 8 passes; beyond that they are re-read)
 #pragma unroll
@@ -122,9 +142,9 @@ __device__ void bin_offsets_body(int T, int64_t cap, const uint32_t* __restrict_
     const uint32_t c = (t < T) ? tile_count[t] : 0u;
     // inclusive scan inside the wave
     uint32_t v = c;
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t u = (uint32_t)__shfl_up((int)v, o);
-      if (lane >= o) v += u;
+    for (int o2 = 1; o2 < 64; o2 <<= 1) {
+      const uint32_t u = (uint32_t)__shfl_up((int)v, o2);
+      if (lane >= o2) v += u;
     }
     if (lane == 63) s_wave[wave] = v;
     __syncthreads();
@@ -143,6 +163,9 @@ __device__ void bin_offsets_body(int T, int64_t cap, const uint32_t* __restrict_
       // forward work queue, step 1: histogram of floor(log2(list length)); the empty tiles go to their own list
       if (hi > lo) atomicAdd(&s_hist[31 - __builtin_clz(hi - lo)], 1u);
       else fwd_empty[atomicAdd(&s_nempty, 1u)] = (uint32_t)t;
+      // ... and the number of tiles that have a k-th segment, k = 1, 2, ...
+      const uint32_t nseg = (hi - lo + RIGGS_SEG - 1) / RIGGS_SEG;
+      for (uint32_t k = 1; k < nseg; k++) atomicAdd(&s_lvl[min(k, (uint32_t)SEG_LMAX - 1u)], 1u);
 #pragma unroll
       for (int k = 0; k < 8; k++) if (pass == k) my_len[k] = hi - lo;
     }
@@ -164,22 +187,54 @@ __device__ void bin_offsets_body(int T, int64_t cap, const uint32_t* __restrict_
   if (tid < 32) {
     const uint32_t h = s_hist[31 - tid];
     uint32_t v = h;
-    for (int o = 1; o < 32; o <<= 1) {
-      const uint32_t u = (uint32_t)__shfl_up((int)v, o);
-      if (tid >= o) v += u;
+    for (int o2 = 1; o2 < 32; o2 <<= 1) {
+      const uint32_t u = (uint32_t)__shfl_up((int)v, o2);
+      if (tid >= o2) v += u;
     }
     s_cur[31 - tid] = v - h;
-    if (tid == 31) { fwd_ctr[0] = v; fwd_ctr[1] = 0u; fwd_ctr[2] = s_nempty; fwd_ctr[64] = 0u; }  // ([64]: backward work-list size, on its own cache line)
+    if (tid == 31) { s_n0 = v; fwd_ctr[1] = 0u; fwd_ctr[2] = s_nempty; fwd_ctr[64] = 0u; }  // ([64]: backward work-list size, on its own cache line)
   }
   __syncthreads();
+  // step 3: the DEEPEST level first (a helper is useful if it is done before the walking workgroup arrives: the far segments
+  // are the ones that can be): start of a level = the non-empty tiles + the deeper levels.  (Scanned in reversed order:
+  // position q <-> level SEG_LMAX - q.)
+  if (tid == 0) s_carry = s_n0;
+  __syncthreads();
+  for (int base = 1; base < SEG_LMAX; base += nthr) {
+    const int q = base + tid, k = SEG_LMAX - q;
+    const uint32_t c = (q < SEG_LMAX) ? s_lvl[k] : 0u;
+    uint32_t v = c;
+    for (int o2 = 1; o2 < 64; o2 <<= 1) {
+      const uint32_t u = (uint32_t)__shfl_up((int)v, o2);
+      if (lane >= o2) v += u;
+    }
+    if (lane == 63) s_wave[wave] = v;
+    __syncthreads();
+    uint32_t wave_off = 0;
+    for (int w = 0; w < wave; w++) wave_off += s_wave[w];
+    const uint32_t carry = s_carry;
+    if (q < SEG_LMAX) s_lvl[SEG_LMAX + k] = carry + wave_off + v - c;
+    __syncthreads();
+    if (tid == nthr - 1) s_carry = carry + wave_off + v;
+    __syncthreads();
+  }
+  if (tid == 0) fwd_ctr[0] = min(s_carry, o.items_cap);  // (<= T + cap / RIGGS_SEG by construction)
+  auto emit = [&](uint32_t t, uint32_t len) {
+    fwd_items[atomicAdd(&s_cur[31 - __builtin_clz(len)], 1u)] = t;
+    const uint32_t nseg = (len + RIGGS_SEG - 1) / RIGGS_SEG;
+    for (uint32_t k = 1; k < nseg; k++) {
+      const uint32_t at = atomicAdd(&s_lvl[SEG_LMAX + min(k, (uint32_t)SEG_LMAX - 1u)], 1u);
+      if (at < o.items_cap) fwd_items[at] = t | (k << 16);
+    }
+  };
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     const int t = k * nthr + tid;
-    if (t < T && my_len[k] > 0u) fwd_items[atomicAdd(&s_cur[31 - __builtin_clz(my_len[k])], 1u)] = (uint32_t)t;
+    if (t < T && my_len[k] > 0u) emit((uint32_t)t, my_len[k]);
   }
   for (int t = 8 * nthr + tid; t < T; t += nthr) {  // (same thread that wrote ranges[t] above)
     const uint2 r = ranges[t];
-    if (r.y > r.x) fwd_items[atomicAdd(&s_cur[31 - __builtin_clz(r.y - r.x)], 1u)] = (uint32_t)t;
+    if (r.y > r.x) emit((uint32_t)t, r.y - r.x);
   }
 }
 
@@ -192,13 +247,10 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(int N, int T, int gri
                                                           const uint32_t* __restrict__ table,
                                                           const uint32_t* __restrict__ tile_count,
                                                           uint32_t* __restrict__ point_list,
-                                                          uint32_t* __restrict__ tile_keys, uint2* __restrict__ ranges,
-                                                          uint32_t* __restrict__ slot_base, uint32_t* __restrict__ tile_max,
-                                                          uint32_t* __restrict__ counters, uint32_t* __restrict__ fwd_items,
-                                                          uint32_t* __restrict__ fwd_empty, uint32_t* __restrict__ fwd_ctr) {
+                                                          uint32_t* __restrict__ tile_keys, const BinOut out) {
   extern __shared__ uint32_t s_mem[];
   if (blockIdx.x == gridDim.x - 1) {  // the extra workgroup: what used to be a single-workgroup launch of its own
-    bin_offsets_body(T, cap, tile_count, ranges, slot_base, tile_max, counters, fwd_items, fwd_empty, fwd_ctr);
+    bin_offsets_body(T, cap, tile_count, out, s_mem);
     return;
   }
   const int W = blockDim.x >> 6;
@@ -378,13 +430,13 @@ size_t bin_table_bytes(int N, int T) {
 }
 
 int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order, const uint32_t* tiles,
-                   const ushort4* rect, void* table_mem, uint32_t* point_list, uint32_t* tile_keys, uint2* ranges,
-                   uint32_t* slot_base, uint32_t* tile_max, uint32_t* counters, uint32_t* fwd_items,
-                   uint32_t* fwd_empty, uint32_t* fwd_ctr, hipStream_t s) {
+                   const ushort4* rect, void* table_mem, uint32_t* point_list, uint32_t* tile_keys, const BinOut& out,
+                   hipStream_t s) {
   BinPlan p = bin_plan(N, T);
   char* mem = (char*)table_mem;
   uint32_t* table = (uint32_t*)mem;
   uint32_t* tile_count = (uint32_t*)(mem + align_up(((size_t)p.n_chunks + 1) * T * 4));
+  if (T > 65535) { set_error("image too large: %d tiles (the forward's work list packs the tile id into 16 bits)", T); return 2; }
   if (p.lds_scatter > 150 * 1024) {  // (bin_plan is down to one wave per workgroup: T * 6 bytes of LDS)
     set_error("image too large: %d tiles, the tile binning holds its per-workgroup tile table in LDS and takes at most 25600 (e.g. 2560 x 2560 px)", T);
     return 2;
@@ -400,9 +452,10 @@ int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order,
                      order, tiles, rect, table);
   hipLaunchKernelGGL(bin_scan_kernel, dim3((T + 63) / 64), dim3(1024), 0, s, T, p.n_chunks, table, tile_count);
   // (+ 1: the extra workgroup that writes the ranges, the counters and the forward's work list)
-  hipLaunchKernelGGL(bin_scatter_kernel, dim3(p.n_chunks + 1), dim3(p.threads), p.lds_scatter, s, N, T, grid_x, cap,
-                     p.g_per_block, p.g_per_wave, order, tiles, rect, table, tile_count, point_list, tile_keys, ranges, slot_base, tile_max,
-                     counters, fwd_items, fwd_empty, fwd_ctr);
+  // (the extra workgroup keeps its segment-level cursors in the dynamic LDS: 2 * SEG_LMAX words)
+  const size_t lds = p.lds_scatter > (size_t)2 * SEG_LMAX * 4 ? p.lds_scatter : (size_t)2 * SEG_LMAX * 4;
+  hipLaunchKernelGGL(bin_scatter_kernel, dim3(p.n_chunks + 1), dim3(p.threads), lds, s, N, T, grid_x, cap,
+                     p.g_per_block, p.g_per_wave, order, tiles, rect, table, tile_count, point_list, tile_keys, out);
   return 0;
 }
 

@@ -72,13 +72,12 @@ ImageLayout image_layout(int H, int W) {
   L.ranges = o; o = align_up(o + (T + 1) * 8);   // ranges, tile_max (+ tile tickets) and slot_base are adjacent: one memset clears them
   L.tile_max = o; o = align_up(o + 2 * (T + 1) * 4);  // [tile_max (T + 1) | arrival tickets of the tile's forward blocks (T + 1)]
   L.slot_base = o; o = align_up(o + (T + 2) * 4);
-  // forward work list (written by the extra workgroup of bin_scatter_kernel): the non-empty tiles, longest lists first; the empty tiles;
-  // {n_nonempty, -, n_empty}
-  L.fwd_items = o; o = align_up(o + (T + 1) * 4);
+  // the empty tiles (written by the extra workgroup of bin_scatter_kernel, like the forward's work list in the binning arena)
   L.fwd_empty = o; o = align_up(o + (T + 1) * 4);
   // {n_nonempty, -, n_empty} read by every forward workgroup; [64] = size of the backward's work list (in quarter-chunks),
   // appended to by the forward with atomics — on a cache line of its own (see render_fwd_oct_kernel)
   L.fwd_ctr = o; o = align_up(o + 512);
+  L.dead_from = o; o = align_up(o + T * 8 * 4);  // segmented tiles: per (tile, pixel block) the first segment nobody reaches
   L.total = o;
   return L;
 }
@@ -93,6 +92,12 @@ BinLayout bin_layout(int64_t cap, int N, int H, int W) {
   L.ckpt = o; o += align_up(L.n_slots * RIGGS_CKPT_FLOATS * 4);
   L.table = o; o += align_up(bin_table_bytes(N, (int)T));
   L.work = o; o += align_up(L.n_slots * 16);  // backward work list: 16-byte entry per active chunk
+  // forward work list: one entry per (non-empty tile, segment of RIGGS_SEG instances); segment slots (raster_internal.h)
+  L.n_seg_slots = seg_slots(cap, T);
+  L.n_items_cap = L.n_seg_slots;
+  L.fwd_items = o; o += align_up(L.n_items_cap * 4);
+  L.seg_state = o; o += align_up(L.n_seg_slots * RIGGS_SEG_WORDS * 256 * 4);
+  L.seg_flags = o; o += align_up(L.n_seg_slots * 8 * 4);
   L.total = o;
   return L;
 }
@@ -190,8 +195,12 @@ static int fill_pre_args(PreArgs& a, const riggs_raster_cfg* c, const float* mea
 }
 
 static unsigned long long* g_raster_trace = nullptr;
-// debugging aid: device buffer of 6 u64 per forward WAVE (8 blocks * tiles * 4 waves), see render_fwd_oct_kernel; NULL disables
+static uint64_t g_raster_trace_items = 0;
+// debugging aid: device buffer of 6 u64 per forward WAVE (work items * 4 waves; a work item = one 8 x 4 pixel block of one
+// segment of one tile, in launch order), see render_fwd_oct_kernel; followed by the backward's per-chunk records; NULL disables
 int riggs_raster_set_trace(void* dev_u64) { g_raster_trace = (unsigned long long*)dev_u64; return 0; }
+// capacity of the forward part in work items (0 = 8 per tile: enough while no tile is segmented)
+int riggs_raster_set_trace_items(uint64_t n_items) { g_raster_trace_items = n_items; return 0; }
 
 int riggs_raster_preprocess(const riggs_raster_cfg* cfg, const float* means3D, const float* shs,
                             const float* shs_rest, const float* colors_precomp, const float* opacities, const float* scales,
@@ -245,13 +254,16 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
   if (binned) {
     // stable counting sort by tile (csrc/binning.hip)
     ProfScope ps(PROF_TILE_SORT, s);
+    BinOut bo;
+    bo.ranges = (uint2*)(img + I.ranges); bo.slot_base = (uint32_t*)(img + I.slot_base); bo.tile_max = (uint32_t*)(img + I.tile_max);
+    bo.counters = counters; bo.fwd_items = (uint32_t*)(bin + B.fwd_items); bo.fwd_empty = (uint32_t*)(img + I.fwd_empty);
+    bo.fwd_ctr = (uint32_t*)(img + I.fwd_ctr); bo.seg_flags = (uint32_t*)(bin + B.seg_flags); bo.dead_from = (uint32_t*)(img + I.dead_from);
+    bo.n_seg_slots = (uint32_t)B.n_seg_slots; bo.items_cap = (uint32_t)B.n_items_cap;
     int rcb = launch_binning(N, T, gx, cap, (const uint32_t*)(geom + G.order), (const uint32_t*)(geom + G.tiles),
                              (const ushort4*)(geom + G.rect), bin + B.table, (uint32_t*)(bin + B.point_list),
                              // the per-instance tile id is only a debugging aid here (2M scattered 4-byte stores):
                              // it is implied by `ranges`, so it is written with cfg.debug only
-                             cfg->debug ? (uint32_t*)(bin + B.tile_keys) : nullptr, (uint2*)(img + I.ranges), (uint32_t*)(img + I.slot_base),
-                             (uint32_t*)(img + I.tile_max), counters, (uint32_t*)(img + I.fwd_items),
-                             (uint32_t*)(img + I.fwd_empty), (uint32_t*)(img + I.fwd_ctr), s);
+                             cfg->debug ? (uint32_t*)(bin + B.tile_keys) : nullptr, bo, s);
     if (rcb) return rcb;
     if (debug_sync(cfg->debug, s, "binning (counting sort)")) return 1;
   }
@@ -270,7 +282,11 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
   r.slot_base = (const uint32_t*)(img + I.slot_base); r.ckpt = (float*)(bin + B.ckpt);
   // longest-list-first work list of the forward (the extra workgroup of bin_scatter_kernel builds it; NULL: every tile is empty)
   r.items = nullptr; r.empties = nullptr; r.item_ctr = nullptr;
-  if (binned) { r.items = (const uint32_t*)(img + I.fwd_items); r.empties = (const uint32_t*)(img + I.fwd_empty); r.item_ctr = (uint32_t*)(img + I.fwd_ctr); }
+  if (binned) { r.items = (const uint32_t*)(bin + B.fwd_items); r.empties = (const uint32_t*)(img + I.fwd_empty); r.item_ctr = (uint32_t*)(img + I.fwd_ctr); }
+  r.seg_state = (float*)(bin + B.seg_state); r.seg_flags = (uint32_t*)(bin + B.seg_flags); r.dead_from = (uint32_t*)(img + I.dead_from);
+  r.n_item_slots = (int64_t)B.n_items_cap;
+  r.deterministic = cfg->deterministic ? 1 : 0;
+  r.trace_items = g_raster_trace_items ? g_raster_trace_items : (uint64_t)T * 8;
   { ProfScope ps(PROF_RENDER_FWD, s); launch_render_fwd(r, s); }
   if (debug_sync(cfg->debug, s, "render_fwd")) return 1;
   return 0;
@@ -308,7 +324,11 @@ int riggs_raster_backward(const riggs_raster_cfg* cfg, const float* means3D, con
   RenderBwdArgs r;
   r.n_points = N;
   // (the backward's statistics follow the forward's: 8 blocks x 4 waves x 6 words per tile)
-  r.trace = g_raster_trace ? g_raster_trace + (size_t)(((W + RIGGS_TILE - 1) / RIGGS_TILE) * ((H + RIGGS_TILE - 1) / RIGGS_TILE)) * 8 * 4 * 6 : nullptr;
+  {
+    const size_t fwd_items = g_raster_trace_items ? (size_t)g_raster_trace_items
+                                                  : (size_t)(((W + RIGGS_TILE - 1) / RIGGS_TILE) * ((H + RIGGS_TILE - 1) / RIGGS_TILE)) * 8;
+    r.trace = g_raster_trace ? g_raster_trace + fwd_items * 4 * 8 : nullptr;
+  }
   r.W = W; r.H = H;
   r.ranges = (const uint2*)(img + I.ranges);
   r.point_list = (const uint32_t*)(bin + B.point_list);
@@ -322,6 +342,7 @@ int riggs_raster_backward(const riggs_raster_cfg* cfg, const float* means3D, con
   r.n_tiles = ((W + RIGGS_TILE - 1) / RIGGS_TILE) * ((H + RIGGS_TILE - 1) / RIGGS_TILE);
   r.n_slots = (int64_t)B.n_slots;
   r.work = (const uint4*)(bin + B.work); r.work_ctr = (const uint32_t*)(img + I.fwd_ctr) + 64;
+  r.seg_state = (const float*)(bin + B.seg_state);
   r.det_rows = nullptr;
   if (cfg->deterministic && cap > 0) {
     // ordered-reduction mode: rows instead of atomics, then a fixed-order sum per Gaussian that overwrites the accumulators

@@ -6,6 +6,8 @@
 // Backward: chunk-parallel and instance-major (lane <-> instance, the wave walks the tile's pixels).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "raster_internal.h"
 
 namespace riggs {
@@ -49,210 +51,579 @@ __device__ __forceinline__ float oct_sum(float v) {
   v += ODPP_F(0.f, v, DPP_HALF_MIRROR, 0xf);
   return v;
 }
+// ---- segmented tiles ---------------------------------------------------------------------------------------------------
+// The workgroup of a block's FIRST segment (the OWNER) walks the tile's list front to back exactly as an unsegmented tile is
+// walked: sequential rule, exact stops, early termination, absolute checkpoints.  A list longer than RIGGS_SEG instances has
+// further work items, one per later segment and block, dealt in level order behind ALL first segments (second segments, then
+// third ones ...): HELPERS.  A helper composites its segment alone, from T = 1 (alpha compositing is associative:
+//   C = sum_s Tin_s * S_s,   Tin_s = prod_{s' < s} P_s'),
+// keeps every pixel's state at the start of each of its four rounds in LDS and, when done, publishes these and its end state in
+// its SEGMENT SLOT (write-through stores) and ORs bit SUMMARY into the segment's hand-shake word.  The owner, one round before
+// it reaches a segment boundary, ORs bit CLAIM into the next segment's word; a helper ORs bit STARTED into it when it begins:
+// of two ORs on a word exactly one sees the other's bit, and whoever is first owns the segment's CHECKPOINTS (a helper that
+// finds the claim leaves; an owner that finds STARTED walks the segment for its own state only and stores no checkpoints).
+// Summary there -> the owner COMBINES it instead of walking 1024 instances (fw_owner_rest), and every further segment that is
+// summarized as well.  A pixel whose running T times the segment's P falls below 1e-4 stops INSIDE the segment: the round
+// where T_in * T_local crosses the threshold is known from the published round states, and the owner composites that round
+// again from the true state, with the same code as the main loop — so the stop, n_contrib and final_T keep the sequential rule
+// (test_T = T (1 - alpha) < 1e-4, not counted).  When every pixel of the block has stopped the owner posts dead_from: helpers
+// that have not started leave at once, running ones at their next round.  Nobody ever waits for anybody.
+// A deep tile whose pixels do not saturate is thus composited by as many workgroups as the chip has free; a tile whose pixels
+// saturate early costs what it did before (its helpers start late — level order — find dead_from, and leave).
+// Checkpoints of a helper's segment are segment-local: the backward multiplies them with the segment's prefix, which the owner
+// stores in the segment's slot (the identity for the segments whose checkpoints are its own).  Which segments are combined depends on
+// timing and T_in * (local product) rounds differently from the running product (1e-7 relative, the class of the 8-lane scans):
+// cfg.deterministic turns the helpers off.
+typedef __attribute__((address_space(1))) uint32_t seg_gu32;
+typedef __attribute__((address_space(1))) float seg_gf32;
+#define SEG_SUMMARY 1u
+#define SEG_CLAIM 2u
+#define SEG_STARTED 4u
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store((seg_gf32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load((seg_gf32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t ld_agent_u(const uint32_t* p) { return __hip_atomic_load((seg_gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// value of lane j of the own group of eight
+__device__ __forceinline__ float oct_get(float v, int j, int lane) { return __shfl(v, (lane & 56) | j); }
+__device__ __forceinline__ float oct_max(float v) {
+  v = fmaxf(v, QUAD_F(v, QP(1, 0, 3, 2)));
+  v = fmaxf(v, QUAD_F(v, QP(2, 3, 0, 1)));
+  return fmaxf(v, ODPP_F(-1.0f, v, DPP_HALF_MIRROR, 0xf));
+}
+__device__ __forceinline__ uint32_t oct_max_u(uint32_t v) {
+  v = max(v, QUAD_U(v, QP(1, 0, 3, 2)));
+  v = max(v, QUAD_U(v, QP(2, 3, 0, 1)));
+  return max(v, ODPP_U(0u, v, DPP_HALF_MIRROR, 0xf));
+}
+
+#define FW_B 256                    // instances per round
+#define FW_NR (RIGGS_SEG / FW_B)    // rounds per segment
+// LDS of the forward (file scope: the main loop and the chain — a function of its own, see fw_seg_chain — share it)
+__shared__ float4 fw_xyd[FW_B];
+__shared__ float4 fw_con[FW_B];
+__shared__ float4 fw_rgb[FW_B];
+__shared__ unsigned short fw_pos[FW_B];  // position of the survivor inside its batch
+__shared__ int fw_cnt[FW_B / 64];        // survivors per chunk
+__shared__ uint32_t fw_wmax[4];
+__shared__ float fw_rs[FW_NR - 1][8][32];  // LOCAL segments: (T, C0, C1, C2, D, A, last, -) of the block's pixels at the start of rounds 1 ..
+__shared__ uint32_t fw_word;
+
+// a pixel's compositing state while its lists are walked: T and the stop bookkeeping are the same in its eight lanes, the
+// sums are per-lane partials
+struct FwWalk {
+  float T, C0, C1, C2, D, A, Tstop;
+  uint32_t last;
+  bool done;
+};
+
+// cull one instance per thread against the block's pixels and compact the survivors of every 64 into LDS
+__device__ __forceinline__ int fw_stage_round(const int tid, const bool in_range, const float4 xy, const float4 co, const float4 cc,
+                                              const float bx0, const float by0) {
+  const int lane = tid & 63, chunk = tid >> 6;  // a wave's 64 lanes = one chunk of the batch
+  const bool keep = in_range && ((xy.x + xy.w >= bx0) && (xy.x - xy.w <= bx0 + 7.0f) && (xy.y + cc.w >= by0) && (xy.y - cc.w <= by0 + 3.0f));
+  const uint64_t mask = __builtin_amdgcn_ballot_w64(keep);
+  const int cnt = __builtin_popcountll(mask);
+  const int slot = chunk * 64 + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+  if (keep) { fw_xyd[slot] = xy; fw_con[slot] = co; fw_rgb[slot] = cc; fw_pos[slot] = (unsigned short)tid; }
+  if (lane >= cnt && lane < ((cnt + 7) & ~7)) {  // null records up to the next multiple of 8
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    fw_xyd[chunk * 64 + lane] = z; fw_con[chunk * 64 + lane] = z; fw_rgb[chunk * 64 + lane] = z; fw_pos[chunk * 64 + lane] = 0;
+  }
+  if (lane == 0) fw_cnt[chunk] = cnt;
+  return cnt;
+}
+
+// the survivors of chunk k of the staged round, eight per step, for this wave's eight pixels
+template <bool TRACE>
+__device__ __forceinline__ void fw_composite_chunk(FwWalk& w, const int k, const int base, const int lane, const float pfx, const float pfy,
+                                                   uint32_t& st_iters, uint32_t& st_full) {
+  const int i = lane & 7;
+  const int nk = fw_cnt[k];
+  for (int g = 64 * k; g < 64 * k + nk; g += 8) {
+    // (no 'all pixels finished' test here: it costs eight instructions per step of every wave to save a few steps
+    // once per wave; the chunk loop has it)
+    const float4 xy = fw_xyd[g + i];
+    const float dx = xy.x - pfx, dy = xy.y - pfy;
+    const float4 co = fw_con[g + i];
+    const float pw = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+    const float alpha = fminf(ALPHA_MAX, co.w * fast_exp(pw));
+    const bool valid = (pw <= 0.0f) && (alpha >= ALPHA_MIN) && !w.done;
+    if constexpr (TRACE) st_iters++;
+    if (__builtin_amdgcn_ballot_w64(valid) == 0) continue;
+    if constexpr (TRACE) st_full++;
+    const float4 c = fw_rgb[g + i];
+    const int pos1 = base + (int)fw_pos[g + i] + 1;
+    // one step: eight consecutive instances (one per lane) of this lane's pixel
+    const float om = valid ? 1.0f - alpha : 1.0f;
+    // exclusive product scan over the eight lanes: inside each quad first ...
+    float b1 = QUAD_F(om, QP(0, 0, 1, 2)); b1 = ((i & 3) >= 1) ? b1 : 1.0f;     // [1, o0, o1, o2]
+    float s1 = QUAD_F(b1, QP(0, 0, 1, 2)); s1 = ((i & 3) >= 1) ? s1 : 1.0f;     // [1, 1, o0, o1]
+    float s2 = QUAD_F(b1, QP(0, 0, 0, 1)); s2 = ((i & 3) >= 2) ? s2 : 1.0f;     // [1, 1, 1, o0]
+    float E = b1 * s1 * s2;                                                     // [1, o0, o0 o1, o0 o1 o2] per quad
+    // ... then the upper quad takes the lower quad's total (row_shr:4 written to banks 1 and 3 only)
+    const float Pq = QUAD_F(E * om, QP(3, 3, 3, 3));                            // product of the own quad
+    E *= ODPP_F(1.0f, Pq, DPP_ROW_SHR4, 0xA);
+    const float Tj = w.T * E;
+    const float test_T = Tj * om;
+    const bool sc = valid && (test_T < T_EPS);
+    const uint64_t bits = __builtin_amdgcn_ballot_w64(sc);
+    const uint32_t ob = (uint32_t)(bits >> (lane & 56)) & 0xFFu;
+    const bool first_stop_before = (ob & ((1u << i) - 1u)) != 0u;
+    const bool use = valid && !sc && !first_stop_before;
+    const float wt = use ? alpha * Tj : 0.f;
+    w.C0 += c.x * wt; w.C1 += c.y * wt; w.C2 += c.z * wt;
+    w.D += xy.z * wt; w.A += wt;
+    w.last = use ? (uint32_t)pos1 : w.last;
+    if (sc && !first_stop_before) w.Tstop = Tj;  // transmittance in front of the instance that ends the pixel
+    // product of all eight: the upper quad's running total, handed down to the lower quad (row_shl:4, banks 0 and 2)
+    const float X3 = QUAD_F(E * om, QP(3, 3, 3, 3));
+    const float prod8 = ODPP_F(X3, X3, DPP_ROW_SHL4, 0x5);
+    const bool nostop = (ob == 0u);
+    w.T = (nostop && !w.done) ? w.T * prod8 : w.T;
+    w.done = w.done || !nostop;
+  }
+}
+
+// The kernel's argument block, read where it is needed: the compiler loads every kernel argument it sees into scalar registers
+// at the kernel's entry and keeps them there — two registers per pointer, two dozen pointers that only the epilogue of a work
+// item uses — and the main loop, which is short of them, then parks live scalars in vector-register lanes.  The epilogues
+// read their pointers through an opaque copy of the kernarg pointer instead.
+typedef const RenderArgs __attribute__((address_space(4))) FwLateArgs;
+__device__ __forceinline__ FwLateArgs* fw_late_args() {
+  FwLateArgs* p = (FwLateArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
+struct FwItem {  // a work item of the forward: one 8 x 4 pixel block of one segment of one tile
+  int tile, sub, seg, total, index;
+  uint32_t list_start;  // range.x
+};
+struct FwPrefix {  // every pixel's state in front of a segment (the same in its eight lanes)
+  float T, c0, c1, c2, D, A;
+  uint32_t last;
+  bool stop;
+};
+struct FwPixel { int pxi, pyi, pix; bool inside; };
+__device__ __forceinline__ FwPixel fw_pixel(const int W, const int H, const int tile, const int sub, const int wave, const int pl) {
+  const int gx = (W + RIGGS_TILE - 1) / RIGGS_TILE;
+  const int prow = (sub >> 1) * 4 + wave, pcol = (sub & 1) * 8 + pl;  // pixel row / column inside the tile
+  FwPixel p;
+  p.pxi = (tile % gx) * RIGGS_TILE + pcol; p.pyi = (tile / gx) * RIGGS_TILE + prow;
+  p.inside = p.pxi < W && p.pyi < H;
+  p.pix = prow * 16 + pcol;  // pixel index inside the tile (checkpoint layout)
+  return p;
+}
+__device__ __forceinline__ float* fw_state_ptr(float* seg_state, const FwItem& it, const int pix, int sg, int word) {
+  const uint32_t sslot0 = it.list_start / RIGGS_SEG + (uint32_t)it.tile;  // segment slot of the tile's segment 0
+  return seg_state + ((size_t)(sslot0 + sg) * RIGGS_SEG_WORDS + word) * 256 + pix;
+}
+__device__ __forceinline__ uint32_t* fw_flag_ptr(uint32_t* seg_flags, const FwItem& it, int sg) {
+  const uint32_t sslot0 = it.list_start / RIGGS_SEG + (uint32_t)it.tile;
+  return seg_flags + (size_t)(sslot0 + sg) * 8 + it.sub;
+}
+// the block's pixels between the main loop and fw_combine: (T — the final T of a stopped pixel —, C0, C1, C2, D, A, last, stopped)
+__shared__ float fw_st[8][32];
+
+// A HELPER's end: publish the states at the start of rounds 1 .. (from LDS: written by this wave) and the end state — lane i
+// writes word i —, then the hand-shake.  (A function of its own, NOT inlined, like fw_combine below: their address arithmetic
+// and state must not lengthen the live ranges of the main loop, which runs at exactly the register budget of six waves per
+// SIMD — a spilled register there is reloaded through the vector memory queue, BEHIND the prefetched gathers of the next
+// round (vmcnt retires in order), and the software pipeline of the rounds is gone: measured, 2.3 -> 7 us per round.
+// Everything is passed by value, in registers: a reference to a kernel-side object would pin it in scratch memory.)
+struct FwEnd { float T, k0, k1, k2, kd, ka; uint32_t lm; bool done; };
+__device__ __attribute__((noinline)) void fw_publish(float* seg_state, uint32_t* seg_flags, const FwItem it, const int pix, const FwEnd end) {
+  const int tid = threadIdx.x, lane = tid & 63, i = lane & 7, bp = (tid >> 6) * 8 + (lane >> 3);
+  for (int e = 0; e < FW_NR - 1; e++) st_agent(fw_state_ptr(seg_state, it, pix, it.seg, 8 * e + i), fw_rs[e][i][bp]);
+  const float v = (i == 0) ? (end.done ? 0.f : end.T) : (i == 1) ? end.k0 : (i == 2) ? end.k1 : (i == 3) ? end.k2 : (i == 4) ? end.kd
+                  : (i == 5) ? end.ka : __uint_as_float(end.lm);
+  st_agent(fw_state_ptr(seg_state, it, pix, it.seg, 8 * (FW_NR - 1) + i), v);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // performed
+  __syncthreads();
+  if (tid == 0) (void)__hip_atomic_fetch_or((seg_gu32*)fw_flag_ptr(seg_flags, it, it.seg), SEG_SUMMARY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The OWNER's way from the first segment whose summary it found (see the comment above) to the end of the list — the rare,
+// cold part of its walk, in a function of its own so that the main loop stays what it was.  The block's state travels through
+// fw_st.  Per segment: a summarized one is COMBINED (the rounds in which pixels stop are composited again from the true
+// state); one that is not is claimed and WALKED, round by round, with the plain version of the main loop (no software
+// pipeline: it is rarely needed — helpers run ahead of the owner).  Ends when every pixel has stopped (dead_from posted) or the
+// list does.
+template <bool TRACE>
+__device__ __attribute__((noinline)) void fw_owner_rest(const RenderArgs* kernargs, const FwItem it, int s) {
+  const RenderArgs& a = *kernargs;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pl = lane >> 3, i = lane & 7, bp = wave * 8 + pl;
+  const FwPixel px = fw_pixel(a.W, a.H, it.tile, it.sub, wave, pl);
+  const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE;
+  const float pfx = (float)px.pxi, pfy = (float)px.pyi;
+  const float bx0 = (float)((it.tile % gx) * RIGGS_TILE + (it.sub & 1) * 8), by0 = (float)((it.tile / gx) * RIGGS_TILE + (it.sub >> 1) * 4);
+  const int total = it.total, nseg = (total + RIGGS_SEG - 1) / RIGGS_SEG;
+  const uint32_t slot0 = a.slot_base[it.tile];
+  const unsigned long long t_chain = (TRACE && a.trace) ? wall_clock64() : 0ull;
+  uint32_t st_steps = 0, st_walk = 0, st_a = 0, st_b = 0;
+  FwPrefix p;
+  p.T = fw_st[0][bp]; p.c0 = fw_st[1][bp]; p.c1 = fw_st[2][bp]; p.c2 = fw_st[3][bp]; p.D = fw_st[4][bp]; p.A = fw_st[5][bp];
+  p.last = __float_as_uint(fw_st[6][bp]); p.stop = fw_st[7][bp] != 0.f;
+  // composite round [base, base + 256) of the list from the state w (CK: and store the checkpoints — absolute ones)
+  auto walk_round = [&](FwWalk& w, const int base, const int hi, const bool ck) {
+    {
+      float4 xy = make_float4(0.f, 0.f, 0.f, 0.f), co = xy, cc = xy;
+      const bool in_range = base + tid < hi;
+      if (in_range) {
+        const uint32_t id = a.point_list[it.list_start + base + tid];
+        xy = a.xyd[id]; co = a.conic_o[id]; cc = a.rgb[id];
+      }
+      fw_stage_round(tid, in_range, xy, co, cc, bx0, by0);
+    }
+    __syncthreads();
+    for (int k = 0; k < FW_B / 64; k++) {
+      if (base + 64 * k >= hi) break;
+      if (__builtin_amdgcn_ballot_w64(!w.done) == 0) break;
+      if (ck) {
+        const float k0 = oct_sum(w.C0), k1 = oct_sum(w.C1), k2 = oct_sum(w.C2), kd = oct_sum(w.D);
+        if (!w.done && i < 5)
+          a.ckpt[((size_t)(slot0 + ((base + 64 * k) >> 6)) * 5 + i) * 256 + px.pix] = (i == 0) ? w.T : (i == 1) ? k0 : (i == 2) ? k1 : (i == 3) ? k2 : kd;
+      }
+      fw_composite_chunk<false>(w, k, base, lane, pfx, pfy, st_a, st_b);
+    }
+    __syncthreads();
+  };
+  for (;;) {
+    // segment s: summarized?  Otherwise it is this workgroup's (claimed)
+    if (tid == 0) {
+      uint32_t f = ld_agent_u(fw_flag_ptr(a.seg_flags, it, s));
+      if (!(f & SEG_SUMMARY)) f = __hip_atomic_fetch_or((seg_gu32*)fw_flag_ptr(a.seg_flags, it, s), SEG_CLAIM, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      fw_word = f;
+    }
+    __syncthreads();
+    const bool summarized = (fw_word & SEG_SUMMARY) != 0u, started = (fw_word & SEG_STARTED) != 0u;
+    __syncthreads();
+    const int s_lo = s * RIGGS_SEG, s_hi = min(total, s_lo + RIGGS_SEG);
+    if (!summarized) {
+      // walk it.  The checkpoints are this workgroup's (absolute; the identity as the segment's prefix for the backward) unless
+      // a helper is at work on the segment: then they are the helper's, segment-local, and the prefix is the true one
+      if (i < 5) *fw_state_ptr(a.seg_state, it, px.pix, s, RIGGS_SEG_PREFIX + i) =
+          !started ? ((i == 0) ? 1.0f : 0.f) : ((i == 0) ? p.T : (i == 1) ? p.c0 : (i == 2) ? p.c1 : (i == 3) ? p.c2 : p.D);
+      FwWalk w;
+      w.T = p.T; w.Tstop = -1.0f; w.last = p.last; w.done = p.stop;
+      w.C0 = (i == 0) ? p.c0 : 0.f; w.C1 = (i == 0) ? p.c1 : 0.f; w.C2 = (i == 0) ? p.c2 : 0.f; w.D = (i == 0) ? p.D : 0.f; w.A = (i == 0) ? p.A : 0.f;
+      for (int base = s_lo; base < s_hi; base += FW_B) {
+        if (__syncthreads_count(w.done) == 256) break;
+        if constexpr (TRACE) st_walk++;
+        walk_round(w, base, s_hi, !started);
+      }
+      const float f0 = oct_sum(w.C0), f1 = oct_sum(w.C1), f2 = oct_sum(w.C2), fd = oct_sum(w.D), fa = oct_sum(w.A);
+      const float t2 = oct_max(w.Tstop);
+      const uint32_t l2 = oct_max_u(w.last);
+      if (!p.stop) {
+        p.c0 = f0; p.c1 = f1; p.c2 = f2; p.D = fd; p.A = fa; p.last = l2;
+        p.stop = w.done;
+        p.T = (t2 >= 0.f) ? t2 : w.T;
+      }
+    } else {
+      // the prefix of segment s, for the backward (its checkpoints are segment-local)
+      if (i < 5) *fw_state_ptr(a.seg_state, it, px.pix, s, RIGGS_SEG_PREFIX + i) = (i == 0) ? p.T : (i == 1) ? p.c0 : (i == 2) ? p.c1 : (i == 3) ? p.c2 : p.D;
+      // combine segment s: lane i holds word i of the states at the start of its rounds 1, 2, 3 and of its end state
+      if constexpr (TRACE) st_steps++;
+      float ev[FW_NR];
+#pragma unroll
+      for (int e = 0; e < FW_NR; e++) ev[e] = ld_agent(fw_state_ptr(a.seg_state, it, px.pix, s, 8 * e + i));
+      int rstar = FW_NR;  // the round the pixel has to be composited again from (FW_NR: none)
+      {
+        const float eP = oct_get(ev[FW_NR - 1], 0, lane), e0 = oct_get(ev[FW_NR - 1], 1, lane), e1 = oct_get(ev[FW_NR - 1], 2, lane),
+                    e2 = oct_get(ev[FW_NR - 1], 3, lane), eD = oct_get(ev[FW_NR - 1], 4, lane), eA = oct_get(ev[FW_NR - 1], 5, lane);
+        const uint32_t eL = __float_as_uint(oct_get(ev[FW_NR - 1], 6, lane));
+        float tr[FW_NR - 1];
+#pragma unroll
+        for (int r = 0; r < FW_NR - 1; r++) tr[r] = oct_get(ev[r], 0, lane);
+        if (!p.stop) {
+          const float tp = p.T * eP;
+          if (tp >= T_EPS) {
+            p.c0 += p.T * e0; p.c1 += p.T * e1; p.c2 += p.T * e2; p.D += p.T * eD; p.A += p.T * eA;
+            p.last = eL ? eL : p.last;
+            p.T = tp;
+          } else {
+            // the pixel stops inside the segment: in the first round at whose END T_in * T_local is below the threshold
+            rstar = FW_NR - 1;
+#pragma unroll
+            for (int r = FW_NR - 2; r >= 0; r--) if (p.T * tr[r] < T_EPS) rstar = r;
+          }
+        }
+      }
+      if (__syncthreads_or(rstar < FW_NR)) {
+        // composite again from the true state: rounds rstar .. of the segment, until the stop (or, should the rounding of
+        // T_in * P have promised a stop that the instance-by-instance product does not find, the segment's end)
+        bool walking = false;
+        FwWalk w;
+        w.T = 1.0f; w.C0 = 0.f; w.C1 = 0.f; w.C2 = 0.f; w.D = 0.f; w.A = 0.f; w.Tstop = -1.0f; w.last = 0u; w.done = true;
+        for (int r = 0; r < FW_NR; r++) {
+          const int base = s_lo + r * FW_B;
+          if (base >= s_hi) break;
+          {
+            // (every lane takes part in the shuffles; only the pixels that enter at this round use the result)
+            const float vv = ev[r > 0 ? r - 1 : 0];
+            const float eT = oct_get(vv, 0, lane), e0 = oct_get(vv, 1, lane), e1 = oct_get(vv, 2, lane), e2 = oct_get(vv, 3, lane),
+                        eD = oct_get(vv, 4, lane), eA = oct_get(vv, 5, lane);
+            const uint32_t eL = __float_as_uint(oct_get(vv, 6, lane));
+            if (rstar == r) {  // enter: the true state at the start of round r
+              walking = true; w.done = false;
+              const bool first = r == 0;
+              w.T = first ? p.T : p.T * eT;
+              w.C0 = (i == 0) ? (first ? p.c0 : p.c0 + p.T * e0) : 0.f; w.C1 = (i == 0) ? (first ? p.c1 : p.c1 + p.T * e1) : 0.f;
+              w.C2 = (i == 0) ? (first ? p.c2 : p.c2 + p.T * e2) : 0.f; w.D = (i == 0) ? (first ? p.D : p.D + p.T * eD) : 0.f;
+              w.A = (i == 0) ? (first ? p.A : p.A + p.T * eA) : 0.f;
+              w.last = (!first && eL) ? eL : p.last;
+            }
+          }
+          if (!__syncthreads_or(walking && !w.done)) continue;
+          if constexpr (TRACE) st_walk++;
+          walk_round(w, base, s_hi, false);
+        }
+        const float f0 = oct_sum(w.C0), f1 = oct_sum(w.C1), f2 = oct_sum(w.C2), fd = oct_sum(w.D), fa = oct_sum(w.A);
+        const float t2 = oct_max(w.Tstop);
+        const uint32_t l2 = oct_max_u(w.last);
+        if (walking) {
+          p.c0 = f0; p.c1 = f1; p.c2 = f2; p.D = fd; p.A = fa; p.last = l2;
+          if (t2 >= 0.f) { p.T = t2; p.stop = true; }  // (T of a stopped pixel: the transmittance in front of the instance that ended it)
+          else p.T = w.T;
+        }
+      }
+    }
+    s++;
+    // the end of the block's work, or of the list?
+    if (__syncthreads_count(p.stop) == 256) {
+      if (s < nseg && tid == 0) __hip_atomic_store((seg_gu32*)(a.dead_from + (size_t)it.tile * 8 + it.sub), (uint32_t)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+    if (s == nseg) break;
+  }
+  if (i == 0) {
+    fw_st[0][bp] = p.T; fw_st[1][bp] = p.c0; fw_st[2][bp] = p.c1; fw_st[3][bp] = p.c2; fw_st[4][bp] = p.D; fw_st[5][bp] = p.A;
+    fw_st[6][bp] = __uint_as_float(p.last); fw_st[7][bp] = p.stop ? 1.0f : 0.f;
+  }
+  if (TRACE && a.trace && lane == 0 && (uint64_t)it.index < a.trace_items)
+    a.trace[((size_t)it.index * 4 + wave) * 8 + 7] = (wall_clock64() - t_chain) | ((unsigned long long)st_steps << 32) | ((unsigned long long)st_walk << 44);
+}
+
 template <bool TRACE>
 __global__ __launch_bounds__(256, 6) void render_fwd_oct_kernel(RenderArgs a) {
-  constexpr int B = 256;      // instances per round
-  constexpr int K = B / 256;  // instances per thread and round
-  __shared__ float4 s_xyd[B];
-  __shared__ float4 s_con[B];
-  __shared__ float4 s_rgb[B];
-  __shared__ unsigned short s_pos[B];  // position of the survivor inside its batch
-  __shared__ int s_cnt[B / 64];        // survivors per chunk
-  __shared__ uint32_t s_wmax[4];
+  constexpr int B = FW_B;
   const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int pl = lane >> 3, i = lane & 7;
   {
     // tiles without instances: background only, one pixel per thread (a.items == NULL: nothing was binned — no
     // Gaussians or an empty arena — and every tile is such a tile)
-    const int n_empty = a.items ? (int)a.item_ctr[2] : gx * ((a.H + RIGGS_TILE - 1) / RIGGS_TILE);
+    FwLateArgs& l = *fw_late_args();
+    const size_t HW = (size_t)l.H * l.W;
+    const int n_empty = l.items ? (int)l.item_ctr[2] : gx * ((l.H + RIGGS_TILE - 1) / RIGGS_TILE);
     for (int e = blockIdx.x; e < n_empty; e += gridDim.x) {
-      const int t = a.items ? (int)a.empties[e] : e;
+      const int t = l.items ? (int)l.empties[e] : e;
       const int px = (t % gx) * RIGGS_TILE + (tid & 15), py = (t / gx) * RIGGS_TILE + (tid >> 4);
-      if (px < a.W && py < a.H) {
-        const size_t pid = (size_t)py * a.W + px, HW = (size_t)a.H * a.W;
-        a.final_T[pid] = 1.0f; a.n_contrib[pid] = 0u; a.final_acc[pid] = make_float4(0.f, 0.f, 0.f, 0.f);
-        a.out_color[pid] = a.bg[0]; a.out_color[HW + pid] = a.bg[1]; a.out_color[2 * HW + pid] = a.bg[2];
-        a.out_depth[pid] = 0.f; a.out_alpha[pid] = 0.f;
+      if (px < l.W && py < l.H) {
+        const size_t pid = (size_t)py * l.W + px;
+        l.final_T[pid] = 1.0f; l.n_contrib[pid] = 0u; l.final_acc[pid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        l.out_color[pid] = l.bg[0]; l.out_color[HW + pid] = l.bg[1]; l.out_color[2 * HW + pid] = l.bg[2];
+        l.out_depth[pid] = 0.f; l.out_alpha[pid] = 0.f;
       }
     }
   }
-  // work list: the non-empty tiles in the order the extra workgroup of bin_scatter_kernel wrote them (longest lists first), dealt round-robin
-  // to the resident workgroups (a shared dequeue word costs more than it balances: same-address atomics from 8 XCDs
-  // serialise at ~10-60 ns each)
-  const int n_items = a.items ? (int)a.item_ctr[0] * 8 : 0;  // eight 8x4 pixel blocks per non-empty tile
-  for (int turn = 0;; turn++) {
-  int tile, sub;
+  // work list: (tile, segment) entries in the order the extra workgroup of bin_scatter_kernel wrote them (first segments of
+  // the longest lists first, deeper segments behind all first ones), eight 8x4 pixel blocks each
+  // (one item per workgroup — the launch covers the capacity of the list: an outer loop over items makes every item-invariant
+  // scalar a loop invariant that the compiler computes up front and keeps, in vector-register lanes once the scalar file is full)
+  const int n_items = a.items ? (int)a.item_ctr[0] * 8 : 0;
+  FwItem item;
+  item.index = (int)blockIdx.x;
   {
-    // the eight blocks of a tile get workgroup ids 8 apart = the same XCD / L2 (workgroup b runs on XCD b % 8)
-    const int it = (int)blockIdx.x + turn * (int)gridDim.x, full = (n_items >> 6) << 6;
-    if (it >= n_items) break;
+    // the eight blocks of an entry get workgroup ids 8 apart = the same XCD / L2 (workgroup b runs on XCD b % 8)
+    const int it = item.index, full = (n_items >> 6) << 6;
+    if (it >= n_items) return;
     int p;
-    if (it < full) { p = ((it >> 6) << 3) + (it & 7); sub = (it >> 3) & 7; }
-    else { p = (full >> 3) + ((it - full) >> 3); sub = (it - full) & 7; }
-    tile = (int)a.items[p];
+    if (it < full) { p = ((it >> 6) << 3) + (it & 7); item.sub = (it >> 3) & 7; }
+    else { p = (full >> 3) + ((it - full) >> 3); item.sub = (it - full) & 7; }
+    const uint32_t e = a.items[p];
+    item.tile = (int)(e & 0xFFFFu); item.seg = (int)(e >> 16);
   }
-  const int prow = (sub >> 1) * 4 + wave;                 // pixel row inside the tile
-  const int pcol = (sub & 1) * 8 + pl;                    // pixel column inside the tile
-  const int pxi = (tile % gx) * RIGGS_TILE + pcol;
-  const int pyi = (tile / gx) * RIGGS_TILE + prow;
-  const bool inside = pxi < a.W && pyi < a.H;
-  const float pfx = (float)pxi, pfy = (float)pyi;
+  const int tile = item.tile, sub = item.sub, seg = item.seg;
   const uint2 range = a.ranges[tile];
   const int total = (int)(range.y - range.x);
+  item.total = total; item.list_start = range.x;
+  const bool helper = seg > 0;                            // (implies a segmented tile)
+  const bool owner_multi = !helper && total > RIGGS_SEG;  // the owner of a segmented tile
+  if (helper) {
+    // leave if every pixel of the block stopped in front of this segment, if the owner has claimed it — or the segment in front
+    // of it: it is walking that one now and will be here before this workgroup is done —, or in the reproducible mode
+    if (tid == 0) {
+      const uint32_t d = ld_agent_u(a.dead_from + (size_t)tile * 8 + sub);
+      const uint32_t fb = seg > 1 ? ld_agent_u(fw_flag_ptr(a.seg_flags, item, seg - 1)) : 0u;  // (segment 0 is always the owner's: no word)
+      uint32_t skip = ((d != 0u && (uint32_t)seg >= d) || (fb & SEG_CLAIM) || a.deterministic) ? 1u : 0u;
+      if (!skip) {  // the segment's checkpoints are this workgroup's unless the owner was first
+        const uint32_t old = __hip_atomic_fetch_or((seg_gu32*)fw_flag_ptr(a.seg_flags, item, seg), SEG_STARTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        skip = (old & SEG_CLAIM) ? 1u : 0u;
+      }
+      fw_word = skip;
+    }
+    __syncthreads();
+    const uint32_t w0 = fw_word;
+    __syncthreads();
+    if (w0) return;
+    if (tid < 32) for (int e = 0; e < FW_NR - 1; e++) fw_rs[e][0][tid] = 0.f;  // "not reached" until a round says otherwise
+  }
+  const int lo = helper ? seg * RIGGS_SEG : 0, hi = helper ? min(total, lo + RIGGS_SEG) : total;
+  const FwPixel px = fw_pixel(a.W, a.H, tile, sub, wave, pl);
+  const float pfx = (float)px.pxi, pfy = (float)px.pyi;
   const uint32_t slot0 = a.slot_base[tile];
-  const int pix = prow * 16 + pcol;                       // pixel index inside the tile (checkpoint layout)
-  const float bx0 = (float)((tile % gx) * RIGGS_TILE + (sub & 1) * 8), bx1 = bx0 + 7.0f;
-  const float by0 = (float)((tile / gx) * RIGGS_TILE + (sub >> 1) * 4), by1 = by0 + 3.0f;
-  bool done = !inside;
-  float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f, Tstop = -1.0f;
-  uint32_t last = 0;
+  const float bx0 = (float)((tile % gx) * RIGGS_TILE + (sub & 1) * 8), by0 = (float)((tile / gx) * RIGGS_TILE + (sub >> 1) * 4);
+  FwWalk w;
+  w.done = !px.inside; w.T = 1.0f; w.Tstop = -1.0f; w.last = 0u;
+  w.C0 = 0.f; w.C1 = 0.f; w.C2 = 0.f; w.D = 0.f; w.A = 0.f;
   const unsigned long long t_begin = (TRACE && a.trace) ? wall_clock64() : 0ull;
   uint32_t st_rounds = 0, st_surv = 0, st_iters = 0, st_full = 0;
-  // prefetch registers for the next round (one instance per thread) and the list entry of the round after it
-  float4 n_xy[K], n_co[K], n_cc[K];
-  uint32_t n_id[K];
-#pragma unroll
-  for (int k = 0; k < K; k++) {
-    n_xy[k] = make_float4(0.f, 0.f, 0.f, 0.f); n_co[k] = n_xy[k]; n_cc[k] = n_xy[k];
-    n_id[k] = 0u;
-    if (B + k * 256 + tid < total) n_id[k] = a.point_list[range.x + B + k * 256 + tid];
-    if (k * 256 + tid < total) {
-      const uint32_t id = a.point_list[range.x + k * 256 + tid];
-      n_xy[k] = a.xyd[id]; n_co[k] = a.conic_o[id]; n_cc[k] = a.rgb[id];
-    }
-  }
+  if (TRACE && a.trace && lane == 0 && (uint64_t)item.index < fw_late_args()->trace_items) a.trace[((size_t)item.index * 4 + wave) * 8 + 7] = 0ull;
   // checkpoints are held one round (lane i keeps chunk i's) and stored ahead of the next round's loads
   float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;
   bool hv = false;
   int hbase = 0;
+  bool ck_on = true;  // (owner) false while it walks a segment whose checkpoints a helper stores
   auto flush_ckpt = [&]() {
     if (hv) {
-      float* ck = a.ckpt + ((size_t)(slot0 + (hbase >> 6) + i) * 5) * 256 + pix;
+      float* ck = a.ckpt + ((size_t)(slot0 + (hbase >> 6) + i) * 5) * 256 + px.pix;
       ck[0] = h0; ck[256] = h1; ck[512] = h2; ck[768] = h3; ck[1024] = h4;
     }
     hv = false;
   };
-  for (int base = 0; base < total; base += B) {
-    if (__syncthreads_count(done) == 256) break;
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-      const int chunk = k * 4 + wave, inb = k * 256 + tid;  // this wave's 64 lanes = one chunk of the batch
-      const bool keep = (base + inb < total) &&
-                        ((n_xy[k].x + n_xy[k].w >= bx0) && (n_xy[k].x - n_xy[k].w <= bx1) &&
-                         (n_xy[k].y + n_cc[k].w >= by0) && (n_xy[k].y - n_cc[k].w <= by1));
-      const uint64_t mask = __builtin_amdgcn_ballot_w64(keep);
-      const int cnt = __builtin_popcountll(mask);
-      const int slot = chunk * 64 + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-      if (keep) { s_xyd[slot] = n_xy[k]; s_con[slot] = n_co[k]; s_rgb[slot] = n_cc[k]; s_pos[slot] = (unsigned short)inb; }
-      if (lane >= cnt && lane < ((cnt + 7) & ~7)) {  // null records up to the next multiple of 8
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        s_xyd[chunk * 64 + lane] = z; s_con[chunk * 64 + lane] = z; s_rgb[chunk * 64 + lane] = z; s_pos[chunk * 64 + lane] = 0;
+  // prefetch registers for the next round (one instance per thread) and the list entry of the round after it
+  float4 n_xy = make_float4(0.f, 0.f, 0.f, 0.f), n_co = n_xy, n_cc = n_xy;
+  uint32_t n_id = 0u;
+  if (lo + B + tid < hi) n_id = a.point_list[range.x + lo + B + tid];
+  if (lo + tid < hi) {
+    const uint32_t id = a.point_list[range.x + lo + tid];
+    n_xy = a.xyd[id]; n_co = a.conic_o[id]; n_cc = a.rgb[id];
+  }
+  uint32_t dnext = 0u;              // (helper) the block's dead_from word, read a round ahead
+  uint32_t claim = 0u;              // (owner, thread 0) what the claim of the next segment returned, requested a round ahead
+  bool dead = false;
+  int resume = 0;  // (owner) the segment from which fw_owner_rest takes over, if any
+  for (int base = lo; base < hi; base += B) {
+    if (helper) {
+      dead = dead || (dnext != 0u && (uint32_t)seg >= dnext);
+      w.done = w.done || dead;
+      dnext = ld_agent_u(a.dead_from + (size_t)tile * 8 + sub);
+    }
+    const bool boundary = owner_multi && base > 0 && (base & (RIGGS_SEG - 1)) == 0;  // the owner enters a new segment
+    if (boundary && tid == 0) fw_word = claim;
+    if (__syncthreads_count(w.done) == 256) break;
+    if (boundary) {
+      const uint32_t f = fw_word;
+      if (f & SEG_SUMMARY) { resume = base / RIGGS_SEG; break; }  // a helper has composited this segment: the rest of the walk is fw_owner_rest's
+      ck_on = !(f & SEG_STARTED);
+      if (ck_on) {
+        // the segment's checkpoints are this workgroup's, absolute ones: the backward finds the identity as the segment's prefix
+        if (i < 5) *fw_state_ptr(a.seg_state, item, px.pix, base / RIGGS_SEG, RIGGS_SEG_PREFIX + i) = (i == 0) ? 1.0f : 0.f;
+      } else {
+        // a helper is at work on this segment and stores its (segment-local) checkpoints: walk it for the state only, and
+        // leave the true prefix for the backward
+        const float k0 = oct_sum(w.C0), k1 = oct_sum(w.C1), k2 = oct_sum(w.C2), kd = oct_sum(w.D);
+        if (i < 5) *fw_state_ptr(a.seg_state, item, px.pix, base / RIGGS_SEG, RIGGS_SEG_PREFIX + i) = (i == 0) ? w.T : (i == 1) ? k0 : (i == 2) ? k1 : (i == 3) ? k2 : kd;
       }
-      if (lane == 0) s_cnt[chunk] = cnt;
+    }
+    if (owner_multi && (base & (RIGGS_SEG - 1)) == RIGGS_SEG - B && base + B < hi && tid == 0)  // the last round of a segment: claim the next one
+      claim = __hip_atomic_fetch_or((seg_gu32*)fw_flag_ptr(a.seg_flags, item, base / RIGGS_SEG + 1), SEG_CLAIM, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+      const int cnt = fw_stage_round(tid, base + tid < hi, n_xy, n_co, n_cc, bx0, by0);
       if constexpr (TRACE) st_surv += (uint32_t)cnt;
     }
     if constexpr (TRACE) st_rounds++;
     flush_ckpt();
     hbase = base;
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-      n_xy[k] = make_float4(0.f, 0.f, 0.f, 0.f); n_co[k] = n_xy[k]; n_cc[k] = n_xy[k];
-      if (base + B + k * 256 + tid < total) {
-        const uint32_t id = n_id[k];
-        n_xy[k] = a.xyd[id]; n_co[k] = a.conic_o[id]; n_cc[k] = a.rgb[id];
+    {
+      n_xy = make_float4(0.f, 0.f, 0.f, 0.f); n_co = n_xy; n_cc = n_xy;
+      if (base + B + tid < hi) {
+        const uint32_t id = n_id;
+        n_xy = a.xyd[id]; n_co = a.conic_o[id]; n_cc = a.rgb[id];
       }
-      if (base + 2 * B + k * 256 + tid < total) n_id[k] = a.point_list[range.x + base + 2 * B + k * 256 + tid];
+      if (base + 2 * B + tid < hi) n_id = a.point_list[range.x + base + 2 * B + tid];
     }
+    if (helper && base > lo) {  // a helper keeps the state at the start of its rounds for the owner
+      const float k0 = oct_sum(w.C0), k1 = oct_sum(w.C1), k2 = oct_sum(w.C2), kd = oct_sum(w.D), fa = oct_sum(w.A);
+      const uint32_t lf = oct_max_u(w.last);
+      if (i == 0) {
+        const int bp = wave * 8 + pl;
+        float (*e)[32] = fw_rs[(base - lo) / B - 1];
+        e[0][bp] = w.done ? 0.f : w.T; e[1][bp] = k0; e[2][bp] = k1; e[3][bp] = k2; e[4][bp] = kd; e[5][bp] = fa; e[6][bp] = __uint_as_float(lf);
+      }
+    }
+#pragma unroll 1
     for (int k = 0; k < B / 64; k++) {
       const int cbase = base + 64 * k;
-      if (cbase >= total) break;
-      if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+      if (cbase >= hi) break;
+      if (__builtin_amdgcn_ballot_w64(!w.done) == 0) break;
       {
         // checkpoint of the state BEFORE instance cbase: fold the eight lanes' partial sums
-        const float k0 = oct_sum(C0), k1 = oct_sum(C1), k2 = oct_sum(C2), kd = oct_sum(D);
-        if (i == k) { h0 = T; h1 = k0; h2 = k1; h3 = k2; h4 = kd; hv = !done; }
+        const float k0 = oct_sum(w.C0), k1 = oct_sum(w.C1), k2 = oct_sum(w.C2), kd = oct_sum(w.D);
+        if (i == k) { h0 = w.T; h1 = k0; h2 = k1; h3 = k2; h4 = kd; hv = !w.done && ck_on; }
       }
-      const int nk = s_cnt[k];
-      for (int g = 64 * k; g < 64 * k + nk; g += 8) {
-        // (no 'all pixels finished' test here: it costs eight instructions per step of every wave to save a few steps
-        // once per wave; the chunk loop above has it)
-        const float4 xy = s_xyd[g + i];
-        const float dx = xy.x - pfx, dy = xy.y - pfy;
-        const float4 co = s_con[g + i];
-        const float pw = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-        const float alpha = fminf(ALPHA_MAX, co.w * fast_exp(pw));
-        const bool valid = (pw <= 0.0f) && (alpha >= ALPHA_MIN) && !done;
-        if constexpr (TRACE) st_iters++;
-        if (__builtin_amdgcn_ballot_w64(valid) == 0) continue;
-        if constexpr (TRACE) st_full++;
-        const float4 c = s_rgb[g + i];
-        const int pos1 = base + (int)s_pos[g + i] + 1;
-        // one step: eight consecutive instances (one per lane) of this lane's pixel
-        const float om = valid ? 1.0f - alpha : 1.0f;
-        // exclusive product scan over the eight lanes: inside each quad first ...
-        float b1 = QUAD_F(om, QP(0, 0, 1, 2)); b1 = ((i & 3) >= 1) ? b1 : 1.0f;     // [1, o0, o1, o2]
-        float s1 = QUAD_F(b1, QP(0, 0, 1, 2)); s1 = ((i & 3) >= 1) ? s1 : 1.0f;     // [1, 1, o0, o1]
-        float s2 = QUAD_F(b1, QP(0, 0, 0, 1)); s2 = ((i & 3) >= 2) ? s2 : 1.0f;     // [1, 1, 1, o0]
-        float E = b1 * s1 * s2;                                                     // [1, o0, o0 o1, o0 o1 o2] per quad
-        // ... then the upper quad takes the lower quad's total (row_shr:4 written to banks 1 and 3 only)
-        const float Pq = QUAD_F(E * om, QP(3, 3, 3, 3));                            // product of the own quad
-        E *= ODPP_F(1.0f, Pq, DPP_ROW_SHR4, 0xA);
-        const float Tj = T * E;
-        const float test_T = Tj * om;
-        const bool sc = valid && (test_T < T_EPS);
-        const uint64_t bits = __builtin_amdgcn_ballot_w64(sc);
-        const uint32_t ob = (uint32_t)(bits >> (lane & 56)) & 0xFFu;
-        const bool first_stop_before = (ob & ((1u << i) - 1u)) != 0u;
-        const bool use = valid && !sc && !first_stop_before;
-        const float w = use ? alpha * Tj : 0.f;
-        C0 += c.x * w; C1 += c.y * w; C2 += c.z * w;
-        D += xy.z * w; A += w;
-        last = use ? (uint32_t)pos1 : last;
-        if (sc && !first_stop_before) Tstop = Tj;  // transmittance in front of the instance that ends the pixel
-        // product of all eight: the upper quad's running total, handed down to the lower quad (row_shl:4, banks 0 and 2)
-        const float X3 = QUAD_F(E * om, QP(3, 3, 3, 3));
-        const float prod8 = ODPP_F(X3, X3, DPP_ROW_SHL4, 0x5);
-        const bool nostop = (ob == 0u);
-        T = (nostop && !done) ? T * prod8 : T;
-        done = done || !nostop;
-      }
+      fw_composite_chunk<TRACE>(w, k, base, lane, pfx, pfy, st_iters, st_full);
     }
   }
-  if (TRACE && a.trace && lane == 0) {
-    unsigned long long* tr = a.trace + ((size_t)(tile * 8 + sub) * 4 + wave) * 6;
+  if (TRACE && a.trace && lane == 0 && (uint64_t)item.index < fw_late_args()->trace_items) {
+    unsigned long long* tr = a.trace + ((size_t)item.index * 4 + wave) * 8;
+    tr[6] = t_begin;
     tr[0] = wall_clock64() - t_begin; tr[1] = st_rounds;
     tr[2] = (unsigned long long)st_surv | ((unsigned long long)(__builtin_amdgcn_s_getreg(63492) & 0xFFFFu) << 32) | ((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 0xFu) << 48);
-    tr[3] = st_iters; tr[4] = st_full; tr[5] = (unsigned long long)total;
+    tr[3] = st_iters; tr[4] = st_full;
+    tr[5] = (unsigned long long)(hi - lo) | ((unsigned long long)tile << 32) | ((unsigned long long)seg << 48) | (helper ? 1ull << 63 : 0ull);
   }
   flush_ckpt();
-  // fold the eight lanes
-  const float k0 = oct_sum(C0), k1 = oct_sum(C1), k2 = oct_sum(C2), kd = oct_sum(D), ka = oct_sum(A);
-  float ts = Tstop;
-  ts = fmaxf(ts, QUAD_F(ts, QP(1, 0, 3, 2)));
-  ts = fmaxf(ts, QUAD_F(ts, QP(2, 3, 0, 1)));
-  ts = fmaxf(ts, ODPP_F(-1.0f, ts, DPP_HALF_MIRROR, 0xf));
-  uint32_t lm = last;
-  lm = max(lm, QUAD_U(lm, QP(1, 0, 3, 2)));
-  lm = max(lm, QUAD_U(lm, QP(2, 3, 0, 1)));
-  lm = max(lm, ODPP_U(0u, lm, DPP_HALF_MIRROR, 0xf));
-  const float Tfin = (ts >= 0.f) ? ts : T;
-  uint32_t m = inside ? lm : 0u;
-  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
-  if (lane == 0) s_wmax[wave] = m;
-  if (inside && i == 0) {
-    const size_t pid = (size_t)pyi * a.W + pxi, HW = (size_t)a.H * a.W;
-    a.final_T[pid] = Tfin;
-    a.n_contrib[pid] = lm;
-    a.final_acc[pid] = make_float4(k0, k1, k2, kd);
-    a.out_color[pid] = k0 + Tfin * a.bg[0];
-    a.out_color[HW + pid] = k1 + Tfin * a.bg[1];
-    a.out_color[2 * HW + pid] = k2 + Tfin * a.bg[2];
-    a.out_depth[pid] = kd;
-    a.out_alpha[pid] = ka;
+  // fold the eight lanes (every lane of a pixel ends up with the same values)
+  const float k0 = oct_sum(w.C0), k1 = oct_sum(w.C1), k2 = oct_sum(w.C2), kd = oct_sum(w.D), ka = oct_sum(w.A);
+  const float ts = oct_max(w.Tstop);
+  const uint32_t lm = oct_max_u(w.last);
+  if (helper) {
+    if (__syncthreads_or(dead)) return;  // (the block is finished: nobody reads this segment)
+    FwEnd end;
+    end.T = w.T; end.k0 = k0; end.k1 = k1; end.k2 = k2; end.kd = kd; end.ka = ka; end.lm = lm; end.done = w.done;
+    fw_publish(a.seg_state, a.seg_flags, item, px.pix, end);
+    return;
   }
-  __syncthreads();  // the staging buffers are reused by the next item (and s_wmax is complete)
+  float Tfin = (ts >= 0.f) ? ts : w.T, o0 = k0, o1 = k1, o2 = k2, od = kd, oa = ka;
+  uint32_t on = lm;
+  if (resume) {
+    if (i == 0) {
+      const int bp = wave * 8 + pl;
+      fw_st[0][bp] = Tfin; fw_st[1][bp] = k0; fw_st[2][bp] = k1; fw_st[3][bp] = k2; fw_st[4][bp] = kd; fw_st[5][bp] = ka;
+      fw_st[6][bp] = __uint_as_float(lm); fw_st[7][bp] = w.done ? 1.0f : 0.f;
+    }
+    __syncthreads();
+    fw_owner_rest<TRACE>((const RenderArgs*)(const void*)fw_late_args(), item, resume);
+    __syncthreads();
+    const int bp = wave * 8 + pl;
+    Tfin = fw_st[0][bp]; o0 = fw_st[1][bp]; o1 = fw_st[2][bp]; o2 = fw_st[3][bp]; od = fw_st[4][bp]; oa = fw_st[5][bp];
+    on = __float_as_uint(fw_st[6][bp]);
+  } else if (owner_multi && tid == 0) {
+    // every pixel of the block is final: helpers of the segments that were not reached have nothing to do
+    const int reached = min((total + RIGGS_SEG - 1) / RIGGS_SEG, hbase / RIGGS_SEG + 1);
+    __hip_atomic_store((seg_gu32*)(a.dead_from + (size_t)tile * 8 + sub), (uint32_t)reached, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  {
+    FwLateArgs& l = *fw_late_args();
+    if (px.inside && i == 0) {
+      const size_t pid = (size_t)px.pyi * l.W + px.pxi, HW = (size_t)l.H * l.W;
+      l.final_T[pid] = Tfin;
+      l.n_contrib[pid] = on;
+      l.final_acc[pid] = make_float4(o0, o1, o2, od);
+      l.out_color[pid] = o0 + Tfin * l.bg[0];
+      l.out_color[HW + pid] = o1 + Tfin * l.bg[1];
+      l.out_color[2 * HW + pid] = o2 + Tfin * l.bg[2];
+      l.out_depth[pid] = od;
+      l.out_alpha[pid] = oa;
+    }
+  }
+  uint32_t m = px.inside ? on : 0u;
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+  if (lane == 0) fw_wmax[wave] = m;
+  __syncthreads();  // (fw_wmax is complete)
   // ---- work list of the backward.  A tile's instances past its last contributor (tile_max = max n_contrib over its 256
   // pixels) need no backward, so the list holds one entry per 64-instance chunk below it.  Every block of the tile folds
   // its maximum into tile_max and takes a ticket; the block that draws the last ticket knows the final value and appends
@@ -262,38 +633,39 @@ __global__ __launch_bounds__(256, 6) void render_fwd_oct_kernel(RenderArgs a) {
   // The list's size word (work_ctr) lives on a cache line of ITS OWN: sharing one with item_ctr — which every one of the
   // launch's 20 000 workgroups reads when it starts — cost 17 us (each of the ~470 atomics throws the line out of the L2s,
   // and the late-dispatched workgroups queue behind it at the memory side).
-  // Only wave 0 stays for this (two dependent atomic round trips to the memory side, ~4 us): the other three waves
-  // leave — or move on to the next item, where the round barrier waits for wave 0 — so their SIMD slots are free.
+  // Only wave 0 stays for this (two dependent atomic round trips to the memory side, ~4 us): the other three waves leave.
   if (wave == 0) {
+    FwLateArgs& l = *fw_late_args();
     uint32_t n_c = 0u, base = 0u, limit = 0u;
     if (lane == 0) {
-      const uint32_t mb = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
-      const uint32_t before = __hip_atomic_fetch_max(&a.tile_max[tile], mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t mb = max(max(fw_wmax[0], fw_wmax[1]), max(fw_wmax[2], fw_wmax[3]));
+      const uint32_t before = __hip_atomic_fetch_max(&l.tile_max[tile], mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const uint32_t ticket = __hip_atomic_fetch_add(&a.tile_ticket[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t ticket = __hip_atomic_fetch_add(&l.tile_ticket[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (ticket == 7u) {  // eight 8 x 4 blocks per tile
-        limit = max(max(before, mb), __hip_atomic_load(&a.tile_max[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        limit = max(max(before, mb), __hip_atomic_load(&l.tile_max[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         limit = min((uint32_t)total, limit);
         n_c = (limit + 63u) >> 6;
-        if (n_c) base = __hip_atomic_fetch_add(a.work_ctr, 4u * n_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 2;  // (quarter-chunks)
+        if (n_c) base = __hip_atomic_fetch_add(l.work_ctr, 4u * n_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 2;  // (quarter-chunks)
       }
     }
     n_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_c);
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
     limit = (uint32_t)__builtin_amdgcn_readfirstlane((int)limit);
-    for (uint32_t k = lane; k < n_c; k += 64) a.work[base + k] = make_uint4((uint32_t)tile, k, range.x, limit);
-  }
+    for (uint32_t k = lane; k < n_c; k += 64) l.work[base + k] = make_uint4((uint32_t)tile, k, range.x, limit);
   }
 }
 
 int launch_render_fwd(const RenderArgs& a, hipStream_t s) {
   const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE, gy = (a.H + RIGGS_TILE - 1) / RIGGS_TILE;
   if (gx * gy == 0) return 0;
-  // one workgroup per 8 x 4 block of every tile; the ones past the non-empty tiles of the work list only help with the
-  // background of the empty tiles and leave (tile_max, the tile tickets and the work-list size were cleared by the extra workgroup of bin_scatter_kernel)
-  // (a grid capped at 2048 .. 8192 persistent workgroups instead: within 1 %)
-  if (a.trace) hipLaunchKernelGGL(render_fwd_oct_kernel<true>, dim3(gx * gy * 8), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(render_fwd_oct_kernel<false>, dim3(gx * gy * 8), dim3(256), 0, s, a);
+  // one workgroup per work item (8 x 4 block of a segment of a tile), bounded by the capacity of the work list; the ones
+  // past the list's end only help with the background of the empty tiles and leave (tile_max, the tile tickets, the
+  // hand-shake words and the work-list size were cleared by the extra workgroup of bin_scatter_kernel)
+  const int64_t blocks = a.items ? a.n_item_slots * 8 : (int64_t)gx * gy * 8;
+  if (blocks > 0x7FFFFFFF) { set_error("instance capacity too large for one forward launch"); return 2; }
+  if (a.trace) hipLaunchKernelGGL(render_fwd_oct_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(render_fwd_oct_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, a);
   return 0;
 }
 
@@ -345,7 +717,7 @@ __device__ __forceinline__ f2v splat2(float v) { return f2v{v, v}; }
 // TRACE = per-chunk statistics (both compiled out of the default instantiation: the ordered branch alone cost 4 VGPRs = one
 // wave per SIMD = 7 us)
 template <int NW, bool ORDERED, bool TRACE>
-__global__ __launch_bounds__(64 * NW) void render_bwd_kernel(RenderBwdArgs a) {
+__global__ __launch_bounds__(64 * NW, 4) void render_bwd_kernel(RenderBwdArgs a) {
   constexpr int PPW = 256 / NW;    // pixels per wave
   constexpr int RSTEP = NW;        // a wave's rows are part, part + NW, ...
   // per-pixel state of the chunk, interleaved per PAIR of neighbouring pixels (A, B): one LDS read delivers the two
@@ -393,12 +765,14 @@ __global__ __launch_bounds__(64 * NW) void render_bwd_kernel(RenderBwdArgs a) {
   struct Level3 {  // what a lane loads for a chunk: its instance's records, its pixel's state
     float4 xy, co, cc, acc;
     float Tn, g0, g1, g2, gD, gA, Ts, S0, S1, S2, Ds;
+    float pT, p0, p1, p2, pD;  // segmented tiles: the prefix in front of the chunk's segment (checkpoints are segment-local)
   };
   auto issue_level3 = [&](const u4v wk, uint32_t id, uint32_t n, Level3& r) {
     const int tile = (int)wk.x, pos0 = (int)wk.y * 64;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     r.xy = z; r.co = z; r.cc = z; r.acc = z;
     r.Tn = 0.f; r.g0 = 0.f; r.g1 = 0.f; r.g2 = 0.f; r.gD = 0.f; r.gA = 0.f; r.Ts = 1.f; r.S0 = 0.f; r.S1 = 0.f; r.S2 = 0.f; r.Ds = 0.f;
+    r.pT = 1.f; r.p0 = 0.f; r.p1 = 0.f; r.p2 = 0.f; r.pD = 0.f;
     if (pos0 + lane < (int)wk.w) { r.xy = a.xyd[id]; r.co = a.conic_o[id]; r.cc = a.rgb[id]; }
     if ((int)n > pos0) {  // (n is 0 for the lanes without a pixel and for the pixels outside the image)
       const int pxi = (tile % gx) * RIGGS_TILE + (spix & 15), pyi = (tile / gx) * RIGGS_TILE + (spix >> 4);
@@ -410,6 +784,11 @@ __global__ __launch_bounds__(64 * NW) void render_bwd_kernel(RenderBwdArgs a) {
       r.gD = a.dL_ddepth ? a.dL_ddepth[pid] : 0.f;
       r.gA = a.dL_dalpha ? a.dL_dalpha[pid] : 0.f;
       r.Ts = ck[spix]; r.S0 = ck[256 + spix]; r.S1 = ck[512 + spix]; r.S2 = ck[768 + spix]; r.Ds = ck[1024 + spix];
+      const uint32_t sg = wk.y / RIGGS_SEG_CHUNKS;
+      if (sg > 0u) {  // (only lists longer than RIGGS_SEG have chunks beyond the first segment)
+        const float* sp = a.seg_state + ((size_t)(wk.z / RIGGS_SEG + wk.x + sg) * RIGGS_SEG_WORDS + RIGGS_SEG_PREFIX) * 256 + spix;
+        r.pT = sp[0]; r.p0 = sp[256]; r.p1 = sp[512]; r.p2 = sp[768]; r.pD = sp[1024];
+      }
     }
   };
   auto stage_pixels = [&](const u4v wk, uint32_t n, const Level3& r) {  // this wave's pixels (one per lane) -> LDS
@@ -417,10 +796,12 @@ __global__ __launch_bounds__(64 * NW) void render_bwd_kernel(RenderBwdArgs a) {
     float4 pa = make_float4(1.f, 0.f, 0.f, 0.f), pb = make_float4(0.f, 0.f, 0.f, 0.f);
     float pc = 0.f;
     if ((int)n > pos0) {
-      const float pre = r.g0 * r.S0 + r.g1 * r.S1 + r.g2 * r.S2 + r.gD * r.Ds + r.gA * (1.0f - r.Ts);
+      const float Ts = r.pT * r.Ts;
+      const float S0 = r.p0 + r.pT * r.S0, S1 = r.p1 + r.pT * r.S1, S2 = r.p2 + r.pT * r.S2, Ds = r.pD + r.pT * r.Ds;
+      const float pre = r.g0 * S0 + r.g1 * S1 + r.g2 * S2 + r.gD * Ds + r.gA * (1.0f - Ts);
       const float qb = (r.g0 * r.acc.x + r.g1 * r.acc.y + r.g2 * r.acc.z + r.gD * r.acc.w + r.gA * (1.0f - r.Tn)) +
                        r.Tn * (bg0 * r.g0 + bg1 * r.g1 + bg2 * r.g2);
-      pa = make_float4(r.Ts, pre, qb, __uint_as_float(n));
+      pa = make_float4(Ts, pre, qb, __uint_as_float(n));
       pb = make_float4(r.g0, r.g1, r.g2, r.gD);
       pc = r.gA;
     }

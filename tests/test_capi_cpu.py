@@ -82,3 +82,32 @@ def test_argument_validation_of_the_next_row_entries_needs_no_gpu():
         rc = L.riggs_skeleton_projection_forward(j, s, m, N, N, N, N, 1.0, 1.0, 0.0, 0.0, N, N, N, N, N, N)
         assert rc != 0 and L.riggs_last_error()
     assert L.riggs_skeleton_projection_state_floats(24, 41, 1500) == 2 * 41 * 23 + 2 * 1500 + 6 * 23
+
+
+def test_integration_stub_matches_the_header_struct():
+    """INTEGRATION.md's ctypes stub of riggs_raster_cfg, the struct in include/riggs_hip.h and riggs_amd._lib.RasterCfg
+    list the same fields in the same order (a binding written from a stale stub makes the library read past the struct)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    stub = doc[doc.index("class RasterCfg(C.Structure)"):]
+    stub = stub[:stub.index("def rasterize")]
+    stub_fields = re.findall(r'\("([a-z_0-9A-Z]+)",\s*C\.(c_[a-z0-9_]+)\)', stub)
+    import ctypes as C
+    canon = lambda name: getattr(C, name).__name__            # (c_int32 is an alias of c_int on this ABI)
+    mine = [(n, t.__name__) for n, t in _lib.RasterCfg._fields_]
+    assert [(n, canon(t)) for n, t in stub_fields] == mine
+    hdr = open(os.path.join(root, "include", "riggs_hip.h")).read()
+    body = hdr[hdr.index("typedef struct riggs_raster_cfg"):hdr.index("} riggs_raster_cfg;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    hdr_fields = re.findall(r"\b(?:const\s+)?(int32_t|float)\s*(\*?)\s*([a-zA-Z_0-9]+)\s*;", body)
+    ctype = {("int32_t", ""): "c_int32", ("float", ""): "c_float", ("float", "*"): "c_void_p"}
+    assert [(n, canon(ctype[(t, p)])) for t, p, n in hdr_fields] == mine
+    # the stub's constructor call passes one value per field
+    call = stub_fields and doc[doc.index("cfg = RasterCfg("):]
+    call = call[:call.index("\n    u8 =")]
+    depth, n_args = 0, 1
+    for ch in call[call.index("(") + 1:call.rindex(")")]:
+        depth += ch in "([" 
+        depth -= ch in ")]"
+        n_args += (ch == "," and depth == 0)
+    assert n_args == len(mine)

@@ -16,7 +16,7 @@ w = bench.WORKLOAD
 sc, cam, gm, sw = bench.build_workload(0, "cuda:0")
 T = ((w["W"] + 15) // 16) * ((w["H"] + 15) // 16)
 NB = 1 << 16  # room for the backward's chunks
-trace = torch.zeros(T * 192 + NB * 4, dtype=torch.int64, device="cuda")
+trace = torch.zeros(T * 256 + NB * 4, dtype=torch.int64, device="cuda")
 gimg = torch.rand(3, w["H"], w["W"], device="cuda") * 1e-6
 step = bench.make_step(cam, gm, sw, gimg, RasterArena(), 1, FlatGradAllReduce(bench.params_of(gm, sw), register=False))
 step()
@@ -24,7 +24,7 @@ L.lib().riggs_raster_set_trace(trace.data_ptr())
 step()
 torch.cuda.synchronize()
 L.lib().riggs_raster_set_trace(None)
-b = trace.cpu().numpy()[T * 192:].reshape(-1, 4)
+b = trace.cpu().numpy()[T * 256:].reshape(-1, 4)
 b = b[b[:, 1] > 0]
 t0 = b[:, 0].min()
 start = (b[:, 0] - t0) / 100.0
