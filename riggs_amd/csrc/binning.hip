@@ -181,9 +181,38 @@ __device__ void bin_offsets_body(int T, int64_t cap, const uint32_t* __restrict_
     counters[0] = R;
     counters[1] = (counters[1] & 2u) | (((int64_t)R > cap) ? 1u : 0u);  // (bit 1: the depth sort's third pass failed to synchronise)
   }
-  // step 2: the longest lists first (the forward deals the tiles to its workgroups in this order, so the long
-  // chains start at once and the short ones fill in around them): exclusive scan of the histogram from the top
-  // bucket down, on the first 32 lanes
+  // Order of the work list:  [walkers of the lists of 1024 and more, longest first]  [EARLY helpers]  [walkers of the short
+  // lists]  [late helpers].  Helpers are speculation — a helper's segment may never be reached (the pixels saturate in front
+  // of it): placed early they double the work of such a scene, placed late they come too late for a scene whose long lists
+  // do not saturate.  Whether lists saturate is a property of the scene more than of the view, so the PREVIOUS frame decides:
+  // seg_stats[0, 32) counts its segmented blocks by the number of segments their walk went through - 1, [32, 64) the blocks
+  // that had a k-th segment; levels 1 .. E are early, E the deepest level such that at least half of the blocks that had a
+  // segment of EVERY level up to it reached it and that the helpers up to it fit the budget (E = 0 in the first frame of an
+  // arena, whose statistics are not there yet: a scheduling matter at most).
+  __shared__ uint32_t s_E, s_nearly, s_nlong;
+  if (tid < 32) {
+    const uint32_t h = o.seg_stats[tid];
+    uint32_t reach = h;  // blocks that went through > tid segments = reached segment tid: suffix sum
+    for (int o2 = 1; o2 < 32; o2 <<= 1) {
+      const uint32_t u = (uint32_t)__shfl_down((int)reach, o2);
+      if (tid + o2 < 32) reach += u;
+    }
+    const uint32_t had = o.seg_stats[32 + tid];
+    uint32_t cum = (tid >= 1) ? 8u * s_lvl[tid] : 0u;  // helper items of levels 1 .. tid: prefix sum
+    for (int o2 = 1; o2 < 32; o2 <<= 1) {
+      const uint32_t u = (uint32_t)__shfl_up((int)cum, o2);
+      if (tid >= o2) cum += u;
+    }
+    const bool ok = tid == 0 || (had > 0u && had < 0x40000000u && reach < 0x40000000u && 2u * reach >= had && cum <= o.helper_budget);
+    const uint32_t okm = (uint32_t)__builtin_amdgcn_ballot_w64(ok);  // (lanes 0 .. 31)
+    if (tid == 0) {
+      const int e = (okm == 0xFFFFFFFFu ? 32 : __builtin_ctz(~okm)) - 1;  // the run of ok levels from 0
+      s_E = (uint32_t)(e > 30 ? 30 : e);      // (level 31 stands for all deeper ones too: never early)
+    }
+    o.seg_stats[tid] = 0u;                                        // this frame's walks start counting
+    o.seg_stats[32 + tid] = (tid >= 1) ? 8u * s_lvl[tid] : 0u;    // blocks that have a tid-th segment
+  }
+  __syncthreads();
   if (tid < 32) {
     const uint32_t h = s_hist[31 - tid];
     uint32_t v = h;
@@ -192,17 +221,20 @@ __device__ void bin_offsets_body(int T, int64_t cap, const uint32_t* __restrict_
       if (tid >= o2) v += u;
     }
     s_cur[31 - tid] = v - h;
+    if (tid == 21) s_nlong = v;  // buckets 31 .. 10: lists of 1024 and more
     if (tid == 31) { s_n0 = v; fwd_ctr[1] = 0u; fwd_ctr[2] = s_nempty; fwd_ctr[64] = 0u; }  // ([64]: backward work-list size, on its own cache line)
+    uint32_t ne = (tid >= 1 && (uint32_t)tid <= s_E) ? s_lvl[tid] : 0u;
+    for (int o2 = 16; o2 > 0; o2 >>= 1) ne += (uint32_t)__shfl_xor((int)ne, o2);
+    if (tid == 0) s_nearly = ne;
   }
   __syncthreads();
-  // step 3: the DEEPEST level first (a helper is useful if it is done before the walking workgroup arrives: the far segments
-  // are the ones that can be): start of a level = the non-empty tiles + the deeper levels.  (Scanned in reversed order:
-  // position q <-> level SEG_LMAX - q.)
-  if (tid == 0) s_carry = s_n0;
+  if (tid < 10) s_cur[tid] += s_nearly;  // the walkers of the short lists come behind the early helpers
+  // start of every helper level: early ones (ascending) behind the long walkers, late ones (ascending) behind everything else
+  if (tid == 0) s_carry = 0u;
   __syncthreads();
   for (int base = 1; base < SEG_LMAX; base += nthr) {
-    const int q = base + tid, k = SEG_LMAX - q;
-    const uint32_t c = (q < SEG_LMAX) ? s_lvl[k] : 0u;
+    const int k = base + tid;
+    const uint32_t c = (k < SEG_LMAX) ? s_lvl[k] : 0u;
     uint32_t v = c;
     for (int o2 = 1; o2 < 64; o2 <<= 1) {
       const uint32_t u = (uint32_t)__shfl_up((int)v, o2);
@@ -213,12 +245,16 @@ __device__ void bin_offsets_body(int T, int64_t cap, const uint32_t* __restrict_
     uint32_t wave_off = 0;
     for (int w = 0; w < wave; w++) wave_off += s_wave[w];
     const uint32_t carry = s_carry;
-    if (q < SEG_LMAX) s_lvl[SEG_LMAX + k] = carry + wave_off + v - c;
+    if (k < SEG_LMAX) {
+      const uint32_t before = carry + wave_off + v - c;  // helper entries of the levels in front of k
+      // (early levels are 1 .. E: `before` counts early entries only for them, and for a late level E + m it counts all E early ones)
+      s_lvl[SEG_LMAX + k] = ((uint32_t)k <= s_E) ? s_nlong + before : s_n0 + before;
+    }
     __syncthreads();
     if (tid == nthr - 1) s_carry = carry + wave_off + v;
     __syncthreads();
   }
-  if (tid == 0) fwd_ctr[0] = min(s_carry, o.items_cap);  // (<= T + cap / RIGGS_SEG by construction)
+  if (tid == 0) fwd_ctr[0] = min(s_n0 + s_carry, o.items_cap);  // (<= T + cap / RIGGS_SEG by construction)
   auto emit = [&](uint32_t t, uint32_t len) {
     fwd_items[atomicAdd(&s_cur[31 - __builtin_clz(len)], 1u)] = t;
     const uint32_t nseg = (len + RIGGS_SEG - 1) / RIGGS_SEG;

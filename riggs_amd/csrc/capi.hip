@@ -98,6 +98,9 @@ BinLayout bin_layout(int64_t cap, int N, int H, int W) {
   L.fwd_items = o; o += align_up(L.n_items_cap * 4);
   L.seg_state = o; o += align_up(L.n_seg_slots * RIGGS_SEG_WORDS * 256 * 4);
   L.seg_flags = o; o += align_up(L.n_seg_slots * 8 * 4);
+  // how deep the walks of segmented tiles went: read by the NEXT frame's work-list builder (the binning arena is the one that
+  // persists from frame to frame: riggs_amd.rasterizer.RasterArena, captured frames)
+  L.seg_stats = o; o += align_up(64 * 4);
   L.total = o;
   return L;
 }
@@ -259,6 +262,7 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
     bo.counters = counters; bo.fwd_items = (uint32_t*)(bin + B.fwd_items); bo.fwd_empty = (uint32_t*)(img + I.fwd_empty);
     bo.fwd_ctr = (uint32_t*)(img + I.fwd_ctr); bo.seg_flags = (uint32_t*)(bin + B.seg_flags); bo.dead_from = (uint32_t*)(img + I.dead_from);
     bo.n_seg_slots = (uint32_t)B.n_seg_slots; bo.items_cap = (uint32_t)B.n_items_cap;
+    bo.seg_stats = (uint32_t*)(bin + B.seg_stats); bo.helper_budget = (uint32_t)forward_helper_budget();
     int rcb = launch_binning(N, T, gx, cap, (const uint32_t*)(geom + G.order), (const uint32_t*)(geom + G.tiles),
                              (const ushort4*)(geom + G.rect), bin + B.table, (uint32_t*)(bin + B.point_list),
                              // the per-instance tile id is only a debugging aid here (2M scattered 4-byte stores):
@@ -284,6 +288,7 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
   r.items = nullptr; r.empties = nullptr; r.item_ctr = nullptr;
   if (binned) { r.items = (const uint32_t*)(bin + B.fwd_items); r.empties = (const uint32_t*)(img + I.fwd_empty); r.item_ctr = (uint32_t*)(img + I.fwd_ctr); }
   r.seg_state = (float*)(bin + B.seg_state); r.seg_flags = (uint32_t*)(bin + B.seg_flags); r.dead_from = (uint32_t*)(img + I.dead_from);
+  r.seg_stats = (uint32_t*)(bin + B.seg_stats);
   r.n_item_slots = (int64_t)B.n_items_cap;
   r.deterministic = cfg->deterministic ? 1 : 0;
   r.trace_items = g_raster_trace_items ? g_raster_trace_items : (uint64_t)T * 8;

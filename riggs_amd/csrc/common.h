@@ -72,7 +72,7 @@ struct ImageLayout {
 ImageLayout image_layout(int H, int W);
 
 struct BinLayout {
-  size_t point_list, tile_keys, ckpt, n_slots, table, work, fwd_items, n_items_cap, seg_state, seg_flags, n_seg_slots, total;
+  size_t point_list, tile_keys, ckpt, n_slots, table, work, fwd_items, n_items_cap, seg_state, seg_flags, n_seg_slots, seg_stats, total;
 };
 #define RIGGS_CKPT_FLOATS (5 * 256)  // floats per checkpoint slot
 BinLayout bin_layout(int64_t cap, int N, int H, int W);

@@ -82,11 +82,14 @@ struct RenderArgs {
   float* seg_state;           // [segment slot][RIGGS_SEG_WORDS][256]
   uint32_t* seg_flags;        // [segment slot][8 pixel blocks]: bit 0 = summary published, bit 1 = prefix published
   uint32_t* dead_from;        // [tile][8 pixel blocks]: 0 = unknown, else the first segment that no pixel of the block reaches
+  uint32_t* seg_stats;        // [0, 32): blocks of segmented tiles by the number of segments their walk went through - 1 (this frame);
+                              // [32, 64): blocks that had a k-th segment, written by the work-list builder
   int64_t n_item_slots;       // capacity of the work list (host-side bound of the grid)
   int deterministic;          // cfg.deterministic: no segment runs as a continuation (bitwise repeatable image)
   uint64_t trace_items;       // capacity of the trace buffer in work items (tools; 0: 8 per tile)
 };
 int launch_render_fwd(const RenderArgs& a, hipStream_t s);
+int64_t forward_helper_budget();  // helper workgroups per forward launch
 
 struct RenderBwdArgs {
   unsigned long long* trace;  // optional per-chunk statistics (riggs_raster_set_trace), else NULL
@@ -127,6 +130,8 @@ struct BinOut {  // what the extra workgroup of bin_scatter_kernel writes once p
   uint32_t *slot_base, *tile_max, *counters, *fwd_items, *fwd_empty, *fwd_ctr;
   uint32_t* seg_flags;   // cleared: [seg_slots][8]
   uint32_t* dead_from;   // cleared: [T][8]
+  uint32_t* seg_stats;   // read (the previous frame's) and reset: RenderArgs::seg_stats
+  uint32_t helper_budget; // helper workgroups that may be placed in front of the walkers of the short lists
   uint32_t n_seg_slots;
   uint32_t items_cap;    // capacity of fwd_items
 };

@@ -98,9 +98,10 @@ __device__ __forceinline__ uint32_t oct_max_u(uint32_t v) {
 #define FW_B 256                    // instances per round
 #define FW_NR (RIGGS_SEG / FW_B)    // rounds per segment
 // LDS of the forward (file scope: the main loop and the chain — a function of its own, see fw_seg_chain — share it)
-__shared__ float4 fw_xyd[FW_B];
-__shared__ float4 fw_con[FW_B];
-__shared__ float4 fw_rgb[FW_B];
+__shared__ float4 fw_stage[3 * FW_B];     // the staged round: records of the survivors (and, in fw_owner_rest, the summaries being combined)
+#define fw_xyd (fw_stage)
+#define fw_con (fw_stage + FW_B)
+#define fw_rgb (fw_stage + 2 * FW_B)
 __shared__ unsigned short fw_pos[FW_B];  // position of the survivor inside its batch
 __shared__ int fw_cnt[FW_B / 64];        // survivors per chunk
 __shared__ uint32_t fw_wmax[4];
@@ -115,21 +116,26 @@ struct FwWalk {
   bool done;
 };
 
-// cull one instance per thread against the block's pixels and compact the survivors of every 64 into LDS
-__device__ __forceinline__ int fw_stage_round(const int tid, const bool in_range, const float4 xy, const float4 co, const float4 cc,
-                                              const float bx0, const float by0) {
-  const int lane = tid & 63, chunk = tid >> 6;  // a wave's 64 lanes = one chunk of the batch
-  const bool keep = in_range && ((xy.x + xy.w >= bx0) && (xy.x - xy.w <= bx0 + 7.0f) && (xy.y + cc.w >= by0) && (xy.y - cc.w <= by0 + 3.0f));
+// cull 64 instances (one per lane) against a box of pixels and compact the survivors into region `chunk` of the staging buffer
+// (`pos`: the instance's position inside its round of 256, what n_contrib is counted from)
+__device__ __forceinline__ int fw_stage_chunk(const int chunk, const int lane, const int pos, const bool in_range, const float4 xy,
+                                              const float4 co, const float4 cc, const float bx0, const float bx1, const float by0, const float by1) {
+  const bool keep = in_range && ((xy.x + xy.w >= bx0) && (xy.x - xy.w <= bx1) && (xy.y + cc.w >= by0) && (xy.y - cc.w <= by1));
   const uint64_t mask = __builtin_amdgcn_ballot_w64(keep);
   const int cnt = __builtin_popcountll(mask);
   const int slot = chunk * 64 + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-  if (keep) { fw_xyd[slot] = xy; fw_con[slot] = co; fw_rgb[slot] = cc; fw_pos[slot] = (unsigned short)tid; }
+  if (keep) { fw_xyd[slot] = xy; fw_con[slot] = co; fw_rgb[slot] = cc; fw_pos[slot] = (unsigned short)pos; }
   if (lane >= cnt && lane < ((cnt + 7) & ~7)) {  // null records up to the next multiple of 8
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     fw_xyd[chunk * 64 + lane] = z; fw_con[chunk * 64 + lane] = z; fw_rgb[chunk * 64 + lane] = z; fw_pos[chunk * 64 + lane] = 0;
   }
   if (lane == 0) fw_cnt[chunk] = cnt;
   return cnt;
+}
+// the main loop's round: every wave stages one chunk of the 256, culled against the block's 8 x 4 pixels
+__device__ __forceinline__ int fw_stage_round(const int tid, const bool in_range, const float4 xy, const float4 co, const float4 cc,
+                                              const float bx0, const float by0) {
+  return fw_stage_chunk(tid >> 6, tid & 63, tid, in_range, xy, co, cc, bx0, bx0 + 7.0f, by0, by0 + 3.0f);
 }
 
 // the survivors of chunk k of the staged round, eight per step, for this wave's eight pixels
@@ -244,164 +250,195 @@ __device__ __attribute__((noinline)) void fw_publish(float* seg_state, uint32_t*
 
 // The OWNER's way from the first segment whose summary it found (see the comment above) to the end of the list — the rare,
 // cold part of its walk, in a function of its own so that the main loop stays what it was.  The block's state travels through
-// fw_st.  Per segment: a summarized one is COMBINED (the rounds in which pixels stop are composited again from the true
-// state); one that is not is claimed and WALKED, round by round, with the plain version of the main loop (no software
-// pipeline: it is rarely needed — helpers run ahead of the owner).  Ends when every pixel has stopped (dead_from posted) or the
-// list does.
+// fw_st.  Here every WAVE goes its own way with its eight pixels (a pixel row of the block), without a barrier: it looks at the
+// hand-shake words itself, keeps its instances in its own quarter of the staging buffer, culls against its own row.
+//  * A RUN of consecutive summarized segments (up to FW_RUN) is combined at once: a scan per pixel over the segments' end states
+//    finds the segment in which it stops (the first one where T_in * P falls below 1e-4) and leaves every segment's prefix for
+//    the backward; then only the rounds in which a pixel of the wave stops are composited again, chunk by chunk with the code
+//    of the main loop, each from the true state at its start (prefix x the helper's round state).
+//  * A segment that is not summarized is claimed and walked the same way, chunk by chunk — with its checkpoints unless a helper
+//    has started on it (then they are the helper's, and the prefix is the true one).
+// Whether a wave sees a summary that another wave of the block just missed does not matter: prefixes and checkpoints are per
+// pixel, and the claim / started words say who owns a segment's checkpoints for the whole block.
+#define FW_RUN 4
+__shared__ unsigned long long fw_wmask[4];  // per wave: rounds of the run in which one of its pixels stops
+__shared__ int fw_wend[4];                  // per wave: the segment its walk ended in front of, or -1 while pixels are alive
 template <bool TRACE>
-__device__ __attribute__((noinline)) void fw_owner_rest(const RenderArgs* kernargs, const FwItem it, int s) {
+__device__ __attribute__((noinline)) int fw_owner_rest(const RenderArgs* kernargs, const FwItem it, int s) {
   const RenderArgs& a = *kernargs;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pl = lane >> 3, i = lane & 7, bp = wave * 8 + pl;
   const FwPixel px = fw_pixel(a.W, a.H, it.tile, it.sub, wave, pl);
   const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE;
   const float pfx = (float)px.pxi, pfy = (float)px.pyi;
-  const float bx0 = (float)((it.tile % gx) * RIGGS_TILE + (it.sub & 1) * 8), by0 = (float)((it.tile / gx) * RIGGS_TILE + (it.sub >> 1) * 4);
+  const float bx0 = (float)((it.tile % gx) * RIGGS_TILE + (it.sub & 1) * 8);
+  const float wy = (float)((it.tile / gx) * RIGGS_TILE + (it.sub >> 1) * 4 + wave);  // the wave's pixel row
   const int total = it.total, nseg = (total + RIGGS_SEG - 1) / RIGGS_SEG;
   const uint32_t slot0 = a.slot_base[it.tile];
   const unsigned long long t_chain = (TRACE && a.trace) ? wall_clock64() : 0ull;
-  uint32_t st_steps = 0, st_walk = 0, st_a = 0, st_b = 0;
+  uint32_t st_steps = 0, st_walk = 0, st_a = 0, st_b = 0, st_runs = 0, st_own = 0;
   FwPrefix p;
   p.T = fw_st[0][bp]; p.c0 = fw_st[1][bp]; p.c1 = fw_st[2][bp]; p.c2 = fw_st[3][bp]; p.D = fw_st[4][bp]; p.A = fw_st[5][bp];
   p.last = __float_as_uint(fw_st[6][bp]); p.stop = fw_st[7][bp] != 0.f;
-  // composite round [base, base + 256) of the list from the state w (CK: and store the checkpoints — absolute ones)
-  auto walk_round = [&](FwWalk& w, const int base, const int hi, const bool ck) {
-    {
-      float4 xy = make_float4(0.f, 0.f, 0.f, 0.f), co = xy, cc = xy;
-      const bool in_range = base + tid < hi;
-      if (in_range) {
-        const uint32_t id = a.point_list[it.list_start + base + tid];
-        xy = a.xyd[id]; co = a.conic_o[id]; cc = a.rgb[id];
-      }
-      fw_stage_round(tid, in_range, xy, co, cc, bx0, by0);
-    }
-    __syncthreads();
-    for (int k = 0; k < FW_B / 64; k++) {
-      if (base + 64 * k >= hi) break;
+  auto seed = [&](FwWalk& w, const FwPrefix& q) {
+    w.T = q.T; w.Tstop = -1.0f; w.last = q.last; w.done = q.stop;
+    w.C0 = (i == 0) ? q.c0 : 0.f; w.C1 = (i == 0) ? q.c1 : 0.f; w.C2 = (i == 0) ? q.c2 : 0.f; w.D = (i == 0) ? q.D : 0.f; w.A = (i == 0) ? q.A : 0.f;
+  };
+  auto harvest = [&](const FwWalk& w, FwPrefix& q) {  // (every lane of the eight takes part)
+    const float f0 = oct_sum(w.C0), f1 = oct_sum(w.C1), f2 = oct_sum(w.C2), fd = oct_sum(w.D), fa = oct_sum(w.A);
+    const float t2 = oct_max(w.Tstop);
+    const uint32_t l2 = oct_max_u(w.last);
+    q.c0 = f0; q.c1 = f1; q.c2 = f2; q.D = fd; q.A = fa; q.last = l2;
+    q.stop = w.done;
+    q.T = (t2 >= 0.f) ? t2 : w.T;  // (T of a stopped pixel: the transmittance in front of the instance that ended it)
+  };
+  auto put_prefix = [&](const int sg, const FwPrefix& q) {
+    if (i < 5) *fw_state_ptr(a.seg_state, it, px.pix, sg, RIGGS_SEG_PREFIX + i) = (i == 0) ? q.T : (i == 1) ? q.c0 : (i == 2) ? q.c1 : (i == 3) ? q.c2 : q.D;
+  };
+  // the wave walks instances [from, to) of the list (from a multiple of 64) with its eight pixels, 64 at a time: list entry two
+  // chunks ahead, records one ahead; `base` of a chunk's round = what n_contrib counts from; ck: store the (absolute) checkpoints
+  auto walk = [&](FwWalk& w, const int from, const int to, const bool ck) {
+    auto load_id = [&](const int cb) { return (cb + lane < to) ? a.point_list[it.list_start + cb + lane] : 0xFFFFFFFFu; };
+    uint32_t id1 = load_id(from), id2 = load_id(from + 64);
+    float4 xy = make_float4(0.f, 0.f, 0.f, 0.f), co = xy, cc = xy;
+    if (id1 != 0xFFFFFFFFu) { xy = a.xyd[id1]; co = a.conic_o[id1]; cc = a.rgb[id1]; }
+    for (int cb = from; cb < to; cb += 64) {
       if (__builtin_amdgcn_ballot_w64(!w.done) == 0) break;
+      if constexpr (TRACE) st_walk++;
+      fw_stage_chunk(wave, lane, (cb & (FW_B - 1)) + lane, id1 != 0xFFFFFFFFu, xy, co, cc, bx0, bx0 + 7.0f, wy, wy);
+      id1 = id2;
+      id2 = load_id(cb + 128);
+      xy = make_float4(0.f, 0.f, 0.f, 0.f); co = xy; cc = xy;
+      if (id1 != 0xFFFFFFFFu) { xy = a.xyd[id1]; co = a.conic_o[id1]; cc = a.rgb[id1]; }
       if (ck) {
         const float k0 = oct_sum(w.C0), k1 = oct_sum(w.C1), k2 = oct_sum(w.C2), kd = oct_sum(w.D);
         if (!w.done && i < 5)
-          a.ckpt[((size_t)(slot0 + ((base + 64 * k) >> 6)) * 5 + i) * 256 + px.pix] = (i == 0) ? w.T : (i == 1) ? k0 : (i == 2) ? k1 : (i == 3) ? k2 : kd;
+          a.ckpt[((size_t)(slot0 + (cb >> 6)) * 5 + i) * 256 + px.pix] = (i == 0) ? w.T : (i == 1) ? k0 : (i == 2) ? k1 : (i == 3) ? k2 : kd;
       }
-      fw_composite_chunk<false>(w, k, base, lane, pfx, pfy, st_a, st_b);
+      fw_composite_chunk<false>(w, wave, cb & ~(FW_B - 1), lane, pfx, pfy, st_a, st_b);
     }
-    __syncthreads();
   };
   for (;;) {
-    // segment s: summarized?  Otherwise it is this workgroup's (claimed)
-    if (tid == 0) {
-      uint32_t f = ld_agent_u(fw_flag_ptr(a.seg_flags, it, s));
-      if (!(f & SEG_SUMMARY)) f = __hip_atomic_fetch_or((seg_gu32*)fw_flag_ptr(a.seg_flags, it, s), SEG_CLAIM, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      fw_word = f;
+    if (__builtin_amdgcn_ballot_w64(!p.stop) == 0 || s >= nseg) break;
+    // the run of summarized segments that starts at s (lane j looks at segment s + j); none: claim segment s
+    int k;
+    bool started = false;
+    {
+      const bool in = lane < FW_RUN && s + lane < nseg;
+      uint32_t f = in ? ld_agent_u(fw_flag_ptr(a.seg_flags, it, s + lane)) : 0u;
+      const unsigned long long ready = __builtin_amdgcn_ballot_w64(in && (f & SEG_SUMMARY));
+      k = __builtin_ctzll(~ready);
+      if (k == 0) {
+        if (lane == 0) f = __hip_atomic_fetch_or((seg_gu32*)fw_flag_ptr(a.seg_flags, it, s), SEG_CLAIM, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        f = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);
+        if (f & SEG_SUMMARY) k = 1;
+        started = (f & SEG_STARTED) != 0u;
+      }
     }
-    __syncthreads();
-    const bool summarized = (fw_word & SEG_SUMMARY) != 0u, started = (fw_word & SEG_STARTED) != 0u;
-    __syncthreads();
-    const int s_lo = s * RIGGS_SEG, s_hi = min(total, s_lo + RIGGS_SEG);
-    if (!summarized) {
-      // walk it.  The checkpoints are this workgroup's (absolute; the identity as the segment's prefix for the backward) unless
-      // a helper is at work on the segment: then they are the helper's, segment-local, and the prefix is the true one
-      if (i < 5) *fw_state_ptr(a.seg_state, it, px.pix, s, RIGGS_SEG_PREFIX + i) =
-          !started ? ((i == 0) ? 1.0f : 0.f) : ((i == 0) ? p.T : (i == 1) ? p.c0 : (i == 2) ? p.c1 : (i == 3) ? p.c2 : p.D);
+    if constexpr (TRACE) { st_runs++; if (k == 0) st_own++; }
+    if (k == 0) {
+      // walk segment s
+      const int s_lo = s * RIGGS_SEG, s_hi = min(total, s_lo + RIGGS_SEG);
+      if (started) put_prefix(s, p);
+      else if (i < 5) *fw_state_ptr(a.seg_state, it, px.pix, s, RIGGS_SEG_PREFIX + i) = (i == 0) ? 1.0f : 0.f;
       FwWalk w;
-      w.T = p.T; w.Tstop = -1.0f; w.last = p.last; w.done = p.stop;
-      w.C0 = (i == 0) ? p.c0 : 0.f; w.C1 = (i == 0) ? p.c1 : 0.f; w.C2 = (i == 0) ? p.c2 : 0.f; w.D = (i == 0) ? p.D : 0.f; w.A = (i == 0) ? p.A : 0.f;
-      for (int base = s_lo; base < s_hi; base += FW_B) {
-        if (__syncthreads_count(w.done) == 256) break;
-        if constexpr (TRACE) st_walk++;
-        walk_round(w, base, s_hi, !started);
-      }
-      const float f0 = oct_sum(w.C0), f1 = oct_sum(w.C1), f2 = oct_sum(w.C2), fd = oct_sum(w.D), fa = oct_sum(w.A);
-      const float t2 = oct_max(w.Tstop);
-      const uint32_t l2 = oct_max_u(w.last);
-      if (!p.stop) {
-        p.c0 = f0; p.c1 = f1; p.c2 = f2; p.D = fd; p.A = fa; p.last = l2;
-        p.stop = w.done;
-        p.T = (t2 >= 0.f) ? t2 : w.T;
-      }
-    } else {
-      // the prefix of segment s, for the backward (its checkpoints are segment-local)
-      if (i < 5) *fw_state_ptr(a.seg_state, it, px.pix, s, RIGGS_SEG_PREFIX + i) = (i == 0) ? p.T : (i == 1) ? p.c0 : (i == 2) ? p.c1 : (i == 3) ? p.c2 : p.D;
-      // combine segment s: lane i holds word i of the states at the start of its rounds 1, 2, 3 and of its end state
-      if constexpr (TRACE) st_steps++;
-      float ev[FW_NR];
+      seed(w, p);
+      walk(w, s_lo, s_hi, !started);
+      FwPrefix q;
+      harvest(w, q);
+      if (!p.stop) p = q;
+      s++;
+      continue;
+    }
+    // ---- combine segments s .. s + k - 1: lane i holds word i of their end states
+    if constexpr (TRACE) st_steps += (uint32_t)k;
+    float ev[FW_RUN];
 #pragma unroll
-      for (int e = 0; e < FW_NR; e++) ev[e] = ld_agent(fw_state_ptr(a.seg_state, it, px.pix, s, 8 * e + i));
-      int rstar = FW_NR;  // the round the pixel has to be composited again from (FW_NR: none)
-      {
-        const float eP = oct_get(ev[FW_NR - 1], 0, lane), e0 = oct_get(ev[FW_NR - 1], 1, lane), e1 = oct_get(ev[FW_NR - 1], 2, lane),
-                    e2 = oct_get(ev[FW_NR - 1], 3, lane), eD = oct_get(ev[FW_NR - 1], 4, lane), eA = oct_get(ev[FW_NR - 1], 5, lane);
-        const uint32_t eL = __float_as_uint(oct_get(ev[FW_NR - 1], 6, lane));
-        float tr[FW_NR - 1];
+    for (int j = 0; j < FW_RUN; j++) ev[j] = (j < k) ? ld_agent(fw_state_ptr(a.seg_state, it, px.pix, s + j, 8 * (FW_NR - 1) + i)) : 0.f;
+    int jstar = -1;  // the segment of the run in which the pixel stops
 #pragma unroll
-        for (int r = 0; r < FW_NR - 1; r++) tr[r] = oct_get(ev[r], 0, lane);
-        if (!p.stop) {
-          const float tp = p.T * eP;
-          if (tp >= T_EPS) {
-            p.c0 += p.T * e0; p.c1 += p.T * e1; p.c2 += p.T * e2; p.D += p.T * eD; p.A += p.T * eA;
-            p.last = eL ? eL : p.last;
-            p.T = tp;
-          } else {
-            // the pixel stops inside the segment: in the first round at whose END T_in * T_local is below the threshold
-            rstar = FW_NR - 1;
-#pragma unroll
-            for (int r = FW_NR - 2; r >= 0; r--) if (p.T * tr[r] < T_EPS) rstar = r;
-          }
-        }
-      }
-      if (__syncthreads_or(rstar < FW_NR)) {
-        // composite again from the true state: rounds rstar .. of the segment, until the stop (or, should the rounding of
-        // T_in * P have promised a stop that the instance-by-instance product does not find, the segment's end)
-        bool walking = false;
-        FwWalk w;
-        w.T = 1.0f; w.C0 = 0.f; w.C1 = 0.f; w.C2 = 0.f; w.D = 0.f; w.A = 0.f; w.Tstop = -1.0f; w.last = 0u; w.done = true;
-        for (int r = 0; r < FW_NR; r++) {
-          const int base = s_lo + r * FW_B;
-          if (base >= s_hi) break;
-          {
-            // (every lane takes part in the shuffles; only the pixels that enter at this round use the result)
-            const float vv = ev[r > 0 ? r - 1 : 0];
-            const float eT = oct_get(vv, 0, lane), e0 = oct_get(vv, 1, lane), e1 = oct_get(vv, 2, lane), e2 = oct_get(vv, 3, lane),
-                        eD = oct_get(vv, 4, lane), eA = oct_get(vv, 5, lane);
-            const uint32_t eL = __float_as_uint(oct_get(vv, 6, lane));
-            if (rstar == r) {  // enter: the true state at the start of round r
-              walking = true; w.done = false;
-              const bool first = r == 0;
-              w.T = first ? p.T : p.T * eT;
-              w.C0 = (i == 0) ? (first ? p.c0 : p.c0 + p.T * e0) : 0.f; w.C1 = (i == 0) ? (first ? p.c1 : p.c1 + p.T * e1) : 0.f;
-              w.C2 = (i == 0) ? (first ? p.c2 : p.c2 + p.T * e2) : 0.f; w.D = (i == 0) ? (first ? p.D : p.D + p.T * eD) : 0.f;
-              w.A = (i == 0) ? (first ? p.A : p.A + p.T * eA) : 0.f;
-              w.last = (!first && eL) ? eL : p.last;
-            }
-          }
-          if (!__syncthreads_or(walking && !w.done)) continue;
-          if constexpr (TRACE) st_walk++;
-          walk_round(w, base, s_hi, false);
-        }
-        const float f0 = oct_sum(w.C0), f1 = oct_sum(w.C1), f2 = oct_sum(w.C2), fd = oct_sum(w.D), fa = oct_sum(w.A);
-        const float t2 = oct_max(w.Tstop);
-        const uint32_t l2 = oct_max_u(w.last);
-        if (walking) {
-          p.c0 = f0; p.c1 = f1; p.c2 = f2; p.D = fd; p.A = fa; p.last = l2;
-          if (t2 >= 0.f) { p.T = t2; p.stop = true; }  // (T of a stopped pixel: the transmittance in front of the instance that ended it)
-          else p.T = w.T;
-        }
+    for (int j = 0; j < FW_RUN; j++) {
+      const float eP = oct_get(ev[j], 0, lane), e0 = oct_get(ev[j], 1, lane), e1 = oct_get(ev[j], 2, lane), e2 = oct_get(ev[j], 3, lane),
+                  eD = oct_get(ev[j], 4, lane), eA = oct_get(ev[j], 5, lane);
+      const uint32_t eL = __float_as_uint(oct_get(ev[j], 6, lane));
+      if (j < k && !p.stop && jstar < 0) {
+        put_prefix(s + j, p);
+        const float tp = p.T * eP;
+        if (tp >= T_EPS) {
+          p.c0 += p.T * e0; p.c1 += p.T * e1; p.c2 += p.T * e2; p.D += p.T * eD; p.A += p.T * eA;
+          p.last = eL ? eL : p.last;
+          p.T = tp;
+        } else jstar = j;  // (p stays the prefix of segment s + jstar)
       }
     }
-    s++;
-    // the end of the block's work, or of the list?
-    if (__syncthreads_count(p.stop) == 256) {
-      if (s < nseg && tid == 0) __hip_atomic_store((seg_gu32*)(a.dead_from + (size_t)it.tile * 8 + it.sub), (uint32_t)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      break;
+    // the round of that segment: the first one at whose END T_in * T_local is below the threshold; its start state
+    int Rstar = 64;  // linear round index in the run (64: none)
+    FwPrefix q = p;
+    if (lane == 0) fw_wmask[wave] = 0ull;
+    if (__builtin_amdgcn_ballot_w64(jstar >= 0) != 0ull) {
+      float e3[FW_NR - 1];
+#pragma unroll
+      for (int e = 0; e < FW_NR - 1; e++) e3[e] = (jstar >= 0) ? ld_agent(fw_state_ptr(a.seg_state, it, px.pix, s + jstar, 8 * e + i)) : 0.f;
+      int rstar = FW_NR - 1;
+#pragma unroll
+      for (int r = FW_NR - 2; r >= 0; r--) if (p.T * oct_get(e3[r], 0, lane) < T_EPS) rstar = r;
+#pragma unroll
+      for (int e = 0; e < FW_NR - 1; e++) {
+        const float eT = oct_get(e3[e], 0, lane), e0 = oct_get(e3[e], 1, lane), e1 = oct_get(e3[e], 2, lane), e2 = oct_get(e3[e], 3, lane),
+                    eD = oct_get(e3[e], 4, lane), eA = oct_get(e3[e], 5, lane);
+        const uint32_t eL = __float_as_uint(oct_get(e3[e], 6, lane));
+        if (jstar >= 0 && rstar == e + 1) {
+          q.T = p.T * eT; q.c0 = p.c0 + p.T * e0; q.c1 = p.c1 + p.T * e1; q.c2 = p.c2 + p.T * e2; q.D = p.D + p.T * eD; q.A = p.A + p.T * eA;
+          q.last = eL ? eL : p.last;
+        }
+      }
+      if (jstar >= 0) {
+        Rstar = jstar * FW_NR + rstar;
+        if (i == 0) atomicOr(&fw_wmask[wave], 1ull << Rstar);
+      }
+      // composite again, from the true state: every round in which a pixel of the wave stops (and, should the rounding of T_in * P
+      // have promised a stop that the instance-by-instance product does not find, the rounds behind it — until the run ends)
+      unsigned long long todo = fw_wmask[wave];
+      const int run_lo = s * RIGGS_SEG, run_hi = min(total, (s + k) * RIGGS_SEG);
+      FwWalk w;
+      w.T = 1.0f; w.C0 = 0.f; w.C1 = 0.f; w.C2 = 0.f; w.D = 0.f; w.A = 0.f; w.Tstop = -1.0f; w.last = 0u; w.done = true;
+      bool walking = false;
+      int R = __builtin_ctzll(todo);
+      for (;;) {
+        const int base = run_lo + R * FW_B;
+        if (Rstar == R) { walking = true; seed(w, q); w.done = false; }
+        if ((R % FW_NR) == 0) {  // (uniform: every lane takes part in the shuffles of harvest)
+          FwPrefix t;
+          harvest(w, t);
+          if (walking && !w.done && R > Rstar) put_prefix(s + R / FW_NR, t);  // a walk that crosses into the next segment: its true prefix
+        }
+        todo &= ~(1ull << R);
+        walk(w, base, min(base + FW_B, run_hi), false);
+        const bool goes_on = __builtin_amdgcn_ballot_w64(walking && !w.done) != 0ull && base + FW_B < run_hi;
+        const int Rn = goes_on ? R + 1 : (todo ? __builtin_ctzll(todo) : 64);
+        if (Rn >= 64 || run_lo + Rn * FW_B >= run_hi) break;
+        R = Rn;
+      }
+      FwPrefix t;
+      harvest(w, t);
+      if (walking) p = t;
     }
-    if (s == nseg) break;
+    s += k;
   }
+  // the block's end: every pixel final -> later segments are nobody's business any more
+  if (lane == 0) fw_wend[wave] = (__builtin_amdgcn_ballot_w64(!p.stop) == 0ull) ? s : -1;
   if (i == 0) {
     fw_st[0][bp] = p.T; fw_st[1][bp] = p.c0; fw_st[2][bp] = p.c1; fw_st[3][bp] = p.c2; fw_st[4][bp] = p.D; fw_st[5][bp] = p.A;
     fw_st[6][bp] = __uint_as_float(p.last); fw_st[7][bp] = p.stop ? 1.0f : 0.f;
   }
+  __syncthreads();
+  const int e0 = fw_wend[0], e1 = fw_wend[1], e2 = fw_wend[2], e3 = fw_wend[3];
+  const int smax = max(max(e0, e1), max(e2, e3));
+  if (tid == 0 && e0 >= 0 && e1 >= 0 && e2 >= 0 && e3 >= 0 && smax < nseg)
+    __hip_atomic_store((seg_gu32*)(a.dead_from + (size_t)it.tile * 8 + it.sub), (uint32_t)smax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (TRACE && a.trace && lane == 0 && (uint64_t)it.index < a.trace_items)
-    a.trace[((size_t)it.index * 4 + wave) * 8 + 7] = (wall_clock64() - t_chain) | ((unsigned long long)st_steps << 32) | ((unsigned long long)st_walk << 44);
+    a.trace[((size_t)it.index * 4 + wave) * 8 + 7] = (wall_clock64() - t_chain) | ((unsigned long long)st_steps << 32) | ((unsigned long long)st_walk << 44) |
+                                                       ((unsigned long long)st_runs << 54) | ((unsigned long long)st_own << 59);
+  return max(smax, s);  // (segments the block's pixels went through)
 }
 
 template <bool TRACE>
@@ -413,11 +450,11 @@ __global__ __launch_bounds__(256, 6) void render_fwd_oct_kernel(RenderArgs a) {
   {
     // tiles without instances: background only, one pixel per thread (a.items == NULL: nothing was binned — no
     // Gaussians or an empty arena — and every tile is such a tile)
-    FwLateArgs& l = *fw_late_args();
-    const size_t HW = (size_t)l.H * l.W;
-    const int n_empty = l.items ? (int)l.item_ctr[2] : gx * ((l.H + RIGGS_TILE - 1) / RIGGS_TILE);
-    for (int e = blockIdx.x; e < n_empty; e += gridDim.x) {
-      const int t = l.items ? (int)l.empties[e] : e;
+    const int n_empty = a.items ? (int)a.item_ctr[2] : gx * ((a.H + RIGGS_TILE - 1) / RIGGS_TILE);
+    if ((int)blockIdx.x < n_empty) {  // (the launch has more workgroups than tiles)
+      FwLateArgs& l = *fw_late_args();
+      const size_t HW = (size_t)l.H * l.W;
+      const int t = l.items ? (int)l.empties[blockIdx.x] : (int)blockIdx.x;
       const int px = (t % gx) * RIGGS_TILE + (tid & 15), py = (t / gx) * RIGGS_TILE + (tid >> 4);
       if (px < l.W && py < l.H) {
         const size_t pid = (size_t)py * l.W + px;
@@ -511,7 +548,10 @@ __global__ __launch_bounds__(256, 6) void render_fwd_oct_kernel(RenderArgs a) {
       dnext = ld_agent_u(a.dead_from + (size_t)tile * 8 + sub);
     }
     const bool boundary = owner_multi && base > 0 && (base & (RIGGS_SEG - 1)) == 0;  // the owner enters a new segment
-    if (boundary && tid == 0) fw_word = claim;
+    if (boundary && tid == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(claim) :: "memory");  // (the claim's result, requested a round ago)
+      fw_word = claim;
+    }
     if (__syncthreads_count(w.done) == 256) break;
     if (boundary) {
       const uint32_t f = fw_word;
@@ -527,8 +567,14 @@ __global__ __launch_bounds__(256, 6) void render_fwd_oct_kernel(RenderArgs a) {
         if (i < 5) *fw_state_ptr(a.seg_state, item, px.pix, base / RIGGS_SEG, RIGGS_SEG_PREFIX + i) = (i == 0) ? w.T : (i == 1) ? k0 : (i == 2) ? k1 : (i == 3) ? k2 : kd;
       }
     }
-    if (owner_multi && (base & (RIGGS_SEG - 1)) == RIGGS_SEG - B && base + B < hi && tid == 0)  // the last round of a segment: claim the next one
-      claim = __hip_atomic_fetch_or((seg_gu32*)fw_flag_ptr(a.seg_flags, item, base / RIGGS_SEG + 1), SEG_CLAIM, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (owner_multi && (base & (RIGGS_SEG - 1)) == RIGGS_SEG - B && base + B < hi && tid == 0) {
+      // the last round of a segment: claim the next one.  The returning atomic is written in assembly so that its result is
+      // waited for where it is read, one round later (the compiler waits for a result defined under a divergent branch at the
+      // end of the branch: a round trip to the memory side on the critical path of every segment).  The hardware retires
+      // vector memory operations in order, so the compiler's own counts stay conservative.
+      const uint32_t* fp = fw_flag_ptr(a.seg_flags, item, base / RIGGS_SEG + 1);
+      asm volatile("global_atomic_or %0, %1, %2, off sc0" : "=v"(claim) : "v"(fp), "v"(SEG_CLAIM) : "memory");
+    }
     {
       const int cnt = fw_stage_round(tid, base + tid < hi, n_xy, n_co, n_cc, bx0, by0);
       if constexpr (TRACE) st_surv += (uint32_t)cnt;
@@ -589,6 +635,7 @@ __global__ __launch_bounds__(256, 6) void render_fwd_oct_kernel(RenderArgs a) {
   }
   float Tfin = (ts >= 0.f) ? ts : w.T, o0 = k0, o1 = k1, o2 = k2, od = kd, oa = ka;
   uint32_t on = lm;
+  int reached = 1;  // (owner of a segmented tile) number of segments its pixels went through
   if (resume) {
     if (i == 0) {
       const int bp = wave * 8 + pl;
@@ -596,16 +643,18 @@ __global__ __launch_bounds__(256, 6) void render_fwd_oct_kernel(RenderArgs a) {
       fw_st[6][bp] = __uint_as_float(lm); fw_st[7][bp] = w.done ? 1.0f : 0.f;
     }
     __syncthreads();
-    fw_owner_rest<TRACE>((const RenderArgs*)(const void*)fw_late_args(), item, resume);
+    reached = fw_owner_rest<TRACE>((const RenderArgs*)(const void*)fw_late_args(), item, resume);
     __syncthreads();
     const int bp = wave * 8 + pl;
     Tfin = fw_st[0][bp]; o0 = fw_st[1][bp]; o1 = fw_st[2][bp]; o2 = fw_st[3][bp]; od = fw_st[4][bp]; oa = fw_st[5][bp];
     on = __float_as_uint(fw_st[6][bp]);
   } else if (owner_multi && tid == 0) {
     // every pixel of the block is final: helpers of the segments that were not reached have nothing to do
-    const int reached = min((total + RIGGS_SEG - 1) / RIGGS_SEG, hbase / RIGGS_SEG + 1);
+    reached = min((total + RIGGS_SEG - 1) / RIGGS_SEG, hbase / RIGGS_SEG + 1);
     __hip_atomic_store((seg_gu32*)(a.dead_from + (size_t)tile * 8 + sub), (uint32_t)reached, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  // statistics for the NEXT frame's work list (bin_offsets_body): how deep the walks of segmented tiles get
+  if (owner_multi && tid == 0) atomicAdd(fw_late_args()->seg_stats + min(max(reached, 1) - 1, 31), 1u);
   {
     FwLateArgs& l = *fw_late_args();
     if (px.inside && i == 0) {
@@ -656,14 +705,31 @@ __global__ __launch_bounds__(256, 6) void render_fwd_oct_kernel(RenderArgs a) {
   }
 }
 
+// helper workgroups per forward launch (RIGGS_FWD_HELPERS overrides: a tuning knob for tools, 0 turns the helpers off)
+int64_t forward_helper_budget() {
+  static int64_t v = -1;
+  if (v < 0) {
+    const char* e = getenv("RIGGS_FWD_HELPERS");
+    v = e ? atoll(e) : 8192;
+  }
+  return v;
+}
+
 int launch_render_fwd(const RenderArgs& a, hipStream_t s) {
   const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE, gy = (a.H + RIGGS_TILE - 1) / RIGGS_TILE;
   if (gx * gy == 0) return 0;
-  // one workgroup per work item (8 x 4 block of a segment of a tile), bounded by the capacity of the work list; the ones
-  // past the list's end only help with the background of the empty tiles and leave (tile_max, the tile tickets, the
-  // hand-shake words and the work-list size were cleared by the extra workgroup of bin_scatter_kernel)
-  const int64_t blocks = a.items ? a.n_item_slots * 8 : (int64_t)gx * gy * 8;
-  if (blocks > 0x7FFFFFFF) { set_error("instance capacity too large for one forward launch"); return 2; }
+  // one workgroup per work item: the walkers of all tiles (they come first in the list; the ones of empty tiles only help with
+  // the background and leave) and as many helpers as fit a BUDGET — helpers are optional, the list has the ones of the longest
+  // lists first, and a helper that finds nothing to do still costs a workgroup launch and a round trip to memory (20 000 of
+  // them behind the last walker: +8 us on a 60 us launch).  (tile_max, the tile tickets, the hand-shake words and the
+  // work-list size were cleared by the extra workgroup of bin_scatter_kernel.)
+  const int64_t walkers = (int64_t)gx * gy * 8;
+  int64_t helpers = a.items ? a.n_item_slots * 8 - walkers : 0;
+  const int64_t budget = forward_helper_budget();
+  if (helpers > budget) helpers = budget;
+  if (helpers < 0) helpers = 0;
+  const int64_t blocks = walkers + helpers;
+  if (blocks > 0x7FFFFFFF) { set_error("image too large for one forward launch"); return 2; }
   if (a.trace) hipLaunchKernelGGL(render_fwd_oct_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(render_fwd_oct_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, a);
   return 0;

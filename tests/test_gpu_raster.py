@@ -156,7 +156,10 @@ def test_arena_mode_matches_sync_mode_and_recovers_from_overflow():
     arena = RasterArena(min_capacity=16)
     a1 = rasterize_forward(st, *args, arena=arena)   # first call synchronises and sizes the arena
     a2 = rasterize_forward(st, *args, arena=arena)   # second call: no host sync, padded sort
-    assert torch.equal(ref[0], a1[0]) and torch.equal(ref[0], a2[0])
+    # (bitwise equality holds in the reproducible mode only: by default a long list may be composited by several workgroups
+    # whose partial results are combined — which ones depends on timing, and the combination rounds differently)
+    same = lambda x, y: float((x - y).abs().max()) <= 2e-6 * max(1.0, float(x.abs().max()))  # noqa: E731
+    assert same(ref[0], a1[0]) and same(ref[0], a2[0])
     assert torch.equal(ref[1], a2[1])
     assert arena.resolve() and arena.last_R == saved_views(ref[4])["R"]
     # force a too-small arena: the frame is flagged when its counters are consumed, then the arena regrows
@@ -167,7 +170,7 @@ def test_arena_mode_matches_sync_mode_and_recovers_from_overflow():
     with pytest.raises(RiggsHipError, match="overflowed"):
         rasterize_forward(st, *args, arena=arena)
     a4 = rasterize_forward(st, *args, arena=arena)
-    assert arena.resolve() and torch.equal(ref[0], a4[0])
+    assert arena.resolve() and same(ref[0], a4[0])
 
 
 @pytest.mark.parametrize("N,J,H,W", [(150_000, 24, 800, 800), (300_000, 32, 800, 800)])

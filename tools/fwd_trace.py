@@ -56,7 +56,7 @@ def main():
             t[deep, 1].sum(), (np.ceil(t[deep, 5] / 256)).sum(), 100.0 * t[deep, 1].sum() / np.ceil(t[deep, 5] / 256).sum()))
     t0 = t[:, 6].min()
     start, main_end = (t[:, 6] - t0) / 100.0, (t[:, 6] - t0 + t[:, 0]) / 100.0
-    chain_us, steps, walk, back = (t[:, 7] & 0xFFFFFFFF) / 100.0, (t[:, 7] >> 32) & 0xFFF, (t[:, 7] >> 44) & 0x3FF, 0 * t[:, 7]
+    chain_us, steps, walk, back = (t[:, 7] & 0xFFFFFFFF) / 100.0, (t[:, 7] >> 32) & 0xFFF, (t[:, 7] >> 44) & 0x3FF, (t[:, 7] >> 54) & 0x3FF
     print("starts: p50 %.1f p90 %.1f p99 %.1f max %.1f us; compositing loops end: p50 %.1f p99 %.1f max %.1f us" % (
         *np.percentile(start, [50, 90, 99, 100]), *np.percentile(main_end, [50, 99, 100])))
     endall = main_end + chain_us
@@ -70,10 +70,10 @@ def main():
         end = main_end + chain_us
         print("chains: %d waves took part; time in the chain p50 %.1f p90 %.1f p99 %.1f max %.1f us; last chain ends at %.1f us" % (
             ch.sum(), *np.percentile(chain_us[ch], [50, 90, 99, 100]), end.max()))
-        print("        segments combined: total %d, max per holder %d; rounds composited again: total %d, max %d; (unused) %d %d" % (
+        print("        segments combined: total %d, max per holder %d; rounds composited (again, or of segments walked here): total %d, max %d; loop passes | own walks << 5: total %d, max %d" % (
             steps.sum() // 1, steps.max(), walk.sum(), walk.max(), back.sum(), back.max()))
         o2 = np.argsort(-chain_us)[:10]
-        print("        slowest chain holders: [chain us, segments, re-walked, scanned back, tile, seg, start us]")
+        print("        slowest chain holders: [chain us, segments combined, rounds composited, passes | own walks << 5, tile, seg, start us]")
         for k in o2:
             print("          %7.1f %4d %4d %4d %6d %4d %7.1f" % (chain_us[k], steps[k], walk[k], back[k], tile_of[k], seg_of[k], start[k]))
     print("mean wave time %.1f us; sum of wave times / (1024 SIMDs x 6 waves) = %.1f us" % (us.mean(), us.sum() / (1024 * 6)))
