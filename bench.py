@@ -207,9 +207,12 @@ def dense_scene_timing(dev, steps=50):
             "what": "same path / sizes / camera, thin opaque skin around the bones (synth.make_surface_scene); not the headline metric"}
 
 
-def _oracle_iteration(sc, cam_cpu, gimg_cpu, pose=None):
+def _oracle_iteration(sc, cam_cpu, gimg_cpu, pose=None, deformed=None, want_saved=False):
     """One iteration of the CPU oracle (torch-CPU deform restatement + C/OpenMP rasterizer, fwd + bwd) on a scene; returns
-    (image, gradient dict, R).  ``pose`` = (local_rotation, global_trans) replaces the scene's own pose."""
+    (image, gradient dict, R).  ``pose`` = (local_rotation, global_trans) replaces the scene's own pose.
+    ``deformed`` = (d_xyz, d_rotation) computed by the OTHER side: the rasterizer then sees exactly these values (so that both
+    sides take the same alpha >= 1/255 / 0.99 / T < 1e-4 decisions — a 1-ulp difference in a deformed mean flips a few) while
+    the gradients still flow through the oracle's own deformation (value of theirs, derivative of ours)."""
     import numpy as np
     from oracle import deform_ref as O
     from oracle import raster_ref as RR
@@ -221,6 +224,10 @@ def _oracle_iteration(sc, cam_cpu, gimg_cpu, pose=None):
         P["local_rotation"], P["global_trans"] = leaf(pose[0]), leaf(pose[1])
     dv = O.deform_by_pose(P["xyz"].detach(), sc["joints"], sc["parents"], P["node_radius"], P["local_rotation"],
                           P["global_trans"], sc["motion_mask"], -1)
+    if deformed is not None:
+        dv = dict(dv)
+        dv["d_xyz"] = dv["d_xyz"] + (deformed[0] - dv["d_xyz"]).detach()
+        dv["d_rotation"] = dv["d_rotation"] + (deformed[1] - dv["d_rotation"]).detach()
     m3, op, scl, rot, shs = O.render_glue(P["xyz"], P["features_dc"], P["features_rest"], P["scaling"],
                                           P["rotation"], P["opacity"], dv["d_xyz"], dv["d_rotation"], dv["d_scaling"])
     out, saved = RR.forward(m3.detach().numpy(), op.detach().numpy(), cam_cpu.world_view_transform.numpy(),
@@ -233,6 +240,9 @@ def _oracle_iteration(sc, cam_cpu, gimg_cpu, pose=None):
                                                       T(g["rotations"]), T(g["shs"])])
     grads = {k: P[k].grad.numpy() for k in P if P[k].grad is not None}
     grads["means2D"] = g["means2D"]
+    if want_saved:
+        act = {"means3D": m3.detach(), "opacities": op.detach(), "scales": scl.detach(), "rotations": rot.detach(), "shs": shs.detach()}
+        return out, grads, saved, act
     return out["color"], grads, saved.R
 
 
@@ -370,9 +380,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` launched plainly: start the N ranks ourselves — the same command line under
+        # torch.distributed.run, one process per GPU of this node, rendezvous on 127.0.0.1 (the hostname of a container may
+        # not resolve) — and pass its exit code on.  Rank 0 of that launch prints the JSON line.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     ndev = max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank % ndev)  # (% ndev: lets a 1-GPU box exercise the multi-rank control flow over gloo)
     dev = "cuda:%d" % (local_rank % ndev)

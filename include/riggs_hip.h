@@ -234,7 +234,9 @@ size_t riggs_pose_mlp_sync_bytes(int32_t depth, int32_t width);
  * workgroups by bounded spinning, which needs all of a launch's workgroups co-resident (<= 96 workgroups of 512
  * threads: true on an otherwise idle MI355X; NOT guaranteed when another process or a concurrent stream holds
  * CUs for long).  A spin that times out poisons that launch's outputs with NaN and sets bit 0 of this word; no
- * kernel ever clears it.  The host reads it after a step (PoseMLP.check_status / GraphedFrame.check) and raises. */
+ * kernel ever clears it.  The host reads it after a step (PoseMLP.check_status / GraphedFrame.check) and raises.
+ * The word behind it is a TEST HOOK: bit 0 / bit 1 make one workgroup of the forward / backward launch keep a layer's
+ * hand-off to itself, so that the time-out path can be exercised on an idle GPU (tests/test_gpu_deform.py); leave it 0. */
 size_t riggs_pose_mlp_status_word(int32_t depth, int32_t width);
 /* debugging aid: 128 device u64 that workgroup 0 of the one-launch kernels stamps with the 100 MHz wall clock
  * per stage (forward [0,64), backward [64,128)); NULL (the default) disables it. */
@@ -293,9 +295,12 @@ int riggs_densify_stats(int32_t num_points, const float* viewspace_grad, const u
  * The caller all-gathers the segments of all ranks (equal riggs_grad_rows_segment_bytes) and calls
  * riggs_grad_rows_unpack: per Gaussian the rows are combined IN RANK ORDER — first occurrence overwrites, later ones are
  * added; rows in no segment are left as they are (zero on every rank) — without atomics, so every rank obtains the same
- * bits.  `grads` are HOST arrays of DEVICE pointers to (N, widths[k]) row-major float tensors (<= 8).  status[0] =
- * max over segments of the rows needed, status[1] = 1 when a segment overflowed `capacity` or does not match (N,
- * row_floats): then NOTHING is unpacked (the gradients keep their local values) and the caller exchanges densely.
+ * bits.  `grads` are HOST arrays of DEVICE pointers to (N, widths[k]) row-major float tensors (<= 8).  `status` (4 words)
+ * is STICKY — only ever raised by the kernel, cleared by whoever reads it: [0] = the largest number of rows a segment
+ * needed, [1] != 0 when in some call a segment overflowed `capacity` or did not match (N, row_floats): in that call NOTHING
+ * was unpacked (the gradients kept their local values) and the caller has to exchange that step densely — or, when it polls
+ * only every k steps and the optimizers have already stepped on un-averaged gradients, re-synchronise the replicas; [2] = calls
+ * since it was cleared, [3] = the call (1-based) that failed first.
  * `backward_workspace` is the workspace the last riggs_raster_backward of these N Gaussians used, on the same stream. */
 int32_t riggs_grad_rows_row_floats(int32_t n_tensors, const int32_t* widths);
 size_t riggs_grad_rows_segment_bytes(int32_t num_points, int32_t row_floats, int32_t capacity);

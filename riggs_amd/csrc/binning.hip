@@ -679,7 +679,7 @@ __global__ __launch_bounds__(RS_SC_WAVES * 64) void rs_scatter_kernel(int N, int
 // barrier (one arrival counter, bounded spin: the guide's recipe; counters[3], cleared by the first kernel of the sort) and then
 // each reads the whole 150 KB table — every other chunk's counts — to place its own elements.
 #define RS3_BINS 256
-#define RS3_MAX_WG 512  // workgroups of the third pass (<= 2 per CU: all resident whatever N is; each loops over its chunks)
+#define RS3_MAX_WG 512  // upper bound of the third pass's grid (launch_depth_sort sizes it from the device's occupancy; each workgroup loops over its chunks)
 typedef __attribute__((address_space(1))) uint32_t rs_gu32;
 __global__ __launch_bounds__(RS_SC_WAVES * 64) void rs_third_pass_kernel(int N, int n_chunks, RsBufs bufs,
                                                                          uint32_t* __restrict__ table3,
@@ -820,7 +820,22 @@ int launch_depth_sort(int N, const uint32_t* keys_in, uint32_t* keys_out, uint32
     hipLaunchKernelGGL(rs_scatter_kernel, dim3(chunks), dim3(RS_SC_WAVES * 64), 0, s, N, pass, b, table, bin_count, counters);
   }
   // (the table of the 12-bit passes is free again: chunks x 256 counts fit into it)
-  hipLaunchKernelGGL(rs_third_pass_kernel, dim3(chunks < RS3_MAX_WG ? chunks : RS3_MAX_WG), dim3(RS_SC_WAVES * 64), 0, s, N, chunks,
+  // The in-launch barrier of the third pass needs every workgroup RESIDENT at once: size the grid from what the device can
+  // hold of this kernel (occupancy x compute units), and only HALF of it — kernels of other streams (the RCCL collectives of
+  // the overlapped exchanges) may occupy compute units at the same time.  Each workgroup loops over its chunks, so any grid
+  // size is correct; a workgroup that still does not become resident ends the bounded spin and flags the frame.
+  static int rs3_grid = 0;
+  if (rs3_grid == 0) {
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(rs_third_pass_kernel), RS_SC_WAVES * 64, 0) != hipSuccess ||
+        hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+      per_cu = 1; cus = 64; (void)hipGetLastError();
+    }
+    const int resident = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
+    rs3_grid = resident / 2 > 0 ? resident / 2 : 1;
+    if (rs3_grid > RS3_MAX_WG) rs3_grid = RS3_MAX_WG;
+  }
+  hipLaunchKernelGGL(rs_third_pass_kernel, dim3(chunks < rs3_grid ? chunks : rs3_grid), dim3(RS_SC_WAVES * 64), 0, s, N, chunks,
                      b, table, counters);
   return 0;
 }

@@ -156,7 +156,15 @@ __global__ __launch_bounds__(256) void rows_unpack_kernel(int N, int world, int 
     if (bad) atomicOr(&s_hdr[1], 1u);
   }
   __syncthreads();
-  if (b == 0 && t == 0) { status[0] = s_hdr[0]; status[1] = s_hdr[1]; }
+  // STICKY status (cleared by the host when it reads it, SparseRowExchange.check()): a caller that polls every k steps must
+  // still learn that ONE of them overflowed — on that step every rank skipped the unpack and stepped its optimizer on local
+  // gradients.  {largest need since the last check, overflow flag, unpack calls since the last check, the call (1-based)
+  // that overflowed first}
+  if (b == 0 && t == 0) {
+    atomicMax(&status[0], s_hdr[0]);
+    const uint32_t call = atomicAdd(&status[2], 1u) + 1u;
+    if (s_hdr[1]) { atomicOr(&status[1], s_hdr[1]); atomicCAS(&status[3], 0u, call); }
+  }
   if (s_hdr[1]) return;  // (every workgroup of every rank sees the same headers: all skip, the gradients stay as they were)
   const size_t rows_off = seg_rows_offset(N);
   const int c0 = 4 * sub;                              // this lane's floats of a row (rows wider than 64 floats loop)

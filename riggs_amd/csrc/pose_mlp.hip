@@ -234,6 +234,7 @@ __device__ __forceinline__ bool pm_sweep(const unsigned long long* gran, int n, 
   }
 }
 
+#define PM_FAULT_BIT 1u
 __global__ __launch_bounds__(PMF_WAVES * 64) void pm_forward_fused_kernel(PoseMlpDesc d, const float* __restrict__ t,
                                                                           const float* __restrict__ rot_bias4,
                                                                           float* __restrict__ acts,
@@ -327,6 +328,9 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_forward_fused_kernel(PoseMl
     if (wave == 0 && blockIdx.x == 0) acts[lane] = embv;
   }
   if (threadIdx.x == 0) s_failed = 0;
+  // TEST HOOK (tests/test_gpu_deform.py): the word behind the sticky status word of a persistent sync_state makes workgroup 1 keep
+  // one layer's hand-off to itself — bit 0 in the forward, bit 1 in the backward — so that the consumers' bounded spins time out
+  const bool fault = sticky != nullptr && blockIdx.x == 1 && (sticky[1] & PM_FAULT_BIT) != 0u;
   PM_TRACE(0);
   __syncthreads();
 #pragma unroll
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_forward_fused_kernel(PoseMl
         if (s_failed) v = __builtin_nanf("");
         if (!heads) {
           v = s_failed ? v : fmaxf(v, 0.f);
-          pm_store_granule(gran + (size_t)l * d.width + row, tag0 + (uint32_t)(l + 1), v);
+          if (!(fault && l == 1)) pm_store_granule(gran + (size_t)l * d.width + row, tag0 + (uint32_t)(l + 1), v);
           acts[emb + (size_t)l * d.width + row] = v;
         } else if (row < d.n_rot) {
           rotation[row] = rot_bias4 ? v + rot_bias4[row & 3] : v;
@@ -392,6 +396,8 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_forward_fused_kernel(PoseMl
 // The granules live behind the forward's in `acts` (zeroed by the forward's memset node, so the backward
 // needs none); tags carry a generation word that the last stage bumps, so a second backward over the same
 // activations (retain_graph) never matches the first one's granules.
+#undef PM_FAULT_BIT
+#define PM_FAULT_BIT 2u
 __global__ __launch_bounds__(PMF_WAVES * 64) void pm_backward_fused_kernel(PoseMlpDesc d, PoseMlpGradDesc g,
                                                                            const float* __restrict__ acts,
                                                                            const float* __restrict__ g_rot,
@@ -430,6 +436,9 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_backward_fused_kernel(PoseM
   __shared__ float s_late[PM_MAX_LAYERS + 1];
   for (int i = threadIdx.x; i < emb + d.depth * d.width; i += blockDim.x) s_acts[i] = acts[i];
   if (threadIdx.x == 0) s_failed = 0;
+  // TEST HOOK (tests/test_gpu_deform.py): the word behind the sticky status word of a persistent sync_state makes workgroup 1 keep
+  // one layer's hand-off to itself — bit 0 in the forward, bit 1 in the backward — so that the consumers' bounded spins time out
+  const bool fault = sticky != nullptr && blockIdx.x == 1 && (sticky[1] & PM_FAULT_BIT) != 0u;
   PM_TRACE(0);
   __syncthreads();
   PM_TRACE(1);
@@ -482,7 +491,7 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_backward_fused_kernel(PoseM
           if (r < n_rows) acc += wc[l][k] * sv[k];
         }
         acc = wave_sum(acc);
-        if (lane == 63 && col < d.width) pm_store_granule(gran + (size_t)(l - 1) * d.width + col, tag0 + (uint32_t)l, acc);
+        if (lane == 63 && col < d.width && !(fault && l == 2)) pm_store_granule(gran + (size_t)(l - 1) * d.width + col, tag0 + (uint32_t)l, acc);
       }
       // (b) weight / bias gradients of matrix l, row `col`
       if (wave == 0) {

@@ -105,6 +105,20 @@ class FlatGradAllReduce:
         if self.registered:
             self.register()
 
+    def verify_aliases(self, params=None):
+        """The exchanges that reduce ``flat`` directly (OverlappedExchange, SparseRowExchange over bucket views) are only right
+        when every parameter's ``.grad`` IS its slice of the bucket: a gradient that landed in a fresh buffer (grad_out falls
+        back to one when the parameter is not registered, grad_out_flat when the run of parameters is not contiguous in the
+        bucket) would silently stay unreduced.  Raises naming the first stray gradient; parameters without a gradient yet
+        are skipped."""
+        for p, v in zip(self.params, self.views):
+            if params is not None and not any(p is q for q in params):
+                continue
+            if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+                raise RuntimeError("the gradient of a %s parameter does not alias its slice of the flat bucket: the direct "
+                                   "exchange would leave it unreduced (reduce with FlatGradAllReduce.__call__, which copies "
+                                   "stray gradients in, or register the bucket before the backward)" % (tuple(p.shape),))
+
     def register(self):
         import weakref
         for p, o in zip(self.params, self.offsets):
@@ -192,6 +206,8 @@ class OverlappedExchange:
     def launch(self, phase: int):
         """Issue phase 1 (``flat[:split]``) or phase 2 (``flat[split:]``) behind everything the compute stream has queued."""
         t = self.bucket.flat[:self.split] if phase == 1 else self.bucket.flat[self.split:]
+        if phase == 1 and not (self.cuda and torch.cuda.is_current_stream_capturing()):
+            self.bucket.verify_aliases()
         if self.cuda:
             self.comm.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm):
@@ -250,8 +266,11 @@ class ShardedAdam:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.b1, self.b2, self.eps = float(betas[0]), float(betas[1]), float(eps)
-        self.params = [p for g in groups for p in g["params"]]
-        self.lrs = [g["lr"] for g in groups for _ in g["params"]]
+        # the groups are kept and their "lr" is read at EVERY step, like torch.optim.Adam's param_groups: the reference
+        # trainer rewrites the xyz learning rate every iteration (scene/gaussian_model.py: update_learning_rate)
+        self.param_groups = [dict(g, params=list(g["params"])) for g in groups]
+        self.params = [p for g in self.param_groups for p in g["params"]]
+        self._group_of = [gi for gi, g in enumerate(self.param_groups) for _ in g["params"]]
         self.bucket = FlatGradAllReduce(self.params, average=average, register=False)
         n = self.bucket.numel
         self.shard = (n + 4 * self.world - 1) // (4 * self.world) * 4     # 16-byte aligned, equal on every rank
@@ -279,6 +298,18 @@ class ShardedAdam:
             a, b = max(o, self.lo), min(o + p.numel(), self.hi)
             if a < b:
                 self.segments.append((a, b, lr_i))
+
+    @property
+    def lrs(self):
+        return [float(self.param_groups[gi]["lr"]) for gi in self._group_of]
+
+    def set_lr(self, group_name_or_index, lr: float):
+        """The schedule hook (``update_learning_rate``): by group index or by the group's "name"."""
+        for gi, g in enumerate(self.param_groups):
+            if gi == group_name_or_index or g.get("name") == group_name_or_index:
+                g["lr"] = float(lr)
+                return
+        raise KeyError(group_name_or_index)
 
     def step(self):
         """Gradients (already in the bucket) -> averaged shard -> Adam on the shard -> every replica's parameters."""
@@ -333,7 +364,8 @@ class ShardedAdam:
             M = (C.c_void_p * n)(*[off(self.m, a) for a, _, _ in chunk])
             V = (C.c_void_p * n)(*[off(self.v, a) for a, _, _ in chunk])
             numel = (C.c_int64 * n)(*[b - a for a, b, _ in chunk])
-            lr = (C.c_double * n)(*[float(self.lrs[i]) for _, _, i in chunk])
+            lrs = self.lrs
+            lr = (C.c_double * n)(*[lrs[i] for _, _, i in chunk])
             steps = (C.c_int64 * n)(*[self.steps] * n)
             L.check(lib.riggs_adam_step(n, P, G, M, V, numel, lr, steps, self.b1, self.b2, self.eps, L.stream_ptr()),
                     "riggs_adam_step")
@@ -346,8 +378,9 @@ def sparse_rows_all_reduce(grads, capacity: int, average: bool = True):
     occluded), and different views touch different Gaussians.  Every rank compacts its non-zero rows (fixed ``capacity``: no
     host synchronisation), all-gathers (index, row) pairs and adds them up locally: (W - 1) x capacity x (row bytes + 4) received
     per rank instead of 2 (W - 1) / W x N x row bytes for the ring all-reduce — less traffic while capacity < ~2 N / W.
-    Returns the number of rows the fullest rank needed (a device scalar: when it exceeds ``capacity`` rows were dropped and the
-    caller must redo the exchange densely; checked like the rasterizer's arena overflow, after the fact)."""
+    Returns the number of rows the fullest rank needed (a device scalar: when it exceeds ``capacity`` the gradients are left
+    UNTOUCHED — local — on every rank and the caller must redo the exchange densely; checked like the rasterizer's arena
+    overflow, after the fact)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     N = grads[0].shape[0]
     flat = [g.reshape(N, -1) for g in grads]
@@ -377,10 +410,14 @@ def sparse_rows_all_reduce(grads, capacity: int, average: bool = True):
     acc.index_add_(0, all_idx, all_pay)
     if average:
         acc /= world
+    # on overflow (some rank needed more than `capacity` rows: `need` is the maximum over the ranks, the same on all of them) the
+    # compaction dropped rows, so NOTHING is written back — every rank keeps its local gradients and can still redo the step
+    # densely; decided on the device, no host synchronisation
+    ok = need <= capacity
     o = 0
     for g, f in zip(grads, flat):
         w = f.shape[1]
-        g.copy_(acc[:N, o:o + w].reshape(g.shape))
+        g.copy_(torch.where(ok, acc[:N, o:o + w].reshape(g.shape), g))
         o += w
     return need
 
@@ -423,9 +460,11 @@ class SparseRowExchange:
     that touches other rows needs the dense path).  ``rest`` — a flat tensor with the remaining (dense, small) gradients,
     all-reduced as it is.  ``pack()`` right after the rasterizer's backward on the compute stream, ``launch()`` puts the
     all-gather on the communication stream, ``launch_rest()`` the small all-reduce (after the deformation backward),
-    ``wait()`` joins and unpacks.  ``check()`` (a device->host read: once per step at most, or every k steps) returns
-    False when a segment overflowed ``capacity``: that step's unpack was skipped on EVERY rank (gradients still local),
-    call ``dense_fallback()`` for it and ``resize()``.  The reference has no distributed path."""
+    ``wait()`` joins and unpacks.  ``check()`` (a device->host read of a STICKY status) returns False when a segment
+    overflowed ``capacity`` in any step since the previous check: that step's unpack was skipped on EVERY rank (gradients
+    still local).  Checked before the optimizer steps, ``dense_fallback()`` repairs the step; checked only every k steps,
+    the replicas may already have stepped on un-averaged gradients — ``resync()`` them; then build a larger exchange
+    (``resize()``, before any capture).  The reference has no distributed path."""
 
     def __init__(self, rows, rest=None, capacity=None, average=True, pack=None, unpack=None, world=None):
         self.world = int(world) if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
@@ -447,9 +486,10 @@ class SparseRowExchange:
         self._widths = (C.c_int32 * len(self.rows))(*self.widths)
         dev = self.rows[0].device
         self.comm = torch.cuda.Stream(device=dev) if self.cuda else None
-        self.status = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.status = torch.zeros(4, dtype=torch.int32, device=dev)  # sticky: see check()
         self.pending = []
-        self.need = 0
+        self.need, self.calls, self.overflow_call = 0, 0, 0
+        self._pack_captured = False
         # the backward workspace to pack from: None = the one the most recent rasterizer backward used; a caller that runs
         # other backward passes in between (another stream, an eager profiling step) pins it (GraphedFrame.backward_workspace)
         self.workspace = None
@@ -464,6 +504,11 @@ class SparseRowExchange:
         self.resize(int(capacity) if capacity is not None else max(1024, self.N // 8))
 
     def resize(self, capacity: int):
+        if getattr(self, "_pack_captured", False):
+            # a captured pack has the old segment's address and capacity baked in: it would write into freed memory while the
+            # all-gather sends the new, empty segment (gradients silently stay local)
+            raise RuntimeError("SparseRowExchange.resize() after pack() was captured in a hipGraph: build a new exchange and "
+                               "capture the frame again")
         self.capacity = int(min(max(capacity, 1), self.N))
         words = segment_words(self.N, self.row_floats, self.capacity)
         dev = self.rows[0].device
@@ -476,6 +521,8 @@ class SparseRowExchange:
         return self.capacity * self.world < 2 * self.N
 
     def pack(self):
+        if self.cuda and torch.cuda.is_current_stream_capturing():
+            self._pack_captured = True
         self._pack(self)
 
     def _on_comm(self, fn):
@@ -533,9 +580,27 @@ class SparseRowExchange:
         self._unpack(self)
 
     def check(self) -> bool:
-        need, bad = (int(v) for v in self.status.tolist())
-        self.need = need
+        """Reads and clears the sticky status (a device->host read).  False when ANY unpack since the previous check
+        overflowed ``capacity`` — on such a step every rank skipped the unpack, the gradients stayed local.
+        ``overflow_call`` then holds which of the ``calls`` unpacks since the previous check failed first: if it is the one
+        that has just run and no optimizer has stepped, ``dense_fallback()`` repairs the step; if optimizers have stepped on
+        it (polling every k steps), the replicas have diverged: ``resync(parameters, optimizer)`` broadcasts rank 0's."""
+        need, bad, calls, first = (int(v) for v in self.status.tolist())
+        self.status.zero_()
+        self.need, self.calls, self.overflow_call = need, calls, first if bad else 0
         return not bad
+
+    def resync(self, tensors):
+        """Replicas that stepped on un-averaged gradients (an overflow found late): every tensor in ``tensors`` — parameters,
+        optimizer moments, step counters — becomes rank 0's, then ``resize()`` to what the steps needed."""
+        if self.world > 1 and dist.is_initialized():
+            for t in tensors:
+                if t.is_cuda and dist.get_backend() != "nccl":
+                    h = t.detach().cpu()
+                    dist.broadcast(h, 0)
+                    t.detach().copy_(h)
+                else:
+                    dist.broadcast(t.detach(), 0)
 
     def dense_fallback(self):
         """The step whose ``check()`` failed: its unpack was skipped everywhere, so the rows are averaged densely."""

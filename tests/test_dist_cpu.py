@@ -229,15 +229,18 @@ def _w_sparse(rank, world):
         dist.all_reduce(t)
         t /= world
     small = [t.clone() for t in dense]  # (values irrelevant) a capacity that is too small is reported, not silently wrong
-    over = sparse_rows_all_reduce([torch.ones(N, 2) * (rank + 1)], capacity=16)
-    return [a.numpy() for a in grads], [b.numpy() for b in dense], int(need), int(over), len(small)
+    mine = torch.ones(N, 2) * (rank + 1)
+    over = sparse_rows_all_reduce([mine], capacity=16)
+    kept = bool((mine == rank + 1).all())               # ... and on overflow the LOCAL gradients survive (a dense redo is possible)
+    return [a.numpy() for a in grads], [b.numpy() for b in dense], int(need), int(over), len(small), kept
 
 
 def test_compacted_row_exchange_equals_the_dense_all_reduce_and_reports_overflow():
     got = _spawn(_w_sparse)
     for r in range(2):
-        sparse, dense, need, over, _ = got[r]
+        sparse, dense, need, over, _, kept = got[r]
         assert need == 25 and over == 200   # rows the fullest rank needed; 200 > capacity 16: the caller must go dense
+        assert kept                          # (nothing was written back: no row was zeroed by the truncated compaction)
         for a, b in zip(sparse, dense):
             np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-7)
 
@@ -313,3 +316,40 @@ def test_segment_size_matches_the_library():
     assert lib.riggs_grad_rows_row_floats(6, w) == 60
     for N, cap in ((1, 0), (700, 80), (300_000, 30_000), (2_000_000, 1)):
         assert lib.riggs_grad_rows_segment_bytes(N, 60, cap) == 4 * segment_words(N, 60, cap)
+
+
+def test_sharded_adam_reads_the_learning_rate_of_its_groups_at_every_step():
+    """The reference trainer rewrites the xyz learning rate every iteration (update_learning_rate): the sharded optimizer keeps
+    the param groups and follows them (world 1 on the CPU; the schedule hook ``set_lr`` by group name)."""
+    from riggs_amd.dist import ShardedAdam
+    a = [torch.nn.Parameter(torch.randn(7, 3)), torch.nn.Parameter(torch.randn(5))]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    opt = ShardedAdam([{"params": [a[0]], "lr": 1e-2, "name": "xyz"}, {"params": [a[1]], "lr": 1e-3, "name": "f_dc"}])
+    ref = torch.optim.Adam([{"params": [b[0]], "lr": 1e-2}, {"params": [b[1]], "lr": 1e-3}], eps=1e-15)
+    g = torch.Generator().manual_seed(3)
+    for step, lr in enumerate((1e-2, 5e-3, 1e-4)):
+        opt.set_lr("xyz", lr)
+        ref.param_groups[0]["lr"] = lr
+        for pa, pb, v in zip(a, b, opt.bucket.views):
+            gr = torch.randn(pa.shape, generator=g)
+            v.copy_(gr)
+            pb.grad = gr.clone()
+        opt.step()
+        ref.step()
+    for pa, pb in zip(a, b):
+        np.testing.assert_allclose(pa.detach().numpy(), pb.detach().numpy(), rtol=2e-5, atol=2e-7)
+    with pytest.raises(KeyError):
+        opt.set_lr("nope", 1.0)
+
+
+def test_direct_exchange_refuses_gradients_that_do_not_alias_the_bucket():
+    from riggs_amd.dist import FlatGradAllReduce, OverlappedExchange
+    ps = [torch.nn.Parameter(torch.randn(4, 3)), torch.nn.Parameter(torch.randn(6))]
+    bucket = FlatGradAllReduce(ps, register=False)
+    ps[0].grad = bucket.views[0]
+    ps[1].grad = torch.zeros(6)               # a stray buffer: the direct reduction of bucket.flat would never see it
+    ex = OverlappedExchange(bucket, bucket.offsets[1])
+    with pytest.raises(RuntimeError, match="does not alias"):
+        ex.launch(1)
+    ps[1].grad = bucket.views[1]
+    ex.launch(1); ex.launch(2); ex.wait()

@@ -269,6 +269,14 @@ def test_bench_contract_single_and_two_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     d3 = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert d3["n_gpus"] == 2 and d3["config"]["exchange"].startswith("two-phase")
+    # ... and exactly `python bench.py --gpus 2`: it starts its two ranks itself (what a driver that calls the scaling runs the
+    # way it calls the single-GPU one does)
+    env.pop("MASTER_ADDR", None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d4 = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert d4["n_gpus"] == 2 and d4["steps"] == 3 and d4["config"]["parallelism"] == "frames x2" and d4["value"] > 0
 
 
 def test_dist_knn3_at_initialisation_size():

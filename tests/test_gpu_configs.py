@@ -68,10 +68,20 @@ def test_c4_full_size_properties():
     assert R > 2_000_000 and vis > 0.9 * N
 
 
+PIPE_FRAC = 5e-4     # per tensor: share of the elements allowed beyond 1e-4 of max|oracle| (observed worst: 1.1e-4)
+RADIUS_TOL = 1e-4    # dL/d node_radius (J sums over all Gaussians), relative to its largest entry
+
+
 def _pipeline_parity_vs_oracle(N, J, H, W, cam_cpu, tag, surface=False):
-    """The whole hot path (skeleton deformation -> fused glue -> rasterizer forward + backward) on the HIP side against the
-    CPU oracle run on the same inputs: image and every parameter gradient within the bar bench.py applies at the headline size
-    (per tensor <= 2e-3 of the elements beyond 1e-4 of max|oracle|).  Returns R."""
+    """The whole hot path (PoseMLP -> FK -> skinning -> fused glue -> rasterizer forward + backward) on the HIP side against
+    the CPU oracle AT FULL SIZE.  The oracle's rasterizer is fed the HIP side's deformed means / rotations (values; the
+    derivatives stay the oracle's own), so both sides take the same threshold decisions and the bars are the sharp ones:
+      * radii, tiles_touched, depth bits, pixel centres, R, the sorted point list, the (tile | depth) keys and the tile ranges
+        BIT-EXACT, n_contrib / image / depth / alpha / final_T within tolerance (U.compare_forward_state: the HIP rasterizer on
+        the oracle's activated inputs);
+      * the fused pipeline's image and every parameter gradient: per tensor <= PIPE_FRAC of the elements beyond 1e-4 of
+        max|oracle|, dL/d node_radius and the PoseMLP parameter gradients within RADIUS_TOL of their largest entry.
+    Returns R."""
     import bench
     from riggs_amd.rasterizer import RasterArena
     old = dict(bench.WORKLOAD)
@@ -91,15 +101,30 @@ def _pipeline_parity_vs_oracle(N, J, H, W, cam_cpu, tag, surface=False):
     pkg = step()
     torch.cuda.synchronize()
     names = ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation", "node_radius")
-    hip_grads = {k: p.grad.detach().cpu().numpy() for k, p in zip(names, bench.params_of(gm, sw))}
+    all_params = bench.params_of(gm, sw)
+    hip_grads = {k: p.grad.detach().cpu().numpy() for k, p in zip(names, all_params)}
     hip_grads["means2D"] = pkg["viewspace_points"].grad.detach().cpu().numpy()
+    pose_params = list(sw.pose_net.parameters())
+    assert len(all_params) == len(names) + len(pose_params)
+    hip_pose_grads = [p.grad.detach().clone() for p in pose_params]
+    hip_image = pkg["render"].detach().cpu().numpy()
+    del pkg
     with torch.no_grad():
-        na = sw.get_pose_info(sw.expand_time(cam.fid))
+        t_in = sw.expand_time(cam.fid)
+        na = sw.get_pose_info(t_in)
+        dv = sw(gm.get_xyz.detach(), t_in, motion_mask=gm.motion_mask)
     pose = (na["local_rotation"].detach().cpu(), na["global_trans"].detach().cpu())
+    deformed = (dv["d_xyz"].detach().cpu(), dv["d_rotation"].detach().cpu())
     bench._set_threads(16)
-    ora_image, ora_grads, R = bench._oracle_iteration(sc, cam_cpu, gimg, pose)
+    out_o, ora_grads, so, act = bench._oracle_iteration(sc, cam_cpu, gimg, pose, deformed=deformed, want_saved=True)
+    # ---- (1) the rasterizer's forward state on identical activated inputs: bit-exact ordering and indexing at FULL size
+    color, radii, depth, alpha, s = U.hip_forward(act, cam_cpu, [0.0, 0.0, 0.0])
+    U.compare_forward_state(so, saved_views(s), out_o, color, depth, alpha, radii)
+    del color, radii, depth, alpha, s
+    torch.cuda.empty_cache()
+    # ---- (2) the fused pipeline: image and gradients
     worst = 0.0
-    pairs = [("image", pkg["render"].detach().cpu().numpy(), ora_image)] + [("dL/d_" + k, hip_grads[k], ora_grads[k]) for k in hip_grads]
+    pairs = [("image", hip_image, out_o["color"])] + [("dL/d_" + k, hip_grads[k], ora_grads[k]) for k in hip_grads]
     assert len(pairs) == 9
     for name, a, b in pairs:
         a, b = np.asarray(a, np.float64).reshape(-1), np.asarray(b, np.float64).reshape(-1)
@@ -107,20 +132,32 @@ def _pipeline_parity_vs_oracle(N, J, H, W, cam_cpu, tag, surface=False):
         err = np.abs(a - b)
         assert scale > 0
         if b.size < 1000:
-            # dL/d node_radius: J sums over all the Gaussians of terms that cancel (random-sign cotangent).  The sums inherit
-            # the per-Gaussian outliers counted below — the few Gaussians whose alpha >= 1/255, 0.99-cap or T < 1e-4 decision
-            # flips between the two sides' roundings of the deformed means (SURVEY.md §7 "hard parts") — undiluted: ~1e-4 of
-            # the largest entry in the translucent scenes, 3e-3 in the opaque-skin scene, where every flip is a large term
-            # (the float32 oracle's own deformation backward is within 3e-6 of a float64 run on identical upstream
-            # gradients, so this is not summation order).  The per-Gaussian tensors are the sharp check.
-            assert err.max() <= (1e-2 if surface else 5e-4) * scale, (tag, name, err.max() / scale)
+            # dL/d node_radius: J sums over all the Gaussians of terms that cancel (random-sign cotangent); with the threshold
+            # decisions shared between the two sides what is left is the summation order
+            U.STATS.append((tag + " full size " + name, int(b.size), float((err > RADIUS_TOL * scale).mean()), float(err.max() / scale), 0.0))
+            assert err.max() <= RADIUS_TOL * scale, (tag, name, err.max() / scale)
             continue
         frac = float((err > 1e-4 * scale).mean())
         worst = max(worst, frac)
-        assert frac <= 2e-3, (tag, name, frac, err.max() / scale)
+        assert frac <= PIPE_FRAC, (tag, name, frac, err.max() / scale)
         U.STATS.append((tag + " full size " + name, int(b.size), frac, float(err.max() / scale), float((err > 1e-4 * np.abs(b) + 1e-6 * scale).mean())))
-    assert worst <= 2e-3
-    return R
+    assert worst <= PIPE_FRAC
+    # ---- (3) the PoseMLP parameter gradients: the oracle's dL/d(local_rotation, global_trans) pushed through a float64 torch
+    # copy of the network on the CPU (plain torch ops: the reference's arithmetic, not the HIP kernels)
+    import copy
+    sw64 = copy.deepcopy(sw).cpu().double()
+    for p in sw64.pose_net.parameters():
+        p.grad = None
+    na = sw64.get_pose_info(sw64.expand_time(cam_cpu.fid.double()))
+    torch.autograd.backward([na["local_rotation"], na["global_trans"]],
+                            [torch.from_numpy(ora_grads["local_rotation"]).double(), torch.from_numpy(ora_grads["global_trans"]).double()])
+    ref_pose = [p.grad for p in sw64.pose_net.parameters()]
+    tot = max(float(g.abs().max()) for g in ref_pose)
+    for k, (g, h) in enumerate(zip(ref_pose, hip_pose_grads)):
+        e = float((g - h.double().cpu()).abs().max())
+        U.STATS.append((tag + " full size dL/d_pose_net[%d]" % k, int(h.numel()), 0.0, e / tot, 0.0))
+        assert e <= RADIUS_TOL * tot, (tag, "pose_net", k, e / tot)
+    return so.R
 
 
 def test_c4_full_size_pipeline_parity_vs_oracle():
@@ -228,4 +265,4 @@ def test_c5_full_size_properties_and_memory():
     # 64 joints do not fit the one-launch PoseMLP (4 * 64 + 3 > 256 outputs): the layered kernels ran; LBS walked 63 bones
     assert dv["d_nodes"].shape == (64, 3)
     peak = torch.cuda.max_memory_allocated() / 2 ** 30
-    assert peak < 16.0, "C5 peak memory %.1f GiB" % peak
+    assert peak < 20.0, "C5 peak memory %.1f GiB" % peak  # (7 % of the 288 GB; two forward states of ~7 GB each are alive at the peak of the property checks)

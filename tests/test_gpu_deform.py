@@ -278,3 +278,65 @@ def test_pose_mlp_status_word_is_clean_after_normal_steps_and_raises_when_set():
     with pytest.raises(L.RiggsHipError, match="timed out"):
         sw.pose_net.check_status()
     sw.pose_net.check_status()  # cleared by the raise
+
+
+def test_a_lost_handoff_surfaces_through_check_before_anything_is_exchanged_or_stepped():
+    """The one-launch PoseMLP kernels hand data between workgroups with bounded spins.  When a workgroup's hand-off never
+    arrives — on a GPU shared with long kernels of another stream, e.g. the collectives of an overlapped exchange, a workgroup
+    may not become resident in time — the spin times out: the pose is poisoned with NaN and a sticky status word is set.
+    Forced here through the library's test hook (one workgroup keeps a layer's hand-off to itself), in the forward and in the
+    backward launch of a frame captured as two graphs the way the overlapped exchanges use it: GraphedFrame.check() raises
+    BEFORE the caller exchanges or steps, the step is discarded, and the next replay is clean and equal to the first one.
+    Then the same replay with a long kernel running on a side stream during the deformation backward: either it completes with
+    the same gradients, or it is reported the same way — never silently wrong."""
+    import bench
+    from riggs_amd import _lib as L
+    from riggs_amd.graph import GraphedFrame
+    old = dict(bench.WORKLOAD)
+    bench.WORKLOAD.update(N=20000, J=24, H=128, W=128)
+    try:
+        sc, cam, gm, sw = bench.build_workload(0, "cuda:0")
+    finally:
+        bench.WORKLOAD.clear()
+        bench.WORKLOAD.update(old)
+    params = bench.params_of(gm, sw)
+    gf = GraphedFrame(gm, sw, cam, torch.zeros(3, device="cuda"), params, split_backward=True).capture()
+    gf.set_inputs(gimg=torch.rand(3, 128, 128, generator=torch.Generator().manual_seed(5)).cuda() / (3 * 128 * 128))
+
+    def replay():
+        gf.run_a()
+        gf.run_b()
+        torch.cuda.synchronize()
+        return [p.grad.detach().clone() for p in params]
+
+    ref = replay()
+    gf.check()
+    assert all(torch.isfinite(g).all() for g in ref)
+    pn = sw.pose_net
+    word = int(L.lib().riggs_pose_mlp_status_word(len(pn.net), pn.net[0].out_features))
+    for bit in (1, 2):                       # forward launch, backward launch
+        pn._hip_sync[word + 1] = bit
+        bad = replay()                       # (returns after the bounded spins: a fraction of a second)
+        pn._hip_sync[word + 1] = 0
+        with pytest.raises(L.RiggsHipError, match="PoseMLP"):
+            gf.check()                       # <- the caller's gate in front of the exchange / the optimizer
+        assert not all(torch.isfinite(g).all() for g in bad)   # that step's skeleton gradients are NaN: it must be dropped
+        again = replay()
+        gf.check()                           # the status was cleared by the raise; this replay is clean ...
+        for a, b in zip(again, ref):
+            assert float((a - b).abs().max()) <= 1e-5 * max(1e-12, float(b.abs().max()))   # ... and equal to the first one
+    # a long kernel on a side stream while graph (b) — FK backward, PoseMLP backward — runs
+    side = torch.cuda.Stream()
+    big = torch.randn(8192, 8192, device="cuda")
+    gf.run_a()
+    with torch.cuda.stream(side):
+        for _ in range(6):
+            big = torch.tanh(big @ big * 1e-4)
+    gf.run_b()
+    torch.cuda.synchronize()
+    try:
+        gf.check()
+        for p, b in zip(params, ref):
+            assert float((p.grad - b).abs().max()) <= 1e-5 * max(1e-12, float(b.abs().max()))
+    except L.RiggsHipError:
+        pass  # reported: the caller drops the step

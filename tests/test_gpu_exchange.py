@@ -111,6 +111,18 @@ def test_unpack_skips_everything_when_a_segment_overflowed(frames):
     assert not ex.check() and ex.need >= max(need) - 120        # (need counts listed rows; the numpy list is the non-zero ones)
     for a, b in zip(local, frames[0][0]):
         assert torch.equal(a, b)
+    # the status is STICKY: an overflow on step k is still reported when the caller polls on step k + n, together with the step
+    # that failed first; reading clears it
+    assert ex.check() and ex.calls == 0
+    ex._unpack(ex)                                               # step 1: overflows (the same segments)
+    ok = SparseRowExchange([g.clone() for g in frames[0][0]], capacity=N, world=WORLD)
+    ok.status = ex.status                                        # (same status words: the steps of one exchange)
+    ok.gathered.copy_(torch.cat([f[1] for f in frames]))
+    ok._unpack(ok)                                               # steps 2, 3: fit
+    ok._unpack(ok)
+    torch.cuda.synchronize()
+    assert not ex.check() and ex.calls == 3 and ex.overflow_call == 1 and ex.need >= max(need) - 120
+    assert ex.check() and ex.calls == 0 and ex.overflow_call == 0
 
 
 def test_pack_into_a_small_capacity_reports_the_need_and_keeps_the_first_rows(frames):
@@ -157,6 +169,8 @@ def test_row_exchange_around_a_split_captured_frame_is_the_identity_at_world_one
         gf = GraphedFrame(gm, sw, cam, torch.zeros(3, device="cuda"), bench.params_of(gm, sw), split_backward=True)
         gf.after_raster_backward = rows.pack
         gf.capture()
+        with pytest.raises(RuntimeError, match="captured"):      # the captured pack has the old segment baked in
+            rows.resize(100)
         gf.set_inputs(gimg=torch.rand(3, H, W, generator=torch.Generator().manual_seed(3)).cuda())
         for cam_az in (45.0, 160.0):
             gf.run_a(cam=synth.look_at_camera(H, W, azimuth_deg=cam_az).to("cuda:0"))
