@@ -251,7 +251,8 @@ def test_bench_contract_single_and_two_ranks():
     assert d["train_step"]["value"] > 0
     assert d["cpu_baseline"]["c1_10k_chain8_256"]["ms_median"] > 0 and d["cpu_baseline"]["cpu_model"]
     # the timed frame was checked against the CPU oracle at the bench size (bench.py exits non-zero beyond the bar)
-    assert d["parity_at_bench_size"]["worst_outlier_frac"] <= 2e-3 and "image" in d["parity_at_bench_size"]
+    assert d["parity_at_bench_size"]["worst_outlier_frac"] <= 5e-5 and "image" in d["parity_at_bench_size"]
+    assert d["parity_at_bench_size"]["dL/d_pose_net"]["max_rel"] <= 1e-4 and d["parity_at_bench_size"]["worst_small_tensor_max_rel"] <= 1e-4
     assert d["roofline"]["bound"] in ("valu", "hbm") and 0 < d["dense_gradient_scene"]["gaussians_with_gradient"] <= 1
     env["RIGGS_BENCH_BACKEND"] = "gloo"
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",

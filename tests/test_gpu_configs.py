@@ -68,7 +68,7 @@ def test_c4_full_size_properties():
     assert R > 2_000_000 and vis > 0.9 * N
 
 
-PIPE_FRAC = 5e-4     # per tensor: share of the elements allowed beyond 1e-4 of max|oracle| (observed worst: 1.1e-4)
+PIPE_FRAC = 5e-5     # per tensor: share of the elements allowed beyond 1e-4 of max|oracle| (observed worst: 3.3e-6, one element of C3)
 RADIUS_TOL = 1e-4    # dL/d node_radius (J sums over all Gaussians), relative to its largest entry
 
 
