@@ -207,6 +207,58 @@ def dense_scene_timing(dev, steps=50):
             "what": "same path / sizes / camera, thin opaque skin around the bones (synth.make_surface_scene); not the headline metric"}
 
 
+def cycling_cameras_timing(dev, steps=64, n_cams=8):
+    """Secondary number (NOT the metric): the headline workload replayed the way a trainer uses it — a different camera every
+    iteration (train_rig.py:389 draws a random one): ``n_cams`` cameras on a circle around the subject, rotated through the
+    captured frame's static inputs (GraphedFrame.set_inputs: four small device-to-device copies per replay).  The headline
+    replays ONE camera, the best case of the sparse gradient rows (previous | current rows = current rows); here the union
+    is real.  Reports ms per step, the share of the Gaussians with a gradient in a frame, the share of rows rewritten
+    (previous | current), and how many of the frames overflowed the instance arena (sized from the warm-up frame x 1.5)."""
+    from riggs_amd import _lib as L
+    from riggs_amd import synth
+    from riggs_amd.graph import GraphedFrame
+    w = WORKLOAD
+    sc, cam0, gm, sw = build_workload(0, dev)
+    cams = [synth.look_at_camera(w["H"], w["W"], azimuth_deg=360.0 * k / n_cams, fid=0.1 + 0.8 * k / n_cams).to(dev) for k in range(n_cams)]
+    params = params_of(gm, sw)
+    gf = GraphedFrame(gm, sw, cams[0], torch.zeros(3, device=dev), params, sparse_grad_rows=True).capture()
+    g = torch.Generator().manual_seed(w["seed"] + 7)
+    gf.set_inputs(gimg=(torch.sign(torch.rand(3, w["H"], w["W"], generator=g) - 0.5) / (3 * w["H"] * w["W"])).to(dev))
+    # untimed pass: per frame the rows with a gradient, the union with the previous frame's, the arena
+    import ctypes as C
+    off, nb = C.c_size_t(), C.c_size_t()
+    L.lib().riggs_raster_backward_workspace_rows(w["N"], C.byref(off), C.byref(nb))
+    bits_of = lambda: gf.backward_workspace[off.value:off.value + nb.value].clone()  # noqa: E731
+    import numpy as np
+    pop = lambda b: int(np.unpackbits(b.cpu().numpy()).sum())  # noqa: E731
+    cur_frac, union_frac, overflows, prev = [], [], 0, None
+    for k in range(2 * n_cams):
+        gf.run(cam=cams[k % n_cams])
+        torch.cuda.synchronize()
+        try:
+            gf.check()
+        except L.RiggsHipError:
+            overflows += 1
+        b = bits_of()
+        if k >= n_cams:
+            cur_frac.append(pop(b) / w["N"])
+            union_frac.append(pop(b | prev) / w["N"])
+        prev = b
+    for k in range(n_cams):
+        gf.run(cam=cams[k % n_cams])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        gf.run(cam=cams[k % n_cams])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(1.0 / dt, 2), "unit": "iters/s", "ms_per_step": round(dt * 1e3, 4), "cameras": n_cams,
+            "gaussians_with_gradient": round(sum(cur_frac) / len(cur_frac), 4),
+            "gradient_rows_rewritten": round(sum(union_frac) / len(union_frac), 4), "arena_overflows": overflows,
+            "what": "same workload, %d cameras on a circle rotating through one captured frame (a new camera and time every replay); "
+                    "not the headline metric" % n_cams}
+
+
 def _oracle_iteration(sc, cam_cpu, gimg_cpu, pose=None, deformed=None, want_saved=False):
     """One iteration of the CPU oracle (torch-CPU deform restatement + C/OpenMP rasterizer, fwd + bwd) on a scene; returns
     (image, gradient dict, R).  ``pose`` = (local_rotation, global_trans) replaces the scene's own pose.
@@ -749,6 +801,7 @@ def main():
             out["mlp_heads"] = heads_timing(sc, gm)
             out["next_rows"] = next_rows_timing(sc, gm, cam)
             out["dense_gradient_scene"] = dense_scene_timing(dev)
+            out["cycling_cameras"] = cycling_cameras_timing(dev)
         if not args.no_cpu_baseline and world == 1:  # (the CPU baseline is an N = 1 measurement)
             out["cpu_baseline"], ora_image, ora_grads = cpu_baseline(sc, cam.to("cpu"), gimg.cpu(), hip_pose, hip_deformed)
             out["parity_at_bench_size"] = parity_at_bench_size(hip_image, hip_grads, ora_image, ora_grads, sw_snapshot, hip_pose_grads, cam.fid)

@@ -14,6 +14,7 @@ namespace riggs {
 
 #define PM_MAX_LAYERS 12
 #define PM_MAX_W 256
+#define PM_MAX_HEAD 320  // rows of the two heads together (4 J + 3): J <= 79 in the one-launch kernels
 #define PM_MAX_IN 320
 #define PM_MAX_EMB 64
 #define PM_RPW 8       // rows per wave per pass (forward GEMV)
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_forward_fused_kernel(PoseMl
     __shared__ float s_t[32][33];
     const int emb_ = 1 + 2 * d.multires;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 16
-    const int tiles_per = (PM_MAX_W / 32) * (PM_MAX_W / 32);
+    const int tiles_per = (PM_MAX_HEAD / 32) * (PM_MAX_W / 32);  // (rows: up to PM_MAX_HEAD for the heads) x (columns)
     for (int tile = blockIdx.x - n_chain; tile < d.depth * tiles_per; tile += gridDim.x - n_chain) {
       const int l = 1 + tile / tiles_per, tt = tile % tiles_per;
       const int r0 = (tt / (PM_MAX_W / 32)) * 32, c0 = (tt % (PM_MAX_W / 32)) * 32;
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_forward_fused_kernel(PoseMl
       __syncthreads();
 #pragma unroll
       for (int h = 0; h < 2; h++)
-        wt[((size_t)(l - 1) * PM_MAX_W + c0 + ty + 16 * h) * PM_MAX_W + r0 + tx] = s_t[tx][ty + 16 * h];
+        wt[((size_t)(l - 1) * PM_MAX_W + c0 + ty + 16 * h) * PM_MAX_HEAD + r0 + tx] = s_t[tx][ty + 16 * h];
       __syncthreads();
     }
     return;
@@ -333,9 +334,12 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_forward_fused_kernel(PoseMl
   const bool fault = sticky != nullptr && blockIdx.x == 1 && (sticky[1] & PM_FAULT_BIT) != 0u;
   PM_TRACE(0);
   __syncthreads();
+  // (4 J + 3 > width, e.g. 64 joints: the head rows beyond `width` live in workgroups of their own, which only take part in
+  // the last stage)
+  const bool extra = (int)(blockIdx.x * PMF_WAVES) >= d.width;
 #pragma unroll
   for (int l = 0; l <= PM_MAX_LAYERS; l++) {
-    if (l <= d.depth) {
+    if (l <= d.depth && !(extra && l < d.depth)) {
       const bool heads = (l == d.depth);
       const int n_out = heads ? d.n_rot + 3 : d.width;
       const int in_dim = pm_in_dim(d, l, emb);
@@ -406,10 +410,11 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_backward_fused_kernel(PoseM
                                                                            uint32_t* sticky, uint32_t* gen, float* __restrict__ flat,
                                                                            const float* __restrict__ wt,
                                                                            unsigned long long* trace) {
-  __shared__ float s_v[PM_MAX_W];
+  __shared__ float s_v[PM_MAX_HEAD];
   __shared__ int s_failed;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = blockIdx.x * PMF_WAVES + wave;
+  const bool extra = (int)(blockIdx.x * PMF_WAVES) >= d.width;  // (head rows beyond `width`: only the weight-gradient rows of the heads)
   const int emb = 1 + 2 * d.multires;
   const int n_head = d.n_rot + 3;
   const uint32_t tag0 = __hip_atomic_load((__attribute__((address_space(1))) uint32_t*)gen, __ATOMIC_RELAXED,
@@ -418,18 +423,20 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_backward_fused_kernel(PoseM
   // `wt` (one coalesced 1 KB row per matrix), and the forward activations (8 KB) into LDS: no global load
   // is left on the chain or in the weight-gradient rows
   float wc[PM_MAX_LAYERS + 1][4];
+  float wc_head = 0.f;
 #pragma unroll
   for (int l = 1; l <= PM_MAX_LAYERS; l++) {
 #pragma unroll
     for (int k = 0; k < 4; k++) wc[l][k] = 0.f;
     if (l <= d.depth && col < d.width) {
       const int n_rows = (l == d.depth) ? n_head : d.width;
-      const float* rp = wt + ((size_t)(l - 1) * PM_MAX_W + col) * PM_MAX_W;
+      const float* rp = wt + ((size_t)(l - 1) * PM_MAX_W + col) * PM_MAX_HEAD;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const int r = lane + 64 * k;
         if (r < n_rows) wc[l][k] = rp[r];
       }
+      if (l == d.depth && lane + 256 < n_rows) wc_head = rp[lane + 256];  // (head rows 256 ..)
     }
   }
   __shared__ float s_acts[PM_MAX_EMB + PM_MAX_LAYERS * PM_MAX_W];
@@ -444,7 +451,7 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_backward_fused_kernel(PoseM
   PM_TRACE(1);
 #pragma unroll
   for (int l = PM_MAX_LAYERS; l >= 0; l--) {
-    if (l <= d.depth) {
+    if (l <= d.depth && !(extra && l < d.depth)) {
       const bool heads = (l == d.depth);
       const int n_rows = heads ? n_head : d.width;
       const int in_dim = pm_in_dim(d, l, emb);
@@ -452,9 +459,9 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_backward_fused_kernel(PoseM
       if (wave == 0) {
         if (heads) {
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
+          for (int k = 0; k < PM_MAX_HEAD / 64; k++) {
             const int r = lane + 64 * k;
-            if (r < PM_MAX_W) s_v[r] = (r < d.n_rot) ? g_rot[r] : (r < n_head ? g_tr[r - d.n_rot] : 0.f);
+            s_v[r] = (r < d.n_rot) ? g_rot[r] : (r < n_head ? g_tr[r - d.n_rot] : 0.f);
           }
         } else {
           float h[4];
@@ -479,6 +486,7 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_backward_fused_kernel(PoseM
       float sv[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) sv[k] = s_v[lane + 64 * k];
+      const float sv_head = heads ? s_v[lane + 256] : 0.f;
       float vr = (col < n_rows) ? s_v[col] : 0.f;
       if (s_failed) vr = __builtin_nanf("");
       __syncthreads();  // s_v may be rewritten by wave 0 from here on
@@ -490,6 +498,7 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_backward_fused_kernel(PoseM
           const int r = lane + 64 * k;
           if (r < n_rows) acc += wc[l][k] * sv[k];
         }
+        if (heads && lane + 256 < n_rows) acc += wc_head * sv_head;
         acc = wave_sum(acc);
         if (lane == 63 && col < d.width && !(fault && l == 2)) pm_store_granule(gran + (size_t)(l - 1) * d.width + col, tag0 + (uint32_t)l, acc);
       }
@@ -548,7 +557,7 @@ static int pm_fill(PoseMlpDesc& d, int32_t depth, int32_t width, int32_t multire
   RIGGS_REQUIRE(depth >= 1 && depth <= PM_MAX_LAYERS, "PoseMLP depth out of range");
   RIGGS_REQUIRE(width >= 1 && width <= PM_MAX_W, "PoseMLP width must be <= 256");
   RIGGS_REQUIRE(multires >= 0 && 1 + 2 * multires <= PM_MAX_EMB, "PoseMLP multires out of range");
-  RIGGS_REQUIRE(n_rot >= 1 && n_rot <= 4 * 64, "PoseMLP rotation head too wide");
+  RIGGS_REQUIRE(n_rot >= 1 && n_rot + 3 <= PM_MAX_HEAD, "PoseMLP rotation head too wide");
   d.depth = depth; d.width = width; d.multires = multires; d.skip = skip; d.n_rot = n_rot;
   for (int l = 0; l < depth; l++) { d.W[l] = weights[l]; d.b[l] = biases[l]; }
   d.W_rot = W_rot; d.b_rot = b_rot; d.W_tr = W_tr; d.b_tr = b_tr;
@@ -558,8 +567,13 @@ static int pm_fill(PoseMlpDesc& d, int32_t depth, int32_t width, int32_t multire
 static unsigned long long* g_pm_trace = nullptr;  // 128 u64: forward stamps [0,64), backward stamps [64,128)
 int riggs_pose_mlp_set_trace(void* dev_u64x128) { g_pm_trace = (unsigned long long*)dev_u64x128; return 0; }
 
-// The one-launch kernels need the rotation + translation head to fit one layer's width (n_rot + 3 <= width: up to 63
-// joints at width 256); wider heads (64 joints) and narrow test networks run one launch per layer.
+// The one-launch kernels take the rotation + translation head when it fits one layer's width (n_rot + 3 <= width: up to 63
+// joints at width 256) or, for the networks the reference builds (width >= 128), up to PM_MAX_HEAD rows (79 joints: the
+// rows beyond `width` get workgroups of their own that join for the last stage — C5's 64 joints are 259 rows); narrow
+// test networks with wide heads and anything larger run one launch per layer.
+static bool pm_one_launch(int32_t width, int32_t n_rot) {
+  return n_rot + 3 <= width || (width >= 128 && n_rot + 3 <= PM_MAX_HEAD);
+}
 // acts: activations, then (256-byte aligned) the state of the one-launch kernels:
 //   [forward granules + gen (used when the caller passes no persistent sync_state) | err, gen, pad, pad | backward granules]
 static size_t pm_acts_core(int32_t depth, int32_t width, int32_t multires) {
@@ -574,7 +588,7 @@ size_t riggs_pose_mlp_sync_bytes(int32_t depth, int32_t width) { return pm_sync_
 size_t riggs_pose_mlp_status_word(int32_t depth, int32_t width) { return 2 * (size_t)depth * width + 1; }
 // ... then the transposed consumer matrices (depth x 256 x 256) the forward launch prepares for the backward
 size_t riggs_pose_mlp_acts_floats(int32_t depth, int32_t width, int32_t multires) {
-  return pm_acts_core(depth, width, multires) + 2 * pm_sync_floats(depth, width) + (size_t)depth * PM_MAX_W * PM_MAX_W;
+  return pm_acts_core(depth, width, multires) + 2 * pm_sync_floats(depth, width) + (size_t)depth * PM_MAX_W * PM_MAX_HEAD;
 }
 
 int riggs_pose_mlp_forward(int32_t depth, int32_t width, int32_t multires, int32_t skip, int32_t n_rot,
@@ -587,7 +601,7 @@ int riggs_pose_mlp_forward(int32_t depth, int32_t width, int32_t multires, int32
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(PROF_POSE_FWD, s);
-  if (n_rot + 3 <= width) {
+  if (pm_one_launch(width, n_rot)) {
     const size_t sf = pm_sync_floats(depth, width);
     float* own = acts + pm_acts_core(depth, width, multires);  // [own forward state | backward state]
     float* fs = (float*)sync_state;
@@ -596,7 +610,7 @@ int riggs_pose_mlp_forward(int32_t depth, int32_t width, int32_t multires, int32
       fs = own;
       RIGGS_HIP_CHECK(hipMemsetAsync(fs, 0, sf * sizeof(float), s));
     }
-    const int n_chain = (width + PMF_WAVES - 1) / PMF_WAVES;  // + 64 transposer workgroups on otherwise idle CUs
+    const int n_chain = ((width > n_rot + 3 ? width : n_rot + 3) + PMF_WAVES - 1) / PMF_WAVES;  // + 64 transposer workgroups on otherwise idle CUs
     hipLaunchKernelGGL(pm_forward_fused_kernel, dim3(n_chain + 64), dim3(PMF_WAVES * 64), 0, s, d, t, rot_bias4, acts,
                        (unsigned long long*)fs, (uint32_t*)(fs + 2 * (size_t)depth * width),
                        sync_state ? (uint32_t*)(fs + 2 * (size_t)depth * width) + 1 : nullptr, (uint32_t*)(own + sf), (int)sf,
@@ -651,9 +665,9 @@ int riggs_pose_mlp_backward(int32_t depth, int32_t width, int32_t multires, int3
   g.row_start[depth + 1] = rows; rows += 3;
   g.row_start[depth + 2] = rows;
   ProfScope ps(PROF_POSE_BWD, s);
-  if (n_rot + 3 <= width) {
+  if (pm_one_launch(width, n_rot)) {
     float* tail = acts + pm_acts_core(depth, width, multires) + pm_sync_floats(depth, width);
-    const int nr = width;
+    const int nr = width > n_rot + 3 ? width : n_rot + 3;
     hipLaunchKernelGGL(pm_backward_fused_kernel, dim3((nr + PMF_WAVES - 1) / PMF_WAVES), dim3(PMF_WAVES * 64), 0, s, d, g,
                        acts, g_rotation, g_translation, (unsigned long long*)(tail + 4), (uint32_t*)tail,
                        sync_state ? (uint32_t*)sync_state + 2 * (size_t)depth * width + 1 : nullptr,

@@ -171,6 +171,31 @@ class GraphedFrame:
             self.reset_sparse_rows()
         return self
 
+    def recapture(self, params=None, warmup: int = 1):
+        """After densification / pruning replaced the Gaussians' parameter tensors (a new N: scene/gaussian_model.py:445-514,
+        every ``densification_interval`` iterations in train_rig.py:317-365): everything a captured graph has baked in — the
+        graphs themselves, the instance arena and its capacity, the gradient buffers, the private gradient bucket of the
+        sparse-row mode and that mode's row list — is dropped, the current parameters are picked up (``params``; a
+        ``GraphedTrainStep`` collects them from the models itself) and the frame is captured again (``warmup`` eager frames first:
+        they size the arena for the new N and, for a train step, ARE training iterations).  A data-parallel caller that
+        published a bucket of its own registers a new one for the new tensors before calling this."""
+        self.graph = None
+        if self.split:
+            self.graph_b = None
+        self.out = self.grads = None
+        own = getattr(self, "_own_bucket", None)
+        if own is not None:
+            own.unregister()
+            self._own_bucket = None
+        self.sparse_outputs = []
+        self.backward_workspace = None
+        self.arena = RasterArena(growth=self.arena.growth)
+        if params is not None:
+            self.params = list(params)
+        for p in self.params:
+            p.grad = None
+        return self.capture(warmup=warmup)
+
     def mark_all_rows(self):
         """After another writer of the captured gradient buffers (a dense all-reduce in place ...): the next replay rewrites
         every row; the values now in the buffers are kept."""
@@ -290,6 +315,11 @@ class GraphedTrainStep(GraphedFrame):
         if proj is not None:
             out["projection_loss"] = proj.detach()
         return RenderPkg(out, cache=False)
+
+    def recapture(self, params=None, warmup: int = 1):
+        if params is None:
+            params = self.gm.parameters() + [p for g in self.sw.trainable_parameters() for p in g["params"]]
+        return super().recapture(params, warmup)
 
     def run(self, cam: Camera = None, gt_image: torch.Tensor = None, thinned: torch.Tensor = None,
             projection_weight=None):

@@ -228,6 +228,102 @@ def test_graphed_train_step_matches_eager_iterations(sparse_rows):
         bench.WORKLOAD.update(old)
 
 
+def test_graphed_train_step_survives_densification_by_recapture():
+    """The reference changes N every densification_interval iterations (scene/gaussian_model.py:445-514: clone / split /
+    prune, each replacing the parameter tensors and moving the optimizer state with cat_tensors_to_optimizer /
+    _prune_optimizer).  A captured iteration has N, the arena capacity and the gradient buffers baked in:
+    GraphedTrainStep.recapture() drops them and captures again over the new tensors.  Here: two replays, a densify-style
+    change of N (clone 400 Gaussians, prune 300, optimizer state moved the way the reference's surgery moves it), recapture,
+    two more iterations — against the same iterations issued eagerly with torch.optim.Adam from the same state."""
+    import copy
+    from types import SimpleNamespace
+
+    import bench
+    from riggs_amd.graph import GraphedTrainStep
+    from riggs_amd.loss import l1_loss, ssim
+    from riggs_amd.optim import FusedAdam
+    from riggs_amd.rasterizer import RasterArena
+    from riggs_amd.render import render
+    old = dict(bench.WORKLOAD)
+    bench.WORKLOAD.update(N=5000, J=8, H=80, W=96)
+    args = SimpleNamespace(percent_dense=0.01, position_lr_init=0.00016, position_lr_final=0.0000016, position_lr_delay_mult=0.01,
+                           position_lr_max_steps=30000, feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.001, rotation_lr=0.001)
+    names = {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity", "scaling": "_scaling",
+             "rotation": "_rotation"}
+
+    def surgery(gm_, keep_idx):
+        """new tensor = old[keep_idx] for every Gaussian parameter; optimizer state follows (the reference's
+        cat_tensors_to_optimizer + _prune_optimizer in one index_select)"""
+        for group in gm_.optimizer.param_groups:
+            old_p = group["params"][0]
+            st = gm_.optimizer.state.pop(old_p, None)
+            new_p = torch.nn.Parameter(old_p.detach()[keep_idx].contiguous().requires_grad_(True))
+            if st is not None:
+                st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"][keep_idx].contiguous(), st["exp_avg_sq"][keep_idx].contiguous()
+                gm_.optimizer.state[new_p] = st
+            group["params"][0] = new_p
+            setattr(gm_, names[group["name"]], new_p)
+        n = keep_idx.numel()
+        gm_.xyz_gradient_accum = torch.zeros((n, 1), device="cuda")
+        gm_.denom = torch.zeros((n, 1), device="cuda")
+        gm_.max_radii2D = torch.zeros(n, device="cuda")
+    try:
+        sc, cam, gm, sw = bench.build_workload(0, "cuda:0")
+        gt = torch.rand(3, 80, 96, generator=torch.Generator().manual_seed(2)).cuda()
+        bg = torch.zeros(3, device="cuda")
+        gm.training_setup(args, capturable=True)
+        sk_opt = FusedAdam([{"params": g["params"], "lr": 5e-4, "name": g["name"]} for g in sw.trainable_parameters()],
+                           lr=0.0, eps=1e-15, capturable=True)
+        gts = GraphedTrainStep(gm, sw, cam, bg, gt, [gm.optimizer, sk_opt], lambda_dssim=0.2, sparse_grad_rows=True)
+        gts.capture(warmup=1)
+        gts.run(), gts.run()
+        gts.check()
+        torch.cuda.synchronize()
+        # ---- densify-style change of N: clone the first 400, prune the last 300
+        N0 = gm.get_xyz.shape[0]
+        keep = torch.cat([torch.arange(N0 - 300), torch.arange(400)]).cuda()
+        surgery(gm, keep)
+        N1 = gm.get_xyz.shape[0]
+        assert N1 == N0 + 100
+        # the eager reference starts from the very same state
+        gm2, sw2 = copy.deepcopy(gm), copy.deepcopy(sw)
+        gm2.optimizer = None
+        opt_g = torch.optim.Adam([{"params": [getattr(gm2, names[g["name"]])], "lr": float(g["lr"]), "name": g["name"]}
+                                  for g in gm.optimizer.param_groups], lr=0.0, eps=1e-15)
+        for g, g2 in zip(gm.optimizer.param_groups, opt_g.param_groups):
+            st = gm.optimizer.state[g["params"][0]]
+            opt_g.state[g2["params"][0]] = {"step": torch.tensor(float(st["step"])), "exp_avg": st["exp_avg"].clone(),
+                                            "exp_avg_sq": st["exp_avg_sq"].clone()}
+        opt_s = torch.optim.Adam([{"params": g["params"], "lr": 5e-4} for g in sw2.trainable_parameters()], lr=0.0, eps=1e-15)
+        for (p, p2) in zip([q for g in sw.trainable_parameters() for q in g["params"]], [q for g in sw2.trainable_parameters() for q in g["params"]]):
+            st = sk_opt.state[p]
+            opt_s.state[p2] = {"step": torch.tensor(float(st["step"])), "exp_avg": st["exp_avg"].clone(), "exp_avg_sq": st["exp_avg_sq"].clone()}
+        # ---- graph side: recapture (its one eager warm-up frame is iteration A), then replays B and C
+        gts.recapture(warmup=1)
+        assert gts.out["radii"].shape[0] == N1 and bool(gts.sparse_outputs)
+        losses = [gts.run()["loss"].item(), gts.run()["loss"].item()]
+        gts.check()
+        # ---- eager side: iterations A, B, C
+        ref_losses = []
+        for it in range(3):
+            opt_g.zero_grad(set_to_none=True), opt_s.zero_grad(set_to_none=True)
+            dv = sw2(gm2.get_xyz.detach(), sw2.expand_time(cam.fid), motion_mask=gm2.motion_mask)
+            pkg = render(cam, gm2, bench.Pipe, bg, dv["d_xyz"], dv["d_rotation"], dv["d_scaling"], arena=RasterArena())
+            loss = 0.8 * l1_loss(pkg["render"], gt) + 0.2 * (1.0 - ssim(pkg["render"], gt))
+            loss.backward()
+            opt_g.step(), opt_s.step()
+            ref_losses.append(loss.item())
+        np.testing.assert_allclose(losses, ref_losses[1:], rtol=2e-4)
+        for a, b in zip(gm.parameters(), gm2.parameters()):
+            a, b = a.detach(), b.detach()
+            assert a.shape == b.shape and a.shape[0] == N1
+            bad = (a - b).abs() > 2e-3 * b.abs() + 2e-4 * float(b.abs().max())
+            assert float(bad.float().mean()) <= 1e-3, float(bad.float().mean())
+    finally:
+        bench.WORKLOAD.clear()
+        bench.WORKLOAD.update(old)
+
+
 def test_bench_contract_single_and_two_ranks():
     """bench.py end to end on a tiny scene: the N = 1 JSON line carries every field of the contract (roofline, cpu_baseline,
     train_step), and the 2-rank launch (the driver's torch.distributed.run command line; gloo stands in for RCCL on a

@@ -180,7 +180,7 @@ def test_dense_gradient_scene_full_size_pipeline_parity_vs_oracle():
 
 
 def test_c5_full_size_pipeline_parity_vs_oracle():
-    """C5 at FULL size — 2M Gaussians, 64 joints (the layered PoseMLP kernels: 259 head rows), 1920x1080, R = 38.8 M tile
+    """C5 at FULL size — 2M Gaussians, 64 joints (259 PoseMLP head rows: one launch with an extra workgroup), 1920x1080, R = 38.8 M tile
     instances, the binning walking nine batches per wave — against the CPU oracle (~half a minute on the host)."""
     H, W = 1080, 1920
     assert _pipeline_parity_vs_oracle(2_000_000, 64, H, W, synth.look_at_camera(H, W, fid=0.37), "C5") > 30_000_000
@@ -262,7 +262,8 @@ def test_c5_full_size_properties_and_memory():
     for p in gm.parameters() + [sw._node_radius] + list(sw.pose_net.parameters()):
         assert p.grad is not None and torch.isfinite(p.grad).all()
     assert float(gm._xyz.grad.abs().max()) > 0 and float(sw._node_radius.grad.abs().max()) > 0
-    # 64 joints do not fit the one-launch PoseMLP (4 * 64 + 3 > 256 outputs): the layered kernels ran; LBS walked 63 bones
+    # 64 joints: 4 * 64 + 3 = 259 head rows > width 256 — the one-launch PoseMLP kernels give the three rows beyond the width a
+    # workgroup of their own; LBS walked 63 bones
     assert dv["d_nodes"].shape == (64, 3)
     peak = torch.cuda.max_memory_allocated() / 2 ** 30
     assert peak < 20.0, "C5 peak memory %.1f GiB" % peak  # (7 % of the 288 GB; two forward states of ~7 GB each are alive at the peak of the property checks)
