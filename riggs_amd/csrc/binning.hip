@@ -109,7 +109,8 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(int T, int n_chunks, uin
 // the far segments, the ones a helper can finish before the walker arrives, are taken first (render.hip).
 #define SEG_LMAX 2048  // segment levels with a cursor of their own (deeper ones share the last)
 __device__ void bin_offsets_body(int T, int64_t cap, const uint32_t* __restrict__ tile_count, const BinOut o,
-                                 uint32_t* __restrict__ s_lvl /* LDS, 2 * SEG_LMAX words */) {
+                                 uint32_t* __restrict__ s_lvl /* LDS, 2 * SEG_LMAX words */,
+                                 const uint32_t* __restrict__ total_src = nullptr, int n_total_src = 0) {
   uint2* __restrict__ ranges = o.ranges;
   uint32_t* __restrict__ slot_base = o.slot_base;
   uint32_t* __restrict__ tile_max = o.tile_max;
@@ -171,6 +172,19 @@ __device__ void bin_offsets_body(int T, int64_t cap, const uint32_t* __restrict_
     }
     __syncthreads();
     if (tid == nthr - 1) s_carry = carry + wave_off + v;
+    __syncthreads();
+  }
+  if (total_src) {
+    // (the grouped binning counts only the instances that fit the arena per tile: the true total comes from its group counts)
+    __shared__ uint32_t s_tot;
+    if (tid == 0) s_tot = 0u;
+    __syncthreads();
+    uint32_t part = 0;
+    for (int k = tid; k < n_total_src; k += nthr) part += total_src[k];
+    for (int o2 = 32; o2 > 0; o2 >>= 1) part += (uint32_t)__shfl_xor((int)part, o2);
+    if (lane == 0) atomicAdd(&s_tot, part);
+    __syncthreads();
+    if (tid == 0) s_carry = s_tot;
     __syncthreads();
   }
   if (tid == 0) {
@@ -436,6 +450,278 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(int N, int T, int gri
   }
 }
 
+// =====================================================================================================
+// GROUPED binning for tile grids beyond 25 600 tiles (T > BIN_GROUPED_MIN_T; e.g. 3840 x 2160 = 32 400 tiles), where the
+// direct counting sort above no longer fits: it keeps a cursor per tile and wave in LDS (T x 6 bytes with one wave).  Here
+// the same stable sort runs in TWO levels: (1) by GROUP of 8 horizontally adjacent tiles (cursor tables 8x smaller), writing
+// instance words  gaussian | tile-in-group << 29  into a scratch list (the checkpoint area, which the compositing only fills
+// later); (2) every group's contiguous segment — its tiles' lists back to back — is partitioned stably by the three tile
+// bits, in parts of BIN_PART instances (one workgroup each).  Order: groups by (row, column block) = ascending tile id
+// blocks; inside a group the level-1 order (depth) is kept by both levels: the same list as the direct sort, bit for bit
+// (tests/test_gpu_raster.py: 32 400 tiles against the oracle's key sort).
+// It is NOT faster where both fit (measured at 2 M Gaussians / 8160 tiles / 38.8 M instances: 66 + 30 + 301 + 71 + 329 us
+// against 73 + 20 + 642 us for the direct sort — profiles/round3_C5_grouped_binning_timeline.txt): what bounds either is the
+// 38.8 M scattered 4-byte stores in runs of a few dozen bytes at arbitrary offsets, not the LDS footprint the grouping
+// removes; and the second level's parts are latency chains (a dependent load per 512 instances).  So it only serves the
+// grids the direct sort cannot.
+// =====================================================================================================
+#define BIN_GROUPED_MIN_T 25600
+#define BIN_PART 8192  // instances per workgroup of the second level
+
+__device__ __forceinline__ int grp_of(int x, int y, int gxg) { return y * gxg + (x >> 3); }
+
+// (1a) per chunk of depth-ordered Gaussians: instances per group; block 0 also clears the per-tile counts of level 2
+__global__ __launch_bounds__(1024) void gbin_count_kernel(int N, int T, int G, int gxg, int g_per_block,
+                                                         const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles,
+                                                         const ushort4* __restrict__ rect, uint32_t* __restrict__ table,
+                                                         uint32_t* __restrict__ tile_count) {
+  extern __shared__ uint32_t s_hist[];  // [G]
+  for (int g = threadIdx.x; g < G; g += blockDim.x) s_hist[g] = 0u;
+  if (blockIdx.x == 0) for (int t = threadIdx.x; t <= T; t += blockDim.x) tile_count[t] = 0u;
+  __syncthreads();
+  const int first = blockIdx.x * g_per_block;
+  const int end = min(N, first + g_per_block);
+  for (int s = first + threadIdx.x; s < end; s += blockDim.x) {
+    const uint32_t g = order[s];
+    if (tiles[g] == 0u) continue;
+    const ushort4 rc = rect[g];
+    for (int y = rc.y; y < rc.w; y++)
+      for (int xg = rc.x >> 3; xg <= (rc.z - 1) >> 3; xg++)
+        atomicAdd(&s_hist[y * gxg + xg], (uint32_t)(min((int)rc.z, xg * 8 + 8) - max((int)rc.x, xg * 8)));
+  }
+  __syncthreads();
+  uint32_t* row = table + (size_t)blockIdx.x * G;
+  for (int g = threadIdx.x; g < G; g += blockDim.x) row[g] = s_hist[g];
+}
+
+// (1b) ordered scatter into the groups' segments.  LDS: s_base[G] + per-wave cursors [W][Gpad] (u16, packed pairs while counting)
+__global__ __launch_bounds__(1024) void gbin_scatter_kernel(int N, int G, int gxg, int64_t cap, int g_per_block, int g_per_wave,
+                                                           const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles,
+                                                           const ushort4* __restrict__ rect, const uint32_t* __restrict__ table,
+                                                           const uint32_t* __restrict__ group_count, uint32_t* __restrict__ inter) {
+  extern __shared__ uint32_t s_mem[];
+  const int W = blockDim.x >> 6;
+  uint32_t* s_base = s_mem;
+  const int Gpad = (G + 1) & ~1;
+  unsigned short* s_rel = reinterpret_cast<unsigned short*>(s_mem + G);
+  uint32_t* s_rel32 = s_mem + G;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < W * (Gpad >> 1); e += blockDim.x) s_rel32[e] = 0u;
+  __syncthreads();
+  const int first = blockIdx.x * g_per_block + wave * g_per_wave;
+  const int end = min(N, min(first + g_per_wave, (blockIdx.x + 1) * g_per_block));
+  // (i) per-wave group histogram
+  for (int s0 = first; s0 < end; s0 += 64) {
+    const int s = s0 + lane;
+    if (s < end) {
+      const uint32_t g = order[s];
+      if (tiles[g]) {
+        const ushort4 rc = rect[g];
+        uint32_t* hist = s_rel32 + (size_t)wave * (Gpad >> 1);
+        for (int y = rc.y; y < rc.w; y++)
+          for (int xg = rc.x >> 3; xg <= (rc.z - 1) >> 3; xg++) {
+            const int gi = y * gxg + xg;
+            atomicAdd(&hist[gi >> 1], (uint32_t)(min((int)rc.z, xg * 8 + 8) - max((int)rc.x, xg * 8)) << (16 * (gi & 1)));
+          }
+      }
+    }
+  }
+  __syncthreads();
+  // (ii) start of this chunk's run in every group's segment: exclusive scan of the group counts + the earlier chunks
+  const uint32_t* row = table + (size_t)blockIdx.x * G;
+  {
+    __shared__ uint32_t s_wsum[16];
+    __shared__ uint32_t s_run;
+    if (tid == 0) s_run = 0u;
+    __syncthreads();
+    for (int base = 0; base < G; base += blockDim.x) {
+      const int g = base + tid;
+      const uint32_t c = (g < G) ? group_count[g] : 0u;
+      uint32_t v = c;
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u = (uint32_t)__shfl_up((int)v, o);
+        if (lane >= o) v += u;
+      }
+      if (lane == 63) s_wsum[wave] = v;
+      __syncthreads();
+      uint32_t off = s_run;
+      for (int w = 0; w < wave; w++) off += s_wsum[w];
+      if (g < G) s_base[g] = off + v - c + row[g];
+      __syncthreads();
+      if (tid == (int)blockDim.x - 1) s_run = off + v;
+      __syncthreads();
+    }
+  }
+  for (int g = tid; g < G; g += blockDim.x) {
+    uint32_t run = 0;
+    for (int w = 0; w < W; w++) {
+      const unsigned short c = s_rel[(size_t)w * Gpad + g];
+      s_rel[(size_t)w * Gpad + g] = (unsigned short)run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  // (iii) ordered walk: one Gaussian per step, lanes = the tiles of its rectangle (row-major).  A tile's place = the group's
+  // cursor + its rank inside the Gaussian's span of that group in that tile row; the span's last tile advances the cursor.
+  unsigned short* cur = s_rel + (size_t)wave * Gpad;
+  for (int s0 = first; s0 < end; s0 += 64) {
+    const int s = s0 + lane;
+    uint32_t my_g = 0u, my_n = 0u;
+    int pk_xy = 0, pk_zw = 0;
+    if (s < end) {
+      my_g = order[s];
+      my_n = tiles[my_g];
+      if (my_n) { const ushort4 rc = rect[my_g]; pk_xy = (int)rc.x | ((int)rc.y << 16); pk_zw = (int)rc.z | ((int)rc.w << 16); }
+    }
+    uint64_t live = __builtin_amdgcn_ballot_w64(my_n != 0u);
+    while (live) {
+      const int src = __builtin_ctzll(live);
+      live &= live - 1ull;
+      const int n = __builtin_amdgcn_readlane((int)my_n, src);
+      const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)my_g, src);
+      const int r0 = __builtin_amdgcn_readlane(pk_xy, src), r1 = __builtin_amdgcn_readlane(pk_zw, src);
+      const int rx0 = r0 & 0xFFFF, ry0 = (int)((uint32_t)r0 >> 16), rx1 = r1 & 0xFFFF;
+      const int w = rx1 - rx0;
+      const float rw = __builtin_amdgcn_rcpf((float)w);
+      for (int l = lane; l < n; l += 64) {
+        const int ry = (int)(((float)l + 0.5f) * rw);  // (as rect_tile)
+        const int x = rx0 + (l - ry * w), y = ry0 + ry;
+        const int gi = grp_of(x, y, gxg);
+        const int span0 = max(rx0, (x >> 3) << 3), span1 = min(rx1, ((x >> 3) << 3) + 8);
+        const unsigned short rel = cur[gi];
+        if (x == span1 - 1) cur[gi] = (unsigned short)(rel + (span1 - span0));
+        const int64_t pos = (int64_t)s_base[gi] + rel + (x - span0);
+        if (pos < cap) inter[pos] = g | ((uint32_t)(x & 7) << 29);
+      }
+    }
+  }
+}
+
+// which part of which group is workgroup `b` of the second level?  (every workgroup scans the <= 8192 group counts itself)
+struct GPart { int group; uint32_t first_part; uint32_t start; uint32_t len; uint32_t part; };
+__device__ GPart gbin_find_part(int b, int G, int64_t cap, const uint32_t* __restrict__ group_count) {
+  __shared__ uint32_t s_wc[16], s_wp[16], s_carry_c, s_carry_p;
+  __shared__ GPart s_out;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+  if (tid == 0) { s_carry_c = 0u; s_carry_p = 0u; s_out.group = -1; s_out.first_part = 0u; s_out.start = 0u; s_out.len = 0u; s_out.part = 0u; }
+  __syncthreads();
+  for (int base = 0; base < G; base += nthr) {
+    const int g = base + tid;
+    const uint32_t c = (g < G) ? group_count[g] : 0u;
+    const uint32_t np = (c + BIN_PART - 1) / BIN_PART;
+    uint32_t vc = c, vp = np;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t uc = (uint32_t)__shfl_up((int)vc, o), up = (uint32_t)__shfl_up((int)vp, o);
+      if (lane >= o) { vc += uc; vp += up; }
+    }
+    if (lane == 63) { s_wc[wave] = vc; s_wp[wave] = vp; }
+    __syncthreads();
+    uint32_t oc = s_carry_c, op = s_carry_p;
+    for (int w = 0; w < wave; w++) { oc += s_wc[w]; op += s_wp[w]; }
+    const uint32_t cstart = oc + vc - c, pstart = op + vp - np;
+    if (g < G && (uint32_t)b >= pstart && (uint32_t)b < pstart + np) {
+      const uint32_t part = (uint32_t)b - pstart;
+      const int64_t lo = (int64_t)cstart + (int64_t)part * BIN_PART;
+      const int64_t hi = min((int64_t)cstart + min((int64_t)c, (int64_t)(part + 1) * BIN_PART), cap);
+      s_out.group = g; s_out.first_part = pstart; s_out.part = part;
+      s_out.start = (uint32_t)min(lo, cap); s_out.len = hi > lo ? (uint32_t)(hi - lo) : 0u;
+    }
+    __syncthreads();
+    if (tid == nthr - 1) { s_carry_c = oc + vc; s_carry_p = op + vp; }
+    __syncthreads();
+  }
+  return s_out;
+}
+
+// (2a) per part: instances per tile of the group -> part_hist[part][8]; totals into tile_count
+__global__ __launch_bounds__(512) void gbin_tcount_kernel(int G, int gxg, int grid_x, int64_t cap, const uint32_t* __restrict__ group_count,
+                                                         const uint32_t* __restrict__ inter, uint32_t* __restrict__ part_hist,
+                                                         uint32_t* __restrict__ tile_count) {
+  __shared__ uint32_t s_h[8];
+  const GPart p = gbin_find_part((int)blockIdx.x, G, cap, group_count);
+  if (p.group < 0) return;
+  if (threadIdx.x < 8) s_h[threadIdx.x] = 0u;
+  __syncthreads();
+  uint32_t mine[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  for (uint32_t k = threadIdx.x; k < p.len; k += 512) {
+    const uint32_t c = inter[p.start + k] >> 29;
+#pragma unroll
+    for (int q = 0; q < 8; q++) mine[q] += (c == (uint32_t)q) ? 1u : 0u;
+  }
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    uint32_t v = mine[q];
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_h[q], v);
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    const uint32_t v = s_h[threadIdx.x];
+    part_hist[(size_t)blockIdx.x * 8 + threadIdx.x] = v;
+    const int x = (p.group % gxg) * 8 + (int)threadIdx.x, y = p.group / gxg;
+    if (v && x < grid_x) atomicAdd(&tile_count[y * grid_x + x], v);
+  }
+}
+
+// (2b) per part: stable partition by tile into the final lists; the extra (last) workgroup writes ranges, counters, work lists
+__global__ __launch_bounds__(512) void gbin_tscatter_kernel(int T, int G, int gxg, int grid_x, int64_t cap,
+                                                           const uint32_t* __restrict__ group_count, const uint32_t* __restrict__ inter,
+                                                           const uint32_t* __restrict__ part_hist, const uint32_t* __restrict__ tile_count,
+                                                           uint32_t* __restrict__ point_list, uint32_t* __restrict__ tile_keys,
+                                                           const BinOut out) {
+  extern __shared__ uint32_t s_dyn[];
+  if (blockIdx.x == gridDim.x - 1) {
+    bin_offsets_body(T, cap, tile_count, out, s_dyn, group_count, G);
+    return;
+  }
+  __shared__ uint32_t s_cur[8];
+  __shared__ uint32_t s_wcnt[8][8];  // [wave][tile]
+  const GPart p = gbin_find_part((int)blockIdx.x, G, cap, group_count);
+  if (p.group < 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int gx0 = (p.group % gxg) * 8, gy = p.group / gxg;
+  if (tid < 8) {
+    // start of tile `tid`'s list = start of the group's segment + the group's earlier tiles + this tile's share of the earlier parts
+    uint32_t st = p.start - p.part * BIN_PART;  // (start of the group's segment; the clamp to `cap` only bites on overflow)
+    for (int q = 0; q < tid; q++) { const int x = gx0 + q; if (x < grid_x) st += tile_count[gy * grid_x + x]; }
+    for (uint32_t q = 0; q < p.part; q++) st += part_hist[(size_t)(p.first_part + q) * 8 + tid];
+    s_cur[tid] = st;
+  }
+  if (tid < 64) (&s_wcnt[0][0])[tid] = 0u;
+  __syncthreads();
+  for (uint32_t k0 = 0; k0 < p.len; k0 += 512) {
+    const uint32_t k = k0 + (uint32_t)tid;
+    const bool on = k < p.len;
+    const uint32_t e = on ? inter[p.start + k] : 0u;
+    const int c = (int)(e >> 29);
+    uint64_t same = __builtin_amdgcn_ballot_w64(on);
+#pragma unroll
+    for (int bit = 0; bit < 3; bit++) {
+      const uint64_t vote = __builtin_amdgcn_ballot_w64(on && ((c >> bit) & 1));
+      same &= ((c >> bit) & 1) ? vote : ~vote;
+    }
+    const uint32_t rank = (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull));
+    if (on && rank == 0u) s_wcnt[wave][c] = (uint32_t)__builtin_popcountll(same);  // (the first lane of every tile present; the others stay 0)
+    __syncthreads();
+    uint32_t wbase = 0u;
+    if (on) {
+      for (int w = 0; w < wave; w++) wbase += s_wcnt[w][c];
+      const int64_t pos = (int64_t)s_cur[c] + wbase + rank;
+      if (pos < cap) {
+        point_list[pos] = e & 0x1FFFFFFFu;
+        if (tile_keys) tile_keys[pos] = (uint32_t)(gy * grid_x + gx0 + c);
+      }
+    }
+    __syncthreads();
+    if (tid < 8) {
+      uint32_t tot = 0u;
+      for (int w = 0; w < 8; w++) { tot += s_wcnt[w][tid]; s_wcnt[w][tid] = 0u; }
+      s_cur[tid] += tot;
+    }
+    __syncthreads();
+  }
+}
+
 struct BinPlan { int g_per_block, g_per_wave, threads, n_chunks; size_t lds_scatter; };
 
 static BinPlan bin_plan(int N, int T) {
@@ -460,29 +746,78 @@ static BinPlan bin_plan(int N, int T) {
   return p;
 }
 
-size_t bin_table_bytes(int N, int T) {
+static bool bin_grouped(int T) { return T > BIN_GROUPED_MIN_T; }
+struct GBinPlan { int G, gxg, g_per_block, g_per_wave, n_chunks; size_t lds; };
+static GBinPlan gbin_plan(int N, int T, int grid_x) {
+  GBinPlan p;
+  p.gxg = (grid_x + 7) >> 3;
+  const int grid_y = grid_x > 0 ? (T + grid_x - 1) / grid_x : 0;
+  p.G = p.gxg * grid_y;
+  const int W = 16;
+  // batches of 64 Gaussians per wave so that a launch has <= ~1024 chunks (the chunk x group table and every workgroup's
+  // O(G) set-up stay small)
+  int batches = (int)(((int64_t)N + (int64_t)W * 64 * 1024 - 1) / ((int64_t)W * 64 * 1024));
+  batches = batches < 1 ? 1 : (batches > 16 ? 16 : batches);
+  p.g_per_wave = 64 * batches;
+  p.g_per_block = W * p.g_per_wave;
+  p.n_chunks = (N + p.g_per_block - 1) / p.g_per_block;
+  p.lds = (size_t)p.G * 4 + (size_t)W * ((p.G + 1) & ~1) * 2;
+  return p;
+}
+
+size_t bin_table_bytes(int N, int T, int grid_x) {
+  if (bin_grouped(T)) {
+    GBinPlan p = gbin_plan(N > 0 ? N : 1, T, grid_x);
+    return align_up(((size_t)p.n_chunks + 1) * p.G * 4) + align_up((size_t)(p.G + 1) * 4) + align_up((size_t)(T + 1) * 4);
+  }
   BinPlan p = bin_plan(N > 0 ? N : 1, T);
   return align_up(((size_t)p.n_chunks + 1) * T * 4) + align_up((size_t)(T + 1) * 4);
 }
+size_t bin_scratch_bytes(int64_t cap, int T, int grid_x) {  // (grouped binning: lives in the checkpoint area)
+  if (!bin_grouped(T)) return 0;
+  GBinPlan p = gbin_plan(1, T, grid_x);
+  const size_t c = (size_t)(cap > 0 ? cap : 1);
+  return align_up(c * 4) + align_up((c / BIN_PART + (size_t)p.G + 2) * 8 * 4);
+}
 
 int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order, const uint32_t* tiles,
-                   const ushort4* rect, void* table_mem, uint32_t* point_list, uint32_t* tile_keys, const BinOut& out,
+                   const ushort4* rect, void* table_mem, void* scratch, uint32_t* point_list, uint32_t* tile_keys, const BinOut& out,
                    hipStream_t s) {
-  BinPlan p = bin_plan(N, T);
-  char* mem = (char*)table_mem;
-  uint32_t* table = (uint32_t*)mem;
-  uint32_t* tile_count = (uint32_t*)(mem + align_up(((size_t)p.n_chunks + 1) * T * 4));
   if (T > 65535) { set_error("image too large: %d tiles (the forward's work list packs the tile id into 16 bits)", T); return 2; }
-  if (p.lds_scatter > 150 * 1024) {  // (bin_plan is down to one wave per workgroup: T * 6 bytes of LDS)
-    set_error("image too large: %d tiles, the tile binning holds its per-workgroup tile table in LDS and takes at most 25600 (e.g. 2560 x 2560 px)", T);
-    return 2;
-  }
+  char* mem = (char*)table_mem;
   static bool attr_done = false;
   if (!attr_done) {
     // (dynamic + static LDS <= 160 KB: the kernel also has ~1 KB of static scratch for its scans)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bin_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bin_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gbin_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
     attr_done = true;
+  }
+  if (bin_grouped(T)) {
+    const GBinPlan p = gbin_plan(N, T, grid_x);
+    if (p.lds > 150 * 1024) { set_error("image too large: %d tile groups", p.G); return 2; }
+    uint32_t* table = (uint32_t*)mem;
+    uint32_t* group_count = (uint32_t*)(mem + align_up(((size_t)p.n_chunks + 1) * p.G * 4));
+    uint32_t* tile_count = (uint32_t*)((char*)group_count + align_up((size_t)(p.G + 1) * 4));
+    uint32_t* inter = (uint32_t*)scratch;
+    uint32_t* part_hist = (uint32_t*)((char*)scratch + align_up((size_t)(cap > 0 ? cap : 1) * 4));
+    const unsigned n_parts = (unsigned)((cap > 0 ? cap : 1) / BIN_PART + p.G + 1);
+    hipLaunchKernelGGL(gbin_count_kernel, dim3(p.n_chunks), dim3(1024), (size_t)p.G * 4, s, N, T, p.G, p.gxg, p.g_per_block, order, tiles,
+                       rect, table, tile_count);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3((p.G + 63) / 64), dim3(1024), 0, s, p.G, p.n_chunks, table, group_count);
+    hipLaunchKernelGGL(gbin_scatter_kernel, dim3(p.n_chunks), dim3(1024), p.lds, s, N, p.G, p.gxg, cap, p.g_per_block, p.g_per_wave,
+                       order, tiles, rect, table, group_count, inter);
+    hipLaunchKernelGGL(gbin_tcount_kernel, dim3(n_parts), dim3(512), 0, s, p.G, p.gxg, grid_x, cap, group_count, inter, part_hist, tile_count);
+    hipLaunchKernelGGL(gbin_tscatter_kernel, dim3(n_parts + 1), dim3(512), (size_t)2 * SEG_LMAX * 4, s, T, p.G, p.gxg, grid_x, cap,
+                       group_count, inter, part_hist, tile_count, point_list, tile_keys, out);
+    return 0;
+  }
+  BinPlan p = bin_plan(N, T);
+  uint32_t* table = (uint32_t*)mem;
+  uint32_t* tile_count = (uint32_t*)(mem + align_up(((size_t)p.n_chunks + 1) * T * 4));
+  if (p.lds_scatter > 150 * 1024) {  // (cannot happen: large tile grids take the grouped path)
+    set_error("image too large: %d tiles", T);
+    return 2;
   }
   hipLaunchKernelGGL(bin_count_kernel, dim3(p.n_chunks), dim3(p.threads), (size_t)T * 4, s, N, T, grid_x, p.g_per_block,
                      order, tiles, rect, table);

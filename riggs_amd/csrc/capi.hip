@@ -90,7 +90,7 @@ BinLayout bin_layout(int64_t cap, int N, int H, int W) {
   L.tile_keys = o; o = align_up(o + n * 4);   // per-instance tile id (written with cfg.debug only)
   L.n_slots = (n >> 6) + T + 1;  // tile t, chunk c -> slot (range.x(t) >> 6) + t + c
   L.ckpt = o; o += align_up(L.n_slots * RIGGS_CKPT_FLOATS * 4);
-  L.table = o; o += align_up(bin_table_bytes(N, (int)T));
+  L.table = o; o += align_up(bin_table_bytes(N, (int)T, (W + RIGGS_TILE - 1) / RIGGS_TILE));
   L.work = o; o += align_up(L.n_slots * 16);  // backward work list: 16-byte entry per active chunk
   // forward work list: one entry per (non-empty tile, segment of RIGGS_SEG instances); segment slots (raster_internal.h)
   L.n_seg_slots = seg_slots(cap, T);
@@ -264,7 +264,8 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
     bo.n_seg_slots = (uint32_t)B.n_seg_slots; bo.items_cap = (uint32_t)B.n_items_cap;
     bo.seg_stats = (uint32_t*)(bin + B.seg_stats); bo.helper_budget = (uint32_t)forward_helper_budget();
     int rcb = launch_binning(N, T, gx, cap, (const uint32_t*)(geom + G.order), (const uint32_t*)(geom + G.tiles),
-                             (const ushort4*)(geom + G.rect), bin + B.table, (uint32_t*)(bin + B.point_list),
+                             (const ushort4*)(geom + G.rect), bin + B.table, bin + B.ckpt /* free until the compositing */,
+                             (uint32_t*)(bin + B.point_list),
                              // the per-instance tile id is only a debugging aid here (2M scattered 4-byte stores):
                              // it is implied by `ranges`, so it is written with cfg.debug only
                              cfg->debug ? (uint32_t*)(bin + B.tile_keys) : nullptr, bo, s);

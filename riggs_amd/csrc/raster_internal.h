@@ -124,7 +124,8 @@ int launch_ordered_gather(int N, int n_tiles, int grid_x, int64_t cap, const uin
 size_t depth_sort_table_bytes(int N);
 int launch_depth_sort(int N, const uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_out, void* table_mem,
                       const uint32_t* block_info, uint32_t* counters, hipStream_t s);
-size_t bin_table_bytes(int N, int T);
+size_t bin_table_bytes(int N, int T, int grid_x);
+size_t bin_scratch_bytes(int64_t cap, int T, int grid_x);  // scratch of the grouped binning (<= the checkpoint area it is given)
 struct BinOut {  // what the extra workgroup of bin_scatter_kernel writes once per frame
   uint2* ranges;
   uint32_t *slot_base, *tile_max, *counters, *fwd_items, *fwd_empty, *fwd_ctr;
@@ -136,7 +137,7 @@ struct BinOut {  // what the extra workgroup of bin_scatter_kernel writes once p
   uint32_t items_cap;    // capacity of fwd_items
 };
 int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order, const uint32_t* tiles,
-                   const ushort4* rect, void* table_mem, uint32_t* point_list, uint32_t* tile_keys, const BinOut& out,
+                   const ushort4* rect, void* table_mem, void* scratch, uint32_t* point_list, uint32_t* tile_keys, const BinOut& out,
                    hipStream_t s);
 
 }  // namespace riggs

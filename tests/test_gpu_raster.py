@@ -180,12 +180,12 @@ def test_full_size_properties(N, J, H, W):
     U.check_full_size_properties(act, cam)
 
 
-def test_largest_tile_grid_and_rejection_beyond_it():
-    """The binning keeps a per-workgroup tile table in LDS: 25 600 tiles (2560 x 2560 px) is the largest grid.  At that
-    size a handful of Gaussians must still match the oracle bit for bit in ordering (tile ids far above 16 bits' worth
-    of chunks / the old packed work entries), and one tile row more is rejected with an error, not mis-rendered."""
-    from riggs_amd._lib import RiggsHipError
-    H = W = 2560
+@pytest.mark.parametrize("H,W", [(2560, 2560), (2160, 3840)])
+def test_large_tile_grids(H, W):
+    """Grids beyond 4096 tiles take the two-level (grouped) binning: 25 600 tiles (2560 x 2560 px, the most the one-level
+    sort's per-workgroup tile table ever fitted) and 4K UHD (3840 x 2160: 32 400 tiles — upstream passes any H, W:
+    gaussian_renderer/__init__.py:57-70).  A handful of Gaussians must match the oracle bit for bit in ordering, with tile ids
+    far above 16 000, and the gradients agree."""
     sc, act, cam = U.activated_scene(300, 8, 41, H, W, scale=0.05)
     out_o, so = U.oracle_forward(act, cam, [0.0, 0.1, 0.2])
     color, radii, depth, alpha, s = U.hip_forward(act, cam, [0.0, 0.1, 0.2])
@@ -196,11 +196,19 @@ def test_largest_tile_grid_and_rejection_beyond_it():
     d = lambda t: t.cuda().contiguous()  # noqa: E731
     gh = rasterize_backward(s, d(act["means3D"]), d(act["shs"]), None, d(act["opacities"]), d(act["scales"]),
                             d(act["rotations"]), None, None, None, d(gc), None, None)
-    _grads_close(gh[0], go["means3D"], "dL/dmeans3D (25600 tiles)")
-    _grads_close(gh[4], go["opacities"], "dL/dopacity (25600 tiles)")
-    sc2, act2, cam2 = U.activated_scene(300, 8, 41, H + 16, W, scale=0.05)
+    # (300 Gaussians: a handful of elements that are differences of large cancelling terms carry the atomics' reordering noise
+    # at their neighbours' magnitude — the max-norm bar is the check here)
+    U.assert_close(gh[0].cpu().numpy(), go["means3D"], "dL/dmeans3D (%d tiles)" % (((H + 15) // 16) * ((W + 15) // 16)), U.REL_TOL, 1e-4, 0.05)
+    U.assert_close(gh[4].cpu().numpy().reshape(go["opacities"].shape), go["opacities"], "dL/dopacity (large grid)", U.REL_TOL, 1e-4, 0.05)
+
+
+def test_tile_grids_beyond_the_work_list_packing_are_rejected():
+    """65 535 tiles is the limit (the forward's work list packs the tile id into 16 bits): more is an error, not a mis-render."""
+    from riggs_amd._lib import RiggsHipError
+    H, W = 4112, 4096  # 257 x 256 = 65 792 tiles
+    sc, act, cam = U.activated_scene(50, 8, 41, H, W, scale=0.05)
     with pytest.raises(RiggsHipError, match="image too large"):
-        U.hip_forward(act2, cam2, [0, 0, 0])
+        U.hip_forward(act, cam, [0, 0, 0])
 
 
 def test_loss_on_depth_or_alpha_only_backpropagates():
