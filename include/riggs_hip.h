@@ -59,9 +59,7 @@ typedef struct riggs_raster_cfg {
    * float atomics into the per-Gaussian accumulators, every (tile instance) writes its partial gradient row and a second
    * kernel sums each Gaussian's rows in ascending tile order: gradients are bitwise reproducible run to run.  Needs the
    * larger workspace of riggs_raster_backward_workspace_bytes_ordered; slower (tests / debugging).
-   * riggs_raster_render: the segments of a long tile's list (> 1024 instances) are all composited from T = 1 and combined in
-   * a fixed association; without the flag a segment whose predecessors have already finished continues from their result,
-   * which rounds differently (1e-7 relative) and depends on timing: the image is bitwise reproducible only with the flag. */
+   * (riggs_raster_render is bitwise reproducible with or without it: no two workgroups share a pixel.) */
   int32_t deterministic;
   /* riggs_raster_backward only.  1 = the caller guarantees that the gradient output buffers are the SAME buffers the previous
    * riggs_raster_backward with this workspace wrote and that nobody has written them since (or that buffers and workspace
@@ -398,11 +396,12 @@ int riggs_dist2_knn3(int32_t num_points, const float* points, float* out, void* 
  * last riggs_prof_reset.  Stage ids: riggs_prof_name(i) for i in [0, riggs_prof_count()).
  * ===================================================================== */
 /* debugging aid: per-wave statistics of the forward compositing kernel (8 u64 per wave, 4 waves per work item — a work
- * item is one 8x4 pixel block of one segment of one tile, in launch order: {100 MHz ticks of the compositing loop, rounds,
- * survivors | hardware id << 32, steps, steps with a contribution, segment length | tile << 32 | segment << 48, start tick,
- * ticks in the segment chain | segments combined << 32 | chunks re-walked << 44 | chunks scanned back << 54}), followed (at word
- * n_items * 32; n_items = riggs_raster_set_trace_items, default 8 per tile) by 4 u64 per chunk of the compositing backward
- * ({start, end, hardware id, workgroup << 32 | tile << 16 | chunk}); tools/fwd_trace.py, fwd_placement.py, bwd_trace.py.
+ * item is one pixel block of one tile = one workgroup, in launch order: {100 MHz ticks of the compositing loop, rounds,
+ * survivors | hardware id << 32, steps, steps with a contribution, list length | tile << 32 | wide << 63, start tick, 0}),
+ * followed (at word n_items * 32; n_items = riggs_raster_set_trace_items, default 8 per tile) by 4 u64 per chunk of the
+ * compositing backward ({start, end, hardware id, workgroup << 32 | tile << 16 | chunk}); tools/fwd_trace.py, bwd_trace.py.
+ * Environment (read once, tuning knobs for tools): RIGGS_FWD_WIDE_TILES = the tiles with the longest lists that the forward
+ * composites with 32 lanes per pixel (default 256, 0 = none), RIGGS_FWD_WIDE_MIN = from this list length (default 2048).
  * NULL disables */
 int riggs_raster_set_trace(void* dev_u64);
 int riggs_raster_set_trace_items(uint64_t n_items);

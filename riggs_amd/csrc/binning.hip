@@ -101,15 +101,15 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(int T, int n_chunks, uin
 }
 
 // exclusive scan over the tiles (one workgroup — the extra, last one of bin_scatter_kernel's grid): ranges, checkpoint slot
-// bases, cleared per-tile words, R and the overflow flag, and the forward's work list.
-// The work list has one entry per (non-empty tile, segment of RIGGS_SEG instances): tile | segment << 16.  All FIRST
-// segments come first (longest lists first, as before: the workgroups that walk the lists), then the helpers of the later
-// segments, deepest level first: the hardware starts workgroups in this order, so a helper starts when the walkers leave
-// it room — by then a tile whose pixels saturate has usually told its helpers (dead_from) that they have nothing to do, and
-// the far segments, the ones a helper can finish before the walker arrives, are taken first (render.hip).
-#define SEG_LMAX 2048  // segment levels with a cursor of their own (deeper ones share the last)
+// bases, cleared per-tile words, R and the overflow flag, and the forward's work list: the non-empty tiles, longest lists first
+// (by floor(log2(length))), the empty ones in a list of their own.  In front of them all, fwd_ctr[1] entries: the tiles the
+// forward composites WIDE (render.hip) — the ones whose walk went o.wide_min instances deep in the PREVIOUS frame of this arena
+// (o.walk_hist: max n_contrib per tile, written by the forward; how deep a walk goes is a property of the scene and the view —
+// a list's length says nothing about it: the longest lists of the bench scene, 48 000 instances, saturate within 800) and
+// whose list is that long now; the first o.wide_tiles of them in tile order.  Without a history (a fresh arena: the stamp
+// behind the last tile is missing) or with cfg.deterministic (wide_tiles = 0) no tile is wide.
+#define WALK_HIST_STAMP(T) (0x5EED0000u ^ (uint32_t)(T) * 2654435761u)
 __device__ void bin_offsets_body(int T, int64_t cap, const uint32_t* __restrict__ tile_count, const BinOut o,
-                                 uint32_t* __restrict__ s_lvl /* LDS, 2 * SEG_LMAX words */,
                                  const uint32_t* __restrict__ total_src = nullptr, int n_total_src = 0) {
   uint2* __restrict__ ranges = o.ranges;
   uint32_t* __restrict__ slot_base = o.slot_base;
@@ -118,22 +118,15 @@ __device__ void bin_offsets_body(int T, int64_t cap, const uint32_t* __restrict_
   uint32_t* __restrict__ fwd_items = o.fwd_items;
   uint32_t* __restrict__ fwd_empty = o.fwd_empty;
   uint32_t* __restrict__ fwd_ctr = o.fwd_ctr;
-  __shared__ uint32_t s_wave[16];
-  __shared__ uint32_t s_carry;
-  __shared__ uint32_t s_hist[32], s_cur[32], s_nempty, s_n0;
+  uint32_t* __restrict__ walk_hist = o.walk_hist;
+  __shared__ uint32_t s_wave[16], s_wwave[16];
+  __shared__ uint32_t s_carry, s_wcarry;
+  __shared__ uint32_t s_hist[33], s_cur[33], s_nempty;  // (class 32: the wide tiles)
   const int nthr = (int)blockDim.x;  // <= 1024
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) { s_carry = 0u; s_nempty = 0u; }
-  if (tid < 32) s_hist[tid] = 0u;
-  for (int k = tid; k < 2 * SEG_LMAX; k += nthr) s_lvl[k] = 0u;
-  {
-    // the hand-shake words of the segmented tiles and the per-block "dead from" words start every frame at zero
-    uint4* f4 = reinterpret_cast<uint4*>(o.seg_flags);
-    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-    for (size_t e = tid; e < (size_t)o.n_seg_slots * 2; e += nthr) f4[e] = z;
-    uint4* d4 = reinterpret_cast<uint4*>(o.dead_from);
-    for (size_t e = tid; e < (size_t)T * 2; e += nthr) d4[e] = z;
-  }
+  if (tid == 0) { s_carry = 0u; s_nempty = 0u; s_wcarry = 0u; }
+  if (tid < 33) s_hist[tid] = 0u;
+  const bool have_hist = o.wide_tiles > 0u && walk_hist[T] == WALK_HIST_STAMP(T);
   __syncthreads();
   uint32_t my_len[8];  // list lengths of this thread's tiles (the first 8 passes; beyond that they are re-read)
 #pragma unroll
@@ -147,10 +140,14 @@ __device__ void bin_offsets_body(int T, int64_t cap, const uint32_t* __restrict_
       const uint32_t u = (uint32_t)__shfl_up((int)v, o2);
       if (lane >= o2) v += u;
     }
-    if (lane == 63) s_wave[wave] = v;
+    // candidates for the wide form, counted in tile order
+    const uint32_t prev = (have_hist && t < T) ? walk_hist[t] : 0u;
+    const bool cand = prev >= o.wide_min && prev < 0x80000000u && c >= o.wide_min;
+    const uint64_t cmask = __builtin_amdgcn_ballot_w64(cand);
+    if (lane == 63) { s_wave[wave] = v; s_wwave[wave] = (uint32_t)__builtin_popcountll(cmask); }
     __syncthreads();
-    uint32_t wave_off = 0;
-    for (int w = 0; w < wave; w++) wave_off += s_wave[w];
+    uint32_t wave_off = 0, wrank = s_wcarry + (uint32_t)__builtin_popcountll(cmask & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; w++) { wave_off += s_wave[w]; wrank += s_wwave[w]; }
     const uint32_t carry = s_carry;
     const uint32_t start = carry + wave_off + v - c;
     if (t < T) {
@@ -162,18 +159,18 @@ __device__ void bin_offsets_body(int T, int64_t cap, const uint32_t* __restrict_
       tile_max[T + 1 + t] = 0u;  // ... and the arrival ticket of the tile's forward blocks
       slot_base[t] = (lo >> 6) + (uint32_t)t;
       // forward work queue, step 1: histogram of floor(log2(list length)); the empty tiles go to their own list
-      if (hi > lo) atomicAdd(&s_hist[31 - __builtin_clz(hi - lo)], 1u);
+      const bool wide = cand && wrank < o.wide_tiles && hi - lo >= o.wide_min;
+      walk_hist[t] = wide ? 0x80000000u : 0u;  // (the forward writes this frame's depth over it; an empty tile's stays 0)
+      if (hi > lo) atomicAdd(&s_hist[wide ? 32 : 31 - __builtin_clz(hi - lo)], 1u);
       else fwd_empty[atomicAdd(&s_nempty, 1u)] = (uint32_t)t;
-      // ... and the number of tiles that have a k-th segment, k = 1, 2, ...
-      const uint32_t nseg = (hi - lo + RIGGS_SEG - 1) / RIGGS_SEG;
-      for (uint32_t k = 1; k < nseg; k++) atomicAdd(&s_lvl[min(k, (uint32_t)SEG_LMAX - 1u)], 1u);
 #pragma unroll
       for (int k = 0; k < 8; k++) if (pass == k) my_len[k] = hi - lo;
     }
     __syncthreads();
-    if (tid == nthr - 1) s_carry = carry + wave_off + v;
+    if (tid == nthr - 1) { s_carry = carry + wave_off + v; s_wcarry = wrank + (cand ? 1u : 0u); }
     __syncthreads();
   }
+  if (tid == 0) walk_hist[T] = WALK_HIST_STAMP(T);
   if (total_src) {
     // (the grouped binning counts only the instances that fit the arena per tile: the true total comes from its group counts)
     __shared__ uint32_t s_tot;
@@ -195,88 +192,21 @@ __device__ void bin_offsets_body(int T, int64_t cap, const uint32_t* __restrict_
     counters[0] = R;
     counters[1] = (counters[1] & 2u) | (((int64_t)R > cap) ? 1u : 0u);  // (bit 1: the depth sort's third pass failed to synchronise)
   }
-  // Order of the work list:  [walkers of the lists of 1024 and more, longest first]  [EARLY helpers]  [walkers of the short
-  // lists]  [late helpers].  Helpers are speculation — a helper's segment may never be reached (the pixels saturate in front
-  // of it): placed early they double the work of such a scene, placed late they come too late for a scene whose long lists
-  // do not saturate.  Whether lists saturate is a property of the scene more than of the view, so the PREVIOUS frame decides:
-  // seg_stats[0, 32) counts its segmented blocks by the number of segments their walk went through - 1, [32, 64) the blocks
-  // that had a k-th segment; levels 1 .. E are early, E the deepest level such that at least half of the blocks that had a
-  // segment of EVERY level up to it reached it and that the helpers up to it fit the budget (E = 0 in the first frame of an
-  // arena, whose statistics are not there yet: a scheduling matter at most).
-  __shared__ uint32_t s_E, s_nearly, s_nlong;
-  if (tid < 32) {
-    const uint32_t h = o.seg_stats[tid];
-    uint32_t reach = h;  // blocks that went through > tid segments = reached segment tid: suffix sum
-    for (int o2 = 1; o2 < 32; o2 <<= 1) {
-      const uint32_t u = (uint32_t)__shfl_down((int)reach, o2);
-      if (tid + o2 < 32) reach += u;
-    }
-    const uint32_t had = o.seg_stats[32 + tid];
-    uint32_t cum = (tid >= 1) ? 8u * s_lvl[tid] : 0u;  // helper items of levels 1 .. tid: prefix sum
-    for (int o2 = 1; o2 < 32; o2 <<= 1) {
-      const uint32_t u = (uint32_t)__shfl_up((int)cum, o2);
-      if (tid >= o2) cum += u;
-    }
-    const bool ok = tid == 0 || (had > 0u && had < 0x40000000u && reach < 0x40000000u && 2u * reach >= had && cum <= o.helper_budget);
-    const uint32_t okm = (uint32_t)__builtin_amdgcn_ballot_w64(ok);  // (lanes 0 .. 31)
-    if (tid == 0) {
-      const int e = (okm == 0xFFFFFFFFu ? 32 : __builtin_ctz(~okm)) - 1;  // the run of ok levels from 0
-      s_E = (uint32_t)(e > 30 ? 30 : e);      // (level 31 stands for all deeper ones too: never early)
-    }
-    o.seg_stats[tid] = 0u;                                        // this frame's walks start counting
-    o.seg_stats[32 + tid] = (tid >= 1) ? 8u * s_lvl[tid] : 0u;    // blocks that have a tid-th segment
-  }
   __syncthreads();
   if (tid < 32) {
-    const uint32_t h = s_hist[31 - tid];
+    const uint32_t n_wide = s_hist[32];
+    const uint32_t h = s_hist[31 - tid];  // lane k: length class 31 - k
     uint32_t v = h;
     for (int o2 = 1; o2 < 32; o2 <<= 1) {
       const uint32_t u = (uint32_t)__shfl_up((int)v, o2);
       if (tid >= o2) v += u;
     }
-    s_cur[31 - tid] = v - h;
-    if (tid == 21) s_nlong = v;  // buckets 31 .. 10: lists of 1024 and more
-    if (tid == 31) { s_n0 = v; fwd_ctr[1] = 0u; fwd_ctr[2] = s_nempty; fwd_ctr[64] = 0u; }  // ([64]: backward work-list size, on its own cache line)
-    uint32_t ne = (tid >= 1 && (uint32_t)tid <= s_E) ? s_lvl[tid] : 0u;
-    for (int o2 = 16; o2 > 0; o2 >>= 1) ne += (uint32_t)__shfl_xor((int)ne, o2);
-    if (tid == 0) s_nearly = ne;
+    s_cur[31 - tid] = n_wide + v - h;
+    if (tid == 0) s_cur[32] = 0u;
+    if (tid == 31) { fwd_ctr[0] = n_wide + v; fwd_ctr[1] = n_wide; fwd_ctr[2] = s_nempty; fwd_ctr[64] = 0u; }  // ([64]: backward work-list size, on its own cache line)
   }
   __syncthreads();
-  if (tid < 10) s_cur[tid] += s_nearly;  // the walkers of the short lists come behind the early helpers
-  // start of every helper level: early ones (ascending) behind the long walkers, late ones (ascending) behind everything else
-  if (tid == 0) s_carry = 0u;
-  __syncthreads();
-  for (int base = 1; base < SEG_LMAX; base += nthr) {
-    const int k = base + tid;
-    const uint32_t c = (k < SEG_LMAX) ? s_lvl[k] : 0u;
-    uint32_t v = c;
-    for (int o2 = 1; o2 < 64; o2 <<= 1) {
-      const uint32_t u = (uint32_t)__shfl_up((int)v, o2);
-      if (lane >= o2) v += u;
-    }
-    if (lane == 63) s_wave[wave] = v;
-    __syncthreads();
-    uint32_t wave_off = 0;
-    for (int w = 0; w < wave; w++) wave_off += s_wave[w];
-    const uint32_t carry = s_carry;
-    if (k < SEG_LMAX) {
-      const uint32_t before = carry + wave_off + v - c;  // helper entries of the levels in front of k
-      // (early levels are 1 .. E: `before` counts early entries only for them, and for a late level E + m it counts all E early ones)
-      s_lvl[SEG_LMAX + k] = ((uint32_t)k <= s_E) ? s_nlong + before : s_n0 + before;
-    }
-    __syncthreads();
-    if (tid == nthr - 1) s_carry = carry + wave_off + v;
-    __syncthreads();
-  }
-  if (tid == 0) fwd_ctr[0] = min(s_n0 + s_carry, o.items_cap);  // (<= T + cap / RIGGS_SEG by construction)
-  auto emit = [&](uint32_t t, uint32_t len) {
-    fwd_items[atomicAdd(&s_cur[31 - __builtin_clz(len)], 1u)] = t;
-    const uint32_t nseg = (len + RIGGS_SEG - 1) / RIGGS_SEG;
-    for (uint32_t k = 1; k < nseg; k++) {
-      const uint32_t at = atomicAdd(&s_lvl[SEG_LMAX + min(k, (uint32_t)SEG_LMAX - 1u)], 1u);
-      if (at < o.items_cap) fwd_items[at] = t | (k << 16);
-    }
-  };
+  auto emit = [&](uint32_t t, uint32_t len) { fwd_items[atomicAdd(&s_cur[(walk_hist[t] >> 31) ? 32 : 31 - __builtin_clz(len)], 1u)] = t; };
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     const int t = k * nthr + tid;
@@ -300,7 +230,7 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(int N, int T, int gri
                                                           uint32_t* __restrict__ tile_keys, const BinOut out) {
   extern __shared__ uint32_t s_mem[];
   if (blockIdx.x == gridDim.x - 1) {  // the extra workgroup: what used to be a single-workgroup launch of its own
-    bin_offsets_body(T, cap, tile_count, out, s_mem);
+    bin_offsets_body(T, cap, tile_count, out);
     return;
   }
   const int W = blockDim.x >> 6;
@@ -669,9 +599,8 @@ __global__ __launch_bounds__(512) void gbin_tscatter_kernel(int T, int G, int gx
                                                            const uint32_t* __restrict__ part_hist, const uint32_t* __restrict__ tile_count,
                                                            uint32_t* __restrict__ point_list, uint32_t* __restrict__ tile_keys,
                                                            const BinOut out) {
-  extern __shared__ uint32_t s_dyn[];
   if (blockIdx.x == gridDim.x - 1) {
-    bin_offsets_body(T, cap, tile_count, out, s_dyn, group_count, G);
+    bin_offsets_body(T, cap, tile_count, out, group_count, G);
     return;
   }
   __shared__ uint32_t s_cur[8];
@@ -783,7 +712,7 @@ size_t bin_scratch_bytes(int64_t cap, int T, int grid_x) {  // (grouped binning:
 int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order, const uint32_t* tiles,
                    const ushort4* rect, void* table_mem, void* scratch, uint32_t* point_list, uint32_t* tile_keys, const BinOut& out,
                    hipStream_t s) {
-  if (T > 65535) { set_error("image too large: %d tiles (the forward's work list packs the tile id into 16 bits)", T); return 2; }
+  if (T > 65535) { set_error("image too large: %d tiles (at most 65 535)", T); return 2; }
   char* mem = (char*)table_mem;
   static bool attr_done = false;
   if (!attr_done) {
@@ -808,7 +737,7 @@ int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order,
     hipLaunchKernelGGL(gbin_scatter_kernel, dim3(p.n_chunks), dim3(1024), p.lds, s, N, p.G, p.gxg, cap, p.g_per_block, p.g_per_wave,
                        order, tiles, rect, table, group_count, inter);
     hipLaunchKernelGGL(gbin_tcount_kernel, dim3(n_parts), dim3(512), 0, s, p.G, p.gxg, grid_x, cap, group_count, inter, part_hist, tile_count);
-    hipLaunchKernelGGL(gbin_tscatter_kernel, dim3(n_parts + 1), dim3(512), (size_t)2 * SEG_LMAX * 4, s, T, p.G, p.gxg, grid_x, cap,
+    hipLaunchKernelGGL(gbin_tscatter_kernel, dim3(n_parts + 1), dim3(512), 0, s, T, p.G, p.gxg, grid_x, cap,
                        group_count, inter, part_hist, tile_count, point_list, tile_keys, out);
     return 0;
   }
@@ -823,9 +752,7 @@ int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order,
                      order, tiles, rect, table);
   hipLaunchKernelGGL(bin_scan_kernel, dim3((T + 63) / 64), dim3(1024), 0, s, T, p.n_chunks, table, tile_count);
   // (+ 1: the extra workgroup that writes the ranges, the counters and the forward's work list)
-  // (the extra workgroup keeps its segment-level cursors in the dynamic LDS: 2 * SEG_LMAX words)
-  const size_t lds = p.lds_scatter > (size_t)2 * SEG_LMAX * 4 ? p.lds_scatter : (size_t)2 * SEG_LMAX * 4;
-  hipLaunchKernelGGL(bin_scatter_kernel, dim3(p.n_chunks + 1), dim3(p.threads), lds, s, N, T, grid_x, cap,
+  hipLaunchKernelGGL(bin_scatter_kernel, dim3(p.n_chunks + 1), dim3(p.threads), p.lds_scatter, s, N, T, grid_x, cap,
                      p.g_per_block, p.g_per_wave, order, tiles, rect, table, tile_count, point_list, tile_keys, out);
   return 0;
 }

@@ -77,7 +77,6 @@ ImageLayout image_layout(int H, int W) {
   // {n_nonempty, -, n_empty} read by every forward workgroup; [64] = size of the backward's work list (in quarter-chunks),
   // appended to by the forward with atomics — on a cache line of its own (see render_fwd_oct_kernel)
   L.fwd_ctr = o; o = align_up(o + 512);
-  L.dead_from = o; o = align_up(o + T * 8 * 4);  // segmented tiles: per (tile, pixel block) the first segment nobody reaches
   L.total = o;
   return L;
 }
@@ -92,15 +91,10 @@ BinLayout bin_layout(int64_t cap, int N, int H, int W) {
   L.ckpt = o; o += align_up(L.n_slots * RIGGS_CKPT_FLOATS * 4);
   L.table = o; o += align_up(bin_table_bytes(N, (int)T, (W + RIGGS_TILE - 1) / RIGGS_TILE));
   L.work = o; o += align_up(L.n_slots * 16);  // backward work list: 16-byte entry per active chunk
-  // forward work list: one entry per (non-empty tile, segment of RIGGS_SEG instances); segment slots (raster_internal.h)
-  L.n_seg_slots = seg_slots(cap, T);
-  L.n_items_cap = L.n_seg_slots;
-  L.fwd_items = o; o += align_up(L.n_items_cap * 4);
-  L.seg_state = o; o += align_up(L.n_seg_slots * RIGGS_SEG_WORDS * 256 * 4);
-  L.seg_flags = o; o += align_up(L.n_seg_slots * 8 * 4);
-  // how deep the walks of segmented tiles went: read by the NEXT frame's work-list builder (the binning arena is the one that
+  L.fwd_items = o; o += align_up((T + 1) * 4);  // forward work list: the non-empty tiles, longest lists first
+  // how deep the forward walked every tile's list: read by the NEXT frame's work-list builder (the binning arena is the one that
   // persists from frame to frame: riggs_amd.rasterizer.RasterArena, captured frames)
-  L.seg_stats = o; o += align_up(64 * 4);
+  L.walk_hist = o; o += align_up((T + 2) * 4);
   L.total = o;
   return L;
 }
@@ -260,9 +254,8 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
     BinOut bo;
     bo.ranges = (uint2*)(img + I.ranges); bo.slot_base = (uint32_t*)(img + I.slot_base); bo.tile_max = (uint32_t*)(img + I.tile_max);
     bo.counters = counters; bo.fwd_items = (uint32_t*)(bin + B.fwd_items); bo.fwd_empty = (uint32_t*)(img + I.fwd_empty);
-    bo.fwd_ctr = (uint32_t*)(img + I.fwd_ctr); bo.seg_flags = (uint32_t*)(bin + B.seg_flags); bo.dead_from = (uint32_t*)(img + I.dead_from);
-    bo.n_seg_slots = (uint32_t)B.n_seg_slots; bo.items_cap = (uint32_t)B.n_items_cap;
-    bo.seg_stats = (uint32_t*)(bin + B.seg_stats); bo.helper_budget = (uint32_t)forward_helper_budget();
+    bo.fwd_ctr = (uint32_t*)(img + I.fwd_ctr); bo.wide_tiles = cfg->deterministic ? 0u : forward_wide_tiles(); bo.wide_min = forward_wide_min();
+    bo.walk_hist = (uint32_t*)(bin + B.walk_hist);
     int rcb = launch_binning(N, T, gx, cap, (const uint32_t*)(geom + G.order), (const uint32_t*)(geom + G.tiles),
                              (const ushort4*)(geom + G.rect), bin + B.table, bin + B.ckpt /* free until the compositing */,
                              (uint32_t*)(bin + B.point_list),
@@ -288,10 +281,7 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
   // longest-list-first work list of the forward (the extra workgroup of bin_scatter_kernel builds it; NULL: every tile is empty)
   r.items = nullptr; r.empties = nullptr; r.item_ctr = nullptr;
   if (binned) { r.items = (const uint32_t*)(bin + B.fwd_items); r.empties = (const uint32_t*)(img + I.fwd_empty); r.item_ctr = (uint32_t*)(img + I.fwd_ctr); }
-  r.seg_state = (float*)(bin + B.seg_state); r.seg_flags = (uint32_t*)(bin + B.seg_flags); r.dead_from = (uint32_t*)(img + I.dead_from);
-  r.seg_stats = (uint32_t*)(bin + B.seg_stats);
-  r.n_item_slots = (int64_t)B.n_items_cap;
-  r.deterministic = cfg->deterministic ? 1 : 0;
+  r.walk_hist = (uint32_t*)(bin + B.walk_hist);
   r.trace_items = g_raster_trace_items ? g_raster_trace_items : (uint64_t)T * 8;
   { ProfScope ps(PROF_RENDER_FWD, s); launch_render_fwd(r, s); }
   if (debug_sync(cfg->debug, s, "render_fwd")) return 1;
@@ -348,7 +338,6 @@ int riggs_raster_backward(const riggs_raster_cfg* cfg, const float* means3D, con
   r.n_tiles = ((W + RIGGS_TILE - 1) / RIGGS_TILE) * ((H + RIGGS_TILE - 1) / RIGGS_TILE);
   r.n_slots = (int64_t)B.n_slots;
   r.work = (const uint4*)(bin + B.work); r.work_ctr = (const uint32_t*)(img + I.fwd_ctr) + 64;
-  r.seg_state = (const float*)(bin + B.seg_state);
   r.det_rows = nullptr;
   if (cfg->deterministic && cap > 0) {
     // ordered-reduction mode: rows instead of atomics, then a fixed-order sum per Gaussian that overwrites the accumulators

@@ -67,12 +67,12 @@ struct GeomLayout {
 GeomLayout geom_layout(int N);
 
 struct ImageLayout {
-  size_t final_T, n_contrib, ranges, final_acc, tile_max, slot_base, fwd_empty, fwd_ctr, dead_from, total;
+  size_t final_T, n_contrib, ranges, final_acc, tile_max, slot_base, fwd_empty, fwd_ctr, total;
 };
 ImageLayout image_layout(int H, int W);
 
 struct BinLayout {
-  size_t point_list, tile_keys, ckpt, n_slots, table, work, fwd_items, n_items_cap, seg_state, seg_flags, n_seg_slots, seg_stats, total;
+  size_t point_list, tile_keys, ckpt, n_slots, table, work, fwd_items, walk_hist, total;
 };
 #define RIGGS_CKPT_FLOATS (5 * 256)  // floats per checkpoint slot
 BinLayout bin_layout(int64_t cap, int N, int H, int W);

@@ -40,20 +40,6 @@ static inline size_t ws_blocks_offset(int32_t N) { return ws_bits_offset(N) + al
 int launch_preprocess_fwd(const PreArgs& a, hipStream_t s);
 int launch_preprocess_bwd(const PreBwdArgs& b, hipStream_t s);
 
-// ---- segmented forward compositing ------------------------------------------------------------------------------------
-// A tile's list is walked front to back by the workgroups of its FIRST work item (one per 8x4 pixel block).  A list longer
-// than RIGGS_SEG instances has further work items, one per later segment of RIGGS_SEG instances: helper workgroups that
-// composite their segment from T = 1 (alpha compositing is associative) and publish a summary, which the walking workgroup
-// combines instead of walking the segment if it is there when it arrives (render.hip).  Per (tile, segment) there is one
-// "segment slot"
-//   slot(tile, seg) = (range.x(tile) / RIGGS_SEG) + tile + seg        (injective: a tile has <= total / RIGGS_SEG + 1 segments)
-// holding RIGGS_SEG_WORDS words per pixel and, per pixel block, the hand-shake word of the segment.
-#define RIGGS_SEG 1024
-#define RIGGS_SEG_CHUNKS (RIGGS_SEG / 64)
-#define RIGGS_SEG_WORDS 40  // per pixel and segment slot: 8 per round (a helper's states at the start of rounds 1 .. 3, its end state), then
-#define RIGGS_SEG_PREFIX 32  // ... the segment's prefix (T, C0, C1, C2, D): what the backward multiplies the segment's checkpoints with
-static inline size_t seg_slots(int64_t cap, size_t T) { return (size_t)((cap > 0 ? cap : 1) / RIGGS_SEG) + T + 1; }
-
 struct RenderArgs {
   int W, H;
   unsigned long long* trace;  // optional per-workgroup statistics of render_fwd (riggs_raster_set_trace), else NULL
@@ -72,24 +58,18 @@ struct RenderArgs {
   uint32_t* work_ctr;         // its size in quarter-chunks (zeroed by the extra workgroup of bin_scatter_kernel)
   const uint32_t* slot_base;  // per tile: first checkpoint slot ((range.x >> 6) + tile)
   float* ckpt;                // [slot][5][256]: (T, C0, C1, C2, D) per pixel at every 64th instance
-  // work list (NULL: nothing was binned, every tile is empty): items = the non-empty tiles, longest lists
-  // first; empties = the tiles without instances; item_ctr = {n_nonempty, -, n_empty}
-  // items: tile | (segment << 16), all first segments (longest lists first), then the second segments, ...
+  // work list (NULL: nothing was binned, every tile is empty): items = the non-empty tiles, longest lists first — the
+  // first item_ctr[1] of them are composited WIDE (render.hip) —; empties = the tiles without instances;
+  // item_ctr = {n_nonempty, n_wide, n_empty}
   const uint32_t* items;
   const uint32_t* empties;
   uint32_t* item_ctr;
-  // segmented tiles (see RIGGS_SEG)
-  float* seg_state;           // [segment slot][RIGGS_SEG_WORDS][256]
-  uint32_t* seg_flags;        // [segment slot][8 pixel blocks]: bit 0 = summary published, bit 1 = prefix published
-  uint32_t* dead_from;        // [tile][8 pixel blocks]: 0 = unknown, else the first segment that no pixel of the block reaches
-  uint32_t* seg_stats;        // [0, 32): blocks of segmented tiles by the number of segments their walk went through - 1 (this frame);
-                              // [32, 64): blocks that had a k-th segment, written by the work-list builder
-  int64_t n_item_slots;       // capacity of the work list (host-side bound of the grid)
-  int deterministic;          // cfg.deterministic: no segment runs as a continuation (bitwise repeatable image)
+  uint32_t* walk_hist;        // [T] per tile: max n_contrib, for the NEXT frame's work list (BinOut::walk_hist)
   uint64_t trace_items;       // capacity of the trace buffer in work items (tools; 0: 8 per tile)
 };
 int launch_render_fwd(const RenderArgs& a, hipStream_t s);
-int64_t forward_helper_budget();  // helper workgroups per forward launch
+uint32_t forward_wide_tiles();  // tiles that may be composited wide per launch (bounds the grid)
+uint32_t forward_wide_min();    // list length from which a tile is composited wide
 
 struct RenderBwdArgs {
   unsigned long long* trace;  // optional per-chunk statistics (riggs_raster_set_trace), else NULL
@@ -112,7 +92,6 @@ struct RenderBwdArgs {
   int64_t n_slots;
   const uint4* work;  // per active chunk: (tile, chunk, start of the tile's list, instances to walk); built by the forward
   const uint32_t* work_ctr;  // number of quarter-items
-  const float* seg_state;    // prefixes of the segmented tiles (RenderArgs::seg_state)
 };
 int launch_render_bwd(const RenderBwdArgs& a, hipStream_t s);
 // ordered-reduction mode: sum every Gaussian's instance rows in ascending tile order into the accumulators
@@ -129,12 +108,10 @@ size_t bin_scratch_bytes(int64_t cap, int T, int grid_x);  // scratch of the gro
 struct BinOut {  // what the extra workgroup of bin_scatter_kernel writes once per frame
   uint2* ranges;
   uint32_t *slot_base, *tile_max, *counters, *fwd_items, *fwd_empty, *fwd_ctr;
-  uint32_t* seg_flags;   // cleared: [seg_slots][8]
-  uint32_t* dead_from;   // cleared: [T][8]
-  uint32_t* seg_stats;   // read (the previous frame's) and reset: RenderArgs::seg_stats
-  uint32_t helper_budget; // helper workgroups that may be placed in front of the walkers of the short lists
-  uint32_t n_seg_slots;
-  uint32_t items_cap;    // capacity of fwd_items
+  uint32_t* walk_hist;   // [T + 1] per tile: how deep the forward's walk went in the previous frame (max n_contrib); read, then
+                         // bit 31 = composited wide in this frame; [T] = a stamp that says the words are a history
+  uint32_t wide_tiles;   // at most this many tiles are composited wide by the forward (0: none) ...
+  uint32_t wide_min;     // ... the ones whose walk was, and whose list is, this many instances deep (forward_wide_tiles / forward_wide_min)
 };
 int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order, const uint32_t* tiles,
                    const ushort4* rect, void* table_mem, void* scratch, uint32_t* point_list, uint32_t* tile_keys, const BinOut& out,

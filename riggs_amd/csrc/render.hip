@@ -51,100 +51,115 @@ __device__ __forceinline__ float oct_sum(float v) {
   v += ODPP_F(0.f, v, DPP_HALF_MIRROR, 0xf);
   return v;
 }
-// ---- segmented tiles ---------------------------------------------------------------------------------------------------
-// The workgroup of a block's FIRST segment (the OWNER) walks the tile's list front to back exactly as an unsegmented tile is
-// walked: sequential rule, exact stops, early termination, absolute checkpoints.  A list longer than RIGGS_SEG instances has
-// further work items, one per later segment and block, dealt in level order behind ALL first segments (second segments, then
-// third ones ...): HELPERS.  A helper composites its segment alone, from T = 1 (alpha compositing is associative:
-//   C = sum_s Tin_s * S_s,   Tin_s = prod_{s' < s} P_s'),
-// keeps every pixel's state at the start of each of its four rounds in LDS and, when done, publishes these and its end state in
-// its SEGMENT SLOT (write-through stores) and ORs bit SUMMARY into the segment's hand-shake word.  The owner, one round before
-// it reaches a segment boundary, ORs bit CLAIM into the next segment's word; a helper ORs bit STARTED into it when it begins:
-// of two ORs on a word exactly one sees the other's bit, and whoever is first owns the segment's CHECKPOINTS (a helper that
-// finds the claim leaves; an owner that finds STARTED walks the segment for its own state only and stores no checkpoints).
-// Summary there -> the owner COMBINES it instead of walking 1024 instances (fw_owner_rest), and every further segment that is
-// summarized as well.  A pixel whose running T times the segment's P falls below 1e-4 stops INSIDE the segment: the round
-// where T_in * T_local crosses the threshold is known from the published round states, and the owner composites that round
-// again from the true state, with the same code as the main loop — so the stop, n_contrib and final_T keep the sequential rule
-// (test_T = T (1 - alpha) < 1e-4, not counted).  When every pixel of the block has stopped the owner posts dead_from: helpers
-// that have not started leave at once, running ones at their next round.  Nobody ever waits for anybody.
-// A deep tile whose pixels do not saturate is thus composited by as many workgroups as the chip has free; a tile whose pixels
-// saturate early costs what it did before (its helpers start late — level order — find dead_from, and leave).
-// Checkpoints of a helper's segment are segment-local: the backward multiplies them with the segment's prefix, which the owner
-// stores in the segment's slot (the identity for the segments whose checkpoints are its own).  Which segments are combined depends on
-// timing and T_in * (local product) rounds differently from the running product (1e-7 relative, the class of the 8-lane scans):
-// cfg.deterministic turns the helpers off.
-typedef __attribute__((address_space(1))) uint32_t seg_gu32;
-typedef __attribute__((address_space(1))) float seg_gf32;
-#define SEG_SUMMARY 1u
-#define SEG_CLAIM 2u
-#define SEG_STARTED 4u
-__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store((seg_gf32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load((seg_gf32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint32_t ld_agent_u(const uint32_t* p) { return __hip_atomic_load((seg_gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// value of lane j of the own group of eight
-__device__ __forceinline__ float oct_get(float v, int j, int lane) { return __shfl(v, (lane & 56) | j); }
-__device__ __forceinline__ float oct_max(float v) {
+// ---- wide blocks ---------------------------------------------------------------------------------------------------------
+// A workgroup's time for its block is (rounds of 256 instances it walks) x (one round), and a round is issue-bound: four
+// waves, one per SIMD, ~45 vector instructions per scan step, 32 steps per round with eight lanes per pixel — 2.3 us.  A tile
+// whose list is long and whose pixels do not saturate is walked to the end, alone: the kernel then lasts as long as the longest
+// such list (headline: 25 rounds = 57 us for 35 - 40 us of issue; a scene of thin shells seen edge-on: 70 rounds = 160 us for
+// 30 us of issue).  What shortens the walk is more SIMDs for the same pixels, and that means more workgroups per tile (a
+// workgroup lives on one CU: more waves in it share the same four SIMDs).  So the tiles whose walk went deep in the previous
+// frame (the first `n_wide` entries of the work list — binning.hip, bin_offsets_body: RIGGS_FWD_WIDE_MIN instances and more,
+// at most RIGGS_FWD_WIDE_TILES tiles; a list's LENGTH says nothing: the bench scene's longest lists saturate within 800 instances)
+// are composited with THIRTY-TWO lanes per pixel: a wave is 2 pixels x 32 instance lanes, a workgroup a 4 x 2 pixel block, a
+// tile 32 workgroups instead of 8.  A scan step then covers 32 consecutive instances of a pixel (8 steps per round instead of
+// 32) at about the same instruction count — the exclusive product scan is five DPP multiplies instead of the quad permutes —,
+// the sequential stop rule is resolved by the same ballot, checkpoints and n_contrib keep their meaning, nothing is speculated
+// and no two workgroups ever talk to each other.  The price is the staging: every one of the 32 workgroups gathers and culls
+// the whole list (4x the L2 traffic of the 8-lane form: why this is for the few long lists only), against a 4 x 2 box that
+// lets fewer instances through than the 8 x 4 one.
+// (Round 3 first tried the other way — splitting long LISTS into segments of 1024 that helper workgroups composite from T = 1
+// and the walking workgroup combines, DESIGN.md §4: it needs hand-shakes through memory (3 us round trips), re-composites the
+// rounds in which pixels stop, speculates on segments nobody reaches, and gained 4 %.)
+template <int LPP> struct FwGeom;
+template <> struct FwGeom<8> {
+  static constexpr int LEAD = 0;  // the lane of a pixel's group that holds folded values: every lane does
+  static constexpr int BW = 8, BH = 4;
+};
+template <> struct FwGeom<32> {
+  static constexpr int LEAD = 16;  // folded values land in the upper row of the group (lanes 16 .. 31)
+  static constexpr int BW = 4, BH = 2;
+};
+#define DPP_ROW_MIRROR 0x140
+#define DPP_ROW_BCAST15 0x142
+#define ODPP_FR(old, v, ctrl, rows) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(old)), __builtin_bit_cast(int, (float)(v)), ctrl, rows, 0xf, false))
+#define ODPP_UR(old, v, ctrl, rows) ((uint32_t)__builtin_amdgcn_update_dpp((int)(old), (int)(v), ctrl, rows, 0xf, false))
+// folds over the LPP lanes of a pixel; the result is valid in the lanes i >= LEAD of the group
+template <int LPP> __device__ __forceinline__ float grp_sum(float v) {
+  v += QUAD_F(v, QP(1, 0, 3, 2));
+  v += QUAD_F(v, QP(2, 3, 0, 1));
+  v += ODPP_F(0.f, v, DPP_HALF_MIRROR, 0xf);
+  if constexpr (LPP == 32) {
+    v += ODPP_F(0.f, v, DPP_ROW_MIRROR, 0xf);
+    v += ODPP_FR(0.f, v, DPP_ROW_BCAST15, 0xa);
+  }
+  return v;
+}
+template <int LPP> __device__ __forceinline__ float grp_max(float v) {  // (of values >= -1)
   v = fmaxf(v, QUAD_F(v, QP(1, 0, 3, 2)));
   v = fmaxf(v, QUAD_F(v, QP(2, 3, 0, 1)));
-  return fmaxf(v, ODPP_F(-1.0f, v, DPP_HALF_MIRROR, 0xf));
+  v = fmaxf(v, ODPP_F(-1.0f, v, DPP_HALF_MIRROR, 0xf));
+  if constexpr (LPP == 32) {
+    v = fmaxf(v, ODPP_F(-1.0f, v, DPP_ROW_MIRROR, 0xf));
+    v = fmaxf(v, ODPP_FR(-1.0f, v, DPP_ROW_BCAST15, 0xa));
+  }
+  return v;
 }
-__device__ __forceinline__ uint32_t oct_max_u(uint32_t v) {
+template <int LPP> __device__ __forceinline__ uint32_t grp_max_u(uint32_t v) {
   v = max(v, QUAD_U(v, QP(1, 0, 3, 2)));
   v = max(v, QUAD_U(v, QP(2, 3, 0, 1)));
-  return max(v, ODPP_U(0u, v, DPP_HALF_MIRROR, 0xf));
+  v = max(v, ODPP_U(0u, v, DPP_HALF_MIRROR, 0xf));
+  if constexpr (LPP == 32) {
+    v = max(v, ODPP_U(0u, v, DPP_ROW_MIRROR, 0xf));
+    v = max(v, ODPP_UR(0u, v, DPP_ROW_BCAST15, 0xa));
+  }
+  return v;
 }
 
 #define FW_B 256                    // instances per round
-#define FW_NR (RIGGS_SEG / FW_B)    // rounds per segment
-// LDS of the forward (file scope: the main loop and the chain — a function of its own, see fw_seg_chain — share it)
-__shared__ float4 fw_stage[3 * FW_B];     // the staged round: records of the survivors (and, in fw_owner_rest, the summaries being combined)
+// LDS of the forward
+__shared__ float4 fw_stage[3 * FW_B];     // the staged round: records of the survivors
 #define fw_xyd (fw_stage)
 #define fw_con (fw_stage + FW_B)
 #define fw_rgb (fw_stage + 2 * FW_B)
 __shared__ unsigned short fw_pos[FW_B];  // position of the survivor inside its batch
 __shared__ int fw_cnt[FW_B / 64];        // survivors per chunk
 __shared__ uint32_t fw_wmax[4];
-__shared__ float fw_rs[FW_NR - 1][8][32];  // LOCAL segments: (T, C0, C1, C2, D, A, last, -) of the block's pixels at the start of rounds 1 ..
-__shared__ uint32_t fw_word;
 
-// a pixel's compositing state while its lists are walked: T and the stop bookkeeping are the same in its eight lanes, the
-// sums are per-lane partials
+// a pixel's compositing state while its list is walked: T and the stop bookkeeping are the same in all lanes of its group,
+// the sums are per-lane partials
 struct FwWalk {
   float T, C0, C1, C2, D, A, Tstop;
   uint32_t last;
   bool done;
 };
 
-// cull 64 instances (one per lane) against a box of pixels and compact the survivors into region `chunk` of the staging buffer
-// (`pos`: the instance's position inside its round of 256, what n_contrib is counted from)
-__device__ __forceinline__ int fw_stage_chunk(const int chunk, const int lane, const int pos, const bool in_range, const float4 xy,
-                                              const float4 co, const float4 cc, const float bx0, const float bx1, const float by0, const float by1) {
+// the main loop's round: every wave stages one chunk of the 256 (one instance per lane), culled against the block's pixels,
+// the survivors compacted (`pos`: the instance's position inside its round, what n_contrib is counted from)
+template <int LPP>
+__device__ __forceinline__ int fw_stage_round(const int tid, const bool in_range, const float4 xy, const float4 co, const float4 cc,
+                                              const float bx0, const float by0) {
+  const int chunk = tid >> 6, lane = tid & 63;
+  const float bx1 = bx0 + (float)(FwGeom<LPP>::BW - 1), by1 = by0 + (float)(FwGeom<LPP>::BH - 1);
   const bool keep = in_range && ((xy.x + xy.w >= bx0) && (xy.x - xy.w <= bx1) && (xy.y + cc.w >= by0) && (xy.y - cc.w <= by1));
   const uint64_t mask = __builtin_amdgcn_ballot_w64(keep);
   const int cnt = __builtin_popcountll(mask);
   const int slot = chunk * 64 + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-  if (keep) { fw_xyd[slot] = xy; fw_con[slot] = co; fw_rgb[slot] = cc; fw_pos[slot] = (unsigned short)pos; }
-  if (lane >= cnt && lane < ((cnt + 7) & ~7)) {  // null records up to the next multiple of 8
+  if (keep) { fw_xyd[slot] = xy; fw_con[slot] = co; fw_rgb[slot] = cc; fw_pos[slot] = (unsigned short)tid; }
+  if (lane >= cnt && lane < ((cnt + LPP - 1) & ~(LPP - 1))) {  // null records up to the next multiple of a step
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     fw_xyd[chunk * 64 + lane] = z; fw_con[chunk * 64 + lane] = z; fw_rgb[chunk * 64 + lane] = z; fw_pos[chunk * 64 + lane] = 0;
   }
   if (lane == 0) fw_cnt[chunk] = cnt;
   return cnt;
 }
-// the main loop's round: every wave stages one chunk of the 256, culled against the block's 8 x 4 pixels
-__device__ __forceinline__ int fw_stage_round(const int tid, const bool in_range, const float4 xy, const float4 co, const float4 cc,
-                                              const float bx0, const float by0) {
-  return fw_stage_chunk(tid >> 6, tid & 63, tid, in_range, xy, co, cc, bx0, bx0 + 7.0f, by0, by0 + 3.0f);
-}
 
-// the survivors of chunk k of the staged round, eight per step, for this wave's eight pixels
-template <bool TRACE>
+// the survivors of chunk k of the staged round, LPP per step, for this wave's 64 / LPP pixels
+template <int LPP, bool TRACE>
 __device__ __forceinline__ void fw_composite_chunk(FwWalk& w, const int k, const int base, const int lane, const float pfx, const float pfy,
                                                    uint32_t& st_iters, uint32_t& st_full) {
-  const int i = lane & 7;
+  const int i = lane & (LPP - 1);
   const int nk = fw_cnt[k];
-  for (int g = 64 * k; g < 64 * k + nk; g += 8) {
+  for (int g = 64 * k; g < 64 * k + nk; g += LPP) {
     // (no 'all pixels finished' test here: it costs eight instructions per step of every wave to save a few steps
     // once per wave; the chunk loop has it)
     const float4 xy = fw_xyd[g + i];
@@ -158,21 +173,46 @@ __device__ __forceinline__ void fw_composite_chunk(FwWalk& w, const int k, const
     if constexpr (TRACE) st_full++;
     const float4 c = fw_rgb[g + i];
     const int pos1 = base + (int)fw_pos[g + i] + 1;
-    // one step: eight consecutive instances (one per lane) of this lane's pixel
+    // one step: LPP consecutive instances (one per lane) of this lane's pixel
     const float om = valid ? 1.0f - alpha : 1.0f;
-    // exclusive product scan over the eight lanes: inside each quad first ...
-    float b1 = QUAD_F(om, QP(0, 0, 1, 2)); b1 = ((i & 3) >= 1) ? b1 : 1.0f;     // [1, o0, o1, o2]
-    float s1 = QUAD_F(b1, QP(0, 0, 1, 2)); s1 = ((i & 3) >= 1) ? s1 : 1.0f;     // [1, 1, o0, o1]
-    float s2 = QUAD_F(b1, QP(0, 0, 0, 1)); s2 = ((i & 3) >= 2) ? s2 : 1.0f;     // [1, 1, 1, o0]
-    float E = b1 * s1 * s2;                                                     // [1, o0, o0 o1, o0 o1 o2] per quad
-    // ... then the upper quad takes the lower quad's total (row_shr:4 written to banks 1 and 3 only)
-    const float Pq = QUAD_F(E * om, QP(3, 3, 3, 3));                            // product of the own quad
-    E *= ODPP_F(1.0f, Pq, DPP_ROW_SHR4, 0xA);
+    float E, prod;  // exclusive product of the group's lanes in front of this one; product of the whole group
+    if constexpr (LPP == 8) {
+      // inside each quad first ...
+      float b1 = QUAD_F(om, QP(0, 0, 1, 2)); b1 = ((i & 3) >= 1) ? b1 : 1.0f;     // [1, o0, o1, o2]
+      float s1 = QUAD_F(b1, QP(0, 0, 1, 2)); s1 = ((i & 3) >= 1) ? s1 : 1.0f;     // [1, 1, o0, o1]
+      float s2 = QUAD_F(b1, QP(0, 0, 0, 1)); s2 = ((i & 3) >= 2) ? s2 : 1.0f;     // [1, 1, 1, o0]
+      E = b1 * s1 * s2;                                                           // [1, o0, o0 o1, o0 o1 o2] per quad
+      // ... then the upper quad takes the lower quad's total (row_shr:4 written to banks 1 and 3 only)
+      const float Pq = QUAD_F(E * om, QP(3, 3, 3, 3));                            // product of the own quad
+      E *= ODPP_F(1.0f, Pq, DPP_ROW_SHR4, 0xA);
+      // product of all eight: the upper quad's running total, handed down to the lower quad (row_shl:4, banks 0 and 2)
+      const float X3 = QUAD_F(E * om, QP(3, 3, 3, 3));
+      prod = ODPP_F(X3, X3, DPP_ROW_SHL4, 0x5);
+    } else {
+      // inclusive scan in place (a lane whose DPP source is invalid or masked off is not written: the identity), one row of 16
+      // at a time, then the upper row of each half takes the lower row's total; the shift by one lane makes it exclusive
+      float inc = om;
+      E = 1.0f;  // (lane 0 has no source in the final shift)
+      asm volatile(
+          "s_nop 1\n\t"
+          "v_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+          "v_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+          "v_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+          "v_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+          "v_mul_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+          "v_mov_b32_dpp %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+          "s_nop 0"
+          : "+v"(inc), "+v"(E));
+      E = (i == 0) ? 1.0f : E;  // (lane 32 received the other pixel's total)
+      const float p_lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inc), 31));
+      const float p_hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inc), 63));
+      prod = (lane & 32) ? p_hi : p_lo;
+    }
     const float Tj = w.T * E;
     const float test_T = Tj * om;
     const bool sc = valid && (test_T < T_EPS);
     const uint64_t bits = __builtin_amdgcn_ballot_w64(sc);
-    const uint32_t ob = (uint32_t)(bits >> (lane & 56)) & 0xFFu;
+    const uint32_t ob = (uint32_t)(bits >> (lane & (64 - LPP))) & (uint32_t)((1ull << LPP) - 1ull);
     const bool first_stop_before = (ob & ((1u << i) - 1u)) != 0u;
     const bool use = valid && !sc && !first_stop_before;
     const float wt = use ? alpha * Tj : 0.f;
@@ -180,17 +220,14 @@ __device__ __forceinline__ void fw_composite_chunk(FwWalk& w, const int k, const
     w.D += xy.z * wt; w.A += wt;
     w.last = use ? (uint32_t)pos1 : w.last;
     if (sc && !first_stop_before) w.Tstop = Tj;  // transmittance in front of the instance that ends the pixel
-    // product of all eight: the upper quad's running total, handed down to the lower quad (row_shl:4, banks 0 and 2)
-    const float X3 = QUAD_F(E * om, QP(3, 3, 3, 3));
-    const float prod8 = ODPP_F(X3, X3, DPP_ROW_SHL4, 0x5);
     const bool nostop = (ob == 0u);
-    w.T = (nostop && !w.done) ? w.T * prod8 : w.T;
+    w.T = (nostop && !w.done) ? w.T * prod : w.T;
     w.done = w.done || !nostop;
   }
 }
 
 // The kernel's argument block, read where it is needed: the compiler loads every kernel argument it sees into scalar registers
-// at the kernel's entry and keeps them there — two registers per pointer, two dozen pointers that only the epilogue of a work
+// at the kernel's entry and keeps them there — two registers per pointer, a dozen pointers that only the epilogue of a work
 // item uses — and the main loop, which is short of them, then parks live scalars in vector-register lanes.  The epilogues
 // read their pointers through an opaque copy of the kernarg pointer instead.
 typedef const RenderArgs __attribute__((address_space(4))) FwLateArgs;
@@ -200,253 +237,162 @@ __device__ __forceinline__ FwLateArgs* fw_late_args() {
   return p;
 }
 
-struct FwItem {  // a work item of the forward: one 8 x 4 pixel block of one segment of one tile
-  int tile, sub, seg, total, index;
-  uint32_t list_start;  // range.x
-};
-struct FwPrefix {  // every pixel's state in front of a segment (the same in its eight lanes)
-  float T, c0, c1, c2, D, A;
-  uint32_t last;
-  bool stop;
-};
-struct FwPixel { int pxi, pyi, pix; bool inside; };
-__device__ __forceinline__ FwPixel fw_pixel(const int W, const int H, const int tile, const int sub, const int wave, const int pl) {
-  const int gx = (W + RIGGS_TILE - 1) / RIGGS_TILE;
-  const int prow = (sub >> 1) * 4 + wave, pcol = (sub & 1) * 8 + pl;  // pixel row / column inside the tile
-  FwPixel p;
-  p.pxi = (tile % gx) * RIGGS_TILE + pcol; p.pyi = (tile / gx) * RIGGS_TILE + prow;
-  p.inside = p.pxi < W && p.pyi < H;
-  p.pix = prow * 16 + pcol;  // pixel index inside the tile (checkpoint layout)
-  return p;
-}
-__device__ __forceinline__ float* fw_state_ptr(float* seg_state, const FwItem& it, const int pix, int sg, int word) {
-  const uint32_t sslot0 = it.list_start / RIGGS_SEG + (uint32_t)it.tile;  // segment slot of the tile's segment 0
-  return seg_state + ((size_t)(sslot0 + sg) * RIGGS_SEG_WORDS + word) * 256 + pix;
-}
-__device__ __forceinline__ uint32_t* fw_flag_ptr(uint32_t* seg_flags, const FwItem& it, int sg) {
-  const uint32_t sslot0 = it.list_start / RIGGS_SEG + (uint32_t)it.tile;
-  return seg_flags + (size_t)(sslot0 + sg) * 8 + it.sub;
-}
-// the block's pixels between the main loop and fw_combine: (T — the final T of a stopped pixel —, C0, C1, C2, D, A, last, stopped)
-__shared__ float fw_st[8][32];
-
-// A HELPER's end: publish the states at the start of rounds 1 .. (from LDS: written by this wave) and the end state — lane i
-// writes word i —, then the hand-shake.  (A function of its own, NOT inlined, like fw_combine below: their address arithmetic
-// and state must not lengthen the live ranges of the main loop, which runs at exactly the register budget of six waves per
-// SIMD — a spilled register there is reloaded through the vector memory queue, BEHIND the prefetched gathers of the next
-// round (vmcnt retires in order), and the software pipeline of the rounds is gone: measured, 2.3 -> 7 us per round.
-// Everything is passed by value, in registers: a reference to a kernel-side object would pin it in scratch memory.)
-struct FwEnd { float T, k0, k1, k2, kd, ka; uint32_t lm; bool done; };
-__device__ __attribute__((noinline)) void fw_publish(float* seg_state, uint32_t* seg_flags, const FwItem it, const int pix, const FwEnd end) {
-  const int tid = threadIdx.x, lane = tid & 63, i = lane & 7, bp = (tid >> 6) * 8 + (lane >> 3);
-  for (int e = 0; e < FW_NR - 1; e++) st_agent(fw_state_ptr(seg_state, it, pix, it.seg, 8 * e + i), fw_rs[e][i][bp]);
-  const float v = (i == 0) ? (end.done ? 0.f : end.T) : (i == 1) ? end.k0 : (i == 2) ? end.k1 : (i == 3) ? end.k2 : (i == 4) ? end.kd
-                  : (i == 5) ? end.ka : __uint_as_float(end.lm);
-  st_agent(fw_state_ptr(seg_state, it, pix, it.seg, 8 * (FW_NR - 1) + i), v);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // performed
-  __syncthreads();
-  if (tid == 0) (void)__hip_atomic_fetch_or((seg_gu32*)fw_flag_ptr(seg_flags, it, it.seg), SEG_SUMMARY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// The OWNER's way from the first segment whose summary it found (see the comment above) to the end of the list — the rare,
-// cold part of its walk, in a function of its own so that the main loop stays what it was.  The block's state travels through
-// fw_st.  Here every WAVE goes its own way with its eight pixels (a pixel row of the block), without a barrier: it looks at the
-// hand-shake words itself, keeps its instances in its own quarter of the staging buffer, culls against its own row.
-//  * A RUN of consecutive summarized segments (up to FW_RUN) is combined at once: a scan per pixel over the segments' end states
-//    finds the segment in which it stops (the first one where T_in * P falls below 1e-4) and leaves every segment's prefix for
-//    the backward; then only the rounds in which a pixel of the wave stops are composited again, chunk by chunk with the code
-//    of the main loop, each from the true state at its start (prefix x the helper's round state).
-//  * A segment that is not summarized is claimed and walked the same way, chunk by chunk — with its checkpoints unless a helper
-//    has started on it (then they are the helper's, and the prefix is the true one).
-// Whether a wave sees a summary that another wave of the block just missed does not matter: prefixes and checkpoints are per
-// pixel, and the claim / started words say who owns a segment's checkpoints for the whole block.
-#define FW_RUN 4
-__shared__ unsigned long long fw_wmask[4];  // per wave: rounds of the run in which one of its pixels stops
-__shared__ int fw_wend[4];                  // per wave: the segment its walk ended in front of, or -1 while pixels are alive
-template <bool TRACE>
-__device__ __attribute__((noinline)) int fw_owner_rest(const RenderArgs* kernargs, const FwItem it, int s) {
-  const RenderArgs& a = *kernargs;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pl = lane >> 3, i = lane & 7, bp = wave * 8 + pl;
-  const FwPixel px = fw_pixel(a.W, a.H, it.tile, it.sub, wave, pl);
+// one work item: a block of 256 / LPP pixels of one tile (LPP = 8: 8 x 4, one pixel row per wave; LPP = 32: 4 x 2, two
+// neighbouring pixels per wave), its list walked front to back
+template <int LPP, bool TRACE>
+__device__ __forceinline__ void fw_block(const RenderArgs& a, const int tile, const int sub, const int index) {
+  constexpr int B = FW_B, LEAD = FwGeom<LPP>::LEAD;
   const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE;
-  const float pfx = (float)px.pxi, pfy = (float)px.pyi;
-  const float bx0 = (float)((it.tile % gx) * RIGGS_TILE + (it.sub & 1) * 8);
-  const float wy = (float)((it.tile / gx) * RIGGS_TILE + (it.sub >> 1) * 4 + wave);  // the wave's pixel row
-  const int total = it.total, nseg = (total + RIGGS_SEG - 1) / RIGGS_SEG;
-  const uint32_t slot0 = a.slot_base[it.tile];
-  const unsigned long long t_chain = (TRACE && a.trace) ? wall_clock64() : 0ull;
-  uint32_t st_steps = 0, st_walk = 0, st_a = 0, st_b = 0, st_runs = 0, st_own = 0;
-  FwPrefix p;
-  p.T = fw_st[0][bp]; p.c0 = fw_st[1][bp]; p.c1 = fw_st[2][bp]; p.c2 = fw_st[3][bp]; p.D = fw_st[4][bp]; p.A = fw_st[5][bp];
-  p.last = __float_as_uint(fw_st[6][bp]); p.stop = fw_st[7][bp] != 0.f;
-  auto seed = [&](FwWalk& w, const FwPrefix& q) {
-    w.T = q.T; w.Tstop = -1.0f; w.last = q.last; w.done = q.stop;
-    w.C0 = (i == 0) ? q.c0 : 0.f; w.C1 = (i == 0) ? q.c1 : 0.f; w.C2 = (i == 0) ? q.c2 : 0.f; w.D = (i == 0) ? q.D : 0.f; w.A = (i == 0) ? q.A : 0.f;
-  };
-  auto harvest = [&](const FwWalk& w, FwPrefix& q) {  // (every lane of the eight takes part)
-    const float f0 = oct_sum(w.C0), f1 = oct_sum(w.C1), f2 = oct_sum(w.C2), fd = oct_sum(w.D), fa = oct_sum(w.A);
-    const float t2 = oct_max(w.Tstop);
-    const uint32_t l2 = oct_max_u(w.last);
-    q.c0 = f0; q.c1 = f1; q.c2 = f2; q.D = fd; q.A = fa; q.last = l2;
-    q.stop = w.done;
-    q.T = (t2 >= 0.f) ? t2 : w.T;  // (T of a stopped pixel: the transmittance in front of the instance that ended it)
-  };
-  auto put_prefix = [&](const int sg, const FwPrefix& q) {
-    if (i < 5) *fw_state_ptr(a.seg_state, it, px.pix, sg, RIGGS_SEG_PREFIX + i) = (i == 0) ? q.T : (i == 1) ? q.c0 : (i == 2) ? q.c1 : (i == 3) ? q.c2 : q.D;
-  };
-  // the wave walks instances [from, to) of the list (from a multiple of 64) with its eight pixels, 64 at a time: list entry two
-  // chunks ahead, records one ahead; `base` of a chunk's round = what n_contrib counts from; ck: store the (absolute) checkpoints
-  auto walk = [&](FwWalk& w, const int from, const int to, const bool ck) {
-    auto load_id = [&](const int cb) { return (cb + lane < to) ? a.point_list[it.list_start + cb + lane] : 0xFFFFFFFFu; };
-    uint32_t id1 = load_id(from), id2 = load_id(from + 64);
-    float4 xy = make_float4(0.f, 0.f, 0.f, 0.f), co = xy, cc = xy;
-    if (id1 != 0xFFFFFFFFu) { xy = a.xyd[id1]; co = a.conic_o[id1]; cc = a.rgb[id1]; }
-    for (int cb = from; cb < to; cb += 64) {
-      if (__builtin_amdgcn_ballot_w64(!w.done) == 0) break;
-      if constexpr (TRACE) st_walk++;
-      fw_stage_chunk(wave, lane, (cb & (FW_B - 1)) + lane, id1 != 0xFFFFFFFFu, xy, co, cc, bx0, bx0 + 7.0f, wy, wy);
-      id1 = id2;
-      id2 = load_id(cb + 128);
-      xy = make_float4(0.f, 0.f, 0.f, 0.f); co = xy; cc = xy;
-      if (id1 != 0xFFFFFFFFu) { xy = a.xyd[id1]; co = a.conic_o[id1]; cc = a.rgb[id1]; }
-      if (ck) {
-        const float k0 = oct_sum(w.C0), k1 = oct_sum(w.C1), k2 = oct_sum(w.C2), kd = oct_sum(w.D);
-        if (!w.done && i < 5)
-          a.ckpt[((size_t)(slot0 + (cb >> 6)) * 5 + i) * 256 + px.pix] = (i == 0) ? w.T : (i == 1) ? k0 : (i == 2) ? k1 : (i == 3) ? k2 : kd;
-      }
-      fw_composite_chunk<false>(w, wave, cb & ~(FW_B - 1), lane, pfx, pfy, st_a, st_b);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & (LPP - 1);
+  int prow, pcol, brow, bcol;  // the pixel and the block's first pixel inside the tile
+  if constexpr (LPP == 8) {
+    brow = (sub >> 1) * 4; bcol = (sub & 1) * 8;
+    prow = brow + wave; pcol = bcol + (lane >> 3);
+  } else {
+    brow = (sub >> 2) * 2; bcol = (sub & 3) * 4;
+    const int p = wave * 2 + (lane >> 5);
+    prow = brow + (p >> 2); pcol = bcol + (p & 3);
+  }
+  const int pxi = (tile % gx) * RIGGS_TILE + pcol, pyi = (tile / gx) * RIGGS_TILE + prow;
+  const bool inside = pxi < a.W && pyi < a.H;
+  const int pix = prow * 16 + pcol;  // pixel index inside the tile (checkpoint layout)
+  const float pfx = (float)pxi, pfy = (float)pyi;
+  const uint2 range = a.ranges[tile];
+  const int total = (int)(range.y - range.x);
+  const uint32_t slot0 = a.slot_base[tile];
+  const float bx0 = (float)((tile % gx) * RIGGS_TILE + bcol), by0 = (float)((tile / gx) * RIGGS_TILE + brow);
+  FwWalk w;
+  w.done = !inside; w.T = 1.0f; w.Tstop = -1.0f; w.last = 0u;
+  w.C0 = 0.f; w.C1 = 0.f; w.C2 = 0.f; w.D = 0.f; w.A = 0.f;
+  const unsigned long long t_begin = (TRACE && a.trace) ? wall_clock64() : 0ull;
+  uint32_t st_rounds = 0, st_surv = 0, st_iters = 0, st_full = 0;
+  // checkpoints are held one round (lane LEAD + k of a pixel's group keeps chunk k's) and stored ahead of the next round's loads
+  float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;
+  bool hv = false;
+  int hbase = 0;
+  auto flush_ckpt = [&]() {
+    if (hv) {
+      float* ck = a.ckpt + ((size_t)(slot0 + (hbase >> 6) + (i - LEAD)) * 5) * 256 + pix;
+      ck[0] = h0; ck[256] = h1; ck[512] = h2; ck[768] = h3; ck[1024] = h4;
     }
+    hv = false;
   };
-  for (;;) {
-    if (__builtin_amdgcn_ballot_w64(!p.stop) == 0 || s >= nseg) break;
-    // the run of summarized segments that starts at s (lane j looks at segment s + j); none: claim segment s
-    int k;
-    bool started = false;
+  // prefetch registers for the next round (one instance per thread) and the list entry of the round after it.  The loads are
+  // unconditional, with the index clamped into the list (a lane past the end re-reads the last instance; fw_stage_round drops
+  // it): a conditional load of a float4 makes the compiler split the vector and copy a component out right behind the load —
+  // an s_waitcnt in the middle of the gathers, one exposed memory latency per round.
+  const uint32_t last_entry = range.y - 1u;  // (total >= 1: only non-empty tiles are work items)
+  float4 n_xy, n_co, n_cc;
+  uint32_t n_id = a.point_list[min(range.x + (uint32_t)(B + tid), last_entry)];
+  {
+    const uint32_t id = a.point_list[min(range.x + (uint32_t)tid, last_entry)];
+    n_xy = a.xyd[id]; n_co = a.conic_o[id]; n_cc = a.rgb[id];
+  }
+  unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, tc = TRACE ? clock64() : 0ull;  // (TRACE) shader clocks per phase of the rounds
+  auto lap = [&](unsigned long long& acc) { if constexpr (TRACE) { const unsigned long long t = clock64(); acc += t - tc; tc = t; } };
+  for (int base = 0; base < total; base += B) {
+    if (__syncthreads_count(w.done) == 256) break;
+    lap(ph0);
     {
-      const bool in = lane < FW_RUN && s + lane < nseg;
-      uint32_t f = in ? ld_agent_u(fw_flag_ptr(a.seg_flags, it, s + lane)) : 0u;
-      const unsigned long long ready = __builtin_amdgcn_ballot_w64(in && (f & SEG_SUMMARY));
-      k = __builtin_ctzll(~ready);
-      if (k == 0) {
-        if (lane == 0) f = __hip_atomic_fetch_or((seg_gu32*)fw_flag_ptr(a.seg_flags, it, s), SEG_CLAIM, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        f = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);
-        if (f & SEG_SUMMARY) k = 1;
-        started = (f & SEG_STARTED) != 0u;
-      }
+      const int cnt = fw_stage_round<LPP>(tid, base + tid < total, n_xy, n_co, n_cc, bx0, by0);
+      if constexpr (TRACE) st_surv += (uint32_t)cnt;
     }
-    if constexpr (TRACE) { st_runs++; if (k == 0) st_own++; }
-    if (k == 0) {
-      // walk segment s
-      const int s_lo = s * RIGGS_SEG, s_hi = min(total, s_lo + RIGGS_SEG);
-      if (started) put_prefix(s, p);
-      else if (i < 5) *fw_state_ptr(a.seg_state, it, px.pix, s, RIGGS_SEG_PREFIX + i) = (i == 0) ? 1.0f : 0.f;
-      FwWalk w;
-      seed(w, p);
-      walk(w, s_lo, s_hi, !started);
-      FwPrefix q;
-      harvest(w, q);
-      if (!p.stop) p = q;
-      s++;
-      continue;
+    if constexpr (TRACE) st_rounds++;
+    flush_ckpt();
+    hbase = base;
+    __syncthreads();
+    lap(ph1);
+    {
+      const uint32_t id = n_id;
+      n_xy = a.xyd[id]; n_co = a.conic_o[id]; n_cc = a.rgb[id];
+      n_id = a.point_list[min(range.x + (uint32_t)(base + 2 * B + tid), last_entry)];
     }
-    // ---- combine segments s .. s + k - 1: lane i holds word i of their end states
-    if constexpr (TRACE) st_steps += (uint32_t)k;
-    float ev[FW_RUN];
-#pragma unroll
-    for (int j = 0; j < FW_RUN; j++) ev[j] = (j < k) ? ld_agent(fw_state_ptr(a.seg_state, it, px.pix, s + j, 8 * (FW_NR - 1) + i)) : 0.f;
-    int jstar = -1;  // the segment of the run in which the pixel stops
-#pragma unroll
-    for (int j = 0; j < FW_RUN; j++) {
-      const float eP = oct_get(ev[j], 0, lane), e0 = oct_get(ev[j], 1, lane), e1 = oct_get(ev[j], 2, lane), e2 = oct_get(ev[j], 3, lane),
-                  eD = oct_get(ev[j], 4, lane), eA = oct_get(ev[j], 5, lane);
-      const uint32_t eL = __float_as_uint(oct_get(ev[j], 6, lane));
-      if (j < k && !p.stop && jstar < 0) {
-        put_prefix(s + j, p);
-        const float tp = p.T * eP;
-        if (tp >= T_EPS) {
-          p.c0 += p.T * e0; p.c1 += p.T * e1; p.c2 += p.T * e2; p.D += p.T * eD; p.A += p.T * eA;
-          p.last = eL ? eL : p.last;
-          p.T = tp;
-        } else jstar = j;  // (p stays the prefix of segment s + jstar)
+    lap(ph2);
+#pragma unroll 1
+    for (int k = 0; k < B / 64; k++) {
+      const int cbase = base + 64 * k;
+      if (cbase >= total) break;
+      if (__builtin_amdgcn_ballot_w64(!w.done) == 0) break;
+      {
+        // checkpoint of the state BEFORE instance cbase: fold the lanes' partial sums
+        const float k0 = grp_sum<LPP>(w.C0), k1 = grp_sum<LPP>(w.C1), k2 = grp_sum<LPP>(w.C2), kd = grp_sum<LPP>(w.D);
+        if (i == LEAD + k) { h0 = w.T; h1 = k0; h2 = k1; h3 = k2; h4 = kd; hv = !w.done; }
       }
+      fw_composite_chunk<LPP, TRACE>(w, k, base, lane, pfx, pfy, st_iters, st_full);
     }
-    // the round of that segment: the first one at whose END T_in * T_local is below the threshold; its start state
-    int Rstar = 64;  // linear round index in the run (64: none)
-    FwPrefix q = p;
-    if (lane == 0) fw_wmask[wave] = 0ull;
-    if (__builtin_amdgcn_ballot_w64(jstar >= 0) != 0ull) {
-      float e3[FW_NR - 1];
-#pragma unroll
-      for (int e = 0; e < FW_NR - 1; e++) e3[e] = (jstar >= 0) ? ld_agent(fw_state_ptr(a.seg_state, it, px.pix, s + jstar, 8 * e + i)) : 0.f;
-      int rstar = FW_NR - 1;
-#pragma unroll
-      for (int r = FW_NR - 2; r >= 0; r--) if (p.T * oct_get(e3[r], 0, lane) < T_EPS) rstar = r;
-#pragma unroll
-      for (int e = 0; e < FW_NR - 1; e++) {
-        const float eT = oct_get(e3[e], 0, lane), e0 = oct_get(e3[e], 1, lane), e1 = oct_get(e3[e], 2, lane), e2 = oct_get(e3[e], 3, lane),
-                    eD = oct_get(e3[e], 4, lane), eA = oct_get(e3[e], 5, lane);
-        const uint32_t eL = __float_as_uint(oct_get(e3[e], 6, lane));
-        if (jstar >= 0 && rstar == e + 1) {
-          q.T = p.T * eT; q.c0 = p.c0 + p.T * e0; q.c1 = p.c1 + p.T * e1; q.c2 = p.c2 + p.T * e2; q.D = p.D + p.T * eD; q.A = p.A + p.T * eA;
-          q.last = eL ? eL : p.last;
-        }
-      }
-      if (jstar >= 0) {
-        Rstar = jstar * FW_NR + rstar;
-        if (i == 0) atomicOr(&fw_wmask[wave], 1ull << Rstar);
-      }
-      // composite again, from the true state: every round in which a pixel of the wave stops (and, should the rounding of T_in * P
-      // have promised a stop that the instance-by-instance product does not find, the rounds behind it — until the run ends)
-      unsigned long long todo = fw_wmask[wave];
-      const int run_lo = s * RIGGS_SEG, run_hi = min(total, (s + k) * RIGGS_SEG);
-      FwWalk w;
-      w.T = 1.0f; w.C0 = 0.f; w.C1 = 0.f; w.C2 = 0.f; w.D = 0.f; w.A = 0.f; w.Tstop = -1.0f; w.last = 0u; w.done = true;
-      bool walking = false;
-      int R = __builtin_ctzll(todo);
-      for (;;) {
-        const int base = run_lo + R * FW_B;
-        if (Rstar == R) { walking = true; seed(w, q); w.done = false; }
-        if ((R % FW_NR) == 0) {  // (uniform: every lane takes part in the shuffles of harvest)
-          FwPrefix t;
-          harvest(w, t);
-          if (walking && !w.done && R > Rstar) put_prefix(s + R / FW_NR, t);  // a walk that crosses into the next segment: its true prefix
-        }
-        todo &= ~(1ull << R);
-        walk(w, base, min(base + FW_B, run_hi), false);
-        const bool goes_on = __builtin_amdgcn_ballot_w64(walking && !w.done) != 0ull && base + FW_B < run_hi;
-        const int Rn = goes_on ? R + 1 : (todo ? __builtin_ctzll(todo) : 64);
-        if (Rn >= 64 || run_lo + Rn * FW_B >= run_hi) break;
-        R = Rn;
-      }
-      FwPrefix t;
-      harvest(w, t);
-      if (walking) p = t;
-    }
-    s += k;
+    lap(ph3);
   }
-  // the block's end: every pixel final -> later segments are nobody's business any more
-  if (lane == 0) fw_wend[wave] = (__builtin_amdgcn_ballot_w64(!p.stop) == 0ull) ? s : -1;
-  if (i == 0) {
-    fw_st[0][bp] = p.T; fw_st[1][bp] = p.c0; fw_st[2][bp] = p.c1; fw_st[3][bp] = p.c2; fw_st[4][bp] = p.D; fw_st[5][bp] = p.A;
-    fw_st[6][bp] = __uint_as_float(p.last); fw_st[7][bp] = p.stop ? 1.0f : 0.f;
+  if (TRACE && a.trace && lane == 0 && (uint64_t)index < fw_late_args()->trace_items) {
+    unsigned long long* tr = a.trace + ((size_t)index * 4 + wave) * 8;
+    tr[6] = t_begin;
+    tr[0] = wall_clock64() - t_begin; tr[1] = st_rounds;
+    tr[2] = (unsigned long long)st_surv | ((unsigned long long)(__builtin_amdgcn_s_getreg(63492) & 0xFFFFu) << 32) | ((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 0xFu) << 48);
+    tr[3] = st_iters; tr[4] = st_full;
+    tr[5] = (unsigned long long)total | ((unsigned long long)tile << 32) | (LPP == 32 ? 1ull << 63 : 0ull);
+    tr[7] = min(ph0 >> 6, 0xFFFFull) | (min(ph1 >> 6, 0xFFFFull) << 16) | (min(ph2 >> 6, 0xFFFFull) << 32) | (min(ph3 >> 6, 0xFFFFull) << 48);
   }
-  __syncthreads();
-  const int e0 = fw_wend[0], e1 = fw_wend[1], e2 = fw_wend[2], e3 = fw_wend[3];
-  const int smax = max(max(e0, e1), max(e2, e3));
-  if (tid == 0 && e0 >= 0 && e1 >= 0 && e2 >= 0 && e3 >= 0 && smax < nseg)
-    __hip_atomic_store((seg_gu32*)(a.dead_from + (size_t)it.tile * 8 + it.sub), (uint32_t)smax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (TRACE && a.trace && lane == 0 && (uint64_t)it.index < a.trace_items)
-    a.trace[((size_t)it.index * 4 + wave) * 8 + 7] = (wall_clock64() - t_chain) | ((unsigned long long)st_steps << 32) | ((unsigned long long)st_walk << 44) |
-                                                       ((unsigned long long)st_runs << 54) | ((unsigned long long)st_own << 59);
-  return max(smax, s);  // (segments the block's pixels went through)
+  flush_ckpt();
+  // fold the lanes (the lanes i >= LEAD of a pixel end up with the same values)
+  const float k0 = grp_sum<LPP>(w.C0), k1 = grp_sum<LPP>(w.C1), k2 = grp_sum<LPP>(w.C2), kd = grp_sum<LPP>(w.D), ka = grp_sum<LPP>(w.A);
+  const float ts = grp_max<LPP>(w.Tstop);
+  const uint32_t lm = grp_max_u<LPP>(w.last);
+  const float Tfin = (ts >= 0.f) ? ts : w.T;
+  {
+    FwLateArgs& l = *fw_late_args();
+    if (inside && i == LEAD) {
+      const size_t pid = (size_t)pyi * l.W + pxi, HW = (size_t)l.H * l.W;
+      l.final_T[pid] = Tfin;
+      l.n_contrib[pid] = lm;
+      l.final_acc[pid] = make_float4(k0, k1, k2, kd);
+      l.out_color[pid] = k0 + Tfin * l.bg[0];
+      l.out_color[HW + pid] = k1 + Tfin * l.bg[1];
+      l.out_color[2 * HW + pid] = k2 + Tfin * l.bg[2];
+      l.out_depth[pid] = kd;
+      l.out_alpha[pid] = ka;
+    }
+  }
+  uint32_t m = (inside && i >= LEAD) ? lm : 0u;
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+  if (lane == 0) fw_wmax[wave] = m;
+  __syncthreads();  // (fw_wmax is complete)
+  // ---- work list of the backward.  A tile's instances past its last contributor (tile_max = max n_contrib over its 256
+  // pixels) need no backward, so the list holds one entry per 64-instance chunk below it.  Every block of the tile folds
+  // its maximum into tile_max and takes a ticket; the block that draws the last ticket knows the final value and appends
+  // the tile's entries (tile, chunk, start of the tile's list, instances to walk) — a separate list-building launch used to
+  // cost 10 us.  Both words are only ever touched with agent-scope atomics, and a block takes its ticket after its
+  // maximum has RETURNED (the returning atomic has been performed), so the last ticket holder reads the final maximum.
+  // The list's size word (work_ctr) lives on a cache line of ITS OWN: sharing one with item_ctr — which every one of the
+  // launch's 20 000 workgroups reads when it starts — cost 17 us (each of the ~470 atomics throws the line out of the L2s,
+  // and the late-dispatched workgroups queue behind it at the memory side).
+  // Only wave 0 stays for this (two dependent atomic round trips to the memory side, ~4 us): the other three waves leave.
+  if (wave == 0) {
+    FwLateArgs& l = *fw_late_args();
+    uint32_t n_c = 0u, wbase = 0u, limit = 0u;
+    if (lane == 0) {
+      const uint32_t mb = max(max(fw_wmax[0], fw_wmax[1]), max(fw_wmax[2], fw_wmax[3]));
+      const uint32_t before = __hip_atomic_fetch_max(&l.tile_max[tile], mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const uint32_t ticket = __hip_atomic_fetch_add(&l.tile_ticket[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (ticket == (uint32_t)LPP - 1u) {  // LPP blocks of 256 / LPP pixels per tile
+        limit = max(max(before, mb), __hip_atomic_load(&l.tile_max[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        limit = min((uint32_t)total, limit);
+        l.walk_hist[tile] = limit;  // (for the next frame's work list: how deep this tile's walk went)
+        n_c = (limit + 63u) >> 6;
+        if (n_c) wbase = __hip_atomic_fetch_add(l.work_ctr, 4u * n_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 2;  // (quarter-chunks)
+      }
+    }
+    n_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_c);
+    wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+    limit = (uint32_t)__builtin_amdgcn_readfirstlane((int)limit);
+    for (uint32_t k = lane; k < n_c; k += 64) l.work[wbase + k] = make_uint4((uint32_t)tile, k, range.x, limit);
+  }
 }
 
 template <bool TRACE>
 __global__ __launch_bounds__(256, 6) void render_fwd_oct_kernel(RenderArgs a) {
-  constexpr int B = FW_B;
   const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int pl = lane >> 3, i = lane & 7;
+  const int tid = threadIdx.x;
   {
     // tiles without instances: background only, one pixel per thread (a.items == NULL: nothing was binned — no
     // Gaussians or an empty arena — and every tile is such a tile)
@@ -464,271 +410,61 @@ __global__ __launch_bounds__(256, 6) void render_fwd_oct_kernel(RenderArgs a) {
       }
     }
   }
-  // work list: (tile, segment) entries in the order the extra workgroup of bin_scatter_kernel wrote them (first segments of
-  // the longest lists first, deeper segments behind all first ones), eight 8x4 pixel blocks each
-  // (one item per workgroup — the launch covers the capacity of the list: an outer loop over items makes every item-invariant
-  // scalar a loop invariant that the compiler computes up front and keeps, in vector-register lanes once the scalar file is full)
-  const int n_items = a.items ? (int)a.item_ctr[0] * 8 : 0;
-  FwItem item;
-  item.index = (int)blockIdx.x;
-  {
-    // the eight blocks of an entry get workgroup ids 8 apart = the same XCD / L2 (workgroup b runs on XCD b % 8)
-    const int it = item.index, full = (n_items >> 6) << 6;
-    if (it >= n_items) return;
-    int p;
-    if (it < full) { p = ((it >> 6) << 3) + (it & 7); item.sub = (it >> 3) & 7; }
-    else { p = (full >> 3) + ((it - full) >> 3); item.sub = (it - full) & 7; }
-    const uint32_t e = a.items[p];
-    item.tile = (int)(e & 0xFFFFu); item.seg = (int)(e >> 16);
-  }
-  const int tile = item.tile, sub = item.sub, seg = item.seg;
-  const uint2 range = a.ranges[tile];
-  const int total = (int)(range.y - range.x);
-  item.total = total; item.list_start = range.x;
-  const bool helper = seg > 0;                            // (implies a segmented tile)
-  const bool owner_multi = !helper && total > RIGGS_SEG;  // the owner of a segmented tile
-  if (helper) {
-    // leave if every pixel of the block stopped in front of this segment, if the owner has claimed it — or the segment in front
-    // of it: it is walking that one now and will be here before this workgroup is done —, or in the reproducible mode
-    if (tid == 0) {
-      const uint32_t d = ld_agent_u(a.dead_from + (size_t)tile * 8 + sub);
-      const uint32_t fb = seg > 1 ? ld_agent_u(fw_flag_ptr(a.seg_flags, item, seg - 1)) : 0u;  // (segment 0 is always the owner's: no word)
-      uint32_t skip = ((d != 0u && (uint32_t)seg >= d) || (fb & SEG_CLAIM) || a.deterministic) ? 1u : 0u;
-      if (!skip) {  // the segment's checkpoints are this workgroup's unless the owner was first
-        const uint32_t old = __hip_atomic_fetch_or((seg_gu32*)fw_flag_ptr(a.seg_flags, item, seg), SEG_STARTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        skip = (old & SEG_CLAIM) ? 1u : 0u;
-      }
-      fw_word = skip;
-    }
-    __syncthreads();
-    const uint32_t w0 = fw_word;
-    __syncthreads();
-    if (w0) return;
-    if (tid < 32) for (int e = 0; e < FW_NR - 1; e++) fw_rs[e][0][tid] = 0.f;  // "not reached" until a round says otherwise
-  }
-  const int lo = helper ? seg * RIGGS_SEG : 0, hi = helper ? min(total, lo + RIGGS_SEG) : total;
-  const FwPixel px = fw_pixel(a.W, a.H, tile, sub, wave, pl);
-  const float pfx = (float)px.pxi, pfy = (float)px.pyi;
-  const uint32_t slot0 = a.slot_base[tile];
-  const float bx0 = (float)((tile % gx) * RIGGS_TILE + (sub & 1) * 8), by0 = (float)((tile / gx) * RIGGS_TILE + (sub >> 1) * 4);
-  FwWalk w;
-  w.done = !px.inside; w.T = 1.0f; w.Tstop = -1.0f; w.last = 0u;
-  w.C0 = 0.f; w.C1 = 0.f; w.C2 = 0.f; w.D = 0.f; w.A = 0.f;
-  const unsigned long long t_begin = (TRACE && a.trace) ? wall_clock64() : 0ull;
-  uint32_t st_rounds = 0, st_surv = 0, st_iters = 0, st_full = 0;
-  if (TRACE && a.trace && lane == 0 && (uint64_t)item.index < fw_late_args()->trace_items) a.trace[((size_t)item.index * 4 + wave) * 8 + 7] = 0ull;
-  // checkpoints are held one round (lane i keeps chunk i's) and stored ahead of the next round's loads
-  float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;
-  bool hv = false;
-  int hbase = 0;
-  bool ck_on = true;  // (owner) false while it walks a segment whose checkpoints a helper stores
-  auto flush_ckpt = [&]() {
-    if (hv) {
-      float* ck = a.ckpt + ((size_t)(slot0 + (hbase >> 6) + i) * 5) * 256 + px.pix;
-      ck[0] = h0; ck[256] = h1; ck[512] = h2; ck[768] = h3; ck[1024] = h4;
-    }
-    hv = false;
-  };
-  // prefetch registers for the next round (one instance per thread) and the list entry of the round after it
-  float4 n_xy = make_float4(0.f, 0.f, 0.f, 0.f), n_co = n_xy, n_cc = n_xy;
-  uint32_t n_id = 0u;
-  if (lo + B + tid < hi) n_id = a.point_list[range.x + lo + B + tid];
-  if (lo + tid < hi) {
-    const uint32_t id = a.point_list[range.x + lo + tid];
-    n_xy = a.xyd[id]; n_co = a.conic_o[id]; n_cc = a.rgb[id];
-  }
-  uint32_t dnext = 0u;              // (helper) the block's dead_from word, read a round ahead
-  uint32_t claim = 0u;              // (owner, thread 0) what the claim of the next segment returned, requested a round ahead
-  bool dead = false;
-  int resume = 0;  // (owner) the segment from which fw_owner_rest takes over, if any
-  for (int base = lo; base < hi; base += B) {
-    if (helper) {
-      dead = dead || (dnext != 0u && (uint32_t)seg >= dnext);
-      w.done = w.done || dead;
-      dnext = ld_agent_u(a.dead_from + (size_t)tile * 8 + sub);
-    }
-    const bool boundary = owner_multi && base > 0 && (base & (RIGGS_SEG - 1)) == 0;  // the owner enters a new segment
-    if (boundary && tid == 0) {
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(claim) :: "memory");  // (the claim's result, requested a round ago)
-      fw_word = claim;
-    }
-    if (__syncthreads_count(w.done) == 256) break;
-    if (boundary) {
-      const uint32_t f = fw_word;
-      if (f & SEG_SUMMARY) { resume = base / RIGGS_SEG; break; }  // a helper has composited this segment: the rest of the walk is fw_owner_rest's
-      ck_on = !(f & SEG_STARTED);
-      if (ck_on) {
-        // the segment's checkpoints are this workgroup's, absolute ones: the backward finds the identity as the segment's prefix
-        if (i < 5) *fw_state_ptr(a.seg_state, item, px.pix, base / RIGGS_SEG, RIGGS_SEG_PREFIX + i) = (i == 0) ? 1.0f : 0.f;
-      } else {
-        // a helper is at work on this segment and stores its (segment-local) checkpoints: walk it for the state only, and
-        // leave the true prefix for the backward
-        const float k0 = oct_sum(w.C0), k1 = oct_sum(w.C1), k2 = oct_sum(w.C2), kd = oct_sum(w.D);
-        if (i < 5) *fw_state_ptr(a.seg_state, item, px.pix, base / RIGGS_SEG, RIGGS_SEG_PREFIX + i) = (i == 0) ? w.T : (i == 1) ? k0 : (i == 2) ? k1 : (i == 3) ? k2 : kd;
-      }
-    }
-    if (owner_multi && (base & (RIGGS_SEG - 1)) == RIGGS_SEG - B && base + B < hi && tid == 0) {
-      // the last round of a segment: claim the next one.  The returning atomic is written in assembly so that its result is
-      // waited for where it is read, one round later (the compiler waits for a result defined under a divergent branch at the
-      // end of the branch: a round trip to the memory side on the critical path of every segment).  The hardware retires
-      // vector memory operations in order, so the compiler's own counts stay conservative.
-      const uint32_t* fp = fw_flag_ptr(a.seg_flags, item, base / RIGGS_SEG + 1);
-      asm volatile("global_atomic_or %0, %1, %2, off sc0" : "=v"(claim) : "v"(fp), "v"(SEG_CLAIM) : "memory");
-    }
-    {
-      const int cnt = fw_stage_round(tid, base + tid < hi, n_xy, n_co, n_cc, bx0, by0);
-      if constexpr (TRACE) st_surv += (uint32_t)cnt;
-    }
-    if constexpr (TRACE) st_rounds++;
-    flush_ckpt();
-    hbase = base;
-    __syncthreads();
-    {
-      n_xy = make_float4(0.f, 0.f, 0.f, 0.f); n_co = n_xy; n_cc = n_xy;
-      if (base + B + tid < hi) {
-        const uint32_t id = n_id;
-        n_xy = a.xyd[id]; n_co = a.conic_o[id]; n_cc = a.rgb[id];
-      }
-      if (base + 2 * B + tid < hi) n_id = a.point_list[range.x + base + 2 * B + tid];
-    }
-    if (helper && base > lo) {  // a helper keeps the state at the start of its rounds for the owner
-      const float k0 = oct_sum(w.C0), k1 = oct_sum(w.C1), k2 = oct_sum(w.C2), kd = oct_sum(w.D), fa = oct_sum(w.A);
-      const uint32_t lf = oct_max_u(w.last);
-      if (i == 0) {
-        const int bp = wave * 8 + pl;
-        float (*e)[32] = fw_rs[(base - lo) / B - 1];
-        e[0][bp] = w.done ? 0.f : w.T; e[1][bp] = k0; e[2][bp] = k1; e[3][bp] = k2; e[4][bp] = kd; e[5][bp] = fa; e[6][bp] = __uint_as_float(lf);
-      }
-    }
-#pragma unroll 1
-    for (int k = 0; k < B / 64; k++) {
-      const int cbase = base + 64 * k;
-      if (cbase >= hi) break;
-      if (__builtin_amdgcn_ballot_w64(!w.done) == 0) break;
-      {
-        // checkpoint of the state BEFORE instance cbase: fold the eight lanes' partial sums
-        const float k0 = oct_sum(w.C0), k1 = oct_sum(w.C1), k2 = oct_sum(w.C2), kd = oct_sum(w.D);
-        if (i == k) { h0 = w.T; h1 = k0; h2 = k1; h3 = k2; h4 = kd; hv = !w.done && ck_on; }
-      }
-      fw_composite_chunk<TRACE>(w, k, base, lane, pfx, pfy, st_iters, st_full);
-    }
-  }
-  if (TRACE && a.trace && lane == 0 && (uint64_t)item.index < fw_late_args()->trace_items) {
-    unsigned long long* tr = a.trace + ((size_t)item.index * 4 + wave) * 8;
-    tr[6] = t_begin;
-    tr[0] = wall_clock64() - t_begin; tr[1] = st_rounds;
-    tr[2] = (unsigned long long)st_surv | ((unsigned long long)(__builtin_amdgcn_s_getreg(63492) & 0xFFFFu) << 32) | ((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 0xFu) << 48);
-    tr[3] = st_iters; tr[4] = st_full;
-    tr[5] = (unsigned long long)(hi - lo) | ((unsigned long long)tile << 32) | ((unsigned long long)seg << 48) | (helper ? 1ull << 63 : 0ull);
-  }
-  flush_ckpt();
-  // fold the eight lanes (every lane of a pixel ends up with the same values)
-  const float k0 = oct_sum(w.C0), k1 = oct_sum(w.C1), k2 = oct_sum(w.C2), kd = oct_sum(w.D), ka = oct_sum(w.A);
-  const float ts = oct_max(w.Tstop);
-  const uint32_t lm = oct_max_u(w.last);
-  if (helper) {
-    if (__syncthreads_or(dead)) return;  // (the block is finished: nobody reads this segment)
-    FwEnd end;
-    end.T = w.T; end.k0 = k0; end.k1 = k1; end.k2 = k2; end.kd = kd; end.ka = ka; end.lm = lm; end.done = w.done;
-    fw_publish(a.seg_state, a.seg_flags, item, px.pix, end);
-    return;
-  }
-  float Tfin = (ts >= 0.f) ? ts : w.T, o0 = k0, o1 = k1, o2 = k2, od = kd, oa = ka;
-  uint32_t on = lm;
-  int reached = 1;  // (owner of a segmented tile) number of segments its pixels went through
-  if (resume) {
-    if (i == 0) {
-      const int bp = wave * 8 + pl;
-      fw_st[0][bp] = Tfin; fw_st[1][bp] = k0; fw_st[2][bp] = k1; fw_st[3][bp] = k2; fw_st[4][bp] = kd; fw_st[5][bp] = ka;
-      fw_st[6][bp] = __uint_as_float(lm); fw_st[7][bp] = w.done ? 1.0f : 0.f;
-    }
-    __syncthreads();
-    reached = fw_owner_rest<TRACE>((const RenderArgs*)(const void*)fw_late_args(), item, resume);
-    __syncthreads();
-    const int bp = wave * 8 + pl;
-    Tfin = fw_st[0][bp]; o0 = fw_st[1][bp]; o1 = fw_st[2][bp]; o2 = fw_st[3][bp]; od = fw_st[4][bp]; oa = fw_st[5][bp];
-    on = __float_as_uint(fw_st[6][bp]);
-  } else if (owner_multi && tid == 0) {
-    // every pixel of the block is final: helpers of the segments that were not reached have nothing to do
-    reached = min((total + RIGGS_SEG - 1) / RIGGS_SEG, hbase / RIGGS_SEG + 1);
-    __hip_atomic_store((seg_gu32*)(a.dead_from + (size_t)tile * 8 + sub), (uint32_t)reached, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  // statistics for the NEXT frame's work list (bin_offsets_body): how deep the walks of segmented tiles get
-  if (owner_multi && tid == 0) atomicAdd(fw_late_args()->seg_stats + min(max(reached, 1) - 1, 31), 1u);
-  {
-    FwLateArgs& l = *fw_late_args();
-    if (px.inside && i == 0) {
-      const size_t pid = (size_t)px.pyi * l.W + px.pxi, HW = (size_t)l.H * l.W;
-      l.final_T[pid] = Tfin;
-      l.n_contrib[pid] = on;
-      l.final_acc[pid] = make_float4(o0, o1, o2, od);
-      l.out_color[pid] = o0 + Tfin * l.bg[0];
-      l.out_color[HW + pid] = o1 + Tfin * l.bg[1];
-      l.out_color[2 * HW + pid] = o2 + Tfin * l.bg[2];
-      l.out_depth[pid] = od;
-      l.out_alpha[pid] = oa;
-    }
-  }
-  uint32_t m = px.inside ? on : 0u;
-  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
-  if (lane == 0) fw_wmax[wave] = m;
-  __syncthreads();  // (fw_wmax is complete)
-  // ---- work list of the backward.  A tile's instances past its last contributor (tile_max = max n_contrib over its 256
-  // pixels) need no backward, so the list holds one entry per 64-instance chunk below it.  Every block of the tile folds
-  // its maximum into tile_max and takes a ticket; the block that draws the last ticket knows the final value and appends
-  // the tile's entries (tile, chunk, start of the tile's list, instances to walk) — a separate list-building launch used to
-  // cost 10 us.  Both words are only ever touched with agent-scope atomics, and a block takes its ticket after its
-  // maximum has RETURNED (the returning atomic has been performed), so the last ticket holder reads the final maximum.
-  // The list's size word (work_ctr) lives on a cache line of ITS OWN: sharing one with item_ctr — which every one of the
-  // launch's 20 000 workgroups reads when it starts — cost 17 us (each of the ~470 atomics throws the line out of the L2s,
-  // and the late-dispatched workgroups queue behind it at the memory side).
-  // Only wave 0 stays for this (two dependent atomic round trips to the memory side, ~4 us): the other three waves leave.
-  if (wave == 0) {
-    FwLateArgs& l = *fw_late_args();
-    uint32_t n_c = 0u, base = 0u, limit = 0u;
-    if (lane == 0) {
-      const uint32_t mb = max(max(fw_wmax[0], fw_wmax[1]), max(fw_wmax[2], fw_wmax[3]));
-      const uint32_t before = __hip_atomic_fetch_max(&l.tile_max[tile], mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const uint32_t ticket = __hip_atomic_fetch_add(&l.tile_ticket[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (ticket == 7u) {  // eight 8 x 4 blocks per tile
-        limit = max(max(before, mb), __hip_atomic_load(&l.tile_max[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        limit = min((uint32_t)total, limit);
-        n_c = (limit + 63u) >> 6;
-        if (n_c) base = __hip_atomic_fetch_add(l.work_ctr, 4u * n_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 2;  // (quarter-chunks)
-      }
-    }
-    n_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_c);
-    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    limit = (uint32_t)__builtin_amdgcn_readfirstlane((int)limit);
-    for (uint32_t k = lane; k < n_c; k += 64) l.work[base + k] = make_uint4((uint32_t)tile, k, range.x, limit);
+  // work list: the non-empty tiles in the order the extra workgroup of bin_scatter_kernel wrote them (longest lists first);
+  // the first item_ctr[1] entries are WIDE (32 blocks of 4 x 2 pixels each), the others 8 blocks of 8 x 4.  One block per
+  // workgroup (the launch covers the most the list can hold: an outer loop over items makes every item-invariant scalar a
+  // loop invariant that the compiler computes up front and keeps, in vector-register lanes once the scalar file is full).
+  if (!a.items) return;
+  const int n_entries = (int)a.item_ctr[0], n_wide = (int)a.item_ctr[1];
+  const int it = (int)blockIdx.x, wide_items = n_wide * 32;
+  // the blocks of an entry get workgroup ids 8 apart = the same XCD / L2 (workgroup b runs on XCD b % 8)
+  if (it < wide_items) {
+    const int full = (n_wide >> 3) << 8;
+    int p, sub;
+    if (it < full) { p = ((it >> 8) << 3) + (it & 7); sub = (it >> 3) & 31; }
+    else { p = (full >> 5) + ((it - full) >> 5); sub = (it - full) & 31; }
+    fw_block<32, TRACE>(a, (int)a.items[p], sub, it);
+  } else {
+    const int j = it - wide_items, n_items = (n_entries - n_wide) * 8, full = (n_items >> 6) << 6;
+    if (j >= n_items) return;
+    int p, sub;
+    if (j < full) { p = ((j >> 6) << 3) + (j & 7); sub = (j >> 3) & 7; }
+    else { p = (full >> 3) + ((j - full) >> 3); sub = (j - full) & 7; }
+    fw_block<8, TRACE>(a, (int)a.items[n_wide + p], sub, it);
   }
 }
 
-// helper workgroups per forward launch (RIGGS_FWD_HELPERS overrides: a tuning knob for tools, 0 turns the helpers off)
-int64_t forward_helper_budget() {
+// the tiles that may be composited wide per launch, and the list length from which a tile is (RIGGS_FWD_WIDE_TILES,
+// RIGGS_FWD_WIDE_MIN override: tuning knobs for tools; 0 tiles turns the wide form off)
+uint32_t forward_wide_tiles() {
   static int64_t v = -1;
   if (v < 0) {
-    const char* e = getenv("RIGGS_FWD_HELPERS");
-    v = e ? atoll(e) : 8192;
+    const char* e = getenv("RIGGS_FWD_WIDE_TILES");
+    v = e ? atoll(e) : 256;
+    if (v < 0) v = 0;
+    if (v > 65535) v = 65535;
   }
-  return v;
+  return (uint32_t)v;
+}
+uint32_t forward_wide_min() {
+  static int64_t v = -1;
+  if (v < 0) {
+    const char* e = getenv("RIGGS_FWD_WIDE_MIN");
+    v = e ? atoll(e) : 4096;
+    if (v < 256) v = 256;
+  }
+  return (uint32_t)v;
 }
 
 int launch_render_fwd(const RenderArgs& a, hipStream_t s) {
   const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE, gy = (a.H + RIGGS_TILE - 1) / RIGGS_TILE;
   if (gx * gy == 0) return 0;
-  // one workgroup per work item: the walkers of all tiles (they come first in the list; the ones of empty tiles only help with
-  // the background and leave) and as many helpers as fit a BUDGET — helpers are optional, the list has the ones of the longest
-  // lists first, and a helper that finds nothing to do still costs a workgroup launch and a round trip to memory (20 000 of
-  // them behind the last walker: +8 us on a 60 us launch).  (tile_max, the tile tickets, the hand-shake words and the
-  // work-list size were cleared by the extra workgroup of bin_scatter_kernel.)
-  const int64_t walkers = (int64_t)gx * gy * 8;
-  int64_t helpers = a.items ? a.n_item_slots * 8 - walkers : 0;
-  const int64_t budget = forward_helper_budget();
-  if (helpers > budget) helpers = budget;
-  if (helpers < 0) helpers = 0;
-  const int64_t blocks = walkers + helpers;
+  // one workgroup per block: eight per tile, 24 more for every tile that may be wide; the ones past the end of the list only
+  // help with the background of the empty tiles and leave (tile_max, the tile tickets and the work-list size were cleared by
+  // the extra workgroup of bin_scatter_kernel)
+  const int64_t T = (int64_t)gx * gy;
+  const int64_t wide = a.items ? (T < (int64_t)forward_wide_tiles() ? T : (int64_t)forward_wide_tiles()) : 0;
+  const int64_t blocks = T * 8 + wide * 24;
   if (blocks > 0x7FFFFFFF) { set_error("image too large for one forward launch"); return 2; }
   if (a.trace) hipLaunchKernelGGL(render_fwd_oct_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(render_fwd_oct_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, a);
@@ -783,7 +519,7 @@ __device__ __forceinline__ f2v splat2(float v) { return f2v{v, v}; }
 // TRACE = per-chunk statistics (both compiled out of the default instantiation: the ordered branch alone cost 4 VGPRs = one
 // wave per SIMD = 7 us)
 template <int NW, bool ORDERED, bool TRACE>
-__global__ __launch_bounds__(64 * NW, 4) void render_bwd_kernel(RenderBwdArgs a) {
+__global__ __launch_bounds__(64 * NW) void render_bwd_kernel(RenderBwdArgs a) {
   constexpr int PPW = 256 / NW;    // pixels per wave
   constexpr int RSTEP = NW;        // a wave's rows are part, part + NW, ...
   // per-pixel state of the chunk, interleaved per PAIR of neighbouring pixels (A, B): one LDS read delivers the two
@@ -831,14 +567,12 @@ __global__ __launch_bounds__(64 * NW, 4) void render_bwd_kernel(RenderBwdArgs a)
   struct Level3 {  // what a lane loads for a chunk: its instance's records, its pixel's state
     float4 xy, co, cc, acc;
     float Tn, g0, g1, g2, gD, gA, Ts, S0, S1, S2, Ds;
-    float pT, p0, p1, p2, pD;  // segmented tiles: the prefix in front of the chunk's segment (checkpoints are segment-local)
   };
   auto issue_level3 = [&](const u4v wk, uint32_t id, uint32_t n, Level3& r) {
     const int tile = (int)wk.x, pos0 = (int)wk.y * 64;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     r.xy = z; r.co = z; r.cc = z; r.acc = z;
     r.Tn = 0.f; r.g0 = 0.f; r.g1 = 0.f; r.g2 = 0.f; r.gD = 0.f; r.gA = 0.f; r.Ts = 1.f; r.S0 = 0.f; r.S1 = 0.f; r.S2 = 0.f; r.Ds = 0.f;
-    r.pT = 1.f; r.p0 = 0.f; r.p1 = 0.f; r.p2 = 0.f; r.pD = 0.f;
     if (pos0 + lane < (int)wk.w) { r.xy = a.xyd[id]; r.co = a.conic_o[id]; r.cc = a.rgb[id]; }
     if ((int)n > pos0) {  // (n is 0 for the lanes without a pixel and for the pixels outside the image)
       const int pxi = (tile % gx) * RIGGS_TILE + (spix & 15), pyi = (tile / gx) * RIGGS_TILE + (spix >> 4);
@@ -850,11 +584,6 @@ __global__ __launch_bounds__(64 * NW, 4) void render_bwd_kernel(RenderBwdArgs a)
       r.gD = a.dL_ddepth ? a.dL_ddepth[pid] : 0.f;
       r.gA = a.dL_dalpha ? a.dL_dalpha[pid] : 0.f;
       r.Ts = ck[spix]; r.S0 = ck[256 + spix]; r.S1 = ck[512 + spix]; r.S2 = ck[768 + spix]; r.Ds = ck[1024 + spix];
-      const uint32_t sg = wk.y / RIGGS_SEG_CHUNKS;
-      if (sg > 0u) {  // (only lists longer than RIGGS_SEG have chunks beyond the first segment)
-        const float* sp = a.seg_state + ((size_t)(wk.z / RIGGS_SEG + wk.x + sg) * RIGGS_SEG_WORDS + RIGGS_SEG_PREFIX) * 256 + spix;
-        r.pT = sp[0]; r.p0 = sp[256]; r.p1 = sp[512]; r.p2 = sp[768]; r.pD = sp[1024];
-      }
     }
   };
   auto stage_pixels = [&](const u4v wk, uint32_t n, const Level3& r) {  // this wave's pixels (one per lane) -> LDS
@@ -862,9 +591,8 @@ __global__ __launch_bounds__(64 * NW, 4) void render_bwd_kernel(RenderBwdArgs a)
     float4 pa = make_float4(1.f, 0.f, 0.f, 0.f), pb = make_float4(0.f, 0.f, 0.f, 0.f);
     float pc = 0.f;
     if ((int)n > pos0) {
-      const float Ts = r.pT * r.Ts;
-      const float S0 = r.p0 + r.pT * r.S0, S1 = r.p1 + r.pT * r.S1, S2 = r.p2 + r.pT * r.S2, Ds = r.pD + r.pT * r.Ds;
-      const float pre = r.g0 * S0 + r.g1 * S1 + r.g2 * S2 + r.gD * Ds + r.gA * (1.0f - Ts);
+      const float Ts = r.Ts;
+      const float pre = r.g0 * r.S0 + r.g1 * r.S1 + r.g2 * r.S2 + r.gD * r.Ds + r.gA * (1.0f - Ts);
       const float qb = (r.g0 * r.acc.x + r.g1 * r.acc.y + r.g2 * r.acc.z + r.gD * r.acc.w + r.gA * (1.0f - r.Tn)) +
                        r.Tn * (bg0 * r.g0 + bg1 * r.g1 + bg2 * r.g2);
       pa = make_float4(Ts, pre, qb, __uint_as_float(n));

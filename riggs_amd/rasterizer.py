@@ -117,10 +117,8 @@ ORDERED_BACKWARD = False
 
 def set_ordered_backward(on: bool = True):
     """Reproducible mode (riggs_raster_cfg.deterministic): the compositing backward sums per-instance gradient rows per
-    Gaussian in ascending tile order instead of float atomics, and the forward composites every segment of a long tile from
-    T = 1 (no segment runs as a continuation of an already finished predecessor, which rounds differently and depends on
-    timing) — bitwise reproducible images and gradients, for tests and debugging.  Applies to rasterizations
-    started after the call."""
+    Gaussian in ascending tile order instead of float atomics — bitwise reproducible gradients, for tests and debugging
+    (the image is bitwise reproducible in either mode).  Applies to rasterizations started after the call."""
     global ORDERED_BACKWARD
     ORDERED_BACKWARD = bool(on)
 

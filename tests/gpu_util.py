@@ -158,20 +158,10 @@ def check_full_size_properties(act, cam):
     color1 = rasterize_forward(bg1, *args)[0]
     ref = color + fT[None] * torch.tensor([0.25, 0.5, 1.0], device="cuda")[:, None, None]
     assert float((color1 - ref).abs().max()) < 1e-5
-    # determinism of the forward: bitwise in the reproducible mode (cfg.deterministic: every segment of a long list is
-    # composited from T = 1); otherwise a segment may continue from its finished predecessors, which rounds differently
-    from riggs_amd import rasterizer as RZ
-    again = rasterize_forward(bg0, *args)[0]
-    assert float((color - again).abs().max()) <= 2e-6 * max(1.0, float(color.abs().max()))
+    # determinism of the forward: bitwise (no two workgroups share a pixel, the order inside a pixel is the list's)
+    again = rasterize_forward(bg0, *args)[:4]
+    assert torch.equal(color, again[0]) and torch.equal(depth, again[2]) and torch.equal(alpha, again[3])
     del again
-    RZ.set_ordered_backward(True)
-    try:
-        det = [rasterize_forward(bg0, *args)[:4] for _ in range(2)]  # (the saved states — the arenas — are dropped at once)
-    finally:
-        RZ.set_ordered_backward(False)
-    assert torch.equal(det[0][0], det[1][0]) and torch.equal(det[0][2], det[1][2]) and torch.equal(det[0][3], det[1][3])
-    assert float((color - det[0][0]).abs().max()) <= 2e-6 * max(1.0, float(color.abs().max()))
-    del det
     # backward is linear in the incoming gradient
     g = torch.Generator().manual_seed(0)
     gc = (torch.sign(torch.rand(3, H, W, generator=g) - 0.5) / (3 * H * W)).cuda()

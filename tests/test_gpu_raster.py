@@ -203,7 +203,7 @@ def test_large_tile_grids(H, W):
 
 
 def test_tile_grids_beyond_the_work_list_packing_are_rejected():
-    """65 535 tiles is the limit (the forward's work list packs the tile id into 16 bits): more is an error, not a mis-render."""
+    """65 535 tiles is the limit: more is an error, not a mis-render."""
     from riggs_amd._lib import RiggsHipError
     H, W = 4112, 4096  # 257 x 256 = 65 792 tiles
     sc, act, cam = U.activated_scene(50, 8, 41, H, W, scale=0.05)

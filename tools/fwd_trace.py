@@ -23,7 +23,7 @@ def main():
         gm = GaussianModel.from_tensors(sc["xyz"], sc["features_dc"], sc["features_rest"], sc["scaling"], sc["rotation"],
                                         sc["opacity"], device="cuda:0")
     T = ((w["W"] + 15) // 16) * ((w["H"] + 15) // 16)
-    n_items = (T + 8_000_000 // 1024) * 8  # work items: 8 pixel blocks per (tile, segment of 1024 instances); 4 waves each
+    n_items = T * 8 + min(T, int(os.environ.get("RIGGS_FWD_WIDE_TILES", 256))) * 24  # work items = workgroups of the launch; 4 waves each
     trace = torch.zeros((n_items * 4 * 8 + 4 * 200_000), dtype=torch.int64, device="cuda")
     L.lib().riggs_raster_set_trace_items(n_items)
     gimg = torch.rand(3, w["H"], w["W"], device="cuda") * 1e-6
@@ -35,47 +35,47 @@ def main():
     L.lib().riggs_raster_set_trace(None)
     t = trace.cpu().numpy()[:n_items * 4 * 8].reshape(-1, 8).copy()
     t = t[t[:, 5] != 0]
-    tile_of, seg_of, local = (t[:, 5] >> 32) & 0xFFFF, (t[:, 5] >> 48) & 0x7FFF, (t[:, 5] >> 63) & 1
+    tile_of, wide = (t[:, 5] >> 32) & 0xFFFFFF, (t[:, 5] >> 63) & 1
     t[:, 5] &= 0xFFFFFFFF
     us = t[:, 0] / 100.0
     order = np.argsort(-us)
     print("waves with work: %d; time us: max %.1f p99 %.1f p90 %.1f median %.1f" % (len(t), us.max(), *np.percentile(us, [99, 90, 50])))
-    print("slowest waves: [us, rounds, survivors/4waves, iterations, full iterations, segment length]")
+    print("slowest waves: [us, rounds, survivors/4waves, iterations, full iterations, list length, wide]")
+    ph = np.stack([(t[:, 7] >> (16 * k)) & 0xFFFF for k in range(4)], 1) * 64.0  # shader clocks: barrier at the top | stage + stores + barrier | prefetch issue | chunks
     for i in order[:12]:
-        print("  %7.1f %5d %7d %6d %6d %7d" % (us[i], t[i, 1], t[i, 2] & 0xFFFFFFFF, t[i, 3], t[i, 4], t[i, 5]))
+        print("  %7.1f %5d %7d %6d %6d %7d %d   clocks/round: top %5.0f stage %5.0f issue %5.0f chunks %5.0f" % (
+            us[i], t[i, 1], t[i, 2] & 0xFFFFFFFF, t[i, 3], t[i, 4], t[i, 5], wide[i], *(ph[i] / max(1, t[i, 1]))))
     # simple linear model of a wave's time
     A = np.stack([np.ones(len(t)), t[:, 1], t[:, 3] - t[:, 4], t[:, 4]], 1).astype(np.float64)
     coef, *_ = np.linalg.lstsq(A, us, rcond=None)
     print("fit: us = %.2f + %.3f*rounds + %.3f*skipped_iterations + %.3f*full_iterations" % tuple(coef))
-    print("work items that ran: %d (first segments %d, deeper %d); tiles %d; deepest segment %d" % (
-        len(t) // 4, (seg_of == 0).sum() // 4, (seg_of > 0).sum() // 4, len(np.unique(tile_of)), seg_of.max()))
-    deep = seg_of > 0
-    print("deeper segments that ran as continuations: %d, from T = 1 (local): %d" % (((deep) & (local == 0)).sum() // 4, (local == 1).sum() // 4))
-    if deep.any():
-        print("deeper segments: rounds walked %d of %d possible (%.0f %% — the rest was cut short by dead_from)" % (
-            t[deep, 1].sum(), (np.ceil(t[deep, 5] / 256)).sum(), 100.0 * t[deep, 1].sum() / np.ceil(t[deep, 5] / 256).sum()))
+    print("work items that ran: %d (wide %d: %d tiles); tiles %d" % (len(t) // 4, wide.sum() // 4, len(np.unique(tile_of[wide == 1])), len(np.unique(tile_of))))
+    for nm, sel in (("8 lanes / pixel", wide == 0), ("32 lanes / pixel", wide == 1)):
+        if sel.any():
+            r = t[sel, 1] > 0
+            print("  %s: us per round (waves with rounds): median %.2f; rounds max %d; wave time max %.1f us" % (
+                nm, np.median(us[sel][r] / t[sel, 1][r]), t[sel, 1].max(), us[sel].max()))
+    # per tile: list length against the rounds its slowest block walked
+    tl = {}
+    for k in range(len(t)):
+        a = tl.setdefault(int(tile_of[k]), [int(t[k, 5]), 0])
+        a[1] = max(a[1], int(t[k, 1]))
+    arr = np.array(sorted(tl.values(), reverse=True))
+    print("tiles by list length: [length, rounds walked by the slowest block] (longest 24): %s" % " ".join("%d:%d" % (a, b) for a, b in arr[:24]))
+    for lo in (1024, 2048, 4096, 8192, 16384):
+        sel = arr[:, 0] >= lo
+        if sel.any():
+            print("  lists >= %5d: %4d tiles; rounds walked: median %d max %d; tiles walking >= 16 rounds: %d" % (
+                lo, sel.sum(), np.median(arr[sel, 1]), arr[sel, 1].max(), (arr[sel, 1] >= 16).sum()))
     t0 = t[:, 6].min()
     start, main_end = (t[:, 6] - t0) / 100.0, (t[:, 6] - t0 + t[:, 0]) / 100.0
-    chain_us, steps, walk, back = (t[:, 7] & 0xFFFFFFFF) / 100.0, (t[:, 7] >> 32) & 0xFFF, (t[:, 7] >> 44) & 0x3FF, (t[:, 7] >> 54) & 0x3FF
     print("starts: p50 %.1f p90 %.1f p99 %.1f max %.1f us; compositing loops end: p50 %.1f p99 %.1f max %.1f us" % (
         *np.percentile(start, [50, 90, 99, 100]), *np.percentile(main_end, [50, 99, 100])))
-    endall = main_end + chain_us
-    lvl0 = seg_of == 0
-    print("starts of first segments: p50 %.1f p99 %.1f max %.1f; of deeper ones: p1 %.1f p50 %.1f max %.1f" % (
-        *np.percentile(start[lvl0], [50, 99, 100]), *(np.percentile(start[~lvl0], [1, 50, 100]) if (~lvl0).any() else (0, 0, 0))))
     print("waves in flight (of %d slots) at t us: %s" % (1024 * 6, "  ".join(
-        "%d:%d" % (tt, ((start <= tt) & (endall > tt)).sum()) for tt in range(0, int(endall.max()) + 10, 10))))
-    ch = chain_us > 0
-    if ch.any():
-        end = main_end + chain_us
-        print("chains: %d waves took part; time in the chain p50 %.1f p90 %.1f p99 %.1f max %.1f us; last chain ends at %.1f us" % (
-            ch.sum(), *np.percentile(chain_us[ch], [50, 90, 99, 100]), end.max()))
-        print("        segments combined: total %d, max per holder %d; rounds composited (again, or of segments walked here): total %d, max %d; loop passes | own walks << 5: total %d, max %d" % (
-            steps.sum() // 1, steps.max(), walk.sum(), walk.max(), back.sum(), back.max()))
-        o2 = np.argsort(-chain_us)[:10]
-        print("        slowest chain holders: [chain us, segments combined, rounds composited, passes | own walks << 5, tile, seg, start us]")
-        for k in o2:
-            print("          %7.1f %4d %4d %4d %6d %4d %7.1f" % (chain_us[k], steps[k], walk[k], back[k], tile_of[k], seg_of[k], start[k]))
+        "%d:%d" % (tt, ((start <= tt) & (main_end > tt)).sum()) for tt in range(0, int(main_end.max()) + 10, 10))))
+    if (wide == 1).any():
+        print("wide blocks: start p50 %.1f max %.1f us, end p50 %.1f max %.1f us" % (
+            *np.percentile(start[wide == 1], [50, 100]), *np.percentile(main_end[wide == 1], [50, 100])))
     print("mean wave time %.1f us; sum of wave times / (1024 SIMDs x 6 waves) = %.1f us" % (us.mean(), us.sum() / (1024 * 6)))
     print("totals: rounds %d, iterations %d (full %d), survivors(sum over waves' own chunks) %d" % (t[:, 1].sum(), t[:, 3].sum(), t[:, 4].sum(), (t[:, 2] & 0xFFFFFFFF).sum()))
 
