@@ -184,9 +184,13 @@ __global__ __launch_bounds__(64) void pm_backward_weights_kernel(PoseMlpDesc d, 
 #define PMF_SPIN_MAX (1u << 17)
 typedef __attribute__((address_space(1))) unsigned long long pm_gu64;
 
-__device__ __forceinline__ void pm_store_granule(unsigned long long* g, uint32_t tag, float value) {
-  __hip_atomic_store((pm_gu64*)g, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(value),
-                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// `local`: every workgroup of the chain runs on the same XCD (pm_chain_is_local): a plain 8-byte store lands in the L2 they
+// share, where the consumers' agent-scope loads find it — half the latency of the write-through store (tools/scratch/
+// pingpong.hip: 0.52 us round trip against 1.10 us), which takes the value to the memory side and drops the line from L2.
+__device__ __forceinline__ void pm_store_granule(unsigned long long* g, uint32_t tag, float value, bool local) {
+  const unsigned long long x = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(value);
+  if (local) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(g), "v"(x) : "memory");
+  else __hip_atomic_store((pm_gu64*)g, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // one wave re-reads its <= 4 granules per lane until every tag matches (wave-uniform exit).  A granule
@@ -235,6 +239,29 @@ __device__ __forceinline__ bool pm_sweep(const unsigned long long* gran, int n, 
   }
 }
 
+// Placement of the chain.  The hardware deals a launch's workgroups round-robin over the eight XCDs (workgroup b -> XCD b % 8),
+// so the chain's workgroups are the ones whose index is a multiple of eight: all on one XCD, one L2 — when one XCD can hold
+// them all at once (pm_chain_stride; else they are the launch's first workgroups, on all XCDs).  Nothing RELIES on the
+// placement: every chain workgroup publishes the XCD it finds itself on (hardware register XCC_ID) with the always-correct
+// write-through granule, and only if all of them report the same one are the layer hand-offs stored the cheap way
+// (pm_store_granule).
+#define PM_CHAIN_STRIDE 8
+#define PM_MAX_CHAIN 64   // chain workgroups (granules of the placement check)
+__device__ __forceinline__ bool pm_chain_is_local(unsigned long long* xg, int rank, int n_chain, uint32_t tag, uint32_t* err,
+                                                  uint32_t* sticky, int lane, int wave, int* s_word) {
+  if (wave == 0) {
+    const uint32_t mine = __builtin_amdgcn_s_getreg(63508) & 0xFu;  // HW_REG_XCC_ID
+    if (lane == 0) pm_store_granule(xg + rank, tag, __uint_as_float(mine), false);
+    float v[4];
+    const bool ok = pm_sweep(xg, n_chain, tag, v, err, sticky, lane);
+    const bool same = ok && (lane >= n_chain || __float_as_uint(v[0]) == mine);  // (n_chain <= 64: one granule per lane)
+    const bool all_same = __all(same);
+    if (lane == 0) *s_word = all_same ? 1 : 0;
+  }
+  __syncthreads();
+  return *s_word != 0;
+}
+
 #define PM_FAULT_BIT 1u
 __global__ __launch_bounds__(PMF_WAVES * 64) void pm_forward_fused_kernel(PoseMlpDesc d, const float* __restrict__ t,
                                                                           const float* __restrict__ rot_bias4,
@@ -243,12 +270,14 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_forward_fused_kernel(PoseMl
                                                                           uint32_t* sticky, uint32_t* bwd_state, int bwd_words,
                                                                           float* __restrict__ rotation,
                                                                           float* __restrict__ translation,
-                                                                          float* __restrict__ wt, int n_chain,
+                                                                          float* __restrict__ wt, int n_chain, int stride,
+                                                                          unsigned long long* xcc_gran,
                                                                           unsigned long long* trace) {
   __shared__ float s_in[PM_MAX_IN];
-  __shared__ int s_failed;
+  __shared__ int s_failed, s_local;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if ((int)blockIdx.x >= n_chain) {
+  const int rank = (int)blockIdx.x / stride;  // (chain workgroups: index in the chain)
+  if ((int)blockIdx.x % stride != 0 || rank >= n_chain) {
     // ---- transposer workgroups (idle CUs, off the chain): WT_l[c][r] = M_l[r][off_l + c] for the backward,
     // whose waves own COLUMNS: read in place a column costs 64 cache lines per load and ~12 us of per-CU
     // miss latency at the head of that kernel; from WT it is one coalesced row like the forward's.
@@ -256,7 +285,8 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_forward_fused_kernel(PoseMl
     const int emb_ = 1 + 2 * d.multires;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 16
     const int tiles_per = (PM_MAX_HEAD / 32) * (PM_MAX_W / 32);  // (rows: up to PM_MAX_HEAD for the heads) x (columns)
-    for (int tile = blockIdx.x - n_chain; tile < d.depth * tiles_per; tile += gridDim.x - n_chain) {
+    const int n_side = (int)gridDim.x - n_chain, side = (int)blockIdx.x - min(n_chain, (int)blockIdx.x / stride + 1);
+    for (int tile = side; tile < d.depth * tiles_per; tile += n_side) {
       const int l = 1 + tile / tiles_per, tt = tile % tiles_per;
       const int r0 = (tt / (PM_MAX_W / 32)) * 32, c0 = (tt % (PM_MAX_W / 32)) * 32;
       const bool heads = (l == d.depth);
@@ -282,10 +312,10 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_forward_fused_kernel(PoseMl
     }
     return;
   }
-  const int row = blockIdx.x * PMF_WAVES + wave;
+  const int row = rank * PMF_WAVES + wave;
   const int emb = 1 + 2 * d.multires;
   uint32_t* err = bwd_state;  // {err, gen, pad, pad, backward granules...}: cleared here for the backward launch
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < bwd_words; i += n_chain * blockDim.x) bwd_state[i] = 0u;
+  for (int i = rank * blockDim.x + threadIdx.x; i < bwd_words; i += n_chain * blockDim.x) bwd_state[i] = 0u;
   // `gen` (persistent across launches, bumped by workgroup 0 at the end) makes this launch's tags unique:
   // granules left by the previous launch — or replay — never match, so no per-launch memset is needed
   const uint32_t tag0 = __hip_atomic_load((__attribute__((address_space(1))) uint32_t*)gen, __ATOMIC_RELAXED,
@@ -326,17 +356,18 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_forward_fused_kernel(PoseMl
       embv = ((lane - 1) & 1) ? cosf(tv * f) : sinf(tv * f);
     }
     if (wave == 0) s_in[lane] = embv;
-    if (wave == 0 && blockIdx.x == 0) acts[lane] = embv;
+    if (wave == 0 && rank == 0) acts[lane] = embv;
   }
   if (threadIdx.x == 0) s_failed = 0;
   // TEST HOOK (tests/test_gpu_deform.py): the word behind the sticky status word of a persistent sync_state makes workgroup 1 keep
   // one layer's hand-off to itself — bit 0 in the forward, bit 1 in the backward — so that the consumers' bounded spins time out
-  const bool fault = sticky != nullptr && blockIdx.x == 1 && (sticky[1] & PM_FAULT_BIT) != 0u;
+  const bool fault = sticky != nullptr && rank == 1 && (sticky[1] & PM_FAULT_BIT) != 0u;
   PM_TRACE(0);
-  __syncthreads();
+  // (behind the weight loads in the memory queue, off the chain: the first layer waits for the weights anyway)
+  const bool local = pm_chain_is_local(xcc_gran, rank, n_chain, tag0 + 31u, err, sticky, lane, wave, &s_local);
   // (4 J + 3 > width, e.g. 64 joints: the head rows beyond `width` live in workgroups of their own, which only take part in
   // the last stage)
-  const bool extra = (int)(blockIdx.x * PMF_WAVES) >= d.width;
+  const bool extra = rank * PMF_WAVES >= d.width;
 #pragma unroll
   for (int l = 0; l <= PM_MAX_LAYERS; l++) {
     if (l <= d.depth && !(extra && l < d.depth)) {
@@ -374,7 +405,7 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_forward_fused_kernel(PoseMl
         if (s_failed) v = __builtin_nanf("");
         if (!heads) {
           v = s_failed ? v : fmaxf(v, 0.f);
-          if (!(fault && l == 1)) pm_store_granule(gran + (size_t)l * d.width + row, tag0 + (uint32_t)(l + 1), v);
+          if (!(fault && l == 1)) pm_store_granule(gran + (size_t)l * d.width + row, tag0 + (uint32_t)(l + 1), v, local);
           acts[emb + (size_t)l * d.width + row] = v;
         } else if (row < d.n_rot) {
           rotation[row] = rot_bias4 ? v + rot_bias4[row & 3] : v;
@@ -386,7 +417,7 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_forward_fused_kernel(PoseMl
     }
   }
   // workgroup 0 has swept the last hidden layer, which every workgroup published after reading `gen`
-  if (blockIdx.x == 0 && threadIdx.x == 0)
+  if (rank == 0 && threadIdx.x == 0)
     __hip_atomic_store((__attribute__((address_space(1))) uint32_t*)gen, tag0 / 32u + 1u, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -408,13 +439,16 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_backward_fused_kernel(PoseM
                                                                            const float* __restrict__ g_tr,
                                                                            unsigned long long* gran, uint32_t* err,
                                                                            uint32_t* sticky, uint32_t* gen, float* __restrict__ flat,
-                                                                           const float* __restrict__ wt,
+                                                                           const float* __restrict__ wt, int n_chain, int stride,
+                                                                           unsigned long long* xcc_gran,
                                                                            unsigned long long* trace) {
   __shared__ float s_v[PM_MAX_HEAD];
-  __shared__ int s_failed;
+  __shared__ int s_failed, s_local;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int col = blockIdx.x * PMF_WAVES + wave;
-  const bool extra = (int)(blockIdx.x * PMF_WAVES) >= d.width;  // (head rows beyond `width`: only the weight-gradient rows of the heads)
+  const int rank = (int)blockIdx.x / stride;  // (placement of the chain: see pm_chain_is_local)
+  if ((int)blockIdx.x % stride != 0 || rank >= n_chain) return;
+  const int col = rank * PMF_WAVES + wave;
+  const bool extra = rank * PMF_WAVES >= d.width;  // (head rows beyond `width`: only the weight-gradient rows of the heads)
   const int emb = 1 + 2 * d.multires;
   const int n_head = d.n_rot + 3;
   const uint32_t tag0 = __hip_atomic_load((__attribute__((address_space(1))) uint32_t*)gen, __ATOMIC_RELAXED,
@@ -445,9 +479,9 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_backward_fused_kernel(PoseM
   if (threadIdx.x == 0) s_failed = 0;
   // TEST HOOK (tests/test_gpu_deform.py): the word behind the sticky status word of a persistent sync_state makes workgroup 1 keep
   // one layer's hand-off to itself — bit 0 in the forward, bit 1 in the backward — so that the consumers' bounded spins time out
-  const bool fault = sticky != nullptr && blockIdx.x == 1 && (sticky[1] & PM_FAULT_BIT) != 0u;
+  const bool fault = sticky != nullptr && rank == 1 && (sticky[1] & PM_FAULT_BIT) != 0u;
   PM_TRACE(0);
-  __syncthreads();
+  const bool local = pm_chain_is_local(xcc_gran, rank, n_chain, tag0 + 31u, err, sticky, lane, wave, &s_local);
   PM_TRACE(1);
 #pragma unroll
   for (int l = PM_MAX_LAYERS; l >= 0; l--) {
@@ -500,7 +534,7 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_backward_fused_kernel(PoseM
         }
         if (heads && lane + 256 < n_rows) acc += wc_head * sv_head;
         acc = wave_sum(acc);
-        if (lane == 63 && col < d.width && !(fault && l == 2)) pm_store_granule(gran + (size_t)(l - 1) * d.width + col, tag0 + (uint32_t)l, acc);
+        if (lane == 63 && col < d.width && !(fault && l == 2)) pm_store_granule(gran + (size_t)(l - 1) * d.width + col, tag0 + (uint32_t)l, acc, local);
       }
       // (b) weight / bias gradients of matrix l, row `col`
       if (wave == 0) {
@@ -518,7 +552,7 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_backward_fused_kernel(PoseM
   __syncthreads();
   {
     // wave 0's own rows (it was busy polling): matrix l goes to wave l % 8
-    const int col0 = blockIdx.x * PMF_WAVES;
+    const int col0 = rank * PMF_WAVES;
 #pragma unroll
     for (int l = PM_MAX_LAYERS; l >= 0; l--) {
       if (l <= d.depth && (l % PMF_WAVES) == wave) {
@@ -539,7 +573,7 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_backward_fused_kernel(PoseM
   if (wave == 0) {
     PM_TRACE(5 + 2 * d.depth);
     // workgroup 0 has swept the last stage, i.e. every workgroup has read `gen`: bump it for a later backward
-    if (blockIdx.x == 0 && lane == 0)
+    if (rank == 0 && lane == 0)
       __hip_atomic_store((__attribute__((address_space(1))) uint32_t*)gen, tag0 / 32u + 1u, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -564,6 +598,17 @@ static int pm_fill(PoseMlpDesc& d, int32_t depth, int32_t width, int32_t multire
   return 0;
 }
 
+// 8 when an eighth of the device (one XCD) holds `n_chain` workgroups of `kernel` at once, else 1
+static int pm_chain_stride(const void* kernel, int n_chain) {
+  int per_cu = 0, dev = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, PMF_WAVES * 64, 0) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return 1;
+  }
+  return (per_cu * (cus / PM_CHAIN_STRIDE) >= n_chain) ? PM_CHAIN_STRIDE : 1;
+}
+
 static unsigned long long* g_pm_trace = nullptr;  // 128 u64: forward stamps [0,64), backward stamps [64,128)
 int riggs_pose_mlp_set_trace(void* dev_u64x128) { g_pm_trace = (unsigned long long*)dev_u64x128; return 0; }
 
@@ -579,8 +624,9 @@ static bool pm_one_launch(int32_t width, int32_t n_rot) {
 static size_t pm_acts_core(int32_t depth, int32_t width, int32_t multires) {
   return ((size_t)(1 + 2 * multires) + (size_t)depth * width + 63) & ~(size_t)63;
 }
-static size_t pm_sync_floats(int32_t depth, int32_t width) {  // granules (2 floats each) + {gen, pad...}
-  return (2 * (size_t)depth * width + 4 + 63) & ~(size_t)63;
+static size_t pm_xcc_offset(int32_t depth, int32_t width) { return (2 * (size_t)depth * width + 4 + 63) & ~(size_t)63; }
+static size_t pm_sync_floats(int32_t depth, int32_t width) {  // granules (2 floats each) + {gen, pad...} + the placement check's granules
+  return pm_xcc_offset(depth, width) + 2 * PM_MAX_CHAIN;
 }
 size_t riggs_pose_mlp_sync_bytes(int32_t depth, int32_t width) { return pm_sync_floats(depth, width) * sizeof(float); }
 // index (in 32-bit words) of the sticky status word inside sync_state: bit 0 = a hand-off spin of the one-launch
@@ -610,11 +656,16 @@ int riggs_pose_mlp_forward(int32_t depth, int32_t width, int32_t multires, int32
       fs = own;
       RIGGS_HIP_CHECK(hipMemsetAsync(fs, 0, sf * sizeof(float), s));
     }
-    const int n_chain = ((width > n_rot + 3 ? width : n_rot + 3) + PMF_WAVES - 1) / PMF_WAVES;  // + 64 transposer workgroups on otherwise idle CUs
-    hipLaunchKernelGGL(pm_forward_fused_kernel, dim3(n_chain + 64), dim3(PMF_WAVES * 64), 0, s, d, t, rot_bias4, acts,
+    // the chain's workgroups are every eighth one of the launch (one XCD: pm_chain_is_local), the others transpose
+    const int n_chain = ((width > n_rot + 3 ? width : n_rot + 3) + PMF_WAVES - 1) / PMF_WAVES;
+    static int stride_f[PM_MAX_CHAIN + 1];
+    if (stride_f[n_chain] == 0) stride_f[n_chain] = pm_chain_stride(reinterpret_cast<const void*>(pm_forward_fused_kernel), n_chain);
+    const int stride = stride_f[n_chain];
+    hipLaunchKernelGGL(pm_forward_fused_kernel, dim3(stride > 1 ? n_chain * stride : n_chain + 64), dim3(PMF_WAVES * 64), 0, s, d, t, rot_bias4, acts,
                        (unsigned long long*)fs, (uint32_t*)(fs + 2 * (size_t)depth * width),
                        sync_state ? (uint32_t*)(fs + 2 * (size_t)depth * width) + 1 : nullptr, (uint32_t*)(own + sf), (int)sf,
-                       rotation, translation, own + 2 * sf, n_chain, g_pm_trace);
+                       rotation, translation, own + 2 * sf, n_chain, stride, (unsigned long long*)(fs + pm_xcc_offset(depth, width)),
+                       g_pm_trace);
     RIGGS_HIP_CHECK(hipGetLastError());
     return 0;
   }
@@ -668,11 +719,15 @@ int riggs_pose_mlp_backward(int32_t depth, int32_t width, int32_t multires, int3
   if (pm_one_launch(width, n_rot)) {
     float* tail = acts + pm_acts_core(depth, width, multires) + pm_sync_floats(depth, width);
     const int nr = width > n_rot + 3 ? width : n_rot + 3;
-    hipLaunchKernelGGL(pm_backward_fused_kernel, dim3((nr + PMF_WAVES - 1) / PMF_WAVES), dim3(PMF_WAVES * 64), 0, s, d, g,
+    const int n_chain = (nr + PMF_WAVES - 1) / PMF_WAVES;
+    static int stride_b[PM_MAX_CHAIN + 1];
+    if (stride_b[n_chain] == 0) stride_b[n_chain] = pm_chain_stride(reinterpret_cast<const void*>(pm_backward_fused_kernel), n_chain);
+    const int stride = stride_b[n_chain];
+    hipLaunchKernelGGL(pm_backward_fused_kernel, dim3(n_chain * stride), dim3(PMF_WAVES * 64), 0, s, d, g,
                        acts, g_rotation, g_translation, (unsigned long long*)(tail + 4), (uint32_t*)tail,
                        sync_state ? (uint32_t*)sync_state + 2 * (size_t)depth * width + 1 : nullptr,
-                       (uint32_t*)tail + 1, flat_grads, tail + pm_sync_floats(depth, width),
-                       g_pm_trace ? g_pm_trace + 64 : nullptr);
+                       (uint32_t*)tail + 1, flat_grads, tail + pm_sync_floats(depth, width), n_chain, stride,
+                       (unsigned long long*)(tail + pm_xcc_offset(depth, width)), g_pm_trace ? g_pm_trace + 64 : nullptr);
     RIGGS_HIP_CHECK(hipGetLastError());
     return 0;
   }

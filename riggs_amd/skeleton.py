@@ -48,7 +48,9 @@ class PoseMLP(nn.Module):
         self.translation_predictor = nn.Linear(hidden_dimensions, 3)
         # hand-off state of the one-launch HIP forward (include/riggs_hip.h: sync_state): zeroed once, here
         # (never inside a hipGraph capture), then owned by the kernel; follows the module across .cuda()/.to()
-        self.register_buffer("_hip_sync", torch.zeros(2 * depth * hidden_dimensions + 64, dtype=torch.int32),
+        # (size: riggs_pose_mlp_sync_bytes — granules, the status words, the granules of the placement check; the formula is
+        # restated here because the module is also built where the library is not, and checked in forward())
+        self.register_buffer("_hip_sync", torch.zeros((2 * depth * hidden_dimensions + 4 + 63) // 64 * 64 + 128, dtype=torch.int32),
                              persistent=False)
 
     def check_status(self):

@@ -111,3 +111,14 @@ def test_integration_stub_matches_the_header_struct():
         depth -= ch in ")]"
         n_args += (ch == "," and depth == 0)
     assert n_args == len(mine)
+
+
+def test_pose_mlp_sync_buffer_is_as_large_as_the_library_wants():
+    """PoseMLP restates riggs_pose_mlp_sync_bytes for its persistent hand-off state (built on CPU-only hosts too); a buffer
+    that is too small silently falls back to a per-launch private state (no sticky status word)."""
+    from riggs_amd import _lib as L
+    from riggs_amd.skeleton import PoseMLP
+    for joints, depth, width in ((24, 8, 256), (64, 8, 256), (6, 3, 32), (12, 12, 128)):
+        net = PoseMLP(1, joints * 4, hidden_dimensions=width, depth=depth)
+        assert net._hip_sync.numel() * 4 >= L.lib().riggs_pose_mlp_sync_bytes(depth, width)
+        assert int(L.lib().riggs_pose_mlp_status_word(depth, width)) + 1 < net._hip_sync.numel()
