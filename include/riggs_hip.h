@@ -197,6 +197,15 @@ int riggs_lbs_forward(int32_t num_points, int32_t num_joints, int32_t K, const f
                       const float* node_rot, const float* global_trans, const float* motion_mask,
                       const float* weight_mod /* NULL, or (N, J-1) = sigmoid(WeightMLP(x)): skeleton_warp.py:56-69; K = -1 only */,
                       float* d_xyz, float* d_rotation, float* nn_weight, int64_t* nn_idx, riggs_stream stream);
+/* The same with the forward kinematics INSIDE the launch (every workgroup runs the chain of J - 1 dependent 3x4 products
+ * itself — 2 us — instead of a launch of its own in front — 6.5 us of a captured frame): takes the pose, and workgroup 0
+ * leaves what riggs_fk_forward would have written (transforms (J,12), node_rot (J,4), d_nodes (J,3)) for the backward and
+ * the caller.  SkeletonWarp.forward(x, t, mask) uses it (riggs_amd/skeleton.py: _PoseDeform). */
+int riggs_lbs_forward_fk(int32_t num_points, int32_t num_joints, int32_t K, const float* x, const float* joints,
+                         const int32_t* parents, const float* node_radius_log, const float* local_rot,
+                         const float* global_trans, const float* motion_mask, const float* weight_mod,
+                         float* transforms, float* node_rot, float* d_nodes, float* d_xyz, float* d_rotation,
+                         riggs_stream stream);
 /* Backward: cotangents g_xyz (N,3), g_rot (N,4) -> dL/dtransforms (J,12), dL/dnode_radius_log (J),
  * dL/dglobal_trans (3), optional dL/dmotion_mask (N).  Reduction over N is done in-kernel
  * (registers -> workgroup partials -> a fixed-order second stage: run-to-run deterministic).
@@ -250,6 +259,21 @@ int riggs_pose_mlp_backward(int32_t depth, int32_t width, int32_t multires, int3
                             const float* b_rot, const float* W_tr, const float* b_tr, float* acts,
                             const float* g_rotation, const float* g_translation, float* workspace,
                             float* flat_grads, void* sync_state /* the forward's, or NULL */, riggs_stream stream);
+
+/* riggs_pose_mlp_backward with the reverse sweep of the kinematic chain (riggs_fk_backward) in front, in the same launch:
+ * the gradients of the heads' outputs are computed from (dL/dtransforms (J,12), dL/dd_nodes (J,3) or NULL) by every workgroup
+ * of the chain while its weights load, instead of by a launch of one workgroup in front (10 us of a captured frame).
+ * g_rotation (4J, may be NULL) is ADDED to the sweep's dL/dlocal_rot (other consumers of the predicted quaternions);
+ * g_translation (3, may be NULL) is the gradient of the predicted translation from elsewhere (the skinning's
+ * dL/dglobal_trans), to which sum_j dL/dd_nodes_j is added.  dL_dlocal_rot (J,4) and dL_dglobal_trans (3) receive the two
+ * totals (required for networks that run one launch per layer, else optional).  n_rot must be 4 * num_joints. */
+int riggs_pose_mlp_backward_fk(int32_t depth, int32_t width, int32_t multires, int32_t skip, int32_t n_rot,
+                               const float* const* weights, const float* const* biases, const float* W_rot,
+                               const float* b_rot, const float* W_tr, const float* b_tr, float* acts, int32_t num_joints,
+                               const float* local_rot, const float* joints, const int32_t* parents,
+                               const float* dL_dtransforms, const float* dL_dd_nodes, const float* g_rotation,
+                               const float* g_translation, float* dL_dlocal_rot, float* dL_dglobal_trans, float* workspace,
+                               float* flat_grads, void* sync_state, riggs_stream stream);
 
 /* =====================================================================
  * Gaussian optimizer.

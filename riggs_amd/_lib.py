@@ -52,6 +52,7 @@ _SIGS = {
     "riggs_fk_backward": (C.c_int, [C.c_int32] + [_P] * 8),
     "riggs_lbs_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [_P] * 14),
     "riggs_lbs_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [_P] * 18),
+    "riggs_lbs_forward_fk": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [_P] * 14),
     "riggs_lbs_backward_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "riggs_pose_mlp_acts_floats": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "riggs_pose_mlp_backward_workspace_floats": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
@@ -59,6 +60,7 @@ _SIGS = {
     "riggs_pose_mlp_sync_bytes": (C.c_size_t, [C.c_int32] * 2),
     "riggs_pose_mlp_set_trace": (C.c_int, [_P]),
     "riggs_pose_mlp_backward": (C.c_int, [C.c_int32] * 5 + [_P] * 13),
+    "riggs_pose_mlp_backward_fk": (C.c_int, [C.c_int32] * 5 + [_P] * 7 + [C.c_int32] + [_P] * 13),
     "riggs_pose_mlp_status_word": (C.c_size_t, [C.c_int32] * 2),
     "riggs_grad_rows_row_floats": (C.c_int32, [C.c_int32, _P]),
     "riggs_grad_rows_segment_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),

@@ -5,78 +5,12 @@
 //            <= 63 bone records (segment, radius, 3x4 transform, quaternion) staged in LDS.
 // Backward reduces over the N Gaussians inside the kernel: wave64 DPP sums -> LDS -> one atomic
 // per workgroup per output.
-#include "common.h"
+#include "fk_device.h"
 
 namespace riggs {
 
-#define MAX_J 64
 #define LOG2E 1.4426950408889634f
-
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * LOG2E); }
-
-// quaternion_to_matrix with two_s = 2/|q|^2 (utils/time_utils.py:115-132)
-__device__ __forceinline__ void quat_to_R_unnorm(const float* q, float* R) {
-  const float r = q[0], i = q[1], j = q[2], k = q[3];
-  const float two_s = 2.0f / (r * r + i * i + j * j + k * k);
-  R[0] = 1.f - two_s * (j * j + k * k); R[1] = two_s * (i * j - k * r); R[2] = two_s * (i * k + j * r);
-  R[3] = two_s * (i * j + k * r); R[4] = 1.f - two_s * (i * i + k * k); R[5] = two_s * (j * k - i * r);
-  R[6] = two_s * (i * k - j * r); R[7] = two_s * (j * k + i * r); R[8] = 1.f - two_s * (i * i + j * j);
-}
-
-// matrix_to_quaternion (utils/time_utils.py:146-205): best-conditioned candidate, no sign fix
-__device__ __forceinline__ void R_to_quat(const float* m, float* q) {
-  const float m00 = m[0], m01 = m[1], m02 = m[2], m10 = m[4], m11 = m[5], m12 = m[6], m20 = m[8], m21 = m[9], m22 = m[10];
-  float a[4] = {1.0f + m00 + m11 + m22, 1.0f + m00 - m11 - m22, 1.0f - m00 + m11 - m22, 1.0f - m00 - m11 + m22};
-  float qa[4];
-  int pick = 0;
-#pragma unroll
-  for (int c = 0; c < 4; c++) qa[c] = a[c] > 0.f ? sqrtf(a[c]) : 0.f;
-#pragma unroll
-  for (int c = 1; c < 4; c++) if (qa[c] > qa[pick]) pick = c;
-  float cand[4];
-  if (pick == 0) { cand[0] = qa[0] * qa[0]; cand[1] = m21 - m12; cand[2] = m02 - m20; cand[3] = m10 - m01; }
-  else if (pick == 1) { cand[0] = m21 - m12; cand[1] = qa[1] * qa[1]; cand[2] = m10 + m01; cand[3] = m02 + m20; }
-  else if (pick == 2) { cand[0] = m02 - m20; cand[1] = m10 + m01; cand[2] = qa[2] * qa[2]; cand[3] = m12 + m21; }
-  else { cand[0] = m10 - m01; cand[1] = m20 + m02; cand[2] = m21 + m12; cand[3] = qa[3] * qa[3]; }
-  const float den = 2.0f * fmaxf(qa[pick], 0.1f);
-#pragma unroll
-  for (int c = 0; c < 4; c++) q[c] = cand[c] / den;
-}
-
-// Shared by fk forward and backward: local transforms T (J,12) and the global chain G (J,12) in LDS.
-// transforms are 3x4 row-major [R|t].
-__device__ void fk_chain_lds(int J, const float* __restrict__ local_rot, const float* __restrict__ joints,
-                             const int32_t* __restrict__ parents, float (*T)[12], float (*G)[12], int* par) {
-  const int j = threadIdx.x;
-  if (j < J) {
-    float q[4] = {local_rot[4 * j], local_rot[4 * j + 1], local_rot[4 * j + 2], local_rot[4 * j + 3]};
-    float R[9];
-    quat_to_R_unnorm(q, R);
-    const int vp = (j == 0) ? 0 : parents[j];  // skeleton_warp.py:246-247
-    par[j] = vp;
-    const float cx = joints[3 * vp], cy = joints[3 * vp + 1], cz = joints[3 * vp + 2];
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-      T[j][4 * r] = R[3 * r]; T[j][4 * r + 1] = R[3 * r + 1]; T[j][4 * r + 2] = R[3 * r + 2];
-      const float c = (r == 0) ? cx : (r == 1 ? cy : cz);
-      T[j][4 * r + 3] = c - (R[3 * r] * cx + R[3 * r + 1] * cy + R[3 * r + 2] * cz);  // rotate about the PARENT joint
-    }
-  }
-  __syncthreads();
-  if (j < 12) G[0][j] = T[0][j];
-  __syncthreads();
-  // G_i = G_parent(i) * T_i in index order (parents[i] < i); 12 lanes own the 12 entries
-  const int r = j >> 2, c = j & 3;
-  for (int i = 1; i < J; i++) {
-    if (j < 12) {
-      const float* Gp = G[par[i]];
-      float v = Gp[4 * r] * T[i][c] + Gp[4 * r + 1] * T[i][4 + c] + Gp[4 * r + 2] * T[i][8 + c];
-      if (c == 3) v += Gp[4 * r + 3];
-      G[i][j] = v;
-    }
-    __syncthreads();
-  }
-}
 
 __global__ __launch_bounds__(64) void fk_forward_kernel(int J, const float* __restrict__ local_rot,
                                                         const float* __restrict__ joints,
@@ -84,20 +18,20 @@ __global__ __launch_bounds__(64) void fk_forward_kernel(int J, const float* __re
                                                         const float* __restrict__ global_trans,
                                                         float* __restrict__ transforms, float* __restrict__ node_rot,
                                                         float* __restrict__ d_nodes) {
-  __shared__ float T[MAX_J][12];
-  __shared__ float G[MAX_J][12];
-  __shared__ int par[MAX_J];
-  fk_chain_lds(J, local_rot, joints, parents, T, G, par);
+  FkIn in;
+  fk_load(J, local_rot, joints, parents, nullptr, nullptr, in);
+  FkLane f;
+  fk_wave_forward(J, in, f);
   const int j = threadIdx.x;
   if (j < J) {
-    const float x = joints[3 * j], y = joints[3 * j + 1], z = joints[3 * j + 2];
+    const float x = in.x[0], y = in.x[1], z = in.x[2];
 #pragma unroll
-    for (int e = 0; e < 12; e++) transforms[12 * j + e] = G[j][e];
+    for (int e = 0; e < 12; e++) transforms[12 * j + e] = f.G[e];
 #pragma unroll
     for (int r = 0; r < 3; r++)
-      d_nodes[3 * j + r] = (G[j][4 * r] * x + G[j][4 * r + 1] * y + G[j][4 * r + 2] * z + G[j][4 * r + 3]) + global_trans[r];
+      d_nodes[3 * j + r] = (f.G[4 * r] * x + f.G[4 * r + 1] * y + f.G[4 * r + 2] * z + f.G[4 * r + 3]) + global_trans[r];
     float q[4];
-    R_to_quat(G[j], q);
+    R_to_quat(f.G, q);
 #pragma unroll
     for (int e = 0; e < 4; e++) node_rot[4 * j + e] = q[e];
   }
@@ -110,76 +44,21 @@ __global__ __launch_bounds__(64) void fk_backward_kernel(int J, const float* __r
                                                          const float* __restrict__ dL_dnodes,
                                                          float* __restrict__ dL_dlocal_rot,
                                                          float* __restrict__ dL_dglobal_trans) {
-  __shared__ float T[MAX_J][12];
-  __shared__ float G[MAX_J][12];
-  __shared__ float dG[MAX_J][12];
-  __shared__ float dT[MAX_J][12];
-  __shared__ int par[MAX_J];
-  fk_chain_lds(J, local_rot, joints, parents, T, G, par);
+  FkIn in;
+  fk_load(J, local_rot, joints, parents, dL_dG_in, dL_dnodes, in);
+  FkLane f;
+  fk_wave_forward(J, in, f);
   const int j = threadIdx.x;
-  if (j < J) {
-    const float x = joints[3 * j], y = joints[3 * j + 1], z = joints[3 * j + 2];
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-      const float e = dL_dnodes ? dL_dnodes[3 * j + r] : 0.f;  // posed_j = G_j [joint_j; 1]
-      dG[j][4 * r] = dL_dG_in[12 * j + 4 * r] + e * x;
-      dG[j][4 * r + 1] = dL_dG_in[12 * j + 4 * r + 1] + e * y;
-      dG[j][4 * r + 2] = dL_dG_in[12 * j + 4 * r + 2] + e * z;
-      dG[j][4 * r + 3] = dL_dG_in[12 * j + 4 * r + 3] + e;
-    }
-  }
   if (dL_dnodes && j < 3) {  // d_nodes = posed + global_trans
     float s = 0.f;
     for (int k = 0; k < J; k++) s += dL_dnodes[3 * k + j];
     dL_dglobal_trans[j] += s;
   }
-  __syncthreads();
-  const int r = j >> 2, c = j & 3;
-  for (int i = J - 1; i >= 1; i--) {
-    const int p = par[i];
-    float add = 0.f, dt = 0.f;
-    if (j < 12) {
-      // dT_i = Rp^T dG_i  (both the rotation block and the translation column)
-      dt = G[p][r] * dG[i][c] + G[p][4 + r] * dG[i][4 + c] + G[p][8 + r] * dG[i][8 + c];
-      // dG_p += [dR_G R_T^T + dt_G t_T^T | dt_G]
-      if (c < 3) add = dG[i][4 * r] * T[i][4 * c] + dG[i][4 * r + 1] * T[i][4 * c + 1] + dG[i][4 * r + 2] * T[i][4 * c + 2] +
-                       dG[i][4 * r + 3] * T[i][4 * c + 3];
-      else add = dG[i][4 * r + 3];
-    }
-    __syncthreads();
-    if (j < 12) { dT[i][j] = dt; dG[p][j] += add; }
-    __syncthreads();
-  }
-  if (j < 12) dT[0][j] = dG[0][j];
-  __syncthreads();
+  float dq[4];
+  fk_wave_backward(J, in, f, dq);
   if (j < J) {
-    const int vp = par[j];
-    const float cx = joints[3 * vp], cy = joints[3 * vp + 1], cz = joints[3 * vp + 2];
-    const float cc[3] = {cx, cy, cz};
-    float dR[9];
 #pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-      for (int b = 0; b < 3; b++) dR[3 * a + b] = dT[j][4 * a + b] - dT[j][4 * a + 3] * cc[b];  // t = c - R c
-    const float qr = local_rot[4 * j], qi = local_rot[4 * j + 1], qj = local_rot[4 * j + 2], qk = local_rot[4 * j + 3];
-    const float n = qr * qr + qi * qi + qj * qj + qk * qk;
-    const float s = 2.0f / n;
-    // A = (R - I)/s
-    const float A[9] = {-(qj * qj + qk * qk), qi * qj - qk * qr, qi * qk + qj * qr,
-                        qi * qj + qk * qr, -(qi * qi + qk * qk), qj * qk - qi * qr,
-                        qi * qk - qj * qr, qj * qk + qi * qr, -(qi * qi + qj * qj)};
-    float dotA = 0.f;
-#pragma unroll
-    for (int e = 0; e < 9; e++) dotA += dR[e] * A[e];
-    const float gr = -qk * dR[1] + qj * dR[2] + qk * dR[3] - qi * dR[5] - qj * dR[6] + qi * dR[7];
-    const float gi = qj * dR[1] + qk * dR[2] + qj * dR[3] - 2.f * qi * dR[4] - qr * dR[5] + qk * dR[6] + qr * dR[7] - 2.f * qi * dR[8];
-    const float gj = -2.f * qj * dR[0] + qi * dR[1] + qr * dR[2] + qi * dR[3] + qk * dR[5] - qr * dR[6] + qk * dR[7] - 2.f * qj * dR[8];
-    const float gk = -2.f * qk * dR[0] - qr * dR[1] + qi * dR[2] + qr * dR[3] - 2.f * qk * dR[4] + qj * dR[5] + qi * dR[6] + qj * dR[7];
-    const float s2 = s * s;
-    dL_dlocal_rot[4 * j] = s * gr - s2 * qr * dotA;
-    dL_dlocal_rot[4 * j + 1] = s * gi - s2 * qi * dotA;
-    dL_dlocal_rot[4 * j + 2] = s * gj - s2 * qj * dotA;
-    dL_dlocal_rot[4 * j + 3] = s * gk - s2 * qk * dotA;
+    for (int e = 0; e < 4; e++) dL_dlocal_rot[4 * j + e] = dq[e];
   }
 }
 
@@ -207,9 +86,15 @@ struct LbsArgs {
   const float *g_xyz, *g_rot;
   float *dG, *drho, *dgt, *dmask;
   float* partial;  // [workgroups][(J-1)*13 + 3] per-workgroup sums (deterministic two-stage reduction)
+  // forward with the kinematic chain inside (riggs_lbs_forward_fk): the pose, and where workgroup 0 leaves the chain's results
+  const float* local_rot;
+  float *fk_transforms, *fk_node_rot, *fk_d_nodes;
 };
 
-__device__ __forceinline__ void stage_bones(const LbsArgs& a, Bone* bones) {
+// (transforms / node_rot: global memory, or the LDS arrays of a kinematic chain that this workgroup ran itself)
+__device__ __forceinline__ void stage_bones(const LbsArgs& a, Bone* bones, const float* transforms, const float* node_rot);
+__device__ __forceinline__ void stage_bones(const LbsArgs& a, Bone* bones) { stage_bones(a, bones, a.transforms, a.node_rot); }
+__device__ __forceinline__ void stage_bones(const LbsArgs& a, Bone* bones, const float* transforms, const float* node_rot) {
   for (int k = threadIdx.x; k < a.J - 1; k += blockDim.x) {
     const int child = k + 1, par = a.parents[child];
     Bone b;
@@ -225,9 +110,9 @@ __device__ __forceinline__ void stage_bones(const LbsArgs& a, Bone* bones) {
     const float rad = expf(a.node_radius_log[child]);
     b.inv2r2 = 1.0f / (2.0f * rad * rad);
 #pragma unroll
-    for (int e = 0; e < 12; e++) b.G[e] = a.transforms[12 * child + e];
+    for (int e = 0; e < 12; e++) b.G[e] = transforms[12 * child + e];
 #pragma unroll
-    for (int e = 0; e < 4; e++) b.q[e] = a.node_rot[4 * child + e];
+    for (int e = 0; e < 4; e++) b.q[e] = node_rot[4 * child + e];
     bones[k] = b;
   }
   __syncthreads();
@@ -273,10 +158,44 @@ __device__ __forceinline__ uint64_t topk_mask(const Bone* bones, int B, int K, f
   return mask;
 }
 
-template <bool TOPK>
+// FK: the workgroup runs the kinematic chain itself (fk_device.h: ~1 us on its first wave, against a launch of its own in front
+// of this one — every workgroup repeats it, workgroup 0 keeps the results)
+template <bool TOPK, bool FK>
 __global__ __launch_bounds__(256) void lbs_forward_kernel(LbsArgs a) {
   __shared__ Bone bones[MAX_J - 1];
-  stage_bones(a, bones);
+  if constexpr (FK) {
+    __shared__ float G[MAX_J][12];
+    __shared__ float Q[MAX_J][4];
+    if (threadIdx.x < 64) {  // (wave 0: one joint per lane)
+      FkIn in;
+      fk_load(a.J, a.local_rot, a.joints, a.parents, nullptr, nullptr, in);
+      FkLane f;
+      fk_wave_forward(a.J, in, f);
+      const int j = threadIdx.x;
+      if (j < a.J) {
+        float q[4];
+        R_to_quat(f.G, q);
+#pragma unroll
+        for (int e = 0; e < 12; e++) G[j][e] = f.G[e];
+#pragma unroll
+        for (int e = 0; e < 4; e++) Q[j][e] = q[e];
+        if (blockIdx.x == 0) {
+          const float x = in.x[0], y = in.x[1], z = in.x[2];
+#pragma unroll
+          for (int e = 0; e < 12; e++) a.fk_transforms[12 * j + e] = f.G[e];
+#pragma unroll
+          for (int r = 0; r < 3; r++)
+            a.fk_d_nodes[3 * j + r] = (f.G[4 * r] * x + f.G[4 * r + 1] * y + f.G[4 * r + 2] * z + f.G[4 * r + 3]) + a.global_trans[r];
+#pragma unroll
+          for (int e = 0; e < 4; e++) a.fk_node_rot[4 * j + e] = q[e];
+        }
+      }
+    }
+    __syncthreads();
+    stage_bones(a, bones, &G[0][0], &Q[0][0]);
+  } else {
+    stage_bones(a, bones);
+  }
   const int n = blockIdx.x * 256 + threadIdx.x;
   if (n >= a.N) return;
   const int B = a.J - 1;
@@ -692,8 +611,30 @@ int riggs_lbs_forward(int32_t N, int32_t J, int32_t K, const float* x, const flo
   if (N == 0) return 0;
   {
     ProfScope ps(PROF_LBS_FWD, (hipStream_t)stream);
-    if (a.K > 0) hipLaunchKernelGGL(lbs_forward_kernel<true>, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(lbs_forward_kernel<false>, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    if (a.K > 0) hipLaunchKernelGGL((lbs_forward_kernel<true, false>), dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((lbs_forward_kernel<false, false>), dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+  }
+  RIGGS_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int riggs_lbs_forward_fk(int32_t N, int32_t J, int32_t K, const float* x, const float* joints, const int32_t* parents,
+                         const float* node_radius_log, const float* local_rot, const float* global_trans,
+                         const float* motion_mask, const float* weight_mod, float* transforms, float* node_rot, float* d_nodes,
+                         float* d_xyz, float* d_rotation, riggs_stream stream) {
+  LbsArgs a;
+  int rc = fill_lbs(a, N, J, K, x, joints, parents, node_radius_log, transforms, node_rot, global_trans, motion_mask);
+  if (rc) return rc;
+  a.d_xyz = d_xyz; a.d_rot = d_rotation;
+  a.weight_mod = weight_mod;
+  a.local_rot = local_rot; a.fk_transforms = transforms; a.fk_node_rot = node_rot; a.fk_d_nodes = d_nodes;
+  RIGGS_REQUIRE(weight_mod == nullptr || K <= 0, "weight_mod is supported with K = -1 (all bones) only");
+  RIGGS_REQUIRE(local_rot && transforms && node_rot && d_nodes, "riggs_lbs_forward_fk needs the pose and the three chain outputs");
+  if (N == 0) return riggs_fk_forward(J, local_rot, joints, parents, global_trans, transforms, node_rot, d_nodes, stream);
+  {
+    ProfScope ps(PROF_LBS_FWD, (hipStream_t)stream);
+    if (a.K > 0) hipLaunchKernelGGL((lbs_forward_kernel<true, true>), dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((lbs_forward_kernel<false, true>), dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
   }
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;

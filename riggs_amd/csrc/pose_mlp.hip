@@ -8,7 +8,7 @@
 // stride the row (coalesced 256-B reads), DPP reduces the 64 partial sums.  The backward chain
 // (dz_l, dh_l) runs the same way with thread-per-column accumulation (coalesced along rows);
 // the 0.5 M weight gradients are outer products written by a wide second kernel.
-#include "common.h"
+#include "fk_device.h"
 
 namespace riggs {
 
@@ -197,7 +197,12 @@ __device__ __forceinline__ void pm_store_granule(unsigned long long* g, uint32_t
 // load is a round trip to the memory side (~1-2 us: the producers' write-through stores drop the line
 // from L2), so PMF_INFLIGHT sweeps are kept in flight and checked oldest first: the hand-off is seen one
 // load latency after it lands instead of up to two.
+#ifndef PMF_INFLIGHT
 #define PMF_INFLIGHT 4
+#endif
+#ifndef PMF_SLEEP
+#define PMF_SLEEP 2
+#endif
 __device__ __forceinline__ void pm_sweep_issue(pm_gu64* g, int n, int lane, unsigned long long (&x)[4]) {
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -222,7 +227,7 @@ __device__ __forceinline__ bool pm_sweep(const unsigned long long* gran, int n, 
 #pragma unroll
   for (int q = 0; q < PMF_INFLIGHT; q++) {
     pm_sweep_issue(g, n, lane, x[q]);
-    __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_s_sleep(PMF_SLEEP);
   }
   for (uint32_t spins = 0;; spins++) {
 #pragma unroll
@@ -247,9 +252,10 @@ __device__ __forceinline__ bool pm_sweep(const unsigned long long* gran, int n, 
 // (pm_store_granule).
 #define PM_CHAIN_STRIDE 8
 #define PM_MAX_CHAIN 64   // chain workgroups (granules of the placement check)
+// (`by`: the wave that does it — the backward's first wave is busy with the kinematic chain at that time)
 __device__ __forceinline__ bool pm_chain_is_local(unsigned long long* xg, int rank, int n_chain, uint32_t tag, uint32_t* err,
-                                                  uint32_t* sticky, int lane, int wave, int* s_word) {
-  if (wave == 0) {
+                                                  uint32_t* sticky, int lane, int wave, int* s_word, int by = 0) {
+  if (wave == by) {
     const uint32_t mine = __builtin_amdgcn_s_getreg(63508) & 0xFu;  // HW_REG_XCC_ID
     if (lane == 0) pm_store_granule(xg + rank, tag, __uint_as_float(mine), false);
     float v[4];
@@ -431,9 +437,20 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_forward_fused_kernel(PoseMl
 // The granules live behind the forward's in `acts` (zeroed by the forward's memset node, so the backward
 // needs none); tags carry a generation word that the last stage bumps, so a second backward over the same
 // activations (retain_graph) never matches the first one's granules.
+// The reverse sweep of the kinematic chain in front of the backward chain (riggs_pose_mlp_backward_fk): the gradients of the
+// two heads' outputs are then not read but computed here — by EVERY chain workgroup, redundantly, while its weights are on
+// their way: dL/dlocal_rot = FK^T (dL/dtransforms, dL/dd_nodes) (+ g_rot, if given), dL/dglobal_trans = g_tr + sum_j dL/dd_nodes_j.
+// As a launch of its own in front of this one the sweep costs 10 us of a 385 us frame (one workgroup, 2 x 23 dependent steps).
+struct PmFkArgs {
+  int J;  // 0: no chain in front (g_rot / g_tr are the heads' gradients)
+  const float *local_rot, *joints;
+  const int32_t* parents;
+  const float *dG, *g_nodes;
+  float *dq_out, *dgt_out;  // optional: workgroup 0 leaves the two gradients here (NULL: not wanted)
+};
 #undef PM_FAULT_BIT
 #define PM_FAULT_BIT 2u
-__global__ __launch_bounds__(PMF_WAVES * 64) void pm_backward_fused_kernel(PoseMlpDesc d, PoseMlpGradDesc g,
+__global__ __launch_bounds__(PMF_WAVES * 64) void pm_backward_fused_kernel(PoseMlpDesc d, PoseMlpGradDesc g, PmFkArgs fk,
                                                                            const float* __restrict__ acts,
                                                                            const float* __restrict__ g_rot,
                                                                            const float* __restrict__ g_tr,
@@ -453,6 +470,10 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_backward_fused_kernel(PoseM
   const int n_head = d.n_rot + 3;
   const uint32_t tag0 = __hip_atomic_load((__attribute__((address_space(1))) uint32_t*)gen, __ATOMIC_RELAXED,
                                           __HIP_MEMORY_SCOPE_AGENT) * 32u;
+  // ---- (with the kinematic chain in front) the first wave's loads for the reverse sweep go out ahead of its weights'
+  __shared__ float s_gq[4 * MAX_J + 4];  // the heads' gradients: dL/dlocal_rot, then dL/dglobal_trans
+  FkIn fin;
+  if (fk.J > 0 && wave == 0) fk_load(fk.J, fk.local_rot, fk.joints, fk.parents, fk.dG, fk.g_nodes, fin);
   // ---- this wave's column of every consumer matrix, from the transposed copy the forward launch left in
   // `wt` (one coalesced 1 KB row per matrix), and the forward activations (8 KB) into LDS: no global load
   // is left on the chain or in the weight-gradient rows
@@ -481,7 +502,31 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_backward_fused_kernel(PoseM
   // one layer's hand-off to itself — bit 0 in the forward, bit 1 in the backward — so that the consumers' bounded spins time out
   const bool fault = sticky != nullptr && rank == 1 && (sticky[1] & PM_FAULT_BIT) != 0u;
   PM_TRACE(0);
-  const bool local = pm_chain_is_local(xcc_gran, rank, n_chain, tag0 + 31u, err, sticky, lane, wave, &s_local);
+  // the sweep (one joint per lane of the first wave: fk_device.h) while the second wave checks the placement of the chain;
+  // the check's barrier publishes both results
+  if (fk.J > 0 && wave == 0) {
+    FkLane f;
+    fk_wave_forward(fk.J, fin, f);
+    float dq[4];
+    fk_wave_backward(fk.J, fin, f, dq);
+    if (lane < fk.J) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) s_gq[4 * lane + e] = dq[e];
+    }
+  }
+  const bool local = pm_chain_is_local(xcc_gran, rank, n_chain, tag0 + 31u, err, sticky, lane, wave, &s_local, 1);
+  if (fk.J > 0) {
+    if (threadIdx.x < 3) {
+      float sgt = g_tr ? g_tr[threadIdx.x] : 0.f;
+      if (fk.g_nodes) for (int k = 0; k < fk.J; k++) sgt += fk.g_nodes[3 * k + threadIdx.x];
+      s_gq[4 * fk.J + threadIdx.x] = sgt;
+      if (rank == 0 && fk.dgt_out) fk.dgt_out[threadIdx.x] = sgt;
+    }
+    __syncthreads();
+    if (g_rot && (int)threadIdx.x < 4 * fk.J) s_gq[threadIdx.x] += g_rot[threadIdx.x];
+    __syncthreads();
+    if (rank == 0 && fk.dq_out && (int)threadIdx.x < 4 * fk.J) fk.dq_out[threadIdx.x] = s_gq[threadIdx.x];
+  }
   PM_TRACE(1);
 #pragma unroll
   for (int l = PM_MAX_LAYERS; l >= 0; l--) {
@@ -495,7 +540,8 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_backward_fused_kernel(PoseM
 #pragma unroll
           for (int k = 0; k < PM_MAX_HEAD / 64; k++) {
             const int r = lane + 64 * k;
-            s_v[r] = (r < d.n_rot) ? g_rot[r] : (r < n_head ? g_tr[r - d.n_rot] : 0.f);
+            if (fk.J > 0) s_v[r] = (r < n_head) ? s_gq[r] : 0.f;  // (n_rot = 4 J: the translation's three follow the quaternions)
+            else s_v[r] = (r < d.n_rot) ? g_rot[r] : (r < n_head ? g_tr[r - d.n_rot] : 0.f);
           }
         } else {
           float h[4];
@@ -686,11 +732,11 @@ size_t riggs_pose_mlp_backward_workspace_floats(int32_t depth, int32_t width, in
   return pm_bwd_core(depth, width);  // used by the layered (one launch per layer) variant only
 }
 
-int riggs_pose_mlp_backward(int32_t depth, int32_t width, int32_t multires, int32_t skip, int32_t n_rot,
+static int pm_backward_impl(int32_t depth, int32_t width, int32_t multires, int32_t skip, int32_t n_rot,
                             const float* const* weights, const float* const* biases, const float* W_rot,
                             const float* b_rot, const float* W_tr, const float* b_tr, float* acts,
                             const float* g_rotation, const float* g_translation, float* workspace,
-                            float* flat_grads, void* sync_state, riggs_stream stream) {
+                            float* flat_grads, void* sync_state, riggs_stream stream, PmFkArgs fk) {
   PoseMlpDesc d;
   int rc = pm_fill(d, depth, width, multires, skip, n_rot, weights, biases, W_rot, b_rot, W_tr, b_tr);
   if (rc) return rc;
@@ -723,13 +769,23 @@ int riggs_pose_mlp_backward(int32_t depth, int32_t width, int32_t multires, int3
     static int stride_b[PM_MAX_CHAIN + 1];
     if (stride_b[n_chain] == 0) stride_b[n_chain] = pm_chain_stride(reinterpret_cast<const void*>(pm_backward_fused_kernel), n_chain);
     const int stride = stride_b[n_chain];
-    hipLaunchKernelGGL(pm_backward_fused_kernel, dim3(n_chain * stride), dim3(PMF_WAVES * 64), 0, s, d, g,
+    hipLaunchKernelGGL(pm_backward_fused_kernel, dim3(n_chain * stride), dim3(PMF_WAVES * 64), 0, s, d, g, fk,
                        acts, g_rotation, g_translation, (unsigned long long*)(tail + 4), (uint32_t*)tail,
                        sync_state ? (uint32_t*)sync_state + 2 * (size_t)depth * width + 1 : nullptr,
                        (uint32_t*)tail + 1, flat_grads, tail + pm_sync_floats(depth, width), n_chain, stride,
                        (unsigned long long*)(tail + pm_xcc_offset(depth, width)), g_pm_trace ? g_pm_trace + 64 : nullptr);
     RIGGS_HIP_CHECK(hipGetLastError());
     return 0;
+  }
+  if (fk.J > 0) {
+    // (one launch per layer — networks the one-launch kernels do not take: the reverse sweep is a launch of its own as well)
+    RIGGS_REQUIRE(fk.dq_out && fk.dgt_out, "riggs_pose_mlp_backward_fk needs dL_dlocal_rot and dL_dglobal_trans");
+    if (g_translation) RIGGS_HIP_CHECK(hipMemcpyAsync(fk.dgt_out, g_translation, 12, hipMemcpyDeviceToDevice, s));
+    else RIGGS_HIP_CHECK(hipMemsetAsync(fk.dgt_out, 0, 12, s));
+    int rc2 = riggs_fk_backward(fk.J, fk.local_rot, fk.joints, fk.parents, fk.dG, fk.g_nodes, fk.dq_out, fk.dgt_out, stream);
+    if (rc2) return rc2;
+    RIGGS_REQUIRE(g_rotation == nullptr, "riggs_pose_mlp_backward_fk: an extra rotation gradient needs the one-launch kernels");
+    g_rotation = fk.dq_out; g_translation = fk.dgt_out;
   }
   RIGGS_HIP_CHECK(hipMemsetAsync(dh, 0, (size_t)(depth + 1) * PM_MAX_IN * sizeof(float), s));
   for (int l = depth; l >= 0; l--) {
@@ -742,6 +798,33 @@ int riggs_pose_mlp_backward(int32_t depth, int32_t width, int32_t multires, int3
                      g_translation, flat_grads);
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
+}
+
+int riggs_pose_mlp_backward(int32_t depth, int32_t width, int32_t multires, int32_t skip, int32_t n_rot,
+                            const float* const* weights, const float* const* biases, const float* W_rot,
+                            const float* b_rot, const float* W_tr, const float* b_tr, float* acts,
+                            const float* g_rotation, const float* g_translation, float* workspace,
+                            float* flat_grads, void* sync_state, riggs_stream stream) {
+  PmFkArgs fk;
+  memset(&fk, 0, sizeof(fk));
+  return pm_backward_impl(depth, width, multires, skip, n_rot, weights, biases, W_rot, b_rot, W_tr, b_tr, acts, g_rotation,
+                          g_translation, workspace, flat_grads, sync_state, stream, fk);
+}
+
+int riggs_pose_mlp_backward_fk(int32_t depth, int32_t width, int32_t multires, int32_t skip, int32_t n_rot,
+                               const float* const* weights, const float* const* biases, const float* W_rot,
+                               const float* b_rot, const float* W_tr, const float* b_tr, float* acts, int32_t num_joints,
+                               const float* local_rot, const float* joints, const int32_t* parents,
+                               const float* dL_dtransforms, const float* dL_dd_nodes, const float* g_rotation,
+                               const float* g_translation, float* dL_dlocal_rot, float* dL_dglobal_trans, float* workspace,
+                               float* flat_grads, void* sync_state, riggs_stream stream) {
+  RIGGS_REQUIRE(num_joints >= 1 && num_joints <= MAX_J && 4 * num_joints == n_rot, "the rotation head must predict one quaternion per joint");
+  RIGGS_REQUIRE(local_rot && joints && parents && dL_dtransforms, "riggs_pose_mlp_backward_fk: missing chain input");
+  PmFkArgs fk;
+  fk.J = num_joints; fk.local_rot = local_rot; fk.joints = joints; fk.parents = parents; fk.dG = dL_dtransforms;
+  fk.g_nodes = dL_dd_nodes; fk.dq_out = dL_dlocal_rot; fk.dgt_out = dL_dglobal_trans;
+  return pm_backward_impl(depth, width, multires, skip, n_rot, weights, biases, W_rot, b_rot, W_tr, b_tr, acts, g_rotation,
+                          g_translation, workspace, flat_grads, sync_state, stream, fk);
 }
 
 }  // extern "C"

@@ -310,6 +310,99 @@ class _DeformByPose(torch.autograd.Function):
         return dq, dgt, drho, gmask, None, None, None, None, dmod
 
 
+class _PoseDeform(torch.autograd.Function):
+    """SkeletonWarp.forward(x, t, mask) as ONE autograd node over three launches forward and three backward: PoseMLP, then
+    forward kinematics + skinning in one launch (riggs_lbs_forward_fk); skinning backward (two launches), then the reverse
+    sweep of the kinematic chain + PoseMLP backward in one launch (riggs_pose_mlp_backward_fk).  Same arithmetic as
+    _PoseMLPFn + _DeformByPose (get_pose_info + deform_by_pose), two launches fewer per frame (~13 us of a 385 us frame)."""
+
+    @staticmethod
+    def forward(ctx, t, rot_bias, sync, rho, mask, x, joints, parents_i32, K, weight_mod, depth, width, multires, skip, *params):
+        ctx.set_materialize_grads(False)
+        params = [p.contiguous() for p in params]
+        lib, dev = L.lib(), x.device
+        N, J = x.shape[0], joints.shape[0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        n_rot = params[2 * depth].shape[0]
+        if weight_mod is not None:
+            weight_mod = L.require_cuda_f32("skinning weight offsets", weight_mod, (N, J - 1))
+        rho = L.require_cuda_f32("_node_radius", rho, (J,))
+        mflat = None if mask is None else L.require_cuda_f32("motion_mask", mask.reshape(-1), (N,))
+        acts = torch.empty(lib.riggs_pose_mlp_acts_floats(depth, width, multires), **f32)
+        local_rot = torch.empty(J, 4, **f32)
+        global_trans = torch.empty(3, **f32)
+        Wp, bp = _PoseMLPFn._ptrs(params, depth)
+        h = params[2 * depth:]
+        st = L.stream_ptr()
+        L.check(lib.riggs_pose_mlp_forward(depth, width, multires, skip, n_rot, Wp, bp, h[0].data_ptr(), h[1].data_ptr(),
+                                           h[2].data_ptr(), h[3].data_ptr(), t.data_ptr(), L.ptr(rot_bias), L.ptr(sync),
+                                           acts.data_ptr(), local_rot.data_ptr(), global_trans.data_ptr(), st),
+                "riggs_pose_mlp_forward")
+        transforms = torch.empty(J, 12, **f32)
+        node_rot = torch.empty(J, 4, **f32)
+        d_nodes = torch.empty(J, 3, **f32)
+        d_xyz = torch.empty(N, 3, **f32)
+        d_rot = torch.empty(N, 4, **f32)
+        L.check(lib.riggs_lbs_forward_fk(N, J, K, x.data_ptr(), joints.data_ptr(), parents_i32.data_ptr(), rho.data_ptr(),
+                                         local_rot.data_ptr(), global_trans.data_ptr(), L.ptr(mflat), L.ptr(weight_mod),
+                                         transforms.data_ptr(), node_rot.data_ptr(), d_nodes.data_ptr(), d_xyz.data_ptr(),
+                                         d_rot.data_ptr(), st), "riggs_lbs_forward_fk")
+        ctx.save_for_backward(acts, local_rot, global_trans, rho, mflat, x, joints, parents_i32, transforms, node_rot, weight_mod,
+                              *params)
+        ctx.cfg = (depth, width, multires, skip, n_rot, K)
+        ctx.sync = sync
+        ctx.mask_shape = None if mask is None else mask.shape
+        ctx.mark_non_differentiable(node_rot)
+        return d_xyz, d_rot, d_nodes, local_rot, global_trans, transforms, node_rot
+
+    @staticmethod
+    def backward(ctx, g_xyz, g_rot, g_nodes, g_local_rot, g_global_trans, g_transforms, _g_node_rot):
+        acts, local_rot, global_trans, rho, mflat, x, joints, parents_i32, transforms, node_rot, weight_mod, *params = ctx.saved_tensors
+        depth, width, multires, skip, n_rot, K = ctx.cfg
+        N, J = x.shape[0], joints.shape[0]
+        lib, dev = L.lib(), x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        g_xyz = torch.zeros(N, 3, **f32) if g_xyz is None else g_xyz.contiguous()
+        g_rot = torch.zeros(N, 4, **f32) if g_rot is None else g_rot.contiguous()
+        dG = torch.empty(J, 12, **f32)
+        from .dist import grad_out, grad_out_flat
+        drho = grad_out(rho, (J,))
+        dgt = torch.empty(3, **f32)
+        need_mask = mflat is not None and ctx.needs_input_grad[4]
+        dmask = torch.empty(N, **f32) if need_mask else None
+        dmod = torch.empty(N, J - 1, **f32) if weight_mod is not None else None
+        st = L.stream_ptr()
+        ws = torch.empty(lib.riggs_lbs_backward_workspace_bytes(N, J), dtype=torch.uint8, device=dev)
+        L.check(lib.riggs_lbs_backward(N, J, K, x.data_ptr(), joints.data_ptr(), parents_i32.data_ptr(), rho.data_ptr(),
+                                       transforms.data_ptr(), node_rot.data_ptr(), global_trans.data_ptr(), L.ptr(mflat),
+                                       L.ptr(weight_mod), g_xyz.data_ptr(), g_rot.data_ptr(), dG.data_ptr(), drho.data_ptr(),
+                                       dgt.data_ptr(), L.ptr(dmask), L.ptr(dmod), ws.data_ptr(), st), "riggs_lbs_backward")
+        if g_transforms is not None:
+            dG = dG + g_transforms
+        if g_global_trans is not None:
+            dgt = dgt + g_global_trans.reshape(-1)
+        gn = None if g_nodes is None else g_nodes.contiguous()
+        gq = None if g_local_rot is None else g_local_rot.contiguous()
+        flat = grad_out_flat(params)  # the flat gradient bucket's own range when one is registered
+        dzs = torch.empty(lib.riggs_pose_mlp_backward_workspace_floats(depth, width, multires), **f32)
+        dq = torch.empty(J, 4, **f32)
+        dgt_total = torch.empty(3, **f32)
+        Wp, bp = _PoseMLPFn._ptrs(params, depth)
+        h = params[2 * depth:]
+        L.check(lib.riggs_pose_mlp_backward_fk(depth, width, multires, skip, n_rot, Wp, bp, h[0].data_ptr(), h[1].data_ptr(),
+                                               h[2].data_ptr(), h[3].data_ptr(), acts.data_ptr(), J, local_rot.data_ptr(),
+                                               joints.data_ptr(), parents_i32.data_ptr(), dG.data_ptr(), L.ptr(gn), L.ptr(gq),
+                                               dgt.data_ptr(), dq.data_ptr(), dgt_total.data_ptr(), dzs.data_ptr(),
+                                               flat.data_ptr(), L.ptr(ctx.sync), st), "riggs_pose_mlp_backward_fk")
+        grads, o = [], 0
+        for p in params:
+            n = p.numel()
+            grads.append(flat[o:o + n].view_as(p))
+            o += n
+        gmask = dmask.reshape(ctx.mask_shape) if need_mask else None
+        return (None, None, None, drho, gmask, None, None, None, None, dmod, None, None, None, None, *grads)
+
+
 class _LazyDeformDict(dict):
     """deform_by_pose's return dict; ``nn_idx`` / ``nn_weight`` (needed by render_rig.py:156-158,
     not by training) are materialised by the HIP kernel on first access."""
@@ -437,6 +530,10 @@ class SkeletonWarp(nn.Module):
         return {"local_rotation": m["rotation"].reshape(-1, 4), "global_trans": m["translation"], "t": t[0]}
 
     def forward(self, x, t, motion_mask, **kwargs):
+        if t.dim() == 0:
+            t = self.expand_time(t)
+        if x.is_cuda and self.pose_net._fusable(t[0]) and self.pose_net.rotation_predictor.out_features == 4 * self.nodes.shape[0]:
+            return self.deform_by_pose(x, None, motion_mask, _time=t[0])  # PoseMLP + FK + skinning as one autograd node
         return self.deform_by_pose(x, self.get_pose_info(t), motion_mask)
 
     # ---- the per-Gaussian MLP heads: fp32 GEMMs through torch (the reference's arithmetic, default), or — opt-in —
@@ -474,9 +571,10 @@ class SkeletonWarp(nn.Module):
         x_emb = _embed(x, net.multires) if net.multires > 0 else x
         return self._fh_d(torch.cat([x_emb, t_emb], dim=-1))
 
-    def deform_by_pose(self, x, node_attrs, motion_mask):
+    def deform_by_pose(self, x, node_attrs, motion_mask, _time=None):
         x = L.require_cuda_f32("x", x.detach(), (x.shape[0], 3))
-        local_rot, global_trans = node_attrs["local_rotation"], node_attrs["global_trans"]
+        if _time is None:
+            local_rot, global_trans = node_attrs["local_rotation"], node_attrs["global_trans"]
         joints = self._joints()
         par = self._parents_dev(x.device)
         mask = motion_mask
@@ -490,8 +588,23 @@ class SkeletonWarp(nn.Module):
                                           "only K = -1 is well defined")
             weight_mod = self._head_weight(x)
             self.skinning_weight_offsets = weight_mod
-        d_xyz, d_rot, d_nodes, transforms, node_rot = _DeformByPose.apply(
-            local_rot, global_trans, self._node_radius, mask, x, joints, par, self.K, weight_mod)
+        if _time is not None:
+            pn = self.pose_net
+            params = []
+            for l in pn.net:
+                params += [l.weight, l.bias]
+            params += [pn.rotation_predictor.weight, pn.rotation_predictor.bias, pn.translation_predictor.weight,
+                       pn.translation_predictor.bias]
+            sync = pn._hip_sync
+            if sync.device != x.device or sync.numel() * 4 < L.lib().riggs_pose_mlp_sync_bytes(len(pn.net), pn.net[0].out_features):
+                sync = None
+            d_xyz, d_rot, d_nodes, local_rot, global_trans, transforms, node_rot = _PoseDeform.apply(
+                _time.reshape(1), self._rot_bias, sync, self._node_radius, mask, x, joints, par, self.K, weight_mod,
+                len(pn.net), pn.net[0].out_features, pn.multires, pn.skips[0], *params)
+            node_attrs = {"local_rotation": local_rot, "global_trans": global_trans, "t": _time}
+        else:
+            d_xyz, d_rot, d_nodes, transforms, node_rot = _DeformByPose.apply(
+                local_rot, global_trans, self._node_radius, mask, x, joints, par, self.K, weight_mod)
         if self.use_template_offsets:  # skeleton_warp.py:152-158: offsets join the blended position before the mask
             pose = local_rot.detach().reshape(-1)[None].expand(x.shape[0], -1)
             self.template_offsets = self._head_detail(x, pose)

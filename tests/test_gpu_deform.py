@@ -340,3 +340,42 @@ def test_a_lost_handoff_surfaces_through_check_before_anything_is_exchanged_or_s
             assert float((p.grad - b).abs().max()) <= 1e-5 * max(1e-12, float(b.abs().max()))
     except L.RiggsHipError:
         pass  # reported: the caller drops the step
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("J,K,heads", [(24, -1, False), (64, -1, False), (12, 3, False), (24, -1, True)])
+def test_forward_as_one_node_matches_pose_net_plus_deform_by_pose(J, K, heads):
+    """SkeletonWarp.forward runs PoseMLP, FK + skinning (one launch) and, backward, skinning, then FK^T + PoseMLP (one launch) as
+    ONE autograd node; get_pose_info + deform_by_pose are the same arithmetic over two nodes and two launches more.  Outputs
+    and every gradient agree (the FK chain is evaluated by different workgroups, not in a different order)."""
+    from riggs_amd import synth
+    from riggs_amd.skeleton import SkeletonWarp
+    sc = synth.make_scene(3000, J, 7)
+    torch.manual_seed(3)
+    sw = SkeletonWarp(joints=sc["joints"], parent_indices=sc["parents"], K=K, hyper_dim=8, use_skinning_weight_mlp=heads,
+                      use_template_offsets=heads).cuda()
+    sw._node_radius.data = sc["node_radius"].cuda()
+    x = sc["xyz"].cuda()
+    mask = torch.rand(x.shape[0], 1, device="cuda")
+    t = torch.tensor(0.41, device="cuda")
+    g = torch.Generator().manual_seed(1)
+    w_xyz, w_rot, w_nodes = (torch.randn(s, generator=g).cuda() for s in ((x.shape[0], 3), (x.shape[0], 4), (J, 3)))
+
+    def run(fused):
+        for p in sw.parameters():
+            p.grad = None
+        dv = sw(x, t, mask) if fused else sw.deform_by_pose(x, sw.get_pose_info(sw.expand_time(t)), mask)
+        loss = (dv["d_xyz"] * w_xyz).sum() + (dv["d_rotation"] * w_rot).sum() + (dv["d_nodes"] * w_nodes).sum() \
+            + 0.1 * (dv["local_rotation"] ** 2).sum() + 0.3 * dv["global_trans"].sum()
+        loss.backward()
+        return ({k: dv[k].detach().clone() for k in ("d_xyz", "d_rotation", "d_nodes", "local_rotation", "global_trans")},
+                {n: p.grad.detach().clone() for n, p in sw.named_parameters() if p.grad is not None})
+
+    o1, g1 = run(True)
+    o0, g0 = run(False)
+    sw.pose_net.check_status()
+    for k in o0:
+        assert float((o1[k] - o0[k]).abs().max()) <= 1e-6 * max(1.0, float(o0[k].abs().max())), k
+    assert set(g0) == set(g1) and len(g0) >= 20
+    for n in g0:
+        assert float((g1[n] - g0[n]).abs().max()) <= 2e-5 * max(1e-9, float(g0[n].abs().max())), n
