@@ -6,8 +6,9 @@ instead of a KNN extension call, ~10 (N, K, ·) gathers, an einsum and autograd'
 Covered: the configuration the trainer ships (KNN weights; ``local_frame``, ``d_rot_as_res``, ``with_node_weight``, ``hyper_dim``
 free) through the HIP kernels; ``pred_opacity`` / ``pred_color`` (two more blends with the same weights, torch ops on the
 kernel's neighbour lists) and ``skinning=True`` (softmax of a per-Gaussian (N, M) feature instead of KNN weights: a dense
-(N, M) x (M, 14) product, left to the GEMM library) as the reference defines them; ``node_trans_bias`` (the GUI's editing
-path) raises.  The node network
+(N, M) x (M, 14) product, left to the GEMM library) as the reference defines them; ``node_trans_bias`` (the GUI's drag-to-edit
+path, time_utils.py:1165-1213: an as-rigid-as-possible re-posing of the Gaussians around dragged nodes, under ``no_grad``) in
+torch ops on top of the kernel's blend — it runs per mouse event, not per training step.  The node network
 (``self.network``: nodes, t -> per-node attributes; 512-1024 rows, time_utils.py:990-1002) stays a torch module supplied by the
 caller — it is a few hundred rows through an MLP, not a per-Gaussian cost.  No CPU / eager fallback.
 """
@@ -144,6 +145,53 @@ def skinning_blend(feature, motion_mask, node_attrs, d_rot_as_res=True, pred_opa
     return out
 
 
+# ---- the editing path's geometry (all under no_grad; M nodes, a few hundred) -------------------------------------------------
+def _quat_to_mat(q):
+    """Rotation matrices of un-normalised (w, x, y, z) quaternions, scale 2 / |q|^2 (time_utils.py:115-132)."""
+    w, a, b, c = q.unbind(-1)
+    s = 2.0 / (q * q).sum(-1)
+    rows = [1 - s * (b * b + c * c), s * (a * b - c * w), s * (a * c + b * w),
+            s * (a * b + c * w), 1 - s * (a * a + c * c), s * (b * c - a * w),
+            s * (a * c - b * w), s * (b * c + a * w), 1 - s * (a * a + b * b)]
+    return torch.stack(rows, -1).reshape(q.shape[:-1] + (3, 3))
+
+
+def _mat_to_quat(m):
+    """(w, x, y, z) of rotation matrices: of the four algebraically equal candidates the one with the largest denominator
+    (time_utils.py:146-205; no sign convention)."""
+    sq = torch.stack([1.0 + m[..., 0, 0] + m[..., 1, 1] + m[..., 2, 2], 1.0 + m[..., 0, 0] - m[..., 1, 1] - m[..., 2, 2],
+                      1.0 - m[..., 0, 0] + m[..., 1, 1] - m[..., 2, 2], 1.0 - m[..., 0, 0] - m[..., 1, 1] + m[..., 2, 2]], -1)
+    qa = torch.where(sq > 0, sq.clamp_min(0).sqrt(), torch.zeros_like(sq))
+    a, b, c = m[..., 2, 1] - m[..., 1, 2], m[..., 0, 2] - m[..., 2, 0], m[..., 1, 0] - m[..., 0, 1]
+    e, f, g = m[..., 1, 0] + m[..., 0, 1], m[..., 0, 2] + m[..., 2, 0], m[..., 1, 2] + m[..., 2, 1]
+    cand = torch.stack([torch.stack([qa[..., 0] ** 2, a, b, c], -1), torch.stack([a, qa[..., 1] ** 2, e, f], -1),
+                        torch.stack([b, e, qa[..., 2] ** 2, g], -1), torch.stack([c, f, g, qa[..., 3] ** 2], -1)], -2)
+    cand = cand / (2.0 * qa[..., None].clamp_min(0.1))
+    pick = qa.argmax(-1)
+    return torch.gather(cand, -2, pick[..., None, None].expand(pick.shape + (1, 4))).squeeze(-2)
+
+
+def _quat_mul(p, q):
+    """Hamilton product, result with a non-negative real part (time_utils.py:99-113)."""
+    pw, px, py, pz = p.unbind(-1)
+    qw, qx, qy, qz = q.unbind(-1)
+    r = torch.stack([pw * qw - px * qx - py * qy - pz * qz, pw * qx + px * qw + py * qz - pz * qy,
+                     pw * qy - px * qz + py * qw + pz * qx, pw * qz + px * qy - py * qx + pz * qw], -1)
+    return torch.where(r[..., :1] < 0, -r, r)
+
+
+def _knn_sq(a, b, K, rows=32768):
+    """The K nearest rows of ``b`` for every row of ``a`` by squared Euclidean distance, ascending (what the reference asks
+    pytorch3d.ops.knn_points for); exact differences, in slabs of rows."""
+    ds, ix = [], []
+    for s0 in range(0, a.shape[0], rows):
+        d = ((a[s0:s0 + rows, None, :] - b[None, :, :]) ** 2).sum(-1)
+        dk, ik = d.topk(K, dim=1, largest=False, sorted=True)
+        ds.append(dk)
+        ix.append(ik)
+    return torch.cat(ds), torch.cat(ix)
+
+
 class StaticNodeNetwork(nn.Module):
     """``StaticNetwork(return_tensors=True)`` (time_utils.py:288-301): zero attributes for every node."""
 
@@ -197,16 +245,124 @@ class ControlNodeWarp(nn.Module):
         return t.unsqueeze(0).expand(self.nodes.shape[0], -1)
 
     def node_deform(self, t, **kwargs):
+        if t.dim() == 3:  # (M, T, 1): the nodes at T times each (time_utils.py:990-1002)
+            M, T = t.shape[0], t.shape[1]
+            x = self.nodes[:, None, :3].detach().expand(M, T, 3).reshape(-1, 3)
+            v = self.network(x=x, t=t.reshape(-1, 1), **kwargs)
+            return {k: (a.view(M, T, a.shape[-1]) if a is not None else None) for k, a in v.items()}
         return self.network(x=self.nodes[..., :3].detach(), t=t, **kwargs)
 
+    # ---- the editing path (node_trans_bias): time_utils.py:1004-1011, 1044-1077, 969-988, 1122-1131, 1165-1213 -------------
+    def get_trajectory(self, t_samp_num=8):
+        t = torch.linspace(0, 1, t_samp_num, device=self.nodes.device)[None, :, None].expand(self.node_num, t_samp_num, 1)
+        nd = self.node_deform(t=t)
+        traj = self.nodes[:, None, :3].detach() + nd["d_xyz"]
+        return traj.detach(), {k: (v[:, 0] if v is not None else None) for k, v in nd.items()}
+
+    def geodesic_distance_floyd(self, cur_node, K=8):
+        """All-pairs shortest paths over the K-nearest-neighbour graph of the nodes (Floyd-Warshall on an (M, M) matrix)."""
+        M = cur_node.shape[0]
+        d2, idx = _knn_sq(cur_node, cur_node, K + 1)
+        dist = torch.full((M, M), float("inf"), device=cur_node.device)
+        dist.scatter_(1, idx, d2.sqrt())
+        dist = torch.minimum(dist, dist.T)
+        for i in range(M):
+            dist = torch.minimum(dist[:, i, None] + dist[None, i, :], dist)
+        return dist
+
+    def cal_nn_weight_floyd(self, x, t0, cur_node, K=None, GraphK=2, temperature=1.0, cache_name="floyd", XisNode=False):
+        """Weights of the K graph-nearest nodes of every point's nearest node; the graph distances are cached per name until
+        the time moves by more than 1e-2 (time_utils.py:969-988)."""
+        if not hasattr(self, cache_name + "_nn_dist") or (t0 is not None and (getattr(self, cache_name + "_t") - t0).abs().max() > 1e-2):
+            gd, gi = self.geodesic_distance_floyd(cur_node=cur_node, K=GraphK).sort(dim=1)
+            o = 1 if XisNode else 0
+            setattr(self, cache_name + "_nn_dist", gd[:, o:K + o])
+            setattr(self, cache_name + "_nn_idx", gi[:, o:K + o])
+            if t0 is not None:
+                setattr(self, cache_name + "_t", t0.clone())
+        d2, i1 = _knn_sq(x, cur_node, 1)
+        d2, i1 = d2[:, 0], i1[:, 0]
+        kd = getattr(self, cache_name + "_nn_dist")[i1] + d2[:, None]
+        return torch.softmax(-kd / temperature, dim=-1), kd, getattr(self, cache_name + "_nn_idx")[i1]
+
+    def p2dR(self, p, p0=None, K=8, as_quat=True, mode="trajectory", t0=None):
+        """Per node the rotation that best maps its edges to its K neighbours at rest (``p0``) onto the edges after the drag
+        (``p``): Kabsch on weighted unit edges (time_utils.py:1044-1077).  Neighbours: K nearest by the nodes' trajectories
+        (four time samples), by graph distance (``floyd``) or by rest position."""
+        p = p.detach()
+        nodes = self.nodes[..., :3].detach()
+        t0_deform = None
+        if mode == "trajectory":
+            traj, t0_deform = self.get_trajectory(t_samp_num=4)
+            base = traj[:, 0] if p0 is None else p0
+            flat = traj.reshape(traj.shape[0], -1)
+            d2, idx = _knn_sq(flat, flat, K + 1)
+            d2, idx = d2[:, 1:], idx[:, 1:]
+            w = torch.softmax(d2 / d2.mean(), dim=-1)
+            edges = base[idx] - base[:, None]
+        elif mode == "floyd":
+            w, _, idx = self.cal_nn_weight_floyd(x=p, t0=t0, cur_node=p0, K=K + 1, GraphK=4, temperature=1e-1, cache_name="p2dR", XisNode=True)
+            w, idx = w[:, 1:], idx[:, 1:]
+            edges = p0[idx] - p0[:, None]
+        else:
+            d2, idx = _knn_sq(nodes, nodes, K + 1)
+            d2, idx = d2[:, 1:], idx[:, 1:]
+            w = torch.softmax(d2 / d2.mean(), dim=-1)
+            base = nodes if p0 is None else p0
+            edges = base[idx] - base[:, None]
+        edges_t = p[idx] - p[:, None]
+        edges = edges / (edges.norm(dim=-1, keepdim=True) + 1e-5)
+        edges_t = edges_t / (edges_t.norm(dim=-1, keepdim=True) + 1e-5)
+        S = torch.einsum("nka,nk,nkb->nab", edges, w, edges_t)
+        U, _, Vh = torch.linalg.svd(S.cpu())  # (M, 3, 3): tiny, and the host's LAPACK is what torch.svd means everywhere
+        dR = (Vh.transpose(-1, -2) @ U.transpose(-1, -2)).to(S.device)
+        return (_mat_to_quat(dR) if as_quat else dR), t0_deform
+
+    @torch.no_grad()
+    def _edit(self, x, t, out, node_attrs, node_trans_bias, motion_mask):
+        """The Gaussians re-posed around dragged nodes: every Gaussian keeps its offset to its (graph-)nearest nodes, rotated
+        with them (time_utils.py:1165-1213).  ``out``: the blend without the drag."""
+        rot_bias = torch.tensor([1.0, 0.0, 0.0, 0.0], device=x.device)
+        node_trans = node_attrs["d_xyz"]
+        cur_node = (self.nodes[..., :3] + node_trans).detach()
+        nodes_t = cur_node + node_trans_bias
+        gs_init = x + out["d_xyz"]
+        if not self.d_rot_as_res:
+            node_rot = node_attrs["d_rotation"]  # (already bias-multiplied by forward())
+            d2, idx = _knn_sq(gs_init, cur_node, 32)
+            w = torch.exp(-d2 / (2 * self.node_radius[idx] ** 2))
+            if self.with_node_weight:
+                w = w * self.node_weight[idx][..., 0]
+            w = w + 1e-7
+            w = w / w.sum(dim=-1, keepdim=True)
+            R = _quat_to_mat(node_rot + rot_bias)[idx]
+            gs_t = nodes_t[idx] + torch.einsum("gkab,gkb->gka", R, gs_init[:, None] - cur_node[idx])
+            out["d_xyz"] = ((gs_t * w[..., None]).sum(dim=1) - x) * motion_mask
+            return out
+        w, _, idx = self.cal_nn_weight_floyd(x=gs_init, t0=t, cur_node=cur_node, K=8, GraphK=3, temperature=1e-3, XisNode=False)
+        q_bias, _ = self.p2dR(p=nodes_t, p0=cur_node, K=8, as_quat=True, mode="trajectory", t0=t)
+        R = _quat_to_mat(q_bias)[idx]
+        gs_t = nodes_t[idx] + torch.einsum("gkab,gkb->gka", R, gs_init[:, None] - cur_node[idx])
+        out["d_xyz"] = ((gs_t * w[..., None]).sum(dim=1) - x) * motion_mask
+        out["d_rotation_bias"] = ((q_bias[idx] * w[..., None]).sum(dim=1) - rot_bias) * motion_mask + rot_bias
+        return out
+
     def forward(self, x, t, feature, motion_mask, animation_d_values=None, node_trans_bias=None, **kwargs):
-        if node_trans_bias is not None:
-            raise NotImplementedError("node_trans_bias (the editing path, time_utils.py:1165-1213) is out of scope")
         if t.dim() == 0:
             t = self.expand_time(t)
         node_attrs = dict(self.node_deform(t=t))
         if animation_d_values is not None:
             node_attrs.update(animation_d_values)
+        if node_trans_bias is not None:
+            if self.skinning:
+                raise NotImplementedError("node_trans_bias with skinning: the reference's own forward fails there (cal_nn_weight "
+                                          "is asked for the weights of feature=None, time_utils.py:936)")
+            if not self.d_rot_as_res:  # the dragged nodes' rotations enter the blend itself (time_utils.py:1165-1172)
+                with torch.no_grad():
+                    rb = torch.tensor([1.0, 0.0, 0.0, 0.0], device=x.device)
+                    cur = (self.nodes[..., :3] + node_attrs["d_xyz"]).detach()
+                    q_bias, _ = self.p2dR(p=cur + node_trans_bias, p0=cur, K=8, as_quat=True, mode="trajectory", t0=t)
+                node_attrs["d_rotation"] = _quat_mul(q_bias, node_attrs["d_rotation"] + rb) - rb
         if self.skinning:
             out = skinning_blend(feature, motion_mask, node_attrs, self.d_rot_as_res, self.pred_opacity, self.pred_color)
         else:
@@ -221,4 +377,6 @@ class ControlNodeWarp(nn.Module):
                 if self.pred_color:
                     out["d_color"] = (node_attrs["d_color"][idx] * w[..., None]).sum(dim=1) * motion_mask
         out["d_nodes"] = self.nodes[..., :3] + node_attrs["d_xyz"]
+        if node_trans_bias is not None:
+            out = self._edit(x.detach(), t, out, node_attrs, node_trans_bias, motion_mask)
         return out

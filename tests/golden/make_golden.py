@@ -452,6 +452,56 @@ def fixture_control_nodes_blends(name, seed, N, M, skinning, d_rot_as_res):
     print("wrote", name, {k: float(np.abs(v).max()) for k, v in z.items() if k.startswith("grad_")})
 
 
+class WavingNodes(torch.nn.Module):
+    """A closed-form node network for the editing fixtures (the reference asks its network for the nodes' trajectory at four
+    times, time_utils.py:1004-1011): d_xyz = 0.08 sin(2 pi t + 3 x), the other attributes zero.  tests/test_gpu_cnode.py builds
+    the same module."""
+
+    def forward(self, x, t, **kwargs):
+        z3, z4 = torch.zeros_like(x), torch.zeros(x.shape[0], 4, dtype=x.dtype, device=x.device)
+        return {"d_xyz": 0.08 * torch.sin(6.283185307179586 * t + 3.0 * x), "d_rotation": z4, "d_scaling": z3,
+                "local_rotation": z4.clone(), "hidden": None, "d_opacity": None, "d_color": None}
+
+
+def fixture_control_nodes_edit(name, seed, N, M, d_rot_as_res):
+    """ControlNodeWarp.forward with ``node_trans_bias`` (utils/time_utils.py:1165-1213, the GUI's drag-to-edit path, under
+    no_grad): p2dR (:1044-1077, trajectory mode through get_trajectory :1004-1011 and torch.svd), cal_nn_weight_floyd /
+    geodesic_distance_floyd (:969-988, 1122-1131), cal_nn_weight on the posed nodes with K = 32.  knn_points is the published-
+    contract stand-in (see above)."""
+    import pytorch3d.ops as p3o
+    import pytorch3d as p3
+    p3o.knn_points = knn_points_published
+    p3.ops = p3o
+    with S.quiet():
+        from utils.time_utils import ControlNodeWarp
+        cn = ControlNodeWarp(is_blender=True, node_num=M, K=3, with_node_weight=True, local_frame=False, d_rot_as_res=d_rot_as_res,
+                             hyper_dim=2, is_scene_static=True)
+    cn.network = WavingNodes()
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, 3, generator=g) * 0.5
+    nodes = torch.cat([x[torch.randint(0, N, (M,), generator=g)] + 0.05 * torch.randn(M, 3, generator=g),
+                       1e-2 + 0.02 * torch.randn(M, 2, generator=g)], -1)
+    cn.nodes = torch.nn.Parameter(nodes)
+    cn._node_radius = torch.nn.Parameter(math.log(0.15) + 0.3 * torch.randn(M, generator=g))
+    cn._node_weight = torch.nn.Parameter(0.5 * torch.randn(M, 1, generator=g))
+    feature = 0.02 * torch.randn(N, 3, generator=g)
+    mask = torch.rand(N, 1, generator=g)
+    # a drag: a handful of nodes pulled along one direction, their neighbours less
+    pull = torch.zeros(M, 3)
+    centre = nodes[0, :3]
+    pull[:] = torch.tensor([0.25, -0.1, 0.15]) * torch.exp(-((nodes[:, :3] - centre) ** 2).sum(-1, keepdim=True) / 0.08)
+    t = torch.tensor(0.3)
+    with torch.no_grad():
+        out = cn(x, t, feature, mask, node_trans_bias=pull)
+    z = dict(x=np_(x), nodes=np_(nodes), _node_radius=np_(cn._node_radius), _node_weight=np_(cn._node_weight), feature=np_(feature),
+             motion_mask=np_(mask), node_trans_bias=np_(pull), t=float(t), d_rot_as_res=d_rot_as_res,
+             out_d_xyz=np_(out["d_xyz"]), out_d_rotation=np_(out["d_rotation"]), out_d_scaling=np_(out["d_scaling"]))
+    if "d_rotation_bias" in out:
+        z["out_d_rotation_bias"] = np_(out["d_rotation_bias"])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **z)
+    print("wrote", name, {k: float(np.abs(v).max()) for k, v in z.items() if k.startswith("out_")})
+
+
 def seeded_heads(J, WeightCls, DeformCls, seed):
     """The two per-Gaussian MLP heads with reproducible weights (the fixture stores checksums, not 4 MB of weights):
     constructed standalone, in this order, right after torch.manual_seed(seed)."""
@@ -530,5 +580,7 @@ if __name__ == "__main__":
     fixture_control_nodes_blends("cnodes_skinning_m48", 84, 220, 48, True, True)
     fixture_control_nodes_blends("cnodes_skinning_abs_m32", 85, 150, 32, True, False)
     fixture_control_nodes_blends("cnodes_knn_pred_opacity_color", 86, 260, 64, False, True)
+    fixture_control_nodes_edit("cnodes_edit_res_m96", 87, 500, 96, True)
+    fixture_control_nodes_edit("cnodes_edit_abs_m64", 88, 350, 64, False)
     fixture_skeleton_projection("skelproj_chain8_m90_K", 72, 8, 90, True, chain=True)
     fixture_state_dict_layout()

@@ -123,8 +123,9 @@ def test_no_feature_means_xyz_only_and_unsupported_options_raise():
     assert float(out["d_xyz"].detach().abs().max()) == 0 and out["d_nodes"].shape == (32, 3)   # static network: zero deformation
     with pytest.raises(NotImplementedError):
         ControlNodeWarp(skinning=True, local_frame=True)  # (the reference's own forward fails in this combination)
-    with pytest.raises(NotImplementedError):
-        cn(x, torch.tensor(0.1, device="cuda"), None, 1.0, node_trans_bias=torch.zeros(32, 3, device="cuda"))
+    with pytest.raises(NotImplementedError):  # (the reference's own forward fails here as well)
+        ControlNodeWarp(node_num=8, skinning=True).cuda()(x, torch.tensor(0.1, device="cuda"), torch.randn(100, 8, device="cuda"), 1.0,
+                                                          node_trans_bias=torch.zeros(8, 3, device="cuda"))
     with pytest.raises(L.RiggsHipError):
         control_node_blend(x.cpu(), None, None, cn.nodes, cn._node_radius, None, cn.node_deform(torch.zeros(32, 1, device="cuda")))
     with pytest.raises(L.RiggsHipError):  # K > 8
@@ -248,3 +249,38 @@ def test_pred_opacity_and_color_match_reference_golden():
     assert rel(cn.nodes.grad.cpu().numpy(), g["grad_nodes"]) < 2e-4
     for k in ("d_xyz", "d_rotation", "d_scaling", "d_opacity", "d_color"):
         assert rel(attrs[k].grad.cpu().numpy(), g["grad_attr_" + k]) < 2e-4, k
+
+
+class _WavingNodes(torch.nn.Module):
+    """The closed-form node network of the editing fixtures (tests/golden/make_golden.py: WavingNodes)."""
+
+    def forward(self, x, t, **kwargs):
+        z3, z4 = torch.zeros_like(x), torch.zeros(x.shape[0], 4, dtype=x.dtype, device=x.device)
+        return {"d_xyz": 0.08 * torch.sin(6.283185307179586 * t + 3.0 * x), "d_rotation": z4, "d_scaling": z3,
+                "local_rotation": z4.clone(), "hidden": None, "d_opacity": None, "d_color": None}
+
+
+@pytest.mark.parametrize("name", ["cnodes_edit_res_m96", "cnodes_edit_abs_m64"])
+def test_node_trans_bias_editing_path_matches_reference_golden(name):
+    """ControlNodeWarp.forward(node_trans_bias=...) — the GUI's drag-to-edit path (utils/time_utils.py:1165-1213: Kabsch rotations
+    of the dragged nodes from their trajectory neighbours, graph-distance weights, the Gaussians re-posed rigidly around their
+    nodes) — against outputs of the reference module itself (generated by tests/golden/make_golden.py)."""
+    from riggs_amd.control_nodes import ControlNodeWarp
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    cu = lambda a: torch.from_numpy(np.asarray(a)).cuda()  # noqa: E731
+    cn = ControlNodeWarp(node_num=z["nodes"].shape[0], K=3, with_node_weight=True, local_frame=False, d_rot_as_res=bool(z["d_rot_as_res"]),
+                         hyper_dim=2, network=_WavingNodes()).cuda()
+    with torch.no_grad():
+        cn.nodes.copy_(cu(z["nodes"])); cn._node_radius.copy_(cu(z["_node_radius"])); cn._node_weight.copy_(cu(z["_node_weight"]))
+    with torch.no_grad():
+        out = cn(cu(z["x"]), torch.tensor(float(z["t"]), device="cuda"), cu(z["feature"]), cu(z["motion_mask"]),
+                 node_trans_bias=cu(z["node_trans_bias"]))
+    keys = ["d_xyz", "d_rotation", "d_scaling"] + (["d_rotation_bias"] if "out_d_rotation_bias" in z.files else [])
+    for k in keys:
+        ref = z["out_" + k]
+        err = np.abs(out[k].cpu().numpy() - ref).max()
+        assert err <= 2e-4 * max(1.0, np.abs(ref).max()), (k, err)
+    # the drag moved something (a zero drag is NOT the plain blend in the reference either: the re-posing uses other weights)
+    with torch.no_grad():
+        plain = cn(cu(z["x"]), torch.tensor(float(z["t"]), device="cuda"), cu(z["feature"]), cu(z["motion_mask"]))
+    assert float((out["d_xyz"] - plain["d_xyz"]).abs().max()) > 1e-2
