@@ -195,14 +195,7 @@ __device__ __forceinline__ void pm_store_granule(unsigned long long* g, uint32_t
 
 // one wave re-reads its <= 4 granules per lane until every tag matches (wave-uniform exit).  A granule
 // load is a round trip to the memory side (~1-2 us: the producers' write-through stores drop the line
-// from L2), so PMF_INFLIGHT sweeps are kept in flight and checked oldest first: the hand-off is seen one
-// load latency after it lands instead of up to two.
-#ifndef PMF_INFLIGHT
-#define PMF_INFLIGHT 4
-#endif
-#ifndef PMF_SLEEP
-#define PMF_SLEEP 2
-#endif
+// from L2), so several sweeps are kept in flight and checked oldest first (pm_sweep_n).
 __device__ __forceinline__ void pm_sweep_issue(pm_gu64* g, int n, int lane, unsigned long long (&x)[4]) {
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -220,28 +213,37 @@ __device__ __forceinline__ bool pm_sweep_check(const unsigned long long (&x)[4],
   }
   return __all(ok);
 }
-__device__ __forceinline__ bool pm_sweep(const unsigned long long* gran, int n, uint32_t tag, float (&v)[4],
-                                         uint32_t* err, uint32_t* sticky, int lane) {
+// NQ sweeps in flight: 4 when the granules come from the memory side (a load is 1-2 us: the hand-off is seen one load latency
+// after it lands instead of up to two), 2 when the chain shares an L2 (pm_chain_is_local: the loads are 0.3 us, and what a
+// hand-off then waits for is the queue of 32 pollers x 16 lines at that L2 — forward 15.8 -> 13.2 us, backward 19.0 -> 14.2 us
+// on workgroup 0's stage stamps, tools/pose_mlp_trace.py)
+template <int NQ>
+__device__ __forceinline__ bool pm_sweep_n(const unsigned long long* gran, int n, uint32_t tag, float (&v)[4],
+                                           uint32_t* err, uint32_t* sticky, int lane) {
   pm_gu64* g = (pm_gu64*)gran;
-  unsigned long long x[PMF_INFLIGHT][4];
+  unsigned long long x[NQ][4];
 #pragma unroll
-  for (int q = 0; q < PMF_INFLIGHT; q++) {
+  for (int q = 0; q < NQ; q++) {
     pm_sweep_issue(g, n, lane, x[q]);
-    __builtin_amdgcn_s_sleep(PMF_SLEEP);
+    __builtin_amdgcn_s_sleep(2);
   }
   for (uint32_t spins = 0;; spins++) {
 #pragma unroll
-    for (int q = 0; q < PMF_INFLIGHT; q++) {
+    for (int q = 0; q < NQ; q++) {
       if (pm_sweep_check(x[q], n, lane, tag, v)) return true;
       pm_sweep_issue(g, n, lane, x[q]);
     }
-    if (spins > PMF_SPIN_MAX / PMF_INFLIGHT) {
+    if (spins > PMF_SPIN_MAX / NQ) {
       // per-call word (poisons this launch's outputs) and, when the caller keeps a persistent sync_state, its
       // STICKY status word: never cleared by a kernel, read by the host (riggs_pose_mlp_status_word)
       if (lane == 0) { atomicOr(err, 1u); if (sticky) atomicOr(sticky, 1u); }
       return false;
     }
   }
+}
+__device__ __forceinline__ bool pm_sweep(const unsigned long long* gran, int n, uint32_t tag, float (&v)[4],
+                                         uint32_t* err, uint32_t* sticky, int lane, bool local = false) {
+  return local ? pm_sweep_n<2>(gran, n, tag, v, err, sticky, lane) : pm_sweep_n<4>(gran, n, tag, v, err, sticky, lane);
 }
 
 // Placement of the chain.  The hardware deals a launch's workgroups round-robin over the eight XCDs (workgroup b -> XCD b % 8),
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_forward_fused_kernel(PoseMl
           // input of layer l = h_{l-1} (behind the embedding when layer l-1 was the skip layer)
           float v[4];
           bool ok = (s_failed == 0);
-          if (ok) ok = pm_sweep(gran + (size_t)(l - 1) * d.width, d.width, tag0 + (uint32_t)l, v, err, sticky, lane);
+          if (ok) ok = pm_sweep(gran + (size_t)(l - 1) * d.width, d.width, tag0 + (uint32_t)l, v, err, sticky, lane, local);
           if (!ok && lane == 0) s_failed = 1;
           const int off = (l - 1 == d.skip) ? emb : 0;
           if (off > 0 && lane < emb) s_in[lane] = embv;
@@ -552,7 +554,7 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_backward_fused_kernel(PoseM
           }
           float v[4];
           bool ok = (s_failed == 0);
-          if (ok) ok = pm_sweep(gran + (size_t)l * d.width, d.width, tag0 + (uint32_t)(l + 1), v, err, sticky, lane);
+          if (ok) ok = pm_sweep(gran + (size_t)l * d.width, d.width, tag0 + (uint32_t)(l + 1), v, err, sticky, lane, local);
           if (!ok && lane == 0) s_failed = 1;
 #pragma unroll
           for (int k = 0; k < 4; k++) {
