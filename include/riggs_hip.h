@@ -271,6 +271,7 @@ int riggs_pose_mlp_backward_fk(int32_t depth, int32_t width, int32_t multires, i
                                const float* const* weights, const float* const* biases, const float* W_rot,
                                const float* b_rot, const float* W_tr, const float* b_tr, float* acts, int32_t num_joints,
                                const float* local_rot, const float* joints, const int32_t* parents,
+                               const float* transforms /* (J,12) as the forward wrote them, or NULL: the chain is re-run */,
                                const float* dL_dtransforms, const float* dL_dd_nodes, const float* g_rotation,
                                const float* g_translation, float* dL_dlocal_rot, float* dL_dglobal_trans, float* workspace,
                                float* flat_grads, void* sync_state, riggs_stream stream);

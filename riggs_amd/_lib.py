@@ -60,7 +60,7 @@ _SIGS = {
     "riggs_pose_mlp_sync_bytes": (C.c_size_t, [C.c_int32] * 2),
     "riggs_pose_mlp_set_trace": (C.c_int, [_P]),
     "riggs_pose_mlp_backward": (C.c_int, [C.c_int32] * 5 + [_P] * 13),
-    "riggs_pose_mlp_backward_fk": (C.c_int, [C.c_int32] * 5 + [_P] * 7 + [C.c_int32] + [_P] * 13),
+    "riggs_pose_mlp_backward_fk": (C.c_int, [C.c_int32] * 5 + [_P] * 7 + [C.c_int32] + [_P] * 14),
     "riggs_pose_mlp_status_word": (C.c_size_t, [C.c_int32] * 2),
     "riggs_grad_rows_row_floats": (C.c_int32, [C.c_int32, _P]),
     "riggs_grad_rows_segment_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),

@@ -59,11 +59,12 @@ struct FkIn {
   float x[3];      // the joint's own rest position
   float dG[12];    // (backward) dL/dtransforms of the joint
   float gn[3];     // (backward) dL/dd_nodes of the joint, or zeros
+  float G[12];     // (backward, optional) the joint's global transform as the forward left it: the chain is then not re-run
   int par;
 };
 __device__ __forceinline__ void fk_load(int J, const float* __restrict__ local_rot, const float* __restrict__ joints,
                                         const int32_t* __restrict__ parents, const float* __restrict__ dL_dG_in,
-                                        const float* __restrict__ dL_dnodes, FkIn& in) {
+                                        const float* __restrict__ dL_dnodes, FkIn& in, const float* __restrict__ transforms = nullptr) {
   const int j = threadIdx.x & 63;
   in.par = 0;
 #pragma unroll
@@ -71,8 +72,12 @@ __device__ __forceinline__ void fk_load(int J, const float* __restrict__ local_r
 #pragma unroll
   for (int e = 0; e < 3; e++) { in.c[e] = 0.f; in.x[e] = 0.f; in.gn[e] = 0.f; }
 #pragma unroll
-  for (int e = 0; e < 12; e++) in.dG[e] = 0.f;
+  for (int e = 0; e < 12; e++) { in.dG[e] = 0.f; in.G[e] = 0.f; }
   if (j < J) {
+    if (transforms) {
+#pragma unroll
+      for (int e = 0; e < 12; e++) in.G[e] = transforms[12 * j + e];
+    }
     const int vp = (j == 0) ? 0 : parents[j];  // skeleton_warp.py:246-247
     in.par = vp;
 #pragma unroll
@@ -90,7 +95,7 @@ __device__ __forceinline__ void fk_load(int J, const float* __restrict__ local_r
   }
 }
 
-__device__ __forceinline__ void fk_wave_forward(int J, const FkIn& in, FkLane& f) {
+__device__ __forceinline__ void fk_wave_forward(int J, const FkIn& in, FkLane& f, bool have_G = false) {
   const int j = threadIdx.x & 63;
   const bool on = j < J;
   f.par = 0;
@@ -126,10 +131,10 @@ __device__ __forceinline__ void fk_wave_forward(int J, const FkIn& in, FkLane& f
     const unsigned long long c = __builtin_amdgcn_ballot_w64(on && j >= 1 && f.par == p);
     if (j == p) f.kids = c;
   }
-  // G_i = G_parent(i) * T_i: after step k the joints of depth <= k are final
+  // G_i = G_parent(i) * T_i: after step k the joints of depth <= k are final (have_G: the forward's result is given)
 #pragma unroll
-  for (int e = 0; e < 12; e++) f.G[e] = f.T[e];
-  for (int l = 1; l <= f.maxlev; l++) {
+  for (int e = 0; e < 12; e++) f.G[e] = have_G ? in.G[e] : f.T[e];
+  for (int l = 1; !have_G && l <= f.maxlev; l++) {
     float Gp[12];
 #pragma unroll
     for (int e = 0; e < 12; e++) Gp[e] = fk_lane_get(f.G[e], f.par);

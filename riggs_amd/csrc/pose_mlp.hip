@@ -448,6 +448,7 @@ struct PmFkArgs {
   const float *local_rot, *joints;
   const int32_t* parents;
   const float *dG, *g_nodes;
+  const float* transforms;  // optional: the chain's forward result (riggs_lbs_forward_fk / riggs_fk_forward), so that only the reverse sweep runs
   float *dq_out, *dgt_out;  // optional: workgroup 0 leaves the two gradients here (NULL: not wanted)
 };
 #undef PM_FAULT_BIT
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_backward_fused_kernel(PoseM
   // ---- (with the kinematic chain in front) the first wave's loads for the reverse sweep go out ahead of its weights'
   __shared__ float s_gq[4 * MAX_J + 4];  // the heads' gradients: dL/dlocal_rot, then dL/dglobal_trans
   FkIn fin;
-  if (fk.J > 0 && wave == 0) fk_load(fk.J, fk.local_rot, fk.joints, fk.parents, fk.dG, fk.g_nodes, fin);
+  if (fk.J > 0 && wave == 0) fk_load(fk.J, fk.local_rot, fk.joints, fk.parents, fk.dG, fk.g_nodes, fin, fk.transforms);
   // ---- this wave's column of every consumer matrix, from the transposed copy the forward launch left in
   // `wt` (one coalesced 1 KB row per matrix), and the forward activations (8 KB) into LDS: no global load
   // is left on the chain or in the weight-gradient rows
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_backward_fused_kernel(PoseM
   // the check's barrier publishes both results
   if (fk.J > 0 && wave == 0) {
     FkLane f;
-    fk_wave_forward(fk.J, fin, f);
+    fk_wave_forward(fk.J, fin, f, fk.transforms != nullptr);
     float dq[4];
     fk_wave_backward(fk.J, fin, f, dq);
     if (lane < fk.J) {
@@ -816,7 +817,7 @@ int riggs_pose_mlp_backward(int32_t depth, int32_t width, int32_t multires, int3
 int riggs_pose_mlp_backward_fk(int32_t depth, int32_t width, int32_t multires, int32_t skip, int32_t n_rot,
                                const float* const* weights, const float* const* biases, const float* W_rot,
                                const float* b_rot, const float* W_tr, const float* b_tr, float* acts, int32_t num_joints,
-                               const float* local_rot, const float* joints, const int32_t* parents,
+                               const float* local_rot, const float* joints, const int32_t* parents, const float* transforms,
                                const float* dL_dtransforms, const float* dL_dd_nodes, const float* g_rotation,
                                const float* g_translation, float* dL_dlocal_rot, float* dL_dglobal_trans, float* workspace,
                                float* flat_grads, void* sync_state, riggs_stream stream) {
@@ -824,7 +825,7 @@ int riggs_pose_mlp_backward_fk(int32_t depth, int32_t width, int32_t multires, i
   RIGGS_REQUIRE(local_rot && joints && parents && dL_dtransforms, "riggs_pose_mlp_backward_fk: missing chain input");
   PmFkArgs fk;
   fk.J = num_joints; fk.local_rot = local_rot; fk.joints = joints; fk.parents = parents; fk.dG = dL_dtransforms;
-  fk.g_nodes = dL_dd_nodes; fk.dq_out = dL_dlocal_rot; fk.dgt_out = dL_dglobal_trans;
+  fk.g_nodes = dL_dd_nodes; fk.dq_out = dL_dlocal_rot; fk.dgt_out = dL_dglobal_trans; fk.transforms = transforms;
   return pm_backward_impl(depth, width, multires, skip, n_rot, weights, biases, W_rot, b_rot, W_tr, b_tr, acts, g_rotation,
                           g_translation, workspace, flat_grads, sync_state, stream, fk);
 }

@@ -391,7 +391,7 @@ class _PoseDeform(torch.autograd.Function):
         h = params[2 * depth:]
         L.check(lib.riggs_pose_mlp_backward_fk(depth, width, multires, skip, n_rot, Wp, bp, h[0].data_ptr(), h[1].data_ptr(),
                                                h[2].data_ptr(), h[3].data_ptr(), acts.data_ptr(), J, local_rot.data_ptr(),
-                                               joints.data_ptr(), parents_i32.data_ptr(), dG.data_ptr(), L.ptr(gn), L.ptr(gq),
+                                               joints.data_ptr(), parents_i32.data_ptr(), transforms.data_ptr(), dG.data_ptr(), L.ptr(gn), L.ptr(gq),
                                                dgt.data_ptr(), dq.data_ptr(), dgt_total.data_ptr(), dzs.data_ptr(),
                                                flat.data_ptr(), L.ptr(ctx.sync), st), "riggs_pose_mlp_backward_fk")
         grads, o = [], 0
