@@ -245,6 +245,13 @@ size_t riggs_pose_mlp_sync_bytes(int32_t depth, int32_t width);
  * The word behind it is a TEST HOOK: bit 0 / bit 1 make one workgroup of the forward / backward launch keep a layer's
  * hand-off to itself, so that the time-out path can be exercised on an idle GPU (tests/test_gpu_deform.py); leave it 0. */
 size_t riggs_pose_mlp_status_word(int32_t depth, int32_t width);
+/* Placement of the one-launch kernels' chain (process-wide; default 1): 1 = its workgroups are every eighth workgroup of the
+ * launch, i.e. on ONE XCD when the dispatcher deals round-robin, and hand their layers over through that XCD's L2 (verified
+ * inside every launch; falls back by itself when one XCD cannot hold the chain) — 5-7 us faster per launch on an idle device;
+ * 0 = the launch's first workgroups, on all XCDs: choose it when another stream keeps compute units busy for long (RCCL
+ * collectives overlapped with the deformation backward: the chain needs EVERY compute unit of its XCD to hold one of its
+ * workgroups, and waits for the collective's kernel where it cannot).  riggs_amd.dist selects 0 for world sizes > 1. */
+int riggs_pose_mlp_set_placement(int32_t one_xcd);
 /* debugging aid: 128 device u64 that workgroup 0 of the one-launch kernels stamps with the 100 MHz wall clock
  * per stage (forward [0,64), backward [64,128)); NULL (the default) disables it. */
 int riggs_pose_mlp_set_trace(void* dev_u64x128);

@@ -58,6 +58,7 @@ _SIGS = {
     "riggs_pose_mlp_backward_workspace_floats": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "riggs_pose_mlp_forward": (C.c_int, [C.c_int32] * 5 + [_P] * 13),
     "riggs_pose_mlp_sync_bytes": (C.c_size_t, [C.c_int32] * 2),
+    "riggs_pose_mlp_set_placement": (C.c_int, [C.c_int32]),
     "riggs_pose_mlp_set_trace": (C.c_int, [_P]),
     "riggs_pose_mlp_backward": (C.c_int, [C.c_int32] * 5 + [_P] * 13),
     "riggs_pose_mlp_backward_fk": (C.c_int, [C.c_int32] * 5 + [_P] * 7 + [C.c_int32] + [_P] * 14),

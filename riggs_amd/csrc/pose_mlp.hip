@@ -648,6 +648,7 @@ static int pm_fill(PoseMlpDesc& d, int32_t depth, int32_t width, int32_t multire
 }
 
 // 8 when an eighth of the device (one XCD) holds `n_chain` workgroups of `kernel` at once, else 1
+static int g_pm_one_xcd = 1;  // riggs_pose_mlp_set_placement
 static int pm_chain_stride(const void* kernel, int n_chain) {
   int per_cu = 0, dev = 0, cus = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, PMF_WAVES * 64, 0) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
@@ -657,6 +658,8 @@ static int pm_chain_stride(const void* kernel, int n_chain) {
   }
   return (per_cu * (cus / PM_CHAIN_STRIDE) >= n_chain) ? PM_CHAIN_STRIDE : 1;
 }
+
+int riggs_pose_mlp_set_placement(int32_t one_xcd) { g_pm_one_xcd = one_xcd ? 1 : 0; return 0; }
 
 static unsigned long long* g_pm_trace = nullptr;  // 128 u64: forward stamps [0,64), backward stamps [64,128)
 int riggs_pose_mlp_set_trace(void* dev_u64x128) { g_pm_trace = (unsigned long long*)dev_u64x128; return 0; }
@@ -709,7 +712,7 @@ int riggs_pose_mlp_forward(int32_t depth, int32_t width, int32_t multires, int32
     const int n_chain = ((width > n_rot + 3 ? width : n_rot + 3) + PMF_WAVES - 1) / PMF_WAVES;
     static int stride_f[PM_MAX_CHAIN + 1];
     if (stride_f[n_chain] == 0) stride_f[n_chain] = pm_chain_stride(reinterpret_cast<const void*>(pm_forward_fused_kernel), n_chain);
-    const int stride = stride_f[n_chain];
+    const int stride = g_pm_one_xcd ? stride_f[n_chain] : 1;
     hipLaunchKernelGGL(pm_forward_fused_kernel, dim3(stride > 1 ? n_chain * stride : n_chain + 64), dim3(PMF_WAVES * 64), 0, s, d, t, rot_bias4, acts,
                        (unsigned long long*)fs, (uint32_t*)(fs + 2 * (size_t)depth * width),
                        sync_state ? (uint32_t*)(fs + 2 * (size_t)depth * width) + 1 : nullptr, (uint32_t*)(own + sf), (int)sf,
@@ -771,7 +774,7 @@ static int pm_backward_impl(int32_t depth, int32_t width, int32_t multires, int3
     const int n_chain = (nr + PMF_WAVES - 1) / PMF_WAVES;
     static int stride_b[PM_MAX_CHAIN + 1];
     if (stride_b[n_chain] == 0) stride_b[n_chain] = pm_chain_stride(reinterpret_cast<const void*>(pm_backward_fused_kernel), n_chain);
-    const int stride = stride_b[n_chain];
+    const int stride = g_pm_one_xcd ? stride_b[n_chain] : 1;
     hipLaunchKernelGGL(pm_backward_fused_kernel, dim3(n_chain * stride), dim3(PMF_WAVES * 64), 0, s, d, g, fk,
                        acts, g_rotation, g_translation, (unsigned long long*)(tail + 4), (uint32_t*)tail,
                        sync_state ? (uint32_t*)sync_state + 2 * (size_t)depth * width + 1 : nullptr,

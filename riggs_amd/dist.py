@@ -81,6 +81,14 @@ def grad_out_flat(params) -> torch.Tensor:
     return torch.empty(total, dtype=torch.float32, device=params[0].device)
 
 
+def _spread_pose_mlp_chain(on_gpu: bool):
+    """Exchanges overlap RCCL kernels with the deformation backward: the one-launch PoseMLP kernels then must not need every
+    compute unit of one XCD (include/riggs_hip.h: riggs_pose_mlp_set_placement)."""
+    if on_gpu and dist.is_initialized() and dist.get_world_size() > 1:
+        from . import _lib as L
+        L.lib().riggs_pose_mlp_set_placement(0)
+
+
 class FlatGradAllReduce:
     """ONE flat fp32 buffer holding ``dL/dp`` of every parameter, all-reduced (averaged) in place once per step.
 
@@ -190,6 +198,7 @@ class OverlappedExchange:
         self.bucket, self.split = bucket, int(split)
         self.chunk = int(chunk_bytes) // 4
         self.cuda = bucket.flat.is_cuda
+        _spread_pose_mlp_chain(self.cuda)
         self.comm = torch.cuda.Stream(device=bucket.flat.device) if self.cuda else None
         self.pending = []
 
@@ -466,8 +475,13 @@ class SparseRowExchange:
     the replicas may already have stepped on un-averaged gradients — ``resync()`` them; then build a larger exchange
     (``resize()``, before any capture).  The reference has no distributed path."""
 
+    @staticmethod
+    def rows_on_gpu(rows):
+        return len(rows) > 0 and rows[0].is_cuda
+
     def __init__(self, rows, rest=None, capacity=None, average=True, pack=None, unpack=None, world=None):
         self.world = int(world) if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        _spread_pose_mlp_chain(self.rows_on_gpu(rows))
         self.rows = [g for g in rows]
         self.N = int(self.rows[0].shape[0])
         if any(g.shape[0] != self.N or not g.is_contiguous() or g.dtype != torch.float32 for g in self.rows):

@@ -379,3 +379,32 @@ def test_forward_as_one_node_matches_pose_net_plus_deform_by_pose(J, K, heads):
     assert set(g0) == set(g1) and len(g0) >= 20
     for n in g0:
         assert float((g1[n] - g0[n]).abs().max()) <= 2e-5 * max(1e-9, float(g0[n].abs().max())), n
+
+
+@pytest.mark.gpu
+def test_pose_mlp_chain_placement_does_not_change_results():
+    """riggs_pose_mlp_set_placement: the chain's workgroups on one XCD (plain-store hand-offs through its L2, after the in-kernel
+    placement check) or spread over the device (write-through granules; what riggs_amd.dist selects for world sizes > 1) — the
+    same arithmetic, bit for bit, forward and backward."""
+    from riggs_amd import _lib as L
+    from riggs_amd.skeleton import PoseMLP
+    torch.manual_seed(5)
+    net = PoseMLP(1, 24 * 4).cuda()
+    bias = torch.tensor([1.0, 0, 0, 0], device="cuda")
+    t = torch.tensor([0.63], device="cuda")
+    res = []
+    try:
+        for one_xcd in (1, 0, 1):
+            L.lib().riggs_pose_mlp_set_placement(one_xcd)
+            for p in net.parameters():
+                p.grad = None
+            m = net(t, rot_bias=bias)
+            ((m["rotation"] ** 2).sum() + m["translation"].sum()).backward()
+            net.check_status()
+            res.append([m["rotation"].detach().clone(), m["translation"].detach().clone()] + [p.grad.clone() for p in net.parameters()])
+    finally:
+        L.lib().riggs_pose_mlp_set_placement(1)
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    for a, b in zip(res[0], res[2]):
+        assert torch.equal(a, b)
