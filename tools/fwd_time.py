@@ -1,5 +1,5 @@
 """Event-timed duration of the compositing kernels (forward, backward) on the bench workload and on the dense-gradient scene,
-eagerly issued: the quick A/B number for kernel experiments (tools/variants.sh).   usage: python tools/fwd_time.py [label]"""
+eagerly issued: the quick A/B number for kernel experiments.   usage: python tools/fwd_time.py [label]"""
 import ctypes as C
 import os
 import sys
