@@ -210,7 +210,7 @@ def dense_scene_timing(dev, steps=50):
 def cycling_cameras_timing(dev, steps=64, n_cams=8):
     """Secondary number (NOT the metric): the headline workload replayed the way a trainer uses it — a different camera every
     iteration (train_rig.py:389 draws a random one): ``n_cams`` cameras on a circle around the subject, rotated through the
-    captured frame's static inputs (GraphedFrame.set_inputs: four small device-to-device copies per replay).  The headline
+    captured frame's static inputs (GraphedFrame.set_inputs: one multi-tensor copy launch per replay).  The headline
     replays ONE camera, the best case of the sparse gradient rows (previous | current rows = current rows); here the union
     is real.  Reports ms per step, the share of the Gaussians with a gradient in a frame, the share of rows rewritten
     (previous | current), and how many of the frames overflowed the instance arena (sized from the warm-up frame x 1.5)."""

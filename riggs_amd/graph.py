@@ -94,10 +94,13 @@ class GraphedFrame:
             if (cam.image_height, cam.image_width, cam.FoVx, cam.FoVy) != (
                     self.cam.image_height, self.cam.image_width, self.cam.FoVx, self.cam.FoVy):
                 raise ValueError("image size / field of view are baked into the captured graph: capture a new one")
-            self.cam.world_view_transform.copy_(cam.world_view_transform, non_blocking=True)
-            self.cam.full_proj_transform.copy_(cam.full_proj_transform, non_blocking=True)
-            self.cam.camera_center.copy_(cam.camera_center, non_blocking=True)
-            self.cam.fid.copy_(cam.fid, non_blocking=True)
+            dst = [self.cam.world_view_transform, self.cam.full_proj_transform, self.cam.camera_center, self.cam.fid]
+            src = [cam.world_view_transform, cam.full_proj_transform, cam.camera_center, cam.fid]
+            if all(t.is_cuda and t.dtype == d.dtype and t.shape == d.shape for t, d in zip(src, dst)):
+                torch._foreach_copy_(dst, src)  # ONE launch for the four small tensors (four are ~20 us of every replay)
+            else:
+                for d, t in zip(dst, src):
+                    d.copy_(t, non_blocking=True)
         if gimg is not None:
             self.gimg.copy_(gimg, non_blocking=True)
 
