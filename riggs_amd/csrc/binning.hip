@@ -324,10 +324,41 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(int N, int T, int gri
     if (s0 + 64 < end) load_batch(s0 + 64, nx_g, nx_n, nx_rc);  // (the next batch's loads fly during this one's walk)
     const uint64_t live = __builtin_amdgcn_ballot_w64(cur_n != 0u);
     const uint64_t large = __builtin_amdgcn_ballot_w64(cur_n > 16u);
+    const uint64_t huge = __builtin_amdgcn_ballot_w64(cur_n > 32u);
     const int pk_xy = (int)cur_rc.x | ((int)cur_rc.y << 16), pk_zw = (int)cur_rc.z | ((int)cur_rc.w << 16);
 #pragma unroll
     for (int q = 0; q < 16; q++) {
       if (((live >> (4 * q)) & 0xFull) == 0ull) continue;
+      if (((large >> (4 * q)) & 0xFull) != 0ull && ((huge >> (4 * q)) & 0xFull) == 0ull) {
+        // rectangles of 17 .. 32 tiles (the usual size at 1080p with millions of Gaussians): TWO Gaussians per step, lanes =
+        // (slot, tile) with 32 tiles per slot, the same rank-by-earlier-slot rule
+        const int slot2 = lane >> 5, l32 = lane & 31;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int sa = 4 * q + 2 * h, sb = sa + 1;
+          const int a0 = __builtin_amdgcn_readlane(pk_xy, sa), b0 = __builtin_amdgcn_readlane(pk_zw, sa);
+          const int a1 = __builtin_amdgcn_readlane(pk_xy, sb), b1 = __builtin_amdgcn_readlane(pk_zw, sb);
+          const int axy = slot2 ? a1 : a0, bzw = slot2 ? b1 : b0;
+          const uint32_t g = (uint32_t)__shfl((int)cur_g, sa + slot2);
+          const int rx0 = axy & 0xFFFF, ry0 = (int)((uint32_t)axy >> 16), rx1 = bzw & 0xFFFF, ry1 = (int)((uint32_t)bzw >> 16);
+          const int w = rx1 - rx0;
+          const int ry = (int)(((float)l32 + 0.5f) * __builtin_amdgcn_rcpf((float)w));  // (as rect_tile)
+          const int x = rx0 + (l32 - ry * w), y = ry0 + ry;
+          const bool valid = l32 < w * (ry1 - ry0);
+          const bool in0 = x >= (a0 & 0xFFFF) && y >= (int)((uint32_t)a0 >> 16) && x < (b0 & 0xFFFF) && y < (int)((uint32_t)b0 >> 16);
+          const bool in1 = x >= (a1 & 0xFFFF) && y >= (int)((uint32_t)a1 >> 16) && x < (b1 & 0xFFFF) && y < (int)((uint32_t)b1 >> 16);
+          const int before = (slot2 && in0) ? 1 : 0;
+          const bool last = slot2 || !in1;  // no later slot of the step holds this tile
+          if (valid) {
+            const int t = y * grid_x + x;
+            const unsigned short rel = cur[t];
+            if (last) cur[t] = (unsigned short)(rel + before + 1);
+            const int64_t pos = (int64_t)s_base[t] + rel + before;
+            if (pos < cap) { point_list[pos] = g; if (tile_keys) tile_keys[pos] = (uint32_t)t; }
+          }
+        }
+        continue;
+      }
       if (((large >> (4 * q)) & 0xFull) != 0ull) {
         // one Gaussian per step
 #pragma unroll
