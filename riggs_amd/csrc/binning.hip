@@ -427,58 +427,42 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(int N, int T, int gri
 // grids the direct sort cannot.
 // =====================================================================================================
 #define BIN_GROUPED_MIN_T 25600
+#define BIN_GROUPED_AUTO_T 6000
+#define BIN_GROUPED_AUTO_N 1000000
 #define BIN_PART 8192  // instances per workgroup of the second level
+#ifndef GTS_THREADS
+#define GTS_THREADS 512  // threads of gbin_tscatter_kernel
+#define GTS_WAVES 4     // (its waves per SIMD: 128 VGPRs)
+#endif
 
 __device__ __forceinline__ int grp_of(int x, int y, int gxg) { return y * gxg + (x >> 3); }
 
-// (1a) per chunk of depth-ordered Gaussians: instances per group; block 0 also clears the per-tile counts of level 2
-__global__ __launch_bounds__(1024) void gbin_count_kernel(int N, int T, int G, int gxg, int g_per_block,
+// (1a) per chunk of depth-ordered Gaussians: instances per group, counted PER WAVE (wave w of the scatter kernel below walks
+// the chunk's Gaussians [w * g_per_wave, (w + 1) * g_per_wave) — the same split here): the chunk's totals go to the table,
+// the waves' starts inside the chunk's run of every group to wave_start[chunk][wave][group] (u16), so that the scatter kernel
+// does not count again (its own histogram pass cost it 27 - 45 us per workgroup at 2 M Gaussians: LDS atomics on a few hot
+// groups).  Block 0 also clears the per-tile counts of level 2.  LDS: [W][Gpad] u16, packed pairs while counting.
+__global__ __launch_bounds__(1024) void gbin_count_kernel(int N, int T, int G, int gxg, int g_per_block, int g_per_wave,
                                                          const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles,
                                                          const ushort4* __restrict__ rect, uint32_t* __restrict__ table,
-                                                         uint32_t* __restrict__ tile_count) {
-  extern __shared__ uint32_t s_hist[];  // [G]
-  for (int g = threadIdx.x; g < G; g += blockDim.x) s_hist[g] = 0u;
-  if (blockIdx.x == 0) for (int t = threadIdx.x; t <= T; t += blockDim.x) tile_count[t] = 0u;
-  __syncthreads();
-  const int first = blockIdx.x * g_per_block;
-  const int end = min(N, first + g_per_block);
-  for (int s = first + threadIdx.x; s < end; s += blockDim.x) {
-    const uint32_t g = order[s];
-    if (tiles[g] == 0u) continue;
-    const ushort4 rc = rect[g];
-    for (int y = rc.y; y < rc.w; y++)
-      for (int xg = rc.x >> 3; xg <= (rc.z - 1) >> 3; xg++)
-        atomicAdd(&s_hist[y * gxg + xg], (uint32_t)(min((int)rc.z, xg * 8 + 8) - max((int)rc.x, xg * 8)));
-  }
-  __syncthreads();
-  uint32_t* row = table + (size_t)blockIdx.x * G;
-  for (int g = threadIdx.x; g < G; g += blockDim.x) row[g] = s_hist[g];
-}
-
-// (1b) ordered scatter into the groups' segments.  LDS: s_base[G] + per-wave cursors [W][Gpad] (u16, packed pairs while counting)
-__global__ __launch_bounds__(1024) void gbin_scatter_kernel(int N, int G, int gxg, int64_t cap, int g_per_block, int g_per_wave,
-                                                           const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles,
-                                                           const ushort4* __restrict__ rect, const uint32_t* __restrict__ table,
-                                                           const uint32_t* __restrict__ group_count, uint32_t* __restrict__ inter) {
-  extern __shared__ uint32_t s_mem[];
+                                                         uint32_t* __restrict__ wave_start, uint32_t* __restrict__ tile_count) {
+  extern __shared__ uint32_t s_rel32[];
   const int W = blockDim.x >> 6;
-  uint32_t* s_base = s_mem;
   const int Gpad = (G + 1) & ~1;
-  unsigned short* s_rel = reinterpret_cast<unsigned short*>(s_mem + G);
-  uint32_t* s_rel32 = s_mem + G;
+  unsigned short* s_rel = reinterpret_cast<unsigned short*>(s_rel32);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int e = tid; e < W * (Gpad >> 1); e += blockDim.x) s_rel32[e] = 0u;
+  if (blockIdx.x == 0) for (int t = tid; t <= T; t += blockDim.x) tile_count[t] = 0u;
   __syncthreads();
   const int first = blockIdx.x * g_per_block + wave * g_per_wave;
   const int end = min(N, min(first + g_per_wave, (blockIdx.x + 1) * g_per_block));
-  // (i) per-wave group histogram
+  uint32_t* hist = s_rel32 + (size_t)wave * (Gpad >> 1);
   for (int s0 = first; s0 < end; s0 += 64) {
     const int s = s0 + lane;
     if (s < end) {
       const uint32_t g = order[s];
       if (tiles[g]) {
         const ushort4 rc = rect[g];
-        uint32_t* hist = s_rel32 + (size_t)wave * (Gpad >> 1);
         for (int y = rc.y; y < rc.w; y++)
           for (int xg = rc.x >> 3; xg <= (rc.z - 1) >> 3; xg++) {
             const int gi = y * gxg + xg;
@@ -488,6 +472,54 @@ __global__ __launch_bounds__(1024) void gbin_scatter_kernel(int N, int G, int gx
     }
   }
   __syncthreads();
+  uint32_t* row = table + (size_t)blockIdx.x * G;
+  for (int g = tid; g < G; g += blockDim.x) {
+    uint32_t run = 0;
+    for (int w = 0; w < W; w++) {
+      const unsigned short c = s_rel[(size_t)w * Gpad + g];
+      s_rel[(size_t)w * Gpad + g] = (unsigned short)run;
+      run += c;
+    }
+    row[g] = run;
+  }
+  __syncthreads();
+  uint32_t* ws = wave_start + (size_t)blockIdx.x * W * (Gpad >> 1);
+  for (int e = tid; e < W * (Gpad >> 1); e += blockDim.x) ws[e] = s_rel32[e];
+}
+
+__device__ void gbin_parts_body(int G, int64_t cap, uint32_t n_parts, const uint32_t* __restrict__ group_count, uint4* __restrict__ part_tab);
+
+// (1b) ordered scatter into the groups' segments.  LDS: s_base[G] + per-wave cursors [W][Gpad] (u16)
+__global__ __launch_bounds__(1024) void gbin_scatter_kernel(int N, int G, int gxg, int64_t cap, int g_per_block, int g_per_wave,
+                                                           const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles,
+                                                           const ushort4* __restrict__ rect, const uint32_t* __restrict__ table,
+                                                           const uint32_t* __restrict__ wave_start,
+                                                           const uint32_t* __restrict__ group_count, uint32_t* __restrict__ inter,
+                                                           uint4* __restrict__ part_tab, uint32_t n_parts) {
+  if (blockIdx.x == gridDim.x - 1) {  // (the extra workgroup: the second level's parts)
+    gbin_parts_body(G, cap, n_parts, group_count, part_tab);
+    return;
+  }
+  extern __shared__ uint32_t s_mem[];
+  const int W = blockDim.x >> 6;
+  uint32_t* s_base = s_mem;
+  const int Gpad = (G + 1) & ~1;
+  unsigned short* s_rel = reinterpret_cast<unsigned short*>(s_mem + G);
+  uint32_t* s_rel32 = s_mem + G;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef GB_TIME
+  const uint64_t tm0 = wall_clock64();
+#endif
+  // (i) the waves' starts inside the chunk's run of every group (counted by gbin_count_kernel)
+  {
+    const uint32_t* ws = wave_start + (size_t)blockIdx.x * W * (Gpad >> 1);
+    for (int e = tid; e < W * (Gpad >> 1); e += blockDim.x) s_rel32[e] = ws[e];
+  }
+  const int first = blockIdx.x * g_per_block + wave * g_per_wave;
+  const int end = min(N, min(first + g_per_wave, (blockIdx.x + 1) * g_per_block));
+#ifdef GB_TIME
+  const uint64_t tm1 = wall_clock64();
+#endif
   // (ii) start of this chunk's run in every group's segment: exclusive scan of the group counts + the earlier chunks
   const uint32_t* row = table + (size_t)blockIdx.x * G;
   {
@@ -513,17 +545,18 @@ __global__ __launch_bounds__(1024) void gbin_scatter_kernel(int N, int G, int gx
       __syncthreads();
     }
   }
-  for (int g = tid; g < G; g += blockDim.x) {
-    uint32_t run = 0;
-    for (int w = 0; w < W; w++) {
-      const unsigned short c = s_rel[(size_t)w * Gpad + g];
-      s_rel[(size_t)w * Gpad + g] = (unsigned short)run;
-      run += c;
-    }
-  }
+#ifdef GB_TIME
+  const uint64_t tm2 = wall_clock64();
+#endif
   __syncthreads();
-  // (iii) ordered walk: one Gaussian per step, lanes = the tiles of its rectangle (row-major).  A tile's place = the group's
-  // cursor + its rank inside the Gaussian's span of that group in that tile row; the span's last tile advances the cursor.
+  // (iii) ordered walk.  A tile's place = the group's cursor + its rank inside the Gaussian's span of that group (the
+  // rectangle's columns that fall into the group's eight, in that tile row); the span's last tile advances the cursor.  As
+  // in the direct sort, four Gaussians share a step when their rectangles have at most 16 tiles (two with at most 32):
+  // lane = (slot, tile); a lane's place then also counts the spans of the step's EARLIER slots in its group, and only the
+  // last slot with a span there advances the cursor.
+#ifdef GB_TIME
+  const uint64_t tm3 = wall_clock64();
+#endif
   unsigned short* cur = s_rel + (size_t)wave * Gpad;
   for (int s0 = first; s0 < end; s0 += 64) {
     const int s = s0 + lane;
@@ -534,37 +567,95 @@ __global__ __launch_bounds__(1024) void gbin_scatter_kernel(int N, int G, int gx
       my_n = tiles[my_g];
       if (my_n) { const ushort4 rc = rect[my_g]; pk_xy = (int)rc.x | ((int)rc.y << 16); pk_zw = (int)rc.z | ((int)rc.w << 16); }
     }
-    uint64_t live = __builtin_amdgcn_ballot_w64(my_n != 0u);
-    while (live) {
-      const int src = __builtin_ctzll(live);
-      live &= live - 1ull;
-      const int n = __builtin_amdgcn_readlane((int)my_n, src);
-      const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)my_g, src);
-      const int r0 = __builtin_amdgcn_readlane(pk_xy, src), r1 = __builtin_amdgcn_readlane(pk_zw, src);
-      const int rx0 = r0 & 0xFFFF, ry0 = (int)((uint32_t)r0 >> 16), rx1 = r1 & 0xFFFF;
-      const int w = rx1 - rx0;
-      const float rw = __builtin_amdgcn_rcpf((float)w);
-      for (int l = lane; l < n; l += 64) {
-        const int ry = (int)(((float)l + 0.5f) * rw);  // (as rect_tile)
+    const uint64_t live = __builtin_amdgcn_ballot_w64(my_n != 0u);
+    const uint64_t large = __builtin_amdgcn_ballot_w64(my_n > 16u);
+    const uint64_t huge = __builtin_amdgcn_ballot_w64(my_n > 32u);
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      if (((live >> (4 * q)) & 0xFull) == 0ull) continue;
+      if (((huge >> (4 * q)) & 0xFull) != 0ull) {
+        // one Gaussian per step, lanes = the tiles of its rectangle (row-major)
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+          const int src = 4 * q + jj;
+          const int n = __builtin_amdgcn_readlane((int)my_n, src);
+          if (n == 0) continue;
+          const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)my_g, src);
+          const int r0 = __builtin_amdgcn_readlane(pk_xy, src), r1 = __builtin_amdgcn_readlane(pk_zw, src);
+          const int rx0 = r0 & 0xFFFF, ry0 = (int)((uint32_t)r0 >> 16), rx1 = r1 & 0xFFFF;
+          const int w = rx1 - rx0;
+          const float rw = __builtin_amdgcn_rcpf((float)w);
+          for (int l = lane; l < n; l += 64) {
+            const int ry = (int)(((float)l + 0.5f) * rw);  // (as rect_tile)
+            const int x = rx0 + (l - ry * w), y = ry0 + ry;
+            const int gi = grp_of(x, y, gxg);
+            const int span0 = max(rx0, (x >> 3) << 3), span1 = min(rx1, ((x >> 3) << 3) + 8);
+            const unsigned short rel = cur[gi];
+            if (x == span1 - 1) cur[gi] = (unsigned short)(rel + (span1 - span0));
+            const int64_t pos = (int64_t)s_base[gi] + rel + (x - span0);
+            if (pos < cap) inter[pos] = g | ((uint32_t)(x & 7) << 29);
+          }
+        }
+        continue;
+      }
+      // the four rectangles, wave-uniform (an invisible Gaussian has the empty rectangle 0,0,0,0)
+      int ra[4], rb[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++) { ra[jj] = __builtin_amdgcn_readlane(pk_xy, 4 * q + jj); rb[jj] = __builtin_amdgcn_readlane(pk_zw, 4 * q + jj); }
+      auto step = [&](const int slot, const int l, const int nslot, const int sbase) {
+        // lanes (slot, l) over the slots sbase .. sbase + nslot - 1 of the four
+        int axy = ra[sbase], bzw = rb[sbase];
+#pragma unroll
+        for (int jj = 1; jj < 4; jj++) if (jj < nslot && slot == jj) { axy = ra[sbase + jj]; bzw = rb[sbase + jj]; }
+        const uint32_t g = (uint32_t)__shfl((int)my_g, 4 * q + sbase + slot);
+        const int rx0 = axy & 0xFFFF, ry0 = (int)((uint32_t)axy >> 16), rx1 = bzw & 0xFFFF, ry1 = (int)((uint32_t)bzw >> 16);
+        const int w = rx1 - rx0;
+        const int ry = (int)(((float)l + 0.5f) * __builtin_amdgcn_rcpf((float)w));  // (as rect_tile)
         const int x = rx0 + (l - ry * w), y = ry0 + ry;
-        const int gi = grp_of(x, y, gxg);
-        const int span0 = max(rx0, (x >> 3) << 3), span1 = min(rx1, ((x >> 3) << 3) + 8);
-        const unsigned short rel = cur[gi];
-        if (x == span1 - 1) cur[gi] = (unsigned short)(rel + (span1 - span0));
-        const int64_t pos = (int64_t)s_base[gi] + rel + (x - span0);
-        if (pos < cap) inter[pos] = g | ((uint32_t)(x & 7) << 29);
+        const bool valid = l < w * (ry1 - ry0);
+        const int gx8 = (x >> 3) << 3;
+        int before = 0, after = 0;
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+          if (jj >= nslot) continue;
+          const int a = ra[sbase + jj], b = rb[sbase + jj];
+          const bool row_in = y >= (int)((uint32_t)a >> 16) && y < (int)((uint32_t)b >> 16);
+          const int ov = row_in ? max(0, min(b & 0xFFFF, gx8 + 8) - max(a & 0xFFFF, gx8)) : 0;
+          before += (jj < slot) ? ov : 0;
+          after += (jj > slot) ? ov : 0;
+        }
+        if (valid) {
+          const int gi = grp_of(x, y, gxg);
+          const int span0 = max(rx0, gx8), span1 = min(rx1, gx8 + 8);
+          const unsigned short rel = cur[gi];
+          if (x == span1 - 1 && after == 0) cur[gi] = (unsigned short)(rel + before + (span1 - span0));
+          const int64_t pos = (int64_t)s_base[gi] + rel + before + (x - span0);
+          if (pos < cap) inter[pos] = g | ((uint32_t)(x & 7) << 29);
+        }
+      };
+      if (((large >> (4 * q)) & 0xFull) != 0ull) {
+        step(lane >> 5, lane & 31, 2, 0);
+        step(lane >> 5, lane & 31, 2, 2);
+      } else {
+        step(lane >> 4, lane & 15, 4, 0);
       }
     }
   }
+#ifdef GB_TIME
+  __syncthreads();
+  if (tid == 0 && blockIdx.x % 97 == 5) printf("GBS %d hist %d scan %d prefix %d walk %d (x10ns)\n", (int)blockIdx.x, (int)(tm1 - tm0), (int)(tm2 - tm1), (int)(tm3 - tm2), (int)(wall_clock64() - tm3));
+#endif
 }
 
-// which part of which group is workgroup `b` of the second level?  (every workgroup scans the <= 8192 group counts itself)
+// The parts of the second level: workgroup b of its kernels takes part_tab[b] = {group, first part of the group, start in
+// the scratch list, length}; group = 0xFFFFFFFF beyond the last part.  Written by the EXTRA (last) workgroup of
+// gbin_scatter_kernel from the group counts (every workgroup scanning the <= 8192 counts itself cost the second level's
+// kernels 3.5 us each, 5 700 times over).
 struct GPart { int group; uint32_t first_part; uint32_t start; uint32_t len; uint32_t part; };
-__device__ GPart gbin_find_part(int b, int G, int64_t cap, const uint32_t* __restrict__ group_count) {
+__device__ void gbin_parts_body(int G, int64_t cap, uint32_t n_parts, const uint32_t* __restrict__ group_count, uint4* __restrict__ part_tab) {
   __shared__ uint32_t s_wc[16], s_wp[16], s_carry_c, s_carry_p;
-  __shared__ GPart s_out;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
-  if (tid == 0) { s_carry_c = 0u; s_carry_p = 0u; s_out.group = -1; s_out.first_part = 0u; s_out.start = 0u; s_out.len = 0u; s_out.part = 0u; }
+  if (tid == 0) { s_carry_c = 0u; s_carry_p = 0u; }
   __syncthreads();
   for (int base = 0; base < G; base += nthr) {
     const int g = base + tid;
@@ -580,38 +671,43 @@ __device__ GPart gbin_find_part(int b, int G, int64_t cap, const uint32_t* __res
     uint32_t oc = s_carry_c, op = s_carry_p;
     for (int w = 0; w < wave; w++) { oc += s_wc[w]; op += s_wp[w]; }
     const uint32_t cstart = oc + vc - c, pstart = op + vp - np;
-    if (g < G && (uint32_t)b >= pstart && (uint32_t)b < pstart + np) {
-      const uint32_t part = (uint32_t)b - pstart;
+    for (uint32_t part = 0; part < np; part++) {
       const int64_t lo = (int64_t)cstart + (int64_t)part * BIN_PART;
       const int64_t hi = min((int64_t)cstart + min((int64_t)c, (int64_t)(part + 1) * BIN_PART), cap);
-      s_out.group = g; s_out.first_part = pstart; s_out.part = part;
-      s_out.start = (uint32_t)min(lo, cap); s_out.len = hi > lo ? (uint32_t)(hi - lo) : 0u;
+      if (pstart + part < n_parts) part_tab[pstart + part] = make_uint4((uint32_t)g, pstart, (uint32_t)min(lo, cap), hi > lo ? (uint32_t)(hi - lo) : 0u);
     }
     __syncthreads();
     if (tid == nthr - 1) { s_carry_c = oc + vc; s_carry_p = op + vp; }
     __syncthreads();
   }
-  return s_out;
+  for (uint32_t b = s_carry_p + (uint32_t)tid; b < n_parts; b += (uint32_t)nthr) part_tab[b] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+}
+__device__ __forceinline__ GPart gbin_part(int b, const uint4* __restrict__ part_tab) {
+  const uint4 t = part_tab[b];
+  GPart p;
+  p.group = (int)t.x; p.first_part = t.y; p.start = t.z; p.len = t.w; p.part = (uint32_t)b - t.y;
+  return p;
 }
 
 // (2a) per part: instances per tile of the group -> part_hist[part][8]; totals into tile_count
-__global__ __launch_bounds__(512) void gbin_tcount_kernel(int G, int gxg, int grid_x, int64_t cap, const uint32_t* __restrict__ group_count,
+__global__ __launch_bounds__(512) void gbin_tcount_kernel(int gxg, int grid_x, const uint4* __restrict__ part_tab,
                                                          const uint32_t* __restrict__ inter, uint32_t* __restrict__ part_hist,
                                                          uint32_t* __restrict__ tile_count) {
   __shared__ uint32_t s_h[8];
-  const GPart p = gbin_find_part((int)blockIdx.x, G, cap, group_count);
+  const GPart p = gbin_part((int)blockIdx.x, part_tab);
   if (p.group < 0) return;
   if (threadIdx.x < 8) s_h[threadIdx.x] = 0u;
   __syncthreads();
-  uint32_t mine[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-  for (uint32_t k = threadIdx.x; k < p.len; k += 512) {
-    const uint32_t c = inter[p.start + k] >> 29;
+  // eight 8-bit counters in one 64-bit word (a thread sees at most BIN_PART / 512 = 16 instances)
+  uint64_t packed = 0ull;
 #pragma unroll
-    for (int q = 0; q < 8; q++) mine[q] += (c == (uint32_t)q) ? 1u : 0u;
+  for (int it = 0; it < BIN_PART / 512; it++) {
+    const uint32_t k = (uint32_t)it * 512u + threadIdx.x;
+    if (k < p.len) packed += 1ull << ((inter[p.start + k] >> 29) * 8u);
   }
 #pragma unroll
   for (int q = 0; q < 8; q++) {
-    uint32_t v = mine[q];
+    uint32_t v = (uint32_t)(packed >> (8 * q)) & 0xFFu;
     for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_h[q], v);
   }
@@ -624,62 +720,155 @@ __global__ __launch_bounds__(512) void gbin_tcount_kernel(int G, int gxg, int gr
   }
 }
 
-// (2b) per part: stable partition by tile into the final lists; the extra (last) workgroup writes ranges, counters, work lists
-__global__ __launch_bounds__(512) void gbin_tscatter_kernel(int T, int G, int gxg, int grid_x, int64_t cap,
-                                                           const uint32_t* __restrict__ group_count, const uint32_t* __restrict__ inter,
-                                                           const uint32_t* __restrict__ part_hist, const uint32_t* __restrict__ tile_count,
-                                                           uint32_t* __restrict__ point_list, uint32_t* __restrict__ tile_keys,
-                                                           const BinOut out) {
-  if (blockIdx.x == gridDim.x - 1) {
-    bin_offsets_body(T, cap, tile_count, out, group_count, G);
-    return;
-  }
-  __shared__ uint32_t s_cur[8];
-  __shared__ uint32_t s_wcnt[8][8];  // [wave][tile]
-  const GPart p = gbin_find_part((int)blockIdx.x, G, cap, group_count);
+// (2b) per part: stable partition by tile into the final lists; the extra (last) workgroup writes ranges, counters, work lists.
+// The second level is VALU work, not memory work (38.8 M instances x every instruction spent per instance; the version that
+// ranked 64 instances at a time with ballots took 85 wave instructions per 64: 239 us), so a thread takes SIXTEEN
+// CONSECUTIVE instances: counts them in packed counters, one packed scan over the threads, places them from packed running
+// offsets — and the part goes through LDS twice: in (coalesced loads -> a thread's 16 in a row) and out (final order ->
+// long coalesced runs).
+__global__ __launch_bounds__(1024) void gbin_offsets_kernel(int T, int G, int64_t cap, const uint32_t* __restrict__ group_count,
+                                                           const uint32_t* __restrict__ tile_count, const BinOut out) {
+  bin_offsets_body(T, cap, tile_count, out, group_count, G);
+}
+__global__ __launch_bounds__(GTS_THREADS, GTS_WAVES) void gbin_tscatter_kernel(int gxg, int grid_x, int64_t cap, const uint4* __restrict__ part_tab,
+                                                              const uint32_t* __restrict__ inter,
+                                                              const uint32_t* __restrict__ part_hist, const uint32_t* __restrict__ tile_count,
+                                                              uint32_t* __restrict__ point_list, uint32_t* __restrict__ tile_keys) {
+  constexpr int EPT = BIN_PART / GTS_THREADS, NW = GTS_THREADS / 64;  // instances per thread, waves
+  static_assert(EPT * 64 < 65536 && BIN_PART < 65536, "packed 16-bit counters below");
+  __shared__ uint32_t s_cur[8];            // start of the group's tiles' lists for this part (global)
+  __shared__ uint32_t s_wtot[NW][4];        // [wave] packed pairs of 16-bit counts: tiles (0,1) (2,3) (4,5) (6,7)
+  __shared__ uint32_t s_wbase[NW][4];       // [wave] packed pairs: place (in the part's final order) of the wave's first instance of each tile
+  __shared__ uint32_t s_lstart[9];         // start of each tile in the part's final order
+  __shared__ uint32_t s_stage[BIN_PART + BIN_PART / EPT];
+#ifdef GB_TIME
+  const uint64_t tm0 = wall_clock64();
+#endif
+  const GPart p = gbin_part((int)blockIdx.x, part_tab);
   if (p.group < 0) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gx0 = (p.group % gxg) * 8, gy = p.group / gxg;
-  if (tid < 8) {
-    // start of tile `tid`'s list = start of the group's segment + the group's earlier tiles + this tile's share of the earlier parts
-    uint32_t st = p.start - p.part * BIN_PART;  // (start of the group's segment; the clamp to `cap` only bites on overflow)
-    for (int q = 0; q < tid; q++) { const int x = gx0 + q; if (x < grid_x) st += tile_count[gy * grid_x + x]; }
-    for (uint32_t q = 0; q < p.part; q++) st += part_hist[(size_t)(p.first_part + q) * 8 + tid];
-    s_cur[tid] = st;
+  if (wave == 0) {
+    // start of tile q's list = start of the group's segment + the group's earlier tiles + tile q's share of the earlier parts
+    // (lane = (stride s, tile q): the earlier parts s, s + 8, ... — a dense group has over a hundred parts)
+    const int q = lane & 7, sl = lane >> 3;
+    uint32_t share = 0u;
+    for (uint32_t k = (uint32_t)sl; k < p.part; k += 8u) share += part_hist[(size_t)(p.first_part + k) * 8 + q];
+    share += (uint32_t)__shfl_xor((int)share, 8);
+    share += (uint32_t)__shfl_xor((int)share, 16);
+    share += (uint32_t)__shfl_xor((int)share, 32);
+    const uint32_t tc = (gx0 + q < grid_x) ? tile_count[gy * grid_x + gx0 + q] : 0u;
+    uint32_t v = tc;
+    for (int o = 1; o < 8; o <<= 1) {
+      const uint32_t u = (uint32_t)__shfl_up((int)v, o);
+      if (q >= o) v += u;
+    }
+    if (lane < 8) s_cur[q] = (p.start - p.part * BIN_PART) + (v - tc) + share;  // (p.start - ...: the group's segment; the clamp to `cap` only bites on overflow)
   }
-  if (tid < 64) (&s_wcnt[0][0])[tid] = 0u;
-  __syncthreads();
-  for (uint32_t k0 = 0; k0 < p.len; k0 += 512) {
-    const uint32_t k = k0 + (uint32_t)tid;
-    const bool on = k < p.len;
-    const uint32_t e = on ? inter[p.start + k] : 0u;
-    const int c = (int)(e >> 29);
-    uint64_t same = __builtin_amdgcn_ballot_w64(on);
+#ifdef GB_TIME
+  const uint64_t tm1 = wall_clock64();
+#endif
+  // in: coalesced loads, padded rows of 16 in LDS, a thread's row into registers
 #pragma unroll
-    for (int bit = 0; bit < 3; bit++) {
-      const uint64_t vote = __builtin_amdgcn_ballot_w64(on && ((c >> bit) & 1));
-      same &= ((c >> bit) & 1) ? vote : ~vote;
-    }
-    const uint32_t rank = (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull));
-    if (on && rank == 0u) s_wcnt[wave][c] = (uint32_t)__builtin_popcountll(same);  // (the first lane of every tile present; the others stay 0)
-    __syncthreads();
-    uint32_t wbase = 0u;
-    if (on) {
-      for (int w = 0; w < wave; w++) wbase += s_wcnt[w][c];
-      const int64_t pos = (int64_t)s_cur[c] + wbase + rank;
-      if (pos < cap) {
-        point_list[pos] = e & 0x1FFFFFFFu;
-        if (tile_keys) tile_keys[pos] = (uint32_t)(gy * grid_x + gx0 + c);
-      }
-    }
-    __syncthreads();
-    if (tid < 8) {
-      uint32_t tot = 0u;
-      for (int w = 0; w < 8; w++) { tot += s_wcnt[w][tid]; s_wcnt[w][tid] = 0u; }
-      s_cur[tid] += tot;
-    }
-    __syncthreads();
+  for (int it = 0; it < EPT; it++) {
+    const uint32_t k = (uint32_t)it * GTS_THREADS + (uint32_t)tid;
+    s_stage[k + k / EPT] = (k < p.len) ? inter[p.start + k] : 0u;
   }
+  __syncthreads();
+  uint32_t ev[EPT];
+#pragma unroll
+  for (int i = 0; i < EPT; i++) ev[i] = s_stage[tid * (EPT + 1) + i];
+#ifdef GB_TIME
+  const uint64_t tm2 = wall_clock64();
+#endif
+  const uint32_t k_first = (uint32_t)tid * EPT;
+  // packed counts: word w = tiles (2w, 2w+1) in 16-bit halves
+  uint32_t cnt[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int i = 0; i < EPT; i++) {
+    const uint32_t c = ev[i] >> 29;
+    const uint32_t inc = (k_first + i < p.len) ? (1u << ((c & 1u) * 16u)) : 0u;
+#pragma unroll
+    for (int w = 0; w < 4; w++) cnt[w] += ((c >> 1) == (uint32_t)w) ? inc : 0u;
+  }
+  uint32_t inc_scan[4];
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    uint32_t v = cnt[w];
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t u = (uint32_t)__shfl_up((int)v, o);
+      if (lane >= o) v += u;
+    }
+    inc_scan[w] = v;
+    if (lane == 63) s_wtot[wave][w] = v;
+  }
+  __syncthreads();  // (also: every thread has its row out of s_stage)
+#ifdef GB_TIME
+  const uint64_t tm3 = wall_clock64();
+#endif
+  if (tid < 8) {
+    // tile `tid`: its total, then (after the exchange below) the waves' bases
+    uint32_t tot = 0u;
+    for (int w = 0; w < NW; w++) tot += (s_wtot[w][tid >> 1] >> ((tid & 1) * 16)) & 0xFFFFu;
+    uint32_t v = tot;
+    for (int o = 1; o < 8; o <<= 1) {
+      const uint32_t u = (uint32_t)__shfl_up((int)v, o);
+      if (tid >= o) v += u;
+    }
+    s_lstart[tid + 1] = v;
+    if (tid == 0) s_lstart[0] = 0u;
+    uint32_t run = v - tot;  // (the tile's start in the part's final order: < 8192, and so is every place below: 16 bits hold it)
+    for (int w = 0; w < NW; w++) {
+      const uint32_t c = (s_wtot[w][tid >> 1] >> ((tid & 1) * 16)) & 0xFFFFu;
+      // the two tiles of a word are written by two lanes: 16-bit halves through a short pointer
+      reinterpret_cast<unsigned short*>(&s_wbase[w][0])[tid] = (unsigned short)run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  // running places, packed like the counts: the wave's base + the earlier threads of the wave
+  uint32_t place[4];
+#pragma unroll
+  for (int w = 0; w < 4; w++) place[w] = s_wbase[wave][w] + inc_scan[w] - cnt[w];
+#pragma unroll
+  for (int i = 0; i < EPT; i++) {
+    const uint32_t c = ev[i] >> 29;
+    const uint32_t sh = (c & 1u) * 16u;
+    uint32_t word = place[0];
+#pragma unroll
+    for (int w = 1; w < 4; w++) word = ((c >> 1) == (uint32_t)w) ? place[w] : word;
+    const uint32_t at = (word >> sh) & 0xFFFFu;
+    const bool on = k_first + i < p.len;
+    const uint32_t inc = on ? (1u << sh) : 0u;
+#pragma unroll
+    for (int w = 0; w < 4; w++) place[w] += ((c >> 1) == (uint32_t)w) ? inc : 0u;
+    if (on) s_stage[at] = ev[i];
+  }
+  __syncthreads();
+#ifdef GB_TIME
+  const uint64_t tm4 = wall_clock64();
+#endif
+  // out: the part in its final order, tile after tile: long runs
+  uint32_t lstart[9];
+#pragma unroll
+  for (int q = 0; q < 9; q++) lstart[q] = s_lstart[q];
+  for (uint32_t k = (uint32_t)tid; k < p.len; k += GTS_THREADS) {
+    int c = 0;
+#pragma unroll
+    for (int q = 1; q < 8; q++) c += (k >= lstart[q]) ? 1 : 0;
+    uint32_t ls = 0u;
+#pragma unroll
+    for (int q = 1; q < 8; q++) ls = (c == q) ? lstart[q] : ls;
+    const int64_t pos = (int64_t)s_cur[c] + (k - ls);
+    if (pos < cap) {
+      point_list[pos] = s_stage[k] & 0x1FFFFFFFu;
+      if (tile_keys) tile_keys[pos] = (uint32_t)(gy * grid_x + gx0 + c);
+    }
+  }
+#ifdef GB_TIME
+  __syncthreads();
+  if (tid == 0 && blockIdx.x % 397 == 5) printf("GTS %d/%d len %d part %d cur %d load %d count+scan %d place %d store %d (x10ns) cap %ld\n", (int)blockIdx.x, (int)gridDim.x, (int)p.len, (int)p.part, (int)(tm1 - tm0), (int)(tm2 - tm1), (int)(tm3 - tm2), (int)(tm4 - tm3), (int)(wall_clock64() - tm4), (long)cap);
+#endif
 }
 
 struct BinPlan { int g_per_block, g_per_wave, threads, n_chunks; size_t lds_scatter; };
@@ -706,7 +895,19 @@ static BinPlan bin_plan(int N, int T) {
   return p;
 }
 
-static bool bin_grouped(int T) { return T > BIN_GROUPED_MIN_T; }
+// which sort?  Beyond BIN_GROUPED_MIN_T tiles only the grouped one fits; below, it wins on many Gaussians over many tiles
+// (2 M / 8160 tiles: 0.54 ms against 0.70 ms) and loses on the small scenes (its five launches cost more than they save).
+// RIGGS_BIN_GROUPED=0 / 1 overrides the choice where both fit (measurements).
+static bool bin_grouped(int N, int T) {
+  if (T > BIN_GROUPED_MIN_T) return true;
+  static int forced = -2;
+  if (forced == -2) {
+    const char* e = getenv("RIGGS_BIN_GROUPED");
+    forced = (e && *e) ? atoi(e) : -1;
+  }
+  if (forced >= 0) return forced != 0 && T >= 64;
+  return T >= BIN_GROUPED_AUTO_T && N >= BIN_GROUPED_AUTO_N;
+}
 struct GBinPlan { int G, gxg, g_per_block, g_per_wave, n_chunks; size_t lds; };
 static GBinPlan gbin_plan(int N, int T, int grid_x) {
   GBinPlan p;
@@ -726,18 +927,18 @@ static GBinPlan gbin_plan(int N, int T, int grid_x) {
 }
 
 size_t bin_table_bytes(int N, int T, int grid_x) {
-  if (bin_grouped(T)) {
+  if (bin_grouped(N, T)) {
     GBinPlan p = gbin_plan(N > 0 ? N : 1, T, grid_x);
-    return align_up(((size_t)p.n_chunks + 1) * p.G * 4) + align_up((size_t)(p.G + 1) * 4) + align_up((size_t)(T + 1) * 4);
+    return align_up(((size_t)p.n_chunks + 1) * p.G * 4) + align_up((size_t)(p.G + 1) * 4) + align_up((size_t)(T + 1) * 4) +
+           align_up((size_t)p.n_chunks * 16 * ((p.G + 1) & ~1) * 2);
   }
   BinPlan p = bin_plan(N > 0 ? N : 1, T);
   return align_up(((size_t)p.n_chunks + 1) * T * 4) + align_up((size_t)(T + 1) * 4);
 }
 size_t bin_scratch_bytes(int64_t cap, int T, int grid_x) {  // (grouped binning: lives in the checkpoint area)
-  if (!bin_grouped(T)) return 0;
   GBinPlan p = gbin_plan(1, T, grid_x);
   const size_t c = (size_t)(cap > 0 ? cap : 1);
-  return align_up(c * 4) + align_up((c / BIN_PART + (size_t)p.G + 2) * 8 * 4);
+  return align_up(c * 4) + align_up((c / BIN_PART + (size_t)p.G + 2) * 8 * 4) + align_up((c / BIN_PART + (size_t)p.G + 2) * 16);
 }
 
 int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order, const uint32_t* tiles,
@@ -751,25 +952,30 @@ int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order,
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bin_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bin_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gbin_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gbin_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
     attr_done = true;
   }
-  if (bin_grouped(T)) {
+  if (bin_grouped(N, T)) {
     const GBinPlan p = gbin_plan(N, T, grid_x);
     if (p.lds > 150 * 1024) { set_error("image too large: %d tile groups", p.G); return 2; }
     uint32_t* table = (uint32_t*)mem;
     uint32_t* group_count = (uint32_t*)(mem + align_up(((size_t)p.n_chunks + 1) * p.G * 4));
     uint32_t* tile_count = (uint32_t*)((char*)group_count + align_up((size_t)(p.G + 1) * 4));
+    uint32_t* wave_start = (uint32_t*)((char*)tile_count + align_up((size_t)(T + 1) * 4));
     uint32_t* inter = (uint32_t*)scratch;
     uint32_t* part_hist = (uint32_t*)((char*)scratch + align_up((size_t)(cap > 0 ? cap : 1) * 4));
     const unsigned n_parts = (unsigned)((cap > 0 ? cap : 1) / BIN_PART + p.G + 1);
-    hipLaunchKernelGGL(gbin_count_kernel, dim3(p.n_chunks), dim3(1024), (size_t)p.G * 4, s, N, T, p.G, p.gxg, p.g_per_block, order, tiles,
-                       rect, table, tile_count);
+    uint4* part_tab = (uint4*)((char*)part_hist + align_up(((size_t)(cap > 0 ? cap : 1) / BIN_PART + (size_t)p.G + 2) * 8 * 4));
+    hipLaunchKernelGGL(gbin_count_kernel, dim3(p.n_chunks), dim3(1024), p.lds - (size_t)p.G * 4, s, N, T, p.G, p.gxg, p.g_per_block,
+                       p.g_per_wave, order, tiles, rect, table, wave_start, tile_count);
     hipLaunchKernelGGL(bin_scan_kernel, dim3((p.G + 63) / 64), dim3(1024), 0, s, p.G, p.n_chunks, table, group_count);
-    hipLaunchKernelGGL(gbin_scatter_kernel, dim3(p.n_chunks), dim3(1024), p.lds, s, N, p.G, p.gxg, cap, p.g_per_block, p.g_per_wave,
-                       order, tiles, rect, table, group_count, inter);
-    hipLaunchKernelGGL(gbin_tcount_kernel, dim3(n_parts), dim3(512), 0, s, p.G, p.gxg, grid_x, cap, group_count, inter, part_hist, tile_count);
-    hipLaunchKernelGGL(gbin_tscatter_kernel, dim3(n_parts + 1), dim3(512), 0, s, T, p.G, p.gxg, grid_x, cap,
-                       group_count, inter, part_hist, tile_count, point_list, tile_keys, out);
+    // (+ 1: the extra workgroup that lists the second level's parts)
+    hipLaunchKernelGGL(gbin_scatter_kernel, dim3(p.n_chunks + 1), dim3(1024), p.lds, s, N, p.G, p.gxg, cap, p.g_per_block, p.g_per_wave,
+                       order, tiles, rect, table, wave_start, group_count, inter, part_tab, n_parts);
+    hipLaunchKernelGGL(gbin_tcount_kernel, dim3(n_parts), dim3(512), 0, s, p.gxg, grid_x, part_tab, inter, part_hist, tile_count);
+    hipLaunchKernelGGL(gbin_offsets_kernel, dim3(1), dim3(1024), 0, s, T, p.G, cap, group_count, tile_count, out);
+    hipLaunchKernelGGL(gbin_tscatter_kernel, dim3(n_parts), dim3(GTS_THREADS), 0, s, p.gxg, grid_x, cap, part_tab, inter, part_hist, tile_count,
+                       point_list, tile_keys);
     return 0;
   }
   BinPlan p = bin_plan(N, T);
