@@ -427,8 +427,8 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(int N, int T, int gri
 // grids the direct sort cannot.
 // =====================================================================================================
 #define BIN_GROUPED_MIN_T 25600
-#define BIN_GROUPED_AUTO_T 6000
-#define BIN_GROUPED_AUTO_N 1000000
+#define BIN_GROUPED_AUTO_T 4096
+#define BIN_GROUPED_AUTO_N 500000
 #define BIN_PART 8192  // instances per workgroup of the second level
 #ifndef GTS_THREADS
 #define GTS_THREADS 512  // threads of gbin_tscatter_kernel
@@ -496,10 +496,11 @@ __global__ __launch_bounds__(1024) void gbin_scatter_kernel(int N, int G, int gx
                                                            const uint32_t* __restrict__ wave_start,
                                                            const uint32_t* __restrict__ group_count, uint32_t* __restrict__ inter,
                                                            uint4* __restrict__ part_tab, uint32_t n_parts) {
-  if (blockIdx.x == gridDim.x - 1) {  // (the extra workgroup: the second level's parts)
+  if (blockIdx.x == 0) {  // (the extra workgroup, first in the grid: the second level's parts)
     gbin_parts_body(G, cap, n_parts, group_count, part_tab);
     return;
   }
+  const int chunk = (int)blockIdx.x - 1;
   extern __shared__ uint32_t s_mem[];
   const int W = blockDim.x >> 6;
   uint32_t* s_base = s_mem;
@@ -507,21 +508,15 @@ __global__ __launch_bounds__(1024) void gbin_scatter_kernel(int N, int G, int gx
   unsigned short* s_rel = reinterpret_cast<unsigned short*>(s_mem + G);
   uint32_t* s_rel32 = s_mem + G;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#ifdef GB_TIME
-  const uint64_t tm0 = wall_clock64();
-#endif
   // (i) the waves' starts inside the chunk's run of every group (counted by gbin_count_kernel)
   {
-    const uint32_t* ws = wave_start + (size_t)blockIdx.x * W * (Gpad >> 1);
+    const uint32_t* ws = wave_start + (size_t)chunk * W * (Gpad >> 1);
     for (int e = tid; e < W * (Gpad >> 1); e += blockDim.x) s_rel32[e] = ws[e];
   }
-  const int first = blockIdx.x * g_per_block + wave * g_per_wave;
-  const int end = min(N, min(first + g_per_wave, (blockIdx.x + 1) * g_per_block));
-#ifdef GB_TIME
-  const uint64_t tm1 = wall_clock64();
-#endif
+  const int first = chunk * g_per_block + wave * g_per_wave;
+  const int end = min(N, min(first + g_per_wave, (chunk + 1) * g_per_block));
   // (ii) start of this chunk's run in every group's segment: exclusive scan of the group counts + the earlier chunks
-  const uint32_t* row = table + (size_t)blockIdx.x * G;
+  const uint32_t* row = table + (size_t)chunk * G;
   {
     __shared__ uint32_t s_wsum[16];
     __shared__ uint32_t s_run;
@@ -545,18 +540,12 @@ __global__ __launch_bounds__(1024) void gbin_scatter_kernel(int N, int G, int gx
       __syncthreads();
     }
   }
-#ifdef GB_TIME
-  const uint64_t tm2 = wall_clock64();
-#endif
   __syncthreads();
   // (iii) ordered walk.  A tile's place = the group's cursor + its rank inside the Gaussian's span of that group (the
   // rectangle's columns that fall into the group's eight, in that tile row); the span's last tile advances the cursor.  As
   // in the direct sort, four Gaussians share a step when their rectangles have at most 16 tiles (two with at most 32):
   // lane = (slot, tile); a lane's place then also counts the spans of the step's EARLIER slots in its group, and only the
   // last slot with a span there advances the cursor.
-#ifdef GB_TIME
-  const uint64_t tm3 = wall_clock64();
-#endif
   unsigned short* cur = s_rel + (size_t)wave * Gpad;
   for (int s0 = first; s0 < end; s0 += 64) {
     const int s = s0 + lane;
@@ -641,10 +630,6 @@ __global__ __launch_bounds__(1024) void gbin_scatter_kernel(int N, int G, int gx
       }
     }
   }
-#ifdef GB_TIME
-  __syncthreads();
-  if (tid == 0 && blockIdx.x % 97 == 5) printf("GBS %d hist %d scan %d prefix %d walk %d (x10ns)\n", (int)blockIdx.x, (int)(tm1 - tm0), (int)(tm2 - tm1), (int)(tm3 - tm2), (int)(wall_clock64() - tm3));
-#endif
 }
 
 // The parts of the second level: workgroup b of its kernels takes part_tab[b] = {group, first part of the group, start in
@@ -726,14 +711,16 @@ __global__ __launch_bounds__(512) void gbin_tcount_kernel(int gxg, int grid_x, c
 // CONSECUTIVE instances: counts them in packed counters, one packed scan over the threads, places them from packed running
 // offsets — and the part goes through LDS twice: in (coalesced loads -> a thread's 16 in a row) and out (final order ->
 // long coalesced runs).
-__global__ __launch_bounds__(1024) void gbin_offsets_kernel(int T, int G, int64_t cap, const uint32_t* __restrict__ group_count,
-                                                           const uint32_t* __restrict__ tile_count, const BinOut out) {
-  bin_offsets_body(T, cap, tile_count, out, group_count, G);
-}
-__global__ __launch_bounds__(GTS_THREADS, GTS_WAVES) void gbin_tscatter_kernel(int gxg, int grid_x, int64_t cap, const uint4* __restrict__ part_tab,
+__global__ __launch_bounds__(GTS_THREADS, GTS_WAVES) void gbin_tscatter_kernel(int T, int G, int gxg, int grid_x, int64_t cap,
+                                                              const uint32_t* __restrict__ group_count, const uint4* __restrict__ part_tab,
                                                               const uint32_t* __restrict__ inter,
                                                               const uint32_t* __restrict__ part_hist, const uint32_t* __restrict__ tile_count,
-                                                              uint32_t* __restrict__ point_list, uint32_t* __restrict__ tile_keys) {
+                                                              uint32_t* __restrict__ point_list, uint32_t* __restrict__ tile_keys,
+                                                              const BinOut out) {
+  if (blockIdx.x == 0) {  // (the extra workgroup FIRST: it runs for ~20 us, and the last of 8 000 workgroups would start it at the very end)
+    bin_offsets_body(T, cap, tile_count, out, group_count, G);
+    return;
+  }
   constexpr int EPT = BIN_PART / GTS_THREADS, NW = GTS_THREADS / 64;  // instances per thread, waves
   static_assert(EPT * 64 < 65536 && BIN_PART < 65536, "packed 16-bit counters below");
   __shared__ uint32_t s_cur[8];            // start of the group's tiles' lists for this part (global)
@@ -741,10 +728,7 @@ __global__ __launch_bounds__(GTS_THREADS, GTS_WAVES) void gbin_tscatter_kernel(i
   __shared__ uint32_t s_wbase[NW][4];       // [wave] packed pairs: place (in the part's final order) of the wave's first instance of each tile
   __shared__ uint32_t s_lstart[9];         // start of each tile in the part's final order
   __shared__ uint32_t s_stage[BIN_PART + BIN_PART / EPT];
-#ifdef GB_TIME
-  const uint64_t tm0 = wall_clock64();
-#endif
-  const GPart p = gbin_part((int)blockIdx.x, part_tab);
+  const GPart p = gbin_part((int)blockIdx.x - 1, part_tab);
   if (p.group < 0) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gx0 = (p.group % gxg) * 8, gy = p.group / gxg;
@@ -765,9 +749,6 @@ __global__ __launch_bounds__(GTS_THREADS, GTS_WAVES) void gbin_tscatter_kernel(i
     }
     if (lane < 8) s_cur[q] = (p.start - p.part * BIN_PART) + (v - tc) + share;  // (p.start - ...: the group's segment; the clamp to `cap` only bites on overflow)
   }
-#ifdef GB_TIME
-  const uint64_t tm1 = wall_clock64();
-#endif
   // in: coalesced loads, padded rows of 16 in LDS, a thread's row into registers
 #pragma unroll
   for (int it = 0; it < EPT; it++) {
@@ -778,9 +759,6 @@ __global__ __launch_bounds__(GTS_THREADS, GTS_WAVES) void gbin_tscatter_kernel(i
   uint32_t ev[EPT];
 #pragma unroll
   for (int i = 0; i < EPT; i++) ev[i] = s_stage[tid * (EPT + 1) + i];
-#ifdef GB_TIME
-  const uint64_t tm2 = wall_clock64();
-#endif
   const uint32_t k_first = (uint32_t)tid * EPT;
   // packed counts: word w = tiles (2w, 2w+1) in 16-bit halves
   uint32_t cnt[4] = {0u, 0u, 0u, 0u};
@@ -803,9 +781,6 @@ __global__ __launch_bounds__(GTS_THREADS, GTS_WAVES) void gbin_tscatter_kernel(i
     if (lane == 63) s_wtot[wave][w] = v;
   }
   __syncthreads();  // (also: every thread has its row out of s_stage)
-#ifdef GB_TIME
-  const uint64_t tm3 = wall_clock64();
-#endif
   if (tid < 8) {
     // tile `tid`: its total, then (after the exchange below) the waves' bases
     uint32_t tot = 0u;
@@ -845,9 +820,6 @@ __global__ __launch_bounds__(GTS_THREADS, GTS_WAVES) void gbin_tscatter_kernel(i
     if (on) s_stage[at] = ev[i];
   }
   __syncthreads();
-#ifdef GB_TIME
-  const uint64_t tm4 = wall_clock64();
-#endif
   // out: the part in its final order, tile after tile: long runs
   uint32_t lstart[9];
 #pragma unroll
@@ -865,10 +837,6 @@ __global__ __launch_bounds__(GTS_THREADS, GTS_WAVES) void gbin_tscatter_kernel(i
       if (tile_keys) tile_keys[pos] = (uint32_t)(gy * grid_x + gx0 + c);
     }
   }
-#ifdef GB_TIME
-  __syncthreads();
-  if (tid == 0 && blockIdx.x % 397 == 5) printf("GTS %d/%d len %d part %d cur %d load %d count+scan %d place %d store %d (x10ns) cap %ld\n", (int)blockIdx.x, (int)gridDim.x, (int)p.len, (int)p.part, (int)(tm1 - tm0), (int)(tm2 - tm1), (int)(tm3 - tm2), (int)(tm4 - tm3), (int)(wall_clock64() - tm4), (long)cap);
-#endif
 }
 
 struct BinPlan { int g_per_block, g_per_wave, threads, n_chunks; size_t lds_scatter; };
@@ -896,7 +864,8 @@ static BinPlan bin_plan(int N, int T) {
 }
 
 // which sort?  Beyond BIN_GROUPED_MIN_T tiles only the grouped one fits; below, it wins on many Gaussians over many tiles
-// (2 M / 8160 tiles: 0.54 ms against 0.70 ms) and loses on the small scenes (its five launches cost more than they save).
+// (2 M / 8160 tiles: 0.50 ms against 0.70 ms; 500 k / 4096 tiles: level) and loses on the small scenes (300 k / 2500 tiles:
+// +0.04 ms — its five launches cost more than they save).
 // RIGGS_BIN_GROUPED=0 / 1 overrides the choice where both fit (measurements).
 static bool bin_grouped(int N, int T) {
   if (T > BIN_GROUPED_MIN_T) return true;
@@ -915,10 +884,12 @@ static GBinPlan gbin_plan(int N, int T, int grid_x) {
   const int grid_y = grid_x > 0 ? (T + grid_x - 1) / grid_x : 0;
   p.G = p.gxg * grid_y;
   const int W = 16;
-  // batches of 64 Gaussians per wave so that a launch has <= ~1024 chunks (the chunk x group table and every workgroup's
-  // O(G) set-up stay small)
-  int batches = (int)(((int64_t)N + (int64_t)W * 64 * 1024 - 1) / ((int64_t)W * 64 * 1024));
-  batches = batches < 1 ? 1 : (batches > 16 ? 16 : batches);
+  // batches of 64 Gaussians per wave so that a launch has <= ~512 chunks (one round of the scatter kernel's workgroups; the
+  // chunk x group table and every workgroup's O(G) set-up stay small; bin_scan keeps a column segment in registers up to
+  // 16 x 32 chunks) — and at most 7: a Gaussian adds up to 8 instances to a group, and the waves' starts inside a chunk's
+  // run are 16-bit (16 waves x 7 x 64 x 8 = 57 344)
+  int batches = (int)(((int64_t)N + (int64_t)W * 64 * 512 - 1) / ((int64_t)W * 64 * 512));
+  batches = batches < 1 ? 1 : (batches > 7 ? 7 : batches);
   p.g_per_wave = 64 * batches;
   p.g_per_block = W * p.g_per_wave;
   p.n_chunks = (N + p.g_per_block - 1) / p.g_per_block;
@@ -973,9 +944,9 @@ int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order,
     hipLaunchKernelGGL(gbin_scatter_kernel, dim3(p.n_chunks + 1), dim3(1024), p.lds, s, N, p.G, p.gxg, cap, p.g_per_block, p.g_per_wave,
                        order, tiles, rect, table, wave_start, group_count, inter, part_tab, n_parts);
     hipLaunchKernelGGL(gbin_tcount_kernel, dim3(n_parts), dim3(512), 0, s, p.gxg, grid_x, part_tab, inter, part_hist, tile_count);
-    hipLaunchKernelGGL(gbin_offsets_kernel, dim3(1), dim3(1024), 0, s, T, p.G, cap, group_count, tile_count, out);
-    hipLaunchKernelGGL(gbin_tscatter_kernel, dim3(n_parts), dim3(GTS_THREADS), 0, s, p.gxg, grid_x, cap, part_tab, inter, part_hist, tile_count,
-                       point_list, tile_keys);
+    // (+ 1: the extra workgroup that writes the ranges, the counters and the forward's work list)
+    hipLaunchKernelGGL(gbin_tscatter_kernel, dim3(n_parts + 1), dim3(GTS_THREADS), 0, s, T, p.G, p.gxg, grid_x, cap, group_count, part_tab,
+                       inter, part_hist, tile_count, point_list, tile_keys, out);
     return 0;
   }
   BinPlan p = bin_plan(N, T);

@@ -81,10 +81,15 @@ class RasterArena:
 
     def ensure(self, cap: int, N: int, H: int, W: int, device):
         cap = max(int(cap), self.min_capacity)
-        if self.binning is None or cap > self.capacity or self.binning.device != device:
-            nbytes = L.lib().riggs_raster_binning_bytes(cap, N, H, W)
-            self.binning = torch.empty(nbytes, dtype=torch.uint8, device=device)
-            self.capacity = cap
+        same = self.binning is not None and self.binning.device == device
+        if same and cap <= self.capacity:
+            # enough instances — but the arena also holds tables sized by the number of Gaussians and of tiles (the tile
+            # sort's chunk x tile table): a scene that grew, or a larger image, needs a larger arena at the same capacity
+            if L.lib().riggs_raster_binning_bytes(self.capacity, N, H, W) <= self.binning.numel():
+                return self.binning
+            cap = self.capacity
+        self.binning = torch.empty(L.lib().riggs_raster_binning_bytes(cap, N, H, W), dtype=torch.uint8, device=device)
+        self.capacity = cap
         return self.binning
 
 

@@ -173,6 +173,26 @@ def test_arena_mode_matches_sync_mode_and_recovers_from_overflow():
     assert arena.resolve() and same(ref[0], a4[0])
 
 
+def test_arena_follows_a_growing_scene_and_image():
+    """The arena also holds tables sized by the number of Gaussians and of tiles: at an unchanged instance capacity a scene with
+    more Gaussians or a larger image must get a larger arena (it used to be sized by the capacity alone)."""
+    d = lambda t: t.cuda().contiguous()  # noqa: E731
+    arena = RasterArena(min_capacity=1 << 21)  # (plenty for both frames: the capacity never forces a regrow)
+    same = lambda x, y: float((x - y).abs().max()) <= 2e-6 * max(1.0, float(x.abs().max()))  # noqa: E731
+    sizes = []
+    for n, hw in ((2000, 64), (60_000, 512), (2000, 64)):
+        sc, act, cam = U.activated_scene(n, 8, 5, hw, hw, scale=0.01)
+        st = U.settings_for(cam, [0, 0, 0])
+        args = (d(act["means3D"]), d(act["shs"]), None, d(act["opacities"]), d(act["scales"]), d(act["rotations"]), None)
+        ref = rasterize_forward(st, *args)
+        for _ in range(2):  # (the second call is the one without the host synchronisation)
+            out = rasterize_forward(st, *args, arena=arena)
+            assert same(ref[0], out[0]) and torch.equal(ref[1], out[1])
+        assert arena.resolve()
+        sizes.append(arena.binning.numel())
+    assert sizes[1] > sizes[0] and sizes[2] == sizes[1] and arena.capacity == 1 << 21
+
+
 @pytest.mark.parametrize("N,J,H,W", [(150_000, 24, 800, 800), (300_000, 32, 800, 800)])
 def test_full_size_properties(N, J, H, W):
     """BASELINE configs C2 / C3 at full size: size-independent properties instead of the oracle."""
