@@ -985,6 +985,10 @@ int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order,
 #define RS_BITS 12
 #define RS_BINS (1 << RS_BITS)
 #define RS_CHUNK 2048   // elements per workgroup
+#define RS_CHUNK_BIG 8192  // ... from RS_BIG_MIN_N keys on
+#ifndef RS_BIG_MIN_N
+#define RS_BIG_MIN_N 1000000
+#endif
 #define RS_SC_WAVES 8   // waves of a scatter workgroup (4 steps of 64 elements each)
 
 // routing of a pass: (source, destination) by the "third pass needed" flag (counters[2])
@@ -1004,16 +1008,18 @@ __device__ __forceinline__ void rs_route(const RsBufs& b, int pass, bool three, 
 // (the last workgroup of the first pass also totals the per-workgroup tile counts of preprocess_fwd into
 // counters[0] = R for the host, and every workgroup of it derives the flag from the recorded top bytes — the last one
 // publishes it in counters[2] for the later launches)
-__global__ __launch_bounds__(256) void rs_count_kernel(int N, int pass, RsBufs bufs, uint32_t* __restrict__ table,
-                                                       const uint32_t* __restrict__ part, int n_part,
-                                                       uint32_t* __restrict__ counters) {
+template <int CHUNK>
+__global__ __launch_bounds__(CHUNK / 8) void rs_count_kernel(int N, int pass, RsBufs bufs, uint32_t* __restrict__ table,
+                                                             const uint32_t* __restrict__ part, int n_part,
+                                                             uint32_t* __restrict__ counters) {
+  constexpr int NT = CHUNK / 8, NW = NT / 64;  // (eight elements per thread)
   __shared__ uint32_t s_hist[RS_BINS];
-  __shared__ uint32_t s_w[4], s_lo[4], s_hi[4];
+  __shared__ uint32_t s_w[NW], s_lo[NW], s_hi[NW];
   bool three;
   if (pass == 0) {
     // part[0 .. n_part): tile counts; part[n_part .. 2 n_part): (min top byte << 8) | max top byte of the visible keys
     uint32_t v = 0, lo = 0xFFu, hi = 0u;
-    for (int i = threadIdx.x; i < n_part; i += 256) {
+    for (int i = threadIdx.x; i < n_part; i += NT) {
       v += part[i];
       const uint32_t tb = part[n_part + i];
       lo = min(lo, tb >> 8); hi = max(hi, tb & 0xFFu);
@@ -1024,10 +1030,13 @@ __global__ __launch_bounds__(256) void rs_count_kernel(int N, int pass, RsBufs b
     }
     if ((threadIdx.x & 63) == 0) { s_w[threadIdx.x >> 6] = v; s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
     __syncthreads();
-    lo = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3])); hi = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
+    uint32_t total = 0;
+    lo = 0xFFu; hi = 0u;
+#pragma unroll
+    for (int w = 0; w < NW; w++) { total += s_w[w]; lo = min(lo, s_lo[w]); hi = max(hi, s_hi[w]); }
     three = hi > lo;  // (no visible key at all: lo = 255 > hi = 0: two passes)
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-      counters[0] = s_w[0] + s_w[1] + s_w[2] + s_w[3]; counters[1] = 0u; counters[2] = three ? 1u : 0u; counters[3] = 0u;
+      counters[0] = total; counters[1] = 0u; counters[2] = three ? 1u : 0u; counters[3] = 0u;
     }
   } else {
     three = counters[2] != 0u;
@@ -1035,17 +1044,17 @@ __global__ __launch_bounds__(256) void rs_count_kernel(int N, int pass, RsBufs b
   const uint32_t *ks, *vs; uint32_t *kd, *vd;
   rs_route(bufs, pass, three, ks, vs, kd, vd);
   const int shift = pass * RS_BITS;
-  for (int b = threadIdx.x; b < RS_BINS; b += 256) s_hist[b] = 0u;
+  for (int b = threadIdx.x; b < RS_BINS; b += NT) s_hist[b] = 0u;
   __syncthreads();
-  const int first = blockIdx.x * RS_CHUNK;
+  const int first = blockIdx.x * CHUNK;
 #pragma unroll
-  for (int k = 0; k < RS_CHUNK / 256; k++) {
-    const int i = first + k * 256 + threadIdx.x;
+  for (int k = 0; k < CHUNK / NT; k++) {
+    const int i = first + k * NT + threadIdx.x;
     if (i < N) atomicAdd(&s_hist[(ks[i] >> shift) & (RS_BINS - 1)], 1u);
   }
   __syncthreads();
   uint32_t* row = table + (size_t)blockIdx.x * RS_BINS;
-  for (int b = threadIdx.x; b < RS_BINS; b += 256) row[b] = s_hist[b];
+  for (int b = threadIdx.x; b < RS_BINS; b += NT) row[b] = s_hist[b];
 }
 
 // (the third pass's scan when that pass is skipped: bin_scan_kernel itself is shared with the tile binning, so a thin
@@ -1056,6 +1065,7 @@ __global__ __launch_bounds__(1024) void rs_scan_kernel(int n_chunks, uint32_t* _
   bin_scan_body(RS_BINS, n_chunks, table, bin_count);
 }
 
+template <int CHUNK>
 __global__ __launch_bounds__(RS_SC_WAVES * 64) void rs_scatter_kernel(int N, int pass, RsBufs bufs,
                                                                       const uint32_t* __restrict__ table /* exclusive over chunks */,
                                                                       const uint32_t* __restrict__ bin_count,
@@ -1072,8 +1082,8 @@ __global__ __launch_bounds__(RS_SC_WAVES * 64) void rs_scatter_kernel(int N, int
   // every global load of the workgroup up front — its elements, its row of the chunk table, the bin totals — so that the
   // scan and the two barriers below run under ONE round trip instead of in front of two more (the compiler keeps loads
   // behind a barrier where it finds them)
-  constexpr int STEPS = RS_CHUNK / NT;
-  const int wfirst = blockIdx.x * RS_CHUNK + wave * (64 * STEPS);
+  constexpr int STEPS = CHUNK / NT;
+  const int wfirst = blockIdx.x * CHUNK + wave * (64 * STEPS);
   uint32_t key[STEPS], val[STEPS];
 #pragma unroll
   for (int st = 0; st < STEPS; st++) {
@@ -1101,7 +1111,7 @@ __global__ __launch_bounds__(RS_SC_WAVES * 64) void rs_scatter_kernel(int N, int
   for (int w = 0; w < wave; w++) run += s_part[w];
 #pragma unroll
   for (int k = 0; k < PER; k++) { s_start[tid * PER + k] = run + rw[k]; run += c[k]; }
-  // this wave's elements: 4 steps of 64 consecutive elements
+  // this wave's elements: STEPS steps of 64 consecutive elements
   int dig[STEPS];
 #pragma unroll
   for (int st = 0; st < STEPS; st++) {
@@ -1109,7 +1119,7 @@ __global__ __launch_bounds__(RS_SC_WAVES * 64) void rs_scatter_kernel(int N, int
     dig[st] = -1;
     if (i < N) {
       dig[st] = (int)((key[st] >> shift) & (RS_BINS - 1));
-      // 16-bit counters packed in pairs (a wave adds at most 256 per bin)
+      // 16-bit counters packed in pairs (a wave adds at most 64 x STEPS <= 1024 per bin, a chunk at most 8192)
       atomicAdd(reinterpret_cast<uint32_t*>(&s_wave[wave][0]) + (dig[st] >> 1), 1u << (16 * (dig[st] & 1)));
     }
   }
@@ -1151,6 +1161,7 @@ __global__ __launch_bounds__(RS_SC_WAVES * 64) void rs_scatter_kernel(int N, int
 #define RS3_BINS 256
 #define RS3_MAX_WG 512  // upper bound of the third pass's grid (launch_depth_sort sizes it from the device's occupancy; each workgroup loops over its chunks)
 typedef __attribute__((address_space(1))) uint32_t rs_gu32;
+template <int CHUNK>
 __global__ __launch_bounds__(RS_SC_WAVES * 64) void rs_third_pass_kernel(int N, int n_chunks, RsBufs bufs,
                                                                          uint32_t* __restrict__ table3,
                                                                          uint32_t* __restrict__ counters) {
@@ -1161,7 +1172,7 @@ __global__ __launch_bounds__(RS_SC_WAVES * 64) void rs_third_pass_kernel(int N, 
   __shared__ int s_fail;
   const uint32_t *ks = bufs.k_tmp, *vs = bufs.v_tmp;
   uint32_t *kd = bufs.k_out, *vd = bufs.v_out;
-  constexpr int NT = RS_SC_WAVES * 64, STEPS = RS_CHUNK / NT;
+  constexpr int NT = RS_SC_WAVES * 64, STEPS = CHUNK / NT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int G = (int)gridDim.x;
   // ---- phase A: the counts of this workgroup's chunks, published with write-through stores
@@ -1170,7 +1181,7 @@ __global__ __launch_bounds__(RS_SC_WAVES * 64) void rs_third_pass_kernel(int N, 
     __syncthreads();
 #pragma unroll
     for (int st = 0; st < STEPS; st++) {
-      const int i = chunk * RS_CHUNK + wave * (64 * STEPS) + st * 64 + lane;
+      const int i = chunk * CHUNK + wave * (64 * STEPS) + st * 64 + lane;
       if (i < N) atomicAdd(&s_hist[ks[i] >> 24], 1u);
     }
     __syncthreads();
@@ -1216,7 +1227,7 @@ __global__ __launch_bounds__(RS_SC_WAVES * 64) void rs_third_pass_kernel(int N, 
     int dig[STEPS];
 #pragma unroll
     for (int st = 0; st < STEPS; st++) {
-      const int i = chunk * RS_CHUNK + wave * (64 * STEPS) + st * 64 + lane;
+      const int i = chunk * CHUNK + wave * (64 * STEPS) + st * 64 + lane;
       key[st] = 0u; val[st] = 0u; dig[st] = -1;
       if (i < N) {
         key[st] = ks[i]; val[st] = vs[i];
@@ -1273,21 +1284,23 @@ size_t depth_sort_table_bytes(int N) {
 }
 
 // the result ends in (keys_out, vals_out); keys_in is left intact; values are the element indices
-int launch_depth_sort(int N, const uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_out, void* table_mem,
-                      const uint32_t* block_info, uint32_t* counters, hipStream_t s) {
-  const int chunks = (N + RS_CHUNK - 1) / RS_CHUNK;
+template <int CHUNK>
+static int launch_depth_sort_t(int N, const uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_out, void* table_mem,
+                               const uint32_t* block_info, uint32_t* counters, hipStream_t s) {
+  const int chunks = (N + CHUNK - 1) / CHUNK;
   char* mem = (char*)table_mem;
   uint32_t* table = (uint32_t*)mem;
-  uint32_t* bin_count = (uint32_t*)(mem + align_up(((size_t)chunks + 1) * RS_BINS * 4));
+  // (the layout of depth_sort_table_bytes: sized for the small chunks, whichever are used)
+  uint32_t* bin_count = (uint32_t*)(mem + align_up(((size_t)((N + RS_CHUNK - 1) / RS_CHUNK) + 1) * RS_BINS * 4));
   RsBufs b;
   b.k_in = keys_in; b.v_in = nullptr;
   b.k_tmp = (uint32_t*)((char*)bin_count + align_up(RS_BINS * 4));
   b.v_tmp = (uint32_t*)((char*)b.k_tmp + align_up((size_t)(N > 0 ? N : 1) * 4));
   b.k_out = keys_out; b.v_out = vals_out;
   for (int pass = 0; pass < 2; pass++) {
-    hipLaunchKernelGGL(rs_count_kernel, dim3(chunks), dim3(256), 0, s, N, pass, b, table, block_info, (N + 255) / 256, counters);
+    hipLaunchKernelGGL(rs_count_kernel<CHUNK>, dim3(chunks), dim3(CHUNK / 8), 0, s, N, pass, b, table, block_info, (N + 255) / 256, counters);
     hipLaunchKernelGGL(rs_scan_kernel, dim3((RS_BINS + 63) / 64), dim3(1024), 0, s, chunks, table, bin_count, counters, pass);
-    hipLaunchKernelGGL(rs_scatter_kernel, dim3(chunks), dim3(RS_SC_WAVES * 64), 0, s, N, pass, b, table, bin_count, counters);
+    hipLaunchKernelGGL(rs_scatter_kernel<CHUNK>, dim3(chunks), dim3(RS_SC_WAVES * 64), 0, s, N, pass, b, table, bin_count, counters);
   }
   // (the table of the 12-bit passes is free again: chunks x 256 counts fit into it)
   // The in-launch barrier of the third pass needs every workgroup RESIDENT at once: size the grid from what the device can
@@ -1297,7 +1310,7 @@ int launch_depth_sort(int N, const uint32_t* keys_in, uint32_t* keys_out, uint32
   static int rs3_grid = 0;
   if (rs3_grid == 0) {
     int per_cu = 0, dev = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(rs_third_pass_kernel), RS_SC_WAVES * 64, 0) != hipSuccess ||
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(rs_third_pass_kernel<CHUNK>), RS_SC_WAVES * 64, 0) != hipSuccess ||
         hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
       per_cu = 1; cus = 64; (void)hipGetLastError();
     }
@@ -1305,9 +1318,19 @@ int launch_depth_sort(int N, const uint32_t* keys_in, uint32_t* keys_out, uint32
     rs3_grid = resident / 2 > 0 ? resident / 2 : 1;
     if (rs3_grid > RS3_MAX_WG) rs3_grid = RS3_MAX_WG;
   }
-  hipLaunchKernelGGL(rs_third_pass_kernel, dim3(chunks < rs3_grid ? chunks : rs3_grid), dim3(RS_SC_WAVES * 64), 0, s, N, chunks,
+  hipLaunchKernelGGL(rs_third_pass_kernel<CHUNK>, dim3(chunks < rs3_grid ? chunks : rs3_grid), dim3(RS_SC_WAVES * 64), 0, s, N, chunks,
                      b, table, counters);
   return 0;
+}
+
+// the result ends in (keys_out, vals_out); keys_in is left intact; values are the element indices
+int launch_depth_sort(int N, const uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_out, void* table_mem,
+                      const uint32_t* block_info, uint32_t* counters, hipStream_t s) {
+  // chunks of 2048 keys fill the chip at the bench size (98 workgroups at 200 k keys; a chunk costs its workgroup an O(4096)
+  // set-up); from a million keys on the chunk x bin table of those (16 MB at 2 M) is what the passes spend their time on:
+  // 8192 keys per chunk there (2 M keys: count 16 -> ?, scan 21 -> ?, scatter 61 -> ? us per pass)
+  if (N >= RS_BIG_MIN_N) return launch_depth_sort_t<RS_CHUNK_BIG>(N, keys_in, keys_out, vals_out, table_mem, block_info, counters, s);
+  return launch_depth_sort_t<RS_CHUNK>(N, keys_in, keys_out, vals_out, table_mem, block_info, counters, s);
 }
 
 }  // namespace riggs

@@ -282,6 +282,16 @@ def test_depth_sort_takes_two_passes_when_the_depths_share_their_top_byte_and_th
         U.compare_forward_state(so, saved_views(s), out_o, color, depth, alpha, radii)
 
 
+def test_depth_sort_of_a_million_keys_uses_the_large_chunks():
+    """From a million Gaussians on the depth sort works on chunks of 8192 keys instead of 2048 (launch_depth_sort): all three
+    passes of that variant, bit for bit against the oracle (tests/test_gpu_configs.py: C5 covers its two-pass path)."""
+    sc, act, cam = U.activated_scene(1_050_000, 8, 23, 96, 128, scale=0.004, radius=1.6)
+    out_o, so = U.oracle_forward(act, cam, [0, 0, 0])
+    color, radii, depth, alpha, s = U.hip_forward(act, cam, [0, 0, 0])
+    assert int(s.counters[2]) == 1
+    U.compare_forward_state(so, saved_views(s), out_o, color, depth, alpha, radii)
+
+
 def test_ordered_reduction_mode_gives_bitwise_reproducible_gradients():
     """riggs_raster_cfg.deterministic: every tile instance writes its gradient row, a second kernel sums each
     Gaussian's rows in ascending tile order — no float atomics, so two runs agree BIT FOR BIT (the default path only to
