@@ -1327,8 +1327,11 @@ static int launch_depth_sort_t(int N, const uint32_t* keys_in, uint32_t* keys_ou
 int launch_depth_sort(int N, const uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_out, void* table_mem,
                       const uint32_t* block_info, uint32_t* counters, hipStream_t s) {
   // chunks of 2048 keys fill the chip at the bench size (98 workgroups at 200 k keys; a chunk costs its workgroup an O(4096)
-  // set-up); from a million keys on the chunk x bin table of those (16 MB at 2 M) is what the passes spend their time on:
-  // 8192 keys per chunk there (2 M keys: count 16 -> ?, scan 21 -> ?, scatter 61 -> ? us per pass)
+  // set-up); from a million keys on the chunk x bin table of those (16 MB at 2 M) is what the count and scan kernels spend
+  // their time on: 8192 keys per chunk there (2 M keys, per pass: count 16 -> 10, scan 21 -> 5.5, scatter 61 -> 56 us;
+  // 4096 keys per chunk: 12 / 7 / 60).  The scatter kernel stays at ~55 us whatever the chunk: 4 M scattered 4-byte stores
+  // (key and value, up to 64 different bins per wave step) at the rate the L2 takes single-dword line writes — the same
+  // bound as the tile sort's walk; runs only get longer with fewer bins (8-bit digits: four passes), not with larger chunks.
   if (N >= RS_BIG_MIN_N) return launch_depth_sort_t<RS_CHUNK_BIG>(N, keys_in, keys_out, vals_out, table_mem, block_info, counters, s);
   return launch_depth_sort_t<RS_CHUNK>(N, keys_in, keys_out, vals_out, table_mem, block_info, counters, s);
 }
