@@ -14,6 +14,7 @@
 // HBM traffic: N*(4+8+4) read per pass, R*4(+4) written once, 2*chunks*T*4 for the table — against
 // ~R*32 B for two radix passes over (key, value) pairs plus the emit pass.
 #include <stdlib.h>
+#include <type_traits>
 #include "raster_internal.h"
 
 namespace riggs {
@@ -435,7 +436,8 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(int N, int T, int gri
 #define GTS_WAVES 4     // (its waves per SIMD: 128 VGPRs)
 #endif
 
-__device__ __forceinline__ int grp_of(int x, int y, int gxg) { return y * gxg + (x >> 3); }
+struct __attribute__((packed, aligned(4))) GU4 { uint32_t a, b, c, d; };  // (dword-aligned 16- and 8-byte stores)
+struct __attribute__((packed, aligned(4))) GU2 { uint32_t a, b; };
 
 // (1a) per chunk of depth-ordered Gaussians: instances per group, counted PER WAVE (wave w of the scatter kernel below walks
 // the chunk's Gaussians [w * g_per_wave, (w + 1) * g_per_wave) — the same split here): the chunk's totals go to the table,
@@ -541,92 +543,98 @@ __global__ __launch_bounds__(1024) void gbin_scatter_kernel(int N, int G, int gx
     }
   }
   __syncthreads();
-  // (iii) ordered walk.  A tile's place = the group's cursor + its rank inside the Gaussian's span of that group (the
-  // rectangle's columns that fall into the group's eight, in that tile row); the span's last tile advances the cursor.  As
-  // in the direct sort, four Gaussians share a step when their rectangles have at most 16 tiles (two with at most 32):
-  // lane = (slot, tile); a lane's place then also counts the spans of the step's EARLIER slots in its group, and only the
-  // last slot with a span there advances the cursor.
+  // (iii) ordered walk.  The unit is a SPAN: the columns of a Gaussian's rectangle that fall into one group, in one tile
+  // row — up to eight instances that go to consecutive places of the group's segment.  Lane = (slot, span): eight Gaussians
+  // share a step when each has at most 8 spans (a 5 x 4 rectangle has 4 - 8), four with at most 16; a larger one takes a
+  // step of its own (lanes = its spans).  The slots CLAIM their places one after the other — slot j's lanes read the group
+  // cursors and advance them by their span lengths, then slot j + 1's: the LDS keeps a wave's operations in order, so the
+  // instances of a group land in the Gaussians' order whatever overlaps whatever, without a rectangle test (the version
+  // with lane = tile and geometric tests of the earlier slots: 75 instructions per step of two Gaussians; the walk is bound
+  // by instruction issue).  A span is then written with up to four stores (4 + 4, 4 + 2 + 1, ... dwords; the places are
+  // only dword-aligned, which global stores of any width accept).
   unsigned short* cur = s_rel + (size_t)wave * Gpad;
+  auto put_span = [&](const int64_t pos, const uint32_t g, const int span0, const int L) {
+    const uint32_t v0 = g | ((uint32_t)(span0 & 7) << 29);  // (a span stays inside its group: no wrap of the three tile bits)
+    if (pos + L <= cap) {
+      uint32_t* q = inter + pos;
+      int off = 0;
+      if (L >= 4) { GU4 v; v.a = v0; v.b = v0 + (1u << 29); v.c = v0 + (2u << 29); v.d = v0 + (3u << 29); *reinterpret_cast<GU4*>(q) = v; off = 4; }
+      if (L == 8) { GU4 v; v.a = v0 + (4u << 29); v.b = v0 + (5u << 29); v.c = v0 + (6u << 29); v.d = v0 + (7u << 29); *reinterpret_cast<GU4*>(q + 4) = v; off = 8; }
+      const int rem = L - off;  // 0 .. 3
+      if (rem & 2) { GU2 v; v.a = v0 + ((uint32_t)off << 29); v.b = v0 + ((uint32_t)(off + 1) << 29); *reinterpret_cast<GU2*>(q + off) = v; off += 2; }
+      if (rem & 1) q[off] = v0 + ((uint32_t)off << 29);
+    } else {
+      for (int k = 0; k < L; k++) if (pos + k < cap) inter[pos + k] = v0 + ((uint32_t)k << 29);  // (the arena overflows: the frame is flagged)
+    }
+  };
   for (int s0 = first; s0 < end; s0 += 64) {
     const int s = s0 + lane;
-    uint32_t my_g = 0u, my_n = 0u;
-    int pk_xy = 0, pk_zw = 0;
+    uint32_t my_g = 0u;
+    int pk_xy = 0, pk_zw = 0, my_ns = 0;
     if (s < end) {
       my_g = order[s];
-      my_n = tiles[my_g];
-      if (my_n) { const ushort4 rc = rect[my_g]; pk_xy = (int)rc.x | ((int)rc.y << 16); pk_zw = (int)rc.z | ((int)rc.w << 16); }
+      if (tiles[my_g]) {
+        const ushort4 rc = rect[my_g];
+        pk_xy = (int)rc.x | ((int)rc.y << 16); pk_zw = (int)rc.z | ((int)rc.w << 16);
+        my_ns = ((int)rc.w - (int)rc.y) * ((((int)rc.z - 1) >> 3) - ((int)rc.x >> 3) + 1);
+      }
     }
-    const uint64_t live = __builtin_amdgcn_ballot_w64(my_n != 0u);
-    const uint64_t large = __builtin_amdgcn_ballot_w64(my_n > 16u);
-    const uint64_t huge = __builtin_amdgcn_ballot_w64(my_n > 32u);
+    const uint64_t live = __builtin_amdgcn_ballot_w64(my_ns != 0);
+    const uint64_t over8 = __builtin_amdgcn_ballot_w64(my_ns > 8);
+    const uint64_t over16 = __builtin_amdgcn_ballot_w64(my_ns > 16);
+    // one step of SLOTS Gaussians (lanes base .. base + SLOTS - 1 of the batch), 64 / SLOTS lanes each
+    auto step = [&](const int base, auto slots_tag) {
+      constexpr int SLOTS = decltype(slots_tag)::value, LN = 64 / SLOTS;
+      const int slot = lane / LN, l = lane % LN;
+      const int axy = __shfl(pk_xy, base + slot), bzw = __shfl(pk_zw, base + slot);
+      const uint32_t g = (uint32_t)__shfl((int)my_g, base + slot);
+      const int rx0 = axy & 0xFFFF, ry0 = (int)((uint32_t)axy >> 16), rx1 = bzw & 0xFFFF, ry1 = (int)((uint32_t)bzw >> 16);
+      const int gc0 = rx0 >> 3, ncol = ((rx1 - 1) >> 3) - gc0 + 1;  // (the empty rectangle 0,0,0,0 of an invisible Gaussian: ncol = 0)
+      const bool valid = l < (ry1 - ry0) * ncol;
+      const int row = (int)(((float)l + 0.5f) * __builtin_amdgcn_rcpf((float)ncol));  // (l / ncol, as rect_tile)
+      const int col = gc0 + (l - row * ncol), y = ry0 + row;
+      const int span0 = max(rx0, col << 3), L = min(rx1, (col << 3) + 8) - span0;
+      const int gi = valid ? y * gxg + col : 0;
+      uint32_t rel = 0u;
 #pragma unroll
-    for (int q = 0; q < 16; q++) {
-      if (((live >> (4 * q)) & 0xFull) == 0ull) continue;
-      if (((huge >> (4 * q)) & 0xFull) != 0ull) {
-        // one Gaussian per step, lanes = the tiles of its rectangle (row-major)
-#pragma unroll
+      for (int jj = 0; jj < SLOTS; jj++) {
+        if (valid && slot == jj) {
+          rel = cur[gi];
+          cur[gi] = (unsigned short)(rel + (uint32_t)L);
+        }
+      }
+      if (valid) put_span((int64_t)s_base[gi] + rel, g, span0, L);
+    };
+#pragma unroll 1
+    for (int q = 0; q < 8; q++) {  // (not unrolled: the three kinds of step, eight times over, would not fit the instruction cache)
+      if (((live >> (8 * q)) & 0xFFull) == 0ull) continue;
+      if (((over8 >> (8 * q)) & 0xFFull) == 0ull) { step(8 * q, std::integral_constant<int, 8>{}); continue; }
+#pragma unroll 1
+      for (int hh = 0; hh < 2; hh++) {
+        const int base = 8 * q + 4 * hh;
+        if (((live >> base) & 0xFull) == 0ull) continue;
+        if (((over16 >> base) & 0xFull) == 0ull) { step(base, std::integral_constant<int, 4>{}); continue; }
+#pragma unroll 1
         for (int jj = 0; jj < 4; jj++) {
-          const int src = 4 * q + jj;
-          const int n = __builtin_amdgcn_readlane((int)my_n, src);
-          if (n == 0) continue;
+          // a step of its own: lanes = the Gaussian's spans, 64 at a time (every group at most once per Gaussian)
+          const int src = base + jj;
+          const int ns = __builtin_amdgcn_readlane(my_ns, src);
+          if (ns == 0) continue;
           const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)my_g, src);
           const int r0 = __builtin_amdgcn_readlane(pk_xy, src), r1 = __builtin_amdgcn_readlane(pk_zw, src);
           const int rx0 = r0 & 0xFFFF, ry0 = (int)((uint32_t)r0 >> 16), rx1 = r1 & 0xFFFF;
-          const int w = rx1 - rx0;
-          const float rw = __builtin_amdgcn_rcpf((float)w);
-          for (int l = lane; l < n; l += 64) {
-            const int ry = (int)(((float)l + 0.5f) * rw);  // (as rect_tile)
-            const int x = rx0 + (l - ry * w), y = ry0 + ry;
-            const int gi = grp_of(x, y, gxg);
-            const int span0 = max(rx0, (x >> 3) << 3), span1 = min(rx1, ((x >> 3) << 3) + 8);
-            const unsigned short rel = cur[gi];
-            if (x == span1 - 1) cur[gi] = (unsigned short)(rel + (span1 - span0));
-            const int64_t pos = (int64_t)s_base[gi] + rel + (x - span0);
-            if (pos < cap) inter[pos] = g | ((uint32_t)(x & 7) << 29);
+          const int gc0 = rx0 >> 3, ncol = ((rx1 - 1) >> 3) - gc0 + 1;
+          const float rn = __builtin_amdgcn_rcpf((float)ncol);
+          for (int l = lane; l < ns; l += 64) {
+            const int row = (int)(((float)l + 0.5f) * rn);
+            const int col = gc0 + (l - row * ncol), y = ry0 + row;
+            const int span0 = max(rx0, col << 3), L = min(rx1, (col << 3) + 8) - span0;
+            const int gi = y * gxg + col;
+            const uint32_t rel = cur[gi];
+            cur[gi] = (unsigned short)(rel + (uint32_t)L);
+            put_span((int64_t)s_base[gi] + rel, g, span0, L);
           }
         }
-        continue;
-      }
-      // the four rectangles, wave-uniform (an invisible Gaussian has the empty rectangle 0,0,0,0)
-      int ra[4], rb[4];
-#pragma unroll
-      for (int jj = 0; jj < 4; jj++) { ra[jj] = __builtin_amdgcn_readlane(pk_xy, 4 * q + jj); rb[jj] = __builtin_amdgcn_readlane(pk_zw, 4 * q + jj); }
-      auto step = [&](const int slot, const int l, const int nslot, const int sbase) {
-        // lanes (slot, l) over the slots sbase .. sbase + nslot - 1 of the four
-        int axy = ra[sbase], bzw = rb[sbase];
-#pragma unroll
-        for (int jj = 1; jj < 4; jj++) if (jj < nslot && slot == jj) { axy = ra[sbase + jj]; bzw = rb[sbase + jj]; }
-        const uint32_t g = (uint32_t)__shfl((int)my_g, 4 * q + sbase + slot);
-        const int rx0 = axy & 0xFFFF, ry0 = (int)((uint32_t)axy >> 16), rx1 = bzw & 0xFFFF, ry1 = (int)((uint32_t)bzw >> 16);
-        const int w = rx1 - rx0;
-        const int ry = (int)(((float)l + 0.5f) * __builtin_amdgcn_rcpf((float)w));  // (as rect_tile)
-        const int x = rx0 + (l - ry * w), y = ry0 + ry;
-        const bool valid = l < w * (ry1 - ry0);
-        const int gx8 = (x >> 3) << 3;
-        int before = 0, after = 0;
-#pragma unroll
-        for (int jj = 0; jj < 4; jj++) {
-          if (jj >= nslot) continue;
-          const int a = ra[sbase + jj], b = rb[sbase + jj];
-          const bool row_in = y >= (int)((uint32_t)a >> 16) && y < (int)((uint32_t)b >> 16);
-          const int ov = row_in ? max(0, min(b & 0xFFFF, gx8 + 8) - max(a & 0xFFFF, gx8)) : 0;
-          before += (jj < slot) ? ov : 0;
-          after += (jj > slot) ? ov : 0;
-        }
-        if (valid) {
-          const int gi = grp_of(x, y, gxg);
-          const int span0 = max(rx0, gx8), span1 = min(rx1, gx8 + 8);
-          const unsigned short rel = cur[gi];
-          if (x == span1 - 1 && after == 0) cur[gi] = (unsigned short)(rel + before + (span1 - span0));
-          const int64_t pos = (int64_t)s_base[gi] + rel + before + (x - span0);
-          if (pos < cap) inter[pos] = g | ((uint32_t)(x & 7) << 29);
-        }
-      };
-      if (((large >> (4 * q)) & 0xFull) != 0ull) {
-        step(lane >> 5, lane & 31, 2, 0);
-        step(lane >> 5, lane & 31, 2, 2);
-      } else {
-        step(lane >> 4, lane & 15, 4, 0);
       }
     }
   }
@@ -824,6 +832,7 @@ __global__ __launch_bounds__(GTS_THREADS, GTS_WAVES) void gbin_tscatter_kernel(i
   uint32_t lstart[9];
 #pragma unroll
   for (int q = 0; q < 9; q++) lstart[q] = s_lstart[q];
+#pragma unroll 4
   for (uint32_t k = (uint32_t)tid; k < p.len; k += GTS_THREADS) {
     int c = 0;
 #pragma unroll
