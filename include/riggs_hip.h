@@ -71,7 +71,9 @@ typedef struct riggs_raster_cfg {
   int32_t sparse_zero;
 } riggs_raster_cfg;
 
-/* Opaque arenas (upstream: geomBuffer / binningBuffer / imgBuffer byte tensors). */
+/* Opaque arenas (upstream: geomBuffer / binningBuffer / imgBuffer byte tensors).  The binning arena's size depends on ALL
+ * four arguments (the tile sort's tables are sized by the number of Gaussians and of tiles, not only by the instance
+ * capacity): ask again when the scene or the image grows. */
 size_t riggs_raster_geom_bytes(int32_t num_points);
 size_t riggs_raster_image_bytes(int32_t image_height, int32_t image_width);
 size_t riggs_raster_binning_bytes(int64_t instance_capacity, int32_t num_points, int32_t image_height,
@@ -123,8 +125,10 @@ int riggs_raster_preprocess(const riggs_raster_cfg* cfg, const float* means3D, c
 
 /* Stage 2: stable counting sort of the (depth-ordered) Gaussians' tile instances by tile — the order of upstream's
  * duplicateWithKeys + 64-bit key sort + identifyTileRanges — and the per-tile alpha compositing.
- * Limits: at most 25 600 tiles (e.g. 2560 x 2560 px; the per-workgroup tile table of the binning lives in LDS) —
- * larger images are rejected with an error, never mis-rendered.  `instance_capacity` bounds R: if R > capacity the launch is
+ * Limits: at most 65 535 tiles and ~4 200 groups of eight tiles in a row (3840 x 2160 px is fine): beyond 25 600 tiles, and
+ * from 500 000 Gaussians over 4 096 tiles on, the sort runs in two levels (by tile group, then by tile; the same list bit
+ * for bit; RIGGS_BIN_GROUPED=0/1 in the environment forces the choice where both fit) — larger images are rejected with an
+ * error, never mis-rendered.  `instance_capacity` bounds R: if R > capacity the launch is
  * still memory-safe, counters[1] is set to 1 and the image is undefined (caller retries
  * with a larger arena; riggs_amd.rasterizer does that). */
 int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom, void* binning, int64_t instance_capacity,

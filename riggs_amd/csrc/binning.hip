@@ -433,7 +433,7 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(int N, int T, int gri
 #define BIN_PART 8192  // instances per workgroup of the second level
 #ifndef GTS_THREADS
 #define GTS_THREADS 512  // threads of gbin_tscatter_kernel
-#define GTS_WAVES 4     // (its waves per SIMD: 128 VGPRs)
+#define GTS_WAVES 8     // (its waves per SIMD: four workgroups per CU, LDS 4 x 35.5 KB)
 #endif
 
 struct __attribute__((packed, aligned(4))) GU4 { uint32_t a, b, c, d; };  // (dword-aligned 16- and 8-byte stores)
@@ -771,15 +771,14 @@ __global__ __launch_bounds__(GTS_THREADS, GTS_WAVES) void gbin_tscatter_kernel(i
 #pragma unroll
   for (int i = 0; i < EPT; i++) ev[i] = s_stage[tid * (EPT + 1) + i];
   const uint32_t k_first = (uint32_t)tid * EPT;
-  // packed counts: word w = tiles (2w, 2w+1) in 16-bit halves
-  uint32_t cnt[4] = {0u, 0u, 0u, 0u};
+  // packed counts: eight 8-bit counters in a 64-bit word while counting (a thread has 16 instances), then word w = tiles
+  // (2w, 2w+1) in 16-bit halves for the scan over the threads
+  uint64_t cnt8 = 0ull;
 #pragma unroll
-  for (int i = 0; i < EPT; i++) {
-    const uint32_t c = ev[i] >> 29;
-    const uint32_t inc = (k_first + i < p.len) ? (1u << ((c & 1u) * 16u)) : 0u;
+  for (int i = 0; i < EPT; i++) cnt8 += (k_first + i < p.len) ? (1ull << ((ev[i] >> 29) * 8u)) : 0ull;
+  uint32_t cnt[4];
 #pragma unroll
-    for (int w = 0; w < 4; w++) cnt[w] += ((c >> 1) == (uint32_t)w) ? inc : 0u;
-  }
+  for (int w = 0; w < 4; w++) cnt[w] = ((uint32_t)(cnt8 >> (16 * w)) & 0xFFu) | (((uint32_t)(cnt8 >> (16 * w + 8)) & 0xFFu) << 16);
   uint32_t inc_scan[4];
 #pragma unroll
   for (int w = 0; w < 4; w++) {
@@ -812,23 +811,29 @@ __global__ __launch_bounds__(GTS_THREADS, GTS_WAVES) void gbin_tscatter_kernel(i
     }
   }
   __syncthreads();
-  // running places, packed like the counts: the wave's base + the earlier threads of the wave
-  uint32_t place[4];
+  // running places: the wave's base + the earlier threads of the wave; tiles 0-3 and 4-7 in two 64-bit words of four 16-bit
+  // fields (written so that nothing per instance is shared with the counting loop above: the compiler kept 64 registers of
+  // common subexpressions alive between the two, i.e. half the occupancy)
+  uint64_t place_lo, place_hi;
+  {
+    uint32_t pw[4];
 #pragma unroll
-  for (int w = 0; w < 4; w++) place[w] = s_wbase[wave][w] + inc_scan[w] - cnt[w];
+    for (int w = 0; w < 4; w++) pw[w] = s_wbase[wave][w] + inc_scan[w] - cnt[w];
+    place_lo = (uint64_t)pw[0] | ((uint64_t)pw[1] << 32);
+    place_hi = (uint64_t)pw[2] | ((uint64_t)pw[3] << 32);
+  }
 #pragma unroll
   for (int i = 0; i < EPT; i++) {
     const uint32_t c = ev[i] >> 29;
-    const uint32_t sh = (c & 1u) * 16u;
-    uint32_t word = place[0];
-#pragma unroll
-    for (int w = 1; w < 4; w++) word = ((c >> 1) == (uint32_t)w) ? place[w] : word;
-    const uint32_t at = (word >> sh) & 0xFFFFu;
+    const bool hi = c >= 4u;
+    const uint32_t sh = (c & 3u) * 16u;
+    const uint32_t at = (uint32_t)((hi ? place_hi : place_lo) >> sh) & 0xFFFFu;
     const bool on = k_first + i < p.len;
-    const uint32_t inc = on ? (1u << sh) : 0u;
-#pragma unroll
-    for (int w = 0; w < 4; w++) place[w] += ((c >> 1) == (uint32_t)w) ? inc : 0u;
+    const uint64_t inc = on ? (1ull << sh) : 0ull;
+    place_lo += hi ? 0ull : inc;
+    place_hi += hi ? inc : 0ull;
     if (on) s_stage[at] = ev[i];
+    __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();
   // out: the part in its final order, tile after tile: long runs
