@@ -413,19 +413,33 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(int N, int T, int gri
 }
 
 // =====================================================================================================
-// GROUPED binning for tile grids beyond 25 600 tiles (T > BIN_GROUPED_MIN_T; e.g. 3840 x 2160 = 32 400 tiles), where the
-// direct counting sort above no longer fits: it keeps a cursor per tile and wave in LDS (T x 6 bytes with one wave).  Here
-// the same stable sort runs in TWO levels: (1) by GROUP of 8 horizontally adjacent tiles (cursor tables 8x smaller), writing
-// instance words  gaussian | tile-in-group << 29  into a scratch list (the checkpoint area, which the compositing only fills
-// later); (2) every group's contiguous segment — its tiles' lists back to back — is partitioned stably by the three tile
-// bits, in parts of BIN_PART instances (one workgroup each).  Order: groups by (row, column block) = ascending tile id
-// blocks; inside a group the level-1 order (depth) is kept by both levels: the same list as the direct sort, bit for bit
-// (tests/test_gpu_raster.py: 32 400 tiles against the oracle's key sort).
-// It is NOT faster where both fit (measured at 2 M Gaussians / 8160 tiles / 38.8 M instances: 66 + 30 + 301 + 71 + 329 us
-// against 73 + 20 + 642 us for the direct sort — profiles/round3_C5_grouped_binning_timeline.txt): what bounds either is the
-// 38.8 M scattered 4-byte stores in runs of a few dozen bytes at arbitrary offsets, not the LDS footprint the grouping
-// removes; and the second level's parts are latency chains (a dependent load per 512 instances).  So it only serves the
-// grids the direct sort cannot.
+// GROUPED (two-level) tile sort: for tile grids beyond 25 600 tiles (T > BIN_GROUPED_MIN_T; e.g. 3840 x 2160 = 32 400
+// tiles), where the direct counting sort above no longer fits (it keeps a cursor per tile and wave in LDS), and for many
+// Gaussians over many tiles (bin_grouped below), where it is the faster one.  The same stable sort in TWO levels:
+//   (1) by GROUP of 8 horizontally adjacent tiles — gbin_count (per chunk and wave: instances per group), bin_scan (over the
+//       chunks), gbin_scatter (the ordered walk) — writing instance words  gaussian | tile-in-group << 29  into a scratch
+//       list (the checkpoint area, which the compositing only fills later);
+//   (2) every group's contiguous segment — its tiles' lists back to back — is partitioned stably by the three tile bits, in
+//       parts of BIN_PART instances (one workgroup each): gbin_tcount (per part and tile), gbin_tscatter.
+// Order: groups by (row, column block) = ascending tile id blocks; inside a group the level-1 order (depth) is kept by both
+// levels: the same list as the direct sort, bit for bit (tests/test_gpu_raster.py: 32 400 tiles against the oracle's key
+// sort; tests/test_gpu_configs.py: C4 and C5 take this path; the whole raster suite also passes with RIGGS_BIN_GROUPED=1).
+// Why it pays at 2 M Gaussians / 8160 tiles / 38.8 M instances (0.40 ms against 0.70 ms): the direct sort's walk is 38.8 M
+// 4-byte stores to as many different lines; here level 1 writes a SPAN — a rectangle's columns inside one group, up to 32
+// bytes — with one to four stores, and level 2 moves whole parts through LDS with coalesced loads and stores.  What it took
+// (first version: 66 + 30 + 301 + 71 + 329 us, slower than the direct sort — profiles/round3_C5_grouped_binning_timeline.txt;
+// now 72 + 6 + 175 + 48 + 99 — profiles/round3_final_C5_graph_timeline.txt):
+//   * level 1 counted twice (per chunk in gbin_count, per wave in gbin_scatter: LDS atomics on a few hot groups, 27 - 45 us
+//     per workgroup): gbin_count counts per wave and hands the waves' starts over;
+//   * level 1's walk is bound by instruction issue, not by memory: lanes = spans instead of tiles, eight Gaussians per step,
+//     their order kept by letting the slots claim the group cursors one after the other instead of rectangle tests;
+//   * level 2 found its part by scanning all group counts in every workgroup (3.5 us, 5 700 times, twice): a part table
+//     written once by an extra workgroup of gbin_scatter; extra workgroups go FIRST in their grids (the last of 8 000
+//     workgroups starts when the kernel is almost over);
+//   * level 2 ranked 64 instances at a time with ballots and three barriers per 512: now a thread takes 16 consecutive
+//     instances with packed counters, and the part goes through LDS in and out; its registers were what bound it last (128:
+//     two workgroups per CU, phases of 3 - 5 us latency each that did not overlap; 50: four, 157 -> 99 us);
+//   * bin_scan over 977 chunks ran its slow path on 16 workgroups: <= 512 chunks (30 -> 6 us).
 // =====================================================================================================
 #define BIN_GROUPED_MIN_T 25600
 #define BIN_GROUPED_AUTO_T 4096
@@ -881,9 +895,9 @@ static BinPlan bin_plan(int N, int T) {
 }
 
 // which sort?  Beyond BIN_GROUPED_MIN_T tiles only the grouped one fits; below, it wins on many Gaussians over many tiles
-// (2 M / 8160 tiles: 0.50 ms against 0.70 ms; 500 k / 4096 tiles: level) and loses on the small scenes (300 k / 2500 tiles:
-// +0.04 ms — its five launches cost more than they save).
-// RIGGS_BIN_GROUPED=0 / 1 overrides the choice where both fit (measurements).
+// (2 M / 8160 tiles / 38.8 M instances: 0.40 ms against 0.70 ms; 500 k / 4096 tiles / 4.5 M instances: the frame 0.531
+// against 0.551 ms) and loses on the small scenes (300 k / 2500 tiles: +0.04 ms per frame, 150 k / 2500: +0.02 — its five
+// launches cost more than they save).  RIGGS_BIN_GROUPED=0 / 1 overrides the choice where both fit (measurements, tests).
 static bool bin_grouped(int N, int T) {
   if (T > BIN_GROUPED_MIN_T) return true;
   static int forced = -2;
