@@ -158,9 +158,12 @@ __device__ __forceinline__ uint64_t topk_mask(const Bone* bones, int B, int K, f
   return mask;
 }
 
+#define LBS_PTS2_MIN_N 1000000
+#define LBS_MAX_GRID 1280  // (five workgroups per CU)
+#define LBS_PTS2_MIN_J 16
 // FK: the workgroup runs the kinematic chain itself (fk_device.h: ~1 us on its first wave, against a launch of its own in front
 // of this one — every workgroup repeats it, workgroup 0 keeps the results)
-template <bool TOPK, bool FK>
+template <bool TOPK, bool FK, int PTS>
 __global__ __launch_bounds__(256) void lbs_forward_kernel(LbsArgs a) {
   __shared__ Bone bones[MAX_J - 1];
   if constexpr (FK) {
@@ -196,57 +199,92 @@ __global__ __launch_bounds__(256) void lbs_forward_kernel(LbsArgs a) {
   } else {
     stage_bones(a, bones);
   }
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= a.N) return;
+  // PTS Gaussians per thread (all-bones configuration): what bounds this loop at 64 joints is the LDS handing every wave the
+  // bone records (24 floats per bone, broadcast: 8 cycles of the CU's 128 B / clk return path per ds_read_b128 and wave,
+  // ~48 per bone and wave against ~26 VALU instructions per SIMD) — two Gaussians per lane read each record once for both
+  // (2 M x 63: 148 -> 133 us; the kernel is then bound by vector issue: ~32 instructions per Gaussian and bone, 16 of them
+  // the blend.  The blend on the matrix pipe instead — v_mfma_f32_16x16x4_f32, lane = (Gaussian i of a tile of 16, bone
+  // 4 s + j): the same k-ordered fmaf chain, 19 vector instructions per pair — measured 128 us: its four dependent-free MFMAs
+  // per step still cost the wave their issue, plus a transposing epilogue through LDS; not kept for 4 %).
+  static_assert(!TOPK || PTS == 1, "the top-K path takes one Gaussian per thread");
+  // (a grid-stride loop over the blocks of 256 * PTS Gaussians: the chain and the staging above cost a workgroup ~3 us at 64
+  // joints, as much as half of its work on one block — the launch is capped at what is resident at once)
   const int B = a.J - 1;
-  const float px = a.x[3 * n], py = a.x[3 * n + 1], pz = a.x[3 * n + 2];
-  const uint64_t selmask = TOPK ? topk_mask(bones, B, a.K, px, py, pz) : ~0ull;
-  float M[12], qa[4] = {0.f, 0.f, 0.f, 0.f}, sum = 0.f;
+  const int n_blocks = (a.N + 256 * PTS - 1) / (256 * PTS);
+  for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+  const int n0 = blk * (256 * PTS) + threadIdx.x;
+  if (n0 >= a.N) continue;
+  float px[PTS], py[PTS], pz[PTS];
+  bool on[PTS];
 #pragma unroll
-  for (int e = 0; e < 12; e++) M[e] = 0.f;
+  for (int p = 0; p < PTS; p++) {
+    const int n = n0 + 256 * p;
+    on[p] = n < a.N;
+    const int nn = on[p] ? n : n0;
+    px[p] = a.x[3 * nn]; py[p] = a.x[3 * nn + 1]; pz[p] = a.x[3 * nn + 2];
+  }
+  const uint64_t selmask = TOPK ? topk_mask(bones, B, a.K, px[0], py[0], pz[0]) : ~0ull;
+  float M[PTS][12], qa[PTS][4], sum[PTS];
+#pragma unroll
+  for (int p = 0; p < PTS; p++) {
+    sum[p] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 12; e++) M[p][e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; e++) qa[p][e] = 0.f;
+  }
   for (int k = 0; k < B; k++) {
     const Bone& b = bones[k];
     if (TOPK && !((selmask >> k) & 1ull)) continue;
-    const float d2 = TOPK ? bone_d2(b, px, py, pz) : bone_d2_fast(b, px, py, pz);
-    float u = fast_exp(-d2 * b.inv2r2);                // skeleton_warp.py:66
-    if (a.weight_mod) u *= a.weight_mod[(size_t)n * B + k];  // :68-69
-    const float v = u + 1e-7f;                          // :71
-    sum += v;
 #pragma unroll
-    for (int e = 0; e < 12; e++) M[e] += v * b.G[e];
+    for (int p = 0; p < PTS; p++) {
+      const float d2 = TOPK ? bone_d2(b, px[p], py[p], pz[p]) : bone_d2_fast(b, px[p], py[p], pz[p]);
+      float u = fast_exp(-d2 * b.inv2r2);                // skeleton_warp.py:66
+      if (a.weight_mod) u *= a.weight_mod[(size_t)(on[p] ? n0 + 256 * p : n0) * B + k];  // :68-69
+      const float v = u + 1e-7f;                          // :71
+      sum[p] += v;
 #pragma unroll
-    for (int e = 0; e < 4; e++) qa[e] += v * b.q[e];
+      for (int e = 0; e < 12; e++) M[p][e] += v * b.G[e];
+#pragma unroll
+      for (int e = 0; e < 4; e++) qa[p][e] += v * b.q[e];
+    }
   }
-  const float inv = 1.0f / sum;
-  const float m = a.motion_mask ? a.motion_mask[n] : 1.0f;
   const float gx = a.global_trans[0], gy = a.global_trans[1], gz = a.global_trans[2];
-  const float ax = (M[0] * px + M[1] * py + M[2] * pz + M[3]) * inv + gx;
-  const float ay = (M[4] * px + M[5] * py + M[6] * pz + M[7]) * inv + gy;
-  const float az = (M[8] * px + M[9] * py + M[10] * pz + M[11]) * inv + gz;
-  a.d_xyz[3 * n] = (ax - px) * m; a.d_xyz[3 * n + 1] = (ay - py) * m; a.d_xyz[3 * n + 2] = (az - pz) * m;
-  reinterpret_cast<float4*>(a.d_rot)[n] = make_float4(qa[0] * inv * m, qa[1] * inv * m, qa[2] * inv * m, qa[3] * inv * m);
-  if (a.nn_weight || a.nn_idx) {
-    if (TOPK) {
-      // ascending-d2 order like torch.topk(largest=False): K selection passes inside the mask
-      uint64_t left = selmask;
-      for (int s = 0; s < a.K; s++) {
-        float best = INFINITY; int bi = -1;
-        for (int k = 0; k < B; k++) {
-          if (!((left >> k) & 1ull)) continue;
-          const float d2 = bone_d2(bones[k], px, py, pz);
-          if (d2 < best || bi < 0) { best = d2; bi = k; }
+#pragma unroll
+  for (int p = 0; p < PTS; p++) {
+    if (!on[p]) continue;
+    const int n = n0 + 256 * p;
+    const float inv = 1.0f / sum[p];
+    const float m = a.motion_mask ? a.motion_mask[n] : 1.0f;
+    const float ax = (M[p][0] * px[p] + M[p][1] * py[p] + M[p][2] * pz[p] + M[p][3]) * inv + gx;
+    const float ay = (M[p][4] * px[p] + M[p][5] * py[p] + M[p][6] * pz[p] + M[p][7]) * inv + gy;
+    const float az = (M[p][8] * px[p] + M[p][9] * py[p] + M[p][10] * pz[p] + M[p][11]) * inv + gz;
+    a.d_xyz[3 * n] = (ax - px[p]) * m; a.d_xyz[3 * n + 1] = (ay - py[p]) * m; a.d_xyz[3 * n + 2] = (az - pz[p]) * m;
+    reinterpret_cast<float4*>(a.d_rot)[n] = make_float4(qa[p][0] * inv * m, qa[p][1] * inv * m, qa[p][2] * inv * m, qa[p][3] * inv * m);
+    if (a.nn_weight || a.nn_idx) {
+      if (TOPK) {
+        // ascending-d2 order like torch.topk(largest=False): K selection passes inside the mask
+        uint64_t left = selmask;
+        for (int s = 0; s < a.K; s++) {
+          float best = INFINITY; int bi = -1;
+          for (int k = 0; k < B; k++) {
+            if (!((left >> k) & 1ull)) continue;
+            const float d2 = bone_d2(bones[k], px[p], py[p], pz[p]);
+            if (d2 < best || bi < 0) { best = d2; bi = k; }
+          }
+          left &= ~(1ull << bi);
+          if (a.nn_weight) a.nn_weight[(size_t)n * a.K + s] = (fast_exp(-best * bones[bi].inv2r2) + 1e-7f) * inv;
+          if (a.nn_idx) a.nn_idx[(size_t)n * a.K + s] = bi + 1;
         }
-        left &= ~(1ull << bi);
-        if (a.nn_weight) a.nn_weight[(size_t)n * a.K + s] = (fast_exp(-best * bones[bi].inv2r2) + 1e-7f) * inv;
-        if (a.nn_idx) a.nn_idx[(size_t)n * a.K + s] = bi + 1;
-      }
-    } else {
-      for (int k = 0; k < B; k++) {
-        if (a.nn_weight) a.nn_weight[(size_t)n * B + k] = (fast_exp(-bone_d2_fast(bones[k], px, py, pz) * bones[k].inv2r2) *
-                                                              (a.weight_mod ? a.weight_mod[(size_t)n * B + k] : 1.0f) + 1e-7f) * inv;
-        if (a.nn_idx) a.nn_idx[(size_t)n * B + k] = k + 1;
+      } else {
+        for (int k = 0; k < B; k++) {
+          if (a.nn_weight) a.nn_weight[(size_t)n * B + k] = (fast_exp(-bone_d2_fast(bones[k], px[p], py[p], pz[p]) * bones[k].inv2r2) *
+                                                                (a.weight_mod ? a.weight_mod[(size_t)n * B + k] : 1.0f) + 1e-7f) * inv;
+          if (a.nn_idx) a.nn_idx[(size_t)n * B + k] = k + 1;
+        }
       }
     }
+  }
   }
 }
 
@@ -598,6 +636,20 @@ static int fill_lbs(LbsArgs& a, int32_t N, int32_t J, int32_t K, const float* x,
   return 0;
 }
 
+// two Gaussians per thread in the all-bones forward (see lbs_forward_kernel) where the launch still fills the chip
+static bool lbs_two_per_thread(int N, int J) {
+  static int forced = -2;
+  if (forced == -2) { const char* e = getenv("RIGGS_LBS_PTS2"); forced = (e && *e) ? atoi(e) : -1; }
+  if (forced >= 0) return forced != 0;
+  return N >= LBS_PTS2_MIN_N && J >= LBS_PTS2_MIN_J;
+}
+
+// workgroups of the forward: one per block of 256 * pts Gaussians, at most LBS_MAX_GRID (they loop)
+static unsigned lbs_grid(int N, int pts) {
+  const int blocks = (N + 256 * pts - 1) / (256 * pts);
+  return (unsigned)(blocks < LBS_MAX_GRID ? blocks : LBS_MAX_GRID);
+}
+
 int riggs_lbs_forward(int32_t N, int32_t J, int32_t K, const float* x, const float* joints, const int32_t* parents,
                       const float* node_radius_log, const float* transforms, const float* node_rot,
                       const float* global_trans, const float* motion_mask, const float* weight_mod, float* d_xyz,
@@ -611,8 +663,9 @@ int riggs_lbs_forward(int32_t N, int32_t J, int32_t K, const float* x, const flo
   if (N == 0) return 0;
   {
     ProfScope ps(PROF_LBS_FWD, (hipStream_t)stream);
-    if (a.K > 0) hipLaunchKernelGGL((lbs_forward_kernel<true, false>), dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((lbs_forward_kernel<false, false>), dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    if (a.K > 0) hipLaunchKernelGGL((lbs_forward_kernel<true, false, 1>), dim3(lbs_grid(N, 1)), dim3(256), 0, (hipStream_t)stream, a);
+    else if (lbs_two_per_thread(N, J)) hipLaunchKernelGGL((lbs_forward_kernel<false, false, 2>), dim3(lbs_grid(N, 2)), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((lbs_forward_kernel<false, false, 1>), dim3(lbs_grid(N, 1)), dim3(256), 0, (hipStream_t)stream, a);
   }
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
@@ -633,8 +686,9 @@ int riggs_lbs_forward_fk(int32_t N, int32_t J, int32_t K, const float* x, const 
   if (N == 0) return riggs_fk_forward(J, local_rot, joints, parents, global_trans, transforms, node_rot, d_nodes, stream);
   {
     ProfScope ps(PROF_LBS_FWD, (hipStream_t)stream);
-    if (a.K > 0) hipLaunchKernelGGL((lbs_forward_kernel<true, true>), dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((lbs_forward_kernel<false, true>), dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    if (a.K > 0) hipLaunchKernelGGL((lbs_forward_kernel<true, true, 1>), dim3(lbs_grid(N, 1)), dim3(256), 0, (hipStream_t)stream, a);
+    else if (lbs_two_per_thread(N, J)) hipLaunchKernelGGL((lbs_forward_kernel<false, true, 2>), dim3(lbs_grid(N, 2)), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((lbs_forward_kernel<false, true, 1>), dim3(lbs_grid(N, 1)), dim3(256), 0, (hipStream_t)stream, a);
   }
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
