@@ -1042,7 +1042,7 @@ __device__ __forceinline__ void rs_route(const RsBufs& b, int pass, bool three, 
 template <int CHUNK>
 __global__ __launch_bounds__(CHUNK / 8) void rs_count_kernel(int N, int pass, RsBufs bufs, uint32_t* __restrict__ table,
                                                              const uint32_t* __restrict__ part, int n_part,
-                                                             uint32_t* __restrict__ counters) {
+                                                             uint32_t* __restrict__ counters, uint32_t* __restrict__ arrivals) {
   constexpr int NT = CHUNK / 8, NW = NT / 64;  // (eight elements per thread)
   __shared__ uint32_t s_hist[RS_BINS];
   __shared__ uint32_t s_w[NW], s_lo[NW], s_hi[NW];
@@ -1068,6 +1068,7 @@ __global__ __launch_bounds__(CHUNK / 8) void rs_count_kernel(int N, int pass, Rs
     three = hi > lo;  // (no visible key at all: lo = 255 > hi = 0: two passes)
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
       counters[0] = total; counters[1] = 0u; counters[2] = three ? 1u : 0u; counters[3] = 0u;
+      arrivals[0] = 0u;
     }
   } else {
     three = counters[2] != 0u;
@@ -1096,107 +1097,20 @@ __global__ __launch_bounds__(1024) void rs_scan_kernel(int n_chunks, uint32_t* _
   bin_scan_body(RS_BINS, n_chunks, table, bin_count);
 }
 
-template <int CHUNK>
-__global__ __launch_bounds__(RS_SC_WAVES * 64) void rs_scatter_kernel(int N, int pass, RsBufs bufs,
-                                                                      const uint32_t* __restrict__ table /* exclusive over chunks */,
-                                                                      const uint32_t* __restrict__ bin_count,
-                                                                      const uint32_t* __restrict__ counters) {
-  __shared__ uint32_t s_start[RS_BINS];                      // global start of this chunk's segment in each bin
-  __shared__ unsigned short s_wave[RS_SC_WAVES][RS_BINS];    // per-wave counts -> per-wave running offsets
-  __shared__ uint32_t s_part[RS_SC_WAVES];
-  const bool three = counters[2] != 0u;
-  const uint32_t *ks, *vs; uint32_t *kd, *vd;
-  rs_route(bufs, pass, three, ks, vs, kd, vd);
-  const int shift = pass * RS_BITS;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int NT = RS_SC_WAVES * 64, PER = RS_BINS / NT;   // bins per thread in the scan
-  // every global load of the workgroup up front — its elements, its row of the chunk table, the bin totals — so that the
-  // scan and the two barriers below run under ONE round trip instead of in front of two more (the compiler keeps loads
-  // behind a barrier where it finds them)
-  constexpr int STEPS = CHUNK / NT;
-  const int wfirst = blockIdx.x * CHUNK + wave * (64 * STEPS);
-  uint32_t key[STEPS], val[STEPS];
-#pragma unroll
-  for (int st = 0; st < STEPS; st++) {
-    const int i = wfirst + st * 64 + lane;
-    key[st] = 0u; val[st] = 0u;
-    if (i < N) { key[st] = ks[i]; val[st] = vs ? vs[i] : (uint32_t)i; }
-  }
-  const uint32_t* row = table + (size_t)blockIdx.x * RS_BINS;
-  uint32_t rw[PER];
-#pragma unroll
-  for (int k = 0; k < PER; k++) rw[k] = row[tid * PER + k];
-  // exclusive scan of bin_count
-  uint32_t c[PER], tsum = 0;
-#pragma unroll
-  for (int k = 0; k < PER; k++) { c[k] = bin_count[tid * PER + k]; tsum += c[k]; }
-  uint32_t v = tsum;
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t u = (uint32_t)__shfl_up((int)v, o);
-    if (lane >= o) v += u;
-  }
-  if (lane == 63) s_part[wave] = v;
-  for (int e = tid; e < RS_SC_WAVES * RS_BINS / 2; e += NT) reinterpret_cast<uint32_t*>(&s_wave[0][0])[e] = 0u;
-  __syncthreads();
-  uint32_t run = v - tsum;
-  for (int w = 0; w < wave; w++) run += s_part[w];
-#pragma unroll
-  for (int k = 0; k < PER; k++) { s_start[tid * PER + k] = run + rw[k]; run += c[k]; }
-  // this wave's elements: STEPS steps of 64 consecutive elements
-  int dig[STEPS];
-#pragma unroll
-  for (int st = 0; st < STEPS; st++) {
-    const int i = wfirst + st * 64 + lane;
-    dig[st] = -1;
-    if (i < N) {
-      dig[st] = (int)((key[st] >> shift) & (RS_BINS - 1));
-      // 16-bit counters packed in pairs (a wave adds at most 64 x STEPS <= 1024 per bin, a chunk at most 8192)
-      atomicAdd(reinterpret_cast<uint32_t*>(&s_wave[wave][0]) + (dig[st] >> 1), 1u << (16 * (dig[st] & 1)));
-    }
-  }
-  __syncthreads();
-  // counts -> offsets of the waves inside the chunk's segment
-  for (int b = tid; b < RS_BINS; b += NT) {
-    unsigned short r = 0;
-#pragma unroll
-    for (int w = 0; w < RS_SC_WAVES; w++) { const unsigned short cw = s_wave[w][b]; s_wave[w][b] = r; r += cw; }
-  }
-  __syncthreads();
-  unsigned short* cur = s_wave[wave];
-#pragma unroll
-  for (int st = 0; st < STEPS; st++) {
-    const bool on = dig[st] >= 0;
-    // lanes with the same digit (match-any over the digit's bits)
-    uint64_t same = __builtin_amdgcn_ballot_w64(on);
-#pragma unroll
-    for (int b = 0; b < RS_BITS; b++) {
-      const uint64_t vote = __builtin_amdgcn_ballot_w64(on && ((dig[st] >> b) & 1));
-      same &= ((dig[st] >> b) & 1) ? vote : ~vote;
-    }
-    if (on) {
-      const uint64_t below = same & ((1ull << lane) - 1ull);
-      const uint32_t rank = (uint32_t)__builtin_popcountll(below);
-      const unsigned short base = cur[dig[st]];
-      const uint32_t pos = s_start[dig[st]] + base + rank;
-      kd[pos] = key[st]; vd[pos] = val[st];
-      if ((same >> lane) >> 1 == 0ull) cur[dig[st]] = base + (unsigned short)__builtin_popcountll(same);  // highest lane of the group
-    }
-  }
-}
-
-// The THIRD pass (top byte: 256 bins) as ONE launch: it runs only when the depths straddle a power-of-four boundary, and three
-// launches that leave at once cost 13.7 us of every frame against 4.5 us for one.  Its workgroups (one per chunk, all
-// resident: <= 147 at 300k keys) histogram their chunk, publish the 256 counts with write-through stores, meet at an in-launch
-// barrier (one arrival counter, bounded spin: the guide's recipe; counters[3], cleared by the first kernel of the sort) and then
-// each reads the whole 150 KB table — every other chunk's counts — to place its own elements.
+// The THIRD pass (top byte: 256 bins) INSIDE the second pass's scatter launch: it runs only when the depths straddle a
+// power-of-four boundary; as three launches that leave at once it cost 13.7 us of every frame, as one 4.8 us (a graph node's
+// floor), here a load of the flag.  When it does run: every workgroup of the scatter launch publishes its part of the second
+// pass (release fence: the other XCDs' L2s do not see plain stores before a kernel boundary) and arrives at a counter; the
+// first G of them — G = half of what is resident at once, so that the others always find a CU — wait for all arrivals
+// (bounded spin), invalidate their caches and run the pass: they histogram their chunks, publish the 256 counts with
+// write-through stores, meet at a second in-launch barrier (counters[3]; both counters cleared by the first kernel of the
+// sort) and then each reads the whole table — every other chunk's counts — to place its own elements.
 #define RS3_BINS 256
-#define RS3_MAX_WG 512  // upper bound of the third pass's grid (launch_depth_sort sizes it from the device's occupancy; each workgroup loops over its chunks)
+#define RS3_MAX_WG 512  // upper bound of the third pass's workgroups (launch_depth_sort takes half of what is resident; each loops over its chunks)
 typedef __attribute__((address_space(1))) uint32_t rs_gu32;
 template <int CHUNK>
-__global__ __launch_bounds__(RS_SC_WAVES * 64) void rs_third_pass_kernel(int N, int n_chunks, RsBufs bufs,
-                                                                         uint32_t* __restrict__ table3,
-                                                                         uint32_t* __restrict__ counters) {
-  if (counters[2] == 0u) return;  // two passes sufficed (the usual case)
+__device__ void rs_third_pass_body(int N, int n_chunks, const RsBufs& bufs, uint32_t* __restrict__ table3,
+                                   uint32_t* __restrict__ counters, const int G /* participating workgroups: blockIdx.x < G */) {
   __shared__ uint32_t s_hist[RS3_BINS];
   __shared__ uint32_t s_start[RS3_BINS];
   __shared__ unsigned short s_wave[RS_SC_WAVES][RS3_BINS];
@@ -1205,7 +1119,6 @@ __global__ __launch_bounds__(RS_SC_WAVES * 64) void rs_third_pass_kernel(int N, 
   uint32_t *kd = bufs.k_out, *vd = bufs.v_out;
   constexpr int NT = RS_SC_WAVES * 64, STEPS = CHUNK / NT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int G = (int)gridDim.x;
   // ---- phase A: the counts of this workgroup's chunks, published with write-through stores
   for (int chunk = blockIdx.x; chunk < n_chunks; chunk += G) {
     if (tid < RS3_BINS) s_hist[tid] = 0u;
@@ -1309,9 +1222,123 @@ __global__ __launch_bounds__(RS_SC_WAVES * 64) void rs_third_pass_kernel(int N, 
   }
 }
 
+template <int CHUNK>
+__global__ __launch_bounds__(RS_SC_WAVES * 64) void rs_scatter_kernel(int N, int pass, RsBufs bufs,
+                                                                      const uint32_t* __restrict__ table /* exclusive over chunks */,
+                                                                      const uint32_t* __restrict__ bin_count,
+                                                                      uint32_t* __restrict__ counters,
+                                                                      uint32_t* __restrict__ table3 /* = table, for the third pass */,
+                                                                      uint32_t* __restrict__ arrivals, int g3) {
+  __shared__ uint32_t s_start[RS_BINS];                      // global start of this chunk's segment in each bin
+  __shared__ unsigned short s_wave[RS_SC_WAVES][RS_BINS];    // per-wave counts -> per-wave running offsets
+  __shared__ uint32_t s_part[RS_SC_WAVES];
+  const bool three = counters[2] != 0u;
+  const uint32_t *ks, *vs; uint32_t *kd, *vd;
+  rs_route(bufs, pass, three, ks, vs, kd, vd);
+  const int shift = pass * RS_BITS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NT = RS_SC_WAVES * 64, PER = RS_BINS / NT;   // bins per thread in the scan
+  // every global load of the workgroup up front — its elements, its row of the chunk table, the bin totals — so that the
+  // scan and the two barriers below run under ONE round trip instead of in front of two more (the compiler keeps loads
+  // behind a barrier where it finds them)
+  constexpr int STEPS = CHUNK / NT;
+  const int wfirst = blockIdx.x * CHUNK + wave * (64 * STEPS);
+  uint32_t key[STEPS], val[STEPS];
+#pragma unroll
+  for (int st = 0; st < STEPS; st++) {
+    const int i = wfirst + st * 64 + lane;
+    key[st] = 0u; val[st] = 0u;
+    if (i < N) { key[st] = ks[i]; val[st] = vs ? vs[i] : (uint32_t)i; }
+  }
+  const uint32_t* row = table + (size_t)blockIdx.x * RS_BINS;
+  uint32_t rw[PER];
+#pragma unroll
+  for (int k = 0; k < PER; k++) rw[k] = row[tid * PER + k];
+  // exclusive scan of bin_count
+  uint32_t c[PER], tsum = 0;
+#pragma unroll
+  for (int k = 0; k < PER; k++) { c[k] = bin_count[tid * PER + k]; tsum += c[k]; }
+  uint32_t v = tsum;
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t u = (uint32_t)__shfl_up((int)v, o);
+    if (lane >= o) v += u;
+  }
+  if (lane == 63) s_part[wave] = v;
+  for (int e = tid; e < RS_SC_WAVES * RS_BINS / 2; e += NT) reinterpret_cast<uint32_t*>(&s_wave[0][0])[e] = 0u;
+  __syncthreads();
+  uint32_t run = v - tsum;
+  for (int w = 0; w < wave; w++) run += s_part[w];
+#pragma unroll
+  for (int k = 0; k < PER; k++) { s_start[tid * PER + k] = run + rw[k]; run += c[k]; }
+  // this wave's elements: STEPS steps of 64 consecutive elements
+  int dig[STEPS];
+#pragma unroll
+  for (int st = 0; st < STEPS; st++) {
+    const int i = wfirst + st * 64 + lane;
+    dig[st] = -1;
+    if (i < N) {
+      dig[st] = (int)((key[st] >> shift) & (RS_BINS - 1));
+      // 16-bit counters packed in pairs (a wave adds at most 64 x STEPS <= 1024 per bin, a chunk at most 8192)
+      atomicAdd(reinterpret_cast<uint32_t*>(&s_wave[wave][0]) + (dig[st] >> 1), 1u << (16 * (dig[st] & 1)));
+    }
+  }
+  __syncthreads();
+  // counts -> offsets of the waves inside the chunk's segment
+  for (int b = tid; b < RS_BINS; b += NT) {
+    unsigned short r = 0;
+#pragma unroll
+    for (int w = 0; w < RS_SC_WAVES; w++) { const unsigned short cw = s_wave[w][b]; s_wave[w][b] = r; r += cw; }
+  }
+  __syncthreads();
+  unsigned short* cur = s_wave[wave];
+#pragma unroll
+  for (int st = 0; st < STEPS; st++) {
+    const bool on = dig[st] >= 0;
+    // lanes with the same digit (match-any over the digit's bits)
+    uint64_t same = __builtin_amdgcn_ballot_w64(on);
+#pragma unroll
+    for (int b = 0; b < RS_BITS; b++) {
+      const uint64_t vote = __builtin_amdgcn_ballot_w64(on && ((dig[st] >> b) & 1));
+      same &= ((dig[st] >> b) & 1) ? vote : ~vote;
+    }
+    if (on) {
+      const uint64_t below = same & ((1ull << lane) - 1ull);
+      const uint32_t rank = (uint32_t)__builtin_popcountll(below);
+      const unsigned short base = cur[dig[st]];
+      const uint32_t pos = s_start[dig[st]] + base + rank;
+      kd[pos] = key[st]; vd[pos] = val[st];
+      if ((same >> lane) >> 1 == 0ull) cur[dig[st]] = base + (unsigned short)__builtin_popcountll(same);  // highest lane of the group
+    }
+  }
+  if (pass != 1 || !three) return;  // two passes sufficed (the usual case)
+  // ---- the third pass, inside this launch (see rs_third_pass_body)
+  __shared__ int s_late;
+  __atomic_thread_fence(__ATOMIC_RELEASE);  // (agent scope: this workgroup's part of the second pass reaches memory)
+  __syncthreads();
+  if (tid == 0) {
+    s_late = 0;
+    __hip_atomic_fetch_add((rs_gu32*)arrivals, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int)blockIdx.x < g3) {
+      uint32_t spins = 0;
+      while (__hip_atomic_load((rs_gu32*)arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1u << 22)) { s_late = 1; break; }
+      }
+    }
+  }
+  __syncthreads();
+  if ((int)blockIdx.x >= g3) return;
+  if (s_late) {  // flag the frame (bit 1 of counters[1]) instead of hanging: its ordering is undefined
+    if (tid == 0) atomicOr(counters + 1, 2u);
+    return;
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);  // (agent scope: drop what this XCD's caches hold of the second pass's output)
+  rs_third_pass_body<CHUNK>(N, (int)gridDim.x, bufs, table3, counters, g3);
+}
+
 size_t depth_sort_table_bytes(int N) {
   const size_t n = (size_t)(N > 0 ? N : 1), chunks = (n + RS_CHUNK - 1) / RS_CHUNK;
-  return align_up((chunks + 1) * RS_BINS * 4) + align_up(RS_BINS * 4) + 2 * align_up(n * 4);  // table, bin counts, scratch pair
+  return align_up((chunks + 1) * RS_BINS * 4) + align_up(RS_BINS * 4) + 2 * align_up(n * 4) + 256;  // table, bin counts, scratch pair, arrival counter
 }
 
 // the result ends in (keys_out, vals_out); keys_in is left intact; values are the element indices
@@ -1328,20 +1355,14 @@ static int launch_depth_sort_t(int N, const uint32_t* keys_in, uint32_t* keys_ou
   b.k_tmp = (uint32_t*)((char*)bin_count + align_up(RS_BINS * 4));
   b.v_tmp = (uint32_t*)((char*)b.k_tmp + align_up((size_t)(N > 0 ? N : 1) * 4));
   b.k_out = keys_out; b.v_out = vals_out;
-  for (int pass = 0; pass < 2; pass++) {
-    hipLaunchKernelGGL(rs_count_kernel<CHUNK>, dim3(chunks), dim3(CHUNK / 8), 0, s, N, pass, b, table, block_info, (N + 255) / 256, counters);
-    hipLaunchKernelGGL(rs_scan_kernel, dim3((RS_BINS + 63) / 64), dim3(1024), 0, s, chunks, table, bin_count, counters, pass);
-    hipLaunchKernelGGL(rs_scatter_kernel<CHUNK>, dim3(chunks), dim3(RS_SC_WAVES * 64), 0, s, N, pass, b, table, bin_count, counters);
-  }
-  // (the table of the 12-bit passes is free again: chunks x 256 counts fit into it)
-  // The in-launch barrier of the third pass needs every workgroup RESIDENT at once: size the grid from what the device can
-  // hold of this kernel (occupancy x compute units), and only HALF of it — kernels of other streams (the RCCL collectives of
-  // the overlapped exchanges) may occupy compute units at the same time.  Each workgroup loops over its chunks, so any grid
-  // size is correct; a workgroup that still does not become resident ends the bounded spin and flags the frame.
+  // The third pass (inside the second scatter launch) has in-launch barriers: its G workgroups must be RESIDENT at once — half
+  // of what the device holds of the scatter kernel (occupancy x compute units), so that the launch's other workgroups, and
+  // kernels of other streams (the RCCL collectives of the overlapped exchanges), find compute units.  Each of the G loops over
+  // its chunks, so any G is correct; a workgroup that still does not become resident ends the bounded spin and flags the frame.
   static int rs3_grid = 0;
   if (rs3_grid == 0) {
     int per_cu = 0, dev = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(rs_third_pass_kernel<CHUNK>), RS_SC_WAVES * 64, 0) != hipSuccess ||
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(rs_scatter_kernel<CHUNK>), RS_SC_WAVES * 64, 0) != hipSuccess ||
         hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
       per_cu = 1; cus = 64; (void)hipGetLastError();
     }
@@ -1349,8 +1370,15 @@ static int launch_depth_sort_t(int N, const uint32_t* keys_in, uint32_t* keys_ou
     rs3_grid = resident / 2 > 0 ? resident / 2 : 1;
     if (rs3_grid > RS3_MAX_WG) rs3_grid = RS3_MAX_WG;
   }
-  hipLaunchKernelGGL(rs_third_pass_kernel<CHUNK>, dim3(chunks < rs3_grid ? chunks : rs3_grid), dim3(RS_SC_WAVES * 64), 0, s, N, chunks,
-                     b, table, counters);
+  uint32_t* arrivals = (uint32_t*)((char*)b.v_tmp + align_up((size_t)(N > 0 ? N : 1) * 4));
+  for (int pass = 0; pass < 2; pass++) {
+    hipLaunchKernelGGL(rs_count_kernel<CHUNK>, dim3(chunks), dim3(CHUNK / 8), 0, s, N, pass, b, table, block_info, (N + 255) / 256, counters,
+                       arrivals);
+    hipLaunchKernelGGL(rs_scan_kernel, dim3((RS_BINS + 63) / 64), dim3(1024), 0, s, chunks, table, bin_count, counters, pass);
+    // (the table of the 12-bit passes is free again when the third pass starts: chunks x 256 counts fit into it)
+    hipLaunchKernelGGL(rs_scatter_kernel<CHUNK>, dim3(chunks), dim3(RS_SC_WAVES * 64), 0, s, N, pass, b, table, bin_count, counters,
+                       table, arrivals, chunks < rs3_grid ? chunks : rs3_grid);
+  }
   return 0;
 }
 
