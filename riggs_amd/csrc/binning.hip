@@ -1007,8 +1007,8 @@ int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order,
 // The top byte of a positive float is its sign and the upper seven exponent bits: it is the same for every depth of a
 // scene that lies inside one of the ranges [2, 8), [0.5, 2), [8, 32), ... (a D-NeRF / ZJU camera looks at its subject
 // from 2 - 6 units).  preprocess_fwd records the top bytes it saw; the first kernel folds them into counters[2] =
-// "third pass needed", and the third pass — ONE launch with an in-launch barrier — leaves at once when it is not: two
-// passes (six short launches + one empty one) instead of three 11-bit passes (nine).  The result always ends in (keys_out, vals_out): the
+// "third pass needed", and the third pass — inside the second pass's scatter launch, behind in-launch barriers — is a load
+// of that flag when it is not: two passes (six short launches) instead of three 11-bit passes (nine).  The result always ends in (keys_out, vals_out): the
 // first two passes go through a scratch pair or through the output pair depending on the flag.
 // rocPRIM picks a block sort + ~9 merge passes (18 launches, 0.12 ms) at N = 3e5 and Onesweep's chained
 // look-back costs the same at this size.
