@@ -159,7 +159,6 @@ __device__ __forceinline__ uint64_t topk_mask(const Bone* bones, int B, int K, f
 }
 
 #define LBS_PTS2_MIN_N 1000000
-#define LBS_MAX_GRID 1280  // (five workgroups per CU)
 #define LBS_PTS2_MIN_J 16
 // FK: the workgroup runs the kinematic chain itself (fk_device.h: ~1 us on its first wave, against a launch of its own in front
 // of this one — every workgroup repeats it, workgroup 0 keeps the results)
@@ -207,13 +206,11 @@ __global__ __launch_bounds__(256) void lbs_forward_kernel(LbsArgs a) {
   // 4 s + j): the same k-ordered fmaf chain, 19 vector instructions per pair — measured 128 us: its four dependent-free MFMAs
   // per step still cost the wave their issue, plus a transposing epilogue through LDS; not kept for 4 %).
   static_assert(!TOPK || PTS == 1, "the top-K path takes one Gaussian per thread");
-  // (a grid-stride loop over the blocks of 256 * PTS Gaussians: the chain and the staging above cost a workgroup ~3 us at 64
-  // joints, as much as half of its work on one block — the launch is capped at what is resident at once)
+  // (one block of 256 * PTS Gaussians per workgroup: fewer, looping workgroups — the chain and the staging above once per
+  // workgroup instead of once per block — are slower: 17.5 -> 19.7 -> 24.6 us at 1172 / 586 / 293 workgroups)
   const int B = a.J - 1;
-  const int n_blocks = (a.N + 256 * PTS - 1) / (256 * PTS);
-  for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
-  const int n0 = blk * (256 * PTS) + threadIdx.x;
-  if (n0 >= a.N) continue;
+  const int n0 = blockIdx.x * (256 * PTS) + threadIdx.x;
+  if (n0 >= a.N) return;
   float px[PTS], py[PTS], pz[PTS];
   bool on[PTS];
 #pragma unroll
@@ -284,7 +281,6 @@ __global__ __launch_bounds__(256) void lbs_forward_kernel(LbsArgs a) {
         }
       }
     }
-  }
   }
 }
 
@@ -644,11 +640,7 @@ static bool lbs_two_per_thread(int N, int J) {
   return N >= LBS_PTS2_MIN_N && J >= LBS_PTS2_MIN_J;
 }
 
-// workgroups of the forward: one per block of 256 * pts Gaussians, at most LBS_MAX_GRID (they loop)
-static unsigned lbs_grid(int N, int pts) {
-  const int blocks = (N + 256 * pts - 1) / (256 * pts);
-  return (unsigned)(blocks < LBS_MAX_GRID ? blocks : LBS_MAX_GRID);
-}
+static unsigned lbs_grid(int N, int pts) { return (unsigned)((N + 256 * pts - 1) / (256 * pts)); }
 
 int riggs_lbs_forward(int32_t N, int32_t J, int32_t K, const float* x, const float* joints, const int32_t* parents,
                       const float* node_radius_log, const float* transforms, const float* node_rot,
