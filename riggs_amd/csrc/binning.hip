@@ -508,7 +508,7 @@ __global__ __launch_bounds__(1024) void gbin_count_kernel(int N, int T, int G, i
 
 __device__ void gbin_parts_body(int G, int64_t cap, uint32_t n_parts, const uint32_t* __restrict__ group_count, uint4* __restrict__ part_tab);
 
-// (1b) ordered scatter into the groups' segments.  LDS: s_base[G] + per-wave cursors [W][Gpad] (u16)
+// (1b) ordered scatter into the groups' segments.  LDS: s_base[G] + per-wave cursors [W][G] (u32)
 __global__ __launch_bounds__(1024) void gbin_scatter_kernel(int N, int G, int gxg, int64_t cap, int g_per_block, int g_per_wave,
                                                            const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles,
                                                            const ushort4* __restrict__ rect, const uint32_t* __restrict__ table,
@@ -522,16 +522,10 @@ __global__ __launch_bounds__(1024) void gbin_scatter_kernel(int N, int G, int gx
   const int chunk = (int)blockIdx.x - 1;
   extern __shared__ uint32_t s_mem[];
   const int W = blockDim.x >> 6;
-  uint32_t* s_base = s_mem;
+  uint32_t* s_base = s_mem;         // [G]     start of this chunk's run in every group's segment
+  uint32_t* s_cur = s_mem + G;      // [W][G]  the waves' cursors: ABSOLUTE places in the scratch list
   const int Gpad = (G + 1) & ~1;
-  unsigned short* s_rel = reinterpret_cast<unsigned short*>(s_mem + G);
-  uint32_t* s_rel32 = s_mem + G;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // (i) the waves' starts inside the chunk's run of every group (counted by gbin_count_kernel)
-  {
-    const uint32_t* ws = wave_start + (size_t)chunk * W * (Gpad >> 1);
-    for (int e = tid; e < W * (Gpad >> 1); e += blockDim.x) s_rel32[e] = ws[e];
-  }
   const int first = chunk * g_per_block + wave * g_per_wave;
   const int end = min(N, min(first + g_per_wave, (chunk + 1) * g_per_block));
   // (ii) start of this chunk's run in every group's segment: exclusive scan of the group counts + the earlier chunks
@@ -559,17 +553,26 @@ __global__ __launch_bounds__(1024) void gbin_scatter_kernel(int N, int G, int gx
       __syncthreads();
     }
   }
+  // (i) cursor of wave w in group g = the chunk's start + the wave's start inside the chunk's run (counted by gbin_count_kernel)
+  {
+    const unsigned short* ws = reinterpret_cast<const unsigned short*>(wave_start + (size_t)chunk * W * (Gpad >> 1));
+    for (int w = 0; w < W; w++)
+      for (int g = tid; g < G; g += blockDim.x) s_cur[(size_t)w * G + g] = s_base[g] + ws[(size_t)w * Gpad + g];
+  }
   __syncthreads();
   // (iii) ordered walk.  The unit is a SPAN: the columns of a Gaussian's rectangle that fall into one group, in one tile
   // row — up to eight instances that go to consecutive places of the group's segment.  Lane = (slot, span): eight Gaussians
   // share a step when each has at most 8 spans (a 5 x 4 rectangle has 4 - 8), four with at most 16; a larger one takes a
-  // step of its own (lanes = its spans).  The slots CLAIM their places one after the other — slot j's lanes read the group
-  // cursors and advance them by their span lengths, then slot j + 1's: the LDS keeps a wave's operations in order, so the
-  // instances of a group land in the Gaussians' order whatever overlaps whatever, without a rectangle test (the version
-  // with lane = tile and geometric tests of the earlier slots: 75 instructions per step of two Gaussians; the walk is bound
-  // by instruction issue).  A span is then written with up to four stores (4 + 4, 4 + 2 + 1, ... dwords; the places are
-  // only dword-aligned, which global stores of any width accept).
-  unsigned short* cur = s_rel + (size_t)wave * Gpad;
+  // step of its own (lanes = its spans).  The slots CLAIM their places one after the other — slot j's lanes advance the
+  // group cursors by their span lengths with ONE LDS atomic that returns the old value, then slot j + 1's: the LDS keeps
+  // a wave's operations in order, so the instances of a group land in the Gaussians' order whatever overlaps whatever,
+  // without a rectangle test, and the eight atomics of a step are in flight together (inside a slot no two spans share a
+  // group, so their order does not matter).  History: lane = tile with geometric tests of the earlier slots, 75
+  // instructions per step of two Gaussians, bound by instruction issue: 208 us; span lanes with a read and a write of a
+  // 16-bit cursor per slot — 22 LDS instructions per step, each waiting for the one before: 175 us, bound by the LDS.
+  // A span is then written with up to four stores (4 + 4, 4 + 2 + 1, ... dwords; the places are only dword-aligned, which
+  // global stores of any width accept).
+  uint32_t* cur = s_cur + (size_t)wave * G;
   auto put_span = [&](const int64_t pos, const uint32_t g, const int span0, const int L) {
     const uint32_t v0 = g | ((uint32_t)(span0 & 7) << 29);  // (a span stays inside its group: no wrap of the three tile bits)
     if (pos + L <= cap) {
@@ -612,15 +615,17 @@ __global__ __launch_bounds__(1024) void gbin_scatter_kernel(int N, int G, int gx
       const int col = gc0 + (l - row * ncol), y = ry0 + row;
       const int span0 = max(rx0, col << 3), L = min(rx1, (col << 3) + 8) - span0;
       const int gi = valid ? y * gxg + col : 0;
-      uint32_t rel = 0u;
+      // (a result register per slot, OR-ed afterwards: into one register the compiler waits for every atomic before the next)
+      uint32_t got[SLOTS];
 #pragma unroll
-      for (int jj = 0; jj < SLOTS; jj++) {
-        if (valid && slot == jj) {
-          rel = cur[gi];
-          cur[gi] = (unsigned short)(rel + (uint32_t)L);
-        }
-      }
-      if (valid) put_span((int64_t)s_base[gi] + rel, g, span0, L);
+      for (int jj = 0; jj < SLOTS; jj++) got[jj] = 0u;
+#pragma unroll
+      for (int jj = 0; jj < SLOTS; jj++)
+        if (valid && slot == jj) got[jj] = atomicAdd(&cur[gi], (uint32_t)L);
+      uint32_t pos = 0u;
+#pragma unroll
+      for (int jj = 0; jj < SLOTS; jj++) pos |= got[jj];
+      if (valid) put_span((int64_t)pos, g, span0, L);
     };
 #pragma unroll 1
     for (int q = 0; q < 8; q++) {  // (not unrolled: the three kinds of step, eight times over, would not fit the instruction cache)
@@ -647,9 +652,7 @@ __global__ __launch_bounds__(1024) void gbin_scatter_kernel(int N, int G, int gx
             const int col = gc0 + (l - row * ncol), y = ry0 + row;
             const int span0 = max(rx0, col << 3), L = min(rx1, (col << 3) + 8) - span0;
             const int gi = y * gxg + col;
-            const uint32_t rel = cur[gi];
-            cur[gi] = (unsigned short)(rel + (uint32_t)L);
-            put_span((int64_t)s_base[gi] + rel, g, span0, L);
+            put_span((int64_t)atomicAdd(&cur[gi], (uint32_t)L), g, span0, L);
           }
         }
       }
@@ -908,23 +911,29 @@ static bool bin_grouped(int N, int T) {
   if (forced >= 0) return forced != 0 && T >= 64;
   return T >= BIN_GROUPED_AUTO_T && N >= BIN_GROUPED_AUTO_N;
 }
-struct GBinPlan { int G, gxg, g_per_block, g_per_wave, n_chunks; size_t lds; };
+struct GBinPlan { int G, gxg, W, g_per_block, g_per_wave, n_chunks; size_t lds; };
 static GBinPlan gbin_plan(int N, int T, int grid_x) {
   GBinPlan p;
   p.gxg = (grid_x + 7) >> 3;
   const int grid_y = grid_x > 0 ? (T + grid_x - 1) / grid_x : 0;
   p.G = p.gxg * grid_y;
-  const int W = 16;
+  // waves per workgroup: sixteen, fewer where their 32-bit cursors (G x 4 bytes per wave, next to the G x 4 of the chunk's
+  // starts) would not fit the LDS (3840 x 2160: 4050 groups, 8 waves)
+  int W = 16;
+  while (W > 1 && (size_t)p.G * 4 + (size_t)W * p.G * 4 > 150 * 1024) W >>= 1;
+  p.W = W;
   // batches of 64 Gaussians per wave so that a launch has <= ~512 chunks (one round of the scatter kernel's workgroups; the
   // chunk x group table and every workgroup's O(G) set-up stay small; bin_scan keeps a column segment in registers up to
-  // 16 x 32 chunks) — and at most 7: a Gaussian adds up to 8 instances to a group, and the waves' starts inside a chunk's
-  // run are 16-bit (16 waves x 7 x 64 x 8 = 57 344)
+  // 16 x 32 chunks) — and so few that a chunk's run in a group stays below 65 536 instances: a Gaussian adds up to 8
+  // instances to a group, and the waves' starts inside a chunk's run are handed over as 16-bit (16 waves: 7 batches,
+  // 16 x 7 x 64 x 8 = 57 344)
   int batches = (int)(((int64_t)N + (int64_t)W * 64 * 512 - 1) / ((int64_t)W * 64 * 512));
-  batches = batches < 1 ? 1 : (batches > 7 ? 7 : batches);
+  const int max_batches = 65535 / (W * 64 * 8);
+  batches = batches < 1 ? 1 : (batches > max_batches ? max_batches : batches);
   p.g_per_wave = 64 * batches;
   p.g_per_block = W * p.g_per_wave;
   p.n_chunks = (N + p.g_per_block - 1) / p.g_per_block;
-  p.lds = (size_t)p.G * 4 + (size_t)W * ((p.G + 1) & ~1) * 2;
+  p.lds = (size_t)p.G * 4 + (size_t)W * p.G * 4;
   return p;
 }
 
@@ -932,7 +941,7 @@ size_t bin_table_bytes(int N, int T, int grid_x) {
   if (bin_grouped(N, T)) {
     GBinPlan p = gbin_plan(N > 0 ? N : 1, T, grid_x);
     return align_up(((size_t)p.n_chunks + 1) * p.G * 4) + align_up((size_t)(p.G + 1) * 4) + align_up((size_t)(T + 1) * 4) +
-           align_up((size_t)p.n_chunks * 16 * ((p.G + 1) & ~1) * 2);
+           align_up((size_t)p.n_chunks * p.W * ((p.G + 1) & ~1) * 2);
   }
   BinPlan p = bin_plan(N > 0 ? N : 1, T);
   return align_up(((size_t)p.n_chunks + 1) * T * 4) + align_up((size_t)(T + 1) * 4);
@@ -968,11 +977,11 @@ int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order,
     uint32_t* part_hist = (uint32_t*)((char*)scratch + align_up((size_t)(cap > 0 ? cap : 1) * 4));
     const unsigned n_parts = (unsigned)((cap > 0 ? cap : 1) / BIN_PART + p.G + 1);
     uint4* part_tab = (uint4*)((char*)part_hist + align_up(((size_t)(cap > 0 ? cap : 1) / BIN_PART + (size_t)p.G + 2) * 8 * 4));
-    hipLaunchKernelGGL(gbin_count_kernel, dim3(p.n_chunks), dim3(1024), p.lds - (size_t)p.G * 4, s, N, T, p.G, p.gxg, p.g_per_block,
-                       p.g_per_wave, order, tiles, rect, table, wave_start, tile_count);
+    hipLaunchKernelGGL(gbin_count_kernel, dim3(p.n_chunks), dim3(p.W * 64), (size_t)p.W * ((p.G + 1) & ~1) * 2, s, N, T, p.G, p.gxg,
+                       p.g_per_block, p.g_per_wave, order, tiles, rect, table, wave_start, tile_count);
     hipLaunchKernelGGL(bin_scan_kernel, dim3((p.G + 63) / 64), dim3(1024), 0, s, p.G, p.n_chunks, table, group_count);
     // (+ 1: the extra workgroup that lists the second level's parts)
-    hipLaunchKernelGGL(gbin_scatter_kernel, dim3(p.n_chunks + 1), dim3(1024), p.lds, s, N, p.G, p.gxg, cap, p.g_per_block, p.g_per_wave,
+    hipLaunchKernelGGL(gbin_scatter_kernel, dim3(p.n_chunks + 1), dim3(p.W * 64), p.lds, s, N, p.G, p.gxg, cap, p.g_per_block, p.g_per_wave,
                        order, tiles, rect, table, wave_start, group_count, inter, part_tab, n_parts);
     hipLaunchKernelGGL(gbin_tcount_kernel, dim3(n_parts), dim3(512), 0, s, p.gxg, grid_x, part_tab, inter, part_hist, tile_count);
     // (+ 1: the extra workgroup that writes the ranges, the counters and the forward's work list)
