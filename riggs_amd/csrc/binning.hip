@@ -32,6 +32,7 @@ __global__ __launch_bounds__(1024) void bin_count_kernel(int N, int T, int grid_
                                                         const uint32_t* __restrict__ order,
                                                         const uint32_t* __restrict__ tiles,
                                                         const ushort4* __restrict__ rect,
+                                                        ushort4* __restrict__ srect /* [N]: the rectangles in depth order (empty if invisible) */,
                                                         uint32_t* __restrict__ table) {
   extern __shared__ uint32_t s_hist[];  // [T]
   for (int t = threadIdx.x; t < T; t += blockDim.x) s_hist[t] = 0u;
@@ -41,8 +42,11 @@ __global__ __launch_bounds__(1024) void bin_count_kernel(int N, int T, int grid_
   for (int s = first + threadIdx.x; s < end; s += blockDim.x) {
     const uint32_t g = order[s];
     const int n = (int)tiles[g];
+    // (the one gather of the rectangles by depth order — a 64-byte line per Gaussian for 8 bytes; the scatter kernel reads
+    // this sorted copy, coalesced)
+    const ushort4 rc = n ? rect[g] : make_ushort4(0, 0, 0, 0);
+    srect[s] = rc;
     if (n == 0) continue;
-    const ushort4 rc = rect[g];
     for (int y = rc.y; y < rc.w; y++)
       for (int x = rc.x; x < rc.z; x++) atomicAdd(&s_hist[y * grid_x + x], 1u);
   }
@@ -223,8 +227,7 @@ __device__ void bin_offsets_body(int T, int64_t cap, const uint32_t* __restrict_
 // s_rel[W][T] (u16 offsets of each wave's sub-segment, then used as that wave's running cursor).
 __global__ __launch_bounds__(1024) void bin_scatter_kernel(int N, int T, int grid_x, int64_t cap, int g_per_block, int g_per_wave,
                                                           const uint32_t* __restrict__ order,
-                                                          const uint32_t* __restrict__ tiles,
-                                                          const ushort4* __restrict__ rect,
+                                                          const ushort4* __restrict__ srect /* rectangles in depth order (bin_count_kernel) */,
                                                           const uint32_t* __restrict__ table,
                                                           const uint32_t* __restrict__ tile_count,
                                                           uint32_t* __restrict__ point_list,
@@ -252,8 +255,8 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(int N, int T, int gri
     g = 0u; n = 0u; rc = make_ushort4(0, 0, 0, 0);
     if (s < end) {
       g = order[s];
-      n = tiles[g];
-      if (n) rc = rect[g];
+      rc = srect[s];
+      n = (uint32_t)((int)(rc.z - rc.x) * (int)(rc.w - rc.y));
     }
   };
   // (i) per-wave tile histogram (16-bit counters packed in pairs; a wave adds at most g_per_wave <= 1024 per tile)
@@ -463,7 +466,8 @@ struct __attribute__((packed, aligned(4))) GU2 { uint32_t a, b; };
 // same instruction, and the LDS serialises equal addresses.)
 __global__ __launch_bounds__(1024) void gbin_count_kernel(int N, int T, int G, int gxg, int g_per_block, int g_per_wave,
                                                          const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles,
-                                                         const ushort4* __restrict__ rect, uint32_t* __restrict__ table,
+                                                         const ushort4* __restrict__ rect, ushort4* __restrict__ srect,
+                                                         uint32_t* __restrict__ table,
                                                          uint32_t* __restrict__ wave_start, uint32_t* __restrict__ tile_count) {
   extern __shared__ uint32_t s_rel32[];
   const int W = blockDim.x >> 6;
@@ -480,8 +484,9 @@ __global__ __launch_bounds__(1024) void gbin_count_kernel(int N, int T, int G, i
     const int s = s0 + lane;
     if (s < end) {
       const uint32_t g = order[s];
-      if (tiles[g]) {
-        const ushort4 rc = rect[g];
+      const ushort4 rc = tiles[g] ? rect[g] : make_ushort4(0, 0, 0, 0);
+      srect[s] = rc;  // (the rectangles in depth order: see bin_count_kernel)
+      if (rc.z > rc.x) {
         for (int y = rc.y; y < rc.w; y++)
           for (int xg = rc.x >> 3; xg <= (rc.z - 1) >> 3; xg++) {
             const int gi = y * gxg + xg;
@@ -510,8 +515,8 @@ __device__ void gbin_parts_body(int G, int64_t cap, uint32_t n_parts, const uint
 
 // (1b) ordered scatter into the groups' segments.  LDS: s_base[G] + per-wave cursors [W][G] (u32)
 __global__ __launch_bounds__(1024) void gbin_scatter_kernel(int N, int G, int gxg, int64_t cap, int g_per_block, int g_per_wave,
-                                                           const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles,
-                                                           const ushort4* __restrict__ rect, const uint32_t* __restrict__ table,
+                                                           const uint32_t* __restrict__ order, const ushort4* __restrict__ srect,
+                                                           const uint32_t* __restrict__ table,
                                                            const uint32_t* __restrict__ wave_start,
                                                            const uint32_t* __restrict__ group_count, uint32_t* __restrict__ inter,
                                                            uint4* __restrict__ part_tab, uint32_t n_parts) {
@@ -593,8 +598,8 @@ __global__ __launch_bounds__(1024) void gbin_scatter_kernel(int N, int G, int gx
     int pk_xy = 0, pk_zw = 0, my_ns = 0;
     if (s < end) {
       my_g = order[s];
-      if (tiles[my_g]) {
-        const ushort4 rc = rect[my_g];
+      const ushort4 rc = srect[s];
+      if (rc.z > rc.x) {
         pk_xy = (int)rc.x | ((int)rc.y << 16); pk_zw = (int)rc.z | ((int)rc.w << 16);
         my_ns = ((int)rc.w - (int)rc.y) * ((((int)rc.z - 1) >> 3) - ((int)rc.x >> 3) + 1);
       }
@@ -941,10 +946,10 @@ size_t bin_table_bytes(int N, int T, int grid_x) {
   if (bin_grouped(N, T)) {
     GBinPlan p = gbin_plan(N > 0 ? N : 1, T, grid_x);
     return align_up(((size_t)p.n_chunks + 1) * p.G * 4) + align_up((size_t)(p.G + 1) * 4) + align_up((size_t)(T + 1) * 4) +
-           align_up((size_t)p.n_chunks * p.W * ((p.G + 1) & ~1) * 2);
+           align_up((size_t)p.n_chunks * p.W * ((p.G + 1) & ~1) * 2) + align_up((size_t)(N > 0 ? N : 1) * 8);
   }
   BinPlan p = bin_plan(N > 0 ? N : 1, T);
-  return align_up(((size_t)p.n_chunks + 1) * T * 4) + align_up((size_t)(T + 1) * 4);
+  return align_up(((size_t)p.n_chunks + 1) * T * 4) + align_up((size_t)(T + 1) * 4) + align_up((size_t)(N > 0 ? N : 1) * 8);
 }
 size_t bin_scratch_bytes(int64_t cap, int T, int grid_x) {  // (grouped binning: lives in the checkpoint area)
   GBinPlan p = gbin_plan(1, T, grid_x);
@@ -973,16 +978,17 @@ int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order,
     uint32_t* group_count = (uint32_t*)(mem + align_up(((size_t)p.n_chunks + 1) * p.G * 4));
     uint32_t* tile_count = (uint32_t*)((char*)group_count + align_up((size_t)(p.G + 1) * 4));
     uint32_t* wave_start = (uint32_t*)((char*)tile_count + align_up((size_t)(T + 1) * 4));
+    ushort4* srect = (ushort4*)((char*)wave_start + align_up((size_t)p.n_chunks * p.W * ((p.G + 1) & ~1) * 2));
     uint32_t* inter = (uint32_t*)scratch;
     uint32_t* part_hist = (uint32_t*)((char*)scratch + align_up((size_t)(cap > 0 ? cap : 1) * 4));
     const unsigned n_parts = (unsigned)((cap > 0 ? cap : 1) / BIN_PART + p.G + 1);
     uint4* part_tab = (uint4*)((char*)part_hist + align_up(((size_t)(cap > 0 ? cap : 1) / BIN_PART + (size_t)p.G + 2) * 8 * 4));
     hipLaunchKernelGGL(gbin_count_kernel, dim3(p.n_chunks), dim3(p.W * 64), (size_t)p.W * ((p.G + 1) & ~1) * 2, s, N, T, p.G, p.gxg,
-                       p.g_per_block, p.g_per_wave, order, tiles, rect, table, wave_start, tile_count);
+                       p.g_per_block, p.g_per_wave, order, tiles, rect, srect, table, wave_start, tile_count);
     hipLaunchKernelGGL(bin_scan_kernel, dim3((p.G + 63) / 64), dim3(1024), 0, s, p.G, p.n_chunks, table, group_count);
     // (+ 1: the extra workgroup that lists the second level's parts)
     hipLaunchKernelGGL(gbin_scatter_kernel, dim3(p.n_chunks + 1), dim3(p.W * 64), p.lds, s, N, p.G, p.gxg, cap, p.g_per_block, p.g_per_wave,
-                       order, tiles, rect, table, wave_start, group_count, inter, part_tab, n_parts);
+                       order, srect, table, wave_start, group_count, inter, part_tab, n_parts);
     hipLaunchKernelGGL(gbin_tcount_kernel, dim3(n_parts), dim3(512), 0, s, p.gxg, grid_x, part_tab, inter, part_hist, tile_count);
     // (+ 1: the extra workgroup that writes the ranges, the counters and the forward's work list)
     hipLaunchKernelGGL(gbin_tscatter_kernel, dim3(n_parts + 1), dim3(GTS_THREADS), 0, s, T, p.G, p.gxg, grid_x, cap, group_count, part_tab,
@@ -992,16 +998,17 @@ int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order,
   BinPlan p = bin_plan(N, T);
   uint32_t* table = (uint32_t*)mem;
   uint32_t* tile_count = (uint32_t*)(mem + align_up(((size_t)p.n_chunks + 1) * T * 4));
+  ushort4* srect = (ushort4*)((char*)tile_count + align_up((size_t)(T + 1) * 4));
   if (p.lds_scatter > 150 * 1024) {  // (cannot happen: large tile grids take the grouped path)
     set_error("image too large: %d tiles", T);
     return 2;
   }
   hipLaunchKernelGGL(bin_count_kernel, dim3(p.n_chunks), dim3(p.threads), (size_t)T * 4, s, N, T, grid_x, p.g_per_block,
-                     order, tiles, rect, table);
+                     order, tiles, rect, srect, table);
   hipLaunchKernelGGL(bin_scan_kernel, dim3((T + 63) / 64), dim3(1024), 0, s, T, p.n_chunks, table, tile_count);
   // (+ 1: the extra workgroup that writes the ranges, the counters and the forward's work list)
   hipLaunchKernelGGL(bin_scatter_kernel, dim3(p.n_chunks + 1), dim3(p.threads), p.lds_scatter, s, N, T, grid_x, cap,
-                     p.g_per_block, p.g_per_wave, order, tiles, rect, table, tile_count, point_list, tile_keys, out);
+                     p.g_per_block, p.g_per_wave, order, srect, table, tile_count, point_list, tile_keys, out);
   return 0;
 }
 

@@ -1,12 +1,13 @@
 #!/bin/bash
-# the raster tests under both tile sorts; C4/C5; C5 timeline
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r4w
 timeout 300 python -m pytest tests/test_gpu_raster.py tests/test_gpu_configs.py -q -m gpu -x 2>&1 | tail -n 3
 RIGGS_BIN_GROUPED=1 timeout 300 python -m pytest tests/test_gpu_raster.py tests/test_gpu_configs.py -q -m gpu -x 2>&1 | tail -n 3
-timeout 400 python tools/configs_sweep.py 2>&1 | grep -E "^C[45]"
+timeout 400 python tools/configs_sweep.py 2>&1 | grep -E "^C[1-5]"
 rm -rf gpurun_out/r4w/c5
 timeout 200 rocprofv3 --kernel-trace -f rocpd -d gpurun_out/r4w/c5 -o t -- python tools/config_timeline.py C5 > gpurun_out/r4w/c5.log 2>&1
-python tools/timeline.py $(find gpurun_out/r4w/c5 -name "*_results.db" | head -1) > gpurun_out/r4w/c5_timeline.txt 2>&1
-grep -E "period|bin" gpurun_out/r4w/c5_timeline.txt
+python tools/timeline.py $(find gpurun_out/r4w/c5 -name "*_results.db" | head -1) 2>&1 | grep -E "period|bin"
+rm -rf gpurun_out/r4w/hl
+timeout 300 rocprofv3 --kernel-trace -f rocpd -d gpurun_out/r4w/hl -o t -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --metric-only > gpurun_out/r4w/hl.log 2>&1
+python tools/timeline.py $(find gpurun_out/r4w/hl -name "*_results.db" | head -1) 2>&1 | grep -E "period|bin"
 find gpurun_out/r4w -name "*.db" -delete
