@@ -30,7 +30,6 @@ __device__ __forceinline__ int rect_tile(const ushort4 rc, int l, int grid_x) {
 
 __global__ __launch_bounds__(1024) void bin_count_kernel(int N, int T, int grid_x, int g_per_block,
                                                         const uint32_t* __restrict__ order,
-                                                        const uint32_t* __restrict__ tiles,
                                                         const ushort4* __restrict__ rect,
                                                         ushort4* __restrict__ srect /* [N]: the rectangles in depth order (empty if invisible) */,
                                                         uint32_t* __restrict__ table) {
@@ -41,12 +40,11 @@ __global__ __launch_bounds__(1024) void bin_count_kernel(int N, int T, int grid_
   const int end = min(N, first + g_per_block);
   for (int s = first + threadIdx.x; s < end; s += blockDim.x) {
     const uint32_t g = order[s];
-    const int n = (int)tiles[g];
     // (the one gather of the rectangles by depth order — a 64-byte line per Gaussian for 8 bytes; the scatter kernel reads
-    // this sorted copy, coalesced)
-    const ushort4 rc = n ? rect[g] : make_ushort4(0, 0, 0, 0);
+    // this sorted copy, coalesced.  A culled Gaussian's rectangle is empty: preprocess_fwd writes it for every Gaussian)
+    const ushort4 rc = rect[g];
     srect[s] = rc;
-    if (n == 0) continue;
+    if (rc.z == rc.x) continue;
     for (int y = rc.y; y < rc.w; y++)
       for (int x = rc.x; x < rc.z; x++) atomicAdd(&s_hist[y * grid_x + x], 1u);
   }
@@ -465,7 +463,7 @@ struct __attribute__((packed, aligned(4))) GU2 { uint32_t a, b; };
 // eight Gaussians — took 138 us instead of 73: the spans of eight depth-adjacent Gaussians hit the same hot groups in the
 // same instruction, and the LDS serialises equal addresses.)
 __global__ __launch_bounds__(1024) void gbin_count_kernel(int N, int T, int G, int gxg, int g_per_block, int g_per_wave,
-                                                         const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles,
+                                                         const uint32_t* __restrict__ order,
                                                          const ushort4* __restrict__ rect, ushort4* __restrict__ srect,
                                                          uint32_t* __restrict__ table,
                                                          uint32_t* __restrict__ wave_start, uint32_t* __restrict__ tile_count) {
@@ -484,7 +482,7 @@ __global__ __launch_bounds__(1024) void gbin_count_kernel(int N, int T, int G, i
     const int s = s0 + lane;
     if (s < end) {
       const uint32_t g = order[s];
-      const ushort4 rc = tiles[g] ? rect[g] : make_ushort4(0, 0, 0, 0);
+      const ushort4 rc = rect[g];
       srect[s] = rc;  // (the rectangles in depth order: see bin_count_kernel)
       if (rc.z > rc.x) {
         for (int y = rc.y; y < rc.w; y++)
@@ -960,6 +958,7 @@ size_t bin_scratch_bytes(int64_t cap, int T, int grid_x) {  // (grouped binning:
 int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order, const uint32_t* tiles,
                    const ushort4* rect, void* table_mem, void* scratch, uint32_t* point_list, uint32_t* tile_keys, const BinOut& out,
                    hipStream_t s) {
+  (void)tiles;  // (the rectangles alone say which Gaussians are visible: preprocess_fwd leaves a culled one's empty)
   if (T > 65535) { set_error("image too large: %d tiles (at most 65 535)", T); return 2; }
   char* mem = (char*)table_mem;
   static bool attr_done = false;
@@ -984,7 +983,7 @@ int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order,
     const unsigned n_parts = (unsigned)((cap > 0 ? cap : 1) / BIN_PART + p.G + 1);
     uint4* part_tab = (uint4*)((char*)part_hist + align_up(((size_t)(cap > 0 ? cap : 1) / BIN_PART + (size_t)p.G + 2) * 8 * 4));
     hipLaunchKernelGGL(gbin_count_kernel, dim3(p.n_chunks), dim3(p.W * 64), (size_t)p.W * ((p.G + 1) & ~1) * 2, s, N, T, p.G, p.gxg,
-                       p.g_per_block, p.g_per_wave, order, tiles, rect, srect, table, wave_start, tile_count);
+                       p.g_per_block, p.g_per_wave, order, rect, srect, table, wave_start, tile_count);
     hipLaunchKernelGGL(bin_scan_kernel, dim3((p.G + 63) / 64), dim3(1024), 0, s, p.G, p.n_chunks, table, group_count);
     // (+ 1: the extra workgroup that lists the second level's parts)
     hipLaunchKernelGGL(gbin_scatter_kernel, dim3(p.n_chunks + 1), dim3(p.W * 64), p.lds, s, N, p.G, p.gxg, cap, p.g_per_block, p.g_per_wave,
@@ -1004,7 +1003,7 @@ int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order,
     return 2;
   }
   hipLaunchKernelGGL(bin_count_kernel, dim3(p.n_chunks), dim3(p.threads), (size_t)T * 4, s, N, T, grid_x, p.g_per_block,
-                     order, tiles, rect, srect, table);
+                     order, rect, srect, table);
   hipLaunchKernelGGL(bin_scan_kernel, dim3((T + 63) / 64), dim3(1024), 0, s, T, p.n_chunks, table, tile_count);
   // (+ 1: the extra workgroup that writes the ranges, the counters and the forward's work list)
   hipLaunchKernelGGL(bin_scatter_kernel, dim3(p.n_chunks + 1), dim3(p.threads), p.lds_scatter, s, N, T, grid_x, cap,

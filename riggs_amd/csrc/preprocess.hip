@@ -191,6 +191,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a) {
     __syncthreads();
   }
   uint32_t my_tiles = 0u, my_top = 0xFFFFFFFFu;  // (top byte of the depth key of a visible Gaussian, else none)
+  ushort4 my_rect = make_ushort4(0, 0, 0, 0);   // (stays empty for a culled Gaussian: the tile sorts read the rectangles alone)
   do {
   if (i >= a.N) break;
   const float* __restrict__ V = a.view;
@@ -271,11 +272,12 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a) {
   for (int k = 0; k < 6; k++) a.cov3D[6 * i + k] = c6[k];
   a.clamped[i] = cl;
   a.tiles[i] = (uint32_t)((x1 - x0) * (y1 - y0));
-  a.rect[i] = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
+  my_rect = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
   a.depth_key[i] = __float_as_uint(vz);
   my_top = __float_as_uint(vz) >> 24;
   my_tiles = (uint32_t)((x1 - x0) * (y1 - y0));
   } while (0);
+  if (i < a.N) a.rect[i] = my_rect;
   // instance count R = sum of tiles_touched: wave reduction -> per-workgroup partial (summed by the first kernel of
   // the depth sort; thousands of same-address atomics would serialise in L2)
   // ... and the range of the top bytes of the visible depth keys (the depth sort skips its third pass when they all agree)
