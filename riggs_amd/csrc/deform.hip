@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void lbs_backward_kernel(LbsArgs a) {
 #define LB_BONES 8                      // bone lanes per Gaussian slot
 #define LB_MAXBLK ((MAX_J - 1 + LB_BONES - 1) / LB_BONES)
 #ifndef LB_GPB
-#define LB_GPB 1024                     // Gaussians per workgroup: every wave looks at LB_GPB / 4, 64 at a time
+#define LB_GPB 1024                     // Gaussians per workgroup: every wave looks at a quarter of them, 64 at a time
 #endif
 
 __device__ __forceinline__ float row8_sum(float v) {
@@ -398,7 +398,7 @@ __device__ __forceinline__ float row8_sum(float v) {
   return v;
 }
 
-template <int NBLK, bool MOD>
+template <int NBLK, bool MOD, int GPB>
 __global__ __launch_bounds__(256) void lbs_backward_bonelane_kernel(LbsArgs a) {
   __shared__ Bone bones[MAX_J - 1 + LB_BONES];
   __shared__ float s_acc[MAX_J - 1 + LB_BONES][13];
@@ -416,8 +416,8 @@ __global__ __launch_bounds__(256) void lbs_backward_bonelane_kernel(LbsArgs a) {
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int slot = lane >> 3, bl = lane & 7;
-  const int wave_first = blockIdx.x * LB_GPB + wave * (LB_GPB / 4);
-  const int wave_end = min(a.N, wave_first + LB_GPB / 4);
+  const int wave_first = blockIdx.x * GPB + wave * (GPB / 4);
+  const int wave_end = min(a.N, wave_first + GPB / 4);
   float acc[NBLK][13];
 #pragma unroll
   for (int bb = 0; bb < NBLK; bb++)
@@ -431,15 +431,18 @@ __global__ __launch_bounds__(256) void lbs_backward_bonelane_kernel(LbsArgs a) {
   // The wave's Gaussians are looked at in ONE batch — the loads of all its 64-Gaussian groups are in flight together —
   // and the ones with a gradient are listed across the groups: walking group by group paid two dependent round trips
   // (test, then the listed Gaussians' operands) per group, which was most of this kernel's time in a sparse frame.
-  constexpr int GROUPS = LB_GPB / 4 / 64;
-  __shared__ unsigned short s_list[4][LB_GPB / 4];
+  // (a large scene's workgroups take four times the Gaussians — GPB = 4096: the bones' staging, the fold of the sums and the
+  // partials cost a workgroup ~10 us whatever it walks — and look at them in batches of four groups)
+  constexpr int GROUPS = GPB / 4 / 64, GBATCH = 4;
+  __shared__ unsigned short s_list[4][GPB / 4];
   int n_work = 0;
-  {
-    float4 hq[GROUPS];
-    float gq[GROUPS][3];
+#pragma unroll 1
+  for (int gb = 0; gb < GROUPS; gb += GBATCH) {
+    float4 hq[GBATCH];
+    float gq[GBATCH][3];
 #pragma unroll
-    for (int g4 = 0; g4 < GROUPS; g4++) {
-      const int n = wave_first + 64 * g4 + lane;
+    for (int g4 = 0; g4 < GBATCH; g4++) {
+      const int n = wave_first + 64 * (gb + g4) + lane;
       hq[g4] = make_float4(0.f, 0.f, 0.f, 0.f); gq[g4][0] = 0.f; gq[g4][1] = 0.f; gq[g4][2] = 0.f;
       if (n < wave_end) {
         hq[g4] = reinterpret_cast<const float4*>(a.g_rot)[n];
@@ -447,8 +450,8 @@ __global__ __launch_bounds__(256) void lbs_backward_bonelane_kernel(LbsArgs a) {
       }
     }
 #pragma unroll
-    for (int g4 = 0; g4 < GROUPS; g4++) {
-      const int n = wave_first + 64 * g4 + lane;
+    for (int g4 = 0; g4 < GBATCH; g4++) {
+      const int n = wave_first + 64 * (gb + g4) + lane;
       const bool touched = (gq[g4][0] != 0.f) || (gq[g4][1] != 0.f) || (gq[g4][2] != 0.f) ||
                            (hq[g4].x != 0.f) || (hq[g4].y != 0.f) || (hq[g4].z != 0.f) || (hq[g4].w != 0.f);
       if (n < wave_end && !touched) {
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(256) void lbs_backward_bonelane_kernel(LbsArgs a) {
         if constexpr (MOD) for (int k = 0; k < B; k++) a.dmod[(size_t)n * B + k] = 0.f;
       }
       const uint64_t tm = __builtin_amdgcn_ballot_w64(touched);
-      if (touched) s_list[wave][n_work + __builtin_popcountll(tm & ((1ull << lane) - 1ull))] = (unsigned short)(64 * g4 + lane);
+      if (touched) s_list[wave][n_work + __builtin_popcountll(tm & ((1ull << lane) - 1ull))] = (unsigned short)(64 * (gb + g4) + lane);
       n_work += __builtin_popcountll(tm);
     }
   }
@@ -579,13 +582,23 @@ __global__ __launch_bounds__(256) void lbs_backward_finish_kernel(LbsArgs a, int
   if (e == 0 && threadIdx.x == 12) a.drho[0] = 0.f;
 }
 
+template <int NBLK, int GPB>
+static void launch_lbs_bwd_bonelane_g(const LbsArgs& a, hipStream_t s) {
+  const int blocks = (a.N + GPB - 1) / GPB;
+  // (the weight-modulated variant — WeightMLP head on — is a separate instantiation: the LBS-only kernel keeps its registers)
+  if (a.weight_mod) hipLaunchKernelGGL((lbs_backward_bonelane_kernel<NBLK, true, GPB>), dim3(blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((lbs_backward_bonelane_kernel<NBLK, false, GPB>), dim3(blocks), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(lbs_backward_finish_kernel, dim3((a.J - 1) * 13 + 3), dim3(256), 0, s, a, blocks);
+}
 template <int NBLK>
 static void launch_lbs_bwd_bonelane(const LbsArgs& a, hipStream_t s) {
-  const int blocks = (a.N + LB_GPB - 1) / LB_GPB;
-  // (the weight-modulated variant — WeightMLP head on — is a separate instantiation: the LBS-only kernel keeps its registers)
-  if (a.weight_mod) hipLaunchKernelGGL((lbs_backward_bonelane_kernel<NBLK, true>), dim3(blocks), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((lbs_backward_bonelane_kernel<NBLK, false>), dim3(blocks), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(lbs_backward_finish_kernel, dim3((a.J - 1) * 13 + 3), dim3(256), 0, s, a, blocks);
+  // 1024 Gaussians per workgroup fill the chip at the bench size (293 workgroups).  At 64 joints the kernel holds 13 sums for
+  // 8 blocks of bones per lane — 256 VGPRs, ONE workgroup per CU — and a workgroup costs ~15 us whatever it walks (staging
+  // the bones, the fold of the sums, the partials): 2 M Gaussians were 1954 workgroups = 7.6 rounds = 154 us.  So a large
+  // scene's workgroups take as many Gaussians as leave about one workgroup per CU.
+  if (a.N >= 8 * 240 * 1024) launch_lbs_bwd_bonelane_g<NBLK, 8192>(a, s);
+  else if (a.N >= 4 * 240 * 1024) launch_lbs_bwd_bonelane_g<NBLK, 4096>(a, s);
+  else launch_lbs_bwd_bonelane_g<NBLK, LB_GPB>(a, s);
 }
 
 }  // namespace riggs
