@@ -1023,8 +1023,9 @@ int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order,
 // scene that lies inside one of the ranges [2, 8), [0.5, 2), [8, 32), ... (a D-NeRF / ZJU camera looks at its subject
 // from 2 - 6 units).  preprocess_fwd records the top bytes it saw; the first kernel folds them into counters[2] =
 // "third pass needed", and the third pass — inside the second pass's scatter launch, behind in-launch barriers — is a load
-// of that flag when it is not: two passes (six short launches) instead of three 11-bit passes (nine).  The result always ends in (keys_out, vals_out): the
-// first two passes go through a scratch pair or through the output pair depending on the flag.
+// of that flag when it is not: two passes (six short launches) instead of three 11-bit passes (nine).  Between the passes the elements
+// travel as (key, value) PAIRS — one 8-byte scattered store per element instead of two of 4: the scatter kernels are bound by
+// the number of single-dword line writes — and the last pass writes the values alone (no kernel reads sorted keys).
 // rocPRIM picks a block sort + ~9 merge passes (18 launches, 0.12 ms) at N = 3e5 and Onesweep's chained
 // look-back costs the same at this size.
 // =====================================================================================================
@@ -1039,16 +1040,15 @@ int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order,
 
 // routing of a pass: (source, destination) by the "third pass needed" flag (counters[2])
 struct RsBufs {
-  const uint32_t *k_in, *v_in;        // the caller's input (never written): pass 0 reads it (v_in may be NULL: value = index)
-  uint32_t *k_tmp, *v_tmp;            // scratch pair
-  uint32_t *k_out, *v_out;            // the result
+  const uint32_t* k_in;   // the caller's keys (never written): pass 0 reads them, the value is the index
+  uint2 *a, *b;           // two scratch lists of (key, value) PAIRS: one 8-byte scattered store per element instead of two of 4
+  uint32_t* v_out;        // the result: the values in key order (the LAST pass writes only them: nobody reads sorted keys)
 };
-__device__ __forceinline__ void rs_route(const RsBufs& b, int pass, bool three, const uint32_t*& ks, const uint32_t*& vs,
-                                         uint32_t*& kd, uint32_t*& vd) {
-  // two passes:   in -> tmp -> out            three passes:   in -> out -> tmp -> out
-  if (pass == 0) { ks = b.k_in; vs = b.v_in; kd = three ? b.k_out : b.k_tmp; vd = three ? b.v_out : b.v_tmp; }
-  else if (pass == 1) { ks = three ? b.k_out : b.k_tmp; vs = three ? b.v_out : b.v_tmp; kd = three ? b.k_tmp : b.k_out; vd = three ? b.v_tmp : b.v_out; }
-  else { ks = b.k_tmp; vs = b.v_tmp; kd = b.k_out; vd = b.v_out; }
+// two passes:   in -> a -> out            three passes:   in -> b -> a -> out
+__device__ __forceinline__ void rs_route(const RsBufs& r, int pass, bool three, const uint2*& src, uint2*& dst) {
+  if (pass == 0) { src = nullptr; dst = three ? r.b : r.a; }
+  else if (pass == 1) { src = three ? r.b : r.a; dst = three ? r.a : nullptr; }
+  else { src = r.a; dst = nullptr; }
 }
 
 // (the last workgroup of the first pass also totals the per-workgroup tile counts of preprocess_fwd into
@@ -1088,8 +1088,8 @@ __global__ __launch_bounds__(CHUNK / 8) void rs_count_kernel(int N, int pass, Rs
   } else {
     three = counters[2] != 0u;
   }
-  const uint32_t *ks, *vs; uint32_t *kd, *vd;
-  rs_route(bufs, pass, three, ks, vs, kd, vd);
+  const uint2* src; uint2* dst;
+  rs_route(bufs, pass, three, src, dst);
   const int shift = pass * RS_BITS;
   for (int b = threadIdx.x; b < RS_BINS; b += NT) s_hist[b] = 0u;
   __syncthreads();
@@ -1097,7 +1097,7 @@ __global__ __launch_bounds__(CHUNK / 8) void rs_count_kernel(int N, int pass, Rs
 #pragma unroll
   for (int k = 0; k < CHUNK / NT; k++) {
     const int i = first + k * NT + threadIdx.x;
-    if (i < N) atomicAdd(&s_hist[(ks[i] >> shift) & (RS_BINS - 1)], 1u);
+    if (i < N) atomicAdd(&s_hist[((src ? src[i].x : bufs.k_in[i]) >> shift) & (RS_BINS - 1)], 1u);
   }
   __syncthreads();
   uint32_t* row = table + (size_t)blockIdx.x * RS_BINS;
@@ -1130,8 +1130,8 @@ __device__ void rs_third_pass_body(int N, int n_chunks, const RsBufs& bufs, uint
   __shared__ uint32_t s_start[RS3_BINS];
   __shared__ unsigned short s_wave[RS_SC_WAVES][RS3_BINS];
   __shared__ int s_fail;
-  const uint32_t *ks = bufs.k_tmp, *vs = bufs.v_tmp;
-  uint32_t *kd = bufs.k_out, *vd = bufs.v_out;
+  const uint2* src = bufs.a;
+  uint32_t* vd = bufs.v_out;
   constexpr int NT = RS_SC_WAVES * 64, STEPS = CHUNK / NT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // ---- phase A: the counts of this workgroup's chunks, published with write-through stores
@@ -1141,7 +1141,7 @@ __device__ void rs_third_pass_body(int N, int n_chunks, const RsBufs& bufs, uint
 #pragma unroll
     for (int st = 0; st < STEPS; st++) {
       const int i = chunk * CHUNK + wave * (64 * STEPS) + st * 64 + lane;
-      if (i < N) atomicAdd(&s_hist[ks[i] >> 24], 1u);
+      if (i < N) atomicAdd(&s_hist[src[i].x >> 24], 1u);
     }
     __syncthreads();
     if (tid < RS3_BINS)
@@ -1189,7 +1189,8 @@ __device__ void rs_third_pass_body(int N, int n_chunks, const RsBufs& bufs, uint
       const int i = chunk * CHUNK + wave * (64 * STEPS) + st * 64 + lane;
       key[st] = 0u; val[st] = 0u; dig[st] = -1;
       if (i < N) {
-        key[st] = ks[i]; val[st] = vs[i];
+        const uint2 kv = src[i];
+        key[st] = kv.x; val[st] = kv.y;
         dig[st] = (int)(key[st] >> 24);
         atomicAdd(reinterpret_cast<uint32_t*>(&s_wave[wave][0]) + (dig[st] >> 1), 1u << (16 * (dig[st] & 1)));
       }
@@ -1229,7 +1230,7 @@ __device__ void rs_third_pass_body(int N, int n_chunks, const RsBufs& bufs, uint
         const uint32_t rank = (uint32_t)__builtin_popcountll(below);
         const unsigned short base = cur[dig[st]];
         const uint32_t pos = s_start[dig[st]] + base + rank;
-        kd[pos] = key[st]; vd[pos] = val[st];
+        vd[pos] = val[st];
         if ((same >> lane) >> 1 == 0ull) cur[dig[st]] = base + (unsigned short)__builtin_popcountll(same);
       }
     }
@@ -1248,8 +1249,8 @@ __global__ __launch_bounds__(RS_SC_WAVES * 64) void rs_scatter_kernel(int N, int
   __shared__ unsigned short s_wave[RS_SC_WAVES][RS_BINS];    // per-wave counts -> per-wave running offsets
   __shared__ uint32_t s_part[RS_SC_WAVES];
   const bool three = counters[2] != 0u;
-  const uint32_t *ks, *vs; uint32_t *kd, *vd;
-  rs_route(bufs, pass, three, ks, vs, kd, vd);
+  const uint2* src; uint2* dst;
+  rs_route(bufs, pass, three, src, dst);
   const int shift = pass * RS_BITS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int NT = RS_SC_WAVES * 64, PER = RS_BINS / NT;   // bins per thread in the scan
@@ -1263,7 +1264,10 @@ __global__ __launch_bounds__(RS_SC_WAVES * 64) void rs_scatter_kernel(int N, int
   for (int st = 0; st < STEPS; st++) {
     const int i = wfirst + st * 64 + lane;
     key[st] = 0u; val[st] = 0u;
-    if (i < N) { key[st] = ks[i]; val[st] = vs ? vs[i] : (uint32_t)i; }
+    if (i < N) {
+      if (src) { const uint2 kv = src[i]; key[st] = kv.x; val[st] = kv.y; }
+      else { key[st] = bufs.k_in[i]; val[st] = (uint32_t)i; }
+    }
   }
   const uint32_t* row = table + (size_t)blockIdx.x * RS_BINS;
   uint32_t rw[PER];
@@ -1321,7 +1325,7 @@ __global__ __launch_bounds__(RS_SC_WAVES * 64) void rs_scatter_kernel(int N, int
       const uint32_t rank = (uint32_t)__builtin_popcountll(below);
       const unsigned short base = cur[dig[st]];
       const uint32_t pos = s_start[dig[st]] + base + rank;
-      kd[pos] = key[st]; vd[pos] = val[st];
+      if (dst) dst[pos] = make_uint2(key[st], val[st]); else bufs.v_out[pos] = val[st];
       if ((same >> lane) >> 1 == 0ull) cur[dig[st]] = base + (unsigned short)__builtin_popcountll(same);  // highest lane of the group
     }
   }
@@ -1353,7 +1357,7 @@ __global__ __launch_bounds__(RS_SC_WAVES * 64) void rs_scatter_kernel(int N, int
 
 size_t depth_sort_table_bytes(int N) {
   const size_t n = (size_t)(N > 0 ? N : 1), chunks = (n + RS_CHUNK - 1) / RS_CHUNK;
-  return align_up((chunks + 1) * RS_BINS * 4) + align_up(RS_BINS * 4) + 2 * align_up(n * 4) + 256;  // table, bin counts, scratch pair, arrival counter
+  return align_up((chunks + 1) * RS_BINS * 4) + align_up(RS_BINS * 4) + 2 * align_up(n * 8) + 256;  // table, bin counts, two lists of pairs, arrival counter
 }
 
 // the result ends in (keys_out, vals_out); keys_in is left intact; values are the element indices
@@ -1366,10 +1370,11 @@ static int launch_depth_sort_t(int N, const uint32_t* keys_in, uint32_t* keys_ou
   // (the layout of depth_sort_table_bytes: sized for the small chunks, whichever are used)
   uint32_t* bin_count = (uint32_t*)(mem + align_up(((size_t)((N + RS_CHUNK - 1) / RS_CHUNK) + 1) * RS_BINS * 4));
   RsBufs b;
-  b.k_in = keys_in; b.v_in = nullptr;
-  b.k_tmp = (uint32_t*)((char*)bin_count + align_up(RS_BINS * 4));
-  b.v_tmp = (uint32_t*)((char*)b.k_tmp + align_up((size_t)(N > 0 ? N : 1) * 4));
-  b.k_out = keys_out; b.v_out = vals_out;
+  (void)keys_out;  // (the sorted keys are not produced: no kernel reads them — the order is the result)
+  b.k_in = keys_in;
+  b.a = (uint2*)((char*)bin_count + align_up(RS_BINS * 4));
+  b.b = (uint2*)((char*)b.a + align_up((size_t)(N > 0 ? N : 1) * 8));
+  b.v_out = vals_out;
   // The third pass (inside the second scatter launch) has in-launch barriers: its G workgroups must be RESIDENT at once — half
   // of what the device holds of the scatter kernel (occupancy x compute units), so that the launch's other workgroups, and
   // kernels of other streams (the RCCL collectives of the overlapped exchanges), find compute units.  Each of the G loops over
@@ -1385,7 +1390,7 @@ static int launch_depth_sort_t(int N, const uint32_t* keys_in, uint32_t* keys_ou
     rs3_grid = resident / 2 > 0 ? resident / 2 : 1;
     if (rs3_grid > RS3_MAX_WG) rs3_grid = RS3_MAX_WG;
   }
-  uint32_t* arrivals = (uint32_t*)((char*)b.v_tmp + align_up((size_t)(N > 0 ? N : 1) * 4));
+  uint32_t* arrivals = (uint32_t*)((char*)b.b + align_up((size_t)(N > 0 ? N : 1) * 8));
   for (int pass = 0; pass < 2; pass++) {
     hipLaunchKernelGGL(rs_count_kernel<CHUNK>, dim3(chunks), dim3(CHUNK / 8), 0, s, N, pass, b, table, block_info, (N + 255) / 256, counters,
                        arrivals);
