@@ -7,10 +7,10 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
-from configs_sweep import CONFIGS  # noqa: E402
+from configs_sweep import CONFIGS, EXTRA  # noqa: E402
 from riggs_amd.graph import GraphedFrame  # noqa: E402
 
-cfg = CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "C5"]
+cfg = {**CONFIGS, **EXTRA}[sys.argv[1] if len(sys.argv) > 1 else "C5"]
 bench.WORKLOAD.update(cfg)
 sc, cam, gm, sw = bench.build_workload(0, "cuda:0")
 gf = GraphedFrame(gm, sw, cam, torch.zeros(3, device="cuda"), bench.params_of(gm, sw)).capture()

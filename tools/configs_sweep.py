@@ -13,6 +13,7 @@ from riggs_amd.graph import GraphedFrame  # noqa: E402
 CONFIGS = {"C1": dict(N=10_000, J=8, H=256, W=256), "C2": dict(N=150_000, J=24, H=800, W=800),
            "C3": dict(N=300_000, J=32, H=800, W=800), "C4": dict(N=500_000, J=24, H=1024, W=1024),
            "C5": dict(N=2_000_000, J=64, H=1080, W=1920)}
+EXTRA = {"HL": dict(N=300_000, J=24, H=800, W=800)}  # (the bench workload itself, for tools/config_timeline.py / config_counters.sh)
 
 
 def main():
