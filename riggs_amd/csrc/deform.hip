@@ -165,6 +165,19 @@ __device__ __forceinline__ uint64_t topk_mask(const Bone* bones, int B, int K, f
 template <bool TOPK, bool FK, int PTS>
 __global__ __launch_bounds__(256) void lbs_forward_kernel(LbsArgs a) {
   __shared__ Bone bones[MAX_J - 1];
+  // (the Gaussians' positions first: their round trip runs under the chain and the staging — the compiler keeps loads behind
+  // the barriers where it finds them)
+  static_assert(!TOPK || PTS == 1, "the top-K path takes one Gaussian per thread");
+  const int n0 = blockIdx.x * (256 * PTS) + threadIdx.x;
+  float px[PTS], py[PTS], pz[PTS];
+  bool on[PTS];
+#pragma unroll
+  for (int p = 0; p < PTS; p++) {
+    const int n = n0 + 256 * p;
+    on[p] = n < a.N;
+    const int nn = min(on[p] ? n : n0, a.N - 1);
+    px[p] = a.x[3 * nn]; py[p] = a.x[3 * nn + 1]; pz[p] = a.x[3 * nn + 2];
+  }
   if constexpr (FK) {
     __shared__ float G[MAX_J][12];
     __shared__ float Q[MAX_J][4];
@@ -205,21 +218,10 @@ __global__ __launch_bounds__(256) void lbs_forward_kernel(LbsArgs a) {
   // the blend.  The blend on the matrix pipe instead — v_mfma_f32_16x16x4_f32, lane = (Gaussian i of a tile of 16, bone
   // 4 s + j): the same k-ordered fmaf chain, 19 vector instructions per pair — measured 128 us: its four dependent-free MFMAs
   // per step still cost the wave their issue, plus a transposing epilogue through LDS; not kept for 4 %).
-  static_assert(!TOPK || PTS == 1, "the top-K path takes one Gaussian per thread");
   // (one block of 256 * PTS Gaussians per workgroup: fewer, looping workgroups — the chain and the staging above once per
   // workgroup instead of once per block — are slower: 17.5 -> 19.7 -> 24.6 us at 1172 / 586 / 293 workgroups)
   const int B = a.J - 1;
-  const int n0 = blockIdx.x * (256 * PTS) + threadIdx.x;
   if (n0 >= a.N) return;
-  float px[PTS], py[PTS], pz[PTS];
-  bool on[PTS];
-#pragma unroll
-  for (int p = 0; p < PTS; p++) {
-    const int n = n0 + 256 * p;
-    on[p] = n < a.N;
-    const int nn = on[p] ? n : n0;
-    px[p] = a.x[3 * nn]; py[p] = a.x[3 * nn + 1]; pz[p] = a.x[3 * nn + 2];
-  }
   const uint64_t selmask = TOPK ? topk_mask(bones, B, a.K, px[0], py[0], pz[0]) : ~0ull;
   float M[PTS][12], qa[PTS][4], sum[PTS];
 #pragma unroll
@@ -404,6 +406,34 @@ __global__ __launch_bounds__(256) void lbs_backward_bonelane_kernel(LbsArgs a) {
   __shared__ float s_acc[MAX_J - 1 + LB_BONES][13];
   __shared__ float s_gt[3];
   const int B = a.J - 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = lane >> 3, bl = lane & 7;
+  const int wave_first = blockIdx.x * GPB + wave * (GPB / 4);
+  const int wave_end = min(a.N, wave_first + GPB / 4);
+  // Gaussians without an incoming gradient (behind saturated pixels, never at alpha >= 1/255, invisible: most of a
+  // deep scene) contribute exact zeros to every sum: the wave looks at its Gaussians once, writes the zeros of
+  // the per-Gaussian outputs, and walks only the others, eight at a time.
+  // The wave's Gaussians are looked at in batches of four groups of 64 — their loads in flight together — and the ones with a
+  // gradient are listed across the groups: walking group by group paid two dependent round trips (test, then the listed
+  // Gaussians' operands) per group, which was most of this kernel's time in a sparse frame.  The FIRST batch is requested
+  // before the bones are staged: its round trip runs under theirs.
+  // (a large scene's workgroups take four or eight times the Gaussians — GPB = 4096 / 8192: the bones' staging, the fold of
+  // the sums and the partials cost a workgroup ~15 us whatever it walks)
+  constexpr int GROUPS = GPB / 4 / 64, GBATCH = 4;
+  float4 hq[GBATCH];
+  float gq[GBATCH][3];
+  auto request = [&](const int gb) {
+#pragma unroll
+    for (int g4 = 0; g4 < GBATCH; g4++) {
+      const int n = wave_first + 64 * (gb + g4) + lane;
+      hq[g4] = make_float4(0.f, 0.f, 0.f, 0.f); gq[g4][0] = 0.f; gq[g4][1] = 0.f; gq[g4][2] = 0.f;
+      if (n < wave_end) {
+        hq[g4] = reinterpret_cast<const float4*>(a.g_rot)[n];
+        gq[g4][0] = a.g_xyz[3 * n]; gq[g4][1] = a.g_xyz[3 * n + 1]; gq[g4][2] = a.g_xyz[3 * n + 2];
+      }
+    }
+  };
+  request(0);
   stage_bones(a, bones);
   for (int k = B + threadIdx.x; k < NBLK * LB_BONES; k += 256) {  // padding bones: never selected
     Bone z;
@@ -414,10 +444,6 @@ __global__ __launch_bounds__(256) void lbs_backward_bonelane_kernel(LbsArgs a) {
   for (int e = threadIdx.x; e < NBLK * LB_BONES * 13; e += 256) (&s_acc[0][0])[e] = 0.f;
   if (threadIdx.x < 3) s_gt[threadIdx.x] = 0.f;
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int slot = lane >> 3, bl = lane & 7;
-  const int wave_first = blockIdx.x * GPB + wave * (GPB / 4);
-  const int wave_end = min(a.N, wave_first + GPB / 4);
   float acc[NBLK][13];
 #pragma unroll
   for (int bb = 0; bb < NBLK; bb++)
@@ -425,30 +451,11 @@ __global__ __launch_bounds__(256) void lbs_backward_bonelane_kernel(LbsArgs a) {
     for (int e = 0; e < 13; e++) acc[bb][e] = 0.f;
   float gt0 = 0.f, gt1 = 0.f, gt2 = 0.f;
   const float gx = a.global_trans[0], gy = a.global_trans[1], gz = a.global_trans[2];
-  // Gaussians without an incoming gradient (behind saturated pixels, never at alpha >= 1/255, invisible: most of a
-  // deep scene) contribute exact zeros to every sum: the wave looks at its 64 Gaussians once, writes the zeros of
-  // the per-Gaussian outputs, and walks only the others, eight at a time.
-  // The wave's Gaussians are looked at in ONE batch — the loads of all its 64-Gaussian groups are in flight together —
-  // and the ones with a gradient are listed across the groups: walking group by group paid two dependent round trips
-  // (test, then the listed Gaussians' operands) per group, which was most of this kernel's time in a sparse frame.
-  // (a large scene's workgroups take four times the Gaussians — GPB = 4096: the bones' staging, the fold of the sums and the
-  // partials cost a workgroup ~10 us whatever it walks — and look at them in batches of four groups)
-  constexpr int GROUPS = GPB / 4 / 64, GBATCH = 4;
   __shared__ unsigned short s_list[4][GPB / 4];
   int n_work = 0;
 #pragma unroll 1
   for (int gb = 0; gb < GROUPS; gb += GBATCH) {
-    float4 hq[GBATCH];
-    float gq[GBATCH][3];
-#pragma unroll
-    for (int g4 = 0; g4 < GBATCH; g4++) {
-      const int n = wave_first + 64 * (gb + g4) + lane;
-      hq[g4] = make_float4(0.f, 0.f, 0.f, 0.f); gq[g4][0] = 0.f; gq[g4][1] = 0.f; gq[g4][2] = 0.f;
-      if (n < wave_end) {
-        hq[g4] = reinterpret_cast<const float4*>(a.g_rot)[n];
-        gq[g4][0] = a.g_xyz[3 * n]; gq[g4][1] = a.g_xyz[3 * n + 1]; gq[g4][2] = a.g_xyz[3 * n + 2];
-      }
-    }
+    if (gb > 0) request(gb);
 #pragma unroll
     for (int g4 = 0; g4 < GBATCH; g4++) {
       const int n = wave_first + 64 * (gb + g4) + lane;
