@@ -653,12 +653,7 @@ static int fill_lbs(LbsArgs& a, int32_t N, int32_t J, int32_t K, const float* x,
 }
 
 // two Gaussians per thread in the all-bones forward (see lbs_forward_kernel) where the launch still fills the chip
-static bool lbs_two_per_thread(int N, int J) {
-  static int forced = -2;
-  if (forced == -2) { const char* e = getenv("RIGGS_LBS_PTS2"); forced = (e && *e) ? atoi(e) : -1; }
-  if (forced >= 0) return forced != 0;
-  return N >= LBS_PTS2_MIN_N && J >= LBS_PTS2_MIN_J;
-}
+static bool lbs_two_per_thread(int N, int J) { return N >= LBS_PTS2_MIN_N && J >= LBS_PTS2_MIN_J; }
 
 static unsigned lbs_grid(int N, int pts) { return (unsigned)((N + 256 * pts - 1) / (256 * pts)); }
 
