@@ -289,7 +289,7 @@ class GraphedTrainStep(GraphedFrame):
                 d_nodes = sw(gm.get_xyz.detach()[:1], sw.expand_time(self.cam.fid), motion_mask=None)["d_nodes"]
             self.proj_steps = sampling_steps(d_nodes, sw.parents)
             self.proj_parents = sw.parents.to(device=bg.device, dtype=torch.int32).clone()
-            self.one = torch.ones((), device=bg.device)
+        self.one = torch.ones((), device=bg.device)
 
     def _frame(self):
         from .loss import image_loss, cal_skeleton_loss
@@ -302,15 +302,15 @@ class GraphedTrainStep(GraphedFrame):
         loss, l1 = image_loss(pkg["render"], self.gt, self.lam)
         proj = None
         if self.thinned is None:
-            loss.backward()
+            torch.autograd.backward([loss], [self.one])  # (an explicit seed: ``loss.backward()`` launches a fill for its ones)
         else:
             # two roots, one backward pass: no launches for "loss + weight * projection" and its autograd mirror
             self.cam.thinned = self.thinned
             proj, wproj = cal_skeleton_loss(dv["d_nodes"], self.proj_parents, self.cam, t=self.proj_steps, weight=self.proj_weight,
                                             pixel_count=self.pixel_count)
             torch.autograd.backward([loss, wproj], [self.one, self.one])
-        for o in self.optimizers:
-            o.step()
+        from .optim import step_many
+        step_many(self.optimizers)
         out = {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in dict.items(pkg)
                if k not in ("viewspace_points", "visibility_filter")}
         out["viewspace_points_grad"] = pkg["viewspace_points"].grad

@@ -39,9 +39,15 @@ class FusedAdam(torch.optim.Adam):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        lib = L.lib()
-        cap = getattr(self, "hip_capturable", False)
         by_cfg = {}
+        self._gather(by_cfg)
+        _launch(by_cfg, getattr(self, "hip_capturable", False))
+        return loss
+
+    def _gather(self, by_cfg):
+        """Append this optimizer's (parameter, gradient, moments, lr, step) tuples to ``by_cfg`` (keyed by betas / eps), creating
+        the state lazily like torch.optim.Adam."""
+        cap = getattr(self, "hip_capturable", False)
         for group in self.param_groups:
             if group.get("weight_decay", 0) != 0 or group.get("amsgrad", False) or group.get("maximize", False):
                 raise NotImplementedError("FusedAdam: plain Adam only")
@@ -69,35 +75,58 @@ class FusedAdam(torch.optim.Adam):
                 g = L.require_cuda_f32("gradient", p.grad, tuple(p.shape))
                 key = (group["betas"][0], group["betas"][1], group["eps"])
                 by_cfg.setdefault(key, []).append((p, g, m, v, lr, st["step"]))
-        st_ptr = L.stream_ptr()
-        if cap:
-            steps = [t[5] for items in by_cfg.values() for t in items]
-            if steps:
-                torch._foreach_add_(steps, 1.0)  # one multi-tensor launch; the kernels below read the new counts
-        for (b1, b2, eps), items in by_cfg.items():
-            for i in range(0, len(items), _MAX):
-                chunk = items[i:i + _MAX]
-                n = len(chunk)
-                arr = lambda k: (C.c_void_p * n)(*[t[k].data_ptr() for t in chunk])  # noqa: E731
-                numel = (C.c_int64 * n)(*[t[0].numel() for t in chunk])
-                if cap:
-                    lr_host = (C.c_double * n)(*[0.0 if isinstance(t[4], torch.Tensor) else float(t[4]) for t in chunk])
-                    lr_dev = (C.c_void_p * n)(*[L.require_cuda_f32("lr", t[4]).data_ptr() if isinstance(t[4], torch.Tensor) else None
-                                                for t in chunk])
-                    L.check(lib.riggs_adam_step_capturable(n, arr(0), arr(1), arr(2), arr(3), numel, lr_host, arr(5), lr_dev,
-                                                           float(b1), float(b2), float(eps), st_ptr), "riggs_adam_step_capturable")
-                else:
-                    for t in chunk:
-                        t[5].add_(1)
-                    lr = (C.c_double * n)(*[float(t[4]) for t in chunk])
-                    steps = (C.c_int64 * n)(*[int(t[5].item()) for t in chunk])
-                    L.check(lib.riggs_adam_step(n, arr(0), arr(1), arr(2), arr(3), numel, lr, steps, float(b1), float(b2),
-                                                float(eps), st_ptr), "riggs_adam_step")
-                # the kernels write through raw pointers: tell autograd (and anything that caches derived copies of the
-                # parameters by version, e.g. the bf16 weights of riggs_amd.mlp) that the tensors changed
+
+
+def _launch(by_cfg, cap):
+    lib = L.lib()
+    st_ptr = L.stream_ptr()
+    if cap:
+        steps = [t[5] for items in by_cfg.values() for t in items]
+        if steps:
+            torch._foreach_add_(steps, 1.0)  # one multi-tensor launch; the kernels below read the new counts
+    for (b1, b2, eps), items in by_cfg.items():
+        for i in range(0, len(items), _MAX):
+            chunk = items[i:i + _MAX]
+            n = len(chunk)
+            arr = lambda k: (C.c_void_p * n)(*[t[k].data_ptr() for t in chunk])  # noqa: E731
+            numel = (C.c_int64 * n)(*[t[0].numel() for t in chunk])
+            if cap:
+                lr_host = (C.c_double * n)(*[0.0 if isinstance(t[4], torch.Tensor) else float(t[4]) for t in chunk])
+                lr_dev = (C.c_void_p * n)(*[L.require_cuda_f32("lr", t[4]).data_ptr() if isinstance(t[4], torch.Tensor) else None
+                                            for t in chunk])
+                L.check(lib.riggs_adam_step_capturable(n, arr(0), arr(1), arr(2), arr(3), numel, lr_host, arr(5), lr_dev,
+                                                       float(b1), float(b2), float(eps), st_ptr), "riggs_adam_step_capturable")
+            else:
                 for t in chunk:
-                    torch.autograd.graph.increment_version(t[0])
-        return loss
+                    t[5].add_(1)
+                lr = (C.c_double * n)(*[float(t[4]) for t in chunk])
+                steps = (C.c_int64 * n)(*[int(t[5].item()) for t in chunk])
+                L.check(lib.riggs_adam_step(n, arr(0), arr(1), arr(2), arr(3), numel, lr, steps, float(b1), float(b2),
+                                            float(eps), st_ptr), "riggs_adam_step")
+            # the kernels write through raw pointers: tell autograd (and anything that caches derived copies of the
+            # parameters by version, e.g. the bf16 weights of riggs_amd.mlp) that the tensors changed
+            for t in chunk:
+                torch.autograd.graph.increment_version(t[0])
+
+
+@torch.no_grad()
+def step_many(optimizers):
+    """``for o in optimizers: o.step()`` for FusedAdam instances with ONE step-count increment and one Adam launch per (betas, eps)
+    configuration ACROSS the optimizers (train_rig.py:527-554 steps the Gaussians' and the skeleton's optimizers back to back: two
+    launches of ~5 us floor each and a second Adam kernel otherwise).  Other optimizers in the list are stepped as they are."""
+    fused = [o for o in optimizers if isinstance(o, FusedAdam)]
+    caps = {bool(getattr(o, "hip_capturable", False)) for o in fused}
+    if len(fused) < 2 or len(caps) != 1:
+        for o in optimizers:
+            o.step()
+        return
+    by_cfg = {}
+    for o in fused:
+        o._gather(by_cfg)
+    _launch(by_cfg, caps.pop())
+    for o in optimizers:
+        if not isinstance(o, FusedAdam):
+            o.step()
 
 
 def densify_stats(viewspace_grad, update_filter, xyz_gradient_accum, denom, radii=None, max_radii2D=None):

@@ -187,3 +187,34 @@ def test_capturable_adam_replays_in_a_hipgraph_like_eager_torch_adam():
     for a, b in zip(pa, pb):
         torch.testing.assert_close(a.detach(), b.detach(), rtol=5e-6, atol=5e-7 * float(b.detach().abs().max()))
         assert float(oa.state[a]["step"]) == 5.0 and oa.state[a]["step"].is_cuda
+
+
+@pytest.mark.parametrize("capturable", [False, True])
+def test_step_many_equals_stepping_each_optimizer(capturable):
+    """``optim.step_many`` (one step-count increment and one Adam launch per (betas, eps) across the optimizers — what a
+    captured train step uses for the Gaussians' and the skeleton's optimizers) gives bit for bit what ``o.step()`` per
+    optimizer gives, lazy state initialisation and a different configuration (its own launch) included."""
+    from riggs_amd.optim import FusedAdam, step_many
+    g = torch.Generator().manual_seed(7)
+    shapes = [(301, 3), (17,), (64, 8), (5, 5, 5)]
+
+    def make():
+        ps = [torch.randn(*s, generator=torch.Generator().manual_seed(11 + i)).cuda().requires_grad_(True) for i, s in enumerate(shapes)]
+        a = FusedAdam([{"params": [ps[0]], "lr": 1e-3}, {"params": [ps[1]], "lr": 5e-3}], lr=0.0, eps=1e-15, capturable=capturable)
+        b = FusedAdam([{"params": [ps[2]], "lr": 2e-3}], lr=0.0, eps=1e-15, capturable=capturable)
+        c = FusedAdam([{"params": [ps[3]], "lr": 1e-2}], lr=0.0, eps=1e-8, betas=(0.8, 0.99), capturable=capturable)
+        return ps, [a, b, c]
+    (p1, o1), (p2, o2) = make(), make()
+    for it in range(3):
+        grads = [torch.randn(*s, generator=g).cuda() for s in shapes]
+        for p, q, gr in zip(p1, p2, grads):
+            p.grad, q.grad = gr.clone(), gr.clone()
+        for o in o1:
+            o.step()
+        step_many(o2)
+        for p, q in zip(p1, p2):
+            assert torch.equal(p, q), it
+    for oa, ob in zip(o1, o2):
+        for sa, sb in zip(oa.state.values(), ob.state.values()):
+            assert float(sa["step"]) == float(sb["step"]) == 3.0
+            assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
