@@ -277,6 +277,15 @@ def _oracle_iteration(sc, cam_cpu, gimg_cpu, pose=None, deformed=None, want_save
     dv = O.deform_by_pose(P["xyz"].detach(), sc["joints"], sc["parents"], P["node_radius"], P["local_rotation"],
                           P["global_trans"], sc["motion_mask"], -1)
     if deformed is not None:
+        # the HIP deformation's OWN forward values against the oracle's, BEFORE they replace them (after the substitution
+        # the oracle would agree with whatever the HIP skinning produced): north_star's 1e-4 of the largest value
+        for k, theirs in (("d_xyz", deformed[0]), ("d_rotation", deformed[1])):
+            ours = dv[k].detach()
+            scale = max(float(ours.abs().max()), 1e-30)
+            e = float((theirs - ours).abs().max()) / scale
+            DEFORM_PARITY[k] = float("%.3g" % e)
+            if not e <= DEFORM_BAR:
+                raise RuntimeError("HIP deformation forward differs from the oracle: %s max error %.3g of max|oracle|" % (k, e))
         dv = dict(dv)
         dv["d_xyz"] = dv["d_xyz"] + (deformed[0] - dv["d_xyz"]).detach()
         dv["d_rotation"] = dv["d_rotation"] + (deformed[1] - dv["d_rotation"]).detach()
@@ -296,6 +305,10 @@ def _oracle_iteration(sc, cam_cpu, gimg_cpu, pose=None, deformed=None, want_save
         act = {"means3D": m3.detach(), "opacities": op.detach(), "scales": scl.detach(), "rotations": rot.detach(), "shs": shs.detach()}
         return out, grads, saved, act
     return out["color"], grads, saved.R
+
+
+DEFORM_BAR = 1e-4    # HIP d_xyz / d_rotation vs the oracle's deformation, in units of max|oracle| (observed ~1e-6)
+DEFORM_PARITY = {}   # filled by _oracle_iteration(deformed=...): the last comparison
 
 
 def _cpu_model():
@@ -441,6 +454,8 @@ def parity_at_bench_size(hip_image, hip_grads, ora_image, ora_grads, pose_net=No
         e = max(float((g - h.double().cpu()).abs().max()) for g, h in zip(ref, hip_pose_grads)) / max(tot, 1e-30)
         out["dL/d_pose_net"] = {"max_rel": float("%.3g" % e), "tensors": len(ref)}
         worst_small = max(worst_small, e)
+    if DEFORM_PARITY:  # checked (and enforced) by _oracle_iteration before the HIP values replaced the oracle's
+        out["deform_forward_vs_oracle_max_rel"] = dict(DEFORM_PARITY, bar=DEFORM_BAR)
     worst = max(v["outlier_frac"] for v in out.values() if "outlier_frac" in v)
     out["worst_outlier_frac"] = worst
     out["worst_small_tensor_max_rel"] = float("%.3g" % worst_small)

@@ -25,6 +25,19 @@ typedef void* riggs_stream; /* hipStream_t */
 int riggs_version(void);
 const char* riggs_last_error(void);
 
+/* Library options (process-wide; the library reads NOTHING from the environment).  Names and defaults:
+ *   "fwd_wide_tiles"    256   at most this many tiles per frame are composited by the forward's 32-lanes-per-pixel blocks (0 = none)
+ *   "fwd_wide_min"      4096  ... the tiles whose walk went this many instances deep in the previous frame of the same arena
+ *                             and whose list is that long now (minimum 256; a negative value restores the default)
+ *   "bin_grouped"       -1    which tile sort riggs_raster_render runs where both fit: -1 = chosen by the number of Gaussians
+ *                             and of tiles, 0 = the direct counting sort, 1 = the two-level sort (identical lists, bit for bit).
+ *                             riggs_raster_binning_bytes reserves the larger of the two layouts, so flipping this never
+ *                             invalidates an arena
+ *   "cnode_bwd_atomics" 0     1 = riggs_cnode_backward's first design (LDS float atomics); set it BEFORE sizing its workspace
+ * Unknown names fail.  Set them between frames, not while a launch that reads them is being issued from another thread. */
+int riggs_set_option(const char* name, int32_t value);
+int riggs_get_option(const char* name, int32_t* value);
+
 /* =====================================================================
  * Rasterizer.  Replaces the un-vendored CUDA extension
  *   diff_gaussian_rasterization._C.rasterize_gaussians / rasterize_gaussians_backward
@@ -59,7 +72,10 @@ typedef struct riggs_raster_cfg {
    * float atomics into the per-Gaussian accumulators, every (tile instance) writes its partial gradient row and a second
    * kernel sums each Gaussian's rows in ascending tile order: gradients are bitwise reproducible run to run.  Needs the
    * larger workspace of riggs_raster_backward_workspace_bytes_ordered; slower (tests / debugging).
-   * (riggs_raster_render is bitwise reproducible with or without it: no two workgroups share a pixel.) */
+   * riggs_raster_render: with it the forward never uses the previous frame's walk history, so it is bitwise reproducible
+   * frame after frame; without it the forward is bitwise reproducible only while no tile is composited wide — always in a
+   * fresh (zero-filled) binning arena — because a tile composited by the 32-lane blocks folds its sums in another order
+   * (same values to ~1e-7; "fwd_wide_tiles" = 0 turns that off as well). */
   int32_t deterministic;
   /* riggs_raster_backward only.  1 = the caller guarantees that the gradient output buffers are the SAME buffers the previous
    * riggs_raster_backward with this workspace wrote and that nobody has written them since (or that buffers and workspace
@@ -73,11 +89,19 @@ typedef struct riggs_raster_cfg {
 
 /* Opaque arenas (upstream: geomBuffer / binningBuffer / imgBuffer byte tensors).  The binning arena's size depends on ALL
  * four arguments (the tile sort's tables are sized by the number of Gaussians and of tiles, not only by the instance
- * capacity): ask again when the scene or the image grows. */
+ * capacity) and is NOT monotonic in them in general: ask again whenever num_points, image_height or image_width change
+ * (in either direction), and pass the arena's byte size to riggs_raster_render, which rejects an arena that is too small
+ * for its arguments.  A freshly allocated binning arena must be zero-filled once (its walk-history stamp). */
 size_t riggs_raster_geom_bytes(int32_t num_points);
 size_t riggs_raster_image_bytes(int32_t image_height, int32_t image_width);
 size_t riggs_raster_binning_bytes(int64_t instance_capacity, int32_t num_points, int32_t image_height,
                                   int32_t image_width);
+/* The binning arena carries ONE piece of state from frame to frame: how deep the forward walked every tile's list (which
+ * tiles the next frame composites with 32 lanes per pixel), valid when a stamp word derived from the tile and Gaussian
+ * counts follows it.  Call this after allocating an arena and whenever (capacity, N, H, W) change for an arena in use
+ * (the words' offset depends on them): the next frame then starts without a history.  Equivalent: zero-fill the arena. */
+int riggs_raster_binning_reset_history(void* binning, int64_t instance_capacity, int32_t num_points, int32_t image_height,
+                                       int32_t image_width, riggs_stream stream);
 
 /* Field offsets (bytes) inside the arenas, for tests / debugging tools. */
 enum {
@@ -95,6 +119,7 @@ enum {
   RIGGS_IMG_FINAL_T = 0,   /* float  H*W */
   RIGGS_IMG_N_CONTRIB,     /* uint32 H*W */
   RIGGS_IMG_RANGES,        /* uint2  tiles */
+  RIGGS_IMG_FWD_CTR,       /* uint32[3] of the last forward: non-empty tiles, tiles composited by the 32-lane blocks, empty tiles */
   RIGGS_IMG_NFIELDS_
 };
 enum {
@@ -127,11 +152,12 @@ int riggs_raster_preprocess(const riggs_raster_cfg* cfg, const float* means3D, c
  * duplicateWithKeys + 64-bit key sort + identifyTileRanges — and the per-tile alpha compositing.
  * Limits: at most 65 535 tiles and ~4 200 groups of eight tiles in a row (3840 x 2160 px is fine): beyond 25 600 tiles, and
  * from 500 000 Gaussians over 4 096 tiles on, the sort runs in two levels (by tile group, then by tile; the same list bit
- * for bit; RIGGS_BIN_GROUPED=0/1 in the environment forces the choice where both fit) — larger images are rejected with an
+ * for bit; riggs_set_option("bin_grouped", 0 / 1) forces the choice where both fit) — larger images are rejected with an
  * error, never mis-rendered.  `instance_capacity` bounds R: if R > capacity the launch is
  * still memory-safe, counters[1] is set to 1 and the image is undefined (caller retries
  * with a larger arena; riggs_amd.rasterizer does that). */
 int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom, void* binning, int64_t instance_capacity,
+                        size_t binning_bytes /* size of `binning`: must be >= riggs_raster_binning_bytes(capacity, N, H, W) */,
                         void* image_state, float* out_color /*(3,H,W)*/, float* out_depth /*(1,H,W)*/,
                         float* out_alpha /*(1,H,W)*/, uint32_t* counters, riggs_stream stream);
 
@@ -436,8 +462,7 @@ int riggs_dist2_knn3(int32_t num_points, const float* points, float* out, void* 
  * survivors | hardware id << 32, steps, steps with a contribution, list length | tile << 32 | wide << 63, start tick, 0}),
  * followed (at word n_items * 32; n_items = riggs_raster_set_trace_items, default 8 per tile) by 4 u64 per chunk of the
  * compositing backward ({start, end, hardware id, workgroup << 32 | tile << 16 | chunk}); tools/fwd_trace.py, bwd_trace.py.
- * Environment (read once, tuning knobs for tools): RIGGS_FWD_WIDE_TILES = the tiles with the longest lists that the forward
- * composites with 32 lanes per pixel (default 256, 0 = none), RIGGS_FWD_WIDE_MIN = from this list length (default 2048).
+ * (How many tiles the forward may composite with 32 lanes per pixel and from which walk depth: riggs_set_option.)
  * NULL disables */
 int riggs_raster_set_trace(void* dev_u64);
 int riggs_raster_set_trace_items(uint64_t n_items);

@@ -14,7 +14,7 @@ SO_PATH = os.path.join(_HERE, "lib", "libriggs_hip.so")
 # enum mirrors (include/riggs_hip.h)
 GEOM_XYD, GEOM_CONIC_O, GEOM_RGB, GEOM_COV3D, GEOM_CLAMPED, GEOM_TILES, GEOM_RECT, GEOM_DEPTH_ORDER, \
     GEOM_NFIELDS = range(9)
-IMG_FINAL_T, IMG_N_CONTRIB, IMG_RANGES, IMG_NFIELDS = range(4)
+IMG_FINAL_T, IMG_N_CONTRIB, IMG_RANGES, IMG_FWD_CTR, IMG_NFIELDS = range(5)
 BIN_POINT_LIST, BIN_TILE_KEYS, BIN_NFIELDS = range(3)
 
 
@@ -45,7 +45,10 @@ _SIGS = {
     "riggs_raster_image_layout": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
     "riggs_raster_binning_layout": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
     "riggs_raster_preprocess": (C.c_int, [C.POINTER(RasterCfg)] + [_P] * 11 + [_P, _P, _P, _P]),
-    "riggs_raster_render": (C.c_int, [C.POINTER(RasterCfg), _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P]),
+    "riggs_set_option": (C.c_int, [C.c_char_p, C.c_int32]),
+    "riggs_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32)]),
+    "riggs_raster_binning_reset_history": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "riggs_raster_render": (C.c_int, [C.POINTER(RasterCfg), _P, _P, C.c_int64, C.c_size_t, _P, _P, _P, _P, _P, _P]),
     "riggs_raster_backward": (C.c_int, [C.POINTER(RasterCfg)] + [_P] * 11 + [_P, _P, _P, C.c_int64, _P, _P] + [_P] * 3
                               + [_P] + [_P] * 10 + [_P]),
     "riggs_fk_forward": (C.c_int, [C.c_int32] + [_P] * 8),
@@ -117,6 +120,17 @@ def lib():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+def set_option(name: str, value: int):
+    """riggs_set_option (include/riggs_hip.h): "fwd_wide_tiles", "fwd_wide_min", "bin_grouped", "cnode_bwd_atomics"."""
+    check(lib().riggs_set_option(name.encode(), int(value)), "riggs_set_option")
+
+
+def get_option(name: str) -> int:
+    v = C.c_int32()
+    check(lib().riggs_get_option(name.encode(), C.byref(v)), "riggs_get_option")
+    return int(v.value)
 
 
 def exported_symbols():

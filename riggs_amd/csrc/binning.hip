@@ -109,9 +109,10 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(int T, int n_chunks, uin
 // forward composites WIDE (render.hip) — the ones whose walk went o.wide_min instances deep in the PREVIOUS frame of this arena
 // (o.walk_hist: max n_contrib per tile, written by the forward; how deep a walk goes is a property of the scene and the view —
 // a list's length says nothing about it: the longest lists of the bench scene, 48 000 instances, saturate within 800) and
-// whose list is that long now; the first o.wide_tiles of them in tile order.  Without a history (a fresh arena: the stamp
-// behind the last tile is missing) or with cfg.deterministic (wide_tiles = 0) no tile is wide.
-#define WALK_HIST_STAMP(T) (0x5EED0000u ^ (uint32_t)(T) * 2654435761u)
+// whose list is that long now; the first o.wide_tiles of them in tile order.  Without a history (the stamp behind the last
+// tile — a function of the tile and Gaussian counts, o.hist_stamp — is missing: the arena's owner zero-fills the words when
+// it allocates the arena or changes the scene / image size, riggs_raster_binning_reset_history) or with cfg.deterministic
+// (wide_tiles = 0) no tile is wide.
 __device__ void bin_offsets_body(int T, int64_t cap, const uint32_t* __restrict__ tile_count, const BinOut o,
                                  const uint32_t* __restrict__ total_src = nullptr, int n_total_src = 0) {
   uint2* __restrict__ ranges = o.ranges;
@@ -129,7 +130,7 @@ __device__ void bin_offsets_body(int T, int64_t cap, const uint32_t* __restrict_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) { s_carry = 0u; s_nempty = 0u; s_wcarry = 0u; }
   if (tid < 33) s_hist[tid] = 0u;
-  const bool have_hist = o.wide_tiles > 0u && walk_hist[T] == WALK_HIST_STAMP(T);
+  const bool have_hist = o.wide_tiles > 0u && walk_hist[T] == o.hist_stamp;
   __syncthreads();
   uint32_t my_len[8];  // list lengths of this thread's tiles (the first 8 passes; beyond that they are re-read)
 #pragma unroll
@@ -173,7 +174,7 @@ __device__ void bin_offsets_body(int T, int64_t cap, const uint32_t* __restrict_
     if (tid == nthr - 1) { s_carry = carry + wave_off + v; s_wcarry = wrank + (cand ? 1u : 0u); }
     __syncthreads();
   }
-  if (tid == 0) walk_hist[T] = WALK_HIST_STAMP(T);
+  if (tid == 0) walk_hist[T] = o.hist_stamp;
   if (total_src) {
     // (the grouped binning counts only the instances that fit the arena per tile: the true total comes from its group counts)
     __shared__ uint32_t s_tot;
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(int N, int T, int gri
 //       parts of BIN_PART instances (one workgroup each): gbin_tcount (per part and tile), gbin_tscatter.
 // Order: groups by (row, column block) = ascending tile id blocks; inside a group the level-1 order (depth) is kept by both
 // levels: the same list as the direct sort, bit for bit (tests/test_gpu_raster.py: 32 400 tiles against the oracle's key
-// sort; tests/test_gpu_configs.py: C4 and C5 take this path; the whole raster suite also passes with RIGGS_BIN_GROUPED=1).
+// sort; tests/test_gpu_configs.py: C4 and C5 take this path; the whole raster suite also passes with riggs_set_option("bin_grouped", 1)).
 // Why it pays at 2 M Gaussians / 8160 tiles / 38.8 M instances (0.40 ms against 0.70 ms): the direct sort's walk is 38.8 M
 // 4-byte stores to as many different lines; here level 1 writes a SPAN — a rectangle's columns inside one group, up to 32
 // bytes — with one to four stores, and level 2 moves whole parts through LDS with coalesced loads and stores.  What it took
@@ -903,14 +904,11 @@ static BinPlan bin_plan(int N, int T) {
 // which sort?  Beyond BIN_GROUPED_MIN_T tiles only the grouped one fits; below, it wins on many Gaussians over many tiles
 // (2 M / 8160 tiles / 38.8 M instances: 0.40 ms against 0.70 ms; 500 k / 4096 tiles / 4.5 M instances: the frame 0.531
 // against 0.551 ms) and loses on the small scenes (300 k / 2500 tiles: +0.04 ms per frame, 150 k / 2500: +0.02 — its five
-// launches cost more than they save).  RIGGS_BIN_GROUPED=0 / 1 overrides the choice where both fit (measurements, tests).
+// launches cost more than they save).  riggs_set_option("bin_grouped", 0 / 1) overrides the choice where both fit
+// (measurements, tests; -1 = by size, the default).
 static bool bin_grouped(int N, int T) {
   if (T > BIN_GROUPED_MIN_T) return true;
-  static int forced = -2;
-  if (forced == -2) {
-    const char* e = getenv("RIGGS_BIN_GROUPED");
-    forced = (e && *e) ? atoi(e) : -1;
-  }
+  const int forced = option(OPT_BIN_GROUPED);
   if (forced >= 0) return forced != 0 && T >= 64;
   return T >= BIN_GROUPED_AUTO_T && N >= BIN_GROUPED_AUTO_N;
 }
@@ -940,14 +938,21 @@ static GBinPlan gbin_plan(int N, int T, int grid_x) {
   return p;
 }
 
+// (the larger of the two sorts' tables wherever both sorts fit: which one runs — by size, or forced with
+// riggs_set_option("bin_grouped") — then never changes what an arena must hold, and pruning a scene across the switch
+// (499 999 Gaussians instead of 500 000 over 25 600 tiles) does not ask for a LARGER arena than before)
 size_t bin_table_bytes(int N, int T, int grid_x) {
-  if (bin_grouped(N, T)) {
+  size_t grouped = 0, direct = 0;
+  if (T >= 64) {
     GBinPlan p = gbin_plan(N > 0 ? N : 1, T, grid_x);
-    return align_up(((size_t)p.n_chunks + 1) * p.G * 4) + align_up((size_t)(p.G + 1) * 4) + align_up((size_t)(T + 1) * 4) +
-           align_up((size_t)p.n_chunks * p.W * ((p.G + 1) & ~1) * 2) + align_up((size_t)(N > 0 ? N : 1) * 8);
+    grouped = align_up(((size_t)p.n_chunks + 1) * p.G * 4) + align_up((size_t)(p.G + 1) * 4) + align_up((size_t)(T + 1) * 4) +
+              align_up((size_t)p.n_chunks * p.W * ((p.G + 1) & ~1) * 2) + align_up((size_t)(N > 0 ? N : 1) * 8);
   }
-  BinPlan p = bin_plan(N > 0 ? N : 1, T);
-  return align_up(((size_t)p.n_chunks + 1) * T * 4) + align_up((size_t)(T + 1) * 4) + align_up((size_t)(N > 0 ? N : 1) * 8);
+  if (T <= BIN_GROUPED_MIN_T) {
+    BinPlan p = bin_plan(N > 0 ? N : 1, T);
+    direct = align_up(((size_t)p.n_chunks + 1) * T * 4) + align_up((size_t)(T + 1) * 4) + align_up((size_t)(N > 0 ? N : 1) * 8);
+  }
+  return grouped > direct ? grouped : direct;
 }
 size_t bin_scratch_bytes(int64_t cap, int T, int grid_x) {  // (grouped binning: lives in the checkpoint area)
   GBinPlan p = gbin_plan(1, T, grid_x);

@@ -17,6 +17,12 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// ---- library options -------------------------------------------------------------------
+static const char* kOptNames[OPT_COUNT] = {"fwd_wide_tiles", "fwd_wide_min", "bin_grouped", "cnode_bwd_atomics"};
+static const int kOptDefaults[OPT_COUNT] = {256, 4096, -1, 0};
+static int g_opt[OPT_COUNT] = {256, 4096, -1, 0};
+int option(int id) { return g_opt[id]; }
+
 // ---- event-based kernel timing -------------------------------------------------------
 static const char* kProfNames[PROF_COUNT] = {
     "preprocess_fwd", "depth_sort", "tile_sort", "render_fwd", "render_bwd",
@@ -130,6 +136,28 @@ int riggs_prof_read(int32_t id, float* total_ms, int32_t* launches) {
 }
 const char* riggs_last_error(void) { return g_err; }
 
+static int opt_id(const char* name) {
+  for (int i = 0; i < OPT_COUNT; i++) if (name && !strcmp(name, kOptNames[i])) return i;
+  return -1;
+}
+int riggs_set_option(const char* name, int32_t value) {
+  const int id = opt_id(name);
+  if (id < 0) { set_error("riggs_set_option: unknown option '%s'", name ? name : "(null)"); return 2; }
+  int v = value;
+  if (id == OPT_FWD_WIDE_TILES) { if (v < 0) v = kOptDefaults[id]; if (v > 65535) v = 65535; }
+  if (id == OPT_FWD_WIDE_MIN) { if (v < 0) v = kOptDefaults[id]; if (v < 256) v = 256; }
+  if (id == OPT_BIN_GROUPED) { if (v < -1 || v > 1) { set_error("riggs_set_option: bin_grouped takes -1 (by size), 0 or 1"); return 2; } }
+  if (id == OPT_CNODE_BWD_ATOMICS) v = v ? 1 : 0;
+  g_opt[id] = v;
+  return 0;
+}
+int riggs_get_option(const char* name, int32_t* value) {
+  const int id = opt_id(name);
+  if (id < 0 || !value) { set_error("riggs_get_option: unknown option '%s'", name ? name : "(null)"); return 2; }
+  *value = g_opt[id];
+  return 0;
+}
+
 size_t riggs_raster_geom_bytes(int32_t N) { return geom_layout(N).total; }
 size_t riggs_raster_image_bytes(int32_t H, int32_t W) { return image_layout(H, W).total; }
 size_t riggs_raster_binning_bytes(int64_t cap, int32_t N, int32_t H, int32_t W) { return bin_layout(cap, N, H, W).total; }
@@ -154,6 +182,7 @@ int riggs_raster_geom_layout(int32_t N, size_t* o) {
 int riggs_raster_image_layout(int32_t H, int32_t W, size_t* o) {
   ImageLayout L = image_layout(H, W);
   o[RIGGS_IMG_FINAL_T] = L.final_T; o[RIGGS_IMG_N_CONTRIB] = L.n_contrib; o[RIGGS_IMG_RANGES] = L.ranges;
+  o[RIGGS_IMG_FWD_CTR] = L.fwd_ctr;
   return 0;
 }
 int riggs_raster_binning_layout(int64_t cap, int32_t N, int32_t H, int32_t W, size_t* o) {
@@ -229,12 +258,25 @@ int riggs_raster_preprocess(const riggs_raster_cfg* cfg, const float* means3D, c
   return 0;
 }
 
-int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* binning_, int64_t cap, void* image_,
-                        float* out_color, float* out_depth, float* out_alpha, uint32_t* counters,
+int riggs_raster_binning_reset_history(void* binning_, int64_t cap, int32_t N, int32_t H, int32_t W, riggs_stream stream_) {
+  RIGGS_REQUIRE(binning_ != nullptr && H > 0 && W > 0, "bad arguments");
+  const size_t T = (size_t)((W + RIGGS_TILE - 1) / RIGGS_TILE) * ((H + RIGGS_TILE - 1) / RIGGS_TILE);
+  BinLayout B = bin_layout(cap, N, H, W);
+  RIGGS_HIP_CHECK(hipMemsetAsync((char*)binning_ + B.walk_hist, 0, (T + 2) * 4, (hipStream_t)stream_));
+  return 0;
+}
+
+int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* binning_, int64_t cap, size_t binning_bytes,
+                        void* image_, float* out_color, float* out_depth, float* out_alpha, uint32_t* counters,
                         riggs_stream stream_) {
   hipStream_t s = (hipStream_t)stream_;
   RIGGS_REQUIRE(cfg != nullptr, "cfg is NULL");
   const int N = cfg->num_points, H = cfg->image_height, W = cfg->image_width;
+  if (binning_bytes < bin_layout(cap, N, H, W).total) {
+    set_error("riggs_raster_render: the binning arena (%zu bytes) is smaller than riggs_raster_binning_bytes(%lld, %d, %d, %d) = %zu",
+              binning_bytes, (long long)cap, N, H, W, bin_layout(cap, N, H, W).total);
+    return 2;
+  }
   const int gx = (W + RIGGS_TILE - 1) / RIGGS_TILE, gy = (H + RIGGS_TILE - 1) / RIGGS_TILE, T = gx * gy;
   const char* geom = (const char*)geom_;
   char* bin = (char*)binning_;
@@ -256,6 +298,7 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
     bo.counters = counters; bo.fwd_items = (uint32_t*)(bin + B.fwd_items); bo.fwd_empty = (uint32_t*)(img + I.fwd_empty);
     bo.fwd_ctr = (uint32_t*)(img + I.fwd_ctr); bo.wide_tiles = cfg->deterministic ? 0u : forward_wide_tiles(); bo.wide_min = forward_wide_min();
     bo.walk_hist = (uint32_t*)(bin + B.walk_hist);
+    bo.hist_stamp = 0x5EED0000u ^ ((uint32_t)T * 2654435761u) ^ ((uint32_t)N * 0x9E3779B1u);
     int rcb = launch_binning(N, T, gx, cap, (const uint32_t*)(geom + G.order), (const uint32_t*)(geom + G.tiles),
                              (const ushort4*)(geom + G.rect), bin + B.table, bin + B.ckpt /* free until the compositing */,
                              (uint32_t*)(bin + B.point_list),

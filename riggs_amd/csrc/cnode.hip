@@ -11,7 +11,7 @@
 // 21 + hyper_dim contributions (translation, rotation, scale, dL/dR of the local frame, radius, node weight, hyper coordinates)
 // as a 128-byte row at the entry's sorted position, and one workgroup per node that sums its contiguous rows and applies the
 // node-level chain rules (quaternion -> matrix, exp, sigmoid).  The first backward (LDS float atomics + per-workgroup partial
-// tables) is kept behind RIGGS_CNODE_BWD=atomics: the LDS executes float atomics lane by lane.  Forward is issue-bound by the
+// tables) is kept behind riggs_set_option("cnode_bwd_atomics", 1): the LDS executes float atomics lane by lane.  Forward is issue-bound by the
 // scan (N M (3 + hyper) FMAs); the tables it reads are L2-resident.
 #include "common.h"
 
@@ -496,11 +496,7 @@ static int cn_list_blocks(int N, int K) {
   return b < 1 ? 1 : b;
 }
 
-static bool cn_use_lists() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("RIGGS_CNODE_BWD"); v = (e && !strcmp(e, "atomics")) ? 0 : 1; }
-  return v == 1;
-}
+static bool cn_use_lists() { return option(OPT_CNODE_BWD_ATOMICS) == 0; }
 
 size_t riggs_cnode_backward_workspace_floats(int32_t N, int32_t M, int32_t K, int32_t hyper) {
   const size_t atomics = (size_t)riggs_cnode_backward_blocks(N, M, hyper) * M * (CN_ACC_FIXED + hyper);

@@ -110,6 +110,7 @@ struct BinOut {  // what the extra workgroup of bin_scatter_kernel writes once p
   uint32_t *slot_base, *tile_max, *counters, *fwd_items, *fwd_empty, *fwd_ctr;
   uint32_t* walk_hist;   // [T + 1] per tile: how deep the forward's walk went in the previous frame (max n_contrib); read, then
                          // bit 31 = composited wide in this frame; [T] = a stamp that says the words are a history
+  uint32_t hist_stamp;   // the value of walk_hist[T] that marks a history of THIS scene size and tile grid
   uint32_t wide_tiles;   // at most this many tiles are composited wide by the forward (0: none) ...
   uint32_t wide_min;     // ... the ones whose walk was, and whose list is, this many instances deep (forward_wide_tiles / forward_wide_min)
 };

@@ -58,8 +58,8 @@ __device__ __forceinline__ float oct_sum(float v) {
 // such list (headline: 25 rounds = 57 us for 35 - 40 us of issue; a scene of thin shells seen edge-on: 70 rounds = 160 us for
 // 30 us of issue).  What shortens the walk is more SIMDs for the same pixels, and that means more workgroups per tile (a
 // workgroup lives on one CU: more waves in it share the same four SIMDs).  So the tiles whose walk went deep in the previous
-// frame (the first `n_wide` entries of the work list — binning.hip, bin_offsets_body: RIGGS_FWD_WIDE_MIN instances and more,
-// at most RIGGS_FWD_WIDE_TILES tiles; a list's LENGTH says nothing: the bench scene's longest lists saturate within 800 instances)
+// frame (the first `n_wide` entries of the work list — binning.hip, bin_offsets_body: "fwd_wide_min" instances and more,
+// at most "fwd_wide_tiles" tiles (riggs_set_option); a list's LENGTH says nothing: the bench scene's longest lists saturate within 800 instances)
 // are composited with THIRTY-TWO lanes per pixel: a wave is 2 pixels x 32 instance lanes, a workgroup a 4 x 2 pixel block, a
 // tile 32 workgroups instead of 8.  A scan step then covers 32 consecutive instances of a pixel (8 steps per round instead of
 // 32) at about the same instruction count — the exclusive product scan is five DPP multiplies instead of the quad permutes —,
@@ -474,27 +474,10 @@ __global__ __launch_bounds__(256, 6) void render_fwd_oct_kernel(RenderArgs a) {
   }
 }
 
-// the tiles that may be composited wide per launch, and the list length from which a tile is (RIGGS_FWD_WIDE_TILES,
-// RIGGS_FWD_WIDE_MIN override: tuning knobs for tools; 0 tiles turns the wide form off)
-uint32_t forward_wide_tiles() {
-  static int64_t v = -1;
-  if (v < 0) {
-    const char* e = getenv("RIGGS_FWD_WIDE_TILES");
-    v = e ? atoll(e) : 256;
-    if (v < 0) v = 0;
-    if (v > 65535) v = 65535;
-  }
-  return (uint32_t)v;
-}
-uint32_t forward_wide_min() {
-  static int64_t v = -1;
-  if (v < 0) {
-    const char* e = getenv("RIGGS_FWD_WIDE_MIN");
-    v = e ? atoll(e) : 4096;
-    if (v < 256) v = 256;
-  }
-  return (uint32_t)v;
-}
+// the tiles that may be composited wide per launch (default 256; 0 turns the wide form off), and the walk depth / list length
+// from which a tile is (default 4096): riggs_set_option("fwd_wide_tiles" / "fwd_wide_min"), for tools and tests
+uint32_t forward_wide_tiles() { return (uint32_t)option(OPT_FWD_WIDE_TILES); }
+uint32_t forward_wide_min() { return (uint32_t)option(OPT_FWD_WIDE_MIN); }
 
 int launch_render_fwd(const RenderArgs& a, hipStream_t s) {
   const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE, gy = (a.H + RIGGS_TILE - 1) / RIGGS_TILE;

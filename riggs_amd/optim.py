@@ -116,7 +116,12 @@ def step_many(optimizers):
     launches of ~5 us floor each and a second Adam kernel otherwise).  Other optimizers in the list are stepped as they are."""
     fused = [o for o in optimizers if isinstance(o, FusedAdam)]
     caps = {bool(getattr(o, "hip_capturable", False)) for o in fused}
-    if len(fused) < 2 or len(caps) != 1:
+    # an optimizer with registered step hooks, or whose ``step`` an lr_scheduler has wrapped (it counts the calls and warns
+    # when ``scheduler.step()`` comes first), must go through ITS ``step()``: the merged launch below bypasses both
+    from torch.optim.optimizer import _global_optimizer_post_hooks, _global_optimizer_pre_hooks
+    hooked = bool(_global_optimizer_pre_hooks or _global_optimizer_post_hooks) or any(
+        o._optimizer_step_pre_hooks or o._optimizer_step_post_hooks or hasattr(o.step, "_wrapped_by_lr_sched") for o in fused)
+    if len(fused) < 2 or len(caps) != 1 or hooked:
         for o in optimizers:
             o.step()
         return

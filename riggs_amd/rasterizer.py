@@ -47,6 +47,7 @@ class RasterArena:
         self.last_R = -1
         self._pending = None  # (event, pinned host counters, capacity used)
         self.static_counters = None
+        self._layout_key = None  # (capacity, N, H, W) the arena's walk history belongs to
 
     def _post(self, counters: torch.Tensor, cap: int):
         """Queue an asynchronous read-back of (R, overflow) behind the frame just launched."""
@@ -86,10 +87,22 @@ class RasterArena:
             # enough instances — but the arena also holds tables sized by the number of Gaussians and of tiles (the tile
             # sort's chunk x tile table): a scene that grew, or a larger image, needs a larger arena at the same capacity
             if L.lib().riggs_raster_binning_bytes(self.capacity, N, H, W) <= self.binning.numel():
-                return self.binning
+                return self._with_fresh_history(N, H, W)
             cap = self.capacity
         self.binning = torch.empty(L.lib().riggs_raster_binning_bytes(cap, N, H, W), dtype=torch.uint8, device=device)
         self.capacity = cap
+        self._layout_key = None
+        return self._with_fresh_history(N, H, W)
+
+    def _with_fresh_history(self, N: int, H: int, W: int):
+        """The arena's one piece of frame-to-frame state — how deep the forward walked every tile's list — sits at an offset
+        that depends on (capacity, N, H, W) and is trusted when a stamp word follows it: a new allocation (torch.empty may hand
+        back a block that still holds another arena's stamp) or a changed scene / image size starts without a history."""
+        key = (self.capacity, N, H, W)
+        if self._layout_key != key:
+            L.check(L.lib().riggs_raster_binning_reset_history(self.binning.data_ptr(), self.capacity, N, H, W, L.stream_ptr()),
+                    "riggs_raster_binning_reset_history")
+            self._layout_key = key
         return self.binning
 
 
@@ -123,7 +136,9 @@ ORDERED_BACKWARD = False
 def set_ordered_backward(on: bool = True):
     """Reproducible mode (riggs_raster_cfg.deterministic): the compositing backward sums per-instance gradient rows per
     Gaussian in ascending tile order instead of float atomics — bitwise reproducible gradients, for tests and debugging
-    (the image is bitwise reproducible in either mode).  Applies to rasterizations started after the call."""
+    (SURVEY.md §5).  It also makes the forward ignore the arena's walk history: with it the image is bitwise reproducible frame
+    after frame; without it only while no tile is composited by the forward's 32-lane blocks — always in a fresh arena —,
+    whose sums fold in another order (same values to ~1e-7).  Applies to rasterizations started after the call."""
     global ORDERED_BACKWARD
     ORDERED_BACKWARD = bool(on)
 
@@ -165,13 +180,14 @@ def rasterize_forward(settings, means3D, shs, colors_precomp, opacities, scales,
             arena.last_R = R
         else:
             binning = torch.empty(lib.riggs_raster_binning_bytes(cap, N, H, W), dtype=torch.uint8, device=dev)
+            L.check(lib.riggs_raster_binning_reset_history(binning.data_ptr(), cap, N, H, W, st), "riggs_raster_binning_reset_history")
         s.R = R
     else:
         arena.resolve(block=True)
         binning = arena.ensure(int(arena.last_R * arena.growth) + 1, N, H, W, dev)
         cap = arena.capacity
         s.R = None  # unknown until counters are read
-    L.check(lib.riggs_raster_render(C.byref(cfg), geom.data_ptr(), binning.data_ptr(), cap, img.data_ptr(),
+    L.check(lib.riggs_raster_render(C.byref(cfg), geom.data_ptr(), binning.data_ptr(), cap, binning.numel(), img.data_ptr(),
                                     color.data_ptr(), depth.data_ptr(), alpha.data_ptr(), counters.data_ptr(), st),
             "riggs_raster_render")
     if arena is not None and s.R is None:
@@ -393,6 +409,7 @@ def saved_views(s: _Saved):
         "final_T": view(s.img, io[L.IMG_FINAL_T], H * W * 4, torch.float32, (H, W)),
         "n_contrib": view(s.img, io[L.IMG_N_CONTRIB], H * W * 4, torch.int32, (H, W)),
         "ranges": view(s.img, io[L.IMG_RANGES], T * 8, torch.int32, (T, 2)),
+        "fwd_ctr": view(s.img, io[L.IMG_FWD_CTR], 12, torch.int32, (3,)),
         "point_list": view(s.binning, bo[L.BIN_POINT_LIST], s.R * 4, torch.int32, (s.R,)),
         "tile_keys": view(s.binning, bo[L.BIN_TILE_KEYS], s.R * 4, torch.int32, (s.R,)),
         "R": s.R,

@@ -212,17 +212,19 @@ def test_stage1_iteration_through_the_rasterizer_matches_torch_blend():
 
 
 def test_atomics_backward_variant_passes_the_same_goldens():
-    """RIGGS_CNODE_BWD=atomics (the first backward: LDS float atomics + partial tables) is read once per process: run the golden
-    and oracle cases in a child process with the switch set."""
-    import subprocess
-    import sys
-    if os.environ.get("RIGGS_CNODE_BWD") == "atomics":
-        pytest.skip("already inside the child")
-    env = dict(os.environ, RIGGS_CNODE_BWD="atomics")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_cnode.py", "-m", "gpu", "-q", "-x", "-k", "golden or oracle"],
-                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    """riggs_set_option("cnode_bwd_atomics", 1) selects the first backward (LDS float atomics + partial tables): the golden
+    and oracle cases once more with it (workspaces are sized per call, after the option is set)."""
+    from riggs_amd import _lib as L
+    assert L.get_option("cnode_bwd_atomics") == 0
+    L.set_option("cnode_bwd_atomics", 1)
+    try:
+        for name in NAMES:
+            test_module_matches_reference_golden(name)
+        test_against_oracle(20_000, 512, 3, 8, True, True, True, True)
+        test_against_oracle(3_001, 40, 8, 0, True, False, False, True)
+        test_against_oracle(1, 64, 3, 11, True, True, False, True)
+    finally:
+        L.set_option("cnode_bwd_atomics", 0)
 
 
 def test_pred_opacity_and_color_match_reference_golden():

@@ -69,6 +69,7 @@ def test_c4_full_size_properties():
 
 
 PIPE_FRAC = 5e-5     # per tensor: share of the elements allowed beyond 1e-4 of max|oracle| (observed worst: 3.3e-6, one element of C3)
+DEFORM_TOL = 2e-5    # HIP d_xyz / d_rotation vs the oracle's deformation at full size, of max|oracle| (observed ~1e-6; bench.py's bar: 1e-4)
 RADIUS_TOL = 1e-4    # dL/d node_radius (J sums over all Gaussians), relative to its largest entry
 
 
@@ -116,7 +117,15 @@ def _pipeline_parity_vs_oracle(N, J, H, W, cam_cpu, tag, surface=False):
     pose = (na["local_rotation"].detach().cpu(), na["global_trans"].detach().cpu())
     deformed = (dv["d_xyz"].detach().cpu(), dv["d_rotation"].detach().cpu())
     bench._set_threads(16)
+    bench.DEFORM_PARITY.clear()
     out_o, ora_grads, so, act = bench._oracle_iteration(sc, cam_cpu, gimg, pose, deformed=deformed, want_saved=True)
+    # ---- (0) the HIP deformation's forward values against the oracle's own (oracle/deform_ref.py restating
+    # skeleton_warp.py:130-172), checked inside _oracle_iteration BEFORE they replace them: without this the oracle below
+    # rasterizes whatever the HIP skinning produced and agrees with it (at C5 this is the two-Gaussians-per-lane instantiation)
+    assert set(bench.DEFORM_PARITY) == {"d_xyz", "d_rotation"}
+    for k, e in bench.DEFORM_PARITY.items():
+        U.STATS.append((tag + " full size deform forward " + k, int(N), 0.0, float(e), 0.0))
+        assert e <= DEFORM_TOL, (tag, k, e)
     # ---- (1) the rasterizer's forward state on identical activated inputs: bit-exact ordering and indexing at FULL size
     color, radii, depth, alpha, s = U.hip_forward(act, cam_cpu, [0.0, 0.0, 0.0])
     U.compare_forward_state(so, saved_views(s), out_o, color, depth, alpha, radii)

@@ -104,6 +104,42 @@ def test_deform_matches_oracle_large(N, J, chain, seed):
     U.assert_close(sw._node_radius.grad.cpu().numpy(), rho.grad.numpy(), "dL/d_node_radius", 2e-4)
 
 
+@pytest.mark.parametrize("N,J,two", [(1_000_001, 16, True), (1_000_000, 15, False), (999_999, 64, False), (2_000_000, 64, True)])
+def test_deform_forward_values_vs_oracle_at_both_sides_of_the_two_per_lane_switch(N, J, two):
+    """The skinning forward takes TWO Gaussians per lane from a million Gaussians and 16 joints on (csrc/deform.hip:
+    LBS_PTS2_MIN_N / LBS_PTS2_MIN_J — the C5 path): its output VALUES against oracle/deform_ref.py (which restates
+    skeleton_warp.py:130-172) at sizes on both sides of the switch, with a ragged last block, through both entry points —
+    riggs_lbs_forward (deform_by_pose: FK as its own launch) and riggs_lbs_forward_fk (SkeletonWarp.forward: FK inside).  The
+    oracle runs in slices of 125k Gaussians (the deformation of a Gaussian depends on the pose alone)."""
+    assert (N >= 1_000_000 and J >= 16) == two
+    sc = synth.make_scene(N, J, 77 + J)
+    g = torch.Generator().manual_seed(N % 1000 + J)
+    mask = torch.rand(N, 1, generator=g)  # a real motion mask, not ones
+    sw = make_warp(sc["joints"], sc["parents"], sc["node_radius"], -1)
+    x = sc["xyz"].cuda()
+    with torch.no_grad():
+        h = sw.deform_by_pose(x, {"local_rotation": sc["local_rotation"].cuda(), "global_trans": sc["global_trans"].cuda()}, mask.cuda())
+        t = sw.expand_time(torch.tensor([0.41], device="cuda"))
+        f = sw(x, t, motion_mask=mask.cuda())
+    torch.cuda.synchronize()
+    for tag, got, q, gt in (("two launches", h, sc["local_rotation"], sc["global_trans"]),
+                            ("FK inside", f, f["local_rotation"].cpu(), f["global_trans"].cpu().reshape(-1))):
+        dx, dr = got["d_xyz"].cpu().numpy(), got["d_rotation"].cpu().numpy()
+        ox, orr = np.empty_like(dx), np.empty_like(dr)
+        with torch.no_grad():
+            for a in range(0, N, 125_000):
+                b = min(N, a + 125_000)
+                o = O.deform_by_pose(sc["xyz"][a:b], sc["joints"], sc["parents"], sc["node_radius"], q, gt, mask[a:b], -1)
+                ox[a:b], orr[a:b] = o["d_xyz"].numpy(), o["d_rotation"].numpy()
+        U.assert_close(dx, ox, "d_xyz (%s, N=%d, J=%d)" % (tag, N, J), 2e-5)
+        U.assert_close(dr, orr, "d_rotation (%s)" % tag, 2e-5)
+        U.assert_close(got["d_nodes"].cpu().numpy(), o["d_nodes"].numpy(), "d_nodes (%s)" % tag, 1e-5)
+        # the last, ragged block and the second Gaussian of every lane pair are the places a two-per-lane indexing slip would
+        # show: compare them on their own so that a failure names them
+        U.assert_close(dx[-700:], ox[-700:], "d_xyz tail (%s)" % tag, 2e-5)
+        U.assert_close(dx[256:512], ox[256:512], "d_xyz second half of the first 512-block (%s)" % tag, 2e-5)
+
+
 @pytest.mark.parametrize("keep", [0.0, 0.05, 0.5])
 def test_deform_backward_with_sparse_incoming_gradient(keep):
     """The LBS backward walks only the Gaussians whose incoming gradient is non-zero (most of a deep scene gets none

@@ -218,3 +218,34 @@ def test_step_many_equals_stepping_each_optimizer(capturable):
         for sa, sb in zip(oa.state.values(), ob.state.values()):
             assert float(sa["step"]) == float(sb["step"]) == 3.0
             assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
+
+
+def test_step_many_honours_step_hooks_and_lr_schedulers():
+    """``step_many`` merges the optimizers' launches only while nothing hangs on their ``step()``: with a registered step
+    hook or an lr_scheduler wrapped around one of them it steps each optimizer through its own ``step()`` (hooks fire, the
+    scheduler's call counter moves, no "scheduler.step() before optimizer.step()" warning) — same parameters either way."""
+    import warnings
+    from riggs_amd.optim import FusedAdam, step_many
+
+    def make():
+        ps = [torch.randn(33, 3, generator=torch.Generator().manual_seed(3 + i)).cuda().requires_grad_(True) for i in range(2)]
+        return ps, [FusedAdam([{"params": [p], "lr": 1e-2}], lr=0.0, eps=1e-15) for p in ps]
+    (p1, o1), (p2, o2) = make(), make()
+    fired = []
+    o2[0].register_step_post_hook(lambda opt, args, kwargs: fired.append("post"))
+    sched = torch.optim.lr_scheduler.StepLR(o2[1], step_size=1, gamma=0.5)
+    g = torch.Generator().manual_seed(5)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # the scheduler's ordering warning would fail the test
+        for it in range(2):
+            grads = [torch.randn(33, 3, generator=g).cuda() for _ in range(2)]
+            for p, q, gr in zip(p1, p2, grads):
+                p.grad, q.grad = gr.clone(), gr.clone()
+            step_many(o1)
+            if it == 1:
+                o1[1].param_groups[0]["lr"] = 5e-3  # what the scheduler did to its twin
+            step_many(o2)
+            sched.step()
+    assert fired == ["post", "post"]
+    assert torch.equal(p1[0], p2[0]) and torch.equal(p1[1], p2[1])
+    assert o2[1].param_groups[0]["lr"] == pytest.approx(2.5e-3)

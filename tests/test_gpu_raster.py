@@ -156,8 +156,8 @@ def test_arena_mode_matches_sync_mode_and_recovers_from_overflow():
     arena = RasterArena(min_capacity=16)
     a1 = rasterize_forward(st, *args, arena=arena)   # first call synchronises and sizes the arena
     a2 = rasterize_forward(st, *args, arena=arena)   # second call: no host sync, padded sort
-    # (bitwise equality holds in the reproducible mode only: by default a long list may be composited by several workgroups
-    # whose partial results are combined — which ones depends on timing, and the combination rounds differently)
+    # (bitwise equality frame after frame holds with cfg.deterministic or while no tile is composited wide — see
+    # test_wide_forward_blocks_against_the_oracle; this small scene never qualifies, the bound is kept loose on purpose)
     same = lambda x, y: float((x - y).abs().max()) <= 2e-6 * max(1.0, float(x.abs().max()))  # noqa: E731
     assert same(ref[0], a1[0]) and same(ref[0], a2[0])
     assert torch.equal(ref[1], a2[1])
@@ -171,6 +171,151 @@ def test_arena_mode_matches_sync_mode_and_recovers_from_overflow():
         rasterize_forward(st, *args, arena=arena)
     a4 = rasterize_forward(st, *args, arena=arena)
     assert arena.resolve() and same(ref[0], a4[0])
+
+
+def test_wide_forward_blocks_against_the_oracle():
+    """The forward composites the tiles whose walk went "fwd_wide_min" instances deep in the PREVIOUS frame of the same arena
+    with 32 lanes per pixel on 4 x 2 pixel blocks (render.hip: fw_block<32>: hand-written DPP scans and folds, checkpoints from
+    lanes LEAD + k, ticket == 31) — a path no fresh-arena comparison reaches.  Here: a translucent scene (no pixel saturates, so
+    a walk is as deep as its list), the gate lowered to 256 instances, two frames through one arena; the SECOND frame must have
+    wide tiles, and its image / n_contrib / final_T, the checkpoints the backward consumes (through every gradient) and the
+    bit-exact ordering state are compared with the oracle, and the image with the history-free frame (same values to ~1e-6:
+    another fold order).  With cfg.deterministic the history is ignored: no wide tile, bitwise equal frames."""
+    from riggs_amd import _lib as L
+    from riggs_amd.rasterizer import set_ordered_backward
+    N, H, W = 30_000, 160, 208
+    sc, act, cam = U.activated_scene(N, 8, 41, H, W, scale=0.03)
+    act["opacities"] = act["opacities"] * 0.02  # translucent: T stays > 1e-4 through thousands of instances
+    bg = [0.1, 0.3, 0.7]
+    out_o, so = U.oracle_forward(act, cam, bg)
+    assert int(so.n_contrib.max()) >= 1024, "the scene must walk deep for this test"
+    d = lambda t: t.cuda().contiguous()  # noqa: E731
+    st = U.settings_for(cam, bg, debug=True)
+    args = (d(act["means3D"]), d(act["shs"]), None, d(act["opacities"]), d(act["scales"]), d(act["rotations"]), None)
+    assert L.get_option("fwd_wide_min") == 4096 and L.get_option("fwd_wide_tiles") == 256
+    L.set_option("fwd_wide_min", 256)
+    try:
+        arena = RasterArena(min_capacity=16)
+        f1 = rasterize_forward(st, *args, arena=arena)
+        v1 = saved_views(f1[4])
+        assert int(v1["fwd_ctr"][1]) == 0, "a fresh arena has no history: no wide tile"
+        img1 = f1[0].clone()
+        f2 = rasterize_forward(st, *args, arena=arena)
+        color, radii, depth, alpha, s = f2
+        v2 = saved_views(s)
+        n_wide, n_tiles = int(v2["fwd_ctr"][1]), int(v2["fwd_ctr"][0])
+        assert n_wide >= 8 and n_wide < n_tiles, (n_wide, n_tiles)  # both block shapes in one launch
+        U.compare_forward_state(so, v2, out_o, color, depth, alpha, radii)
+        assert float((color - img1).abs().max()) <= 2e-6 * max(1.0, float(img1.abs().max()))
+        # the backward reads the wide blocks' checkpoints and n_contrib
+        g = torch.Generator().manual_seed(3)
+        gc = torch.sign(torch.rand(3, H, W, generator=g) - 0.5) / (3 * H * W)
+        gd = torch.randn(1, H, W, generator=g) / (H * W)
+        ga = torch.randn(1, H, W, generator=g) / (H * W)
+        go = RR.backward(so, gc.numpy(), gd.numpy()[0], ga.numpy()[0])
+        gh = rasterize_backward(s, *args[:2], None, *args[3:6], None, None, None, d(gc), d(gd), d(ga))
+        for got, name in ((gh[1], "means2D"), (gh[0], "means3D"), (gh[4], "opacities"), (gh[5], "scales"), (gh[6], "rotations"), (gh[2], "shs")):
+            _grads_close(got, go[name], "wide tiles: dL/d" + name)
+        # a third frame: the history now comes from a frame that had wide tiles (their depth is written by the 32nd block)
+        f3 = rasterize_forward(st, *args, arena=arena)
+        assert int(saved_views(f3[4])["fwd_ctr"][1]) == n_wide and torch.equal(f3[0], color)
+        # the deterministic configuration ignores the history: frame after frame bitwise equal, never wide
+        set_ordered_backward(True)
+        try:
+            arena_d = RasterArena(min_capacity=16)
+            frames = [rasterize_forward(st, *args, arena=arena_d) for _ in range(3)]
+            for f in frames:
+                assert int(saved_views(f[4])["fwd_ctr"][1]) == 0
+            assert torch.equal(frames[0][0], frames[2][0]) and torch.equal(frames[1][0], frames[2][0])
+            assert torch.equal(frames[0][0], img1)  # ... and equal to the history-free frame of the default configuration
+        finally:
+            set_ordered_backward(False)
+        # "fwd_wide_tiles" = 0 turns the wide form off in the default configuration as well
+        L.set_option("fwd_wide_tiles", 0)
+        f4 = rasterize_forward(st, *args, arena=arena)
+        assert int(saved_views(f4[4])["fwd_ctr"][1]) == 0 and torch.equal(f4[0], img1)
+    finally:
+        L.set_option("fwd_wide_min", -1)
+        L.set_option("fwd_wide_tiles", -1)
+    assert L.get_option("fwd_wide_min") == 4096 and L.get_option("fwd_wide_tiles") == 256
+
+
+def test_arena_history_does_not_survive_a_new_scene_size_or_a_recycled_block():
+    """The walk history is trusted when a stamp follows it; the stamp is a function of the tile AND Gaussian counts and
+    RasterArena zero-fills the words when it allocates or when (capacity, N, H, W) change — so a frame never composites wide
+    because of ANOTHER scene's history (same image, other N, through one arena; and a new arena on a recycled allocator block)."""
+    from riggs_amd import _lib as L
+    H, W = 160, 208
+    d = lambda t: t.cuda().contiguous()  # noqa: E731
+    L.set_option("fwd_wide_min", 256)
+    try:
+        def frame(n, arena, seed=41):
+            sc, act, cam = U.activated_scene(n, 8, seed, H, W, scale=0.03)
+            st = U.settings_for(cam, [0, 0, 0])
+            a = (d(act["means3D"]), d(act["shs"]), None, d(act["opacities"] * 0.02), d(act["scales"]), d(act["rotations"]), None)
+            return rasterize_forward(st, *a, arena=arena)
+        arena = RasterArena(min_capacity=1 << 21)
+        frame(30_000, arena)
+        assert int(saved_views(frame(30_000, arena)[4])["fwd_ctr"][1]) > 0    # history in use
+        assert int(saved_views(frame(29_000, arena)[4])["fwd_ctr"][1]) == 0   # another N in the same arena: no history
+        assert int(saved_views(frame(29_000, arena)[4])["fwd_ctr"][1]) > 0    # ... until this size has its own
+        nbytes = arena.binning.numel()
+        del arena
+        arena2 = RasterArena(min_capacity=1 << 21)   # the caching allocator hands the block back, stamp and all
+        out = frame(29_000, arena2)
+        assert arena2.binning.numel() == nbytes
+        assert int(saved_views(out[4])["fwd_ctr"][1]) == 0
+    finally:
+        L.set_option("fwd_wide_min", -1)
+
+
+@pytest.mark.parametrize("case", [1, 4, 6])
+def test_two_level_tile_sort_forced_where_both_sorts_fit(case):
+    """riggs_set_option("bin_grouped", 1): the two-level tile sort on scenes the direct counting sort would take — the same
+    list, ranges and images bit for bit against the oracle's key sort — and back."""
+    from riggs_amd import _lib as L
+    N, J, seed, H, W, scale, camkw = CASES[case]
+    sc, act, cam = U.activated_scene(N, J, seed, H, W, scale=scale, **camkw)
+    out_o, so = U.oracle_forward(act, cam, [0, 0, 0])
+    assert L.get_option("bin_grouped") == -1
+    imgs = []
+    try:
+        for forced in (1, 0):
+            L.set_option("bin_grouped", forced)
+            color, radii, depth, alpha, s = U.hip_forward(act, cam, [0, 0, 0])
+            U.compare_forward_state(so, saved_views(s), out_o, color, depth, alpha, radii)
+            imgs.append(color)
+    finally:
+        L.set_option("bin_grouped", -1)
+    assert torch.equal(imgs[0], imgs[1])
+    from riggs_amd._lib import RiggsHipError
+    with pytest.raises(RiggsHipError, match="bin_grouped"):
+        L.set_option("bin_grouped", 2)
+    with pytest.raises(RiggsHipError, match="unknown option"):
+        L.set_option("no_such_option", 1)
+
+
+def test_render_rejects_a_binning_arena_that_is_too_small():
+    """riggs_raster_render is told the arena's size and refuses one smaller than riggs_raster_binning_bytes for its arguments
+    (a C caller that kept an arena across a change of N / H / W would otherwise write out of bounds)."""
+    import ctypes as C
+    from riggs_amd import _lib as L
+    sc, act, cam = U.activated_scene(2000, 8, 5, 64, 64, scale=0.03)
+    color, radii, depth, alpha, s = U.hip_forward(act, cam, [0, 0, 0])
+    lib = L.lib()
+    need = lib.riggs_raster_binning_bytes(s.cap, s.N, s.H, s.W)
+    assert s.binning.numel() >= need
+    rc = lib.riggs_raster_render(C.byref(s.cfg), s.geom.data_ptr(), s.binning.data_ptr(), s.cap, need - 1, s.img.data_ptr(),
+                                 color.data_ptr(), depth.data_ptr(), alpha.data_ptr(), s.counters.data_ptr(), L.stream_ptr())
+    assert rc != 0 and b"smaller than riggs_raster_binning_bytes" in lib.riggs_last_error()
+    # the size is the same whichever tile sort runs (the larger layout is reserved): forcing one never invalidates an arena
+    sizes = set()
+    for forced in (-1, 0, 1):
+        L.set_option("bin_grouped", forced)
+        sizes.add(lib.riggs_raster_binning_bytes(1 << 20, 499_999, 2560, 2560))
+        sizes.add(lib.riggs_raster_binning_bytes(1 << 20, 500_000, 2560, 2560) - (500_000 - 499_999) * 8)
+    L.set_option("bin_grouped", -1)
+    assert len(sizes) <= 2 and max(sizes) - min(sizes) <= 4096, sizes  # (monotonic up to alignment in N across the switch)
 
 
 def test_arena_follows_a_growing_scene_and_image():

@@ -23,7 +23,7 @@ def main():
         gm = GaussianModel.from_tensors(sc["xyz"], sc["features_dc"], sc["features_rest"], sc["scaling"], sc["rotation"],
                                         sc["opacity"], device="cuda:0")
     T = ((w["W"] + 15) // 16) * ((w["H"] + 15) // 16)
-    n_items = T * 8 + min(T, int(os.environ.get("RIGGS_FWD_WIDE_TILES", 256))) * 24  # work items = workgroups of the launch; 4 waves each
+    n_items = T * 8 + min(T, L.get_option("fwd_wide_tiles")) * 24  # work items = workgroups of the launch; 4 waves each
     trace = torch.zeros((n_items * 4 * 8 + 4 * 200_000), dtype=torch.int64, device="cuda")
     L.lib().riggs_raster_set_trace_items(n_items)
     gimg = torch.rand(3, w["H"], w["W"], device="cuda") * 1e-6
