@@ -452,6 +452,29 @@ size_t riggs_knn_workspace_bytes(int32_t num_points);
 int riggs_dist2_knn3(int32_t num_points, const float* points, float* out, void* workspace, riggs_stream stream);
 
 /* =====================================================================
+ * Dual-quaternion blending of rigid transforms — utils/dual_quaternion.py: QT2DQ :135-143, DQ2QT :146-165,
+ * DQBlending :168-179 (what these two entry points compute), interpolate :182-187 and transformation_blending :190-197
+ * (host compositions of them: riggs_amd/dual_quaternion.py).  The reference never calls the module on the skeleton path
+ * (SURVEY.md §0.3); BASELINE.json's north_star names it, so it is here as an operator of its own.
+ *   shared != 0: ONE set of K <= 1024 transforms for all rows — q (K, 4) raw quaternions (w, x, y, z), t (K, 3),
+ *                weights (N, K): skinning.   shared == 0: every row has its own K <= 8 — q (N, K, 4), t (N, K, 3), weights (N, K).
+ *   norm_over_nodes: QT2DQ normalises with torch.nn.functional.normalize(q), whose default axis is dim=1 — the quaternion
+ *                axis of a 2-D q (0 here), the NODE axis of a 3-D q (1 here: every component is divided by its norm over the K
+ *                nodes).  Both are the reference's results for the respective input rank.
+ *   out_mode 0: out_rot (N, 9) row-major rotation matrix (rot_as_q=False), 1: out_rot (N, 4) through matrix_to_quaternion
+ *                (rot_as_q=True; no sign standardisation), 2: out_rot (N, 16) = [R | t; 0 0 0 1] and out_t unused.
+ * The dual part of a node is standardize_quaternion((0, t) * q) / 2 as in the reference (its sign does not follow q's).
+ * Backward: cotangents in the layout of the outputs (g_t NULL = zeros; ignored with out_mode 2); dL_dq / dL_dt in the shape
+ * of q / t, dL_dweights (N, K) or NULL; deterministic (no atomics).  workspace: riggs_dqb_backward_workspace_floats floats.
+ * ===================================================================== */
+int riggs_dqb_forward(int32_t num_rows, int32_t K, int32_t shared, int32_t norm_over_nodes, int32_t out_mode, const float* q,
+                      const float* t, const float* weights, float* out_rot, float* out_t, riggs_stream stream);
+size_t riggs_dqb_backward_workspace_floats(int32_t num_rows, int32_t K, int32_t shared);
+int riggs_dqb_backward(int32_t num_rows, int32_t K, int32_t shared, int32_t norm_over_nodes, int32_t out_mode, const float* q,
+                       const float* t, const float* weights, const float* g_rot, const float* g_t, float* dL_dq, float* dL_dt,
+                       float* dL_dweights, float* workspace, riggs_stream stream);
+
+/* =====================================================================
  * Kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
  * `mask` has bit i set to time stage i; 0 disables (default: no events, no overhead).
  * riggs_prof_read synchronises on the recorded events and returns the sum / count since the

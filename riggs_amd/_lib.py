@@ -91,6 +91,9 @@ _SIGS = {
     "riggs_mlp_embed": (C.c_int, [C.c_int32] * 3 + [_P] * 3 + [C.c_int32, _P]),
     "riggs_mlp_pack": (C.c_int, [C.c_int32] * 4 + [_P] * 6 + [C.c_int32, _P]),
     "riggs_mlp_layout_probe": (C.c_int, [_P, _P]),
+    "riggs_dqb_forward": (C.c_int, [C.c_int32] * 5 + [_P] * 6),
+    "riggs_dqb_backward_workspace_floats": (C.c_size_t, [C.c_int32] * 3),
+    "riggs_dqb_backward": (C.c_int, [C.c_int32] * 5 + [_P] * 10),
     "riggs_prof_count": (C.c_int, []),
     "riggs_prof_name": (C.c_char_p, [C.c_int32]),
     "riggs_prof_enable": (C.c_int, [C.c_uint32]),

@@ -27,6 +27,7 @@ SOURCES = {
     "cnode.hip": ["-ffp-contract=off"],
     "mlp.hip": ["-ffp-contract=fast"],
     "exchange.hip": ["-ffp-contract=off"],
+    "dq.hip": ["-ffp-contract=off"],
     "capi.hip": [],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fhip-fp32-correctly-rounded-divide-sqrt",

@@ -548,6 +548,54 @@ def fixture_deform_heads(name, seed, J, N):
     print("wrote", name)
 
 
+def fixture_dqb(name, seed, N, K, mode, rot_as_q):
+    """Dual-quaternion blending exactly as the reference computes it (utils/dual_quaternion.py: QT2DQ :135, DQ2QT :146,
+    DQBlending :168, interpolate :182, transformation_blending :190) with autograd's gradients w.r.t. (q, t, weights).
+    mode: "shared2d"  q (K, 4), t (K, 3), weights (N, K)            -> DQBlending (per-quaternion normalisation)
+          "shared3d"  q (1, K, 4)                                   -> DQBlending (F.normalize acts on the node axis)
+          "rows3d"    q (N, K, 4), t (N, K, 3), weights (N, K)      -> DQBlending, every row its own K transforms
+          "interp"    q0, q1 (N, 4), weight (N, 1)                  -> interpolate
+          "tblend"    transformations (K, 4, 4), weights (N, K)     -> transformation_blending (N, 4, 4)"""
+    import utils.dual_quaternion as DQ
+    g = torch.Generator().manual_seed(seed)
+    R = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+    out = {"mode": np.array(mode), "rot_as_q": np.array(rot_as_q)}
+    w = torch.rand(N, K, generator=g) ** 3 + 1e-3
+    w = (w / w.sum(-1, keepdim=True)).requires_grad_(True)
+    if mode == "tblend":
+        q = torch.nn.functional.normalize(R(K, 4), dim=-1)
+        T = torch.eye(4)[None].repeat(K, 1, 1)
+        T[:, :3, :3] = DQ.quaternion_to_matrix(q)
+        T[:, :3, 3] = 0.4 * R(K, 3)
+        T = T.requires_grad_(True)
+        res = DQ.transformation_blending(T, w)
+        gout = R(N, 4, 4)
+        (res * gout).sum().backward()
+        out.update(transformations=np_(T), weights=np_(w), out=np_(res), gout=np_(gout), grad_transformations=np_(T.grad),
+                   grad_weights=np_(w.grad))
+    elif mode == "interp":
+        q0, q1 = (R(N, 4) * (0.5 + torch.rand(N, 1, generator=g))).requires_grad_(True), (R(N, 4) * 1.3).requires_grad_(True)
+        t0, t1 = (0.5 * R(N, 3)).requires_grad_(True), (0.5 * R(N, 3)).requires_grad_(True)
+        wt = torch.rand(N, 1, generator=g).requires_grad_(True)
+        rot, t_ = DQ.interpolate(q0, t0, q1, t1, wt, rot_as_q=rot_as_q)
+        g_rot, g_t = R(*rot.shape), R(N, 3)
+        ((rot * g_rot).sum() + (t_ * g_t).sum()).backward()
+        out.update(q0=np_(q0), t0=np_(t0), q1=np_(q1), t1=np_(t1), weight=np_(wt), out_rot=np_(rot), out_t=np_(t_), g_rot=np_(g_rot),
+                   g_t=np_(g_t), grad_q0=np_(q0.grad), grad_t0=np_(t0.grad), grad_q1=np_(q1.grad), grad_t1=np_(t1.grad),
+                   grad_weight=np_(wt.grad))
+    else:
+        shape = {"shared2d": (K,), "shared3d": (1, K), "rows3d": (N, K)}[mode]
+        q = (R(*shape, 4) * (0.6 + torch.rand(*shape, 1, generator=g))).requires_grad_(True)   # non-unit on purpose
+        t = (0.5 * R(*shape, 3)).requires_grad_(True)
+        rot, t_ = DQ.DQBlending(q, t, w, rot_as_q=rot_as_q)
+        g_rot, g_t = R(*rot.shape), R(N, 3)
+        ((rot * g_rot).sum() + (t_ * g_t).sum()).backward()
+        out.update(q=np_(q), t=np_(t), weights=np_(w), out_rot=np_(rot), out_t=np_(t_), g_rot=np_(g_rot), g_t=np_(g_t),
+                   grad_q=np_(q.grad), grad_t=np_(t.grad), grad_weights=np_(w.grad))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name)
+
+
 def fixture_state_dict_layout():
     """§8-f rank 4a: names and shapes of the reference SkeletonWarp's state dict (what skeleton.pth holds), J = 6,
     hyper_dim = 8, with its static and its non-static base network."""
@@ -583,4 +631,11 @@ if __name__ == "__main__":
     fixture_control_nodes_edit("cnodes_edit_res_m96", 87, 500, 96, True)
     fixture_control_nodes_edit("cnodes_edit_abs_m64", 88, 350, 64, False)
     fixture_skeleton_projection("skelproj_chain8_m90_K", 72, 8, 90, True, chain=True)
+    fixture_dqb("dqb_shared2d_k23_q", 91, 300, 23, "shared2d", True)
+    fixture_dqb("dqb_shared3d_k63_R", 92, 257, 63, "shared3d", False)
+    fixture_dqb("dqb_rows3d_k3_q", 93, 400, 3, "rows3d", True)
+    fixture_dqb("dqb_rows3d_k8_R", 94, 129, 8, "rows3d", False)
+    fixture_dqb("dqb_interp_q", 95, 200, 2, "interp", True)
+    fixture_dqb("dqb_tblend_k31", 96, 150, 31, "tblend", True)
+    fixture_dqb("dqb_shared2d_k100_R", 97, 130, 100, "shared2d", False)
     fixture_state_dict_layout()
