@@ -414,6 +414,168 @@ def cpu_baseline(sc, cam_cpu, gimg_cpu, pose, deformed=None):
             "c1_10k_chain8_256": c1, "c2_150k_tree24_800": c2}, image, grads
 
 
+def verify_rows_exchange(gf, rows, world):
+    """Outside any timed region: one more step of a split frame whose exchanged gradients are compared with a plain all-reduce
+    of the same local gradients (the row exchange must be the mean, on every rank)."""
+    import torch.distributed as dist
+    gf.run_a()
+    gf.run_b()
+    local = [g.clone() for g in rows.rows]
+    rows.pack()
+    rows.launch()
+    rows.launch_rest()
+    rows.wait()
+    for g in local:
+        dist.all_reduce(g)
+        g /= world
+    torch.cuda.synchronize()
+    for got, want in zip(rows.rows, local):
+        tol = 1e-5 * float(want.abs().max()) + 1e-30
+        assert float((got - want).abs().max()) <= tol, "gradient-row exchange differs from the dense all-reduce"
+
+
+def exchange_path_child(steps=200):
+    """``python bench.py --exchange-path-child`` (started by the N = 1 run, in a process of its own so that nothing RCCL does
+    can touch the headline measurement): the EXACT host and device sequence of a data-parallel rank's step — split frame,
+    rows.pack -> all_gather of the packed rows (communication stream, under the deformation backward) -> run_b ->
+    all_reduce of the skeleton's gradients -> ordered unpack — on a real RCCL communicator of ONE rank on this GPU (the
+    collectives are then the identity, but they are RCCL's kernels, streams and enqueue path).  Timed twice: the frame as two
+    graphs with the five exchange calls issued eagerly between them (what ``--gpus N`` runs by default), and the whole step
+    captured as ONE graph (GraphedFrame.capture_exchange: RCCL collectives inside the capture).  The exchanged gradients are
+    compared with the plain frame's (one rank: they must be bitwise the same).  Prints one JSON object."""
+    import faulthandler
+    import socket
+    import torch.distributed as dist
+    from riggs_amd.dist import FlatGradAllReduce, SparseRowExchange, exchange_order, row_exchange_order
+    from riggs_amd.graph import GraphedFrame
+    from riggs_amd.rasterizer import RasterArena
+    faulthandler.enable()
+    note = lambda m: (sys.stderr.write("[exchange-path] %s\n" % m), sys.stderr.flush())  # noqa: E731
+    dev = "cuda:0"
+    torch.cuda.set_device(0)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(dev))
+    note("process group up")
+    probe = torch.ones(1024, device=dev)
+    dist.all_reduce(probe)
+    torch.cuda.synchronize()
+    note("first collective done")
+    w = WORKLOAD
+    sc, cam, gm, sw = build_workload(0, dev)
+    ordered, _ = exchange_order(gm, sw)
+    n_rows = row_exchange_order(gm, sw)[1]
+    bucket = FlatGradAllReduce(ordered)
+    g = torch.Generator().manual_seed(w["seed"] + 100)
+    target = torch.rand(3, w["H"], w["W"], generator=g).to(dev)
+    gimg = torch.zeros(3, w["H"], w["W"], device=dev)
+    pkg = make_step(cam, gm, sw, gimg, RasterArena(), 1, bucket)()
+    gimg.copy_(torch.sign(pkg["render"].detach() - target) / (3 * w["H"] * w["W"]))
+    del pkg
+    params = params_of(gm, sw)
+    bg = torch.zeros(3, device=dev)
+
+    def timed(fn, n):
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    def rows_for():
+        return SparseRowExchange([v.view(w["N"], -1) for v in bucket.views[:n_rows]], rest=bucket.flat[bucket.offsets[n_rows]:],
+                                 capacity=max(1024, w["N"] // 8), force_collectives=True)
+    out = {"backend": "nccl (RCCL), one-rank communicator on this GPU", "steps": steps}
+    # (0) the plain frame in this process: the reference the two exchange paths are priced against, and their gradients' oracle
+    gf = GraphedFrame(gm, sw, cam, bg, params, sparse_grad_rows=False).capture()
+    gf.set_inputs(gimg=gimg)
+    out["plain_frame_ms"] = round(timed(gf.run, steps), 4)
+    note("plain frame timed")
+    R = gf.check()
+    want = [p.grad.detach().clone() for p in params]
+    del gf
+
+    def verify(tag):
+        # (pack / unpack move the rows bit for bit; the bound is there because float atomics reorder the sums of the
+        # compositing backward from one replay to the next)
+        torch.cuda.synchronize()
+        for p, ref in zip(params, want):
+            scale = float(ref.abs().max())
+            assert float((p.grad - ref).abs().max()) <= 2e-4 * max(scale, 1e-30), (tag, tuple(p.shape))
+    # (1) two graphs, the exchange's calls eager between them
+    rows = rows_for()
+    gf = GraphedFrame(gm, sw, cam, bg, params, split_backward=True, sparse_grad_rows=True).capture()
+    gf.set_inputs(gimg=gimg)
+    rows.workspace, rows.record_rows = gf.backward_workspace, True
+
+    def step_eager():
+        gf.run_a()
+        rows.pack()
+        rows.launch()
+        gf.run_b()
+        rows.launch_rest()
+        rows.wait()
+    note("split frame captured")
+    step_eager()
+    torch.cuda.synchronize()
+    note("first exchanged step done")
+    assert rows.check(), "row segments overflowed"
+    rows.resize(int(rows.need * 1.1) + 256)
+    out["rows_needed"], out["segment_MB"] = int(rows.need), round(rows.segment.numel() * 4 / 1e6, 3)
+    out["two_graphs_eager_collectives_ms"] = round(timed(step_eager, steps), 4)
+    assert gf.check() == R and rows.check()
+    verify("eager collectives")
+    need = rows.need
+    del gf, rows
+    out["tile_instances_R"] = int(R)
+    out["verified"] = "exchanged gradients equal the plain frame's (2e-4 of max: float atomics reorder sums between replays)"
+    # (printed now: a failure of the capture below has been a segmentation fault inside hipStreamEndCapture, not an exception)
+    print(json.dumps(dict(out, one_graph_error="the process died while capturing the step with its RCCL collectives")), flush=True)
+    if os.environ.get("RIGGS_BENCH_CAPTURE_COLLECTIVES", "1") == "0":
+        dist.destroy_process_group()
+        return
+    # (2) ONE graph: the collectives captured with the frame
+    try:
+        rows = SparseRowExchange([v.view(w["N"], -1) for v in bucket.views[:n_rows]], rest=bucket.flat[bucket.offsets[n_rows]:],
+                                 capacity=int(need * 1.1) + 256, force_collectives=True)
+        rows.record_rows = True
+        gf = GraphedFrame(gm, sw, cam, bg, params, split_backward=True, sparse_grad_rows=True)
+        gf.set_inputs(gimg=gimg)
+        note("capturing the step with its collectives")
+        gf.capture_exchange(rows)
+        note("captured")
+        out["one_graph_ms"] = round(timed(gf.run, steps), 4)
+        assert gf.check() == R and rows.check()
+        verify("captured collectives")
+        out["one_graph"] = "frame + pack + all_gather + all_reduce + unpack captured as one hipGraph"
+    except Exception as e:  # (recorded, not hidden: the eager-collective number above stands on its own)
+        out["one_graph_error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
+    print(json.dumps(out), flush=True)
+    dist.destroy_process_group()
+
+
+def exchange_path_timing():
+    """Runs ``exchange_path_child`` in a child process (bounded by a time-out) and returns its JSON object."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--exchange-path-child"], capture_output=True, text=True,
+                           timeout=300, env=dict(os.environ))
+    except subprocess.TimeoutExpired:
+        return {"error": "the exchange-path child did not finish within 300 s"}
+    for line in reversed(r.stdout.strip().splitlines()):
+        if line.startswith("{"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                pass
+    return {"error": "exchange-path child failed (rc %d): %s" % (r.returncode, (r.stderr or r.stdout)[-600:])}
+
+
 PARITY_BAR = 5e-5  # share of a tensor's elements allowed beyond 1e-4 of max|oracle| (observed: <= 4e-6)
 
 
@@ -477,7 +639,12 @@ def main():
     ap.add_argument("--exchange", choices=("rows", "dense"), default="rows",
                     help="N > 1: gradient-row exchange (packed rows of the Gaussians with a gradient) or the dense two-phase all-reduce")
     ap.add_argument("--metric-only", action="store_true", help="skip the secondary timings (train step, heads, next rows, dense scene)")
+    ap.add_argument("--exchange-graph", action="store_true",
+                    help="N > 1: capture the whole data-parallel step (frame + pack + collectives + unpack) as ONE hipGraph")
+    ap.add_argument("--exchange-path-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.exchange_path_child:
+        return exchange_path_child()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -596,6 +763,18 @@ def main():
                 step()
                 torch.cuda.synchronize()
                 assert rows.check(), "gradient-row segments overflowed right after sizing"
+                if args.exchange_graph:
+                    verify_rows_exchange(gf, rows, world)
+                    # the whole step as ONE graph: frame (a) -> pack -> all-gather on the communication stream -> frame (b) ->
+                    # all-reduce of the skeleton's gradients -> unpack, collectives included (their first eager calls are above)
+                    gf = GraphedFrame(gm, sw, cam, torch.zeros(3, device=dev), params, split_backward=True, sparse_grad_rows=True)
+                    gf.set_inputs(gimg=gimg)
+                    rows.record_rows = True
+                    gf.capture_exchange(rows)
+                    step = gf.run  # noqa: F811
+                    step()
+                    torch.cuda.synchronize()
+                    assert gf.check() == R and rows.check()
 
     names = [lib.riggs_prof_name(i).decode() for i in range(lib.riggs_prof_count())]
     eager_step = make_step(cam, gm, sw, gimg, arena, 1, bucket)  # profiling leg: rank 0 alone, so NO collective inside
@@ -619,22 +798,8 @@ def main():
         assert gf.check() == R, "the timed frames disagree with the first frame on the instance count"
     if world > 1 and rows is not None and not args.no_graph:
         assert rows.check(), "a gradient-row segment overflowed inside the timed region (that step was not exchanged)"
-        # outside the timed region: one more step whose exchanged gradients are compared with a plain all-reduce of the same
-        # local gradients (the row exchange must be the mean, on every rank)
-        gf.run_a()
-        gf.run_b()
-        local = [g.clone() for g in rows.rows]
-        rows.pack()
-        rows.launch()
-        rows.launch_rest()
-        rows.wait()
-        for g in local:
-            dist.all_reduce(g)
-            g /= world
-        torch.cuda.synchronize()
-        for got, want in zip(rows.rows, local):
-            tol = 1e-5 * float(want.abs().max()) + 1e-30
-            assert float((got - want).abs().max()) <= tol, "gradient-row exchange differs from the dense all-reduce"
+        if not gf.exchange_in_graph:  # (with --exchange-graph the same comparison ran before the step was captured)
+            verify_rows_exchange(gf, rows, world)
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -828,6 +993,9 @@ def main():
             out["next_rows"] = next_rows_timing(sc, gm, cam)
             out["dense_gradient_scene"] = dense_scene_timing(dev)
             out["cycling_cameras"] = cycling_cameras_timing(dev)
+            # the data-parallel step's host + device sequence on a one-rank RCCL communicator (a child process)
+            out["exchange_path"] = exchange_path_timing()
+            out["exchange_path_ms"] = out["exchange_path"].get("one_graph_ms", out["exchange_path"].get("two_graphs_eager_collectives_ms"))
         if not args.no_cpu_baseline and world == 1:  # (the CPU baseline is an N = 1 measurement)
             out["cpu_baseline"], ora_image, ora_grads = cpu_baseline(sc, cam.to("cpu"), gimg.cpu(), hip_pose, hip_deformed)
             out["parity_at_bench_size"] = parity_at_bench_size(hip_image, hip_grads, ora_image, ora_grads, sw_snapshot, hip_pose_grads, cam.fid)

@@ -479,8 +479,12 @@ class SparseRowExchange:
     def rows_on_gpu(rows):
         return len(rows) > 0 and rows[0].is_cuda
 
-    def __init__(self, rows, rest=None, capacity=None, average=True, pack=None, unpack=None, world=None):
+    def __init__(self, rows, rest=None, capacity=None, average=True, pack=None, unpack=None, world=None,
+                 force_collectives=False):
+        """``force_collectives``: issue the collectives even on a communicator of ONE rank (where they are the identity) —
+        what ``bench.py``'s single-GPU exchange-path measurement uses to run the real RCCL enqueue path on one device."""
         self.world = int(world) if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        self.force = bool(force_collectives) and dist.is_initialized() and world is None
         _spread_pose_mlp_chain(self.rows_on_gpu(rows))
         self.rows = [g for g in rows]
         self.N = int(self.rows[0].shape[0])
@@ -513,7 +517,7 @@ class SparseRowExchange:
         # the small dense all-reduce gets its OWN communicator: collectives of one process group run one after the other
         # on that group's internal stream, and this one must not queue behind the all-gather of the rows
         self.rest_group = None
-        if rest is not None and self.world > 1 and dist.is_initialized() and world is None:
+        if rest is not None and (self.world > 1 or self.force) and dist.is_initialized() and world is None:
             self.rest_group = dist.new_group()
         self.resize(int(capacity) if capacity is not None else max(1024, self.N // 8))
 
@@ -539,8 +543,15 @@ class SparseRowExchange:
             self._pack_captured = True
         self._pack(self)
 
+    def _capturing(self):
+        return self.cuda and torch.cuda.is_current_stream_capturing()
+
     def _on_comm(self, fn):
-        if self.cuda:
+        # Inside a hipGraph capture the collectives are issued from the capturing stream itself: the process group forks to
+        # its internal stream and joins at ``wait()``, which the capture records as a branch of the graph — the overlap with
+        # the deformation backward is the same.  (A fork to a user side stream around an RCCL call crashes
+        # hipStreamEndCapture on ROCm 7.2 / torch 2.10: tools/scratch/rccl_capture_probe.py.)
+        if self.cuda and not self._capturing():
             self.comm.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm):
                 fn()
@@ -549,7 +560,7 @@ class SparseRowExchange:
 
     def launch(self):
         def go():
-            if self.world == 1:
+            if self.world == 1 and not self.force:
                 self.gathered.copy_(self.segment)
             elif self.cuda and dist.get_backend() == "nccl":
                 self.pending.append((dist.all_gather_into_tensor(self.gathered, self.segment, async_op=True), None))
@@ -564,7 +575,7 @@ class SparseRowExchange:
         self._on_comm(go)
 
     def _reduce_dense(self, t, group=None):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         if self.average and self.cuda and dist.get_backend() == "nccl":
             self.pending.append((dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group, async_op=True), None))
@@ -582,7 +593,7 @@ class SparseRowExchange:
                 if needs_div is not None:
                     needs_div.div_(self.world)
             self.pending = []
-        if self.cuda:
+        if self.cuda and not self._capturing():
             with torch.cuda.stream(self.comm):
                 go()
             torch.cuda.current_stream().wait_stream(self.comm)

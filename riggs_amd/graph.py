@@ -51,6 +51,12 @@ class GraphedFrame:
         # optional callable issued right behind the rasterizer's backward of a split frame, INSIDE graph (a): e.g. the pack
         # of riggs_amd.dist.SparseRowExchange (it then bakes that object's segment buffer into the graph)
         self.after_raster_backward = None
+        # optional exchange object (pack / launch / launch_rest / wait: riggs_amd.dist.SparseRowExchange) whose whole step —
+        # pack behind the rasterizer's backward, the all-gather on the links under the deformation backward, the small dense
+        # all-reduce, the ordered unpack — is captured together with the split frame as ONE graph (``capture_exchange``): a
+        # rank's step is then a single graph launch instead of two plus five eager host calls
+        self.exchange = None
+        self.exchange_in_graph = False
 
     def _frame(self):
         for p in self.params:
@@ -89,6 +95,21 @@ class GraphedFrame:
         torch.autograd.backward([self._dv["d_xyz"], self._dv["d_rotation"]], [self._dx.grad, self._dr.grad])
         self._dv = None
 
+    def _frame_exchanged(self):
+        """The split frame with the exchange's calls between its halves — eagerly in the warm-up (which also brings the
+        communicators up: a collective cannot be captured before its first eager call), then inside ONE capture."""
+        from .rasterizer import last_backward_workspace
+        ex = self.exchange
+        out = self._frame_a()
+        # (pack from — and, with record_rows, record the unpacked rows in — the workspace THIS frame's backward uses)
+        ex.workspace = last_backward_workspace()[0]
+        ex.pack()
+        ex.launch()
+        self._frame_b()
+        ex.launch_rest()
+        ex.wait()
+        return out
+
     def set_inputs(self, cam: Camera = None, gimg: torch.Tensor = None):
         if cam is not None:
             if (cam.image_height, cam.image_width, cam.FoVx, cam.FoVy) != (
@@ -126,7 +147,9 @@ class GraphedFrame:
         try:
             with torch.cuda.stream(s):
                 for _ in range(warmup):
-                    if self.split:
+                    if self.split and self.exchange_in_graph:
+                        self.out = self._frame_exchanged()
+                    elif self.split:
                         self.out = self._frame_a()
                         self._frame_b()
                     else:
@@ -144,7 +167,11 @@ class GraphedFrame:
         self.graph = torch.cuda.CUDAGraph()
         R.SPARSE_GRAD_ROWS = self.sparse_rows
         try:
-            if self.split:
+            if self.split and self.exchange_in_graph:
+                self.graph_b = None
+                with torch.cuda.graph(self.graph, stream=s):
+                    self.out = self._frame_exchanged()
+            elif self.split:
                 self.graph_b = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph, stream=s):
                     self.out = self._frame_a()
@@ -173,6 +200,15 @@ class GraphedFrame:
             self.sparse_outputs = [alive[ptr] for ptr in wanted]
             self.reset_sparse_rows()
         return self
+
+    def capture_exchange(self, exchange, warmup: int = 2):
+        """Capture the split frame AND ``exchange``'s step as one graph (see ``self.exchange``): ``run()`` is then the whole
+        data-parallel step.  The exchange's segment buffers are baked in (``resize`` afterwards raises); its status words stay
+        readable (``exchange.check()``)."""
+        if not self.split:
+            raise ValueError("capture_exchange needs split_backward=True")
+        self.exchange, self.exchange_in_graph = exchange, True
+        return self.capture(warmup=warmup)
 
     def recapture(self, params=None, warmup: int = 1):
         """After densification / pruning replaced the Gaussians' parameter tensors (a new N: scene/gaussian_model.py:445-514,
@@ -233,7 +269,7 @@ class GraphedFrame:
             self.capture()
         self.set_inputs(cam, gimg)
         self.graph.replay()
-        if self.split:
+        if self.split and not self.exchange_in_graph:
             self.graph_b.replay()
         return self.out
 

@@ -259,12 +259,16 @@ def test_arena_history_does_not_survive_a_new_scene_size_or_a_recycled_block():
         assert int(saved_views(frame(30_000, arena)[4])["fwd_ctr"][1]) > 0    # history in use
         assert int(saved_views(frame(29_000, arena)[4])["fwd_ctr"][1]) == 0   # another N in the same arena: no history
         assert int(saved_views(frame(29_000, arena)[4])["fwd_ctr"][1]) > 0    # ... until this size has its own
-        nbytes = arena.binning.numel()
         del arena
-        arena2 = RasterArena(min_capacity=1 << 21)   # the caching allocator hands the block back, stamp and all
+        arena1 = RasterArena(min_capacity=1 << 21)
+        frame(29_000, arena1)
+        assert int(saved_views(frame(29_000, arena1)[4])["fwd_ctr"][1]) > 0
+        nbytes, where = arena1.binning.numel(), arena1.binning.data_ptr()
+        del arena1
+        arena2 = RasterArena(min_capacity=1 << 21)   # same size: the caching allocator hands the block back, stamp and all
         out = frame(29_000, arena2)
         assert arena2.binning.numel() == nbytes
-        assert int(saved_views(out[4])["fwd_ctr"][1]) == 0
+        assert int(saved_views(out[4])["fwd_ctr"][1]) == 0, "recycled block at %s" % ("the same address" if arena2.binning.data_ptr() == where else "another address")
     finally:
         L.set_option("fwd_wide_min", -1)
 
