@@ -65,7 +65,10 @@ def params_of(gm, sw):
     return gm.parameters() + [sw._node_radius] + list(sw.pose_net.parameters())
 
 
-def make_step(cam, gm, sw, gimg, arena, world, allreduce):
+def make_step(cam, gm, sw, gimg, arena, world, allreduce, frame_entry=False):
+    """One eagerly issued frame.  ``frame_entry``: through riggs_amd.frame.deform_render (ONE autograd node over one C call per
+    direction) instead of the reference's two calls skeleton.step() + render() (two nodes, seven C calls)."""
+    from riggs_amd.frame import deform_render
     from riggs_amd.render import render
     bg = torch.zeros(3, device=gimg.device)
     params = params_of(gm, sw)
@@ -74,13 +77,38 @@ def make_step(cam, gm, sw, gimg, arena, world, allreduce):
     def step():
         for p in params:
             p.grad = None
-        dv = sw(gm.get_xyz.detach(), t_in, motion_mask=gm.motion_mask)  # skeleton.step() (train_rig.py:411)
-        pkg = render(cam, gm, Pipe, bg, dv["d_xyz"], dv["d_rotation"], dv["d_scaling"], fused=True, arena=arena)
+        if frame_entry:
+            pkg = deform_render(cam, gm, sw, Pipe, bg, arena=arena)
+        else:
+            dv = sw(gm.get_xyz.detach(), t_in, motion_mask=gm.motion_mask)  # skeleton.step() (train_rig.py:411)
+            pkg = render(cam, gm, Pipe, bg, dv["d_xyz"], dv["d_rotation"], dv["d_scaling"], fused=True, arena=arena)
         pkg["render"].backward(gimg)
         if world > 1:
             allreduce()  # RCCL over xGMI: one all-reduce of the flat gradient buffer, averaged
         return pkg
     return step
+
+
+def eager_api_timing(cam, gm, sw, gimg, steps=200):
+    """Secondary number (NOT the metric): the SAME workload issued eagerly, launch by launch — what a trainer that is not
+    rewritten around a captured graph gets.  (a) the reference's own two calls per iteration, ``skeleton.step()`` then
+    ``render()`` (train_rig.py:411, 488), each a HIP-backed autograd node; (b) ``riggs_amd.frame.deform_render``: the same frame
+    as one node over riggs_frame_forward / riggs_frame_backward.  Host-bound either way; wall clock per frame."""
+    from riggs_amd.rasterizer import RasterArena
+    res = {}
+    for name, fe in (("two_calls_ms", False), ("frame_entry_ms", True)):
+        step = make_step(cam, gm, sw, gimg, RasterArena(), 1, None, frame_entry=fe)
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        res[name] = round((time.perf_counter() - t0) / steps * 1e3, 4)
+    res["what"] = ("same workload, every launch issued eagerly through autograd + ctypes: skeleton.step() + render() as the reference "
+                   "calls them, and riggs_amd.frame.deform_render (one C call per direction); not the headline metric")
+    return res
 
 
 def heads_timing(sc, gm, iters=5):
@@ -559,6 +587,63 @@ def exchange_path_child(steps=200):
     dist.destroy_process_group()
 
 
+def capture_probe_child():
+    """``python bench.py --capture-probe-child`` (one per rank, started by ``captured_collectives_work``): joins a SECOND
+    rendezvous of all ranks, captures the exchange's collective pattern — an async all-gather and an async all-reduce on a second
+    communicator, issued from the capturing stream, compute between launch and wait — in a hipGraph, replays it and checks the
+    values.  Exit code 0 = RCCL collectives survive capture + replay across these ranks (a failure has been a segmentation
+    fault inside hipStreamEndCapture, which is why this runs in a process of its own)."""
+    import torch.distributed as dist
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = max(1, torch.cuda.device_count())
+    dev = torch.device("cuda:%d" % (local % ndev))
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    g2 = dist.new_group()
+    x = torch.full((1 << 18,), float(rank + 1), device=dev)
+    y = torch.zeros(world << 18, device=dev)
+    z = torch.zeros(1 << 18, device=dev)
+
+    def body():
+        w1 = dist.all_gather_into_tensor(y, x, async_op=True)
+        z.copy_(x * 2.0)
+        w2 = dist.all_reduce(z, group=g2, async_op=True)
+        w1.wait()
+        w2.wait()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            body()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        body()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    ok = float(z[0]) == 2.0 * world * (world + 1) / 2 and all(float(y[(r << 18) + 5]) == r + 1 for r in range(world))
+    dist.barrier()
+    dist.destroy_process_group()
+    raise SystemExit(0 if ok else 4)
+
+
+def captured_collectives_work(rank, world, local_rank, dev):
+    """Do RCCL collectives survive a hipGraph capture across THESE ranks?  Every rank runs ``capture_probe_child`` in a child
+    process (own rendezvous on MASTER_PORT + 29); the answer is the minimum over the ranks, so all of them take the same path."""
+    import subprocess
+    import torch.distributed as dist
+    env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank),
+               MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 29))
+    try:
+        rc = subprocess.run([sys.executable, os.path.abspath(__file__), "--capture-probe-child"], env=env, capture_output=True,
+                            timeout=180).returncode
+    except subprocess.TimeoutExpired:
+        rc = -1
+    ok = torch.tensor([1.0 if rc == 0 else 0.0], device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    return bool(ok.item() > 0.5)
+
+
 def exchange_path_timing():
     """Runs ``exchange_path_child`` in a child process (bounded by a time-out) and returns its JSON object."""
     import subprocess
@@ -639,12 +724,16 @@ def main():
     ap.add_argument("--exchange", choices=("rows", "dense"), default="rows",
                     help="N > 1: gradient-row exchange (packed rows of the Gaussians with a gradient) or the dense two-phase all-reduce")
     ap.add_argument("--metric-only", action="store_true", help="skip the secondary timings (train step, heads, next rows, dense scene)")
-    ap.add_argument("--exchange-graph", action="store_true",
-                    help="N > 1: capture the whole data-parallel step (frame + pack + collectives + unpack) as ONE hipGraph")
+    ap.add_argument("--exchange-graph", choices=("auto", "on", "off"), default="auto",
+                    help="N > 1: capture the whole data-parallel step (frame + pack + collectives + unpack) as ONE hipGraph; "
+                         "auto = when a probe (child processes, own rendezvous) shows that RCCL collectives survive a capture here")
     ap.add_argument("--exchange-path-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--capture-probe-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.exchange_path_child:
         return exchange_path_child()
+    if args.capture_probe_child:
+        return capture_probe_child()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -763,7 +852,9 @@ def main():
                 step()
                 torch.cuda.synchronize()
                 assert rows.check(), "gradient-row segments overflowed right after sizing"
-                if args.exchange_graph:
+                use_graph = args.exchange_graph == "on" or (args.exchange_graph == "auto" and backend == "nccl"
+                                                             and captured_collectives_work(rank, world, local_rank, dev))
+                if use_graph:
                     verify_rows_exchange(gf, rows, world)
                     # the whole step as ONE graph: frame (a) -> pack -> all-gather on the communication stream -> frame (b) ->
                     # all-reduce of the skeleton's gradients -> unpack, collectives included (their first eager calls are above)
@@ -866,6 +957,8 @@ def main():
         exchange_label = ("packed rows of the Gaussians with a gradient (%d of %d rows needed by the fullest rank, capacity %d, %.1f MB per "
                           "segment) all-gathered during the deformation backward + dense all-reduce of the skeleton's %d floats; ordered "
                           "unpack" % (rows.need, w["N"], rows.capacity, rows.segment.numel() * 4 / 1e6, rows.rest.numel()))
+        exchange_label += ("; the whole step (frame, pack, collectives, unpack) is ONE hipGraph per rank" if gf.exchange_in_graph else
+                           "; the frame is two hipGraphs, the exchange's five calls are issued eagerly between and behind them")
     elif args.no_graph:
         exchange_label = "one in-place all-reduce (AVG) of the flat bucket"
     if rank == 0:
@@ -957,6 +1050,8 @@ def main():
                            "frac_hbm": round((N * 985 + R * 278 + HW * 56) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "kernels": per_kernel, "kernels_ms": table,
         }
+        if world == 1 and not args.metric_only:
+            out["eager_api"] = eager_api_timing(cam, gm, sw, gimg)
         if world == 1 and not args.no_graph and not args.metric_only:
             # Secondary number (NOT the metric): one WHOLE training iteration as a hipGraph — the metric's path plus the
             # fused image loss, its backward, and the capturable FusedAdam steps of the Gaussians and the skeleton

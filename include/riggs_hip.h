@@ -314,6 +314,58 @@ int riggs_pose_mlp_backward_fk(int32_t depth, int32_t width, int32_t multires, i
                                float* flat_grads, void* sync_state, riggs_stream stream);
 
 /* =====================================================================
+ * The whole frame behind ONE call per direction — what train_rig.py:535-554 issues per iteration as skeleton.step() + render()
+ * + loss.backward(): riggs_pose_mlp_forward -> riggs_lbs_forward_fk -> riggs_raster_preprocess -> riggs_raster_render, and
+ * riggs_raster_backward -> riggs_lbs_backward -> riggs_pose_mlp_backward_fk.  Same kernels, same results; the point is the
+ * host: an eagerly issued frame crosses the binding seven times and is host-bound (0.65 ms per frame at the bench workload
+ * against 0.36 ms of device time); through these two entries it is two crossings.  Every field has the meaning of the
+ * like-named argument of the entry points above.  The rasterizer runs with the fused render glue (cfg.glue must be 1): xyz /
+ * opacity / scaling / rotation are the RAW parameters, features_dc / features_rest the two SH tensors read in place; `xyz` is
+ * also the (detached) input of the skinning.  The binning arena must hold `instance_capacity` instances (a caller that does
+ * not know R yet runs its first frame through the separate entry points, as riggs_amd.rasterizer.RasterArena does).
+ * ===================================================================== */
+typedef struct riggs_frame {
+  /* PoseMLP (riggs_pose_mlp_forward) */
+  int32_t depth, width, multires, skip, n_rot;
+  const float* const* weights; const float* const* biases;       /* host arrays of `depth` device pointers */
+  const float *W_rot, *b_rot, *W_tr, *b_tr, *t, *rot_bias4;
+  void* sync_state; float* acts;
+  float* local_rot;      /* out (J,4) */
+  float* global_trans;   /* out (3,) */
+  /* skeleton (riggs_lbs_forward_fk) */
+  int32_t num_joints, K;
+  const float* joints; const int32_t* parents; const float* node_radius_log; const float* motion_mask; const float* weight_mod;
+  float *transforms, *node_rot, *d_nodes;   /* out (J,12), (J,4), (J,3) */
+  float *d_xyz, *d_rotation;                /* out (N,3), (N,4): the residuals the rasterizer's glue adds */
+  /* rasterizer (riggs_raster_preprocess + riggs_raster_render) */
+  riggs_raster_cfg cfg;
+  const float *xyz, *features_dc, *features_rest, *opacity, *scaling, *rotation, *d_scaling /* or NULL */;
+  void* geom; int32_t* radii; uint32_t* counters;
+  void* binning; int64_t instance_capacity; size_t binning_bytes; void* image_state;
+  float *out_color, *out_depth, *out_alpha;
+} riggs_frame;
+
+typedef struct riggs_frame_grads {
+  const float *dL_dcolor, *dL_ddepth /* or NULL */, *dL_dalpha /* or NULL */;
+  void* raster_workspace;                    /* riggs_raster_backward_workspace_bytes(N), see riggs_raster_backward */
+  float *dL_dxyz, *dL_dmeans2D, *dL_dfeatures_dc, *dL_dfeatures_rest, *dL_dopacity, *dL_dscaling, *dL_drotation;
+  float* dL_dd_scaling;                      /* or NULL */
+  float* dL_dtransforms;                     /* (J,12) scratch: the skinning's gradient, consumed by the chain's reverse sweep */
+  float* dL_dnode_radius_log;                /* (J,) */
+  float* dL_dglobal_trans_skinning;          /* (3,) scratch */
+  float *dL_dmotion_mask, *dL_dweight_mod;   /* or NULL */
+  void* lbs_workspace;                       /* riggs_lbs_backward_workspace_bytes(N, J) */
+  const float *dL_dd_nodes, *g_local_rot, *g_global_trans; /* cotangents of d_nodes (J,3) / local_rot (J,4) / global_trans (3,)
+                                                from other consumers (regularisers, the projection loss), or NULL */
+  float *dL_dlocal_rot, *dL_dglobal_trans;   /* out (J,4), (3,) */
+  float* pose_workspace;                     /* riggs_pose_mlp_backward_workspace_floats */
+  float* pose_flat_grads;                    /* the PoseMLP's parameter gradients, flat, in parameter order */
+} riggs_frame_grads;
+
+int riggs_frame_forward(const riggs_frame* frame, riggs_stream stream);
+int riggs_frame_backward(const riggs_frame* frame, const riggs_frame_grads* grads, riggs_stream stream);
+
+/* =====================================================================
  * Gaussian optimizer.
  *   GaussianModel.training_setup  scene/gaussian_model.py:197-221 builds torch.optim.Adam(l, lr=0.0, eps=1e-15)
  *   with ONE parameter tensor per group and per-group learning rates; train_rig.py:527 steps it.

@@ -28,6 +28,7 @@ SOURCES = {
     "mlp.hip": ["-ffp-contract=fast"],
     "exchange.hip": ["-ffp-contract=off"],
     "dq.hip": ["-ffp-contract=off"],
+    "frame.hip": [],
     "capi.hip": [],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fhip-fp32-correctly-rounded-divide-sqrt",

@@ -324,6 +324,80 @@ def test_graphed_train_step_survives_densification_by_recapture():
         bench.WORKLOAD.update(old)
 
 
+@pytest.mark.parametrize("with_mask,extra_heads", [(False, False), (True, True)])
+def test_frame_entry_equals_the_two_calls_and_the_oracle(with_mask, extra_heads):
+    """riggs_amd.frame.deform_render — the frame as ONE autograd node over riggs_frame_forward / riggs_frame_backward — against
+    the two calls it replaces (SkeletonWarp.forward + render(fused=True): the same kernels, so the image is bitwise the same and
+    the gradients agree to the float atomics' reordering) and against the CPU oracle; with cotangents on d_nodes /
+    local_rotation / global_trans (the projection loss and the pose regularisers of train_rig.py hang on them) and a motion
+    mask.  The first frame of an arena goes through the separate calls (its size is not known yet): both kinds are covered."""
+    from riggs_amd.frame import deform_render
+    from riggs_amd.rasterizer import RasterArena
+    N, J, H, W = 6000, 24, 128, 160
+    sc = synth.make_scene(N, J, 1240, scale=0.03)
+    cam = synth.look_at_camera(H, W, fid=0.41).to("cuda")
+    gm = GaussianModel.from_tensors(sc["xyz"], sc["features_dc"], sc["features_rest"], sc["scaling"], sc["rotation"], sc["opacity"])
+    if with_mask:
+        gm.with_motion_mask = True
+        gm.feature = torch.nn.Parameter(torch.randn(N, 9, generator=torch.Generator().manual_seed(2)).cuda())
+    torch.manual_seed(3)
+    sw = SkeletonWarp(joints=sc["joints"], parent_indices=sc["parents"], K=-1, hyper_dim=8, use_skinning_weight_mlp=False,
+                      use_template_offsets=False).cuda()
+    sw._node_radius.data = sc["node_radius"].cuda()
+    with torch.no_grad():
+        sw.pose_net.rotation_predictor.weight.mul_(0.1)
+    bg = torch.tensor([0.1, 0.2, 0.3], device="cuda")
+    g = torch.Generator().manual_seed(4)
+    gimg = (torch.sign(torch.rand(3, H, W, generator=g) - 0.5) / (3 * H * W)).cuda()
+    gn, gq, gt = (torch.randn(J, 3, generator=g) * 1e-3).cuda(), (torch.randn(J, 4, generator=g) * 1e-3).cuda(), (torch.randn(3, generator=g) * 1e-3).cuda()
+    params = gm.parameters() + [sw._node_radius] + list(sw.pose_net.parameters()) + ([gm.feature] if with_mask else [])
+
+    def run(frame_entry, arena):
+        for p in params:
+            p.grad = None
+        if frame_entry:
+            pkg = deform_render(cam, gm, sw, Pipe, bg, arena=arena)
+            dn, lq, tr = pkg["d_nodes"], pkg["local_rotation"], pkg["global_trans"]
+        else:
+            dv = sw(gm.get_xyz.detach(), sw.expand_time(cam.fid), motion_mask=gm.motion_mask)
+            pkg = render(cam, gm, Pipe, bg, dv["d_xyz"], dv["d_rotation"], dv["d_scaling"], fused=True, arena=arena)
+            dn, lq, tr = dv["d_nodes"], dv["local_rotation"], dv["global_trans"]
+        loss = (pkg["render"] * gimg).sum()
+        if extra_heads:
+            loss = loss + (dn * gn).sum() + (lq * gq).sum() + (tr.reshape(-1) * gt).sum()
+        loss.backward()
+        torch.cuda.synchronize()
+        return pkg["render"].detach().clone(), pkg["radii"].clone(), [p.grad.detach().clone() for p in params], \
+            pkg["viewspace_points"].grad.detach().clone()
+    a_ref = RasterArena(min_capacity=16)
+    run(False, a_ref)
+    img0, radii0, grads0, vg0 = run(False, a_ref)
+    a_new = RasterArena(min_capacity=16)
+    img_first, _, grads_first, _ = run(True, a_new)      # first frame of the arena: the separate calls
+    assert a_new.last_R >= 0
+    img1, radii1, grads1, vg1 = run(True, a_new)          # the frame entry
+    img2, _, grads2, _ = run(True, a_new)
+    assert torch.equal(img0, img1) and torch.equal(img0, img_first) and torch.equal(img1, img2) and torch.equal(radii0, radii1)
+    for k, (a, b) in enumerate(zip(grads0 + [vg0], grads1 + [vg1])):
+        scale = float(a.abs().max())
+        assert scale > 0, k
+        assert float((a - b).abs().max()) <= 2e-5 * scale, (k, float((a - b).abs().max()) / scale)
+    # against the oracle: image
+    o = O.deform_by_pose(sc["xyz"], sc["joints"], sc["parents"], sc["node_radius"], None, None, None, -1) if False else None
+    with torch.no_grad():
+        pose = sw.get_pose_info(sw.expand_time(cam.fid))
+    mask_cpu = gm.motion_mask.detach().cpu() if with_mask else sc["motion_mask"]
+    o = O.deform_by_pose(sc["xyz"], sc["joints"], sc["parents"], sc["node_radius"], pose["local_rotation"].cpu(), pose["global_trans"].cpu(),
+                         mask_cpu, -1)
+    m3, op, scl, rot, shs = O.render_glue(sc["xyz"], sc["features_dc"], sc["features_rest"], sc["scaling"], sc["rotation"], sc["opacity"],
+                                          o["d_xyz"], o["d_rotation"], o["d_scaling"])
+    camc = cam.to("cpu")
+    out_o, _ = RR.forward(m3.numpy(), op.numpy(), camc.world_view_transform.numpy(), camc.full_proj_transform.numpy(),
+                          camc.camera_center.numpy(), math.tan(camc.FoVx / 2), math.tan(camc.FoVy / 2), H, W, bg.cpu().numpy(),
+                          shs=shs.numpy(), scales=scl.numpy(), rotations=rot.numpy())
+    U.assert_close(img1.cpu().numpy(), out_o["color"], "frame entry image vs oracle", U.REL_TOL, 1e-3)
+
+
 def test_bench_contract_single_and_two_ranks():
     """bench.py end to end on a tiny scene: the N = 1 JSON line carries every field of the contract (roofline, cpu_baseline,
     train_step), and the 2-rank launch (the driver's torch.distributed.run command line; gloo stands in for RCCL on a
@@ -350,6 +424,18 @@ def test_bench_contract_single_and_two_ranks():
     assert d["parity_at_bench_size"]["worst_outlier_frac"] <= 5e-5 and "image" in d["parity_at_bench_size"]
     assert d["parity_at_bench_size"]["dL/d_pose_net"]["max_rel"] <= 1e-4 and d["parity_at_bench_size"]["worst_small_tensor_max_rel"] <= 1e-4
     assert d["roofline"]["bound"] in ("valu", "hbm") and 0 < d["dense_gradient_scene"]["gaussians_with_gradient"] <= 1
+    # ... after the HIP deformation's own forward values were compared with the oracle's (before they replace them)
+    dp = d["parity_at_bench_size"]["deform_forward_vs_oracle_max_rel"]
+    assert dp["d_xyz"] <= 1e-4 and dp["d_rotation"] <= 1e-4
+    # the data-parallel step's sequence on a one-rank RCCL communicator (a child process): the exchange calls issued eagerly
+    # around two graphs, and the whole step — collectives included — captured as one graph
+    # the eagerly issued frame, as the reference's two calls and through the frame entry
+    assert 0 < d["eager_api"]["frame_entry_ms"] and 0 < d["eager_api"]["two_calls_ms"]
+    ex = d["exchange_path"]
+    assert "error" not in ex, ex
+    assert ex["two_graphs_eager_collectives_ms"] > 0 and ex["plain_frame_ms"] > 0 and ex["rows_needed"] > 0
+    assert ex.get("one_graph_ms", 0) > 0, ex
+    assert d["exchange_path_ms"] == ex["one_graph_ms"]
     env["RIGGS_BENCH_BACKEND"] = "gloo"
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1"],
