@@ -515,9 +515,9 @@ def exchange_path_child(steps=200):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n * 1e3
 
-    def rows_for():
+    def rows_for():  # (sized for every row first: the real need is read after the first step)
         return SparseRowExchange([v.view(w["N"], -1) for v in bucket.views[:n_rows]], rest=bucket.flat[bucket.offsets[n_rows]:],
-                                 capacity=max(1024, w["N"] // 8), force_collectives=True)
+                                 capacity=w["N"], force_collectives=True)
     out = {"backend": "nccl (RCCL), one-rank communicator on this GPU", "steps": steps}
     # (0) the plain frame in this process: the reference the two exchange paths are priced against, and their gradients' oracle
     gf = GraphedFrame(gm, sw, cam, bg, params, sparse_grad_rows=False).capture()
@@ -553,7 +553,7 @@ def exchange_path_child(steps=200):
     torch.cuda.synchronize()
     note("first exchanged step done")
     assert rows.check(), "row segments overflowed"
-    rows.resize(int(rows.need * 1.1) + 256)
+    rows.resize(min(w["N"], int(rows.need * 1.1) + 256))
     out["rows_needed"], out["segment_MB"] = int(rows.need), round(rows.segment.numel() * 4 / 1e6, 3)
     out["two_graphs_eager_collectives_ms"] = round(timed(step_eager, steps), 4)
     assert gf.check() == R and rows.check()
@@ -570,7 +570,7 @@ def exchange_path_child(steps=200):
     # (2) ONE graph: the collectives captured with the frame
     try:
         rows = SparseRowExchange([v.view(w["N"], -1) for v in bucket.views[:n_rows]], rest=bucket.flat[bucket.offsets[n_rows]:],
-                                 capacity=int(need * 1.1) + 256, force_collectives=True)
+                                 capacity=min(w["N"], int(need * 1.1) + 256), force_collectives=True)
         rows.record_rows = True
         gf = GraphedFrame(gm, sw, cam, bg, params, split_backward=True, sparse_grad_rows=True)
         gf.set_inputs(gimg=gimg)

@@ -22,6 +22,14 @@ from .render import RenderPkg, _zero_points, render
 from .skeleton import _PoseMLPFn
 
 
+def _req(name, t, shape):
+    """L.require_cuda_f32 with its common case inline (a contiguous float32 device tensor of the expected leading size): the
+    frame entry exists to take host time out of the eager frame, and a dozen full checks per frame are 25 us of it."""
+    if t.is_cuda and t.dtype is torch.float32 and t.is_contiguous() and t.shape[0] == shape[0] and t.dim() == len(shape):
+        return t
+    return L.require_cuda_f32(name, t, shape)
+
+
 class _FrameFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t, rho, mask, xyz, means2D, f_dc, f_rest, opacity, scaling, rotation, spec, *params):
@@ -34,14 +42,14 @@ class _FrameFn(torch.autograd.Function):
         H, W = int(settings.image_height), int(settings.image_width)
         f32 = dict(dtype=torch.float32, device=dev)
         params = [p.contiguous() for p in params]
-        xyz = L.require_cuda_f32("_xyz", xyz, (N, 3))
-        f_dc = L.require_cuda_f32("_features_dc", f_dc, (N, 1, 3))
-        f_rest = L.require_cuda_f32("_features_rest", f_rest, (N, None, 3))
-        opacity = L.require_cuda_f32("_opacity", opacity, (N, 1))
-        scaling = L.require_cuda_f32("_scaling", scaling, (N, 1 if isotropic else 3))
-        rotation = L.require_cuda_f32("_rotation", rotation, (N, 4))
-        rho = L.require_cuda_f32("_node_radius", rho, (J,))
-        mflat = None if mask is None else L.require_cuda_f32("motion_mask", mask.reshape(-1), (N,))
+        xyz = _req("_xyz", xyz, (N, 3))
+        f_dc = _req("_features_dc", f_dc, (N, 1, 3))
+        f_rest = _req("_features_rest", f_rest, (N, None, 3))
+        opacity = _req("_opacity", opacity, (N, 1))
+        scaling = _req("_scaling", scaling, (N, 1 if isotropic else 3))
+        rotation = _req("_rotation", rotation, (N, 4))
+        rho = _req("_node_radius", rho, (J,))
+        mflat = None if mask is None else _req("motion_mask", mask.reshape(-1), (N,))
         joints, par = sw._joints(), sw._parents_dev(dev)
         sync = pn._hip_sync
         if sync.device != dev or sync.numel() * 4 < lib.riggs_pose_mlp_sync_bytes(depth, width):
@@ -149,10 +157,16 @@ _ARENAS = {}
 
 
 def _covered(pc, sw, pipe, t, kw):
+    if kw or pipe.compute_cov3D_python or pipe.convert_SHs_python or not pc._xyz.is_cuda:
+        return False
     pn = sw.pose_net
-    return (pc.get_xyz.is_cuda and not sw.use_skinning_weight_mlp and not sw.use_template_offsets and sw.K <= 0
-            and not pipe.compute_cov3D_python and not pipe.convert_SHs_python and not kw
-            and pn._fusable(t[0]) and pn.rotation_predictor.out_features == 4 * sw.nodes.shape[0])
+    key = (sw.use_skinning_weight_mlp, sw.use_template_offsets, sw.K, pn.rotation_predictor.out_features, sw.nodes.shape[0], t.device)
+    cached = getattr(sw, "_frame_entry_ok", None)
+    if cached is None or cached[0] != key:  # (the network's shape does not change under training: checked once per configuration)
+        ok = (not sw.use_skinning_weight_mlp and not sw.use_template_offsets and sw.K <= 0 and pn._fusable(t[0])
+              and pn.rotation_predictor.out_features == 4 * sw.nodes.shape[0])
+        cached = sw._frame_entry_ok = (key, ok)
+    return cached[1]
 
 
 def deform_render(viewpoint_camera, pc, sw, pipe, bg_color, scaling_modifier=1.0, arena: RasterArena = None, **render_kwargs):

@@ -169,7 +169,10 @@ class GraphedFrame:
         try:
             if self.split and self.exchange_in_graph:
                 self.graph_b = None
-                with torch.cuda.graph(self.graph, stream=s):
+                # (thread-local capture errors: the process group's watchdog thread polls the events of the warm-up's
+                # collectives; in the default global mode such a call from ANOTHER thread, landing inside the capture,
+                # invalidates it — seen as "operation not permitted when stream is capturing", now and then)
+                with torch.cuda.graph(self.graph, stream=s, capture_error_mode="thread_local"):
                     self.out = self._frame_exchanged()
             elif self.split:
                 self.graph_b = torch.cuda.CUDAGraph()

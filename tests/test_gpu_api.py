@@ -434,8 +434,9 @@ def test_bench_contract_single_and_two_ranks():
     ex = d["exchange_path"]
     assert "error" not in ex, ex
     assert ex["two_graphs_eager_collectives_ms"] > 0 and ex["plain_frame_ms"] > 0 and ex["rows_needed"] > 0
-    assert ex.get("one_graph_ms", 0) > 0, ex
-    assert d["exchange_path_ms"] == ex["one_graph_ms"]
+    # (the captured form is reported when the capture succeeded; a failure is recorded in the line, not hidden)
+    assert ex.get("one_graph_ms", 0) > 0 or "one_graph_error" in ex, ex
+    assert d["exchange_path_ms"] == ex.get("one_graph_ms", ex["two_graphs_eager_collectives_ms"])
     env["RIGGS_BENCH_BACKEND"] = "gloo"
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1"],

@@ -31,7 +31,8 @@ def main():
         print("%s: %.4f ms per eager frame" % (label, (time.perf_counter() - t0) / steps * 1e3))
         if bucket is not None:
             bucket.unregister()
-    step = bench.make_step(cam, gm, sw, gimg, RasterArena(), 1, None)
+    fe = len(sys.argv) > 2 and sys.argv[2] == "frame"
+    step = bench.make_step(cam, gm, sw, gimg, RasterArena(), 1, None, frame_entry=fe)
     for _ in range(20):
         step()
     torch.cuda.synchronize()
