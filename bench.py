@@ -235,6 +235,31 @@ def dense_scene_timing(dev, steps=50):
             "what": "same path / sizes / camera, thin opaque skin around the bones (synth.make_surface_scene); not the headline metric"}
 
 
+def tight_lists_timing(dev, gimg, steps=100):
+    """Secondary number (NOT the metric): the headline workload with riggs_raster_cfg.tight_lists — tile rectangles cut down to the
+    tiles a Gaussian can reach with alpha >= 1/255 (same image and gradients to rounding, fewer instances to sort, stage and
+    walk; the canonical lists stay the headline's because they are what upstream builds)."""
+    from riggs_amd import rasterizer as RZ
+    from riggs_amd.graph import GraphedFrame
+    sc, cam, gm, sw = build_workload(0, dev)
+    RZ.set_tight_lists(True)
+    try:
+        gf = GraphedFrame(gm, sw, cam, torch.zeros(3, device=dev), params_of(gm, sw), sparse_grad_rows=True).capture()
+    finally:
+        RZ.set_tight_lists(False)
+    gf.set_inputs(gimg=gimg)
+    for _ in range(10):
+        gf.run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        gf.run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(1.0 / dt, 2), "unit": "iters/s", "ms_per_step": round(dt * 1e3, 4), "tile_instances_R": int(gf.check()),
+            "what": "same workload with cfg.tight_lists (alpha-box tile rectangles); not the headline metric"}
+
+
 def cycling_cameras_timing(dev, steps=64, n_cams=8):
     """Secondary number (NOT the metric): the headline workload replayed the way a trainer uses it — a different camera every
     iteration (train_rig.py:389 draws a random one): ``n_cams`` cameras on a circle around the subject, rotated through the
@@ -1088,6 +1113,7 @@ def main():
             out["next_rows"] = next_rows_timing(sc, gm, cam)
             out["dense_gradient_scene"] = dense_scene_timing(dev)
             out["cycling_cameras"] = cycling_cameras_timing(dev)
+            out["tight_lists"] = tight_lists_timing(dev, gimg)
             # the data-parallel step's host + device sequence on a one-rank RCCL communicator (a child process)
             out["exchange_path"] = exchange_path_timing()
             out["exchange_path_ms"] = out["exchange_path"].get("one_graph_ms", out["exchange_path"].get("two_graphs_eager_collectives_ms"))

@@ -85,6 +85,14 @@ typedef struct riggs_raster_cfg {
    * autograd backward, whose outputs are fresh allocations, does not.  riggs_grad_rows_unpack keeps the guarantee intact
    * when it is given the workspace (it records the rows it writes). */
   int32_t sparse_zero;
+  /* 1 = tight instance lists: a Gaussian's tile rectangle (upstream: every tile its ceil(3 sigma) square overlaps) is cut down
+   * to the tiles in which alpha = o * exp(power) can reach 1/255 at some pixel centre, by the axis-aligned box of that
+   * region (conservative margins).  The dropped instances contribute nothing to any pixel or gradient — they fail the
+   * alpha test at every pixel of their tile — so images and gradients are the canonical ones to rounding (the lists'
+   * positions move, and with them the grouping of the transmittance products); `radii` is unchanged; the instance list is
+   * the canonical list with those instances removed, in the same order.  About a fifth of the instances of a translucent
+   * scene (tools/dead_instances.py); the canonical lists (0) are the default and what the ordering parity tests pin. */
+  int32_t tight_lists;
 } riggs_raster_cfg;
 
 /* Opaque arenas (upstream: geomBuffer / binningBuffer / imgBuffer byte tensors).  The binning arena's size depends on ALL

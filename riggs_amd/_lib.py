@@ -25,7 +25,7 @@ class RasterCfg(C.Structure):
         ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
         ("bg", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
         ("debug", C.c_int32), ("glue", C.c_int32), ("isotropic", C.c_int32), ("deterministic", C.c_int32),
-        ("sparse_zero", C.c_int32),
+        ("sparse_zero", C.c_int32), ("tight_lists", C.c_int32),
     ]
 
 

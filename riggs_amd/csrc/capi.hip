@@ -207,7 +207,7 @@ static int fill_pre_args(PreArgs& a, const riggs_raster_cfg* c, const float* mea
   RIGGS_REQUIRE(!(c->glue && cov3D_precomp), "glue mode needs scales/rotations");
   GeomLayout L = geom_layout(c->num_points);
   a.N = c->num_points; a.deg = c->sh_degree; a.M = c->sh_coeffs; a.W = c->image_width; a.H = c->image_height;
-  a.glue = c->glue; a.isotropic = c->isotropic;
+  a.glue = c->glue; a.isotropic = c->isotropic; a.tight = c->tight_lists;
   a.tanx = c->tanfovx; a.tany = c->tanfovy; a.mod = c->scale_modifier;
   a.view = c->viewmatrix; a.proj = c->projmatrix; a.campos = c->campos;
   a.means3D = means3D; a.shs = shs; a.shs_rest = shs_rest; a.colors_precomp = colors_precomp; a.opac = opac; a.scales = scales; a.rots = rots;

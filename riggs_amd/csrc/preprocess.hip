@@ -264,6 +264,18 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a) {
     if (tau > 0.0f) { cull_hx = sqrtf(tau * cv.a) + 0.01f; cull_hy = sqrtf(tau * cv.c) + 0.01f; }
     if (!(cull_hx == cull_hx) || !(cull_hy == cull_hy)) { cull_hx = 1e30f; cull_hy = 1e30f; }  // NaN: never cull
   }
+  if (a.tight) {
+    // cfg.tight_lists: the tile rectangle is cut down to the tiles whose PIXEL CENTRES (integer coordinates 16 t .. 16 t + 15)
+    // the alpha >= 1/255 box [p - h, p + h] reaches — the extents above carry their margins, so no tile with a reachable pixel
+    // is dropped.  A Gaussian that reaches none (opacity below 1/255, or a box that falls between tiles at the image border)
+    // keeps its radius (it is "visible" as upstream defines it) and gets no instance.
+    if (cull_hx < 0.0f) { x1 = x0; y1 = y0; }
+    else {
+      x0 = max(x0, (int)floorf((px - cull_hx) * (1.0f / RIGGS_TILE))); x1 = min(x1, (int)floorf((px + cull_hx) * (1.0f / RIGGS_TILE)) + 1);
+      y0 = max(y0, (int)floorf((py - cull_hy) * (1.0f / RIGGS_TILE))); y1 = min(y1, (int)floorf((py + cull_hy) * (1.0f / RIGGS_TILE)) + 1);
+      if (x1 <= x0 || y1 <= y0) { x1 = x0; y1 = y0; }
+    }
+  }
   a.radii[i] = ir;
   a.xyd[i] = make_float4(px, py, vz, cull_hx);
   a.conic_o[i] = make_float4(cv.c * det_inv, -cv.b * det_inv, cv.a * det_inv, g.o);

@@ -5,7 +5,7 @@
 namespace riggs {
 
 struct PreArgs {
-  int N, deg, M, W, H, glue, isotropic;
+  int N, deg, M, W, H, glue, isotropic, tight;
   float tanx, tany, mod;
   const float *view, *proj, *campos;
   const float *means3D, *shs, *shs_rest, *colors_precomp, *opac, *scales, *rots, *cov3D_precomp, *d_xyz, *d_rot, *d_scaling;

@@ -322,6 +322,80 @@ def test_render_rejects_a_binning_arena_that_is_too_small():
     assert len(sizes) <= 2 and max(sizes) - min(sizes) <= 4096, sizes  # (monotonic up to alignment in N across the switch)
 
 
+@pytest.mark.parametrize("case,opacity_scale", [(1, 1.0), (2, 0.05), (5, 1.0), (4, 0.3)])
+def test_tight_lists_are_the_canonical_lists_minus_the_instances_that_cannot_reach_a_pixel(case, opacity_scale):
+    """cfg.tight_lists (rasterizer.set_tight_lists): the tile rectangle of a Gaussian is cut down by its alpha >= 1/255 box.
+    Contract: radii unchanged; the instance list = the CANONICAL list (the oracle's key sort) with the instances outside the box
+    removed, order kept — bit for bit, the predicate evaluated here in float32 from the extents the kernel stored; no instance
+    that reaches alpha >= 1/255 at a pixel centre of its tile (float64 truth) is ever dropped; image, depth, alpha and every
+    gradient equal the canonical ones (the dropped instances fail the alpha test everywhere in their tile)."""
+    from riggs_amd import rasterizer as RZ
+    N, J, seed, H, W, scale, camkw = CASES[case]
+    sc, act, cam = U.activated_scene(N, J, seed, H, W, scale=scale, **camkw)
+    act["opacities"] = act["opacities"] * opacity_scale
+    bg = [0.1, 0.3, 0.7]
+    out_o, so = U.oracle_forward(act, cam, bg)
+    c_color, c_radii, c_depth, c_alpha, c_s = U.hip_forward(act, cam, bg)
+    RZ.set_tight_lists(True)
+    try:
+        color, radii, depth, alpha, s = U.hip_forward(act, cam, bg)
+        assert s.cfg.tight_lists == 1
+        v = saved_views(s)
+        g = torch.Generator().manual_seed(seed)
+        gc = torch.sign(torch.rand(3, H, W, generator=g) - 0.5) / (3 * H * W)
+        gd = torch.randn(1, H, W, generator=g) / (H * W)
+        ga = torch.randn(1, H, W, generator=g) / (H * W)
+        d = lambda t: t.cuda().contiguous()  # noqa: E731
+        gh = rasterize_backward(s, d(act["means3D"]), d(act["shs"]), None, d(act["opacities"]), d(act["scales"]), d(act["rotations"]),
+                                None, None, None, d(gc), d(gd), d(ga))
+    finally:
+        RZ.set_tight_lists(False)
+    assert torch.equal(radii, c_radii) and np.array_equal(radii.cpu().numpy(), so.radii)
+    gx = (W + 15) // 16
+    xyd, rgbh = v["xyd"].cpu().numpy(), v["rgb"].cpu().numpy()
+    px, py, hx, hy = xyd[:, 0], xyd[:, 1], xyd[:, 3], rgbh[:, 3]
+    pl = so.point_list.astype(np.int64)
+    tile = (so.keys >> np.uint64(32)).astype(np.int64)
+    tx, ty = tile % gx, tile // gx
+    f32, inv16 = np.float32, np.float32(1.0 / 16.0)
+    with np.errstate(invalid="ignore", over="ignore"):
+        x_lo, x_hi = np.floor((px - hx) * inv16), np.floor((px + hx) * inv16)
+        y_lo, y_hi = np.floor((py - hy) * inv16), np.floor((py + hy) * inv16)
+    keep = (hx[pl] >= 0) & (tx >= x_lo[pl]) & (tx <= x_hi[pl]) & (ty >= y_lo[pl]) & (ty <= y_hi[pl])
+    # a rectangle that the box empties in ONE direction is emptied altogether
+    want_pl, want_tile = pl[keep], tile[keep]
+    assert v["R"] == int(keep.sum()), (v["R"], int(keep.sum()), so.R)
+    assert np.array_equal(v["point_list"].cpu().numpy().astype(np.int64), want_pl), "tight list != filtered canonical list"
+    assert np.array_equal(v["tile_keys"].cpu().numpy().astype(np.int64), want_tile)
+    assert np.array_equal(v["tiles_touched"].cpu().numpy().astype(np.int64), np.bincount(want_pl, minlength=N))
+    T = gx * ((H + 15) // 16)
+    cnt = np.bincount(want_tile, minlength=T)
+    rg = v["ranges"].cpu().numpy().astype(np.int64)
+    assert np.array_equal((rg[:, 1] - rg[:, 0]), cnt)
+    removed = 1.0 - keep.mean()
+    assert removed > (0.02 if opacity_scale == 1.0 else 0.10), removed
+    # nothing alive is dropped: float64 truth over the pixel centres of every canonical instance's tile
+    co = so.conic_o[pl].astype(np.float64)
+    cx, cy = so.xy[pl, 0].astype(np.float64), so.xy[pl, 1].astype(np.float64)
+    alive = np.zeros(pl.shape[0], bool)
+    for a in range(0, pl.shape[0], 100_000):
+        b = min(pl.shape[0], a + 100_000)
+        qx = (tx[a:b, None] * 16 + np.arange(16)[None]).astype(np.float64)
+        qy = (ty[a:b, None] * 16 + np.arange(16)[None]).astype(np.float64)
+        dx, dy = (cx[a:b, None] - qx)[:, None, :], (cy[a:b, None] - qy)[:, :, None]
+        power = -0.5 * (co[a:b, 0, None, None] * dx * dx + co[a:b, 2, None, None] * dy * dy) - co[a:b, 1, None, None] * dx * dy
+        ok = (power <= 0) & (co[a:b, 3, None, None] * np.exp(np.minimum(power, 0)) >= 1.0 / 255.0) & (qx[:, None, :] < W) & (qy[:, :, None] < H)
+        alive[a:b] = ok.any(axis=(1, 2))
+    assert not (alive & ~keep).any(), "a contributing instance was dropped"
+    # same picture, same gradients
+    for got, ref, name in ((color, c_color, "color"), (depth, c_depth, "depth"), (alpha, c_alpha, "alpha")):
+        assert float((got - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max())), name
+    U.assert_close(color.cpu().numpy(), out_o["color"], "tight color vs oracle", U.REL_TOL, 2e-5)
+    go = RR.backward(so, gc.numpy(), gd.numpy()[0], ga.numpy()[0])
+    for got, name in ((gh[1], "means2D"), (gh[0], "means3D"), (gh[4], "opacities"), (gh[5], "scales"), (gh[6], "rotations"), (gh[2], "shs")):
+        _grads_close(got, go[name], "tight lists: dL/d" + name)
+
+
 def test_arena_follows_a_growing_scene_and_image():
     """The arena also holds tables sized by the number of Gaussians and of tiles: at an unchanged instance capacity a scene with
     more Gaussians or a larger image must get a larger arena (it used to be sized by the capacity alone)."""
