@@ -512,6 +512,34 @@ size_t riggs_knn_workspace_bytes(int32_t num_points);
 int riggs_dist2_knn3(int32_t num_points, const float* points, float* out, void* workspace, riggs_stream stream);
 
 /* =====================================================================
+ * Densification / pruning of the Gaussian cloud on the device (SURVEY.md §2 row 6 "next") — scene/gaussian_model.py:
+ * densify_and_prune :500-514, densify_and_clone :475-498, densify_and_split :440-473, prune_points :373-392 and the optimizer
+ * surgery around them (:338-417), called every densification_interval iterations at train_rig.py:359-365.
+ *   riggs_densify_select   the three predicates of ONE densify_and_prune call as byte flags (3, N): [0] the old row survives
+ *                          (not split, not pruned), [1] a clone of it is made and survives, [2] its split children survive
+ *                          (grads = accum / denom with NaN -> 0; clone: |grad| >= thr and max scale <= dense_limit; split: grad
+ *                          >= thr and max scale > dense_limit; prune: sigmoid(opacity) < min_opacity or, with world_limit >= 0,
+ *                          max scale > world_limit — the children with their scale / child_div; the reference's screen-size
+ *                          test never fires there: densification_postfix has zeroed max_radii2D by then)
+ *   riggs_compact_indices  ascending indices of the set flags + their number (device int32), three launches, no atomics
+ *   riggs_rows_gather      dst[t][m, :] = src[t][plan[m], :] for up to 32 tensors in ONE launch; plan[m] < 0 marks a NEW row made
+ *                          from source ~plan[m]: tensors with zero_new[t] (the Adam moments) get zeros there
+ *   riggs_split_children   the children's position R(q_parent) (z * scale_parent) + xyz_parent and log(scale_parent / child_div)
+ *                          (z: unit normals, (n_children, 3); child j has parent parents[j % n_parents]: copy-major like .repeat(N, 1))
+ * ===================================================================== */
+int riggs_densify_select(int32_t num_points, int32_t scaling_columns, const float* xyz_gradient_accum, const float* denom,
+                         const float* scaling, const float* opacity, float grad_threshold, float dense_limit, float min_opacity,
+                         float world_limit, float child_div, uint8_t* flags, riggs_stream stream);
+size_t riggs_compact_workspace_bytes(int32_t num_points);
+int riggs_compact_indices(int32_t num_points, const uint8_t* flags, int32_t* out_indices, int32_t* count, void* workspace,
+                          riggs_stream stream);
+int riggs_rows_gather(int32_t n_out, const int32_t* plan, int32_t n_tensors, const float* const* src, float* const* dst,
+                      const int32_t* row_floats, const uint8_t* zero_new, riggs_stream stream);
+int riggs_split_children(int32_t n_children, int32_t n_parents, int32_t scaling_columns, const int32_t* parents,
+                         const float* unit_normals, const float* xyz, const float* scaling, const float* rotation, float child_div,
+                         float* new_xyz, float* new_scaling, riggs_stream stream);
+
+/* =====================================================================
  * Dual-quaternion blending of rigid transforms — utils/dual_quaternion.py: QT2DQ :135-143, DQ2QT :146-165,
  * DQBlending :168-179 (what these two entry points compute), interpolate :182-187 and transformation_blending :190-197
  * (host compositions of them: riggs_amd/dual_quaternion.py).  The reference never calls the module on the skeleton path

@@ -119,6 +119,11 @@ _SIGS = {
     "riggs_mlp_embed": (C.c_int, [C.c_int32] * 3 + [_P] * 3 + [C.c_int32, _P]),
     "riggs_mlp_pack": (C.c_int, [C.c_int32] * 4 + [_P] * 6 + [C.c_int32, _P]),
     "riggs_mlp_layout_probe": (C.c_int, [_P, _P]),
+    "riggs_densify_select": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P] + [C.c_float] * 5 + [_P, _P]),
+    "riggs_compact_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "riggs_compact_indices": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P]),
+    "riggs_rows_gather": (C.c_int, [C.c_int32, _P, C.c_int32, _P, _P, _P, _P, _P]),
+    "riggs_split_children": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P]),
     "riggs_frame_forward": (C.c_int, [C.POINTER(Frame), _P]),
     "riggs_frame_backward": (C.c_int, [C.POINTER(Frame), C.POINTER(FrameGrads), _P]),
     "riggs_dqb_forward": (C.c_int, [C.c_int32] * 5 + [_P] * 6),

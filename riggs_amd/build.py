@@ -29,6 +29,7 @@ SOURCES = {
     "exchange.hip": ["-ffp-contract=off"],
     "dq.hip": ["-ffp-contract=off"],
     "frame.hip": [],
+    "densify.hip": ["-ffp-contract=off"],
     "capi.hip": [],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fhip-fp32-correctly-rounded-divide-sqrt",

@@ -185,3 +185,155 @@ class GaussianModel:
             self.feature = P(feas)
         self.max_radii2D = torch.zeros(n, device=device)
         self.active_sh_degree = self.max_sh_degree
+
+    # ---- densification / pruning (scene/gaussian_model.py:275-278, 338-514; train_rig.py:359-365) --------------------------
+    # Same method names, arguments and results as the reference.  The row work — every parameter tensor and both Adam moments
+    # of every group re-assembled for the new cloud — is ONE gather launch from an index plan (csrc/densify.hip); the plan comes
+    # from stream compactions of byte flags, and densify_and_prune's three predicates from one selection kernel.
+    def _groups(self):
+        return {g["name"]: g for g in self.optimizer.param_groups}
+
+    def _compact(self, flags):
+        """Ascending int32 indices of the non-zero entries of a uint8 / bool device vector (riggs_compact_indices)."""
+        from . import _lib as L
+        f = flags.to(torch.uint8).contiguous()
+        n, dev = f.numel(), f.device
+        lib = L.lib()
+        idx = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        cnt = torch.empty(1, dtype=torch.int32, device=dev)
+        ws = torch.empty(lib.riggs_compact_workspace_bytes(n), dtype=torch.uint8, device=dev)
+        L.check(lib.riggs_compact_indices(n, f.data_ptr(), idx.data_ptr(), cnt.data_ptr(), ws.data_ptr(), L.stream_ptr()),
+                "riggs_compact_indices")
+        return idx[:int(cnt.item())]
+
+    def _regather(self, plan, stats="zero", children=None):
+        """The new cloud from an index plan: row m of every tensor comes from row ``plan[m]`` of the old one; ``plan[m] < 0``
+        marks a NEW row made from source ``~plan[m]`` (its Adam moments start at zero: cat_tensors_to_optimizer :394-417; kept
+        rows keep theirs: _prune_optimizer :355-371).  ``children`` = (first row, parents (S,), copies, unit normals or None):
+        the rows of split children, whose position and scale are then re-drawn (densify_and_split :452-460).  ``stats``:
+        "zero" (densification_postfix :435-437) or "gather" (prune_points :388-392)."""
+        import ctypes as C
+        from . import _lib as L
+        lib = L.lib()
+        plan = plan.to(torch.int32).contiguous()
+        n_out, dev = plan.numel(), plan.device
+        src, dst, width, zero_new, owners = [], [], [], [], []
+        for g in self.optimizer.param_groups:
+            p = g["params"][0]
+            st = self.optimizer.state.get(p, None)
+            new_p = torch.empty((n_out,) + tuple(p.shape[1:]), dtype=torch.float32, device=dev)
+            src.append(p.detach().contiguous()); dst.append(new_p); width.append(max(1, p.numel() // max(1, p.shape[0])) if p.shape[0] else int(math.prod(p.shape[1:]))); zero_new.append(0)
+            moments = None
+            if st is not None and "exp_avg" in st:
+                moments = (torch.empty_like(new_p), torch.empty_like(new_p))
+                for m_old, m_new in zip((st["exp_avg"], st["exp_avg_sq"]), moments):
+                    src.append(m_old.contiguous()); dst.append(m_new); width.append(width[-1]); zero_new.append(1)
+            owners.append((g, p, st, new_p, moments))
+        if stats == "gather":
+            new_stats = []
+            for t in (self.xyz_gradient_accum, self.denom, self.max_radii2D):
+                nt = torch.empty((n_out,) + tuple(t.shape[1:]), dtype=torch.float32, device=dev)
+                src.append(t.contiguous()); dst.append(nt); width.append(1); zero_new.append(1)
+                new_stats.append(nt)
+        k = len(src)
+        if n_out:
+            L.check(lib.riggs_rows_gather(n_out, plan.data_ptr(), k, (C.c_void_p * k)(*[t.data_ptr() for t in src]),
+                                          (C.c_void_p * k)(*[t.data_ptr() for t in dst]), (C.c_int32 * k)(*width),
+                                          (C.c_uint8 * k)(*zero_new), L.stream_ptr()), "riggs_rows_gather")
+        if children is not None and children[1].numel():
+            row0, parents, copies, z = children
+            S = int(parents.numel())
+            n_ch = S * copies
+            if z is None:
+                z = torch.randn(n_ch, 3, device=dev)
+            z = z.to(dev, torch.float32).contiguous()
+            grp = self._groups()
+            old_xyz, old_sc, old_rot = grp["xyz"]["params"][0], grp["scaling"]["params"][0], grp["rotation"]["params"][0]
+            new_xyz = next(o[3] for o in owners if o[0]["name"] == "xyz")
+            new_sc = next(o[3] for o in owners if o[0]["name"] == "scaling")
+            cols = old_sc.shape[1]
+            L.check(lib.riggs_split_children(n_ch, S, cols, parents.data_ptr(), z.data_ptr(), old_xyz.data_ptr(), old_sc.data_ptr(),
+                                             old_rot.data_ptr(), 0.8 * copies, new_xyz[row0:].data_ptr(), new_sc[row0:].data_ptr(),
+                                             L.stream_ptr()), "riggs_split_children")
+        out = {}
+        for g, p, st, new_p, moments in owners:
+            new_param = nn.Parameter(new_p.requires_grad_(True))
+            if st is not None:
+                del self.optimizer.state[p]
+                if moments is not None:
+                    st["exp_avg"], st["exp_avg_sq"] = moments
+                self.optimizer.state[new_param] = st
+            g["params"][0] = new_param
+            out[g["name"]] = new_param
+        self._xyz, self._features_dc, self._features_rest = out["xyz"], out["f_dc"], out["f_rest"]
+        self._opacity, self._scaling, self._rotation = out["opacity"], out["scaling"], out["rotation"]
+        if self.fea_dim > 0:
+            self.feature = out["feature"]
+        if stats == "gather":
+            self.xyz_gradient_accum, self.denom, self.max_radii2D = new_stats
+        else:
+            self.xyz_gradient_accum = torch.zeros((n_out, 1), device=dev)
+            self.denom = torch.zeros((n_out, 1), device=dev)
+            self.max_radii2D = torch.zeros(n_out, device=dev)
+        self._ones_mask = None
+        return out
+
+    def replace_tensor_to_optimizer(self, tensor, name):  # :338-353
+        out = {}
+        for group in self.optimizer.param_groups:
+            if group["name"] == name:
+                st = self.optimizer.state.get(group["params"][0], None)
+                new_param = nn.Parameter(tensor.requires_grad_(True))
+                if st is not None:
+                    st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(tensor), torch.zeros_like(tensor)
+                    del self.optimizer.state[group["params"][0]]
+                    self.optimizer.state[new_param] = st
+                group["params"][0] = new_param
+                out[name] = new_param
+        return out
+
+    def reset_opacity(self):  # :275-278
+        op = torch.minimum(self.get_opacity, torch.full_like(self._opacity, 0.01))
+        self._opacity = self.replace_tensor_to_optimizer(torch.log(op / (1 - op)), "opacity")["opacity"]
+
+    def prune_points(self, mask):  # :373-392
+        self._regather(self._compact(~mask.reshape(-1).bool()), stats="gather")
+
+    def densify_and_clone(self, grads=None, grad_threshold=None, scene_extent=None, selected_pts_mask=None):  # :475-498
+        if selected_pts_mask is None:
+            selected_pts_mask = (torch.norm(grads, dim=-1) >= grad_threshold) & \
+                (torch.max(self.get_scaling, dim=1).values <= self.percent_dense * scene_extent)
+        n = self._xyz.shape[0]
+        clones = self._compact(selected_pts_mask.reshape(-1))
+        self._regather(torch.cat([torch.arange(n, dtype=torch.int32, device=clones.device), ~clones]), stats="zero")
+
+    def densify_and_split(self, grads=None, grad_threshold=None, scene_extent=None, N=2, selected_pts_mask=None, without_prune=False,
+                          unit_normals=None):  # :440-473
+        """``unit_normals`` (S * N, 3): the standard-normal draws behind the children's offsets (the reference draws
+        ``torch.normal(0, stds)`` = stds * z itself; tests hand the same z to both sides)."""
+        n = self._xyz.shape[0]
+        if selected_pts_mask is None:
+            padded = torch.zeros(n, device=self._xyz.device)
+            padded[:grads.shape[0]] = grads.squeeze()
+            selected_pts_mask = (padded >= grad_threshold) & (torch.max(self.get_scaling, dim=1).values > self.percent_dense * scene_extent)
+        sel = selected_pts_mask.reshape(-1).bool()
+        parents = self._compact(sel)
+        kept = torch.arange(n, dtype=torch.int32, device=parents.device) if without_prune else self._compact(~sel)
+        plan = torch.cat([kept] + [~parents] * N)
+        self._regather(plan, stats="zero", children=(int(kept.numel()), parents, N, unit_normals))
+
+    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, unit_normals=None):  # :500-514
+        """clone -> split -> prune as ONE selection + three compactions + ONE gather; the resulting rows and their order are
+        the reference's: surviving old rows, surviving clones, surviving children (copy-major)."""
+        from . import _lib as L
+        n, dev = self._xyz.shape[0], self._xyz.device
+        flags = torch.empty(3, n, dtype=torch.uint8, device=dev)
+        sc = self._scaling.detach().contiguous()
+        L.check(L.lib().riggs_densify_select(n, sc.shape[1], self.xyz_gradient_accum.contiguous().data_ptr(), self.denom.contiguous().data_ptr(),
+                                             sc.data_ptr(), self._opacity.detach().contiguous().data_ptr(), float(max_grad),
+                                             float(self.percent_dense * extent), float(min_opacity),
+                                             float(0.1 * extent) if max_screen_size else -1.0, 1.6, flags.data_ptr(), L.stream_ptr()),
+                "riggs_densify_select")
+        kept, clones, parents = self._compact(flags[0]), self._compact(flags[1]), self._compact(flags[2])
+        plan = torch.cat([kept, ~clones, ~parents, ~parents])
+        self._regather(plan, stats="zero", children=(int(kept.numel() + clones.numel()), parents, 2, unit_normals))

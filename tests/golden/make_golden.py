@@ -548,6 +548,99 @@ def fixture_deform_heads(name, seed, J, N):
     print("wrote", name)
 
 
+def fixture_densify(name, seed, N, isotropic, fea_dim):
+    """the reference's own densify_and_prune (scene/gaussian_model.py:500-514 -> densify_and_clone :475,
+    densify_and_split :440, prune_points :373 with the optimizer surgery :338-417) and reset_opacity (:275) on a model that
+    has taken one Adam step (so the moments are non-trivial) and has densification statistics; plus prune_points /
+    densify_and_clone / densify_and_split called on their own.  torch.normal is wrapped to record the unit normals behind the
+    split children (the draw is samples = std * z)."""
+    from types import SimpleNamespace
+    args = SimpleNamespace(percent_dense=0.01, position_lr_init=0.00016, position_lr_final=0.0000016,
+                           position_lr_delay_mult=0.01, position_lr_max_steps=30000, feature_lr=0.0025, opacity_lr=0.05,
+                           scaling_lr=0.001, rotation_lr=0.001, skeleton_gs_position_lr=0.00001)
+    names = ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"] + (["feature"] if fea_dim else [])
+
+    def model():
+        g = torch.Generator().manual_seed(seed)
+        gm = GaussianModel(3, fea_dim=fea_dim, with_motion_mask=False, use_isotropic_gs=isotropic)
+        P = torch.nn.Parameter
+        gm._xyz = P(torch.randn(N, 3, generator=g))
+        gm._features_dc = P(torch.randn(N, 1, 3, generator=g))
+        gm._features_rest = P(0.1 * torch.randn(N, 15, 3, generator=g))
+        gm._scaling = P(math.log(0.04 if isotropic else 0.015) + 0.9 * torch.randn(N, 1 if isotropic else 3, generator=g))
+        gm._rotation = P(torch.randn(N, 4, generator=g))
+        gm._opacity = P(2.5 * torch.randn(N, 1, generator=g))
+        if fea_dim:
+            gm.feature = P(torch.randn(N, fea_dim, generator=g))
+        gm.max_radii2D = torch.rand(N, generator=g) * 40
+        with S.quiet():
+            gm.training_setup(args)
+        for grp in gm.optimizer.param_groups:
+            grp["params"][0].grad = torch.randn(grp["params"][0].shape, generator=g)
+        gm.optimizer.step()
+        gm.optimizer.zero_grad(set_to_none=True)
+        gm.xyz_gradient_accum = (torch.rand(N, 1, generator=g) ** 3) * 6e-4 * torch.randint(0, 4, (N, 1), generator=g)
+        gm.denom = torch.randint(0, 4, (N, 1), generator=g).float()   # zeros among them: 0 / 0 = NaN -> 0 (:502)
+        return gm, g
+
+    def snap(gm, tag, out):
+        grp = {g_["name"]: g_ for g_ in gm.optimizer.param_groups}
+        for k in names:
+            p = grp[k]["params"][0]
+            st = gm.optimizer.state[p]
+            out["%s_%s" % (tag, k)] = np_(p).copy()
+            out["%s_m_%s" % (tag, k)] = np_(st["exp_avg"]).copy()
+            out["%s_v_%s" % (tag, k)] = np_(st["exp_avg_sq"]).copy()
+            out["%s_step_%s" % (tag, k)] = np.array(float(st["step"]))
+        out[tag + "_accum"], out[tag + "_denom"], out[tag + "_radii2D"] = np_(gm.xyz_gradient_accum).copy(), np_(gm.denom).copy(), np_(gm.max_radii2D).copy()
+    out = {"isotropic": np.array(isotropic), "fea_dim": np.array(fea_dim), "percent_dense": np.array(args.percent_dense)}
+    rec = []
+    orig_normal = torch.normal
+
+    def normal(mean=None, std=None, **kw):
+        z = torch.randn(std.shape, generator=torch.Generator().manual_seed(seed + 7 + len(rec)))
+        rec.append(z)
+        return mean + std * z
+    torch.normal = normal
+    try:
+        # (1) densify_and_prune as the trainer calls it (train_rig.py:361): with and without the screen-size argument
+        for tag, extent, screen in (("dp", 2.0, 20), ("dq", 2.0, None)):
+            gm, g = model()
+            snap(gm, tag + "0", out)
+            rec.clear()
+            with S.quiet():
+                gm.densify_and_prune(0.0002, 0.005, extent, screen)
+            snap(gm, tag + "1", out)
+            out[tag + "_z"] = np_(rec[0])
+            out[tag + "_args"] = np.array([0.0002, 0.005, extent, -1.0 if screen is None else float(screen)])
+        # (2) the pieces on their own
+        gm, g = model()
+        mask = torch.rand(N, generator=g) < 0.3
+        gm.prune_points(mask)
+        snap(gm, "pr1", out)
+        out["pr_mask"] = np_(mask)
+        gm, g = model()
+        grads = gm.xyz_gradient_accum / gm.denom
+        grads[grads.isnan()] = 0.0
+        gm.densify_and_clone(grads, 0.0002, 2.0)
+        snap(gm, "cl1", out)
+        gm, g = model()
+        grads = gm.xyz_gradient_accum / gm.denom
+        grads[grads.isnan()] = 0.0
+        rec.clear()
+        gm.densify_and_split(grads, 0.0002, 2.0)
+        snap(gm, "sp1", out)
+        out["sp_z"] = np_(rec[0])
+        # (3) reset_opacity
+        gm, g = model()
+        gm.reset_opacity()
+        snap(gm, "ro1", out)
+    finally:
+        torch.normal = orig_normal
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, {k: out[k].shape for k in ("dp0_xyz", "dp1_xyz", "dq1_xyz", "pr1_xyz", "cl1_xyz", "sp1_xyz")})
+
+
 def fixture_dqb(name, seed, N, K, mode, rot_as_q):
     """Dual-quaternion blending exactly as the reference computes it (utils/dual_quaternion.py: QT2DQ :135, DQ2QT :146,
     DQBlending :168, interpolate :182, transformation_blending :190) with autograd's gradients w.r.t. (q, t, weights).
@@ -631,6 +724,8 @@ if __name__ == "__main__":
     fixture_control_nodes_edit("cnodes_edit_res_m96", 87, 500, 96, True)
     fixture_control_nodes_edit("cnodes_edit_abs_m64", 88, 350, 64, False)
     fixture_skeleton_projection("skelproj_chain8_m90_K", 72, 8, 90, True, chain=True)
+    fixture_densify("densify_aniso_n96", 101, 96, False, 0)
+    fixture_densify("densify_iso_fea9_n80", 102, 80, True, 9)
     fixture_dqb("dqb_shared2d_k23_q", 91, 300, 23, "shared2d", True)
     fixture_dqb("dqb_shared3d_k63_R", 92, 257, 63, "shared3d", False)
     fixture_dqb("dqb_rows3d_k3_q", 93, 400, 3, "rows3d", True)
