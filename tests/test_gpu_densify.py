@@ -75,8 +75,9 @@ def test_hip_methods_match_reference_golden(path):
     for tag in ("dp", "dq"):
         gm = mk()
         a = g[tag + "_args"]
-        gm.densify_and_prune(float(a[0]), float(a[1]), float(a[2]), None if a[3] < 0 else float(a[3]),
-                             unit_normals=torch.from_numpy(g[tag + "_z"]))
+        zk, _, _ = kept_children_draws(load(g, "dp0")[0], g["dp0_accum"], g["dp0_denom"], iso, g[tag + "_z"], float(a[0]), float(a[1]),
+                                       float(a[2]), None if a[3] < 0 else float(a[3]))
+        gm.densify_and_prune(float(a[0]), float(a[1]), float(a[2]), None if a[3] < 0 else float(a[3]), unit_normals=torch.from_numpy(zk))
         check(gm, *load(g, tag + "1"), st(tag + "1"), tag)
         for grp in gm.optimizer.param_groups:
             assert float(gm.optimizer.state[grp["params"][0]]["step"]) == 1.0
@@ -98,6 +99,20 @@ def test_hip_methods_match_reference_golden(path):
         grp["params"][0].grad = torch.ones_like(grp["params"][0])
     gm.optimizer.step()
     assert float(gm.optimizer.state[gm._xyz]["step"]) == 2.0
+
+
+def kept_children_draws(P, accum, denom, iso, z, max_grad, min_opacity, extent, screen, percent_dense=0.01):
+    """The reference draws normals for the children of EVERY split parent and prunes afterwards; the device path draws only for
+    the children that survive.  Picks those rows out of the reference's draws (layout: copy-major over the split parents)."""
+    with np.errstate(invalid="ignore", divide="ignore"):
+        gr = np.nan_to_num(accum / denom).reshape(-1)
+    smax = D.get_scaling(P, iso).max(1)
+    sel = (gr >= max_grad) & (smax > percent_dense * extent)
+    op = 1 / (1 + np.exp(-P["opacity"].reshape(-1).astype(np.float64)))
+    kept = sel & ~((op < min_opacity) | ((smax / 1.6 > 0.1 * extent) if screen else False))
+    S = int(sel.sum())
+    pick = (np.cumsum(sel) - 1)[kept]
+    return np.concatenate([z[:S][pick], z[S:2 * S][pick]], 0), S, int(kept.sum())
 
 
 def gm_grads(mk_):
@@ -123,6 +138,8 @@ def test_densify_and_prune_against_the_oracle_at_training_size(N, iso):
     with np.errstate(invalid="ignore", divide="ignore"):
         gr = np.nan_to_num(accum / denom)
     accum[np.abs(gr - 0.0002) < 1e-8] = 0
+    with np.errstate(invalid="ignore", divide="ignore"):
+        gr = np.nan_to_num(accum / denom)
     gm = build({k: v.copy() for k, v in P.items()}, M, V, 3.0, accum, denom, np.zeros(N, f32), iso, 0)
     n_children_max = 2 * N
     z = rng.normal(size=(n_children_max, 3)).astype(f32)
@@ -133,15 +150,12 @@ def test_densify_and_prune_against_the_oracle_at_training_size(N, iso):
     S = int(sel.sum())
     stats = D.densify_and_prune(Po, Mo, Vo, accum.copy(), denom.copy(), 0.0002, 0.005, 2.0, 20, 0.01, iso, z[:2 * S])
     # HIP: the children kept after the final prune are a subset of the split ones — hand it the draws of exactly those, in order
-    op = 1 / (1 + np.exp(-P["opacity"].reshape(-1).astype(np.float64)))
-    child_kept = sel & ~((op < 0.005) | (smax / 1.6 > 0.2))
-    rank = np.cumsum(sel) - 1
-    pick = rank[child_kept]
-    zk = np.concatenate([z[:S][pick], z[S:2 * S][pick]], 0)
+    zk, S2, n_kept = kept_children_draws(P, accum, denom, iso, z[:2 * S], 0.0002, 0.005, 2.0, 20)
+    assert S2 == S
     gm.densify_and_prune(0.0002, 0.005, 2.0, 20, unit_normals=torch.from_numpy(zk))
     assert gm._xyz.shape[0] == Po["xyz"].shape[0] and gm._xyz.shape[0] != N
     check(gm, Po, Mo, Vo, stats, "densify_and_prune at %d" % N, tol=1e-5)
-    assert S > 100 and int(child_kept.sum()) < S  # some parents' children do not survive the final prune: the draws were re-indexed
+    assert S > 100 and n_kept < S  # some parents' children do not survive the final prune: the draws were re-indexed
 
 
 def test_captured_training_iteration_survives_a_device_side_densification():
@@ -178,4 +192,4 @@ def test_captured_training_iteration_survives_a_device_side_densification():
         out = gts.run()
     torch.cuda.synchronize()
     assert out["radii"].shape[0] == n1 and math.isfinite(float(out["loss"])) and float(out["loss"]) < 1.5 * l0
-    assert float(gm.optimizer.state[gm._xyz]["step"]) == 10.0 + 1.0  # five + (one eager warm-up + five) iterations
+    assert float(gm.optimizer.state[gm._xyz]["step"]) == 2.0 + 5.0 + 1.0 + 5.0  # the eager warm-up frames of a capture ARE iterations
