@@ -143,48 +143,41 @@ class GraphedFrame:
             self.stream = torch.cuda.Stream()  # (one stream per frame: a re-capture finds its persistent buffers again)
         s = self.stream
         s.wait_stream(torch.cuda.current_stream())
-        R.SPARSE_GRAD_ROWS = self.sparse_rows  # (eager frames never skip rows; they create the persistent screen-space buffer)
-        try:
-            with torch.cuda.stream(s):
-                for _ in range(warmup):
-                    if self.split and self.exchange_in_graph:
-                        self.out = self._frame_exchanged()
-                    elif self.split:
-                        self.out = self._frame_a()
-                        self._frame_b()
-                    else:
-                        self.out = self._frame()
-                    torch.cuda.current_stream().synchronize()
-                    self.arena.resolve()
-                    self.out = None
-        finally:
-            R.SPARSE_GRAD_ROWS = False
+        self.arena.sparse_grad_rows = self.sparse_rows  # (eager frames never skip rows; they create the persistent screen-space buffer)
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                if self.split and self.exchange_in_graph:
+                    self.out = self._frame_exchanged()
+                elif self.split:
+                    self.out = self._frame_a()
+                    self._frame_b()
+                else:
+                    self.out = self._frame()
+                torch.cuda.current_stream().synchronize()
+                self.arena.resolve()
+                self.out = None
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         for p in self.params:
             p.grad = None
         gc.collect()
         self.graph = torch.cuda.CUDAGraph()
-        R.SPARSE_GRAD_ROWS = self.sparse_rows
-        try:
-            if self.split and self.exchange_in_graph:
-                self.graph_b = None
-                # (thread-local capture errors: the process group's watchdog thread polls the events of the warm-up's
-                # collectives; in the default global mode such a call from ANOTHER thread, landing inside the capture,
-                # invalidates it — seen as "operation not permitted when stream is capturing", now and then)
-                with torch.cuda.graph(self.graph, stream=s, capture_error_mode="thread_local"):
-                    self.out = self._frame_exchanged()
-            elif self.split:
-                self.graph_b = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph, stream=s):
-                    self.out = self._frame_a()
-                with torch.cuda.graph(self.graph_b, stream=s, pool=self.graph.pool()):
-                    self._frame_b()
-            else:
-                with torch.cuda.graph(self.graph, stream=s):  # same stream as the warm-up: AccumulateGrad nodes match
-                    self.out = self._frame()
-        finally:
-            R.SPARSE_GRAD_ROWS = False
+        if self.split and self.exchange_in_graph:
+            self.graph_b = None
+            # (thread-local capture errors: the process group's watchdog thread polls the events of the warm-up's
+            # collectives; in the default global mode such a call from ANOTHER thread, landing inside the capture,
+            # invalidates it — seen as "operation not permitted when stream is capturing", now and then)
+            with torch.cuda.graph(self.graph, stream=s, capture_error_mode="thread_local"):
+                self.out = self._frame_exchanged()
+        elif self.split:
+            self.graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=s):
+                self.out = self._frame_a()
+            with torch.cuda.graph(self.graph_b, stream=s, pool=self.graph.pool()):
+                self._frame_b()
+        else:
+            with torch.cuda.graph(self.graph, stream=s):  # same stream as the warm-up: AccumulateGrad nodes match
+                self.out = self._frame()
         self.grads = [p.grad for p in self.params]  # static gradient buffers refilled by every replay
         self.backward_workspace = R.last_backward_workspace()[0]  # baked into the graph: must live as long as it does
         self.sparse_outputs = []
@@ -232,6 +225,7 @@ class GraphedFrame:
         self.sparse_outputs = []
         self.backward_workspace = None
         self.arena = RasterArena(growth=self.arena.growth)
+        self.arena.sparse_grad_rows = self.sparse_rows
         if params is not None:
             self.params = list(params)
         for p in self.params:

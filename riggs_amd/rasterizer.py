@@ -47,6 +47,11 @@ class RasterArena:
         self.last_R = -1
         self._pending = None  # (event, pinned host counters, capacity used)
         self.static_counters = None
+        # set by the OWNER of a captured frame (riggs_amd.graph.GraphedFrame(sparse_grad_rows=True)): backwards of frames
+        # rendered through THIS arena inside a hipGraph capture may skip the zero fill of gradient rows that have no gradient
+        # now and had none in the previous replay (riggs_raster_cfg.sparse_zero).  It travels with the arena — the object that
+        # is the frame's persistent state — instead of being a module-wide switch toggled around the capture.
+        self.sparse_grad_rows = False
         self._layout_key = None  # (capacity, N, H, W) the arena's walk history belongs to
 
     def _post(self, counters: torch.Tensor, cap: int):
@@ -219,7 +224,9 @@ def arena_check(s: _Saved, arena: RasterArena) -> bool:
 
 def rasterize_backward(s: _Saved, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                        d_xyz, d_rotation, grad_color, grad_depth, grad_alpha, d_scaling=None,
-                       want_d_scaling_grad=False, shs_rest=None):
+                       want_d_scaling_grad=False, shs_rest=None, sparse_rows=False):
+    """``sparse_rows``: the frame's arena belongs to a captured frame whose owner asked for sparse gradient rows
+    (RasterArena.sparse_grad_rows)."""
     lib = L.lib()
     N, M, dev = s.N, s.M, means3D.device
     f32 = dict(dtype=torch.float32, device=dev)
@@ -241,7 +248,7 @@ def rasterize_backward(s: _Saved, means3D, shs, colors_precomp, opacities, scale
     # (GraphedFrame(sparse_grad_rows=True): static gradient buffers, zero-filled together with the workspace after the
     # capture), with the fused glue (the outputs ARE the parameters' gradient buffers, not autograd intermediates whose
     # memory the graph's pool may hand to a later allocation) and without the optional outputs
-    sparse = bool(SPARSE_GRAD_ROWS and cfg.glue and not cfg.deterministic and g_colors is None and g_cov is None
+    sparse = bool(sparse_rows and cfg.glue and not cfg.deterministic and g_colors is None and g_cov is None
                   and g_dscaling is None and torch.cuda.is_current_stream_capturing())
     if sparse:
         # ... and every output must be PERSISTENT memory that nothing else is ever placed in: a tensor allocated inside the
@@ -251,7 +258,7 @@ def rasterize_backward(s: _Saved, means3D, shs, colors_precomp, opacities, scale
         from .dist import in_bucket
         pairs = [(means3D, g_means3D), (shs, g_sh), (shs_rest, g_sh_rest), (opacities, g_opac), (scales, g_scales), (rotations, g_rots)]
         sparse = all(in_bucket(p, g) for p, g in pairs if g is not None)
-    if SPARSE_GRAD_ROWS and cfg.glue:
+    if sparse_rows and cfg.glue:
         # (the buffer is created by the owner's EAGER warm-up frames on this stream — outside any graph pool — and handed
         # out as a fresh view per call, so that autograd adopts it as viewspace_points.grad instead of cloning it)
         key = (dev.index if dev.index is not None else torch.cuda.current_device(), L.stream_ptr(), N)
@@ -298,7 +305,6 @@ _WORKSPACES = {}
 _LAST_WORKSPACE = [None, 0]
 _MEANS2D = {}              # (device, stream, N) -> persistent screen-space gradient buffer of the sparse mode
 _LAST_SPARSE_OUTPUTS = []  # addresses of the gradient buffers of the most recent backward that ran with cfg.sparse_zero
-SPARSE_GRAD_ROWS = False   # set by GraphedFrame around its capture only
 
 
 def mark_all_rows(workspace: torch.Tensor, N: int):

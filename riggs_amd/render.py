@@ -107,7 +107,8 @@ class _FusedGlueRaster(torch.autograd.Function):
             ctx.arena.resolve(block=False)  # raises if the forward of this frame is known to have overflowed
         need_ds = d_scaling is not None and ctx.needs_input_grad[9]
         g = rasterize_backward(s, xyz, f_dc, None, opacity, scaling, rotation, None, d_xyz, d_rot, g_color, g_depth,
-                               g_alpha, d_scaling=d_scaling, want_d_scaling_grad=need_ds, shs_rest=f_rest)
+                               g_alpha, d_scaling=d_scaling, want_d_scaling_grad=need_ds, shs_rest=f_rest,
+                               sparse_rows=bool(ctx.arena is not None and ctx.arena.sparse_grad_rows))
         g_means3D, g_means2D, (g_dc, g_rest), _, g_opac, g_scales, g_rots, _, g_ds = g
         # dL/d(d_xyz) == dL/dxyz and dL/d(d_rotation) == dL/d_rotation: hand the residual branches an alias (a
         # second tensor object on the same storage) so that AccumulateGrad can adopt the parameter gradients
