@@ -510,6 +510,8 @@ int riggs_cnode_backward(int32_t N, int32_t M, int32_t K, int32_t hyper, int32_t
  * ===================================================================== */
 size_t riggs_knn_workspace_bytes(int32_t num_points);
 int riggs_dist2_knn3(int32_t num_points, const float* points, float* out, void* workspace, riggs_stream stream);
+/* the exact all-pairs search riggs_dist2_knn3 uses below 2048 points, callable at any size: the grid search's test oracle */
+int riggs_dist2_knn3_bruteforce(int32_t num_points, const float* points, float* out, riggs_stream stream);
 
 /* =====================================================================
  * Densification / pruning of the Gaussian cloud on the device (SURVEY.md §2 row 6 "next") — scene/gaussian_model.py:

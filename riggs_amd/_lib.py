@@ -136,6 +136,7 @@ _SIGS = {
     "riggs_prof_read": (C.c_int, [C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "riggs_knn_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "riggs_dist2_knn3": (C.c_int, [C.c_int32, _P, _P, _P, _P]),
+    "riggs_dist2_knn3_bruteforce": (C.c_int, [C.c_int32, _P, _P, _P]),
 }
 
 

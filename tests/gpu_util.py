@@ -90,7 +90,7 @@ def assert_close(a, b, what, rel=REL_TOL, allow_frac=0.0, allow_frac_elem=None):
     assert fe <= lim, "%s: %.3g of elements beyond the per-element bound %.1e |b| + %.0e max|b|" % (what, fe, rel, ELEM_ABS)
 
 
-def compare_forward_state(saved_oracle, v, out_oracle, color, depth, alpha, radii, px_outlier_frac=2e-5):
+def compare_forward_state(saved_oracle, v, out_oracle, color, depth, alpha, radii, px_outlier_frac=5e-6):
     """Bit-exact index/ordering work + toleranced images.  `px_outlier_frac` admits the rare pixel
     where a 1-ulp difference in exp() flips an alpha<1/255 / T<1e-4 threshold decision."""
     so = saved_oracle

@@ -485,6 +485,60 @@ def test_dist_knn3_at_initialisation_size():
     print("distCUDA2(150k points): %.1f ms" % (dt * 1e3))
 
 
+@pytest.mark.parametrize("kind,P", [("gauss", 2048), ("gauss", 60_001), ("clusters_and_outliers", 40_000), ("plane", 20_000),
+                                    ("line", 5_000), ("duplicates", 9_000), ("lattice", 32_768), ("big", 2_000_000)])
+def test_grid_knn_equals_the_all_pairs_search(kind, P):
+    """riggs_dist2_knn3 from 2048 points on: uniform grid + ring search.  It must return what the exact all-pairs kernel
+    returns (riggs_dist2_knn3_bruteforce; same distance expression: equal to rounding) on clouds that stress the grid —
+    far outliers (rings widen to the whole grid), a plane and a line (degenerate axes), duplicated points (zero distances, more
+    points in a cell than neighbours asked for), a lattice (points on cell faces) — and stay fast at 2 M points."""
+    import time
+    from riggs_amd import _lib as L
+    from simple_knn._C import distCUDA2
+    g = torch.Generator().manual_seed(P)
+    if kind == "gauss" or kind == "big":
+        pts = torch.randn(P, 3, generator=g) * torch.tensor([1.0, 0.6, 0.3])
+    elif kind == "clusters_and_outliers":
+        c = torch.randn(20, 3, generator=g) * 3
+        pts = c[torch.randint(0, 20, (P,), generator=g)] + 0.01 * torch.randn(P, 3, generator=g)
+        pts[:7] = torch.tensor([[500.0, 0, 0], [0, -800.0, 3], [1e3, 1e3, 1e3], [-1e3, 2, 2], [0, 0, 900.0], [901.0, 0, 0], [901.0, 0.1, 0]])
+    elif kind == "plane":
+        pts = torch.cat([torch.rand(P, 2, generator=g), torch.full((P, 1), 0.25)], 1)
+    elif kind == "line":
+        pts = torch.stack([torch.rand(P, generator=g), torch.full((P,), -1.0), torch.full((P,), 2.0)], 1)
+    elif kind == "duplicates":
+        base = torch.randn(P // 9, 3, generator=g)
+        pts = base.repeat(9, 1)[torch.randperm(P // 9 * 9, generator=g)]
+    else:
+        k = round(P ** (1 / 3))
+        ax = torch.arange(k, dtype=torch.float32) * 0.125
+        pts = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)
+    pts = pts.contiguous()
+    n = pts.shape[0]
+    x = pts.cuda()
+    got = distCUDA2(x)
+    torch.cuda.synchronize()
+    if kind == "big":
+        t0 = time.perf_counter()
+        got = distCUDA2(x)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert dt < 0.5, "distCUDA2(2M points) took %.3f s" % dt
+        print("distCUDA2(2M points): %.1f ms" % (dt * 1e3))
+        sub = torch.randperm(n, generator=g)[:2000]
+        d = ((pts[sub, None, :].double() - pts[None, :, :].double()) ** 2).sum(-1) if False else None
+        from scipy.spatial import cKDTree
+        dd, _ = cKDTree(pts.double().numpy()).query(pts[sub].double().numpy(), k=4)
+        np.testing.assert_allclose(got.cpu().numpy()[sub.numpy()], (dd[:, 1:] ** 2).mean(1), rtol=2e-4, atol=1e-10)
+        return
+    ref = torch.empty(n, device="cuda")
+    L.check(L.lib().riggs_dist2_knn3_bruteforce(n, x.data_ptr(), ref.data_ptr(), L.stream_ptr()), "riggs_dist2_knn3_bruteforce")
+    torch.cuda.synchronize()
+    a, b = got.cpu().numpy(), ref.cpu().numpy()
+    np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-12 * max(1.0, float(np.abs(b).max())))
+    assert np.isfinite(a).all()
+
+
 def test_captured_frame_skips_the_zero_fill_of_untouched_rows_without_leaving_stale_gradients():
     """riggs_raster_cfg.sparse_zero through GraphedFrame: replay after replay with changing cameras (so that rows gain and
     lose their gradient), every parameter gradient and the screen-space gradient equal those of a frame that rewrites every

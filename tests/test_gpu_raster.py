@@ -18,7 +18,10 @@ from riggs_amd.rasterizer import (GaussianRasterizer, rasterize_backward, raster
 from tests import gpu_util as U  # noqa: E402
 
 
-def _grads_close(hip, ref, what, frac=1e-4):
+def _grads_close(hip, ref, what, frac=1e-5):
+    """Every gradient element within 1e-4 of the tensor's largest entry, up to ``frac`` of the elements (round 3: 1e-4; the
+    observed share over the whole suite is ZERO since the threshold flips are gone — profiles/*_parity_stats.json — so the
+    allowance is a tenth of what it was; the per-element bound stays: sums of cancelling terms sit at 1.4e-3 of it)."""
     U.assert_close(hip.cpu().numpy().reshape(ref.shape), ref, what, U.REL_TOL, frac)
 
 
