@@ -1050,6 +1050,18 @@ def main():
                 per_kernel[k] = e
         traffic = counter_traffic(dom)
         compositing = dom.startswith("render")
+        # bytes one step MOVES, two ways, next to the SURVEY 8-d figure (which charges R*150 B for a radix sort of the R
+        # instances that this design never performs and so flatters it): (a) the sum of the path's kernels' own algorithmic
+        # bytes; (b) the sum of what the PMC counters saw per launch x launches per step
+        path = ("preprocess_fwd", "depth_sort", "tile_sort", "render_fwd", "render_bwd", "preprocess_bwd", "lbs_fwd", "lbs_bwd")
+        moved_alg = sum(alg_bytes[k] for k in path) + 2 * 2_300_000  # (+ the PoseMLP's weights, read by either direction)
+        per_step_launches = {"preprocess_fwd_kernel": 1, "rs_count_kernel": 2, "rs_scan_kernel": 2, "rs_scatter_kernel": 2, "bin_count_kernel": 1,
+                             "bin_scan_kernel": 1, "bin_scatter_kernel": 1, "render_fwd_oct_kernel": 1, "render_bwd_kernel": 1,
+                             "preprocess_bwd_kernel": 1, "lbs_forward_kernel": 1, "lbs_backward_bonelane_kernel": 1,
+                             "lbs_backward_finish_kernel": 1, "pm_forward_fused_kernel": 1, "pm_backward_fused_kernel": 1}
+        moved_ctr = None
+        if all(("read_bytes_x2_corrected" in pm.get(k, {}) and "write_bytes" in pm.get(k, {})) for k in per_step_launches):
+            moved_ctr = int(sum(n * (pm[k]["read_bytes_x2_corrected"] + pm[k]["write_bytes"]) for k, n in per_step_launches.items()))
         out = {
             "metric": "train iters/sec (deform+raster fwd+bwd), 300k Gaussians @800x800",
             "value": round(value, 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -1072,7 +1084,14 @@ def main():
                          "ms_per_launch": dom_ms, "algorithmic_bytes_per_launch": dom_bytes,
                          "pixel_gaussian_pairs_per_s": round(256.0 * R / (dom_ms * 1e-3), 1) if compositing else None},
             "step_bytes": {"what": "SURVEY.md 8-d bytes per iteration: N*985 + R*278 + HW*56", "bytes": int(N * 985 + R * 278 + HW * 56),
-                           "frac_hbm": round((N * 985 + R * 278 + HW * 56) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                           "frac_hbm": round((N * 985 + R * 278 + HW * 56) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           "moved_algorithmic_bytes": int(moved_alg),
+                           "frac_hbm_moved_algorithmic": round(moved_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           "moved_counter_bytes": moved_ctr,
+                           "frac_hbm_moved_counter": round(moved_ctr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if moved_ctr else None,
+                           "note": "the 8-d formula prices a 6-pass radix sort of the R instances (R*150 B) that this design replaces by a "
+                                   "depth sort of N keys + a counting sort by tile: the two 'moved' figures are what the step's kernels "
+                                   "actually read and write (their own algorithmic bytes; the PMC counters of profiles/kernel_counters.json)"},
             "kernels": per_kernel, "kernels_ms": table,
         }
         if world == 1 and not args.metric_only:
