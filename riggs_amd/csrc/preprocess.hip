@@ -135,6 +135,26 @@ __device__ __forceinline__ void sh_stage_store(const float* __restrict__ src, in
   }
 }
 
+// The same copy with NO registers and no LDS-write pass: direct-to-LDS loads (global_load_lds_dwordx4: a wave instruction moves
+// 64 x 16 bytes to M0-base + lane x 16).  The LDS image is then the run itself, unpadded — which is the conflict-free layout
+// whenever the record length is odd (45 floats: the reference's _features_rest rows; stride 45 = 13 mod 32), so no swizzle is
+// needed; even record lengths (48: one (N,16,3) tensor) keep the register path with its padded rows.  The tail of the last
+// workgroup's run (< 1 KB) goes lane-masked, its last < 16 bytes as scalars.  __syncthreads() behind it carries the vmcnt(0).
+typedef __attribute__((address_space(1))) const void* sh_gptr;
+typedef __attribute__((address_space(3))) void* sh_lptr;
+__device__ __forceinline__ void sh_stage_dma(const float* __restrict__ src, int total /* floats */, float* lds) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int bytes = total * 4;
+  const char* g = reinterpret_cast<const char*>(src);
+  char* l = reinterpret_cast<char*>(lds);
+  for (int c = wave * 1024; c < bytes; c += 4096) {
+    if (c + lane * 16 + 16 <= bytes)
+      __builtin_amdgcn_global_load_lds((sh_gptr)(g + c + lane * 16), (sh_lptr)(l + c), 16, 0, 0);
+  }
+  const int done = bytes & ~15;
+  if ((int)threadIdx.x < (bytes - done) / 4) lds[done / 4 + threadIdx.x] = src[done / 4 + threadIdx.x];
+}
+
 __device__ __forceinline__ void sh_stage_out(float* __restrict__ dst, int per, int count, const float* lds) {
   const int total = count * per;
   const int stride = sh_lds_stride(per);
@@ -172,9 +192,11 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a) {
   const int sh_first = blockIdx.x * 256, sh_total = min(256, a.N - sh_first) * sh_per;
   const float* sh_src = sh_mode ? (a.shs_rest ? a.shs_rest : a.shs) + (size_t)sh_first * sh_per : nullptr;
   const bool sh_fast = sh_mode && sh_per > 0 && sh_per <= 48 && ((reinterpret_cast<uintptr_t>(sh_src) & 15) == 0);
+  const bool sh_dma = sh_fast && (sh_per & 1);  // (odd record length: the unpadded run is the conflict-free LDS image)
   float4 shq[SH_IT];
   RawIn raw;
-  if (sh_fast) sh_stage_load(sh_src, sh_total, shq);
+  if (sh_dma) sh_stage_dma(sh_src, sh_total, s_sh);
+  else if (sh_fast) sh_stage_load(sh_src, sh_total, shq);
   if (i < a.N) load_raw(a, i, raw, need_sr);
   float c6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (i < a.N && a.cov3D_precomp) {
@@ -186,7 +208,8 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a) {
   if (i < a.N && sh_mode && a.shs_rest) { dc0[0] = a.shs[3 * i]; dc0[1] = a.shs[3 * i + 1]; dc0[2] = a.shs[3 * i + 2]; }
   __builtin_amdgcn_sched_barrier(0);
   if (sh_mode && sh_per > 0) {
-    if (sh_fast) sh_stage_store(sh_src, sh_per, sh_total, shq, s_sh);
+    if (sh_dma) {}
+    else if (sh_fast) sh_stage_store(sh_src, sh_per, sh_total, shq, s_sh);
     else sh_stage_in(sh_src, sh_per, min(256, a.N - sh_first), s_sh);
     __syncthreads();
   }
@@ -376,7 +399,12 @@ __global__ __launch_bounds__(256, 3) void preprocess_bwd_kernel(PreBwdArgs b) {
   }
   // the block's coefficients are staged through LDS when most of it has work, else the few read their own rows
   const bool staged = sh_mode && sh_per > 0 && n_work > 64;
-  if (staged) sh_stage_in((a.shs_rest ? a.shs_rest : a.shs) + (size_t)sh_first * sh_per, sh_per, sh_count, s_sh);
+  if (staged) {
+    const float* sh_src = (a.shs_rest ? a.shs_rest : a.shs) + (size_t)sh_first * sh_per;
+    // (odd record length + 16-byte aligned run: direct-to-LDS loads, as in the forward; else through registers)
+    if ((sh_per & 1) && sh_per <= 48 && ((reinterpret_cast<uintptr_t>(sh_src) & 15) == 0)) sh_stage_dma(sh_src, sh_count * sh_per, s_sh);
+    else sh_stage_in(sh_src, sh_per, sh_count, s_sh);
+  }
   __syncthreads();  // s_list (and the staged coefficients)
   const bool in_range = t0 < n_work;                       // from here on: "this thread has a Gaussian to work on"
   const int slot = in_range ? (int)s_list[t0] : t0;        // its place in the block (LDS row of its coefficients)
