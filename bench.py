@@ -672,18 +672,22 @@ def captured_collectives_work(rank, world, local_rank, dev):
 def exchange_path_timing():
     """Runs ``exchange_path_child`` in a child process (bounded by a time-out) and returns its JSON object."""
     import subprocess
-    try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--exchange-path-child"], capture_output=True, text=True,
-                           timeout=300, env=dict(os.environ))
-    except subprocess.TimeoutExpired:
-        return {"error": "the exchange-path child did not finish within 300 s"}
-    for line in reversed(r.stdout.strip().splitlines()):
-        if line.startswith("{"):
-            try:
-                return json.loads(line)
-            except ValueError:
-                pass
-    return {"error": "exchange-path child failed (rc %d): %s" % (r.returncode, (r.stderr or r.stdout)[-600:])}
+    last = None
+    for attempt in range(2):  # (one retry: the child's rendezvous port is picked and released before RCCL binds it)
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--exchange-path-child"], capture_output=True, text=True,
+                               timeout=300, env=dict(os.environ))
+        except subprocess.TimeoutExpired:
+            last = {"error": "the exchange-path child did not finish within 300 s"}
+            continue
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                try:
+                    return dict(json.loads(line), attempts=attempt + 1)
+                except ValueError:
+                    pass
+        last = {"error": "exchange-path child failed (rc %d): %s" % (r.returncode, (r.stderr or r.stdout)[-600:])}
+    return last
 
 
 PARITY_BAR = 5e-5  # share of a tensor's elements allowed beyond 1e-4 of max|oracle| (observed: <= 4e-6)

@@ -438,8 +438,14 @@ def test_bench_contract_single_and_two_ranks():
     assert ex.get("one_graph_ms", 0) > 0 or "one_graph_error" in ex, ex
     assert d["exchange_path_ms"] == ex.get("one_graph_ms", ex["two_graphs_eager_collectives_ms"])
     env["RIGGS_BENCH_BACKEND"] = "gloo"
+    import socket
+
+    def free_port():
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            return str(sk.getsockname()[1])
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1"],
+                        "127.0.0.1", "--master-port", free_port(), "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d2 = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
@@ -448,7 +454,7 @@ def test_bench_contract_single_and_two_ranks():
     # the default exchange is the packed-row one (bench.py itself compares it with a plain all-reduce after the timed region)
     assert d2["config"]["exchange"].startswith("packed rows")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", "29534", "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "127.0.0.1", "--master-port", free_port(), "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1",
                         "--exchange", "dense"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d3 = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
