@@ -235,18 +235,21 @@ def dense_scene_timing(dev, steps=50):
             "what": "same path / sizes / camera, thin opaque skin around the bones (synth.make_surface_scene); not the headline metric"}
 
 
-def tight_lists_timing(dev, gimg, steps=100):
-    """Secondary number (NOT the metric): the headline workload with riggs_raster_cfg.tight_lists — tile rectangles cut down to the
-    tiles a Gaussian can reach with alpha >= 1/255 (same image and gradients to rounding, fewer instances to sort, stage and
-    walk; the canonical lists stay the headline's because they are what upstream builds)."""
+LISTS = "tight"  # (--lists)
+
+
+def other_lists_timing(dev, gimg, steps=100):
+    """Secondary number (NOT the metric): the headline workload with the OTHER kind of per-tile lists — upstream's canonical
+    ceil(3 sigma) squares when the run uses riggs_raster_cfg.tight_lists (the default: the alpha >= 1/255 box the compositing
+    culls with anyway, applied at emission), and the reverse."""
     from riggs_amd import rasterizer as RZ
     from riggs_amd.graph import GraphedFrame
     sc, cam, gm, sw = build_workload(0, dev)
-    RZ.set_tight_lists(True)
+    RZ.set_tight_lists(LISTS != "tight")
     try:
         gf = GraphedFrame(gm, sw, cam, torch.zeros(3, device=dev), params_of(gm, sw), sparse_grad_rows=True).capture()
     finally:
-        RZ.set_tight_lists(False)
+        RZ.set_tight_lists(LISTS == "tight")
     gf.set_inputs(gimg=gimg)
     for _ in range(10):
         gf.run()
@@ -257,7 +260,8 @@ def tight_lists_timing(dev, gimg, steps=100):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     return {"value": round(1.0 / dt, 2), "unit": "iters/s", "ms_per_step": round(dt * 1e3, 4), "tile_instances_R": int(gf.check()),
-            "what": "same workload with cfg.tight_lists (alpha-box tile rectangles); not the headline metric"}
+            "lists": "canonical" if LISTS == "tight" else "tight",
+            "what": "same workload with the other kind of per-tile lists (see --lists); not the headline metric"}
 
 
 def cycling_cameras_timing(dev, steps=64, n_cams=8):
@@ -675,7 +679,7 @@ def exchange_path_timing():
     last = None
     for attempt in range(2):  # (one retry: the child's rendezvous port is picked and released before RCCL binds it)
         try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--exchange-path-child"], capture_output=True, text=True,
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--exchange-path-child", "--lists", LISTS], capture_output=True, text=True,
                                timeout=300, env=dict(os.environ))
         except subprocess.TimeoutExpired:
             last = {"error": "the exchange-path child did not finish within 300 s"}
@@ -756,9 +760,18 @@ def main():
     ap.add_argument("--exchange-graph", choices=("auto", "on", "off"), default="auto",
                     help="N > 1: capture the whole data-parallel step (frame + pack + collectives + unpack) as ONE hipGraph; "
                          "auto = when a probe (child processes, own rendezvous) shows that RCCL collectives survive a capture here")
+    ap.add_argument("--lists", choices=("tight", "canonical"), default="tight",
+                    help="per-tile instance lists: 'tight' = riggs_raster_cfg.tight_lists (the tile rectangle cut down to the tiles a "
+                         "Gaussian can reach with alpha >= 1/255: the instances dropped are exactly ones the compositing skips, "
+                         "so image and gradients are the canonical ones — asserted against the oracle at the bench size below); "
+                         "'canonical' = upstream's ceil(3 sigma) squares (reported beside the headline either way)")
     ap.add_argument("--exchange-path-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--capture-probe-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    global LISTS
+    LISTS = args.lists
+    from riggs_amd import rasterizer as RZ
+    RZ.set_tight_lists(LISTS == "tight")  # (every process of the run, children included, before anything is captured)
     if args.exchange_path_child:
         return exchange_path_child()
     if args.capture_probe_child:
@@ -1003,14 +1016,18 @@ def main():
         N, HW, Bn = w["N"], w["H"] * w["W"], w["J"] - 1
         # ALGORITHMIC bytes per launch of each kernel (DESIGN.md "Kernels and rooflines")
         alg_bytes = {
-            "preprocess_fwd": N * (12 + 12 + 16 + 12 + 16 + 12 + 4 + 192) + N * (48 + 24 + 1 + 4 + 8 + 4 + 4 + 4),
+            # (geometry only: the SH colours of the frame are evaluated by extra workgroups of the tile sort's scatter launch —
+            # csrc/color_job.h — and their bytes are counted there)
+            "preprocess_fwd": N * (12 + 12 + 16 + 12 + 16 + 12 + 4) + N * (48 + 24 + 4 + 8 + 4 + 4 + 4),
             "render_fwd": R * (4 + 48) + HW * (12 + 4 + 4 + 4 + 4 + 16),
             "render_bwd": R * (4 + 48 + 36) + HW * (12 + 4 + 4 + 16),
             "preprocess_bwd": N * (276 + 24 + 1 + 4 + 48) + N * (12 + 12 + 192 + 4 + 12 + 16),
             "lbs_fwd": N * (12 + 4 + 12 + 16),
             "lbs_bwd": N * (12 + 4 + 12 + 16),
             # counting-sort binning: 3 passes over (order, tiles, rect) + the chunk table twice + the instance list
-            "tile_sort": 2 * N * 16 + R * 8 + 2 * ((N + 1023) // 1024) * (((w["W"] + 15) // 16) * ((w["H"] + 15) // 16)) * 4,
+            # + the colour job: SH rows, means + residual, radius in; colour and clamp bits out
+            "tile_sort": 2 * N * 16 + R * 8 + 2 * ((N + 1023) // 1024) * (((w["W"] + 15) // 16) * ((w["H"] + 15) // 16)) * 4
+                         + N * (192 + 12 + 12 + 4 + 12 + 1),
             "depth_sort": N * 16 * 4,
             "adam": N * 59 * 28,  # p, g, m, v read + p, m, v written, 59 floats per Gaussian
             "loss_fwd": 3 * HW * 4 * (2 + 3),   # two images read, three derivative maps written
@@ -1080,7 +1097,10 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "300k Gaussians / 24-joint skeleton / 800x800, LBS-only, SH degree 3, anisotropic, "
                                    "one frame per GPU per step", "num_gaussians": w["N"], "num_joints": w["J"],
-                       "image": [w["H"], w["W"]], "tile_instances_R": R, "parallelism": "frames x%d" % world, "exchange": None if world == 1 else exchange_label,
+                       "image": [w["H"], w["W"]], "tile_instances_R": R,
+                       "tile_lists": "tight: rectangles cut by the alpha >= 1/255 box at emission (riggs_raster_cfg.tight_lists; same image and "
+                                     "gradients, parity below)" if LISTS == "tight" else "canonical ceil(3 sigma) squares",
+                       "parallelism": "frames x%d" % world, "exchange": None if world == 1 else exchange_label,
                        "launch": "eager" if args.no_graph else "hipGraph replay",
                        "gradient_rows": "every row written" if (args.no_graph or not gf.sparse_outputs) else
                        "rows without a gradient now and in the previous replay are not rewritten (they hold their zeros); the timed "
@@ -1143,7 +1163,7 @@ def main():
             out["next_rows"] = next_rows_timing(sc, gm, cam)
             out["dense_gradient_scene"] = dense_scene_timing(dev)
             out["cycling_cameras"] = cycling_cameras_timing(dev)
-            out["tight_lists"] = tight_lists_timing(dev, gimg)
+            out["canonical_lists" if LISTS == "tight" else "tight_lists"] = other_lists_timing(dev, gimg)
             # the data-parallel step's host + device sequence on a one-rank RCCL communicator (a child process)
             out["exchange_path"] = exchange_path_timing()
             out["exchange_path_ms"] = out["exchange_path"].get("one_graph_ms", out["exchange_path"].get("two_graphs_eager_collectives_ms"))

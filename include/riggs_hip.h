@@ -34,6 +34,11 @@ const char* riggs_last_error(void);
  *                             riggs_raster_binning_bytes reserves the larger of the two layouts, so flipping this never
  *                             invalidates an arena
  *   "cnode_bwd_atomics" 0     1 = riggs_cnode_backward's first design (LDS float atomics); set it BEFORE sizing its workspace
+ *   "color_side_jobs"   1     the SH colours of a frame are evaluated by extra workgroups of the tile sort's scatter launch
+ *                             (riggs_raster_render) wherever the direct tile sort runs, instead of by riggs_raster_preprocess's
+ *                             kernel: the same colours and clamp bits, bit for bit; the geometry arena's colours are then
+ *                             complete after riggs_raster_render, not after riggs_raster_preprocess.  0 = always in preprocess.
+ *                             Like "bin_grouped", it must not change between the two calls of one frame
  * Unknown names fail.  Set them between frames, not while a launch that reads them is being issued from another thread. */
 int riggs_set_option(const char* name, int32_t value);
 int riggs_get_option(const char* name, int32_t* value);
@@ -113,9 +118,9 @@ int riggs_raster_binning_reset_history(void* binning, int64_t instance_capacity,
 
 /* Field offsets (bytes) inside the arenas, for tests / debugging tools. */
 enum {
-  RIGGS_GEOM_XYD = 0,      /* float4 (px, py, depth, 0) */
+  RIGGS_GEOM_XYD = 0,      /* float4 (px, py, depth, x half extent of the alpha >= 1/255 box) */
   RIGGS_GEOM_CONIC_O,      /* float4 (A, B, C, opacity) */
-  RIGGS_GEOM_RGB,          /* float4 (r, g, b, 0) */
+  RIGGS_GEOM_RGB,          /* float4 (r, g, b, y half extent of that box); complete after riggs_raster_render ("color_side_jobs") */
   RIGGS_GEOM_COV3D,        /* float[6] */
   RIGGS_GEOM_CLAMPED,      /* uint8 bitmask (bit ch) */
   RIGGS_GEOM_TILES,        /* uint32 tiles_touched */

@@ -162,7 +162,8 @@ def lib():
 
 
 def set_option(name: str, value: int):
-    """riggs_set_option (include/riggs_hip.h): "fwd_wide_tiles", "fwd_wide_min", "bin_grouped", "cnode_bwd_atomics"."""
+    """riggs_set_option (include/riggs_hip.h): "fwd_wide_tiles", "fwd_wide_min", "bin_grouped", "cnode_bwd_atomics",
+    "color_side_jobs"."""
     check(lib().riggs_set_option(name.encode(), int(value)), "riggs_set_option")
 
 

@@ -17,7 +17,7 @@ SO = os.path.join(LIBDIR, "libriggs_hip.so")
 SOURCES = {
     "preprocess.hip": ["-ffp-contract=off"],
     "render.hip": ["-ffp-contract=fast"],
-    "binning.hip": ["-ffp-contract=fast"],
+    "binning.hip": ["-ffp-contract=off"],  # (hosts color_job.h: the same colours, bit for bit, as preprocess.hip)
     "deform.hip": ["-ffp-contract=fast"],
     "knn.hip": ["-ffp-contract=fast"],
     "pose_mlp.hip": ["-ffp-contract=fast"],

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "raster_internal.h"
+#include "color_job.h"
 
 namespace riggs {
 
@@ -230,10 +231,18 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(int N, int T, int gri
                                                           const uint32_t* __restrict__ table,
                                                           const uint32_t* __restrict__ tile_count,
                                                           uint32_t* __restrict__ point_list,
-                                                          uint32_t* __restrict__ tile_keys, const BinOut out) {
+                                                          uint32_t* __restrict__ tile_keys, const BinOut out,
+                                                          const int n_main, const ColorJob* __restrict__ job_rec, const int job_gpb) {
   extern __shared__ uint32_t s_mem[];
-  if (blockIdx.x == gridDim.x - 1) {  // the extra workgroup: what used to be a single-workgroup launch of its own
+  if ((int)blockIdx.x == n_main) {  // the extra workgroup: what used to be a single-workgroup launch of its own
     bin_offsets_body(T, cap, tile_count, out);
+    return;
+  }
+  if ((int)blockIdx.x > n_main) {
+    // the workgroups behind: the SH colours of the frame (color_job.h), job_gpb Gaussians each; the record is preprocess_fwd's
+    // (N = 0: it evaluated the colours itself).  They start behind the sort's own workgroups (block index order).
+    const ColorJob job = *job_rec;
+    color_block(job, (int)blockIdx.x - n_main - 1, job_gpb, reinterpret_cast<float*>(s_mem));
     return;
   }
   const int W = blockDim.x >> 6;
@@ -912,6 +921,10 @@ static bool bin_grouped(int N, int T) {
   if (forced >= 0) return forced != 0 && T >= 64;
   return T >= BIN_GROUPED_AUTO_T && N >= BIN_GROUPED_AUTO_N;
 }
+// (the direct sort's scatter launch hosts the colour job; up to 16 coefficients per channel — degree 3)
+bool binning_hosts_color(int N, int T, int sh_coeffs) {
+  return option(OPT_COLOR_SIDE_JOBS) != 0 && N > 0 && sh_coeffs >= 1 && sh_coeffs <= 16 && T <= 65535 && !bin_grouped(N, T);
+}
 struct GBinPlan { int G, gxg, W, g_per_block, g_per_wave, n_chunks; size_t lds; };
 static GBinPlan gbin_plan(int N, int T, int grid_x) {
   GBinPlan p;
@@ -962,7 +975,7 @@ size_t bin_scratch_bytes(int64_t cap, int T, int grid_x) {  // (grouped binning:
 
 int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order, const uint32_t* tiles,
                    const ushort4* rect, void* table_mem, void* scratch, uint32_t* point_list, uint32_t* tile_keys, const BinOut& out,
-                   hipStream_t s) {
+                   hipStream_t s, const ColorJob* job_rec, int job_sh_coeffs) {
   (void)tiles;  // (the rectangles alone say which Gaussians are visible: preprocess_fwd leaves a culled one's empty)
   if (T > 65535) { set_error("image too large: %d tiles (at most 65 535)", T); return 2; }
   char* mem = (char*)table_mem;
@@ -1011,8 +1024,19 @@ int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order,
                      order, rect, srect, table);
   hipLaunchKernelGGL(bin_scan_kernel, dim3((T + 63) / 64), dim3(1024), 0, s, T, p.n_chunks, table, tile_count);
   // (+ 1: the extra workgroup that writes the ranges, the counters and the forward's work list)
-  hipLaunchKernelGGL(bin_scatter_kernel, dim3(p.n_chunks + 1), dim3(p.threads), p.lds_scatter, s, N, T, grid_x, cap,
-                     p.g_per_block, p.g_per_wave, order, srect, table, tile_count, point_list, tile_keys, out);
+  // the colour job rides on the scatter launch (binning_hosts_color): blocks of gpb Gaussians, as many as the workgroup has
+  // threads and its LDS holds rows for (at least 64)
+  int n_col = 0, gpb = 0;
+  size_t lds = p.lds_scatter;
+  if (job_rec && binning_hosts_color(N, T, job_sh_coeffs)) {
+    const size_t row = (size_t)((job_sh_coeffs * 3) | 1) * 4;  // (the longest row: one (N, M, 3) tensor)
+    gpb = p.threads < 384 ? p.threads : 384;
+    while (gpb > 64 && gpb * row > (lds > 256 * row ? lds : 256 * row)) gpb -= 64;
+    if (gpb * row > lds) lds = gpb * row;
+    n_col = (N + gpb - 1) / gpb;
+  }
+  hipLaunchKernelGGL(bin_scatter_kernel, dim3(p.n_chunks + 1 + n_col), dim3(p.threads), lds, s, N, T, grid_x, cap,
+                     p.g_per_block, p.g_per_wave, order, srect, table, tile_count, point_list, tile_keys, out, p.n_chunks, job_rec, gpb);
   return 0;
 }
 

@@ -18,9 +18,9 @@ void set_error(const char* fmt, ...) {
 }
 
 // ---- library options -------------------------------------------------------------------
-static const char* kOptNames[OPT_COUNT] = {"fwd_wide_tiles", "fwd_wide_min", "bin_grouped", "cnode_bwd_atomics"};
-static const int kOptDefaults[OPT_COUNT] = {256, 4096, -1, 0};
-static int g_opt[OPT_COUNT] = {256, 4096, -1, 0};
+static const char* kOptNames[OPT_COUNT] = {"fwd_wide_tiles", "fwd_wide_min", "bin_grouped", "cnode_bwd_atomics", "color_side_jobs"};
+static const int kOptDefaults[OPT_COUNT] = {256, 4096, -1, 0, 1};
+static int g_opt[OPT_COUNT] = {256, 4096, -1, 0, 1};
 int option(int id) { return g_opt[id]; }
 
 // ---- event-based kernel timing -------------------------------------------------------
@@ -63,6 +63,7 @@ GeomLayout geom_layout(int N) {
   L.depth_key_sorted = o; o = align_up(o + n * 4);
   L.order = o; o = align_up(o + n * 4);
   L.block_tiles = o; o = align_up(o + 2 * ((n + 255) / 256) * 4);  // per workgroup of preprocess_fwd: tile sums | depth top bytes
+  L.color_job = o; o = align_up(o + sizeof(ColorJob));            // the colour job's record (color_job.h)
   L.sort_table = o; o += align_up(depth_sort_table_bytes(N));
   L.total = o;
   return L;
@@ -147,7 +148,7 @@ int riggs_set_option(const char* name, int32_t value) {
   if (id == OPT_FWD_WIDE_TILES) { if (v < 0) v = kOptDefaults[id]; if (v > 65535) v = 65535; }
   if (id == OPT_FWD_WIDE_MIN) { if (v < 0) v = kOptDefaults[id]; if (v < 256) v = 256; }
   if (id == OPT_BIN_GROUPED) { if (v < -1 || v > 1) { set_error("riggs_set_option: bin_grouped takes -1 (by size), 0 or 1"); return 2; } }
-  if (id == OPT_CNODE_BWD_ATOMICS) v = v ? 1 : 0;
+  if (id == OPT_CNODE_BWD_ATOMICS || id == OPT_COLOR_SIDE_JOBS) v = v ? 1 : 0;
   g_opt[id] = v;
   return 0;
 }
@@ -207,7 +208,7 @@ static int fill_pre_args(PreArgs& a, const riggs_raster_cfg* c, const float* mea
   RIGGS_REQUIRE(!(c->glue && cov3D_precomp), "glue mode needs scales/rotations");
   GeomLayout L = geom_layout(c->num_points);
   a.N = c->num_points; a.deg = c->sh_degree; a.M = c->sh_coeffs; a.W = c->image_width; a.H = c->image_height;
-  a.glue = c->glue; a.isotropic = c->isotropic; a.tight = c->tight_lists;
+  a.glue = c->glue; a.isotropic = c->isotropic; a.tight = c->tight_lists; a.defer_color = 0; a.job_rec = nullptr;
   a.tanx = c->tanfovx; a.tany = c->tanfovy; a.mod = c->scale_modifier;
   a.view = c->viewmatrix; a.proj = c->projmatrix; a.campos = c->campos;
   a.means3D = means3D; a.shs = shs; a.shs_rest = shs_rest; a.colors_precomp = colors_precomp; a.opac = opac; a.scales = scales; a.rots = rots;
@@ -245,6 +246,12 @@ int riggs_raster_preprocess(const riggs_raster_cfg* cfg, const float* means3D, c
   if (N == 0) RIGGS_HIP_CHECK(hipMemsetAsync(counters, 0, 16, s));
   if (N == 0) return 0;
   GeomLayout L = geom_layout(N);
+  // SH colours: by extra workgroups of the tile sort's scatter launch where that sort runs (color_job.h), else here
+  a.job_rec = (ColorJob*)(geom + L.color_job);
+  {
+    const int T = ((a.W + RIGGS_TILE - 1) / RIGGS_TILE) * ((a.H + RIGGS_TILE - 1) / RIGGS_TILE);
+    a.defer_color = (shs && binning_hosts_color(N, T, a.M)) ? 1 : 0;
+  }
   // counters[0] = R (and [1..3] = 0) is written by the first kernel of the depth sort
   { ProfScope ps(PROF_PREPROCESS_FWD, s); launch_preprocess_fwd(a, s); }
   if (debug_sync(cfg->debug, s, "preprocess_fwd")) return 1;
@@ -304,7 +311,8 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
                              (uint32_t*)(bin + B.point_list),
                              // the per-instance tile id is only a debugging aid here (2M scattered 4-byte stores):
                              // it is implied by `ranges`, so it is written with cfg.debug only
-                             cfg->debug ? (uint32_t*)(bin + B.tile_keys) : nullptr, bo, s);
+                             cfg->debug ? (uint32_t*)(bin + B.tile_keys) : nullptr, bo, s,
+                             (const ColorJob*)(geom + G.color_job), cfg->sh_coeffs);
     if (rcb) return rcb;
     if (debug_sync(cfg->debug, s, "binning (counting sort)")) return 1;
   }

@@ -46,7 +46,7 @@ inline int debug_sync(int debug, hipStream_t s, const char* what) {
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 // ---- library options (riggs_set_option / riggs_get_option in the ABI; process-wide, nothing is read from the environment) ----
-enum OptId { OPT_FWD_WIDE_TILES = 0, OPT_FWD_WIDE_MIN, OPT_BIN_GROUPED, OPT_CNODE_BWD_ATOMICS, OPT_COUNT };
+enum OptId { OPT_FWD_WIDE_TILES = 0, OPT_FWD_WIDE_MIN, OPT_BIN_GROUPED, OPT_CNODE_BWD_ATOMICS, OPT_COLOR_SIDE_JOBS, OPT_COUNT };
 int option(int id);
 
 // ---- in-library kernel timing (HIP events on the launch stream; see riggs_prof_* in the ABI) ----
@@ -66,7 +66,7 @@ struct ProfScope {
 // ---- arena layouts ---------------------------------------------------------
 struct GeomLayout {
   size_t xyd, conic_o, rgb, cov3D, clamped, tiles, rect, depth_key, depth_key_sorted, order, block_tiles,
-      sort_table, total;
+      color_job, sort_table, total;
 };
 GeomLayout geom_layout(int N);
 

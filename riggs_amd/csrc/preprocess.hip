@@ -7,7 +7,7 @@
 //
 // This translation unit is compiled with FP contraction OFF (gauss_math.h) — geometry is
 // bit-identical to oracle/raster_ref.c.
-#include "gauss_math.h"
+#include "color_job.h"
 #include "raster_internal.h"
 
 namespace riggs {
@@ -59,42 +59,7 @@ __device__ __forceinline__ void finish_inputs(const PreArgs& a, const RawIn& w, 
   }
 }
 
-// ---- coalesced SH staging -----------------------------------------------------------------
-// A workgroup's 256 Gaussians own one contiguous run of coefficients in HBM ((N,16,3) records of
-// 192 B, or the reference's split parameters _features_dc (N,1,3) / _features_rest (N,15,3) of
-// 12 B + 180 B, scene/gaussian_model.py:177-195).  Per-thread record reads would touch every
-// 128-B line from 8+ different load instructions; instead the run is copied with full-line float4
-// accesses into LDS (row stride padded to an odd number of dwords -> conflict-free b32 reads) and
-// each thread then picks its own record.  The same path, reversed, writes dL/dsh.
-__device__ __forceinline__ int sh_lds_stride(int per) { return per | 1; }
-
-__device__ __forceinline__ void sh_stage_in(const float* __restrict__ src, int per, int count, float* lds) {
-  const int total = count * per;
-  const int stride = sh_lds_stride(per);
-  const bool aligned = ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
-  const int q1024 = 1024 / per, r1024 = 1024 % per;
-  int e = threadIdx.x * 4;
-  int g = e / per, k = e % per;
-  for (; e < total; e += 1024) {
-    float v[4];
-    if (aligned && e + 3 < total) {
-      const float4 t = *reinterpret_cast<const float4*>(src + e);
-      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    } else {
-#pragma unroll
-      for (int q = 0; q < 4; q++) v[q] = (e + q < total) ? src[e + q] : 0.f;
-    }
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      int kk = k + q, gg = g;
-      if (kk >= per) { kk -= per; gg++; }
-      if (e + q < total) lds[gg * stride + kk] = v[q];
-    }
-    k += r1024; g += q1024;
-    if (k >= per) { k -= per; g++; }
-  }
-}
-
+// ---- SH staging (sh_lds_stride, sh_stage_in, sh_stage_dma: color_job.h) ----------------------------
 // The same copy in two steps — every global load of the thread first (up to SH_IT independent 16-byte loads in flight),
 // the LDS writes after — so that a workgroup's staging costs ONE memory round trip instead of one per 4 KB slice: written
 // as a single loop the compiler waits for each load before its LDS write.  (Reading each Gaussian's 180-byte row straight
@@ -135,26 +100,6 @@ __device__ __forceinline__ void sh_stage_store(const float* __restrict__ src, in
   }
 }
 
-// The same copy with NO registers and no LDS-write pass: direct-to-LDS loads (global_load_lds_dwordx4: a wave instruction moves
-// 64 x 16 bytes to M0-base + lane x 16).  The LDS image is then the run itself, unpadded — which is the conflict-free layout
-// whenever the record length is odd (45 floats: the reference's _features_rest rows; stride 45 = 13 mod 32), so no swizzle is
-// needed; even record lengths (48: one (N,16,3) tensor) keep the register path with its padded rows.  The tail of the last
-// workgroup's run (< 1 KB) goes lane-masked, its last < 16 bytes as scalars.  __syncthreads() behind it carries the vmcnt(0).
-typedef __attribute__((address_space(1))) const void* sh_gptr;
-typedef __attribute__((address_space(3))) void* sh_lptr;
-__device__ __forceinline__ void sh_stage_dma(const float* __restrict__ src, int total /* floats */, float* lds) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int bytes = total * 4;
-  const char* g = reinterpret_cast<const char*>(src);
-  char* l = reinterpret_cast<char*>(lds);
-  for (int c = wave * 1024; c < bytes; c += 4096) {
-    if (c + lane * 16 + 16 <= bytes)
-      __builtin_amdgcn_global_load_lds((sh_gptr)(g + c + lane * 16), (sh_lptr)(l + c), 16, 0, 0);
-  }
-  const int done = bytes & ~15;
-  if ((int)threadIdx.x < (bytes - done) / 4) lds[done / 4 + threadIdx.x] = src[done / 4 + threadIdx.x];
-}
-
 __device__ __forceinline__ void sh_stage_out(float* __restrict__ dst, int per, int count, const float* lds) {
   const int total = count * per;
   const int stride = sh_lds_stride(per);
@@ -184,7 +129,16 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a) {
   extern __shared__ float s_sh[];
   const int i = blockIdx.x * 256 + threadIdx.x;
   // SH records of this workgroup -> LDS (uniform; before any per-Gaussian exit)
-  const bool sh_mode = (a.colors_precomp == nullptr);
+  // (a.defer_color: the colours are evaluated by extra workgroups of the tile sort's scatter launch — color_job.h — and this
+  // kernel neither stages nor reads a coefficient; either way it leaves the job's record for that launch: N = 0 = nothing to do)
+  if (a.job_rec && blockIdx.x == 0 && threadIdx.x == 0) {
+    ColorJob r;
+    r.N = a.defer_color ? a.N : 0; r.deg = a.deg; r.M = a.M; r.pad_ = 0;
+    r.shs = a.shs; r.shs_rest = a.shs_rest; r.means3D = a.means3D; r.d_xyz = (a.glue && a.d_xyz) ? a.d_xyz : nullptr;
+    r.campos = a.campos; r.radii = a.radii; r.rgb = a.rgb; r.clamped = a.clamped;
+    *a.job_rec = r;
+  }
+  const bool sh_mode = (a.colors_precomp == nullptr) && !a.defer_color;
   const int sh_per = a.shs_rest ? (a.M - 1) * 3 : a.M * 3;  // floats per Gaussian in the staged array
   // every global load of the thread is issued before anything waits: its slices of the workgroup's SH run and its own
   // Gaussian's parameters (the compiler otherwise serialises them: one round trip per load)
@@ -253,30 +207,12 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a) {
   y0 = min(gy, max(0, y0)); y1 = min(gy, max(0, y1));
   if ((x1 - x0) * (y1 - y0) == 0) break;
 
-  float rgbv[3];
+  float rgbv[3] = {0.f, 0.f, 0.f};
   uint8_t cl = 0;
   if (a.colors_precomp) {
     rgbv[0] = cpre[0]; rgbv[1] = cpre[1]; rgbv[2] = cpre[2];
-  } else {
-    float dx = p[0] - a.campos[0], dy = p[1] - a.campos[1], dz = p[2] - a.campos[2];
-    float len = sqrtf(dx * dx + dy * dy + dz * dz);
-    dx = dx / len; dy = dy / len; dz = dz / len;
-    float B[16];
-    sh_basis(a.deg, dx, dy, dz, B);
-    const int nb = (a.deg + 1) * (a.deg + 1);
-    const float* mine = s_sh + threadIdx.x * sh_lds_stride(sh_per);
-    const int koff = a.shs_rest ? 3 : 0;  // split layout: coefficient 0 comes from _features_dc
-    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-    if (a.shs_rest) { r0 = B[0] * dc0[0]; r1 = B[0] * dc0[1]; r2 = B[0] * dc0[2]; }
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-      if (k < nb && 3 * k >= koff) {
-        r0 += B[k] * mine[3 * k - koff]; r1 += B[k] * mine[3 * k + 1 - koff]; r2 += B[k] * mine[3 * k + 2 - koff];
-      }
-    }
-    r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
-    cl = (uint8_t)((r0 < 0.f ? 1 : 0) | (r1 < 0.f ? 2 : 0) | (r2 < 0.f ? 4 : 0));
-    rgbv[0] = fmaxf(r0, 0.f); rgbv[1] = fmaxf(r1, 0.f); rgbv[2] = fmaxf(r2, 0.f);
+  } else if (!a.defer_color) {
+    cl = sh_color(a.deg, p, a.campos, a.shs_rest != nullptr, dc0, s_sh + threadIdx.x * sh_lds_stride(sh_per), rgbv);
   }
   // axis-aligned half extents of the region where alpha = o * exp(power) can reach 1/255 (the compositing
   // kernels cull instances against pixel blocks with it): q(d) <= tau = 2 ln(255 o), x-extent sqrt(tau * Sxx).
@@ -305,7 +241,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a) {
   a.rgb[i] = make_float4(rgbv[0], rgbv[1], rgbv[2], cull_hy);
 #pragma unroll
   for (int k = 0; k < 6; k++) a.cov3D[6 * i + k] = c6[k];
-  a.clamped[i] = cl;
+  if (!a.defer_color) a.clamped[i] = cl;
   a.tiles[i] = (uint32_t)((x1 - x0) * (y1 - y0));
   my_rect = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
   a.depth_key[i] = __float_as_uint(vz);
@@ -643,7 +579,7 @@ __global__ __launch_bounds__(256, 3) void preprocess_bwd_kernel(PreBwdArgs b) {
 int launch_preprocess_fwd(const PreArgs& a, hipStream_t s) {
   if (a.N == 0) return 0;
   const int per = a.shs_rest ? (a.M - 1) * 3 : a.M * 3;
-  const size_t lds = a.colors_precomp ? 0 : (size_t)256 * (per | 1) * sizeof(float);
+  const size_t lds = (a.colors_precomp || a.defer_color) ? 0 : (size_t)256 * (per | 1) * sizeof(float);
   hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((a.N + 255) / 256), dim3(256), lds, s, a);
   return 0;
 }

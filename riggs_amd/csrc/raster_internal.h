@@ -4,8 +4,24 @@
 
 namespace riggs {
 
+// SH colour evaluation as a job of Gaussian blocks (color_job.h) that the tile sort's scatter launch hosts.  The record lives
+// in the geometry arena: preprocess_fwd writes it (N = 0: it evaluated the colours itself), the hosting launch reads it.
+struct ColorJob {
+  int N, deg, M, pad_;
+  const float *shs, *shs_rest, *means3D, *d_xyz /* or NULL */, *campos;
+  const int32_t* radii;  // (0: culled — no colour)
+  float4* rgb;           // .xyz written by the job; .w (a culling extent) is preprocess_fwd's
+  uint8_t* clamped;
+};
+// Is the colour job of a frame with these sizes hosted by the tile sort (launch_binning)?  Asked by riggs_raster_preprocess
+// (which then leaves the colours out of preprocess_fwd) and by riggs_raster_render (which then launches the extra workgroups):
+// both must see the same options ("color_side_jobs", "bin_grouped").
+bool binning_hosts_color(int N, int T, int sh_coeffs);
+
 struct PreArgs {
   int N, deg, M, W, H, glue, isotropic, tight;
+  int defer_color;      // forward only: the SH colours are left to the tile sort's scatter launch (color_job.h)
+  ColorJob* job_rec;    // forward only: the job's record in the geometry arena (written by this launch), or NULL
   float tanx, tany, mod;
   const float *view, *proj, *campos;
   const float *means3D, *shs, *shs_rest, *colors_precomp, *opac, *scales, *rots, *cov3D_precomp, *d_xyz, *d_rot, *d_scaling;
@@ -116,6 +132,7 @@ struct BinOut {  // what the extra workgroup of bin_scatter_kernel writes once p
 };
 int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order, const uint32_t* tiles,
                    const ushort4* rect, void* table_mem, void* scratch, uint32_t* point_list, uint32_t* tile_keys, const BinOut& out,
-                   hipStream_t s);
+                   hipStream_t s, const ColorJob* job_rec = nullptr /* device record, when the launch hosts the colour job */,
+                   int job_sh_coeffs = 0);
 
 }  // namespace riggs

@@ -325,6 +325,54 @@ def test_render_rejects_a_binning_arena_that_is_too_small():
     assert len(sizes) <= 2 and max(sizes) - min(sizes) <= 4096, sizes  # (monotonic up to alignment in N across the switch)
 
 
+@pytest.mark.parametrize("case,deg,split,glue", [(1, 3, True, True), (3, 3, True, False), (2, 2, False, False), (0, 0, True, True),
+                                                 (4, 1, False, True), (6, 3, True, False)])
+def test_colour_job_of_the_tile_sort_equals_the_colours_of_preprocess(case, deg, split, glue):
+    """riggs_set_option("color_side_jobs"): the SH colours evaluated by extra workgroups of the tile sort's scatter launch
+    (csrc/color_job.h; the default wherever the direct tile sort runs) against preprocess_fwd evaluating them itself: colours,
+    clamp bits, images bit for bit — and both against the oracle.  Split (_features_dc / _features_rest: direct-to-LDS rows)
+    and single-tensor layouts, every degree, with and without the fused deformation residual (the view direction is taken
+    from the DEFORMED mean), ragged last blocks (odd N), 9 417 tiles (one wave per workgroup of the scatter launch)."""
+    from riggs_amd import _lib as L
+    N, J, seed, H, W, scale, camkw = CASES[case]
+    sc, act, cam = U.activated_scene(N, J, seed, H, W, scale=scale, **camkw)
+    M = (deg + 1) ** 2
+    d = lambda t: t.cuda().contiguous()  # noqa: E731
+    gen = torch.Generator().manual_seed(seed)
+    dx = 0.02 * torch.randn(N, 3, generator=gen)
+    means = act["means3D"] + dx if glue else act["means3D"]
+    shs = act["shs"][:, :M].contiguous()
+    act_o = dict(act, means3D=means, shs=shs)
+    out_o, so = U.oracle_forward(act_o, cam, [0.1, 0.2, 0.3], sh_degree=deg)
+    st = U.settings_for(cam, [0.1, 0.2, 0.3], deg, 1.0, True)
+    assert L.get_option("color_side_jobs") == 1
+    res = []
+    try:
+        for on in (1, 0):
+            L.set_option("color_side_jobs", on)
+            a_shs = d(shs[:, :1]) if split else d(shs)
+            a_rest = d(shs[:, 1:]) if split else None
+            if glue:  # raw parameters in, activations in the kernel
+                color, radii, depth, alpha, s = rasterize_forward(
+                    st, d(sc["xyz"]), a_shs, None, d(sc["opacity"]), d(sc["scaling"]), d(sc["rotation"]), None, d_xyz=d(dx),
+                    glue=True, shs_rest=a_rest)
+            else:
+                color, radii, depth, alpha, s = rasterize_forward(st, d(act["means3D"]), a_shs, None, d(act["opacities"]),
+                                                                  d(act["scales"]), d(act["rotations"]), None, shs_rest=a_rest)
+            v = saved_views(s)
+            res.append((color, v["rgb"].clone(), v["clamped"].clone(), radii))
+    finally:
+        L.set_option("color_side_jobs", 1)
+    vis = (res[0][3] > 0)
+    assert int(vis.sum()) > 100
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1][vis], res[1][1][vis]) and torch.equal(res[0][2][vis], res[1][2][vis])
+    rgb_o = so.rgb[vis.cpu().numpy()]
+    U.assert_close(res[0][1].cpu().numpy()[vis.cpu().numpy(), :3], rgb_o, "rgb (colour job)", 1e-5 if not glue else 1e-4)
+    if not glue:
+        U.assert_close(res[0][0].cpu().numpy(), out_o["color"], "image (colour job)", U.REL_TOL, 1e-4)
+
+
 @pytest.mark.parametrize("case,opacity_scale", [(1, 1.0), (2, 0.05), (5, 1.0), (4, 0.3)])
 def test_tight_lists_are_the_canonical_lists_minus_the_instances_that_cannot_reach_a_pixel(case, opacity_scale):
     """cfg.tight_lists (rasterizer.set_tight_lists): the tile rectangle of a Gaussian is cut down by its alpha >= 1/255 box.
