@@ -921,9 +921,22 @@ static bool bin_grouped(int N, int T) {
   if (forced >= 0) return forced != 0 && T >= 64;
   return T >= BIN_GROUPED_AUTO_T && N >= BIN_GROUPED_AUTO_N;
 }
-// (the direct sort's scatter launch hosts the colour job; up to 16 coefficients per channel — degree 3)
+// (the direct sort's scatter launch hosts the colour job; up to 16 coefficients per channel — degree 3.  The grouped sort's
+// first-level scatter does not: where that sort runs — half a million Gaussians and more — its launches have no idle slots, and the
+// colour blocks in its 1024-thread workgroups cost more than they save: C4 0.511 -> 0.518 ms, C5 1.423 -> 1.497 ms)
 bool binning_hosts_color(int N, int T, int sh_coeffs) {
   return option(OPT_COLOR_SIDE_JOBS) != 0 && N > 0 && sh_coeffs >= 1 && sh_coeffs <= 16 && T <= 65535 && !bin_grouped(N, T);
+}
+// the colour job rides on a scatter launch of `threads` threads and `lds` bytes per workgroup: blocks of gpb Gaussians — as many
+// as the workgroup has threads and its LDS holds rows for (at least 64; the LDS grows to 256 rows if it is smaller)
+static void color_job_plan(const ColorJob* job_rec, int N, int T, int sh_coeffs, int threads, int& n_col, int& gpb, size_t& lds) {
+  n_col = 0; gpb = 0;
+  if (!job_rec || !binning_hosts_color(N, T, sh_coeffs)) return;
+  const size_t row = (size_t)((sh_coeffs * 3) | 1) * 4;  // (the longest row: one (N, M, 3) tensor)
+  gpb = threads < 384 ? threads : 384;
+  while (gpb > 64 && gpb * row > (lds > 256 * row ? lds : 256 * row)) gpb -= 64;
+  if (gpb * row > lds) lds = gpb * row;
+  n_col = (N + gpb - 1) / gpb;
 }
 struct GBinPlan { int G, gxg, W, g_per_block, g_per_wave, n_chunks; size_t lds; };
 static GBinPlan gbin_plan(int N, int T, int grid_x) {
@@ -1024,17 +1037,9 @@ int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order,
                      order, rect, srect, table);
   hipLaunchKernelGGL(bin_scan_kernel, dim3((T + 63) / 64), dim3(1024), 0, s, T, p.n_chunks, table, tile_count);
   // (+ 1: the extra workgroup that writes the ranges, the counters and the forward's work list)
-  // the colour job rides on the scatter launch (binning_hosts_color): blocks of gpb Gaussians, as many as the workgroup has
-  // threads and its LDS holds rows for (at least 64)
   int n_col = 0, gpb = 0;
   size_t lds = p.lds_scatter;
-  if (job_rec && binning_hosts_color(N, T, job_sh_coeffs)) {
-    const size_t row = (size_t)((job_sh_coeffs * 3) | 1) * 4;  // (the longest row: one (N, M, 3) tensor)
-    gpb = p.threads < 384 ? p.threads : 384;
-    while (gpb > 64 && gpb * row > (lds > 256 * row ? lds : 256 * row)) gpb -= 64;
-    if (gpb * row > lds) lds = gpb * row;
-    n_col = (N + gpb - 1) / gpb;
-  }
+  color_job_plan(job_rec, N, T, job_sh_coeffs, p.threads, n_col, gpb, lds);
   hipLaunchKernelGGL(bin_scatter_kernel, dim3(p.n_chunks + 1 + n_col), dim3(p.threads), lds, s, N, T, grid_x, cap,
                      p.g_per_block, p.g_per_wave, order, srect, table, tile_count, point_list, tile_keys, out, p.n_chunks, job_rec, gpb);
   return 0;
