@@ -152,6 +152,13 @@ def lib():
             raise RiggsHipError(
                 "libriggs_hip.so not found at %s — build it with `python -m riggs_amd.build` "
                 "(or __graft_entry__.build()).  There is no fallback path." % SO_PATH)
+        # (torch's HIP runtime first: a process whose first HIP activity is this library's load — its kernels register with
+        # the runtime from static initialisers — and which initialises torch.cuda afterwards ends with the library's launches
+        # failing "no ROCm-capable device is detected"; the other order is the one every caller that allocates a tensor
+        # before its first call takes anyway)
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
         L = C.CDLL(SO_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)  # AttributeError if a declared symbol is not exported

@@ -5,9 +5,6 @@ import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 
-import torch
-
-torch.cuda.init()
 import riggs_amd._lib as L  # noqa: E402
 
 i = sys.argv.index("--")
