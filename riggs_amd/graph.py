@@ -156,6 +156,7 @@ class GraphedFrame:
                 torch.cuda.current_stream().synchronize()
                 self.arena.resolve()
                 self.out = None
+            self.arena.top_up()  # (the captured frame must find its arena: an allocation + a history reset inside the capture replay for ever)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         for p in self.params:

@@ -45,6 +45,7 @@ class RasterArena:
         self.min_capacity = min_capacity
         self.binning: Optional[torch.Tensor] = None
         self.last_R = -1
+        self._dims = None     # (N, H, W, device) of the last frame
         self._pending = None  # (event, pinned host counters, capacity used)
         self.static_counters = None
         # set by the OWNER of a captured frame (riggs_amd.graph.GraphedFrame(sparse_grad_rows=True)): backwards of frames
@@ -85,10 +86,15 @@ class RasterArena:
                                   "outputs are invalid.  The arena is regrown on the next call." % (R, cap))
         return True
 
-    def ensure(self, cap: int, N: int, H: int, W: int, device):
+    def ensure(self, cap: int, N: int, H: int, W: int, device, minimum: Optional[int] = None):
+        """The arena for ``cap`` instances (the previous frame's count with the growth head-room).  An arena that still holds
+        ``minimum`` (the count with a THIRD of that head-room; default: ``cap``) is kept: a scene whose count creeps up from
+        frame to frame — every training iteration — would otherwise be given a new arena, and a fresh walk history, by each
+        frame, including the one a hipGraph capture records (the allocation and the history's memset then replay for ever)."""
         cap = max(int(cap), self.min_capacity)
+        self._dims = (N, H, W, device)
         same = self.binning is not None and self.binning.device == device
-        if same and cap <= self.capacity:
+        if same and (cap if minimum is None else min(int(minimum), cap)) <= self.capacity:
             # enough instances — but the arena also holds tables sized by the number of Gaussians and of tiles (the tile
             # sort's chunk x tile table): a scene that grew, or a larger image, needs a larger arena at the same capacity
             if L.lib().riggs_raster_binning_bytes(self.capacity, N, H, W) <= self.binning.numel():
@@ -98,6 +104,12 @@ class RasterArena:
         self.capacity = cap
         self._layout_key = None
         return self._with_fresh_history(N, H, W)
+
+    def top_up(self):
+        """Full head-room over the last frame's count, now (eagerly): what the owner of a hipGraph capture calls between its
+        warm-up frames and the capture, so that the captured frame neither allocates nor resets the history."""
+        if self._dims is not None and self.last_R >= 0:
+            self.ensure(int(self.last_R * self.growth) + 1, *self._dims)
 
     def _with_fresh_history(self, N: int, H: int, W: int):
         """The arena's one piece of frame-to-frame state — how deep the forward walked every tile's list — sits at an offset
@@ -200,7 +212,8 @@ def rasterize_forward(settings, means3D, shs, colors_precomp, opacities, scales,
         s.R = R
     else:
         arena.resolve(block=True)
-        binning = arena.ensure(int(arena.last_R * arena.growth) + 1, N, H, W, dev)
+        binning = arena.ensure(int(arena.last_R * arena.growth) + 1, N, H, W, dev,
+                               minimum=int(arena.last_R * (1.0 + (arena.growth - 1.0) / 3.0)) + 1)
         cap = arena.capacity
         s.R = None  # unknown until counters are read
     L.check(lib.riggs_raster_render(C.byref(cfg), geom.data_ptr(), binning.data_ptr(), cap, binning.numel(), img.data_ptr(),

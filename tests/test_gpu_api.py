@@ -228,6 +228,52 @@ def test_graphed_train_step_matches_eager_iterations(sparse_rows):
         bench.WORKLOAD.update(old)
 
 
+def test_capture_of_a_drifting_scene_records_no_arena_allocation():
+    """Training iterations change the instance count from frame to frame.  The arena keeps its allocation while the count stays
+    inside a third of the head-room, and the owner of a capture tops the head-room up BEFORE capturing: the captured iteration
+    must contain neither an allocation of the arena nor the memset that clears its walk history (they would replay for ever:
+    9 us of every iteration, and the forward's wide blocks never engaged — seen in a kernel trace of the captured iteration)."""
+    from types import SimpleNamespace
+
+    import bench
+    from riggs_amd import _lib as L
+    from riggs_amd.graph import GraphedTrainStep
+    from riggs_amd.optim import FusedAdam
+    old = dict(bench.WORKLOAD)
+    bench.WORKLOAD.update(N=20000, J=8, H=160, W=160)
+    args = SimpleNamespace(percent_dense=0.01, position_lr_init=0.016, position_lr_final=0.0000016, position_lr_delay_mult=0.01,
+                           position_lr_max_steps=30000, feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.05, rotation_lr=0.001)
+    lib = L.lib()
+    orig = lib.riggs_raster_binning_reset_history
+    calls = []
+
+    def spy(*a):
+        calls.append(bool(torch.cuda.is_current_stream_capturing()))
+        return orig(*a)
+    try:
+        lib.riggs_raster_binning_reset_history = spy
+        sc, cam, gm, sw = bench.build_workload(0, "cuda:0")
+        gt = torch.rand(3, 160, 160, generator=torch.Generator().manual_seed(2)).cuda()
+        gm.training_setup(args, capturable=True)  # (large position / scale steps: the count moves by per cents per iteration)
+        sk_opt = FusedAdam([{"params": g["params"], "lr": 5e-4, "name": g["name"]} for g in sw.trainable_parameters()],
+                           lr=0.0, eps=1e-15, capturable=True)
+        gts = GraphedTrainStep(gm, sw, cam, torch.zeros(3, device="cuda"), gt, [gm.optimizer, sk_opt], sparse_grad_rows=True)
+        gts.capture(warmup=3)
+        assert calls and not any(calls), calls   # (resets happened, all of them eagerly)
+        where, cap = gts.arena.binning.data_ptr(), gts.arena.capacity
+        counts = []
+        for _ in range(4):
+            gts.run()
+            counts.append(gts.check())
+        assert gts.arena.binning.data_ptr() == where and gts.arena.capacity == cap
+        assert len(set(counts)) > 1, counts     # the scene did drift
+        assert cap >= int(min(counts) * 1.3)    # ... inside the topped-up head-room (1.5)
+    finally:
+        lib.riggs_raster_binning_reset_history = orig
+        bench.WORKLOAD.clear()
+        bench.WORKLOAD.update(old)
+
+
 def test_graphed_train_step_survives_densification_by_recapture():
     """The reference changes N every densification_interval iterations (scene/gaussian_model.py:445-514: clone / split /
     prune, each replacing the parameter tensors and moving the optimizer state with cat_tensors_to_optimizer /
