@@ -969,18 +969,34 @@ def main():
         for _ in range(3):
             eager_step()
         torch.cuda.synchronize()
+        # An event pair around a kernel that the host launches into an EMPTY queue also times the launch's way to the device
+        # (round 3 read 102 us for the 76 us Adam kernel, 55 us for the 33 us loss kernel: what the rocprofv3 trace of the same
+        # kernels inside a graph shows).  So every profiled sequence is issued behind a spinning kernel that holds the queue
+        # while the host enqueues it: the events then bracket what a kernel costs BEHIND another kernel — the situation of a
+        # graph node, and the duration the kernel trace reports.
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        torch.cuda._sleep(4_000_000)
+        e1.record()
+        torch.cuda.synchronize()
+        cycles_per_ms = 4_000_000 / max(e0.elapsed_time(e1), 1e-3)
+
+        def hold(ms):
+            torch.cuda._sleep(int(ms * cycles_per_ms))
         lib.riggs_prof_reset()
         lib.riggs_prof_enable(0xFFFFFFFF)
         # (the Gaussian optimizer step of SURVEY.md §8-f rank 1 is timed here as well — it is NOT part of the headline
         # metric, whose definition is deform + raster forward + backward)
         gm.training_setup(_train_args())
         for _ in range(min(args.steps, 20)):
+            hold(1.0)      # (an eagerly issued frame is ~0.5 ms of host time)
             eager_step()
-        # the Adam launches are issued BACK TO BACK (learning rates 0: nothing moves): an event pair around a kernel that the
-        # host launches into an empty queue also times the host (round 3 read 102 us here for a 76 us kernel)
+            torch.cuda.synchronize()
+        # the Adam launches back to back (learning rates 0: nothing moves)
         lrs = [g_["lr"] for g_ in gm.optimizer.param_groups]
         for g_ in gm.optimizer.param_groups:
             g_["lr"] = 0.0
+        hold(3.0)
         for _ in range(min(args.steps, 20) + 5):
             gm.optimizer.step()
         for g_, lr_ in zip(gm.optimizer.param_groups, lrs):
@@ -988,6 +1004,8 @@ def main():
         # ... and the fused image loss of §8-f rank 2 (L1 + SSIM forward, dL/dimage backward) on the rendered image
         from riggs_amd.loss import l1_ssim
         img_leaf = eager_step()["render"].detach().clone().requires_grad_(True)
+        torch.cuda.synchronize()
+        hold(8.0)
         for _ in range(min(args.steps, 20)):
             l1v, sv = l1_ssim(img_leaf, gimg)
             (0.8 * l1v + 0.2 * (1.0 - sv)).backward()
