@@ -205,15 +205,28 @@ def stream_ptr():
     return torch.cuda.current_stream().cuda_stream
 
 
+_F32 = None
+
+
 def require_cuda_f32(name, t, shape=None):
-    import torch
+    global _F32
     if t is None:
         return None
+    if _F32 is None:
+        import torch
+        _F32 = torch.float32
     if not t.is_cuda:
         raise RiggsHipError("%s must be a CUDA(HIP) tensor — the product path is GPU-only" % name)
-    if t.dtype != torch.float32:
+    if t.dtype is not _F32:
         raise RiggsHipError("%s must be float32, got %s" % (name, t.dtype))
     if shape is not None:
-        if len(shape) != t.dim() or any(s is not None and s != d for s, d in zip(shape, t.shape)):
-            raise RiggsHipError("%s has shape %s, expected %s" % (name, tuple(t.shape), shape))
-    return t.contiguous()
+        ts = t.shape
+        ok = len(shape) == len(ts)
+        if ok:
+            for s, d in zip(shape, ts):
+                if s is not None and s != d:
+                    ok = False
+                    break
+        if not ok:
+            raise RiggsHipError("%s has shape %s, expected %s" % (name, tuple(ts), shape))
+    return t if t.is_contiguous() else t.contiguous()

@@ -30,6 +30,9 @@ def _req(name, t, shape):
     return L.require_cuda_f32(name, t, shape)
 
 
+_SIZES = {}  # (N, H, W, PoseMLP shape) -> sizes the library reports for them
+
+
 class _FrameFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t, rho, mask, xyz, means2D, f_dc, f_rest, opacity, scaling, rotation, spec, *params):
@@ -56,16 +59,34 @@ class _FrameFn(torch.autograd.Function):
             sync = None
         keep = []
         cfg = _cfg(settings, N, f_dc.shape[1] + f_rest.shape[1], True, isotropic, keep)
-        # outputs and saved state (the small per-joint arrays share one allocation)
-        small = torch.empty(J * 23 + 4, **f32)
+        # outputs and saved state: ONE float allocation for the per-joint arrays, the PoseMLP's activations, the residuals and
+        # the counters, ONE byte allocation for the two rasterizer arenas (ten torch.empty calls were 29 us of an eager frame;
+        # every piece starts on a 256-byte boundary)
+        def up(n):
+            return (n + 63) & ~63
+        skey = (N, H, W, depth, width, pn.multires)
+        sizes = _SIZES.get(skey)
+        if sizes is None:
+            if len(_SIZES) > 64:
+                _SIZES.clear()
+            sizes = _SIZES[skey] = (lib.riggs_pose_mlp_acts_floats(depth, width, pn.multires), lib.riggs_raster_geom_bytes(N),
+                                    lib.riggs_raster_image_bytes(H, W))
+        n_small, n_acts = J * 23 + 4, sizes[0]
+        o_acts = up(n_small)
+        o_dx = o_acts + up(n_acts)
+        o_dr = o_dx + up(3 * N)
+        o_cnt = o_dr + up(4 * N)
+        o_rad = o_cnt + 64
+        fbuf = torch.empty(o_rad + up(N), **f32)
+        small, acts = fbuf[:n_small], fbuf[o_acts:o_acts + n_acts]
         local_rot, transforms = small[:J * 4].view(J, 4), small[J * 4:J * 16].view(J, 12)
         node_rot, d_nodes, global_trans = small[J * 16:J * 20].view(J, 4), small[J * 20:J * 23].view(J, 3), small[J * 23:J * 23 + 3]
-        acts = torch.empty(lib.riggs_pose_mlp_acts_floats(depth, width, pn.multires), **f32)
-        d_xyz, d_rot = torch.empty(N, 3, **f32), torch.empty(N, 4, **f32)
-        geom = torch.empty(lib.riggs_raster_geom_bytes(N), dtype=torch.uint8, device=dev)
-        img = torch.empty(lib.riggs_raster_image_bytes(H, W), dtype=torch.uint8, device=dev)
-        radii = torch.empty(N, dtype=torch.int32, device=dev)
-        counters = torch.empty(4, dtype=torch.int32, device=dev)
+        d_xyz, d_rot = fbuf[o_dx:o_dx + 3 * N].view(N, 3), fbuf[o_dr:o_dr + 4 * N].view(N, 4)
+        ibuf = fbuf.view(torch.int32)
+        counters, radii = ibuf[o_cnt:o_cnt + 4], ibuf[o_rad:o_rad + N]
+        n_geom = (sizes[1] + 255) & ~255
+        bbuf = torch.empty(n_geom + sizes[2], dtype=torch.uint8, device=dev)
+        geom, img = bbuf[:n_geom], bbuf[n_geom:]
         out = torch.empty(5, H, W, **f32)
         color, depth_img, alpha = out[:3], out[3:4], out[4:5]
         arena.resolve(block=True)
@@ -144,11 +165,8 @@ class _FrameFn(torch.autograd.Function):
             _WORKSPACES.clear()
             raise
         _LAST_WORKSPACE[:] = [ws, N]
-        grads, o = [], 0
-        for p in params:
-            n = p.numel()
-            grads.append(flat[o:o + n].view_as(p))
-            o += n
+        # (one split + a view per matrix: a slice and a view per parameter were 30 us of an eager frame)
+        grads = [g_ if p.dim() == 1 else g_.view(p.shape) for g_, p in zip(flat.split_with_sizes([p.numel() for p in params]), params)]
         gmask = dmask.reshape(mask_shape) if need_mask else None
         return (None, drho, gmask, g_xyz, g_m2d, g_dc, g_rest, g_op, g_sc, g_rot, None, *grads)
 
@@ -192,9 +210,11 @@ def deform_render(viewpoint_camera, pc, sw, pipe, bg_color, scaling_modifier=1.0
         return pkg
     pn = sw.pose_net
     params = []
-    for layer in pn.net:
-        params += [layer.weight, layer.bias]
-    params += [pn.rotation_predictor.weight, pn.rotation_predictor.bias, pn.translation_predictor.weight, pn.translation_predictor.bias]
+    for layer in pn.net._modules.values():  # (straight from the registries: Module.__getattr__ per access is 10 us a frame)
+        pd = layer._parameters
+        params += [pd["weight"], pd["bias"]]
+    for head in (pn._modules["rotation_predictor"], pn._modules["translation_predictor"]):
+        params += [head._parameters["weight"], head._parameters["bias"]]
     settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
         tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5), bg=bg_color,

@@ -46,6 +46,8 @@ class RasterArena:
         self.binning: Optional[torch.Tensor] = None
         self.last_R = -1
         self._dims = None     # (N, H, W, device) of the last frame
+        self._ring, self._ring_at = [], -1  # recycled (event, pinned host counters) pairs of the asynchronous read-back
+        self._fits = None     # (capacity, N, H, W) the current allocation is known to hold
         self._pending = None  # (event, pinned host counters, capacity used)
         self.static_counters = None
         # set by the OWNER of a captured frame (riggs_amd.graph.GraphedFrame(sparse_grad_rows=True)): backwards of frames
@@ -60,9 +62,15 @@ class RasterArena:
         self.static_counters = counters
         if torch.cuda.is_current_stream_capturing():
             return  # inside a hipGraph capture: GraphedFrame.check() reads the counters after the replay
-        host = torch.empty(4, dtype=torch.int32, pin_memory=True)
+        # (pinned buffers and events are recycled: allocating a pinned tensor and an event per frame was 15 us of an eager frame)
+        ring = self._ring
+        if len(ring) < 4:
+            ring.append((torch.cuda.Event(), torch.empty(4, dtype=torch.int32, pin_memory=True)))
+        self._ring_at = (self._ring_at + 1) % len(ring)
+        ev, host = ring[self._ring_at]
+        if not ev.query():  # (its copy of four frames ago is still in flight: a read-back nobody resolved — leave that pair alone)
+            ev, host = torch.cuda.Event(), torch.empty(4, dtype=torch.int32, pin_memory=True)
         host.copy_(counters, non_blocking=True)
-        ev = torch.cuda.Event()
         ev.record()
         self._pending = (ev, host, cap)
 
@@ -76,7 +84,8 @@ class RasterArena:
             return False
         ev.synchronize()
         self._pending = None
-        R, overflow = int(host[0]) & 0xFFFFFFFF, int(host[1])
+        c = host.tolist()
+        R, overflow = c[0] & 0xFFFFFFFF, c[1]
         self.last_R = R
         if overflow & 2:
             raise L.RiggsHipError("the depth sort's third pass could not synchronise its workgroups on the previous frame (GPU shared "
@@ -97,12 +106,18 @@ class RasterArena:
         if same and (cap if minimum is None else min(int(minimum), cap)) <= self.capacity:
             # enough instances — but the arena also holds tables sized by the number of Gaussians and of tiles (the tile
             # sort's chunk x tile table): a scene that grew, or a larger image, needs a larger arena at the same capacity
+            # (asked of the library once per (capacity, N, H, W))
+            key = (self.capacity, N, H, W)
+            if self._fits == key:
+                return self._with_fresh_history(N, H, W)
             if L.lib().riggs_raster_binning_bytes(self.capacity, N, H, W) <= self.binning.numel():
+                self._fits = key
                 return self._with_fresh_history(N, H, W)
             cap = self.capacity
         self.binning = torch.empty(L.lib().riggs_raster_binning_bytes(cap, N, H, W), dtype=torch.uint8, device=device)
         self.capacity = cap
         self._layout_key = None
+        self._fits = (cap, N, H, W)
         return self._with_fresh_history(N, H, W)
 
     def top_up(self):
@@ -125,7 +140,8 @@ class RasterArena:
 
 def _cfg(settings: GaussianRasterizationSettings, N: int, M: int, glue: bool, isotropic: bool, keep: list):
     dev = settings.viewmatrix.device
-    bg = L.require_cuda_f32("bg", settings.bg.to(dev).reshape(-1), (3,))
+    bg = settings.bg
+    bg = L.require_cuda_f32("bg", (bg if bg.device == dev else bg.to(dev)).reshape(-1), (3,))
     view = L.require_cuda_f32("viewmatrix", settings.viewmatrix, (4, 4))
     proj = L.require_cuda_f32("projmatrix", settings.projmatrix, (4, 4))
     campos = L.require_cuda_f32("campos", settings.campos.reshape(-1), (3,))
