@@ -1161,8 +1161,14 @@ def main():
             gm.training_setup(_train_args(), capturable=True)
             sk_opt = FusedAdam([{"params": g_["params"], "lr": 5e-4, "name": g_["name"]} for g_ in sw.trainable_parameters()],
                                lr=0.0, eps=1e-15, capturable=True)
+            # The iteration's target is the scene's own first render plus noise: a target the scene can be near.  (Against the
+            # uniform-random image of the frame metric, Adam walks every scale up by its learning rate per step: the instance
+            # count tripled within a hundred iterations and the captured iteration overflowed its arena — rounds 2-4 reported
+            # the time of that truncated frame.  The count is now read back and reported, and an overflow raises.)
+            img0 = gf.run()["render"].detach().clone()
+            target_ts = (img0 + 0.05 * torch.randn(img0.shape, generator=torch.Generator().manual_seed(w["seed"] + 7)).to(dev)).clamp_(0.0, 1.0)
             # (the headline frame `gf` shares these gradient buffers but is not replayed any more: this frame is their only writer)
-            gts = GraphedTrainStep(gm, sw, cam, torch.zeros(3, device=dev), target, [gm.optimizer, sk_opt], lambda_dssim=0.2,
+            gts = GraphedTrainStep(gm, sw, cam, torch.zeros(3, device=dev), target_ts, [gm.optimizer, sk_opt], lambda_dssim=0.2,
                                    sparse_grad_rows=True)
             gts.capture()
             for _ in range(5):
@@ -1174,10 +1180,45 @@ def main():
                 gts.run()
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t1) / n_ts
-            out["train_step"] = {"value": round(1.0 / dt, 2), "unit": "iters/s", "ms_per_step": round(dt * 1e3, 4),
+            R_ts = gts.check()  # (raises if the captured iteration's arena overflowed while the scene trained: the time would be of truncated lists)
+            out["train_step"] = {"value": round(1.0 / dt, 2), "unit": "iters/s", "ms_per_step": round(dt * 1e3, 4), "tile_instances_R": int(R_ts),
                                  "includes": "deform + raster fwd/bwd + fused L1/SSIM loss fwd/bwd + FusedAdam (Gaussians, "
                                              "skeleton), one hipGraph; not the headline metric",
                                  "final_loss": round(float(gts.out["loss"]), 6)}
+            # ... and the same iteration issued EAGERLY, call by call, as the reference's loop does (train_rig.py:411-554:
+            # skeleton step, render, l1 + ssim, backward, the two optimizers' steps) — what an unmodified trainer gets
+            from riggs_amd.loss import l1_loss, ssim
+            from riggs_amd.render import render as render_fn
+            del gts
+            gm.training_setup(_train_args())
+            sk_eager = FusedAdam([{"params": g_["params"], "lr": 5e-4, "name": g_["name"]} for g_ in sw.trainable_parameters()],
+                                 lr=0.0, eps=1e-15)
+            t_in = sw.expand_time(cam.fid)
+            arena_e = RasterArena()
+            bg_e = torch.zeros(3, device=dev)
+
+            def eager_iteration():
+                gm.optimizer.zero_grad(set_to_none=True)
+                sk_eager.zero_grad(set_to_none=True)
+                dv = sw(gm.get_xyz.detach(), t_in, motion_mask=gm.motion_mask)
+                pkg_e = render_fn(cam, gm, Pipe, bg_e, dv["d_xyz"], dv["d_rotation"], dv["d_scaling"], arena=arena_e)
+                loss_e = 0.8 * l1_loss(pkg_e["render"], target_ts) + 0.2 * (1.0 - ssim(pkg_e["render"], target_ts))
+                loss_e.backward()
+                gm.optimizer.step()
+                sk_eager.step()
+            for _ in range(20):
+                eager_iteration()
+            blocks = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(n_ts):
+                    eager_iteration()
+                torch.cuda.synchronize()
+                blocks.append(round((time.perf_counter() - t1) / n_ts * 1e3, 4))
+            out["train_step"]["eager_ms_per_step"] = min(blocks)
+            out["train_step"]["eager"] = ("the same iteration issued eagerly, call by call, as train_rig.py:411-554 does (two optimizers "
+                                          "stepped one after the other); fastest of three blocks")
         if world == 1 and not args.no_graph and not args.metric_only:
             # Secondary number (NOT the metric): the deformation with both per-Gaussian MLP heads on (the stage-2 recipe,
             # SURVEY.md §8-f rank 3), forward + backward, fp32 library GEMMs vs the fused MFMA kernels (fp16 operands)

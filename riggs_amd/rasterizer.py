@@ -228,8 +228,12 @@ def rasterize_forward(settings, means3D, shs, colors_precomp, opacities, scales,
         s.R = R
     else:
         arena.resolve(block=True)
-        binning = arena.ensure(int(arena.last_R * arena.growth) + 1, N, H, W, dev,
-                               minimum=int(arena.last_R * (1.0 + (arena.growth - 1.0) / 3.0)) + 1)
+        # (inside a hipGraph capture an arena that still has a third of the head-room is kept — its owner topped it up before
+        # capturing, RasterArena.top_up — so that the captured frame neither allocates nor resets the walk history; an eagerly
+        # issued frame gets the full head-room back whenever the count reached a new maximum: a scene under training can grow by
+        # 10 % from one frame to the next)
+        minimum = int(arena.last_R * (1.0 + (arena.growth - 1.0) / 3.0)) + 1 if torch.cuda.is_current_stream_capturing() else None
+        binning = arena.ensure(int(arena.last_R * arena.growth) + 1, N, H, W, dev, minimum=minimum)
         cap = arena.capacity
         s.R = None  # unknown until counters are read
     L.check(lib.riggs_raster_render(C.byref(cfg), geom.data_ptr(), binning.data_ptr(), cap, binning.numel(), img.data_ptr(),
