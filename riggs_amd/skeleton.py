@@ -310,6 +310,9 @@ class _DeformByPose(torch.autograd.Function):
         return dq, dgt, drho, gmask, None, None, None, None, dmod
 
 
+_ACTS_FLOATS = {}  # PoseMLP shape -> riggs_pose_mlp_acts_floats
+
+
 class _PoseDeform(torch.autograd.Function):
     """SkeletonWarp.forward(x, t, mask) as ONE autograd node over three launches forward and three backward: PoseMLP, then
     forward kinematics + skinning in one launch (riggs_lbs_forward_fk); skinning backward (two launches), then the reverse
@@ -328,9 +331,20 @@ class _PoseDeform(torch.autograd.Function):
             weight_mod = L.require_cuda_f32("skinning weight offsets", weight_mod, (N, J - 1))
         rho = L.require_cuda_f32("_node_radius", rho, (J,))
         mflat = None if mask is None else L.require_cuda_f32("motion_mask", mask.reshape(-1), (N,))
-        acts = torch.empty(lib.riggs_pose_mlp_acts_floats(depth, width, multires), **f32)
-        local_rot = torch.empty(J, 4, **f32)
-        global_trans = torch.empty(3, **f32)
+        # (two allocations for the eight outputs / saved arrays — every piece on a 256-byte boundary: eight torch.empty calls
+        # were 15 us of an eagerly issued frame)
+        key = (depth, width, multires)
+        n_acts = _ACTS_FLOATS.get(key)
+        if n_acts is None:
+            n_acts = _ACTS_FLOATS[key] = lib.riggs_pose_mlp_acts_floats(depth, width, multires)
+        o_small = (n_acts + 63) & ~63
+        sbuf = torch.empty(o_small + J * 23 + 4, **f32)
+        acts, small = sbuf[:n_acts], sbuf[o_small:]
+        local_rot, transforms = small[:J * 4].view(J, 4), small[J * 4:J * 16].view(J, 12)
+        node_rot, d_nodes, global_trans = small[J * 16:J * 20].view(J, 4), small[J * 20:J * 23].view(J, 3), small[J * 23:J * 23 + 3]
+        o_rot = (3 * N + 63) & ~63
+        dbuf = torch.empty(o_rot + 4 * N, **f32)
+        d_xyz, d_rot = dbuf[:3 * N].view(N, 3), dbuf[o_rot:].view(N, 4)
         Wp, bp = _PoseMLPFn._ptrs(params, depth)
         h = params[2 * depth:]
         st = L.stream_ptr()
@@ -338,11 +352,6 @@ class _PoseDeform(torch.autograd.Function):
                                            h[2].data_ptr(), h[3].data_ptr(), t.data_ptr(), L.ptr(rot_bias), L.ptr(sync),
                                            acts.data_ptr(), local_rot.data_ptr(), global_trans.data_ptr(), st),
                 "riggs_pose_mlp_forward")
-        transforms = torch.empty(J, 12, **f32)
-        node_rot = torch.empty(J, 4, **f32)
-        d_nodes = torch.empty(J, 3, **f32)
-        d_xyz = torch.empty(N, 3, **f32)
-        d_rot = torch.empty(N, 4, **f32)
         L.check(lib.riggs_lbs_forward_fk(N, J, K, x.data_ptr(), joints.data_ptr(), parents_i32.data_ptr(), rho.data_ptr(),
                                          local_rot.data_ptr(), global_trans.data_ptr(), L.ptr(mflat), L.ptr(weight_mod),
                                          transforms.data_ptr(), node_rot.data_ptr(), d_nodes.data_ptr(), d_xyz.data_ptr(),
@@ -364,10 +373,11 @@ class _PoseDeform(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         g_xyz = torch.zeros(N, 3, **f32) if g_xyz is None else g_xyz.contiguous()
         g_rot = torch.zeros(N, 4, **f32) if g_rot is None else g_rot.contiguous()
-        dG = torch.empty(J, 12, **f32)
+        bsmall = torch.empty(J * 16 + 12, **f32)  # (dG | dq | dgt | dgt_total: one allocation)
+        dG, dq = bsmall[:J * 12].view(J, 12), bsmall[J * 12:J * 16].view(J, 4)
+        dgt, dgt_total = bsmall[J * 16:J * 16 + 3], bsmall[J * 16 + 4:J * 16 + 7]
         from .dist import grad_out, grad_out_flat
         drho = grad_out(rho, (J,))
-        dgt = torch.empty(3, **f32)
         need_mask = mflat is not None and ctx.needs_input_grad[4]
         dmask = torch.empty(N, **f32) if need_mask else None
         dmod = torch.empty(N, J - 1, **f32) if weight_mod is not None else None
@@ -385,8 +395,6 @@ class _PoseDeform(torch.autograd.Function):
         gq = None if g_local_rot is None else g_local_rot.contiguous()
         flat = grad_out_flat(params)  # the flat gradient bucket's own range when one is registered
         dzs = torch.empty(lib.riggs_pose_mlp_backward_workspace_floats(depth, width, multires), **f32)
-        dq = torch.empty(J, 4, **f32)
-        dgt_total = torch.empty(3, **f32)
         Wp, bp = _PoseMLPFn._ptrs(params, depth)
         h = params[2 * depth:]
         L.check(lib.riggs_pose_mlp_backward_fk(depth, width, multires, skip, n_rot, Wp, bp, h[0].data_ptr(), h[1].data_ptr(),
@@ -394,11 +402,8 @@ class _PoseDeform(torch.autograd.Function):
                                                joints.data_ptr(), parents_i32.data_ptr(), transforms.data_ptr(), dG.data_ptr(), L.ptr(gn), L.ptr(gq),
                                                dgt.data_ptr(), dq.data_ptr(), dgt_total.data_ptr(), dzs.data_ptr(),
                                                flat.data_ptr(), L.ptr(ctx.sync), st), "riggs_pose_mlp_backward_fk")
-        grads, o = [], 0
-        for p in params:
-            n = p.numel()
-            grads.append(flat[o:o + n].view_as(p))
-            o += n
+        # (one split + a view per matrix: a slice and a view per parameter were 30 us of an eagerly issued frame)
+        grads = [g_ if p.dim() == 1 else g_.view(p.shape) for g_, p in zip(flat.split_with_sizes([p.numel() for p in params]), params)]
         gmask = dmask.reshape(ctx.mask_shape) if need_mask else None
         return (None, None, None, drho, gmask, None, None, None, None, dmod, None, None, None, None, *grads)
 
