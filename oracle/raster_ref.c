@@ -324,7 +324,11 @@ long rr_forward(int N, int deg, int M, int W, int H, const float *bg, const floa
   return R;
 }
 
-static inline void atomic_addf(float *p, float v) {
+/* The per-Gaussian sums over pixels are kept in DOUBLE: upstream adds them with float atomicAdd one pixel at a time, in
+ * whatever order the hardware serves — for a splat that covers 10^5 pixels under a cotangent of changing sign the float sum
+ * carries per-cent-level rounding (seen: 3-5 % on dL/dmean of a screen-filling near-camera Gaussian, tests/test_gpu_fuzz.py
+ * case 20), i.e. the reference itself has no single float answer there.  A checker should sit at the exact sum. */
+static inline void atomic_addd(double *p, double v) {
 #pragma omp atomic
   *p += v;
 }
@@ -347,6 +351,8 @@ void rr_backward(int N, int deg, int M, int W, int H, const float *bg, const flo
   size_t HW = (size_t)H * W;
   float *g_conic = (float *)calloc((size_t)N * 3 + 3, 4);  /* true dL/d(A,B,C) */
   float *g_depth = (float *)calloc((size_t)N + 1, 4);
+  /* double accumulators of the compositing backward: [conic 3 | depth 1 | mean2D 2 | colour 3 | opacity 1] per Gaussian */
+  double *acc = (double *)calloc((size_t)N * 10 + 10, 8);
   memset(dL_dmeans3D, 0, (size_t)N * 12); memset(dL_dmeans2D, 0, (size_t)N * 12);
   memset(dL_dcolors, 0, (size_t)N * 12); memset(dL_dopacity, 0, (size_t)N * 4);
   memset(dL_dscales, 0, (size_t)N * 12); memset(dL_drots, 0, (size_t)N * 16);
@@ -388,12 +394,12 @@ void rr_backward(int N, int deg, int M, int W, int H, const float *bg, const flo
           accum[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum[ch];
           last_color[ch] = cc;
           dL_dalpha += (cc - accum[ch]) * gC[ch];
-          atomic_addf(&dL_dcolors[3 * id + ch], w * gC[ch]);
+          atomic_addd(&acc[10 * (size_t)id + 6 + ch], (double)(w * gC[ch]));
         }
         float cd = depths[id];
         accum_d = last_alpha * last_d + (1.f - last_alpha) * accum_d; last_d = cd;
         dL_dalpha += (cd - accum_d) * gD;
-        atomic_addf(&g_depth[id], w * gD);
+        atomic_addd(&acc[10 * (size_t)id + 3], (double)(w * gD));
         accum_a = last_alpha * 1.0f + (1.f - last_alpha) * accum_a;
         dL_dalpha += (1.0f - accum_a) * gA;
         dL_dalpha *= Tr;
@@ -403,17 +409,26 @@ void rr_backward(int N, int deg, int M, int W, int H, const float *bg, const flo
         float gdx = G * dx, gdy = G * dy;
         float dG_ddelx = -gdx * co[0] - gdy * co[1];
         float dG_ddely = -gdy * co[2] - gdx * co[1];
-        atomic_addf(&dL_dmeans2D[3 * id], dL_dG * dG_ddelx * ddelx_dx);
-        atomic_addf(&dL_dmeans2D[3 * id + 1], dL_dG * dG_ddely * ddely_dy);
-        atomic_addf(&g_conic[3 * id], -0.5f * gdx * dx * dL_dG);
-        atomic_addf(&g_conic[3 * id + 1], -gdx * dy * dL_dG);
-        atomic_addf(&g_conic[3 * id + 2], -0.5f * gdy * dy * dL_dG);
-        atomic_addf(&dL_dopacity[id], G * dL_dalpha);
+        atomic_addd(&acc[10 * (size_t)id + 4], (double)(dL_dG * dG_ddelx * ddelx_dx));
+        atomic_addd(&acc[10 * (size_t)id + 5], (double)(dL_dG * dG_ddely * ddely_dy));
+        atomic_addd(&acc[10 * (size_t)id + 0], (double)(-0.5f * gdx * dx * dL_dG));
+        atomic_addd(&acc[10 * (size_t)id + 1], (double)(-gdx * dy * dL_dG));
+        atomic_addd(&acc[10 * (size_t)id + 2], (double)(-0.5f * gdy * dy * dL_dG));
+        atomic_addd(&acc[10 * (size_t)id + 9], (double)(G * dL_dalpha));
       }
       (void)e;
     }
   }
 
+  for (int i = 0; i < N; i++) {  /* the sums, rounded once */
+    const double *a = acc + 10 * (size_t)i;
+    g_conic[3 * i] = (float)a[0]; g_conic[3 * i + 1] = (float)a[1]; g_conic[3 * i + 2] = (float)a[2];
+    g_depth[i] = (float)a[3];
+    dL_dmeans2D[3 * i] = (float)a[4]; dL_dmeans2D[3 * i + 1] = (float)a[5];
+    dL_dcolors[3 * i] = (float)a[6]; dL_dcolors[3 * i + 1] = (float)a[7]; dL_dcolors[3 * i + 2] = (float)a[8];
+    dL_dopacity[i] = (float)a[9];
+  }
+  free(acc);
   /* per-Gaussian backward */
   const float *V = view, *P = proj;
   float fx = W / (2.0f * tanfovx), fy = H / (2.0f * tanfovy);
