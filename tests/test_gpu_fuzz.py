@@ -80,3 +80,72 @@ def test_random_configuration_matches_the_oracle(seed):
         RZ.set_ordered_backward(False)
         L.set_option("color_side_jobs", 1)
         L.set_option("bin_grouped", -1)
+
+
+# ------------------------------------------------------------------------------------------- the deformation
+def _deform_case(seed):
+    r = np.random.RandomState(7000 + seed)
+    J = int(r.choice([2, 3, 8, 15, 16, 24, 33, 63, 64]))
+    K = int(r.choice([-1, -1, 1, 2, 3, 4])) if J > 4 else -1
+    return dict(N=int(r.choice([1, 63, 64, 65, 255, 257, 1023, 1025, 5000, 30011])), J=J, K=min(K, J - 1), chain=bool(r.randint(2)),
+                mask=r.choice(["ones", "rand", "zeros-mixed"]), nonunit=bool(r.randint(2)))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_deformation_matches_the_oracle(seed):
+    """deform_by_pose (forward kinematics, bone-distance weights — all bones or top-K —, LBS of means and quaternions) forward
+    and backward against oracle/deform_ref.py (skeleton_warp.py:41-76,130-172) on random skeletons of 2..64 joints, chains and
+    trees, ragged Gaussian counts, motion masks with exact zeros, un-normalised local rotations."""
+    from oracle import deform_ref as O
+    from riggs_amd import synth
+    from riggs_amd.skeleton import SkeletonWarp
+    c = _deform_case(seed)
+    N, J, K = c["N"], c["J"], c["K"]
+    sc = synth.make_scene(N, J, 900 + seed, chain=c["chain"])
+    g = torch.Generator().manual_seed(seed)
+    gx, gr, gn = torch.randn(N, 3, generator=g), torch.randn(N, 4, generator=g), torch.randn(J, 3, generator=g)
+    mask = {"ones": torch.ones(N, 1), "rand": torch.rand(N, 1, generator=g),
+            "zeros-mixed": (torch.rand(N, 1, generator=g) > 0.4).float() * torch.rand(N, 1, generator=g)}[c["mask"]]
+    lr = sc["local_rotation"] * ((0.5 + torch.rand(J, 1, generator=g)) if c["nonunit"] else 1.0)
+    q = lr.clone().requires_grad_(True)
+    gt = sc["global_trans"].clone().requires_grad_(True)
+    rho = sc["node_radius"].clone().requires_grad_(True)
+    mo = mask.clone().requires_grad_(True)
+    o = O.deform_by_pose(sc["xyz"], sc["joints"], sc["parents"], rho, q, gt, mo, K)
+    ((o["d_xyz"] * gx).sum() + (o["d_rotation"] * gr).sum() + (o["d_nodes"] * gn).sum()).backward()
+    sw = SkeletonWarp(is_blender=True, joints=sc["joints"], parent_indices=sc["parents"], K=K, hyper_dim=8,
+                      use_skinning_weight_mlp=False, use_template_offsets=False).cuda()
+    sw._node_radius.data = sc["node_radius"].cuda()
+    qh, gth = lr.cuda().requires_grad_(True), sc["global_trans"].cuda().requires_grad_(True)
+    mh = mask.cuda().requires_grad_(True)
+    h = sw.deform_by_pose(sc["xyz"].cuda(), {"local_rotation": qh, "global_trans": gth}, mh)
+    ((h["d_xyz"] * gx.cuda()).sum() + (h["d_rotation"] * gr.cuda()).sum() + (h["d_nodes"] * gn.cuda()).sum()).backward()
+    tag = str(c)
+    U.assert_close(h["d_nodes"].detach().cpu().numpy(), o["d_nodes"].detach().numpy(), "d_nodes " + tag, 1e-5)
+    hx, ox = h["d_xyz"].detach().cpu().numpy(), o["d_xyz"].detach().numpy()
+    hr, orr = h["d_rotation"].detach().cpu().numpy(), o["d_rotation"].detach().numpy()
+    if K > 0:
+        # top-K: bones that share a joint are at EQUAL distance from every Gaussian whose nearest point on them is that joint, and
+        # torch.topk does not define which of equal values it returns (the reference itself depends on its torch build there):
+        # rows whose K-th and (K+1)-th distances are apart must select the same bones and agree in value; the others are free
+        d2_all = O.bone_dist2(sc["xyz"], sc["joints"], sc["parents"]).numpy()
+        srt = np.sort(d2_all, 1)
+        clear = np.ones(N, bool) if K >= J - 1 else (srt[:, K] - srt[:, K - 1]) > 1e-5 * np.maximum(srt[:, K], 1e-12)
+        idx, oidx = h["nn_idx"].cpu().numpy(), o["nn_idx"].numpy()
+        assert np.array_equal(np.sort(idx[clear], 1), np.sort(oidx[clear], 1)), "top-K selection differs on rows without ties " + tag
+        if clear.any():
+            U.assert_close(hx[clear], ox[clear], "d_xyz (untied rows) " + tag)
+            U.assert_close(hr[clear], orr[clear], "d_rotation (untied rows) " + tag)
+        if not clear.all():
+            return  # (gradients are only comparable when every row made the same choice)
+    else:
+        U.assert_close(hx, ox, "d_xyz " + tag)
+        U.assert_close(hr, orr, "d_rotation " + tag)
+    U.assert_close(qh.grad.cpu().numpy(), q.grad.numpy(), "dL/dlocal_rotation " + tag, 2e-4)
+    U.assert_close(gth.grad.cpu().numpy(), gt.grad.numpy(), "dL/dglobal_trans " + tag, 2e-4)
+    if J > 2:  # (one bone: its weight is 1 whatever its radius — the gradient is 0 and both sides return their own rounding noise)
+        U.assert_close(sw._node_radius.grad.cpu().numpy(), rho.grad.numpy(), "dL/d_node_radius " + tag, 2e-4)
+    else:
+        scale_ref = float(np.abs(q.grad.numpy()).max())
+        assert float(sw._node_radius.grad.abs().max()) <= 1e-4 * scale_ref and float(rho.grad.abs().max()) <= 1e-4 * scale_ref
+    U.assert_close(mh.grad.cpu().numpy(), mo.grad.numpy(), "dL/dmotion_mask " + tag, 2e-4)
