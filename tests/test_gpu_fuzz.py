@@ -149,3 +149,57 @@ def test_random_deformation_matches_the_oracle(seed):
         scale_ref = float(np.abs(q.grad.numpy()).max())
         assert float(sw._node_radius.grad.abs().max()) <= 1e-4 * scale_ref and float(rho.grad.abs().max()) <= 1e-4 * scale_ref
     U.assert_close(mh.grad.cpu().numpy(), mo.grad.numpy(), "dL/dmotion_mask " + tag, 2e-4)
+
+
+# ------------------------------------------------------------------------------------------- the captured frame
+@pytest.mark.parametrize("seed", range(8))
+def test_random_captured_frame_equals_the_eager_frame(seed):
+    """GraphedFrame (hipGraph of deform -> render -> backward) at random sizes, with sparse gradient rows / tight lists / the
+    colour job drawn per case, replayed over changing cameras and image gradients, against the same frames issued eagerly on a
+    copy of the models: images, radii, every parameter gradient; no arena overflow, and no arena allocation inside the capture."""
+    import copy
+
+    import bench
+    from riggs_amd import synth
+    from riggs_amd.graph import GraphedFrame
+    from riggs_amd.rasterizer import RasterArena
+    r = np.random.RandomState(300 + seed)
+    N, J = int(r.choice([300, 2049, 7001, 20000])), int(r.choice([4, 8, 24]))
+    H, W = int(r.randint(40, 260)), int(r.randint(40, 260))
+    sparse, tight, jobs = bool(r.randint(2)), bool(r.randint(2)), bool(r.randint(2))
+    old = dict(bench.WORKLOAD)
+    bench.WORKLOAD.update(N=N, J=J, H=H, W=W)
+    try:
+        sc, cam, gm, sw = bench.build_workload(0, "cuda:0")
+    finally:
+        bench.WORKLOAD.clear()
+        bench.WORKLOAD.update(old)
+    gm2, sw2 = copy.deepcopy(gm), copy.deepcopy(sw)
+    bg = torch.zeros(3, device="cuda")
+    try:
+        RZ.set_tight_lists(tight)
+        L.set_option("color_side_jobs", int(jobs))
+        gf = GraphedFrame(gm, sw, cam, bg, bench.params_of(gm, sw), sparse_grad_rows=sparse).capture()
+        where = gf.arena.binning.data_ptr()
+        arena2 = RasterArena()
+        g = torch.Generator().manual_seed(seed)
+        for k in range(4):
+            c = synth.look_at_camera(H, W, azimuth_deg=float(r.uniform(0, 360)), elevation_deg=float(r.uniform(-40, 60)),
+                                     radius=float(r.uniform(2.5, 4.5)), fid=float(r.uniform(0, 1))).to("cuda:0")
+            gimg = (torch.rand(3, H, W, generator=g) - 0.5).cuda() / (H * W)
+            a = gf.run(cam=c, gimg=gimg)
+            gf.check()
+            step = bench.make_step(c, gm2, sw2, gimg, arena2, 1, None)
+            for p in bench.params_of(gm2, sw2):
+                p.grad = None
+            b = step()
+            torch.cuda.synchronize()
+            assert torch.equal(a["radii"], b["radii"]), (seed, k)
+            torch.testing.assert_close(a["render"], b["render"].detach(), rtol=1e-4, atol=2e-6)
+            for ga, p2 in zip(gf.grads, bench.params_of(gm2, sw2)):
+                gb = p2.grad
+                torch.testing.assert_close(ga, gb, rtol=2e-4, atol=3e-6 * float(gb.abs().max()) + 1e-12)
+        assert gf.arena.binning.data_ptr() == where
+    finally:
+        RZ.set_tight_lists(False)
+        L.set_option("color_side_jobs", 1)
