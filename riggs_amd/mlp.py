@@ -206,17 +206,17 @@ class _FusedMLP(torch.autograd.Function):
         scale = grad_scale(g_out) if p.fp16 else None
         dpre, db = backward_data(p, g_out, masks, scale)
         xb = xb[:ctx.n]
-        # hidden-to-hidden layers share shapes: one batched split-K GEMM per run of consecutive layers (1 .. skip and
-        # skip + 2 .. depth - 1) instead of one per layer
+        # every layer's product with the previous layer's activations has the same shape — the skip layer's hidden block
+        # included — so layers 1 .. depth - 1 are ONE batched split-K GEMM (before round 4's trace the skip layer's block
+        # went alone, at 2.3 TB/s against the batch's 5.9); the two products with the embedding stay single calls (their
+        # gradient slabs are not adjacent: folding them into one batch would copy them)
         gws = [None] * p.depth
-        for lo, hi in ((1, p.skip + 1), (p.skip + 2, p.depth)):
-            if hi > lo:
-                g_run = _wgrad_multi(dpre[lo:hi], acts[lo - 1:hi - 1])
-                for l in range(lo, hi):
-                    gws[l] = g_run[l - lo]
-        gws[0] = _wgrad(dpre[0], xb)[:, :p.in_ch]
         ls = p.skip + 1
-        gws[ls] = torch.cat([_wgrad(dpre[ls], xb)[:, :p.in_ch], _wgrad(dpre[ls], acts[ls - 1])], 1)
+        g_run = _wgrad_multi(dpre[1:p.depth], acts[0:p.depth - 1])
+        for l in range(1, p.depth):
+            gws[l] = g_run[l - 1]
+        gws[0] = _wgrad(dpre[0], xb)[:, :p.in_ch]
+        gws[ls] = torch.cat([_wgrad(dpre[ls], xb)[:, :p.in_ch], gws[ls]], 1)
         grads = []
         for l in range(p.depth):
             grads += [gws[l], db[l]]
