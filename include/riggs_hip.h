@@ -39,6 +39,9 @@ const char* riggs_last_error(void);
  *                             kernel: the same colours and clamp bits, bit for bit; the geometry arena's colours are then
  *                             complete after riggs_raster_render, not after riggs_raster_preprocess.  0 = always in preprocess.
  *                             Like "bin_grouped", it must not change between the two calls of one frame
+ *   "preprocess_bwd_lean" -1  riggs_raster_backward's per-Gaussian kernel as one wave per 256 Gaussians (no LDS image, every block
+ *                             resident at once): -1 = with cfg.sparse_zero (sparse gradient rows: -3 .. -6 us of a frame; with
+ *                             every row written the 256-thread form is 18 us faster), 0 / 1 = never / always.  Same results
  * Unknown names fail.  Set them between frames, not while a launch that reads them is being issued from another thread. */
 int riggs_set_option(const char* name, int32_t value);
 int riggs_get_option(const char* name, int32_t* value);

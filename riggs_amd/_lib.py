@@ -170,7 +170,7 @@ def lib():
 
 def set_option(name: str, value: int):
     """riggs_set_option (include/riggs_hip.h): "fwd_wide_tiles", "fwd_wide_min", "bin_grouped", "cnode_bwd_atomics",
-    "color_side_jobs"."""
+    "color_side_jobs", "preprocess_bwd_lean"."""
     check(lib().riggs_set_option(name.encode(), int(value)), "riggs_set_option")
 
 

@@ -46,7 +46,7 @@ inline int debug_sync(int debug, hipStream_t s, const char* what) {
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 // ---- library options (riggs_set_option / riggs_get_option in the ABI; process-wide, nothing is read from the environment) ----
-enum OptId { OPT_FWD_WIDE_TILES = 0, OPT_FWD_WIDE_MIN, OPT_BIN_GROUPED, OPT_CNODE_BWD_ATOMICS, OPT_COLOR_SIDE_JOBS, OPT_COUNT };
+enum OptId { OPT_FWD_WIDE_TILES = 0, OPT_FWD_WIDE_MIN, OPT_BIN_GROUPED, OPT_CNODE_BWD_ATOMICS, OPT_COLOR_SIDE_JOBS, OPT_PREPROCESS_BWD_LEAN, OPT_COUNT };
 int option(int id);
 
 // ---- in-library kernel timing (HIP events on the launch stream; see riggs_prof_* in the ABI) ----

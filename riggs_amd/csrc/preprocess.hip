@@ -267,56 +267,10 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a) {
 }
 
 // ---------------------------------------------------------------------------- backward
-__global__ __launch_bounds__(256, 3) void preprocess_bwd_kernel(PreBwdArgs b) {
-  extern __shared__ float s_sh[];
-  __shared__ unsigned char s_list[256];
-  __shared__ int s_wcount[4];
-  const PreArgs& a = b.f;
-  const float* __restrict__ V = a.view;
-  const float* __restrict__ P = a.proj;
-  const bool sh_mode = (a.colors_precomp == nullptr);
-  const int sh_per = a.shs_rest ? (a.M - 1) * 3 : a.M * 3;
-  const int sh_first = blockIdx.x * 256, sh_count = min(256, a.N - sh_first);
-  // ---- which Gaussians of this block received any gradient from the compositing backward?  A Gaussian whose
-  // accumulator record is all zeros (invisible, behind saturated pixels, or never at alpha >= 1/255 in a tile it
-  // overlaps: 93 % of the bench scene) has an exactly zero gradient: its thread writes the zeros right away, and
-  // the others are COMPACTED onto the first threads of the block, so that the long arithmetic below runs on full
-  // lanes of few waves instead of a few lanes of every wave, and nothing is read for the rest.
-  const int t0 = threadIdx.x, lane0 = t0 & 63, wave0 = t0 >> 6;
-  const int i0 = blockIdx.x * 256 + t0;
-  bool touched0 = false;
-  // (a frame whose instance arena overflowed composited truncated lists: its gradients are undefined, so every
-  // Gaussian is treated as untouched and the optimizer sees zeros until the host notices the flag and re-renders)
-  const bool overflowed = b.counters != nullptr && b.counters[1] != 0u;
-  if (i0 < a.N && a.radii[i0] > 0) {
-    float4* acc4 = reinterpret_cast<float4*>(b.gacc + (size_t)i0 * RIGGS_GACC);
-    const float4 q0 = acc4[0], q1 = acc4[1], q2 = acc4[2];
-    touched0 = (q0.x != 0.f) || (q0.y != 0.f) || (q0.z != 0.f) || (q0.w != 0.f) || (q1.x != 0.f) || (q1.y != 0.f) ||
-               (q1.z != 0.f) || (q1.w != 0.f) || (q2.x != 0.f) || (q2.y != 0.f);
-    if (touched0 && overflowed) {  // nobody will consume (and clear) this record below
-      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-      acc4[0] = z; acc4[1] = z; acc4[2] = z;
-      touched0 = false;
-    }
-  }
-  const uint64_t tmask = __builtin_amdgcn_ballot_w64(touched0);
-  // cfg.sparse_zero: the gradient buffers still hold what the previous call with this workspace left — zeros outside the
-  // rows it listed (its bits are still in the workspace) — so only the rows of (previous | current) need a store: the
-  // zero fill of the other 86-93 % was two thirds of this kernel's HBM traffic
-  uint64_t pmask = ~0ull;
-  if (b.sparse_zero) pmask = (blockIdx.x * 256 + wave0 * 64 < a.N) ? b.touched_bits[blockIdx.x * 4 + wave0] : 0ull;
-  const bool was0 = (pmask >> lane0) & 1ull;
-  __shared__ unsigned long long s_need[4];
-  if (lane0 == 0) s_need[wave0] = tmask | pmask;
-  if (lane0 == 0) s_wcount[wave0] = __builtin_popcountll(tmask);
-  __syncthreads();
-  int tbase = 0;
-  for (int w = 0; w < wave0; w++) tbase += s_wcount[w];
-  const int n_work = s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
-  if (lane0 == 0 && blockIdx.x * 256 + wave0 * 64 < a.N) b.touched_bits[blockIdx.x * 4 + wave0] = tmask;
-  if (t0 == 0) b.block_touched[blockIdx.x] = (uint32_t)n_work;
-  if (touched0) s_list[tbase + __builtin_popcountll(tmask & ((1ull << lane0) - 1ull))] = (unsigned char)t0;
-  if (i0 < a.N && !touched0 && was0) {
+// One Gaussian's backward arithmetic (cov2D / Sigma3D / SH / projection + the glue's chain rule), shared by the two launch forms
+// of preprocess_bwd below.
+// the exact-zero gradient of a Gaussian whose accumulator record is all zeros: every per-Gaussian output except its dL/dsh row
+__device__ __forceinline__ void bwd_zero_row(const PreBwdArgs& b, const PreArgs& a, const int i0, const bool sh_mode) {
     b.dL_dmeans3D[3 * i0] = 0.f; b.dL_dmeans3D[3 * i0 + 1] = 0.f; b.dL_dmeans3D[3 * i0 + 2] = 0.f;
     b.dL_dmeans2D[3 * i0] = 0.f; b.dL_dmeans2D[3 * i0 + 1] = 0.f; b.dL_dmeans2D[3 * i0 + 2] = 0.f;
     if (b.dL_dcolors) { b.dL_dcolors[3 * i0] = 0.f; b.dL_dcolors[3 * i0 + 1] = 0.f; b.dL_dcolors[3 * i0 + 2] = 0.f; }
@@ -332,65 +286,17 @@ __global__ __launch_bounds__(256, 3) void preprocess_bwd_kernel(PreBwdArgs b) {
       for (int k = 0; k < 6; k++) b.dL_dcov3D[6 * i0 + k] = 0.f;
     }
     if (sh_mode && a.shs_rest) { b.dL_dsh[3 * i0] = 0.f; b.dL_dsh[3 * i0 + 1] = 0.f; b.dL_dsh[3 * i0 + 2] = 0.f; }
-  }
-  // the block's coefficients are staged through LDS when most of it has work, else the few read their own rows
-  const bool staged = sh_mode && sh_per > 0 && n_work > 64;
-  if (staged) {
-    const float* sh_src = (a.shs_rest ? a.shs_rest : a.shs) + (size_t)sh_first * sh_per;
-    // (odd record length + 16-byte aligned run: direct-to-LDS loads, as in the forward; else through registers)
-    if ((sh_per & 1) && sh_per <= 48 && ((reinterpret_cast<uintptr_t>(sh_src) & 15) == 0)) sh_stage_dma(sh_src, sh_count * sh_per, s_sh);
-    else sh_stage_in(sh_src, sh_per, sh_count, s_sh);
-  }
-  __syncthreads();  // s_list (and the staged coefficients)
-  const bool in_range = t0 < n_work;                       // from here on: "this thread has a Gaussian to work on"
-  const int slot = in_range ? (int)s_list[t0] : t0;        // its place in the block (LDS row of its coefficients)
-  const int i = blockIdx.x * 256 + slot;
-  const bool visible = in_range;
-  float Bk[16], gcs[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-  for (int k = 0; k < 16; k++) Bk[k] = 0.f;
-  const bool need_sr = (a.cov3D_precomp == nullptr);
-  float gm[3] = {0.f, 0.f, 0.f};
-  float g2x = 0.f, g2y = 0.f, g_op = 0.f;
-  float gcol[3] = {0.f, 0.f, 0.f};
-  float gs[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f}, gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  GlueIn g;
-  g.vnorm = 1.f;
-  // ---- every global load of this Gaussian up front, nothing used yet: left to itself the compiler sinks each load
-  // next to its use and the arithmetic below becomes a chain of ~45 exposed round trips (25 us for a wave that has
-  // the SIMD to itself, and few waves have work here)
-  RawIn raw;
-  float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
-  float c6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  uint8_t cl = 0;
-  float shv[48];  // coefficient k, channel c at [3 k + c] whatever the parameter layout
-#pragma unroll
-  for (int e = 0; e < 48; e++) shv[e] = 0.f;
-  if (visible) {
-    load_raw(a, i, raw, need_sr);
-    // the accumulators are SELF-CLEANING: whoever consumes a touched record puts the zeros back (7 % of the records in
-    // the bench scene), so the compositing backward of the next frame finds them cleared without a 14 MB fill per frame
-    float4* acc4 = reinterpret_cast<float4*>(b.gacc + (size_t)i * RIGGS_GACC);
-    q0 = acc4[0]; q1 = acc4[1]; q2 = acc4[2];
-    { const float4 z = make_float4(0.f, 0.f, 0.f, 0.f); acc4[0] = z; acc4[1] = z; acc4[2] = z; }
-#pragma unroll
-    for (int k = 0; k < 6; k++) c6[k] = a.cov3D[6 * i + k];
-    if (sh_mode) {
-      cl = a.clamped[i];
-      const float* mine = staged ? s_sh + slot * sh_lds_stride(sh_per)
-                                 : (a.shs_rest ? a.shs_rest : a.shs) + (size_t)i * sh_per;
-      if (a.shs_rest) {
-        shv[0] = a.shs[3 * i]; shv[1] = a.shs[3 * i + 1]; shv[2] = a.shs[3 * i + 2];
-#pragma unroll
-        for (int e = 0; e < 45; e++) if (e < sh_per) shv[3 + e] = mine[e];
-      } else {
-#pragma unroll
-        for (int e = 0; e < 48; e++) if (e < sh_per) shv[e] = mine[e];
-      }
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  if (visible) {
+}
+
+// (q0, q1, q2: the Gaussian's accumulator record of the compositing backward; c6: its Sigma3D; cl: clamp bits; shv: its coefficients)
+__device__ __forceinline__ void bwd_math(const PreArgs& a, const bool sh_mode, const bool need_sr, const RawIn& raw, const float4 q0,
+                                         const float4 q1, const float4 q2, const float (&c6)[6], const uint8_t cl,
+                                         const float (&shv)[48], GlueIn& g, float (&gm)[3], float& g2x, float& g2y, float& g_op,
+                                         float (&gcol)[3], float (&gs)[3], float (&gq)[4], float (&gcov)[6], float (&Bk)[16],
+                                         float (&gcs)[3]) {
+  const float* __restrict__ V = a.view;
+  const float* __restrict__ P = a.proj;
+  {
     finish_inputs(a, raw, g, need_sr);
     const float* p = g.p;
     g2x = q0.x; g2y = q0.y;
@@ -497,43 +403,11 @@ __global__ __launch_bounds__(256, 3) void preprocess_bwd_kernel(PreBwdArgs b) {
       gq[3] = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
     }
   }
-  // ---- dL/dsh: per-thread records -> LDS -> full-line stores (zeros for invisible Gaussians)
-  if (sh_mode) {
-    const int koff = a.shs_rest ? 3 : 0;
-    if (sh_per > 0) {
-      __syncthreads();  // every thread is done reading the staged coefficients
-      {  // zero rows for the Gaussians without work
-        float* row = s_sh + t0 * sh_lds_stride(sh_per);
-        for (int k = 0; k < sh_per; k++) row[k] = 0.f;
-      }
-      __syncthreads();
-      if (in_range) {
-        float* mine = s_sh + slot * sh_lds_stride(sh_per);
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-          if (k < a.M && 3 * k >= koff) {
-            mine[3 * k - koff] = Bk[k] * gcs[0]; mine[3 * k + 1 - koff] = Bk[k] * gcs[1]; mine[3 * k + 2 - koff] = Bk[k] * gcs[2];
-          }
-        }
-      }
-      __syncthreads();
-      float* dst = (a.shs_rest ? b.dL_dsh_rest : b.dL_dsh) + (size_t)sh_first * sh_per;
-      if (b.sparse_zero) {  // only the rows listed now or last time: a wave stores its own 64 Gaussians' rows, lane = float
-        uint64_t m = s_need[wave0];
-        const int stride = sh_lds_stride(sh_per);
-        while (m) {
-          const int row = wave0 * 64 + __builtin_ctzll(m);
-          m &= m - 1ull;
-          if (row < sh_count)
-            for (int c = lane0; c < sh_per; c += 64) dst[(size_t)row * sh_per + c] = s_sh[row * stride + c];
-        }
-      } else sh_stage_out(dst, sh_per, sh_count, s_sh);
-    }
-    if (a.shs_rest && in_range) {
-      b.dL_dsh[3 * i] = Bk[0] * gcs[0]; b.dL_dsh[3 * i + 1] = Bk[0] * gcs[1]; b.dL_dsh[3 * i + 2] = Bk[0] * gcs[2];
-    }
-  }
-  if (!in_range) return;
+}
+// every per-Gaussian output except the rows of dL/dsh (the callers stage those): with the chain rule of the render glue when fused
+__device__ __forceinline__ void bwd_outputs(const PreBwdArgs& b, const PreArgs& a, const int i, const bool sh_mode, const bool visible,
+                                            const GlueIn& g, const float (&gm)[3], const float g2x, const float g2y, const float g_op,
+                                            const float (&gcol)[3], const float (&gs)[3], const float (&gq)[4], const float (&gcov)[6]) {
   // ---- outputs (with the chain rule of the render glue when fused) ----
   b.dL_dmeans3D[3 * i] = gm[0]; b.dL_dmeans3D[3 * i + 1] = gm[1]; b.dL_dmeans3D[3 * i + 2] = gm[2];
   b.dL_dmeans2D[3 * i] = g2x; b.dL_dmeans2D[3 * i + 1] = g2y; b.dL_dmeans2D[3 * i + 2] = 0.f;
@@ -575,6 +449,294 @@ __global__ __launch_bounds__(256, 3) void preprocess_bwd_kernel(PreBwdArgs b) {
   }
 }
 
+__global__ __launch_bounds__(256, 3) void preprocess_bwd_kernel(PreBwdArgs b) {
+  extern __shared__ float s_sh[];
+  __shared__ unsigned char s_list[256];
+  __shared__ int s_wcount[4];
+  const PreArgs& a = b.f;
+  const bool sh_mode = (a.colors_precomp == nullptr);
+  const int sh_per = a.shs_rest ? (a.M - 1) * 3 : a.M * 3;
+  const int sh_first = blockIdx.x * 256, sh_count = min(256, a.N - sh_first);
+  // ---- which Gaussians of this block received any gradient from the compositing backward?  A Gaussian whose
+  // accumulator record is all zeros (invisible, behind saturated pixels, or never at alpha >= 1/255 in a tile it
+  // overlaps: 93 % of the bench scene) has an exactly zero gradient: its thread writes the zeros right away, and
+  // the others are COMPACTED onto the first threads of the block, so that the long arithmetic below runs on full
+  // lanes of few waves instead of a few lanes of every wave, and nothing is read for the rest.
+  const int t0 = threadIdx.x, lane0 = t0 & 63, wave0 = t0 >> 6;
+  const int i0 = blockIdx.x * 256 + t0;
+  bool touched0 = false;
+  // (a frame whose instance arena overflowed composited truncated lists: its gradients are undefined, so every
+  // Gaussian is treated as untouched and the optimizer sees zeros until the host notices the flag and re-renders)
+  const bool overflowed = b.counters != nullptr && b.counters[1] != 0u;
+  if (i0 < a.N && a.radii[i0] > 0) {
+    float4* acc4 = reinterpret_cast<float4*>(b.gacc + (size_t)i0 * RIGGS_GACC);
+    const float4 q0 = acc4[0], q1 = acc4[1], q2 = acc4[2];
+    touched0 = (q0.x != 0.f) || (q0.y != 0.f) || (q0.z != 0.f) || (q0.w != 0.f) || (q1.x != 0.f) || (q1.y != 0.f) ||
+               (q1.z != 0.f) || (q1.w != 0.f) || (q2.x != 0.f) || (q2.y != 0.f);
+    if (touched0 && overflowed) {  // nobody will consume (and clear) this record below
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      acc4[0] = z; acc4[1] = z; acc4[2] = z;
+      touched0 = false;
+    }
+  }
+  const uint64_t tmask = __builtin_amdgcn_ballot_w64(touched0);
+  // cfg.sparse_zero: the gradient buffers still hold what the previous call with this workspace left — zeros outside the
+  // rows it listed (its bits are still in the workspace) — so only the rows of (previous | current) need a store: the
+  // zero fill of the other 86-93 % was two thirds of this kernel's HBM traffic
+  uint64_t pmask = ~0ull;
+  if (b.sparse_zero) pmask = (blockIdx.x * 256 + wave0 * 64 < a.N) ? b.touched_bits[blockIdx.x * 4 + wave0] : 0ull;
+  const bool was0 = (pmask >> lane0) & 1ull;
+  __shared__ unsigned long long s_need[4];
+  if (lane0 == 0) s_need[wave0] = tmask | pmask;
+  if (lane0 == 0) s_wcount[wave0] = __builtin_popcountll(tmask);
+  __syncthreads();
+  int tbase = 0;
+  for (int w = 0; w < wave0; w++) tbase += s_wcount[w];
+  const int n_work = s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
+  if (lane0 == 0 && blockIdx.x * 256 + wave0 * 64 < a.N) b.touched_bits[blockIdx.x * 4 + wave0] = tmask;
+  if (t0 == 0) b.block_touched[blockIdx.x] = (uint32_t)n_work;
+  if (touched0) s_list[tbase + __builtin_popcountll(tmask & ((1ull << lane0) - 1ull))] = (unsigned char)t0;
+  if (i0 < a.N && !touched0 && was0) bwd_zero_row(b, a, i0, sh_mode);
+  // the block's coefficients are staged through LDS when most of it has work, else the few read their own rows
+  const bool staged = sh_mode && sh_per > 0 && n_work > 64;
+  if (staged) {
+    const float* sh_src = (a.shs_rest ? a.shs_rest : a.shs) + (size_t)sh_first * sh_per;
+    // (odd record length + 16-byte aligned run: direct-to-LDS loads, as in the forward; else through registers)
+    if ((sh_per & 1) && sh_per <= 48 && ((reinterpret_cast<uintptr_t>(sh_src) & 15) == 0)) sh_stage_dma(sh_src, sh_count * sh_per, s_sh);
+    else sh_stage_in(sh_src, sh_per, sh_count, s_sh);
+  }
+  __syncthreads();  // s_list (and the staged coefficients)
+  const bool in_range = t0 < n_work;                       // from here on: "this thread has a Gaussian to work on"
+  const int slot = in_range ? (int)s_list[t0] : t0;        // its place in the block (LDS row of its coefficients)
+  const int i = blockIdx.x * 256 + slot;
+  const bool visible = in_range;
+  float Bk[16], gcs[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 16; k++) Bk[k] = 0.f;
+  const bool need_sr = (a.cov3D_precomp == nullptr);
+  float gm[3] = {0.f, 0.f, 0.f};
+  float g2x = 0.f, g2y = 0.f, g_op = 0.f;
+  float gcol[3] = {0.f, 0.f, 0.f};
+  float gs[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f}, gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  GlueIn g;
+  g.vnorm = 1.f;
+  // ---- every global load of this Gaussian up front, nothing used yet: left to itself the compiler sinks each load
+  // next to its use and the arithmetic below becomes a chain of ~45 exposed round trips (25 us for a wave that has
+  // the SIMD to itself, and few waves have work here)
+  RawIn raw;
+  float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
+  float c6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  uint8_t cl = 0;
+  float shv[48];  // coefficient k, channel c at [3 k + c] whatever the parameter layout
+#pragma unroll
+  for (int e = 0; e < 48; e++) shv[e] = 0.f;
+  if (visible) {
+    load_raw(a, i, raw, need_sr);
+    // the accumulators are SELF-CLEANING: whoever consumes a touched record puts the zeros back (7 % of the records in
+    // the bench scene), so the compositing backward of the next frame finds them cleared without a 14 MB fill per frame
+    float4* acc4 = reinterpret_cast<float4*>(b.gacc + (size_t)i * RIGGS_GACC);
+    q0 = acc4[0]; q1 = acc4[1]; q2 = acc4[2];
+    { const float4 z = make_float4(0.f, 0.f, 0.f, 0.f); acc4[0] = z; acc4[1] = z; acc4[2] = z; }
+#pragma unroll
+    for (int k = 0; k < 6; k++) c6[k] = a.cov3D[6 * i + k];
+    if (sh_mode) {
+      cl = a.clamped[i];
+      const float* mine = staged ? s_sh + slot * sh_lds_stride(sh_per)
+                                 : (a.shs_rest ? a.shs_rest : a.shs) + (size_t)i * sh_per;
+      if (a.shs_rest) {
+        shv[0] = a.shs[3 * i]; shv[1] = a.shs[3 * i + 1]; shv[2] = a.shs[3 * i + 2];
+#pragma unroll
+        for (int e = 0; e < 45; e++) if (e < sh_per) shv[3 + e] = mine[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 48; e++) if (e < sh_per) shv[e] = mine[e];
+      }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if (visible) bwd_math(a, sh_mode, need_sr, raw, q0, q1, q2, c6, cl, shv, g, gm, g2x, g2y, g_op, gcol, gs, gq, gcov, Bk, gcs);
+  // ---- dL/dsh: per-thread records -> LDS -> full-line stores (zeros for invisible Gaussians)
+  if (sh_mode) {
+    const int koff = a.shs_rest ? 3 : 0;
+    if (sh_per > 0) {
+      __syncthreads();  // every thread is done reading the staged coefficients
+      {  // zero rows for the Gaussians without work
+        float* row = s_sh + t0 * sh_lds_stride(sh_per);
+        for (int k = 0; k < sh_per; k++) row[k] = 0.f;
+      }
+      __syncthreads();
+      if (in_range) {
+        float* mine = s_sh + slot * sh_lds_stride(sh_per);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          if (k < a.M && 3 * k >= koff) {
+            mine[3 * k - koff] = Bk[k] * gcs[0]; mine[3 * k + 1 - koff] = Bk[k] * gcs[1]; mine[3 * k + 2 - koff] = Bk[k] * gcs[2];
+          }
+        }
+      }
+      __syncthreads();
+      float* dst = (a.shs_rest ? b.dL_dsh_rest : b.dL_dsh) + (size_t)sh_first * sh_per;
+      if (b.sparse_zero) {  // only the rows listed now or last time: a wave stores its own 64 Gaussians' rows, lane = float
+        uint64_t m = s_need[wave0];
+        const int stride = sh_lds_stride(sh_per);
+        while (m) {
+          const int row = wave0 * 64 + __builtin_ctzll(m);
+          m &= m - 1ull;
+          if (row < sh_count)
+            for (int c = lane0; c < sh_per; c += 64) dst[(size_t)row * sh_per + c] = s_sh[row * stride + c];
+        }
+      } else sh_stage_out(dst, sh_per, sh_count, s_sh);
+    }
+    if (a.shs_rest && in_range) {
+      b.dL_dsh[3 * i] = Bk[0] * gcs[0]; b.dL_dsh[3 * i + 1] = Bk[0] * gcs[1]; b.dL_dsh[3 * i + 2] = Bk[0] * gcs[2];
+    }
+  }
+  if (!in_range) return;
+  bwd_outputs(b, a, i, sh_mode, visible, g, gm, g2x, g2y, g_op, gcol, gs, gq, gcov);
+}
+
+// The same backward as ONE WAVE per 256 Gaussians — for frames whose gradient rows are sparse (cfg.sparse_zero: a captured frame
+// whose owner keeps the rows' history; 7 - 12 % of the bench scene's Gaussians receive a gradient).  The kernel above keeps 46 KB
+// of LDS (the block's dL/dsh rows) and 157 registers: three workgroups per CU, 1.5 rounds of workgroups at 300 k Gaussians, and in
+// each of them the long arithmetic runs on ONE wave with a third of its lanes while the other three wait at its barriers — the
+// kernel trace reads 9.4 us for the screening alone and 26 us with the arithmetic.  Here a workgroup IS that one wave: it screens
+// its 256 Gaussians four to a lane (all records in flight together), works through the listed ones 64 at a time, and stages only
+// those rows (12 KB); twelve workgroups fit a CU: every block of the frame is resident at once.
+__global__ __launch_bounds__(64) void preprocess_bwd_lean_kernel(PreBwdArgs b) {
+  __shared__ unsigned char s_list[256];
+  const PreArgs& a = b.f;
+  const bool sh_mode = (a.colors_precomp == nullptr);
+  const int sh_per = a.shs_rest ? (a.M - 1) * 3 : a.M * 3;
+  const bool need_sr = (a.cov3D_precomp == nullptr);
+  const int lane = threadIdx.x;
+  const int first = blockIdx.x * 256, count = min(256, a.N - first);
+  const bool overflowed = b.counters != nullptr && b.counters[1] != 0u;
+  // ---- screening: which of the block's Gaussians received a gradient (see the kernel above)
+  // (one round trip for everything the screening reads: the four records of the lane, their radii — a culled Gaussian's record is
+  // zero, the radius only spares the compare — and the previous call's bits)
+  float4 rq[4][3];
+  uint64_t prev[4];
+#pragma unroll
+  for (int sub = 0; sub < 4; sub++) {
+    const int i0 = first + sub * 64 + lane;
+    rq[sub][0] = rq[sub][1] = rq[sub][2] = make_float4(0.f, 0.f, 0.f, 0.f);
+    prev[sub] = ~0ull;
+    if (b.sparse_zero) prev[sub] = (sub * 64 < count) ? b.touched_bits[blockIdx.x * 4 + sub] : 0ull;
+    if (i0 < a.N) {
+      const float4* acc4 = reinterpret_cast<const float4*>(b.gacc + (size_t)i0 * RIGGS_GACC);
+      rq[sub][0] = acc4[0]; rq[sub][1] = acc4[1]; rq[sub][2] = acc4[2];
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  uint64_t tmask[4], need[4];
+  int n_work = 0;
+#pragma unroll
+  for (int sub = 0; sub < 4; sub++) {
+    const int i0 = first + sub * 64 + lane;
+    const float4 q0 = rq[sub][0], q1 = rq[sub][1], q2 = rq[sub][2];
+    bool touched = (q0.x != 0.f) || (q0.y != 0.f) || (q0.z != 0.f) || (q0.w != 0.f) || (q1.x != 0.f) || (q1.y != 0.f) ||
+                   (q1.z != 0.f) || (q1.w != 0.f) || (q2.x != 0.f) || (q2.y != 0.f);
+    if (touched && overflowed) {  // (an overflowed frame back-propagates exact zeros; nobody will consume this record)
+      float4* acc4 = reinterpret_cast<float4*>(b.gacc + (size_t)i0 * RIGGS_GACC);
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      acc4[0] = z; acc4[1] = z; acc4[2] = z;
+      touched = false;
+    }
+    const uint64_t tm = __builtin_amdgcn_ballot_w64(touched);
+    const uint64_t pm = prev[sub];
+    tmask[sub] = tm;
+    need[sub] = tm | pm;
+    if (touched) s_list[n_work + __builtin_popcountll(tm & ((1ull << lane) - 1ull))] = (unsigned char)(sub * 64 + lane);
+    n_work += __builtin_popcountll(tm);
+    if (lane == 0 && sub * 64 < count) b.touched_bits[blockIdx.x * 4 + sub] = tm;
+    if (i0 < a.N && !touched && ((pm >> lane) & 1ull)) bwd_zero_row(b, a, i0, sh_mode);
+  }
+  if (lane == 0) b.block_touched[blockIdx.x] = (uint32_t)n_work;
+  __syncthreads();  // s_list
+  float* const dst_rest = sh_mode && sh_per > 0 ? (a.shs_rest ? b.dL_dsh_rest : b.dL_dsh) + (size_t)first * sh_per : nullptr;
+  const int koff = a.shs_rest ? 3 : 0;
+  // ---- the listed Gaussians, 64 at a time
+  for (int base = 0; base < n_work; base += 64) {
+    const int tq = base + lane;
+    const bool in_range = tq < n_work;
+    const int slot = in_range ? (int)s_list[tq] : 0;
+    const int i = first + slot;
+    float Bk[16], gcs[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 16; k++) Bk[k] = 0.f;
+    float gm[3] = {0.f, 0.f, 0.f};
+    float g2x = 0.f, g2y = 0.f, g_op = 0.f;
+    float gcol[3] = {0.f, 0.f, 0.f};
+    float gs[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f}, gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    GlueIn g;
+    g.vnorm = 1.f;
+    RawIn raw;
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
+    float c6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    uint8_t cl = 0;
+    float shv[48];
+#pragma unroll
+    for (int e = 0; e < 48; e++) shv[e] = 0.f;
+    if (in_range) {  // every global load of the Gaussian up front (see the kernel above)
+      load_raw(a, i, raw, need_sr);
+      float4* acc4 = reinterpret_cast<float4*>(b.gacc + (size_t)i * RIGGS_GACC);
+      q0 = acc4[0]; q1 = acc4[1]; q2 = acc4[2];
+      { const float4 z = make_float4(0.f, 0.f, 0.f, 0.f); acc4[0] = z; acc4[1] = z; acc4[2] = z; }  // (self-cleaning accumulators)
+#pragma unroll
+      for (int k = 0; k < 6; k++) c6[k] = a.cov3D[6 * i + k];
+      if (sh_mode) {
+        cl = a.clamped[i];
+        // (its own coefficient row, 45 loads of 64 different lines each: staging the batch's rows through LDS with a row per
+        // direct-to-LDS load instruction measured the same, 22.7 against 22.9 us, and cost two barriers)
+        const float* mine = (a.shs_rest ? a.shs_rest : a.shs) + (size_t)i * sh_per;
+        if (a.shs_rest) {
+          shv[0] = a.shs[3 * i]; shv[1] = a.shs[3 * i + 1]; shv[2] = a.shs[3 * i + 2];
+#pragma unroll
+          for (int e = 0; e < 45; e++) if (e < sh_per) shv[3 + e] = mine[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 48; e++) if (e < sh_per) shv[e] = mine[e];
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_range) bwd_math(a, sh_mode, need_sr, raw, q0, q1, q2, c6, cl, shv, g, gm, g2x, g2y, g_op, gcol, gs, gq, gcov, Bk, gcs);
+    if (sh_mode) {
+      if (sh_per > 0) {
+        // dL/dsh rows of the batch: every listed lane stores its own row (45 stores nobody waits for; through LDS and a row per
+        // store instruction the wave stood at two barriers and 2 x 20 LDS round trips: 6.5 us of a 22.7 us kernel)
+        if (in_range) {
+          float* mine = dst_rest + (size_t)slot * sh_per;
+#pragma unroll
+          for (int k = 0; k < 16; k++) {
+            if (k < a.M && 3 * k >= koff) {
+              mine[3 * k - koff] = Bk[k] * gcs[0]; mine[3 * k + 1 - koff] = Bk[k] * gcs[1]; mine[3 * k + 2 - koff] = Bk[k] * gcs[2];
+            }
+          }
+        }
+      }
+      if (a.shs_rest && in_range) {
+        b.dL_dsh[3 * i] = Bk[0] * gcs[0]; b.dL_dsh[3 * i + 1] = Bk[0] * gcs[1]; b.dL_dsh[3 * i + 2] = Bk[0] * gcs[2];
+      }
+    }
+    if (in_range) bwd_outputs(b, a, i, sh_mode, true, g, gm, g2x, g2y, g_op, gcol, gs, gq, gcov);
+  }
+  // ---- zero rows of dL/dsh for the Gaussians that need a store and have no gradient (listed by the previous call, or — without
+  // cfg.sparse_zero — every other one)
+  if (dst_rest) {
+#pragma unroll
+    for (int sub = 0; sub < 4; sub++) {
+      uint64_t m = need[sub] & ~tmask[sub];
+      while (m) {
+        const int row = sub * 64 + __builtin_ctzll(m);
+        m &= m - 1ull;
+        if (row < count)
+          for (int c = lane; c < sh_per; c += 64) dst_rest[(size_t)row * sh_per + c] = 0.f;
+      }
+    }
+  }
+}
+
 // host-side launchers (called from capi.hip)
 int launch_preprocess_fwd(const PreArgs& a, hipStream_t s) {
   if (a.N == 0) return 0;
@@ -586,6 +748,10 @@ int launch_preprocess_fwd(const PreArgs& a, hipStream_t s) {
 int launch_preprocess_bwd(const PreBwdArgs& b, hipStream_t s) {
   if (b.f.N == 0) return 0;
   const int per = b.f.shs_rest ? (b.f.M - 1) * 3 : b.f.M * 3;
+  if (option(OPT_PREPROCESS_BWD_LEAN) == 1 || (option(OPT_PREPROCESS_BWD_LEAN) < 0 && b.sparse_zero)) {
+    hipLaunchKernelGGL(preprocess_bwd_lean_kernel, dim3((b.f.N + 255) / 256), dim3(64), 0, s, b);
+    return 0;
+  }
   const size_t lds = b.f.colors_precomp ? 0 : (size_t)256 * (per | 1) * sizeof(float);
   hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((b.f.N + 255) / 256), dim3(256), lds, s, b);
   return 0;

@@ -1,7 +1,7 @@
 """Seeded random sweep of the rasterizer against the CPU oracle with the mode switches crossed: sizes from one Gaussian to
 tens of thousands, ragged images from a single tile to hundreds, splat scales from sub-pixel to tile-filling, every SH degree,
-cameras near and far, and — per case — tight / canonical lists, the colour job on / off, the direct / two-level tile sort and
-the ordered backward.  What the fixed cases of test_gpu_raster.py pin one at a time, here in combinations nobody chose."""
+cameras near and far, and — per case — tight / canonical lists, the colour job on / off, the direct / two-level tile sort, the
+ordered backward and either launch form of preprocess_bwd.  What the fixed cases of test_gpu_raster.py pin one at a time, here in combinations nobody chose."""
 import os
 import sys
 
@@ -27,7 +27,7 @@ def _case(seed):
     return dict(N=N, J=int(r.choice([2, 8, 24])), H=H, W=W, scale=scale, deg=int(r.randint(0, 4)),
                 radius=float(r.uniform(1.5, 5.0)), azimuth=float(r.uniform(0, 360)),
                 tight=bool(r.randint(2)), jobs=bool(r.randint(2)), grouped=int(r.choice([-1, 0, 1])), ordered=bool(r.rand() < 0.25),
-                bg=[float(x) for x in r.rand(3)], opacity_scale=float(r.choice([1.0, 1.0, 0.3, 0.05])))
+                bg=[float(x) for x in r.rand(3)], opacity_scale=float(r.choice([1.0, 1.0, 0.3, 0.05])), lean=int(r.choice([0, 1])))
 
 
 @pytest.mark.parametrize("seed", range(40))
@@ -44,6 +44,7 @@ def test_random_configuration_matches_the_oracle(seed):
         RZ.set_ordered_backward(c["ordered"])
         L.set_option("color_side_jobs", int(c["jobs"]))
         L.set_option("bin_grouped", int(c["grouped"]))
+        L.set_option("preprocess_bwd_lean", c["lean"])
         color, radii, depth, alpha, s = U.hip_forward(act, cam, c["bg"], sh_degree=c["deg"])
         v = saved_views(s)
         assert np.array_equal(radii.cpu().numpy(), so.radii), c
@@ -80,6 +81,7 @@ def test_random_configuration_matches_the_oracle(seed):
         RZ.set_ordered_backward(False)
         L.set_option("color_side_jobs", 1)
         L.set_option("bin_grouped", -1)
+        L.set_option("preprocess_bwd_lean", -1)
 
 
 # ------------------------------------------------------------------------------------------- the deformation
@@ -167,6 +169,7 @@ def test_random_captured_frame_equals_the_eager_frame(seed):
     N, J = int(r.choice([300, 2049, 7001, 20000])), int(r.choice([4, 8, 24]))
     H, W = int(r.randint(40, 260)), int(r.randint(40, 260))
     sparse, tight, jobs = bool(r.randint(2)), bool(r.randint(2)), bool(r.randint(2))
+    lean = int(r.choice([-1, 0, 1]))
     old = dict(bench.WORKLOAD)
     bench.WORKLOAD.update(N=N, J=J, H=H, W=W)
     try:
@@ -179,6 +182,7 @@ def test_random_captured_frame_equals_the_eager_frame(seed):
     try:
         RZ.set_tight_lists(tight)
         L.set_option("color_side_jobs", int(jobs))
+        L.set_option("preprocess_bwd_lean", lean)
         gf = GraphedFrame(gm, sw, cam, bg, bench.params_of(gm, sw), sparse_grad_rows=sparse).capture()
         where = gf.arena.binning.data_ptr()
         arena2 = RasterArena()
@@ -203,3 +207,4 @@ def test_random_captured_frame_equals_the_eager_frame(seed):
     finally:
         RZ.set_tight_lists(False)
         L.set_option("color_side_jobs", 1)
+        L.set_option("preprocess_bwd_lean", -1)
