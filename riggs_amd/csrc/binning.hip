@@ -294,22 +294,36 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(int N, int T, int gri
     __shared__ uint32_t s_run;
     if (tid == 0) s_run = 0u;
     __syncthreads();
-    for (int base = 0; base < T; base += blockDim.x) {
-      const int t = base + tid;
-      const uint32_t c = (t < T) ? tile_count[t] : 0u;
-      uint32_t v = c;
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t u = (uint32_t)__shfl_up((int)v, o);
-        if (lane >= o) v += u;
+    // (the counts and the chunk's row for FOUR rounds of the scan are asked for at once: taken a round at a time — a load, the
+    // scan, a barrier, the second load — the workgroup stood through eight dependent round trips at 2 500 tiles)
+    for (int base0 = 0; base0 < T; base0 += 4 * blockDim.x) {
+      uint32_t cq[4], rq[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int t = base0 + k * (int)blockDim.x + tid;
+        cq[k] = (t < T) ? tile_count[t] : 0u;
+        rq[k] = (t < T) ? row[t] : 0u;
       }
-      if (lane == 63) s_wsum[wave] = v;
-      __syncthreads();
-      uint32_t off = s_run;
-      for (int w = 0; w < wave; w++) off += s_wsum[w];
-      if (t < T) s_base[t] = off + v - c + row[t];
-      __syncthreads();
-      if (tid == (int)blockDim.x - 1) s_run = off + v;
-      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int base = base0 + k * (int)blockDim.x;
+        if (base >= T) break;
+        const int t = base + tid;
+        const uint32_t c = cq[k];
+        uint32_t v = c;
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t u = (uint32_t)__shfl_up((int)v, o);
+          if (lane >= o) v += u;
+        }
+        if (lane == 63) s_wsum[wave] = v;
+        __syncthreads();
+        uint32_t off = s_run;
+        for (int w = 0; w < wave; w++) off += s_wsum[w];
+        if (t < T) s_base[t] = off + v - c + rq[k];
+        __syncthreads();
+        if (tid == (int)blockDim.x - 1) s_run = off + v;
+        __syncthreads();
+      }
     }
   }
   for (int t = tid; t < T; t += blockDim.x) {
