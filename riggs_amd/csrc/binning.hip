@@ -1109,6 +1109,15 @@ __global__ __launch_bounds__(CHUNK / 8) void rs_count_kernel(int N, int pass, Rs
   constexpr int NT = CHUNK / 8, NW = NT / 64;  // (eight elements per thread)
   __shared__ uint32_t s_hist[RS_BINS];
   __shared__ uint32_t s_w[NW], s_lo[NW], s_hi[NW];
+  // (pass 0: this thread's keys are asked for before the reduction below, not behind its round trip and barrier; the later passes
+  // read their source list where the flag they route by is known)
+  const int first = blockIdx.x * CHUNK;
+  uint32_t k0[CHUNK / NT];
+#pragma unroll
+  for (int k = 0; k < CHUNK / NT; k++) {
+    const int i = first + k * NT + threadIdx.x;
+    k0[k] = (pass == 0 && i < N) ? bufs.k_in[i] : 0u;
+  }
   bool three;
   if (pass == 0) {
     // part[0 .. n_part): tile counts; part[n_part .. 2 n_part): (min top byte << 8) | max top byte of the visible keys
@@ -1141,11 +1150,10 @@ __global__ __launch_bounds__(CHUNK / 8) void rs_count_kernel(int N, int pass, Rs
   const int shift = pass * RS_BITS;
   for (int b = threadIdx.x; b < RS_BINS; b += NT) s_hist[b] = 0u;
   __syncthreads();
-  const int first = blockIdx.x * CHUNK;
 #pragma unroll
   for (int k = 0; k < CHUNK / NT; k++) {
     const int i = first + k * NT + threadIdx.x;
-    if (i < N) atomicAdd(&s_hist[((src ? src[i].x : bufs.k_in[i]) >> shift) & (RS_BINS - 1)], 1u);
+    if (i < N) atomicAdd(&s_hist[((src ? src[i].x : k0[k]) >> shift) & (RS_BINS - 1)], 1u);
   }
   __syncthreads();
   uint32_t* row = table + (size_t)blockIdx.x * RS_BINS;
