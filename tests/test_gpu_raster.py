@@ -103,6 +103,25 @@ def test_colors_precomp_and_cov3d_precomp():
     _grads_close(gh[0], go["means3D"], "dL/dmeans3D")
 
 
+@pytest.mark.parametrize("which", ["precomp", "deg0", "deg1", "deg2", "case3", "case5"])
+def test_one_wave_per_block_backward_on_the_optional_inputs(which):
+    """riggs_set_option("preprocess_bwd_lean", 1): the one-wave-per-block form of the per-Gaussian backward (the default only
+    with sparse gradient rows) forced onto the paths the random sweep does not draw — precomputed colours and covariances, the
+    lower SH degrees with their shorter rows, a camera inside the cloud, the deep-occlusion scene whose blocks list nothing —
+    through the very assertions of the tests above."""
+    from riggs_amd import _lib as L
+    try:
+        L.set_option("preprocess_bwd_lean", 1)
+        if which == "precomp":
+            test_colors_precomp_and_cov3d_precomp()
+        elif which.startswith("deg"):
+            test_lower_sh_degrees(int(which[3:]))
+        else:
+            test_forward_backward_parity_vs_oracle(*CASES[int(which[4:])])
+    finally:
+        L.set_option("preprocess_bwd_lean", -1)
+
+
 def test_scale_modifier():
     sc, act, cam = U.activated_scene(2000, 8, 5, 64, 64, scale=0.03)
     out_o, so = U.oracle_forward(act, cam, [0, 0, 0], mod=0.5)
