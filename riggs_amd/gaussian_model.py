@@ -1,33 +1,131 @@
-"""Parameter store with the attribute names / layouts / getters of the reference's
-``GaussianModel`` (/root/reference/scene/gaussian_model.py:37-132, :177-195) — only what the
-hot path reads, plus the optimizer set-up / step statistics of §8-f rank 1 (``training_setup``,
-``update_learning_rate``, ``add_densification_stats``).  Densification surgery and PLY I/O are later §8-f items."""
+"""Parameter store with the class surface of the reference's ``GaussianModel`` / ``StandardGaussianModel``
+(/root/reference/scene/gaussian_model.py:37-546): attribute names and layouts, getters, ``create_from_pcd`` (the one
+caller of ``distCUDA2``), ``training_setup`` and the learning-rate hooks, ``get_covariance``, PLY I/O, and the
+densification surgery — the row work of which runs on the device (csrc/densify.hip) and the optimizer step in one HIP
+launch (``riggs_amd.optim.FusedAdam``).  ``SkeletonWarp.as_gaussians`` builds its J-point model from this class when the
+trainer's own ``scene.gaussian_model`` is not importable."""
 from __future__ import annotations
 
 import math
+from typing import NamedTuple
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 
+class BasicPointCloud(NamedTuple):  # utils/graphics_utils.py:17-20
+    points: object
+    colors: object
+    normals: object
+
+
+_SH_C0 = 0.28209479177387814
+
+
+def RGB2SH(rgb):  # utils/sh_utils.py:115-116
+    return (rgb - 0.5) / _SH_C0
+
+
+def inverse_sigmoid(x):  # utils/general_utils.py:24-25
+    return torch.log(x / (1 - x))
+
+
+def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
+    """Log-linear interpolation lr_init -> lr_final over ``max_steps`` with the optional sine warm-up of the first
+    ``lr_delay_steps`` (utils/general_utils.py:49-82); negative steps or two zero rates switch the group off."""
+    def rate(step):
+        if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+            return 0.0
+        warm = 1.0
+        if lr_delay_steps > 0:
+            warm = lr_delay_mult + (1 - lr_delay_mult) * math.sin(0.5 * math.pi * min(max(step / lr_delay_steps, 0.0), 1.0))
+        t = min(max(step / max_steps, 0.0), 1.0)
+        return warm * math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
+    return rate
+
+
+def quaternion_multiply(a, b):  # Hamilton product, (w, x, y, z): scene/gaussian_model.py:25-34
+    aw, ax, ay, az = a.unbind(-1)
+    bw, bx, by, bz = b.unbind(-1)
+    return torch.stack((aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                        aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw), -1)
+
+
+def build_rotation(r):
+    """(N, 4) quaternions (w, x, y, z), normalised here, -> (N, 3, 3) (utils/general_utils.py:137-160)."""
+    q = r / r.norm(dim=1, keepdim=True)
+    w, x, y, z = q.unbind(-1)
+    return torch.stack((1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                        2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                        2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)), -1).reshape(-1, 3, 3)
+
+
+def build_scaling_rotation(s, r):  # R diag(s): utils/general_utils.py:163-172
+    return build_rotation(r) * s[:, None, :]
+
+
+def strip_symmetric(m):  # upper triangle xx xy xz yy yz zz: utils/general_utils.py:121-134
+    return torch.stack((m[:, 0, 0], m[:, 0, 1], m[:, 0, 2], m[:, 1, 1], m[:, 1, 2], m[:, 2, 2]), -1)
+
+
+def farthest_point_sample(xyz, npoint):
+    """(B, N, C) -> (B, npoint) indices of an iterative farthest-point sweep from a random start
+    (utils/time_utils.py:461-482)."""
+    B, N, _ = xyz.shape
+    dev = xyz.device
+    picked = torch.zeros(B, npoint, dtype=torch.long, device=dev)
+    nearest = torch.full((B, N), 1e10, device=dev)
+    cur = torch.randint(0, N, (B,), dtype=torch.long, device=dev)
+    rows = torch.arange(B, device=dev)
+    for i in range(npoint):
+        picked[:, i] = cur
+        d = ((xyz - xyz[rows, cur][:, None]) ** 2).sum(-1)
+        nearest = torch.minimum(nearest, d)
+        cur = nearest.argmax(-1)
+    return picked
+
+
 class GaussianModel:
-    def __init__(self, sh_degree: int = 3, fea_dim: int = 0, with_motion_mask: bool = False,
-                 use_isotropic_gs: bool = False):
+    def __init__(self, sh_degree: int, fea_dim=0, with_motion_mask=True, use_isotropic_gs=False, **kwargs):
         self.active_sh_degree = 0
         self.max_sh_degree = sh_degree
-        self.fea_dim = fea_dim + (1 if with_motion_mask else 0)
         self.with_motion_mask = with_motion_mask
+        self.fea_dim = fea_dim + (1 if with_motion_mask else 0)  # the mask is the last feature column (:57-61)
         self.use_isotropic_gs = use_isotropic_gs
         e = torch.empty(0)
         self._xyz = self._features_dc = self._features_rest = self._scaling = self._rotation = self._opacity = e
         self.feature = e
         self.max_radii2D = e
+        self.xyz_gradient_accum = e
+        self.optimizer = None
+        self.scaling_activation, self.scaling_inverse_activation = torch.exp, torch.log
+        self.opacity_activation, self.inverse_opacity_activation = torch.sigmoid, inverse_sigmoid
+        self.rotation_activation = F.normalize
+        self.covariance_activation = self._covariance_from_scaling_rotation
+
+    @staticmethod
+    def _covariance_from_scaling_rotation(scaling, scaling_modifier, rotation):  # :40-44
+        M = build_scaling_rotation(scaling_modifier * scaling, rotation)
+        return strip_symmetric(M @ M.transpose(1, 2))
+
+    def param_names(self):  # :81-82
+        return ["_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity", "max_radii2D", "xyz_gradient_accum"]
+
+    @classmethod
+    def build_from(cls, gs, **kwargs):  # :84-95 (shares the geometry, zeroes the colours)
+        new = GaussianModel(**kwargs)
+        new._xyz, new._scaling, new._rotation = nn.Parameter(gs._xyz), nn.Parameter(gs._scaling), nn.Parameter(gs._rotation)
+        new._features_dc = nn.Parameter(torch.zeros_like(gs._features_dc))
+        new._features_rest = nn.Parameter(torch.zeros_like(gs._features_rest))
+        new._opacity, new.feature = nn.Parameter(gs._opacity), nn.Parameter(gs.feature)
+        new.max_radii2D = torch.zeros(new.get_xyz.shape[0], device=gs._xyz.device)
+        return new
 
     @classmethod
     def from_tensors(cls, xyz, features_dc, features_rest, scaling, rotation, opacity, device="cuda",
                      use_isotropic_gs=False, active_sh_degree=3):
-        gm = cls(3, use_isotropic_gs=use_isotropic_gs)
+        gm = cls(3, with_motion_mask=False, use_isotropic_gs=use_isotropic_gs)
         P = lambda t: nn.Parameter(t.detach().to(device).float().contiguous().requires_grad_(True))  # noqa: E731
         gm._xyz, gm._features_dc, gm._features_rest = P(xyz), P(features_dc), P(features_rest)
         gm._scaling, gm._rotation, gm._opacity = P(scaling), P(rotation), P(opacity)
@@ -73,9 +171,52 @@ class GaussianModel:
     def get_opacity(self):
         return torch.sigmoid(self._opacity)
 
+    def get_covariance(self, scaling_modifier=1, d_rotation=None, gs_rot_bias=None):
+        """(N, 6) upper triangle of R S S^T R^T; a rotation residual composes by quaternion PRODUCT here — not the
+        additive residual of the default branch (:134-142)."""
+        rotation = self._rotation if d_rotation is None else quaternion_multiply(self._rotation, d_rotation)
+        if gs_rot_bias is not None:
+            rotation = quaternion_multiply(gs_rot_bias, rotation / rotation.norm(dim=-1, keepdim=True))
+        return self.covariance_activation(self.get_scaling, scaling_modifier, rotation)
+
+    def get_covariance_inv(self):  # :144-147
+        M = build_rotation(self._rotation).transpose(1, 2) * (1.0 / self.get_scaling)[:, None, :]
+        return M @ M.transpose(1, 2)
+
     def oneupSHdegree(self):
         if self.active_sh_degree < self.max_sh_degree:
             self.active_sh_degree += 1
+
+    def create_from_pcd(self, pcd, spatial_lr_scale: float = 5.0, print_info=True, max_point_num=150_000):
+        """Initial cloud from points + colours (:153-195): DC coefficients from the colours, isotropic log-scales from
+        the mean squared distance to the 3 nearest neighbours (``distCUDA2``: csrc/knn.hip), identity rotations,
+        opacity 0.1, features -1e-2 (mask column 0).  Arrays go to ``cuda``; tensors stay on their device."""
+        import numpy as np
+        from .knn import distCUDA2
+        self.spatial_lr_scale = 1
+        pts = torch.tensor(np.asarray(pcd.points)).float().cuda() if isinstance(pcd.points, np.ndarray) else pcd.points
+        col = RGB2SH(torch.tensor(np.asarray(pcd.colors)).float().cuda()) if isinstance(pcd.colors, np.ndarray) else pcd.colors
+        n, dev = pts.shape[0], pts.device
+        if print_info:
+            print("Number of points at initialisation : ", n)
+        n_coef = (self.max_sh_degree + 1) ** 2
+        dist2 = torch.clamp_min(distCUDA2(pts), 0.0000001)
+        scales = torch.log(torch.sqrt(dist2))[..., None]
+        if not self.use_isotropic_gs:
+            scales = scales.repeat(1, 3)
+        rots = torch.zeros((n, 4), device=dev)
+        rots[:, 0] = 1
+        P = lambda t: nn.Parameter(t.contiguous().requires_grad_(True))  # noqa: E731
+        self._xyz = P(pts)
+        self._features_dc = P(col.to(dev).float().reshape(n, 1, 3).clone())
+        self._features_rest = P(torch.zeros((n, n_coef - 1, 3), device=dev))
+        self._scaling, self._rotation = P(scales), P(rots)
+        self._opacity = P(inverse_sigmoid(0.1 * torch.ones((n, 1), dtype=torch.float, device=dev)))
+        self.max_radii2D = torch.zeros(n, device=dev)
+        self.feature = nn.Parameter(-1e-2 * torch.ones((n, self.fea_dim), dtype=torch.float32, device=dev), requires_grad=True)
+        if self.with_motion_mask:
+            self.feature.data[..., -1] = 0.0
+        self._ones_mask = None
 
     # ---- optimizer (scene/gaussian_model.py:197-231, :516-518) --------------------------------------------------
     def training_setup(self, training_args, capturable=False):
@@ -100,26 +241,26 @@ class GaussianModel:
         if capturable:  # scheduled learning rate as a device scalar (see FusedAdam): update_learning_rate fills it
             groups[0]["lr"] = torch.tensor(float(groups[0]["lr"]), dtype=torch.float32, device=dev)
         self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15, capturable=capturable)
-        lr0 = training_args.position_lr_init * self.spatial_lr_scale
-        lr1 = training_args.position_lr_final * self.spatial_lr_scale
-        steps = training_args.position_lr_max_steps  # (position_lr_delay_mult is inert: lr_delay_steps stays 0)
+        self.xyz_scheduler_args = get_expon_lr_func(lr_init=training_args.position_lr_init * self.spatial_lr_scale,
+                                                    lr_final=training_args.position_lr_final * self.spatial_lr_scale,
+                                                    lr_delay_mult=training_args.position_lr_delay_mult,
+                                                    max_steps=training_args.position_lr_max_steps)
+        self.skeleton_gs_position_lr = getattr(training_args, "skeleton_gs_position_lr",
+                                               training_args.position_lr_init * self.spatial_lr_scale)
 
-        def xyz_lr(step):  # get_expon_lr_func (utils/general_utils.py:49-87) with lr_delay_steps = 0
-            if step < 0 or (lr0 == 0.0 and lr1 == 0.0):
-                return 0.0
-            t = min(max(step / steps, 0.0), 1.0)
-            return math.exp(math.log(lr0) * (1 - t) + math.log(lr1) * t)
-        self.xyz_scheduler_args = xyz_lr
-        self.skeleton_gs_position_lr = getattr(training_args, "skeleton_gs_position_lr", lr0)
-
-    def update_learning_rate(self, iteration):  # :222-228
+    def _set_xyz_lr(self, lr):
         for group in self.optimizer.param_groups:
             if group["name"] == "xyz":
-                lr = self.xyz_scheduler_args(iteration)
                 if isinstance(group["lr"], torch.Tensor):
                     group["lr"].fill_(lr)
                 else:
                     group["lr"] = lr
+
+    def update_learning_rate(self, iteration):  # :222-228
+        self._set_xyz_lr(self.xyz_scheduler_args(iteration))
+
+    def update_learning_rate_for_skeleton_step(self, iteration):  # :231-235
+        self._set_xyz_lr(self.skeleton_gs_position_lr)
 
     def add_densification_stats(self, viewspace_point_tensor, update_filter, radii=None):  # :516-518 (+ train_rig.py:333-335)
         from .optim import densify_stats
@@ -337,3 +478,28 @@ class GaussianModel:
         kept, clones, parents = self._compact(flags[0]), self._compact(flags[1]), self._compact(flags[2])
         plan = torch.cat([kept, ~clones, ~parents, ~parents])
         self._regather(plan, stats="zero", children=(int(kept.numel() + clones.numel()), parents, 2, unit_normals))
+
+    def sampling_and_prune(self, num_sample=5000):  # :520-531 (train_rig.py:196)
+        keep = farthest_point_sample(self.get_xyz.detach()[None], num_sample)[0]
+        n = self.get_xyz.shape[0]
+        drop = torch.ones(n, dtype=torch.bool, device=self.get_xyz.device)
+        drop[keep] = False
+        if self.max_radii2D.shape[0] != n:
+            self.max_radii2D = torch.zeros(n, device=self.get_xyz.device)
+        self.prune_points(drop)
+        print("sample gaussians from", n, "to", self.get_xyz.shape[0])
+
+
+class StandardGaussianModel(GaussianModel):
+    """Every axis (``all_the_same``: every Gaussian) shares the mean log-scale (:534-546) — the J-point model the
+    skeleton's joints are drawn with (``SkeletonWarp.as_gaussians``)."""
+
+    def __init__(self, sh_degree: int, fea_dim=0, with_motion_mask=True, all_the_same=False):
+        super().__init__(sh_degree, fea_dim, with_motion_mask)
+        self.all_the_same = all_the_same
+
+    @property
+    def get_scaling(self):
+        s = self._scaling[..., :1].repeat(1, 3) if self.use_isotropic_gs else self._scaling
+        mean = s.mean()[None, None] if self.all_the_same else s.mean(dim=1, keepdim=True)
+        return self.scaling_activation(mean.expand_as(s))

@@ -436,27 +436,61 @@ class _LazyDeformDict(dict):
         return dict.get(self, key, default)
 
 
-class SkeletonWarp(nn.Module):
-    """HIP-backed mirror of skeleton_utils/skeleton_warp.py:SkeletonWarp (LBS mode)."""
+class _BaseNetworkPlaceholder(nn.Module):
+    """Stand-in for the stage-1 network a ``ControlNodeWarp`` owns (utils/time_utils.py:797-804).  ``SkeletonWarp.forward``
+    never evaluates it; it exists in checkpoints (``network.*``) and is ticked by ``update`` (a frequency-mask schedule of
+    the stage-1 embedding: utils/time_utils.py:455-458) — nothing on this path depends on either."""
 
-    def __init__(self, is_blender=True, joints=None, parent_indices=None, init_pcl=None, K=3, hyper_dim=2,
-                 d_rot_as_res=True, use_skinning_weight_mlp=True, use_template_offsets=True, **kwargs):
+    def __init__(self):
+        super().__init__()
+        self.name = "static"
+        self.param = nn.Parameter(torch.zeros(1), requires_grad=False)
+        self.reg_loss = 0.0
+
+    def update(self, iteration, *args, **kwargs):
+        return
+
+
+class SkeletonWarp(nn.Module):
+    """HIP-backed mirror of skeleton_utils/skeleton_warp.py:SkeletonWarp (:10-300) and of what it inherits from
+    ``ControlNodeWarp`` (utils/time_utils.py:770-932, :1238-1260): constructor signature, attributes, state-dict keys,
+    ``as_gaussians`` / ``init_gaussians`` / ``update`` — the surface ``scene/skeleton_model.py``, ``train_rig.py``,
+    ``render_rig.py`` and ``interactive_GUI.py`` touch (recorded from the reference: tests/golden/skeleton_api_calls.json)."""
+
+    def __init__(self, is_blender=True, joints=None, parent_indices=None, init_pcl=None, K=3, use_hash=False, hash_time=False,
+                 enable_densify_prune=False, pred_opacity=False, pred_color=False, with_arap_loss=False, with_node_weight=False,
+                 local_frame=False, d_rot_as_res=True, skinning=False, hyper_dim=2, progressive_brand_time=False, max_d_scale=-1,
+                 is_scene_static=False, use_skinning_weight_mlp=True, use_template_offsets=True, **kwargs):
         super().__init__()
         if joints is None or parent_indices is None:
             raise ValueError("joints and parent_indices are required")
+        if skinning:
+            raise ValueError("skinning=True leaves the reference's SkeletonWarp without _node_radius (utils/time_utils.py:809) "
+                             "and its deform_by_pose fails on node_radius: not a configuration of this path")
         J = joints.shape[0]
         if J > 64:
             raise ValueError("at most 64 joints are supported by the LDS-staged kernels")
         self.K = K
         self.name = "node"
+        # attributes of the base class (utils/time_utils.py:773-819), kept because callers and checkpoints read them
+        self.use_hash, self.hash_time, self.enable_dp = use_hash, hash_time, enable_densify_prune
+        self.with_node_weight, self.local_frame, self.skinning = with_node_weight, local_frame, False
+        self.pred_opacity, self.pred_color, self.max_d_scale = pred_opacity, pred_color, max_d_scale
+        self.is_scene_static = is_scene_static
         self.is_blender = is_blender
         self.d_rot_as_res = d_rot_as_res
         self.hyper_dim = hyper_dim
         self.reg_loss = 0.0
+        if with_arap_loss and not is_scene_static:  # :789-794 (read by the stage-1 trainer only)
+            self.lambda_arap_landmarks, self.lambda_arap_steps = [1e-4, 1e-4, 1e-5, 1e-5, 0], [0, 5000, 10000, 20000, 20001]
+        else:
+            self.lambda_arap_landmarks, self.lambda_arap_steps = [0], [0]
         nodes = torch.randn(J, 3 + hyper_dim)
         nodes[:, :3] = joints.detach().float().cpu()
         self.nodes = nn.Parameter(nodes, requires_grad=False)  # skeleton_warp.py:14-16
         self._node_radius = nn.Parameter(torch.randn(J))        # utils/time_utils.py:807
+        if with_node_weight:
+            self._node_weight = nn.Parameter(torch.zeros(J, 1))  # :811 (state only: the skeleton's weights ignore it)
         self.register_buffer("parents", parent_indices.detach().long().cpu().clone(), persistent=False)  # an attribute, not state, in the reference
         self.use_skinning_weight_mlp = use_skinning_weight_mlp
         self.use_template_offsets = use_template_offsets
@@ -472,9 +506,12 @@ class SkeletonWarp(nn.Module):
         # checkpoint compatibility (skeleton.pth, scene/skeleton_model.py:43-72): the reference's state dict also holds the
         # `inited` flag and the parameter of its (static) base network — utils/time_utils.py:288-300, :799-805
         self.register_buffer("inited", torch.tensor(True))
-        self.network = nn.Module()
-        self.network.param = nn.Parameter(torch.zeros(1), requires_grad=False)
+        self.network = _BaseNetworkPlaceholder()
         self.register_buffer("_rot_bias", torch.tensor([1.0, 0.0, 0.0, 0.0]), persistent=False)  # skeleton_warp.py:118
+        self.nodes_color_visualization = torch.ones(J, 3 + hyper_dim)  # :816
+        self.cached_nn_weight = False  # :819-820 (a GUI toggle; the skeleton's weights are never cached)
+        self.nn_weight = self.nn_dist = self.nn_idxs = None
+        self.gs = None
         self._parents_i32 = None
         self._joints_key, self._joints_cache = None, None
 
@@ -493,12 +530,86 @@ class SkeletonWarp(nn.Module):
     def update_control_nodes(self, nodes):
         self.control_nodes.data = nodes
 
+    @property
+    def node_weight(self):  # utils/time_utils.py:877-879
+        return torch.sigmoid(self._node_weight)
+
+    def update(self, iteration):
+        """Per-iteration hook of the base network (utils/time_utils.py:821-822 <- scene/skeleton_model.py:84-85 <-
+        train_rig.py:533): nothing the skeleton path evaluates has a schedule."""
+        self.network.update(iteration)
+
+    @property
+    def param_names(self):  # utils/time_utils.py:834-842 (skinning is never on here)
+        return ["nodes", "_node_radius", "_node_weight"] if self.with_node_weight else ["nodes", "_node_radius"]
+
+    # ---- the joints as a small Gaussian model (utils/time_utils.py:1238-1260): what SkeletonModel.train_setting sets an
+    # optimizer up for (scene/skeleton_model.py:38-39) and the GUI's skeleton-only view renders (interactive_GUI.py:265,391)
+    @staticmethod
+    def _gaussian_classes():
+        try:  # the trainer's own classes when this module runs inside a RigGS checkout
+            from scene.gaussian_model import BasicPointCloud, StandardGaussianModel
+        except Exception:
+            from .gaussian_model import BasicPointCloud, StandardGaussianModel
+        return BasicPointCloud, StandardGaussianModel
+
+    @property
+    def as_gaussians(self):
+        if getattr(self, "gs", None) is None:
+            print("Building Learnable Gaussians for Nodes!")
+            BasicPointCloud, StandardGaussianModel = self._gaussian_classes()
+            joints = self.nodes[..., :3].detach()
+            pcd = BasicPointCloud(points=joints, colors=torch.zeros_like(joints), normals=joints)
+            self.gs = StandardGaussianModel(sh_degree=0, all_the_same=True, with_motion_mask=False)
+            self.gs.create_from_pcd(pcd=pcd, spatial_lr_scale=0.0, print_info=False)  # distCUDA2 on J points
+            self.gs._scaling.data = torch.log(1e-2 * torch.ones_like(self.gs._scaling))
+            self.gs._xyz.data = self.nodes[..., :3]
+        return self.gs
+
+    def init_gaussians(self, init_pcl, with_motion_mask):
+        if getattr(self, "gs", None) is None:
+            print("Initialize Learnable Gaussians for Nodes with Point Clouds!")
+            BasicPointCloud, StandardGaussianModel = self._gaussian_classes()
+            pcd = BasicPointCloud(points=init_pcl.detach(), colors=torch.zeros_like(init_pcl), normals=torch.zeros_like(init_pcl))
+            self.gs = StandardGaussianModel(sh_degree=0, all_the_same=True, with_motion_mask=with_motion_mask)
+            self.gs.create_from_pcd(pcd=pcd, spatial_lr_scale=0.0, print_info=False)
+        return self.gs
+
+    def state_dict(self, *args, **kwargs):
+        """The module's entries plus, once the joint Gaussians exist, theirs as ``gs_<name>`` (utils/time_utils.py:867-872)."""
+        sd = super().state_dict(*args, **kwargs)
+        if getattr(self, "gs", None) is not None:
+            prefix = kwargs.get("prefix", args[1] if len(args) > 1 else "")
+            for name in self.gs.param_names():
+                sd[prefix + "gs_" + name] = getattr(self.gs, name)
+        return sd
+
     def load_state_dict(self, state_dict, strict=True, **kw):
-        """Accepts the reference's ``skeleton.pth``: entries of its base deformation network other than the static
-        placeholder (a stage-1 leftover this path never evaluates) are dropped."""
-        mine = self.state_dict()
+        """Accepts the reference's ``skeleton.pth`` (utils/time_utils.py:844-865): node parameters are assigned (re-created
+        when the joint count differs), ``gs_*`` entries go to the joint Gaussians, and entries of the base deformation
+        network other than the static placeholder (a stage-1 leftover this path never evaluates) are dropped."""
+        state_dict = dict(state_dict)
+        for key in self.param_names:
+            if key in state_dict:
+                v = state_dict.pop(key)
+                cur = getattr(self, key)
+                if cur.shape != v.shape:
+                    print(f"Loading nodes mismatching the original setting: {cur.shape} and {v.shape}")
+                    setattr(self, key, nn.Parameter(v.detach().clone().to(cur.device), requires_grad=cur.requires_grad))
+                else:
+                    cur.data = v.detach().to(cur.device, cur.dtype).clone()
+        for key in [k for k in state_dict if k.startswith("gs_")]:
+            v, name = state_dict.pop(key), key[3:]
+            try:
+                getattr(self.as_gaussians, name).data = v
+            except Exception:
+                print(f"Directly set as values for {key} when loading deform gaussians")
+                setattr(self.as_gaussians, name, v)
+        mine = super().state_dict()
         sd = {k: v for k, v in state_dict.items() if k in mine or not k.startswith("network.")}
         sd.setdefault("network.param", mine["network.param"])  # absent when the file's base network was not the static one
+        for key in self.param_names:
+            sd[key] = getattr(self, key).data
         return super().load_state_dict(sd, strict=strict, **kw)
 
     def trainable_parameters(self):
@@ -645,12 +756,14 @@ class SkeletonWarp(nn.Module):
 
 
 class SkeletonModel:
-    """scene/skeleton_model.py: thin wrapper; only the hot-path surface is mirrored."""
+    """scene/skeleton_model.py:9-85, method for method: the deformation module, its Adam with one group per entry of
+    ``trainable_parameters()``, the exponential learning-rate schedule, checkpoints."""
 
     def __init__(self, is_blender=False, d_rot_as_res=True, **kwargs):
         self.deform = SkeletonWarp(is_blender=is_blender, d_rot_as_res=d_rot_as_res, **kwargs).cuda()
         self.name = self.deform.name
         self.optimizer = None
+        self.spatial_lr_scale = 1
         self.d_rot_as_res = d_rot_as_res
 
     @property
@@ -660,9 +773,25 @@ class SkeletonModel:
     def step(self, xyz, time_emb, **kwargs):
         return self.deform(xyz, time_emb, **kwargs)
 
-    def train_setting(self, lr=5e-4):
-        groups = [{"params": g["params"], "lr": lr, "name": g["name"]} for g in self.deform.trainable_parameters()]
+    def train_setting(self, training_args):  # :24-39
+        from .gaussian_model import get_expon_lr_func
+        groups = [{"params": g["params"], "lr": training_args.deform_mlp_lr_init, "name": g["name"]}
+                  for g in self.deform.trainable_parameters()]
         self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        self.deform_scheduler_args = get_expon_lr_func(lr_init=training_args.deform_mlp_lr_init,
+                                                       lr_final=training_args.deform_mlp_lr_final,
+                                                       lr_delay_mult=training_args.deform_mlp_lr_delay_mult,
+                                                       max_steps=training_args.deform_mlp_lr_max_steps)
+        if self.name == "node":
+            self.deform.as_gaussians.training_setup(training_args)
+
+    def update_learning_rate(self, iteration, warmup_stage):  # :74-82
+        lr = 5e-4 if warmup_stage else self.deform_scheduler_args(iteration)
+        for group in self.optimizer.param_groups:
+            group["lr"] = lr
+
+    def update(self, iteration):  # :84-85
+        self.deform.update(iteration)
 
     # ---- checkpoints (scene/skeleton_model.py:43-72) --------------------------------------------------------------
     def save_weights(self, model_path, iteration):
@@ -670,6 +799,16 @@ class SkeletonModel:
         out = os.path.join(model_path, "skeleton/iteration_{}".format(iteration))
         os.makedirs(out, exist_ok=True)
         torch.save(self.deform.state_dict(), os.path.join(out, "skeleton.pth"))
+
+    def save_joints(self, model_path, iteration, d_nodes, idx):  # :49-56
+        import os
+        out = os.path.join(model_path, "skeleton/iteration_{}".format(iteration))
+        os.makedirs(out, exist_ok=True)
+        parents = self.deform.parents.cpu()
+        tag = "/t" + str(idx).zfill(3)
+        write_to_obj(self.deform.nodes[:, :3].detach().cpu(), out + "/template_nodes.obj", parents)
+        write_to_obj(d_nodes.detach().cpu(), out + tag + "_d_nodes.obj", parents)
+        write_to_obj(self.deform.control_nodes.detach().cpu(), out + tag + "_control_nodes.obj", parents)
 
     def load_weights(self, model_path, iteration=-1):
         import os
@@ -683,4 +822,16 @@ class SkeletonModel:
         if not os.path.exists(path):
             return False
         self.deform.load_state_dict(torch.load(path, map_location=self.deform.nodes.device))
+        self.deform.parents = self.deform.parents.int()  # :68
         return True
+
+
+def write_to_obj(points, path, parents=None):
+    """Wavefront OBJ: one ``v x y z`` row per point, then — with a parent array — one 1-based ``l child parent`` row per
+    non-root entry (the format of skeleton_utils/visualization.py's writer of the same name)."""
+    with open(path, "w") as f:
+        for p in points:
+            f.write("v %f %f %f\n" % (float(p[0]), float(p[1]), float(p[2])))
+        if parents is not None:
+            for j in range(1, len(parents)):
+                f.write("l %d %d\n" % (j + 1, int(parents[j]) + 1))
