@@ -603,7 +603,7 @@ def exchange_path_child(steps=200):
     # (2) ONE graph: the collectives captured with the frame
     try:
         rows = SparseRowExchange([v.view(w["N"], -1) for v in bucket.views[:n_rows]], rest=bucket.flat[bucket.offsets[n_rows]:],
-                                 capacity=min(w["N"], int(need * 1.1) + 256), force_collectives=True)
+                                 capacity=min(w["N"], int(need * 1.1) + 256), force_collectives=True, validity=bucket)
         rows.record_rows = True
         gf = GraphedFrame(gm, sw, cam, bg, params, split_backward=True, sparse_grad_rows=True)
         gf.set_inputs(gimg=gimg)
@@ -613,7 +613,20 @@ def exchange_path_child(steps=200):
         out["one_graph_ms"] = round(timed(gf.run, steps), 4)
         assert gf.check() == R and rows.check()
         verify("captured collectives")
-        out["one_graph"] = "frame + pack + all_gather + all_reduce + unpack captured as one hipGraph"
+        out["one_graph"] = ("frame + gated pack + all_gather + validity flag + all_reduce + unpack captured as one hipGraph (an invalid "
+                            "frame marks its segment / raises the bucket's validity slot: every rank's optimizer is gated on them)")
+        # soak: the PoseMLP chain's bounded hand-offs next to asynchronous RCCL collectives, many times over — the sticky status
+        # word says whether ANY of the replays lost one (that replay would have been a skipped step on every rank)
+        n_soak = int(os.environ.get("RIGGS_BENCH_SOAK", "10000"))
+        t0 = time.perf_counter()
+        for _ in range(n_soak):
+            gf.run()
+        torch.cuda.synchronize()
+        st = gf._pose_status()
+        out["soak"] = {"replays": n_soak, "ms_per_step": round((time.perf_counter() - t0) / max(n_soak, 1) * 1e3, 4),
+                       "pose_handoff_timeouts": int(st[0][st[1]].item()) if st is not None else None,
+                       "arena_flags": int(gf.arena.static_counters[1].item()) & 3, "exchange_status_clean": bool(rows.check()),
+                       "invalid_frames": bool(rows.invalid_frame)}
     except Exception as e:  # (recorded, not hidden: the eager-collective number above stands on its own)
         out["one_graph_error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
     print(json.dumps(out), flush=True)

@@ -42,6 +42,10 @@ const char* riggs_last_error(void);
  *   "preprocess_bwd_lean" -1  riggs_raster_backward's per-Gaussian kernel as one wave per 256 Gaussians (no LDS image, every block
  *                             resident at once): -1 = with cfg.sparse_zero (sparse gradient rows: -3 .. -6 us of a frame; with
  *                             every row written the 256-thread form is 18 us faster), 0 / 1 = never / always.  Same results
+ *   "pose_mlp_layered"  0     1 = riggs_pose_mlp_forward / _backward(_fk) run one launch per layer (no workgroup hand-off inside a
+ *                             launch, nothing that can time out; ~20 launches instead of 2) whatever the network's size: what a
+ *                             host re-runs a frame with after the one-launch kernels reported a lost hand-off.  It must not
+ *                             change between the forward and the backward of one frame
  * Unknown names fail.  Set them between frames, not while a launch that reads them is being issued from another thread. */
 int riggs_set_option(const char* name, int32_t value);
 int riggs_get_option(const char* name, int32_t* value);
@@ -406,6 +410,42 @@ int riggs_adam_step_capturable(int32_t n_groups, float* const* params, const flo
                                float* const* exp_avg_sq, const int64_t* numel, const double* lr,
                                const float* const* step_dev, const float* const* lr_dev, double beta1, double beta2,
                                double eps, riggs_stream stream);
+/* ---- A frame's "valid" gate.  Every way a frame of this library can go wrong WITHOUT the host noticing in time leaves a
+ * non-zero device word behind: the sticky status word of the one-launch PoseMLP kernels (a workgroup hand-off timed out, the
+ * pose was poisoned with NaN: sync_state[riggs_pose_mlp_status_word()]), the rasterizer's counters[1] (bit 0: the instance
+ * arena overflowed, the lists were truncated; bit 1: the depth sort's in-launch barrier timed out), the gradient-row
+ * exchange's status[1] (a segment overflowed or some rank's frame was invalid: nothing was unpacked).  A host that steps its
+ * optimizer inside the same hipGraph cannot look at them first — so the kernels that CONSUME a frame's gradients take the
+ * words themselves: when (word[i][0] & mask[i]) != 0 for any i < n they leave every output untouched.
+ *   riggs_adam_step_gated         = riggs_adam_step_capturable that also advances the step counts (step_dev[k][0] += 1, as a
+ *                                   first launch) — parameters, both moments and the counts are bit-identical to before the
+ *                                   call when the gate is set, and *skipped (device u32, may be NULL) is incremented instead.
+ *   riggs_grad_rows_pack_gated    = riggs_grad_rows_pack that marks the segment "frame invalid" (rows needed = 0xFFFFFFFF)
+ *                                   instead of packing: every rank's riggs_grad_rows_unpack then skips (gradients untouched) and
+ *                                   raises bit 1 of status[1] — which the ranks' optimizers take as THEIR gate, so that all
+ *                                   replicas skip the step together and stay bit-identical.
+ *   riggs_gate_flag               writes 1.0f (gate set) or 0.0f into `flag` — a spare float INSIDE the buffer of a dense
+ *                                   gradient all-reduce (sum or average), issued in front of that collective: afterwards the
+ *                                   slot is non-zero on every rank when SOME rank's frame was invalid (the NaN of a poisoned
+ *                                   frame spreads to every rank's gradients through the sum; so does this flag), and serves as
+ *                                   a gate word (mask 0x7FFFFFFF) of every rank's optimizer.
+ */
+#define RIGGS_GATE_MAX 4
+typedef struct riggs_gate {
+    int32_t n;                                  /* words in use (0: never gated) */
+    int32_t reserved;
+    const uint32_t* word[RIGGS_GATE_MAX];       /* device pointers */
+    uint32_t mask[RIGGS_GATE_MAX];
+} riggs_gate;
+int riggs_gate_flag(const riggs_gate* gate, float* flag, riggs_stream stream);
+/* (advance_steps = 0: the counts were advanced by riggs_adam_steps_advance_gated — one launch for up to 128 of them, what a
+ * host with more than 32 parameter tensors issues once in front of its riggs_adam_step_gated calls; `skipped` is counted there) */
+int riggs_adam_steps_advance_gated(int32_t n_steps, float* const* step_dev, const riggs_gate* gate, uint32_t* skipped,
+                                   riggs_stream stream);
+int riggs_adam_step_gated(int32_t n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
+                          float* const* exp_avg_sq, const int64_t* numel, const double* lr, float* const* step_dev,
+                          const float* const* lr_dev, double beta1, double beta2, double eps, const riggs_gate* gate,
+                          uint32_t* skipped, int32_t advance_steps, riggs_stream stream);
 int riggs_densify_stats(int32_t num_points, const float* viewspace_grad, const uint8_t* update_filter,
                         const int32_t* radii, float* xyz_gradient_accum, float* denom, float* max_radii2D,
                         riggs_stream stream);
@@ -425,7 +465,8 @@ int riggs_densify_stats(int32_t num_points, const float* viewspace_grad, const u
  * added; rows in no segment are left as they are (zero on every rank) — without atomics, so every rank obtains the same
  * bits.  `grads` are HOST arrays of DEVICE pointers to (N, widths[k]) row-major float tensors (<= 8).  `status` (4 words)
  * is STICKY — only ever raised by the kernel, cleared by whoever reads it: [0] = the largest number of rows a segment
- * needed, [1] != 0 when in some call a segment overflowed `capacity` or did not match (N, row_floats): in that call NOTHING
+ * needed, [1] != 0 when in some call a segment overflowed `capacity` or did not match (N, row_floats) (bit 0) or was marked
+ * "frame invalid" by riggs_grad_rows_pack_gated (bit 1): in that call NOTHING
  * was unpacked (the gradients kept their local values) and the caller has to exchange that step densely — or, when it polls
  * only every k steps and the optimizers have already stepped on un-averaged gradients, re-synchronise the replicas; [2] = calls
  * since it was cleared, [3] = the call (1-based) that failed first.
@@ -434,6 +475,9 @@ int32_t riggs_grad_rows_row_floats(int32_t n_tensors, const int32_t* widths);
 size_t riggs_grad_rows_segment_bytes(int32_t num_points, int32_t row_floats, int32_t capacity);
 int riggs_grad_rows_pack(int32_t num_points, const void* backward_workspace, int32_t n_tensors, const float* const* grads,
                          const int32_t* widths, float scale, int32_t capacity, void* segment, riggs_stream stream);
+int riggs_grad_rows_pack_gated(int32_t num_points, const void* backward_workspace, int32_t n_tensors, const float* const* grads,
+                               const int32_t* widths, float scale, int32_t capacity, void* segment, const riggs_gate* gate,
+                               riggs_stream stream);
 /* backward_workspace (may be NULL): when given, the rows written are recorded in it as "rows that hold a gradient", which
  * keeps cfg.sparse_zero of the next riggs_raster_backward valid (rows other ranks touched are zeroed there when due). */
 int riggs_grad_rows_unpack(int32_t num_points, int32_t world, int32_t capacity, const void* segments, int32_t n_tensors,

@@ -57,6 +57,52 @@ class FrameGrads(C.Structure):
         "dL_dlocal_rot", "dL_dglobal_trans", "pose_workspace", "pose_flat_grads")]
 
 
+class GateStruct(C.Structure):
+    """struct riggs_gate."""
+    _fields_ = [("n", C.c_int32), ("reserved", C.c_int32), ("word", C.c_void_p * 4), ("mask", C.c_uint32 * 4)]
+
+
+class FrameGate:
+    """A frame's "valid" gate (include/riggs_hip.h: riggs_gate): up to four (device word, mask) pairs — the sticky status word
+    of the one-launch PoseMLP kernels, the rasterizer's overflow / sort-barrier flags, the gradient-row exchange's status —
+    that the consumers of the frame's gradients (the fused Adam, the exchange's pack) read ON THE DEVICE: a frame that went
+    wrong is a skipped step, also inside a hipGraph where the host cannot look first.  ``sources``: callables returning
+    ``(int32 / uint32 device tensor, word index, mask)`` or None, resolved at every launch (the rasterizer's counters are a
+    new tensor per frame until a capture pins them).  ``skipped`` counts the steps the gate turned into no-ops."""
+
+    def __init__(self, sources=(), device=None):
+        import torch
+        self.sources = list(sources)
+        self.skipped = torch.zeros(1, dtype=torch.int32, device=device or "cuda")
+        self._keep = []
+
+    def struct(self):
+        g = GateStruct()
+        keep, n = [], 0
+        for src in self.sources:
+            got = src()
+            if got is None:
+                continue
+            t, index, mask = got
+            if not (t.is_cuda and t.element_size() == 4 and t.is_contiguous() and 0 <= index < t.numel()):
+                raise RiggsHipError("a gate word must be an element of a contiguous 32-bit device tensor")
+            if n >= 4:
+                raise RiggsHipError("at most four gate words")
+            g.word[n] = t.data_ptr() + 4 * int(index)
+            g.mask[n] = int(mask) & 0xFFFFFFFF
+            keep.append(t)
+            n += 1
+        g.n = n
+        self._keep = keep  # the words outlive the launches that were handed their addresses
+        return g
+
+    def read_skipped(self, clear=True) -> int:
+        n = int(self.skipped.item())
+        if clear and n:
+            self.skipped.zero_()
+        return n
+
+
 _lib = None
 
 _P = C.c_void_p
@@ -100,6 +146,11 @@ _SIGS = {
     "riggs_grad_rows_unpack": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, _P]),
     "riggs_adam_step": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, _P]),
     "riggs_adam_step_capturable": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, _P]),
+    "riggs_adam_step_gated": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double,
+                                        C.POINTER(GateStruct), _P, C.c_int32, _P]),
+    "riggs_gate_flag": (C.c_int, [C.POINTER(GateStruct), _P, _P]),
+    "riggs_adam_steps_advance_gated": (C.c_int, [C.c_int32, _P, C.POINTER(GateStruct), _P, _P]),
+    "riggs_grad_rows_pack_gated": (C.c_int, [C.c_int32, _P, C.c_int32, _P, _P, C.c_float, C.c_int32, _P, C.POINTER(GateStruct), _P]),
     "riggs_densify_stats": (C.c_int, [C.c_int32] + [_P] * 7),
     "riggs_l1_ssim_state_floats": (C.c_size_t, [C.c_int32] * 3),
     "riggs_l1_ssim_forward": (C.c_int, [C.c_int32] * 3 + [_P, _P, C.c_float, _P, _P, _P]),
@@ -170,7 +221,7 @@ def lib():
 
 def set_option(name: str, value: int):
     """riggs_set_option (include/riggs_hip.h): "fwd_wide_tiles", "fwd_wide_min", "bin_grouped", "cnode_bwd_atomics",
-    "color_side_jobs", "preprocess_bwd_lean"."""
+    "color_side_jobs", "preprocess_bwd_lean", "pose_mlp_layered"."""
     check(lib().riggs_set_option(name.encode(), int(value)), "riggs_set_option")
 
 

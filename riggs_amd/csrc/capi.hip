@@ -18,9 +18,9 @@ void set_error(const char* fmt, ...) {
 }
 
 // ---- library options -------------------------------------------------------------------
-static const char* kOptNames[OPT_COUNT] = {"fwd_wide_tiles", "fwd_wide_min", "bin_grouped", "cnode_bwd_atomics", "color_side_jobs", "preprocess_bwd_lean"};
-static const int kOptDefaults[OPT_COUNT] = {256, 4096, -1, 0, 1, -1};
-static int g_opt[OPT_COUNT] = {256, 4096, -1, 0, 1, -1};
+static const char* kOptNames[OPT_COUNT] = {"fwd_wide_tiles", "fwd_wide_min", "bin_grouped", "cnode_bwd_atomics", "color_side_jobs", "preprocess_bwd_lean", "pose_mlp_layered"};
+static const int kOptDefaults[OPT_COUNT] = {256, 4096, -1, 0, 1, -1, 0};
+static int g_opt[OPT_COUNT] = {256, 4096, -1, 0, 1, -1, 0};
 int option(int id) { return g_opt[id]; }
 
 // ---- event-based kernel timing -------------------------------------------------------
@@ -149,7 +149,7 @@ int riggs_set_option(const char* name, int32_t value) {
   if (id == OPT_FWD_WIDE_MIN) { if (v < 0) v = kOptDefaults[id]; if (v < 256) v = 256; }
   if (id == OPT_BIN_GROUPED) { if (v < -1 || v > 1) { set_error("riggs_set_option: bin_grouped takes -1 (by size), 0 or 1"); return 2; } }
   if (id == OPT_PREPROCESS_BWD_LEAN) { if (v < -1 || v > 1) { set_error("riggs_set_option: preprocess_bwd_lean takes -1 (with cfg.sparse_zero), 0 or 1"); return 2; } }
-  if (id == OPT_CNODE_BWD_ATOMICS || id == OPT_COLOR_SIDE_JOBS) v = v ? 1 : 0;
+  if (id == OPT_CNODE_BWD_ATOMICS || id == OPT_COLOR_SIDE_JOBS || id == OPT_POSE_MLP_LAYERED) v = v ? 1 : 0;
   g_opt[id] = v;
   return 0;
 }

@@ -46,8 +46,35 @@ inline int debug_sync(int debug, hipStream_t s, const char* what) {
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 // ---- library options (riggs_set_option / riggs_get_option in the ABI; process-wide, nothing is read from the environment) ----
-enum OptId { OPT_FWD_WIDE_TILES = 0, OPT_FWD_WIDE_MIN, OPT_BIN_GROUPED, OPT_CNODE_BWD_ATOMICS, OPT_COLOR_SIDE_JOBS, OPT_PREPROCESS_BWD_LEAN, OPT_COUNT };
+enum OptId { OPT_FWD_WIDE_TILES = 0, OPT_FWD_WIDE_MIN, OPT_BIN_GROUPED, OPT_CNODE_BWD_ATOMICS, OPT_COLOR_SIDE_JOBS, OPT_PREPROCESS_BWD_LEAN, OPT_POSE_MLP_LAYERED, OPT_COUNT };
 int option(int id);
+
+// ---- a frame's "valid" gate (include/riggs_hip.h: riggs_gate) as a kernel argument ----
+struct GateArg {
+  int n;
+  const uint32_t* word[RIGGS_GATE_MAX];
+  uint32_t mask[RIGGS_GATE_MAX];
+};
+static inline int gate_arg(GateArg& g, const riggs_gate* gate) {
+  g.n = 0;
+  for (int i = 0; i < RIGGS_GATE_MAX; i++) { g.word[i] = nullptr; g.mask[i] = 0u; }
+  if (!gate) return 0;
+  if (gate->n < 0 || gate->n > RIGGS_GATE_MAX) return 1;
+  for (int i = 0; i < gate->n; i++) {
+    if (!gate->word[i]) return 1;
+    g.word[g.n] = gate->word[i]; g.mask[g.n] = gate->mask[i]; g.n++;
+  }
+  return 0;
+}
+#ifdef __HIPCC__
+__device__ __forceinline__ bool gate_is_set(const GateArg& g) {
+  uint32_t any = 0u;
+#pragma unroll
+  for (int i = 0; i < RIGGS_GATE_MAX; i++)
+    if (i < g.n) any |= __hip_atomic_load(g.word[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & g.mask[i];
+  return any != 0u;
+}
+#endif
 
 // ---- in-library kernel timing (HIP events on the launch stream; see riggs_prof_* in the ABI) ----
 enum ProfId {

@@ -46,12 +46,22 @@ __device__ inline bool column_source(const RowTensors& T, int c, const float*& b
   return false;
 }
 
+#define RIGGS_SEG_INVALID 0xFFFFFFFFu  // "rows needed" of a segment whose frame was invalid (riggs_grad_rows_pack_gated)
+
 __global__ __launch_bounds__(256) void rows_pack_kernel(int N, const unsigned long long* __restrict__ bits,
                                                         const uint32_t* __restrict__ block_touched, RowTensors T, float scale,
-                                                        int capacity, uint32_t* __restrict__ seg) {
+                                                        int capacity, uint32_t* __restrict__ seg, GateArg gate) {
   __shared__ uint32_t s_part[4];
   const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int nb = (N + 255) / 256;
+  if (gate.n > 0 && gate_is_set(gate)) {
+    // this rank's frame is invalid (NaN pose, truncated lists): nothing of it travels; the header says so to every rank
+    if (t == 0) {
+      seg[4 + b] = 0u;
+      if (b == nb - 1) { seg[4 + nb] = 0u; seg[0] = 0u; seg[1] = RIGGS_SEG_INVALID; seg[2] = (uint32_t)N; seg[3] = (uint32_t)T.row_words; }
+    }
+    return;
+  }
   // rows of the blocks before this one (<= 1172 counts at 300k: a few loads per thread)
   uint32_t sum = 0;
   for (int i = t; i < b; i += 256) sum += block_touched[i];
@@ -149,11 +159,13 @@ __global__ __launch_bounds__(256) void rows_unpack_kernel(int N, int world, int 
   if (t < world) {  // every segment's header and this block's slice of it, all loads in flight at once
     const uint32_t* seg = all + (size_t)t * seg_words;
     const uint32_t need = seg[1];
-    const bool bad = need > (uint32_t)capacity || seg[2] != (uint32_t)N || seg[3] != (uint32_t)RW;
+    const bool invalid = need == RIGGS_SEG_INVALID;   // that rank's frame was invalid: the step is skipped everywhere
+    const bool bad = !invalid && (need > (uint32_t)capacity || seg[2] != (uint32_t)N || seg[3] != (uint32_t)RW);
     const uint32_t first = seg[4 + b], last = seg[4 + b + 1];
     s_range[2 * t] = first; s_range[2 * t + 1] = last < (uint32_t)capacity ? last : (uint32_t)capacity;
-    atomicMax(&s_hdr[0], need);
+    if (!invalid) atomicMax(&s_hdr[0], need);
     if (bad) atomicOr(&s_hdr[1], 1u);
+    if (invalid) atomicOr(&s_hdr[1], 2u);
   }
   __syncthreads();
   // STICKY status (cleared by the host when it reads it, SparseRowExchange.check()): a caller that polls every k steps must
@@ -236,6 +248,10 @@ __global__ __launch_bounds__(256) void rows_unpack_kernel(int N, int world, int 
   }
 }
 
+// 1.0f / 0.0f into a slot of the buffer a dense all-reduce is about to sum: afterwards the slot is non-zero on EVERY rank when
+// some rank's frame was invalid — the word the ranks' optimizers are gated on, so that all replicas skip that step together
+__global__ void gate_flag_kernel(GateArg gate, float* flag) { flag[0] = gate_is_set(gate) ? 1.0f : 0.0f; }
+
 static int fill_tensors(RowTensors& T, int n, float* const* grads, const int32_t* widths) {
   RIGGS_REQUIRE(n >= 1 && n <= RIGGS_ROW_TENSORS, "1..8 gradient tensors");
   int words = 1;
@@ -265,19 +281,36 @@ size_t riggs_grad_rows_segment_bytes(int32_t N, int32_t row_floats, int32_t capa
   return align_up((seg_rows_offset(N > 0 ? N : 1) + (size_t)(capacity > 0 ? capacity : 0) * (size_t)row_floats) * 4);
 }
 
-int riggs_grad_rows_pack(int32_t N, const void* backward_workspace, int32_t n_tensors, const float* const* grads,
-                         const int32_t* widths, float scale, int32_t capacity, void* segment, riggs_stream stream_) {
+int riggs_gate_flag(const riggs_gate* gate, float* flag, riggs_stream stream_) {
+  RIGGS_REQUIRE(flag != nullptr, "riggs_gate_flag: flag is NULL");
+  GateArg g;
+  RIGGS_REQUIRE(gate_arg(g, gate) == 0, "riggs_gate: 0..4 non-NULL words");
+  hipLaunchKernelGGL(gate_flag_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, g, flag);
+  RIGGS_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int riggs_grad_rows_pack_gated(int32_t N, const void* backward_workspace, int32_t n_tensors, const float* const* grads,
+                               const int32_t* widths, float scale, int32_t capacity, void* segment, const riggs_gate* gate,
+                               riggs_stream stream_) {
   hipStream_t s = (hipStream_t)stream_;
   RIGGS_REQUIRE(N > 0 && backward_workspace && segment && capacity >= 0, "riggs_grad_rows_pack: bad arguments");
   RowTensors T;
   int rc = fill_tensors(T, n_tensors, const_cast<float* const*>(grads), widths);
   if (rc) return rc;
+  GateArg g;
+  RIGGS_REQUIRE(gate_arg(g, gate) == 0, "riggs_gate: 0..4 non-NULL words");
   const char* ws = (const char*)backward_workspace;
   hipLaunchKernelGGL(rows_pack_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N,
                      (const unsigned long long*)(ws + ws_bits_offset(N)), (const uint32_t*)(ws + ws_blocks_offset(N)), T, scale,
-                     capacity, (uint32_t*)segment);
+                     capacity, (uint32_t*)segment, g);
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
+}
+
+int riggs_grad_rows_pack(int32_t N, const void* backward_workspace, int32_t n_tensors, const float* const* grads,
+                         const int32_t* widths, float scale, int32_t capacity, void* segment, riggs_stream stream_) {
+  return riggs_grad_rows_pack_gated(N, backward_workspace, n_tensors, grads, widths, scale, capacity, segment, nullptr, stream_);
 }
 
 int riggs_grad_rows_unpack(int32_t N, int32_t world, int32_t capacity, const void* segments, int32_t n_tensors,

@@ -30,7 +30,25 @@ struct AdamArgs {
   const float* lr_dev[ADAM_MAX_GROUPS];    // 0-dim float tensors, or NULL (= lr_host)
   double lr_host[ADAM_MAX_GROUPS];
   double beta1_d, beta2_d;
+  GateArg gate;                            // the frame's "valid" words (include/riggs_hip.h: riggs_gate); n == 0: never gated
 };
+
+// The step counts of a gated update: advanced by ONE small launch in front of it (every workgroup of the update reads them, so
+// none of them may be the writer) — or, when the frame is invalid, left alone and `skipped` counted up instead.
+#define ADAM_ADVANCE_MAX 128
+struct AdvanceArgs {
+  int n;
+  float* step[ADAM_ADVANCE_MAX];
+  GateArg gate;
+};
+__global__ __launch_bounds__(ADAM_ADVANCE_MAX) void adam_advance_kernel(AdvanceArgs a, uint32_t* skipped) {
+  const bool closed = gate_is_set(a.gate);
+  if (closed) {
+    if (threadIdx.x == 0 && skipped) atomicAdd(skipped, 1u);
+    return;
+  }
+  if ((int)threadIdx.x < a.n) a.step[threadIdx.x][0] += 1.0f;
+}
 
 __device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, float w1, float beta2, float w2, float eps,
                                             float neg_step, float bc2s) {
@@ -43,6 +61,9 @@ __device__ __forceinline__ void adam_update(float& p, float g, float& m, float& 
 
 __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a) {
   __shared__ float s_ns[ADAM_MAX_GROUPS], s_bs[ADAM_MAX_GROUPS];
+  // an invalid frame (NaN pose after a lost PoseMLP hand-off, truncated lists, an exchange that unpacked nothing) is a
+  // SKIPPED step: p, m, v stay bit for bit what they were (every workgroup reads the same words: a uniform decision)
+  if (a.gate.n > 0 && gate_is_set(a.gate)) return;
   if (threadIdx.x < ADAM_MAX_GROUPS) {
     const int k = threadIdx.x;
     float ns = a.neg_step_size[k], bs = a.bc2_sqrt[k];
@@ -111,10 +132,11 @@ extern "C" {
 static int adam_launch(int32_t n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
                        float* const* exp_avg_sq, const int64_t* numel, const double* lr, const int64_t* step,
                        const float* const* step_dev, const float* const* lr_dev, double beta1, double beta2, double eps,
-                       riggs_stream stream) {
+                       riggs_stream stream, const riggs_gate* gate = nullptr) {
   RIGGS_REQUIRE(n_groups >= 0 && n_groups <= ADAM_MAX_GROUPS, "at most 32 parameter tensors per launch");
   AdamArgs a;
   memset(&a, 0, sizeof(a));
+  RIGGS_REQUIRE(gate_arg(a.gate, gate) == 0, "riggs_gate: 0..4 non-NULL words");
   a.n_groups = n_groups;
   int64_t vs = 0;
   for (int k = 0; k < n_groups; k++) {
@@ -166,6 +188,37 @@ int riggs_adam_step_capturable(int32_t n_groups, float* const* params, const flo
                                double eps, riggs_stream stream) {
   RIGGS_REQUIRE(step_dev != nullptr, "step_dev is NULL");
   return adam_launch(n_groups, params, grads, exp_avg, exp_avg_sq, numel, lr, nullptr, step_dev, lr_dev, beta1, beta2, eps, stream);
+}
+
+int riggs_adam_steps_advance_gated(int32_t n_steps, float* const* step_dev, const riggs_gate* gate, uint32_t* skipped,
+                                   riggs_stream stream) {
+  RIGGS_REQUIRE(n_steps >= 0 && (n_steps == 0 || step_dev != nullptr), "riggs_adam_steps_advance_gated: bad arguments");
+  for (int at = 0; at < n_steps; at += ADAM_ADVANCE_MAX) {
+    AdvanceArgs adv;
+    memset(&adv, 0, sizeof(adv));
+    RIGGS_REQUIRE(gate_arg(adv.gate, gate) == 0, "riggs_gate: 0..4 non-NULL words");
+    adv.n = n_steps - at < ADAM_ADVANCE_MAX ? n_steps - at : ADAM_ADVANCE_MAX;
+    for (int k = 0; k < adv.n; k++) {
+      RIGGS_REQUIRE(step_dev[at + k] != nullptr, "NULL step tensor");
+      adv.step[k] = step_dev[at + k];
+    }
+    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(ADAM_ADVANCE_MAX), 0, (hipStream_t)stream, adv, at == 0 ? skipped : nullptr);
+    RIGGS_HIP_CHECK(hipGetLastError());
+  }
+  return 0;
+}
+
+int riggs_adam_step_gated(int32_t n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
+                          float* const* exp_avg_sq, const int64_t* numel, const double* lr, float* const* step_dev,
+                          const float* const* lr_dev, double beta1, double beta2, double eps, const riggs_gate* gate,
+                          uint32_t* skipped, int32_t advance_steps, riggs_stream stream) {
+  RIGGS_REQUIRE(step_dev != nullptr, "step_dev is NULL");
+  RIGGS_REQUIRE(n_groups >= 0 && n_groups <= ADAM_MAX_GROUPS, "at most 32 parameter tensors per launch");
+  if (advance_steps && n_groups > 0) {
+    int rc = riggs_adam_steps_advance_gated(n_groups, step_dev, gate, skipped, stream);
+    if (rc) return rc;
+  }
+  return adam_launch(n_groups, params, grads, exp_avg, exp_avg_sq, numel, lr, nullptr, step_dev, lr_dev, beta1, beta2, eps, stream, gate);
 }
 
 int riggs_densify_stats(int32_t N, const float* viewspace_grad, const uint8_t* update_filter, const int32_t* radii,

@@ -669,6 +669,7 @@ int riggs_pose_mlp_set_trace(void* dev_u64x128) { g_pm_trace = (unsigned long lo
 // rows beyond `width` get workgroups of their own that join for the last stage — C5's 64 joints are 259 rows); narrow
 // test networks with wide heads and anything larger run one launch per layer.
 static bool pm_one_launch(int32_t width, int32_t n_rot) {
+  if (option(OPT_POSE_MLP_LAYERED)) return false;  // (a host re-running a frame whose hand-off was lost)
   return n_rot + 3 <= width || (width >= 128 && n_rot + 3 <= PM_MAX_HEAD);
 }
 // acts: activations, then (256-byte aligned) the state of the one-launch kernels:

@@ -107,7 +107,11 @@ class FlatGradAllReduce:
             o += (p.numel() + 3) & ~3
         self.numel = o
         p0 = self.params[0]
-        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=p0.device)
+        # four spare floats behind the gradients travel with every collective over ``flat``: tail[0] is the step's VALIDITY
+        # slot (``publish_validity``: 1 when this rank's frame went wrong; after the sum it is non-zero on every rank)
+        self.flat = torch.zeros(self.numel + 4, dtype=torch.float32, device=p0.device)
+        self.tail = self.flat[self.numel:]
+        self.frame_gate = None  # riggs_amd._lib.FrameGate over THIS rank's frame (GraphedFrame.gate_sources())
         self.views = [self.flat[o:o + p.numel()].view_as(p) for p, o in zip(self.params, self.offsets)]
         self.registered = p0.is_cuda if register is None else register
         if self.registered:
@@ -126,6 +130,19 @@ class FlatGradAllReduce:
                 raise RuntimeError("the gradient of a %s parameter does not alias its slice of the flat bucket: the direct "
                                    "exchange would leave it unreduced (reduce with FlatGradAllReduce.__call__, which copies "
                                    "stray gradients in, or register the bucket before the backward)" % (tuple(p.shape),))
+
+    def publish_validity(self):
+        """In front of the collective that carries ``tail``: this rank's frame status into the validity slot (one tiny launch;
+        nothing without a ``frame_gate``).  The NaN of a poisoned frame reaches every rank's gradients through the sum — and so
+        does this flag, which every rank's optimizer takes as a gate word (``validity_source``): all replicas skip that step."""
+        if self.frame_gate is not None and self.tail is not None and self.flat.is_cuda:
+            from . import _lib as L
+            import ctypes as C
+            L.check(L.lib().riggs_gate_flag(C.byref(self.frame_gate.struct()), self.tail.data_ptr(), L.stream_ptr()), "riggs_gate_flag")
+
+    def validity_source(self):
+        """(tensor, word index, mask) of the validity slot, for the ``FrameGate`` of the optimizers that step on this bucket."""
+        return (self.flat, self.numel, 0x7FFFFFFF)
 
     def register(self):
         import weakref
@@ -165,6 +182,7 @@ class FlatGradAllReduce:
                     p.grad = v
             # a static list of gradient tensors (a captured hipGraph's) that already ARE the slices: skip this loop next time
             self._in_place = sources if (in_place and sources is not None) else None
+        self.publish_validity()
         if world > 1:
             if self.average and self.flat.is_cuda and dist.get_backend() == "nccl":
                 dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)  # RCCL averages in the collective: no divide pass
@@ -217,6 +235,8 @@ class OverlappedExchange:
         t = self.bucket.flat[:self.split] if phase == 1 else self.bucket.flat[self.split:]
         if phase == 1 and not (self.cuda and torch.cuda.is_current_stream_capturing()):
             self.bucket.verify_aliases()
+        if phase != 1:
+            self.bucket.publish_validity()  # (phase 2 carries the bucket's tail: the frame is complete by now)
         if self.cuda:
             self.comm.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm):
@@ -286,9 +306,9 @@ class ShardedAdam:
         dev = self.params[0].device
         self.flat_p = torch.zeros(self.shard * self.world, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(self.shard * self.world, dtype=torch.float32, device=dev)
-        self.flat_g[:n] = self.bucket.flat
+        self.flat_g[:n] = self.bucket.flat[:n]
         # the bucket's gradient buffer and the parameters move into the padded flat buffers (views keep their offsets)
-        self.bucket.flat = self.flat_g[:n]
+        self.bucket.flat, self.bucket.tail = self.flat_g[:n], None
         self.bucket.views = [self.bucket.flat[o:o + p.numel()].view_as(p) for p, o in zip(self.params, self.bucket.offsets)]
         with torch.no_grad():
             for p, o in zip(self.params, self.bucket.offsets):
@@ -445,7 +465,13 @@ def _hip_pack(ex):
     ws, n = (ex.workspace, ex.N) if ex.workspace is not None else last_backward_workspace()
     if n != ex.N or ws.device != ex.segment.device:
         raise RuntimeError("the last rasterizer backward was not over these %d Gaussians" % ex.N)
-    L.check(L.lib().riggs_grad_rows_pack(ex.N, ws.data_ptr(), len(ex.rows), ex._ptrs, ex._widths, C.c_float(1.0 / ex.world if ex.average else 1.0),
+    scale = C.c_float(1.0 / ex.world if ex.average else 1.0)
+    if ex.gate is not None:  # an invalid frame marks its segment instead of packing: every rank then skips this step
+        L.check(L.lib().riggs_grad_rows_pack_gated(ex.N, ws.data_ptr(), len(ex.rows), ex._ptrs, ex._widths, scale, ex.capacity,
+                                                   ex.segment.data_ptr(), C.byref(ex.gate.struct()), L.stream_ptr()),
+                "riggs_grad_rows_pack_gated")
+        return
+    L.check(L.lib().riggs_grad_rows_pack(ex.N, ws.data_ptr(), len(ex.rows), ex._ptrs, ex._widths, scale,
                                          ex.capacity, ex.segment.data_ptr(), L.stream_ptr()), "riggs_grad_rows_pack")
 
 
@@ -480,11 +506,15 @@ class SparseRowExchange:
         return len(rows) > 0 and rows[0].is_cuda
 
     def __init__(self, rows, rest=None, capacity=None, average=True, pack=None, unpack=None, world=None,
-                 force_collectives=False):
+                 force_collectives=False, validity=None):
         """``force_collectives``: issue the collectives even on a communicator of ONE rank (where they are the identity) —
         what ``bench.py``'s single-GPU exchange-path measurement uses to run the real RCCL enqueue path on one device."""
         self.world = int(world) if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.force = bool(force_collectives) and dist.is_initialized() and world is None
+        # the FlatGradAllReduce whose tail ``rest`` ends with (rest = bucket.flat[offset:]): its validity slot is published in
+        # front of the dense all-reduce of ``rest`` — a PoseMLP hand-off lost in the deformation BACKWARD happens after the
+        # pack, poisons only the skeleton's gradients, and reaches the other ranks through that sum
+        self.validity = validity
         _spread_pose_mlp_chain(self.rows_on_gpu(rows))
         self.rows = [g for g in rows]
         self.N = int(self.rows[0].shape[0])
@@ -507,6 +537,10 @@ class SparseRowExchange:
         self.status = torch.zeros(4, dtype=torch.int32, device=dev)  # sticky: see check()
         self.pending = []
         self.need, self.calls, self.overflow_call = 0, 0, 0
+        self.invalid_frame = False  # as of the last check(): some rank's frame was invalid in a step since the previous one
+        # riggs_amd._lib.FrameGate over THIS rank's frame (GraphedFrame.gate_sources()): pack() then marks the segment
+        # "frame invalid" instead of packing when the frame went wrong (GraphedFrame.capture_exchange sets it)
+        self.gate = None
         self._pack_captured = False
         # the backward workspace to pack from: None = the one the most recent rasterizer backward used; a caller that runs
         # other backward passes in between (another stream, an eager profiling step) pins it (GraphedFrame.backward_workspace)
@@ -584,6 +618,8 @@ class SparseRowExchange:
 
     def launch_rest(self):
         if self.rest is not None:
+            if self.validity is not None:
+                self.validity.publish_validity()
             self._on_comm(lambda: self._reduce_dense(self.rest, self.rest_group))
 
     def _join(self):
@@ -604,15 +640,24 @@ class SparseRowExchange:
         self._join()
         self._unpack(self)
 
+    def status_source(self):
+        """For the ``FrameGate`` of the optimizers that consume the exchanged gradients: the exchange's sticky status word —
+        raised on EVERY rank in the same step when a segment overflowed or some rank's frame was invalid (nothing was
+        unpacked).  Gated on it, all replicas skip that step — and the following ones, until ``check()`` clears it — together:
+        they stay bit-identical without a ``resync()``."""
+        return (self.status, 1, 0xFFFFFFFF)
+
     def check(self) -> bool:
         """Reads and clears the sticky status (a device->host read).  False when ANY unpack since the previous check
-        overflowed ``capacity`` — on such a step every rank skipped the unpack, the gradients stayed local.
+        overflowed ``capacity`` — on such a step every rank skipped the unpack, the gradients stayed local — or when some
+        rank's frame was invalid (``invalid_frame``: its pack was gated, every rank skipped).
         ``overflow_call`` then holds which of the ``calls`` unpacks since the previous check failed first: if it is the one
         that has just run and no optimizer has stepped, ``dense_fallback()`` repairs the step; if optimizers have stepped on
         it (polling every k steps), the replicas have diverged: ``resync(parameters, optimizer)`` broadcasts rank 0's."""
         need, bad, calls, first = (int(v) for v in self.status.tolist())
         self.status.zero_()
         self.need, self.calls, self.overflow_call = need, calls, first if bad else 0
+        self.invalid_frame = bool(bad & 2)
         return not bad
 
     def resync(self, tensors):

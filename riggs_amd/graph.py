@@ -58,6 +58,24 @@ class GraphedFrame:
         self.exchange = None
         self.exchange_in_graph = False
 
+    # ---- the frame's "valid" words (include/riggs_hip.h: riggs_gate), for whoever consumes its gradients on the device
+    def _pose_status(self):
+        pn = getattr(self.sw, "pose_net", None)
+        sync = getattr(pn, "_hip_sync", None)
+        if sync is None or not sync.is_cuda:
+            return None
+        w = int(L.lib().riggs_pose_mlp_status_word(len(pn.net), pn.net[0].out_features))
+        return (sync, w, 0xFFFFFFFF) if w < sync.numel() else None
+
+    def _arena_flags(self):
+        c = self.arena.static_counters  # (this frame's counters; pinned by a capture)
+        return None if c is None else (c, 1, 3)  # bit 0: the instance arena overflowed, bit 1: the depth sort's barrier timed out
+
+    def gate_sources(self):
+        """Callables for a ``riggs_amd._lib.FrameGate``: the sticky status word of the one-launch PoseMLP kernels and the
+        rasterizer's overflow / sort-barrier flags of the frame rendered last through this object's arena."""
+        return [self._pose_status, self._arena_flags]
+
     def _frame(self):
         for p in self.params:
             p.grad = None
@@ -205,6 +223,13 @@ class GraphedFrame:
         if not self.split:
             raise ValueError("capture_exchange needs split_backward=True")
         self.exchange, self.exchange_in_graph = exchange, True
+        if getattr(exchange, "gate", None) is None and hasattr(exchange, "gate"):
+            # an invalid frame of THIS rank (NaN pose, truncated lists) must not travel: its segment is marked instead, every
+            # rank skips the unpack and raises its exchange status — the word the ranks' optimizers are gated on
+            exchange.gate = L.FrameGate(self.gate_sources(), device=self.bg.device)
+        bucket = getattr(exchange, "validity", None)
+        if bucket is not None and bucket.frame_gate is None:
+            bucket.frame_gate = exchange.gate
         return self.capture(warmup=warmup)
 
     def recapture(self, params=None, warmup: int = 1):
@@ -324,6 +349,15 @@ class GraphedTrainStep(GraphedFrame):
             self.proj_steps = sampling_steps(d_nodes, sw.parents)
             self.proj_parents = sw.parents.to(device=bg.device, dtype=torch.int32).clone()
         self.one = torch.ones((), device=bg.device)
+        # A frame that went wrong inside the graph — the pose NaN after a lost PoseMLP hand-off, the lists truncated by an arena
+        # overflow, the depth sort's barrier timed out — must not reach the parameters: the optimizers' launches read the
+        # frame's status words themselves and turn into no-ops (parameters, moments, step counts bit for bit; check() counts
+        # the skipped steps and repairs a lost hand-off by running the iteration once through the layered PoseMLP kernels)
+        self.gate = L.FrameGate(self.gate_sources(), device=bg.device)
+        for o in self.optimizers:
+            o.gate = self.gate
+        self.skipped_steps = 0     # replays the gate turned into no-ops, as of the last check()
+        self.recovered_steps = 0   # iterations re-run eagerly after a lost hand-off
 
     def _frame(self):
         from .loss import image_loss, cal_skeleton_loss
@@ -357,6 +391,33 @@ class GraphedTrainStep(GraphedFrame):
         if params is None:
             params = self.gm.parameters() + [p for g in self.sw.trainable_parameters() for p in g["params"]]
         return super().recapture(params, warmup)
+
+    def check(self):
+        """As ``GraphedFrame.check`` — but here nothing a bad replay computed has reached the parameters (the optimizer
+        launches were gated on the device), so a lost PoseMLP hand-off is REPAIRED instead of raised: the sticky word is
+        cleared and the iteration is run once, eagerly, through the one-launch-per-layer PoseMLP kernels (no hand-off inside a
+        launch); ``skipped_steps`` / ``recovered_steps`` say what happened.  An arena overflow still raises (the graph has to
+        be captured again with a larger arena); the replays since it happened were skipped steps."""
+        self.skipped_steps = self.gate.read_skipped()
+        st = self._pose_status()
+        if st is not None and int(st[0][st[1]].item()) != 0:
+            st[0][st[1]] = 0
+            self._rerun_layered()
+        return super().check()
+
+    def _rerun_layered(self):
+        L.set_option("pose_mlp_layered", 1)
+        try:
+            with torch.cuda.stream(self.stream):
+                self._frame()  # (the current static inputs: the iteration the last replay skipped)
+                torch.cuda.current_stream().synchronize()
+                self.arena.resolve()
+        finally:
+            L.set_option("pose_mlp_layered", 0)
+        for p, g in zip(self.params, self.grads):  # the graph's own gradient buffers stay the parameters' .grad
+            p.grad = g
+        self.mark_all_rows()  # (the eager backward went through the same workspace: the next replay rewrites every row)
+        self.recovered_steps += 1
 
     def run(self, cam: Camera = None, gt_image: torch.Tensor = None, thinned: torch.Tensor = None,
             projection_weight=None):

@@ -32,6 +32,10 @@ class FusedAdam(torch.optim.Adam):
         kw.pop("foreach", None), kw.pop("fused", None)
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, foreach=False)
         self.hip_capturable = bool(capturable)
+        # a frame's "valid" gate (riggs_amd._lib.FrameGate; capturable mode): when any of its device words is raised — the
+        # pose was NaN after a lost PoseMLP hand-off, the instance lists were truncated, the exchange unpacked nothing — the
+        # update is a no-op ON THE DEVICE: parameters, moments and step counts stay bit for bit (GraphedTrainStep sets it)
+        self.gate = None
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -41,7 +45,7 @@ class FusedAdam(torch.optim.Adam):
                 loss = closure()
         by_cfg = {}
         self._gather(by_cfg)
-        _launch(by_cfg, getattr(self, "hip_capturable", False))
+        _launch(by_cfg, getattr(self, "hip_capturable", False), getattr(self, "gate", None))
         return loss
 
     def _gather(self, by_cfg):
@@ -81,13 +85,19 @@ class FusedAdam(torch.optim.Adam):
                 by_cfg.setdefault(key, []).append((p, g, m, v, lr, st["step"]))
 
 
-def _launch(by_cfg, cap):
+def _launch(by_cfg, cap, gate=None):
     lib = L.lib()
     st_ptr = L.stream_ptr()
+    if gate is not None and not cap:
+        raise L.RiggsHipError("a gated FusedAdam keeps its step counts on the device: capturable=True")
+    gs = gate.struct() if gate is not None else None
     if cap:
         steps = [t[5] for items in by_cfg.values() for t in items]
-        if steps:
+        if steps and gate is None:
             torch._foreach_add_(steps, 1.0)  # one multi-tensor launch; the kernels below read the new counts
+        elif steps:  # ... or one launch of the library's that advances them behind the gate (and counts a skipped step)
+            L.check(lib.riggs_adam_steps_advance_gated(len(steps), (C.c_void_p * len(steps))(*[t.data_ptr() for t in steps]),
+                                                       C.byref(gs), gate.skipped.data_ptr(), st_ptr), "riggs_adam_steps_advance_gated")
     for (b1, b2, eps), items in by_cfg.items():
         for i in range(0, len(items), _MAX):
             chunk = items[i:i + _MAX]
@@ -98,6 +108,10 @@ def _launch(by_cfg, cap):
                 lr_host = (C.c_double * n)(*[0.0 if isinstance(t[4], torch.Tensor) else float(t[4]) for t in chunk])
                 lr_dev = (C.c_void_p * n)(*[L.require_cuda_f32("lr", t[4]).data_ptr() if isinstance(t[4], torch.Tensor) else None
                                             for t in chunk])
+            if cap and gate is not None:
+                L.check(lib.riggs_adam_step_gated(n, arr(0), arr(1), arr(2), arr(3), numel, lr_host, arr(5), lr_dev, float(b1),
+                                                  float(b2), float(eps), C.byref(gs), None, 0, st_ptr), "riggs_adam_step_gated")
+            elif cap:
                 L.check(lib.riggs_adam_step_capturable(n, arr(0), arr(1), arr(2), arr(3), numel, lr_host, arr(5), lr_dev,
                                                        float(b1), float(b2), float(eps), st_ptr), "riggs_adam_step_capturable")
             else:
@@ -129,10 +143,15 @@ def step_many(optimizers):
         for o in optimizers:
             o.step()
         return
+    gates = {id(getattr(o, "gate", None)) for o in fused}
+    if len(gates) != 1:  # (optimizers behind different gates keep their own launches)
+        for o in optimizers:
+            o.step()
+        return
     by_cfg = {}
     for o in fused:
         o._gather(by_cfg)
-    _launch(by_cfg, caps.pop())
+    _launch(by_cfg, caps.pop(), getattr(fused[0], "gate", None))
     for o in optimizers:
         if not isinstance(o, FusedAdam):
             o.step()
