@@ -1006,14 +1006,13 @@ int launch_binning(int N, int T, int grid_x, int64_t cap, const uint32_t* order,
   (void)tiles;  // (the rectangles alone say which Gaussians are visible: preprocess_fwd leaves a culled one's empty)
   if (T > 65535) { set_error("image too large: %d tiles (at most 65 535)", T); return 2; }
   char* mem = (char*)table_mem;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0ull;  // (per device: once_per_device)
+  if (once_per_device(attr_done)) {
     // (dynamic + static LDS <= 160 KB: the kernel also has ~1 KB of static scratch for its scans)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bin_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bin_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gbin_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gbin_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
-    attr_done = true;
   }
   if (bin_grouped(N, T)) {
     const GBinPlan p = gbin_plan(N, T, grid_x);

@@ -112,6 +112,22 @@ using namespace riggs;
 
 extern "C" {
 
+// Which frames left their SH colours to the tile sort's scatter launch: riggs_raster_preprocess decides (from process-wide options)
+// and riggs_raster_render must launch the workgroups that do it — a decision re-taken there would disagree when an option changed
+// between the two calls, and then NOTHING would write the colours.  Remembered per geometry arena (the frame's identity between
+// the calls), a few frames deep; a render that finds "deferred" but would not host the job fails instead of compositing garbage.
+struct DeferNote { const void* geom; int deferred; };
+static DeferNote g_defer[16];
+static unsigned g_defer_at = 0;
+static void defer_note(const void* geom, int deferred) {
+  for (auto& d : g_defer) if (d.geom == geom) { d.deferred = deferred; return; }
+  g_defer[g_defer_at++ % 16] = DeferNote{geom, deferred};
+}
+static int defer_lookup(const void* geom) {  // -1: unknown (the arena of a frame more than 16 preprocess calls ago)
+  for (auto& d : g_defer) if (d.geom == geom) return d.deferred;
+  return -1;
+}
+
 int riggs_version(void) { return 100; }
 
 int riggs_prof_count(void) { return PROF_COUNT; }
@@ -252,6 +268,7 @@ int riggs_raster_preprocess(const riggs_raster_cfg* cfg, const float* means3D, c
   {
     const int T = ((a.W + RIGGS_TILE - 1) / RIGGS_TILE) * ((a.H + RIGGS_TILE - 1) / RIGGS_TILE);
     a.defer_color = (shs && binning_hosts_color(N, T, a.M)) ? 1 : 0;
+    defer_note(geom, a.defer_color);
   }
   // counters[0] = R (and [1..3] = 0) is written by the first kernel of the depth sort
   { ProfScope ps(PROF_PREPROCESS_FWD, s); launch_preprocess_fwd(a, s); }
@@ -298,6 +315,10 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
     RIGGS_HIP_CHECK(hipMemsetAsync(img + I.fwd_ctr, 0, 512, s));
   }
   const uint32_t* point_list = (const uint32_t*)(bin + B.point_list);
+  if (defer_lookup(geom) == 1)
+    RIGGS_REQUIRE(binned && binning_hosts_color(N, T, cfg->sh_coeffs),
+                  "riggs_raster_render: riggs_raster_preprocess left this frame's SH colours to the tile sort's scatter launch, but an "
+                  "option (color_side_jobs / bin_grouped) changed since: options must not change between the two calls of a frame");
   if (binned) {
     // stable counting sort by tile (csrc/binning.hip)
     ProfScope ps(PROF_TILE_SORT, s);

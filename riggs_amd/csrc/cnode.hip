@@ -523,12 +523,11 @@ int riggs_cnode_forward(int32_t N, int32_t M, int32_t K, int32_t hyper, int32_t 
   a.weight_logit = node_weight_logit; a.trans = node_trans; a.rot = node_rot; a.scale = node_scale; a.local_rot = local_rot;
   a.d_xyz = d_xyz; a.d_rot = d_rot; a.d_scale = d_scale; a.nn_idx = nn_idx; a.nn_weight = nn_weight; a.nn_dist = nn_dist;
   hipStream_t s = (hipStream_t)stream;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0ull;
+  if (once_per_device(attr_set)) {
 #define CN_ATTR(KK, DD) RIGGS_HIP_CHECK(hipFuncSetAttribute((const void*)cnode_forward_kernel<KK, DD>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
 #define CN_ATTR4(KK) CN_ATTR(KK, 1) CN_ATTR(KK, 2) CN_ATTR(KK, 3) CN_ATTR(KK, 4)
     CN_ATTR4(1) CN_ATTR4(2) CN_ATTR4(3) CN_ATTR4(4) CN_ATTR4(5) CN_ATTR4(6) CN_ATTR4(7) CN_ATTR4(8)
-    attr_set = true;
   }
   switch (K) {
     case 1: cn_launch_forward<1>(a, dp4, s); break;
@@ -601,11 +600,10 @@ int riggs_cnode_backward(int32_t N, int32_t M, int32_t K, int32_t hyper, int32_t
   } else {
     const size_t lds = (size_t)M * a.nacc * sizeof(float);
     RIGGS_REQUIRE(lds <= 160 * 1024 - 1024, "per-node gradient table does not fit LDS (M (21 + hyper_dim) floats <= 159 KB)");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0ull;
+    if (once_per_device(attr_set)) {
 #define CN_BATTR(KK) RIGGS_HIP_CHECK(hipFuncSetAttribute((const void*)cnode_backward_kernel<KK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       CN_BATTR(1) CN_BATTR(2) CN_BATTR(3) CN_BATTR(4) CN_BATTR(5) CN_BATTR(6) CN_BATTR(7) CN_BATTR(8)
-      attr_set = true;
     }
     const int blocks = riggs_cnode_backward_blocks(N, M, hyper);
     const dim3 grid(blocks), block(CN_BWD_THREADS);

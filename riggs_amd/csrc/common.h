@@ -45,6 +45,17 @@ inline int debug_sync(int debug, hipStream_t s, const char* what) {
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
+// Function attributes (hipFuncAttributeMaxDynamicSharedMemorySize ...) are PER DEVICE: a process that drives a second GPU must
+// set them there too.  `done` is a static bitset of the caller, one bit per device ordinal; true the first time on this device.
+static inline bool once_per_device(unsigned long long& done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return true; }
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done & bit) return false;
+  done |= bit;
+  return true;
+}
+
 // ---- library options (riggs_set_option / riggs_get_option in the ABI; process-wide, nothing is read from the environment) ----
 enum OptId { OPT_FWD_WIDE_TILES = 0, OPT_FWD_WIDE_MIN, OPT_BIN_GROUPED, OPT_CNODE_BWD_ATOMICS, OPT_COLOR_SIDE_JOBS, OPT_PREPROCESS_BWD_LEAN, OPT_POSE_MLP_LAYERED, OPT_COUNT };
 int option(int id);

@@ -352,8 +352,8 @@ int riggs_dqb_forward(int32_t N, int32_t K, int32_t shared, int32_t norm_over_no
   a.N = N; a.K = K; a.norm_nodes = norm_over_nodes ? 1 : 0; a.out_mode = out_mode;
   a.q = q; a.t = t; a.w = weights; a.out_rot = out_rot; a.out_t = out_t;
   if (shared) {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dqb_shared_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr = true; }
+    static unsigned long long attr = 0ull;  // (per device)
+    if (once_per_device(attr)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dqb_shared_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     hipLaunchKernelGGL(dqb_shared_fwd_kernel, dim3(dq_shared_grid(N)), dim3(256), dq_shared_lds(K, false), s, a);
   } else {
     const dim3 g((N + 255) / 256);
@@ -388,12 +388,11 @@ int riggs_dqb_backward(int32_t N, int32_t K, int32_t shared, int32_t norm_over_n
   a.n_wg = N > 0 ? dq_shared_grid(N) : 0;
   if (N > 0) {
     RIGGS_REQUIRE(weights && g_rot, "riggs_dqb_backward: NULL argument");
-    static bool attr = false;
-    if (!attr) {
+    static unsigned long long attr = 0ull;
+    if (once_per_device(attr)) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dqb_shared_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dqb_shared_bwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dqb_shared_bwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-      attr = true;
     }
     const size_t lds = dq_shared_lds(K, true);
     if (K <= 64) hipLaunchKernelGGL(dqb_shared_bwd_kernel<1>, dim3(a.n_wg), dim3(256), lds, s, a);

@@ -142,21 +142,30 @@ class _DQBlend(torch.autograd.Function):
         return gq, gt, gw, None, None, None
 
 
+def _blend_general(q, t, weights, out_mode):
+    """Shapes the kernels have no form for — leading batch dimensions beyond one, more than 8 transforms of its own per row —
+    through the composition the reference itself is (:168-179): QT2DQ -> weighted sum over the node axis -> DQ2QT, on the
+    tensors' device with this module's torch helpers.  Not a CPU fallback: device tensors stay on the device."""
+    dq = QT2DQ(q, t)
+    return DQ2QT((dq * weights[..., None]).sum(dim=-2), rot_as_q=(out_mode == 1))
+
+
 def _blend(q, t, weights, out_mode):
     """Shape dispatch of DQBlending: which axis QT2DQ's ``normalize`` hits follows from q's rank, as in the reference."""
-    if weights.dim() != 2:
-        raise NotImplementedError("DQBlending: weights must be (N, K)")
+    if weights.dim() != 2 or not weights.is_cuda:
+        if not weights.is_cuda:
+            raise L.RiggsHipError("DQBlending: CUDA(HIP) tensors required — the product path is GPU-only")
+        return _blend_general(q, t, weights, out_mode)
     N, K = weights.shape
     if q.dim() == 2:                       # (K, 4): shared nodes, per-quaternion normalisation
         return _DQBlend.apply(q, t, weights, True, False, out_mode)
     if q.dim() == 3 and q.shape[0] == 1:   # (1, K, 4): shared nodes, F.normalize on the node axis
         return _DQBlend.apply(q[0], t.reshape(K, 3), weights, True, True, out_mode)
     if q.dim() == 3 and q.shape[0] == N:   # (N, K, 4): every row its own K transforms
-        if K > 8:
-            raise NotImplementedError("DQBlending with per-row transforms: at most 8 per row on the HIP path (use a shared node set)")
+        if K > 8:  # (the rows kernel keeps a row's K transforms in registers: 8 at most)
+            return _blend_general(q, t, weights, out_mode)
         return _DQBlend.apply(q, t, weights, False, True, out_mode)
-    raise NotImplementedError("DQBlending: q must be (K, 4), (1, K, 4) or (N, K, 4) with weights (N, K); got %s / %s"
-                              % (tuple(q.shape), tuple(weights.shape)))
+    return _blend_general(q, t, weights, out_mode)
 
 
 def DQBlending(q, t, weights, rot_as_q=True):

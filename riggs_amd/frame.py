@@ -58,7 +58,7 @@ class _FrameFn(torch.autograd.Function):
         if sync.device != dev or sync.numel() * 4 < lib.riggs_pose_mlp_sync_bytes(depth, width):
             sync = None
         keep = []
-        cfg = _cfg(settings, N, f_dc.shape[1] + f_rest.shape[1], True, isotropic, keep)
+        cfg = _cfg(settings, N, f_dc.shape[1] + f_rest.shape[1], True, isotropic, keep, arena.tight_lists)
         # outputs and saved state: ONE float allocation for the per-joint arrays, the PoseMLP's activations, the residuals and
         # the counters, ONE byte allocation for the two rasterizer arenas (ten torch.empty calls were 29 us of an eager frame;
         # every piece starts on a 256-byte boundary)
@@ -171,9 +171,6 @@ class _FrameFn(torch.autograd.Function):
         return (None, drho, gmask, g_xyz, g_m2d, g_dc, g_rest, g_op, g_sc, g_rot, None, *grads)
 
 
-_ARENAS = {}
-
-
 def _covered(pc, sw, pipe, t, kw):
     if kw or pipe.compute_cov3D_python or pipe.convert_SHs_python or not pc._xyz.is_cuda:
         return False
@@ -194,12 +191,12 @@ def deform_render(viewpoint_camera, pc, sw, pipe, bg_color, scaling_modifier=1.0
     instance arena (riggs_amd.rasterizer.RasterArena); one per Gaussian model is kept here when none is given."""
     sw = getattr(sw, "deform", sw)  # (a SkeletonModel wrapper)
     if arena is None:
-        key = id(pc)
-        arena = _ARENAS.get(key)
-        if arena is None:
-            if len(_ARENAS) >= 4:
-                _ARENAS.pop(next(iter(_ARENAS)))
-            arena = _ARENAS[key] = RasterArena()
+        # (kept ON the model — it is that model's frame-to-frame state and dies with it; a cache keyed by id(pc) would hand a
+        # new model that got a dead one's address an arena with a stale instance count)
+        arena = getattr(pc, "_frame_arena", None)
+        if arena is None or getattr(pc, "_frame_arena_n", None) != pc._xyz.shape[0]:
+            arena = pc._frame_arena = RasterArena()
+            pc._frame_arena_n = pc._xyz.shape[0]  # (densification changed N: the count of the last frame says nothing any more)
     t = sw.expand_time(viewpoint_camera.fid)
     if not _covered(pc, sw, pipe, t, render_kwargs) or arena.last_R < 0:
         dv = sw(pc.get_xyz.detach(), t, motion_mask=pc.motion_mask)

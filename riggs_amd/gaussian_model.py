@@ -334,18 +334,23 @@ class GaussianModel:
     def _groups(self):
         return {g["name"]: g for g in self.optimizer.param_groups}
 
-    def _compact(self, flags):
-        """Ascending int32 indices of the non-zero entries of a uint8 / bool device vector (riggs_compact_indices)."""
+    def _compact(self, *flag_vectors):
+        """Ascending int32 indices of the non-zero entries of uint8 / bool device vectors (riggs_compact_indices): one launch
+        per vector, ONE device->host read for all the counts.  Returns a tensor per vector (the tensor itself for one)."""
         from . import _lib as L
-        f = flags.to(torch.uint8).contiguous()
-        n, dev = f.numel(), f.device
         lib = L.lib()
-        idx = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-        cnt = torch.empty(1, dtype=torch.int32, device=dev)
-        ws = torch.empty(lib.riggs_compact_workspace_bytes(n), dtype=torch.uint8, device=dev)
-        L.check(lib.riggs_compact_indices(n, f.data_ptr(), idx.data_ptr(), cnt.data_ptr(), ws.data_ptr(), L.stream_ptr()),
-                "riggs_compact_indices")
-        return idx[:int(cnt.item())]
+        cnts = torch.empty(len(flag_vectors), dtype=torch.int32, device=flag_vectors[0].device)
+        out = []
+        for k, flags in enumerate(flag_vectors):
+            f = flags.to(torch.uint8).contiguous()
+            n, dev = f.numel(), f.device
+            idx = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+            ws = torch.empty(lib.riggs_compact_workspace_bytes(n), dtype=torch.uint8, device=dev)
+            L.check(lib.riggs_compact_indices(n, f.data_ptr(), idx.data_ptr(), cnts[k:].data_ptr(), ws.data_ptr(), L.stream_ptr()),
+                    "riggs_compact_indices")
+            out.append(idx)
+        out = [idx[:c] for idx, c in zip(out, cnts.tolist())]
+        return out[0] if len(out) == 1 else out
 
     def _regather(self, plan, stats="zero", children=None):
         """The new cloud from an index plan: row m of every tensor comes from row ``plan[m]`` of the old one; ``plan[m] < 0``
@@ -458,8 +463,11 @@ class GaussianModel:
             padded[:grads.shape[0]] = grads.squeeze()
             selected_pts_mask = (padded >= grad_threshold) & (torch.max(self.get_scaling, dim=1).values > self.percent_dense * scene_extent)
         sel = selected_pts_mask.reshape(-1).bool()
-        parents = self._compact(sel)
-        kept = torch.arange(n, dtype=torch.int32, device=parents.device) if without_prune else self._compact(~sel)
+        if without_prune:
+            parents = self._compact(sel)
+            kept = torch.arange(n, dtype=torch.int32, device=parents.device)
+        else:
+            parents, kept = self._compact(sel, ~sel)
         plan = torch.cat([kept] + [~parents] * N)
         self._regather(plan, stats="zero", children=(int(kept.numel()), parents, N, unit_normals))
 
@@ -475,7 +483,7 @@ class GaussianModel:
                                              float(self.percent_dense * extent), float(min_opacity),
                                              float(0.1 * extent) if max_screen_size else -1.0, 1.6, flags.data_ptr(), L.stream_ptr()),
                 "riggs_densify_select")
-        kept, clones, parents = self._compact(flags[0]), self._compact(flags[1]), self._compact(flags[2])
+        kept, clones, parents = self._compact(flags[0], flags[1], flags[2])
         plan = torch.cat([kept, ~clones, ~parents, ~parents])
         self._regather(plan, stats="zero", children=(int(kept.numel() + clones.numel()), parents, 2, unit_normals))
 

@@ -39,8 +39,15 @@ class RasterArena:
     detected when the count is finally read, then the frame is re-rendered with a larger arena.
     """
 
-    def __init__(self, growth: float = 1.25, min_capacity: int = 1 << 16):
+    def __init__(self, growth: float = 1.25, min_capacity: int = 1 << 16, tight_lists: bool = False):
         self.growth = growth
+        # riggs_raster_cfg.tight_lists for the frames rendered through this arena: tile rectangles cut down to the tiles in which
+        # the Gaussian can reach alpha >= 1/255 (its axis-aligned alpha box instead of the ceil(3 sigma) square).  The dropped
+        # instances fail the alpha test at every pixel of their tile, so radii, images and gradients are the canonical ones;
+        # about a fifth fewer instances to sort, stage and walk in a translucent scene.  Off by default: the canonical lists —
+        # upstream's, bit for bit — are what north_star's ordering / indexing parity is stated on.  It travels with the arena
+        # (the frame's persistent state), like ``sparse_grad_rows``; there is no module-wide switch.
+        self.tight_lists = bool(tight_lists)
         self.capacity = 0
         self.min_capacity = min_capacity
         self.binning: Optional[torch.Tensor] = None
@@ -138,7 +145,7 @@ class RasterArena:
         return self.binning
 
 
-def _cfg(settings: GaussianRasterizationSettings, N: int, M: int, glue: bool, isotropic: bool, keep: list):
+def _cfg(settings: GaussianRasterizationSettings, N: int, M: int, glue: bool, isotropic: bool, keep: list, tight_lists: bool = False):
     dev = settings.viewmatrix.device
     bg = settings.bg
     bg = L.require_cuda_f32("bg", (bg if bg.device == dev else bg.to(dev)).reshape(-1), (3,))
@@ -160,21 +167,11 @@ def _cfg(settings: GaussianRasterizationSettings, N: int, M: int, glue: bool, is
     c.glue = 1 if glue else 0
     c.isotropic = 1 if isotropic else 0
     c.deterministic = 1 if ORDERED_BACKWARD else 0
-    c.tight_lists = 1 if TIGHT_LISTS else 0
+    c.tight_lists = 1 if tight_lists else 0
     return c
 
 
 ORDERED_BACKWARD = False
-TIGHT_LISTS = False
-
-
-def set_tight_lists(on: bool = True):
-    """riggs_raster_cfg.tight_lists for rasterizations started after the call: tile rectangles cut down to the tiles in which
-    the Gaussian can reach alpha >= 1/255 (its axis-aligned alpha box instead of the 3-sigma square).  The dropped instances fail
-    the alpha test at every pixel of their tile, so images and gradients are unchanged to rounding; about a fifth fewer instances
-    to sort, stage and walk in a translucent scene.  Off by default: the canonical lists are what the ordering tests pin."""
-    global TIGHT_LISTS
-    TIGHT_LISTS = bool(on)
 
 
 def set_ordered_backward(on: bool = True):
@@ -193,15 +190,18 @@ class _Saved:
 
 def rasterize_forward(settings, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                       d_xyz=None, d_rotation=None, d_scaling=None, glue=False, isotropic=False,
-                      arena: Optional[RasterArena] = None, shs_rest=None):
-    """Runs both forward stages.  Returns (color, radii, depth, alpha, saved-state)."""
+                      arena: Optional[RasterArena] = None, shs_rest=None, tight_lists: Optional[bool] = None):
+    """Runs both forward stages.  Returns (color, radii, depth, alpha, saved-state).  ``tight_lists``: riggs_raster_cfg.tight_lists
+    for this frame (default: the arena's setting; False without an arena — see ``RasterArena``)."""
+    if tight_lists is None:
+        tight_lists = arena is not None and arena.tight_lists
     lib = L.lib()
     N = means3D.shape[0]
     dev = means3D.device
     H, W = int(settings.image_height), int(settings.image_width)
     M = 0 if shs is None else shs.shape[1] + (0 if shs_rest is None else shs_rest.shape[1])
     keep = []
-    cfg = _cfg(settings, N, M, glue, isotropic, keep)
+    cfg = _cfg(settings, N, M, glue, isotropic, keep, tight_lists)
     geom = torch.empty(lib.riggs_raster_geom_bytes(N), dtype=torch.uint8, device=dev)
     img = torch.empty(lib.riggs_raster_image_bytes(H, W), dtype=torch.uint8, device=dev)
     radii = torch.empty(N, dtype=torch.int32, device=dev)

@@ -46,12 +46,12 @@ def oracle_forward(act, cam, bg, sh_degree=3, colors=None, cov6=None, mod=1.0):
                       cov3D_precomp=None if cov6 is None else cov6.numpy(), sh_degree=sh_degree, scale_modifier=mod)
 
 
-def hip_forward(act, cam, bg, sh_degree=3, colors=None, cov6=None, mod=1.0, debug=True):
+def hip_forward(act, cam, bg, sh_degree=3, colors=None, cov6=None, mod=1.0, debug=True, tight_lists=False):
     d = lambda t: None if t is None else t.cuda().contiguous()  # noqa: E731
     st = settings_for(cam, bg, sh_degree, mod, debug)
     return rasterize_forward(st, d(act["means3D"]), None if colors is not None else d(act["shs"]), d(colors),
                              d(act["opacities"]), None if cov6 is not None else d(act["scales"]),
-                             None if cov6 is not None else d(act["rotations"]), d(cov6))
+                             None if cov6 is not None else d(act["rotations"]), d(cov6), tight_lists=tight_lists)
 
 
 def frac_bad(a, b, rel=REL_TOL):

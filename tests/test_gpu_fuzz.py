@@ -40,12 +40,11 @@ def test_random_configuration_matches_the_oracle(seed):
     act["shs"] = act["shs"][:, :M].contiguous()
     out_o, so = U.oracle_forward(act, cam, c["bg"], sh_degree=c["deg"])
     try:
-        RZ.set_tight_lists(c["tight"])
         RZ.set_ordered_backward(c["ordered"])
         L.set_option("color_side_jobs", int(c["jobs"]))
         L.set_option("bin_grouped", int(c["grouped"]))
         L.set_option("preprocess_bwd_lean", c["lean"])
-        color, radii, depth, alpha, s = U.hip_forward(act, cam, c["bg"], sh_degree=c["deg"])
+        color, radii, depth, alpha, s = U.hip_forward(act, cam, c["bg"], sh_degree=c["deg"], tight_lists=c["tight"])
         v = saved_views(s)
         assert np.array_equal(radii.cpu().numpy(), so.radii), c
         if not c["tight"]:
@@ -77,7 +76,6 @@ def test_random_configuration_matches_the_oracle(seed):
             row = int(np.prod(want.shape[1:])) if want.ndim > 1 else 1
             U.assert_close(got.cpu().numpy().reshape(want.shape), want, "dL/d%s %s" % (name, c), 1e-4, max(1e-4, 2.0 * row / want.size))
     finally:
-        RZ.set_tight_lists(False)
         RZ.set_ordered_backward(False)
         L.set_option("color_side_jobs", 1)
         L.set_option("bin_grouped", -1)
@@ -180,12 +178,11 @@ def test_random_captured_frame_equals_the_eager_frame(seed):
     gm2, sw2 = copy.deepcopy(gm), copy.deepcopy(sw)
     bg = torch.zeros(3, device="cuda")
     try:
-        RZ.set_tight_lists(tight)
         L.set_option("color_side_jobs", int(jobs))
         L.set_option("preprocess_bwd_lean", lean)
-        gf = GraphedFrame(gm, sw, cam, bg, bench.params_of(gm, sw), sparse_grad_rows=sparse).capture()
+        gf = GraphedFrame(gm, sw, cam, bg, bench.params_of(gm, sw), sparse_grad_rows=sparse, tight_lists=tight).capture()
         where = gf.arena.binning.data_ptr()
-        arena2 = RasterArena()
+        arena2 = RasterArena(tight_lists=tight)
         g = torch.Generator().manual_seed(seed)
         for k in range(4):
             c = synth.look_at_camera(H, W, azimuth_deg=float(r.uniform(0, 360)), elevation_deg=float(r.uniform(-40, 60)),
@@ -205,6 +202,5 @@ def test_random_captured_frame_equals_the_eager_frame(seed):
                 torch.testing.assert_close(ga, gb, rtol=2e-4, atol=3e-6 * float(gb.abs().max()) + 1e-12)
         assert gf.arena.binning.data_ptr() == where
     finally:
-        RZ.set_tight_lists(False)
         L.set_option("color_side_jobs", 1)
         L.set_option("preprocess_bwd_lean", -1)

@@ -394,7 +394,7 @@ def test_colour_job_of_the_tile_sort_equals_the_colours_of_preprocess(case, deg,
 
 @pytest.mark.parametrize("case,opacity_scale", [(1, 1.0), (2, 0.05), (5, 1.0), (4, 0.3)])
 def test_tight_lists_are_the_canonical_lists_minus_the_instances_that_cannot_reach_a_pixel(case, opacity_scale):
-    """cfg.tight_lists (rasterizer.set_tight_lists): the tile rectangle of a Gaussian is cut down by its alpha >= 1/255 box.
+    """cfg.tight_lists (RasterArena(tight_lists=True) / rasterize_forward(tight_lists=True)): the tile rectangle of a Gaussian is cut down by its alpha >= 1/255 box.
     Contract: radii unchanged; the instance list = the CANONICAL list (the oracle's key sort) with the instances outside the box
     removed, order kept — bit for bit, the predicate evaluated here in float32 from the extents the kernel stored; no instance
     that reaches alpha >= 1/255 at a pixel centre of its tile (float64 truth) is ever dropped; image, depth, alpha and every
@@ -406,9 +406,9 @@ def test_tight_lists_are_the_canonical_lists_minus_the_instances_that_cannot_rea
     bg = [0.1, 0.3, 0.7]
     out_o, so = U.oracle_forward(act, cam, bg)
     c_color, c_radii, c_depth, c_alpha, c_s = U.hip_forward(act, cam, bg)
-    RZ.set_tight_lists(True)
+    assert c_s.cfg.tight_lists == 0
     try:
-        color, radii, depth, alpha, s = U.hip_forward(act, cam, bg)
+        color, radii, depth, alpha, s = U.hip_forward(act, cam, bg, tight_lists=True)
         assert s.cfg.tight_lists == 1
         v = saved_views(s)
         g = torch.Generator().manual_seed(seed)
@@ -419,7 +419,7 @@ def test_tight_lists_are_the_canonical_lists_minus_the_instances_that_cannot_rea
         gh = rasterize_backward(s, d(act["means3D"]), d(act["shs"]), None, d(act["opacities"]), d(act["scales"]), d(act["rotations"]),
                                 None, None, None, d(gc), d(gd), d(ga))
     finally:
-        RZ.set_tight_lists(False)
+        pass
     assert torch.equal(radii, c_radii) and np.array_equal(radii.cpu().numpy(), so.radii)
     gx = (W + 15) // 16
     xyd, rgbh = v["xyd"].cpu().numpy(), v["rgb"].cpu().numpy()
