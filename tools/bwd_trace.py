@@ -1,5 +1,5 @@
 """Per-chunk timeline of the compositing backward on the bench workload.
-usage: python tools/bwd_trace.py"""
+usage: python tools/bwd_trace.py [dense]"""
 import os
 import sys
 
@@ -14,6 +14,11 @@ from riggs_amd.rasterizer import RasterArena  # noqa: E402
 
 w = bench.WORKLOAD
 sc, cam, gm, sw = bench.build_workload(0, "cuda:0")
+if len(sys.argv) > 1 and sys.argv[1] == "dense":
+    from riggs_amd import synth
+    from riggs_amd.gaussian_model import GaussianModel
+    sc = synth.make_surface_scene(w["N"], w["J"], w["seed"])
+    gm = GaussianModel.from_tensors(sc["xyz"], sc["features_dc"], sc["features_rest"], sc["scaling"], sc["rotation"], sc["opacity"], device="cuda:0")
 T = ((w["W"] + 15) // 16) * ((w["H"] + 15) // 16)
 NB = 1 << 16  # room for the backward's chunks
 trace = torch.zeros(T * 256 + NB * 4, dtype=torch.int64, device="cuda")
