@@ -639,8 +639,11 @@ int riggs_raster_set_trace_items(uint64_t n_items);
  * within 1-2 % of the fp32 arithmetic instead of 3-11 %, same rate; its range is the caller's business — see g_scale).
  * x_emb_bf16 (N rounded up to 128, in_pad) bf16, zero padded -> depth x [Linear(256) + ReLU], the embedding
  * re-concatenated IN FRONT of the hidden vector after layer `skip` (network_utils.py:58-61, 103-106) -> Linear(out_ch <= 32).
- * weights_bf16[l]: (256, K_l) row-major bf16 with K_0 = in_pad, K_{skip+1} = in_pad + 256, else 256, where
- * in_pad = in_ch rounded up to 32 and the padding columns are zero; w_out_bf16: (32, 256), rows >= out_ch zero.
+ * weights_bf16[l]: the 256 x K_l weights (K_0 = in_pad, K_{skip+1} = in_pad + 256 with the embedding columns first, else 256;
+ * in_pad = in_ch rounded up to 32, padding columns zero) in the kernels' FRAGMENT-MAJOR order — [neuron tile T of 32][K-step s
+ * of 16][lane 0..63][8 values], value j of a lane = W[32 T + (lane & 31)][16 s + 8 (lane >> 5) + j]: the 1 KB a wave loads per
+ * (tile, step) is one contiguous run; w_out_bf16: the head alike, one tile of 32 outputs (>= out_ch zero) x 16 steps.
+ * riggs_mlp_pack produces all of them from the fp32 masters; no caller needs to know the order.
  * acts_bf16 (depth, N, 256) receives the post-ReLU activations (operand of the weight gradients) and relu_masks
  * (depth, ceil(N / riggs_mlp_rows_per_workgroup()), 256) x 16 bytes their signs in the kernels' accumulator layout, for
  * riggs_mlp_backward (both NULL for inference).
@@ -652,8 +655,9 @@ int riggs_mlp_forward(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, i
                       int32_t fp16, riggs_stream stream);
 /* Data-gradient pass of the same MLP: g_out (N, out_ch) = dL/d(output) -> dpre_bf16 (depth, N, 256) = dL/d(pre-activation)
  * of every hidden layer, the operand of the weight gradients  dW_l = dpre_l^T · input_l ,  db_l = sum_n dpre_l  (plain
- * GEMMs / reductions, left to the library).  weights_t_bf16[l] (l >= 1): (256, 256) = W_l[:, hidden part]^T;
- * w_out_t_bf16: (256, 32) = W_out^T with zero columns >= out_ch.  No gradient w.r.t. x_emb (detached in the reference).
+ * GEMMs / reductions, left to the library).  weights_t_bf16[l] (l >= 1): W_l[:, hidden part]^T (rows = the units of layer
+ * l - 1), 256 x 256 values, fragment-major as above; w_out_t_bf16: W_out^T (rows = hidden units, 32 padded outputs as
+ * inputs), fragment-major.  No gradient w.r.t. x_emb (detached in the reference).
  * g_scale (device scalar, may be NULL = 1): g_out is multiplied by it on load, so dpre and db_partial come out scaled by it —
  * with fp16 the caller passes a power of two that lifts max|g_out| to ~2^10 (loss-scaled gradients: a per-pixel-averaged
  * loss leaves |g_out| ~ 1e-7, below half precision's normal range) and divides the parameter gradients by it. */

@@ -7,13 +7,16 @@
 // bf16 operands, fp32 accumulation (v_mfma_f32_32x32x16_bf16): the reference computes in fp32, so this path is
 // opt-in and its parity bar is the bf16 one ("parity tolerance must be renegotiated for bf16").
 //
-// Forward: a workgroup owns 64 rows (Gaussians).  The hidden vector of those rows lives in LDS as bf16
-// [64][256 (+pad)], the embedding as bf16 [64][in_pad (+pad)]; a layer is  H <- relu(H W^T + b)  with the weights
-// streamed from L2 (128 KB per layer, shared by all workgroups).  Wave w computes output columns [64 w, 64 w + 64)
-// of all 64 rows: 2 x 2 tiles of 32 x 32, K in steps of 16; A fragments (8 consecutive k of one row) are 16-byte LDS
-// reads, B fragments (8 consecutive k of one output column = 16 contiguous bytes of a weight row) are 16-byte global
-// loads.  The post-ReLU activations go back to LDS (in place, behind a barrier) and — for the backward — to HBM as
-// bf16 with full-line stores.
+// Forward: a workgroup owns 128 rows (Gaussians).  The hidden vector of those rows lives in LDS as 16-bit
+// [128][256 (+pad)]; a layer is  H^T <- relu(W H^T + b)  — the product is formed TRANSPOSED: the weights are the
+// MFMA's A operand (rows = output neurons), the hidden vectors its B operand (columns = Gaussians).  Wave w computes
+// neurons [64 w, 64 w + 64) of all 128 Gaussians: 2 x 4 tiles of 32 x 32, K in steps of 16.  The weights are stored
+// FRAGMENT-MAJOR (riggs_mlp_pack): the 64 x 16 bytes a wave loads for (neuron tile, K-step) are one contiguous 1 KB run
+// — eight cache lines per load instruction instead of a 16-byte piece of each of 32 weight rows (32 lines), which kept
+// the texture path as busy as the matrix pipe; the hidden fragments (8 consecutive k of one Gaussian) are 16-byte LDS
+// reads.  In the transposed accumulator a lane holds four CONSECUTIVE neurons of one Gaussian per register group, so the
+// post-ReLU activations go back to LDS as 8-byte stores (32 per lane and layer instead of 128 two-byte ones), in place,
+// behind a barrier, and — for the backward — to HBM as 16-bit values with full-line stores.
 //
 // Backward (data gradient): the same tiling with the transposed weights,  dH_{l-1} = (dH_l * relu'(H_l)) W_l ;
 // every layer's masked gradient is stored as bf16 for the weight gradients, which are plain (256 x N)·(N x K) GEMMs
@@ -56,95 +59,119 @@ template <bool H16> __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b,
 
 struct MlpDesc {
   int N, in_ch, in_pad, out_ch, depth, skip;
-  const unsigned short* Wp[10];   // packed bf16 weights, layer l: [256][K_l], K_0 = in_pad, K_{skip+1} = in_pad + 256, else 256
+  const unsigned short* Wp[10];   // packed 16-bit weights of layer l, FRAGMENT-MAJOR (below): 8 neuron tiles x K_l / 16 steps x 512,
+                                  // K_0 = in_pad, K_{skip+1} = in_pad + 256 (embedding columns first), else 256
   const float* bias[10];          // [256]
-  const unsigned short* Wout;     // [32][256] (rows >= out_ch are zero)
+  const unsigned short* Wout;     // the head, fragment-major: 1 tile (outputs >= out_ch are zero) x 16 steps x 512
   const float* bout;              // [out_ch]
 };
 
 __device__ __forceinline__ int mlp_k(const MlpDesc& d, int l) { return l == 0 ? d.in_pad : (l == d.skip + 1 ? d.in_pad + MLP_W : MLP_W); }
 
-// acc[rt][ct] += A(rows 32 rt .. +31, k) * B(k, cols col0 + 32 ct .. +31) over k in [0, K): A from LDS (row stride
-// `as` bf16), B[k][n] = Wrow[n][k] with row stride `ws` bf16 in global memory
-template <int RT, int CT, bool H16>
-__device__ __forceinline__ void mlp_gemm_part(f32x16 (&acc)[RT][CT], const unsigned short* A, int as, const unsigned short* Wg,
-                                              int ws, int K, int lane) {
+// Fragment-major weights: for neuron tile T (32 neurons) and K-step s (16 inputs) the wave's A operand is the 1 KB run
+//   Wf[((T * S + s) * 64 + lane) * 8 + j] = W[32 T + (lane & 31)][16 s + 8 (lane >> 5) + j],   S = K / 16 K-steps of the layer
+// (riggs_mlp_pack writes it; the transposed copies of the backward alike).
+#define MLP_FRAG 512  // 16-bit values per (tile, K-step) fragment block
+
+// acc[nt][gt] += Wtile(nt, k) * H(gaussian tile gt, k)^T over `steps` K-steps: the weights (A operand) from their
+// fragment-major run `Wf` (this wave's first tile at its first step; `tile_stride` values between neuron tiles), the hidden
+// vectors (B operand: 8 consecutive k of one Gaussian) from `Bsrc` (LDS or the embedding copy), row stride `bs`
+template <int NT, int GT, bool H16>
+__device__ __forceinline__ void mlp_gemm_t(f32x16 (&acc)[NT][GT], const unsigned short* __restrict__ Wf, size_t tile_stride,
+                                           const unsigned short* Bsrc, int bs, int steps, int lane) {
   const int r = lane & 31, kq = (lane >> 5) * 8;
   // software-pipelined by one K-step: the fragments of step k + 1 are requested before the MFMAs of step k are issued
-  // (two waves per SIMD cannot hide an L2 round trip per step on their own)
-  bf16x8 a[RT], b[CT], an[RT], bn[CT];
+  bf16x8 a[NT], b[GT], an[NT], bn[GT];
+  const unsigned short* wl = Wf + lane * 8;
 #pragma unroll
-  for (int rt = 0; rt < RT; rt++) a[rt] = *reinterpret_cast<const bf16x8*>(A + (size_t)(32 * rt + r) * as + kq);
+  for (int nt = 0; nt < NT; nt++) a[nt] = *reinterpret_cast<const bf16x8*>(wl + nt * tile_stride);
 #pragma unroll
-  for (int ct = 0; ct < CT; ct++) b[ct] = *reinterpret_cast<const bf16x8*>(Wg + (size_t)(32 * ct + r) * ws + kq);
-  for (int k0 = 0; k0 < K; k0 += 16) {
-    const int kn = (k0 + 16 < K) ? k0 + 16 : k0;  // (the last trip re-reads its own step: harmless, keeps the loop branch-free)
+  for (int gt = 0; gt < GT; gt++) b[gt] = *reinterpret_cast<const bf16x8*>(Bsrc + (size_t)(32 * gt + r) * bs + kq);
+  for (int s = 0; s < steps; s++) {
+    const int sn = (s + 1 < steps) ? s + 1 : s;  // (the last trip re-reads its own step: harmless, keeps the loop branch-free)
 #pragma unroll
-    for (int ct = 0; ct < CT; ct++) bn[ct] = *reinterpret_cast<const bf16x8*>(Wg + (size_t)(32 * ct + r) * ws + kn + kq);
+    for (int nt = 0; nt < NT; nt++) an[nt] = *reinterpret_cast<const bf16x8*>(wl + nt * tile_stride + (size_t)sn * MLP_FRAG);
 #pragma unroll
-    for (int rt = 0; rt < RT; rt++) an[rt] = *reinterpret_cast<const bf16x8*>(A + (size_t)(32 * rt + r) * as + kn + kq);
+    for (int gt = 0; gt < GT; gt++) bn[gt] = *reinterpret_cast<const bf16x8*>(Bsrc + (size_t)(32 * gt + r) * bs + 16 * sn + kq);
 #pragma unroll
-    for (int rt = 0; rt < RT; rt++)
+    for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-      for (int ct = 0; ct < CT; ct++) acc[rt][ct] = mfma16<H16>(a[rt], b[ct], acc[rt][ct]);
+      for (int gt = 0; gt < GT; gt++) acc[nt][gt] = mfma16<H16>(a[nt], b[gt], acc[nt][gt]);
 #pragma unroll
-    for (int rt = 0; rt < RT; rt++) a[rt] = an[rt];
+    for (int nt = 0; nt < NT; nt++) a[nt] = an[nt];
 #pragma unroll
-    for (int ct = 0; ct < CT; ct++) b[ct] = bn[ct];
+    for (int gt = 0; gt < GT; gt++) b[gt] = bn[gt];
   }
 }
 
 // C/D layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 __device__ __forceinline__ int mlp_c_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
-template <int RT, bool H16>  // 32-row tiles per workgroup (rows per workgroup = 32 RT); every wave owns 64 output columns of all of them
-__global__ __launch_bounds__(256, RT == 2 ? 3 : 2) void mlp_forward_kernel(MlpDesc d, const unsigned short* __restrict__ xb,
+// one lane's post-activation values of a tile group -> LDS: four CONSECUTIVE neurons of one Gaussian, 8 bytes
+__device__ __forceinline__ void mlp_store4(unsigned short* dst, unsigned short v0, unsigned short v1, unsigned short v2, unsigned short v3) {
+  *reinterpret_cast<uint2*>(dst) = make_uint2((uint32_t)v0 | ((uint32_t)v1 << 16), (uint32_t)v2 | ((uint32_t)v3 << 16));
+}
+
+template <int GT, bool H16>  // 32-Gaussian tiles per workgroup (rows per workgroup = 32 GT); every wave owns 64 neurons for all of them
+__global__ __launch_bounds__(256, GT == 2 ? 3 : 2) void mlp_forward_kernel(MlpDesc d, const unsigned short* __restrict__ xb,
                                                                             unsigned short* __restrict__ acts /* [depth][N][256] or NULL */,
                                                                             uint4* __restrict__ masks /* [depth][workgroups][256] or NULL */,
                                                                             float* __restrict__ out /* [N][out_ch] */) {
-  constexpr int ROWS = 32 * RT;
+  constexpr int ROWS = 32 * GT;
   __shared__ unsigned short s_h[ROWS * MLP_HS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = blockIdx.x * ROWS;
-  // the embedding is read from its bf16 copy in HBM ((rows rounded up to 128) x in_pad, zero padded): it is an A operand
+  // the embedding is read from its 16-bit copy in HBM ((rows rounded up to 128) x in_pad, zero padded): it is an operand
   // of two layers only, and keeping it out of LDS lets two 128-row workgroups share a CU
   const unsigned short* xrow = xb + (size_t)row0 * d.in_pad;
-  const int col0 = wave * 64;
+  const int n0 = wave * 64;                 // this wave's first neuron
+  const int emb_steps = d.in_pad >> 4;
   for (int l = 0; l < d.depth; l++) {
-    f32x16 acc[RT][2];
+    f32x16 acc[2][GT];
 #pragma unroll
-    for (int rt = 0; rt < RT; rt++)
+    for (int nt = 0; nt < 2; nt++)
 #pragma unroll
-      for (int ct = 0; ct < 2; ct++)
+      for (int gt = 0; gt < GT; gt++)
 #pragma unroll
-        for (int e = 0; e < 16; e++) acc[rt][ct][e] = 0.f;
-    const int K = mlp_k(d, l);
-    const unsigned short* Wl = d.Wp[l] + (size_t)col0 * K;
-    if (l == 0) mlp_gemm_part<RT, 2, H16>(acc, xrow, d.in_pad, Wl, K, d.in_pad, lane);
+        for (int e = 0; e < 16; e++) acc[nt][gt][e] = 0.f;
+    const int S = mlp_k(d, l) >> 4;         // K-steps of the layer
+    const size_t ts = (size_t)S * MLP_FRAG;  // values between neuron tiles
+    const unsigned short* Wl = d.Wp[l] + (size_t)(2 * wave) * ts;
+    if (l == 0) mlp_gemm_t<2, GT, H16>(acc, Wl, ts, xrow, d.in_pad, emb_steps, lane);
     else if (l == d.skip + 1) {
-      mlp_gemm_part<RT, 2, H16>(acc, xrow, d.in_pad, Wl, K, d.in_pad, lane);
-      mlp_gemm_part<RT, 2, H16>(acc, s_h, MLP_HS, Wl + d.in_pad, K, MLP_W, lane);
-    } else mlp_gemm_part<RT, 2, H16>(acc, s_h, MLP_HS, Wl, K, MLP_W, lane);
+      mlp_gemm_t<2, GT, H16>(acc, Wl, ts, xrow, d.in_pad, emb_steps, lane);
+      mlp_gemm_t<2, GT, H16>(acc, Wl + (size_t)emb_steps * MLP_FRAG, ts, s_h, MLP_HS, MLP_W >> 4, lane);
+    } else mlp_gemm_t<2, GT, H16>(acc, Wl, ts, s_h, MLP_HS, MLP_W >> 4, lane);
     __syncthreads();  // every wave is done reading the previous hidden vector
-    uint32_t mbits[4] = {0u, 0u, 0u, 0u};  // ReLU mask of this lane's accumulator elements: bit (rt * 2 + ct) * 16 + e
+    uint32_t mbits[GT] ;  // ReLU mask of this lane's accumulator elements: word gt, bit nt * 16 + e
 #pragma unroll
-    for (int ct = 0; ct < 2; ct++) {
-      const int col = col0 + 32 * ct + (lane & 31);
-      const float b = d.bias[l][col];
+    for (int gt = 0; gt < GT; gt++) mbits[gt] = 0u;
+    const int g_in_tile = lane & 31, nq = 4 * (lane >> 5);
 #pragma unroll
-      for (int rt = 0; rt < RT; rt++)
+    for (int nt = 0; nt < 2; nt++) {
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-          const int row = 32 * rt + mlp_c_row(e, lane);
-          const float v = acc[rt][ct][e] + b;
-          const unsigned short hv = f2h<H16>(fmaxf(v, 0.f));
-          s_h[row * MLP_HS + col] = hv;
-          if ((hv & 0x7FFFu) != 0u) mbits[(rt * 2 + ct) >> 1] |= 1u << ((((rt * 2 + ct) & 1) << 4) + e);
+      for (int q = 0; q < 4; q++) {          // register group q: neurons n0 + 32 nt + 8 q + nq .. + 3
+        const int nb = n0 + 32 * nt + 8 * q + nq;
+        const float4 b = *reinterpret_cast<const float4*>(d.bias[l] + nb);
+#pragma unroll
+        for (int gt = 0; gt < GT; gt++) {
+          unsigned short hv[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const float bj = j == 0 ? b.x : (j == 1 ? b.y : (j == 2 ? b.z : b.w));
+            hv[j] = f2h<H16>(fmaxf(acc[nt][gt][4 * q + j] + bj, 0.f));
+            if ((hv[j] & 0x7FFFu) != 0u) mbits[gt] |= 1u << (16 * nt + 4 * q + j);
+          }
+          mlp_store4(s_h + (size_t)(32 * gt + g_in_tile) * MLP_HS + nb, hv[0], hv[1], hv[2], hv[3]);
         }
+      }
     }
     // (the data-gradient kernel uses the same tiling, so the mask travels in the accumulator layout: 16 bytes per lane
     // and layer instead of re-reading the layer's activations)
-    if (masks) masks[((size_t)l * gridDim.x + blockIdx.x) * 256 + tid] = make_uint4(mbits[0], mbits[1], mbits[2], mbits[3]);
+    if (masks) {
+      static_assert(GT == 4, "the mask record is one uint4 per lane: four Gaussian tiles");
+      masks[((size_t)l * gridDim.x + blockIdx.x) * 256 + tid] = make_uint4(mbits[0], mbits[1], mbits[2], mbits[3]);
+    }
     __syncthreads();
     if (acts) {  // full-line stores of the layer's activations (operand of the weight gradients)
       unsigned short* dst = acts + ((size_t)l * d.N + row0) * MLP_W;
@@ -155,21 +182,23 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 2) void mlp_forward_kernel(MlpDe
       }
     }
   }
-  // output head: 32 RT rows x 32 (padded) columns, K = 256: wave w < RT takes the 32-row tile w
-  if (wave < RT) {
-    f32x16 acc[1][1];
+  // output head: 32 (padded) outputs x 32 GT Gaussians, K = 256: wave w < GT takes the Gaussian tile w; the results meet in
+  // LDS (the hidden vector's storage, free behind a barrier) and leave as one contiguous run of the workgroup's rows
+  f32x16 hacc[1][1];
 #pragma unroll
-    for (int e = 0; e < 16; e++) acc[0][0][e] = 0.f;
-    mlp_gemm_part<1, 1, H16>(acc, s_h + (size_t)(32 * wave) * MLP_HS, MLP_HS, d.Wout, MLP_W, MLP_W, lane);
-    const int col = lane & 31;
-    if (col < d.out_ch) {
-      const float b = d.bout[col];
+  for (int e = 0; e < 16; e++) hacc[0][0][e] = 0.f;
+  if (wave < GT) mlp_gemm_t<1, 1, H16>(hacc, d.Wout, 0, s_h + (size_t)(32 * wave) * MLP_HS, MLP_HS, MLP_W >> 4, lane);
+  __syncthreads();
+  float* s_out = reinterpret_cast<float*>(s_h);  // [ROWS][33]
+  if (wave < GT) {
 #pragma unroll
-      for (int e = 0; e < 16; e++) {
-        const int row = row0 + 32 * wave + mlp_c_row(e, lane);
-        if (row < d.N) out[(size_t)row * d.out_ch + col] = acc[0][0][e] + b;
-      }
-    }
+    for (int e = 0; e < 16; e++) s_out[(32 * wave + (lane & 31)) * 33 + mlp_c_row(e, lane)] = hacc[0][0][e];
+  }
+  __syncthreads();
+  const int n_rows = min(ROWS, d.N - row0);
+  for (int e = tid; e < n_rows * d.out_ch; e += 256) {
+    const int r = e / d.out_ch, c = e - r * d.out_ch;
+    out[(size_t)row0 * d.out_ch + e] = s_out[r * 33 + c] + d.bout[c];
   }
 }
 
@@ -180,17 +209,18 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 2) void mlp_forward_kernel(MlpDe
 // n contiguous).  No gradient leaves the first layer: both heads' inputs are detached in the reference.
 struct MlpBwdDesc {
   int N, out_ch, depth, skip;
-  const unsigned short* Wt[10];   // l >= 1: [256 (k)][256 (n)] bf16 = W_l[:, hidden part]^T
-  const unsigned short* Wout_t;   // [256 (k)][32 (c)] bf16, columns >= out_ch zero
+  const unsigned short* Wt[10];   // l >= 1: W_l[:, hidden part]^T (rows = units k of layer l - 1, inputs = neurons n), fragment-major: 8 x 16 x 512
+  const unsigned short* Wout_t;   // the head transposed (rows = hidden units, inputs = 32 padded outputs), fragment-major: 8 x 2 x 512
 };
 
-template <int RT, bool H16>
-__global__ __launch_bounds__(256, RT == 2 ? 3 : 2) void mlp_backward_kernel(MlpBwdDesc d, const float* __restrict__ g_out,
+template <int GT, bool H16>
+__global__ __launch_bounds__(256, GT == 2 ? 3 : 2) void mlp_backward_kernel(MlpBwdDesc d, const float* __restrict__ g_out,
                                                            const float* __restrict__ g_scale /* device scalar or NULL */,
                                                            const uint4* __restrict__ masks /* [depth][workgroups][256], from the forward */,
                                                            unsigned short* __restrict__ dpre /* [depth][N][256] */,
                                                            float* __restrict__ db_part /* [workgroups][depth][256] */) {
-  constexpr int ROWS = 32 * RT;
+  constexpr int ROWS = 32 * GT;
+  static_assert(GT == 4, "the mask record is one uint4 per lane: four Gaussian tiles");
   __shared__ unsigned short s_d[ROWS * MLP_HS];
   __shared__ unsigned short s_g[ROWS * 40];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -203,33 +233,38 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 2) void mlp_backward_kernel(MlpB
     s_g[r * 40 + c] = f2h<H16>(v);
   }
   __syncthreads();
-  const int col0 = wave * 64;
+  const int k0 = wave * 64;  // this wave's first hidden unit (of the layer below)
+  const int g_in_tile = lane & 31, nq = 4 * (lane >> 5);
   for (int l = d.depth - 1; l >= 0; l--) {
-    // ---- d_post_l for this wave's 64 columns
-    f32x16 acc[RT][2];
+    // ---- d_post_l for this wave's 64 units, transposed like the forward: A = the transposed weights (rows = units of layer
+    // l, fragment-major), B = the gradient above (8 consecutive units of one Gaussian, LDS)
+    f32x16 acc[2][GT];
 #pragma unroll
-    for (int rt = 0; rt < RT; rt++)
+    for (int nt = 0; nt < 2; nt++)
 #pragma unroll
-      for (int ct = 0; ct < 2; ct++)
+      for (int gt = 0; gt < GT; gt++)
 #pragma unroll
-        for (int e = 0; e < 16; e++) acc[rt][ct][e] = 0.f;
-    if (l == d.depth - 1) mlp_gemm_part<RT, 2, H16>(acc, s_g, 40, d.Wout_t + (size_t)col0 * 32, 32, 32, lane);
-    else mlp_gemm_part<RT, 2, H16>(acc, s_d, MLP_HS, d.Wt[l + 1] + (size_t)col0 * MLP_W, MLP_W, MLP_W, lane);
+        for (int e = 0; e < 16; e++) acc[nt][gt][e] = 0.f;
+    if (l == d.depth - 1) mlp_gemm_t<2, GT, H16>(acc, d.Wout_t + (size_t)(2 * wave) * (2 * MLP_FRAG), 2 * MLP_FRAG, s_g, 40, 2, lane);
+    else mlp_gemm_t<2, GT, H16>(acc, d.Wt[l + 1] + (size_t)(2 * wave) * (16 * MLP_FRAG), 16 * MLP_FRAG, s_d, MLP_HS, MLP_W >> 4, lane);
     __syncthreads();  // every wave is done reading d_pre_{l+1}
     // ---- d_pre_l = d_post_l where the forward's activation was positive (mask bits in this lane's accumulator layout)
     const uint4 mk = masks[((size_t)l * gridDim.x + blockIdx.x) * 256 + tid];
     const uint32_t mbits[4] = {mk.x, mk.y, mk.z, mk.w};
 #pragma unroll
-    for (int ct = 0; ct < 2; ct++) {
-      const int col = col0 + 32 * ct + (lane & 31);
+    for (int nt = 0; nt < 2; nt++)
 #pragma unroll
-      for (int rt = 0; rt < RT; rt++) {
-        const uint32_t m16 = mbits[(rt * 2 + ct) >> 1] >> (((rt * 2 + ct) & 1) << 4);
+      for (int q = 0; q < 4; q++) {
+        const int nb = k0 + 32 * nt + 8 * q + nq;
 #pragma unroll
-        for (int e = 0; e < 16; e++)
-          s_d[(32 * rt + mlp_c_row(e, lane)) * MLP_HS + col] = ((m16 >> e) & 1u) ? f2h<H16>(acc[rt][ct][e]) : (unsigned short)0;
+        for (int gt = 0; gt < GT; gt++) {
+          const uint32_t m4 = mbits[gt] >> (16 * nt + 4 * q);
+          unsigned short hv[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) hv[j] = ((m4 >> j) & 1u) ? f2h<H16>(acc[nt][gt][4 * q + j]) : (unsigned short)0;
+          mlp_store4(s_d + (size_t)(32 * gt + g_in_tile) * MLP_HS + nb, hv[0], hv[1], hv[2], hv[3]);
+        }
       }
-    }
     __syncthreads();
     // ---- out to HBM (operand of the weight gradients), full lines
     unsigned short* dl = dpre + ((size_t)l * d.N + row0) * MLP_W;
@@ -289,22 +324,26 @@ struct MlpPackDesc {
   int in_ch, in_pad, out_ch, depth, skip;
   const float* W[10];            // (256, K_true): K_true = in_ch, in_ch + 256 (layer skip + 1) or 256
   const float* Wout;             // (out_ch, 256)
-  unsigned short* Wp[10];        // (256, K_pad)
-  unsigned short* Wt[10];        // l >= 1: (256 k, 256 n) = hidden part transposed
-  unsigned short* Wout_p;        // (32, 256)
-  unsigned short* Wout_t;        // (256, 32)
+  unsigned short* Wp[10];        // 256 x K_pad values, fragment-major
+  unsigned short* Wt[10];        // l >= 1: the hidden part transposed, 256 x 256 values, fragment-major
+  unsigned short* Wout_p;        // 32 x 256 values, fragment-major
+  unsigned short* Wout_t;        // 256 x 32 values, fragment-major
 };
+// value j of lane `lane` of the fragment block (tile T, step st) of a matrix with rows r and inputs k: row 32 T + (lane & 31),
+// input 16 st + 8 (lane >> 5) + j
 template <bool H16>
 __global__ __launch_bounds__(256) void mlp_pack_kernel(MlpPackDesc d) {
   const int l = blockIdx.y;  // depth = the head
   const int tid = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
   if (l == d.depth) {
-    for (int e = tid; e < 32 * MLP_W; e += stride) {
-      const int c = e / MLP_W, k = e - c * MLP_W;
+    for (int e = tid; e < 16 * MLP_FRAG; e += stride) {           // Wout: 1 tile x 16 steps
+      const int st = e / MLP_FRAG, w = e - st * MLP_FRAG, lane = w >> 3, j = w & 7;
+      const int c = lane & 31, k = 16 * st + 8 * (lane >> 5) + j;
       d.Wout_p[e] = f2h<H16>(c < d.out_ch ? d.Wout[(size_t)c * MLP_W + k] : 0.f);
     }
-    for (int e = tid; e < MLP_W * 32; e += stride) {
-      const int k = e >> 5, c = e & 31;
+    for (int e = tid; e < 8 * 2 * MLP_FRAG; e += stride) {         // Wout^T: 8 tiles (hidden units) x 2 steps (32 padded outputs)
+      const int T = e / (2 * MLP_FRAG), rem = e - T * (2 * MLP_FRAG), st = rem / MLP_FRAG, w = rem - st * MLP_FRAG, lane = w >> 3, j = w & 7;
+      const int k = 32 * T + (lane & 31), c = 16 * st + 8 * (lane >> 5) + j;
       d.Wout_t[e] = f2h<H16>(c < d.out_ch ? d.Wout[(size_t)c * MLP_W + k] : 0.f);
     }
     return;
@@ -314,16 +353,19 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(MlpPackDesc d) {
   const int k_pad = first ? d.in_pad : (sk ? d.in_pad + MLP_W : MLP_W);
   const int hoff_true = sk ? d.in_ch : 0, hoff_pad = sk ? d.in_pad : 0;  // where the hidden part starts
   const float* W = d.W[l];
-  for (int e = tid; e < MLP_W * k_pad; e += stride) {
-    const int n = e / k_pad, k = e - n * k_pad;
+  const int S = k_pad >> 4;
+  for (int e = tid; e < MLP_W * k_pad; e += stride) {              // W_l: 8 tiles x S steps
+    const int T = e / (S * MLP_FRAG), rem = e - T * (S * MLP_FRAG), st = rem / MLP_FRAG, w = rem - st * MLP_FRAG, lane = w >> 3, j = w & 7;
+    const int n = 32 * T + (lane & 31), k = 16 * st + 8 * (lane >> 5) + j;
     float v = 0.f;
     if (first || (sk && k < hoff_pad)) { if (k < d.in_ch) v = W[(size_t)n * k_true + k]; }
     else v = W[(size_t)n * k_true + hoff_true + (k - hoff_pad)];
     d.Wp[l][e] = f2h<H16>(v);
   }
   if (!first)
-    for (int e = tid; e < MLP_W * MLP_W; e += stride) {
-      const int k = e >> 8, n = e & 255;
+    for (int e = tid; e < MLP_W * MLP_W; e += stride) {            // (hidden part of W_l)^T: 8 tiles (units k) x 16 steps (neurons n)
+      const int T = e / (16 * MLP_FRAG), rem = e - T * (16 * MLP_FRAG), st = rem / MLP_FRAG, w = rem - st * MLP_FRAG, lane = w >> 3, j = w & 7;
+      const int k = 32 * T + (lane & 31), n = 16 * st + 8 * (lane >> 5) + j;
       d.Wt[l][e] = f2h<H16>(W[(size_t)n * k_true + hoff_true + k]);
     }
 }
@@ -359,7 +401,7 @@ int riggs_mlp_layout_probe(float* out32x32, riggs_stream stream) {
   return 0;
 }
 
-// 128-row workgroups: 4 x 2 tiles of 32 x 32 per wave (64-row workgroups with 2 x 2 tiles cost 0.84 / 1.01 ms against
+// 128-row workgroups: 2 (neuron) x 4 (Gaussian) tiles of 32 x 32 per wave (64-row workgroups cost 0.84 / 1.01 ms against
 // 0.66 / 0.63 ms: twice the weight loads per MFMA)
 #define MLP_RT 4
 

@@ -63,6 +63,14 @@ class Packed:
         self._wtp = (C.c_void_p * self.depth)(*[(t.data_ptr() if t is not None else None) for t in self.wt])
         self.repack()
 
+    def rows(self, l: int) -> torch.Tensor:
+        """Layer ``l``'s packed weights back in row-major (256, K_pad) order (tests, debugging): the kernels' copy is
+        FRAGMENT-MAJOR — [neuron tile T][K-step s][lane][8 values] with value j of lane = W[32 T + (lane & 31)][16 s + 8 (lane >> 5) + j]
+        (csrc/mlp.hip: one contiguous 1 KB run per wave load)."""
+        w = self.w[l]
+        S = w.shape[1] // 16
+        return w.reshape(8, S, 2, 32, 8).permute(0, 3, 1, 2, 4).reshape(256, S * 16)
+
     def repack(self):
         ws = [L.require_cuda_f32("weight", lin.weight.detach()) for lin in self.linears]
         wo = L.require_cuda_f32("head weight", self.head.weight.detach())

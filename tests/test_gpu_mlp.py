@@ -193,4 +193,4 @@ def test_fused_heads_inside_a_captured_training_iteration():
     assert all(v == v and v < 10 for v in losses)
     assert float((w1 - w0).abs().max()) > 1e-4                       # the captured optimizer moved the masters
     pk = sw._fh_w._pk                                                 # the bf16 copy the LAST replay used = masters before its own step
-    assert float((pk.w[2][:, :256].float() - w1).abs().max()) < 2e-3   # within one Adam step (5e-4) + bf16 rounding of the masters
+    assert float((pk.rows(2)[:, :256].float() - w1).abs().max()) < 2e-3   # within one Adam step (5e-4) + bf16 rounding of the masters
