@@ -76,15 +76,9 @@ __device__ __forceinline__ int mlp_k(const MlpDesc& d, int l) { return l == 0 ? 
 // acc[nt][gt] += Wtile(nt, k) * H(gaussian tile gt, k)^T over `steps` K-steps: the weights (A operand) from their
 // fragment-major run `Wf` (this wave's first tile at its first step; `tile_stride` values between neuron tiles), the hidden
 // vectors (B operand: 8 consecutive k of one Gaussian) from `Bsrc` (LDS or the embedding copy), row stride `bs`
-// `cdst` (optional): while the product runs, the workgroup also streams the B operand's 32 GT rows x 256 values — the layer
-// output that sits in LDS (`Bsrc`, row stride MLP_HS) — to HBM as full lines, one 16-byte piece per thread and K-step: the
-// stores of a layer's activations / gradients (operands of the weight gradients: 1.2 GB per MLP and direction at 300k rows,
-// a quarter of a millisecond of pure HBM writing) then overlap the matrix pipe instead of sitting between two barriers.
-// 16 K-steps x 256 threads = the 4096 pieces of 128 rows.
 template <int NT, int GT, bool H16>
 __device__ __forceinline__ void mlp_gemm_t(f32x16 (&acc)[NT][GT], const unsigned short* __restrict__ Wf, size_t tile_stride,
-                                           const unsigned short* Bsrc, int bs, int steps, int lane,
-                                           unsigned short* __restrict__ cdst = nullptr, int crows = 0) {
+                                           const unsigned short* Bsrc, int bs, int steps, int lane) {
   const int r = lane & 31, kq = (lane >> 5) * 8;
   // software-pipelined by one K-step: the fragments of step k + 1 are requested before the MFMAs of step k are issued
   bf16x8 a[NT], b[GT], an[NT], bn[GT];
@@ -95,10 +89,6 @@ __device__ __forceinline__ void mlp_gemm_t(f32x16 (&acc)[NT][GT], const unsigned
   for (int gt = 0; gt < GT; gt++) b[gt] = *reinterpret_cast<const bf16x8*>(Bsrc + (size_t)(32 * gt + r) * bs + kq);
   for (int s = 0; s < steps; s++) {
     const int sn = (s + 1 < steps) ? s + 1 : s;  // (the last trip re-reads its own step: harmless, keeps the loop branch-free)
-    if (cdst) {
-      const int e = s * 256 + (int)threadIdx.x, cr = e >> 5, c8 = e & 31;
-      if (cr < crows) *reinterpret_cast<bf16x8*>(cdst + (size_t)cr * MLP_W + 8 * c8) = *reinterpret_cast<const bf16x8*>(Bsrc + (size_t)cr * bs + 8 * c8);
-    }
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) an[nt] = *reinterpret_cast<const bf16x8*>(wl + nt * tile_stride + (size_t)sn * MLP_FRAG);
 #pragma unroll
@@ -147,14 +137,11 @@ __global__ __launch_bounds__(256, GT == 2 ? 3 : 2) void mlp_forward_kernel(MlpDe
     const int S = mlp_k(d, l) >> 4;         // K-steps of the layer
     const size_t ts = (size_t)S * MLP_FRAG;  // values between neuron tiles
     const unsigned short* Wl = d.Wp[l] + (size_t)(2 * wave) * ts;
-    // (the previous layer's activations leave for HBM under this layer's product over them)
-    unsigned short* cdst = (acts && l > 0) ? acts + ((size_t)(l - 1) * d.N + row0) * MLP_W : nullptr;
-    const int crows = min(ROWS, d.N - row0);
     if (l == 0) mlp_gemm_t<2, GT, H16>(acc, Wl, ts, xrow, d.in_pad, emb_steps, lane);
     else if (l == d.skip + 1) {
       mlp_gemm_t<2, GT, H16>(acc, Wl, ts, xrow, d.in_pad, emb_steps, lane);
-      mlp_gemm_t<2, GT, H16>(acc, Wl + (size_t)emb_steps * MLP_FRAG, ts, s_h, MLP_HS, MLP_W >> 4, lane, cdst, crows);
-    } else mlp_gemm_t<2, GT, H16>(acc, Wl, ts, s_h, MLP_HS, MLP_W >> 4, lane, cdst, crows);
+      mlp_gemm_t<2, GT, H16>(acc, Wl + (size_t)emb_steps * MLP_FRAG, ts, s_h, MLP_HS, MLP_W >> 4, lane);
+    } else mlp_gemm_t<2, GT, H16>(acc, Wl, ts, s_h, MLP_HS, MLP_W >> 4, lane);
     __syncthreads();  // every wave is done reading the previous hidden vector
     uint32_t mbits[GT] ;  // ReLU mask of this lane's accumulator elements: word gt, bit nt * 16 + e
 #pragma unroll
@@ -186,31 +173,21 @@ __global__ __launch_bounds__(256, GT == 2 ? 3 : 2) void mlp_forward_kernel(MlpDe
       masks[((size_t)l * gridDim.x + blockIdx.x) * 256 + tid] = make_uint4(mbits[0], mbits[1], mbits[2], mbits[3]);
     }
     __syncthreads();
+    if (acts) {  // full-line stores of the layer's activations (operand of the weight gradients)
+      unsigned short* dst = acts + ((size_t)l * d.N + row0) * MLP_W;
+      for (int e = tid; e < ROWS * (MLP_W / 8); e += 256) {
+        const int r = e / (MLP_W / 8), c8 = e - r * (MLP_W / 8);
+        if (row0 + r < d.N)
+          *reinterpret_cast<bf16x8*>(dst + (size_t)r * MLP_W + 8 * c8) = *reinterpret_cast<const bf16x8*>(s_h + r * MLP_HS + 8 * c8);
+      }
+    }
   }
   // output head: 32 (padded) outputs x 32 GT Gaussians, K = 256: wave w < GT takes the Gaussian tile w; the results meet in
   // LDS (the hidden vector's storage, free behind a barrier) and leave as one contiguous run of the workgroup's rows
   f32x16 hacc[1][1];
 #pragma unroll
   for (int e = 0; e < 16; e++) hacc[0][0][e] = 0.f;
-  // (the last hidden layer's activations leave under the head's product: every wave of the workgroup runs it — GT = 4 waves)
-  static_assert(GT == 4, "one wave per Gaussian tile in the head");
-  {
-    // the side copy walks ALL rows of the workgroup, so it is handed the hidden vector's base, not this wave's tile: the
-    // product's own B operand is offset by hand
-    const int crows = min(ROWS, d.N - row0);
-    unsigned short* cdst = acts ? acts + ((size_t)(d.depth - 1) * d.N + row0) * MLP_W : nullptr;
-    const int r = lane & 31, kq = (lane >> 5) * 8;
-    const unsigned short* hb = s_h + (size_t)(32 * wave) * MLP_HS;
-    for (int st = 0; st < (MLP_W >> 4); st++) {
-      if (cdst) {
-        const int e = st * 256 + tid, cr = e >> 5, c8 = e & 31;
-        if (cr < crows) *reinterpret_cast<bf16x8*>(cdst + (size_t)cr * MLP_W + 8 * c8) = *reinterpret_cast<const bf16x8*>(s_h + (size_t)cr * MLP_HS + 8 * c8);
-      }
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(d.Wout + (size_t)st * MLP_FRAG + lane * 8);
-      const bf16x8 b = *reinterpret_cast<const bf16x8*>(hb + (size_t)r * MLP_HS + 16 * st + kq);
-      hacc[0][0] = mfma16<H16>(a, b, hacc[0][0]);
-    }
-  }
+  if (wave < GT) mlp_gemm_t<1, 1, H16>(hacc, d.Wout, 0, s_h + (size_t)(32 * wave) * MLP_HS, MLP_HS, MLP_W >> 4, lane);
   __syncthreads();
   float* s_out = reinterpret_cast<float*>(s_h);  // [ROWS][33]
   if (wave < GT) {
@@ -268,11 +245,8 @@ __global__ __launch_bounds__(256, GT == 2 ? 3 : 2) void mlp_backward_kernel(MlpB
       for (int gt = 0; gt < GT; gt++)
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[nt][gt][e] = 0.f;
-    // (the gradient of the layer above leaves for HBM — operand of the weight gradients, full lines — under this product over it)
-    const int crows = min(ROWS, d.N - row0);
     if (l == d.depth - 1) mlp_gemm_t<2, GT, H16>(acc, d.Wout_t + (size_t)(2 * wave) * (2 * MLP_FRAG), 2 * MLP_FRAG, s_g, 40, 2, lane);
-    else mlp_gemm_t<2, GT, H16>(acc, d.Wt[l + 1] + (size_t)(2 * wave) * (16 * MLP_FRAG), 16 * MLP_FRAG, s_d, MLP_HS, MLP_W >> 4, lane,
-                                dpre + ((size_t)(l + 1) * d.N + row0) * MLP_W, crows);
+    else mlp_gemm_t<2, GT, H16>(acc, d.Wt[l + 1] + (size_t)(2 * wave) * (16 * MLP_FRAG), 16 * MLP_FRAG, s_d, MLP_HS, MLP_W >> 4, lane);
     __syncthreads();  // every wave is done reading d_pre_{l+1}
     // ---- d_pre_l = d_post_l where the forward's activation was positive (mask bits in this lane's accumulator layout)
     const uint4 mk = masks[((size_t)l * gridDim.x + blockIdx.x) * 256 + tid];
@@ -292,13 +266,12 @@ __global__ __launch_bounds__(256, GT == 2 ? 3 : 2) void mlp_backward_kernel(MlpB
         }
       }
     __syncthreads();
-    if (l == 0) {  // (no product follows the first layer's gradient: it leaves here)
-      unsigned short* dl = dpre + (size_t)row0 * MLP_W;
-      for (int e = tid; e < ROWS * (MLP_W / 8); e += 256) {
-        const int r = e / (MLP_W / 8), c8 = e - r * (MLP_W / 8);
-        if (row0 + r < d.N)
-          *reinterpret_cast<bf16x8*>(dl + (size_t)r * MLP_W + 8 * c8) = *reinterpret_cast<const bf16x8*>(s_d + r * MLP_HS + 8 * c8);
-      }
+    // ---- out to HBM (operand of the weight gradients), full lines
+    unsigned short* dl = dpre + ((size_t)l * d.N + row0) * MLP_W;
+    for (int e = tid; e < ROWS * (MLP_W / 8); e += 256) {
+      const int r = e / (MLP_W / 8), c8 = e - r * (MLP_W / 8);
+      if (row0 + r < d.N)
+        *reinterpret_cast<bf16x8*>(dl + (size_t)r * MLP_W + 8 * c8) = *reinterpret_cast<const bf16x8*>(s_d + r * MLP_HS + 8 * c8);
     }
     // bias gradient of the layer: this workgroup's column sums (thread = column; summed over the workgroups in a fixed
     // order by the caller — deterministic, and cheaper than a column reduction of the (N, 256) tensor)
