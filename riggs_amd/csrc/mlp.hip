@@ -76,31 +76,46 @@ __device__ __forceinline__ int mlp_k(const MlpDesc& d, int l) { return l == 0 ? 
 // acc[nt][gt] += Wtile(nt, k) * H(gaussian tile gt, k)^T over `steps` K-steps: the weights (A operand) from their
 // fragment-major run `Wf` (this wave's first tile at its first step; `tile_stride` values between neuron tiles), the hidden
 // vectors (B operand: 8 consecutive k of one Gaussian) from `Bsrc` (LDS or the embedding copy), row stride `bs`
+// The weights come from L2 (a layer's 128 KB stay there, shared by every workgroup): ~1000 shader cycles per load, against
+// 256 cycles of MFMA work per K-step and wave — one step of look-ahead left every step waiting for its fragments (a layer
+// took 8 us per workgroup where its MFMAs need 1.7).  MLP_PF steps are kept in flight in a ring of registers (the hidden
+// fragments come from LDS: one step ahead is enough for them).
+#define MLP_PF 4
 template <int NT, int GT, bool H16>
 __device__ __forceinline__ void mlp_gemm_t(f32x16 (&acc)[NT][GT], const unsigned short* __restrict__ Wf, size_t tile_stride,
                                            const unsigned short* Bsrc, int bs, int steps, int lane) {
   const int r = lane & 31, kq = (lane >> 5) * 8;
-  // software-pipelined by one K-step: the fragments of step k + 1 are requested before the MFMAs of step k are issued
-  bf16x8 a[NT], b[GT], an[NT], bn[GT];
+  bf16x8 aq[MLP_PF][NT], b[GT], bn[GT];
   const unsigned short* wl = Wf + lane * 8;
+  const int last = steps - 1;
 #pragma unroll
-  for (int nt = 0; nt < NT; nt++) a[nt] = *reinterpret_cast<const bf16x8*>(wl + nt * tile_stride);
+  for (int p = 0; p < MLP_PF; p++)
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) aq[p][nt] = *reinterpret_cast<const bf16x8*>(wl + nt * tile_stride + (size_t)min(p, last) * MLP_FRAG);
 #pragma unroll
   for (int gt = 0; gt < GT; gt++) b[gt] = *reinterpret_cast<const bf16x8*>(Bsrc + (size_t)(32 * gt + r) * bs + kq);
-  for (int s = 0; s < steps; s++) {
-    const int sn = (s + 1 < steps) ? s + 1 : s;  // (the last trip re-reads its own step: harmless, keeps the loop branch-free)
+  for (int s0 = 0; s0 < steps; s0 += MLP_PF) {
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++) an[nt] = *reinterpret_cast<const bf16x8*>(wl + nt * tile_stride + (size_t)sn * MLP_FRAG);
+    for (int u = 0; u < MLP_PF; u++) {
+      const int s = s0 + u;
+      if (s < steps) {  // (wave-uniform; steps is a multiple of MLP_PF everywhere but in the backward's two-step head product)
+        const int sn = min(s + 1, last), sp = min(s + MLP_PF, last);  // (past the end: re-reads of the last step, harmless)
 #pragma unroll
-    for (int gt = 0; gt < GT; gt++) bn[gt] = *reinterpret_cast<const bf16x8*>(Bsrc + (size_t)(32 * gt + r) * bs + 16 * sn + kq);
+        for (int gt = 0; gt < GT; gt++) bn[gt] = *reinterpret_cast<const bf16x8*>(Bsrc + (size_t)(32 * gt + r) * bs + 16 * sn + kq);
+        bf16x8 a[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++)
+        for (int nt = 0; nt < NT; nt++) {
+          a[nt] = aq[u][nt];
+          aq[u][nt] = *reinterpret_cast<const bf16x8*>(wl + nt * tile_stride + (size_t)sp * MLP_FRAG);
+        }
 #pragma unroll
-      for (int gt = 0; gt < GT; gt++) acc[nt][gt] = mfma16<H16>(a[nt], b[gt], acc[nt][gt]);
+        for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++) a[nt] = an[nt];
+          for (int gt = 0; gt < GT; gt++) acc[nt][gt] = mfma16<H16>(a[nt], b[gt], acc[nt][gt]);
 #pragma unroll
-    for (int gt = 0; gt < GT; gt++) b[gt] = bn[gt];
+        for (int gt = 0; gt < GT; gt++) b[gt] = bn[gt];
+      }
+    }
   }
 }
 
