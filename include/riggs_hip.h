@@ -640,7 +640,7 @@ int riggs_raster_set_trace_items(uint64_t n_items);
  * x_emb_bf16 (N rounded up to 128, in_pad) bf16, zero padded -> depth x [Linear(256) + ReLU], the embedding
  * re-concatenated IN FRONT of the hidden vector after layer `skip` (network_utils.py:58-61, 103-106) -> Linear(out_ch <= 32).
  * weights_bf16[l]: the 256 x K_l weights (K_0 = in_pad, K_{skip+1} = in_pad + 256 with the embedding columns first, else 256;
- * in_pad = in_ch rounded up to 32, padding columns zero) in the kernels' FRAGMENT-MAJOR order — [neuron tile T of 32][K-step s
+ * in_pad = in_ch rounded up to 64, padding columns zero) in the kernels' FRAGMENT-MAJOR order — [neuron tile T of 32][K-step s
  * of 16][lane 0..63][8 values], value j of a lane = W[32 T + (lane & 31)][16 s + 8 (lane >> 5) + j]: the 1 KB a wave loads per
  * (tile, step) is one contiguous run; w_out_bf16: the head alike, one tile of 32 outputs (>= out_ch zero) x 16 steps.
  * riggs_mlp_pack produces all of them from the fp32 masters; no caller needs to know the order.
@@ -673,7 +673,7 @@ int riggs_mlp_pack(int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip, c
                    void* const* weights_bf16, void* const* weights_t_bf16, void* w_out_bf16, void* w_out_t_bf16,
                    int32_t fp16, riggs_stream stream);
 /* The kernels' input operand from positions: row n = [x_n, sin(2^k x_n), cos(2^k x_n) for k < multires, tail (n_tail floats,
- * the same for every row: DeformMLP's pose), 0 ...] as bf16, (N rounded up to 128) x (width rounded up to 32)
+ * the same for every row: DeformMLP's pose), 0 ...] as bf16, (N rounded up to 128) x (width rounded up to 64)
  * (utils/time_utils.py:208-256 get_embedder + the concatenation of network_utils.py:40-46). */
 int riggs_mlp_embed(int32_t N, int32_t multires, int32_t n_tail, const float* x, const float* tail, void* out_bf16,
                     int32_t fp16, riggs_stream stream);

@@ -83,39 +83,100 @@ __device__ __forceinline__ int mlp_k(const MlpDesc& d, int l) { return l == 0 ? 
 #define MLP_PF 4
 template <int NT, int GT, bool H16>
 __device__ __forceinline__ void mlp_gemm_t(f32x16 (&acc)[NT][GT], const unsigned short* __restrict__ Wf, size_t tile_stride,
-                                           const unsigned short* Bsrc, int bs, int steps, int lane) {
+                                           const unsigned short* Bsrc, int bs, int steps /* a multiple of MLP_PF */, int lane) {
   const int r = lane & 31, kq = (lane >> 5) * 8;
-  bf16x8 aq[MLP_PF][NT], b[GT], bn[GT];
+  bf16x8 aq[MLP_PF][NT], bq[2][GT];  // the weight ring; the hidden fragments ping-pong (MLP_PF is even: static parity)
   const unsigned short* wl = Wf + lane * 8;
+  const unsigned short* bl = Bsrc + (size_t)r * bs + kq;
   const int last = steps - 1;
 #pragma unroll
   for (int p = 0; p < MLP_PF; p++)
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++) aq[p][nt] = *reinterpret_cast<const bf16x8*>(wl + nt * tile_stride + (size_t)min(p, last) * MLP_FRAG);
+    for (int nt = 0; nt < NT; nt++) aq[p][nt] = *reinterpret_cast<const bf16x8*>(wl + nt * tile_stride + (size_t)p * MLP_FRAG);
 #pragma unroll
-  for (int gt = 0; gt < GT; gt++) b[gt] = *reinterpret_cast<const bf16x8*>(Bsrc + (size_t)(32 * gt + r) * bs + kq);
+  for (int gt = 0; gt < GT; gt++) bq[0][gt] = *reinterpret_cast<const bf16x8*>(bl + (size_t)(32 * gt) * bs);
   for (int s0 = 0; s0 < steps; s0 += MLP_PF) {
 #pragma unroll
     for (int u = 0; u < MLP_PF; u++) {
       const int s = s0 + u;
-      if (s < steps) {  // (wave-uniform; steps is a multiple of MLP_PF everywhere but in the backward's two-step head product)
-        const int sn = min(s + 1, last), sp = min(s + MLP_PF, last);  // (past the end: re-reads of the last step, harmless)
+      const int sn = min(s + 1, last), sp = min(s + MLP_PF, last);  // (past the end: re-reads of the last step, harmless)
 #pragma unroll
-        for (int gt = 0; gt < GT; gt++) bn[gt] = *reinterpret_cast<const bf16x8*>(Bsrc + (size_t)(32 * gt + r) * bs + 16 * sn + kq);
-        bf16x8 a[NT];
+      for (int gt = 0; gt < GT; gt++) bq[(u + 1) & 1][gt] = *reinterpret_cast<const bf16x8*>(bl + (size_t)(32 * gt) * bs + 16 * sn);
 #pragma unroll
-        for (int nt = 0; nt < NT; nt++) {
-          a[nt] = aq[u][nt];
-          aq[u][nt] = *reinterpret_cast<const bf16x8*>(wl + nt * tile_stride + (size_t)sp * MLP_FRAG);
-        }
+      for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-        for (int nt = 0; nt < NT; nt++)
+        for (int gt = 0; gt < GT; gt++) acc[nt][gt] = mfma16<H16>(aq[u][nt], bq[u & 1][gt], acc[nt][gt]);
 #pragma unroll
-          for (int gt = 0; gt < GT; gt++) acc[nt][gt] = mfma16<H16>(a[nt], b[gt], acc[nt][gt]);
-#pragma unroll
-        for (int gt = 0; gt < GT; gt++) b[gt] = bn[gt];
-      }
+      for (int nt = 0; nt < NT; nt++) aq[u][nt] = *reinterpret_cast<const bf16x8*>(wl + nt * tile_stride + (size_t)sp * MLP_FRAG);
     }
+  }
+}
+// The product over a hidden layer (K = 256: sixteen steps, the hidden fragments from LDS) with the weight ring OUT OF THE
+// COMPILER'S HANDS.  hipcc sinks every global load to just in front of its first use (it minimises live ranges): the ring
+// above compiles to load - s_waitcnt vmcnt(0) - MFMA, an L2 round trip (~1000 cycles) in front of every 256 cycles of matrix
+// work.  Here the loads are issued by inline asm and waited for with a counted s_waitcnt vmcnt(6) — the six loads of the three
+// steps behind the one consumed stay in flight — the CDNA form of cp.async / wait_group.  Straight-line code (STEPS is a
+// template argument): no loop-carried copies of registers whose load has not landed; every wait names its two destinations
+// as "+v", so the MFMAs that read them cannot be scheduled above it.  The loop holds NO other vector-memory operation (the
+// hidden fragments are LDS reads: lgkmcnt), so the count is exact; compiler-issued operations before it are older and only
+// make the first waits more conservative.
+#define MLP_GLOAD(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+#define MLP_WAIT2(n, a, b) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(a), "+v"(b))
+template <int STEPS, int GT, bool H16>
+__device__ __forceinline__ void mlp_gemm_hidden(f32x16 (&acc)[2][GT], const unsigned short* __restrict__ Wf, size_t tile_stride,
+                                                const unsigned short* Bsrc, int bs, int lane) {
+  static_assert(STEPS % MLP_PF == 0 && STEPS >= 2 * MLP_PF && MLP_PF == 4, "the wait counts below are written out for a ring of four");
+  const int r = lane & 31, kq = (lane >> 5) * 8;
+  bf16x8 aq[MLP_PF][2], bq[2][GT];
+  const unsigned short* w0 = Wf + lane * 8;
+  const unsigned short* w1 = w0 + tile_stride;
+  const unsigned short* bl = Bsrc + (size_t)r * bs + kq;
+#pragma unroll
+  for (int p = 0; p < MLP_PF; p++) {
+    MLP_GLOAD(aq[p][0], w0 + (size_t)p * MLP_FRAG);
+    MLP_GLOAD(aq[p][1], w1 + (size_t)p * MLP_FRAG);
+  }
+#pragma unroll
+  for (int gt = 0; gt < GT; gt++) bq[0][gt] = *reinterpret_cast<const bf16x8*>(bl + (size_t)(32 * gt) * bs);
+#pragma unroll
+  for (int s = 0; s < STEPS; s++) {
+    const int u = s & (MLP_PF - 1);
+    // loads younger than this step's: two per step still ahead in the ring
+    const int ahead = (STEPS - 1 - s) < (MLP_PF - 1) ? (STEPS - 1 - s) : (MLP_PF - 1);
+    if (ahead == 3) MLP_WAIT2(6, aq[u][0], aq[u][1]);
+    else if (ahead == 2) MLP_WAIT2(4, aq[u][0], aq[u][1]);
+    else if (ahead == 1) MLP_WAIT2(2, aq[u][0], aq[u][1]);
+    else MLP_WAIT2(0, aq[u][0], aq[u][1]);
+    if (s + 1 < STEPS) {
+#pragma unroll
+      for (int gt = 0; gt < GT; gt++) bq[(s + 1) & 1][gt] = *reinterpret_cast<const bf16x8*>(bl + (size_t)(32 * gt) * bs + 16 * (s + 1));
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+      for (int gt = 0; gt < GT; gt++) acc[nt][gt] = mfma16<H16>(aq[u][nt], bq[s & 1][gt], acc[nt][gt]);
+    if (s + MLP_PF < STEPS) {  // the slot just consumed takes the step four ahead
+      MLP_GLOAD(aq[u][0], w0 + (size_t)(s + MLP_PF) * MLP_FRAG);
+      MLP_GLOAD(aq[u][1], w1 + (size_t)(s + MLP_PF) * MLP_FRAG);
+    }
+  }
+}
+
+// the backward's head product: two K-steps (32 padded outputs), no ring
+template <int NT, int GT, bool H16>
+__device__ __forceinline__ void mlp_gemm_small(f32x16 (&acc)[NT][GT], const unsigned short* __restrict__ Wf, size_t tile_stride,
+                                               const unsigned short* Bsrc, int bs, int steps, int lane) {
+  const int r = lane & 31, kq = (lane >> 5) * 8;
+  for (int s = 0; s < steps; s++) {
+    bf16x8 a[NT], b[GT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) a[nt] = *reinterpret_cast<const bf16x8*>(Wf + lane * 8 + nt * tile_stride + (size_t)s * MLP_FRAG);
+#pragma unroll
+    for (int gt = 0; gt < GT; gt++) b[gt] = *reinterpret_cast<const bf16x8*>(Bsrc + (size_t)(32 * gt + r) * bs + 16 * s + kq);
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+      for (int gt = 0; gt < GT; gt++) acc[nt][gt] = mfma16<H16>(a[nt], b[gt], acc[nt][gt]);
   }
 }
 
@@ -155,8 +216,8 @@ __global__ __launch_bounds__(256, GT == 2 ? 3 : 2) void mlp_forward_kernel(MlpDe
     if (l == 0) mlp_gemm_t<2, GT, H16>(acc, Wl, ts, xrow, d.in_pad, emb_steps, lane);
     else if (l == d.skip + 1) {
       mlp_gemm_t<2, GT, H16>(acc, Wl, ts, xrow, d.in_pad, emb_steps, lane);
-      mlp_gemm_t<2, GT, H16>(acc, Wl + (size_t)emb_steps * MLP_FRAG, ts, s_h, MLP_HS, MLP_W >> 4, lane);
-    } else mlp_gemm_t<2, GT, H16>(acc, Wl, ts, s_h, MLP_HS, MLP_W >> 4, lane);
+      mlp_gemm_hidden<MLP_W / 16, GT, H16>(acc, Wl + (size_t)emb_steps * MLP_FRAG, ts, s_h, MLP_HS, lane);
+    } else mlp_gemm_hidden<MLP_W / 16, GT, H16>(acc, Wl, ts, s_h, MLP_HS, lane);
     __syncthreads();  // every wave is done reading the previous hidden vector
     uint32_t mbits[GT] ;  // ReLU mask of this lane's accumulator elements: word gt, bit nt * 16 + e
 #pragma unroll
@@ -260,8 +321,8 @@ __global__ __launch_bounds__(256, GT == 2 ? 3 : 2) void mlp_backward_kernel(MlpB
       for (int gt = 0; gt < GT; gt++)
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[nt][gt][e] = 0.f;
-    if (l == d.depth - 1) mlp_gemm_t<2, GT, H16>(acc, d.Wout_t + (size_t)(2 * wave) * (2 * MLP_FRAG), 2 * MLP_FRAG, s_g, 40, 2, lane);
-    else mlp_gemm_t<2, GT, H16>(acc, d.Wt[l + 1] + (size_t)(2 * wave) * (16 * MLP_FRAG), 16 * MLP_FRAG, s_d, MLP_HS, MLP_W >> 4, lane);
+    if (l == d.depth - 1) mlp_gemm_small<2, GT, H16>(acc, d.Wout_t + (size_t)(2 * wave) * (2 * MLP_FRAG), 2 * MLP_FRAG, s_g, 40, 2, lane);
+    else mlp_gemm_hidden<MLP_W / 16, GT, H16>(acc, d.Wt[l + 1] + (size_t)(2 * wave) * (16 * MLP_FRAG), 16 * MLP_FRAG, s_d, MLP_HS, lane);
     __syncthreads();  // every wave is done reading d_pre_{l+1}
     // ---- d_pre_l = d_post_l where the forward's activation was positive (mask bits in this lane's accumulator layout)
     const uint4 mk = masks[((size_t)l * gridDim.x + blockIdx.x) * 256 + tid];
@@ -426,7 +487,7 @@ static int mlp_fill(MlpDesc& d, int32_t N, int32_t in_ch, int32_t out_ch, int32_
   RIGGS_REQUIRE(in_ch >= 1 && in_ch <= MLP_MAX_IN, "MLP input width must be <= 128");
   RIGGS_REQUIRE(out_ch >= 1 && out_ch <= 32, "MLP output width must be <= 32");
   RIGGS_REQUIRE(skip >= 0 && skip < depth - 1, "MLP skip layer out of range");
-  d.N = N; d.in_ch = in_ch; d.in_pad = (in_ch + 31) & ~31; d.out_ch = out_ch; d.depth = depth; d.skip = skip;
+  d.N = N; d.in_ch = in_ch; d.in_pad = (in_ch + 63) & ~63; d.out_ch = out_ch; d.depth = depth; d.skip = skip;
   for (int l = 0; l < depth; l++) { d.Wp[l] = (const unsigned short*)Wp[l]; d.bias[l] = bias[l]; RIGGS_REQUIRE(Wp[l] && bias[l], "MLP layer pointers"); }
   d.Wout = (const unsigned short*)Wout; d.bout = bout;
   RIGGS_REQUIRE(Wout && bout, "MLP head pointers");
@@ -471,7 +532,7 @@ int riggs_mlp_backward(int32_t N, int32_t out_ch, int32_t depth, int32_t skip, c
 int riggs_mlp_embed(int32_t N, int32_t multires, int32_t n_tail, const float* x, const float* tail, void* out_bf16,
                     int32_t fp16, riggs_stream stream) {
   RIGGS_REQUIRE(N >= 0 && multires >= 0 && n_tail >= 0, "MLP embedding arguments");
-  const int in_ch = 3 * (1 + 2 * multires) + n_tail, in_pad = (in_ch + 31) & ~31;
+  const int in_ch = 3 * (1 + 2 * multires) + n_tail, in_pad = (in_ch + 63) & ~63;
   RIGGS_REQUIRE(in_ch <= MLP_MAX_IN, "MLP input width must be <= 128");
   const int n_rows = (N + 127) / 128 * 128;
   if (n_rows == 0) return 0;
@@ -491,7 +552,7 @@ int riggs_mlp_pack(int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip, c
   RIGGS_REQUIRE(depth >= 1 && depth <= 10 && in_ch >= 1 && in_ch <= MLP_MAX_IN && out_ch >= 1 && out_ch <= 32 && skip >= 0 &&
                 skip < depth - 1, "MLP shape out of range");
   MlpPackDesc d;
-  d.in_ch = in_ch; d.in_pad = (in_ch + 31) & ~31; d.out_ch = out_ch; d.depth = depth; d.skip = skip;
+  d.in_ch = in_ch; d.in_pad = (in_ch + 63) & ~63; d.out_ch = out_ch; d.depth = depth; d.skip = skip;
   for (int l = 0; l < depth; l++) {
     d.W[l] = weights[l]; d.Wp[l] = (unsigned short*)weights_bf16[l]; d.Wt[l] = (unsigned short*)weights_t_bf16[l];
     RIGGS_REQUIRE(d.W[l] && d.Wp[l] && (l == 0 || d.Wt[l]), "MLP pack pointers");

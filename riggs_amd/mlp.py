@@ -51,7 +51,7 @@ class Packed:
         self.fmt = fmt or DEFAULT_FORMAT
         self.dtype, self.fp16 = _fmt_dtype(self.fmt), int(self.fmt == "fp16")
         self.linears, self.head = list(linears), head
-        self.in_ch, self.in_pad, self.skip, self.depth = in_ch, (in_ch + 31) & ~31, skip, len(self.linears)
+        self.in_ch, self.in_pad, self.skip, self.depth = in_ch, (in_ch + 63) & ~63, skip, len(self.linears)
         self.out_ch = head.weight.shape[0]
         bf = dict(dtype=self.dtype, device=dev)
         kpad = [self.in_pad if l == 0 else (self.in_pad + 256 if l == skip + 1 else 256) for l in range(self.depth)]
@@ -99,7 +99,7 @@ def embed_positions_bf16(x: torch.Tensor, multires: int, tail: torch.Tensor = No
     N = x.shape[0]
     x = L.require_cuda_f32("x", x, (N, 3))
     n_tail = 0 if tail is None else tail.numel()
-    in_pad = (3 * (1 + 2 * multires) + n_tail + 31) & ~31
+    in_pad = (3 * (1 + 2 * multires) + n_tail + 63) & ~63
     if tail is not None:
         tail = L.require_cuda_f32("tail", tail.reshape(-1))
     xb = torch.empty((N + 127) // 128 * 128, in_pad, dtype=dtype, device=x.device)

@@ -1,0 +1,44 @@
+"""The fused MLP kernels alone (csrc/mlp.hip) at the bench size: forward with / without the stores the backward needs, the
+data-gradient kernel, per head.  usage: python tools/mlp_kernel_time.py"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from riggs_amd import mlp as M  # noqa: E402
+from riggs_amd.skeleton import DeformMLP, WeightMLP  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 300000
+torch.manual_seed(0)
+x = torch.randn(N, 3, device="cuda") * 0.5
+wm = WeightMLP(3, 23).cuda()
+dn = DeformMLP(xyz_input_ch=3, time_input_ch=96).cuda()
+pose = torch.randn(96, device="cuda")
+
+
+def timed(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+for name, net, head, xb in (("WeightMLP", wm, wm.weight_predict, M.embed_positions_bf16(x, wm.multires, fmt="fp16")),
+                            ("DeformMLP", dn, dn.gaussian_warp, M.embed_positions_bf16(x, dn.multires, pose, fmt="fp16"))):
+    fh = M.FusedHead(net.linear, head, net.input_ch, net.skips[0], "fp16")
+    p = fh._packed()
+    flops = 2.0 * N * sum(q.numel() for n_, q in net.named_parameters() if q.dim() == 2)
+    t_inf = timed(lambda: M.forward(p, xb[:N], False, xb))
+    t_fwd = timed(lambda: M.forward(p, xb[:N], True, xb))
+    out, (acts, masks) = M.forward(p, xb[:N], True, xb)
+    g = torch.randn(N, p.out_ch, device="cuda")
+    sc = M.grad_scale(g)
+    t_bwd = timed(lambda: M.backward_data(p, g, masks, sc))
+    print("%s N=%d: forward %.3f ms (%.0f TFLOP/s; %.3f ms without the activation / mask stores), data gradient %.3f ms (%.0f TFLOP/s)"
+          % (name, N, t_fwd, flops / t_fwd / 1e9, t_inf, t_bwd, flops / t_bwd / 1e9))
