@@ -141,8 +141,16 @@ def heads_timing(sc, gm, iters=5):
             it()
         torch.cuda.synchronize()
         res[fused] = (time.perf_counter() - t0) / iters
+    # forward + data gradient + weight gradient = 3 x (2 flops per weight) per Gaussian, both heads
+    flops = 3.0 * x.shape[0] * sum(2 * p.numel() for name in ("skinning_weight_mlp", "detail_net")
+                                   for p in getattr(sw, name).parameters() if p.dim() == 2)
+    MFMA_F16_DENSE_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense fp16 / bf16
     return {"what": "deform_by_pose forward+backward with WeightMLP and DeformMLP on, %d Gaussians; not the headline metric" % x.shape[0],
-            "ms_fp32_gemms": round(res[False] * 1e3, 3), "ms_fused_mfma": round(res[True] * 1e3, 3), "fused_operand_format": "fp16 (fp32 accumulation, device-side gradient scaling)"}
+            "ms_fp32_gemms": round(res[False] * 1e3, 3), "ms_fused_mfma": round(res[True] * 1e3, 3), "fused_operand_format": "fp16 (fp32 accumulation, device-side gradient scaling)",
+            "tflop_per_iteration": round(flops / 1e12, 3),
+            "mfma_frac": round(flops / res[True] / 1e12 / MFMA_F16_DENSE_TFLOPS, 4),
+            "mfma_frac_note": "the MLPs' flops (forward, data gradient, weight gradient) over the WHOLE iteration's time (incl. skinning, "
+                              "embeddings, the library's weight-gradient GEMMs) over the dense fp16 MFMA peak"}
 
 
 def next_rows_timing(sc, gm, cam, iters=20):
