@@ -122,9 +122,16 @@ __device__ __forceinline__ void mlp_gemm_t(f32x16 (&acc)[NT][GT], const unsigned
 // make the first waits more conservative.
 #define MLP_GLOAD(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
 #define MLP_WAIT2(n, a, b) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(a), "+v"(b))
-template <int STEPS, int GT, bool H16>
+// COPY: the B operand's rows — the layer output that sits in LDS, 128 x 256 values — also leave for HBM here (operand of the
+// weight gradients: 1.2 GB per MLP and direction, a quarter of a millisecond of HBM writing that used to sit between two
+// barriers with every wave's next product waiting for it: on gfx9 stores and loads share vmcnt, IN ORDER).  The sixteen 16-byte
+// stores of a thread are issued BEHIND the ring's first eight loads, so the first four steps' waits leave them in flight
+// (vmcnt(6 + 16)); they have to have landed when step 4's fragments — the first loads issued behind them — are waited for:
+// four steps of matrix work later.  (One store per K-step, interleaved, LOST: every wait then had a store in front of it.)
+template <int STEPS, int GT, bool H16, bool COPY = false>
 __device__ __forceinline__ void mlp_gemm_hidden(f32x16 (&acc)[2][GT], const unsigned short* __restrict__ Wf, size_t tile_stride,
-                                                const unsigned short* Bsrc, int bs, int lane) {
+                                                const unsigned short* Bsrc, int bs, int lane,
+                                                unsigned short* __restrict__ cdst = nullptr, int crows = 0) {
   static_assert(STEPS % MLP_PF == 0 && STEPS >= 2 * MLP_PF && MLP_PF == 4, "the wait counts below are written out for a ring of four");
   const int r = lane & 31, kq = (lane >> 5) * 8;
   bf16x8 aq[MLP_PF][2], bq[2][GT];
@@ -138,12 +145,34 @@ __device__ __forceinline__ void mlp_gemm_hidden(f32x16 (&acc)[2][GT], const unsi
   }
 #pragma unroll
   for (int gt = 0; gt < GT; gt++) bq[0][gt] = *reinterpret_cast<const bf16x8*>(bl + (size_t)(32 * gt) * bs);
+  if constexpr (COPY) {
+    // exactly 16 stores per thread, whatever the row count (rows past the end go to the thread's own first piece again: the
+    // count in the waits below must not depend on data) — inline asm, so that the order against the ring's loads is the source's
+    static_assert(GT == 4, "128 rows: 4096 pieces over 256 threads");
+#pragma unroll
+    for (int k0 = 0; k0 < 16; k0 += 2) {  // (two pieces at a time: sixteen LDS reads hoisted in front of the stores spill)
+      bf16x8 v[2];
+      unsigned short* to[2];
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const int e = (k0 + k) * 256 + (int)threadIdx.x;
+        int cr = e >> 5;
+        const int c8 = e & 31;
+        cr = cr < crows ? cr : 0;
+        v[k] = *reinterpret_cast<const bf16x8*>(Bsrc + (size_t)cr * bs + 8 * c8);
+        to[k] = cdst + (size_t)cr * MLP_W + 8 * c8;
+      }
+#pragma unroll
+      for (int k = 0; k < 2; k++) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(to[k]), "v"(v[k]) : "memory");
+    }
+  }
 #pragma unroll
   for (int s = 0; s < STEPS; s++) {
     const int u = s & (MLP_PF - 1);
     // loads younger than this step's: two per step still ahead in the ring
     const int ahead = (STEPS - 1 - s) < (MLP_PF - 1) ? (STEPS - 1 - s) : (MLP_PF - 1);
-    if (ahead == 3) MLP_WAIT2(6, aq[u][0], aq[u][1]);
+    if (COPY && s < MLP_PF) MLP_WAIT2(22, aq[u][0], aq[u][1]);  // (+ the sixteen stores issued behind the first eight loads)
+    else if (ahead == 3) MLP_WAIT2(6, aq[u][0], aq[u][1]);
     else if (ahead == 2) MLP_WAIT2(4, aq[u][0], aq[u][1]);
     else if (ahead == 1) MLP_WAIT2(2, aq[u][0], aq[u][1]);
     else MLP_WAIT2(0, aq[u][0], aq[u][1]);
@@ -188,7 +217,9 @@ __device__ __forceinline__ void mlp_store4(unsigned short* dst, unsigned short v
   *reinterpret_cast<uint2*>(dst) = make_uint2((uint32_t)v0 | ((uint32_t)v1 << 16), (uint32_t)v2 | ((uint32_t)v3 << 16));
 }
 
-template <int GT, bool H16>  // 32-Gaussian tiles per workgroup (rows per workgroup = 32 GT); every wave owns 64 neurons for all of them
+// STORE: the activations / ReLU masks the backward needs are written (acts, masks non-NULL); a kernel of its own per value — both
+// forms of the hidden product inlined behind a run-time test spilled 343 registers
+template <int GT, bool H16, bool STORE>  // 32-Gaussian tiles per workgroup (rows per workgroup = 32 GT); every wave owns 64 neurons for all of them
 __global__ __launch_bounds__(256, GT == 2 ? 3 : 2) void mlp_forward_kernel(MlpDesc d, const unsigned short* __restrict__ xb,
                                                                             unsigned short* __restrict__ acts /* [depth][N][256] or NULL */,
                                                                             uint4* __restrict__ masks /* [depth][workgroups][256] or NULL */,
@@ -214,10 +245,16 @@ __global__ __launch_bounds__(256, GT == 2 ? 3 : 2) void mlp_forward_kernel(MlpDe
     const size_t ts = (size_t)S * MLP_FRAG;  // values between neuron tiles
     const unsigned short* Wl = d.Wp[l] + (size_t)(2 * wave) * ts;
     if (l == 0) mlp_gemm_t<2, GT, H16>(acc, Wl, ts, xrow, d.in_pad, emb_steps, lane);
-    else if (l == d.skip + 1) {
-      mlp_gemm_t<2, GT, H16>(acc, Wl, ts, xrow, d.in_pad, emb_steps, lane);
-      mlp_gemm_hidden<MLP_W / 16, GT, H16>(acc, Wl + (size_t)emb_steps * MLP_FRAG, ts, s_h, MLP_HS, lane);
-    } else mlp_gemm_hidden<MLP_W / 16, GT, H16>(acc, Wl, ts, s_h, MLP_HS, lane);
+    else {
+      const unsigned short* Wh = Wl;
+      if (l == d.skip + 1) {
+        mlp_gemm_t<2, GT, H16>(acc, Wl, ts, xrow, d.in_pad, emb_steps, lane);
+        Wh = Wl + (size_t)emb_steps * MLP_FRAG;
+      }
+      // (the forward keeps its activation stores between the barriers: behind the ring's prologue — the backward's form — the
+      // kernel needs all 256 registers and loses what the overlap gains: 0.454 -> 0.470 ms; the backward gains, 0.541 -> 0.515)
+      mlp_gemm_hidden<MLP_W / 16, GT, H16, false>(acc, Wh, ts, s_h, MLP_HS, lane);
+    }
     __syncthreads();  // every wave is done reading the previous hidden vector
     uint32_t mbits[GT] ;  // ReLU mask of this lane's accumulator elements: word gt, bit nt * 16 + e
 #pragma unroll
@@ -244,12 +281,12 @@ __global__ __launch_bounds__(256, GT == 2 ? 3 : 2) void mlp_forward_kernel(MlpDe
     }
     // (the data-gradient kernel uses the same tiling, so the mask travels in the accumulator layout: 16 bytes per lane
     // and layer instead of re-reading the layer's activations)
-    if (masks) {
+    if constexpr (STORE) {
       static_assert(GT == 4, "the mask record is one uint4 per lane: four Gaussian tiles");
       masks[((size_t)l * gridDim.x + blockIdx.x) * 256 + tid] = make_uint4(mbits[0], mbits[1], mbits[2], mbits[3]);
     }
     __syncthreads();
-    if (acts) {  // full-line stores of the layer's activations (operand of the weight gradients)
+    if constexpr (STORE) {  // full-line stores of the layer's activations (operand of the weight gradients)
       unsigned short* dst = acts + ((size_t)l * d.N + row0) * MLP_W;
       for (int e = tid; e < ROWS * (MLP_W / 8); e += 256) {
         const int r = e / (MLP_W / 8), c8 = e - r * (MLP_W / 8);
@@ -322,7 +359,9 @@ __global__ __launch_bounds__(256, GT == 2 ? 3 : 2) void mlp_backward_kernel(MlpB
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[nt][gt][e] = 0.f;
     if (l == d.depth - 1) mlp_gemm_small<2, GT, H16>(acc, d.Wout_t + (size_t)(2 * wave) * (2 * MLP_FRAG), 2 * MLP_FRAG, s_g, 40, 2, lane);
-    else mlp_gemm_hidden<MLP_W / 16, GT, H16>(acc, d.Wt[l + 1] + (size_t)(2 * wave) * (16 * MLP_FRAG), 16 * MLP_FRAG, s_d, MLP_HS, lane);
+    else  // (the gradient of layer l + 1 — this product's B operand — leaves for HBM under it)
+      mlp_gemm_hidden<MLP_W / 16, GT, H16, true>(acc, d.Wt[l + 1] + (size_t)(2 * wave) * (16 * MLP_FRAG), 16 * MLP_FRAG, s_d, MLP_HS, lane,
+                                                 dpre + ((size_t)(l + 1) * d.N + row0) * MLP_W, min(ROWS, d.N - row0));
     __syncthreads();  // every wave is done reading d_pre_{l+1}
     // ---- d_pre_l = d_post_l where the forward's activation was positive (mask bits in this lane's accumulator layout)
     const uint4 mk = masks[((size_t)l * gridDim.x + blockIdx.x) * 256 + tid];
@@ -342,12 +381,13 @@ __global__ __launch_bounds__(256, GT == 2 ? 3 : 2) void mlp_backward_kernel(MlpB
         }
       }
     __syncthreads();
-    // ---- out to HBM (operand of the weight gradients), full lines
-    unsigned short* dl = dpre + ((size_t)l * d.N + row0) * MLP_W;
-    for (int e = tid; e < ROWS * (MLP_W / 8); e += 256) {
-      const int r = e / (MLP_W / 8), c8 = e - r * (MLP_W / 8);
-      if (row0 + r < d.N)
-        *reinterpret_cast<bf16x8*>(dl + (size_t)r * MLP_W + 8 * c8) = *reinterpret_cast<const bf16x8*>(s_d + r * MLP_HS + 8 * c8);
+    if (l == 0) {  // (no product follows the first layer's gradient: it leaves here, full lines)
+      unsigned short* dl = dpre + (size_t)row0 * MLP_W;
+      for (int e = tid; e < ROWS * (MLP_W / 8); e += 256) {
+        const int r = e / (MLP_W / 8), c8 = e - r * (MLP_W / 8);
+        if (row0 + r < d.N)
+          *reinterpret_cast<bf16x8*>(dl + (size_t)r * MLP_W + 8 * c8) = *reinterpret_cast<const bf16x8*>(s_d + r * MLP_HS + 8 * c8);
+      }
     }
     // bias gradient of the layer: this workgroup's column sums (thread = column; summed over the workgroups in a fixed
     // order by the caller — deterministic, and cheaper than a column reduction of the (N, 256) tensor)
@@ -502,10 +542,19 @@ int riggs_mlp_forward(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, i
   if (rc) return rc;
   if (N == 0) return 0;
   RIGGS_REQUIRE(x_emb_bf16 && out, "MLP input / output pointers");
-  if (fp16) hipLaunchKernelGGL((mlp_forward_kernel<MLP_RT, true>), dim3((N + 127) / 128), dim3(256), 0, (hipStream_t)stream, d,
-                               (const unsigned short*)x_emb_bf16, (unsigned short*)acts_bf16, (uint4*)relu_masks, out);
-  else hipLaunchKernelGGL((mlp_forward_kernel<MLP_RT, false>), dim3((N + 127) / 128), dim3(256), 0, (hipStream_t)stream, d,
-                          (const unsigned short*)x_emb_bf16, (unsigned short*)acts_bf16, (uint4*)relu_masks, out);
+  RIGGS_REQUIRE((acts_bf16 == nullptr) == (relu_masks == nullptr), "acts_bf16 and relu_masks: both (training) or neither (inference)");
+  const dim3 grid((N + 127) / 128), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned short* xb = (const unsigned short*)x_emb_bf16;
+  unsigned short* ab = (unsigned short*)acts_bf16;
+  uint4* mk = (uint4*)relu_masks;
+  if (ab) {
+    if (fp16) hipLaunchKernelGGL((mlp_forward_kernel<MLP_RT, true, true>), grid, block, 0, s, d, xb, ab, mk, out);
+    else hipLaunchKernelGGL((mlp_forward_kernel<MLP_RT, false, true>), grid, block, 0, s, d, xb, ab, mk, out);
+  } else {
+    if (fp16) hipLaunchKernelGGL((mlp_forward_kernel<MLP_RT, true, false>), grid, block, 0, s, d, xb, ab, mk, out);
+    else hipLaunchKernelGGL((mlp_forward_kernel<MLP_RT, false, false>), grid, block, 0, s, d, xb, ab, mk, out);
+  }
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
 }
