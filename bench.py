@@ -34,12 +34,13 @@ class Pipe:
     debug = False
 
 
-def build_workload(rank: int, device: str):
+def build_workload(rank: int, device: str, surface: bool = False):
+    """The headline scene (a deep translucent cloud) or, ``surface``, the opaque-skin scene of ``dense_scene_timing``."""
     from riggs_amd import synth
     from riggs_amd.gaussian_model import GaussianModel
     from riggs_amd.skeleton import SkeletonWarp
     w = WORKLOAD
-    sc = synth.make_scene(w["N"], w["J"], w["seed"])
+    sc = (synth.make_surface_scene if surface else synth.make_scene)(w["N"], w["J"], w["seed"])
     cam = synth.look_at_camera(w["H"], w["W"], azimuth_deg=45.0 * rank, fid=0.37 + 0.05 * rank).to(device)
     gm = GaussianModel.from_tensors(sc["xyz"], sc["features_dc"], sc["features_rest"], sc["scaling"], sc["rotation"],
                                     sc["opacity"], device=device)
@@ -210,22 +211,9 @@ def dense_scene_timing(dev, steps=50):
     riggs_amd.synth.make_surface_scene (a thin opaque skin around the bones: a surface-like capture in which a large share of
     the Gaussians receives a gradient every frame, where the headline scene — a deep translucent cloud, SURVEY.md §8-d —
     leaves 93 % of them without one).  hipGraph replay, same timing protocol."""
-    from riggs_amd import synth
-    from riggs_amd.gaussian_model import GaussianModel
     from riggs_amd.graph import GraphedFrame
-    from riggs_amd.skeleton import SkeletonWarp
     w = WORKLOAD
-    sc = synth.make_surface_scene(w["N"], w["J"], w["seed"])
-    cam = synth.look_at_camera(w["H"], w["W"], fid=0.37).to(dev)
-    gm = GaussianModel.from_tensors(sc["xyz"], sc["features_dc"], sc["features_rest"], sc["scaling"], sc["rotation"],
-                                    sc["opacity"], device=dev)
-    torch.manual_seed(w["seed"])
-    sw = SkeletonWarp(joints=sc["joints"], parent_indices=sc["parents"], K=-1, hyper_dim=8,
-                      use_skinning_weight_mlp=False, use_template_offsets=False).to(dev)
-    sw._node_radius.data = sc["node_radius"].to(dev)
-    with torch.no_grad():
-        sw.pose_net.rotation_predictor.weight.mul_(0.1)
-        sw.pose_net.translation_predictor.weight.mul_(0.1)
+    sc, cam, gm, sw = build_workload(0, dev, surface=True)
     params = params_of(gm, sw)
     gf = GraphedFrame(gm, sw, cam, torch.zeros(3, device=dev), params, tight_lists=_tight()).capture()
     g = torch.Generator().manual_seed(w["seed"] + 100)
@@ -504,7 +492,7 @@ def verify_rows_exchange(gf, rows, world):
         assert float((got - want).abs().max()) <= tol, "gradient-row exchange differs from the dense all-reduce"
 
 
-def exchange_path_child(steps=200):
+def exchange_path_child(steps=200, scene="headline"):
     """``python bench.py --exchange-path-child`` (started by the N = 1 run, in a process of its own so that nothing RCCL does
     can touch the headline measurement): the EXACT host and device sequence of a data-parallel rank's step — split frame,
     rows.pack -> all_gather of the packed rows (communication stream, under the deformation backward) -> run_b ->
@@ -534,7 +522,7 @@ def exchange_path_child(steps=200):
     torch.cuda.synchronize()
     note("first collective done")
     w = WORKLOAD
-    sc, cam, gm, sw = build_workload(0, dev)
+    sc, cam, gm, sw = build_workload(0, dev, surface=(scene == "dense"))
     ordered, _ = exchange_order(gm, sw)
     n_rows = row_exchange_order(gm, sw)[1]
     bucket = FlatGradAllReduce(ordered)
@@ -560,7 +548,8 @@ def exchange_path_child(steps=200):
     def rows_for():  # (sized for every row first: the real need is read after the first step)
         return SparseRowExchange([v.view(w["N"], -1) for v in bucket.views[:n_rows]], rest=bucket.flat[bucket.offsets[n_rows]:],
                                  capacity=w["N"], force_collectives=True)
-    out = {"backend": "nccl (RCCL), one-rank communicator on this GPU", "steps": steps}
+    out = {"backend": "nccl (RCCL), one-rank communicator on this GPU", "steps": steps,
+           "scene": "headline (deep translucent cloud)" if scene != "dense" else "opaque skin around the bones (synth.make_surface_scene)"}
     # (0) the plain frame in this process: the reference the two exchange paths are priced against, and their gradients' oracle
     gf = GraphedFrame(gm, sw, cam, bg, params, sparse_grad_rows=False, tight_lists=_tight()).capture()
     gf.set_inputs(gimg=gimg)
@@ -699,23 +688,32 @@ def captured_collectives_work(rank, world, local_rank, dev):
     return bool(ok.item() > 0.5)
 
 
-def exchange_path_timing():
-    """Runs ``exchange_path_child`` in a child process (bounded by a time-out) and returns its JSON object."""
+def exchange_path_timing(scene="headline", soak=None):
+    """Runs ``exchange_path_child`` in a child process (bounded by a time-out) and returns its JSON object, plus ``form``: which
+    form of the step its ``ms`` is — what ``--gpus N --exchange-graph auto`` would pick on this stack."""
     import subprocess
     last = None
+    env = dict(os.environ)
+    if soak is not None:
+        env.setdefault("RIGGS_BENCH_SOAK", str(soak))
     for attempt in range(2):  # (one retry: the child's rendezvous port is picked and released before RCCL binds it)
         try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--exchange-path-child", "--lists", LISTS], capture_output=True, text=True,
-                               timeout=300, env=dict(os.environ))
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--exchange-path-child", "--lists", LISTS, "--scene", scene],
+                               capture_output=True, text=True, timeout=300, env=env)
         except subprocess.TimeoutExpired:
             last = {"error": "the exchange-path child did not finish within 300 s"}
             continue
         for line in reversed(r.stdout.strip().splitlines()):
             if line.startswith("{"):
                 try:
-                    return dict(json.loads(line), attempts=attempt + 1)
+                    got = json.loads(line)
                 except ValueError:
-                    pass
+                    continue
+                one = "one_graph_ms" in got
+                got["captured_collectives_work"] = one  # (the capture itself is the probe here: RCCL's kernels inside a hipGraph)
+                got["form"] = "one_graph" if one else "two_graphs_eager_collectives"
+                got["ms"] = got.get("one_graph_ms", got.get("two_graphs_eager_collectives_ms"))
+                return dict(got, attempts=attempt + 1)
         last = {"error": "exchange-path child failed (rc %d): %s" % (r.returncode, (r.stderr or r.stdout)[-600:])}
     return last
 
@@ -793,12 +791,13 @@ def main():
                          "dropped are exactly ones the compositing skips, so image and gradients are the canonical ones — asserted "
                          "against the oracle at the bench size).  The other kind is reported beside the headline either way")
     ap.add_argument("--exchange-path-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--scene", choices=("headline", "dense"), default="headline", help=argparse.SUPPRESS)
     ap.add_argument("--capture-probe-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     global LISTS
     LISTS = args.lists
     if args.exchange_path_child:
-        return exchange_path_child()
+        return exchange_path_child(scene=args.scene)
     if args.capture_probe_child:
         return capture_probe_child()
 
@@ -1295,7 +1294,9 @@ def main():
             out["canonical_lists" if LISTS == "tight" else "tight_lists"] = other_lists_timing(dev, gimg)
             # the data-parallel step's host + device sequence on a one-rank RCCL communicator (a child process)
             out["exchange_path"] = exchange_path_timing()
-            out["exchange_path_ms"] = out["exchange_path"].get("one_graph_ms", out["exchange_path"].get("two_graphs_eager_collectives_ms"))
+            out["exchange_path_ms"] = out["exchange_path"].get("ms")
+            # ... and on the opaque-skin scene, whose packed segments are the large ones (every Gaussian with a gradient travels)
+            out["exchange_path"]["dense_scene"] = exchange_path_timing("dense", soak=1000)
         if not args.no_cpu_baseline and world == 1:  # (the CPU baseline is an N = 1 measurement)
             out["cpu_baseline"], ora_image, ora_grads = cpu_baseline(sc, cam.to("cpu"), gimg.cpu(), hip_pose, hip_deformed)
             out["parity_at_bench_size"] = parity_at_bench_size(hip_image, hip_grads, ora_image, ora_grads, sw_snapshot, hip_pose_grads, cam.fid)

@@ -482,7 +482,12 @@ def test_bench_contract_single_and_two_ranks():
     assert ex["two_graphs_eager_collectives_ms"] > 0 and ex["plain_frame_ms"] > 0 and ex["rows_needed"] > 0
     # (the captured form is reported when the capture succeeded; a failure is recorded in the line, not hidden)
     assert ex.get("one_graph_ms", 0) > 0 or "one_graph_error" in ex, ex
-    assert d["exchange_path_ms"] == ex.get("one_graph_ms", ex["two_graphs_eager_collectives_ms"])
+    assert d["exchange_path_ms"] == ex.get("one_graph_ms", ex["two_graphs_eager_collectives_ms"]) == ex["ms"]
+    assert ex["form"] == ("one_graph" if ex["captured_collectives_work"] else "two_graphs_eager_collectives")
+    # ... and the same on the opaque-skin scene, whose segments are the large ones
+    dx = ex["dense_scene"]
+    assert "error" not in dx, dx
+    assert dx["rows_needed"] > 2 * ex["rows_needed"] and dx["segment_MB"] > ex["segment_MB"] and dx["ms"] > 0
     env["RIGGS_BENCH_BACKEND"] = "gloo"
     import socket
 
