@@ -654,8 +654,8 @@ int riggs_mlp_forward(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, i
                       const float* b_out, const void* x_emb_bf16, void* acts_bf16, void* relu_masks, float* out,
                       int32_t fp16, riggs_stream stream);
 /* Data-gradient pass of the same MLP: g_out (N, out_ch) = dL/d(output) -> dpre_bf16 (depth, N, 256) = dL/d(pre-activation)
- * of every hidden layer, the operand of the weight gradients  dW_l = dpre_l^T · input_l ,  db_l = sum_n dpre_l  (plain
- * GEMMs / reductions, left to the library).  weights_t_bf16[l] (l >= 1): W_l[:, hidden part]^T (rows = the units of layer
+ * of every hidden layer, the operand of the weight gradients  dW_l = dpre_l^T · input_l ,  db_l = sum_n dpre_l
+ * (riggs_mlp_wgrad).  weights_t_bf16[l] (l >= 1): W_l[:, hidden part]^T (rows = the units of layer
  * l - 1), 256 x 256 values, fragment-major as above; w_out_t_bf16: W_out^T (rows = hidden units, 32 padded outputs as
  * inputs), fragment-major.  No gradient w.r.t. x_emb (detached in the reference).
  * g_scale (device scalar, may be NULL = 1): g_out is multiplied by it on load, so dpre and db_partial come out scaled by it —
@@ -665,8 +665,22 @@ int riggs_mlp_backward(int32_t N, int32_t out_ch, int32_t depth, int32_t skip, c
                        const void* w_out_t_bf16, const float* g_out, const float* g_scale, const void* relu_masks,
                        void* dpre_bf16, float* db_partial, int32_t fp16, riggs_stream stream);
 /* db_partial: (ceil(N / riggs_mlp_rows_per_workgroup()), depth, 256) fp32 — per-workgroup column sums of dpre; the bias
- * gradients are their sum over the first axis */
+ * gradients are their sum over the first axis.  May be NULL when riggs_mlp_wgrad follows (it sums the columns itself). */
 int32_t riggs_mlp_rows_per_workgroup(void);
+/* The parameter gradients of one MLP from what the two passes left in memory, in three launches: every product
+ *   dW_l = dpre_l^T · input_l   (input_0 = x_emb, input_l = acts_{l-1}; layer skip + 1: [x_emb | acts_skip]),
+ *   dW_out = (g_out · g_scale)^T · acts_{depth-1},   db_l = sum_n dpre_l,   db_out = sum_n g_out · g_scale
+ * streamed once by one workgroup per CU (split over the Gaussians, fp32 accumulators, LDS-direct loads — mlp_wgrad.hip), the
+ * split partials summed, divided by g_scale (NULL = 1) and written to the fp32 tensors torch.autograd hands back:
+ * grad_weights[l] (256, K_true) row-major with K_true = in_ch / in_ch + 256 (layer skip + 1) / 256, grad_biases[l] (256),
+ * grad_w_out (out_ch, 256), grad_b_out (out_ch).  x_emb_bf16 / acts_bf16 / dpre_bf16: the buffers of riggs_mlp_forward /
+ * riggs_mlp_backward, same format.  workspace: riggs_mlp_wgrad_workspace_bytes bytes, 256-byte aligned, contents irrelevant
+ * (depends on N, the shape and the device's CU count). */
+size_t riggs_mlp_wgrad_workspace_bytes(int32_t N, int32_t in_ch, int32_t depth, int32_t skip);
+int riggs_mlp_wgrad(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip, const void* x_emb_bf16,
+                    const void* acts_bf16, const void* dpre_bf16, const float* g_out, const float* g_scale, void* workspace,
+                    size_t workspace_bytes, float* const* grad_weights, float* const* grad_biases, float* grad_w_out,
+                    float* grad_b_out, int32_t fp16, riggs_stream stream);
 /* fp32 master weights ((256, K_true) row-major per layer, (out_ch, 256) for the head) -> every bf16 operand the two kernels
  * read (layouts above), in one launch. */
 int riggs_mlp_pack(int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip, const float* const* weights, const float* w_out,

@@ -26,6 +26,7 @@ SOURCES = {
     "skel_loss.hip": ["-ffp-contract=off"],
     "cnode.hip": ["-ffp-contract=off"],
     "mlp.hip": ["-ffp-contract=fast"],
+    "mlp_wgrad.hip": ["-ffp-contract=fast"],
     "exchange.hip": ["-ffp-contract=off"],
     "dq.hip": ["-ffp-contract=off"],
     "frame.hip": [],

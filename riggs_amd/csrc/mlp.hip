@@ -19,8 +19,8 @@
 // behind a barrier, and — for the backward — to HBM as 16-bit values with full-line stores.
 //
 // Backward (data gradient): the same tiling with the transposed weights,  dH_{l-1} = (dH_l * relu'(H_l)) W_l ;
-// every layer's masked gradient is stored as bf16 for the weight gradients, which are plain (256 x N)·(N x K) GEMMs
-// left to the library (hipBLASLt through torch, bf16 in / fp32 out).  The inputs of both heads are detached in the
+// every layer's masked gradient is stored as bf16 for the weight gradients (mlp_wgrad.hip: every product of one MLP in one
+// launch, streamed at the HBM rate).  The inputs of both heads are detached in the
 // reference (positions and pose), so no gradient flows past the first layer.
 #include "common.h"
 
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256, GT == 2 ? 3 : 2) void mlp_backward_kernel(MlpB
     }
     // bias gradient of the layer: this workgroup's column sums (thread = column; summed over the workgroups in a fixed
     // order by the caller — deterministic, and cheaper than a column reduction of the (N, 256) tensor)
-    {
+    if (db_part) {  // (NULL: riggs_mlp_wgrad sums the columns of dpre beside its products)
       float sum = 0.f;
 #pragma unroll 8
       for (int r = 0; r < ROWS; r++) sum += h2f<H16>(s_d[r * MLP_HS + tid]);
@@ -569,7 +569,7 @@ int riggs_mlp_backward(int32_t N, int32_t out_ch, int32_t depth, int32_t skip, c
   d.N = N; d.out_ch = out_ch; d.depth = depth; d.skip = skip;
   for (int l = 0; l < depth; l++) { d.Wt[l] = (const unsigned short*)weights_t_bf16[l]; RIGGS_REQUIRE(l == 0 || d.Wt[l], "MLP transposed weights"); }
   d.Wout_t = (const unsigned short*)w_out_t_bf16;
-  RIGGS_REQUIRE(d.Wout_t && g_out && relu_masks && dpre_bf16 && db_partial, "MLP backward pointers");
+  RIGGS_REQUIRE(d.Wout_t && g_out && relu_masks && dpre_bf16, "MLP backward pointers");
   if (fp16) hipLaunchKernelGGL((mlp_backward_kernel<MLP_RT, true>), dim3((N + 127) / 128), dim3(256), 0, (hipStream_t)stream, d, g_out,
                                g_scale, (const uint4*)relu_masks, (unsigned short*)dpre_bf16, db_partial);
   else hipLaunchKernelGGL((mlp_backward_kernel<MLP_RT, false>), dim3((N + 127) / 128), dim3(256), 0, (hipStream_t)stream, d, g_out,

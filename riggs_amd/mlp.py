@@ -2,8 +2,8 @@
 
 ``FusedHead`` wraps a WeightMLP / DeformMLP host mirror (riggs_amd.skeleton): same parameters (fp32 masters, the ones
 the optimizer and the checkpoints see), but forward and backward run as ONE HIP launch each with 16-bit operands and
-fp32 accumulation; the weight gradients are (256 x N)·(N x K) GEMMs handed to hipBLASLt (16-bit in, fp32 out: they
-already run at the HBM roof).  The operand format is a choice: ``"fp16"`` (default: 11 significand bits —
+fp32 accumulation; the parameter gradients — (256 x N)·(N x K) products over all Gaussians — are one streaming launch per MLP
+(csrc/mlp_wgrad.hip: ``riggs_mlp_wgrad``, every layer's product and bias sum, split partials summed by a second launch).  The operand format is a choice: ``"fp16"`` (default: 11 significand bits —
 parameter gradients within ~2 % of the fp32 mirror; the incoming gradient is scaled by a power of two on the device so
 that half precision's narrow range is never the limit, and the parameter gradients are scaled back) or ``"bf16"``
 (8 bits, fp32's range, 3-11 % on the gradients).  The reference computes these MLPs in fp32
@@ -133,20 +133,51 @@ def grad_scale(g_out: torch.Tensor) -> torch.Tensor:
     return torch.exp2(torch.floor(torch.log2(1024.0 / amax))).reshape(1)
 
 
-def backward_data(p: Packed, g_out: torch.Tensor, masks: torch.Tensor, scale: torch.Tensor = None) -> torch.Tensor:
-    """dL/d(pre-activation) of every hidden layer in the 16-bit format (depth, N, 256), and the bias gradients (depth, 256)
-    — both times ``scale`` when given (``grad_scale``)."""
+def backward_data(p: Packed, g_out: torch.Tensor, masks: torch.Tensor, scale: torch.Tensor = None, bias_sums: bool = True):
+    """dL/d(pre-activation) of every hidden layer in the 16-bit format (depth, N, 256), and (``bias_sums``) the bias gradients
+    (depth, 256) — both times ``scale`` when given (``grad_scale``).  Without ``bias_sums`` the second value is None:
+    ``param_grads`` sums the columns beside its products."""
     N = g_out.shape[0]
     g_out = L.require_cuda_f32("g_out", g_out, (N, p.out_ch))
     dpre = torch.empty(p.depth, N, 256, dtype=p.dtype, device=g_out.device)
     rows = L.lib().riggs_mlp_rows_per_workgroup()
-    db_part = torch.empty((N + rows - 1) // rows, p.depth, 256, device=g_out.device)
+    db_part = torch.empty((N + rows - 1) // rows, p.depth, 256, device=g_out.device) if bias_sums else None
     L.check(L.lib().riggs_mlp_backward(N, p.out_ch, p.depth, p.skip, p._wtp, p.w_out_t_bf16.data_ptr(), g_out.data_ptr(),
-                                       L.ptr(scale), masks.data_ptr(), dpre.data_ptr(), db_part.data_ptr(), p.fp16,
+                                       L.ptr(scale), masks.data_ptr(), dpre.data_ptr(), L.ptr(db_part), p.fp16,
                                        L.stream_ptr()), "riggs_mlp_backward")
-    return dpre, db_part.sum(0)
+    return dpre, (db_part.sum(0) if bias_sums else None)
 
 
+def param_grads(p: Packed, xb: torch.Tensor, acts: torch.Tensor, dpre: torch.Tensor, g_out: torch.Tensor, scale: torch.Tensor = None):
+    """Every parameter gradient of the MLP — [dW_0, db_0, ..., dW_{D-1}, db_{D-1}, dW_out, db_out], fp32, the masters' shapes,
+    ``scale`` taken out again — from the operands the two passes left in memory (``riggs_mlp_wgrad``: three launches)."""
+    N = g_out.shape[0]
+    dev = g_out.device
+    g_out = L.require_cuda_f32("g_out", g_out, (N, p.out_ch))
+    k_true = [p.in_ch if l == 0 else (p.in_ch + 256 if l == p.skip + 1 else 256) for l in range(p.depth)]
+    if N == 0:
+        out = []
+        for k in k_true:
+            out += [torch.zeros(256, k, device=dev), torch.zeros(256, device=dev)]
+        return out + [torch.zeros(p.out_ch, 256, device=dev), torch.zeros(p.out_ch, device=dev)]
+    gw = [torch.empty(256, k, device=dev) for k in k_true]
+    gb = torch.empty(p.depth, 256, device=dev)
+    gwo, gbo = torch.empty(p.out_ch, 256, device=dev), torch.empty(p.out_ch, device=dev)
+    nbytes = int(L.lib().riggs_mlp_wgrad_workspace_bytes(N, p.in_ch, p.depth, p.skip))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    gwp = (C.c_void_p * p.depth)(*[t.data_ptr() for t in gw])
+    gbp = (C.c_void_p * p.depth)(*[gb[l].data_ptr() for l in range(p.depth)])
+    L.check(L.lib().riggs_mlp_wgrad(N, p.in_ch, p.out_ch, p.depth, p.skip, xb.data_ptr(), acts.data_ptr(), dpre.data_ptr(),
+                                    g_out.data_ptr(), L.ptr(scale), ws.data_ptr(), nbytes, gwp, gbp, gwo.data_ptr(), gbo.data_ptr(),
+                                    p.fp16, L.stream_ptr()), "riggs_mlp_wgrad")
+    out = []
+    for l in range(p.depth):
+        out += [gw[l], gb[l]]
+    return out + [gwo, gbo]
+
+
+# ---- the same gradients through the library (torch.bmm = hipBLASLt): what ``param_grads`` replaced; kept as the comparison
+# the tests and tools/mlp_kernel_time.py run beside it, never called by the product path
 def _wgrad(d: torch.Tensor, a: torch.Tensor, splits: int = 128) -> torch.Tensor:
     """d^T · a for d (N, M), a (N, K) in bf16 with fp32 output.  The reduction runs over N = 3e5 rows: one GEMM with
     K_gemm = N leaves the library without parallelism (0.63 ms at 256 x 256 outputs); a batched GEMM over `splits` row
@@ -193,6 +224,30 @@ def _colsum(d: torch.Tensor) -> torch.Tensor:
     return _wgrad(d, ones)[:, 0].contiguous()
 
 
+def library_param_grads(p: Packed, xb: torch.Tensor, acts: torch.Tensor, dpre: torch.Tensor, db: torch.Tensor, g_out: torch.Tensor,
+                        scale: torch.Tensor = None):
+    """``param_grads`` through library GEMMs (comparison only; ``db`` from ``backward_data(..., bias_sums=True)``)."""
+    # every layer's product with the previous layer's activations has the same shape — the skip layer's hidden block
+    # included — so layers 1 .. depth - 1 are ONE batched split-K GEMM; the two products with the embedding stay single calls
+    gws = [None] * p.depth
+    ls = p.skip + 1
+    xb = xb[:g_out.shape[0]]
+    g_run = _wgrad_multi(dpre[1:p.depth], acts[0:p.depth - 1])
+    for l in range(1, p.depth):
+        gws[l] = g_run[l - 1]
+    gws[0] = _wgrad(dpre[0], xb)[:, :p.in_ch]
+    gws[ls] = torch.cat([_wgrad(dpre[ls], xb)[:, :p.in_ch], gws[ls]], 1)
+    grads = []
+    for l in range(p.depth):
+        grads += [gws[l], db[l]]
+    gob = torch.nn.functional.pad(g_out if scale is None else g_out * scale, (0, 32 - p.out_ch)).to(p.dtype)
+    grads += [_wgrad(gob, acts[p.depth - 1])[:p.out_ch], _colsum(gob)[:p.out_ch]]
+    if scale is not None:  # every product above carries the factor once: take it out again (a power of two: exact)
+        grads = [g.contiguous() for g in grads]
+        torch._foreach_mul_(grads, torch.reciprocal(scale).reshape(()))
+    return grads
+
+
 class _FusedMLP(torch.autograd.Function):
     """out = MLP(x_emb) with the fused kernels; gradients for the (fp32 master) parameters only."""
 
@@ -212,27 +267,8 @@ class _FusedMLP(torch.autograd.Function):
         p = ctx.p
         g_out = g_out.contiguous()
         scale = grad_scale(g_out) if p.fp16 else None
-        dpre, db = backward_data(p, g_out, masks, scale)
-        xb = xb[:ctx.n]
-        # every layer's product with the previous layer's activations has the same shape — the skip layer's hidden block
-        # included — so layers 1 .. depth - 1 are ONE batched split-K GEMM (before round 4's trace the skip layer's block
-        # went alone, at 2.3 TB/s against the batch's 5.9); the two products with the embedding stay single calls (their
-        # gradient slabs are not adjacent: folding them into one batch would copy them)
-        gws = [None] * p.depth
-        ls = p.skip + 1
-        g_run = _wgrad_multi(dpre[1:p.depth], acts[0:p.depth - 1])
-        for l in range(1, p.depth):
-            gws[l] = g_run[l - 1]
-        gws[0] = _wgrad(dpre[0], xb)[:, :p.in_ch]
-        gws[ls] = torch.cat([_wgrad(dpre[ls], xb)[:, :p.in_ch], gws[ls]], 1)
-        grads = []
-        for l in range(p.depth):
-            grads += [gws[l], db[l]]
-        gob = torch.nn.functional.pad(g_out if scale is None else g_out * scale, (0, 32 - p.out_ch)).to(p.dtype)
-        grads += [_wgrad(gob, acts[p.depth - 1])[:p.out_ch], _colsum(gob)[:p.out_ch]]
-        if scale is not None:  # every product above carries the factor once: take it out again (a power of two: exact)
-            grads = [g.contiguous() for g in grads]
-            torch._foreach_mul_(grads, torch.reciprocal(scale).reshape(()))
+        dpre, _ = backward_data(p, g_out, masks, scale, bias_sums=False)
+        grads = param_grads(p, xb, acts, dpre, g_out, scale)
         return (None, None) + tuple(grads)
 
 

@@ -110,6 +110,41 @@ def test_forward_and_gradients_vs_fp32_mirror_and_bf16_emulation(N, fmt, gscale)
             q.grad = None
 
 
+@pytest.mark.parametrize("fmt", ["fp16", "bf16"])
+@pytest.mark.parametrize("N", [1, 31, 33, 4097, 50_003])
+def test_param_grads_kernel_equals_the_products_of_its_operands(N, fmt):
+    """riggs_mlp_wgrad (csrc/mlp_wgrad.hip) against float64 products of the SAME 16-bit operands — what is left is the fp32
+    accumulation order (1e-5 of a tensor's largest entry) — for both heads (embedding widths 64 and 128 after padding), ragged
+    N (the last 32-Gaussian stage reads a zero page), with and without the gradient scale; and against the library path."""
+    for name, net, head, xe in _nets(N):
+        fh = M.FusedHead(net.linear, head, xe.shape[1], net.skips[0], fmt)
+        pk = fh._packed()
+        xb = M.embed_bf16(pk, xe)
+        _out, (acts, masks) = M.forward(pk, xe, True, xb)
+        g = torch.randn(N, pk.out_ch, device="cuda") * (3e-8 if fmt == "fp16" else 1.0)
+        sc = M.grad_scale(g) if fmt == "fp16" else None
+        dpre, db = M.backward_data(pk, g, masks, sc)
+        got = M.param_grads(pk, xb, acts, dpre, g, sc)
+        lib = M.library_param_grads(pk, xb, acts, dpre, db, g, sc)
+        inv = 1.0 if sc is None else 1.0 / float(sc)
+        gob = (g if sc is None else g * sc).to(pk.dtype).double()
+        x64 = xb[:N, :pk.in_ch].double()
+        want = []
+        for l in range(pk.depth):
+            d64 = dpre[l].double()
+            a64 = x64 if l == 0 else acts[l - 1].double()
+            if l == pk.skip + 1:
+                a64 = torch.cat([x64, a64], 1)
+            want += [d64.t() @ a64 * inv, d64.sum(0) * inv]
+        want += [gob.t() @ acts[pk.depth - 1].double() * inv, gob.sum(0) * inv]
+        assert len(got) == len(want) == len(lib) == 2 * pk.depth + 2
+        for i, (a, b, c) in enumerate(zip(got, want, lib)):
+            assert a.shape == b.shape == c.shape and a.dtype == torch.float32, (name, i, a.shape, b.shape)
+            tol = 2e-5 * float(b.abs().max()) + 1e-30
+            assert float((a.double() - b).abs().max()) <= tol, (name, fmt, N, i, float((a.double() - b).abs().max()), tol)
+            assert float((c.double() - b).abs().max()) <= 50 * tol, (name, "library", i)
+
+
 def test_skeleton_warp_with_fused_heads_tracks_the_fp32_heads():
     from riggs_amd import synth
     from riggs_amd.skeleton import SkeletonWarp

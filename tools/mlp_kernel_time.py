@@ -1,5 +1,6 @@
-"""The fused MLP kernels alone (csrc/mlp.hip) at the bench size: forward with / without the stores the backward needs, the
-data-gradient kernel, per head.  usage: python tools/mlp_kernel_time.py"""
+"""The fused MLP kernels alone (csrc/mlp.hip, csrc/mlp_wgrad.hip) at the bench size: forward with / without the stores the
+backward needs, the data-gradient kernel, the parameter gradients (riggs_mlp_wgrad vs the library GEMMs it replaced), per head.
+usage: python tools/mlp_kernel_time.py [N]"""
 import os
 import sys
 import time
@@ -39,6 +40,13 @@ for name, net, head, xb in (("WeightMLP", wm, wm.weight_predict, M.embed_positio
     out, (acts, masks) = M.forward(p, xb[:N], True, xb)
     g = torch.randn(N, p.out_ch, device="cuda")
     sc = M.grad_scale(g)
-    t_bwd = timed(lambda: M.backward_data(p, g, masks, sc))
+    t_bwd = timed(lambda: M.backward_data(p, g, masks, sc, bias_sums=False))
+    t_bwd_b = timed(lambda: M.backward_data(p, g, masks, sc))
+    dpre, db = M.backward_data(p, g, masks, sc)
+    t_wg = timed(lambda: M.param_grads(p, xb, acts, dpre, g, sc))
+    t_lib = timed(lambda: M.library_param_grads(p, xb, acts, dpre, db, g, sc))
+    gb = (2 * (p.depth - 1) * N * 512 + 2 * N * (512 + 2 * p.in_pad) + N * (512 + 64)) / 1e9
     print("%s N=%d: forward %.3f ms (%.0f TFLOP/s; %.3f ms without the activation / mask stores), data gradient %.3f ms (%.0f TFLOP/s)"
           % (name, N, t_fwd, flops / t_fwd / 1e9, t_inf, t_bwd, flops / t_bwd / 1e9))
+    print("    parameter gradients: riggs_mlp_wgrad %.3f ms (%.2f GB of operands: %.2f TB/s) | library GEMMs %.3f ms + bias sums in the "
+          "data-gradient kernel %.3f ms" % (t_wg, gb, gb / t_wg, t_lib, t_bwd_b - t_bwd))
