@@ -151,7 +151,7 @@ def heads_timing(sc, gm, iters=5):
             "tflop_per_iteration": round(flops / 1e12, 3),
             "mfma_frac": round(flops / res[True] / 1e12 / MFMA_F16_DENSE_TFLOPS, 4),
             "mfma_frac_note": "the MLPs' flops (forward, data gradient, weight gradient) over the WHOLE iteration's time (incl. skinning, "
-                              "embeddings, the library's weight-gradient GEMMs) over the dense fp16 MFMA peak"}
+                              "embeddings, operand packing) over the dense fp16 MFMA peak"}
 
 
 def next_rows_timing(sc, gm, cam, iters=20):
