@@ -36,6 +36,7 @@ class FusedAdam(torch.optim.Adam):
         # pose was NaN after a lost PoseMLP hand-off, the instance lists were truncated, the exchange unpacked nothing — the
         # update is a no-op ON THE DEVICE: parameters, moments and step counts stay bit for bit (GraphedTrainStep sets it)
         self.gate = None
+        self._hip_plan = None
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -43,27 +44,31 @@ class FusedAdam(torch.optim.Adam):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        by_cfg = {}
-        self._gather(by_cfg)
-        _launch(by_cfg, getattr(self, "hip_capturable", False), getattr(self, "gate", None))
+        _step([self])
         return loss
 
+    # (everything that can replace state tensors behind a parameter that stays the same object drops the cached launch plan; the
+    # reference's optimizer surgery — replace_tensor_to_optimizer, _prune_optimizer, cat_tensors_to_optimizer — installs NEW
+    # parameter objects, which the plan's signature sees by itself)
+    def load_state_dict(self, state_dict):
+        self._hip_plan = None
+        return super().load_state_dict(state_dict)
+
+    def add_param_group(self, param_group):
+        self._hip_plan = None
+        return super().add_param_group(param_group)
+
     def _gather(self, by_cfg):
-        """Append this optimizer's (parameter, gradient, moments, lr, step) tuples to ``by_cfg`` (keyed by betas / eps), creating
+        """Append this optimizer's (parameter, gradient, moments, group, step) tuples to ``by_cfg`` (keyed by betas / eps), creating
         the state lazily like torch.optim.Adam."""
         cap = getattr(self, "hip_capturable", False)
         for group in self.param_groups:
             if group.get("weight_decay", 0) != 0 or group.get("amsgrad", False) or group.get("maximize", False):
                 raise NotImplementedError("FusedAdam: plain Adam only")
-            lr = group["lr"]
-            if isinstance(lr, torch.Tensor) and not cap:
-                lr = float(lr)
             for p in group["params"]:
                 g = p.grad
                 if g is None:
                     continue
-                # (the usual case inline — a contiguous float32 device parameter with a dense gradient of its shape: the full
-                # checks per parameter were 5 us each, 33 parameters per training iteration)
                 if not (p.is_cuda and p.dtype is torch.float32 and p.is_contiguous()):
                     L.require_cuda_f32("parameter", p)
                     raise L.RiggsHipError("FusedAdam needs contiguous parameters")
@@ -82,49 +87,157 @@ class FusedAdam(torch.optim.Adam):
                 if not (g.is_cuda and g.dtype is torch.float32 and g.is_contiguous() and g.shape == p.shape):
                     g = L.require_cuda_f32("gradient", g, tuple(p.shape))
                 key = (group["betas"][0], group["betas"][1], group["eps"])
-                by_cfg.setdefault(key, []).append((p, g, m, v, lr, st["step"]))
+                by_cfg.setdefault(key, []).append((p, g, m, v, group, st))
 
 
-def _launch(by_cfg, cap, gate=None):
-    lib = L.lib()
-    st_ptr = L.stream_ptr()
+class _Chunk:
+    """One Adam launch (<= 32 tensors of one (betas, eps) configuration): its marshalled argument arrays, kept across steps."""
+    __slots__ = ("n", "b1", "b2", "eps", "params", "groups", "states", "moments", "pptr", "p_arr", "g_arr", "m_arr", "v_arr", "numel",
+                 "lr", "lr_dev", "step_arr", "steps_i64", "keep")
+
+
+class _Plan:
+    """What a step of a fixed set of optimizers launches, marshalled once: a training iteration steps the same 33 tensors every time
+    and only their GRADIENTS are new objects (zero_grad(set_to_none=True)), yet checking and marshalling every tensor from scratch
+    was ~8 us each — 0.27 ms of host time per eagerly issued iteration.  ``sig`` = the parameter objects that had a gradient, in
+    order; ``refresh`` re-validates what can change behind an unchanged signature (the parameter's storage, the moment tensors,
+    the gradient's layout, the learning rates) and re-reads the gradient pointers — anything unexpected rebuilds the plan."""
+
+    def __init__(self, optimizers, cap):
+        self.cap = cap
+        by_cfg = {}
+        for o in optimizers:
+            o._gather(by_cfg)
+        self.chunks = []
+        for (b1, b2, eps), items in by_cfg.items():
+            for i in range(0, len(items), _MAX):
+                it = items[i:i + _MAX]
+                c = _Chunk()
+                n = c.n = len(it)
+                c.b1, c.b2, c.eps = float(b1), float(b2), float(eps)
+                c.params, c.groups, c.states = [t[0] for t in it], [t[4] for t in it], [t[5] for t in it]
+                c.moments = [(t[2], t[3]) for t in it]
+                c.pptr = [t[0].data_ptr() for t in it]
+                arr = lambda k: (C.c_void_p * n)(*[t[k].data_ptr() for t in it])  # noqa: E731
+                c.p_arr, c.g_arr, c.m_arr, c.v_arr = arr(0), arr(1), arr(2), arr(3)
+                c.numel = (C.c_int64 * n)(*[t[0].numel() for t in it])
+                c.lr = (C.c_double * n)()
+                c.lr_dev = (C.c_void_p * n)()
+                c.step_arr = (C.c_void_p * n)()
+                c.steps_i64 = (C.c_int64 * n)()
+                c.keep = [t[1] for t in it]  # (gradients the pointers of this step belong to, incl. converted copies)
+                self.chunks.append(c)
+        self.sig = _signature(optimizers)[0]
+
+    def refresh(self, grads):
+        """False = something changed behind the signature: rebuild."""
+        k = 0
+        f32 = torch.float32
+        for c in self.chunks:
+            g_arr, pptr, moments, states, params = c.g_arr, c.pptr, c.moments, c.states, c.params
+            for j in range(c.n):
+                p, g, st = params[j], grads[k], states[j]
+                k += 1
+                m, v = moments[j]
+                if (st.get("exp_avg") is not m or st.get("exp_avg_sq") is not v or p.data_ptr() != pptr[j] or g.dtype is not f32
+                        or g.layout is not torch.strided or not g.is_cuda or not g.is_contiguous() or g.shape != p.shape):
+                    return False
+                g_arr[j] = g.data_ptr()
+            c.keep = None
+        return k == len(grads)
+
+
+def _signature(optimizers):
+    sig, grads = [], []
+    for o in optimizers:
+        for group in o.param_groups:
+            key = (group["betas"][0], group["betas"][1], group["eps"])
+            for p in group["params"]:
+                g = p.grad
+                if g is not None:
+                    sig.append((id(p), key))
+                    grads.append(g)
+    return sig, grads
+
+
+def _ordered_grads(plan, optimizers):
+    """The gradients in the plan's chunk order (chunks are grouped by configuration, not by optimizer)."""
+    out = []
+    for c in plan.chunks:
+        out += [p.grad for p in c.params]
+    return out
+
+
+def _step(optimizers):
+    """One step of FusedAdam instances of the same mode and gate: the merged, cached launch plan (kept on the first optimizer)."""
+    first = optimizers[0]
+    cap, gate = bool(getattr(first, "hip_capturable", False)), getattr(first, "gate", None)
     if gate is not None and not cap:
         raise L.RiggsHipError("a gated FusedAdam keeps its step counts on the device: capturable=True")
+    plan = getattr(first, "_hip_plan", None)
+    others = tuple(id(o) for o in optimizers)
+    ok = False
+    if isinstance(plan, _Plan) and plan.cap == cap and getattr(first, "_hip_plan_for", None) == others and all(
+            getattr(o, "_hip_plan", None) is not None or o is first for o in optimizers):
+        sig, _ = _signature(optimizers)
+        ok = sig == plan.sig and plan.refresh(_ordered_grads(plan, optimizers))
+    if not ok:
+        plan = _Plan(optimizers, cap)
+        first._hip_plan, first._hip_plan_for = plan, others
+        for o in optimizers[1:]:
+            o._hip_plan = True  # (marker: load_state_dict / add_param_group of ANY member resets it and forces a rebuild)
+    _launch(plan, cap, gate)
+
+
+def _launch(plan, cap, gate=None):
+    lib = L.lib()
+    st_ptr = L.stream_ptr()
     gs = gate.struct() if gate is not None else None
+    chunks = plan.chunks
     if cap:
-        steps = [t[5] for items in by_cfg.values() for t in items]
+        steps = []
+        for c in chunks:
+            for j in range(c.n):
+                st = c.states[j]["step"]
+                if not st.is_cuda:
+                    st = c.states[j]["step"] = st.to(c.params[j].device)
+                steps.append(st)
+                c.step_arr[j] = st.data_ptr()
         if steps and gate is None:
             torch._foreach_add_(steps, 1.0)  # one multi-tensor launch; the kernels below read the new counts
         elif steps:  # ... or one launch of the library's that advances them behind the gate (and counts a skipped step)
             L.check(lib.riggs_adam_steps_advance_gated(len(steps), (C.c_void_p * len(steps))(*[t.data_ptr() for t in steps]),
                                                        C.byref(gs), gate.skipped.data_ptr(), st_ptr), "riggs_adam_steps_advance_gated")
-    for (b1, b2, eps), items in by_cfg.items():
-        for i in range(0, len(items), _MAX):
-            chunk = items[i:i + _MAX]
-            n = len(chunk)
-            arr = lambda k: (C.c_void_p * n)(*[t[k].data_ptr() for t in chunk])  # noqa: E731
-            numel = (C.c_int64 * n)(*[t[0].numel() for t in chunk])
-            if cap:
-                lr_host = (C.c_double * n)(*[0.0 if isinstance(t[4], torch.Tensor) else float(t[4]) for t in chunk])
-                lr_dev = (C.c_void_p * n)(*[L.require_cuda_f32("lr", t[4]).data_ptr() if isinstance(t[4], torch.Tensor) else None
-                                            for t in chunk])
-            if cap and gate is not None:
-                L.check(lib.riggs_adam_step_gated(n, arr(0), arr(1), arr(2), arr(3), numel, lr_host, arr(5), lr_dev, float(b1),
-                                                  float(b2), float(eps), C.byref(gs), None, 0, st_ptr), "riggs_adam_step_gated")
-            elif cap:
-                L.check(lib.riggs_adam_step_capturable(n, arr(0), arr(1), arr(2), arr(3), numel, lr_host, arr(5), lr_dev,
-                                                       float(b1), float(b2), float(eps), st_ptr), "riggs_adam_step_capturable")
+    for c in chunks:
+        n = c.n
+        for j in range(n):
+            lr = c.groups[j]["lr"]
+            if isinstance(lr, torch.Tensor):
+                if cap:
+                    c.lr[j], c.lr_dev[j] = 0.0, L.require_cuda_f32("lr", lr).data_ptr()
+                else:
+                    c.lr[j] = float(lr)
             else:
-                # (host-side step counts, as torch.optim.Adam keeps them: ONE increment and one read for the chunk)
-                cpu_steps = [t[5] for t in chunk]
-                torch._foreach_add_(cpu_steps, 1)
-                lr = (C.c_double * n)(*[float(t[4]) for t in chunk])
-                steps = (C.c_int64 * n)(*[int(v) for v in torch.stack(cpu_steps).tolist()])
-                L.check(lib.riggs_adam_step(n, arr(0), arr(1), arr(2), arr(3), numel, lr, steps, float(b1), float(b2),
-                                            float(eps), st_ptr), "riggs_adam_step")
-            # the kernels write through raw pointers: tell autograd (and anything that caches derived copies of the
-            # parameters by version, e.g. the bf16 weights of riggs_amd.mlp) that the tensors changed
-            torch.autograd.graph.increment_version([t[0] for t in chunk])
+                c.lr[j] = float(lr)
+                if cap:
+                    c.lr_dev[j] = None
+        if cap and gate is not None:
+            L.check(lib.riggs_adam_step_gated(n, c.p_arr, c.g_arr, c.m_arr, c.v_arr, c.numel, c.lr, c.step_arr, c.lr_dev, c.b1, c.b2,
+                                              c.eps, C.byref(gs), None, 0, st_ptr), "riggs_adam_step_gated")
+        elif cap:
+            L.check(lib.riggs_adam_step_capturable(n, c.p_arr, c.g_arr, c.m_arr, c.v_arr, c.numel, c.lr, c.step_arr, c.lr_dev,
+                                                   c.b1, c.b2, c.eps, st_ptr), "riggs_adam_step_capturable")
+        else:
+            # (host-side step counts, as torch.optim.Adam keeps them: ONE increment and one read for the chunk)
+            cpu_steps = [st["step"] for st in c.states]
+            torch._foreach_add_(cpu_steps, 1)
+            for j, v in enumerate(torch.stack(cpu_steps).tolist()):
+                c.steps_i64[j] = int(v)
+            L.check(lib.riggs_adam_step(n, c.p_arr, c.g_arr, c.m_arr, c.v_arr, c.numel, c.lr, c.steps_i64, c.b1, c.b2, c.eps, st_ptr),
+                    "riggs_adam_step")
+        # the kernels write through raw pointers: tell autograd (and anything that caches derived copies of the
+        # parameters by version, e.g. the bf16 weights of riggs_amd.mlp) that the tensors changed
+        torch.autograd.graph.increment_version(c.params)
 
 
 @torch.no_grad()
@@ -148,10 +261,7 @@ def step_many(optimizers):
         for o in optimizers:
             o.step()
         return
-    by_cfg = {}
-    for o in fused:
-        o._gather(by_cfg)
-    _launch(by_cfg, caps.pop(), getattr(fused[0], "gate", None))
+    _step(fused)
     for o in optimizers:
         if not isinstance(o, FusedAdam):
             o.step()

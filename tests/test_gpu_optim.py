@@ -249,3 +249,92 @@ def test_step_many_honours_step_hooks_and_lr_schedulers():
     assert fired == ["post", "post"]
     assert torch.equal(p1[0], p2[0]) and torch.equal(p1[1], p2[1])
     assert o2[1].param_groups[0]["lr"] == pytest.approx(2.5e-3)
+
+
+@pytest.mark.parametrize("capturable", [False, True])
+def test_cached_launch_plan_follows_everything_that_can_change_between_steps(capturable):
+    """FusedAdam keeps its marshalled launch arguments across steps (riggs_amd.optim._Plan).  Whatever changes between two steps —
+    new gradient tensors, a gradient missing, a non-contiguous gradient, a learning rate, ``p.data`` re-pointed, a moment tensor
+    replaced, ``load_state_dict``, the reference's optimizer surgery (new parameter objects), an optimizer stepped alone after a
+    merged step — the update equals torch.optim.Adam's on a twin, step for step."""
+    from riggs_amd.optim import FusedAdam, step_many
+    gen = torch.Generator().manual_seed(5)
+    shapes = [(301, 3), (301, 1, 3), (301, 15, 3), (301, 1), (7,), (64, 5)]
+
+    def make(cls, **kw):
+        ps = [torch.nn.Parameter(torch.randn(s, generator=torch.Generator().manual_seed(i)).cuda()) for i, s in enumerate(shapes)]
+        return ps, cls([{"params": [p], "lr": 1e-3 * (i + 1), "name": str(i)} for i, p in enumerate(ps[:4])], lr=0.0, eps=1e-15, **kw), \
+            cls([{"params": ps[4:], "lr": 5e-4, "name": "rest"}], lr=0.0, eps=1e-15, **kw)
+    pa, a1, a2 = make(FusedAdam, capturable=capturable)
+    pb, b1, b2 = make(torch.optim.Adam)
+
+    def grads(skip=(), strided=()):
+        for i, (p, q) in enumerate(zip(pa, pb)):
+            if i in skip:
+                p.grad = q.grad = None
+                continue
+            g = torch.randn(p.shape, generator=gen).cuda()
+            if i in strided:  # a non-contiguous view of the same values
+                g2 = torch.empty(p.shape + (2,), device="cuda")[..., 0]
+                g2.copy_(g)
+                p.grad, q.grad = g2, g.clone()
+            else:
+                p.grad, q.grad = g, g.clone()
+
+    def both(merged=True):
+        if merged:
+            step_many([a1, a2])
+        else:
+            a1.step()
+            a2.step()
+        b1.step()
+        b2.step()
+        for i, (p, q) in enumerate(zip(pa, pb)):
+            assert float((p.detach() - q.detach()).abs().max()) <= 2e-6 * float(q.detach().abs().max()) + 1e-9, i
+    for _ in range(3):
+        grads()
+        both()                                             # same plan, new gradient objects
+    assert a1._hip_plan is not None
+    plan = a1._hip_plan
+    grads()
+    both()
+    assert a1._hip_plan is plan                            # ... reused, not rebuilt
+    grads(skip=(2, 5))
+    both()                                                 # two parameters without a gradient this step
+    grads(strided=(1,))
+    both()                                                 # a gradient that has to be made contiguous
+    grads()
+    for o in (a1, b1):
+        o.param_groups[1]["lr"] = 7e-3                      # update_learning_rate between steps
+    both()
+    with torch.no_grad():                                  # p.data re-pointed (same object, new storage)
+        pa[0].data = pa[0].data.clone()
+    grads()
+    both()
+    st = a1.state[pa[3]]
+    st["exp_avg"] = st["exp_avg"].clone()                  # a moment tensor replaced behind the same parameter
+    grads()
+    both()
+    sd_a, sd_b = a1.state_dict(), b1.state_dict()
+    a1.load_state_dict(sd_a)
+    b1.load_state_dict(sd_b)
+    grads()
+    both()
+    both(merged=False)                                     # the members stepped alone after merged steps (same gradients again)
+    grads()
+    both()
+    # the reference's replace_tensor_to_optimizer (scene/gaussian_model.py:338-351): a new, longer parameter object in the group
+    for o, ps in ((a1, pa), (b1, pb)):
+        grp = o.param_groups[0]
+        old = grp["params"][0]
+        stored = o.state.pop(old)
+        new = torch.nn.Parameter(torch.cat([old.detach(), old.detach()[:10]]).requires_grad_(True))
+        stored["exp_avg"] = torch.cat([stored["exp_avg"], torch.zeros_like(stored["exp_avg"][:10])])
+        stored["exp_avg_sq"] = torch.cat([stored["exp_avg_sq"], torch.zeros_like(stored["exp_avg_sq"][:10])])
+        grp["params"][0] = new
+        o.state[new] = stored
+        ps[0] = new
+    grads()
+    both()
+    grads()
+    both()
