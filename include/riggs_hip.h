@@ -402,6 +402,14 @@ int riggs_frame_backward(const riggs_frame* frame, const riggs_frame_grads* grad
 int riggs_adam_step(int32_t n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
                     float* const* exp_avg_sq, const int64_t* numel, const double* lr, const int64_t* step, double beta1,
                     double beta2, double eps, riggs_stream stream);
+/* riggs_adam_step for a trainer that issues every call eagerly and never looks at the frame's status words (an unmodified
+ * train_rig.py): an element whose gradient is NaN or Inf — what a frame poisoned by a lost PoseMLP hand-off produces — keeps its
+ * parameter and both moments, and *nonfinite_count (device u32, not NULL, never reset by the library) is incremented per such
+ * element; every other element is updated exactly as by riggs_adam_step.  (The step counts of such a trainer live on the host:
+ * a whole-step gate would leave them ahead of the device.  Inside a hipGraph use riggs_adam_step_gated.) */
+int riggs_adam_step_guarded(int32_t n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
+                            float* const* exp_avg_sq, const int64_t* numel, const double* lr, const int64_t* step, double beta1,
+                            double beta2, double eps, uint32_t* nonfinite_count, riggs_stream stream);
 /* The same update with the step counts (and optionally the learning rates) in DEVICE memory, the layout of
  * torch.optim.Adam(capturable=True): step_dev[k] / lr_dev[k] are HOST arrays of DEVICE pointers to 0-dim float tensors;
  * step_dev[k][0] holds the count AFTER this update (the caller increments it on the stream beforehand); lr_dev may be

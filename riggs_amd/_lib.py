@@ -62,6 +62,29 @@ class GateStruct(C.Structure):
     _fields_ = [("n", C.c_int32), ("reserved", C.c_int32), ("word", C.c_void_p * 4), ("mask", C.c_uint32 * 4)]
 
 
+class Watch:
+    """A non-blocking look at one 32-bit device word, for callers that must not synchronise (an eagerly issued training
+    iteration is bound by the host: a blocking read per iteration would expose the whole queue's latency).  Every ``period``-th
+    ``poll`` enqueues an asynchronous copy of the word into pinned host memory behind the work issued so far; a poll returns the
+    most recent value whose copy has landed (0 until then).  Never call it while the current stream is being captured."""
+
+    def __init__(self, period: int = 16):
+        self.period, self.n, self.event, self.host, self.value = int(period), 0, None, None, 0
+
+    def poll(self, tensor, index: int) -> int:
+        import torch
+        if self.event is not None and self.event.query():
+            self.value, self.event = int(self.host[0]), None
+        self.n += 1
+        if self.event is None and self.n % self.period == 0:
+            if self.host is None:
+                self.host = torch.zeros(1, dtype=tensor.dtype).pin_memory()
+            self.host.copy_(tensor[index:index + 1], non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record()
+        return self.value
+
+
 class FrameGate:
     """A frame's "valid" gate (include/riggs_hip.h: riggs_gate): up to four (device word, mask) pairs — the sticky status word
     of the one-launch PoseMLP kernels, the rasterizer's overflow / sort-barrier flags, the gradient-row exchange's status —
@@ -145,6 +168,7 @@ _SIGS = {
     "riggs_grad_rows_pack": (C.c_int, [C.c_int32, _P, C.c_int32, _P, _P, C.c_float, C.c_int32, _P, _P]),
     "riggs_grad_rows_unpack": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, _P]),
     "riggs_adam_step": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, _P]),
+    "riggs_adam_step_guarded": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, _P, _P]),
     "riggs_adam_step_capturable": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, _P]),
     "riggs_adam_step_gated": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double,
                                         C.POINTER(GateStruct), _P, C.c_int32, _P]),

@@ -31,6 +31,7 @@ struct AdamArgs {
   double lr_host[ADAM_MAX_GROUPS];
   double beta1_d, beta2_d;
   GateArg gate;                            // the frame's "valid" words (include/riggs_hip.h: riggs_gate); n == 0: never gated
+  uint32_t* nonfinite;                     // riggs_adam_step_guarded: elements whose gradient is NaN / Inf are left alone and counted here
 };
 
 // The step counts of a gated update: advanced by ONE small launch in front of it (every workgroup of the update reads them, so
@@ -59,6 +60,16 @@ __device__ __forceinline__ void adam_update(float& p, float g, float& m, float& 
   p = p + neg_step * (m / denom);
 }
 
+// riggs_adam_step_guarded: an element whose gradient is not finite keeps p, m, v (a frame poisoned by a lost PoseMLP hand-off must
+// not reach the parameters of an EAGER trainer either — it has no gate: its step counts live on the host); returns 1 for it
+__device__ __forceinline__ uint32_t adam_update_guarded(float& p, float g, float& m, float& v, float w1, float beta2, float w2, float eps,
+                                                        float neg_step, float bc2s) {
+  if (!__builtin_isfinite(g)) return 1u;
+  adam_update(p, g, m, v, w1, beta2, w2, eps, neg_step, bc2s);
+  return 0u;
+}
+
+template <bool GUARD>
 __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a) {
   __shared__ float s_ns[ADAM_MAX_GROUPS], s_bs[ADAM_MAX_GROUPS];
   // an invalid frame (NaN pose after a lost PoseMLP hand-off, truncated lists, an exchange that unpacked nothing) is a
@@ -77,6 +88,7 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a) {
   }
   __syncthreads();
   const int64_t total = a.vec_start[a.n_groups];
+  uint32_t bad = 0u;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     int gi = 0;
 #pragma unroll
@@ -93,20 +105,31 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a) {
       float4 p = *reinterpret_cast<float4*>(P + e);
       const float4 g = *reinterpret_cast<const float4*>(G + e);
       float4 m = *reinterpret_cast<float4*>(M + e), v = *reinterpret_cast<float4*>(V + e);
-      adam_update(p.x, g.x, m.x, v.x, a.w1, a.beta2, a.w2, a.eps, ns, bs);
-      adam_update(p.y, g.y, m.y, v.y, a.w1, a.beta2, a.w2, a.eps, ns, bs);
-      adam_update(p.z, g.z, m.z, v.z, a.w1, a.beta2, a.w2, a.eps, ns, bs);
-      adam_update(p.w, g.w, m.w, v.w, a.w1, a.beta2, a.w2, a.eps, ns, bs);
+      if constexpr (GUARD) {
+        bad += adam_update_guarded(p.x, g.x, m.x, v.x, a.w1, a.beta2, a.w2, a.eps, ns, bs);
+        bad += adam_update_guarded(p.y, g.y, m.y, v.y, a.w1, a.beta2, a.w2, a.eps, ns, bs);
+        bad += adam_update_guarded(p.z, g.z, m.z, v.z, a.w1, a.beta2, a.w2, a.eps, ns, bs);
+        bad += adam_update_guarded(p.w, g.w, m.w, v.w, a.w1, a.beta2, a.w2, a.eps, ns, bs);
+      } else {
+        adam_update(p.x, g.x, m.x, v.x, a.w1, a.beta2, a.w2, a.eps, ns, bs);
+        adam_update(p.y, g.y, m.y, v.y, a.w1, a.beta2, a.w2, a.eps, ns, bs);
+        adam_update(p.z, g.z, m.z, v.z, a.w1, a.beta2, a.w2, a.eps, ns, bs);
+        adam_update(p.w, g.w, m.w, v.w, a.w1, a.beta2, a.w2, a.eps, ns, bs);
+      }
       *reinterpret_cast<float4*>(P + e) = p;
       *reinterpret_cast<float4*>(M + e) = m;
       *reinterpret_cast<float4*>(V + e) = v;
     } else {
       for (int64_t j = e; j < n; j++) {
         float p = P[j], m = M[j], v = V[j];
-        adam_update(p, G[j], m, v, a.w1, a.beta2, a.w2, a.eps, ns, bs);
+        if constexpr (GUARD) bad += adam_update_guarded(p, G[j], m, v, a.w1, a.beta2, a.w2, a.eps, ns, bs);
+        else adam_update(p, G[j], m, v, a.w1, a.beta2, a.w2, a.eps, ns, bs);
         P[j] = p; M[j] = m; V[j] = v;
       }
     }
+  }
+  if constexpr (GUARD) {
+    if (bad) atomicAdd(a.nonfinite, bad);  // (the rare path: nothing is added on a healthy step)
   }
 }
 
@@ -132,12 +155,13 @@ extern "C" {
 static int adam_launch(int32_t n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
                        float* const* exp_avg_sq, const int64_t* numel, const double* lr, const int64_t* step,
                        const float* const* step_dev, const float* const* lr_dev, double beta1, double beta2, double eps,
-                       riggs_stream stream, const riggs_gate* gate = nullptr) {
+                       riggs_stream stream, const riggs_gate* gate = nullptr, uint32_t* nonfinite = nullptr) {
   RIGGS_REQUIRE(n_groups >= 0 && n_groups <= ADAM_MAX_GROUPS, "at most 32 parameter tensors per launch");
   AdamArgs a;
   memset(&a, 0, sizeof(a));
   RIGGS_REQUIRE(gate_arg(a.gate, gate) == 0, "riggs_gate: 0..4 non-NULL words");
   a.n_groups = n_groups;
+  a.nonfinite = nonfinite;
   int64_t vs = 0;
   for (int k = 0; k < n_groups; k++) {
     RIGGS_REQUIRE(params[k] && grads[k] && exp_avg[k] && exp_avg_sq[k], "NULL tensor in an Adam group");
@@ -170,7 +194,8 @@ static int adam_launch(int32_t n_groups, float* const* params, const float* cons
     ProfScope ps(PROF_ADAM, s);
     const int64_t want = (vs + 255) / 256;
     const unsigned blocks = (unsigned)(want < 256 * 64 ? want : 256 * 64);  // grid-stride beyond 64 workgroups per CU (measured: 16 -> 64 = -7 %)
-    hipLaunchKernelGGL(adam_step_kernel, dim3(blocks), dim3(256), 0, s, a);
+    if (nonfinite) hipLaunchKernelGGL(adam_step_kernel<true>, dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(adam_step_kernel<false>, dim3(blocks), dim3(256), 0, s, a);
   }
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
@@ -180,6 +205,14 @@ int riggs_adam_step(int32_t n_groups, float* const* params, const float* const* 
                     float* const* exp_avg_sq, const int64_t* numel, const double* lr, const int64_t* step, double beta1,
                     double beta2, double eps, riggs_stream stream) {
   return adam_launch(n_groups, params, grads, exp_avg, exp_avg_sq, numel, lr, step, nullptr, nullptr, beta1, beta2, eps, stream);
+}
+
+int riggs_adam_step_guarded(int32_t n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
+                            float* const* exp_avg_sq, const int64_t* numel, const double* lr, const int64_t* step, double beta1,
+                            double beta2, double eps, uint32_t* nonfinite_count, riggs_stream stream) {
+  RIGGS_REQUIRE(nonfinite_count != nullptr, "riggs_adam_step_guarded: the counter is NULL");
+  return adam_launch(n_groups, params, grads, exp_avg, exp_avg_sq, numel, lr, step, nullptr, nullptr, beta1, beta2, eps, stream, nullptr,
+                     nonfinite_count);
 }
 
 int riggs_adam_step_capturable(int32_t n_groups, float* const* params, const float* const* grads, float* const* exp_avg,

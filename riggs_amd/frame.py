@@ -57,6 +57,8 @@ class _FrameFn(torch.autograd.Function):
         sync = pn._hip_sync
         if sync.device != dev or sync.numel() * 4 < lib.riggs_pose_mlp_sync_bytes(depth, width):
             sync = None
+        else:
+            pn.watch()
         keep = []
         cfg = _cfg(settings, N, f_dc.shape[1] + f_rest.shape[1], True, isotropic, keep, arena.tight_lists)
         # outputs and saved state: ONE float allocation for the per-joint arrays, the PoseMLP's activations, the residuals and

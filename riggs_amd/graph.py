@@ -60,6 +60,11 @@ class GraphedFrame:
         # rank's step is then a single graph launch instead of two plus five eager host calls
         self.exchange = None
         self.exchange_in_graph = False
+        # the PoseMLP's sticky status word belongs to this object from here on (gated consumers, ``check()``): the eager
+        # callers' non-blocking watcher (PoseMLP.watch) must not clear it underneath
+        pn = getattr(sw, "pose_net", None)
+        if pn is not None:
+            pn._status_owned = True
 
     # ---- the frame's "valid" words (include/riggs_hip.h: riggs_gate), for whoever consumes its gradients on the device
     def _pose_status(self):

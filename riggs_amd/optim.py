@@ -25,7 +25,8 @@ class FusedAdam(torch.optim.Adam):
     then evaluated inside the kernel, so a captured hipGraph of the step stays correct across replays (a learning-rate
     schedule is applied with ``group["lr"].fill_(value)`` between replays)."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, capturable=False, **kw):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, capturable=False,
+                 skip_nonfinite=True, **kw):
         if weight_decay != 0 or amsgrad or kw.get("maximize", False):
             raise NotImplementedError("FusedAdam implements the reference's configuration: plain Adam "
                                       "(weight_decay=0, amsgrad=False, maximize=False)")
@@ -37,6 +38,12 @@ class FusedAdam(torch.optim.Adam):
         # update is a no-op ON THE DEVICE: parameters, moments and step counts stay bit for bit (GraphedTrainStep sets it)
         self.gate = None
         self._hip_plan = None
+        # the eager mode (host-side step counts: no gate): an element whose gradient is NaN / Inf keeps its parameter and moments
+        # (riggs_adam_step_guarded) — a frame poisoned by a lost PoseMLP hand-off must not destroy an unmodified trainer's run —
+        # and is counted on the device; the count is looked at without blocking (riggs_amd._lib.Watch) and reported as a
+        # RuntimeWarning.  ``skip_nonfinite=False``: torch.optim.Adam's behaviour (NaN propagates into the parameters).
+        self.skip_nonfinite = bool(skip_nonfinite)
+        self.nonfinite_seen = 0
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -186,10 +193,30 @@ def _step(optimizers):
         first._hip_plan, first._hip_plan_for = plan, others
         for o in optimizers[1:]:
             o._hip_plan = True  # (marker: load_state_dict / add_param_group of ANY member resets it and forces a rebuild)
-    _launch(plan, cap, gate)
+    guard = None
+    if not cap and all(getattr(o, "skip_nonfinite", False) for o in optimizers) and plan.chunks:
+        guard = _nonfinite_counter(first, plan.chunks[0].params[0].device)
+    _launch(plan, cap, gate, guard)
+    if guard is not None and not torch.cuda.is_current_stream_capturing():
+        n = first._nonfinite_watch.poll(guard, 0)
+        if n > first.nonfinite_seen:
+            import warnings
+            warnings.warn("FusedAdam: %d gradient elements were NaN or Inf since the last report and were NOT applied (their "
+                          "parameters and moments are unchanged); skip_nonfinite=False restores torch.optim.Adam's behaviour"
+                          % (n - first.nonfinite_seen), RuntimeWarning, stacklevel=3)
+            first.nonfinite_seen = n
 
 
-def _launch(plan, cap, gate=None):
+def _nonfinite_counter(opt, device):
+    c = getattr(opt, "_nonfinite_count", None)
+    if c is None or c.device != device:
+        c = opt._nonfinite_count = torch.zeros(1, dtype=torch.int32, device=device)
+        opt._nonfinite_watch = L.Watch(period=16)
+        opt.nonfinite_seen = 0
+    return c
+
+
+def _launch(plan, cap, gate=None, guard=None):
     lib = L.lib()
     st_ptr = L.stream_ptr()
     gs = gate.struct() if gate is not None else None
@@ -233,8 +260,12 @@ def _launch(plan, cap, gate=None):
             torch._foreach_add_(cpu_steps, 1)
             for j, v in enumerate(torch.stack(cpu_steps).tolist()):
                 c.steps_i64[j] = int(v)
-            L.check(lib.riggs_adam_step(n, c.p_arr, c.g_arr, c.m_arr, c.v_arr, c.numel, c.lr, c.steps_i64, c.b1, c.b2, c.eps, st_ptr),
-                    "riggs_adam_step")
+            if guard is not None:
+                L.check(lib.riggs_adam_step_guarded(n, c.p_arr, c.g_arr, c.m_arr, c.v_arr, c.numel, c.lr, c.steps_i64, c.b1, c.b2, c.eps,
+                                                    guard.data_ptr(), st_ptr), "riggs_adam_step_guarded")
+            else:
+                L.check(lib.riggs_adam_step(n, c.p_arr, c.g_arr, c.m_arr, c.v_arr, c.numel, c.lr, c.steps_i64, c.b1, c.b2, c.eps, st_ptr),
+                        "riggs_adam_step")
         # the kernels write through raw pointers: tell autograd (and anything that caches derived copies of the
         # parameters by version, e.g. the bf16 weights of riggs_amd.mlp) that the tensors changed
         torch.autograd.graph.increment_version(c.params)

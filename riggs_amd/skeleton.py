@@ -67,6 +67,36 @@ class PoseMLP(nn.Module):
             raise L.RiggsHipError("PoseMLP: a workgroup hand-off of the one-launch kernel timed out (GPU shared with "
                                   "another long-running kernel?); the pose of that step was NaN — discard the step")
 
+    def watch(self):
+        """What an EAGER caller gets instead of ``check_status`` (an unmodified train_rig.py never calls it, and a blocking read
+        per iteration would stall a host-bound loop): a non-blocking look at the sticky status word every few calls
+        (riggs_amd._lib.Watch).  A time-out seen this way is reported as a RuntimeWarning and the word cleared; the frame it
+        belongs to had a NaN pose — ``FusedAdam`` leaves every element whose gradient is not finite untouched
+        (riggs_adam_step_guarded), so the parameters survive it — and from the third one on the process switches to the
+        one-launch-per-layer PoseMLP kernels (``riggs_set_option("pose_mlp_layered", 1)``: no hand-offs to lose).  Does nothing
+        for a module whose word a captured graph owns (GraphedFrame / GraphedTrainStep gate on it and repair in ``check()``)."""
+        sync = self._hip_sync
+        if getattr(self, "_status_owned", False) or not sync.is_cuda or torch.cuda.is_current_stream_capturing():
+            return
+        w = getattr(self, "_status_index", None)
+        if w is None:
+            w = self._status_index = int(L.lib().riggs_pose_mlp_status_word(len(self.net), self.net[0].out_features))
+            self._watch, self.handoff_timeouts = L.Watch(), 0
+        if w >= sync.numel():
+            return
+        if self._watch.poll(sync, w):
+            import warnings
+            self._watch.value = 0
+            sync[w:w + 1].zero_()
+            self.handoff_timeouts += 1
+            safe = self.handoff_timeouts >= 3
+            if safe:
+                L.set_option("pose_mlp_layered", 1)
+            warnings.warn("PoseMLP: a workgroup hand-off of the one-launch kernel timed out (GPU shared with another long-running "
+                          "kernel?) — %d so far; the pose of that frame was NaN and its non-finite gradients were not applied by "
+                          "FusedAdam%s" % (self.handoff_timeouts, "; switching to the one-launch-per-layer PoseMLP kernels" if safe else ""),
+                          RuntimeWarning, stacklevel=3)
+
     def _fusable(self, t):
         w = self.net[0].out_features
         return (t.is_cuda and t.dtype == torch.float32 and t.numel() == 1 and self.multires > 0 and w <= 256
@@ -86,6 +116,8 @@ class PoseMLP(nn.Module):
             if sync.device != t.device or sync.numel() * 4 < L.lib().riggs_pose_mlp_sync_bytes(len(self.net),
                                                                                                    self.net[0].out_features):
                 sync = None  # the library then clears a private state per call
+            else:
+                self.watch()
             rot, tr = _PoseMLPFn.apply(t.reshape(1), len(self.net), self.net[0].out_features, self.multires,
                                        self.skips[0], rot_bias, sync, *params)
             return {"rotation": rot, "translation": tr}
@@ -714,6 +746,8 @@ class SkeletonWarp(nn.Module):
             sync = pn._hip_sync
             if sync.device != x.device or sync.numel() * 4 < L.lib().riggs_pose_mlp_sync_bytes(len(pn.net), pn.net[0].out_features):
                 sync = None
+            else:
+                pn.watch()
             d_xyz, d_rot, d_nodes, local_rot, global_trans, transforms, node_rot = _PoseDeform.apply(
                 _time.reshape(1), self._rot_bias, sync, self._node_radius, mask, x, joints, par, self.K, weight_mod,
                 len(pn.net), pn.net[0].out_features, pn.multires, pn.skips[0], *params)

@@ -225,3 +225,81 @@ def test_a_gated_pack_marks_the_segment_and_every_rank_skips_the_unpack():
     words[0] = 0
     bucket.publish_validity()
     assert float(bucket.tail[0]) == 0.0 and (int(t.view(torch.int32)[i]) & m) == 0
+
+
+def test_an_eager_trainer_survives_a_poisoned_frame_and_is_told():
+    """An unmodified train_rig.py issues everything eagerly and never looks at a status word.  A frame poisoned by a lost PoseMLP
+    hand-off (the library's fault hook) must not reach its parameters: the eager FusedAdam leaves every element whose gradient is
+    not finite untouched (riggs_adam_step_guarded) and says so; the skeleton's non-blocking watcher (PoseMLP.watch) reports the
+    time-out, clears the sticky word and — from the third one on — switches to the layered PoseMLP kernels."""
+    import warnings
+
+    import bench
+    from riggs_amd import _lib as L
+    from riggs_amd.optim import FusedAdam
+    from riggs_amd.render import render
+    old = dict(bench.WORKLOAD)
+    bench.WORKLOAD.update(N=5000, J=8, H=64, W=64)
+    try:
+        sc, cam, gm, sw = bench.build_workload(0, "cuda:0")
+    finally:
+        bench.WORKLOAD.clear()
+        bench.WORKLOAD.update(old)
+    gm.training_setup(bench._train_args())                      # the reference's call: an eager (non-capturable) FusedAdam
+    sk = FusedAdam([{"params": g["params"], "lr": 5e-4, "name": g["name"]} for g in sw.trainable_parameters()], lr=0.0, eps=1e-15)
+    assert gm.optimizer.skip_nonfinite and not gm.optimizer.hip_capturable
+    pn = sw.pose_net
+    word = int(L.lib().riggs_pose_mlp_status_word(len(pn.net), pn.net[0].out_features))
+    bg = torch.zeros(3, device="cuda")
+    target = torch.rand(3, 64, 64, generator=torch.Generator().manual_seed(1)).cuda()
+
+    def iteration():
+        for o in (gm.optimizer, sk):
+            o.zero_grad(set_to_none=True)
+        d = sw(gm.get_xyz, sw.expand_time(cam.fid), motion_mask=gm.motion_mask)
+        out = render(cam, gm, bench.Pipe, bg, d["d_xyz"], d["d_rotation"], d["d_scaling"])
+        ((out["render"] - target).abs().mean() + 1e-3 * d["d_nodes"].square().sum()).backward()
+        gm.optimizer.step()
+        sk.step()
+    params = [p for o in (gm.optimizer, sk) for g in o.param_groups for p in g["params"]]
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        for _ in range(3):
+            iteration()
+        torch.cuda.synchronize()
+        ours = lambda: [str(w.message) for w in seen if "hand-off" in str(w.message) or "NaN or Inf" in str(w.message)]  # noqa: E731
+        assert all(torch.isfinite(p).all() for p in params) and not ours()
+        try:
+            for k in range(3):                                      # three poisoned frames, healthy ones in between
+                pn._hip_sync[word + 1] = 1                          # the fault hook: this launch loses a hand-off
+                iteration()
+                pn._hip_sync[word + 1] = 0
+                torch.cuda.synchronize()
+                assert int(pn._hip_sync[word]) != 0 or pn.handoff_timeouts > k   # the sticky word is up (or already reported)
+                assert all(torch.isfinite(p).all() for p in params), "a poisoned frame reached the parameters"
+                for o in (gm.optimizer, sk):
+                    for st in o.state.values():
+                        assert torch.isfinite(st["exp_avg"]).all() and torch.isfinite(st["exp_avg_sq"]).all()
+                for _ in range(40):                                 # the watcher looks every 16th call, without blocking
+                    iteration()
+                torch.cuda.synchronize()
+                assert pn.handoff_timeouts == k + 1 and int(pn._hip_sync[word]) == 0
+            texts = ours()
+            assert sum("hand-off" in t for t in texts) == 3 and any("one-launch-per-layer" in t for t in texts)
+            assert any("NaN or Inf" in t for t in texts) and sk.nonfinite_seen > 0
+        finally:
+            L.set_option("pose_mlp_layered", 0)
+    # torch.optim.Adam's behaviour on request
+    p = torch.nn.Parameter(torch.ones(8, device="cuda"))
+    o = FusedAdam([p], lr=1e-2, skip_nonfinite=False)
+    p.grad = torch.full_like(p, float("nan"))
+    o.step()
+    assert torch.isnan(p).all()
+    q = torch.nn.Parameter(torch.ones(8, device="cuda"))
+    o = FusedAdam([q], lr=1e-2)
+    q.grad = torch.tensor([float("nan"), 1.0, float("inf"), 1.0, 1.0, 1.0, 1.0, -float("inf")], device="cuda")
+    o.step()
+    torch.cuda.synchronize()
+    want = torch.ones(8) - 1e-2
+    want[[0, 2, 7]] = 1.0
+    assert torch.allclose(q.detach().cpu(), want, atol=1e-6) and int(o._nonfinite_count) == 3
