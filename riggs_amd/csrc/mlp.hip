@@ -435,35 +435,62 @@ __global__ __launch_bounds__(256, GT == 2 ? 3 : 2) void mlp_backward_kernel(MlpB
 // Positional encoding straight into the kernels' operand: row n = [x_n, sin(2^k x_n), cos(2^k x_n) (k < multires), tail, 0 ...]
 // as bf16, (rows rounded up to 128) x in_pad — get_embedder of utils/time_utils.py:208-256 followed by the concatenation
 // with a per-call constant vector (DeformMLP's pose), instead of ~45 elementwise launches and a 75 MB fp32 intermediate.
+// Phase 1: thread = one row of the workgroup's 256.  sin / cos of the base angle once per coordinate (full-precision sincosf),
+// every further octave by angle doubling — sin 2a = 2 sin a cos a, cos 2a = 1 - 2 sin^2 a: two multiply-adds instead of two
+// range-reduced transcendentals; the error doubles per octave (<= 2^9 x 6e-8 = 3e-5 at the tenth: a tenth of half a 16-bit ulp at
+// 1) — 63 columns cost 3 sincosf + 54 FMAs instead of 60 sinf / cosf calls (the kernel was 55 us of vector work for 38 MB of
+// output).  The values meet in LDS (row stride 132 bytes: one column of 32 rows = 32 banks).  Phase 2: the workgroup's rows are
+// one contiguous run of the output — 16-byte pieces, consecutive threads = consecutive addresses; a thread's piece sits at the
+// same columns in every row it copies, so the tail's values (the same in every row: DeformMLP's pose) are converted once.
+#define MLP_EMB_PE 64  // positional-encoding columns staged per row (multires <= 10: 63)
 template <bool H16>
 __global__ __launch_bounds__(256) void mlp_embed_kernel(int N, int n_rows, int multires, int n_tail, int in_pad,
                                                         const float* __restrict__ x, const float* __restrict__ tail,
                                                         unsigned short* __restrict__ out) {
-  // thread = 8 consecutive columns of one row: 16-byte stores, consecutive threads -> consecutive addresses
-  const int segs = in_pad >> 3;
-  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (size_t)n_rows * segs) return;
-  const int n = (int)(t / segs), c0 = (int)(t - (size_t)n * segs) * 8;
+  __shared__ unsigned short s_pe[256][MLP_EMB_PE + 2];
+  const int tid = threadIdx.x, row0 = blockIdx.x * 256;
   const int pe = 3 * (1 + 2 * multires);
-  bf16x8 v;
+  {
+    const int n = row0 + tid;
+    unsigned short* r = s_pe[tid];
+    if (n < N) {
+      const float xv[3] = {x[3 * n], x[3 * n + 1], x[3 * n + 2]};
+      float sn[3], cs[3];
 #pragma unroll
-  for (int q = 0; q < 8; q++) v[q] = 0;
-  if (n < N) {
-    const float xv[3] = {x[3 * n], x[3 * n + 1], x[3 * n + 2]};
+      for (int w = 0; w < 3; w++) { r[w] = f2h<H16>(xv[w]); sincosf(xv[w], &sn[w], &cs[w]); }
+      for (int k = 0; k < multires; k++) {
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-      const int c = c0 + q;
-      float f = 0.f;
-      if (c < 3) f = xv[c];
-      else if (c < pe) {
-        const int k = (c - 3) / 6, w = (c - 3) - 6 * k;
-        const float a = xv[w % 3] * (float)(1 << k);
-        f = (w < 3) ? sinf(a) : cosf(a);
-      } else if (c < pe + n_tail) f = tail[c - pe];
-      v[q] = (short)f2h<H16>(f);
+        for (int w = 0; w < 3; w++) {
+          r[3 + 6 * k + w] = f2h<H16>(sn[w]);
+          r[6 + 6 * k + w] = f2h<H16>(cs[w]);
+          const float s2 = 2.0f * sn[w] * cs[w], c2 = 1.0f - 2.0f * sn[w] * sn[w];
+          sn[w] = s2; cs[w] = c2;
+        }
+      }
+    } else {
+      for (int c = 0; c < pe; c++) r[c] = 0;
     }
   }
-  *reinterpret_cast<bf16x8*>(out + (size_t)n * in_pad + c0) = v;
+  __syncthreads();
+  const int segs = in_pad >> 3;            // 8 or 16: divides 256, so (e % segs) is the same for every piece of a thread
+  const int c8 = (tid % segs) * 8;
+  unsigned short tl[8];                    // this thread's columns where they lie in the tail (rows < N)
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    const int c = c8 + q;
+    tl[q] = (c >= pe && c < pe + n_tail) ? f2h<H16>(tail[c - pe]) : (unsigned short)0;
+  }
+  for (int e = tid; e < 256 * segs; e += 256) {
+    const int r = e / segs, n = row0 + r;
+    if (n >= n_rows) break;
+    bf16x8 v;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int c = c8 + q;
+      v[q] = (short)((c < pe) ? s_pe[r][c < MLP_EMB_PE ? c : 0] : (n < N ? tl[q] : (unsigned short)0));
+    }
+    *reinterpret_cast<bf16x8*>(out + (size_t)n * in_pad + c8) = v;
+  }
 }
 
 // fp32 master weights -> the bf16 operand layouts of both kernels, in ONE launch (the masters change every optimizer step,
@@ -618,7 +645,8 @@ int riggs_mlp_embed(int32_t N, int32_t multires, int32_t n_tail, const float* x,
   const int n_rows = (N + 127) / 128 * 128;
   if (n_rows == 0) return 0;
   RIGGS_REQUIRE(x && out_bf16 && (n_tail == 0 || tail), "MLP embedding pointers");
-  const size_t n_thr = (size_t)n_rows * (in_pad >> 3);
+  RIGGS_REQUIRE(3 * (1 + 2 * multires) <= MLP_EMB_PE, "MLP embedding: multires must be <= 10");
+  const size_t n_thr = (size_t)n_rows;
   if (fp16) hipLaunchKernelGGL(mlp_embed_kernel<true>, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N, n_rows,
                                multires, n_tail, in_pad, x, tail, (unsigned short*)out_bf16);
   else hipLaunchKernelGGL(mlp_embed_kernel<false>, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N, n_rows,
