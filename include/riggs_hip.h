@@ -672,6 +672,10 @@ int riggs_mlp_forward(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, i
 int riggs_mlp_backward(int32_t N, int32_t out_ch, int32_t depth, int32_t skip, const void* const* weights_t_bf16,
                        const void* w_out_t_bf16, const float* g_out, const float* g_scale, const void* relu_masks,
                        void* dpre_bf16, float* db_partial, int32_t fp16, riggs_stream stream);
+/* The g_scale of the fp16 format from the gradient itself: scale[0] = 2^floor(log2(1024 / max|g|)) (max|g| clamped at 1e-30), two
+ * launches, no host synchronisation.  zero_word: a device u32 that is ZERO on entry (the caller clears it once) and zero again
+ * behind the call. */
+int riggs_mlp_grad_scale(int64_t n, const float* g, float* scale, uint32_t* zero_word, riggs_stream stream);
 /* db_partial: (ceil(N / riggs_mlp_rows_per_workgroup()), depth, 256) fp32 — per-workgroup column sums of dpre; the bias
  * gradients are their sum over the first axis.  May be NULL when riggs_mlp_wgrad follows (it sums the columns itself). */
 int32_t riggs_mlp_rows_per_workgroup(void);

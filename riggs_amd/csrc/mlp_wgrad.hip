@@ -256,6 +256,26 @@ __global__ __launch_bounds__(256) void mlp_gob_kernel(int N, int rows, int out_c
   *reinterpret_cast<wg_h8*>(gob + e * 8) = v;
 }
 
+// max |g| over a tensor -> the power of two that lifts it to ~2^10 (riggs_mlp_grad_scale): the maximum is taken on the bit
+// patterns (non-negative floats order like unsigned integers) into a word that is zero between calls; a second, one-thread launch
+// turns it into the scale and clears the word again
+__global__ __launch_bounds__(256) void mlp_amax_kernel(int64_t n, const float* __restrict__ g, uint32_t* __restrict__ word) {
+  uint32_t m = 0u;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const uint4 v = reinterpret_cast<const uint4*>(g)[i];
+    m = max(max(m, v.x & 0x7FFFFFFFu), max(max(v.y & 0x7FFFFFFFu, v.z & 0x7FFFFFFFu), v.w & 0x7FFFFFFFu));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) m = max(m, __float_as_uint(g[(n4 << 2) + threadIdx.x]) & 0x7FFFFFFFu);
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(word, m);
+}
+__global__ void mlp_scale_kernel(uint32_t* __restrict__ word, float* __restrict__ scale) {
+  const float amax = fmaxf(__uint_as_float(word[0]), 1e-30f);
+  scale[0] = exp2f(floorf(log2f(1024.0f / amax)));
+  word[0] = 0u;
+}
+
 struct WgOut {
   const float* part;  // (splits, M, K)
   float* dst;         // row-major, leading dimension ld, first column col_off
@@ -372,6 +392,20 @@ static void wg_plan(WgPlan& P, int N, int in_ch, int depth, int skip, int cus) {
 using namespace riggs;
 
 extern "C" {
+
+int riggs_mlp_grad_scale(int64_t n, const float* g, float* scale, uint32_t* zero_word, riggs_stream stream) {
+  RIGGS_REQUIRE(n >= 0 && scale && zero_word && (n == 0 || g), "riggs_mlp_grad_scale: bad arguments");
+  RIGGS_REQUIRE(((uintptr_t)g & 15) == 0, "riggs_mlp_grad_scale: the tensor must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  if (n > 0) {
+    const int64_t want = ((n >> 2) + 255) / 256;
+    hipLaunchKernelGGL(mlp_amax_kernel, dim3((unsigned)(want < 2048 ? (want > 0 ? want : 1) : 2048)), dim3(256), 0, s, n, g, zero_word);
+    RIGGS_HIP_CHECK(hipGetLastError());
+  }
+  hipLaunchKernelGGL(mlp_scale_kernel, dim3(1), dim3(1), 0, s, zero_word, scale);
+  RIGGS_HIP_CHECK(hipGetLastError());
+  return 0;
+}
 
 size_t riggs_mlp_wgrad_workspace_bytes(int32_t N, int32_t in_ch, int32_t depth, int32_t skip) {
   if (N <= 0 || depth < 1 || depth > 10 || in_ch < 1 || in_ch > 128 || skip < 0 || skip >= depth - 1) return 0;

@@ -124,13 +124,22 @@ def forward(p: Packed, x_emb: torch.Tensor, want_acts: bool, xb: torch.Tensor = 
     return out, (acts, masks) if want_acts else None
 
 
+_ZERO_WORD = {}
+
+
 def grad_scale(g_out: torch.Tensor) -> torch.Tensor:
     """The power of two (a device scalar: no host synchronisation) that lifts max|g_out| to ~2^10: with fp16 operands the
-    gradients of a per-pixel-averaged loss (1e-6 .. 1e-9) would otherwise sit in half precision's subnormals."""
+    gradients of a per-pixel-averaged loss (1e-6 .. 1e-9) would otherwise sit in half precision's subnormals.  Two launches
+    (``riggs_mlp_grad_scale``; as torch ops it was seven and a copy of the tensor)."""
     if g_out.numel() == 0:
         return torch.ones(1, device=g_out.device)
-    amax = g_out.abs().amax().clamp_min(1e-30)
-    return torch.exp2(torch.floor(torch.log2(1024.0 / amax))).reshape(1)
+    g = L.require_cuda_f32("g_out", g_out)
+    word = _ZERO_WORD.get(g.device)
+    if word is None:
+        word = _ZERO_WORD[g.device] = torch.zeros(1, dtype=torch.int32, device=g.device)
+    scale = torch.empty(1, device=g.device)
+    L.check(L.lib().riggs_mlp_grad_scale(g.numel(), g.data_ptr(), scale.data_ptr(), word.data_ptr(), L.stream_ptr()), "riggs_mlp_grad_scale")
+    return scale
 
 
 def backward_data(p: Packed, g_out: torch.Tensor, masks: torch.Tensor, scale: torch.Tensor = None, bias_sums: bool = True):
