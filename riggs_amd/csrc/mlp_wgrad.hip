@@ -268,7 +268,15 @@ __global__ __launch_bounds__(256) void mlp_amax_kernel(int64_t n, const float* _
   }
   if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) m = max(m, __float_as_uint(g[(n4 << 2) + threadIdx.x]) & 0x7FFFFFFFu);
   for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(word, m);
+  // ONE atomic per workgroup, a few hundred workgroups: atomics on one address are served one after the other at the memory
+  // side (one per wave of 2 048 workgroups were 8 192 of them: 70 us for a 6 us read)
+  __shared__ uint32_t s_m[4];
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
+    if (m) atomicMax(word, m);
+  }
 }
 __global__ void mlp_scale_kernel(uint32_t* __restrict__ word, float* __restrict__ scale) {
   const float amax = fmaxf(__uint_as_float(word[0]), 1e-30f);
@@ -399,7 +407,7 @@ int riggs_mlp_grad_scale(int64_t n, const float* g, float* scale, uint32_t* zero
   hipStream_t s = (hipStream_t)stream;
   if (n > 0) {
     const int64_t want = ((n >> 2) + 255) / 256;
-    hipLaunchKernelGGL(mlp_amax_kernel, dim3((unsigned)(want < 2048 ? (want > 0 ? want : 1) : 2048)), dim3(256), 0, s, n, g, zero_word);
+    hipLaunchKernelGGL(mlp_amax_kernel, dim3((unsigned)(want < 512 ? (want > 0 ? want : 1) : 512)), dim3(256), 0, s, n, g, zero_word);
     RIGGS_HIP_CHECK(hipGetLastError());
   }
   hipLaunchKernelGGL(mlp_scale_kernel, dim3(1), dim3(1), 0, s, zero_word, scale);
