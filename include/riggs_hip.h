@@ -454,6 +454,17 @@ int riggs_adam_step_gated(int32_t n_groups, float* const* params, const float* c
                           float* const* exp_avg_sq, const int64_t* numel, const double* lr, float* const* step_dev,
                           const float* const* lr_dev, double beta1, double beta2, double eps, const riggs_gate* gate,
                           uint32_t* skipped, int32_t advance_steps, riggs_stream stream);
+/* The gated pair with the bias corrections evaluated ONCE: riggs_adam_steps_advance_coef advances the counts like
+ * riggs_adam_steps_advance_gated and writes coef[2 k] = 1 - beta1^t, coef[2 k + 1] = sqrt(1 - beta2^t) of the new counts (double
+ * precision, one thread per count; coef: 2 n_steps device floats); riggs_adam_step_gated_coef = riggs_adam_step_gated
+ * (advance_steps = 0) reading them (coef: the 2 n_groups floats of ITS tensors) instead of evaluating two double-precision pow()
+ * in the prologue of each of its 16 384 workgroups — a tenth of the update's time.  All counts of one call share the betas. */
+int riggs_adam_steps_advance_coef(int32_t n_steps, float* const* step_dev, const riggs_gate* gate, uint32_t* skipped, double beta1,
+                                  double beta2, float* coef, riggs_stream stream);
+int riggs_adam_step_gated_coef(int32_t n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
+                               float* const* exp_avg_sq, const int64_t* numel, const double* lr, float* const* step_dev,
+                               const float* const* lr_dev, double beta1, double beta2, double eps, const riggs_gate* gate,
+                               const float* coef, riggs_stream stream);
 int riggs_densify_stats(int32_t num_points, const float* viewspace_grad, const uint8_t* update_filter,
                         const int32_t* radii, float* xyz_gradient_accum, float* denom, float* max_radii2D,
                         riggs_stream stream);

@@ -170,6 +170,8 @@ _SIGS = {
     "riggs_adam_step": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, _P]),
     "riggs_adam_step_guarded": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, _P, _P]),
     "riggs_adam_step_capturable": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, _P]),
+    "riggs_adam_steps_advance_coef": (C.c_int, [C.c_int32, _P, _P, _P, C.c_double, C.c_double, _P, _P]),
+    "riggs_adam_step_gated_coef": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, _P, _P, _P]),
     "riggs_adam_step_gated": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double,
                                         C.POINTER(GateStruct), _P, C.c_int32, _P]),
     "riggs_gate_flag": (C.c_int, [C.POINTER(GateStruct), _P, _P]),

@@ -32,6 +32,7 @@ struct AdamArgs {
   double beta1_d, beta2_d;
   GateArg gate;                            // the frame's "valid" words (include/riggs_hip.h: riggs_gate); n == 0: never gated
   uint32_t* nonfinite;                     // riggs_adam_step_guarded: elements whose gradient is NaN / Inf are left alone and counted here
+  const float* coef[ADAM_MAX_GROUPS];      // capturable mode: (1 - beta1^t, sqrt(1 - beta2^t)) from adam_advance_kernel, or NULL (computed here)
 };
 
 // The step counts of a gated update: advanced by ONE small launch in front of it (every workgroup of the update reads them, so
@@ -41,6 +42,11 @@ struct AdvanceArgs {
   int n;
   float* step[ADAM_ADVANCE_MAX];
   GateArg gate;
+  // the bias corrections of the new counts, evaluated HERE once (double precision, as torch does with Python floats) instead of
+  // in the prologue of every one of the update's 16 384 workgroups — two double-precision pow() per workgroup were a tenth of a
+  // bandwidth-bound kernel: coef[2 k] = 1 - beta1^t, coef[2 k + 1] = sqrt(1 - beta2^t)   (NULL: not wanted)
+  float* coef;
+  double beta1, beta2;
 };
 __global__ __launch_bounds__(ADAM_ADVANCE_MAX) void adam_advance_kernel(AdvanceArgs a, uint32_t* skipped) {
   const bool closed = gate_is_set(a.gate);
@@ -48,7 +54,14 @@ __global__ __launch_bounds__(ADAM_ADVANCE_MAX) void adam_advance_kernel(AdvanceA
     if (threadIdx.x == 0 && skipped) atomicAdd(skipped, 1u);
     return;
   }
-  if ((int)threadIdx.x < a.n) a.step[threadIdx.x][0] += 1.0f;
+  if ((int)threadIdx.x < a.n) {
+    const float t = a.step[threadIdx.x][0] + 1.0f;
+    a.step[threadIdx.x][0] = t;
+    if (a.coef) {
+      a.coef[2 * threadIdx.x] = (float)(1.0 - pow(a.beta1, (double)t));
+      a.coef[2 * threadIdx.x + 1] = (float)sqrt(1.0 - pow(a.beta2, (double)t));
+    }
+  }
 }
 
 __device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, float w1, float beta2, float w2, float eps,
@@ -79,10 +92,15 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a) {
     const int k = threadIdx.x;
     float ns = a.neg_step_size[k], bs = a.bc2_sqrt[k];
     if (k < a.n_groups && a.step_dev[k]) {  // same double-precision bias corrections as the host path, from device state
-      const double t = (double)a.step_dev[k][0];
       const double lr = a.lr_dev[k] ? (double)a.lr_dev[k][0] : a.lr_host[k];
-      ns = (float)(-(lr / (1.0 - pow(a.beta1_d, t))));
-      bs = (float)sqrt(1.0 - pow(a.beta2_d, t));
+      if (a.coef[k]) {  // (evaluated by adam_advance_kernel)
+        ns = (float)(-(lr / (double)a.coef[k][0]));
+        bs = a.coef[k][1];
+      } else {
+        const double t = (double)a.step_dev[k][0];
+        ns = (float)(-(lr / (1.0 - pow(a.beta1_d, t))));
+        bs = (float)sqrt(1.0 - pow(a.beta2_d, t));
+      }
     }
     s_ns[k] = ns; s_bs[k] = bs;
   }
@@ -155,7 +173,8 @@ extern "C" {
 static int adam_launch(int32_t n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
                        float* const* exp_avg_sq, const int64_t* numel, const double* lr, const int64_t* step,
                        const float* const* step_dev, const float* const* lr_dev, double beta1, double beta2, double eps,
-                       riggs_stream stream, const riggs_gate* gate = nullptr, uint32_t* nonfinite = nullptr) {
+                       riggs_stream stream, const riggs_gate* gate = nullptr, uint32_t* nonfinite = nullptr,
+                       const float* coef = nullptr) {
   RIGGS_REQUIRE(n_groups >= 0 && n_groups <= ADAM_MAX_GROUPS, "at most 32 parameter tensors per launch");
   AdamArgs a;
   memset(&a, 0, sizeof(a));
@@ -176,6 +195,7 @@ static int adam_launch(int32_t n_groups, float* const* params, const float* cons
     if (step_dev) {
       RIGGS_REQUIRE(step_dev[k] != nullptr, "capturable mode needs a device step tensor per group");
       a.step_dev[k] = step_dev[k];
+      a.coef[k] = coef ? coef + 2 * k : nullptr;
       a.lr_dev[k] = lr_dev ? lr_dev[k] : nullptr;
       a.lr_host[k] = lr[k];
     } else {
@@ -223,12 +243,13 @@ int riggs_adam_step_capturable(int32_t n_groups, float* const* params, const flo
   return adam_launch(n_groups, params, grads, exp_avg, exp_avg_sq, numel, lr, nullptr, step_dev, lr_dev, beta1, beta2, eps, stream);
 }
 
-int riggs_adam_steps_advance_gated(int32_t n_steps, float* const* step_dev, const riggs_gate* gate, uint32_t* skipped,
-                                   riggs_stream stream) {
+static int adam_advance(int32_t n_steps, float* const* step_dev, const riggs_gate* gate, uint32_t* skipped, double beta1, double beta2,
+                        float* coef, riggs_stream stream) {
   RIGGS_REQUIRE(n_steps >= 0 && (n_steps == 0 || step_dev != nullptr), "riggs_adam_steps_advance_gated: bad arguments");
   for (int at = 0; at < n_steps; at += ADAM_ADVANCE_MAX) {
     AdvanceArgs adv;
     memset(&adv, 0, sizeof(adv));
+    adv.coef = coef ? coef + 2 * at : nullptr; adv.beta1 = beta1; adv.beta2 = beta2;
     RIGGS_REQUIRE(gate_arg(adv.gate, gate) == 0, "riggs_gate: 0..4 non-NULL words");
     adv.n = n_steps - at < ADAM_ADVANCE_MAX ? n_steps - at : ADAM_ADVANCE_MAX;
     for (int k = 0; k < adv.n; k++) {
@@ -239,6 +260,24 @@ int riggs_adam_steps_advance_gated(int32_t n_steps, float* const* step_dev, cons
     RIGGS_HIP_CHECK(hipGetLastError());
   }
   return 0;
+}
+int riggs_adam_steps_advance_gated(int32_t n_steps, float* const* step_dev, const riggs_gate* gate, uint32_t* skipped,
+                                   riggs_stream stream) {
+  return adam_advance(n_steps, step_dev, gate, skipped, 0.0, 0.0, nullptr, stream);
+}
+int riggs_adam_steps_advance_coef(int32_t n_steps, float* const* step_dev, const riggs_gate* gate, uint32_t* skipped, double beta1,
+                                  double beta2, float* coef, riggs_stream stream) {
+  RIGGS_REQUIRE(coef != nullptr, "riggs_adam_steps_advance_coef: coef is NULL");
+  return adam_advance(n_steps, step_dev, gate, skipped, beta1, beta2, coef, stream);
+}
+int riggs_adam_step_gated_coef(int32_t n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
+                               float* const* exp_avg_sq, const int64_t* numel, const double* lr, float* const* step_dev,
+                               const float* const* lr_dev, double beta1, double beta2, double eps, const riggs_gate* gate,
+                               const float* coef, riggs_stream stream) {
+  RIGGS_REQUIRE(step_dev != nullptr && coef != nullptr, "riggs_adam_step_gated_coef: step_dev / coef is NULL");
+  RIGGS_REQUIRE(n_groups >= 0 && n_groups <= ADAM_MAX_GROUPS, "at most 32 parameter tensors per launch");
+  return adam_launch(n_groups, params, grads, exp_avg, exp_avg_sq, numel, lr, nullptr, step_dev, lr_dev, beta1, beta2, eps, stream, gate,
+                     nullptr, coef);
 }
 
 int riggs_adam_step_gated(int32_t n_groups, float* const* params, const float* const* grads, float* const* exp_avg,

@@ -221,6 +221,7 @@ def _launch(plan, cap, gate=None, guard=None):
     st_ptr = L.stream_ptr()
     gs = gate.struct() if gate is not None else None
     chunks = plan.chunks
+    coef = None
     if cap:
         steps = []
         for c in chunks:
@@ -233,8 +234,20 @@ def _launch(plan, cap, gate=None, guard=None):
         if steps and gate is None:
             torch._foreach_add_(steps, 1.0)  # one multi-tensor launch; the kernels below read the new counts
         elif steps:  # ... or one launch of the library's that advances them behind the gate (and counts a skipped step)
-            L.check(lib.riggs_adam_steps_advance_gated(len(steps), (C.c_void_p * len(steps))(*[t.data_ptr() for t in steps]),
-                                                       C.byref(gs), gate.skipped.data_ptr(), st_ptr), "riggs_adam_steps_advance_gated")
+            sp = (C.c_void_p * len(steps))(*[t.data_ptr() for t in steps])
+            if len({(c.b1, c.b2) for c in chunks}) == 1:
+                # ... and evaluates the bias corrections of the new counts once, for the update's launches to read (they are
+                # two double-precision pow() in the prologue of each of the update's 16 384 workgroups otherwise)
+                coef = getattr(plan, "coef", None)
+                if coef is None or coef.numel() != 2 * len(steps) or coef.device != steps[0].device:
+                    coef = plan.coef = torch.empty(2 * len(steps), device=steps[0].device)
+                L.check(lib.riggs_adam_steps_advance_coef(len(steps), sp, C.byref(gs), gate.skipped.data_ptr(), chunks[0].b1, chunks[0].b2,
+                                                          coef.data_ptr(), st_ptr), "riggs_adam_steps_advance_coef")
+            else:
+                coef = None
+                L.check(lib.riggs_adam_steps_advance_gated(len(steps), sp, C.byref(gs), gate.skipped.data_ptr(), st_ptr),
+                        "riggs_adam_steps_advance_gated")
+    at = 0
     for c in chunks:
         n = c.n
         for j in range(n):
@@ -248,7 +261,11 @@ def _launch(plan, cap, gate=None, guard=None):
                 c.lr[j] = float(lr)
                 if cap:
                     c.lr_dev[j] = None
-        if cap and gate is not None:
+        if cap and gate is not None and coef is not None:
+            L.check(lib.riggs_adam_step_gated_coef(n, c.p_arr, c.g_arr, c.m_arr, c.v_arr, c.numel, c.lr, c.step_arr, c.lr_dev, c.b1, c.b2,
+                                                   c.eps, C.byref(gs), coef.data_ptr() + 8 * at, st_ptr), "riggs_adam_step_gated_coef")
+            at += n
+        elif cap and gate is not None:
             L.check(lib.riggs_adam_step_gated(n, c.p_arr, c.g_arr, c.m_arr, c.v_arr, c.numel, c.lr, c.step_arr, c.lr_dev, c.b1, c.b2,
                                               c.eps, C.byref(gs), None, 0, st_ptr), "riggs_adam_step_gated")
         elif cap:
