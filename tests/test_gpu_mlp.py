@@ -229,3 +229,22 @@ def test_fused_heads_inside_a_captured_training_iteration():
     assert float((w1 - w0).abs().max()) > 1e-4                       # the captured optimizer moved the masters
     pk = sw._fh_w._pk                                                 # the bf16 copy the LAST replay used = masters before its own step
     assert float((pk.rows(2)[:, :256].float() - w1).abs().max()) < 2e-3   # within one Adam step (5e-4) + bf16 rounding of the masters
+
+
+def test_grad_scale_kernels_match_the_formula():
+    """riggs_mlp_grad_scale: 2^floor(log2(1024 / max|g|)) from two launches — against the same formula in torch, for ragged sizes
+    (the vector loop's tail), a single element, all zeros (clamped at 1e-30), values around the 16-bit subnormal range, and twice in
+    a row (the scratch word is left zero)."""
+    torch.manual_seed(0)
+    for n, mag in ((1, 1.0), (3, 1e-8), (4, 3.0), (1025, 1e-6), (300_000 * 23, 3e-8), (7, 0.0)):
+        g = torch.randn(n, device="cuda") * mag
+        for _ in range(2):
+            sc = M.grad_scale(g)
+            amax = g.abs().amax().clamp_min(1e-30)
+            want = torch.exp2(torch.floor(torch.log2(1024.0 / amax)))
+            assert sc.shape == (1,) and float(torch.log2(sc).frac()) == 0.0
+            ratio = float(sc) / float(want)
+            assert ratio in (0.5, 1.0, 2.0), (n, mag, float(sc), float(want))   # (log2 of an exact power of two may round either way)
+            if mag > 0:
+                assert 256.0 <= float(amax) * float(sc) <= 2048.0
+    assert int(M._ZERO_WORD[torch.device("cuda", torch.cuda.current_device())]) == 0
