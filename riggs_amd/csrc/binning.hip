@@ -129,10 +129,21 @@ __device__ void bin_offsets_body(int T, int64_t cap, const uint32_t* __restrict_
   __shared__ uint32_t s_hist[33], s_cur[33], s_nempty;  // (class 32: the wide tiles)
   const int nthr = (int)blockDim.x;  // <= 1024
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) { s_carry = 0u; s_nempty = 0u; s_wcarry = 0u; }
+  __shared__ int s_cam_far;
+  if (tid == 0) { s_carry = 0u; s_nempty = 0u; s_wcarry = 0u; s_cam_far = 0; }
   if (tid < 33) s_hist[tid] = 0u;
-  const bool have_hist = o.wide_tiles > 0u && walk_hist[T] == o.hist_stamp;
+  // ... nor is there a history when the VIEW is another one: a trainer draws a new camera every iteration, and the walk depths of
+  // a frame seen from elsewhere pick the wrong tiles for the wide form (cycling through eight cameras on a circle: 0.395 ms with
+  // the previous camera's history, 0.388 without any).  The previous frame's view matrix is kept behind the stamp; a history
+  // counts when every entry moved by less than 0.2 (an orbit of a few degrees per frame, a static camera: yes; 45 degrees: no).
+  float cam_cur = 0.f;
   __syncthreads();
+  if (tid < 16 && o.viewmatrix) {
+    cam_cur = o.viewmatrix[tid];
+    if (!(fabsf(cam_cur - __uint_as_float(walk_hist[T + 2 + tid])) <= 0.2f)) atomicOr(&s_cam_far, 1);
+  }
+  __syncthreads();
+  const bool have_hist = o.wide_tiles > 0u && walk_hist[T] == o.hist_stamp && !s_cam_far;
   uint32_t my_len[8];  // list lengths of this thread's tiles (the first 8 passes; beyond that they are re-read)
 #pragma unroll
   for (int k = 0; k < 8; k++) my_len[k] = 0u;
@@ -180,6 +191,7 @@ __device__ void bin_offsets_body(int T, int64_t cap, const uint32_t* __restrict_
     __syncthreads();
   }
   if (tid == 0) walk_hist[T] = o.hist_stamp;
+  if (tid < 16 && o.viewmatrix) walk_hist[T + 2 + tid] = __float_as_uint(cam_cur);
   if (total_src) {
     // (the grouped binning counts only the instances that fit the arena per tile: the true total comes from its group counts)
     __shared__ uint32_t s_tot;

@@ -101,7 +101,7 @@ BinLayout bin_layout(int64_t cap, int N, int H, int W) {
   L.fwd_items = o; o += align_up((T + 1) * 4);  // forward work list: the non-empty tiles, longest lists first
   // how deep the forward walked every tile's list: read by the NEXT frame's work-list builder (the binning arena is the one that
   // persists from frame to frame: riggs_amd.rasterizer.RasterArena, captured frames)
-  L.walk_hist = o; o += align_up((T + 2) * 4);
+  L.walk_hist = o; o += align_up((T + 2 + 16) * 4);  // (+ the stamp, a spare word and the previous frame's view matrix)
   L.total = o;
   return L;
 }
@@ -287,7 +287,7 @@ int riggs_raster_binning_reset_history(void* binning_, int64_t cap, int32_t N, i
   RIGGS_REQUIRE(binning_ != nullptr && H > 0 && W > 0, "bad arguments");
   const size_t T = (size_t)((W + RIGGS_TILE - 1) / RIGGS_TILE) * ((H + RIGGS_TILE - 1) / RIGGS_TILE);
   BinLayout B = bin_layout(cap, N, H, W);
-  RIGGS_HIP_CHECK(hipMemsetAsync((char*)binning_ + B.walk_hist, 0, (T + 2) * 4, (hipStream_t)stream_));
+  RIGGS_HIP_CHECK(hipMemsetAsync((char*)binning_ + B.walk_hist, 0, (T + 2 + 16) * 4, (hipStream_t)stream_));
   return 0;
 }
 
@@ -328,6 +328,7 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
     bo.fwd_ctr = (uint32_t*)(img + I.fwd_ctr); bo.wide_tiles = cfg->deterministic ? 0u : forward_wide_tiles(); bo.wide_min = forward_wide_min();
     bo.walk_hist = (uint32_t*)(bin + B.walk_hist);
     bo.hist_stamp = 0x5EED0000u ^ ((uint32_t)T * 2654435761u) ^ ((uint32_t)N * 0x9E3779B1u);
+    bo.viewmatrix = cfg->viewmatrix;
     int rcb = launch_binning(N, T, gx, cap, (const uint32_t*)(geom + G.order), (const uint32_t*)(geom + G.tiles),
                              (const ushort4*)(geom + G.rect), bin + B.table, bin + B.ckpt /* free until the compositing */,
                              (uint32_t*)(bin + B.point_list),
