@@ -135,12 +135,13 @@ __device__ void bin_offsets_body(int T, int64_t cap, const uint32_t* __restrict_
   // ... nor is there a history when the VIEW is another one: a trainer draws a new camera every iteration, and the walk depths of
   // a frame seen from elsewhere pick the wrong tiles for the wide form (cycling through eight cameras on a circle: 0.395 ms with
   // the previous camera's history, 0.388 without any).  The previous frame's view matrix is kept behind the stamp; a history
-  // counts when every entry moved by less than 0.2 (an orbit of a few degrees per frame, a static camera: yes; 45 degrees: no).
+  // counts when every entry moved by less than o.view_tol (riggs_set_option("fwd_hist_view_tol"), default 0.2: an orbit of a few
+  // degrees per frame, a static camera: yes; 45 degrees: no).
   float cam_cur = 0.f;
   __syncthreads();
   if (tid < 16 && o.viewmatrix) {
     cam_cur = o.viewmatrix[tid];
-    if (!(fabsf(cam_cur - __uint_as_float(walk_hist[T + 2 + tid])) <= 0.2f)) atomicOr(&s_cam_far, 1);
+    if (!(fabsf(cam_cur - __uint_as_float(walk_hist[T + 2 + tid])) <= o.view_tol)) atomicOr(&s_cam_far, 1);
   }
   __syncthreads();
   const bool have_hist = o.wide_tiles > 0u && walk_hist[T] == o.hist_stamp && !s_cam_far;

@@ -18,9 +18,9 @@ void set_error(const char* fmt, ...) {
 }
 
 // ---- library options -------------------------------------------------------------------
-static const char* kOptNames[OPT_COUNT] = {"fwd_wide_tiles", "fwd_wide_min", "bin_grouped", "cnode_bwd_atomics", "color_side_jobs", "preprocess_bwd_lean", "pose_mlp_layered"};
-static const int kOptDefaults[OPT_COUNT] = {256, 4096, -1, 0, 1, -1, 0};
-static int g_opt[OPT_COUNT] = {256, 4096, -1, 0, 1, -1, 0};
+static const char* kOptNames[OPT_COUNT] = {"fwd_wide_tiles", "fwd_wide_min", "bin_grouped", "cnode_bwd_atomics", "color_side_jobs", "preprocess_bwd_lean", "pose_mlp_layered", "fwd_hist_view_tol"};
+static const int kOptDefaults[OPT_COUNT] = {256, 4096, -1, 0, 1, -1, 0, 20};
+static int g_opt[OPT_COUNT] = {256, 4096, -1, 0, 1, -1, 0, 20};
 int option(int id) { return g_opt[id]; }
 
 // ---- event-based kernel timing -------------------------------------------------------
@@ -163,6 +163,7 @@ int riggs_set_option(const char* name, int32_t value) {
   int v = value;
   if (id == OPT_FWD_WIDE_TILES) { if (v < 0) v = kOptDefaults[id]; if (v > 65535) v = 65535; }
   if (id == OPT_FWD_WIDE_MIN) { if (v < 0) v = kOptDefaults[id]; if (v < 256) v = 256; }
+  if (id == OPT_FWD_HIST_VIEW_TOL) { if (v < 0) v = kOptDefaults[id]; }
   if (id == OPT_BIN_GROUPED) { if (v < -1 || v > 1) { set_error("riggs_set_option: bin_grouped takes -1 (by size), 0 or 1"); return 2; } }
   if (id == OPT_PREPROCESS_BWD_LEAN) { if (v < -1 || v > 1) { set_error("riggs_set_option: preprocess_bwd_lean takes -1 (with cfg.sparse_zero), 0 or 1"); return 2; } }
   if (id == OPT_CNODE_BWD_ATOMICS || id == OPT_COLOR_SIDE_JOBS || id == OPT_POSE_MLP_LAYERED) v = v ? 1 : 0;
@@ -328,7 +329,8 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
     bo.fwd_ctr = (uint32_t*)(img + I.fwd_ctr); bo.wide_tiles = cfg->deterministic ? 0u : forward_wide_tiles(); bo.wide_min = forward_wide_min();
     bo.walk_hist = (uint32_t*)(bin + B.walk_hist);
     bo.hist_stamp = 0x5EED0000u ^ ((uint32_t)T * 2654435761u) ^ ((uint32_t)N * 0x9E3779B1u);
-    bo.viewmatrix = cfg->viewmatrix;
+    bo.viewmatrix = option(OPT_FWD_HIST_VIEW_TOL) > 0 ? cfg->viewmatrix : nullptr;
+    bo.view_tol = 0.01f * (float)option(OPT_FWD_HIST_VIEW_TOL);
     int rcb = launch_binning(N, T, gx, cap, (const uint32_t*)(geom + G.order), (const uint32_t*)(geom + G.tiles),
                              (const ushort4*)(geom + G.rect), bin + B.table, bin + B.ckpt /* free until the compositing */,
                              (uint32_t*)(bin + B.point_list),

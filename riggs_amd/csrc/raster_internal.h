@@ -127,6 +127,7 @@ struct BinOut {  // what the extra workgroup of bin_scatter_kernel writes once p
   uint32_t* walk_hist;   // [T + 18] per tile: how deep the forward's walk went in the previous frame (max n_contrib); read, then
                          // bit 31 = composited wide in this frame; [T] = a stamp that says the words are a history
   uint32_t hist_stamp;   // the value of walk_hist[T] that marks a history of THIS scene size and tile grid
+  float view_tol;           // ... a history counts when no entry of the view matrix moved by more than this since its frame
   const float* viewmatrix;  // this frame's view matrix (16 device floats) or NULL; the previous frame's is kept in walk_hist[T + 2 ..]
   uint32_t wide_tiles;   // at most this many tiles are composited wide by the forward (0: none) ...
   uint32_t wide_min;     // ... the ones whose walk was, and whose list is, this many instances deep (forward_wide_tiles / forward_wide_min)
