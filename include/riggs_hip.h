@@ -29,8 +29,9 @@ const char* riggs_last_error(void);
  *   "fwd_wide_tiles"    256   at most this many tiles per frame are composited by the forward's 32-lanes-per-pixel blocks (0 = none)
  *   "fwd_wide_min"      4096  ... the tiles whose walk went this many instances deep in the previous frame of the same arena
  *                             and whose list is that long now (minimum 256; a negative value restores the default)
- *   "fwd_hist_view_tol" 20    ... and only when the view is about the same: the history is taken when no entry of cfg.viewmatrix moved
- *                             by more than value / 100 since the frame it came from (0 = whatever the view was)
+ *   "fwd_hist_view_tol" 20    ... in the last frame of the SAME VIEW: the arena keeps 128 walk histories, each with the view matrix of its
+ *                             frames; a frame uses (and updates) the one no entry of whose matrix is further than value / 100 from
+ *                             cfg.viewmatrix, or starts a new one (round robin).  0 = one history whatever the view
  *   "bin_grouped"       -1    which tile sort riggs_raster_render runs where both fit: -1 = chosen by the number of Gaussians
  *                             and of tiles, 0 = the direct counting sort, 1 = the two-level sort (identical lists, bit for bit).
  *                             riggs_raster_binning_bytes reserves the larger of the two layouts, so flipping this never

@@ -123,28 +123,42 @@ __device__ void bin_offsets_body(int T, int64_t cap, const uint32_t* __restrict_
   uint32_t* __restrict__ fwd_items = o.fwd_items;
   uint32_t* __restrict__ fwd_empty = o.fwd_empty;
   uint32_t* __restrict__ fwd_ctr = o.fwd_ctr;
-  uint32_t* __restrict__ walk_hist = o.walk_hist;
   __shared__ uint32_t s_wave[16], s_wwave[16];
   __shared__ uint32_t s_carry, s_wcarry;
   __shared__ uint32_t s_hist[33], s_cur[33], s_nempty;  // (class 32: the wide tiles)
   const int nthr = (int)blockDim.x;  // <= 1024
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  __shared__ int s_cam_far;
-  if (tid == 0) { s_carry = 0u; s_nempty = 0u; s_wcarry = 0u; s_cam_far = 0; }
+  __shared__ int s_slot;
+  if (tid == 0) { s_carry = 0u; s_nempty = 0u; s_wcarry = 0u; s_slot = RIGGS_HIST_SLOTS; }
   if (tid < 33) s_hist[tid] = 0u;
   // ... nor is there a history when the VIEW is another one: a trainer draws a new camera every iteration, and the walk depths of
-  // a frame seen from elsewhere pick the wrong tiles for the wide form (cycling through eight cameras on a circle: 0.395 ms with
-  // the previous camera's history, 0.388 without any).  The previous frame's view matrix is kept behind the stamp; a history
-  // counts when every entry moved by less than o.view_tol (riggs_set_option("fwd_hist_view_tol"), default 0.2: an orbit of a few
-  // degrees per frame, a static camera: yes; 45 degrees: no).
-  float cam_cur = 0.f;
+  // a frame seen from elsewhere pick the wrong tiles for the wide form (eight cameras on a circle: 0.395 ms with the previous
+  // camera's history, 0.388 without any).  Histories are kept PER VIEW (raster_internal.h): the slot whose view matrix is this
+  // frame's — no entry further off than o.view_tol (riggs_set_option("fwd_hist_view_tol"), default 0.2: a static camera, an orbit
+  // of a few degrees per frame, the same training view coming back) — or, without one, the next slot round robin, whose history
+  // starts with this frame.
+  const uint32_t slot_words = riggs_hist_slot_words((uint32_t)T);
+  uint32_t* const hist_hdr = o.walk_hist;
   __syncthreads();
-  if (tid < 16 && o.viewmatrix) {
-    cam_cur = o.viewmatrix[tid];
-    if (!(fabsf(cam_cur - __uint_as_float(walk_hist[T + 2 + tid])) <= o.view_tol)) atomicOr(&s_cam_far, 1);
+  if (o.viewmatrix) {
+    for (int sl = tid; sl < RIGGS_HIST_SLOTS; sl += nthr) {
+      const uint32_t* hs = hist_hdr + RIGGS_HIST_HDR + (size_t)sl * slot_words;
+      bool ok = hs[T] == o.hist_stamp;
+      for (int e = 0; e < 16 && ok; e++) ok = fabsf(o.viewmatrix[e] - __uint_as_float(hs[T + 2 + e])) <= o.view_tol;  // (NaN: no)
+      if (ok) atomicMin(&s_slot, sl);
+    }
+  } else if (tid == 0 && hist_hdr[RIGGS_HIST_HDR + T] == o.hist_stamp) s_slot = 0;
+  __syncthreads();
+  const bool slot_found = s_slot < RIGGS_HIST_SLOTS;
+  const uint32_t cursor = hist_hdr[0];
+  const int slot = slot_found ? s_slot : (o.viewmatrix ? (int)(cursor % RIGGS_HIST_SLOTS) : 0);
+  uint32_t* __restrict__ walk_hist = hist_hdr + RIGGS_HIST_HDR + (size_t)slot * slot_words;
+  const bool have_hist = o.wide_tiles > 0u && slot_found;
+  __syncthreads();  // (every thread has read the cursor)
+  if (tid == 0) {
+    hist_hdr[1] = (uint32_t)slot;  // where the forward writes this frame's depths
+    if (!slot_found && o.viewmatrix) hist_hdr[0] = cursor + 1u;
   }
-  __syncthreads();
-  const bool have_hist = o.wide_tiles > 0u && walk_hist[T] == o.hist_stamp && !s_cam_far;
   uint32_t my_len[8];  // list lengths of this thread's tiles (the first 8 passes; beyond that they are re-read)
 #pragma unroll
   for (int k = 0; k < 8; k++) my_len[k] = 0u;
@@ -192,7 +206,7 @@ __device__ void bin_offsets_body(int T, int64_t cap, const uint32_t* __restrict_
     __syncthreads();
   }
   if (tid == 0) walk_hist[T] = o.hist_stamp;
-  if (tid < 16 && o.viewmatrix) walk_hist[T + 2 + tid] = __float_as_uint(cam_cur);
+  if (tid < 16 && o.viewmatrix && !slot_found) walk_hist[T + 2 + tid] = __float_as_uint(o.viewmatrix[tid]);  // (a matched slot keeps ITS view: no drift)
   if (total_src) {
     // (the grouped binning counts only the instances that fit the arena per tile: the true total comes from its group counts)
     __shared__ uint32_t s_tot;

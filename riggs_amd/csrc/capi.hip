@@ -101,7 +101,7 @@ BinLayout bin_layout(int64_t cap, int N, int H, int W) {
   L.fwd_items = o; o += align_up((T + 1) * 4);  // forward work list: the non-empty tiles, longest lists first
   // how deep the forward walked every tile's list: read by the NEXT frame's work-list builder (the binning arena is the one that
   // persists from frame to frame: riggs_amd.rasterizer.RasterArena, captured frames)
-  L.walk_hist = o; o += align_up((T + 2 + 16) * 4);  // (+ the stamp, a spare word and the previous frame's view matrix)
+  L.walk_hist = o; o += align_up(riggs_hist_words((uint32_t)T) * 4);  // (per view: raster_internal.h)
   L.total = o;
   return L;
 }
@@ -288,7 +288,7 @@ int riggs_raster_binning_reset_history(void* binning_, int64_t cap, int32_t N, i
   RIGGS_REQUIRE(binning_ != nullptr && H > 0 && W > 0, "bad arguments");
   const size_t T = (size_t)((W + RIGGS_TILE - 1) / RIGGS_TILE) * ((H + RIGGS_TILE - 1) / RIGGS_TILE);
   BinLayout B = bin_layout(cap, N, H, W);
-  RIGGS_HIP_CHECK(hipMemsetAsync((char*)binning_ + B.walk_hist, 0, (T + 2 + 16) * 4, (hipStream_t)stream_));
+  RIGGS_HIP_CHECK(hipMemsetAsync((char*)binning_ + B.walk_hist, 0, riggs_hist_words((uint32_t)T) * 4, (hipStream_t)stream_));
   return 0;
 }
 
@@ -358,6 +358,7 @@ int riggs_raster_render(const riggs_raster_cfg* cfg, const void* geom_, void* bi
   r.items = nullptr; r.empties = nullptr; r.item_ctr = nullptr;
   if (binned) { r.items = (const uint32_t*)(bin + B.fwd_items); r.empties = (const uint32_t*)(img + I.fwd_empty); r.item_ctr = (uint32_t*)(img + I.fwd_ctr); }
   r.walk_hist = (uint32_t*)(bin + B.walk_hist);
+  r.hist_slot_words = riggs_hist_slot_words((uint32_t)T);
   r.trace_items = g_raster_trace_items ? g_raster_trace_items : (uint64_t)T * 8;
   { ProfScope ps(PROF_RENDER_FWD, s); launch_render_fwd(r, s); }
   if (debug_sync(cfg->debug, s, "render_fwd")) return 1;

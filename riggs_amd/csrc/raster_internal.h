@@ -80,7 +80,8 @@ struct RenderArgs {
   const uint32_t* items;
   const uint32_t* empties;
   uint32_t* item_ctr;
-  uint32_t* walk_hist;        // [T] per tile: max n_contrib, for the NEXT frame's work list (BinOut::walk_hist)
+  uint32_t* walk_hist;        // the walk histories (BinOut::walk_hist): the forward writes max n_contrib per tile into the slot of THIS view
+  uint32_t hist_slot_words;   // (riggs_hist_slot_words(T))
   uint64_t trace_items;       // capacity of the trace buffer in work items (tools; 0: 8 per tile)
 };
 int launch_render_fwd(const RenderArgs& a, hipStream_t s);
@@ -121,14 +122,26 @@ int launch_depth_sort(int N, const uint32_t* keys_in, uint32_t* keys_out, uint32
                       const uint32_t* block_info, uint32_t* counters, hipStream_t s);
 size_t bin_table_bytes(int N, int T, int grid_x);
 size_t bin_scratch_bytes(int64_t cap, int T, int grid_x);  // scratch of the grouped binning (<= the checkpoint area it is given)
+// The forward's walk histories: how deep every tile's list was walked, PER VIEW.  A trainer draws another camera every iteration
+// out of a fixed set (train_rig.py:389), so "the previous frame" is a frame seen from elsewhere — but the same views come back.
+// The binning arena keeps RIGGS_HIST_SLOTS histories, each with the view matrix it belongs to; the tile sort's extra workgroup
+// takes the slot whose view matches this frame's (riggs_set_option("fwd_hist_view_tol")) or recycles one round robin (no history
+// for this frame then), and tells the forward which one to write (header word 1).
+//   words: [0] round-robin cursor, [1] this frame's slot, [2 .. 15] spare; then per slot: [T] depths (bit 31: composited wide in
+//   this frame), [T] the stamp, [T + 1] spare, [T + 2 .. T + 17] the view matrix — riggs_hist_slot_words(T) words each
+#define RIGGS_HIST_SLOTS 128
+#define RIGGS_HIST_HDR 16
+__host__ __device__ static inline uint32_t riggs_hist_slot_words(uint32_t T) { return (T + 18u + 15u) & ~15u; }
+static inline size_t riggs_hist_words(uint32_t T) { return RIGGS_HIST_HDR + (size_t)RIGGS_HIST_SLOTS * riggs_hist_slot_words(T); }
+
 struct BinOut {  // what the extra workgroup of bin_scatter_kernel writes once per frame
   uint2* ranges;
   uint32_t *slot_base, *tile_max, *counters, *fwd_items, *fwd_empty, *fwd_ctr;
-  uint32_t* walk_hist;   // [T + 18] per tile: how deep the forward's walk went in the previous frame (max n_contrib); read, then
+  uint32_t* walk_hist;   // the histories (layout above); a slot's [t]: how deep the forward's walk went in that view's last frame; read, then
                          // bit 31 = composited wide in this frame; [T] = a stamp that says the words are a history
   uint32_t hist_stamp;   // the value of walk_hist[T] that marks a history of THIS scene size and tile grid
   float view_tol;           // ... a history counts when no entry of the view matrix moved by more than this since its frame
-  const float* viewmatrix;  // this frame's view matrix (16 device floats) or NULL; the previous frame's is kept in walk_hist[T + 2 ..]
+  const float* viewmatrix;  // this frame's view matrix (16 device floats) or NULL (one history, whatever the view: slot 0)
   uint32_t wide_tiles;   // at most this many tiles are composited wide by the forward (0: none) ...
   uint32_t wide_min;     // ... the ones whose walk was, and whose list is, this many instances deep (forward_wide_tiles / forward_wide_min)
 };

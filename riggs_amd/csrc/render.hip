@@ -417,7 +417,8 @@ __device__ __forceinline__ void fw_block(const RenderArgs& a, const int tile, co
       if (ticket == (uint32_t)LPP - 1u) {  // LPP blocks of 256 / LPP pixels per tile
         limit = max(max(before, mb), __hip_atomic_load(&l.tile_max[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         limit = min((uint32_t)total, limit);
-        l.walk_hist[tile] = limit;  // (for the next frame's work list: how deep this tile's walk went)
+        // (for this view's next frame's work list: how deep this tile's walk went — into the slot the tile sort chose)
+        l.walk_hist[RIGGS_HIST_HDR + (size_t)l.walk_hist[1] * l.hist_slot_words + tile] = limit;
         n_c = (limit + 63u) >> 6;
         if (n_c) wbase = __hip_atomic_fetch_add(l.work_ctr, 4u * n_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 2;  // (quarter-chunks)
       }
