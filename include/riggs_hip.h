@@ -120,8 +120,8 @@ size_t riggs_raster_image_bytes(int32_t image_height, int32_t image_width);
 size_t riggs_raster_binning_bytes(int64_t instance_capacity, int32_t num_points, int32_t image_height,
                                   int32_t image_width);
 /* The binning arena carries ONE piece of state from frame to frame: how deep the forward walked every tile's list (which
- * tiles the next frame composites with 32 lanes per pixel), valid when a stamp word derived from the tile and Gaussian
- * counts follows it.  Call this after allocating an arena and whenever (capacity, N, H, W) change for an arena in use
+ * tiles the next frame composites with 32 lanes per pixel), kept PER VIEW (128 histories, each with the view matrix of its
+ * frames: "fwd_hist_view_tol"), valid when a stamp word derived from the tile and Gaussian counts follows it.  Call this after allocating an arena and whenever (capacity, N, H, W) change for an arena in use
  * (the words' offset depends on them): the next frame then starts without a history.  Equivalent: zero-fill the arena. */
 int riggs_raster_binning_reset_history(void* binning, int64_t instance_capacity, int32_t num_points, int32_t image_height,
                                        int32_t image_width, riggs_stream stream);
@@ -148,6 +148,8 @@ enum {
 enum {
   RIGGS_BIN_POINT_LIST = 0, /* uint32 [capacity]: Gaussian index per sorted instance */
   RIGGS_BIN_TILE_KEYS,      /* uint32 [capacity]: tile id per sorted instance (written with cfg.debug only) */
+  RIGGS_BIN_WALK_HIST,      /* uint32: the forward's walk histories, one per view — [0] round-robin cursor, [1] the slot of the last frame,
+                               [16 ..] 128 slots of ((tiles + 18) rounded up to 16) words: depths per tile, a stamp, the view matrix */
   RIGGS_BIN_NFIELDS_
 };
 int riggs_raster_geom_layout(int32_t num_points, size_t* offsets /*[RIGGS_GEOM_NFIELDS_]*/);

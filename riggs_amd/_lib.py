@@ -15,7 +15,7 @@ SO_PATH = os.path.join(_HERE, "lib", "libriggs_hip.so")
 GEOM_XYD, GEOM_CONIC_O, GEOM_RGB, GEOM_COV3D, GEOM_CLAMPED, GEOM_TILES, GEOM_RECT, GEOM_DEPTH_ORDER, \
     GEOM_NFIELDS = range(9)
 IMG_FINAL_T, IMG_N_CONTRIB, IMG_RANGES, IMG_FWD_CTR, IMG_NFIELDS = range(5)
-BIN_POINT_LIST, BIN_TILE_KEYS, BIN_NFIELDS = range(3)
+BIN_POINT_LIST, BIN_TILE_KEYS, BIN_WALK_HIST, BIN_NFIELDS = range(4)
 
 
 class RasterCfg(C.Structure):

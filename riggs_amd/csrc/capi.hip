@@ -206,7 +206,7 @@ int riggs_raster_image_layout(int32_t H, int32_t W, size_t* o) {
 }
 int riggs_raster_binning_layout(int64_t cap, int32_t N, int32_t H, int32_t W, size_t* o) {
   BinLayout L = bin_layout(cap, N, H, W);
-  o[RIGGS_BIN_POINT_LIST] = L.point_list; o[RIGGS_BIN_TILE_KEYS] = L.tile_keys;
+  o[RIGGS_BIN_POINT_LIST] = L.point_list; o[RIGGS_BIN_TILE_KEYS] = L.tile_keys; o[RIGGS_BIN_WALK_HIST] = L.walk_hist;
   return 0;
 }
 

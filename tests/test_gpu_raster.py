@@ -620,3 +620,55 @@ def test_ordered_reduction_mode_gives_bitwise_reproducible_gradients():
     go = RR.backward(so, gc.cpu().numpy(), gd.cpu().numpy()[0], None)
     _grads_close(ordered[0][0], go["means3D"], "ordered dL/dmeans3D vs oracle")
     _grads_close(ordered[0][4], go["opacities"], "ordered dL/dopacity vs oracle")
+
+
+def test_walk_histories_are_kept_per_view():
+    """The forward's walk history (which tiles the next frame composites wide, the order of its work list) belongs to a VIEW: the
+    binning arena keeps 128 of them keyed by the view matrix (include/riggs_hip.h: RIGGS_BIN_WALK_HIST).  Three cameras in turn:
+    each gets a slot of its own once, comes back to it ever after (the cursor stops), a static camera stays in its slot, and the
+    image does not depend on any of it; "fwd_hist_view_tol" = 0 is one history whatever the view."""
+    import ctypes as C
+
+    import bench
+    from riggs_amd import _lib as L
+    from riggs_amd import synth
+    from riggs_amd.rasterizer import RasterArena
+    from riggs_amd.render import render
+    old = dict(bench.WORKLOAD)
+    bench.WORKLOAD.update(N=20000, J=8, H=160, W=176)
+    try:
+        sc, cam0, gm, sw = bench.build_workload(0, "cuda:0")
+    finally:
+        bench.WORKLOAD.clear()
+        bench.WORKLOAD.update(old)
+    H, W, N = 160, 176, 20000
+    cams = [synth.look_at_camera(H, W, azimuth_deg=a, fid=0.3).to("cuda") for a in (0.0, 120.0, 240.0)]
+    near = synth.look_at_camera(H, W, azimuth_deg=2.0, fid=0.3).to("cuda")   # an orbit step: the first camera's history
+    bg = torch.zeros(3, device="cuda")
+    arena = RasterArena(min_capacity=1 << 20)
+    gm._frame_arena = arena
+
+    def frame(cam):
+        with torch.no_grad():
+            d = sw(gm.get_xyz, sw.expand_time(cam.fid), motion_mask=gm.motion_mask)
+            img = render(cam, gm, bench.Pipe, bg, d["d_xyz"], d["d_rotation"], d["d_scaling"], arena=arena)["render"].clone()
+        torch.cuda.synchronize()
+        off = (C.c_size_t * L.BIN_NFIELDS)()
+        L.lib().riggs_raster_binning_layout(arena.capacity, N, H, W, off)
+        hdr = arena.binning[off[L.BIN_WALK_HIST]:off[L.BIN_WALK_HIST] + 8].view(torch.int32)
+        return img, int(hdr[0]), int(hdr[1])
+    try:
+        seen = []
+        for k in range(9):
+            _, cursor, slot = frame(cams[k % 3])
+            seen.append(slot)
+        assert len(set(seen[:3])) == 3 and seen[3:6] == seen[:3] and seen[6:] == seen[:3] and cursor == 3, (seen, cursor)
+        img_a, cursor, slot = frame(near)
+        assert slot == seen[0] and cursor == 3                    # within the tolerance: the first view's history, no new slot
+        img_b, _, _ = frame(near)
+        assert float((img_a - img_b).abs().max()) <= 1e-6         # (the form a tile is composited in does not change the image)
+        L.set_option("fwd_hist_view_tol", 0)
+        slots = [frame(c)[2] for c in cams]
+        assert slots == [0, 0, 0]
+    finally:
+        L.set_option("fwd_hist_view_tol", -1)
