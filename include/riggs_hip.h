@@ -671,12 +671,15 @@ int riggs_raster_set_trace_items(uint64_t n_items);
  * acts_bf16 (depth, N, 256) receives the post-ReLU activations (operand of the weight gradients) and relu_masks
  * (depth, ceil(N / riggs_mlp_rows_per_workgroup()), 256) x 16 bytes their signs in the kernels' accumulator layout, for
  * riggs_mlp_backward (both NULL for inference).
+ * n_rows_dev (riggs_mlp_forward / _backward / _wgrad; may be NULL): a device int32 — only rows < min(*n_rows_dev, N) exist; N
+ * stays the row stride of acts_bf16 / dpre_bf16 and sizes the grid (the rest of the workgroups leave at once).  This is how the
+ * row-sparse backward runs inside a hipGraph on the rows riggs_mlp_live_rows compacted, their number known to the device only.
  * Opt-in on the host side (riggs_amd.mlp): the reference computes these MLPs in fp32.
  * ===================================================================== */
 int riggs_mlp_forward(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip,
                       const void* const* weights_bf16, const float* const* biases, const void* w_out_bf16,
                       const float* b_out, const void* x_emb_bf16, void* acts_bf16, void* relu_masks, float* out,
-                      int32_t fp16, riggs_stream stream);
+                      const int32_t* n_rows_dev, int32_t fp16, riggs_stream stream);
 /* Data-gradient pass of the same MLP: g_out (N, out_ch) = dL/d(output) -> dpre_bf16 (depth, N, 256) = dL/d(pre-activation)
  * of every hidden layer, the operand of the weight gradients  dW_l = dpre_l^T · input_l ,  db_l = sum_n dpre_l
  * (riggs_mlp_wgrad).  weights_t_bf16[l] (l >= 1): W_l[:, hidden part]^T (rows = the units of layer
@@ -687,7 +690,19 @@ int riggs_mlp_forward(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, i
  * loss leaves |g_out| ~ 1e-7, below half precision's normal range) and divides the parameter gradients by it. */
 int riggs_mlp_backward(int32_t N, int32_t out_ch, int32_t depth, int32_t skip, const void* const* weights_t_bf16,
                        const void* w_out_t_bf16, const float* g_out, const float* g_scale, const void* relu_masks,
-                       void* dpre_bf16, float* db_partial, int32_t fp16, riggs_stream stream);
+                       void* dpre_bf16, float* db_partial, const int32_t* n_rows_dev, int32_t fp16, riggs_stream stream);
+/* Row-sparse backward, step 1: the rows of g_out (N, out_ch) that hold a non-zero — the Gaussians the render gave a gradient;
+ * the WeightMLP has no other cotangent: its regulariser is dead code at train_rig.py:433-444, and the skinning backward writes
+ * exact zeros for the rest — in ascending order: live_idx (N) their indices, live_count (device int32) their number M,
+ * x_live_bf16 ((N rounded up to 128), in_pad) the gathered rows of x_emb_bf16 (zero-filled up to the next multiple of 128
+ * behind row M), g_live (N, out_ch) the gathered rows of g_out.  Two launches, no atomics (deterministic).  A zero row
+ * contributes zero to every data gradient, bias sum and weight product, so riggs_mlp_forward (activations of the live rows
+ * only: the first forward then stores none), riggs_mlp_backward and riggs_mlp_wgrad on (x_live, g_live, n_rows_dev =
+ * live_count) return the parameter gradients of the dense pass.  workspace: riggs_mlp_live_rows_workspace_bytes(N), 8-byte
+ * aligned. */
+size_t riggs_mlp_live_rows_workspace_bytes(int32_t N);
+int riggs_mlp_live_rows(int32_t N, int32_t out_ch, int32_t in_ch, const float* g_out, const void* x_emb_bf16, void* workspace,
+                        int32_t* live_idx, int32_t* live_count, void* x_live_bf16, float* g_live, riggs_stream stream);
 /* The g_scale of the fp16 format from the gradient itself: scale[0] = 2^floor(log2(1024 / max|g|)) (max|g| clamped at 1e-30), two
  * launches, no host synchronisation.  zero_word: a device u32 that is ZERO on entry (the caller clears it once) and zero again
  * behind the call. */
@@ -708,7 +723,7 @@ size_t riggs_mlp_wgrad_workspace_bytes(int32_t N, int32_t in_ch, int32_t depth, 
 int riggs_mlp_wgrad(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip, const void* x_emb_bf16,
                     const void* acts_bf16, const void* dpre_bf16, const float* g_out, const float* g_scale, void* workspace,
                     size_t workspace_bytes, float* const* grad_weights, float* const* grad_biases, float* grad_w_out,
-                    float* grad_b_out, int32_t fp16, riggs_stream stream);
+                    float* grad_b_out, const int32_t* n_rows_dev, int32_t fp16, riggs_stream stream);
 /* fp32 master weights ((256, K_true) row-major per layer, (out_ch, 256) for the head) -> every bf16 operand the two kernels
  * read (layouts above), in one launch. */
 int riggs_mlp_pack(int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip, const float* const* weights, const float* w_out,

@@ -64,6 +64,7 @@ struct MlpDesc {
   const float* bias[10];          // [256]
   const unsigned short* Wout;     // the head, fragment-major: 1 tile (outputs >= out_ch are zero) x 16 steps x 512
   const float* bout;              // [out_ch]
+  const int32_t* n_dev;           // NULL, or a device word: only rows < min(*n_dev, N) exist (N stays the buffers' row stride)
 };
 
 __device__ __forceinline__ int mlp_k(const MlpDesc& d, int l) { return l == 0 ? d.in_pad : (l == d.skip + 1 ? d.in_pad + MLP_W : MLP_W); }
@@ -255,6 +256,9 @@ __global__ __launch_bounds__(256, GT == 2 ? 3 : 2) void mlp_forward_kernel(MlpDe
   __shared__ unsigned short s_h[ROWS * MLP_HS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = blockIdx.x * ROWS;
+  // (a device-side row count — the compacted rows of a row-sparse backward: the grid covers the capacity, the rest leaves here)
+  const int rows = d.n_dev ? min(d.n_dev[0], d.N) : d.N;
+  if (row0 >= rows) return;
   // the embedding is read from its 16-bit copy in HBM ((rows rounded up to 128) x in_pad, zero padded): it is an operand
   // of two layers only, and keeping it out of LDS lets two 128-row workgroups share a CU
   const unsigned short* xrow = xb + (size_t)row0 * d.in_pad;
@@ -320,7 +324,7 @@ __global__ __launch_bounds__(256, GT == 2 ? 3 : 2) void mlp_forward_kernel(MlpDe
       unsigned short* dst = acts + ((size_t)l * d.N + row0) * MLP_W;
       for (int e = tid; e < ROWS * (MLP_W / 8); e += 256) {
         const int r = e / (MLP_W / 8), c8 = e - r * (MLP_W / 8);
-        if (row0 + r < d.N)
+        if (row0 + r < rows)
           *reinterpret_cast<bf16x8*>(dst + (size_t)r * MLP_W + 8 * c8) = *reinterpret_cast<const bf16x8*>(s_h + r * MLP_HS + 8 * c8);
       }
     }
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(256, GT == 2 ? 3 : 2) void mlp_forward_kernel(MlpDe
     for (int e = 0; e < 16; e++) s_out[(32 * wave + (lane & 31)) * 33 + mlp_c_row(e, lane)] = hacc[0][0][e];
   }
   __syncthreads();
-  const int n_rows = min(ROWS, d.N - row0);
+  const int n_rows = min(ROWS, rows - row0);
   for (int e = tid; e < n_rows * d.out_ch; e += 256) {
     const int r = e / d.out_ch, c = e - r * d.out_ch;
     out[(size_t)row0 * d.out_ch + e] = s_out[r * 33 + c] + d.bout[c];
@@ -354,6 +358,7 @@ struct MlpBwdDesc {
   int N, out_ch, depth, skip;
   const unsigned short* Wt[10];   // l >= 1: W_l[:, hidden part]^T (rows = units k of layer l - 1, inputs = neurons n), fragment-major: 8 x 16 x 512
   const unsigned short* Wout_t;   // the head transposed (rows = hidden units, inputs = 32 padded outputs), fragment-major: 8 x 2 x 512
+  const int32_t* n_dev;           // as MlpDesc::n_dev
 };
 
 template <int GT, bool H16>
@@ -368,11 +373,13 @@ __global__ __launch_bounds__(256, GT == 2 ? 3 : 2) void mlp_backward_kernel(MlpB
   __shared__ unsigned short s_g[ROWS * 40];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = blockIdx.x * ROWS;
+  const int rows = d.n_dev ? min(d.n_dev[0], d.N) : d.N;
+  if (row0 >= rows) return;
   const float gs = g_scale ? g_scale[0] : 1.0f;
   for (int e = tid; e < ROWS * 32; e += 256) {
     const int r = e >> 5, c = e & 31;
     float v = 0.f;
-    if (row0 + r < d.N && c < d.out_ch) v = g_out[(size_t)(row0 + r) * d.out_ch + c] * gs;
+    if (row0 + r < rows && c < d.out_ch) v = g_out[(size_t)(row0 + r) * d.out_ch + c] * gs;
     s_g[r * 40 + c] = f2h<H16>(v);
   }
   __syncthreads();
@@ -391,7 +398,7 @@ __global__ __launch_bounds__(256, GT == 2 ? 3 : 2) void mlp_backward_kernel(MlpB
     if (l == d.depth - 1) mlp_gemm_small<2, GT, H16>(acc, d.Wout_t + (size_t)(2 * wave) * (2 * MLP_FRAG), 2 * MLP_FRAG, s_g, 40, 2, lane);
     else  // (the gradient of layer l + 1 — this product's B operand — leaves for HBM under it)
       mlp_gemm_hidden<MLP_W / 16, GT, H16, true>(acc, d.Wt[l + 1] + (size_t)(2 * wave) * (16 * MLP_FRAG), 16 * MLP_FRAG, s_d, MLP_HS, lane,
-                                                 dpre + ((size_t)(l + 1) * d.N + row0) * MLP_W, min(ROWS, d.N - row0));
+                                                 dpre + ((size_t)(l + 1) * d.N + row0) * MLP_W, min(ROWS, rows - row0));
     __syncthreads();  // every wave is done reading d_pre_{l+1}
     // ---- d_pre_l = d_post_l where the forward's activation was positive (mask bits in this lane's accumulator layout)
     const uint4 mk = masks[((size_t)l * gridDim.x + blockIdx.x) * 256 + tid];
@@ -417,7 +424,7 @@ __global__ __launch_bounds__(256, GT == 2 ? 3 : 2) void mlp_backward_kernel(MlpB
       unsigned short* dl = dpre + (size_t)row0 * MLP_W;
       for (int e = tid; e < ROWS * (MLP_W / 8); e += 256) {
         const int r = e / (MLP_W / 8), c8 = e - r * (MLP_W / 8);
-        if (row0 + r < d.N)
+        if (row0 + r < rows)
           *reinterpret_cast<bf16x8*>(dl + (size_t)r * MLP_W + 8 * c8) = *reinterpret_cast<const bf16x8*>(s_d + r * MLP_HS + 8 * c8);
       }
     }
@@ -490,6 +497,83 @@ __global__ __launch_bounds__(256) void mlp_embed_kernel(int N, int n_rows, int m
       v[q] = (short)((c < pe) ? s_pe[r][c < MLP_EMB_PE ? c : 0] : (n < N ? tl[q] : (unsigned short)0));
     }
     *reinterpret_cast<bf16x8*>(out + (size_t)n * in_pad + c8) = v;
+  }
+}
+
+
+// ---- the rows that carry a gradient (row-sparse backward).  The WeightMLP's cotangent is zero in every row whose Gaussian got
+// no gradient from the render (its regulariser is dead code in the reference: train_rig.py:433-444; the skinning backward writes
+// exact zeros there), typically 70-90 % of the rows; a zero row contributes zero to every data gradient, bias sum and weight
+// product, so the backward runs on the COMPACTED live rows: their embedding rows and cotangent rows are gathered here (ascending
+// order, no atomics: the result does not depend on scheduling), the forward is repeated for them alone (the first forward then
+// stores no activations at all) and the data-gradient / weight-gradient launches read the live count from the device.
+// Launch 1: per 256-row block the live flags (as four 64-bit ballots) and their number.
+__global__ __launch_bounds__(256) void mlp_live_flags_kernel(int N, int out_ch, const float* __restrict__ g_out,
+                                                             unsigned long long* __restrict__ bits /* [blocks][4] */,
+                                                             int32_t* __restrict__ counts /* [blocks] */) {
+  __shared__ int s_live[256];
+  const int tid = threadIdx.x, row0 = blockIdx.x * 256;
+  s_live[tid] = 0;
+  __syncthreads();
+  const int n_rows = min(256, N - row0);
+  const float* g = g_out + (size_t)row0 * out_ch;
+  for (int e = tid; e < n_rows * out_ch; e += 256)        // coalesced over the block's contiguous run
+    if (g[e] != 0.0f) s_live[e / out_ch] = 1;             // (benign race: every writer stores 1; NaN != 0 counts as live)
+  __syncthreads();
+  const unsigned long long b = __ballot(s_live[tid] != 0);
+  __shared__ int s_cnt[4];
+  if ((tid & 63) == 0) {
+    bits[(size_t)blockIdx.x * 4 + (tid >> 6)] = b;
+    s_cnt[tid >> 6] = __popcll(b);
+  }
+  __syncthreads();
+  if (tid == 0) counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+// Launch 2: block b sums the counts in front of it (<= a few thousand words), ranks its live rows and copies them.
+__global__ __launch_bounds__(256) void mlp_live_gather_kernel(int N, int out_ch, int in_pad, const float* __restrict__ g_out,
+                                                              const unsigned short* __restrict__ xb,
+                                                              const unsigned long long* __restrict__ bits,
+                                                              const int32_t* __restrict__ counts, int32_t* __restrict__ idx,
+                                                              int32_t* __restrict__ count, unsigned short* __restrict__ x_live,
+                                                              float* __restrict__ g_live) {
+  __shared__ int s_red[4];
+  __shared__ int s_rows[256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row0 = blockIdx.x * 256;
+  int part = 0;
+  for (int i = tid; i < (int)blockIdx.x; i += 256) part += counts[i];
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+  if (lane == 0) s_red[wave] = part;
+  const unsigned long long b0 = bits[(size_t)blockIdx.x * 4], b1 = bits[(size_t)blockIdx.x * 4 + 1],
+                           b2 = bits[(size_t)blockIdx.x * 4 + 2], b3 = bits[(size_t)blockIdx.x * 4 + 3];
+  __syncthreads();
+  const int base = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+  const int c0 = __popcll(b0), c1 = __popcll(b1), c2 = __popcll(b2), c3 = __popcll(b3);
+  const unsigned long long mine = wave == 0 ? b0 : (wave == 1 ? b1 : (wave == 2 ? b2 : b3));
+  const int before = wave == 0 ? 0 : (wave == 1 ? c0 : (wave == 2 ? c0 + c1 : c0 + c1 + c2));
+  if ((mine >> lane) & 1ull) {
+    const int rk = before + __popcll(mine & ((1ull << lane) - 1ull));
+    s_rows[rk] = row0 + tid;
+    idx[base + rk] = row0 + tid;
+  }
+  const int n_live = c0 + c1 + c2 + c3;
+  __syncthreads();
+  const int segs = in_pad >> 3;  // 16-byte pieces per embedding row
+  for (int e = tid; e < n_live * segs; e += 256) {
+    const int r = e / segs, c = e - r * segs;
+    *reinterpret_cast<bf16x8*>(x_live + (size_t)(base + r) * in_pad + 8 * c) =
+        *reinterpret_cast<const bf16x8*>(xb + (size_t)s_rows[r] * in_pad + 8 * c);
+  }
+  for (int e = tid; e < n_live * out_ch; e += 256) {
+    const int r = e / out_ch, c = e - r * out_ch;
+    g_live[(size_t)(base + r) * out_ch + c] = g_out[(size_t)s_rows[r] * out_ch + c];
+  }
+  if (blockIdx.x == gridDim.x - 1) {  // the last block knows the total: it publishes it and zero-fills the rows up to the next
+    const int total = base + n_live;  // multiple of 128 (the forward kernel's workgroups read whole 128-row tiles of x_live)
+    if (tid == 0) count[0] = total;
+    const int pad_rows = ((total + 127) & ~127) - total;
+    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int e = tid; e < pad_rows * segs; e += 256)
+      *reinterpret_cast<bf16x8*>(x_live + (size_t)total * in_pad + 8 * (size_t)e) = z;
   }
 }
 
@@ -581,7 +665,8 @@ int riggs_mlp_layout_probe(float* out32x32, riggs_stream stream) {
 #define MLP_RT 4
 
 static int mlp_fill(MlpDesc& d, int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip, const void* const* Wp,
-                    const float* const* bias, const void* Wout, const float* bout) {
+                    const float* const* bias, const void* Wout, const float* bout, const int32_t* n_dev) {
+  d.n_dev = n_dev;
   RIGGS_REQUIRE(N >= 0 && depth >= 1 && depth <= 10, "MLP depth out of range");
   RIGGS_REQUIRE(in_ch >= 1 && in_ch <= MLP_MAX_IN, "MLP input width must be <= 128");
   RIGGS_REQUIRE(out_ch >= 1 && out_ch <= 32, "MLP output width must be <= 32");
@@ -595,9 +680,9 @@ static int mlp_fill(MlpDesc& d, int32_t N, int32_t in_ch, int32_t out_ch, int32_
 
 int riggs_mlp_forward(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip, const void* const* weights_bf16,
                       const float* const* biases, const void* w_out_bf16, const float* b_out, const void* x_emb_bf16,
-                      void* acts_bf16, void* relu_masks, float* out, int32_t fp16, riggs_stream stream) {
+                      void* acts_bf16, void* relu_masks, float* out, const int32_t* n_rows_dev, int32_t fp16, riggs_stream stream) {
   MlpDesc d;
-  int rc = mlp_fill(d, N, in_ch, out_ch, depth, skip, weights_bf16, biases, w_out_bf16, b_out);
+  int rc = mlp_fill(d, N, in_ch, out_ch, depth, skip, weights_bf16, biases, w_out_bf16, b_out, n_rows_dev);
   if (rc) return rc;
   if (N == 0) return 0;
   RIGGS_REQUIRE(x_emb_bf16 && out, "MLP input / output pointers");
@@ -620,12 +705,12 @@ int riggs_mlp_forward(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, i
 
 int riggs_mlp_backward(int32_t N, int32_t out_ch, int32_t depth, int32_t skip, const void* const* weights_t_bf16,
                        const void* w_out_t_bf16, const float* g_out, const float* g_scale, const void* relu_masks, void* dpre_bf16,
-                       float* db_partial, int32_t fp16, riggs_stream stream) {
+                       float* db_partial, const int32_t* n_rows_dev, int32_t fp16, riggs_stream stream) {
   RIGGS_REQUIRE(N >= 0 && depth >= 1 && depth <= 10, "MLP depth out of range");
   RIGGS_REQUIRE(out_ch >= 1 && out_ch <= 32, "MLP output width must be <= 32");
   if (N == 0) return 0;
   MlpBwdDesc d;
-  d.N = N; d.out_ch = out_ch; d.depth = depth; d.skip = skip;
+  d.N = N; d.out_ch = out_ch; d.depth = depth; d.skip = skip; d.n_dev = n_rows_dev;
   for (int l = 0; l < depth; l++) { d.Wt[l] = (const unsigned short*)weights_t_bf16[l]; RIGGS_REQUIRE(l == 0 || d.Wt[l], "MLP transposed weights"); }
   d.Wout_t = (const unsigned short*)w_out_t_bf16;
   RIGGS_REQUIRE(d.Wout_t && g_out && relu_masks && dpre_bf16, "MLP backward pointers");
@@ -633,6 +718,31 @@ int riggs_mlp_backward(int32_t N, int32_t out_ch, int32_t depth, int32_t skip, c
                                g_scale, (const uint4*)relu_masks, (unsigned short*)dpre_bf16, db_partial);
   else hipLaunchKernelGGL((mlp_backward_kernel<MLP_RT, false>), dim3((N + 127) / 128), dim3(256), 0, (hipStream_t)stream, d, g_out,
                           g_scale, (const uint4*)relu_masks, (unsigned short*)dpre_bf16, db_partial);
+  RIGGS_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+
+size_t riggs_mlp_live_rows_workspace_bytes(int32_t N) {
+  const size_t blocks = N > 0 ? ((size_t)N + 255) / 256 : 0;
+  return blocks * (4 * sizeof(unsigned long long) + sizeof(int32_t)) + 64;
+}
+
+int riggs_mlp_live_rows(int32_t N, int32_t out_ch, int32_t in_ch, const float* g_out, const void* x_emb_bf16, void* workspace,
+                        int32_t* live_idx, int32_t* live_count, void* x_live_bf16, float* g_live, riggs_stream stream) {
+  RIGGS_REQUIRE(N >= 0 && out_ch >= 1 && out_ch <= 32 && in_ch >= 1 && in_ch <= MLP_MAX_IN, "riggs_mlp_live_rows: shape out of range");
+  RIGGS_REQUIRE(live_count, "riggs_mlp_live_rows: live_count");
+  hipStream_t s = (hipStream_t)stream;
+  if (N == 0) { RIGGS_HIP_CHECK(hipMemsetAsync(live_count, 0, sizeof(int32_t), s)); return 0; }
+  RIGGS_REQUIRE(g_out && x_emb_bf16 && workspace && live_idx && x_live_bf16 && g_live, "riggs_mlp_live_rows: pointers");
+  RIGGS_REQUIRE(((uintptr_t)workspace & 7) == 0, "riggs_mlp_live_rows: the workspace must be 8-byte aligned");
+  const int blocks = (N + 255) / 256;
+  unsigned long long* bits = (unsigned long long*)workspace;
+  int32_t* counts = (int32_t*)(bits + (size_t)blocks * 4);
+  hipLaunchKernelGGL(mlp_live_flags_kernel, dim3(blocks), dim3(256), 0, s, N, out_ch, g_out, bits, counts);
+  RIGGS_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(mlp_live_gather_kernel, dim3(blocks), dim3(256), 0, s, N, out_ch, (in_ch + 63) & ~63, g_out,
+                     (const unsigned short*)x_emb_bf16, bits, counts, live_idx, live_count, (unsigned short*)x_live_bf16, g_live);
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -43,7 +43,8 @@ struct WgJob {
   int cls, first_wg, splits, pad;
 };
 struct WgDesc {
-  int N, steps, njobs, pad;
+  int N, steps, njobs, pad;       // N, steps: the host's row count (the buffers' capacity when n_dev is given)
+  const int32_t* n_dev;           // NULL, or a device word: only rows < min(*n_dev, N) exist (row-sparse backward: mlp.hip)
   const unsigned short* zeros;  // WG_ZERO_BYTES of zeros (source of the rows past N and of the padding loads)
   WgJob job[WG_MAX_JOBS];
 };
@@ -118,7 +119,7 @@ template <int N> __device__ __forceinline__ void wg_wait_vm() { asm volatile("s_
 
 // One workgroup's product: stages [t0, t1) of job `jb`.
 template <int TM, int TK, int WM, int WK, bool H16>
-__device__ __forceinline__ void wg_body(const WgDesc& D, const WgJob& jb, int split, int t0, int t1, char* lds) {
+__device__ __forceinline__ void wg_body(const WgDesc& D, const WgJob& jb, int split, int t0, int t1, int n_rows, char* lds) {
   constexpr int M = 32 * TM * WM, K = 32 * TK * WK;
   constexpr int DB = WG_ROWS * M * 2, AB = WG_ROWS * K * 2, STAGE = DB + AB;      // bytes
   constexpr int RBD = 2 * M, RBA = 2 * K;  // bytes per row of the two images
@@ -136,7 +137,6 @@ __device__ __forceinline__ void wg_body(const WgDesc& D, const WgJob& jb, int sp
   const char* ja = reinterpret_cast<const char*>(jb.a);
   float* const jcol = jb.colsum;
   float* const jpart = jb.part;
-  const int n_rows = D.N;
   const uint32_t lds0 = wg_lds_addr(lds);
 
   auto issue = [&](int buf, int t) {
@@ -223,12 +223,18 @@ __global__ __launch_bounds__(512) void mlp_wgrad_kernel(WgDesc D) {
   while (j + 1 < D.njobs && b >= D.job[j + 1].first_wg) j++;
   const WgJob jb = D.job[__builtin_amdgcn_readfirstlane(j)];
   const int split = b - jb.first_wg;
-  const int t0 = (int)((long long)D.steps * split / jb.splits), t1 = (int)((long long)D.steps * (split + 1) / jb.splits);
+  // (the row count may live on the device: read it once, here — an ordinary load inside wg_body's loop would drain its ring)
+  int n_rows = D.N, steps = D.steps;
+  if (D.n_dev) {
+    n_rows = __builtin_amdgcn_readfirstlane(min(D.n_dev[0], D.N));
+    steps = (n_rows + WG_ROWS - 1) / WG_ROWS;
+  }
+  const int t0 = (int)((long long)steps * split / jb.splits), t1 = (int)((long long)steps * (split + 1) / jb.splits);
   switch (jb.cls) {
-    case WG_CLS_HIDDEN: wg_body<2, 4, 4, 2, H16>(D, jb, split, t0, t1, wg_lds); break;
-    case WG_CLS_EMB64: wg_body<1, 2, 8, 1, H16>(D, jb, split, t0, t1, wg_lds); break;
-    case WG_CLS_EMB128: wg_body<1, 4, 8, 1, H16>(D, jb, split, t0, t1, wg_lds); break;
-    default: wg_body<1, 1, 1, 8, H16>(D, jb, split, t0, t1, wg_lds); break;
+    case WG_CLS_HIDDEN: wg_body<2, 4, 4, 2, H16>(D, jb, split, t0, t1, n_rows, wg_lds); break;
+    case WG_CLS_EMB64: wg_body<1, 2, 8, 1, H16>(D, jb, split, t0, t1, n_rows, wg_lds); break;
+    case WG_CLS_EMB128: wg_body<1, 4, 8, 1, H16>(D, jb, split, t0, t1, n_rows, wg_lds); break;
+    default: wg_body<1, 1, 1, 8, H16>(D, jb, split, t0, t1, n_rows, wg_lds); break;
   }
 }
 
@@ -237,8 +243,9 @@ __global__ __launch_bounds__(512) void mlp_wgrad_kernel(WgDesc D) {
 template <bool H16>
 __global__ __launch_bounds__(256) void mlp_gob_kernel(int N, int rows, int out_ch, const float* __restrict__ g_out,
                                                       const float* __restrict__ g_scale, unsigned short* __restrict__ gob,
-                                                      uint32_t* __restrict__ zeros) {
+                                                      uint32_t* __restrict__ zeros, const int32_t* __restrict__ n_dev) {
   const float gs = g_scale ? g_scale[0] : 1.0f;
+  if (n_dev) N = min(n_dev[0], N);
   if (blockIdx.x == 0 && threadIdx.x < WG_ZERO_BYTES / 4) zeros[threadIdx.x] = 0u;
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;  // eight values (16 bytes) per thread
   if (e >= (size_t)rows * 4) return;
@@ -425,7 +432,7 @@ size_t riggs_mlp_wgrad_workspace_bytes(int32_t N, int32_t in_ch, int32_t depth, 
 int riggs_mlp_wgrad(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip, const void* x_emb_bf16,
                     const void* acts_bf16, const void* dpre_bf16, const float* g_out, const float* g_scale, void* workspace,
                     size_t workspace_bytes, float* const* grad_weights, float* const* grad_biases, float* grad_w_out,
-                    float* grad_b_out, int32_t fp16, riggs_stream stream) {
+                    float* grad_b_out, const int32_t* n_rows_dev, int32_t fp16, riggs_stream stream) {
   RIGGS_REQUIRE(N >= 0 && depth >= 2 && depth <= 10, "MLP depth out of range");
   RIGGS_REQUIRE(in_ch >= 1 && in_ch <= 128 && out_ch >= 1 && out_ch <= 32, "MLP width out of range");
   RIGGS_REQUIRE(skip >= 0 && skip < depth - 1, "MLP skip layer out of range");
@@ -449,14 +456,14 @@ int riggs_mlp_wgrad(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, int
   {
     const size_t n_el = (size_t)P.rows32 * 4;
     if (fp16) hipLaunchKernelGGL(mlp_gob_kernel<true>, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, s, N, P.rows32, out_ch, g_out, g_scale,
-                                 gob, (uint32_t*)(ws + P.zeros_off));
+                                 gob, (uint32_t*)(ws + P.zeros_off), n_rows_dev);
     else hipLaunchKernelGGL(mlp_gob_kernel<false>, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, s, N, P.rows32, out_ch, g_out, g_scale,
-                            gob, (uint32_t*)(ws + P.zeros_off));
+                            gob, (uint32_t*)(ws + P.zeros_off), n_rows_dev);
     RIGGS_HIP_CHECK(hipGetLastError());
   }
   WgDesc D;
   WgReduceDesc R;
-  D.N = N; D.steps = P.steps; D.njobs = P.njobs; D.pad = 0;
+  D.N = N; D.steps = P.steps; D.njobs = P.njobs; D.pad = 0; D.n_dev = n_rows_dev;
   D.zeros = (const unsigned short*)(ws + P.zeros_off);
   R.n = P.njobs; R.nb = 0; R.pad0 = R.pad1 = 0; R.g_scale = g_scale;
   for (int j = 0; j < P.njobs; j++) {

@@ -108,7 +108,9 @@ def embed_positions_bf16(x: torch.Tensor, multires: int, tail: torch.Tensor = No
     return xb
 
 
-def forward(p: Packed, x_emb: torch.Tensor, want_acts: bool, xb: torch.Tensor = None):
+def forward(p: Packed, x_emb: torch.Tensor, want_acts: bool, xb: torch.Tensor = None, n_dev: torch.Tensor = None):
+    """``n_dev`` (device int32 scalar, optional): only the first ``min(n_dev, N)`` rows exist (include/riggs_hip.h:
+    n_rows_dev) — the compacted rows of the row-sparse backward."""
     N = x_emb.shape[0]
     if xb is None:
         xb = embed_bf16(p, x_emb)
@@ -119,12 +121,18 @@ def forward(p: Packed, x_emb: torch.Tensor, want_acts: bool, xb: torch.Tensor = 
         acts = torch.empty(p.depth, N, 256, dtype=p.dtype, device=x_emb.device)
         masks = torch.empty(p.depth, (N + rows - 1) // rows, 256, 4, dtype=torch.int32, device=x_emb.device)
     L.check(L.lib().riggs_mlp_forward(N, p.in_ch, p.out_ch, p.depth, p.skip, p._wp, p._bp, p.w_out.data_ptr(),
-                                      p.b_out.data_ptr(), xb.data_ptr(), L.ptr(acts), L.ptr(masks), out.data_ptr(), p.fp16,
-                                      L.stream_ptr()), "riggs_mlp_forward")
+                                      p.b_out.data_ptr(), xb.data_ptr(), L.ptr(acts), L.ptr(masks), out.data_ptr(), L.ptr(n_dev),
+                                      p.fp16, L.stream_ptr()), "riggs_mlp_forward")
     return out, (acts, masks) if want_acts else None
 
 
 _ZERO_WORD = {}
+
+
+def _aligned(t: torch.Tensor) -> torch.Tensor:
+    """``t`` at a 16-byte aligned address (the kernels read 16-byte pieces): a contiguous VIEW at an odd float offset — e.g. a
+    ``narrow`` of a ``torch.cat`` backward — is copied."""
+    return t if t.data_ptr() % 16 == 0 else t.clone()
 
 
 def grad_scale(g_out: torch.Tensor) -> torch.Tensor:
@@ -133,16 +141,35 @@ def grad_scale(g_out: torch.Tensor) -> torch.Tensor:
     (``riggs_mlp_grad_scale``; as torch ops it was seven and a copy of the tensor)."""
     if g_out.numel() == 0:
         return torch.ones(1, device=g_out.device)
-    g = L.require_cuda_f32("g_out", g_out)
-    word = _ZERO_WORD.get(g.device)
+    g = _aligned(L.require_cuda_f32("g_out", g_out))
+    key = (g.device, L.stream_ptr())  # (one accumulator word per stream: two heads' backwards on two streams must not share it)
+    word = _ZERO_WORD.get(key)
     if word is None:
-        word = _ZERO_WORD[g.device] = torch.zeros(1, dtype=torch.int32, device=g.device)
+        word = _ZERO_WORD[key] = torch.zeros(1, dtype=torch.int32, device=g.device)
     scale = torch.empty(1, device=g.device)
     L.check(L.lib().riggs_mlp_grad_scale(g.numel(), g.data_ptr(), scale.data_ptr(), word.data_ptr(), L.stream_ptr()), "riggs_mlp_grad_scale")
     return scale
 
 
-def backward_data(p: Packed, g_out: torch.Tensor, masks: torch.Tensor, scale: torch.Tensor = None, bias_sums: bool = True):
+def live_rows(p: Packed, g_out: torch.Tensor, xb: torch.Tensor):
+    """The rows of ``g_out`` (N, out_ch) that hold a non-zero, compacted in ascending order (``riggs_mlp_live_rows``: two launches,
+    no atomics, no host synchronisation): ``(idx (N) int32, count (1) int32 on the device, xb_live, g_live)`` — the gathered rows
+    of the padded 16-bit operand ``xb`` and of ``g_out``; only the first ``count`` rows of each are defined."""
+    N = g_out.shape[0]
+    dev = g_out.device
+    g_out = L.require_cuda_f32("g_out", g_out, (N, p.out_ch))
+    idx = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    xl = torch.empty_like(xb)
+    gl = torch.empty_like(g_out)
+    ws = torch.empty(int(L.lib().riggs_mlp_live_rows_workspace_bytes(N)) // 8 + 1, dtype=torch.int64, device=dev)
+    L.check(L.lib().riggs_mlp_live_rows(N, p.out_ch, p.in_ch, g_out.data_ptr(), xb.data_ptr(), ws.data_ptr(), idx.data_ptr(),
+                                        count.data_ptr(), xl.data_ptr(), gl.data_ptr(), L.stream_ptr()), "riggs_mlp_live_rows")
+    return idx, count, xl, gl
+
+
+def backward_data(p: Packed, g_out: torch.Tensor, masks: torch.Tensor, scale: torch.Tensor = None, bias_sums: bool = True,
+                  n_dev: torch.Tensor = None):
     """dL/d(pre-activation) of every hidden layer in the 16-bit format (depth, N, 256), and (``bias_sums``) the bias gradients
     (depth, 256) — both times ``scale`` when given (``grad_scale``).  Without ``bias_sums`` the second value is None:
     ``param_grads`` sums the columns beside its products."""
@@ -152,12 +179,15 @@ def backward_data(p: Packed, g_out: torch.Tensor, masks: torch.Tensor, scale: to
     rows = L.lib().riggs_mlp_rows_per_workgroup()
     db_part = torch.empty((N + rows - 1) // rows, p.depth, 256, device=g_out.device) if bias_sums else None
     L.check(L.lib().riggs_mlp_backward(N, p.out_ch, p.depth, p.skip, p._wtp, p.w_out_t_bf16.data_ptr(), g_out.data_ptr(),
-                                       L.ptr(scale), masks.data_ptr(), dpre.data_ptr(), L.ptr(db_part), p.fp16,
+                                       L.ptr(scale), masks.data_ptr(), dpre.data_ptr(), L.ptr(db_part), L.ptr(n_dev), p.fp16,
                                        L.stream_ptr()), "riggs_mlp_backward")
+    if bias_sums and n_dev is not None:
+        raise ValueError("bias_sums with a device-side row count: the workgroups past the count leave their slices unwritten")
     return dpre, (db_part.sum(0) if bias_sums else None)
 
 
-def param_grads(p: Packed, xb: torch.Tensor, acts: torch.Tensor, dpre: torch.Tensor, g_out: torch.Tensor, scale: torch.Tensor = None):
+def param_grads(p: Packed, xb: torch.Tensor, acts: torch.Tensor, dpre: torch.Tensor, g_out: torch.Tensor, scale: torch.Tensor = None,
+                n_dev: torch.Tensor = None):
     """Every parameter gradient of the MLP — [dW_0, db_0, ..., dW_{D-1}, db_{D-1}, dW_out, db_out], fp32, the masters' shapes,
     ``scale`` taken out again — from the operands the two passes left in memory (``riggs_mlp_wgrad``: three launches)."""
     N = g_out.shape[0]
@@ -178,7 +208,7 @@ def param_grads(p: Packed, xb: torch.Tensor, acts: torch.Tensor, dpre: torch.Ten
     gbp = (C.c_void_p * p.depth)(*[gb[l].data_ptr() for l in range(p.depth)])
     L.check(L.lib().riggs_mlp_wgrad(N, p.in_ch, p.out_ch, p.depth, p.skip, xb.data_ptr(), acts.data_ptr(), dpre.data_ptr(),
                                     g_out.data_ptr(), L.ptr(scale), ws.data_ptr(), nbytes, gwp, gbp, gwo.data_ptr(), gbo.data_ptr(),
-                                    p.fp16, L.stream_ptr()), "riggs_mlp_wgrad")
+                                    L.ptr(n_dev), p.fp16, L.stream_ptr()), "riggs_mlp_wgrad")
     out = []
     for l in range(p.depth):
         out += [gw[l], gb[l]]
@@ -265,19 +295,32 @@ class _FusedMLP(torch.autograd.Function):
         p = head._packed()
         n_rows = head._n_rows if x_emb.dtype == p.dtype else x_emb.shape[0]
         xb = x_emb if x_emb.dtype == p.dtype else embed_bf16(p, x_emb)
-        out, (acts, masks) = forward(p, xb[:n_rows], True, xb)
-        ctx.head, ctx.p, ctx.n = head, p, n_rows
-        ctx.save_for_backward(xb, acts, masks)
+        ctx.head, ctx.p, ctx.n, ctx.sparse = head, p, n_rows, bool(head.sparse_rows)
+        if ctx.sparse:
+            # row-sparse backward: nothing is stored here — the backward repeats the forward for the rows that carry a gradient
+            out, _ = forward(p, xb[:n_rows], False, xb)
+            ctx.save_for_backward(xb)
+        else:
+            out, (acts, masks) = forward(p, xb[:n_rows], True, xb)
+            ctx.save_for_backward(xb, acts, masks)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        xb, acts, masks = ctx.saved_tensors
         p = ctx.p
-        g_out = g_out.contiguous()
+        g_out = _aligned(g_out.contiguous())
         scale = grad_scale(g_out) if p.fp16 else None
-        dpre, _ = backward_data(p, g_out, masks, scale, bias_sums=False)
-        grads = param_grads(p, xb, acts, dpre, g_out, scale)
+        if ctx.sparse:
+            (xb,) = ctx.saved_tensors
+            _, count, xl, gl = live_rows(p, g_out, xb)
+            _, (acts, masks) = forward(p, xl[:ctx.n], True, xl, n_dev=count)
+            dpre, _ = backward_data(p, gl, masks, scale, bias_sums=False, n_dev=count)
+            grads = param_grads(p, xl, acts, dpre, gl, scale, n_dev=count)
+            ctx.head.last_live_count = count
+        else:
+            xb, acts, masks = ctx.saved_tensors
+            dpre, _ = backward_data(p, g_out, masks, scale, bias_sums=False)
+            grads = param_grads(p, xb, acts, dpre, g_out, scale)
         return (None, None) + tuple(grads)
 
 
@@ -285,8 +328,14 @@ class FusedHead:
     """Runs ``net`` (a WeightMLP or DeformMLP host mirror) through the fused kernels.  ``net`` keeps owning the fp32
     parameters; the bf16 copies are rebuilt when a parameter's version counter changes (optimizer step, load)."""
 
-    def __init__(self, linears, head_linear, in_ch: int, skip: int, fmt: str = None):
+    def __init__(self, linears, head_linear, in_ch: int, skip: int, fmt: str = None, sparse_rows: bool = False):
+        """``sparse_rows``: the backward runs on the rows whose cotangent is non-zero (``live_rows``) and the forward stores no
+        activations — exact (a zero row contributes zero to every parameter gradient), and the right choice for a head whose
+        cotangent reaches only the Gaussians the render touched (the WeightMLP: 10-30 % of the rows); a head with a dense
+        cotangent (the DeformMLP under its L2 regulariser, train_rig.py:446-454) would pay a second forward for nothing."""
         self.fmt = fmt or DEFAULT_FORMAT
+        self.sparse_rows = bool(sparse_rows)
+        self.last_live_count = None  # device int32 (1,): the live rows of the last row-sparse backward
         self.linears, self.head_linear, self.in_ch, self.skip = list(linears), head_linear, in_ch, skip
         self._pk, self._ver, self._ptrs = None, None, None
 

@@ -687,9 +687,15 @@ class SkeletonWarp(nn.Module):
     # ---- the per-Gaussian MLP heads: fp32 GEMMs through torch (the reference's arithmetic, default), or — opt-in —
     # the fused MFMA kernels of riggs_amd.mlp (~7x faster forward + backward at 300k Gaussians;
     # ``fmt``: "fp16" (default; gradients within ~2 % of the fp32 path) or "bf16")
-    def use_fused_heads(self, on: bool = True, fmt: str = None):
+    def use_fused_heads(self, on: bool = True, fmt: str = None, sparse_weight_rows: bool = True):
+        """``sparse_weight_rows`` (default on): the WeightMLP's backward runs on the rows whose cotangent is non-zero — the
+        Gaussians the render gave a gradient; the skinning backward writes exact zeros for the rest and the reference has no other
+        term on this head (its regulariser is commented out, train_rig.py:433-444) — and its forward stores no activations
+        (riggs_amd.mlp.FusedHead).  Same parameter gradients as the dense pass; turn it off for a caller that puts a dense loss on
+        ``skinning_weight_offsets``."""
         from .mlp import DEFAULT_FORMAT, _fmt_dtype
         self._fused_heads = bool(on)
+        self._fused_sparse_w = bool(sparse_weight_rows)
         self._fused_fmt = fmt or DEFAULT_FORMAT
         _fmt_dtype(self._fused_fmt)
         self._fh_w = self._fh_d = None
@@ -701,7 +707,8 @@ class SkeletonWarp(nn.Module):
         from .mlp import FusedHead
         net = self.skinning_weight_mlp
         if getattr(self, "_fh_w", None) is None:
-            self._fh_w = FusedHead(net.linear, net.weight_predict, net.input_ch, net.skips[0], self._fused_fmt)
+            self._fh_w = FusedHead(net.linear, net.weight_predict, net.input_ch, net.skips[0], self._fused_fmt,
+                                   sparse_rows=getattr(self, "_fused_sparse_w", True))
         from .mlp import embed_positions_bf16
         return torch.sigmoid(self._fh_w(embed_positions_bf16(x, net.multires, fmt=self._fused_fmt), n_rows=x.shape[0]))
 

@@ -247,4 +247,91 @@ def test_grad_scale_kernels_match_the_formula():
             assert ratio in (0.5, 1.0, 2.0), (n, mag, float(sc), float(want))   # (log2 of an exact power of two may round either way)
             if mag > 0:
                 assert 256.0 <= float(amax) * float(sc) <= 2048.0
-    assert int(M._ZERO_WORD[torch.device("cuda", torch.cuda.current_device())]) == 0
+    assert all(int(w) == 0 for w in M._ZERO_WORD.values())
+
+
+def _sparse_cotangent(N, out_ch, frac, seed=5, mag=3e-8):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    v = torch.randn(N, out_ch, device="cuda", generator=g) * mag
+    if frac <= 0.0:
+        return torch.zeros_like(v)
+    if frac >= 1.0:
+        return v
+    live = torch.rand(N, device="cuda", generator=g) < frac
+    # (a live row may hold zeros in some columns, and one row is live through a single column only)
+    v = v * live[:, None] * (torch.rand(N, out_ch, device="cuda", generator=g) < 0.7)
+    if N > 2:
+        v[N // 2] = 0.0
+        v[N // 2, out_ch - 1] = mag
+    return v
+
+
+@pytest.mark.parametrize("N", [1, 255, 256, 257, 4_097, 70_001])
+@pytest.mark.parametrize("frac", [0.0, 0.1, 1.0])
+def test_live_rows_compaction(N, frac):
+    """riggs_mlp_live_rows: ascending indices of the rows with a non-zero, their count, the gathered operand and cotangent rows,
+    the zero fill up to the next multiple of 128 — against torch.nonzero."""
+    name, net, head, xe = _nets(N)[0]
+    pk = M.FusedHead(net.linear, head, xe.shape[1], net.skips[0])._packed()
+    xb = M.embed_bf16(pk, xe)
+    g = _sparse_cotangent(N, pk.out_ch, frac)
+    idx, count, xl, gl = M.live_rows(pk, g, xb)
+    want = torch.nonzero((g != 0).any(1)).flatten()
+    m = int(count)
+    assert m == want.numel()
+    assert torch.equal(idx[:m].long(), want)
+    assert torch.equal(xl[:m], xb[want]) and torch.equal(gl[:m], g[want])
+    pad = (m + 127) // 128 * 128
+    assert float(xl[m:pad].float().abs().max()) == 0.0 if pad > m else True
+
+
+@pytest.mark.parametrize("fmt", ["fp16", "bf16"])
+@pytest.mark.parametrize("N,frac", [(1, 1.0), (300, 0.1), (20_011, 0.0), (20_011, 0.1), (20_011, 0.3), (20_011, 1.0), (70_001, 0.05)])
+def test_row_sparse_backward_equals_the_dense_backward(N, frac, fmt):
+    """FusedHead(sparse_rows=True): no activations stored by the forward; the backward repeats the forward for the rows whose
+    cotangent is non-zero and runs the data-gradient / parameter-gradient launches on those rows (their number stays on the
+    device).  Every parameter gradient equals the dense pass to 1e-5 of the tensor's largest entry (same 16-bit operands, same
+    products; the fp32 accumulation order over the rows differs), the dense pass's data gradients are EXACT zeros in the rows the
+    sparse pass skips, and with an all-zero cotangent every gradient is exactly zero in both."""
+    for name, net, head, xe in _nets(N):
+        g = _sparse_cotangent(N, head.weight.shape[0], frac, mag=3e-8 if fmt == "fp16" else 1.0)
+        grads = {}
+        outs = {}
+        for sparse in (False, True):
+            fh = M.FusedHead(net.linear, head, xe.shape[1], net.skips[0], fmt, sparse_rows=sparse)
+            for q in net.parameters():
+                q.grad = None
+            out = fh(xe)
+            torch.autograd.backward([out], [g])
+            grads[sparse] = [q.grad.clone() for q in net.parameters()]
+            outs[sparse] = out.detach()
+            if sparse:
+                assert int(fh.last_live_count) == int((g != 0).any(1).sum())
+        assert torch.equal(outs[True], outs[False])  # (the same forward kernel arithmetic, with and without the stores)
+        for a, b, (n_, _q) in zip(grads[True], grads[False], net.named_parameters()):
+            tol = 1e-5 * float(b.abs().max())
+            assert float((a - b).abs().max()) <= tol, (name, fmt, N, frac, n_, float((a - b).abs().max()), tol)
+            if frac == 0.0:
+                assert float(a.abs().max()) == 0.0 and float(b.abs().max()) == 0.0
+        # the dense pass's data gradients of the dead rows: exact zeros (what makes skipping them exact)
+        pk = M.FusedHead(net.linear, head, xe.shape[1], net.skips[0], fmt)._packed()
+        _o, (acts, masks) = M.forward(pk, xe, True)
+        sc = M.grad_scale(g) if fmt == "fp16" else None
+        dpre, _ = M.backward_data(pk, g, masks, sc, bias_sums=False)
+        dead = ~(g != 0).any(1)
+        if bool(dead.any()):
+            assert float(dpre[:, dead].float().abs().max()) == 0.0
+        for q in net.parameters():
+            q.grad = None
+
+
+def test_row_sparse_backward_takes_an_unaligned_cotangent_view():
+    """A contiguous gradient VIEW at an odd float offset (a narrow of a torch.cat backward) is accepted."""
+    name, net, head, xe = _nets(257)[0]
+    fh = M.FusedHead(net.linear, head, xe.shape[1], net.skips[0], sparse_rows=True)
+    out = fh(xe)
+    flat = torch.randn(1 + out.numel(), device="cuda") * 1e-6
+    g = flat[1:].view_as(out)
+    assert g.data_ptr() % 16 != 0 and g.is_contiguous()
+    torch.autograd.backward([out], [g])
+    assert all(q.grad is not None and bool(torch.isfinite(q.grad).all()) for q in net.parameters())
