@@ -328,14 +328,20 @@ int riggs_pose_mlp_backward(int32_t depth, int32_t width, int32_t multires, int3
  * g_rotation (4J, may be NULL) is ADDED to the sweep's dL/dlocal_rot (other consumers of the predicted quaternions);
  * g_translation (3, may be NULL) is the gradient of the predicted translation from elsewhere (the skinning's
  * dL/dglobal_trans), to which sum_j dL/dd_nodes_j is added.  dL_dlocal_rot (J,4) and dL_dglobal_trans (3) receive the two
- * totals (required for networks that run one launch per layer, else optional).  n_rot must be 4 * num_joints. */
+ * totals (required for networks that run one launch per layer, else optional).  n_rot must be 4 * num_joints.
+ * template_fixed_coef (device scalar, may be NULL): the template frame's pose regulariser of the stage-2 objective
+ * (train_rig.py:474-482: lambda_template_fixed * mean((local_rotation - (1,0,0,0))^2), template camera only) as a cotangent:
+ * dL/dlocal_rot += coef * (local_rot - unit), coef = 2 lambda / (4 J) on the template frame and 0 elsewhere, refreshed by the host
+ * between replays of a captured iteration; template_fixed_loss (device float, may be NULL) receives mean((local_rot - unit)^2),
+ * the value the reference logs.  No launch of its own. */
 int riggs_pose_mlp_backward_fk(int32_t depth, int32_t width, int32_t multires, int32_t skip, int32_t n_rot,
                                const float* const* weights, const float* const* biases, const float* W_rot,
                                const float* b_rot, const float* W_tr, const float* b_tr, float* acts, int32_t num_joints,
                                const float* local_rot, const float* joints, const int32_t* parents,
                                const float* transforms /* (J,12) as the forward wrote them, or NULL: the chain is re-run */,
                                const float* dL_dtransforms, const float* dL_dd_nodes, const float* g_rotation,
-                               const float* g_translation, float* dL_dlocal_rot, float* dL_dglobal_trans, float* workspace,
+                               const float* g_translation, float* dL_dlocal_rot, float* dL_dglobal_trans,
+                               const float* template_fixed_coef, float* template_fixed_loss, float* workspace,
                                float* flat_grads, void* sync_state, riggs_stream stream);
 
 /* =====================================================================
@@ -707,6 +713,13 @@ int riggs_mlp_live_rows(int32_t N, int32_t out_ch, int32_t in_ch, const float* g
  * launches, no host synchronisation.  zero_word: a device u32 that is ZERO on entry (the caller clears it once) and zero again
  * behind the call. */
 int riggs_mlp_grad_scale(int64_t n, const float* g, float* scale, uint32_t* zero_word, riggs_stream stream);
+/* riggs_mlp_grad_scale with an L2 regulariser on the MLP's OUTPUT folded in — the template offsets' term of the stage-2
+ * objective, train_rig.py:446-454: lambda * mean(template_offsets^2) over all Gaussians (x1e3 on the template frame) —
+ *   g_eff = g + coef[0] * out   (n floats each; coef: a device scalar = 2 lambda / n, refreshed by the host between replays),
+ * scale[0] as riggs_mlp_grad_scale from max|g_eff|, mean_sq[0] (may be NULL) = mean(out^2), the value the reference logs.
+ * The same two launches; partials512: 512 floats of scratch.  The data-gradient and weight-gradient passes then read g_eff. */
+int riggs_mlp_l2_grad_scale(int64_t n, const float* g, const float* out, const float* coef, float* g_eff, float* scale,
+                            uint32_t* zero_word, float* partials512, float* mean_sq, riggs_stream stream);
 /* db_partial: (ceil(N / riggs_mlp_rows_per_workgroup()), depth, 256) fp32 — per-workgroup column sums of dpre; the bias
  * gradients are their sum over the first axis.  May be NULL when riggs_mlp_wgrad follows (it sums the columns itself). */
 int32_t riggs_mlp_rows_per_workgroup(void);

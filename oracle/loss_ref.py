@@ -155,3 +155,28 @@ def skeleton_projection_loss(nodes, parents, world_view_transform, fx, fy, cx, c
     np.add.at(g, np.arange(1, nodes.shape[0]), (t[:, None, None] * gpts).sum(0))
     np.add.at(g, par, ((1.0 - t)[:, None, None] * gpts).sum(0))
     return loss, g
+
+
+# ---- the stage-2 objective's two regularisers (train_rig.py:446-456, 474-482) -----------------------------------------------------
+def stage2_regularisers(template_offsets, local_rotation, is_template, lambda_template_offsets=1.0, lambda_template_fixed=100.0):
+    """The terms ``render_and_cal_loss`` adds to the image loss once the heads are on, and their gradients (float64).
+
+    * train_rig.py:446-456 — ``l2_loss(template_offsets, 0)`` = mean over ALL N x 3 entries (utils/loss_utils.py:29-30), weighted
+      ``lambda_template_offsets``, x1e3 when ``viewpoint_cam.uid == template_idx``;
+    * train_rig.py:474-482 — on the template camera only: ``lambda_template_fixed * l2_loss(local_rotation, (1,0,0,0))``, the
+      mean over the J x 4 entries.
+    Pinned by tests/golden/objective_tree8_n48.npz: the reference's own method run on a bare TrainRig
+    (tests/golden/make_objective_golden.py), both cameras."""
+    T = np.asarray(template_offsets, np.float64)
+    q = np.asarray(local_rotation, np.float64).reshape(-1, 4)
+    lam_t = float(lambda_template_offsets) * (1e3 if is_template else 1.0)
+    t_loss = float((T ** 2).mean())
+    out = {"template_offsets_loss": t_loss, "lambda_template_offsets": lam_t, "g_template_offsets": lam_t * 2.0 * T / T.size,
+           "total": lam_t * t_loss, "template_fixed_loss": None, "g_local_rotation": np.zeros_like(q)}
+    if is_template and lambda_template_fixed > 1e-8:
+        d = q - np.array([1.0, 0.0, 0.0, 0.0])
+        f_loss = float((d ** 2).mean())
+        out["template_fixed_loss"] = f_loss
+        out["g_local_rotation"] = float(lambda_template_fixed) * 2.0 * d / d.size
+        out["total"] += float(lambda_template_fixed) * f_loss
+    return out

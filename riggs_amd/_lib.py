@@ -161,7 +161,7 @@ _SIGS = {
     "riggs_pose_mlp_set_placement": (C.c_int, [C.c_int32]),
     "riggs_pose_mlp_set_trace": (C.c_int, [_P]),
     "riggs_pose_mlp_backward": (C.c_int, [C.c_int32] * 5 + [_P] * 13),
-    "riggs_pose_mlp_backward_fk": (C.c_int, [C.c_int32] * 5 + [_P] * 7 + [C.c_int32] + [_P] * 14),
+    "riggs_pose_mlp_backward_fk": (C.c_int, [C.c_int32] * 5 + [_P] * 7 + [C.c_int32] + [_P] * 16),
     "riggs_pose_mlp_status_word": (C.c_size_t, [C.c_int32] * 2),
     "riggs_grad_rows_row_floats": (C.c_int32, [C.c_int32, _P]),
     "riggs_grad_rows_segment_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
@@ -196,6 +196,7 @@ _SIGS = {
     "riggs_mlp_live_rows": (C.c_int, [C.c_int32] * 3 + [_P] * 8),
     "riggs_mlp_rows_per_workgroup": (C.c_int32, []),
     "riggs_mlp_grad_scale": (C.c_int, [C.c_int64, _P, _P, _P, _P]),
+    "riggs_mlp_l2_grad_scale": (C.c_int, [C.c_int64] + [_P] * 9),
     "riggs_mlp_wgrad_workspace_bytes": (C.c_size_t, [C.c_int32] * 4),
     "riggs_mlp_wgrad": (C.c_int, [C.c_int32] * 5 + [_P] * 6 + [C.c_size_t] + [_P] * 5 + [C.c_int32, _P]),
     "riggs_mlp_embed": (C.c_int, [C.c_int32] * 3 + [_P] * 3 + [C.c_int32, _P]),

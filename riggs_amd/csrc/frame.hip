@@ -46,7 +46,7 @@ int riggs_frame_backward(const riggs_frame* f, const riggs_frame_grads* g, riggs
   return riggs_pose_mlp_backward_fk(f->depth, f->width, f->multires, f->skip, f->n_rot, f->weights, f->biases, f->W_rot, f->b_rot, f->W_tr,
                                     f->b_tr, f->acts, f->num_joints, f->local_rot, f->joints, f->parents, f->transforms, g->dL_dtransforms,
                                     g->dL_dd_nodes, g->g_local_rot, g->dL_dglobal_trans_skinning, g->dL_dlocal_rot, g->dL_dglobal_trans,
-                                    g->pose_workspace, g->pose_flat_grads, f->sync_state, s);
+                                    nullptr, nullptr, g->pose_workspace, g->pose_flat_grads, f->sync_state, s);
 }
 
 }  // extern "C"

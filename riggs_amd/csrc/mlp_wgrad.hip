@@ -291,6 +291,60 @@ __global__ void mlp_scale_kernel(uint32_t* __restrict__ word, float* __restrict_
   word[0] = 0u;
 }
 
+
+// The DeformMLP's L2 regulariser folded into its backward (train_rig.py:446-454: lambda * mean(template_offsets^2) over ALL
+// Gaussians, x1e3 on the template frame): the cotangent the data-gradient pass reads becomes  g_eff = g + coef * out  with
+// coef = 2 lambda / (3 N) a device scalar — written by the launch that takes max|g| for the fp16 gradient scale anyway, so the
+// term costs no launch of its own — and the launch that turns the maximum into the scale also finishes  mean(out^2)  (the value
+// the reference logs) from the per-workgroup partial sums, in a fixed order.
+__global__ __launch_bounds__(256) void mlp_l2_amax_kernel(int64_t n, const float* __restrict__ g, const float* __restrict__ out,
+                                                          const float* __restrict__ coef, float* __restrict__ g_eff,
+                                                          uint32_t* __restrict__ word, float* __restrict__ partials) {
+  const float c = coef[0];
+  uint32_t m = 0u;
+  float ss = 0.f;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 gv = reinterpret_cast<const float4*>(g)[i], ov = reinterpret_cast<const float4*>(out)[i];
+    float4 e;
+    e.x = gv.x + c * ov.x; e.y = gv.y + c * ov.y; e.z = gv.z + c * ov.z; e.w = gv.w + c * ov.w;
+    reinterpret_cast<float4*>(g_eff)[i] = e;
+    m = max(max(m, __float_as_uint(e.x) & 0x7FFFFFFFu), max(max(__float_as_uint(e.y) & 0x7FFFFFFFu, __float_as_uint(e.z) & 0x7FFFFFFFu),
+                                                             __float_as_uint(e.w) & 0x7FFFFFFFu));
+    ss += (ov.x * ov.x + ov.y * ov.y) + (ov.z * ov.z + ov.w * ov.w);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) {
+    const int64_t i = (n4 << 2) + threadIdx.x;
+    const float e = g[i] + c * out[i];
+    g_eff[i] = e;
+    m = max(m, __float_as_uint(e) & 0x7FFFFFFFu);
+    ss += out[i] * out[i];
+  }
+  for (int o = 32; o > 0; o >>= 1) { m = max(m, (uint32_t)__shfl_xor((int)m, o)); ss += __shfl_xor(ss, o); }
+  __shared__ uint32_t s_m[4];
+  __shared__ float s_s[4];
+  if ((threadIdx.x & 63) == 0) { s_m[threadIdx.x >> 6] = m; s_s[threadIdx.x >> 6] = ss; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
+    if (m) atomicMax(word, m);
+    partials[blockIdx.x] = (s_s[0] + s_s[1]) + (s_s[2] + s_s[3]);
+  }
+}
+__global__ __launch_bounds__(64) void mlp_l2_scale_kernel(uint32_t* __restrict__ word, float* __restrict__ scale,
+                                                          const float* __restrict__ partials, int n_partials, float inv_count,
+                                                          float* __restrict__ mean_sq) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n_partials; i += 64) s += partials[i];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (threadIdx.x == 0) {
+    const float amax = fmaxf(__uint_as_float(word[0]), 1e-30f);
+    scale[0] = exp2f(floorf(log2f(1024.0f / amax)));
+    word[0] = 0u;
+    if (mean_sq) mean_sq[0] = s * inv_count;
+  }
+}
+
 struct WgOut {
   const float* part;  // (splits, M, K)
   float* dst;         // row-major, leading dimension ld, first column col_off
@@ -418,6 +472,25 @@ int riggs_mlp_grad_scale(int64_t n, const float* g, float* scale, uint32_t* zero
     RIGGS_HIP_CHECK(hipGetLastError());
   }
   hipLaunchKernelGGL(mlp_scale_kernel, dim3(1), dim3(1), 0, s, zero_word, scale);
+  RIGGS_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+
+int riggs_mlp_l2_grad_scale(int64_t n, const float* g, const float* out, const float* coef, float* g_eff, float* scale,
+                            uint32_t* zero_word, float* partials512, float* mean_sq, riggs_stream stream) {
+  RIGGS_REQUIRE(n >= 0 && scale && zero_word && partials512 && coef, "riggs_mlp_l2_grad_scale: bad arguments");
+  RIGGS_REQUIRE(n == 0 || (g && out && g_eff), "riggs_mlp_l2_grad_scale: tensors");
+  RIGGS_REQUIRE((((uintptr_t)g | (uintptr_t)out | (uintptr_t)g_eff) & 15) == 0, "riggs_mlp_l2_grad_scale: the tensors must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  int blocks = 0;
+  if (n > 0) {
+    const int64_t want = ((n >> 2) + 255) / 256;
+    blocks = (int)(want < 512 ? (want > 0 ? want : 1) : 512);
+    hipLaunchKernelGGL(mlp_l2_amax_kernel, dim3(blocks), dim3(256), 0, s, n, g, out, coef, g_eff, zero_word, partials512);
+    RIGGS_HIP_CHECK(hipGetLastError());
+  }
+  hipLaunchKernelGGL(mlp_l2_scale_kernel, dim3(1), dim3(64), 0, s, zero_word, scale, partials512, blocks, n > 0 ? 1.0f / (float)n : 0.f, mean_sq);
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -450,7 +450,29 @@ struct PmFkArgs {
   const float *dG, *g_nodes;
   const float* transforms;  // optional: the chain's forward result (riggs_lbs_forward_fk / riggs_fk_forward), so that only the reverse sweep runs
   float *dq_out, *dgt_out;  // optional: workgroup 0 leaves the two gradients here (NULL: not wanted)
+  // optional: the template frame's pose regulariser of the stage-2 objective (train_rig.py:474-482: lambda_template_fixed *
+  // mean((local_rotation - (1,0,0,0))^2), on the template camera only) as a cotangent —  dL/dlocal_rot += coef * (q - unit)
+  // with coef = 2 lambda / (4 J) or 0, a device scalar the host refreshes between replays — and its value mean((q - unit)^2)
+  const float* fixed_coef;
+  float* fixed_loss_out;
 };
+
+// the one-launch-per-layer path's form of the same term (the fused kernel adds it while the chain's gradients sit in LDS)
+__global__ __launch_bounds__(256) void pm_fixed_add_kernel(int J, const float* __restrict__ local_rot, const float* __restrict__ coef,
+                                                           float* __restrict__ dq, float* __restrict__ loss_out) {
+  __shared__ float s_p[4];
+  const int t = threadIdx.x;
+  float d = 0.f;
+  if (t < 4 * J) {
+    d = local_rot[t] - ((t & 3) == 0 ? 1.f : 0.f);
+    if (coef) dq[t] += coef[0] * d;
+  }
+  float ss = d * d;
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  if ((t & 63) == 0) s_p[t >> 6] = ss;
+  __syncthreads();
+  if (t == 0 && loss_out) loss_out[0] = ((s_p[0] + s_p[1]) + (s_p[2] + s_p[3])) / (float)(4 * J);
+}
 #undef PM_FAULT_BIT
 #define PM_FAULT_BIT 2u
 __global__ __launch_bounds__(PMF_WAVES * 64) void pm_backward_fused_kernel(PoseMlpDesc d, PoseMlpGradDesc g, PmFkArgs fk,
@@ -527,6 +549,17 @@ __global__ __launch_bounds__(PMF_WAVES * 64) void pm_backward_fused_kernel(PoseM
     }
     __syncthreads();
     if (g_rot && (int)threadIdx.x < 4 * fk.J) s_gq[threadIdx.x] += g_rot[threadIdx.x];
+    if ((fk.fixed_coef || fk.fixed_loss_out) && wave == 0) {  // (4 J <= 256: four elements per lane of the first wave)
+      float ss = 0.f;
+      for (int i = lane; i < 4 * fk.J; i += 64) {
+        const float dqf = fk.local_rot[i] - ((i & 3) == 0 ? 1.f : 0.f);
+        ss += dqf * dqf;
+      }
+      for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+      if (rank == 0 && lane == 0 && fk.fixed_loss_out) fk.fixed_loss_out[0] = ss / (float)(4 * fk.J);
+    }
+    if (fk.fixed_coef && (int)threadIdx.x < 4 * fk.J)
+      s_gq[threadIdx.x] += fk.fixed_coef[0] * (fk.local_rot[threadIdx.x] - ((threadIdx.x & 3) == 0 ? 1.f : 0.f));
     __syncthreads();
     if (rank == 0 && fk.dq_out && (int)threadIdx.x < 4 * fk.J) fk.dq_out[threadIdx.x] = s_gq[threadIdx.x];
   }
@@ -792,6 +825,10 @@ static int pm_backward_impl(int32_t depth, int32_t width, int32_t multires, int3
     int rc2 = riggs_fk_backward(fk.J, fk.local_rot, fk.joints, fk.parents, fk.dG, fk.g_nodes, fk.dq_out, fk.dgt_out, stream);
     if (rc2) return rc2;
     RIGGS_REQUIRE(g_rotation == nullptr, "riggs_pose_mlp_backward_fk: an extra rotation gradient needs the one-launch kernels");
+    if (fk.fixed_coef || fk.fixed_loss_out) {
+      hipLaunchKernelGGL(pm_fixed_add_kernel, dim3(1), dim3(256), 0, s, fk.J, fk.local_rot, fk.fixed_coef, fk.dq_out, fk.fixed_loss_out);
+      RIGGS_HIP_CHECK(hipGetLastError());
+    }
     g_rotation = fk.dq_out; g_translation = fk.dgt_out;
   }
   RIGGS_HIP_CHECK(hipMemsetAsync(dh, 0, (size_t)(depth + 1) * PM_MAX_IN * sizeof(float), s));
@@ -823,13 +860,15 @@ int riggs_pose_mlp_backward_fk(int32_t depth, int32_t width, int32_t multires, i
                                const float* b_rot, const float* W_tr, const float* b_tr, float* acts, int32_t num_joints,
                                const float* local_rot, const float* joints, const int32_t* parents, const float* transforms,
                                const float* dL_dtransforms, const float* dL_dd_nodes, const float* g_rotation,
-                               const float* g_translation, float* dL_dlocal_rot, float* dL_dglobal_trans, float* workspace,
+                               const float* g_translation, float* dL_dlocal_rot, float* dL_dglobal_trans,
+                               const float* template_fixed_coef, float* template_fixed_loss, float* workspace,
                                float* flat_grads, void* sync_state, riggs_stream stream) {
   RIGGS_REQUIRE(num_joints >= 1 && num_joints <= MAX_J && 4 * num_joints == n_rot, "the rotation head must predict one quaternion per joint");
   RIGGS_REQUIRE(local_rot && joints && parents && dL_dtransforms, "riggs_pose_mlp_backward_fk: missing chain input");
   PmFkArgs fk;
   fk.J = num_joints; fk.local_rot = local_rot; fk.joints = joints; fk.parents = parents; fk.dG = dL_dtransforms;
   fk.g_nodes = dL_dd_nodes; fk.dq_out = dL_dlocal_rot; fk.dgt_out = dL_dglobal_trans; fk.transforms = transforms;
+  fk.fixed_coef = template_fixed_coef; fk.fixed_loss_out = template_fixed_loss;
   return pm_backward_impl(depth, width, multires, skip, n_rot, weights, biases, W_rot, b_rot, W_tr, b_tr, acts, g_rotation,
                           g_translation, workspace, flat_grads, sync_state, stream, fk);
 }

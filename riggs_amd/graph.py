@@ -330,11 +330,22 @@ class GraphedTrainStep(GraphedFrame):
     part of the iteration: the gradient is that of ``loss_img + projection_weight * cal_skeleton_loss(d_nodes, camera)``
     (``out["loss"]`` stays the image term, ``out["projection_loss"]`` the unweighted projection term); the weight is a
     device scalar the host refreshes between replays (riggs_amd.loss.ProjectionLossWeights).  The pixel buffer has a fixed
-    capacity (``max_pixels``) and a device-side count, so one graph serves frames of any pixel count up to it."""
+    capacity (``max_pixels``) and a device-side count, so one graph serves frames of any pixel count up to it.
+
+    The two regularisers of the stage-2 objective that the reference adds once the MLP heads are on (85 % of its shipped
+    100 000 iterations) are part of the iteration when their weights are given: ``lambda_template_offsets`` —
+    ``lambda * mean(template_offsets^2)`` over ALL Gaussians, x1e3 on the template camera (train_rig.py:446-456) — and
+    ``lambda_template_fixed`` — ``lambda * mean((local_rotation - (1,0,0,0))^2)`` on the template camera only (:474-482).  Both
+    enter as cotangents INSIDE launches the backward makes anyway (the fused DeformMLP's gradient-scale launch,
+    ``riggs_mlp_l2_grad_scale``; the PoseMLP's backward, ``riggs_pose_mlp_backward_fk``): their coefficients are device scalars
+    that ``run(is_template=...)`` refreshes, their values land in ``out["template_offsets_loss"]`` /
+    ``out["template_fixed_loss"]`` (unweighted means, what the reference logs).  With the fp32 (torch) heads the L2 is a second
+    autograd root instead."""
 
     def __init__(self, gm, sw, cam: Camera, bg: torch.Tensor, gt_image: torch.Tensor, optimizers, lambda_dssim: float = 0.2,
                  headroom: float = 1.5, thinned: torch.Tensor = None, projection_weight: float = 1e-3, K=None,
-                 max_pixels: int = None, sparse_grad_rows: bool = False, tight_lists: bool = False):
+                 max_pixels: int = None, sparse_grad_rows: bool = False, tight_lists: bool = False,
+                 lambda_template_offsets: float = None, lambda_template_fixed: float = None, is_template: bool = False):
         params = gm.parameters() + [p for g in sw.trainable_parameters() for p in g["params"]]
         super().__init__(gm, sw, cam, bg, params, headroom=headroom, fused=True, sparse_grad_rows=sparse_grad_rows,
                          tight_lists=tight_lists)
@@ -367,25 +378,77 @@ class GraphedTrainStep(GraphedFrame):
             o.gate = self.gate
         self.skipped_steps = 0     # replays the gate turned into no-ops, as of the last check()
         self.recovered_steps = 0   # iterations re-run eagerly after a lost hand-off
+        dev = bg.device
+        self.lam_t = None if lambda_template_offsets is None else float(lambda_template_offsets)
+        self.lam_f = None if lambda_template_fixed is None else float(lambda_template_fixed)
+        if self.lam_t is not None:
+            self.template_weight = torch.zeros((), device=dev)        # lambda (x1e3 on the template frame): the torch heads' root weight
+            self.template_coef = torch.zeros(1, device=dev)           # 2 lambda / (3 N): the fused head's cotangent coefficient
+            self.template_loss = torch.zeros(1, device=dev)           # mean(template_offsets^2)
+        if self.lam_f is not None:
+            self.fixed_coef = torch.zeros(1, device=dev)              # 2 lambda / (4 J) on the template frame, else 0
+            self.fixed_loss = torch.zeros(1, device=dev)              # mean((local_rotation - unit)^2)
+        self.set_template_frame(is_template)
+
+    def set_template_frame(self, is_template: bool):
+        """Is the frame of the NEXT replay the template camera's (``viewpoint_cam.uid == template_idx``, train_rig.py:451,475)?
+        Refreshes the regularisers' device-side coefficients (two small fills; also after a densification changed N)."""
+        self.is_template = bool(is_template)
+        n3 = 3.0 * max(1, int(self.gm.get_xyz.shape[0]))
+        if self.lam_t is not None:
+            lam = self.lam_t * (1e3 if self.is_template else 1.0)
+            self.template_weight.fill_(lam)
+            self.template_coef.fill_(2.0 * lam / n3)
+        if self.lam_f is not None:
+            j4 = 4.0 * int(self.sw.nodes.shape[0])
+            self.fixed_coef.fill_(2.0 * self.lam_f / j4 if self.is_template else 0.0)
 
     def _frame(self):
         from .loss import image_loss, cal_skeleton_loss
         for p in self.params:
             p.grad = None
         t_in = self.sw.expand_time(self.cam.fid)
-        dv = self.sw(self.gm.get_xyz.detach(), t_in, motion_mask=self.gm.motion_mask)
+        sw = self.sw
+        fused_heads = bool(getattr(sw, "_fused_heads", False))
+        want_t = self.lam_t is not None and sw.use_template_offsets
+        # the regularisers as cotangents inside the heads' / the PoseMLP's own backward launches (device-side coefficients)
+        sw.template_l2 = (self.template_coef, self.template_loss) if (want_t and fused_heads) else None
+        sw.template_fixed = (self.fixed_coef, self.fixed_loss) if self.lam_f is not None else None
+        sw._fixed_folded = False
+        try:
+            dv = sw(self.gm.get_xyz.detach(), t_in, motion_mask=self.gm.motion_mask)
+        finally:
+            fixed_folded = sw._fixed_folded
+            sw.template_l2 = sw.template_fixed = None  # (eager callers of the same warp carry these terms through autograd)
         pkg = render(self.cam, self.gm, _Pipe, self.bg, dv["d_xyz"], dv["d_rotation"], dv["d_scaling"],
                      fused=self.fused, arena=self.arena)
         loss, l1 = image_loss(pkg["render"], self.gt, self.lam)
         proj = None
-        if self.thinned is None:
-            torch.autograd.backward([loss], [self.one])  # (an explicit seed: ``loss.backward()`` launches a fill for its ones)
-        else:
-            # two roots, one backward pass: no launches for "loss + weight * projection" and its autograd mirror
+        roots, seeds = [loss], [self.one]  # (explicit seeds: ``loss.backward()`` launches a fill for its ones)
+        if self.thinned is not None:
+            # several roots, one backward pass: no launches for "loss + weight * projection" and its autograd mirror
             self.cam.thinned = self.thinned
             proj, wproj = cal_skeleton_loss(dv["d_nodes"], self.proj_parents, self.cam, t=self.proj_steps, weight=self.proj_weight,
                                             pixel_count=self.pixel_count)
-            torch.autograd.backward([loss, wproj], [self.one, self.one])
+            roots.append(wproj)
+            seeds.append(self.one)
+        t_loss = f_loss = None
+        if want_t:
+            if fused_heads:
+                t_loss = self.template_loss
+            else:  # the fp32 heads: the reference's own arithmetic (utils/loss_utils.py:29-30), weighted by the device scalar
+                t_loss = (sw.template_offsets ** 2).mean()
+                roots.append(t_loss)
+                seeds.append(self.template_weight)
+        if self.lam_f is not None:
+            if fixed_folded:
+                f_loss = self.fixed_loss
+            else:  # (a pose network the one-node path does not take: the same term through autograd)
+                unit = torch.tensor([1.0, 0.0, 0.0, 0.0], device=self.bg.device)
+                f_loss = ((dv["local_rotation"].reshape(-1, 4) - unit) ** 2).mean()
+                roots.append(f_loss)
+                seeds.append(self.fixed_coef.reshape(()) * (2.0 * int(sw.nodes.shape[0])))  # coef = 2 lambda / (4 J) -> lambda
+        torch.autograd.backward(roots, seeds)
         from .optim import step_many
         step_many(self.optimizers)
         out = {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in dict.items(pkg)
@@ -394,11 +457,16 @@ class GraphedTrainStep(GraphedFrame):
         out["loss"], out["l1"] = loss.detach(), l1.detach()
         if proj is not None:
             out["projection_loss"] = proj.detach()
+        if t_loss is not None:
+            out["template_offsets_loss"] = t_loss.detach()
+        if f_loss is not None:
+            out["template_fixed_loss"] = f_loss.detach()
         return RenderPkg(out, cache=False)
 
     def recapture(self, params=None, warmup: int = 1):
         if params is None:
             params = self.gm.parameters() + [p for g in self.sw.trainable_parameters() for p in g["params"]]
+        self.set_template_frame(self.is_template)  # (N may have changed: the L2's coefficient is 2 lambda / (3 N))
         return super().recapture(params, warmup)
 
     def check(self):
@@ -429,7 +497,9 @@ class GraphedTrainStep(GraphedFrame):
         self.recovered_steps += 1
 
     def run(self, cam: Camera = None, gt_image: torch.Tensor = None, thinned: torch.Tensor = None,
-            projection_weight=None):
+            projection_weight=None, is_template: bool = None):
+        if is_template is not None and bool(is_template) != self.is_template:
+            self.set_template_frame(is_template)
         if gt_image is not None:
             self.gt.copy_(gt_image, non_blocking=True)
         if thinned is not None:

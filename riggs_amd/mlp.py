@@ -151,6 +151,26 @@ def grad_scale(g_out: torch.Tensor) -> torch.Tensor:
     return scale
 
 
+_L2_SCRATCH = {}
+
+
+def l2_grad_scale(g_out: torch.Tensor, out: torch.Tensor, coef: torch.Tensor, mean_sq: torch.Tensor = None):
+    """``riggs_mlp_l2_grad_scale``: ``g_eff = g_out + coef * out`` (the L2 regulariser on the MLP's output folded into its
+    cotangent; ``coef`` a device scalar), the fp16 gradient scale of ``g_eff`` and — into ``mean_sq`` when given — mean(out^2).
+    The two launches ``grad_scale`` makes anyway.  Returns ``(g_eff, scale)``."""
+    g = _aligned(L.require_cuda_f32("g_out", g_out))
+    o = _aligned(L.require_cuda_f32("out", out, tuple(g.shape)))
+    key = (g.device, L.stream_ptr())
+    sc = _L2_SCRATCH.get(key)
+    if sc is None:
+        sc = _L2_SCRATCH[key] = (torch.zeros(1, dtype=torch.int32, device=g.device), torch.empty(512, device=g.device))
+    g_eff = torch.empty_like(g)
+    scale = torch.empty(1, device=g.device)
+    L.check(L.lib().riggs_mlp_l2_grad_scale(g.numel(), g.data_ptr(), o.data_ptr(), coef.data_ptr(), g_eff.data_ptr(), scale.data_ptr(),
+                                            sc[0].data_ptr(), sc[1].data_ptr(), L.ptr(mean_sq), L.stream_ptr()), "riggs_mlp_l2_grad_scale")
+    return g_eff, scale
+
+
 def live_rows(p: Packed, g_out: torch.Tensor, xb: torch.Tensor):
     """The rows of ``g_out`` (N, out_ch) that hold a non-zero, compacted in ascending order (``riggs_mlp_live_rows``: two launches,
     no atomics, no host synchronisation): ``(idx (N) int32, count (1) int32 on the device, xb_live, g_live)`` — the gathered rows
@@ -291,8 +311,9 @@ class _FusedMLP(torch.autograd.Function):
     """out = MLP(x_emb) with the fused kernels; gradients for the (fp32 master) parameters only."""
 
     @staticmethod
-    def forward(ctx, x_emb, head, *params):
+    def forward(ctx, x_emb, head, l2, *params):
         p = head._packed()
+        ctx.l2 = l2  # None, or (coef, mean_sq): an L2 regulariser on the output folded into the backward (l2_grad_scale)
         n_rows = head._n_rows if x_emb.dtype == p.dtype else x_emb.shape[0]
         xb = x_emb if x_emb.dtype == p.dtype else embed_bf16(p, x_emb)
         ctx.head, ctx.p, ctx.n, ctx.sparse = head, p, n_rows, bool(head.sparse_rows)
@@ -303,13 +324,19 @@ class _FusedMLP(torch.autograd.Function):
         else:
             out, (acts, masks) = forward(p, xb[:n_rows], True, xb)
             ctx.save_for_backward(xb, acts, masks)
+        ctx.out = out if l2 is not None else None  # (detached inside a Function: no reference cycle)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
         p = ctx.p
         g_out = _aligned(g_out.contiguous())
-        scale = grad_scale(g_out) if p.fp16 else None
+        if ctx.l2 is not None:
+            g_out, scale = l2_grad_scale(g_out, ctx.out, ctx.l2[0], ctx.l2[1])
+            if not p.fp16:
+                scale = None
+        else:
+            scale = grad_scale(g_out) if p.fp16 else None
         if ctx.sparse:
             (xb,) = ctx.saved_tensors
             _, count, xl, gl = live_rows(p, g_out, xb)
@@ -321,7 +348,7 @@ class _FusedMLP(torch.autograd.Function):
             xb, acts, masks = ctx.saved_tensors
             dpre, _ = backward_data(p, g_out, masks, scale, bias_sums=False)
             grads = param_grads(p, xb, acts, dpre, g_out, scale)
-        return (None, None) + tuple(grads)
+        return (None, None, None) + tuple(grads)
 
 
 class FusedHead:
@@ -363,7 +390,10 @@ class FusedHead:
             self._ver = ver
         return self._pk
 
-    def __call__(self, x_emb: torch.Tensor, n_rows: int = None) -> torch.Tensor:
-        """``x_emb``: (N, in_ch) fp32, or the padded bf16 operand of ``embed_positions_bf16`` together with ``n_rows`` = N."""
+    def __call__(self, x_emb: torch.Tensor, n_rows: int = None, l2=None) -> torch.Tensor:
+        """``x_emb``: (N, in_ch) fp32, or the padded bf16 operand of ``embed_positions_bf16`` together with ``n_rows`` = N.
+        ``l2``: None, or ``(coef, mean_sq)`` — device scalars: the backward adds ``coef * output`` to the incoming cotangent
+        (d/d output of ``lambda * mean(output^2)`` for ``coef = 2 lambda / output.numel()``) and writes mean(output^2) into
+        ``mean_sq`` (may be None); no launch beyond the gradient scale's two."""
         self._n_rows = n_rows
-        return _FusedMLP.apply(x_emb.contiguous(), self, *self.params())
+        return _FusedMLP.apply(x_emb.contiguous(), self, l2, *self.params())

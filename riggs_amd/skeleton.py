@@ -352,8 +352,9 @@ class _PoseDeform(torch.autograd.Function):
     _PoseMLPFn + _DeformByPose (get_pose_info + deform_by_pose), two launches fewer per frame (~13 us of a 385 us frame)."""
 
     @staticmethod
-    def forward(ctx, t, rot_bias, sync, rho, mask, x, joints, parents_i32, K, weight_mod, depth, width, multires, skip, *params):
+    def forward(ctx, t, rot_bias, sync, rho, mask, x, joints, parents_i32, K, weight_mod, fixed, depth, width, multires, skip, *params):
         ctx.set_materialize_grads(False)
+        ctx.fixed = fixed  # None, or (coef, loss_out) device scalars: the template frame's pose regulariser (riggs_pose_mlp_backward_fk)
         params = [p.contiguous() for p in params]
         lib, dev = L.lib(), x.device
         N, J = x.shape[0], joints.shape[0]
@@ -432,12 +433,13 @@ class _PoseDeform(torch.autograd.Function):
         L.check(lib.riggs_pose_mlp_backward_fk(depth, width, multires, skip, n_rot, Wp, bp, h[0].data_ptr(), h[1].data_ptr(),
                                                h[2].data_ptr(), h[3].data_ptr(), acts.data_ptr(), J, local_rot.data_ptr(),
                                                joints.data_ptr(), parents_i32.data_ptr(), transforms.data_ptr(), dG.data_ptr(), L.ptr(gn), L.ptr(gq),
-                                               dgt.data_ptr(), dq.data_ptr(), dgt_total.data_ptr(), dzs.data_ptr(),
-                                               flat.data_ptr(), L.ptr(ctx.sync), st), "riggs_pose_mlp_backward_fk")
+                                               dgt.data_ptr(), dq.data_ptr(), dgt_total.data_ptr(),
+                                               L.ptr(ctx.fixed[0]) if ctx.fixed else None, L.ptr(ctx.fixed[1]) if ctx.fixed else None,
+                                               dzs.data_ptr(), flat.data_ptr(), L.ptr(ctx.sync), st), "riggs_pose_mlp_backward_fk")
         # (one split + a view per matrix: a slice and a view per parameter were 30 us of an eagerly issued frame)
         grads = [g_ if p.dim() == 1 else g_.view(p.shape) for g_, p in zip(flat.split_with_sizes([p.numel() for p in params]), params)]
         gmask = dmask.reshape(ctx.mask_shape) if need_mask else None
-        return (None, None, None, drho, gmask, None, None, None, None, dmod, None, None, None, None, *grads)
+        return (None, None, None, drho, gmask, None, None, None, None, dmod, None, None, None, None, None, *grads)
 
 
 class _LazyDeformDict(dict):
@@ -529,6 +531,12 @@ class SkeletonWarp(nn.Module):
         self.skinning_weight_offsets = None
         self.control_nodes = nn.Parameter(torch.zeros(512, 3))  # checkpoint compatibility (:31)
         self.template_offsets = None
+        # the stage-2 objective's two regularisers as cotangents inside this module's own backward launches (set per call by
+        # riggs_amd.graph.GraphedTrainStep; None: a caller that writes the terms in torch — the reference's train_rig.py:446-482
+        # — gets them through autograd): (coef, mean_sq) device scalars for the fused DeformMLP (riggs_mlp_l2_grad_scale),
+        # (coef, loss) for the PoseMLP's backward (riggs_pose_mlp_backward_fk)
+        self.template_l2 = None
+        self.template_fixed = None
         self.pose_net = PoseMLP(1, J * 4)
         # (the heads are constructed AFTER pose_net: they draw from the global RNG, and the pose network of a given seed
         # — the benchmark's scene — must not depend on whether they exist)
@@ -721,10 +729,11 @@ class SkeletonWarp(nn.Module):
             self._fh_d = FusedHead(net.linear, net.gaussian_warp, net.input_ch, net.skips[0], self._fused_fmt)
         if net.t_multires <= 0 and net.multires > 0:  # the reference's configuration: PE(x) and the raw pose vector
             from .mlp import embed_positions_bf16
-            return self._fh_d(embed_positions_bf16(x, net.multires, pose[0], fmt=self._fused_fmt), n_rows=x.shape[0])
+            return self._fh_d(embed_positions_bf16(x, net.multires, pose[0], fmt=self._fused_fmt), n_rows=x.shape[0],
+                              l2=getattr(self, "template_l2", None))
         t_emb = _embed(pose, net.t_multires) if net.t_multires > 0 else pose
         x_emb = _embed(x, net.multires) if net.multires > 0 else x
-        return self._fh_d(torch.cat([x_emb, t_emb], dim=-1))
+        return self._fh_d(torch.cat([x_emb, t_emb], dim=-1), l2=getattr(self, "template_l2", None))
 
     def deform_by_pose(self, x, node_attrs, motion_mask, _time=None):
         x = L.require_cuda_f32("x", x.detach(), (x.shape[0], 3))
@@ -755,9 +764,10 @@ class SkeletonWarp(nn.Module):
                 sync = None
             else:
                 pn.watch()
+            self._fixed_folded = getattr(self, "template_fixed", None) is not None
             d_xyz, d_rot, d_nodes, local_rot, global_trans, transforms, node_rot = _PoseDeform.apply(
                 _time.reshape(1), self._rot_bias, sync, self._node_radius, mask, x, joints, par, self.K, weight_mod,
-                len(pn.net), pn.net[0].out_features, pn.multires, pn.skips[0], *params)
+                getattr(self, "template_fixed", None), len(pn.net), pn.net[0].out_features, pn.multires, pn.skips[0], *params)
             node_attrs = {"local_rotation": local_rot, "global_trans": global_trans, "t": _time}
         else:
             d_xyz, d_rot, d_nodes, transforms, node_rot = _DeformByPose.apply(

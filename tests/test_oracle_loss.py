@@ -64,3 +64,31 @@ def test_skeleton_projection_gradient_is_the_derivative_of_the_loss():
     lp, _ = O.skeleton_projection_loss(nodes + h * d, z["parents"], z["world_view_transform"], *intr, z["thinned"], t=t)
     lm, _ = O.skeleton_projection_loss(nodes - h * d, z["parents"], z["world_view_transform"], *intr, z["thinned"], t=t)
     assert abs((lp - lm) / (2 * h) - (g * d).sum()) < 1e-3 * abs((g * d).sum())
+
+
+# ---- the stage-2 objective's regularisers against the reference's own render_and_cal_loss (both cameras) ------------------------
+OBJ = np.load(os.path.join(os.path.dirname(__file__), "golden", "objective_tree8_n48.npz"))
+
+
+def test_stage2_regularisers_match_the_reference_objective():
+    for tag in ("template", "other"):
+        is_t = int(OBJ[tag + "_uid"]) == int(OBJ["template_idx"])
+        r = O.stage2_regularisers(OBJ["template_offsets"], OBJ["local_rotation"], is_t, float(OBJ["lambda_template_offsets"]),
+                                  float(OBJ["lambda_template_fixed"]))
+        assert abs(r["template_offsets_loss"] - float(OBJ[tag + "_template_offsets_loss"])) <= 1e-6 * r["template_offsets_loss"]
+        assert r["lambda_template_offsets"] == float(OBJ[tag + "_lambda_template_offsets"])
+        g = OBJ[tag + "_g_template_offsets"]
+        assert np.abs(r["g_template_offsets"] - g).max() <= 1e-6 * np.abs(g).max()
+        gq = OBJ[tag + "_g_local_rotation"]
+        if is_t:
+            assert abs(r["template_fixed_loss"] - float(OBJ[tag + "_template_fixed_loss"])) <= 1e-6 * r["template_fixed_loss"]
+            assert np.abs(r["g_local_rotation"] - gq).max() <= 1e-6 * np.abs(gq).max()
+        else:
+            assert r["template_fixed_loss"] is None and not gq.any() and not r["g_local_rotation"].any()
+        # the total: the image term (the reference logs it) + the regularisers
+        total = float(OBJ["lambda_rendering_image"]) * float(OBJ[tag + "_loss_img"]) + r["total"]
+        assert abs(total - float(OBJ[tag + "_loss"])) <= 2e-6 * abs(total)
+    # the image term of the golden is the reference's l1 / ssim of the stand-in render: the image-loss oracle reproduces it
+    img, gt = OBJ["template_render"].astype(np.float64), OBJ["gt_image"].astype(np.float64)
+    lam = float(OBJ["lambda_dssim"])
+    assert abs((1 - lam) * O.l1(img, gt) + lam * (1 - O.ssim(img, gt)) - float(OBJ["template_loss_img"])) < 2e-6
