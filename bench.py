@@ -155,6 +155,73 @@ def heads_timing(sc, gm, iters=5):
                               "embeddings, operand packing) over the dense fp16 MFMA peak"}
 
 
+def train_step_heads_timing(dev, surface=False, steps=40):
+    """Secondary number (NOT the metric): the WHOLE training iteration of the shipped stage-2 recipe after iteration 15 000 (85 %
+    of the reference's 100 000: scripts/run_demo.py:32) as one hipGraph — both per-Gaussian MLP heads on (fused fp16-MFMA kernels;
+    the WeightMLP's backward on the rows that carry a gradient), the reference's objective for that phase (image loss +
+    template-offsets L2 over all Gaussians + template_fixed on the template frame: train_rig.py:446-456, 474-482, folded into the
+    heads' / PoseMLP's backward launches), FusedAdam of the Gaussians and the skeleton incl. both heads — next to the same
+    iteration with the heads off; ``heads_ms`` is the difference (what the heads cost inside the iteration)."""
+    from riggs_amd.graph import GraphedTrainStep
+    from riggs_amd.optim import FusedAdam
+    from riggs_amd.skeleton import SkeletonWarp
+    w = WORKLOAD
+    res = {}
+    for heads in (False, True):
+        sc, cam, gm, _sw = build_workload(0, dev, surface=surface)
+        torch.manual_seed(w["seed"])
+        sw = SkeletonWarp(joints=sc["joints"], parent_indices=sc["parents"], K=-1, hyper_dim=8, use_skinning_weight_mlp=heads,
+                          use_template_offsets=heads).to(dev)
+        sw._node_radius.data = sc["node_radius"].to(dev)
+        if heads:
+            sw.use_fused_heads(True)
+        gm.training_setup(_train_args(), capturable=True)
+        opt = FusedAdam([{"params": g_["params"], "lr": 5e-4, "name": g_["name"]} for g_ in sw.trainable_parameters()],
+                        lr=0.0, eps=1e-15, capturable=True)
+        bg = torch.zeros(3, device=dev)
+        from riggs_amd.graph import GraphedFrame
+        img0 = GraphedFrame(gm, sw, cam, bg, params_of(gm, sw)).capture().run()["render"].detach().clone()
+        target = (img0 + 0.05 * torch.randn(img0.shape, generator=torch.Generator().manual_seed(w["seed"] + 7)).to(dev)).clamp_(0.0, 1.0)
+        for p in gm.parameters() + list(sw.parameters()):
+            p.grad = None
+        gts = GraphedTrainStep(gm, sw, cam, bg, target, [gm.optimizer, opt], lambda_dssim=0.2, sparse_grad_rows=True, tight_lists=_tight(),
+                               lambda_template_offsets=1.0 if heads else None, lambda_template_fixed=100.0 if heads else None)
+        gts.capture()
+        for _ in range(5):
+            gts.run()
+        blocks = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                gts.run()
+            torch.cuda.synchronize()
+            blocks.append((time.perf_counter() - t0) / steps)
+        R = gts.check()
+        res[heads] = {"ms": min(blocks) * 1e3, "R": int(R), "loss": float(gts.out["loss"])}
+        if heads:
+            res["live"] = int(sw._fh_w.last_live_count) / float(w["N"])
+            res["t_loss"] = float(gts.out["template_offsets_loss"])
+            # the template frame's replay (x1e3 L2, template_fixed on): same launches, device-side coefficients
+            gts.run(is_template=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                gts.run()
+            torch.cuda.synchronize()
+            res["template_ms"] = (time.perf_counter() - t0) / 10 * 1e3
+        del gts
+    on, off = res[True]["ms"], res[False]["ms"]
+    return {"value": round(1e3 / on, 2), "unit": "iters/s", "ms_per_step": round(on, 4), "heads_off_ms_per_step": round(off, 4),
+            "heads_ms": round(on - off, 4), "template_frame_ms_per_step": round(res["template_ms"], 4),
+            "weight_mlp_live_rows": round(res["live"], 4), "tile_instances_R": res[True]["R"], "final_loss": round(res[True]["loss"], 6),
+            "template_offsets_loss": res["t_loss"],
+            "what": "one hipGraph per training iteration, %s scene, both MLP heads on (fused fp16 MFMA; WeightMLP backward on the rows with a "
+                    "gradient), objective = image loss + template-offsets L2 + template_fixed (train_rig.py:446-482), FusedAdam incl. the heads; "
+                    "heads_ms = this minus the same iteration with the heads off; fastest of three blocks of %d; not the headline metric"
+                    % ("opaque-skin" if surface else "headline", steps)}
+
+
 def next_rows_timing(sc, gm, cam, iters=20):
     """Secondary numbers (NOT the metric) for two more SURVEY.md §8-f rows: the stage-1 control-node deformation (rank 4) and
     the skeleton projection loss (rank 2), forward + backward each, eager launches timed with events."""
@@ -1292,6 +1359,8 @@ def main():
             # Secondary number (NOT the metric): the deformation with both per-Gaussian MLP heads on (the stage-2 recipe,
             # SURVEY.md §8-f rank 3), forward + backward, fp32 library GEMMs vs the fused MFMA kernels (fp16 operands)
             out["mlp_heads"] = heads_timing(sc, gm)
+            out["train_step_heads"] = train_step_heads_timing(dev)
+            out["train_step_heads"]["dense_scene"] = train_step_heads_timing(dev, surface=True, steps=20)
             out["next_rows"] = next_rows_timing(sc, gm, cam)
             out["dense_gradient_scene"] = dense_scene_timing(dev)
             out["cycling_cameras"] = cycling_cameras_timing(dev)
