@@ -696,10 +696,82 @@ def exchange_path_child(steps=200, scene="headline"):
                        "pose_handoff_timeouts": int(st[0][st[1]].item()) if st is not None else None,
                        "arena_flags": int(gf.arena.static_counters[1].item()) & 3, "exchange_status_clean": bool(rows.check()),
                        "invalid_frames": bool(rows.invalid_frame)}
+        # ... and with compute units TAKEN AWAY for the whole soak, as a collective library's channel kernels take them at W = 8:
+        # n workgroups that each hold a whole CU (riggs_debug_pin_cus) on a stream of their own.  The one-launch PoseMLP chain
+        # hands its layers over between CO-RESIDENT workgroups: does it still find room?  (placement 1 = the chain on one XCD,
+        # this graph; placement 0 = the chain spread over all XCDs, what riggs_amd.dist selects for world sizes > 1.)
+        if os.environ.get("RIGGS_BENCH_PIN_SOAK", "1") != "0":
+            out["soak_pinned_cus"] = pinned_cus_soak(gf, dev, gm, sw, cam, bg, params, gimg)
     except Exception as e:  # (recorded, not hidden: the eager-collective number above stands on its own)
         out["one_graph_error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
     print(json.dumps(out), flush=True)
     dist.destroy_process_group()
+
+
+def pinned_cus_soak(gf_one_xcd, dev, gm, sw, cam, bg, params, gimg, counts=(16, 32, 64, 128), replays=None):
+    """Replays of a captured frame while ``k`` compute units are held by spinning workgroups on another stream: per k the time per
+    replay and the PoseMLP chain's lost hand-offs (sticky word, cleared between runs).  Returns {placement: {k: {...}}}."""
+    from riggs_amd import _lib as L
+    from riggs_amd.graph import GraphedFrame
+    n_rep = int(os.environ.get("RIGGS_BENCH_PIN_SOAK_REPLAYS", "10000")) if replays is None else replays
+    res = {"replays": n_rep, "what": "k workgroups holding a whole CU's LDS each spin on a second stream for the whole soak "
+                                      "(riggs_debug_pin_cus); per k: ms per replay and PoseMLP hand-off time-outs (sticky word)"}
+
+    def soak(gf, k, n):
+        st = gf._pose_status()
+        if st is not None:
+            st[0][st[1]] = 0
+        # (the stop word lives in DEVICE memory and is raised by a fill on a third stream: pinned host memory is not coherent
+        # for a running kernel by default — HIP_HOST_COHERENT=0 — and a pinner that never sees its stop word runs to its time limit)
+        stop = torch.zeros(1, dtype=torch.int32, device=dev)
+        started = torch.zeros(1, dtype=torch.int32, device=dev)
+        side, ctrl = torch.cuda.Stream(), torch.cuda.Stream()
+        cur = torch.cuda.current_stream()
+        cur.synchronize()
+        if k:
+            with torch.cuda.stream(side):
+                L.check(L.lib().riggs_debug_pin_cus(k, stop.data_ptr(), 30000, started.data_ptr(), L.stream_ptr()), "riggs_debug_pin_cus")
+            t_wait = time.perf_counter()
+            while int(started.item()) < k and time.perf_counter() - t_wait < 5.0:
+                time.sleep(0.001)
+        resident = int(started.item()) if k else 0
+        for _ in range(20):
+            gf.run()
+        gf.stream.synchronize()
+        cur.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            gf.run()
+        gf.stream.synchronize()
+        cur.synchronize()
+        dt = (time.perf_counter() - t0) / n * 1e3
+        word = int(st[0][st[1]].item()) if st is not None else None
+        flags = int(gf.arena.static_counters[1].item()) & 3
+        with torch.cuda.stream(ctrl):
+            stop.fill_(1)
+        ctrl.synchronize()
+        t_stop = time.perf_counter()
+        side.synchronize()
+        if k and time.perf_counter() - t_stop > 1.0:
+            raise RuntimeError("the CU pinner did not see its stop word")
+        return {"pinned_cus_resident": resident, "ms_per_step": round(dt, 4), "pose_handoff_timeouts_word": word, "arena_flags": flags}
+    one = {}
+    for k in (0,) + tuple(counts):
+        one[str(k)] = soak(gf_one_xcd, k, n_rep if k else min(n_rep, 2000))
+    res["placement_1_one_xcd (this graph: frame + exchange)"] = one
+    L.check(L.lib().riggs_pose_mlp_set_placement(0), "riggs_pose_mlp_set_placement")
+    try:
+        gf0 = GraphedFrame(gm, sw, cam, bg, params, sparse_grad_rows=False, tight_lists=_tight()).capture()
+        gf0.set_inputs(gimg=gimg)
+        spread = {}
+        for k in (0,) + tuple(counts):
+            spread[str(k)] = soak(gf0, k, n_rep if k else min(n_rep, 2000))
+        res["placement_0_all_xcds (plain frame; what world sizes > 1 run)"] = spread
+    finally:
+        L.check(L.lib().riggs_pose_mlp_set_placement(1), "riggs_pose_mlp_set_placement")
+    worst = max(v["pose_handoff_timeouts_word"] or 0 for grp in res.values() if isinstance(grp, dict) for v in grp.values())
+    res["any_timeout"] = bool(worst)
+    return res
 
 
 def capture_probe_child():

@@ -493,7 +493,8 @@ int riggs_densify_stats(int32_t num_points, const float* viewspace_grad, const u
  * The caller all-gathers the segments of all ranks (equal riggs_grad_rows_segment_bytes) and calls
  * riggs_grad_rows_unpack: per Gaussian the rows are combined IN RANK ORDER — first occurrence overwrites, later ones are
  * added; rows in no segment are left as they are (zero on every rank) — without atomics, so every rank obtains the same
- * bits.  `grads` are HOST arrays of DEVICE pointers to (N, widths[k]) row-major float tensors (<= 8).  `status` (4 words)
+ * bits.  `grads` are HOST arrays of DEVICE pointers to (N, widths[k]) row-major float tensors (<= 8).  `status` (8 words;
+ * [4] = THIS call's flag — [1]'s bits for this call alone, rewritten every call: the word a step's optimizers gate on; [0..3])
  * is STICKY — only ever raised by the kernel, cleared by whoever reads it: [0] = the largest number of rows a segment
  * needed, [1] != 0 when in some call a segment overflowed `capacity` or did not match (N, row_floats) (bit 0) or was marked
  * "frame invalid" by riggs_grad_rows_pack_gated (bit 1): in that call NOTHING
@@ -513,6 +514,11 @@ int riggs_grad_rows_pack_gated(int32_t num_points, const void* backward_workspac
 int riggs_grad_rows_unpack(int32_t num_points, int32_t world, int32_t capacity, const void* segments, int32_t n_tensors,
                            float* const* grads, const int32_t* widths, uint32_t* status, void* backward_workspace,
                            riggs_stream stream);
+/* Test / measurement aid (multi-GPU readiness on one GPU): n_cus workgroups that each claim a whole compute unit's LDS — so they
+ * sit on n_cus distinct CUs, as a collective library's channel kernels do beside a rank's frame — and spin until the host raises
+ * *stop_flag (a DEVICE word, raised by a fill on another stream: pinned host memory is not coherent for a running kernel by default) or max_ms have passed (bounded).  *started (device u32, zeroed by the
+ * caller) counts the workgroups that are resident.  Launch it on a stream of its own. */
+int riggs_debug_pin_cus(int32_t n_cus, const int32_t* stop_flag, uint32_t max_ms, uint32_t* started, riggs_stream stream);
 
 /* =====================================================================
  * Image loss: utils/loss_utils.py:17-18 (l1_loss), :33-77 (ssim, 11x11 Gaussian window,

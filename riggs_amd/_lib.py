@@ -177,6 +177,7 @@ _SIGS = {
     "riggs_gate_flag": (C.c_int, [C.POINTER(GateStruct), _P, _P]),
     "riggs_adam_steps_advance_gated": (C.c_int, [C.c_int32, _P, C.POINTER(GateStruct), _P, _P]),
     "riggs_grad_rows_pack_gated": (C.c_int, [C.c_int32, _P, C.c_int32, _P, _P, C.c_float, C.c_int32, _P, C.POINTER(GateStruct), _P]),
+    "riggs_debug_pin_cus": (C.c_int, [C.c_int32, _P, C.c_uint32, _P, _P]),
     "riggs_densify_stats": (C.c_int, [C.c_int32] + [_P] * 7),
     "riggs_l1_ssim_state_floats": (C.c_size_t, [C.c_int32] * 3),
     "riggs_l1_ssim_forward": (C.c_int, [C.c_int32] * 3 + [_P, _P, C.c_float, _P, _P, _P]),

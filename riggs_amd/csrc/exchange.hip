@@ -172,10 +172,13 @@ __global__ __launch_bounds__(256) void rows_unpack_kernel(int N, int world, int 
   // still learn that ONE of them overflowed — on that step every rank skipped the unpack and stepped its optimizer on local
   // gradients.  {largest need since the last check, overflow flag, unpack calls since the last check, the call (1-based)
   // that overflowed first}
+  // status[4] is NOT sticky: this call's flag, rewritten by every call — the word the optimizers of this step gate on (gated on
+  // the sticky word they would also skip every GOOD step up to the host's next look)
   if (b == 0 && t == 0) {
     atomicMax(&status[0], s_hdr[0]);
     const uint32_t call = atomicAdd(&status[2], 1u) + 1u;
     if (s_hdr[1]) { atomicOr(&status[1], s_hdr[1]); atomicCAS(&status[3], 0u, call); }
+    status[4] = s_hdr[1];
   }
   if (s_hdr[1]) return;  // (every workgroup of every rank sees the same headers: all skip, the gradients stay as they were)
   const size_t rows_off = seg_rows_offset(N);
@@ -265,6 +268,22 @@ static int fill_tensors(RowTensors& T, int n, float* const* grads, const int32_t
   return 0;
 }
 
+
+// ---- multi-GPU readiness on ONE GPU: a stand-in for the compute units a collective library's channel kernels hold while a
+// rank's frame runs beside them (W = 8: RCCL keeps 16-64 workgroups resident for the length of a collective).  n workgroups,
+// each claiming a whole CU's LDS (so they land on n distinct compute units), spin — a read of the stop word per ~2 us, nothing
+// else — until the host raises `stop` or `max_ticks` of the 100 MHz wall clock have passed (bounded: it cannot hang the device).
+__global__ __launch_bounds__(64) void cu_pin_kernel(const int32_t* stop, unsigned long long max_ticks, uint32_t* started) {
+  extern __shared__ char pin_lds[];
+  if (threadIdx.x == 0) {
+    pin_lds[0] = 1;  // (the allocation is what matters)
+    atomicAdd(started, 1u);
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && wall_clock64() - t0 < max_ticks)
+      __builtin_amdgcn_s_sleep(127);
+  }
+}
+
 }  // namespace riggs
 
 using namespace riggs;
@@ -328,6 +347,17 @@ int riggs_grad_rows_unpack(int32_t N, int32_t world, int32_t capacity, const voi
   unsigned long long* bits = backward_workspace ? (unsigned long long*)((char*)backward_workspace + ws_bits_offset(N)) : nullptr;
   hipLaunchKernelGGL(rows_unpack_kernel, dim3((N + 255) / 256), dim3(256), lds, s, N, world, capacity, seg_words,
                      (const uint32_t*)segments, T, status, bits);
+  RIGGS_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int riggs_debug_pin_cus(int32_t n_cus, const int32_t* stop_flag, uint32_t max_ms, uint32_t* started, riggs_stream stream_) {
+  RIGGS_REQUIRE(n_cus >= 1 && n_cus <= 1024 && stop_flag && started && max_ms >= 1 && max_ms <= 600000, "riggs_debug_pin_cus: bad arguments");
+  static unsigned long long attr_done = 0ull;
+  const int lds = 160 * 1024;
+  if (once_per_device(attr_done))
+    RIGGS_HIP_CHECK(hipFuncSetAttribute((const void*)cu_pin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipLaunchKernelGGL(cu_pin_kernel, dim3(n_cus), dim3(64), lds, (hipStream_t)stream_, stop_flag, (unsigned long long)max_ms * 100000ull, started);
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
 }

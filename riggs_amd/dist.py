@@ -141,7 +141,11 @@ class FlatGradAllReduce:
             L.check(L.lib().riggs_gate_flag(C.byref(self.frame_gate.struct()), self.tail.data_ptr(), L.stream_ptr()), "riggs_gate_flag")
 
     def validity_source(self):
-        """(tensor, word index, mask) of the validity slot, for the ``FrameGate`` of the optimizers that step on this bucket."""
+        """(tensor, word index, mask) of the validity slot, for the ``FrameGate`` of the optimizers that step on this bucket; None
+        when the bucket has no slot (``ShardedAdam`` moves the gradients into its own padded buffer without one): a FrameGate
+        skips sources that return None."""
+        if self.tail is None:
+            return None
         return (self.flat, self.numel, 0x7FFFFFFF)
 
     def register(self):
@@ -534,7 +538,7 @@ class SparseRowExchange:
         self._widths = (C.c_int32 * len(self.rows))(*self.widths)
         dev = self.rows[0].device
         self.comm = torch.cuda.Stream(device=dev) if self.cuda else None
-        self.status = torch.zeros(4, dtype=torch.int32, device=dev)  # sticky: see check()
+        self.status = torch.zeros(8, dtype=torch.int32, device=dev)  # [0..3] sticky: see check(); [4] this step's flag (the gate's word)
         self.pending = []
         self.need, self.calls, self.overflow_call = 0, 0, 0
         self.invalid_frame = False  # as of the last check(): some rank's frame was invalid in a step since the previous one
@@ -641,11 +645,11 @@ class SparseRowExchange:
         self._unpack(self)
 
     def status_source(self):
-        """For the ``FrameGate`` of the optimizers that consume the exchanged gradients: the exchange's sticky status word —
-        raised on EVERY rank in the same step when a segment overflowed or some rank's frame was invalid (nothing was
-        unpacked).  Gated on it, all replicas skip that step — and the following ones, until ``check()`` clears it — together:
-        they stay bit-identical without a ``resync()``."""
-        return (self.status, 1, 0xFFFFFFFF)
+        """For the ``FrameGate`` of the optimizers that consume the exchanged gradients: THIS step's status word (rewritten by
+        every unpack) — raised on EVERY rank in the same step when a segment overflowed or some rank's frame was invalid
+        (nothing was unpacked).  Gated on it, all replicas skip exactly that step together — they stay bit-identical without a
+        ``resync()`` — and go on with the next good one; the sticky words ``check()`` reads keep the report for the host."""
+        return (self.status, 4, 0xFFFFFFFF)
 
     def check(self) -> bool:
         """Reads and clears the sticky status (a device->host read).  False when ANY unpack since the previous check
@@ -654,7 +658,7 @@ class SparseRowExchange:
         ``overflow_call`` then holds which of the ``calls`` unpacks since the previous check failed first: if it is the one
         that has just run and no optimizer has stepped, ``dense_fallback()`` repairs the step; if optimizers have stepped on
         it (polling every k steps), the replicas have diverged: ``resync(parameters, optimizer)`` broadcasts rank 0's."""
-        need, bad, calls, first = (int(v) for v in self.status.tolist())
+        need, bad, calls, first = (int(v) for v in self.status.tolist()[:4])
         self.status.zero_()
         self.need, self.calls, self.overflow_call = need, calls, first if bad else 0
         self.invalid_frame = bool(bad & 2)

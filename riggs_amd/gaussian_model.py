@@ -411,6 +411,7 @@ class GaussianModel:
                 self.optimizer.state[new_param] = st
             g["params"][0] = new_param
             out[g["name"]] = new_param
+        self._drop_launch_plan()
         self._xyz, self._features_dc, self._features_rest = out["xyz"], out["f_dc"], out["f_rest"]
         self._opacity, self._scaling, self._rotation = out["opacity"], out["scaling"], out["rotation"]
         if self.fea_dim > 0:
@@ -424,7 +425,15 @@ class GaussianModel:
         self._ones_mask = None
         return out
 
+    def _drop_launch_plan(self):
+        """The optimizer's cached launch plan (riggs_amd.optim._Plan) holds the OLD parameter objects, their moments and the last
+        step's gradients: after surgery installed new tensors it would keep the old full-size ones alive through the whole next
+        forward / backward (it is rebuilt by the next step anyway)."""
+        if self.optimizer is not None and hasattr(self.optimizer, "_hip_plan"):
+            self.optimizer._hip_plan = None
+
     def replace_tensor_to_optimizer(self, tensor, name):  # :338-353
+        self._drop_launch_plan()
         out = {}
         for group in self.optimizer.param_groups:
             if group["name"] == name:

@@ -66,6 +66,24 @@ class GraphedFrame:
         if pn is not None:
             pn._status_owned = True
 
+    def release(self):
+        """Give the PoseMLP's sticky status word back to the eager callers' watcher (PoseMLP.watch reports and clears time-outs
+        again) and drop the captured graph: call it when this object is not replayed any more."""
+        pn = getattr(self.sw, "pose_net", None)
+        if pn is not None:
+            pn._status_owned = False
+        self.graph = None
+        if self.split:
+            self.graph_b = None
+
+    def __del__(self):
+        try:
+            pn = getattr(getattr(self, "sw", None), "pose_net", None)
+            if pn is not None:
+                pn._status_owned = False
+        except Exception:
+            pass
+
     # ---- the frame's "valid" words (include/riggs_hip.h: riggs_gate), for whoever consumes its gradients on the device
     def _pose_status(self):
         pn = getattr(self.sw, "pose_net", None)
@@ -478,11 +496,15 @@ class GraphedTrainStep(GraphedFrame):
         self.skipped_steps = self.gate.read_skipped()
         st = self._pose_status()
         if st is not None and int(st[0][st[1]].item()) != 0:
-            st[0][st[1]] = 0
+            # (cleared on the frame's own stream, in front of the re-run: its gated optimizer launches must see the word down)
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                st[0][st[1]] = 0
             self._rerun_layered()
         return super().check()
 
     def _rerun_layered(self):
+        before = L.get_option("pose_mlp_layered")  # (a permanent switch made by PoseMLP.watch() or by the user stays as it was)
         L.set_option("pose_mlp_layered", 1)
         try:
             with torch.cuda.stream(self.stream):
@@ -490,7 +512,7 @@ class GraphedTrainStep(GraphedFrame):
                 torch.cuda.current_stream().synchronize()
                 self.arena.resolve()
         finally:
-            L.set_option("pose_mlp_layered", 0)
+            L.set_option("pose_mlp_layered", before)
         for p, g in zip(self.params, self.grads):  # the graph's own gradient buffers stay the parameters' .grad
             p.grad = g
         self.mark_all_rows()  # (the eager backward went through the same workspace: the next replay rewrites every row)

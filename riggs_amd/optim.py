@@ -17,6 +17,7 @@ import torch
 from . import _lib as L
 
 _MAX = 32  # tensors per launch (ADAM_MAX_GROUPS in csrc/optim.hip)
+NONFINITE_WINDOWS_LIMIT = 4  # consecutive watch windows (16 steps each) with non-finite gradients before the eager guard raises
 
 
 class FusedAdam(torch.optim.Adam):
@@ -41,7 +42,9 @@ class FusedAdam(torch.optim.Adam):
         # the eager mode (host-side step counts: no gate): an element whose gradient is NaN / Inf keeps its parameter and moments
         # (riggs_adam_step_guarded) — a frame poisoned by a lost PoseMLP hand-off must not destroy an unmodified trainer's run —
         # and is counted on the device; the count is looked at without blocking (riggs_amd._lib.Watch) and reported as a
-        # RuntimeWarning.  ``skip_nonfinite=False``: torch.optim.Adam's behaviour (NaN propagates into the parameters).
+        # RuntimeWarning; non-finite gradients in NONFINITE_WINDOWS_LIMIT consecutive windows raise (a diverged run must not train
+        # on unnoticed).  A deviation from torch.optim.Adam, documented in INTEGRATION.md section 4; ``skip_nonfinite=False``:
+        # torch's behaviour (NaN propagates into the parameters).
         self.skip_nonfinite = bool(skip_nonfinite)
         self.nonfinite_seen = 0
 
@@ -198,13 +201,25 @@ def _step(optimizers):
         guard = _nonfinite_counter(first, plan.chunks[0].params[0].device)
     _launch(plan, cap, gate, guard)
     if guard is not None and not torch.cuda.is_current_stream_capturing():
-        n = first._nonfinite_watch.poll(guard, 0)
+        w = first._nonfinite_watch
+        before = w.n // w.period
+        n = w.poll(guard, 0)
         if n > first.nonfinite_seen:
             import warnings
             warnings.warn("FusedAdam: %d gradient elements were NaN or Inf since the last report and were NOT applied (their "
                           "parameters and moments are unchanged); skip_nonfinite=False restores torch.optim.Adam's behaviour"
                           % (n - first.nonfinite_seen), RuntimeWarning, stacklevel=3)
             first.nonfinite_seen = n
+            first._nonfinite_windows = getattr(first, "_nonfinite_windows", 0) + 1
+            first._nonfinite_last_window = w.n // w.period
+            # the guard exists for a TRANSIENT fault (one frame poisoned by a lost PoseMLP hand-off); gradients that keep
+            # coming back non-finite are a diverged run, which torch.optim.Adam would have shown as NaN parameters: say so loudly
+            if first._nonfinite_windows >= NONFINITE_WINDOWS_LIMIT:
+                raise RuntimeError("FusedAdam: non-finite gradients in %d consecutive watch windows (%d steps): the run has diverged "
+                                   "(the guard only rides out single poisoned frames)" % (first._nonfinite_windows,
+                                                                                        first._nonfinite_windows * w.period))
+        elif w.n // w.period != before and w.n // w.period > getattr(first, "_nonfinite_last_window", -10) + 2:
+            first._nonfinite_windows = 0  # (two clean windows in a row: the fault was transient)
 
 
 def _nonfinite_counter(opt, device):

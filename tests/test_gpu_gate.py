@@ -212,6 +212,13 @@ def test_a_gated_pack_marks_the_segment_and_every_rank_skips_the_unpack():
         assert torch.equal(a, b)
     src = ex.status_source()
     assert int(src[0][src[1]]) & 2                    # the word every rank's optimizer is gated on
+    # ... for THIS step only: a following good step lowers it again (its optimizers run), the sticky report stays for the host
+    ex.gathered.copy_(torch.cat([good.segment, good.segment]))
+    ex._unpack(ex)
+    torch.cuda.synchronize()
+    assert int(src[0][src[1]]) == 0 and int(ex.status[1]) & 2
+    for a, b in zip(local, grads):
+        a.copy_(b)
     assert not ex.check() and ex.invalid_frame and ex.need == int(good.segment[1])   # (the marker does not count as a need)
     assert ex.check() and not ex.invalid_frame        # reading cleared it
     # the dense path: the validity slot of the bucket travels with the all-reduce
@@ -303,3 +310,36 @@ def test_an_eager_trainer_survives_a_poisoned_frame_and_is_told():
     want = torch.ones(8) - 1e-2
     want[[0, 2, 7]] = 1.0
     assert torch.allclose(q.detach().cpu(), want, atol=1e-6) and int(o._nonfinite_count) == 3
+
+
+def test_eager_guard_raises_when_the_gradients_stay_nonfinite():
+    """The eager FusedAdam's guard rides out single poisoned frames; gradients that KEEP coming back NaN are a diverged run,
+    which torch.optim.Adam would have shown as NaN parameters: after a few consecutive watch windows it raises."""
+    import warnings
+
+    from riggs_amd import optim as O
+    q = torch.nn.Parameter(torch.ones(64, device="cuda"))
+    o = O.FusedAdam([q], lr=1e-2)
+    raised = None
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for it in range(40 * O.NONFINITE_WINDOWS_LIMIT):
+            q.grad = torch.full_like(q, float("nan"))
+            try:
+                o.step()
+            except RuntimeError as e:
+                raised = (it, str(e))
+                break
+            torch.cuda.synchronize()
+    assert raised is not None and "diverged" in raised[1] and raised[0] <= 16 * (O.NONFINITE_WINDOWS_LIMIT + 2)
+    assert torch.equal(q.detach().cpu(), torch.ones(64))
+    # a transient fault does not: one poisoned step, then healthy ones
+    p = torch.nn.Parameter(torch.ones(64, device="cuda"))
+    o = O.FusedAdam([p], lr=1e-3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for it in range(200):
+            p.grad = torch.full_like(p, float("nan") if it % 50 == 3 else 1.0)
+            o.step()
+            torch.cuda.synchronize()
+    assert torch.isfinite(p).all()
