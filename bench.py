@@ -592,6 +592,11 @@ def exchange_path_child(steps=200, scene="headline"):
     dist.all_reduce(probe)
     torch.cuda.synchronize()
     note("first collective done")
+    # what riggs_amd.dist selects on every rank of a world > 1 (its _spread_pose_mlp_chain): the one-launch PoseMLP chain spread
+    # over all XCDs — on one XCD it needs every compute unit of that XCD, which a collective's channel kernels take away (the
+    # pinned-CU soak below shows what then happens).  This child IS a data-parallel rank's step, so it runs that placement.
+    from riggs_amd import _lib as L_
+    L_.check(L_.lib().riggs_pose_mlp_set_placement(0), "riggs_pose_mlp_set_placement")
     w = WORKLOAD
     sc, cam, gm, sw = build_workload(0, dev, surface=(scene == "dense"))
     ordered, _ = exchange_order(gm, sw)
@@ -713,7 +718,7 @@ def pinned_cus_soak(gf_one_xcd, dev, gm, sw, cam, bg, params, gimg, counts=(16, 
     replay and the PoseMLP chain's lost hand-offs (sticky word, cleared between runs).  Returns {placement: {k: {...}}}."""
     from riggs_amd import _lib as L
     from riggs_amd.graph import GraphedFrame
-    n_rep = int(os.environ.get("RIGGS_BENCH_PIN_SOAK_REPLAYS", "10000")) if replays is None else replays
+    n_rep = int(os.environ.get("RIGGS_BENCH_PIN_SOAK_REPLAYS", "3000")) if replays is None else replays
     res = {"replays": n_rep, "what": "k workgroups holding a whole CU's LDS each spin on a second stream for the whole soak "
                                       "(riggs_debug_pin_cus); per k: ms per replay and PoseMLP hand-off time-outs (sticky word)"}
 
@@ -723,8 +728,11 @@ def pinned_cus_soak(gf_one_xcd, dev, gm, sw, cam, bg, params, gimg, counts=(16, 
             st[0][st[1]] = 0
         # (the stop word lives in DEVICE memory and is raised by a fill on a third stream: pinned host memory is not coherent
         # for a running kernel by default — HIP_HOST_COHERENT=0 — and a pinner that never sees its stop word runs to its time limit)
-        stop = torch.zeros(1, dtype=torch.int32, device=dev)
-        started = torch.zeros(1, dtype=torch.int32, device=dev)
+        # One pair of never-reused words per soak: the per-XCD L2s are not coherent with each other, and a pinner on another XCD
+        # that found the PREVIOUS soak's raised stop word still cached (the allocator hands the same block out again) left at
+        # once — seen as every other soak running unpinned (the probe below tells).
+        at = soak.count = getattr(soak, "count", -1) + 1
+        stop, started = flags[2 * at:2 * at + 1], flags[2 * at + 1:2 * at + 2]
         side, ctrl = torch.cuda.Stream(), torch.cuda.Stream()
         cur = torch.cuda.current_stream()
         cur.synchronize()
@@ -735,6 +743,15 @@ def pinned_cus_soak(gf_one_xcd, dev, gm, sw, cam, bg, params, gimg, counts=(16, 
             while int(started.item()) < k and time.perf_counter() - t_wait < 5.0:
                 time.sleep(0.001)
         resident = int(started.item()) if k else 0
+        # (are the pinned units really gone?  a chip-filling library GEMM, timed with events on this stream beside them)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.mm(probe_a, probe_a)
+        e0.record()
+        for _ in range(5):
+            torch.mm(probe_a, probe_a)
+        e1.record()
+        e1.synchronize()
+        probe_ms = e0.elapsed_time(e1) / 5
         for _ in range(20):
             gf.run()
         gf.stream.synchronize()
@@ -754,23 +771,36 @@ def pinned_cus_soak(gf_one_xcd, dev, gm, sw, cam, bg, params, gimg, counts=(16, 
         side.synchronize()
         if k and time.perf_counter() - t_stop > 1.0:
             raise RuntimeError("the CU pinner did not see its stop word")
-        return {"pinned_cus_resident": resident, "ms_per_step": round(dt, 4), "pose_handoff_timeouts_word": word, "arena_flags": flags}
+        return {"pinned_cus_resident": resident, "ms_per_step": round(dt, 4), "pose_handoff_timeouts_word": word, "arena_flags": flags,
+                "probe_gemm_ms": round(probe_ms, 4)}
+    probe_a = torch.randn(4096, 4096, device=dev)
+    flags = torch.zeros(256, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    # (the caller captured its graph under placement 0 — the chain spread over all XCDs: what every rank of a world > 1 runs)
     one = {}
     for k in (0,) + tuple(counts):
         one[str(k)] = soak(gf_one_xcd, k, n_rep if k else min(n_rep, 2000))
-    res["placement_1_one_xcd (this graph: frame + exchange)"] = one
-    L.check(L.lib().riggs_pose_mlp_set_placement(0), "riggs_pose_mlp_set_placement")
+    res["all_xcds_placement: frame + exchange in one graph"] = one
+    gf0 = GraphedFrame(gm, sw, cam, bg, params, sparse_grad_rows=False, tight_lists=_tight()).capture()
+    gf0.set_inputs(gimg=gimg)
+    spread = {}
+    for k in (0,) + tuple(counts):
+        spread[str(k)] = soak(gf0, k, n_rep if k else min(n_rep, 2000))
+    res["all_xcds_placement: plain frame"] = spread
+    del gf0
+    res["any_timeout_all_xcds_placement"] = bool(max(v["pose_handoff_timeouts_word"] or 0 for grp in (one, spread) for v in grp.values()))
+    # the contrast: the single-GPU default (chain on ONE XCD, 5-7 us faster on an idle device) with the same CUs taken away
+    L.check(L.lib().riggs_pose_mlp_set_placement(1), "riggs_pose_mlp_set_placement")
     try:
-        gf0 = GraphedFrame(gm, sw, cam, bg, params, sparse_grad_rows=False, tight_lists=_tight()).capture()
-        gf0.set_inputs(gimg=gimg)
-        spread = {}
-        for k in (0,) + tuple(counts):
-            spread[str(k)] = soak(gf0, k, n_rep if k else min(n_rep, 2000))
-        res["placement_0_all_xcds (plain frame; what world sizes > 1 run)"] = spread
+        gf1 = GraphedFrame(gm, sw, cam, bg, params, sparse_grad_rows=False, tight_lists=_tight()).capture()
+        gf1.set_inputs(gimg=gimg)
+        plain1 = {}
+        for k in (0, counts[0], counts[-1]):
+            plain1[str(k)] = soak(gf1, k, min(n_rep, 60))
+        res["one_xcd_placement (single-GPU default): plain frame"] = plain1
+        del gf1
     finally:
-        L.check(L.lib().riggs_pose_mlp_set_placement(1), "riggs_pose_mlp_set_placement")
-    worst = max(v["pose_handoff_timeouts_word"] or 0 for grp in res.values() if isinstance(grp, dict) for v in grp.values())
-    res["any_timeout"] = bool(worst)
+        L.check(L.lib().riggs_pose_mlp_set_placement(0), "riggs_pose_mlp_set_placement")
     return res
 
 
