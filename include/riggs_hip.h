@@ -688,10 +688,24 @@ int riggs_raster_set_trace_items(uint64_t n_items);
  * row-sparse backward runs inside a hipGraph on the rows riggs_mlp_live_rows compacted, their number known to the device only.
  * Opt-in on the host side (riggs_amd.mlp): the reference computes these MLPs in fp32.
  * ===================================================================== */
+/* Output epilogue of riggs_mlp_forward (host struct, may be NULL = the head's plain value), applied by the launch that holds the
+ * value anyway instead of elementwise launches behind it:
+ *   sigmoid:  out = sigmoid(head)  — WeightMLP (network_utils.py:107); the backward then multiplies the cotangent by
+ *             out (1 - out) (riggs_mlp_live_rows / riggs_mlp_cotangent: sigmoid_out);
+ *   res_base / res_mask / res_out:  res_out[n][c] = res_base[n][c] + out[n][c] * res_mask[n]  ((N, out_ch), (N) or NULL = 1,
+ *             (N, out_ch)) — DeformMLP: the template offsets join the blended translation in front of the motion mask
+ *             (skeleton_warp.py:152-161); the backward's counterpart is riggs_mlp_cotangent's g_rows / row_mask. */
+struct riggs_mlp_epilogue {
+  int32_t sigmoid;
+  int32_t reserved;
+  const float* res_base;
+  const float* res_mask;
+  float* res_out;
+};
 int riggs_mlp_forward(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip,
                       const void* const* weights_bf16, const float* const* biases, const void* w_out_bf16,
                       const float* b_out, const void* x_emb_bf16, void* acts_bf16, void* relu_masks, float* out,
-                      const int32_t* n_rows_dev, int32_t fp16, riggs_stream stream);
+                      const int32_t* n_rows_dev, const struct riggs_mlp_epilogue* epilogue, int32_t fp16, riggs_stream stream);
 /* Data-gradient pass of the same MLP: g_out (N, out_ch) = dL/d(output) -> dpre_bf16 (depth, N, 256) = dL/d(pre-activation)
  * of every hidden layer, the operand of the weight gradients  dW_l = dpre_l^T · input_l ,  db_l = sum_n dpre_l
  * (riggs_mlp_wgrad).  weights_t_bf16[l] (l >= 1): W_l[:, hidden part]^T (rows = the units of layer
@@ -711,10 +725,15 @@ int riggs_mlp_backward(int32_t N, int32_t out_ch, int32_t depth, int32_t skip, c
  * contributes zero to every data gradient, bias sum and weight product, so riggs_mlp_forward (activations of the live rows
  * only: the first forward then stores none), riggs_mlp_backward and riggs_mlp_wgrad on (x_live, g_live, n_rows_dev =
  * live_count) return the parameter gradients of the dense pass.  workspace: riggs_mlp_live_rows_workspace_bytes(N), 8-byte
- * aligned. */
+ * aligned.
+ * sigmoid_out (N, out_ch; may be NULL): the head's output went through riggs_mlp_epilogue.sigmoid — the cotangent of the head is
+ * g_out * s (1 - s), which is what is tested for a non-zero and gathered into g_live (no sigmoid_backward launch in front).
+ * scale (device float; may be NULL): receives the fp16 gradient scale of riggs_mlp_grad_scale over that cotangent — per-block
+ * maxima from the first launch, reduced by the second: no launch and no atomic of its own. */
 size_t riggs_mlp_live_rows_workspace_bytes(int32_t N);
-int riggs_mlp_live_rows(int32_t N, int32_t out_ch, int32_t in_ch, const float* g_out, const void* x_emb_bf16, void* workspace,
-                        int32_t* live_idx, int32_t* live_count, void* x_live_bf16, float* g_live, riggs_stream stream);
+int riggs_mlp_live_rows(int32_t N, int32_t out_ch, int32_t in_ch, const float* g_out, const float* sigmoid_out, const void* x_emb_bf16,
+                        void* workspace, int32_t* live_idx, int32_t* live_count, void* x_live_bf16, float* g_live, float* scale,
+                        riggs_stream stream);
 /* The g_scale of the fp16 format from the gradient itself: scale[0] = 2^floor(log2(1024 / max|g|)) (max|g| clamped at 1e-30), two
  * launches, no host synchronisation.  zero_word: a device u32 that is ZERO on entry (the caller clears it once) and zero again
  * behind the call. */
@@ -726,6 +745,14 @@ int riggs_mlp_grad_scale(int64_t n, const float* g, float* scale, uint32_t* zero
  * The same two launches; partials512: 512 floats of scratch.  The data-gradient and weight-gradient passes then read g_eff. */
 int riggs_mlp_l2_grad_scale(int64_t n, const float* g, const float* out, const float* coef, float* g_eff, float* scale,
                             uint32_t* zero_word, float* partials512, float* mean_sq, riggs_stream stream);
+/* The general form (the same two launches): the cotangent the data-gradient pass reads, for an (N, out_ch) head,
+ *   g_eff = (g + g_rows * row_mask[row]) * [s (1 - s)] + l2_coef[0] * l2_out
+ * g, g_rows (N, out_ch): at least one; row_mask (N; NULL = 1; needs g_rows): the motion mask that multiplied the head's output on
+ * its way into res_out (riggs_mlp_epilogue); sigmoid_out (N, out_ch; NULL = no factor): the head's sigmoid-ed output;
+ * l2_out / l2_coef (both or neither): the L2 term above.  scale / zero_word / partials512 / mean_sq as above. */
+int riggs_mlp_cotangent(int32_t N, int32_t out_ch, const float* g, const float* g_rows, const float* row_mask,
+                        const float* sigmoid_out, const float* l2_out, const float* l2_coef, float* g_eff, float* scale,
+                        uint32_t* zero_word, float* partials512, float* mean_sq, riggs_stream stream);
 /* db_partial: (ceil(N / riggs_mlp_rows_per_workgroup()), depth, 256) fp32 — per-workgroup column sums of dpre; the bias
  * gradients are their sum over the first axis.  May be NULL when riggs_mlp_wgrad follows (it sums the columns itself). */
 int32_t riggs_mlp_rows_per_workgroup(void);

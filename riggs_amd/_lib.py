@@ -57,6 +57,12 @@ class FrameGrads(C.Structure):
         "dL_dlocal_rot", "dL_dglobal_trans", "pose_workspace", "pose_flat_grads")]
 
 
+class MlpEpilogue(C.Structure):
+    """struct riggs_mlp_epilogue (include/riggs_hip.h): the output epilogue of riggs_mlp_forward."""
+    _fields_ = [("sigmoid", C.c_int32), ("reserved", C.c_int32), ("res_base", C.c_void_p), ("res_mask", C.c_void_p),
+                ("res_out", C.c_void_p)]
+
+
 class GateStruct(C.Structure):
     """struct riggs_gate."""
     _fields_ = [("n", C.c_int32), ("reserved", C.c_int32), ("word", C.c_void_p * 4), ("mask", C.c_uint32 * 4)]
@@ -191,13 +197,14 @@ _SIGS = {
     "riggs_skeleton_projection_backward": (C.c_int, [C.c_int32] * 3 + [_P] * 4 + [C.c_float] * 4 + [_P] * 8),
     "riggs_raster_set_trace": (C.c_int, [_P]),
     "riggs_raster_set_trace_items": (C.c_int, [C.c_uint64]),
-    "riggs_mlp_forward": (C.c_int, [C.c_int32] * 5 + [_P] * 9 + [C.c_int32, _P]),
+    "riggs_mlp_forward": (C.c_int, [C.c_int32] * 5 + [_P] * 10 + [C.c_int32, _P]),
     "riggs_mlp_backward": (C.c_int, [C.c_int32] * 4 + [_P] * 8 + [C.c_int32, _P]),
     "riggs_mlp_live_rows_workspace_bytes": (C.c_size_t, [C.c_int32]),
-    "riggs_mlp_live_rows": (C.c_int, [C.c_int32] * 3 + [_P] * 8),
+    "riggs_mlp_live_rows": (C.c_int, [C.c_int32] * 3 + [_P] * 10),
     "riggs_mlp_rows_per_workgroup": (C.c_int32, []),
     "riggs_mlp_grad_scale": (C.c_int, [C.c_int64, _P, _P, _P, _P]),
     "riggs_mlp_l2_grad_scale": (C.c_int, [C.c_int64] + [_P] * 9),
+    "riggs_mlp_cotangent": (C.c_int, [C.c_int32] * 2 + [_P] * 12),
     "riggs_mlp_wgrad_workspace_bytes": (C.c_size_t, [C.c_int32] * 4),
     "riggs_mlp_wgrad": (C.c_int, [C.c_int32] * 5 + [_P] * 6 + [C.c_size_t] + [_P] * 5 + [C.c_int32, _P]),
     "riggs_mlp_embed": (C.c_int, [C.c_int32] * 3 + [_P] * 3 + [C.c_int32, _P]),

@@ -89,6 +89,7 @@ struct LbsArgs {
   // forward with the kinematic chain inside (riggs_lbs_forward_fk): the pose, and where workgroup 0 leaves the chain's results
   const float* local_rot;
   float *fk_transforms, *fk_node_rot, *fk_d_nodes;
+  int mod_lds;  // forward: weight_mod is staged through LDS (the launch reserved the tile)
 };
 
 // (transforms / node_rot: global memory, or the LDS arrays of a kinematic chain that this workgroup ran itself)
@@ -178,6 +179,24 @@ __global__ __launch_bounds__(256) void lbs_forward_kernel(LbsArgs a) {
     const int nn = min(on[p] ? n : n0, a.N - 1);
     px[p] = a.x[3 * nn]; py[p] = a.x[3 * nn + 1]; pz[p] = a.x[3 * nn + 2];
   }
+  // weight_mod (WeightMLP head on): a thread reads its own row of B floats, bone by bone — as global loads that is B
+  // instructions of 64 addresses 4 B bytes apart each (46 lines per instruction, the L1 thrashes: +20 us on this kernel).  The
+  // wave's 64 rows are one contiguous run: copied once, coalesced, into a wave-private LDS tile (row stride odd: a column
+  // read is conflict-free), where the bone loop reads them.  (a.mod_lds: the launch reserved 256 (B | 1) floats)
+  extern __shared__ float s_mod_dyn[];
+  const int BP = (a.J - 1) | 1;
+  float* s_mod = s_mod_dyn + (threadIdx.x >> 6) * 64 * BP;
+  if (PTS == 1 && a.mod_lds) {
+    const int Bm = a.J - 1, lane_ = threadIdx.x & 63;
+    const int ng = blockIdx.x * 256 + (threadIdx.x & ~63);
+    const int n_el = max(0, min(64, a.N - ng)) * Bm;
+    const float* run = a.weight_mod + (size_t)ng * Bm;
+    const float invB = 1.0f / (float)Bm;
+    for (int e = lane_; e < n_el; e += 64) {
+      const int r = (int)(((float)e + 0.5f) * invB);
+      s_mod[r * BP + (e - r * Bm)] = run[e];
+    }
+  }
   if constexpr (FK) {
     __shared__ float G[MAX_J][12];
     __shared__ float Q[MAX_J][4];
@@ -239,7 +258,8 @@ __global__ __launch_bounds__(256) void lbs_forward_kernel(LbsArgs a) {
     for (int p = 0; p < PTS; p++) {
       const float d2 = TOPK ? bone_d2(b, px[p], py[p], pz[p]) : bone_d2_fast(b, px[p], py[p], pz[p]);
       float u = fast_exp(-d2 * b.inv2r2);                // skeleton_warp.py:66
-      if (a.weight_mod) u *= a.weight_mod[(size_t)(on[p] ? n0 + 256 * p : n0) * B + k];  // :68-69
+      if (a.weight_mod) u *= (PTS == 1 && a.mod_lds) ? s_mod[(threadIdx.x & 63) * BP + k]
+                                                     : a.weight_mod[(size_t)(on[p] ? n0 + 256 * p : n0) * B + k];  // :68-69
       const float v = u + 1e-7f;                          // :71
       sum[p] += v;
 #pragma unroll
@@ -461,11 +481,30 @@ __global__ __launch_bounds__(256) void lbs_backward_bonelane_kernel(LbsArgs a) {
       const int n = wave_first + 64 * (gb + g4) + lane;
       const bool touched = (gq[g4][0] != 0.f) || (gq[g4][1] != 0.f) || (gq[g4][2] != 0.f) ||
                            (hq[g4].x != 0.f) || (hq[g4].y != 0.f) || (hq[g4].z != 0.f) || (hq[g4].w != 0.f);
-      if (n < wave_end && !touched) {
-        if (a.dmask) a.dmask[n] = 0.f;
-        if constexpr (MOD) for (int k = 0; k < B; k++) a.dmod[(size_t)n * B + k] = 0.f;
-      }
+      if (n < wave_end && !touched && a.dmask) a.dmask[n] = 0.f;
       const uint64_t tm = __builtin_amdgcn_ballot_w64(touched);
+      if constexpr (MOD) {
+        // the zeros of dL/dweight_mod for the group's untouched rows: the group's 64 rows are ONE contiguous run of 64 B floats —
+        // 16-byte pieces, consecutive lanes = consecutive addresses (a row of B floats per lane was B stores of 64 scattered
+        // dwords each: 46 partially written lines per instruction, +29 us on this kernel with the WeightMLP on); a piece that
+        // overlaps a touched row (the walk below writes those) is written element by element
+        const int ng = wave_first + 64 * (gb + g4);
+        const int n_el = max(0, min(64, wave_end - ng)) * B;
+        float* run = a.dmod + (size_t)ng * B;
+        const float invB = 1.0f / (float)B;
+        for (int p4 = lane * 4; p4 < n_el; p4 += 256) {
+          const int r0 = (int)(((float)p4 + 0.5f) * invB), r1 = (int)(((float)min(p4 + 3, n_el - 1) + 0.5f) * invB);
+          if (p4 + 3 < n_el && !((tm >> r0) & 1ull) && !((tm >> r1) & 1ull)) {
+            *reinterpret_cast<float4*>(run + p4) = make_float4(0.f, 0.f, 0.f, 0.f);
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              const int e = p4 + q;
+              if (e < n_el && !((tm >> (int)(((float)e + 0.5f) * invB)) & 1ull)) run[e] = 0.f;
+            }
+          }
+        }
+      }
       if (touched) s_list[wave][n_work + __builtin_popcountll(tm & ((1ull << lane) - 1ull))] = (unsigned short)(64 * (gb + g4) + lane);
       n_work += __builtin_popcountll(tm);
     }
@@ -656,6 +695,11 @@ static int fill_lbs(LbsArgs& a, int32_t N, int32_t J, int32_t K, const float* x,
 static bool lbs_two_per_thread(int N, int J) { return N >= LBS_PTS2_MIN_N && J >= LBS_PTS2_MIN_J; }
 
 static unsigned lbs_grid(int N, int pts) { return (unsigned)((N + 256 * pts - 1) / (256 * pts)); }
+// the forward's weight_mod tile (one Gaussian per thread, up to 47 bones: 48 KB; beyond, the rows are read from global memory)
+static size_t lbs_mod_lds(LbsArgs& a, int pts) {
+  a.mod_lds = (a.weight_mod && pts == 1 && a.J - 1 <= 47) ? 1 : 0;
+  return a.mod_lds ? (size_t)256 * ((a.J - 1) | 1) * sizeof(float) : 0;
+}
 
 int riggs_lbs_forward(int32_t N, int32_t J, int32_t K, const float* x, const float* joints, const int32_t* parents,
                       const float* node_radius_log, const float* transforms, const float* node_rot,
@@ -672,7 +716,7 @@ int riggs_lbs_forward(int32_t N, int32_t J, int32_t K, const float* x, const flo
     ProfScope ps(PROF_LBS_FWD, (hipStream_t)stream);
     if (a.K > 0) hipLaunchKernelGGL((lbs_forward_kernel<true, false, 1>), dim3(lbs_grid(N, 1)), dim3(256), 0, (hipStream_t)stream, a);
     else if (lbs_two_per_thread(N, J)) hipLaunchKernelGGL((lbs_forward_kernel<false, false, 2>), dim3(lbs_grid(N, 2)), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((lbs_forward_kernel<false, false, 1>), dim3(lbs_grid(N, 1)), dim3(256), 0, (hipStream_t)stream, a);
+    else { const size_t lds = lbs_mod_lds(a, 1); hipLaunchKernelGGL((lbs_forward_kernel<false, false, 1>), dim3(lbs_grid(N, 1)), dim3(256), lds, (hipStream_t)stream, a); }
   }
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
@@ -695,7 +739,7 @@ int riggs_lbs_forward_fk(int32_t N, int32_t J, int32_t K, const float* x, const 
     ProfScope ps(PROF_LBS_FWD, (hipStream_t)stream);
     if (a.K > 0) hipLaunchKernelGGL((lbs_forward_kernel<true, true, 1>), dim3(lbs_grid(N, 1)), dim3(256), 0, (hipStream_t)stream, a);
     else if (lbs_two_per_thread(N, J)) hipLaunchKernelGGL((lbs_forward_kernel<false, true, 2>), dim3(lbs_grid(N, 2)), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((lbs_forward_kernel<false, true, 1>), dim3(lbs_grid(N, 1)), dim3(256), 0, (hipStream_t)stream, a);
+    else { const size_t lds = lbs_mod_lds(a, 1); hipLaunchKernelGGL((lbs_forward_kernel<false, true, 1>), dim3(lbs_grid(N, 1)), dim3(256), lds, (hipStream_t)stream, a); }
   }
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;

@@ -65,6 +65,13 @@ struct MlpDesc {
   const unsigned short* Wout;     // the head, fragment-major: 1 tile (outputs >= out_ch are zero) x 16 steps x 512
   const float* bout;              // [out_ch]
   const int32_t* n_dev;           // NULL, or a device word: only rows < min(*n_dev, N) exist (N stays the buffers' row stride)
+  // output epilogue (riggs_mlp_epilogue): the head's value through a sigmoid (WeightMLP: network_utils.py:107) and / or joined
+  // with a residual — res_out = res_base + out * res_mask[row] (DeformMLP: skeleton_warp.py:152-161, the template offsets enter
+  // the blended position in front of the motion mask) — in the launch that has the value in its hands anyway
+  int out_sigmoid;
+  const float* res_base;
+  const float* res_mask;
+  float* res_out;
 };
 
 __device__ __forceinline__ int mlp_k(const MlpDesc& d, int l) { return l == 0 ? d.in_pad : (l == d.skip + 1 ? d.in_pad + MLP_W : MLP_W); }
@@ -345,7 +352,11 @@ __global__ __launch_bounds__(256, GT == 2 ? 3 : 2) void mlp_forward_kernel(MlpDe
   const int n_rows = min(ROWS, rows - row0);
   for (int e = tid; e < n_rows * d.out_ch; e += 256) {
     const int r = e / d.out_ch, c = e - r * d.out_ch;
-    out[(size_t)row0 * d.out_ch + e] = s_out[r * 33 + c] + d.bout[c];
+    float v = s_out[r * 33 + c] + d.bout[c];
+    if (d.out_sigmoid) v = 1.0f / (1.0f + expf(-v));
+    const size_t o = (size_t)row0 * d.out_ch + e;
+    out[o] = v;
+    if (d.res_out) d.res_out[o] = d.res_base[o] + (d.res_mask ? v * d.res_mask[row0 + r] : v);
   }
 }
 
@@ -507,18 +518,31 @@ __global__ __launch_bounds__(256) void mlp_embed_kernel(int N, int n_rows, int m
 // product, so the backward runs on the COMPACTED live rows: their embedding rows and cotangent rows are gathered here (ascending
 // order, no atomics: the result does not depend on scheduling), the forward is repeated for them alone (the first forward then
 // stores no activations at all) and the data-gradient / weight-gradient launches read the live count from the device.
-// Launch 1: per 256-row block the live flags (as four 64-bit ballots) and their number.
+// Launch 1: per 256-row block the live flags (as four 64-bit ballots), their number and max|cotangent| of the block.
+// sig (optional): the head's output went through a sigmoid (MlpDesc::out_sigmoid) — the cotangent of the pre-activation is
+// g * s (1 - s), formed here and again in the gather (what was a sigmoid_backward launch over the whole tensor in front).
+__device__ __forceinline__ float mlp_sig_cot(float g, float sg) { return g * (sg * (1.0f - sg)); }
 __global__ __launch_bounds__(256) void mlp_live_flags_kernel(int N, int out_ch, const float* __restrict__ g_out,
+                                                             const float* __restrict__ sig,
                                                              unsigned long long* __restrict__ bits /* [blocks][4] */,
-                                                             int32_t* __restrict__ counts /* [blocks] */) {
+                                                             int32_t* __restrict__ counts /* [blocks] */,
+                                                             uint32_t* __restrict__ bmax /* [blocks] or NULL */) {
   __shared__ int s_live[256];
+  __shared__ uint32_t s_m[4];
   const int tid = threadIdx.x, row0 = blockIdx.x * 256;
   s_live[tid] = 0;
   __syncthreads();
   const int n_rows = min(256, N - row0);
   const float* g = g_out + (size_t)row0 * out_ch;
-  for (int e = tid; e < n_rows * out_ch; e += 256)        // coalesced over the block's contiguous run
-    if (g[e] != 0.0f) s_live[e / out_ch] = 1;             // (benign race: every writer stores 1; NaN != 0 counts as live)
+  const float* sg = sig ? sig + (size_t)row0 * out_ch : nullptr;
+  uint32_t m = 0u;
+  for (int e = tid; e < n_rows * out_ch; e += 256) {      // coalesced over the block's contiguous run
+    const float v = sg ? mlp_sig_cot(g[e], sg[e]) : g[e];
+    m = max(m, __float_as_uint(v) & 0x7FFFFFFFu);
+    if (v != 0.0f) s_live[e / out_ch] = 1;                // (benign race: every writer stores 1; NaN != 0 counts as live)
+  }
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+  if ((tid & 63) == 0) s_m[tid >> 6] = m;
   __syncthreads();
   const unsigned long long b = __ballot(s_live[tid] != 0);
   __shared__ int s_cnt[4];
@@ -527,25 +551,43 @@ __global__ __launch_bounds__(256) void mlp_live_flags_kernel(int N, int out_ch, 
     s_cnt[tid >> 6] = __popcll(b);
   }
   __syncthreads();
-  if (tid == 0) counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+  if (tid == 0) {
+    counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (bmax) bmax[blockIdx.x] = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
+  }
 }
-// Launch 2: block b sums the counts in front of it (<= a few thousand words), ranks its live rows and copies them.
+// Launch 2: block b sums the counts in front of it (<= a few thousand words), ranks its live rows and copies them; with `scale`
+// every block also takes the maximum over ALL blocks' maxima (the same few thousand words) — block 0 turns it into the fp16
+// gradient scale of riggs_mlp_grad_scale, which then costs no launch of its own (and no atomic).
 __global__ __launch_bounds__(256) void mlp_live_gather_kernel(int N, int out_ch, int in_pad, const float* __restrict__ g_out,
+                                                              const float* __restrict__ sig,
                                                               const unsigned short* __restrict__ xb,
                                                               const unsigned long long* __restrict__ bits,
-                                                              const int32_t* __restrict__ counts, int32_t* __restrict__ idx,
+                                                              const int32_t* __restrict__ counts, const uint32_t* __restrict__ bmax,
+                                                              int32_t* __restrict__ idx,
                                                               int32_t* __restrict__ count, unsigned short* __restrict__ x_live,
-                                                              float* __restrict__ g_live) {
+                                                              float* __restrict__ g_live, float* __restrict__ scale) {
   __shared__ int s_red[4];
+  __shared__ uint32_t s_mx[4];
   __shared__ int s_rows[256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row0 = blockIdx.x * 256;
   int part = 0;
   for (int i = tid; i < (int)blockIdx.x; i += 256) part += counts[i];
   for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
   if (lane == 0) s_red[wave] = part;
+  if (scale && blockIdx.x == 0) {
+    uint32_t m = 0u;
+    for (int i = tid; i < (int)gridDim.x; i += 256) m = max(m, bmax[i]);
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+    if (lane == 0) s_mx[wave] = m;
+  }
   const unsigned long long b0 = bits[(size_t)blockIdx.x * 4], b1 = bits[(size_t)blockIdx.x * 4 + 1],
                            b2 = bits[(size_t)blockIdx.x * 4 + 2], b3 = bits[(size_t)blockIdx.x * 4 + 3];
   __syncthreads();
+  if (scale && blockIdx.x == 0 && tid == 0) {
+    const float amax = fmaxf(__uint_as_float(max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3]))), 1e-30f);
+    scale[0] = exp2f(floorf(log2f(1024.0f / amax)));
+  }
   const int base = s_red[0] + s_red[1] + s_red[2] + s_red[3];
   const int c0 = __popcll(b0), c1 = __popcll(b1), c2 = __popcll(b2), c3 = __popcll(b3);
   const unsigned long long mine = wave == 0 ? b0 : (wave == 1 ? b1 : (wave == 2 ? b2 : b3));
@@ -565,7 +607,8 @@ __global__ __launch_bounds__(256) void mlp_live_gather_kernel(int N, int out_ch,
   }
   for (int e = tid; e < n_live * out_ch; e += 256) {
     const int r = e / out_ch, c = e - r * out_ch;
-    g_live[(size_t)(base + r) * out_ch + c] = g_out[(size_t)s_rows[r] * out_ch + c];
+    const size_t src = (size_t)s_rows[r] * out_ch + c;
+    g_live[(size_t)(base + r) * out_ch + c] = sig ? mlp_sig_cot(g_out[src], sig[src]) : g_out[src];
   }
   if (blockIdx.x == gridDim.x - 1) {  // the last block knows the total: it publishes it and zero-fills the rows up to the next
     const int total = base + n_live;  // multiple of 128 (the forward kernel's workgroups read whole 128-row tiles of x_live)
@@ -665,8 +708,16 @@ int riggs_mlp_layout_probe(float* out32x32, riggs_stream stream) {
 #define MLP_RT 4
 
 static int mlp_fill(MlpDesc& d, int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip, const void* const* Wp,
-                    const float* const* bias, const void* Wout, const float* bout, const int32_t* n_dev) {
+                    const float* const* bias, const void* Wout, const float* bout, const int32_t* n_dev,
+                    const riggs_mlp_epilogue* epi = nullptr) {
   d.n_dev = n_dev;
+  d.out_sigmoid = 0; d.res_base = nullptr; d.res_mask = nullptr; d.res_out = nullptr;
+  if (epi) {
+    d.out_sigmoid = epi->sigmoid ? 1 : 0;
+    d.res_base = epi->res_base; d.res_mask = epi->res_mask; d.res_out = epi->res_out;
+    RIGGS_REQUIRE((epi->res_out == nullptr) == (epi->res_base == nullptr), "riggs_mlp_epilogue: res_base and res_out come together");
+    RIGGS_REQUIRE(epi->res_mask == nullptr || epi->res_out != nullptr, "riggs_mlp_epilogue: res_mask without res_out");
+  }
   RIGGS_REQUIRE(N >= 0 && depth >= 1 && depth <= 10, "MLP depth out of range");
   RIGGS_REQUIRE(in_ch >= 1 && in_ch <= MLP_MAX_IN, "MLP input width must be <= 128");
   RIGGS_REQUIRE(out_ch >= 1 && out_ch <= 32, "MLP output width must be <= 32");
@@ -680,9 +731,10 @@ static int mlp_fill(MlpDesc& d, int32_t N, int32_t in_ch, int32_t out_ch, int32_
 
 int riggs_mlp_forward(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip, const void* const* weights_bf16,
                       const float* const* biases, const void* w_out_bf16, const float* b_out, const void* x_emb_bf16,
-                      void* acts_bf16, void* relu_masks, float* out, const int32_t* n_rows_dev, int32_t fp16, riggs_stream stream) {
+                      void* acts_bf16, void* relu_masks, float* out, const int32_t* n_rows_dev,
+                      const struct riggs_mlp_epilogue* epilogue, int32_t fp16, riggs_stream stream) {
   MlpDesc d;
-  int rc = mlp_fill(d, N, in_ch, out_ch, depth, skip, weights_bf16, biases, w_out_bf16, b_out, n_rows_dev);
+  int rc = mlp_fill(d, N, in_ch, out_ch, depth, skip, weights_bf16, biases, w_out_bf16, b_out, n_rows_dev, epilogue);
   if (rc) return rc;
   if (N == 0) return 0;
   RIGGS_REQUIRE(x_emb_bf16 && out, "MLP input / output pointers");
@@ -725,24 +777,31 @@ int riggs_mlp_backward(int32_t N, int32_t out_ch, int32_t depth, int32_t skip, c
 
 size_t riggs_mlp_live_rows_workspace_bytes(int32_t N) {
   const size_t blocks = N > 0 ? ((size_t)N + 255) / 256 : 0;
-  return blocks * (4 * sizeof(unsigned long long) + sizeof(int32_t)) + 64;
+  return blocks * (4 * sizeof(unsigned long long) + 2 * sizeof(int32_t)) + 64;
 }
 
-int riggs_mlp_live_rows(int32_t N, int32_t out_ch, int32_t in_ch, const float* g_out, const void* x_emb_bf16, void* workspace,
-                        int32_t* live_idx, int32_t* live_count, void* x_live_bf16, float* g_live, riggs_stream stream) {
+int riggs_mlp_live_rows(int32_t N, int32_t out_ch, int32_t in_ch, const float* g_out, const float* sigmoid_out, const void* x_emb_bf16,
+                        void* workspace, int32_t* live_idx, int32_t* live_count, void* x_live_bf16, float* g_live, float* scale,
+                        riggs_stream stream) {
   RIGGS_REQUIRE(N >= 0 && out_ch >= 1 && out_ch <= 32 && in_ch >= 1 && in_ch <= MLP_MAX_IN, "riggs_mlp_live_rows: shape out of range");
   RIGGS_REQUIRE(live_count, "riggs_mlp_live_rows: live_count");
   hipStream_t s = (hipStream_t)stream;
-  if (N == 0) { RIGGS_HIP_CHECK(hipMemsetAsync(live_count, 0, sizeof(int32_t), s)); return 0; }
+  if (N == 0) {
+    RIGGS_HIP_CHECK(hipMemsetAsync(live_count, 0, sizeof(int32_t), s));
+    if (scale) { static const float one = 1.0f; RIGGS_HIP_CHECK(hipMemcpyAsync(scale, &one, sizeof(float), hipMemcpyHostToDevice, s)); }
+    return 0;
+  }
   RIGGS_REQUIRE(g_out && x_emb_bf16 && workspace && live_idx && x_live_bf16 && g_live, "riggs_mlp_live_rows: pointers");
   RIGGS_REQUIRE(((uintptr_t)workspace & 7) == 0, "riggs_mlp_live_rows: the workspace must be 8-byte aligned");
   const int blocks = (N + 255) / 256;
   unsigned long long* bits = (unsigned long long*)workspace;
   int32_t* counts = (int32_t*)(bits + (size_t)blocks * 4);
-  hipLaunchKernelGGL(mlp_live_flags_kernel, dim3(blocks), dim3(256), 0, s, N, out_ch, g_out, bits, counts);
+  uint32_t* bmax = (uint32_t*)(counts + blocks);
+  hipLaunchKernelGGL(mlp_live_flags_kernel, dim3(blocks), dim3(256), 0, s, N, out_ch, g_out, sigmoid_out, bits, counts, scale ? bmax : nullptr);
   RIGGS_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(mlp_live_gather_kernel, dim3(blocks), dim3(256), 0, s, N, out_ch, (in_ch + 63) & ~63, g_out,
-                     (const unsigned short*)x_emb_bf16, bits, counts, live_idx, live_count, (unsigned short*)x_live_bf16, g_live);
+  hipLaunchKernelGGL(mlp_live_gather_kernel, dim3(blocks), dim3(256), 0, s, N, out_ch, (in_ch + 63) & ~63, g_out, sigmoid_out,
+                     (const unsigned short*)x_emb_bf16, bits, counts, bmax, live_idx, live_count, (unsigned short*)x_live_bf16, g_live,
+                     scale);
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
 }

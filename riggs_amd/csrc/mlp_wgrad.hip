@@ -297,28 +297,52 @@ __global__ void mlp_scale_kernel(uint32_t* __restrict__ word, float* __restrict_
 // coef = 2 lambda / (3 N) a device scalar — written by the launch that takes max|g| for the fp16 gradient scale anyway, so the
 // term costs no launch of its own — and the launch that turns the maximum into the scale also finishes  mean(out^2)  (the value
 // the reference logs) from the per-workgroup partial sums, in a fixed order.
-__global__ __launch_bounds__(256) void mlp_l2_amax_kernel(int64_t n, const float* __restrict__ g, const float* __restrict__ out,
-                                                          const float* __restrict__ coef, float* __restrict__ g_eff,
-                                                          uint32_t* __restrict__ word, float* __restrict__ partials) {
-  const float c = coef[0];
+// (generalised in round 6 — riggs_mlp_cotangent: the cotangent may also be the SUM of a direct term and a per-row-masked one,
+//   g_eff = (g + g_rows * row_mask[row]) * [s (1 - s)] + coef * out ,
+// every piece optional: g_rows * row_mask is what reaches the template offsets through  d_xyz = blend + offsets * motion_mask
+// (skeleton_warp.py:152-161; was a torch mul in front), s (1 - s) the sigmoid folded into the WeightMLP's head (was a
+// sigmoid_backward launch).)
+struct MlpCot {
+  int64_t n;
+  int out_ch;
+  const float *g, *g_rows, *row_mask, *sig, *out, *coef;
+  float* g_eff;
+};
+__device__ __forceinline__ float mlp_cot_value(const MlpCot& c, int64_t i, float coef) {
+  float v = c.g ? c.g[i] : 0.f;
+  if (c.g_rows) v += c.row_mask ? c.g_rows[i] * c.row_mask[(uint32_t)i / (uint32_t)c.out_ch] : c.g_rows[i];
+  if (c.sig) { const float sg = c.sig[i]; v *= sg * (1.0f - sg); }
+  if (c.out) v += coef * c.out[i];
+  return v;
+}
+__global__ __launch_bounds__(256) void mlp_l2_amax_kernel(MlpCot c, uint32_t* __restrict__ word, float* __restrict__ partials) {
+  const float coef = c.coef ? c.coef[0] : 0.f;
   uint32_t m = 0u;
   float ss = 0.f;
-  const int64_t n4 = n >> 2;
+  const int64_t n4 = c.n >> 2;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    const float4 gv = reinterpret_cast<const float4*>(g)[i], ov = reinterpret_cast<const float4*>(out)[i];
     float4 e;
-    e.x = gv.x + c * ov.x; e.y = gv.y + c * ov.y; e.z = gv.z + c * ov.z; e.w = gv.w + c * ov.w;
-    reinterpret_cast<float4*>(g_eff)[i] = e;
+    if (!c.g_rows && !c.sig && c.g && c.out) {  // the plain L2 form: whole vectors
+      const float4 gv = reinterpret_cast<const float4*>(c.g)[i], ov = reinterpret_cast<const float4*>(c.out)[i];
+      e.x = gv.x + coef * ov.x; e.y = gv.y + coef * ov.y; e.z = gv.z + coef * ov.z; e.w = gv.w + coef * ov.w;
+    } else {
+      e.x = mlp_cot_value(c, 4 * i, coef); e.y = mlp_cot_value(c, 4 * i + 1, coef);
+      e.z = mlp_cot_value(c, 4 * i + 2, coef); e.w = mlp_cot_value(c, 4 * i + 3, coef);
+    }
+    reinterpret_cast<float4*>(c.g_eff)[i] = e;
     m = max(max(m, __float_as_uint(e.x) & 0x7FFFFFFFu), max(max(__float_as_uint(e.y) & 0x7FFFFFFFu, __float_as_uint(e.z) & 0x7FFFFFFFu),
                                                              __float_as_uint(e.w) & 0x7FFFFFFFu));
-    ss += (ov.x * ov.x + ov.y * ov.y) + (ov.z * ov.z + ov.w * ov.w);
+    if (c.out) {
+      const float4 ov = reinterpret_cast<const float4*>(c.out)[i];
+      ss += (ov.x * ov.x + ov.y * ov.y) + (ov.z * ov.z + ov.w * ov.w);
+    }
   }
-  if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) {
+  if (blockIdx.x == 0 && threadIdx.x < (int)(c.n & 3)) {
     const int64_t i = (n4 << 2) + threadIdx.x;
-    const float e = g[i] + c * out[i];
-    g_eff[i] = e;
+    const float e = mlp_cot_value(c, i, coef);
+    c.g_eff[i] = e;
     m = max(m, __float_as_uint(e) & 0x7FFFFFFFu);
-    ss += out[i] * out[i];
+    if (c.out) ss += c.out[i] * c.out[i];
   }
   for (int o = 32; o > 0; o >>= 1) { m = max(m, (uint32_t)__shfl_xor((int)m, o)); ss += __shfl_xor(ss, o); }
   __shared__ uint32_t s_m[4];
@@ -477,6 +501,33 @@ int riggs_mlp_grad_scale(int64_t n, const float* g, float* scale, uint32_t* zero
 }
 
 
+int riggs_mlp_cotangent(int32_t N, int32_t out_ch, const float* g, const float* g_rows, const float* row_mask, const float* sigmoid_out,
+                        const float* l2_out, const float* l2_coef, float* g_eff, float* scale, uint32_t* zero_word, float* partials512,
+                        float* mean_sq, riggs_stream stream) {
+  RIGGS_REQUIRE(N >= 0 && out_ch >= 1 && out_ch <= 32 && scale && zero_word && partials512, "riggs_mlp_cotangent: bad arguments");
+  RIGGS_REQUIRE((int64_t)N * out_ch < (1ll << 31), "riggs_mlp_cotangent: N x out_ch must be < 2^31");
+  RIGGS_REQUIRE(N == 0 || ((g || g_rows) && g_eff), "riggs_mlp_cotangent: tensors");
+  RIGGS_REQUIRE((l2_out == nullptr) == (l2_coef == nullptr), "riggs_mlp_cotangent: l2_out and l2_coef come together");
+  RIGGS_REQUIRE(row_mask == nullptr || g_rows != nullptr, "riggs_mlp_cotangent: row_mask without g_rows");
+  RIGGS_REQUIRE((((uintptr_t)g | (uintptr_t)l2_out | (uintptr_t)g_eff) & 15) == 0, "riggs_mlp_cotangent: g, l2_out and g_eff must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n = (int64_t)N * out_ch;
+  int blocks = 0;
+  if (n > 0) {
+    const int64_t want = ((n >> 2) + 255) / 256;
+    blocks = (int)(want < 512 ? (want > 0 ? want : 1) : 512);
+    MlpCot c;
+    c.n = n; c.out_ch = out_ch; c.g = g; c.g_rows = g_rows; c.row_mask = row_mask; c.sig = sigmoid_out; c.out = l2_out; c.coef = l2_coef;
+    c.g_eff = g_eff;
+    hipLaunchKernelGGL(mlp_l2_amax_kernel, dim3(blocks), dim3(256), 0, s, c, zero_word, partials512);
+    RIGGS_HIP_CHECK(hipGetLastError());
+  }
+  hipLaunchKernelGGL(mlp_l2_scale_kernel, dim3(1), dim3(64), 0, s, zero_word, scale, partials512, blocks, n > 0 ? 1.0f / (float)n : 0.f,
+                     l2_out ? mean_sq : nullptr);
+  RIGGS_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 int riggs_mlp_l2_grad_scale(int64_t n, const float* g, const float* out, const float* coef, float* g_eff, float* scale,
                             uint32_t* zero_word, float* partials512, float* mean_sq, riggs_stream stream) {
   RIGGS_REQUIRE(n >= 0 && scale && zero_word && partials512 && coef, "riggs_mlp_l2_grad_scale: bad arguments");
@@ -487,7 +538,9 @@ int riggs_mlp_l2_grad_scale(int64_t n, const float* g, const float* out, const f
   if (n > 0) {
     const int64_t want = ((n >> 2) + 255) / 256;
     blocks = (int)(want < 512 ? (want > 0 ? want : 1) : 512);
-    hipLaunchKernelGGL(mlp_l2_amax_kernel, dim3(blocks), dim3(256), 0, s, n, g, out, coef, g_eff, zero_word, partials512);
+    MlpCot c;
+    c.n = n; c.out_ch = 1; c.g = g; c.g_rows = nullptr; c.row_mask = nullptr; c.sig = nullptr; c.out = out; c.coef = coef; c.g_eff = g_eff;
+    hipLaunchKernelGGL(mlp_l2_amax_kernel, dim3(blocks), dim3(256), 0, s, c, zero_word, partials512);
     RIGGS_HIP_CHECK(hipGetLastError());
   }
   hipLaunchKernelGGL(mlp_l2_scale_kernel, dim3(1), dim3(64), 0, s, zero_word, scale, partials512, blocks, n > 0 ? 1.0f / (float)n : 0.f, mean_sq);

@@ -108,9 +108,11 @@ def embed_positions_bf16(x: torch.Tensor, multires: int, tail: torch.Tensor = No
     return xb
 
 
-def forward(p: Packed, x_emb: torch.Tensor, want_acts: bool, xb: torch.Tensor = None, n_dev: torch.Tensor = None):
+def forward(p: Packed, x_emb: torch.Tensor, want_acts: bool, xb: torch.Tensor = None, n_dev: torch.Tensor = None,
+            sigmoid: bool = False, res_base: torch.Tensor = None, res_mask: torch.Tensor = None):
     """``n_dev`` (device int32 scalar, optional): only the first ``min(n_dev, N)`` rows exist (include/riggs_hip.h:
-    n_rows_dev) — the compacted rows of the row-sparse backward."""
+    n_rows_dev) — the compacted rows of the row-sparse backward.  ``sigmoid`` / ``res_base`` / ``res_mask``: the output epilogue
+    (``struct riggs_mlp_epilogue``) — with ``res_base`` the third return value is ``res_base + out * res_mask``."""
     N = x_emb.shape[0]
     if xb is None:
         xb = embed_bf16(p, x_emb)
@@ -120,9 +122,22 @@ def forward(p: Packed, x_emb: torch.Tensor, want_acts: bool, xb: torch.Tensor = 
         rows = L.lib().riggs_mlp_rows_per_workgroup()
         acts = torch.empty(p.depth, N, 256, dtype=p.dtype, device=x_emb.device)
         masks = torch.empty(p.depth, (N + rows - 1) // rows, 256, 4, dtype=torch.int32, device=x_emb.device)
+    epi, res_out = None, None
+    if sigmoid or res_base is not None:
+        epi = L.MlpEpilogue()
+        epi.sigmoid = int(bool(sigmoid))
+        if res_base is not None:
+            res_base = L.require_cuda_f32("res_base", res_base, (N, p.out_ch))
+            if res_mask is not None:
+                res_mask = L.require_cuda_f32("res_mask", res_mask.reshape(-1), (N,))
+            res_out = torch.empty_like(res_base)
+            epi.res_base, epi.res_mask, epi.res_out = res_base.data_ptr(), L.ptr(res_mask), res_out.data_ptr()
+        epi = C.byref(epi)
     L.check(L.lib().riggs_mlp_forward(N, p.in_ch, p.out_ch, p.depth, p.skip, p._wp, p._bp, p.w_out.data_ptr(),
                                       p.b_out.data_ptr(), xb.data_ptr(), L.ptr(acts), L.ptr(masks), out.data_ptr(), L.ptr(n_dev),
-                                      p.fp16, L.stream_ptr()), "riggs_mlp_forward")
+                                      epi, p.fp16, L.stream_ptr()), "riggs_mlp_forward")
+    if res_base is not None:
+        return out, ((acts, masks) if want_acts else None), res_out
     return out, (acts, masks) if want_acts else None
 
 
@@ -171,20 +186,53 @@ def l2_grad_scale(g_out: torch.Tensor, out: torch.Tensor, coef: torch.Tensor, me
     return g_eff, scale
 
 
-def live_rows(p: Packed, g_out: torch.Tensor, xb: torch.Tensor):
+def cotangent(g: torch.Tensor, g_rows: torch.Tensor, row_mask: torch.Tensor, sigmoid_out: torch.Tensor, l2_out: torch.Tensor,
+              l2_coef: torch.Tensor, mean_sq: torch.Tensor = None):
+    """``riggs_mlp_cotangent``: ``g_eff = (g + g_rows * row_mask[row]) * [s (1 - s)] + l2_coef * l2_out`` for an (N, out_ch) head —
+    every piece optional (``g`` or ``g_rows`` must be there) — and the fp16 gradient scale of ``g_eff``; the two launches
+    ``grad_scale`` makes anyway, whatever is folded in.  Returns ``(g_eff, scale)``."""
+    ref = g if g is not None else g_rows
+    N, out_ch = ref.shape
+    tens = {}
+    for name, t in (("g", g), ("g_rows", g_rows), ("sigmoid_out", sigmoid_out), ("l2_out", l2_out)):
+        tens[name] = None if t is None else _aligned(L.require_cuda_f32(name, t, (N, out_ch)))
+    if row_mask is not None:
+        row_mask = L.require_cuda_f32("row_mask", row_mask.reshape(-1), (N,))
+    key = (ref.device, L.stream_ptr())
+    sc = _L2_SCRATCH.get(key)
+    if sc is None:
+        sc = _L2_SCRATCH[key] = (torch.zeros(1, dtype=torch.int32, device=ref.device), torch.empty(512, device=ref.device))
+    g_eff = torch.empty(N, out_ch, device=ref.device)
+    scale = torch.empty(1, device=ref.device)
+    L.check(L.lib().riggs_mlp_cotangent(N, out_ch, L.ptr(tens["g"]), L.ptr(tens["g_rows"]), L.ptr(row_mask), L.ptr(tens["sigmoid_out"]),
+                                        L.ptr(tens["l2_out"]), L.ptr(l2_coef) if l2_out is not None else None, g_eff.data_ptr(),
+                                        scale.data_ptr(), sc[0].data_ptr(), sc[1].data_ptr(), L.ptr(mean_sq), L.stream_ptr()),
+            "riggs_mlp_cotangent")
+    return g_eff, scale
+
+
+def live_rows(p: Packed, g_out: torch.Tensor, xb: torch.Tensor, sigmoid_out: torch.Tensor = None, want_scale: bool = False):
     """The rows of ``g_out`` (N, out_ch) that hold a non-zero, compacted in ascending order (``riggs_mlp_live_rows``: two launches,
-    no atomics, no host synchronisation): ``(idx (N) int32, count (1) int32 on the device, xb_live, g_live)`` — the gathered rows
-    of the padded 16-bit operand ``xb`` and of ``g_out``; only the first ``count`` rows of each are defined."""
+    no atomics, no host synchronisation): ``(idx (N) int32, count (1) int32 on the device, xb_live, g_live[, scale])`` — the
+    gathered rows of the padded 16-bit operand ``xb`` and of ``g_out``; only the first ``count`` rows of each are defined.
+    ``sigmoid_out``: the head's sigmoid-ed output — ``g_out * s (1 - s)`` is what is tested and gathered.  ``want_scale``: the fp16
+    gradient scale of that cotangent comes out of the same two launches."""
     N = g_out.shape[0]
     dev = g_out.device
     g_out = L.require_cuda_f32("g_out", g_out, (N, p.out_ch))
+    if sigmoid_out is not None:
+        sigmoid_out = L.require_cuda_f32("sigmoid_out", sigmoid_out, (N, p.out_ch))
     idx = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
     count = torch.empty(1, dtype=torch.int32, device=dev)
     xl = torch.empty_like(xb)
     gl = torch.empty_like(g_out)
+    scale = torch.empty(1, device=dev) if want_scale else None
     ws = torch.empty(int(L.lib().riggs_mlp_live_rows_workspace_bytes(N)) // 8 + 1, dtype=torch.int64, device=dev)
-    L.check(L.lib().riggs_mlp_live_rows(N, p.out_ch, p.in_ch, g_out.data_ptr(), xb.data_ptr(), ws.data_ptr(), idx.data_ptr(),
-                                        count.data_ptr(), xl.data_ptr(), gl.data_ptr(), L.stream_ptr()), "riggs_mlp_live_rows")
+    L.check(L.lib().riggs_mlp_live_rows(N, p.out_ch, p.in_ch, g_out.data_ptr(), L.ptr(sigmoid_out), xb.data_ptr(), ws.data_ptr(),
+                                        idx.data_ptr(), count.data_ptr(), xl.data_ptr(), gl.data_ptr(), L.ptr(scale), L.stream_ptr()),
+            "riggs_mlp_live_rows")
+    if want_scale:
+        return idx, count, xl, gl, scale
     return idx, count, xl, gl
 
 
@@ -308,60 +356,88 @@ def library_param_grads(p: Packed, xb: torch.Tensor, acts: torch.Tensor, dpre: t
 
 
 class _FusedMLP(torch.autograd.Function):
-    """out = MLP(x_emb) with the fused kernels; gradients for the (fp32 master) parameters only."""
+    """out = MLP(x_emb) with the fused kernels; gradients for the (fp32 master) parameters only.  With ``res = (base, mask)`` the
+    function returns ``(out, base + out * mask)`` — the residual join of the forward's epilogue — and hands ``base`` its cotangent
+    straight through."""
 
     @staticmethod
-    def forward(ctx, x_emb, head, l2, *params):
+    def forward(ctx, x_emb, head, l2, res_base, res_mask, *params):
         p = head._packed()
-        ctx.l2 = l2  # None, or (coef, mean_sq): an L2 regulariser on the output folded into the backward (l2_grad_scale)
+        ctx.l2 = l2  # None, or (coef, mean_sq): an L2 regulariser on the output folded into the backward (cotangent)
         n_rows = head._n_rows if x_emb.dtype == p.dtype else x_emb.shape[0]
         xb = x_emb if x_emb.dtype == p.dtype else embed_bf16(p, x_emb)
-        ctx.head, ctx.p, ctx.n, ctx.sparse = head, p, n_rows, bool(head.sparse_rows)
+        ctx.head, ctx.p, ctx.n, ctx.sparse, ctx.sig = head, p, n_rows, bool(head.sparse_rows), bool(head.out_sigmoid)
+        ctx.res = res_base is not None
+        ctx.res_mask = res_mask.detach() if res_mask is not None else None
+        ctx.set_materialize_grads(False)
         if ctx.sparse:
             # row-sparse backward: nothing is stored here — the backward repeats the forward for the rows that carry a gradient
-            out, _ = forward(p, xb[:n_rows], False, xb)
+            r = forward(p, xb[:n_rows], False, xb, sigmoid=ctx.sig, res_base=res_base, res_mask=res_mask)
             ctx.save_for_backward(xb)
         else:
-            out, (acts, masks) = forward(p, xb[:n_rows], True, xb)
+            r = forward(p, xb[:n_rows], True, xb, sigmoid=ctx.sig, res_base=res_base, res_mask=res_mask)
+            acts, masks = r[1]
             ctx.save_for_backward(xb, acts, masks)
-        ctx.out = out if l2 is not None else None  # (detached inside a Function: no reference cycle)
+        out = r[0]
+        ctx.out = out if (l2 is not None or ctx.sig) else None  # (detached inside a Function: no reference cycle)
+        if ctx.res:
+            return out, r[2]
         return out
 
     @staticmethod
-    def backward(ctx, g_out):
+    def backward(ctx, g_out, g_res=None):
         p = ctx.p
-        g_out = _aligned(g_out.contiguous())
-        if ctx.l2 is not None:
-            g_out, scale = l2_grad_scale(g_out, ctx.out, ctx.l2[0], ctx.l2[1])
+        n_lead = 5
+        if g_out is None and g_res is None:
+            return (None,) * (n_lead + 2 * p.depth + 2)
+        g_out = None if g_out is None else _aligned(g_out.contiguous())
+        g_res = None if g_res is None else g_res.contiguous()
+        sig = ctx.out if ctx.sig else None
+        plain = g_res is None and ctx.l2 is None  # the cotangent is g_out (x the sigmoid's factor)
+        if ctx.sparse and plain:
+            (xb,) = ctx.saved_tensors
+            _, count, xl, gl, scale = live_rows(p, g_out, xb, sig, want_scale=True)
             if not p.fp16:
                 scale = None
-        else:
-            scale = grad_scale(g_out) if p.fp16 else None
-        if ctx.sparse:
-            (xb,) = ctx.saved_tensors
-            _, count, xl, gl = live_rows(p, g_out, xb)
             _, (acts, masks) = forward(p, xl[:ctx.n], True, xl, n_dev=count)
             dpre, _ = backward_data(p, gl, masks, scale, bias_sums=False, n_dev=count)
             grads = param_grads(p, xl, acts, dpre, gl, scale, n_dev=count)
             ctx.head.last_live_count = count
         else:
-            xb, acts, masks = ctx.saved_tensors
-            dpre, _ = backward_data(p, g_out, masks, scale, bias_sums=False)
-            grads = param_grads(p, xb, acts, dpre, g_out, scale)
-        return (None, None, None) + tuple(grads)
+            if plain and sig is None:
+                scale = grad_scale(g_out) if p.fp16 else None
+            else:
+                l2o, l2c, msq = (ctx.out, ctx.l2[0], ctx.l2[1]) if ctx.l2 is not None else (None, None, None)
+                g_out, scale = cotangent(g_out, g_res, ctx.res_mask if g_res is not None else None, sig, l2o, l2c, msq)
+                if not p.fp16:
+                    scale = None
+            if ctx.sparse:
+                (xb,) = ctx.saved_tensors
+                _, count, xl, gl = live_rows(p, g_out, xb)
+                _, (acts, masks) = forward(p, xl[:ctx.n], True, xl, n_dev=count)
+                dpre, _ = backward_data(p, gl, masks, scale, bias_sums=False, n_dev=count)
+                grads = param_grads(p, xl, acts, dpre, gl, scale, n_dev=count)
+                ctx.head.last_live_count = count
+            else:
+                xb, acts, masks = ctx.saved_tensors
+                dpre, _ = backward_data(p, g_out, masks, scale, bias_sums=False)
+                grads = param_grads(p, xb, acts, dpre, g_out, scale)
+        return (None, None, None, g_res if ctx.res else None, None) + tuple(grads)
 
 
 class FusedHead:
     """Runs ``net`` (a WeightMLP or DeformMLP host mirror) through the fused kernels.  ``net`` keeps owning the fp32
     parameters; the bf16 copies are rebuilt when a parameter's version counter changes (optimizer step, load)."""
 
-    def __init__(self, linears, head_linear, in_ch: int, skip: int, fmt: str = None, sparse_rows: bool = False):
+    def __init__(self, linears, head_linear, in_ch: int, skip: int, fmt: str = None, sparse_rows: bool = False,
+                 out_sigmoid: bool = False):
         """``sparse_rows``: the backward runs on the rows whose cotangent is non-zero (``live_rows``) and the forward stores no
         activations — exact (a zero row contributes zero to every parameter gradient), and the right choice for a head whose
         cotangent reaches only the Gaussians the render touched (the WeightMLP: 10-30 % of the rows); a head with a dense
         cotangent (the DeformMLP under its L2 regulariser, train_rig.py:446-454) would pay a second forward for nothing."""
         self.fmt = fmt or DEFAULT_FORMAT
         self.sparse_rows = bool(sparse_rows)
+        self.out_sigmoid = bool(out_sigmoid)  # the head's value goes through a sigmoid inside the forward launch (WeightMLP)
         self.last_live_count = None  # device int32 (1,): the live rows of the last row-sparse backward
         self.linears, self.head_linear, self.in_ch, self.skip = list(linears), head_linear, in_ch, skip
         self._pk, self._ver, self._ptrs = None, None, None
@@ -390,10 +466,15 @@ class FusedHead:
             self._ver = ver
         return self._pk
 
-    def __call__(self, x_emb: torch.Tensor, n_rows: int = None, l2=None) -> torch.Tensor:
+    def __call__(self, x_emb: torch.Tensor, n_rows: int = None, l2=None, res=None):
         """``x_emb``: (N, in_ch) fp32, or the padded bf16 operand of ``embed_positions_bf16`` together with ``n_rows`` = N.
         ``l2``: None, or ``(coef, mean_sq)`` — device scalars: the backward adds ``coef * output`` to the incoming cotangent
         (d/d output of ``lambda * mean(output^2)`` for ``coef = 2 lambda / output.numel()``) and writes mean(output^2) into
-        ``mean_sq`` (may be None); no launch beyond the gradient scale's two."""
+        ``mean_sq`` (may be None); no launch beyond the gradient scale's two.
+        ``res``: None, or ``(base, mask)`` — the call returns ``(output, base + output * mask)`` (``mask``: (N, 1) / (N) without a
+        gradient of its own, or None = 1), joined by the forward launch's epilogue; the backward sends the second value's cotangent
+        through to ``base`` and, times ``mask``, into the MLP."""
         self._n_rows = n_rows
-        return _FusedMLP.apply(x_emb.contiguous(), self, l2, *self.params())
+        if res is not None:
+            return _FusedMLP.apply(x_emb.contiguous(), self, l2, res[0], res[1], *self.params())
+        return _FusedMLP.apply(x_emb.contiguous(), self, l2, None, None, *self.params())

@@ -715,12 +715,15 @@ class SkeletonWarp(nn.Module):
         from .mlp import FusedHead
         net = self.skinning_weight_mlp
         if getattr(self, "_fh_w", None) is None:
+            # (the sigmoid of network_utils.py:107 inside the forward launch, its derivative inside the backward's first launch)
             self._fh_w = FusedHead(net.linear, net.weight_predict, net.input_ch, net.skips[0], self._fused_fmt,
-                                   sparse_rows=getattr(self, "_fused_sparse_w", True))
+                                   sparse_rows=getattr(self, "_fused_sparse_w", True), out_sigmoid=True)
         from .mlp import embed_positions_bf16
-        return torch.sigmoid(self._fh_w(embed_positions_bf16(x, net.multires, fmt=self._fused_fmt), n_rows=x.shape[0]))
+        return self._fh_w(embed_positions_bf16(x, net.multires, fmt=self._fused_fmt), n_rows=x.shape[0])
 
-    def _head_detail(self, x, pose):
+    def _head_detail(self, x, pose, res=None):
+        """The template offsets; with ``res = (d_xyz, mask)`` on the fused path ``(offsets, d_xyz + offsets * mask)`` — joined by
+        the forward launch (riggs_mlp_epilogue) instead of two elementwise launches (and one in the backward)."""
         if not getattr(self, "_fused_heads", False):
             return self.detail_net(x, pose)
         from .mlp import FusedHead
@@ -730,7 +733,7 @@ class SkeletonWarp(nn.Module):
         if net.t_multires <= 0 and net.multires > 0:  # the reference's configuration: PE(x) and the raw pose vector
             from .mlp import embed_positions_bf16
             return self._fh_d(embed_positions_bf16(x, net.multires, pose[0], fmt=self._fused_fmt), n_rows=x.shape[0],
-                              l2=getattr(self, "template_l2", None))
+                              l2=getattr(self, "template_l2", None), res=res)
         t_emb = _embed(pose, net.t_multires) if net.t_multires > 0 else pose
         x_emb = _embed(x, net.multires) if net.multires > 0 else x
         return self._fh_d(torch.cat([x_emb, t_emb], dim=-1), l2=getattr(self, "template_l2", None))
@@ -774,8 +777,14 @@ class SkeletonWarp(nn.Module):
                 local_rot, global_trans, self._node_radius, mask, x, joints, par, self.K, weight_mod)
         if self.use_template_offsets:  # skeleton_warp.py:152-158: offsets join the blended position before the mask
             pose = local_rot.detach().reshape(-1)[None].expand(x.shape[0], -1)
-            self.template_offsets = self._head_detail(x, pose)
-            d_xyz = d_xyz + (self.template_offsets if mask is None else self.template_offsets * mask)
+            net = self.detail_net
+            fold = (getattr(self, "_fused_heads", False) and net.t_multires <= 0 and net.multires > 0
+                    and (mask is None or not mask.requires_grad))
+            if fold:
+                self.template_offsets, d_xyz = self._head_detail(x, pose, res=(d_xyz, mask))
+            else:
+                self.template_offsets = self._head_detail(x, pose)
+                d_xyz = d_xyz + (self.template_offsets if mask is None else self.template_offsets * mask)
         else:
             self.template_offsets = None
         wm = None if weight_mod is None else weight_mod.detach()

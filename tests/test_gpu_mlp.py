@@ -335,3 +335,137 @@ def test_row_sparse_backward_takes_an_unaligned_cotangent_view():
     assert g.data_ptr() % 16 != 0 and g.is_contiguous()
     torch.autograd.backward([out], [g])
     assert all(q.grad is not None and bool(torch.isfinite(q.grad).all()) for q in net.parameters())
+
+
+@pytest.mark.parametrize("N", [1, 127, 4_097, 70_001])
+def test_forward_epilogue_sigmoid_and_residual(N):
+    """struct riggs_mlp_epilogue: the head's value through a sigmoid (network_utils.py:107) and joined with a residual,
+    res_out = res_base + out * res_mask (skeleton_warp.py:152-161), inside the forward launch — against torch on the plain output
+    of the same kernel (same products: the epilogue is the only difference)."""
+    for name, net, head, xe in _nets(N):
+        pk = M.FusedHead(net.linear, head, xe.shape[1], net.skips[0])._packed()
+        xb = M.embed_bf16(pk, xe)
+        plain, _ = M.forward(pk, xe, False, xb)
+        g = torch.Generator(device="cuda").manual_seed(N)
+        base = torch.randn(N, pk.out_ch, device="cuda", generator=g)
+        mask = torch.rand(N, 1, device="cuda", generator=g)
+        sig, _ = M.forward(pk, xe, False, xb, sigmoid=True)
+        assert float((sig - torch.sigmoid(plain)).abs().max()) <= 2e-7
+        for m in (None, mask):
+            out, _, joined = M.forward(pk, xe, False, xb, res_base=base, res_mask=m)
+            assert torch.equal(out, plain)
+            want = base + (plain if m is None else plain * m)
+            assert float((joined - want).abs().max()) <= 1e-6 * max(1.0, float(want.abs().max())), (name, N)
+        out, _, joined = M.forward(pk, xe, False, xb, sigmoid=True, res_base=base, res_mask=mask)
+        assert torch.equal(out, sig) and float((joined - (base + sig * mask)).abs().max()) <= 1e-6 * max(1.0, float(base.abs().max()))
+
+
+@pytest.mark.parametrize("N,out_ch", [(1, 3), (5, 3), (1023, 23), (70_001, 3), (20_011, 23)])
+def test_cotangent_kernel_matches_the_formula(N, out_ch):
+    """riggs_mlp_cotangent: g_eff = (g + g_rows * row_mask[row]) * s (1 - s) + coef * out with every piece optional, the fp16 scale
+    of g_eff and mean(out^2) — against torch (ragged sizes: the vector loop's tail; twice in a row: the scratch word is left zero)."""
+    gen = torch.Generator(device="cuda").manual_seed(N + out_ch)
+    r = lambda *s: torch.randn(*s, device="cuda", generator=gen)  # noqa: E731
+    g, gr, out = r(N, out_ch) * 3e-7, r(N, out_ch) * 3e-7, r(N, out_ch) * 0.1
+    mask = torch.rand(N, 1, device="cuda", generator=gen)
+    sig = torch.sigmoid(r(N, out_ch) * 3)
+    coef = torch.full((1,), 2e-6, device="cuda")
+    msq = torch.zeros(1, device="cuda")
+    cases = [(g, None, None, None, None), (g, None, None, sig, None), (None, gr, mask, None, out), (g, gr, mask, None, out),
+             (g, gr, None, sig, out), (None, gr, None, None, None)]
+    for a, b, m, s_, o in cases:
+        for _ in range(2):
+            ge, sc = M.cotangent(a, b, m, s_, o, coef if o is not None else None, msq if o is not None else None)
+            want = torch.zeros(N, out_ch, device="cuda")
+            if a is not None:
+                want = want + a
+            if b is not None:
+                want = want + (b if m is None else b * m)
+            if s_ is not None:
+                want = want * (s_ * (1 - s_))
+            if o is not None:
+                want = want + coef * o
+            assert float((ge - want).abs().max()) <= 1e-6 * float(want.abs().max()) + 1e-30
+            amax = ge.abs().amax().clamp_min(1e-30)
+            assert float(sc) / float(torch.exp2(torch.floor(torch.log2(1024.0 / amax)))) in (0.5, 1.0, 2.0)
+            if o is not None:
+                assert abs(float(msq) - float((o * o).mean())) <= 1e-5 * float((o * o).mean())
+    assert all(int(w[0]) == 0 for w in M._L2_SCRATCH.values())
+
+
+@pytest.mark.parametrize("N,frac", [(1, 1.0), (300, 0.1), (4_097, 0.0), (70_001, 0.1)])
+def test_live_rows_with_the_sigmoid_factor_and_the_scale(N, frac):
+    """riggs_mlp_live_rows(sigmoid_out, scale): the rows are tested and gathered on g * s (1 - s) (a saturated output — s exactly 1
+    — kills its entry like torch's sigmoid_backward does), and the fp16 gradient scale of that cotangent comes out of the same two
+    launches: equal to riggs_mlp_grad_scale on the materialised product."""
+    name, net, head, xe = _nets(N)[0]
+    pk = M.FusedHead(net.linear, head, xe.shape[1], net.skips[0])._packed()
+    xb = M.embed_bf16(pk, xe)
+    g = _sparse_cotangent(N, pk.out_ch, frac)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    sig = torch.sigmoid(torch.randn(N, pk.out_ch, device="cuda", generator=gen) * 4)
+    if N > 4:
+        sig[N // 3] = 1.0   # a saturated row: its cotangent is exactly zero whatever g holds
+    ge = g * (sig * (1 - sig))
+    idx, count, xl, gl, sc = M.live_rows(pk, g, xb, sig, want_scale=True)
+    want = torch.nonzero((ge != 0).any(1)).flatten()
+    m = int(count)
+    assert m == want.numel() and torch.equal(idx[:m].long(), want)
+    assert torch.equal(xl[:m], xb[want])
+    assert float((gl[:m] - ge[want]).abs().max()) <= 1e-6 * float(ge.abs().max()) + 1e-38 if m else True
+    assert float(sc) == float(M.grad_scale(ge))
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+def test_fused_head_with_the_folds_equals_the_composition(sparse):
+    """FusedHead(out_sigmoid=True) and FusedHead(res=(base, mask)): outputs and every parameter gradient equal the same head
+    followed by the sigmoid / the torch residual join (the folds move elementwise work into the launches, nothing else) —
+    to 1e-5 of each tensor's largest entry (2e-4 against torch.sigmoid's own arithmetic); the residual's cotangent reaches `base`
+    untouched."""
+    N = 20_011
+    for name, net, head, xe in _nets(N):
+        out_ch = head.weight.shape[0]
+        gen = torch.Generator(device="cuda").manual_seed(11)
+        g = _sparse_cotangent(N, out_ch, 0.2, mag=3e-7)
+        base0 = torch.randn(N, out_ch, device="cuda", generator=gen)
+        mask = torch.rand(N, 1, device="cuda", generator=gen)
+        res = {}
+        for fold in (False, True):
+            for q in net.parameters():
+                q.grad = None
+            base = base0.clone().requires_grad_(True)
+            if name == "WeightMLP":
+                fh = M.FusedHead(net.linear, head, xe.shape[1], net.skips[0], sparse_rows=sparse, out_sigmoid=fold)
+                if fold:
+                    out = fh(xe)
+                    torch.autograd.backward([out], [g])
+                else:
+                    # (the same sigmoid arithmetic as the kernel's, 1 / (1 + exp(-x)): torch.sigmoid's own form differs by an ulp
+                    # of s, which the factor (1 - s) magnifies to ~2e-5 of the gradients — checked looser below)
+                    o = fh(xe)
+                    out = 1.0 / (1.0 + torch.exp(-o.detach()))
+                    torch.autograd.backward([o], [g * (out * (1 - out))])
+                res[fold] = (out.detach(), None, [q.grad.clone() for q in net.parameters()])
+                if fold:
+                    for q in net.parameters():
+                        q.grad = None
+                    torch.autograd.backward([torch.sigmoid(M.FusedHead(net.linear, head, xe.shape[1], net.skips[0], sparse_rows=sparse)(xe))], [g])
+                    for a, (n_, q) in zip(res[True][2], net.named_parameters()):
+                        assert float((a - q.grad).abs().max()) <= 2e-4 * float(q.grad.abs().max()) + 1e-30, (name, sparse, n_, "torch.sigmoid")
+            else:
+                fh = M.FusedHead(net.linear, head, xe.shape[1], net.skips[0], sparse_rows=sparse)
+                if fold:
+                    off, joined = fh(xe, res=(base, mask))
+                else:
+                    off = fh(xe)
+                    joined = base + off * mask
+                # (a direct cotangent on the offsets AND one through the join, as a caller with its own loss on the offsets has)
+                torch.autograd.backward([off, joined], [0.5 * g, g])
+                res[fold] = (joined.detach(), base.grad.clone(), [q.grad.clone() for q in net.parameters()])
+        assert float((res[True][0] - res[False][0]).abs().max()) <= 1e-6 * max(1.0, float(res[False][0].abs().max()))
+        if res[False][1] is not None:
+            assert torch.equal(res[True][1], res[False][1])
+        for a, b, (n_, _q) in zip(res[True][2], res[False][2], net.named_parameters()):
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-30, (name, sparse, n_)
+        for q in net.parameters():
+            q.grad = None
