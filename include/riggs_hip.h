@@ -251,7 +251,15 @@ int riggs_lbs_forward(int32_t num_points, int32_t num_joints, int32_t K, const f
                       const int32_t* parents, const float* node_radius_log, const float* transforms,
                       const float* node_rot, const float* global_trans, const float* motion_mask,
                       const float* weight_mod /* NULL, or (N, J-1) = sigmoid(WeightMLP(x)): skeleton_warp.py:56-69; K = -1 only */,
-                      float* d_xyz, float* d_rotation, float* nn_weight, int64_t* nn_idx, riggs_stream stream);
+                      float* d_xyz, float* d_rotation, float* nn_weight, int64_t* nn_idx,
+                      void* bone_table /* may be NULL; riggs_lbs_bone_table_bytes() of device scratch, see below */,
+                      riggs_stream stream);
+/* bone_table (riggs_lbs_forward / riggs_lbs_forward_fk; may be NULL): device scratch of riggs_lbs_bone_table_bytes() bytes.  With
+ * it the all-bones forward (K = -1, no weight_mod, no nn outputs) of a LARGE scene (>= 1 M Gaussians, >= 16 joints) reads the bone
+ * records through the scalar cache as SGPR operands — a one-workgroup launch writes the table (and, in the _fk form, runs the
+ * chain) in front — instead of staging them in every workgroup's LDS: 2 M x 64 joints 129 -> 104 us, results bit-identical.
+ * riggs_set_option("lbs_scalar", 1 / -1) forces / forbids the form at every size (default 0: by size). */
+size_t riggs_lbs_bone_table_bytes(void);
 /* The same with the forward kinematics INSIDE the launch (every workgroup runs the chain of J - 1 dependent 3x4 products
  * itself — 2 us — instead of a launch of its own in front — 6.5 us of a captured frame): takes the pose, and workgroup 0
  * leaves what riggs_fk_forward would have written (transforms (J,12), node_rot (J,4), d_nodes (J,3)) for the backward and
@@ -260,7 +268,7 @@ int riggs_lbs_forward_fk(int32_t num_points, int32_t num_joints, int32_t K, cons
                          const int32_t* parents, const float* node_radius_log, const float* local_rot,
                          const float* global_trans, const float* motion_mask, const float* weight_mod,
                          float* transforms, float* node_rot, float* d_nodes, float* d_xyz, float* d_rotation,
-                         riggs_stream stream);
+                         void* bone_table, riggs_stream stream);
 /* Backward: cotangents g_xyz (N,3), g_rot (N,4) -> dL/dtransforms (J,12), dL/dnode_radius_log (J),
  * dL/dglobal_trans (3), optional dL/dmotion_mask (N).  Reduction over N is done in-kernel
  * (registers -> workgroup partials -> a fixed-order second stage: run-to-run deterministic).

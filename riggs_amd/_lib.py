@@ -156,9 +156,10 @@ _SIGS = {
                               + [_P] + [_P] * 10 + [_P]),
     "riggs_fk_forward": (C.c_int, [C.c_int32] + [_P] * 8),
     "riggs_fk_backward": (C.c_int, [C.c_int32] + [_P] * 8),
-    "riggs_lbs_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [_P] * 14),
+    "riggs_lbs_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [_P] * 15),
     "riggs_lbs_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [_P] * 18),
-    "riggs_lbs_forward_fk": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [_P] * 14),
+    "riggs_lbs_forward_fk": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [_P] * 15),
+    "riggs_lbs_bone_table_bytes": (C.c_size_t, []),
     "riggs_lbs_backward_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "riggs_pose_mlp_acts_floats": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "riggs_pose_mlp_backward_workspace_floats": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
@@ -261,8 +262,12 @@ def lib():
 
 def set_option(name: str, value: int):
     """riggs_set_option (include/riggs_hip.h): "fwd_wide_tiles", "fwd_wide_min", "bin_grouped", "cnode_bwd_atomics",
-    "color_side_jobs", "preprocess_bwd_lean", "pose_mlp_layered"."""
+    "color_side_jobs", "preprocess_bwd_lean", "pose_mlp_layered", "fwd_hist_view_tol", "lbs_scalar"."""
     check(lib().riggs_set_option(name.encode(), int(value)), "riggs_set_option")
+    OPTIONS_SET[name] = int(value)
+
+
+OPTIONS_SET = {}  # what this process set through set_option (host-side decisions that follow an option read it here: no C call per frame)
 
 
 def get_option(name: str) -> int:

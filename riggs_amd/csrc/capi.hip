@@ -18,9 +18,9 @@ void set_error(const char* fmt, ...) {
 }
 
 // ---- library options -------------------------------------------------------------------
-static const char* kOptNames[OPT_COUNT] = {"fwd_wide_tiles", "fwd_wide_min", "bin_grouped", "cnode_bwd_atomics", "color_side_jobs", "preprocess_bwd_lean", "pose_mlp_layered", "fwd_hist_view_tol"};
-static const int kOptDefaults[OPT_COUNT] = {256, 4096, -1, 0, 1, -1, 0, 20};
-static int g_opt[OPT_COUNT] = {256, 4096, -1, 0, 1, -1, 0, 20};
+static const char* kOptNames[OPT_COUNT] = {"fwd_wide_tiles", "fwd_wide_min", "bin_grouped", "cnode_bwd_atomics", "color_side_jobs", "preprocess_bwd_lean", "pose_mlp_layered", "fwd_hist_view_tol", "lbs_scalar"};
+static const int kOptDefaults[OPT_COUNT] = {256, 4096, -1, 0, 1, -1, 0, 20, 0};
+static int g_opt[OPT_COUNT] = {256, 4096, -1, 0, 1, -1, 0, 20, 0};
 int option(int id) { return g_opt[id]; }
 
 // ---- event-based kernel timing -------------------------------------------------------
@@ -167,6 +167,7 @@ int riggs_set_option(const char* name, int32_t value) {
   if (id == OPT_BIN_GROUPED) { if (v < -1 || v > 1) { set_error("riggs_set_option: bin_grouped takes -1 (by size), 0 or 1"); return 2; } }
   if (id == OPT_PREPROCESS_BWD_LEAN) { if (v < -1 || v > 1) { set_error("riggs_set_option: preprocess_bwd_lean takes -1 (with cfg.sparse_zero), 0 or 1"); return 2; } }
   if (id == OPT_CNODE_BWD_ATOMICS || id == OPT_COLOR_SIDE_JOBS || id == OPT_POSE_MLP_LAYERED) v = v ? 1 : 0;
+  if (id == OPT_LBS_SCALAR) { if (v < -1 || v > 1) { set_error("riggs_set_option: lbs_scalar takes -1 (never), 0 (by size) or 1 (always)"); return 2; } }
   g_opt[id] = v;
   return 0;
 }

@@ -57,7 +57,7 @@ static inline bool once_per_device(unsigned long long& done) {
 }
 
 // ---- library options (riggs_set_option / riggs_get_option in the ABI; process-wide, nothing is read from the environment) ----
-enum OptId { OPT_FWD_WIDE_TILES = 0, OPT_FWD_WIDE_MIN, OPT_BIN_GROUPED, OPT_CNODE_BWD_ATOMICS, OPT_COLOR_SIDE_JOBS, OPT_PREPROCESS_BWD_LEAN, OPT_POSE_MLP_LAYERED, OPT_FWD_HIST_VIEW_TOL, OPT_COUNT };
+enum OptId { OPT_FWD_WIDE_TILES = 0, OPT_FWD_WIDE_MIN, OPT_BIN_GROUPED, OPT_CNODE_BWD_ATOMICS, OPT_COLOR_SIDE_JOBS, OPT_PREPROCESS_BWD_LEAN, OPT_POSE_MLP_LAYERED, OPT_FWD_HIST_VIEW_TOL, OPT_LBS_SCALAR, OPT_COUNT };
 int option(int id);
 
 // ---- a frame's "valid" gate (include/riggs_hip.h: riggs_gate) as a kernel argument ----

@@ -306,6 +306,108 @@ __global__ __launch_bounds__(256) void lbs_forward_kernel(LbsArgs a) {
   }
 }
 
+// ---- the all-bones forward with the bone records in SGPRs (large scenes; riggs_set_option("lbs_scalar")).  A bone
+// record is the same for every lane: here it comes from a table in global memory through the scalar cache (the constant address
+// space makes the uniform loads s_load_dwordx8 / x4) and feeds the vector instructions as scalar operands — no LDS image, no
+// barrier, no ds_read_b128 broadcast per bone and wave; the results are bit-identical to the LDS form's (same operations, same
+// order).  The table (the staged Bone records) is written by a one-workgroup launch in front: chosen by lbs_use_scalar.
+__global__ __launch_bounds__(64) void lbs_bone_table_kernel(LbsArgs a, Bone* __restrict__ table) {
+  __shared__ Bone bones[MAX_J - 1];
+  stage_bones(a, bones);
+  for (int k = threadIdx.x; k < a.J - 1; k += 64) table[k] = bones[k];
+}
+// ... and with the kinematic chain in front of it (riggs_lbs_forward_fk's large-scene form): one wave runs the chain, leaves its
+// results where the backward reads them, and the table
+__global__ __launch_bounds__(64) void lbs_fk_table_kernel(LbsArgs a, Bone* __restrict__ table) {
+  __shared__ Bone bones[MAX_J - 1];
+  __shared__ float G[MAX_J][12];
+  __shared__ float Q[MAX_J][4];
+  FkIn in;
+  fk_load(a.J, a.local_rot, a.joints, a.parents, nullptr, nullptr, in);
+  FkLane f;
+  fk_wave_forward(a.J, in, f);
+  const int j = threadIdx.x;
+  if (j < a.J) {
+    float q[4];
+    R_to_quat(f.G, q);
+    const float x = in.x[0], y = in.x[1], z = in.x[2];
+#pragma unroll
+    for (int e = 0; e < 12; e++) { G[j][e] = f.G[e]; a.fk_transforms[12 * j + e] = f.G[e]; }
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+      a.fk_d_nodes[3 * j + r] = (f.G[4 * r] * x + f.G[4 * r + 1] * y + f.G[4 * r + 2] * z + f.G[4 * r + 3]) + a.global_trans[r];
+#pragma unroll
+    for (int e = 0; e < 4; e++) { Q[j][e] = q[e]; a.fk_node_rot[4 * j + e] = q[e]; }
+  }
+  __syncthreads();
+  stage_bones(a, bones, &G[0][0], &Q[0][0]);
+  for (int k = threadIdx.x; k < a.J - 1; k += 64) table[k] = bones[k];
+}
+typedef __attribute__((address_space(4))) const Bone* LbsConstBones;
+template <int PTS>
+__global__ __launch_bounds__(256) void lbs_forward_scalar_kernel(LbsArgs a, const Bone* __restrict__ table_g) {
+  const LbsConstBones table = (LbsConstBones)table_g;
+  const int n0 = blockIdx.x * (256 * PTS) + threadIdx.x;
+  float px[PTS], py[PTS], pz[PTS];
+  bool on[PTS];
+#pragma unroll
+  for (int p = 0; p < PTS; p++) {
+    const int n = n0 + 256 * p;
+    on[p] = n < a.N;
+    const int nn = min(on[p] ? n : n0, a.N - 1);
+    px[p] = a.x[3 * nn]; py[p] = a.x[3 * nn + 1]; pz[p] = a.x[3 * nn + 2];
+  }
+  const int B = a.J - 1;
+  if (n0 >= a.N) return;
+  float M[PTS][12], qa[PTS][4], sum[PTS];
+#pragma unroll
+  for (int p = 0; p < PTS; p++) {
+    sum[p] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 12; e++) M[p][e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; e++) qa[p][e] = 0.f;
+  }
+  for (int k = 0; k < B; k++) {
+    const float a0 = table[k].a[0], a1 = table[k].a[1], a2 = table[k].a[2];
+    const float b0 = table[k].ba[0], b1 = table[k].ba[1], b2 = table[k].ba[2];
+    const float rl2 = table[k].rl2, i2r = table[k].inv2r2;
+    float G[12], q[4];
+#pragma unroll
+    for (int e = 0; e < 12; e++) G[e] = table[k].G[e];
+#pragma unroll
+    for (int e = 0; e < 4; e++) q[e] = table[k].q[e];
+#pragma unroll
+    for (int p = 0; p < PTS; p++) {
+      const float ex = px[p] - a0, ey = py[p] - a1, ez = pz[p] - a2;
+      const float t = __builtin_amdgcn_fmed3f((ex * b0 + ey * b1 + ez * b2) * rl2, 0.0f, 1.0f);
+      const float sx = t * b0 - ex, sy = t * b1 - ey, sz = t * b2 - ez;
+      const float d2 = sx * sx + sy * sy + sz * sz;
+      float u = fast_exp(-d2 * i2r);
+      if (a.weight_mod) u *= a.weight_mod[(size_t)(on[p] ? n0 + 256 * p : n0) * B + k];
+      const float v = u + 1e-7f;
+      sum[p] += v;
+#pragma unroll
+      for (int e = 0; e < 12; e++) M[p][e] += v * G[e];
+#pragma unroll
+      for (int e = 0; e < 4; e++) qa[p][e] += v * q[e];
+    }
+  }
+  const float gx = a.global_trans[0], gy = a.global_trans[1], gz = a.global_trans[2];
+#pragma unroll
+  for (int p = 0; p < PTS; p++) {
+    if (!on[p]) continue;
+    const int n = n0 + 256 * p;
+    const float inv = 1.0f / sum[p];
+    const float m = a.motion_mask ? a.motion_mask[n] : 1.0f;
+    const float ax = (M[p][0] * px[p] + M[p][1] * py[p] + M[p][2] * pz[p] + M[p][3]) * inv + gx;
+    const float ay = (M[p][4] * px[p] + M[p][5] * py[p] + M[p][6] * pz[p] + M[p][7]) * inv + gy;
+    const float az = (M[p][8] * px[p] + M[p][9] * py[p] + M[p][10] * pz[p] + M[p][11]) * inv + gz;
+    a.d_xyz[3 * n] = (ax - px[p]) * m; a.d_xyz[3 * n + 1] = (ay - py[p]) * m; a.d_xyz[3 * n + 2] = (az - pz[p]) * m;
+    reinterpret_cast<float4*>(a.d_rot)[n] = make_float4(qa[p][0] * inv * m, qa[p][1] * inv * m, qa[p][2] * inv * m, qa[p][3] * inv * m);
+  }
+}
+
 // Backward.  Per bone 13 sums over the Gaussians: dG_k (12) = sum_n w_nk * (ghat_n (x) [x_n;1]) and
 // drho_k = sum_n dL/dv_nk * u_nk * d2_nk * exp(-2 rho_k).
 // This thread-per-Gaussian kernel serves the top-K configuration (K > 0, skeleton_warp.py:46-49: every Gaussian has its
@@ -695,6 +797,15 @@ static int fill_lbs(LbsArgs& a, int32_t N, int32_t J, int32_t K, const float* x,
 static bool lbs_two_per_thread(int N, int J) { return N >= LBS_PTS2_MIN_N && J >= LBS_PTS2_MIN_J; }
 
 static unsigned lbs_grid(int N, int pts) { return (unsigned)((N + 256 * pts - 1) / (256 * pts)); }
+// The bone records through the scalar cache (lbs_forward_scalar_kernel) where that wins: the large, many-joint scenes whose loop is
+// bound by the LDS handing every wave the records (2 M x 64: 129 -> 104 us; at 300 k x 24 the extra one-workgroup launch in front
+// costs what the loop gains: 13.0 against 15.9 us — tools/lbs_scalar_ab.py); the caller must have handed over a table
+// (riggs_lbs_bone_table_bytes).  riggs_set_option("lbs_scalar", 1) forces it at every size (the A/B), -1 forbids it.
+static bool lbs_use_scalar(const LbsArgs& a, const void* bone_table) {
+  if (!bone_table || a.K > 0 || a.weight_mod) return false;
+  const int o = option(OPT_LBS_SCALAR);
+  return o > 0 || (o == 0 && lbs_two_per_thread(a.N, a.J));
+}
 // the forward's weight_mod tile (one Gaussian per thread, up to 47 bones: 48 KB; beyond, the rows are read from global memory)
 static size_t lbs_mod_lds(LbsArgs& a, int pts) {
   a.mod_lds = (a.weight_mod && pts == 1 && a.J - 1 <= 47) ? 1 : 0;
@@ -704,7 +815,7 @@ static size_t lbs_mod_lds(LbsArgs& a, int pts) {
 int riggs_lbs_forward(int32_t N, int32_t J, int32_t K, const float* x, const float* joints, const int32_t* parents,
                       const float* node_radius_log, const float* transforms, const float* node_rot,
                       const float* global_trans, const float* motion_mask, const float* weight_mod, float* d_xyz,
-                      float* d_rotation, float* nn_weight, int64_t* nn_idx, riggs_stream stream) {
+                      float* d_rotation, float* nn_weight, int64_t* nn_idx, void* bone_table, riggs_stream stream) {
   LbsArgs a;
   int rc = fill_lbs(a, N, J, K, x, joints, parents, node_radius_log, transforms, node_rot, global_trans, motion_mask);
   if (rc) return rc;
@@ -712,6 +823,17 @@ int riggs_lbs_forward(int32_t N, int32_t J, int32_t K, const float* x, const flo
   a.weight_mod = weight_mod;
   RIGGS_REQUIRE(weight_mod == nullptr || K <= 0, "weight_mod is supported with K = -1 (all bones) only");
   if (N == 0) return 0;
+  if (lbs_use_scalar(a, bone_table) && !nn_weight && !nn_idx) {
+    Bone* table = (Bone*)bone_table;
+    hipLaunchKernelGGL(lbs_bone_table_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, table);
+    {
+      ProfScope ps(PROF_LBS_FWD, (hipStream_t)stream);
+      if (lbs_two_per_thread(N, J)) hipLaunchKernelGGL((lbs_forward_scalar_kernel<2>), dim3(lbs_grid(N, 2)), dim3(256), 0, (hipStream_t)stream, a, table);
+      else hipLaunchKernelGGL((lbs_forward_scalar_kernel<1>), dim3(lbs_grid(N, 1)), dim3(256), 0, (hipStream_t)stream, a, table);
+    }
+    RIGGS_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
   {
     ProfScope ps(PROF_LBS_FWD, (hipStream_t)stream);
     if (a.K > 0) hipLaunchKernelGGL((lbs_forward_kernel<true, false, 1>), dim3(lbs_grid(N, 1)), dim3(256), 0, (hipStream_t)stream, a);
@@ -725,7 +847,7 @@ int riggs_lbs_forward(int32_t N, int32_t J, int32_t K, const float* x, const flo
 int riggs_lbs_forward_fk(int32_t N, int32_t J, int32_t K, const float* x, const float* joints, const int32_t* parents,
                          const float* node_radius_log, const float* local_rot, const float* global_trans,
                          const float* motion_mask, const float* weight_mod, float* transforms, float* node_rot, float* d_nodes,
-                         float* d_xyz, float* d_rotation, riggs_stream stream) {
+                         float* d_xyz, float* d_rotation, void* bone_table, riggs_stream stream) {
   LbsArgs a;
   int rc = fill_lbs(a, N, J, K, x, joints, parents, node_radius_log, transforms, node_rot, global_trans, motion_mask);
   if (rc) return rc;
@@ -735,6 +857,17 @@ int riggs_lbs_forward_fk(int32_t N, int32_t J, int32_t K, const float* x, const 
   RIGGS_REQUIRE(weight_mod == nullptr || K <= 0, "weight_mod is supported with K = -1 (all bones) only");
   RIGGS_REQUIRE(local_rot && transforms && node_rot && d_nodes, "riggs_lbs_forward_fk needs the pose and the three chain outputs");
   if (N == 0) return riggs_fk_forward(J, local_rot, joints, parents, global_trans, transforms, node_rot, d_nodes, stream);
+  if (lbs_use_scalar(a, bone_table)) {
+    Bone* table = (Bone*)bone_table;
+    hipLaunchKernelGGL(lbs_fk_table_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, table);
+    {
+      ProfScope ps(PROF_LBS_FWD, (hipStream_t)stream);
+      if (lbs_two_per_thread(N, J)) hipLaunchKernelGGL((lbs_forward_scalar_kernel<2>), dim3(lbs_grid(N, 2)), dim3(256), 0, (hipStream_t)stream, a, table);
+      else hipLaunchKernelGGL((lbs_forward_scalar_kernel<1>), dim3(lbs_grid(N, 1)), dim3(256), 0, (hipStream_t)stream, a, table);
+    }
+    RIGGS_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
   {
     ProfScope ps(PROF_LBS_FWD, (hipStream_t)stream);
     if (a.K > 0) hipLaunchKernelGGL((lbs_forward_kernel<true, true, 1>), dim3(lbs_grid(N, 1)), dim3(256), 0, (hipStream_t)stream, a);
@@ -744,6 +877,8 @@ int riggs_lbs_forward_fk(int32_t N, int32_t J, int32_t K, const float* x, const 
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
 }
+
+size_t riggs_lbs_bone_table_bytes(void) { return sizeof(Bone) * MAX_J; }
 
 size_t riggs_lbs_backward_workspace_bytes(int32_t N, int32_t J) {
   const size_t blocks = (size_t)(N > 0 ? (N + LB_GPB - 1) / LB_GPB : 1);

@@ -18,7 +18,7 @@ int riggs_frame_forward(const riggs_frame* f, riggs_stream s) {
                                   f->b_tr, f->t, f->rot_bias4, f->sync_state, f->acts, f->local_rot, f->global_trans, s);
   if (rc) return rc;
   rc = riggs_lbs_forward_fk(N, f->num_joints, f->K, f->xyz, f->joints, f->parents, f->node_radius_log, f->local_rot, f->global_trans,
-                            f->motion_mask, f->weight_mod, f->transforms, f->node_rot, f->d_nodes, f->d_xyz, f->d_rotation, s);
+                            f->motion_mask, f->weight_mod, f->transforms, f->node_rot, f->d_nodes, f->d_xyz, f->d_rotation, nullptr, s);
   if (rc) return rc;
   RIGGS_REQUIRE(f->cfg.glue != 0, "riggs_frame_forward: the frame entry takes the RAW Gaussian parameters (cfg.glue = 1)");
   rc = riggs_raster_preprocess(&f->cfg, f->xyz, f->features_dc, f->features_rest, nullptr, f->opacity, f->scaling, f->rotation, nullptr,

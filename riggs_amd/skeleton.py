@@ -271,6 +271,18 @@ def fk_forward(local_rot, joints, parents_i32, global_trans):
     return transforms, node_rot, d_nodes
 
 
+_LBS_TABLE_MIN_N = 1_000_000  # (csrc/deform.hip: LBS_PTS2_MIN_N — below it the library keeps the bone records in LDS anyway)
+
+
+def _bone_table(N: int, device):
+    """Scratch for the skinning forward's bone table (``riggs_lbs_bone_table_bytes``; include/riggs_hip.h: bone_table) — handed
+    over for the scenes large enough for the library to use it, or whenever ``riggs_set_option("lbs_scalar", 1)`` asks for the form.
+    A fresh tensor per call: stream-ordered like every other buffer of the call, owned by the graph when captured."""
+    if N < _LBS_TABLE_MIN_N and L.OPTIONS_SET.get("lbs_scalar", 0) <= 0:
+        return None
+    return torch.empty(int(L.lib().riggs_lbs_bone_table_bytes()), dtype=torch.uint8, device=device)
+
+
 def lbs_forward(x, joints, parents_i32, rho, transforms, node_rot, global_trans, mask, K=-1, want_weights=False,
                 weight_mod=None):
     N, J = x.shape[0], joints.shape[0]
@@ -283,7 +295,7 @@ def lbs_forward(x, joints, parents_i32, rho, transforms, node_rot, global_trans,
     L.check(L.lib().riggs_lbs_forward(N, J, K, x.data_ptr(), joints.data_ptr(), parents_i32.data_ptr(), rho.data_ptr(),
                                       transforms.data_ptr(), node_rot.data_ptr(), global_trans.data_ptr(), L.ptr(mask),
                                       L.ptr(weight_mod), d_xyz.data_ptr(), d_rot.data_ptr(), L.ptr(w), L.ptr(idx),
-                                      L.stream_ptr()),
+                                      L.ptr(_bone_table(N, x.device)), L.stream_ptr()),
             "riggs_lbs_forward")
     return d_xyz, d_rot, w, idx
 
@@ -388,7 +400,7 @@ class _PoseDeform(torch.autograd.Function):
         L.check(lib.riggs_lbs_forward_fk(N, J, K, x.data_ptr(), joints.data_ptr(), parents_i32.data_ptr(), rho.data_ptr(),
                                          local_rot.data_ptr(), global_trans.data_ptr(), L.ptr(mflat), L.ptr(weight_mod),
                                          transforms.data_ptr(), node_rot.data_ptr(), d_nodes.data_ptr(), d_xyz.data_ptr(),
-                                         d_rot.data_ptr(), st), "riggs_lbs_forward_fk")
+                                         d_rot.data_ptr(), L.ptr(_bone_table(N, x.device)), st), "riggs_lbs_forward_fk")
         ctx.save_for_backward(acts, local_rot, global_trans, rho, mflat, x, joints, parents_i32, transforms, node_rot, weight_mod,
                               *params)
         ctx.cfg = (depth, width, multires, skip, n_rot, K)

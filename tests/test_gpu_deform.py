@@ -140,6 +140,32 @@ def test_deform_forward_values_vs_oracle_at_both_sides_of_the_two_per_lane_switc
         U.assert_close(dx[256:512], ox[256:512], "d_xyz second half of the first 512-block (%s)" % tag, 2e-5)
 
 
+@pytest.mark.parametrize("N,J", [(1, 2), (257, 8), (40_003, 24), (70_001, 64)])
+def test_scalar_bone_records_give_the_same_bits_as_the_lds_form(N, J):
+    """riggs_set_option("lbs_scalar", 1): the all-bones skinning forward with the bone records read through the scalar cache (a
+    one-workgroup table launch in front — with the kinematic chain inside it in the _fk entry) — against the LDS form
+    ("lbs_scalar" -1): identical bits in d_xyz / d_rotation / d_nodes and the chain's outputs, through both entry points; the default
+    (0) picks by size and is what the million-Gaussian tests above run."""
+    from riggs_amd import _lib as L
+    sc = synth.make_scene(N, J, 5 + J)
+    mask = torch.rand(N, 1, generator=torch.Generator().manual_seed(N)).cuda()
+    sw = make_warp(sc["joints"], sc["parents"], sc["node_radius"], -1)
+    x = sc["xyz"].cuda()
+    res = {}
+    try:
+        for flag in (-1, 1):
+            L.set_option("lbs_scalar", flag)
+            with torch.no_grad():
+                h = sw.deform_by_pose(x, {"local_rotation": sc["local_rotation"].cuda(), "global_trans": sc["global_trans"].cuda()}, mask)
+                f = sw(x, sw.expand_time(torch.tensor([0.41], device="cuda")), motion_mask=mask)
+            res[flag] = [t.clone() for t in (h["d_xyz"], h["d_rotation"], h["d_nodes"], f["d_xyz"], f["d_rotation"], f["d_nodes"],
+                                             f["local_rotation"])]
+    finally:
+        L.set_option("lbs_scalar", 0)
+    for a, b in zip(res[-1], res[1]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("keep", [0.0, 0.05, 0.5])
 def test_deform_backward_with_sparse_incoming_gradient(keep):
     """The LBS backward walks only the Gaussians whose incoming gradient is non-zero (most of a deep scene gets none
