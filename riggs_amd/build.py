@@ -11,6 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 SO = os.path.join(LIBDIR, "libriggs_hip.so")
+TORCH_SO = os.path.join(LIBDIR, "libriggs_torch.so")
+TORCH_SRC = os.path.join(HERE, "csrc_torch", "riggs_torch.cpp")
 
 # translation unit -> extra flags.  preprocess.hip must keep FP contraction off (bit-exact
 # geometry vs. the CPU oracle); the compositing kernels want FMAs.
@@ -85,5 +87,28 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return SO
 
 
+def build_torch(force: bool = False, verbose: bool = False) -> str:
+    """libriggs_torch.so: the PyTorch front-end (csrc_torch/riggs_torch.cpp — TORCH_LIBRARY ops whose autograd nodes call the C ABI
+    of libriggs_hip.so), host C++ only: g++ against torch's headers and libraries, linked to libriggs_hip.so next to it ($ORIGIN).
+    Optional at run time (riggs_amd/_torch_ext.py falls back to the ctypes nodes), built by __graft_entry__.build()."""
+    import torch
+    from torch.utils import cpp_extension as X
+    build(force=False, verbose=verbose)
+    header = os.path.join(os.path.dirname(HERE), "include", "riggs_hip.h")
+    if not (force or _stale(TORCH_SO, [TORCH_SRC, header, SO])):
+        return TORCH_SO
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI), "-Wall", "-Wno-unused-function", TORCH_SRC, "-o", TORCH_SO]
+    cmd += ["-I" + i for i in X.include_paths()] + ["-I" + os.path.join(rocm, "include")]
+    cmd += ["-L" + l for l in X.library_paths()] + ["-L" + LIBDIR, "-Wl,-rpath,$ORIGIN"]
+    cmd += ["-lriggs_hip", "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_hip"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return TORCH_SO
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_torch(force="--force" in sys.argv, verbose=True))

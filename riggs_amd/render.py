@@ -118,6 +118,37 @@ class _FusedGlueRaster(torch.autograd.Function):
                 g_ds, None, None, None)
 
 
+def _extension_frame(settings, pc, arena, dx, dr, ds, scaling, iso, screenspace_points):
+    """The default branch through the PyTorch extension's node (csrc_torch/riggs_torch.cpp: torch.ops.riggs.glue_raster) when the call
+    is the plain eager training frame: an arena that already knows the previous frame's instance count (so that no host read is
+    needed), no registered gradient bucket, no capture, no ordered backward, no sparse rows, no ``pipe.debug``.  The arena policy —
+    sizing, the asynchronous read-back of the count, overflow reporting — stays here, with ``RasterArena``.  None = take the ctypes
+    node."""
+    from . import _torch_ext as TX
+    from . import rasterizer as R
+    from .dist import _SLICES, _entry
+    if (arena is None or arena.last_R < 0 or arena.sparse_grad_rows or R.ORDERED_BACKWARD or settings.debug
+            or not TX.active() or not pc._xyz.is_cuda):
+        return None
+    if _SLICES and any(_entry(p) is not None for p in (pc._xyz, pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, pc._rotation)):
+        return None  # (these parameters' gradients belong into a registered flat bucket: the ctypes node writes them there)
+    N, dev = pc._xyz.shape[0], pc._xyz.device
+    H, W = int(settings.image_height), int(settings.image_width)
+    arena.resolve(block=True)
+    binning = arena.ensure(int(arena.last_R * arena.growth) + 1, N, H, W, dev)
+    cap = arena.capacity
+    ws = R._backward_workspace(L.lib().riggs_raster_backward_workspace_bytes(N), dev, N)
+    bg = settings.bg if settings.bg.device == dev else settings.bg.to(dev)
+    color, radii, depth, alpha, counters = torch.ops.riggs.glue_raster(
+        pc._xyz, screenspace_points, pc._features_dc, pc._features_rest, pc._opacity, scaling, pc._rotation, dx, dr, ds, bg,
+        settings.viewmatrix, settings.projmatrix, settings.campos, binning, ws, cap, H, W, float(settings.tanfovx),
+        float(settings.tanfovy), float(settings.scale_modifier), int(settings.sh_degree), False, iso, bool(arena.tight_lists))
+    arena._post(counters, cap)
+    R._LAST_WORKSPACE[:] = [ws, N]
+    R._LAST_SPARSE_OUTPUTS[:] = []
+    return color, radii, depth, alpha
+
+
 def _is_zero_scalar(v):
     return (not isinstance(v, torch.Tensor)) and float(v) == 0.0
 
@@ -148,9 +179,13 @@ def render(viewpoint_camera, pc, pipe, bg_color, d_xyz, d_rotation, d_scaling, d
         ds = None if _is_zero_scalar(d_scaling) else d_scaling
         iso = bool(getattr(pc, "use_isotropic_gs", False))
         scaling = pc._scaling[..., :1] if iso else pc._scaling
-        color, radii, depth, alpha = _FusedGlueRaster.apply(
-            pc._xyz, screenspace_points, pc._features_dc, pc._features_rest, pc._opacity, scaling, pc._rotation,
-            dx, dr, ds, settings, iso, arena)
+        fast = _extension_frame(settings, pc, arena, dx, dr, ds, scaling, iso, screenspace_points)
+        if fast is not None:
+            color, radii, depth, alpha = fast
+        else:
+            color, radii, depth, alpha = _FusedGlueRaster.apply(
+                pc._xyz, screenspace_points, pc._features_dc, pc._features_rest, pc._opacity, scaling, pc._rotation,
+                dx, dr, ds, settings, iso, arena)
         return RenderPkg({"render": color, "viewspace_points": screenspace_points, "visibility_filter": None,
                           "radii": radii, "depth": depth, "alpha": alpha, "bg_color": bg})
 

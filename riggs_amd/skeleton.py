@@ -780,9 +780,21 @@ class SkeletonWarp(nn.Module):
             else:
                 pn.watch()
             self._fixed_folded = getattr(self, "template_fixed", None) is not None
-            d_xyz, d_rot, d_nodes, local_rot, global_trans, transforms, node_rot = _PoseDeform.apply(
-                _time.reshape(1), self._rot_bias, sync, self._node_radius, mask, x, joints, par, self.K, weight_mod,
-                getattr(self, "template_fixed", None), len(pn.net), pn.net[0].out_features, pn.multires, pn.skips[0], *params)
+            from . import _torch_ext as TX
+            from .dist import _SLICES, _entry
+            if (TX.active() and x.is_cuda and _time.is_cuda
+                    and (not _SLICES or (_entry(self._node_radius) is None and all(_entry(p_) is None for p_ in params)))):
+                # the same node in C++ (csrc_torch/riggs_torch.cpp: torch.ops.riggs.pose_deform) — an eagerly issued frame is
+                # host-bound; with a registered gradient bucket or inside a capture the ctypes node below runs
+                fx = getattr(self, "template_fixed", None)
+                d_xyz, d_rot, d_nodes, local_rot, global_trans, transforms, node_rot = torch.ops.riggs.pose_deform(
+                    _time.reshape(1), self._rot_bias, sync, self._node_radius, mask, x, joints, par, weight_mod,
+                    fx[0] if fx else None, fx[1] if fx else None, _bone_table(x.shape[0], x.device), self.K, len(pn.net),
+                    pn.net[0].out_features, pn.multires, pn.skips[0], params)
+            else:
+                d_xyz, d_rot, d_nodes, local_rot, global_trans, transforms, node_rot = _PoseDeform.apply(
+                    _time.reshape(1), self._rot_bias, sync, self._node_radius, mask, x, joints, par, self.K, weight_mod,
+                    getattr(self, "template_fixed", None), len(pn.net), pn.net[0].out_features, pn.multires, pn.skips[0], *params)
             node_attrs = {"local_rotation": local_rot, "global_trans": global_trans, "t": _time}
         else:
             d_xyz, d_rot, d_nodes, transforms, node_rot = _DeformByPose.apply(
