@@ -276,6 +276,66 @@ __device__ __forceinline__ FwLateArgs* fw_late_args() {
   return p;
 }
 
+// the end of a work item: the block's pixels leave, and the tile's last block appends the backward's work
+template <int LPP>
+__device__ __forceinline__ void fw_finish(const int tile, const int total, const uint2 range, const bool inside, const int pxi, const int pyi,
+                                          const float k0, const float k1, const float k2, const float kd, const float ka, const float Tfin,
+                                          const uint32_t lm) {
+  constexpr int LEAD = FwGeom<LPP>::LEAD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & (LPP - 1);
+  {
+    FwLateArgs& l = *fw_late_args();
+    if (inside && i == LEAD) {
+      const size_t pid = (size_t)pyi * l.W + pxi, HW = (size_t)l.H * l.W;
+      l.final_T[pid] = Tfin;
+      l.n_contrib[pid] = lm;
+      l.final_acc[pid] = make_float4(k0, k1, k2, kd);
+      l.out_color[pid] = k0 + Tfin * l.bg[0];
+      l.out_color[HW + pid] = k1 + Tfin * l.bg[1];
+      l.out_color[2 * HW + pid] = k2 + Tfin * l.bg[2];
+      l.out_depth[pid] = kd;
+      l.out_alpha[pid] = ka;
+    }
+  }
+  uint32_t m = (inside && i >= LEAD) ? lm : 0u;
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+  if (lane == 0) fw_wmax[wave] = m;
+  __syncthreads();  // (fw_wmax is complete)
+  // ---- work list of the backward.  A tile's instances past its last contributor (tile_max = max n_contrib over its 256
+  // pixels) need no backward, so the list holds one entry per 64-instance chunk below it.  Every block of the tile folds
+  // its maximum into tile_max and takes a ticket; the block that draws the last ticket knows the final value and appends
+  // the tile's entries (tile, chunk, start of the tile's list, instances to walk) — a separate list-building launch used to
+  // cost 10 us.  Both words are only ever touched with agent-scope atomics, and a block takes its ticket after its
+  // maximum has RETURNED (the returning atomic has been performed), so the last ticket holder reads the final maximum.
+  // The list's size word (work_ctr) lives on a cache line of ITS OWN: sharing one with item_ctr — which every one of the
+  // launch's 20 000 workgroups reads when it starts — cost 17 us (each of the ~470 atomics throws the line out of the L2s,
+  // and the late-dispatched workgroups queue behind it at the memory side).
+  // Only wave 0 stays for this (two dependent atomic round trips to the memory side, ~4 us): the other three waves leave.
+  if (wave == 0) {
+    FwLateArgs& l = *fw_late_args();
+    uint32_t n_c = 0u, wbase = 0u, limit = 0u;
+    if (lane == 0) {
+      const uint32_t mb = max(max(fw_wmax[0], fw_wmax[1]), max(fw_wmax[2], fw_wmax[3]));
+      const uint32_t before = __hip_atomic_fetch_max(&l.tile_max[tile], mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const uint32_t ticket = __hip_atomic_fetch_add(&l.tile_ticket[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (ticket == (uint32_t)LPP - 1u) {  // LPP blocks of 256 / LPP pixels per tile
+        limit = max(max(before, mb), __hip_atomic_load(&l.tile_max[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        limit = min((uint32_t)total, limit);
+        // (for this view's next frame's work list: how deep this tile's walk went — into the slot the tile sort chose)
+        l.walk_hist[RIGGS_HIST_HDR + (size_t)l.walk_hist[1] * l.hist_slot_words + tile] = limit;
+        n_c = (limit + 63u) >> 6;
+        if (n_c) wbase = __hip_atomic_fetch_add(l.work_ctr, 4u * n_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 2;  // (quarter-chunks)
+      }
+    }
+    n_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_c);
+    wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+    limit = (uint32_t)__builtin_amdgcn_readfirstlane((int)limit);
+    for (uint32_t k = lane; k < n_c; k += 64) l.work[wbase + k] = make_uint4((uint32_t)tile, k, range.x, limit);
+  }
+}
+
 // one work item: a block of 256 / LPP pixels of one tile (LPP = 8: 8 x 4, one pixel row per wave; LPP = 32: 4 x 2, two
 // neighbouring pixels per wave), its list walked front to back
 template <int LPP, bool TRACE>
@@ -378,56 +438,201 @@ __device__ __forceinline__ void fw_block(const RenderArgs& a, const int tile, co
   const float ts = grp_max<LPP>(w.Tstop);
   const uint32_t lm = grp_max_u<LPP>(w.last);
   const float Tfin = (ts >= 0.f) ? ts : w.T;
-  {
-    FwLateArgs& l = *fw_late_args();
-    if (inside && i == LEAD) {
-      const size_t pid = (size_t)pyi * l.W + pxi, HW = (size_t)l.H * l.W;
-      l.final_T[pid] = Tfin;
-      l.n_contrib[pid] = lm;
-      l.final_acc[pid] = make_float4(k0, k1, k2, kd);
-      l.out_color[pid] = k0 + Tfin * l.bg[0];
-      l.out_color[HW + pid] = k1 + Tfin * l.bg[1];
-      l.out_color[2 * HW + pid] = k2 + Tfin * l.bg[2];
-      l.out_depth[pid] = kd;
-      l.out_alpha[pid] = ka;
+  fw_finish<LPP>(tile, total, range, inside, pxi, pyi, k0, k1, k2, kd, ka, Tfin, lm);
+}
+
+// ---- the wide block, round 6: the round's survivors composited as ONE list, checkpoints out of the scans.
+// What a wide block's time was made of (profiles/round5_fwd_trace_dense.txt: 39 rounds of 256 entries = 96 us, ~5 500 clocks per
+// round): ~7 of a round's 256 entries survive the cull against the 4 x 2 pixel box, but the round paid FOUR trips through the
+// chunk loop — a checkpoint fold of 20 DPP instructions and a scan step for one or two survivors in 32 lanes each: ~860 clocks a
+// trip, 3 400 of the round's 5 500, a lone wave per SIMD waiting out every latency.  Here the survivors of the round's four
+// chunks are walked as one list in list order (lane j of a step finds its record in the chunk's compacted region through the
+// chunks' counts: no second compaction, no further barrier), a scan step takes 32 of them whatever chunks they come from, and
+// the checkpoint of chunk k — the state in front of the chunk's first instance — is the EXCLUSIVE state of the first survivor at
+// or behind the chunk's start: the step computes exclusive prefixes anyway (the transmittance product as before, the colour /
+// depth sums as four more DPP scans on top of running totals that are kept folded), and lane LEAD + k of the pixel's group
+// fetches its chunk's values from that survivor's lane (ds_bpermute); a chunk without a later survivor takes the state behind
+// the round.  Same arithmetic per (pixel, instance) as the 8-lane form, sums folded in another order (as the wide form always
+// did).  (Built first with rounds of 1024 entries — four per thread, only position + y extent gathered for the cull, the
+// survivors' records fetched behind it: 38 spilled registers under this kernel's 80, 0.482 -> 0.520 ms on the opaque-skin scene;
+// a kernel of its own would serialise behind the 8-lane blocks it overlaps with today.)
+// four inclusive sum scans over the 32 lanes of a pixel's group at once (two rows of 16; the chains fill each other's DPP slots)
+__device__ __forceinline__ void fww_scan4(float& a, float& b, float& c, float& d) {
+#define FWW_S4(CTRL) \
+  "v_add_f32_dpp %0, %0, %0 " CTRL "\n\tv_add_f32_dpp %1, %1, %1 " CTRL "\n\tv_add_f32_dpp %2, %2, %2 " CTRL "\n\tv_add_f32_dpp %3, %3, %3 " CTRL "\n\t"
+  asm volatile(
+      "s_nop 1\n\t"
+      FWW_S4("row_shr:1 row_mask:0xf bank_mask:0xf")
+      FWW_S4("row_shr:2 row_mask:0xf bank_mask:0xf")
+      FWW_S4("row_shr:4 row_mask:0xf bank_mask:0xf")
+      FWW_S4("row_shr:8 row_mask:0xf bank_mask:0xf")
+      FWW_S4("row_bcast:15 row_mask:0xa bank_mask:0xf")
+      "s_nop 0"
+      : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef FWW_S4
+}
+__device__ __forceinline__ float fww_lane(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ float fww_fetch(float v, int byte_addr) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
+}
+
+template <bool TRACE>
+__device__ __forceinline__ void fw_block_wide(const RenderArgs& a, const int tile, const int sub, const int index) {
+  constexpr int LPP = 32, LEAD = FwGeom<32>::LEAD, B = FW_B;
+  const int gx = (a.W + RIGGS_TILE - 1) / RIGGS_TILE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & (LPP - 1), half = lane & 32;
+  const int brow = (sub >> 2) * 2, bcol = (sub & 3) * 4;
+  const int pp = wave * 2 + (lane >> 5);
+  const int prow = brow + (pp >> 2), pcol = bcol + (pp & 3);
+  const int pxi = (tile % gx) * RIGGS_TILE + pcol, pyi = (tile / gx) * RIGGS_TILE + prow;
+  const bool inside = pxi < a.W && pyi < a.H;
+  const int pix = prow * 16 + pcol;
+  const float pfx = (float)pxi, pfy = (float)pyi;
+  const uint2 range = a.ranges[tile];
+  const int total = (int)(range.y - range.x);
+  const uint32_t slot0 = a.slot_base[tile];
+  const float bx0 = (float)((tile % gx) * RIGGS_TILE + bcol), by0 = (float)((tile / gx) * RIGGS_TILE + brow);
+  // the pixel's state: transmittance and the FOLDED sums (the same in every lane of the group); alpha and the stop
+  // bookkeeping as in the other form
+  float T = 1.0f, R0 = 0.f, R1 = 0.f, R2 = 0.f, RD = 0.f, accA = 0.f, Tstop = -1.0f;
+  uint32_t last = 0u;
+  bool done = !inside;
+  const unsigned long long t_begin = (TRACE && a.trace) ? wall_clock64() : 0ull;
+  uint32_t st_rounds = 0, st_surv = 0, st_iters = 0, st_full = 0;
+  // checkpoints of the round's four chunks: lane LEAD + k of the group holds chunk k's until the next round's flush
+  float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;
+  bool hv = false, hres = true;
+  int hbase = 0;
+  auto flush_ckpt = [&]() {
+    if (hv) {
+      float* ck = a.ckpt + ((size_t)(slot0 + (hbase >> 6) + (i - LEAD)) * 5) * 256 + pix;
+      ck[0] = h0; ck[256] = h1; ck[512] = h2; ck[768] = h3; ck[1024] = h4;
     }
+    hv = false;
+  };
+  const uint32_t last_entry = range.y - 1u;
+  float4 n_xy, n_co, n_cc;
+  uint32_t n_id = a.point_list[min(range.x + (uint32_t)(B + tid), last_entry)];
+  {
+    const uint32_t id = a.point_list[min(range.x + (uint32_t)tid, last_entry)];
+    n_xy = a.xyd[id]; n_co = a.conic_o[id]; n_cc = a.rgb[id];
   }
-  uint32_t m = (inside && i >= LEAD) ? lm : 0u;
-  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
-  if (lane == 0) fw_wmax[wave] = m;
-  __syncthreads();  // (fw_wmax is complete)
-  // ---- work list of the backward.  A tile's instances past its last contributor (tile_max = max n_contrib over its 256
-  // pixels) need no backward, so the list holds one entry per 64-instance chunk below it.  Every block of the tile folds
-  // its maximum into tile_max and takes a ticket; the block that draws the last ticket knows the final value and appends
-  // the tile's entries (tile, chunk, start of the tile's list, instances to walk) — a separate list-building launch used to
-  // cost 10 us.  Both words are only ever touched with agent-scope atomics, and a block takes its ticket after its
-  // maximum has RETURNED (the returning atomic has been performed), so the last ticket holder reads the final maximum.
-  // The list's size word (work_ctr) lives on a cache line of ITS OWN: sharing one with item_ctr — which every one of the
-  // launch's 20 000 workgroups reads when it starts — cost 17 us (each of the ~470 atomics throws the line out of the L2s,
-  // and the late-dispatched workgroups queue behind it at the memory side).
-  // Only wave 0 stays for this (two dependent atomic round trips to the memory side, ~4 us): the other three waves leave.
-  if (wave == 0) {
-    FwLateArgs& l = *fw_late_args();
-    uint32_t n_c = 0u, wbase = 0u, limit = 0u;
-    if (lane == 0) {
-      const uint32_t mb = max(max(fw_wmax[0], fw_wmax[1]), max(fw_wmax[2], fw_wmax[3]));
-      const uint32_t before = __hip_atomic_fetch_max(&l.tile_max[tile], mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const uint32_t ticket = __hip_atomic_fetch_add(&l.tile_ticket[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (ticket == (uint32_t)LPP - 1u) {  // LPP blocks of 256 / LPP pixels per tile
-        limit = max(max(before, mb), __hip_atomic_load(&l.tile_max[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        limit = min((uint32_t)total, limit);
-        // (for this view's next frame's work list: how deep this tile's walk went — into the slot the tile sort chose)
-        l.walk_hist[RIGGS_HIST_HDR + (size_t)l.walk_hist[1] * l.hist_slot_words + tile] = limit;
-        n_c = (limit + 63u) >> 6;
-        if (n_c) wbase = __hip_atomic_fetch_add(l.work_ctr, 4u * n_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 2;  // (quarter-chunks)
+  unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, tc = TRACE ? clock64() : 0ull;
+  auto lap = [&](unsigned long long& acc) { if constexpr (TRACE) { const unsigned long long t = clock64(); acc += t - tc; tc = t; } };
+  for (int base = 0; base < total; base += B) {
+    if (__syncthreads_count(done) == 256) break;
+    lap(ph0);
+    {
+      const int cnt = fw_stage_round<LPP>(tid, base + tid < total, n_xy, n_co, n_cc, bx0, by0);
+      if constexpr (TRACE) st_surv += (uint32_t)cnt;
+    }
+    if constexpr (TRACE) st_rounds++;
+    flush_ckpt();
+    hbase = base;
+    hres = !(i >= LEAD && i < LEAD + B / 64 && base + 64 * (i - LEAD) < total && inside);  // (this lane's chunk exists: its checkpoint is to be resolved)
+    __syncthreads();
+    lap(ph1);
+    {
+      const uint32_t id = n_id;
+      n_xy = a.xyd[id]; n_co = a.conic_o[id]; n_cc = a.rgb[id];
+      n_id = a.point_list[min(range.x + (uint32_t)(base + 2 * B + tid), last_entry)];
+    }
+    lap(ph2);
+    // the round's survivors as one list: chunk k's sit at 64 k .. 64 k + cnt_k of the staged records
+    const int p1 = fw_cnt[0], p2 = p1 + fw_cnt[1], p3 = p2 + fw_cnt[2], n_surv = p3 + fw_cnt[3];
+    const int my_idx = (i == LEAD + 1) ? p1 : ((i == LEAD + 2) ? p2 : ((i == LEAD + 3) ? p3 : 0));  // survivors in front of this lane's chunk
+    if (__builtin_amdgcn_ballot_w64(!done || !hres) != 0) {
+      for (int g = 0; g < n_surv; g += LPP) {
+        const int j0 = g + i;  // this lane's survivor
+        const int ch = (j0 >= p1 ? 1 : 0) + (j0 >= p2 ? 1 : 0) + (j0 >= p3 ? 1 : 0);
+        const int rec = 64 * ch + (j0 - (ch == 0 ? 0 : (ch == 1 ? p1 : (ch == 2 ? p2 : p3))));
+        const bool live = j0 < n_surv;
+        const int ri = live ? rec : 0;
+        const float4 xy = fw_xyd[ri];
+        const float4 c = fw_rgb[ri];
+        const float dx = xy.x - pfx, dy = xy.y - pfy;
+        const float4 co = fw_con[ri];
+        const float pw = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+        const float alpha = fminf(ALPHA_MAX, co.w * fast_exp(pw));
+        const bool valid = live && (pw <= 0.0f) && (alpha >= ALPHA_MIN) && !done;
+        if constexpr (TRACE) st_iters++;
+        const int pos1 = base + (int)fw_pos[ri] + 1;
+        const float om = valid ? 1.0f - alpha : 1.0f;
+        float inc = om, E = 1.0f;
+        asm volatile(
+            "s_nop 1\n\t"
+            "v_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+            "v_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+            "v_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+            "v_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+            "v_mul_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+            "v_mov_b32_dpp %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 0"
+            : "+v"(inc), "+v"(E));
+        E = (i == 0) ? 1.0f : E;
+        const float prod = half ? fww_lane(inc, 63) : fww_lane(inc, 31);
+        const float Tj = T * E;
+        const float test_T = Tj * om;
+        const bool sc = valid && (test_T < T_EPS);
+        const uint64_t bits = __builtin_amdgcn_ballot_w64(sc);
+        const uint32_t ob = (uint32_t)(bits >> half);
+        const bool first_stop_before = (ob & ((1u << i) - 1u)) != 0u;
+        const bool use = valid && !sc && !first_stop_before;
+        const float wt = use ? alpha * Tj : 0.f;
+        if constexpr (TRACE) st_full += (__builtin_amdgcn_ballot_w64(use) != 0) ? 1u : 0u;
+        // the sums in front of every lane: inclusive scans of the lanes' contributions on top of the folded totals
+        float s0 = c.x * wt, s1 = c.y * wt, s2 = c.z * wt, sd = xy.z * wt;
+        const float q0 = s0, q1 = s1, q2 = s2, qd = sd;
+        fww_scan4(s0, s1, s2, sd);
+        accA += wt;
+        last = use ? (uint32_t)pos1 : last;
+        if (sc && !first_stop_before) Tstop = Tj;
+        // checkpoints whose first survivor sits in this step: lane LEAD + k fetches that survivor's exclusive state
+        if (__builtin_amdgcn_ballot_w64(!hres) != 0) {
+          const int j = my_idx - g;
+          const bool mine = !hres && j >= 0 && j < LPP && my_idx < n_surv;
+          const int src = (half + (mine ? j : 0)) << 2;
+          const float f0 = fww_fetch(Tj, src), f1 = fww_fetch(R0 + (s0 - q0), src), f2 = fww_fetch(R1 + (s1 - q1), src),
+                      f3 = fww_fetch(R2 + (s2 - q2), src), f4 = fww_fetch(RD + (sd - qd), src);
+          if (mine) {
+            h0 = f0; h1 = f1; h2 = f2; h3 = f3; h4 = f4;
+            hv = !done && (ob & ((1u << j) - 1u)) == 0u;  // (the pixel has not stopped in front of that survivor)
+            hres = true;
+          }
+        }
+        const bool nostop = (ob == 0u);
+        if (!done) {
+          R0 += half ? fww_lane(s0, 63) : fww_lane(s0, 31);
+          R1 += half ? fww_lane(s1, 63) : fww_lane(s1, 31);
+          R2 += half ? fww_lane(s2, 63) : fww_lane(s2, 31);
+          RD += half ? fww_lane(sd, 63) : fww_lane(sd, 31);
+          T = nostop ? T * prod : T;
+        }
+        done = done || !nostop;
       }
     }
-    n_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_c);
-    wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
-    limit = (uint32_t)__builtin_amdgcn_readfirstlane((int)limit);
-    for (uint32_t k = lane; k < n_c; k += 64) l.work[wbase + k] = make_uint4((uint32_t)tile, k, range.x, limit);
+    // chunks without a survivor at or behind their start: the state behind the round
+    if (!hres) { h0 = T; h1 = R0; h2 = R1; h3 = R2; h4 = RD; hv = !done; hres = true; }
+    lap(ph3);
   }
+  if (TRACE && a.trace && lane == 0 && (uint64_t)index < fw_late_args()->trace_items) {
+    unsigned long long* tr = a.trace + ((size_t)index * 4 + wave) * 8;
+    tr[6] = t_begin;
+    tr[0] = wall_clock64() - t_begin; tr[1] = st_rounds;
+    tr[2] = (unsigned long long)st_surv | ((unsigned long long)(__builtin_amdgcn_s_getreg(63492) & 0xFFFFu) << 32) | ((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 0xFu) << 48);
+    tr[3] = st_iters; tr[4] = st_full;
+    tr[5] = (unsigned long long)total | ((unsigned long long)tile << 32) | (1ull << 63);
+    tr[7] = min(ph0 >> 6, 0xFFFFull) | (min(ph1 >> 6, 0xFFFFull) << 16) | (min(ph2 >> 6, 0xFFFFull) << 32) | (min(ph3 >> 6, 0xFFFFull) << 48);
+  }
+  flush_ckpt();
+  const float ka = grp_sum<LPP>(accA);
+  const float ts = grp_max<LPP>(Tstop);
+  const uint32_t lm = grp_max_u<LPP>(last);
+  const float Tfin = (ts >= 0.f) ? ts : T;
+  fw_finish<LPP>(tile, total, range, inside, pxi, pyi, R0, R1, R2, RD, ka, Tfin, lm);
 }
 
 template <bool TRACE>
@@ -464,7 +669,7 @@ __global__ __launch_bounds__(256, 6) void render_fwd_oct_kernel(RenderArgs a) {
     int p, sub;
     if (it < full) { p = ((it >> 8) << 3) + (it & 7); sub = (it >> 3) & 31; }
     else { p = (full >> 5) + ((it - full) >> 5); sub = (it - full) & 31; }
-    fw_block<32, TRACE>(a, (int)a.items[p], sub, it);
+    fw_block_wide<TRACE>(a, (int)a.items[p], sub, it);
   } else {
     const int j = it - wide_items, n_items = (n_entries - n_wide) * 8, full = (n_items >> 6) << 6;
     if (j >= n_items) return;

@@ -122,3 +122,19 @@ def test_pose_mlp_sync_buffer_is_as_large_as_the_library_wants():
         net = PoseMLP(1, joints * 4, hidden_dimensions=width, depth=depth)
         assert net._hip_sync.numel() * 4 >= L.lib().riggs_pose_mlp_sync_bytes(depth, width)
         assert int(L.lib().riggs_pose_mlp_status_word(depth, width)) + 1 < net._hip_sync.numel()
+
+
+def test_torch_extension_loads_and_registers_its_ops():
+    """lib/libriggs_torch.so (riggs_amd/csrc_torch/riggs_torch.cpp; built by __graft_entry__.build()): loads next to libriggs_hip.so
+    without a GPU, speaks the library's ABI version and registers the two nodes' ops (no compute call here)."""
+    import torch
+    from riggs_amd import _lib as L
+    from riggs_amd import _torch_ext as TX
+    from riggs_amd import build as B
+    B.build_torch()
+    assert TX.available()
+    assert int(torch.ops.riggs.abi_version()) == int(L.lib().riggs_version())
+    for name in ("pose_deform", "glue_raster"):
+        assert hasattr(torch.ops.riggs, name)
+    sch = str(torch.ops.riggs.glue_raster.default._schema)
+    assert "Tensor? d_xyz" in sch or "Tensor?" in sch
