@@ -299,9 +299,35 @@ def dense_scene_timing(dev, steps=50):
     dt = (time.perf_counter() - t0) / steps
     R = gf.check()
     with_grad = float((gm._opacity.grad.reshape(-1) != 0).float().mean())
-    return {"value": round(1.0 / dt, 2), "unit": "iters/s", "ms_per_step": round(dt * 1e3, 4), "tile_instances_R": int(R),
-            "gaussians_with_gradient": round(with_grad, 4), "visible": round(float((out["radii"] > 0).float().mean()), 4),
-            "what": "same path / sizes / form of the graph (sparse gradient rows), thin opaque skin around the bones (synth.make_surface_scene); not the headline metric"}
+    res = {"value": round(1.0 / dt, 2), "unit": "iters/s", "ms_per_step": round(dt * 1e3, 4), "tile_instances_R": int(R),
+           "gaussians_with_gradient": round(with_grad, 4), "visible": round(float((out["radii"] > 0).float().mean()), 4),
+           "what": "same path / sizes / form of the graph (sparse gradient rows), thin opaque skin around the bones (synth.make_surface_scene); not the headline metric"}
+    # this scene's kernels (the library's HIP-event timers around eagerly issued frames, each frame behind a spinning kernel so
+    # that its launches queue: the duration of a kernel BEHIND another kernel, as in the graph; every gradient row written)
+    import ctypes as C
+    from riggs_amd import _lib as L
+    from riggs_amd.rasterizer import RasterArena
+    gimg = torch.sign(out["render"].detach() - target) / (3 * w["H"] * w["W"])
+    del gf
+    lib = L.lib()
+    step = make_step(cam, gm, sw, gimg, RasterArena(tight_lists=_tight()), 1, None)
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    lib.riggs_prof_reset()
+    lib.riggs_prof_enable(0xFFFFFFFF)
+    for _ in range(12):
+        torch.cuda._sleep(2_000_000)
+        step()
+        torch.cuda.synchronize()
+    lib.riggs_prof_enable(0)
+    tot, cnt, us = C.c_float(0), C.c_int32(0), {}
+    for i in range(lib.riggs_prof_count()):
+        L.check(lib.riggs_prof_read(i, C.byref(tot), C.byref(cnt)), "riggs_prof_read")
+        if cnt.value:
+            us[lib.riggs_prof_name(i).decode()] = round(1e3 * tot.value / cnt.value, 1)
+    res["kernels_us"] = us
+    return res
 
 
 LISTS = "canonical"  # (--lists)
@@ -763,7 +789,7 @@ def pinned_cus_soak(gf_one_xcd, dev, gm, sw, cam, bg, params, gimg, counts=(16, 
         cur.synchronize()
         dt = (time.perf_counter() - t0) / n * 1e3
         word = int(st[0][st[1]].item()) if st is not None else None
-        flags = int(gf.arena.static_counters[1].item()) & 3
+        arena_flags = int(gf.arena.static_counters[1].item()) & 3
         with torch.cuda.stream(ctrl):
             stop.fill_(1)
         ctrl.synchronize()
@@ -771,7 +797,7 @@ def pinned_cus_soak(gf_one_xcd, dev, gm, sw, cam, bg, params, gimg, counts=(16, 
         side.synchronize()
         if k and time.perf_counter() - t_stop > 1.0:
             raise RuntimeError("the CU pinner did not see its stop word")
-        return {"pinned_cus_resident": resident, "ms_per_step": round(dt, 4), "pose_handoff_timeouts_word": word, "arena_flags": flags,
+        return {"pinned_cus_resident": resident, "ms_per_step": round(dt, 4), "pose_handoff_timeouts_word": word, "arena_flags": arena_flags,
                 "probe_gemm_ms": round(probe_ms, 4)}
     probe_a = torch.randn(4096, 4096, device=dev)
     flags = torch.zeros(256, dtype=torch.int32, device=dev)
