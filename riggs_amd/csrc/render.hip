@@ -164,6 +164,11 @@ __shared__ unsigned short fw_pos[FW_B];  // position of the survivor inside its 
 __shared__ int fw_cnt[FW_B / 64];        // survivors per chunk
 __shared__ uint32_t fw_wmax[4];
 
+// A workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains the vector-memory counter: behind
+// the staging of a round that is the checkpoint stores just issued (flush_ckpt) — a store's round trip in front of every round's
+// compositing, for ordering nobody needs (no wave reads another's global stores inside the loop).
+#define FW_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 // a pixel's compositing state while its list is walked: T and the stop bookkeeping are the same in all lanes of its group,
 // the sums are per-lane partials
 struct FwWalk {
@@ -400,7 +405,7 @@ __device__ __forceinline__ void fw_block(const RenderArgs& a, const int tile, co
     if constexpr (TRACE) st_rounds++;
     flush_ckpt();
     hbase = base;
-    __syncthreads();
+    FW_LDS_BARRIER();
     lap(ph1);
     {
       const uint32_t id = n_id;
@@ -533,7 +538,7 @@ __device__ __forceinline__ void fw_block_wide(const RenderArgs& a, const int til
     flush_ckpt();
     hbase = base;
     hres = !(i >= LEAD && i < LEAD + B / 64 && base + 64 * (i - LEAD) < total && inside);  // (this lane's chunk exists: its checkpoint is to be resolved)
-    __syncthreads();
+    FW_LDS_BARRIER();
     lap(ph1);
     {
       const uint32_t id = n_id;
