@@ -97,8 +97,12 @@ def eager_api_timing(cam, gm, sw, gimg, steps=200):
     ``render()`` (train_rig.py:411, 488), each a HIP-backed autograd node; (b) ``riggs_amd.frame.deform_render``: the same frame
     as one node over riggs_frame_forward / riggs_frame_backward.  Host-bound either way; wall clock per frame."""
     from riggs_amd.rasterizer import RasterArena
-    res = {}
-    for name, fe in (("two_calls_ms", False), ("frame_entry_ms", True)):
+    from riggs_amd import _torch_ext as TX
+    res = {"torch_extension_nodes": bool(TX.available())}
+    for name, fe, ext in (("two_calls_ms", False, True), ("two_calls_ctypes_nodes_ms", False, False), ("frame_entry_ms", True, True)):
+        if not ext and not TX.available():
+            continue
+        TX.enable(ext)
         step = make_step(cam, gm, sw, gimg, RasterArena(tight_lists=_tight()), 1, None, frame_entry=fe)
         for _ in range(20):
             step()
@@ -112,8 +116,11 @@ def eager_api_timing(cam, gm, sw, gimg, steps=200):
             blocks.append(round((time.perf_counter() - t0) / steps * 1e3, 4))
         res[name] = min(blocks)
         res[name.replace("_ms", "_blocks_ms")] = blocks
-    res["what"] = ("same workload, every launch issued eagerly through autograd + ctypes: skeleton.step() + render() as the reference "
-                   "calls them, and riggs_amd.frame.deform_render (one C call per direction); fastest of three blocks of %d frames; not the headline metric" % steps)
+    TX.enable(True)
+    res["what"] = ("same workload, every launch issued eagerly: skeleton.step() + render() as the reference calls them — two autograd nodes, "
+                   "the PyTorch extension's C++ nodes when lib/libriggs_torch.so is built (torch_extension_nodes), beside the same two calls "
+                   "through the ctypes nodes — and riggs_amd.frame.deform_render (one C call per direction); fastest of three blocks of "
+                   "%d frames; host-bound, moves with the box's host; not the headline metric" % steps)
     return res
 
 

@@ -7,7 +7,8 @@
 //   d(ssim)/d(mu1), d(ssim)/d(E[x^2]), d(ssim)/d(E[xy])
 // and ONE backward launch that convolves the three maps with the (symmetric) window and combines them with the L1 sign:
 //   dL/dx = g_l1 * sign(x - y) / n  +  g_ssim / n * ( G*dmu + 2 x (G*de11) + y (G*de12) ).
-// HBM-bound by construction: forward reads 2 images and writes 3 maps, backward reads 3 maps + 2 images and writes 1.
+// Traffic: forward reads 2 images and writes 3 maps, backward reads 3 maps + 2 images and writes 1 (61 MB at 800 x 800: 8 us of
+// HBM time); what the launches take is their vector instructions — see the packed forms below.
 #include "common.h"
 
 namespace riggs {
@@ -33,21 +34,41 @@ __device__ __forceinline__ float ld_pad(const float* __restrict__ p, int yy, int
   return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? p[(size_t)yy * W + xx] : 0.f;
 }
 
+// Packed fp32 throughout (v_pk_mul / v_pk_fma_f32: two fp32 operations per lane and instruction): the staged images travel as
+// (x, y) PAIRS, the moments as the pairs (mu1, mu2) and (E[x^2], E[y^2]) plus the lone E[xy] — three instructions per tap and
+// output instead of five multiply-adds and three products, the products of a staged pixel formed once instead of once per
+// output it serves.  The kernel was bound by its vector instructions (~1 000 per thread), not by the LDS.  Same operations in
+// the same order per element as the scalar form: bit-identical results.
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2v pk_fma(float w, f2v a, f2v c) { return __builtin_elementwise_fma(f2v{w, w}, a, c); }
+#define LS_PX 44  // row pitch of the staged pairs (in pairs): rows start 16-byte aligned
+
 __global__ __launch_bounds__(256) void l1_ssim_forward_kernel(LossArgs a) {
   // 32x32 outputs per workgroup.  Both passes are register blocked: a thread produces 4 adjacent outputs from 14 staged
-  // inputs (instead of 4 x 11), which cuts the LDS traffic — the bound of this kernel — by ~3x, and the larger tile
-  // brings the halo overhead from 2.6x to 1.7x.
-  __shared__ float s_x[LS_S][LS_S + 1], s_y[LS_S][LS_S + 1];
-  __shared__ float s_h[5][LS_S][LS_T + 1];
+  // inputs (instead of 4 x 11), and the larger tile brings the halo overhead from 2.6x to 1.7x.
+  __shared__ f2v s_xy[LS_S][LS_PX];
+  __shared__ f2v s_m[LS_S][LS_T + 1], s_e[LS_S][LS_T + 1];  // after the horizontal pass: (mu1, mu2), (E[x^2], E[y^2])
+  __shared__ float s_c[LS_S][LS_T + 1];                     // ... E[xy]
   __shared__ float s_red[2][4];
   const int c = blockIdx.z, tx0 = blockIdx.x * LS_T, ty0 = blockIdx.y * LS_T;
   const int tid = threadIdx.x;
   const float* X = a.x + (size_t)c * a.H * a.W;
   const float* Y = a.y + (size_t)c * a.H * a.W;
-  for (int e = tid; e < LS_S * LS_S; e += 256) {
-    const int r = e / LS_S, q = e % LS_S;
-    s_x[r][q] = ld_pad(X, ty0 + r - LS_R, tx0 + q - LS_R, a.H, a.W);
-    s_y[r][q] = ld_pad(Y, ty0 + r - LS_R, tx0 + q - LS_R, a.H, a.W);
+  {
+    constexpr int NST = (LS_S * LS_S + 255) / 256;
+    float gx[NST], gy[NST];
+#pragma unroll
+    for (int i = 0; i < NST; i++) {  // (all of the thread's loads in flight before the first LDS write)
+      const int e = tid + 256 * i, r = e / LS_S, q = e % LS_S;
+      const bool in = e < LS_S * LS_S;
+      gx[i] = in ? ld_pad(X, ty0 + r - LS_R, tx0 + q - LS_R, a.H, a.W) : 0.f;
+      gy[i] = in ? ld_pad(Y, ty0 + r - LS_R, tx0 + q - LS_R, a.H, a.W) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NST; i++) {
+      const int e = tid + 256 * i, r = e / LS_S, q = e % LS_S;
+      if (e < LS_S * LS_S) s_xy[r][q] = f2v{gx[i], gy[i]};
+    }
   }
   __syncthreads();
   float win[2 * LS_R + 1];
@@ -56,35 +77,48 @@ __global__ __launch_bounds__(256) void l1_ssim_forward_kernel(LossArgs a) {
   // horizontal pass: 42 rows x 8 groups of 4 columns
   for (int e = tid; e < LS_S * (LS_T / 4); e += 256) {
     const int r = e >> 3, q0 = (e & 7) * 4;
-    float u[14], v[14];
+    f2v p[14], pp[14];
+    float pc[14];
 #pragma unroll
-    for (int k = 0; k < 14; k++) { u[k] = s_x[r][q0 + k]; v[k] = s_y[r][q0 + k]; }
+    for (int k = 0; k < 14; k++) {
+      p[k] = s_xy[r][q0 + k];
+      pp[k] = p[k] * p[k];
+      pc[k] = p[k].x * p[k].y;
+    }
 #pragma unroll
     for (int o = 0; o < 4; o++) {
-      float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+      f2v m = f2v{0.f, 0.f}, ee = f2v{0.f, 0.f};
+      float e12 = 0.f;
 #pragma unroll
       for (int k = 0; k <= 2 * LS_R; k++) {
-        const float w = win[k], uu = u[o + k], vv = v[o + k];
-        m1 += w * uu; m2 += w * vv; e11 += w * (uu * uu); e22 += w * (vv * vv); e12 += w * (uu * vv);
+        m = pk_fma(win[k], p[o + k], m);
+        ee = pk_fma(win[k], pp[o + k], ee);
+        e12 = fmaf(win[k], pc[o + k], e12);
       }
-      s_h[0][r][q0 + o] = m1; s_h[1][r][q0 + o] = m2; s_h[2][r][q0 + o] = e11; s_h[3][r][q0 + o] = e22; s_h[4][r][q0 + o] = e12;
+      s_m[r][q0 + o] = m; s_e[r][q0 + o] = ee; s_c[r][q0 + o] = e12;
     }
   }
   __syncthreads();
   // vertical pass: thread = (column lx, 4 consecutive rows ly0..ly0+3)
   const int lx = tid & 31, ly0 = (tid >> 5) * 4;
-  float mom[5][4];
+  f2v mo_m[4], mo_e[4];
+  float mo_c[4];
+  {
+    f2v cm[14], ce[14];
+    float cc[14];
 #pragma unroll
-  for (int q = 0; q < 5; q++) {
-    float col[14];
-#pragma unroll
-    for (int k = 0; k < 14; k++) col[k] = s_h[q][ly0 + k][lx];
+    for (int k = 0; k < 14; k++) { cm[k] = s_m[ly0 + k][lx]; ce[k] = s_e[ly0 + k][lx]; cc[k] = s_c[ly0 + k][lx]; }
 #pragma unroll
     for (int o = 0; o < 4; o++) {
-      float acc = 0.f;
+      f2v m = f2v{0.f, 0.f}, ee = f2v{0.f, 0.f};
+      float e12 = 0.f;
 #pragma unroll
-      for (int k = 0; k <= 2 * LS_R; k++) acc += win[k] * col[o + k];
-      mom[q][o] = acc;
+      for (int k = 0; k <= 2 * LS_R; k++) {
+        m = pk_fma(win[k], cm[o + k], m);
+        ee = pk_fma(win[k], ce[o + k], ee);
+        e12 = fmaf(win[k], cc[o + k], e12);
+      }
+      mo_m[o] = m; mo_e[o] = ee; mo_c[o] = e12;
     }
   }
   float ssim_sum = 0.f, ad_sum = 0.f;
@@ -94,7 +128,7 @@ __global__ __launch_bounds__(256) void l1_ssim_forward_kernel(LossArgs a) {
   for (int o = 0; o < 4; o++) {
     const int py = ty0 + ly0 + o;
     if (px < a.W && py < a.H) {
-      const float m1 = mom[0][o], m2 = mom[1][o], e11 = mom[2][o], e22 = mom[3][o], e12 = mom[4][o];
+      const float m1 = mo_m[o].x, m2 = mo_m[o].y, e11 = mo_e[o].x, e22 = mo_e[o].y, e12 = mo_c[o];
       const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;  // loss_utils.py:67-68
       const float mu1_sq = m1 * m1, mu2_sq = m2 * m2, mu12 = m1 * m2;
       const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
@@ -106,7 +140,8 @@ __global__ __launch_bounds__(256) void l1_ssim_forward_kernel(LossArgs a) {
       a.maps[plane + idx] = -ssim / D;                                            // d/dE[x^2]
       a.maps[2 * plane + idx] = 2.f * A * inv;                                    // d/dE[xy]
       ssim_sum += ssim;
-      ad_sum += fabsf(s_x[ly0 + o + LS_R][lx + LS_R] - s_y[ly0 + o + LS_R][lx + LS_R]);
+      const f2v ctr = s_xy[ly0 + o + LS_R][lx + LS_R];
+      ad_sum += fabsf(ctr.x - ctr.y);
     }
   }
   const float ad = wave_sum(ad_sum), ss = wave_sum(ssim_sum);
@@ -138,15 +173,42 @@ __global__ __launch_bounds__(1024) void l1_ssim_finish_kernel(int n_blocks, cons
 }
 
 __global__ __launch_bounds__(256) void l1_ssim_backward_kernel(LossArgs a) {
-  __shared__ float s_m[3][LS_S][LS_S + 1];
-  __shared__ float s_h[3][LS_S][LS_T + 1];
+  // (packed like the forward: the maps d/dmu1 and d/dE[x^2] travel as a pair, d/dE[xy] alone)
+  __shared__ f2v s_ab[LS_S][LS_PX];
+  __shared__ float s_cc[LS_S][LS_S + 1];
+  __shared__ f2v s_hab[LS_S][LS_T + 1];
+  __shared__ float s_hc[LS_S][LS_T + 1];
   const int c = blockIdx.z, tx0 = blockIdx.x * LS_T, ty0 = blockIdx.y * LS_T;
   const int tid = threadIdx.x;
   const size_t plane = (size_t)a.C * a.H * a.W, chan = (size_t)c * a.H * a.W;
-  for (int e = tid; e < LS_S * LS_S; e += 256) {
-    const int r = e / LS_S, q = e % LS_S;
+  {
+    constexpr int NST = (LS_S * LS_S + 255) / 256;
+    float g0[NST], g1[NST], g2[NST];
 #pragma unroll
-    for (int k = 0; k < 3; k++) s_m[k][r][q] = ld_pad(a.maps + k * plane + chan, ty0 + r - LS_R, tx0 + q - LS_R, a.H, a.W);
+    for (int i = 0; i < NST; i++) {
+      const int e = tid + 256 * i, r = e / LS_S, q = e % LS_S;
+      const bool in = e < LS_S * LS_S;
+      g0[i] = in ? ld_pad(a.maps + chan, ty0 + r - LS_R, tx0 + q - LS_R, a.H, a.W) : 0.f;
+      g1[i] = in ? ld_pad(a.maps + plane + chan, ty0 + r - LS_R, tx0 + q - LS_R, a.H, a.W) : 0.f;
+      g2[i] = in ? ld_pad(a.maps + 2 * plane + chan, ty0 + r - LS_R, tx0 + q - LS_R, a.H, a.W) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NST; i++) {
+      const int e = tid + 256 * i, r = e / LS_S, q = e % LS_S;
+      if (e < LS_S * LS_S) { s_ab[r][q] = f2v{g0[i], g1[i]}; s_cc[r][q] = g2[i]; }
+    }
+  }
+  // (this thread's four pixels of both images: asked for here, used behind the two passes)
+  const int lx = tid & 31, ly0 = (tid >> 5) * 4;
+  const int px = tx0 + lx;
+  float xs[4], ys[4];
+#pragma unroll
+  for (int o = 0; o < 4; o++) {
+    const int py = ty0 + ly0 + o;
+    const bool in = px < a.W && py < a.H;
+    const size_t idx = chan + (size_t)py * a.W + px;
+    xs[o] = in ? a.x[idx] : 0.f;
+    ys[o] = in ? a.y[idx] : 0.f;
   }
   __syncthreads();
   float win[2 * LS_R + 1];
@@ -154,37 +216,36 @@ __global__ __launch_bounds__(256) void l1_ssim_backward_kernel(LossArgs a) {
   for (int k = 0; k <= 2 * LS_R; k++) win[k] = a.win[k];
   for (int e = tid; e < LS_S * (LS_T / 4); e += 256) {
     const int r = e >> 3, q0 = (e & 7) * 4;
+    f2v u[14];
+    float w[14];
 #pragma unroll
-    for (int m = 0; m < 3; m++) {
-      float u[14];
+    for (int k = 0; k < 14; k++) { u[k] = s_ab[r][q0 + k]; w[k] = s_cc[r][q0 + k]; }
 #pragma unroll
-      for (int k = 0; k < 14; k++) u[k] = s_m[m][r][q0 + k];
+    for (int o = 0; o < 4; o++) {
+      f2v acc = f2v{0.f, 0.f};
+      float ac = 0.f;
 #pragma unroll
-      for (int o = 0; o < 4; o++) {
-        float acc = 0.f;
-#pragma unroll
-        for (int k = 0; k <= 2 * LS_R; k++) acc += win[k] * u[o + k];
-        s_h[m][r][q0 + o] = acc;
-      }
+      for (int k = 0; k <= 2 * LS_R; k++) { acc = pk_fma(win[k], u[o + k], acc); ac = fmaf(win[k], w[o + k], ac); }
+      s_hab[r][q0 + o] = acc; s_hc[r][q0 + o] = ac;
     }
   }
   __syncthreads();
-  const int lx = tid & 31, ly0 = (tid >> 5) * 4;
-  float cv[3][4];
+  f2v cv_ab[4];
+  float cv_c[4];
+  {
+    f2v col[14];
+    float cc[14];
 #pragma unroll
-  for (int m = 0; m < 3; m++) {
-    float col[14];
-#pragma unroll
-    for (int k = 0; k < 14; k++) col[k] = s_h[m][ly0 + k][lx];
+    for (int k = 0; k < 14; k++) { col[k] = s_hab[ly0 + k][lx]; cc[k] = s_hc[ly0 + k][lx]; }
 #pragma unroll
     for (int o = 0; o < 4; o++) {
-      float acc = 0.f;
+      f2v acc = f2v{0.f, 0.f};
+      float ac = 0.f;
 #pragma unroll
-      for (int k = 0; k <= 2 * LS_R; k++) acc += win[k] * col[o + k];
-      cv[m][o] = acc;
+      for (int k = 0; k <= 2 * LS_R; k++) { acc = pk_fma(win[k], col[o + k], acc); ac = fmaf(win[k], cc[o + k], ac); }
+      cv_ab[o] = acc; cv_c[o] = ac;
     }
   }
-  const int px = tx0 + lx;
   const float inv_n = 1.0f / (float)plane;
   const float gt_ = a.g_loss ? a.g_loss[0] : 0.f;
   const float gl = (a.g_l1 ? a.g_l1[0] : 0.f) + (1.0f - a.lambda_dssim) * gt_;
@@ -194,10 +255,10 @@ __global__ __launch_bounds__(256) void l1_ssim_backward_kernel(LossArgs a) {
     const int py = ty0 + ly0 + o;
     if (px < a.W && py < a.H) {
       const size_t idx = chan + (size_t)py * a.W + px;
-      const float x = a.x[idx], y = a.y[idx];
+      const float x = xs[o], y = ys[o];
       const float d = x - y;
       const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);  // torch.abs backward: sign(0) = 0
-      a.dx[idx] = gl * sgn * inv_n + gs * inv_n * (cv[0][o] + 2.f * x * cv[1][o] + y * cv[2][o]);
+      a.dx[idx] = gl * sgn * inv_n + gs * inv_n * (cv_ab[o].x + 2.f * x * cv_ab[o].y + y * cv_c[o]);
     }
   }
 }
