@@ -13,9 +13,12 @@
 
 namespace riggs {
 
-#define LS_T 32            // output tile edge: 256 threads, 4 outputs each in either pass
+#define LS_T 32            // output tile: 32 columns ...
+#define LS_TH 64           // ... x 64 rows, 512 threads, 4 outputs each in either pass
+#define LS_NT 512
 #define LS_R 5             // window radius (11 taps)
-#define LS_S (LS_T + 2 * LS_R)  // staged edge: 42
+#define LS_S (LS_T + 2 * LS_R)    // staged columns: 42
+#define LS_SH (LS_TH + 2 * LS_R)  // staged rows: 74
 
 struct LossArgs {
   int C, H, W;
@@ -43,39 +46,41 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2v pk_fma(float w, f2v a, f2v c) { return __builtin_elementwise_fma(f2v{w, w}, a, c); }
 #define LS_PX 44  // row pitch of the staged pairs (in pairs): rows start 16-byte aligned
 
-__global__ __launch_bounds__(256) void l1_ssim_forward_kernel(LossArgs a) {
-  // 32x32 outputs per workgroup.  Both passes are register blocked: a thread produces 4 adjacent outputs from 14 staged
-  // inputs (instead of 4 x 11), and the larger tile brings the halo overhead from 2.6x to 1.7x.
-  __shared__ f2v s_xy[LS_S][LS_PX];
-  __shared__ f2v s_m[LS_S][LS_T + 1], s_e[LS_S][LS_T + 1];  // after the horizontal pass: (mu1, mu2), (E[x^2], E[y^2])
-  __shared__ float s_c[LS_S][LS_T + 1];                     // ... E[xy]
-  __shared__ float s_red[2][4];
-  const int c = blockIdx.z, tx0 = blockIdx.x * LS_T, ty0 = blockIdx.y * LS_T;
+__global__ __launch_bounds__(LS_NT) void l1_ssim_forward_kernel(LossArgs a) {
+  // 32 x 64 outputs per workgroup of 512 threads.  Both passes are register blocked: a thread produces 4 adjacent outputs from
+  // 14 staged inputs (instead of 4 x 11).  The tall tile: 75 KB of LDS = two workgroups = four waves per SIMD (32 x 32 tiles of
+  // 256 threads: 42 KB, three workgroups, three waves per SIMD, and 1875 workgroups = 2.4 rounds of the chip at 800 x 800
+  // against 975 = 1.9 rounds here), halo overhead 1.5x instead of 1.7x.
+  __shared__ f2v s_xy[LS_SH][LS_PX];
+  __shared__ f2v s_m[LS_SH][LS_T + 1], s_e[LS_SH][LS_T + 1];  // after the horizontal pass: (mu1, mu2), (E[x^2], E[y^2])
+  __shared__ float s_c[LS_SH][LS_T + 1];                      // ... E[xy]
+  __shared__ float s_red[2][LS_NT / 64];
+  const int c = blockIdx.z, tx0 = blockIdx.x * LS_T, ty0 = blockIdx.y * LS_TH;
   const int tid = threadIdx.x;
   const float* X = a.x + (size_t)c * a.H * a.W;
   const float* Y = a.y + (size_t)c * a.H * a.W;
   {
-    constexpr int NST = (LS_S * LS_S + 255) / 256;
+    constexpr int NST = (LS_SH * LS_S + LS_NT - 1) / LS_NT;
     float gx[NST], gy[NST];
 #pragma unroll
     for (int i = 0; i < NST; i++) {  // (all of the thread's loads in flight before the first LDS write)
-      const int e = tid + 256 * i, r = e / LS_S, q = e % LS_S;
-      const bool in = e < LS_S * LS_S;
+      const int e = tid + LS_NT * i, r = e / LS_S, q = e % LS_S;
+      const bool in = e < LS_SH * LS_S;
       gx[i] = in ? ld_pad(X, ty0 + r - LS_R, tx0 + q - LS_R, a.H, a.W) : 0.f;
       gy[i] = in ? ld_pad(Y, ty0 + r - LS_R, tx0 + q - LS_R, a.H, a.W) : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < NST; i++) {
-      const int e = tid + 256 * i, r = e / LS_S, q = e % LS_S;
-      if (e < LS_S * LS_S) s_xy[r][q] = f2v{gx[i], gy[i]};
+      const int e = tid + LS_NT * i, r = e / LS_S, q = e % LS_S;
+      if (e < LS_SH * LS_S) s_xy[r][q] = f2v{gx[i], gy[i]};
     }
   }
   __syncthreads();
   float win[2 * LS_R + 1];
 #pragma unroll
   for (int k = 0; k <= 2 * LS_R; k++) win[k] = a.win[k];
-  // horizontal pass: 42 rows x 8 groups of 4 columns
-  for (int e = tid; e < LS_S * (LS_T / 4); e += 256) {
+  // horizontal pass: 74 rows x 8 groups of 4 columns
+  for (int e = tid; e < LS_SH * (LS_T / 4); e += LS_NT) {
     const int r = e >> 3, q0 = (e & 7) * 4;
     f2v p[14], pp[14];
     float pc[14];
@@ -149,8 +154,8 @@ __global__ __launch_bounds__(256) void l1_ssim_forward_kernel(LossArgs a) {
   __syncthreads();
   if (tid == 0) {
     const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    a.partial[2 * b] = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
-    a.partial[2 * b + 1] = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
+    a.partial[2 * b] = ((s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3])) + ((s_red[0][4] + s_red[0][5]) + (s_red[0][6] + s_red[0][7]));
+    a.partial[2 * b + 1] = ((s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3])) + ((s_red[1][4] + s_red[1][5]) + (s_red[1][6] + s_red[1][7]));
   }
 }
 
@@ -172,30 +177,30 @@ __global__ __launch_bounds__(1024) void l1_ssim_finish_kernel(int n_blocks, cons
   }
 }
 
-__global__ __launch_bounds__(256) void l1_ssim_backward_kernel(LossArgs a) {
+__global__ __launch_bounds__(LS_NT) void l1_ssim_backward_kernel(LossArgs a) {
   // (packed like the forward: the maps d/dmu1 and d/dE[x^2] travel as a pair, d/dE[xy] alone)
-  __shared__ f2v s_ab[LS_S][LS_PX];
-  __shared__ float s_cc[LS_S][LS_S + 1];
-  __shared__ f2v s_hab[LS_S][LS_T + 1];
-  __shared__ float s_hc[LS_S][LS_T + 1];
-  const int c = blockIdx.z, tx0 = blockIdx.x * LS_T, ty0 = blockIdx.y * LS_T;
+  __shared__ f2v s_ab[LS_SH][LS_PX];
+  __shared__ float s_cc[LS_SH][LS_S + 1];
+  __shared__ f2v s_hab[LS_SH][LS_T + 1];
+  __shared__ float s_hc[LS_SH][LS_T + 1];
+  const int c = blockIdx.z, tx0 = blockIdx.x * LS_T, ty0 = blockIdx.y * LS_TH;
   const int tid = threadIdx.x;
   const size_t plane = (size_t)a.C * a.H * a.W, chan = (size_t)c * a.H * a.W;
   {
-    constexpr int NST = (LS_S * LS_S + 255) / 256;
+    constexpr int NST = (LS_SH * LS_S + LS_NT - 1) / LS_NT;
     float g0[NST], g1[NST], g2[NST];
 #pragma unroll
     for (int i = 0; i < NST; i++) {
-      const int e = tid + 256 * i, r = e / LS_S, q = e % LS_S;
-      const bool in = e < LS_S * LS_S;
+      const int e = tid + LS_NT * i, r = e / LS_S, q = e % LS_S;
+      const bool in = e < LS_SH * LS_S;
       g0[i] = in ? ld_pad(a.maps + chan, ty0 + r - LS_R, tx0 + q - LS_R, a.H, a.W) : 0.f;
       g1[i] = in ? ld_pad(a.maps + plane + chan, ty0 + r - LS_R, tx0 + q - LS_R, a.H, a.W) : 0.f;
       g2[i] = in ? ld_pad(a.maps + 2 * plane + chan, ty0 + r - LS_R, tx0 + q - LS_R, a.H, a.W) : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < NST; i++) {
-      const int e = tid + 256 * i, r = e / LS_S, q = e % LS_S;
-      if (e < LS_S * LS_S) { s_ab[r][q] = f2v{g0[i], g1[i]}; s_cc[r][q] = g2[i]; }
+      const int e = tid + LS_NT * i, r = e / LS_S, q = e % LS_S;
+      if (e < LS_SH * LS_S) { s_ab[r][q] = f2v{g0[i], g1[i]}; s_cc[r][q] = g2[i]; }
     }
   }
   // (this thread's four pixels of both images: asked for here, used behind the two passes)
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(256) void l1_ssim_backward_kernel(LossArgs a) {
   float win[2 * LS_R + 1];
 #pragma unroll
   for (int k = 0; k <= 2 * LS_R; k++) win[k] = a.win[k];
-  for (int e = tid; e < LS_S * (LS_T / 4); e += 256) {
+  for (int e = tid; e < LS_SH * (LS_T / 4); e += LS_NT) {
     const int r = e >> 3, q0 = (e & 7) * 4;
     f2v u[14];
     float w[14];
@@ -276,7 +281,7 @@ using namespace riggs;
 
 extern "C" {
 
-static size_t ls_blocks(int C, int H, int W) { return (size_t)C * ((H + LS_T - 1) / LS_T) * ((W + LS_T - 1) / LS_T); }
+static size_t ls_blocks(int C, int H, int W) { return (size_t)C * ((H + LS_TH - 1) / LS_TH) * ((W + LS_T - 1) / LS_T); }
 
 size_t riggs_l1_ssim_state_floats(int32_t C, int32_t H, int32_t W) {
   return 3 * (size_t)C * H * W + 2 * ls_blocks(C, H, W);
@@ -292,10 +297,10 @@ int riggs_l1_ssim_forward(int32_t C, int32_t H, int32_t W, const float* image, c
   a.maps = state; a.partial = state + 3 * (size_t)C * H * W; a.out2 = out2;
   fill_window(a);
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid((W + LS_T - 1) / LS_T, (H + LS_T - 1) / LS_T, C);
+  const dim3 grid((W + LS_T - 1) / LS_T, (H + LS_TH - 1) / LS_TH, C);
   {
     ProfScope ps(PROF_LOSS_FWD, s);
-    hipLaunchKernelGGL(l1_ssim_forward_kernel, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(l1_ssim_forward_kernel, grid, dim3(LS_NT), 0, s, a);
     hipLaunchKernelGGL(l1_ssim_finish_kernel, dim3(1), dim3(1024), 0, s, (int)ls_blocks(C, H, W), a.partial,
                        1.0 / ((double)C * H * W), lambda_dssim, out2);
   }
@@ -315,10 +320,10 @@ int riggs_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float* image, 
   a.dx = dL_dimage;
   fill_window(a);
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid((W + LS_T - 1) / LS_T, (H + LS_T - 1) / LS_T, C);
+  const dim3 grid((W + LS_T - 1) / LS_T, (H + LS_TH - 1) / LS_TH, C);
   {
     ProfScope ps(PROF_LOSS_BWD, s);
-    hipLaunchKernelGGL(l1_ssim_backward_kernel, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(l1_ssim_backward_kernel, grid, dim3(LS_NT), 0, s, a);
   }
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
