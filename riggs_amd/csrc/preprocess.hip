@@ -602,38 +602,48 @@ __global__ __launch_bounds__(256, 3) void preprocess_bwd_kernel(PreBwdArgs b) {
 // kernel trace reads 9.4 us for the screening alone and 26 us with the arithmetic.  Here a workgroup IS that one wave: it screens
 // its 256 Gaussians four to a lane (all records in flight together), works through the listed ones 64 at a time, and stages only
 // those rows (12 KB); twelve workgroups fit a CU: every block of the frame is resident at once.
-__global__ __launch_bounds__(64) void preprocess_bwd_lean_kernel(PreBwdArgs b) {
+// TWO waves per block since round 6: each screens half of the block (two records per lane) and the listed Gaussians are dealt to
+// the waves in batches of 64 — a scene whose Gaussians mostly receive a gradient (the opaque-skin scene lists 28 %: 72 of a
+// block's 256) used to walk two or three batches one behind the other on the one wave, each a full round of scattered loads,
+// ~1 000 vector instructions and stores.
+#define PBL_WAVES 2
+__global__ __launch_bounds__(64 * PBL_WAVES) void preprocess_bwd_lean_kernel(PreBwdArgs b) {
   __shared__ unsigned char s_list[256];
+  __shared__ int s_cnt[PBL_WAVES];
   const PreArgs& a = b.f;
   const bool sh_mode = (a.colors_precomp == nullptr);
   const int sh_per = a.shs_rest ? (a.M - 1) * 3 : a.M * 3;
   const bool need_sr = (a.cov3D_precomp == nullptr);
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int SUBS = 4 / PBL_WAVES;  // runs of 64 Gaussians a wave screens
   const int first = blockIdx.x * 256, count = min(256, a.N - first);
   const bool overflowed = b.counters != nullptr && b.counters[1] != 0u;
   // ---- screening: which of the block's Gaussians received a gradient (see the kernel above)
   // (one round trip for everything the screening reads: the four records of the lane, their radii — a culled Gaussian's record is
   // zero, the radius only spares the compare — and the previous call's bits)
-  float4 rq[4][3];
-  uint64_t prev[4];
+  float4 rq[SUBS][3];
+  uint64_t prev[SUBS];
 #pragma unroll
-  for (int sub = 0; sub < 4; sub++) {
+  for (int ss = 0; ss < SUBS; ss++) {
+    const int sub = wave * SUBS + ss;
     const int i0 = first + sub * 64 + lane;
-    rq[sub][0] = rq[sub][1] = rq[sub][2] = make_float4(0.f, 0.f, 0.f, 0.f);
-    prev[sub] = ~0ull;
-    if (b.sparse_zero) prev[sub] = (sub * 64 < count) ? b.touched_bits[blockIdx.x * 4 + sub] : 0ull;
+    rq[ss][0] = rq[ss][1] = rq[ss][2] = make_float4(0.f, 0.f, 0.f, 0.f);
+    prev[ss] = ~0ull;
+    if (b.sparse_zero) prev[ss] = (sub * 64 < count) ? b.touched_bits[blockIdx.x * 4 + sub] : 0ull;
     if (i0 < a.N) {
       const float4* acc4 = reinterpret_cast<const float4*>(b.gacc + (size_t)i0 * RIGGS_GACC);
-      rq[sub][0] = acc4[0]; rq[sub][1] = acc4[1]; rq[sub][2] = acc4[2];
+      rq[ss][0] = acc4[0]; rq[ss][1] = acc4[1]; rq[ss][2] = acc4[2];
     }
   }
   __builtin_amdgcn_sched_barrier(0);
-  uint64_t tmask[4], need[4];
-  int n_work = 0;
+  uint64_t tmask[SUBS], need[SUBS];
+  bool tch[SUBS];
+  int n_mine = 0;  // listed by this wave
 #pragma unroll
-  for (int sub = 0; sub < 4; sub++) {
+  for (int ss = 0; ss < SUBS; ss++) {
+    const int sub = wave * SUBS + ss;
     const int i0 = first + sub * 64 + lane;
-    const float4 q0 = rq[sub][0], q1 = rq[sub][1], q2 = rq[sub][2];
+    const float4 q0 = rq[ss][0], q1 = rq[ss][1], q2 = rq[ss][2];
     bool touched = (q0.x != 0.f) || (q0.y != 0.f) || (q0.z != 0.f) || (q0.w != 0.f) || (q1.x != 0.f) || (q1.y != 0.f) ||
                    (q1.z != 0.f) || (q1.w != 0.f) || (q2.x != 0.f) || (q2.y != 0.f);
     if (touched && overflowed) {  // (an overflowed frame back-propagates exact zeros; nobody will consume this record)
@@ -643,20 +653,33 @@ __global__ __launch_bounds__(64) void preprocess_bwd_lean_kernel(PreBwdArgs b) {
       touched = false;
     }
     const uint64_t tm = __builtin_amdgcn_ballot_w64(touched);
-    const uint64_t pm = prev[sub];
-    tmask[sub] = tm;
-    need[sub] = tm | pm;
-    if (touched) s_list[n_work + __builtin_popcountll(tm & ((1ull << lane) - 1ull))] = (unsigned char)(sub * 64 + lane);
-    n_work += __builtin_popcountll(tm);
+    const uint64_t pm = prev[ss];
+    tmask[ss] = tm;
+    need[ss] = tm | pm;
+    tch[ss] = touched;
+    n_mine += __builtin_popcountll(tm);
     if (lane == 0 && sub * 64 < count) b.touched_bits[blockIdx.x * 4 + sub] = tm;
     if (i0 < a.N && !touched && ((pm >> lane) & 1ull)) bwd_zero_row(b, a, i0, sh_mode);
   }
-  if (lane == 0) b.block_touched[blockIdx.x] = (uint32_t)n_work;
+  if (lane == 0) s_cnt[wave] = n_mine;
+  __syncthreads();
+  int n_work = 0, my_off = 0;
+#pragma unroll
+  for (int w = 0; w < PBL_WAVES; w++) { if (w < wave) my_off += s_cnt[w]; n_work += s_cnt[w]; }
+  {
+    int run = my_off;
+#pragma unroll
+    for (int ss = 0; ss < SUBS; ss++) {
+      if (tch[ss]) s_list[run + __builtin_popcountll(tmask[ss] & ((1ull << lane) - 1ull))] = (unsigned char)((wave * SUBS + ss) * 64 + lane);
+      run += __builtin_popcountll(tmask[ss]);
+    }
+  }
+  if (threadIdx.x == 0) b.block_touched[blockIdx.x] = (uint32_t)n_work;
   __syncthreads();  // s_list
   float* const dst_rest = sh_mode && sh_per > 0 ? (a.shs_rest ? b.dL_dsh_rest : b.dL_dsh) + (size_t)first * sh_per : nullptr;
   const int koff = a.shs_rest ? 3 : 0;
-  // ---- the listed Gaussians, 64 at a time
-  for (int base = 0; base < n_work; base += 64) {
+  // ---- the listed Gaussians, 64 at a time, batches dealt to the waves
+  for (int base = wave * 64; base < n_work; base += 64 * PBL_WAVES) {
     const int tq = base + lane;
     const bool in_range = tq < n_work;
     const int slot = in_range ? (int)s_list[tq] : 0;
@@ -725,8 +748,9 @@ __global__ __launch_bounds__(64) void preprocess_bwd_lean_kernel(PreBwdArgs b) {
   // cfg.sparse_zero — every other one)
   if (dst_rest) {
 #pragma unroll
-    for (int sub = 0; sub < 4; sub++) {
-      uint64_t m = need[sub] & ~tmask[sub];
+    for (int ss = 0; ss < SUBS; ss++) {
+      const int sub = wave * SUBS + ss;
+      uint64_t m = need[ss] & ~tmask[ss];
       while (m) {
         const int row = sub * 64 + __builtin_ctzll(m);
         m &= m - 1ull;
@@ -749,7 +773,7 @@ int launch_preprocess_bwd(const PreBwdArgs& b, hipStream_t s) {
   if (b.f.N == 0) return 0;
   const int per = b.f.shs_rest ? (b.f.M - 1) * 3 : b.f.M * 3;
   if (option(OPT_PREPROCESS_BWD_LEAN) == 1 || (option(OPT_PREPROCESS_BWD_LEAN) < 0 && b.sparse_zero)) {
-    hipLaunchKernelGGL(preprocess_bwd_lean_kernel, dim3((b.f.N + 255) / 256), dim3(64), 0, s, b);
+    hipLaunchKernelGGL(preprocess_bwd_lean_kernel, dim3((b.f.N + 255) / 256), dim3(64 * PBL_WAVES), 0, s, b);
     return 0;
   }
   const size_t lds = b.f.colors_precomp ? 0 : (size_t)256 * (per | 1) * sizeof(float);
