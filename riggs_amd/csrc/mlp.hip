@@ -89,6 +89,9 @@ __device__ __forceinline__ int mlp_k(const MlpDesc& d, int l) { return l == 0 ? 
 // took 8 us per workgroup where its MFMAs need 1.7).  MLP_PF steps are kept in flight in a ring of registers (the hidden
 // fragments come from LDS: one step ahead is enough for them).
 #define MLP_PF 4
+#ifndef MLP_STB_PF
+#define MLP_STB_PF 6   // ring depth of the forward's storing product (mlp_gemm_hidden_stb)
+#endif
 template <int NT, int GT, bool H16>
 __device__ __forceinline__ void mlp_gemm_t(f32x16 (&acc)[NT][GT], const unsigned short* __restrict__ Wf, size_t tile_stride,
                                            const unsigned short* Bsrc, int bs, int steps /* a multiple of MLP_PF */, int lane) {
@@ -199,6 +202,79 @@ __device__ __forceinline__ void mlp_gemm_hidden(f32x16 (&acc)[2][GT], const unsi
   }
 }
 
+// The FORWARD's form of "the B operand's rows leave for HBM under the product" (round 6).  The COPY form above re-reads the rows
+// from LDS into registers of their own in front of the loop: in the forward kernel that took the last of the 256 registers and
+// lost what the overlap gained (0.454 -> 0.470 ms).  Here the stores cost no register and no LDS read: at K-step s every wave
+// holds the hidden fragments of ALL 128 Gaussians for k in [16 s, 16 s + 16) as its B operands — lane (r, kq) 16 bytes of row
+// 32 gt + r — so wave w sends tile gt = w: ONE 16-byte store per thread and step, 32-byte pieces of 32 rows per instruction
+// that L2 merges into full lines over the sixteen steps.  Stores and loads share vmcnt IN ORDER, so a store issued at step s has
+// to have landed when the fragments loaded behind it are waited for: with the ring of four that is one microsecond later, and
+// every wait stood behind a store ("one store per K-step, interleaved, LOST" above).  Hence a ring of PF steps (PF = 8: 64
+// registers of fragments; the weights' loads are then waited for eight steps = two microseconds behind their issue at two waves
+// per SIMD, and so are the stores in front of them).  The counts, per step s (vector-memory operations issued behind the loads
+// of step s when they are waited for):  prologue loads L(0..PF-1), then step t issues L(t + PF) (two loads, while they exist)
+// and St(t) behind them.
+template <int N> __device__ __forceinline__ void mlp_wait2(bf16x8& a, bf16x8& b) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
+template <int STEPS, int PF, int S> constexpr int mlp_stb_younger() {
+  int n = 0;
+  if (S < PF) {
+    n = 2 * (PF - 1 - S);
+    for (int t = 0; t < S; t++) n += (t + PF < STEPS ? 2 : 0) + 1;
+  } else {
+    n = 1;  // St(S - PF): issued behind L(S) in the same step
+    for (int t = S - PF + 1; t < S; t++) n += (t + PF < STEPS ? 2 : 0) + 1;
+  }
+  return n;
+}
+__device__ unsigned short mlp_store_sink[64 * 8 + 16 * 16];  // where the stores of a row past the end go (the count of stores must not depend on data)
+template <int STEPS, int PF, int S, int GT, bool H16>
+__device__ __forceinline__ void mlp_stb_step(f32x16 (&acc)[2][GT], bf16x8 (&aq)[PF][2], bf16x8 (&bq)[2][GT], const unsigned short* w0,
+                                             const unsigned short* w1, const unsigned short* bl, int bs, int wave_u, unsigned short* cp) {
+  constexpr int u = S % PF;
+  mlp_wait2<mlp_stb_younger<STEPS, PF, S>()>(aq[u][0], aq[u][1]);
+  if constexpr (S + 1 < STEPS) {
+#pragma unroll
+    for (int gt = 0; gt < GT; gt++) bq[(S + 1) & 1][gt] = *reinterpret_cast<const bf16x8*>(bl + (size_t)(32 * gt) * bs + 16 * (S + 1));
+  }
+#pragma unroll
+  for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+    for (int gt = 0; gt < GT; gt++) acc[nt][gt] = mfma16<H16>(aq[u][nt], bq[S & 1][gt], acc[nt][gt]);
+  if constexpr (S + PF < STEPS) {
+    MLP_GLOAD(aq[u][0], w0 + (size_t)(S + PF) * MLP_FRAG);
+    MLP_GLOAD(aq[u][1], w1 + (size_t)(S + PF) * MLP_FRAG);
+  }
+  // (wave-uniform branches: exactly one store per wave and step; s_nop 1: a store of more than 8 bytes needs two wait states before
+  // its data registers may be written, and the compiler does not look inside the asm)
+  unsigned short* to = cp + 16 * S;
+  if (wave_u == 0) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(to), "v"(bq[S & 1][0]) : "memory");
+  else if (wave_u == 1) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(to), "v"(bq[S & 1][1]) : "memory");
+  else if (wave_u == 2) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(to), "v"(bq[S & 1][2]) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(to), "v"(bq[S & 1][3]) : "memory");
+  if constexpr (S + 1 < STEPS) mlp_stb_step<STEPS, PF, S + 1, GT, H16>(acc, aq, bq, w0, w1, bl, bs, wave_u, cp);
+}
+template <int STEPS, int GT, bool H16, int PF>
+__device__ __forceinline__ void mlp_gemm_hidden_stb(f32x16 (&acc)[2][GT], const unsigned short* __restrict__ Wf, size_t tile_stride,
+                                                    const unsigned short* Bsrc, int bs, int lane, int wave_u /* uniform */,
+                                                    unsigned short* __restrict__ cdst /* row 0 of the workgroup */, int crows) {
+  static_assert(GT == 4 && STEPS >= PF, "four Gaussian tiles, one per wave");
+  const int r = lane & 31, kq = (lane >> 5) * 8;
+  bf16x8 aq[PF][2], bq[2][GT];
+  const unsigned short* w0 = Wf + lane * 8;
+  const unsigned short* w1 = w0 + tile_stride;
+  const unsigned short* bl = Bsrc + (size_t)r * bs + kq;
+#pragma unroll
+  for (int p = 0; p < PF; p++) {
+    MLP_GLOAD(aq[p][0], w0 + (size_t)p * MLP_FRAG);
+    MLP_GLOAD(aq[p][1], w1 + (size_t)p * MLP_FRAG);
+  }
+#pragma unroll
+  for (int gt = 0; gt < GT; gt++) bq[0][gt] = *reinterpret_cast<const bf16x8*>(bl + (size_t)(32 * gt) * bs);
+  const int crow = 32 * wave_u + r;
+  unsigned short* cp = crow < crows ? cdst + (size_t)crow * MLP_W + kq : mlp_store_sink + lane * 8;
+  mlp_stb_step<STEPS, PF, 0, GT, H16>(acc, aq, bq, w0, w1, bl, bs, wave_u, cp);
+}
+
 // the backward's head product: two K-steps (32 padded outputs), no ring
 template <int NT, int GT, bool H16>
 __device__ __forceinline__ void mlp_gemm_small(f32x16 (&acc)[NT][GT], const unsigned short* __restrict__ Wf, size_t tile_stride,
@@ -262,6 +338,7 @@ __global__ __launch_bounds__(256, GT == 2 ? 3 : 2) void mlp_forward_kernel(MlpDe
   constexpr int ROWS = 32 * GT;
   __shared__ unsigned short s_h[ROWS * MLP_HS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int row0 = blockIdx.x * ROWS;
   // (a device-side row count — the compacted rows of a row-sparse backward: the grid covers the capacity, the rest leaves here)
   const int rows = d.n_dev ? min(d.n_dev[0], d.N) : d.N;
@@ -289,9 +366,12 @@ __global__ __launch_bounds__(256, GT == 2 ? 3 : 2) void mlp_forward_kernel(MlpDe
         mlp_gemm_t<2, GT, H16>(acc, Wl, ts, xrow, d.in_pad, emb_steps, lane);
         Wh = Wl + (size_t)emb_steps * MLP_FRAG;
       }
-      // (the forward keeps its activation stores between the barriers: behind the ring's prologue — the backward's form — the
-      // kernel needs all 256 registers and loses what the overlap gains: 0.454 -> 0.470 ms; the backward gains, 0.541 -> 0.515)
-      mlp_gemm_hidden<MLP_W / 16, GT, H16, false>(acc, Wh, ts, s_h, MLP_HS, lane);
+      // (the layer below's activations — this product's B operand — leave for HBM under it, out of the fragment registers:
+      // mlp_gemm_hidden_stb; the last layer's go between the barriers below)
+      if constexpr (STORE)
+        mlp_gemm_hidden_stb<MLP_W / 16, GT, H16, MLP_STB_PF>(acc, Wh, ts, s_h, MLP_HS, lane, wave_u,
+                                                              acts + ((size_t)(l - 1) * d.N + row0) * MLP_W, min(ROWS, rows - row0));
+      else mlp_gemm_hidden<MLP_W / 16, GT, H16, false>(acc, Wh, ts, s_h, MLP_HS, lane);
     }
     __syncthreads();  // every wave is done reading the previous hidden vector
     uint32_t mbits[GT] ;  // ReLU mask of this lane's accumulator elements: word gt, bit nt * 16 + e
@@ -327,7 +407,7 @@ __global__ __launch_bounds__(256, GT == 2 ? 3 : 2) void mlp_forward_kernel(MlpDe
       masks[((size_t)l * gridDim.x + blockIdx.x) * 256 + tid] = make_uint4(mbits[0], mbits[1], mbits[2], mbits[3]);
     }
     __syncthreads();
-    if constexpr (STORE) {  // full-line stores of the layer's activations (operand of the weight gradients)
+    if (STORE && l == d.depth - 1) {  // the last layer's activations (operand of the head's weight gradient): full-line stores
       unsigned short* dst = acts + ((size_t)l * d.N + row0) * MLP_W;
       for (int e = tid; e < ROWS * (MLP_W / 8); e += 256) {
         const int r = e / (MLP_W / 8), c8 = e - r * (MLP_W / 8);

@@ -145,6 +145,35 @@ def test_param_grads_kernel_equals_the_products_of_its_operands(N, fmt):
             assert float((c.double() - b).abs().max()) <= 50 * tol, (name, "library", i)
 
 
+@pytest.mark.parametrize("fmt", ["fp16", "bf16"])
+@pytest.mark.parametrize("N", [1, 129, 4097, 50_003])
+def test_stored_activations_are_the_layers_outputs(N, fmt):
+    """The activations the training forward leaves in HBM — sent out of the next layer's operand fragments, under its product
+    (mlp_gemm_hidden_stb) — are every layer's relu(W a + b) of the STORED layer below (same 16-bit operands, fp32 accumulation:
+    what is left is the rounding of the result), finite everywhere, for ragged row counts and for rows past 2^15 (byte offsets
+    past 2^24); three launches each: a missed wait state or a wrong vmcnt count shows as sporadic garbage."""
+    for name, net, head, xe in _nets(N):
+        fh = M.FusedHead(net.linear, head, xe.shape[1], net.skips[0], fmt)
+        pk = fh._packed()
+        xb = M.embed_bf16(pk, xe)
+        out0 = M.forward(pk, xe, False, xb)[0]
+        x16 = xb[:N, :pk.in_ch].float()
+        eps = 2.0 ** -10 if fmt == "fp16" else 2.0 ** -7
+        for _rep in range(3):
+            out, (acts, _masks) = M.forward(pk, xe, True, xb)
+            assert torch.equal(out, out0), (name, fmt, N)
+            assert bool(torch.isfinite(acts.float()).all()), (name, fmt, N)
+            for l in range(pk.depth):
+                W = net.linear[l].weight.detach().to(pk.dtype).float()
+                b = net.linear[l].bias.detach().float()
+                a_in = x16 if l == 0 else acts[l - 1].float()
+                if l == pk.skip + 1:
+                    a_in = torch.cat([x16, a_in], 1)
+                ref = torch.relu(a_in @ W.t() + b)
+                d = (acts[l].float() - ref).abs()
+                assert bool((d <= 2 * eps * (ref.abs() + a_in.abs().max() * 1e-2 + 1e-6)).all()), (name, fmt, N, l, float(d.max()))
+
+
 def test_skeleton_warp_with_fused_heads_tracks_the_fp32_heads():
     from riggs_amd import synth
     from riggs_amd.skeleton import SkeletonWarp
