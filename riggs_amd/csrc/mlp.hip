@@ -213,7 +213,8 @@ __device__ __forceinline__ void mlp_gemm_hidden(f32x16 (&acc)[2][GT], const unsi
 // registers of fragments; the weights' loads are then waited for eight steps = two microseconds behind their issue at two waves
 // per SIMD, and so are the stores in front of them).  The counts, per step s (vector-memory operations issued behind the loads
 // of step s when they are waited for):  prologue loads L(0..PF-1), then step t issues L(t + PF) (two loads, while they exist)
-// and St(t) behind them.
+// and St(t) behind them.  (The BACKWARD keeps the COPY form: with its gradient rows sent out of the fragments behind rings of six
+// and seven its data-gradient pass went 0.396 -> 0.445 ms and the iteration 2.50 -> 2.57 ms; profiles/round6_mlp_forward_stores_ab.txt.)
 template <int N> __device__ __forceinline__ void mlp_wait2(bf16x8& a, bf16x8& b) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
 template <int STEPS, int PF, int S> constexpr int mlp_stb_younger() {
   int n = 0;
