@@ -216,23 +216,23 @@ __device__ __forceinline__ void mlp_gemm_hidden(f32x16 (&acc)[2][GT], const unsi
 // and St(t) behind them.  (The BACKWARD keeps the COPY form: with its gradient rows sent out of the fragments behind rings of six
 // and seven its data-gradient pass went 0.396 -> 0.445 ms and the iteration 2.50 -> 2.57 ms; profiles/round6_mlp_forward_stores_ab.txt.)
 template <int N> __device__ __forceinline__ void mlp_wait2(bf16x8& a, bf16x8& b) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
-template <int STEPS, int PF, int S> constexpr int mlp_stb_younger() {
+template <int STEPS, int PF, int S, bool ST> constexpr int mlp_stb_younger() {
   int n = 0;
   if (S < PF) {
     n = 2 * (PF - 1 - S);
-    for (int t = 0; t < S; t++) n += (t + PF < STEPS ? 2 : 0) + 1;
+    for (int t = 0; t < S; t++) n += (t + PF < STEPS ? 2 : 0) + (ST ? 1 : 0);
   } else {
-    n = 1;  // St(S - PF): issued behind L(S) in the same step
-    for (int t = S - PF + 1; t < S; t++) n += (t + PF < STEPS ? 2 : 0) + 1;
+    n = ST ? 1 : 0;  // St(S - PF): issued behind L(S) in the same step
+    for (int t = S - PF + 1; t < S; t++) n += (t + PF < STEPS ? 2 : 0) + (ST ? 1 : 0);
   }
   return n;
 }
 __device__ unsigned short mlp_store_sink[64 * 8 + 16 * 16];  // where the stores of a row past the end go (the count of stores must not depend on data)
-template <int STEPS, int PF, int S, int GT, bool H16>
+template <int STEPS, int PF, int S, int GT, bool H16, bool ST>
 __device__ __forceinline__ void mlp_stb_step(f32x16 (&acc)[2][GT], bf16x8 (&aq)[PF][2], bf16x8 (&bq)[2][GT], const unsigned short* w0,
                                              const unsigned short* w1, const unsigned short* bl, int bs, int wave_u, unsigned short* cp) {
   constexpr int u = S % PF;
-  mlp_wait2<mlp_stb_younger<STEPS, PF, S>()>(aq[u][0], aq[u][1]);
+  mlp_wait2<mlp_stb_younger<STEPS, PF, S, ST>()>(aq[u][0], aq[u][1]);
   if constexpr (S + 1 < STEPS) {
 #pragma unroll
     for (int gt = 0; gt < GT; gt++) bq[(S + 1) & 1][gt] = *reinterpret_cast<const bf16x8*>(bl + (size_t)(32 * gt) * bs + 16 * (S + 1));
@@ -247,14 +247,16 @@ __device__ __forceinline__ void mlp_stb_step(f32x16 (&acc)[2][GT], bf16x8 (&aq)[
   }
   // (wave-uniform branches: exactly one store per wave and step; s_nop 1: a store of more than 8 bytes needs two wait states before
   // its data registers may be written, and the compiler does not look inside the asm)
+  if constexpr (ST) {
   unsigned short* to = cp + 16 * S;
   if (wave_u == 0) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(to), "v"(bq[S & 1][0]) : "memory");
   else if (wave_u == 1) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(to), "v"(bq[S & 1][1]) : "memory");
   else if (wave_u == 2) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(to), "v"(bq[S & 1][2]) : "memory");
   else asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(to), "v"(bq[S & 1][3]) : "memory");
-  if constexpr (S + 1 < STEPS) mlp_stb_step<STEPS, PF, S + 1, GT, H16>(acc, aq, bq, w0, w1, bl, bs, wave_u, cp);
+  }
+  if constexpr (S + 1 < STEPS) mlp_stb_step<STEPS, PF, S + 1, GT, H16, ST>(acc, aq, bq, w0, w1, bl, bs, wave_u, cp);
 }
-template <int STEPS, int GT, bool H16, int PF>
+template <int STEPS, int GT, bool H16, int PF, bool ST = true>
 __device__ __forceinline__ void mlp_gemm_hidden_stb(f32x16 (&acc)[2][GT], const unsigned short* __restrict__ Wf, size_t tile_stride,
                                                     const unsigned short* Bsrc, int bs, int lane, int wave_u /* uniform */,
                                                     unsigned short* __restrict__ cdst /* row 0 of the workgroup */, int crows) {
@@ -272,8 +274,8 @@ __device__ __forceinline__ void mlp_gemm_hidden_stb(f32x16 (&acc)[2][GT], const 
 #pragma unroll
   for (int gt = 0; gt < GT; gt++) bq[0][gt] = *reinterpret_cast<const bf16x8*>(bl + (size_t)(32 * gt) * bs);
   const int crow = 32 * wave_u + r;
-  unsigned short* cp = crow < crows ? cdst + (size_t)crow * MLP_W + kq : mlp_store_sink + lane * 8;
-  mlp_stb_step<STEPS, PF, 0, GT, H16>(acc, aq, bq, w0, w1, bl, bs, wave_u, cp);
+  unsigned short* cp = (ST && crow < crows) ? cdst + (size_t)crow * MLP_W + kq : mlp_store_sink + lane * 8;
+  mlp_stb_step<STEPS, PF, 0, GT, H16, ST>(acc, aq, bq, w0, w1, bl, bs, wave_u, cp);
 }
 
 // the backward's head product: two K-steps (32 padded outputs), no ring
@@ -372,6 +374,7 @@ __global__ __launch_bounds__(256, GT == 2 ? 3 : 2) void mlp_forward_kernel(MlpDe
       if constexpr (STORE)
         mlp_gemm_hidden_stb<MLP_W / 16, GT, H16, MLP_STB_PF>(acc, Wh, ts, s_h, MLP_HS, lane, wave_u,
                                                               acts + ((size_t)(l - 1) * d.N + row0) * MLP_W, min(ROWS, rows - row0));
+      // (the product without stores keeps its ring of four: rings of six and eight measured the same, 2.54 / 2.53 / 2.53 ms)
       else mlp_gemm_hidden<MLP_W / 16, GT, H16, false>(acc, Wh, ts, s_h, MLP_HS, lane);
     }
     __syncthreads();  // every wave is done reading the previous hidden vector
