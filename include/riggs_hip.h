@@ -778,11 +778,30 @@ int riggs_mlp_wgrad(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, int
                     const void* acts_bf16, const void* dpre_bf16, const float* g_out, const float* g_scale, void* workspace,
                     size_t workspace_bytes, float* const* grad_weights, float* const* grad_biases, float* grad_w_out,
                     float* grad_b_out, const int32_t* n_rows_dev, int32_t fp16, riggs_stream stream);
+/* riggs_mlp_wgrad for an MLP whose input ends in tail_ch values that are THE SAME FOR EVERY ROW (DeformMLP: the pose vector,
+ * /root/reference/skeleton_utils/skeleton_warp.py:152 `pose = local_rot.detach().reshape(-1)[None].expand(N, -1)`): the masters'
+ * weights of the two layers that read the input have in_ch + tail_ch input columns, the packed operands and x_emb_bf16 only the
+ * first in_ch (riggs_mlp_pack_tail); the gradient of the tail's columns is (bias gradient) x tail — written by the launch that
+ * sums the partials.  tail: tail_ch floats on the device.  tail_ch = 0: riggs_mlp_wgrad. */
+int riggs_mlp_wgrad_tail(int32_t N, int32_t in_ch, int32_t tail_ch, const float* tail, int32_t out_ch, int32_t depth, int32_t skip,
+                         const void* x_emb_bf16, const void* acts_bf16, const void* dpre_bf16, const float* g_out, const float* g_scale,
+                         void* workspace, size_t workspace_bytes, float* const* grad_weights, float* const* grad_biases,
+                         float* grad_w_out, float* grad_b_out, const int32_t* n_rows_dev, int32_t fp16, riggs_stream stream);
 /* fp32 master weights ((256, K_true) row-major per layer, (out_ch, 256) for the head) -> every bf16 operand the two kernels
  * read (layouts above), in one launch. */
 int riggs_mlp_pack(int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip, const float* const* weights, const float* w_out,
                    void* const* weights_bf16, void* const* weights_t_bf16, void* w_out_bf16, void* w_out_t_bf16,
                    int32_t fp16, riggs_stream stream);
+/* riggs_mlp_pack for masters with a constant input tail (riggs_mlp_wgrad_tail): K_true = in_ch + tail_ch (+ 256 in layer skip + 1);
+ * the tail's columns are left out of the packed operands. */
+int riggs_mlp_pack_tail(int32_t in_ch, int32_t tail_ch, int32_t out_ch, int32_t depth, int32_t skip, const float* const* weights,
+                        const float* w_out, void* const* weights_bf16, void* const* weights_t_bf16, void* w_out_bf16,
+                        void* w_out_t_bf16, int32_t fp16, riggs_stream stream);
+/* ... and what they contribute: bias_eff (2, 256) = [b_first + W_first[:, in_ch : in_ch + tail_ch] tail,
+ * b_skip + W_skip[:, in_ch : in_ch + tail_ch] tail] in fp32 — the biases riggs_mlp_forward takes for layer 0 and layer skip + 1
+ * (network_utils.py:46-51: h = cat([x_emb, t_emb]) enters both).  One launch per forward: the tail changes with every frame. */
+int riggs_mlp_tail_bias(int32_t in_ch, int32_t tail_ch, const float* w_first, const float* b_first, const float* w_skip,
+                        const float* b_skip, const float* tail, float* bias_eff, riggs_stream stream);
 /* The kernels' input operand from positions: row n = [x_n, sin(2^k x_n), cos(2^k x_n) for k < multires, tail (n_tail floats,
  * the same for every row: DeformMLP's pose), 0 ...] as bf16, (N rounded up to 128) x (width rounded up to 64)
  * (utils/time_utils.py:208-256 get_embedder + the concatenation of network_utils.py:40-46). */

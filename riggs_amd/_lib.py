@@ -210,6 +210,9 @@ _SIGS = {
     "riggs_mlp_wgrad": (C.c_int, [C.c_int32] * 5 + [_P] * 6 + [C.c_size_t] + [_P] * 5 + [C.c_int32, _P]),
     "riggs_mlp_embed": (C.c_int, [C.c_int32] * 3 + [_P] * 3 + [C.c_int32, _P]),
     "riggs_mlp_pack": (C.c_int, [C.c_int32] * 4 + [_P] * 6 + [C.c_int32, _P]),
+    "riggs_mlp_pack_tail": (C.c_int, [C.c_int32] * 5 + [_P] * 6 + [C.c_int32, _P]),
+    "riggs_mlp_tail_bias": (C.c_int, [C.c_int32] * 2 + [_P] * 7),
+    "riggs_mlp_wgrad_tail": (C.c_int, [C.c_int32] * 3 + [_P] + [C.c_int32] * 3 + [_P] * 6 + [C.c_size_t] + [_P] * 5 + [C.c_int32, _P]),
     "riggs_mlp_layout_probe": (C.c_int, [_P, _P]),
     "riggs_densify_select": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P] + [C.c_float] * 5 + [_P, _P]),
     "riggs_compact_workspace_bytes": (C.c_size_t, [C.c_int32]),

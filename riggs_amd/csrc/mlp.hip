@@ -708,7 +708,9 @@ __global__ __launch_bounds__(256) void mlp_live_gather_kernel(int N, int out_ch,
 // and ~60 small conversion / padding / transposition launches per MLP were a tenth of a heads-on training iteration)
 struct MlpPackDesc {
   int in_ch, in_pad, out_ch, depth, skip;
-  const float* W[10];            // (256, K_true): K_true = in_ch, in_ch + 256 (layer skip + 1) or 256
+  int tail_ch;                   // columns of the masters' input part that are NOT packed (riggs_mlp_pack_tail): they multiply a
+                                 // vector that is the same for every row and enter the layer through its bias (riggs_mlp_tail_bias)
+  const float* W[10];            // (256, K_true): K_true = in_ch + tail_ch, in_ch + tail_ch + 256 (layer skip + 1) or 256
   const float* Wout;             // (out_ch, 256)
   unsigned short* Wp[10];        // 256 x K_pad values, fragment-major
   unsigned short* Wt[10];        // l >= 1: the hidden part transposed, 256 x 256 values, fragment-major
@@ -735,9 +737,10 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(MlpPackDesc d) {
     return;
   }
   const bool first = (l == 0), sk = (l == d.skip + 1);
-  const int k_true = first ? d.in_ch : (sk ? d.in_ch + MLP_W : MLP_W);
+  const int in_true = d.in_ch + d.tail_ch;
+  const int k_true = first ? in_true : (sk ? in_true + MLP_W : MLP_W);
   const int k_pad = first ? d.in_pad : (sk ? d.in_pad + MLP_W : MLP_W);
-  const int hoff_true = sk ? d.in_ch : 0, hoff_pad = sk ? d.in_pad : 0;  // where the hidden part starts
+  const int hoff_true = sk ? in_true : 0, hoff_pad = sk ? d.in_pad : 0;  // where the hidden part starts
   const float* W = d.W[l];
   const int S = k_pad >> 4;
   for (int e = tid; e < MLP_W * k_pad; e += stride) {              // W_l: 8 tiles x S steps
@@ -754,6 +757,23 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(MlpPackDesc d) {
       const int k = 32 * T + (lane & 31), n = 16 * st + 8 * (lane >> 5) + j;
       d.Wt[l][e] = f2h<H16>(W[(size_t)n * k_true + hoff_true + k]);
     }
+}
+
+// The constant tail of the input (DeformMLP: every row's input ends in the SAME pose vector — skeleton_warp.py:152 expands
+// local_rot over the Gaussians, detached): W[:, in_ch : in_ch + tail_ch] · tail is one vector per layer that reads the input (the
+// first and layer skip + 1), so it joins the bias — in fp32, where the packed operands would have rounded the pose to 16 bits —
+// and the layers' products run over the positional embedding alone (K 128 -> 64).  bias_eff[y][n] = b_y[n] + sum_k W_y[n][in_ch + k] tail[k];
+// a wave per row.
+__global__ __launch_bounds__(256) void mlp_tail_bias_kernel(int in_ch, int tail_ch, const float* __restrict__ W0, const float* __restrict__ b0,
+                                                            const float* __restrict__ Ws, const float* __restrict__ bs,
+                                                            const float* __restrict__ tail, float* __restrict__ bias_eff) {
+  const int y = blockIdx.y, n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int ld = in_ch + tail_ch + (y ? MLP_W : 0);
+  const float* row = (y ? Ws : W0) + (size_t)n * ld + in_ch;
+  float acc = 0.f;
+  for (int k = lane; k < tail_ch; k += 64) acc = fmaf(row[k], tail[k], acc);
+  acc = wave_sum(acc);
+  if (lane == 63) bias_eff[y * MLP_W + n] = (y ? bs : b0)[n] + acc;
 }
 
 // Self-test of the fragment layouts this file assumes (A = identity against an ASYMMETRIC B): D must equal B.
@@ -908,13 +928,13 @@ int riggs_mlp_embed(int32_t N, int32_t multires, int32_t n_tail, const float* x,
   return 0;
 }
 
-int riggs_mlp_pack(int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip, const float* const* weights, const float* w_out,
-                   void* const* weights_bf16, void* const* weights_t_bf16, void* w_out_bf16, void* w_out_t_bf16,
-                   int32_t fp16, riggs_stream stream) {
+int riggs_mlp_pack_tail(int32_t in_ch, int32_t tail_ch, int32_t out_ch, int32_t depth, int32_t skip, const float* const* weights,
+                        const float* w_out, void* const* weights_bf16, void* const* weights_t_bf16, void* w_out_bf16,
+                        void* w_out_t_bf16, int32_t fp16, riggs_stream stream) {
   RIGGS_REQUIRE(depth >= 1 && depth <= 10 && in_ch >= 1 && in_ch <= MLP_MAX_IN && out_ch >= 1 && out_ch <= 32 && skip >= 0 &&
-                skip < depth - 1, "MLP shape out of range");
+                skip < depth - 1 && tail_ch >= 0 && tail_ch <= 4096, "MLP shape out of range");
   MlpPackDesc d;
-  d.in_ch = in_ch; d.in_pad = (in_ch + 63) & ~63; d.out_ch = out_ch; d.depth = depth; d.skip = skip;
+  d.in_ch = in_ch; d.in_pad = (in_ch + 63) & ~63; d.out_ch = out_ch; d.depth = depth; d.skip = skip; d.tail_ch = tail_ch;
   for (int l = 0; l < depth; l++) {
     d.W[l] = weights[l]; d.Wp[l] = (unsigned short*)weights_bf16[l]; d.Wt[l] = (unsigned short*)weights_t_bf16[l];
     RIGGS_REQUIRE(d.W[l] && d.Wp[l] && (l == 0 || d.Wt[l]), "MLP pack pointers");
@@ -923,6 +943,23 @@ int riggs_mlp_pack(int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip, c
   RIGGS_REQUIRE(d.Wout && d.Wout_p && d.Wout_t, "MLP pack head pointers");
   if (fp16) hipLaunchKernelGGL(mlp_pack_kernel<true>, dim3(32, depth + 1), dim3(256), 0, (hipStream_t)stream, d);
   else hipLaunchKernelGGL(mlp_pack_kernel<false>, dim3(32, depth + 1), dim3(256), 0, (hipStream_t)stream, d);
+  RIGGS_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int riggs_mlp_pack(int32_t in_ch, int32_t out_ch, int32_t depth, int32_t skip, const float* const* weights, const float* w_out,
+                   void* const* weights_bf16, void* const* weights_t_bf16, void* w_out_bf16, void* w_out_t_bf16,
+                   int32_t fp16, riggs_stream stream) {
+  return riggs_mlp_pack_tail(in_ch, 0, out_ch, depth, skip, weights, w_out, weights_bf16, weights_t_bf16, w_out_bf16, w_out_t_bf16, fp16,
+                             stream);
+}
+
+int riggs_mlp_tail_bias(int32_t in_ch, int32_t tail_ch, const float* w_first, const float* b_first, const float* w_skip,
+                        const float* b_skip, const float* tail, float* bias_eff, riggs_stream stream) {
+  RIGGS_REQUIRE(in_ch >= 1 && in_ch <= MLP_MAX_IN && tail_ch >= 1 && tail_ch <= 4096, "riggs_mlp_tail_bias: widths out of range");
+  RIGGS_REQUIRE(w_first && b_first && w_skip && b_skip && tail && bias_eff, "riggs_mlp_tail_bias: pointers");
+  hipLaunchKernelGGL(mlp_tail_bias_kernel, dim3(MLP_W / 4, 2), dim3(256), 0, (hipStream_t)stream, in_ch, tail_ch, w_first, b_first, w_skip,
+                     b_skip, tail, bias_eff);
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
 }

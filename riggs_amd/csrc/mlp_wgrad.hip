@@ -379,15 +379,35 @@ struct WgBias {
   float* dst;         // (count)
   int splits, M, count, pad;
 };
+// the masters' columns of a constant input tail (riggs_mlp_wgrad_tail): dW[n][col_off + k] = db[n] * tail[k] — the row sums the
+// product's workgroups left beside their partials, times the tail
+struct WgRank1 {
+  const float* part;  // (splits, M): the column sums of the layer's gradient operand
+  float* dst;         // the layer's weight gradient, leading dimension ld
+  int splits, M, ld, col_off;
+};
 struct WgReduceDesc {
-  int n, nb, pad0, pad1;
+  int n, nb, nr1, tail_ch;
   const float* g_scale;  // the gradients are divided by it (a power of two: exact)
+  const float* tail;
   WgOut o[WG_MAX_JOBS];
   WgBias b[WG_MAX_JOBS];
+  WgRank1 r1[2];
 };
 __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(WgReduceDesc D) {
   const float inv = D.g_scale ? 1.0f / D.g_scale[0] : 1.0f;
   const int j = blockIdx.y;
+  if (j == D.n + 1) {  // the constant tail's columns: a wave per row (256 rows over 64 workgroups of four waves)
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    for (int q1 = 0; q1 < D.nr1; q1++) {
+      const WgRank1& r = D.r1[q1];
+      float db = 0.f;
+      for (int q = 0; q < r.splits; q++) db += r.part[(size_t)q * r.M + n];  // (the order of the bias gradient's own sum)
+      db *= inv;
+      for (int k = lane; k < D.tail_ch; k += 64) r.dst[(size_t)n * r.ld + r.col_off + k] = db * D.tail[k];
+    }
+    return;
+  }
   if (j == D.n) {  // the bias gradients: blockIdx.x = which one, thread = column
     if ((int)blockIdx.x >= D.nb) return;
     const WgBias& bb = D.b[blockIdx.x];
@@ -559,7 +579,17 @@ int riggs_mlp_wgrad(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, int
                     const void* acts_bf16, const void* dpre_bf16, const float* g_out, const float* g_scale, void* workspace,
                     size_t workspace_bytes, float* const* grad_weights, float* const* grad_biases, float* grad_w_out,
                     float* grad_b_out, const int32_t* n_rows_dev, int32_t fp16, riggs_stream stream) {
+  return riggs_mlp_wgrad_tail(N, in_ch, 0, nullptr, out_ch, depth, skip, x_emb_bf16, acts_bf16, dpre_bf16, g_out, g_scale, workspace,
+                              workspace_bytes, grad_weights, grad_biases, grad_w_out, grad_b_out, n_rows_dev, fp16, stream);
+}
+
+int riggs_mlp_wgrad_tail(int32_t N, int32_t in_ch, int32_t tail_ch, const float* tail, int32_t out_ch, int32_t depth, int32_t skip,
+                         const void* x_emb_bf16, const void* acts_bf16, const void* dpre_bf16, const float* g_out, const float* g_scale,
+                         void* workspace, size_t workspace_bytes, float* const* grad_weights, float* const* grad_biases,
+                         float* grad_w_out, float* grad_b_out, const int32_t* n_rows_dev, int32_t fp16, riggs_stream stream) {
   RIGGS_REQUIRE(N >= 0 && depth >= 2 && depth <= 10, "MLP depth out of range");
+  RIGGS_REQUIRE(tail_ch >= 0 && tail_ch <= 4096 && (tail_ch == 0 || tail), "MLP weight gradients: the constant tail");
+  const int in_true = in_ch + tail_ch;  // the masters' input columns
   RIGGS_REQUIRE(in_ch >= 1 && in_ch <= 128 && out_ch >= 1 && out_ch <= 32, "MLP width out of range");
   RIGGS_REQUIRE(skip >= 0 && skip < depth - 1, "MLP skip layer out of range");
   if (N == 0) return 0;
@@ -591,7 +621,7 @@ int riggs_mlp_wgrad(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, int
   WgReduceDesc R;
   D.N = N; D.steps = P.steps; D.njobs = P.njobs; D.pad = 0; D.n_dev = n_rows_dev;
   D.zeros = (const unsigned short*)(ws + P.zeros_off);
-  R.n = P.njobs; R.nb = 0; R.pad0 = R.pad1 = 0; R.g_scale = g_scale;
+  R.n = P.njobs; R.nb = 0; R.nr1 = 0; R.tail_ch = tail_ch; R.tail = tail; R.g_scale = g_scale;
   for (int j = 0; j < P.njobs; j++) {
     WgJob& jb = D.job[j];
     WgOut& o = R.o[j];
@@ -606,7 +636,7 @@ int riggs_mlp_wgrad(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, int
       jb.d = dpre + (size_t)l * slab; jb.a = acts + (size_t)(l - 1) * slab;
       RIGGS_REQUIRE(grad_weights[l], "MLP weight-gradient outputs");
       const bool sk = (l == skip + 1);
-      o.dst = grad_weights[l]; o.rows = 256; o.cols = 256; o.ld = sk ? in_ch + 256 : 256; o.col_off = sk ? in_ch : 0;
+      o.dst = grad_weights[l]; o.rows = 256; o.cols = 256; o.ld = sk ? in_true + 256 : 256; o.col_off = sk ? in_true : 0;
       bias_dst = grad_biases[l];
       RIGGS_REQUIRE(bias_dst, "MLP bias-gradient outputs");
     } else if (P.cls[j] == WG_CLS_HEAD) {
@@ -616,13 +646,19 @@ int riggs_mlp_wgrad(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, int
     } else {
       jb.d = dpre + (size_t)l * slab; jb.a = xb;
       RIGGS_REQUIRE(grad_weights[l], "MLP weight-gradient outputs");
-      o.dst = grad_weights[l]; o.rows = 256; o.cols = in_ch; o.ld = (l == 0) ? in_ch : in_ch + 256; o.col_off = 0;
+      o.dst = grad_weights[l]; o.rows = 256; o.cols = in_ch; o.ld = (l == 0) ? in_true : in_true + 256; o.col_off = 0;
       if (l == 0) { bias_dst = grad_biases[0]; RIGGS_REQUIRE(bias_dst, "MLP bias-gradient outputs"); }  // (layer skip + 1's comes from its hidden product)
       (void)in_pad;
     }
     if (bias_dst) {
       WgBias& bb = R.b[R.nb++];
       bb.part = jb.colsum; bb.dst = bias_dst; bb.splits = P.splits[j]; bb.M = P.M[j]; bb.count = bias_count; bb.pad = 0;
+      if (tail_ch > 0 && P.cls[j] != WG_CLS_HEAD && (l == 0 || l == skip + 1)) {  // (the product whose row sums are the layer's bias gradient)
+        RIGGS_REQUIRE(R.nr1 < 2, "MLP weight gradients: more than two layers read the input");
+        WgRank1& r1 = R.r1[R.nr1++];
+        r1.part = jb.colsum; r1.dst = grad_weights[l]; r1.splits = P.splits[j]; r1.M = P.M[j];
+        r1.ld = (l == 0) ? in_true : in_true + 256; r1.col_off = in_ch;
+      }
     } else jb.colsum = nullptr;
   }
   static unsigned long long attr_done = 0ull;
@@ -634,7 +670,7 @@ int riggs_mlp_wgrad(int32_t N, int32_t in_ch, int32_t out_ch, int32_t depth, int
   if (fp16) hipLaunchKernelGGL(mlp_wgrad_kernel<true>, dim3(P.total_wg), dim3(512), lds_bytes, s, D);
   else hipLaunchKernelGGL(mlp_wgrad_kernel<false>, dim3(P.total_wg), dim3(512), lds_bytes, s, D);
   RIGGS_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3(64, P.njobs + 1), dim3(256), 0, s, R);
+  hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3(64, P.njobs + 1 + (R.nr1 > 0 ? 1 : 0)), dim3(256), 0, s, R);
   RIGGS_HIP_CHECK(hipGetLastError());
   return 0;
 }

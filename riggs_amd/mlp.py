@@ -46,8 +46,14 @@ class Packed:
     """bf16 copies of the weights in the kernels' layouts.  The buffers are allocated once; ``repack()`` refills them from
     the fp32 masters with one launch (``riggs_mlp_pack``) whenever those changed."""
 
-    def __init__(self, linears, head, in_ch: int, skip: int, fmt: str = None):
+    def __init__(self, linears, head, in_ch: int, skip: int, fmt: str = None, tail_ch: int = 0):
+        """``tail_ch`` > 0: the masters' input is ``in_ch + tail_ch`` wide and its last ``tail_ch`` values are THE SAME FOR EVERY ROW
+        (DeformMLP's pose, skeleton_warp.py:152): those columns are not packed — ``set_tail(vector)`` folds what they contribute into
+        the biases of the two layers that read the input (fp32), and ``param_grads`` writes their gradient as (bias gradient) x
+        tail.  ``in_ch`` is then the per-row part alone."""
         dev = head.weight.device
+        self.tail_ch = int(tail_ch)
+        self.bias_eff = torch.empty(2, 256, device=dev) if self.tail_ch else None
         self.fmt = fmt or DEFAULT_FORMAT
         self.dtype, self.fp16 = _fmt_dtype(self.fmt), int(self.fmt == "fp16")
         self.linears, self.head = list(linears), head
@@ -75,11 +81,26 @@ class Packed:
         ws = [L.require_cuda_f32("weight", lin.weight.detach()) for lin in self.linears]
         wo = L.require_cuda_f32("head weight", self.head.weight.detach())
         src = (C.c_void_p * self.depth)(*[t.data_ptr() for t in ws])
-        L.check(L.lib().riggs_mlp_pack(self.in_ch, self.out_ch, self.depth, self.skip, src, wo.data_ptr(), self._wp, self._wtp,
-                                       self.w_out.data_ptr(), self.w_out_t_bf16.data_ptr(), self.fp16, L.stream_ptr()), "riggs_mlp_pack")
+        L.check(L.lib().riggs_mlp_pack_tail(self.in_ch, self.tail_ch, self.out_ch, self.depth, self.skip, src, wo.data_ptr(), self._wp,
+                                            self._wtp, self.w_out.data_ptr(), self.w_out_t_bf16.data_ptr(), self.fp16, L.stream_ptr()),
+                "riggs_mlp_pack_tail")
+        self._w_masters = ws
         self.b = [L.require_cuda_f32("bias", lin.bias.detach()) for lin in self.linears]  # (views of the masters)
         self.b_out = L.require_cuda_f32("head bias", self.head.bias.detach())
-        self._bp = (C.c_void_p * self.depth)(*[t.data_ptr() for t in self.b])
+        bp = [t.data_ptr() for t in self.b]
+        if self.tail_ch:  # (the two layers that read the input take their bias from bias_eff: set_tail)
+            bp[0], bp[self.skip + 1] = self.bias_eff[0].data_ptr(), self.bias_eff[1].data_ptr()
+        self._bp = (C.c_void_p * self.depth)(*bp)
+
+    def set_tail(self, tail: torch.Tensor) -> torch.Tensor:
+        """Fold this frame's constant input tail into the biases (``riggs_mlp_tail_bias``: one launch); returns the vector as the
+        kernels read it (what ``param_grads`` needs again)."""
+        tail = L.require_cuda_f32("tail", tail.detach().reshape(-1), (self.tail_ch,))
+        s = self.skip + 1
+        L.check(L.lib().riggs_mlp_tail_bias(self.in_ch, self.tail_ch, self._w_masters[0].data_ptr(), self.b[0].data_ptr(),
+                                            self._w_masters[s].data_ptr(), self.b[s].data_ptr(), tail.data_ptr(),
+                                            self.bias_eff.data_ptr(), L.stream_ptr()), "riggs_mlp_tail_bias")
+        return tail
 
 
 def embed_bf16(p: Packed, x_emb: torch.Tensor) -> torch.Tensor:
@@ -255,13 +276,16 @@ def backward_data(p: Packed, g_out: torch.Tensor, masks: torch.Tensor, scale: to
 
 
 def param_grads(p: Packed, xb: torch.Tensor, acts: torch.Tensor, dpre: torch.Tensor, g_out: torch.Tensor, scale: torch.Tensor = None,
-                n_dev: torch.Tensor = None):
+                n_dev: torch.Tensor = None, tail: torch.Tensor = None):
     """Every parameter gradient of the MLP — [dW_0, db_0, ..., dW_{D-1}, db_{D-1}, dW_out, db_out], fp32, the masters' shapes,
     ``scale`` taken out again — from the operands the two passes left in memory (``riggs_mlp_wgrad``: three launches)."""
     N = g_out.shape[0]
     dev = g_out.device
     g_out = L.require_cuda_f32("g_out", g_out, (N, p.out_ch))
-    k_true = [p.in_ch if l == 0 else (p.in_ch + 256 if l == p.skip + 1 else 256) for l in range(p.depth)]
+    in_true = p.in_ch + p.tail_ch
+    if p.tail_ch and tail is None:
+        raise ValueError("a head with a constant input tail needs the tail of its forward for the parameter gradients")
+    k_true = [in_true if l == 0 else (in_true + 256 if l == p.skip + 1 else 256) for l in range(p.depth)]
     if N == 0:
         out = []
         for k in k_true:
@@ -274,9 +298,10 @@ def param_grads(p: Packed, xb: torch.Tensor, acts: torch.Tensor, dpre: torch.Ten
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     gwp = (C.c_void_p * p.depth)(*[t.data_ptr() for t in gw])
     gbp = (C.c_void_p * p.depth)(*[gb[l].data_ptr() for l in range(p.depth)])
-    L.check(L.lib().riggs_mlp_wgrad(N, p.in_ch, p.out_ch, p.depth, p.skip, xb.data_ptr(), acts.data_ptr(), dpre.data_ptr(),
-                                    g_out.data_ptr(), L.ptr(scale), ws.data_ptr(), nbytes, gwp, gbp, gwo.data_ptr(), gbo.data_ptr(),
-                                    L.ptr(n_dev), p.fp16, L.stream_ptr()), "riggs_mlp_wgrad")
+    L.check(L.lib().riggs_mlp_wgrad_tail(N, p.in_ch, p.tail_ch, L.ptr(tail) if p.tail_ch else None, p.out_ch, p.depth, p.skip,
+                                         xb.data_ptr(), acts.data_ptr(), dpre.data_ptr(), g_out.data_ptr(), L.ptr(scale), ws.data_ptr(),
+                                         nbytes, gwp, gbp, gwo.data_ptr(), gbo.data_ptr(), L.ptr(n_dev), p.fp16, L.stream_ptr()),
+            "riggs_mlp_wgrad_tail")
     out = []
     for l in range(p.depth):
         out += [gw[l], gb[l]]
@@ -336,6 +361,8 @@ def library_param_grads(p: Packed, xb: torch.Tensor, acts: torch.Tensor, dpre: t
     """``param_grads`` through library GEMMs (comparison only; ``db`` from ``backward_data(..., bias_sums=True)``)."""
     # every layer's product with the previous layer's activations has the same shape — the skip layer's hidden block
     # included — so layers 1 .. depth - 1 are ONE batched split-K GEMM; the two products with the embedding stay single calls
+    if p.tail_ch:
+        raise ValueError("library_param_grads: the comparison path knows no constant tail")
     gws = [None] * p.depth
     ls = p.skip + 1
     xb = xb[:g_out.shape[0]]
@@ -363,6 +390,7 @@ class _FusedMLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_emb, head, l2, res_base, res_mask, *params):
         p = head._packed()
+        ctx.tail = p.set_tail(head._tail) if p.tail_ch else None  # (this frame's pose -> the two biases; kept for the backward)
         ctx.l2 = l2  # None, or (coef, mean_sq): an L2 regulariser on the output folded into the backward (cotangent)
         n_rows = head._n_rows if x_emb.dtype == p.dtype else x_emb.shape[0]
         xb = x_emb if x_emb.dtype == p.dtype else embed_bf16(p, x_emb)
@@ -399,9 +427,11 @@ class _FusedMLP(torch.autograd.Function):
             _, count, xl, gl, scale = live_rows(p, g_out, xb, sig, want_scale=True)
             if not p.fp16:
                 scale = None
+            if p.tail_ch:
+                p.set_tail(ctx.tail)  # (the repeated forward reads the biases of THIS call's frame)
             _, (acts, masks) = forward(p, xl[:ctx.n], True, xl, n_dev=count)
             dpre, _ = backward_data(p, gl, masks, scale, bias_sums=False, n_dev=count)
-            grads = param_grads(p, xl, acts, dpre, gl, scale, n_dev=count)
+            grads = param_grads(p, xl, acts, dpre, gl, scale, n_dev=count, tail=ctx.tail)
             ctx.head.last_live_count = count
         else:
             if plain and sig is None:
@@ -414,14 +444,16 @@ class _FusedMLP(torch.autograd.Function):
             if ctx.sparse:
                 (xb,) = ctx.saved_tensors
                 _, count, xl, gl = live_rows(p, g_out, xb)
+                if p.tail_ch:
+                    p.set_tail(ctx.tail)
                 _, (acts, masks) = forward(p, xl[:ctx.n], True, xl, n_dev=count)
                 dpre, _ = backward_data(p, gl, masks, scale, bias_sums=False, n_dev=count)
-                grads = param_grads(p, xl, acts, dpre, gl, scale, n_dev=count)
+                grads = param_grads(p, xl, acts, dpre, gl, scale, n_dev=count, tail=ctx.tail)
                 ctx.head.last_live_count = count
             else:
                 xb, acts, masks = ctx.saved_tensors
                 dpre, _ = backward_data(p, g_out, masks, scale, bias_sums=False)
-                grads = param_grads(p, xb, acts, dpre, g_out, scale)
+                grads = param_grads(p, xb, acts, dpre, g_out, scale, tail=ctx.tail)
         return (None, None, None, g_res if ctx.res else None, None) + tuple(grads)
 
 
@@ -430,7 +462,7 @@ class FusedHead:
     parameters; the bf16 copies are rebuilt when a parameter's version counter changes (optimizer step, load)."""
 
     def __init__(self, linears, head_linear, in_ch: int, skip: int, fmt: str = None, sparse_rows: bool = False,
-                 out_sigmoid: bool = False):
+                 out_sigmoid: bool = False, tail_ch: int = 0):
         """``sparse_rows``: the backward runs on the rows whose cotangent is non-zero (``live_rows``) and the forward stores no
         activations — exact (a zero row contributes zero to every parameter gradient), and the right choice for a head whose
         cotangent reaches only the Gaussians the render touched (the WeightMLP: 10-30 % of the rows); a head with a dense
@@ -440,6 +472,8 @@ class FusedHead:
         self.out_sigmoid = bool(out_sigmoid)  # the head's value goes through a sigmoid inside the forward launch (WeightMLP)
         self.last_live_count = None  # device int32 (1,): the live rows of the last row-sparse backward
         self.linears, self.head_linear, self.in_ch, self.skip = list(linears), head_linear, in_ch, skip
+        self.tail_ch = int(tail_ch)  # the input's last tail_ch values are one vector for all rows (``__call__(..., tail=)``): Packed
+        self._tail = None
         self._pk, self._ver, self._ptrs = None, None, None
 
     def params(self):
@@ -452,7 +486,7 @@ class FusedHead:
         ptrs = tuple(q.data_ptr() for q in self.params())
         ver = tuple(q._version for q in self.params())
         if self._pk is None or ptrs != self._ptrs:
-            self._pk, self._ptrs, self._ver = Packed(self.linears, self.head_linear, self.in_ch, self.skip, self.fmt), ptrs, ver
+            self._pk, self._ptrs, self._ver = Packed(self.linears, self.head_linear, self.in_ch, self.skip, self.fmt, self.tail_ch), ptrs, ver
             fresh = True
         else:
             fresh = False
@@ -466,7 +500,7 @@ class FusedHead:
             self._ver = ver
         return self._pk
 
-    def __call__(self, x_emb: torch.Tensor, n_rows: int = None, l2=None, res=None):
+    def __call__(self, x_emb: torch.Tensor, n_rows: int = None, l2=None, res=None, tail: torch.Tensor = None):
         """``x_emb``: (N, in_ch) fp32, or the padded bf16 operand of ``embed_positions_bf16`` together with ``n_rows`` = N.
         ``l2``: None, or ``(coef, mean_sq)`` — device scalars: the backward adds ``coef * output`` to the incoming cotangent
         (d/d output of ``lambda * mean(output^2)`` for ``coef = 2 lambda / output.numel()``) and writes mean(output^2) into
@@ -475,6 +509,9 @@ class FusedHead:
         gradient of its own, or None = 1), joined by the forward launch's epilogue; the backward sends the second value's cotangent
         through to ``base`` and, times ``mask``, into the MLP."""
         self._n_rows = n_rows
+        if self.tail_ch and tail is None:
+            raise ValueError("this head was built with a constant input tail: pass it (tail=)")
+        self._tail = tail
         if res is not None:
             return _FusedMLP.apply(x_emb.contiguous(), self, l2, res[0], res[1], *self.params())
         return _FusedMLP.apply(x_emb.contiguous(), self, l2, None, None, *self.params())

@@ -740,12 +740,17 @@ class SkeletonWarp(nn.Module):
             return self.detail_net(x, pose)
         from .mlp import FusedHead
         net = self.detail_net
+        if net.t_multires <= 0 and net.multires > 0:  # the reference's configuration: PE(x) and the raw pose vector
+            # (the pose is ONE vector for all Gaussians — skeleton_warp.py:152 expands it — so it enters through the biases of the two
+            # layers that read the input, in fp32, and the kernels' operand is the positional embedding alone: riggs_amd.mlp.Packed)
+            from .mlp import embed_positions_bf16
+            n_pose = int(pose.shape[-1])
+            if getattr(self, "_fh_d", None) is None:
+                self._fh_d = FusedHead(net.linear, net.gaussian_warp, net.input_ch - n_pose, net.skips[0], self._fused_fmt, tail_ch=n_pose)
+            return self._fh_d(embed_positions_bf16(x, net.multires, fmt=self._fused_fmt), n_rows=x.shape[0],
+                              l2=getattr(self, "template_l2", None), res=res, tail=pose[0])
         if getattr(self, "_fh_d", None) is None:
             self._fh_d = FusedHead(net.linear, net.gaussian_warp, net.input_ch, net.skips[0], self._fused_fmt)
-        if net.t_multires <= 0 and net.multires > 0:  # the reference's configuration: PE(x) and the raw pose vector
-            from .mlp import embed_positions_bf16
-            return self._fh_d(embed_positions_bf16(x, net.multires, pose[0], fmt=self._fused_fmt), n_rows=x.shape[0],
-                              l2=getattr(self, "template_l2", None), res=res)
         t_emb = _embed(pose, net.t_multires) if net.t_multires > 0 else pose
         x_emb = _embed(x, net.multires) if net.multires > 0 else x
         return self._fh_d(torch.cat([x_emb, t_emb], dim=-1), l2=getattr(self, "template_l2", None))

@@ -174,6 +174,55 @@ def test_stored_activations_are_the_layers_outputs(N, fmt):
                 assert bool((d <= 2 * eps * (ref.abs() + a_in.abs().max() * 1e-2 + 1e-6)).all()), (name, fmt, N, l, float(d.max()))
 
 
+@pytest.mark.parametrize("fmt", ["fp16", "bf16"])
+@pytest.mark.parametrize("N", [1, 63, 20_011])
+def test_constant_input_tail_through_the_biases(N, fmt):
+    """DeformMLP's pose is ONE vector for all rows (skeleton_warp.py:152): with ``tail_ch`` the head packs the positional
+    embedding alone, the pose enters through the two biases in fp32 (riggs_mlp_tail_bias) and its weight columns' gradient is
+    (bias gradient) x pose (riggs_mlp_wgrad_tail).  Against the fp32 mirror (the bars of the generic fused path) and against the
+    generic fused path itself (same kernels with the pose as 96 more operand columns, rounded to 16 bits)."""
+    name, net, head, xe = _nets(N)[1]
+    assert name == "DeformMLP"
+    torch.manual_seed(11)
+    x = torch.randn(N, 3, device="cuda") * 0.5
+    pose = torch.randn(96, device="cuda")
+    xe = torch.cat([_embed(x, net.multires), pose[None].expand(N, -1)], -1).contiguous()
+    g = torch.randn(N, head.weight.shape[0], device="cuda") * (3e-8 if fmt == "fp16" else 1.0)
+    out32 = head(_hidden(net, xe)[0])
+    (out32 * g).sum().backward()
+    g32 = {n: q.grad.clone() for n, q in net.named_parameters()}
+    for q in net.parameters():
+        q.grad = None
+    gen = M.FusedHead(net.linear, head, xe.shape[1], net.skips[0], fmt)
+    out_g = gen(xe)
+    (out_g * g).sum().backward()
+    ggen = {n: q.grad.clone() for n, q in net.named_parameters()}
+    for q in net.parameters():
+        q.grad = None
+    fh = M.FusedHead(net.linear, head, xe.shape[1] - 96, net.skips[0], fmt, tail_ch=96)
+    with pytest.raises(ValueError):
+        fh(M.embed_positions_bf16(x, net.multires, fmt=fmt), n_rows=N)
+    out = fh(M.embed_positions_bf16(x, net.multires, fmt=fmt), n_rows=N, tail=pose)
+    (out * g).sum().backward()
+    tol = {"fp16": 6e-3, "bf16": 4e-2}[fmt]
+    assert _rel(out, out32) < tol, _rel(out, out32)
+    assert _rel(out, out_g) < tol, _rel(out, out_g)
+    skip_w = "linear.%d.weight" % (net.skips[0] + 1)
+    for n, q in net.named_parameters():
+        assert q.grad is not None and q.grad.shape == g32[n].shape, n
+        assert bool(torch.isfinite(q.grad).all()), n
+        if N > 1000:
+            assert _mrel(q.grad, g32[n]) < {"fp16": 0.08, "bf16": 0.2}[fmt], (n, _mrel(q.grad, g32[n]))
+            assert _mrel(q.grad, ggen[n]) < {"fp16": 0.08, "bf16": 0.2}[fmt], (n, _mrel(q.grad, ggen[n]))
+        if n in ("linear.0.weight", skip_w):  # the pose's columns: exactly (bias gradient) x pose
+            b = net.linear[0].bias.grad if n == "linear.0.weight" else net.linear[net.skips[0] + 1].bias.grad
+            want = b[:, None] * pose[None, :]
+            got = q.grad[:, 27:27 + 96]
+            assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max()) + 1e-30, n
+    for q in net.parameters():
+        q.grad = None
+
+
 def test_skeleton_warp_with_fused_heads_tracks_the_fp32_heads():
     from riggs_amd import synth
     from riggs_amd.skeleton import SkeletonWarp
