@@ -721,6 +721,24 @@ class SkeletonWarp(nn.Module):
         self._fh_w = self._fh_d = None
         return self
 
+    def _fused_embedding(self, x, multires: int):
+        """The positional embedding of ``x`` as the fused heads' 16-bit operand, computed ONCE per call of the warp for both heads:
+        get_embedder's columns are [x, sin(2^k x), cos(2^k x) for k < multires] (utils/time_utils.py:208-256), so the DeformMLP's
+        (multires 4: 27 columns) are the first columns of the WeightMLP's (multires 10: 63) — same values, same rounding — and both
+        operands are 64 wide; the DeformMLP's packed weights are zero past its own columns (riggs_mlp_pack) and the partial-sum
+        launch writes only those of its gradient."""
+        from .mlp import embed_positions_bf16
+        widest = max(int(self.skinning_weight_mlp.multires), int(self.detail_net.multires)) if (
+            self.use_skinning_weight_mlp and self.use_template_offsets) else multires
+        if 3 * (1 + 2 * widest) > 64 or widest < multires:  # (one 64-column operand must hold both)
+            widest = multires
+        # (the cache lives for ONE call of deform_by_pose, which clears it on entry: nothing can change x in between)
+        key = (x.data_ptr(), x.shape[0], self._fused_fmt, widest)
+        hit = getattr(self, "_emb_cache", None)
+        if hit is None or hit[0] != key:
+            hit = self._emb_cache = (key, embed_positions_bf16(x, widest, fmt=self._fused_fmt))
+        return hit[1]
+
     def _head_weight(self, x):
         if not getattr(self, "_fused_heads", False):
             return self.skinning_weight_mlp(x)
@@ -730,8 +748,7 @@ class SkeletonWarp(nn.Module):
             # (the sigmoid of network_utils.py:107 inside the forward launch, its derivative inside the backward's first launch)
             self._fh_w = FusedHead(net.linear, net.weight_predict, net.input_ch, net.skips[0], self._fused_fmt,
                                    sparse_rows=getattr(self, "_fused_sparse_w", True), out_sigmoid=True)
-        from .mlp import embed_positions_bf16
-        return self._fh_w(embed_positions_bf16(x, net.multires, fmt=self._fused_fmt), n_rows=x.shape[0])
+        return self._fh_w(self._fused_embedding(x, net.multires), n_rows=x.shape[0])
 
     def _head_detail(self, x, pose, res=None):
         """The template offsets; with ``res = (d_xyz, mask)`` on the fused path ``(offsets, d_xyz + offsets * mask)`` — joined by
@@ -743,11 +760,10 @@ class SkeletonWarp(nn.Module):
         if net.t_multires <= 0 and net.multires > 0:  # the reference's configuration: PE(x) and the raw pose vector
             # (the pose is ONE vector for all Gaussians — skeleton_warp.py:152 expands it — so it enters through the biases of the two
             # layers that read the input, in fp32, and the kernels' operand is the positional embedding alone: riggs_amd.mlp.Packed)
-            from .mlp import embed_positions_bf16
             n_pose = int(pose.shape[-1])
             if getattr(self, "_fh_d", None) is None:
                 self._fh_d = FusedHead(net.linear, net.gaussian_warp, net.input_ch - n_pose, net.skips[0], self._fused_fmt, tail_ch=n_pose)
-            return self._fh_d(embed_positions_bf16(x, net.multires, fmt=self._fused_fmt), n_rows=x.shape[0],
+            return self._fh_d(self._fused_embedding(x, net.multires), n_rows=x.shape[0],
                               l2=getattr(self, "template_l2", None), res=res, tail=pose[0])
         if getattr(self, "_fh_d", None) is None:
             self._fh_d = FusedHead(net.linear, net.gaussian_warp, net.input_ch, net.skips[0], self._fused_fmt)
@@ -756,6 +772,7 @@ class SkeletonWarp(nn.Module):
         return self._fh_d(torch.cat([x_emb, t_emb], dim=-1), l2=getattr(self, "template_l2", None))
 
     def deform_by_pose(self, x, node_attrs, motion_mask, _time=None):
+        self._emb_cache = None  # (_fused_embedding: shared by the two heads of THIS call)
         x = L.require_cuda_f32("x", x.detach(), (x.shape[0], 3))
         if _time is None:
             local_rot, global_trans = node_attrs["local_rotation"], node_attrs["global_trans"]
