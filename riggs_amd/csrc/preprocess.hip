@@ -607,22 +607,6 @@ __global__ __launch_bounds__(256, 3) void preprocess_bwd_kernel(PreBwdArgs b) {
 // block's 256) used to walk two or three batches one behind the other on the one wave, each a full round of scattered loads,
 // ~1 000 vector instructions and stores.
 #define PBL_WAVES 2
-typedef float pb_f4u __attribute__((ext_vector_type(4), aligned(4)));
-typedef float pb_f3u __attribute__((ext_vector_type(3), aligned(4)));
-template <int KOFF>
-__device__ __forceinline__ void pb_store_row(float* __restrict__ mine, const int sh_per, const int M, const float (&Bk)[16], const float (&gcs)[3]) {
-  auto val = [&](int e) { const int k = (e + KOFF) / 3, c = (e + KOFF) % 3; return (k < 16 && k < M) ? Bk[k < 16 ? k : 15] * gcs[c] : 0.f; };
-#pragma unroll
-  for (int q = 0; q < 12; q++) {
-    if (4 * q + 4 <= sh_per) {
-      pb_f4u t; t.x = val(4 * q); t.y = val(4 * q + 1); t.z = val(4 * q + 2); t.w = val(4 * q + 3);
-      *reinterpret_cast<pb_f4u*>(mine + 4 * q) = t;
-    } else {
-#pragma unroll
-      for (int c = 0; c < 4; c++) if (4 * q + c < sh_per) mine[4 * q + c] = val(4 * q + c);
-    }
-  }
-}
 __global__ __launch_bounds__(64 * PBL_WAVES) void preprocess_bwd_lean_kernel(PreBwdArgs b) {
   __shared__ unsigned char s_list[256];
   __shared__ int s_cnt[PBL_WAVES];
@@ -725,24 +709,13 @@ __global__ __launch_bounds__(64 * PBL_WAVES) void preprocess_bwd_lean_kernel(Pre
       for (int k = 0; k < 6; k++) c6[k] = a.cov3D[6 * i + k];
       if (sh_mode) {
         cl = a.clamped[i];
-        // (its own coefficient row: staging the batch's rows through LDS with a row per direct-to-LDS load instruction measured
-        // the same at the headline, 22.7 against 22.9 us, and cost two barriers.  The row is read 16 bytes at a time — rows are
-        // 4-byte aligned, which is all a multi-dword global access asks for: 12 instructions of 64 different lines each instead
-        // of 45; what the kernel costs beyond its latency chain is lines touched per instruction: round 6)
+        // (its own coefficient row, 45 loads of 64 different lines each: staging the batch's rows through LDS with a row per
+        // direct-to-LDS load instruction measured the same, 22.7 against 22.9 us, and cost two barriers)
         const float* mine = (a.shs_rest ? a.shs_rest : a.shs) + (size_t)i * sh_per;
         if (a.shs_rest) {
           shv[0] = a.shs[3 * i]; shv[1] = a.shs[3 * i + 1]; shv[2] = a.shs[3 * i + 2];
-          if (sh_per == 45) {  // (degree 3: what the trainer runs)
 #pragma unroll
-            for (int q = 0; q < 11; q++) {
-              const pb_f4u t = *reinterpret_cast<const pb_f4u*>(mine + 4 * q);
-              shv[3 + 4 * q] = t.x; shv[4 + 4 * q] = t.y; shv[5 + 4 * q] = t.z; shv[6 + 4 * q] = t.w;
-            }
-            shv[47] = mine[44];
-          } else {
-#pragma unroll
-            for (int e = 0; e < 45; e++) if (e < sh_per) shv[3 + e] = mine[e];
-          }
+          for (int e = 0; e < 45; e++) if (e < sh_per) shv[3 + e] = mine[e];
         } else {
 #pragma unroll
           for (int e = 0; e < 48; e++) if (e < sh_per) shv[e] = mine[e];
@@ -757,9 +730,12 @@ __global__ __launch_bounds__(64 * PBL_WAVES) void preprocess_bwd_lean_kernel(Pre
         // store instruction the wave stood at two barriers and 2 x 20 LDS round trips: 6.5 us of a 22.7 us kernel)
         if (in_range) {
           float* mine = dst_rest + (size_t)slot * sh_per;
-          // (16 bytes per store — see the loads above; element e of the row is Bk[(e + koff) / 3] * gcs[(e + koff) % 3])
-          if (a.shs_rest) pb_store_row<3>(mine, sh_per, a.M, Bk, gcs);
-          else pb_store_row<0>(mine, sh_per, a.M, Bk, gcs);
+#pragma unroll
+          for (int k = 0; k < 16; k++) {
+            if (k < a.M && 3 * k >= koff) {
+              mine[3 * k - koff] = Bk[k] * gcs[0]; mine[3 * k + 1 - koff] = Bk[k] * gcs[1]; mine[3 * k + 2 - koff] = Bk[k] * gcs[2];
+            }
+          }
         }
       }
       if (a.shs_rest && in_range) {
