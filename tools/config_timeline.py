@@ -13,7 +13,7 @@ from riggs_amd.graph import GraphedFrame  # noqa: E402
 cfg = {**CONFIGS, **EXTRA}[sys.argv[1] if len(sys.argv) > 1 else "C5"]
 bench.WORKLOAD.update(cfg)
 sc, cam, gm, sw = bench.build_workload(0, "cuda:0")
-gf = GraphedFrame(gm, sw, cam, torch.zeros(3, device="cuda"), bench.params_of(gm, sw)).capture()
+gf = GraphedFrame(gm, sw, cam, torch.zeros(3, device="cuda"), bench.params_of(gm, sw), sparse_grad_rows=True).capture()  # (as bench.py and configs_sweep.py)
 gf.set_inputs(gimg=torch.rand(3, cfg["H"], cfg["W"], device="cuda") * 1e-6)
 for _ in range(15):
     gf.run()
