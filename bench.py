@@ -223,7 +223,7 @@ def train_step_heads_timing(dev, surface=False, steps=40):
             "heads_ms": round(on - off, 4), "template_frame_ms_per_step": round(res["template_ms"], 4),
             "weight_mlp_live_rows": round(res["live"], 4), "tile_instances_R": res[True]["R"], "final_loss": round(res[True]["loss"], 6),
             "template_offsets_loss": res["t_loss"],
-            "what": "one hipGraph per training iteration, %s scene, both MLP heads on (fused fp16 MFMA; WeightMLP backward on the rows with a "
+            "what": "one hipGraph per training iteration, %s scene, both MLP heads on (fused fp16 MFMA; the DeformMLP's pose through its biases; WeightMLP backward on the rows with a "
                     "gradient), objective = image loss + template-offsets L2 + template_fixed (train_rig.py:446-482), FusedAdam incl. the heads; "
                     "heads_ms = this minus the same iteration with the heads off; fastest of three blocks of %d; not the headline metric"
                     % ("opaque-skin" if surface else "headline", steps)}
