@@ -54,6 +54,7 @@ class Packed:
         dev = head.weight.device
         self.tail_ch = int(tail_ch)
         self.bias_eff = torch.empty(2, 256, device=dev) if self.tail_ch else None
+        self._tail_set = False  # (forward() refuses to read bias_eff before the first set_tail)
         self.fmt = fmt or DEFAULT_FORMAT
         self.dtype, self.fp16 = _fmt_dtype(self.fmt), int(self.fmt == "fp16")
         self.linears, self.head = list(linears), head
@@ -100,6 +101,7 @@ class Packed:
         L.check(L.lib().riggs_mlp_tail_bias(self.in_ch, self.tail_ch, self._w_masters[0].data_ptr(), self.b[0].data_ptr(),
                                             self._w_masters[s].data_ptr(), self.b[s].data_ptr(), tail.data_ptr(),
                                             self.bias_eff.data_ptr(), L.stream_ptr()), "riggs_mlp_tail_bias")
+        self._tail_set = True
         return tail
 
 
@@ -135,6 +137,8 @@ def forward(p: Packed, x_emb: torch.Tensor, want_acts: bool, xb: torch.Tensor = 
     n_rows_dev) — the compacted rows of the row-sparse backward.  ``sigmoid`` / ``res_base`` / ``res_mask``: the output epilogue
     (``struct riggs_mlp_epilogue``) — with ``res_base`` the third return value is ``res_base + out * res_mask``."""
     N = x_emb.shape[0]
+    if p.tail_ch and not p._tail_set:
+        raise ValueError("a head with a constant input tail: Packed.set_tail(vector) comes before its first forward")
     if xb is None:
         xb = embed_bf16(p, x_emb)
     out = torch.empty(N, p.out_ch, device=x_emb.device)
