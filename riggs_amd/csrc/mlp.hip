@@ -90,7 +90,7 @@ __device__ __forceinline__ int mlp_k(const MlpDesc& d, int l) { return l == 0 ? 
 // fragments come from LDS: one step ahead is enough for them).
 #define MLP_PF 4
 #ifndef MLP_STB_PF
-#define MLP_STB_PF 6   // ring depth of the forward's storing product (mlp_gemm_hidden_stb)
+#define MLP_STB_PF 7   // ring depth of the forward's storing product (mlp_gemm_hidden_stb)
 #endif
 template <int NT, int GT, bool H16>
 __device__ __forceinline__ void mlp_gemm_t(f32x16 (&acc)[NT][GT], const unsigned short* __restrict__ Wf, size_t tile_stride,
@@ -202,19 +202,22 @@ __device__ __forceinline__ void mlp_gemm_hidden(f32x16 (&acc)[2][GT], const unsi
   }
 }
 
-// The FORWARD's form of "the B operand's rows leave for HBM under the product" (round 6).  The COPY form above re-reads the rows
-// from LDS into registers of their own in front of the loop: in the forward kernel that took the last of the 256 registers and
-// lost what the overlap gained (0.454 -> 0.470 ms).  Here the stores cost no register and no LDS read: at K-step s every wave
-// holds the hidden fragments of ALL 128 Gaussians for k in [16 s, 16 s + 16) as its B operands — lane (r, kq) 16 bytes of row
-// 32 gt + r — so wave w sends tile gt = w: ONE 16-byte store per thread and step, 32-byte pieces of 32 rows per instruction
-// that L2 merges into full lines over the sixteen steps.  Stores and loads share vmcnt IN ORDER, so a store issued at step s has
-// to have landed when the fragments loaded behind it are waited for: with the ring of four that is one microsecond later, and
-// every wait stood behind a store ("one store per K-step, interleaved, LOST" above).  Hence a ring of PF steps (PF = 8: 64
-// registers of fragments; the weights' loads are then waited for eight steps = two microseconds behind their issue at two waves
-// per SIMD, and so are the stores in front of them).  The counts, per step s (vector-memory operations issued behind the loads
-// of step s when they are waited for):  prologue loads L(0..PF-1), then step t issues L(t + PF) (two loads, while they exist)
-// and St(t) behind them.  (The BACKWARD keeps the COPY form: with its gradient rows sent out of the fragments behind rings of six
-// and seven its data-gradient pass went 0.396 -> 0.445 ms and the iteration 2.50 -> 2.57 ms; profiles/round6_mlp_forward_stores_ab.txt.)
+// The FORWARD's form of "the B operand's rows leave for HBM under the product" (round 6).  The COPY form above issues a layer's
+// sixteen stores per thread together, in front of the loop, out of registers of their own: in the forward kernel that took the last
+// of the 256 registers and lost what the overlap gained (0.454 -> 0.470 ms).  Here ONE store per thread and K-step: at step s the
+// workgroup sends rows 8 s .. 8 s + 7 of the B operand's 128 — 16 bytes per thread, re-read from LDS at the top of the step (the
+// MFMAs of the step hide the read), a wave's store = two whole rows of 512 bytes: full lines — through one register quad.
+// Stores and loads share vmcnt IN ORDER, so a store issued at step s has to have landed when the fragments loaded behind it are
+// waited for: with the ring of four that is one microsecond later, and every wait stood behind a store ("one store per K-step,
+// interleaved, LOST" above).  Hence a ring of PF steps (MLP_STB_PF: the weights' loads are waited for PF steps behind their issue,
+// and so are the stores in front of them).  The counts, per step s (vector-memory operations issued behind the loads of step s
+// when they are waited for): prologue loads L(0..PF-1), then step t issues L(t + PF) (two loads, while they exist) and St(t)
+// behind them.
+// Measured on the way (profiles/round6_mlp_forward_stores_ab.txt): the same store sourced from the B FRAGMENTS a wave holds anyway
+// (wave w sends tile w: no LDS read, no register, but 32-byte pieces of 32 rows per instruction that L2 has to merge) behind a ring
+// of six: heads-on iteration 2.65 -> 2.50 ms; as full lines: -> 2.43 (ring 6) / 2.41 (ring 7).  With `nt` on the stores: 3.38 ms.
+// The BACKWARD keeps the COPY form: with the fragment-sourced stores behind rings of six and seven its data-gradient pass went
+// 0.396 -> 0.445 ms, and with this form behind rings of 6 / 7 / 8 the iteration moved by 2.455 -> 2.449 / 2.457 / 2.440 ms: noise.
 template <int N> __device__ __forceinline__ void mlp_wait2(bf16x8& a, bf16x8& b) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
 template <int STEPS, int PF, int S, bool ST> constexpr int mlp_stb_younger() {
   int n = 0;
@@ -227,12 +230,19 @@ template <int STEPS, int PF, int S, bool ST> constexpr int mlp_stb_younger() {
   }
   return n;
 }
-__device__ unsigned short mlp_store_sink[64 * 8 + 16 * 16];  // where the stores of a row past the end go (the count of stores must not depend on data)
+__device__ unsigned short mlp_store_sink[64 * 8];  // where the store of a row past the end goes (the count of stores must not depend on data)
+struct MlpStbRows {  // this thread's 16-byte piece of rows row, row + 8, ..., row + 120: where it lies in LDS and where it goes
+  const unsigned short* lrow;
+  unsigned short* grow;
+  int row, crows, lane;
+};
 template <int STEPS, int PF, int S, int GT, bool H16, bool ST>
 __device__ __forceinline__ void mlp_stb_step(f32x16 (&acc)[2][GT], bf16x8 (&aq)[PF][2], bf16x8 (&bq)[2][GT], const unsigned short* w0,
-                                             const unsigned short* w1, const unsigned short* bl, int bs, int wave_u, unsigned short* cp) {
+                                             const unsigned short* w1, const unsigned short* bl, int bs, const MlpStbRows& ro) {
   constexpr int u = S % PF;
   mlp_wait2<mlp_stb_younger<STEPS, PF, S, ST>()>(aq[u][0], aq[u][1]);
+  bf16x8 sv;
+  if constexpr (ST) sv = *reinterpret_cast<const bf16x8*>(ro.lrow + (size_t)(8 * S) * bs);
   if constexpr (S + 1 < STEPS) {
 #pragma unroll
     for (int gt = 0; gt < GT; gt++) bq[(S + 1) & 1][gt] = *reinterpret_cast<const bf16x8*>(bl + (size_t)(32 * gt) * bs + 16 * (S + 1));
@@ -245,22 +255,19 @@ __device__ __forceinline__ void mlp_stb_step(f32x16 (&acc)[2][GT], bf16x8 (&aq)[
     MLP_GLOAD(aq[u][0], w0 + (size_t)(S + PF) * MLP_FRAG);
     MLP_GLOAD(aq[u][1], w1 + (size_t)(S + PF) * MLP_FRAG);
   }
-  // (wave-uniform branches: exactly one store per wave and step; s_nop 1: a store of more than 8 bytes needs two wait states before
-  // its data registers may be written, and the compiler does not look inside the asm)
+  // (exactly one store per thread and step, whatever the row count: rows past the end go to the sink.  s_nop 1: a store of more
+  // than 8 bytes needs two wait states before its data registers may be written, and the compiler does not look inside the asm)
   if constexpr (ST) {
-  unsigned short* to = cp + 16 * S;
-  if (wave_u == 0) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(to), "v"(bq[S & 1][0]) : "memory");
-  else if (wave_u == 1) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(to), "v"(bq[S & 1][1]) : "memory");
-  else if (wave_u == 2) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(to), "v"(bq[S & 1][2]) : "memory");
-  else asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(to), "v"(bq[S & 1][3]) : "memory");
+    unsigned short* to = (ro.row + 8 * S < ro.crows) ? ro.grow + (size_t)(8 * S) * MLP_W : mlp_store_sink + ro.lane * 8;
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(to), "v"(sv) : "memory");
   }
-  if constexpr (S + 1 < STEPS) mlp_stb_step<STEPS, PF, S + 1, GT, H16, ST>(acc, aq, bq, w0, w1, bl, bs, wave_u, cp);
+  if constexpr (S + 1 < STEPS) mlp_stb_step<STEPS, PF, S + 1, GT, H16, ST>(acc, aq, bq, w0, w1, bl, bs, ro);
 }
 template <int STEPS, int GT, bool H16, int PF, bool ST = true>
 __device__ __forceinline__ void mlp_gemm_hidden_stb(f32x16 (&acc)[2][GT], const unsigned short* __restrict__ Wf, size_t tile_stride,
                                                     const unsigned short* Bsrc, int bs, int lane, int wave_u /* uniform */,
                                                     unsigned short* __restrict__ cdst /* row 0 of the workgroup */, int crows) {
-  static_assert(GT == 4 && STEPS >= PF, "four Gaussian tiles, one per wave");
+  static_assert(GT == 4 && STEPS == 16 && STEPS >= PF, "128 rows = 16 steps x 8 rows; the LDS row stride is MLP_HS");
   const int r = lane & 31, kq = (lane >> 5) * 8;
   bf16x8 aq[PF][2], bq[2][GT];
   const unsigned short* w0 = Wf + lane * 8;
@@ -273,9 +280,12 @@ __device__ __forceinline__ void mlp_gemm_hidden_stb(f32x16 (&acc)[2][GT], const 
   }
 #pragma unroll
   for (int gt = 0; gt < GT; gt++) bq[0][gt] = *reinterpret_cast<const bf16x8*>(bl + (size_t)(32 * gt) * bs);
-  const int crow = 32 * wave_u + r;
-  unsigned short* cp = (ST && crow < crows) ? cdst + (size_t)crow * MLP_W + kq : mlp_store_sink + lane * 8;
-  mlp_stb_step<STEPS, PF, 0, GT, H16, ST>(acc, aq, bq, w0, w1, bl, bs, wave_u, cp);
+  const int tid_ = wave_u * 64 + lane;
+  MlpStbRows ro;
+  ro.row = tid_ >> 5; ro.crows = ST ? crows : 0; ro.lane = lane;
+  ro.lrow = Bsrc + (size_t)ro.row * bs + 8 * (tid_ & 31);
+  ro.grow = cdst + (size_t)ro.row * MLP_W + 8 * (tid_ & 31);
+  mlp_stb_step<STEPS, PF, 0, GT, H16, ST>(acc, aq, bq, w0, w1, bl, bs, ro);
 }
 
 // the backward's head product: two K-steps (32 padded outputs), no ring
