@@ -148,8 +148,8 @@ def test_param_grads_kernel_equals_the_products_of_its_operands(N, fmt):
 @pytest.mark.parametrize("fmt", ["fp16", "bf16"])
 @pytest.mark.parametrize("N", [1, 129, 4097, 50_003])
 def test_stored_activations_are_the_layers_outputs(N, fmt):
-    """The activations the training forward leaves in HBM — sent out of the next layer's operand fragments, under its product
-    (mlp_gemm_hidden_stb) — are every layer's relu(W a + b) of the STORED layer below (same 16-bit operands, fp32 accumulation:
+    """The activations the training forward leaves in HBM — sent one 16-byte piece per thread and K-step under the NEXT layer's
+    product, behind counted waits (mlp_gemm_hidden_stb) — are every layer's relu(W a + b) of the STORED layer below (same 16-bit operands, fp32 accumulation:
     what is left is the rounding of the result), finite everywhere, for ragged row counts and for rows past 2^15 (byte offsets
     past 2^24); three launches each: a missed wait state or a wrong vmcnt count shows as sporadic garbage."""
     for name, net, head, xe in _nets(N):
