@@ -32,7 +32,8 @@ def test_trainer_usage_matches_reference_golden():
             assert (x.grad[:, -3:, :] == 0).all()
 
 
-@pytest.mark.parametrize("C,H,W", [(3, 800, 800), (1, 17, 5), (3, 33, 129), (4, 16, 16)])
+# (the kernels tile the image 32 columns x 64 rows: sizes on, one under and one over the tile edges, a single pixel, a 5-pixel-wide strip)
+@pytest.mark.parametrize("C,H,W", [(3, 800, 800), (1, 17, 5), (3, 33, 129), (4, 16, 16), (1, 1, 1), (2, 64, 32), (1, 65, 31), (1, 63, 33), (1, 130, 5)])
 def test_against_oracle_ragged_and_full_size(C, H, W):
     from oracle import loss_ref as O
     from riggs_amd.loss import l1_ssim
