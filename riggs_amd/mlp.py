@@ -515,6 +515,8 @@ class FusedHead:
         self._n_rows = n_rows
         if self.tail_ch and tail is None:
             raise ValueError("this head was built with a constant input tail: pass it (tail=)")
+        if tail is not None and not self.tail_ch:
+            raise ValueError("tail= needs a head built with tail_ch (the input's constant part is then left out of x_emb)")
         self._tail = tail
         if res is not None:
             return _FusedMLP.apply(x_emb.contiguous(), self, l2, res[0], res[1], *self.params())
