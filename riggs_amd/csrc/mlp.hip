@@ -361,6 +361,11 @@ __global__ __launch_bounds__(256, GT == 2 ? 3 : 2) void mlp_forward_kernel(MlpDe
   const unsigned short* xrow = xb + (size_t)row0 * d.in_pad;
   const int n0 = wave * 64;                 // this wave's first neuron
   const int emb_steps = d.in_pad >> 4;
+  // every layer's biases once, into LDS: read as global loads inside the epilogue they waited (vmcnt, in order) for the last
+  // activation stores of the product in front of them — a store's round trip per layer in the open
+  __shared__ float s_bias[10 * MLP_W];
+  for (int e = tid; e < d.depth * MLP_W; e += 256) s_bias[e] = d.bias[e >> 8][e & (MLP_W - 1)];
+  __syncthreads();
   for (int l = 0; l < d.depth; l++) {
     f32x16 acc[2][GT];
 #pragma unroll
@@ -397,7 +402,7 @@ __global__ __launch_bounds__(256, GT == 2 ? 3 : 2) void mlp_forward_kernel(MlpDe
 #pragma unroll
       for (int q = 0; q < 4; q++) {          // register group q: neurons n0 + 32 nt + 8 q + nq .. + 3
         const int nb = n0 + 32 * nt + 8 * q + nq;
-        const float4 b = *reinterpret_cast<const float4*>(d.bias[l] + nb);
+        const float4 b = *reinterpret_cast<const float4*>(s_bias + l * MLP_W + nb);
         const mlp_f2 b01 = {b.x, b.y}, b23 = {b.z, b.w};
         // (a value is kept when its 16-bit form is non-zero: fp16 rounds everything up to 2^-25 to zero)
         const float thr = H16 ? 0x1p-25f : 0.f;
